@@ -1,0 +1,65 @@
+// Runtime entry points of librlx.so: error reporting, device enumeration, HIP events.
+#include "rlx_common.hpp"
+#include <cstring>
+
+namespace rlx {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace rlx
+
+extern "C" {
+
+int rlx_abi_version(void) { return 1; }
+const char *rlx_last_error(void) { return rlx::g_err; }
+const char *rlx_build_arch(void) { return "gfx950"; }
+
+// Replaces the reference's libcuda probing (rl_coach/coach.py:61-84).
+int rlx_device_count(int *count_host) {
+    RLX_REQUIRE(count_host != nullptr, "rlx_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count_host = n;
+    return RLX_OK;
+}
+
+int rlx_stream_sync(void *stream) {
+    RLX_HIP(hipStreamSynchronize(rlx::as_stream(stream)));
+    return RLX_OK;
+}
+
+int rlx_event_create(void **event_host) {
+    RLX_REQUIRE(event_host != nullptr, "rlx_event_create: null output");
+    hipEvent_t ev;
+    RLX_HIP(hipEventCreate(&ev));
+    *event_host = ev;
+    return RLX_OK;
+}
+
+int rlx_event_destroy(void *event) {
+    RLX_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return RLX_OK;
+}
+
+int rlx_event_record(void *event, void *stream) {
+    RLX_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(event), rlx::as_stream(stream)));
+    return RLX_OK;
+}
+
+int rlx_event_elapsed_ms(void *start, void *stop, float *ms_host) {
+    RLX_REQUIRE(ms_host != nullptr, "rlx_event_elapsed_ms: null output");
+    RLX_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+    RLX_HIP(hipEventElapsedTime(ms_host, reinterpret_cast<hipEvent_t>(start),
+                                reinterpret_cast<hipEvent_t>(stop)));
+    return RLX_OK;
+}
+
+}  // extern "C"
