@@ -1,0 +1,297 @@
+// K8 / K12 — returns, generalized advantage estimation, advantage standardisation and per-env
+// episode statistics on gfx950.
+//
+// Replaces, in the reference (paths under rl_coach/):
+//   * ActorCriticAgent.discount + get_general_advantage_estimation_values
+//       agents/actor_critic_agent.py:108-125   (scipy.signal.lfilter per episode, fp64)
+//   * ClippedPPOAgent.fill_advantages episode loop + standardisation
+//       agents/clipped_ppo_agent.py:181-201    (np.append per episode; (adv-mean)/std, no epsilon)
+//   * Episode.update_discounted_rewards       core_types.py:771-801 (O(T^2) pad-and-add)
+//   * Signal accumulation / Agent.handle_episode_ended / update_log episode totals
+//       utils.py:162-212, agents/agent.py:509-601
+//
+// The recurrences  A_t = delta_t + (gamma*lambda) * A_{t+1}   and   R_t = r_t + gamma * R_{t+1}
+// (both reset where game_over is set) are first-order linear, i.e. a scan over affine maps
+// x -> b + a*x, which is associative: one workgroup per trajectory runs a reverse wave64 scan
+// (shuffle-based Hillis-Steele inside a wave, LDS across the 4 waves, running carry across tiles).
+// All arithmetic is fp64 like the reference; inputs/outputs are the fp32 arrays the network uses.
+// HBM-bound: 17 B per step (r, V, done in; advantage, value target out) — SURVEY.md §8(d).
+// Compiled with -ffp-contract=off (see Makefile).
+#include "rlx_common.hpp"
+
+namespace {
+
+constexpr int kScanBlock = 256;
+constexpr int kItems = 4;
+constexpr int kTile = kScanBlock * kItems;
+
+struct Affine {
+    double a, b;   // x -> b + a * x
+};
+
+// later ∘ earlier  (apply `earlier` first)
+__device__ __forceinline__ Affine compose(const Affine later, const Affine earlier) {
+    Affine r;
+    r.a = later.a * earlier.a;
+    r.b = later.b + later.a * earlier.b;
+    return r;
+}
+
+__device__ __forceinline__ Affine wave_inclusive_scan(Affine v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double pa = __shfl_up(v.a, d, 64);
+        double pb = __shfl_up(v.b, d, 64);
+        if (lane >= d) {
+            Affine e{pa, pb};
+            v = compose(v, e);
+        }
+    }
+    return v;
+}
+
+// mode 0: GAE.  in: rewards, values (V(s_t)), dones;   out: adv (fp64), vtarget (fp32)
+// mode 1: discounted returns. in: rewards, dones;      out: ret (fp64 in `adv`), optional fp32 copy
+// Sequence q occupies [q*seq_len, (q+1)*seq_len).  Element j of the reversed order is t = L-1-j.
+__global__ void __launch_bounds__(kScanBlock)
+reverse_scan_kernel(const float *__restrict__ rewards, const float *__restrict__ values,
+                    const unsigned char *__restrict__ dones,
+                    const float *__restrict__ bootstrap, long long seq_len, double gamma,
+                    double coef /* gamma*lambda (mode 0) or gamma (mode 1) */, int mode,
+                    double *__restrict__ out64, float *__restrict__ out32) {
+    __shared__ Affine wave_tot[kScanBlock / 64];
+    __shared__ double carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long long base = (long long)blockIdx.x * seq_len;
+    rewards += base;
+    dones += base;
+    if (values) values += base;
+    out64 += base;
+    if (out32) out32 += base;
+    const double boot = bootstrap ? (double)bootstrap[blockIdx.x] : 0.0;
+    if (tid == 0) carry_s = 0.0;
+    __syncthreads();
+
+    for (long long tile0 = 0; tile0 < seq_len; tile0 += kTile) {
+        Affine el[kItems];
+        Affine local{1.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const long long j = tile0 + (long long)tid * kItems + k;
+            Affine f{1.0, 0.0};                       // identity for the padding past the end
+            if (j < seq_len) {
+                const long long t = seq_len - 1 - j;
+                const bool done = dones[t] != 0;
+                const double r = (double)rewards[t];
+                if (mode == 0) {
+                    const double v = (double)values[t];
+                    // values[-1] of the episode is the bootstrap 0 (clipped_ppo_agent.py:188-189)
+                    const double vnext =
+                        done ? 0.0 : (t + 1 < seq_len ? (double)values[t + 1] : boot);
+                    f.b = r + gamma * vnext - v;      // deltas (actor_critic_agent.py:118)
+                } else {
+                    f.b = r;
+                }
+                f.a = done ? 0.0 : coef;
+            }
+            el[k] = f;
+            local = compose(f, local);
+        }
+        // inclusive scan of the per-thread aggregates across the block
+        Affine incl = wave_inclusive_scan(local, lane);
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        Affine prefix{1.0, 0.0};                       // everything before this thread in the tile
+        for (int w = 0; w < wid; ++w) prefix = compose(wave_tot[w], prefix);
+        {
+            double pa = __shfl_up(incl.a, 1, 64), pb = __shfl_up(incl.b, 1, 64);
+            if (lane > 0) prefix = compose(Affine{pa, pb}, prefix);
+        }
+        const double carry = carry_s;                  // value at the element just before the tile
+        double x = prefix.b + prefix.a * carry;
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const long long j = tile0 + (long long)tid * kItems + k;
+            if (j < seq_len) {
+                x = el[k].b + el[k].a * x;
+                const long long t = seq_len - 1 - j;
+                out64[t] = x;
+                if (out32) out32[t] = (float)(mode == 0 ? x + (double)values[t] : x);
+            }
+        }
+        __syncthreads();                               // everyone has read carry_s / wave_tot
+        if (tid == kScanBlock - 1) carry_s = x;        // last element of the tile
+        __syncthreads();
+    }
+}
+
+// (x - mean) / std  with numpy's definitions: mean = sum/n, std = sqrt(mean(|x-mean|^2)).
+// One workgroup; deterministic tree reductions in fp64.
+__global__ void __launch_bounds__(1024)
+standardize_kernel(const double *__restrict__ x, long long n, float *__restrict__ out32,
+                   double *__restrict__ out64, double *__restrict__ stats) {
+    __shared__ double red[1024];
+    __shared__ double mean_s, std_s;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double s = 0.0;
+    for (long long i = tid; i < n; i += nt) s += x[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int d = nt >> 1; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) mean_s = red[0] / (double)n;
+    __syncthreads();
+    const double mean = mean_s;
+    s = 0.0;
+    for (long long i = tid; i < n; i += nt) {
+        double d = x[i] - mean;
+        s += d * d;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int d = nt >> 1; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        std_s = sqrt(red[0] / (double)n);
+        if (stats) {
+            stats[0] = mean;
+            stats[1] = std_s;
+        }
+    }
+    __syncthreads();
+    const double sd = std_s;
+    for (long long i = tid; i < n; i += nt) {
+        double v = (x[i] - mean) / sd;
+        if (out32) out32[i] = (float)v;
+        if (out64) out64[i] = v;
+    }
+}
+
+// K12: per-env running episode totals, segmented at game_over.
+// acc[0..7] = {episodes, sum_return, sumsq_return, max_return, min_return, sum_len, max_len, min_len}
+__global__ void __launch_bounds__(1024)
+episode_stats_kernel(const float *__restrict__ reward, const unsigned char *__restrict__ done,
+                     double *__restrict__ ep_return, int *__restrict__ ep_len, int n_env,
+                     double *__restrict__ acc, double *__restrict__ last_return,
+                     int *__restrict__ last_len) {
+    __shared__ double s_cnt[1024], s_sum[1024], s_sq[1024], s_max[1024], s_min[1024];
+    __shared__ double s_len[1024], s_lmax[1024], s_lmin[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double cnt = 0, sum = 0, sq = 0, mx = -__builtin_huge_val(), mn = __builtin_huge_val();
+    double ln = 0, lmx = -__builtin_huge_val(), lmn = __builtin_huge_val();
+    for (int e = tid; e < n_env; e += nt) {
+        double ret = ep_return[e] + (double)reward[e];
+        int len = ep_len[e] + 1;
+        if (done[e]) {
+            cnt += 1.0;
+            sum += ret;
+            sq += ret * ret;
+            mx = fmax(mx, ret);
+            mn = fmin(mn, ret);
+            ln += (double)len;
+            lmx = fmax(lmx, (double)len);
+            lmn = fmin(lmn, (double)len);
+            if (last_return) last_return[e] = ret;
+            if (last_len) last_len[e] = len;
+            ret = 0.0;
+            len = 0;
+        }
+        ep_return[e] = ret;
+        ep_len[e] = len;
+    }
+    s_cnt[tid] = cnt; s_sum[tid] = sum; s_sq[tid] = sq; s_max[tid] = mx; s_min[tid] = mn;
+    s_len[tid] = ln; s_lmax[tid] = lmx; s_lmin[tid] = lmn;
+    __syncthreads();
+    for (int d = nt >> 1; d > 0; d >>= 1) {
+        if (tid < d) {
+            s_cnt[tid] += s_cnt[tid + d];
+            s_sum[tid] += s_sum[tid + d];
+            s_sq[tid] += s_sq[tid + d];
+            s_max[tid] = fmax(s_max[tid], s_max[tid + d]);
+            s_min[tid] = fmin(s_min[tid], s_min[tid + d]);
+            s_len[tid] += s_len[tid + d];
+            s_lmax[tid] = fmax(s_lmax[tid], s_lmax[tid + d]);
+            s_lmin[tid] = fmin(s_lmin[tid], s_lmin[tid + d]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && s_cnt[0] > 0) {
+        acc[0] += s_cnt[0];
+        acc[1] += s_sum[0];
+        acc[2] += s_sq[0];
+        acc[3] = fmax(acc[3], s_max[0]);
+        acc[4] = fmin(acc[4], s_min[0]);
+        acc[5] += s_len[0];
+        acc[6] = fmax(acc[6], s_lmax[0]);
+        acc[7] = fmin(acc[7], s_lmin[0]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlx_gae(const float *rewards, const float *values, const unsigned char *game_overs,
+            const float *bootstrap_values, int n_seq, long long seq_len, double discount,
+            double gae_lambda, double *advantages, float *value_targets, void *stream) {
+    RLX_REQUIRE(rewards && values && game_overs && advantages, "rlx_gae: null pointer");
+    RLX_REQUIRE(n_seq > 0 && seq_len > 0, "rlx_gae: empty input (n_seq=%d seq_len=%lld)", n_seq,
+                seq_len);
+    reverse_scan_kernel<<<n_seq, kScanBlock, 0, rlx::as_stream(stream)>>>(
+        rewards, values, game_overs, bootstrap_values, seq_len, discount, discount * gae_lambda, 0,
+        advantages, value_targets);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_discounted_returns(const float *rewards, const unsigned char *game_overs, int n_seq,
+                           long long seq_len, double discount, double *returns64,
+                           float *returns32, void *stream) {
+    RLX_REQUIRE(rewards && game_overs && returns64, "rlx_discounted_returns: null pointer");
+    RLX_REQUIRE(n_seq > 0 && seq_len > 0, "rlx_discounted_returns: empty input");
+    reverse_scan_kernel<<<n_seq, kScanBlock, 0, rlx::as_stream(stream)>>>(
+        rewards, nullptr, game_overs, nullptr, seq_len, discount, discount, 1, returns64,
+        returns32);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_standardize(const double *x, long long n, float *out32, double *out64, double *mean_std,
+                    void *stream) {
+    RLX_REQUIRE(x && (out32 || out64), "rlx_standardize: null pointer");
+    RLX_REQUIRE(n > 0, "rlx_standardize: empty input");
+    standardize_kernel<<<1, 1024, 0, rlx::as_stream(stream)>>>(x, n, out32, out64, mean_std);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_episode_stats_init(double *ep_return, int *ep_len, int n_env, double *acc, void *stream) {
+    RLX_REQUIRE(ep_return && ep_len && acc && n_env > 0, "rlx_episode_stats_init: bad arguments");
+    hipStream_t s = rlx::as_stream(stream);
+    RLX_HIP(hipMemsetAsync(ep_return, 0, sizeof(double) * n_env, s));
+    RLX_HIP(hipMemsetAsync(ep_len, 0, sizeof(int) * n_env, s));
+    const double inf = __builtin_huge_val();
+    const double init[8] = {0, 0, 0, -inf, inf, 0, -inf, inf};
+    RLX_HIP(hipMemcpyAsync(acc, init, sizeof(init), hipMemcpyHostToDevice, s));
+    return RLX_OK;
+}
+
+int rlx_episode_stats_step(const float *reward, const unsigned char *game_over, double *ep_return,
+                           int *ep_len, int n_env, double *acc, double *last_return,
+                           int *last_len, void *stream) {
+    RLX_REQUIRE(reward && game_over && ep_return && ep_len && acc,
+                "rlx_episode_stats_step: null pointer");
+    RLX_REQUIRE(n_env > 0, "rlx_episode_stats_step: n_env must be positive");
+    int threads = n_env >= 1024 ? 1024 : 64;
+    while (threads < n_env && threads < 1024) threads <<= 1;
+    episode_stats_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
+        reward, game_over, ep_return, ep_len, n_env, acc, last_return, last_len);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+}  // extern "C"

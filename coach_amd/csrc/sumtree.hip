@@ -45,6 +45,8 @@ __global__ void per_init_kernel(double *__restrict__ sum, double *__restrict__ m
 // mode 1: n consecutive leaves (ring, wrapping at cap) <- *max_priority  (store, :274-279)
 // mode 2: caller supplies the leaf values directly (leaf_pa -> sum/min, leaf_p -> max);
 //         used where p^alpha must be bit-identical to the host libm.
+// mode 3: as mode 1 but the (single) stored value pair comes from the host: eps = p^alpha,
+//         alpha = p  (bit-exact store when the adapter mirrors maximal_priority on the host).
 __global__ void __launch_bounds__(1024)
 per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__restrict__ mx,
                   int cap, int levels, const int *__restrict__ idx,
@@ -54,17 +56,18 @@ per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__r
                   int *__restrict__ status) {
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    const double stored_priority = (mode == 1) ? *max_priority : 0.0;
+    const double stored_priority = (mode == 1) ? *max_priority : alpha;
+    const bool ring = (mode == 1 || mode == 3);
 
     // ---- leaves
     for (int i = tid; i < n; i += nthr) {
         int leaf;
         double pa, p;
         bool live = true;
-        if (mode == 1) {
+        if (ring) {
             leaf = (start_leaf + i) & (cap - 1);
             p = stored_priority;
-            pa = pow(p, alpha);
+            pa = (mode == 1) ? pow(p, alpha) : eps;
         } else {
             leaf = idx[i];
             if (leaf < 0 || leaf >= cap) {          // reference raises ValueError (:123-126)
@@ -99,7 +102,7 @@ per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__r
     // ---- propagate, one level per barrier (leaf level first)
     for (int lvl = 0; lvl < levels; ++lvl) {
         for (int i = tid; i < n; i += nthr) {
-            int leaf = (mode == 1) ? ((start_leaf + i) & (cap - 1)) : idx[i];
+            int leaf = ring ? ((start_leaf + i) & (cap - 1)) : idx[i];
             if (leaf < 0 || leaf >= cap) continue;
             int node = leaf + cap - 1;
             // ancestor of `node` that sits `lvl+1` levels above the leaf level
@@ -114,7 +117,7 @@ per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__r
         }
         __syncthreads();
     }
-    if (tid == 0 && mode != 1) *max_priority = mx[0];      // (:201)
+    if (tid == 0 && !ring) *max_priority = mx[0];          // (:201)
 }
 
 // One draw per thread.  u[i] is CPython's random.random() drawn on the host, so that
@@ -224,6 +227,17 @@ int rlx_per_store(double *sum_tree, double *min_tree, double *max_tree, int capa
     return launch_update(sum_tree, min_tree, max_tree, capacity, nullptr, nullptr, nullptr, nullptr,
                          n, start_leaf, alpha, 0.0, max_priority, 1, status, stream,
                          "rlx_per_store");
+}
+
+int rlx_per_store_value(double *sum_tree, double *min_tree, double *max_tree, int capacity,
+                        int start_leaf, int n, double leaf_pa, double leaf_p,
+                        double *max_priority, int *status, void *stream) {
+    RLX_REQUIRE(start_leaf >= 0 && start_leaf < capacity,
+                "rlx_per_store_value: start leaf %d out of range", start_leaf);
+    RLX_REQUIRE(n <= capacity, "rlx_per_store_value: %d stores exceed the capacity %d", n, capacity);
+    return launch_update(sum_tree, min_tree, max_tree, capacity, nullptr, nullptr, nullptr, nullptr,
+                         n, start_leaf, /*alpha=p*/ leaf_p, /*eps=p^alpha*/ leaf_pa, max_priority, 3,
+                         status, stream, "rlx_per_store_value");
 }
 
 int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,

@@ -1,0 +1,153 @@
+// K7 / K10 — bootstrapped targets of the value-based and actor-critic agents on gfx950.
+//
+// Replaces the per-sample Python / numpy target arithmetic in (paths under rl_coach/agents/):
+//   * DQNAgent.learn_from_batch             dqn_agent.py:92-103   (python loop over the batch)
+//     DDQNAgent.select_actions              ddqn_agent.py:43      (argmax of the ONLINE net)
+//   * DDPGAgent.learn_from_batch            ddpg_agent.py:156-164 (TD targets, optional clip)
+//   * TD3Agent.learn_from_batch             td3_agent.py:162-180  (target-policy smoothing + min Q)
+//   * SoftActorCriticAgent.learn_from_batch soft_actor_critic_agent.py:244,265-266
+//
+// The reference does this arithmetic in fp64 (python floats / numpy promote the fp32 network
+// outputs) and casts to fp32 when the result is fed back to the network; the kernels do the same.
+// Elementwise, HBM-bound, a few hundred bytes per launch at the BASELINE batch sizes: the point
+// of these kernels is that Q values never leave the device between the two network passes.
+#include "rlx_common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// One thread per sample.  q_sel selects the greedy action (target net for DQN, online net for
+// DDQN); np.argmax returns the FIRST maximum.
+__global__ void dqn_targets_kernel(const float *__restrict__ q_next, const float *__restrict__ q_sel,
+                                   float *__restrict__ td_targets, const int *__restrict__ actions,
+                                   const float *__restrict__ rewards,
+                                   const unsigned char *__restrict__ dones, double discount,
+                                   int batch, int n_actions, double *__restrict__ td_errors,
+                                   int *__restrict__ status) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const float *qs = q_sel + (size_t)i * n_actions;
+    int best = 0;
+    float bv = qs[0];
+    for (int a = 1; a < n_actions; ++a) {
+        float v = qs[a];
+        if (v > bv) {
+            bv = v;
+            best = a;
+        }
+    }
+    const int act = actions[i];
+    if (act < 0 || act >= n_actions) {
+        atomicOr(status, 1);
+        return;
+    }
+    // new_target = r + (1.0 - game_over) * discount * q_st_plus_1[i][a*]   (dqn_agent.py:100-101)
+    const double qn = (double)q_next[(size_t)i * n_actions + best];
+    const double new_target =
+        (double)rewards[i] + (1.0 - (dones[i] ? 1.0 : 0.0)) * discount * qn;
+    const size_t o = (size_t)i * n_actions + act;
+    if (td_errors) td_errors[i] = fabs(new_target - (double)td_targets[o]);   // (:102)
+    td_targets[o] = (float)new_target;                                          // (:103)
+}
+
+// TD = r + (1 - done) * discount * q      (or r + discount * q), optionally clipped.
+__global__ void ac_targets_kernel(const float *__restrict__ rewards,
+                                  const unsigned char *__restrict__ dones,
+                                  const float *__restrict__ q_next, int q_stride, double discount,
+                                  int nonzero_terminal_discount, int has_clip, double clip_lo,
+                                  double clip_hi, int batch, float *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const double q = (double)q_next[(size_t)i * q_stride];
+    double t;
+    if (nonzero_terminal_discount)
+        t = (double)rewards[i] + discount * q;
+    else
+        t = (double)rewards[i] + (1.0 - (dones[i] ? 1.0 : 0.0)) * discount * q;
+    if (has_clip) t = fmin(fmax(t, clip_lo), clip_hi);        // np.clip
+    out[i] = (float)t;
+}
+
+// next_actions = clip_action_to_space(mu_target(s') + clip(N(0, sigma), -c, c))   td3_agent.py:162-165
+// `noise` holds the host-drawn np.random.normal(0, sigma, shape) values (fp64) BEFORE clipping so
+// that the host RNG stream is consumed exactly like the reference's.
+__global__ void td3_smooth_kernel(const float *__restrict__ next_actions,
+                                  const double *__restrict__ noise, double noise_clip,
+                                  const float *__restrict__ low, const float *__restrict__ high,
+                                  int batch, int act_dim, float *__restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * act_dim) return;
+    const int a = t % act_dim;
+    double nz = fmin(fmax(noise[t], -noise_clip), noise_clip);
+    double v = (double)next_actions[t] + nz;
+    v = fmin(fmax(v, (double)low[a]), (double)high[a]);       // spaces.py:379 np.clip
+    out[t] = (float)v;
+}
+
+// value_targets = min(Q1,Q2)(s, a~pi) - log pi(a|s)     soft_actor_critic_agent.py:244
+__global__ void sac_value_targets_kernel(const float *__restrict__ q_min,
+                                         const float *__restrict__ logprob, int batch,
+                                         float *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    out[i] = q_min[i] - logprob[i];          // both fp32 numpy arrays in the reference
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlx_dqn_targets(const float *q_next_target, const float *q_next_selector, float *td_targets,
+                    const int *actions, const float *rewards, const unsigned char *game_overs,
+                    double discount, int batch, int n_actions, double *td_errors, int *status,
+                    void *stream) {
+    RLX_REQUIRE(q_next_target && td_targets && actions && rewards && game_overs && status,
+                "rlx_dqn_targets: null pointer");
+    RLX_REQUIRE(batch > 0 && n_actions > 0, "rlx_dqn_targets: bad sizes (batch=%d actions=%d)",
+                batch, n_actions);
+    if (!q_next_selector) q_next_selector = q_next_target;
+    dqn_targets_kernel<<<(batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
+        q_next_target, q_next_selector, td_targets, actions, rewards, game_overs, discount, batch,
+        n_actions, td_errors, status);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_ac_td_targets(const float *rewards, const unsigned char *game_overs, const float *q_next,
+                      int q_stride, double discount, int use_non_zero_discount_for_terminal_states,
+                      int has_clip, double clip_low, double clip_high, int batch,
+                      float *td_targets, void *stream) {
+    RLX_REQUIRE(rewards && game_overs && q_next && td_targets, "rlx_ac_td_targets: null pointer");
+    RLX_REQUIRE(batch > 0 && q_stride > 0, "rlx_ac_td_targets: bad sizes");
+    ac_targets_kernel<<<(batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
+        rewards, game_overs, q_next, q_stride, discount, use_non_zero_discount_for_terminal_states,
+        has_clip, clip_low, clip_high, batch, td_targets);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_td3_smooth_actions(const float *next_actions, const double *noise, double noise_clipping,
+                           const float *action_low, const float *action_high, int batch,
+                           int action_dim, float *out, void *stream) {
+    RLX_REQUIRE(next_actions && noise && action_low && action_high && out,
+                "rlx_td3_smooth_actions: null pointer");
+    RLX_REQUIRE(batch > 0 && action_dim > 0, "rlx_td3_smooth_actions: bad sizes");
+    int n = batch * action_dim;
+    td3_smooth_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
+        next_actions, noise, noise_clipping, action_low, action_high, batch, action_dim, out);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_sac_value_targets(const float *q_min, const float *sampled_logprob, int batch,
+                          float *value_targets, void *stream) {
+    RLX_REQUIRE(q_min && sampled_logprob && value_targets, "rlx_sac_value_targets: null pointer");
+    RLX_REQUIRE(batch > 0, "rlx_sac_value_targets: bad batch");
+    sac_value_targets_kernel<<<(batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
+        q_min, sampled_logprob, batch, value_targets);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+}  // extern "C"

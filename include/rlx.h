@@ -57,6 +57,10 @@ int rlx_per_init(double *sum_tree, double *min_tree, double *max_tree, int capac
 int rlx_per_store(double *sum_tree, double *min_tree, double *max_tree, int capacity,
                   int start_leaf, int n, double alpha, double *max_priority, int *status,
                   void *stream);                                     /* .store :264-283 (n consecutive adds) */
+int rlx_per_store_value(double *sum_tree, double *min_tree, double *max_tree, int capacity,
+                        int start_leaf, int n, double leaf_pa, double leaf_p,
+                        double *max_priority, int *status,
+                        void *stream);                               /* same, host-computed (p**alpha, p) */
 int rlx_per_update(double *sum_tree, double *min_tree, double *max_tree, int capacity,
                    const int *idx, const double *errors, int n, double alpha, double epsilon,
                    double *max_priority, int *status, void *stream); /* .update_priorities :203-217 */
@@ -67,6 +71,97 @@ int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,
                    const double *uniforms, int batch, double num_transitions, double beta,
                    int *out_idx, double *out_weight, double *out_priority,
                    void *stream);                                    /* .sample :229-255; uniforms[i] = random.random() */
+
+/* ------------------------------------------------- replay storage (K1 / K4) -- */
+/* A column of a struct-of-arrays transition store: `row_bytes` bytes per transition. */
+#define RLX_MAX_COLUMNS 8
+typedef struct rlx_column {
+    const void *src;      /* device base of the source array      */
+    void *dst;            /* device base of the destination array */
+    long long row_bytes;  /* bytes per row (same on both sides)   */
+} rlx_column;
+
+/* Row r (0 <= r < n) of every column is copied from source row
+ *   src_idx ? src_idx[r] : (src_start + r) mod src_rows      to destination row
+ *   dst_idx ? dst_idx[r] : (dst_start + r) mod dst_rows.
+ * gather  = ExperienceReplay.sample's `[self.transitions[i] for i in idx]` + Batch collation
+ *           (memories/non_episodic/experience_replay.py:80-90, core_types.py:488-649);
+ * append  = ExperienceReplay.store + _enforce_max_length as a ring (:117-150).
+ * status bit 1 is set for an out-of-range row (the reference's IndexError). */
+int rlx_copy_columns(const rlx_column *columns_host, int ncols, const int *src_idx,
+                     const int *dst_idx, long long src_start, long long dst_start,
+                     long long src_rows, long long dst_rows, int n, int *status, void *stream);
+
+/* Frame-dedup image replay (ObservationStackingFilter + LazyStack,
+ * filters/observation/observation_stacking_filter.py:27-41,89-101).
+ * ring: u8 [n_env][ring_frames][frame_bytes]; env_fpos/env_epoff: int32[n_env] describe every
+ * env's current stacked state; t_fpos (int32) / t_epoff (u8): per stored transition. */
+int rlx_imgreplay_reset(unsigned char *ring, int *env_fpos, int *env_epoff,
+                        const unsigned char *first_frame, int n_env, int ring_frames,
+                        int frame_bytes, void *stream);              /* first observation: stack = [f0]*stack (:90-91) */
+int rlx_imgreplay_append(unsigned char *ring, int *env_fpos, int *env_epoff, int *t_fpos,
+                         unsigned char *t_epoff, const unsigned char *next_frame,
+                         const unsigned char *reset_frame, const unsigned char *done, int n_env,
+                         int ring_frames, int frame_bytes, int stack, long long cursor,
+                         long long capacity, int record, void *stream); /* deque.append (:93-94) for n_env envs */
+int rlx_imgreplay_gather(const unsigned char *ring, const int *t_fpos,
+                         const unsigned char *t_epoff, const int *env_fpos, const int *env_epoff,
+                         const int *idx, int batch, int n_env, int ring_frames, int frame_bytes,
+                         int stack, long long capacity, unsigned char *out_state,
+                         unsigned char *out_next, int *status,
+                         void *stream);                              /* LazyStack.__array__ (:37-41) for a batch */
+
+/* ------------------------------------- returns / GAE / episode stats (K8 / K12) -- */
+/* n_seq independent trajectories of seq_len steps, contiguous; game_overs cut episodes inside a
+ * trajectory.  fp64 arithmetic like the reference; `values` are V(s_t) as predicted (fp32). */
+int rlx_gae(const float *rewards, const float *values, const unsigned char *game_overs,
+            const float *bootstrap_values, int n_seq, long long seq_len, double discount,
+            double gae_lambda, double *advantages, float *value_targets,
+            void *stream);   /* agents/actor_critic_agent.py:108-125 + clipped_ppo_agent.py:181-196 */
+int rlx_discounted_returns(const float *rewards, const unsigned char *game_overs, int n_seq,
+                           long long seq_len, double discount, double *returns64,
+                           float *returns32, void *stream);          /* core_types.py:771-801 (n_step = -1) */
+int rlx_standardize(const double *x, long long n, float *out32, double *out64, double *mean_std,
+                    void *stream);                                   /* clipped_ppo_agent.py:201 (no epsilon) */
+int rlx_episode_stats_init(double *ep_return, int *ep_len, int n_env, double *acc, void *stream);
+int rlx_episode_stats_step(const float *reward, const unsigned char *game_over, double *ep_return,
+                           int *ep_len, int n_env, double *acc, double *last_return,
+                           int *last_len, void *stream);             /* agents/agent.py:558-601,509-556 totals */
+
+/* --------------------------------------------------- agent targets (K7 / K10) -- */
+/* td_targets holds Q_online(s,.) on entry (fp32 [batch, n_actions]); column actions[i] of row i is
+ * replaced by r + (1-done)*discount*Q_target(s', argmax_a q_next_selector(s',a)); td_errors (fp64,
+ * optional) receives |new_target - Q_online(s,a)|.  q_next_selector = NULL -> DQN (target net
+ * selects, agents/dqn_agent.py:78-79), = Q_online(s',.) -> DDQN (agents/ddqn_agent.py:43). */
+int rlx_dqn_targets(const float *q_next_target, const float *q_next_selector, float *td_targets,
+                    const int *actions, const float *rewards, const unsigned char *game_overs,
+                    double discount, int batch, int n_actions, double *td_errors, int *status,
+                    void *stream);                                   /* agents/dqn_agent.py:92-103 */
+int rlx_ac_td_targets(const float *rewards, const unsigned char *game_overs, const float *q_next,
+                      int q_stride, double discount, int use_non_zero_discount_for_terminal_states,
+                      int has_clip, double clip_low, double clip_high, int batch,
+                      float *td_targets, void *stream);              /* agents/ddpg_agent.py:156-164, td3_agent.py:171-180, soft_actor_critic_agent.py:265-266 */
+int rlx_td3_smooth_actions(const float *next_actions, const double *noise, double noise_clipping,
+                           const float *action_low, const float *action_high, int batch,
+                           int action_dim, float *out, void *stream); /* agents/td3_agent.py:162-165 */
+int rlx_sac_value_targets(const float *q_min, const float *sampled_logprob, int batch,
+                          float *value_targets, void *stream);       /* agents/soft_actor_critic_agent.py:244 */
+
+/* --------------------------------------- observation / reward filters (K2 / K3) -- */
+int rlx_rgb_to_y_u8(const unsigned char *rgb, unsigned char *out, long long n_pixels,
+                    double input_low, double input_high,
+                    void *stream);   /* filters/observation/observation_rgb_to_y_filter.py:41-47 + observation_to_uint8_filter.py:51-60 */
+int rlx_running_stats_push(const void *samples, int samples_are_f64, long long n, int dim,
+                           double *sum, double *sum_squares, double *count, double *mean,
+                           double *std, double epsilon,
+                           void *stream);                            /* utilities/shared_running_stats.py:130-140 */
+int rlx_running_stats_normalize(const void *x, int x_is_f64, long long n, int dim,
+                                const double *mean, const double *std, double clip_low,
+                                double clip_high, float *out32, double *out64,
+                                void *stream);                       /* utilities/shared_running_stats.py:162-164 */
+int rlx_reward_filter(const float *rewards, float *out, long long n, double rescale_factor,
+                      int has_clip, double clipping_low, double clipping_high,
+                      void *stream);   /* filters/reward/reward_rescale_filter.py:37-39, reward_clipping_filter.py:41-49 */
 
 #ifdef __cplusplus
 }

@@ -115,7 +115,296 @@ def gen_per():
     _save("per", **out)
 
 
-GROUPS = {"per": gen_per}
+# ------------------------------------------------------------------------------ uniform replay
+def gen_er():
+    """ExperienceReplay store/sample index traces (memories/non_episodic/experience_replay.py:71-150)."""
+    from rl_coach.memories.non_episodic.experience_replay import ExperienceReplay
+    out = {}
+    # SURVEY Appendix B: 50 stored (reward = i), np.random.seed(7), sample(8)
+    m = ExperienceReplay((MemoryGranularity.Transitions, 1000))
+    for i in range(50):
+        m.store(_transition(i))
+    np.random.seed(7)
+    out["appB_rewards"] = np.array([t.reward for t in m.sample(8)])
+    # FIFO eviction: capacity 32, 100 stores interleaved with samples
+    np.random.seed(11)
+    m = ExperienceReplay((MemoryGranularity.Transitions, 32))
+    sampled, counts = [], []
+    for i in range(100):
+        m.store(_transition(i))
+        if i % 7 == 6:
+            counts.append(m.num_transitions())
+            sampled.append([t.reward for t in m.sample(16)])
+    out["fifo_meta"] = np.array([32, 100, 16, 7, 11])
+    out["fifo_counts"] = np.array(counts)
+    out["fifo_rewards"] = np.array(sampled)
+    _save("er", **out)
+
+
+# ------------------------------------------------------------------------------------ stacking
+def gen_stack():
+    """ObservationStackingFilter traces (filters/observation/observation_stacking_filter.py:89-101)."""
+    from rl_coach.filters.observation.observation_stacking_filter import ObservationStackingFilter
+    rng = np.random.RandomState(5)
+    out = {}
+    for name, hw, stack, ep_lens in (("s4", (6, 8), 4, [5, 1, 2, 7]), ("s3", (4, 4), 3, [4, 3])):
+        f = ObservationStackingFilter(stack)
+        frames, stacks, first = [], [], []
+        for L in ep_lens:
+            f.reset() if hasattr(f, "reset") else None
+            f.stack = []                                     # Filter.reset / InputFilter.reset (:380-390)
+            for t in range(L + 1):                           # L transitions -> L+1 observations
+                fr = rng.randint(0, 256, size=hw).astype(np.uint8)
+                frames.append(fr)
+                first.append(t == 0)
+                stacks.append(np.array(f.filter(fr)))
+        out[name + "_frames"] = np.array(frames)
+        out[name + "_first"] = np.array(first)
+        out[name + "_stacks"] = np.array(stacks)
+        out[name + "_eplens"] = np.array(ep_lens)
+    _save("stack", **out)
+
+
+# ------------------------------------------------------------------------------------- filters
+def gen_filters():
+    from rl_coach.filters.observation.observation_rgb_to_y_filter import ObservationRGBToYFilter
+    from rl_coach.filters.observation.observation_to_uint8_filter import ObservationToUInt8Filter
+    from rl_coach.filters.reward.reward_clipping_filter import RewardClippingFilter
+    from rl_coach.filters.reward.reward_rescale_filter import RewardRescaleFilter
+    from rl_coach.utilities.shared_running_stats import NumpySharedRunningStats
+    rng = np.random.RandomState(21)
+    out = {}
+    rgb = rng.randint(0, 256, size=(3, 84, 84, 3)).astype(np.uint8)
+    rgb[0, :4, :4] = 255                                      # saturate: exercises 254.97 -> 254
+    rgb[0, 4:8, :4] = 0
+    y = np.array([ObservationRGBToYFilter().filter(im) for im in rgb])
+    u8 = np.array([ObservationToUInt8Filter(0, 255).filter(v.copy()) for v in y])
+    out["rgb"], out["y"], out["y_u8"] = rgb, y, u8
+    rewards = np.array([-7.5, -1.0, -0.2, 0.0, 0.3, 1.0, 4.0])
+    for name, lo, hi in (("clip11", -1, 1), ("clip0hi", -2, 0), ("clip0lo", 0, 2)):
+        flt = RewardClippingFilter(lo, hi)
+        out[name] = np.array([flt.filter(r) for r in rewards])
+        out[name + "_bounds"] = np.array([lo, hi], dtype=np.float64)
+    out["rewards"] = rewards
+    out["rescale5"] = np.array([RewardRescaleFilter(5).filter(r) for r in rewards])
+    # running stats: Appendix B vector and a 3-push random trace (fp32 observations as the env emits)
+    st = NumpySharedRunningStats(name="golden")
+    st.set_params(shape=(2,), clip_values=(-5, 5))
+    st.push_val(np.array([[1, 2], [3, 6], [5, 10]]))
+    out["rsB_mean"], out["rsB_std"] = st.mean.copy(), st.std.copy()
+    out["rsB_norm"] = st.normalize(np.array([[1.0, 2.0]]))
+    st = NumpySharedRunningStats(name="golden2")
+    st.set_params(shape=(17,), clip_values=(-5, 5))
+    pushes = [rng.randn(n, 17).astype(np.float32) * (1 + 3 * k) + k for k, n in enumerate((64, 1, 2048))]
+    means, stds, sums, sqs, cnts = [], [], [], [], []
+    for p_ in pushes:
+        st.push_val(p_)
+        means.append(st.mean.copy()); stds.append(st.std.copy())
+        sums.append(st._sum.copy()); sqs.append(st._sum_squares.copy()); cnts.append(st._count)
+    for k, p_ in enumerate(pushes):
+        out["rs_push%d" % k] = p_
+    out["rs_mean"], out["rs_std"] = np.array(means), np.array(stds)
+    out["rs_sum"], out["rs_sq"], out["rs_count"] = np.array(sums), np.array(sqs), np.array(cnts)
+    probe = rng.randn(33, 17).astype(np.float32) * 30
+    out["rs_probe"] = probe
+    out["rs_norm"] = st.normalize(probe)
+    _save("filters", **out)
+
+
+# ----------------------------------------------------------------------------- GAE and returns
+class _Obj(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def gen_gae():
+    """ClippedPPOAgent.fill_advantages (agents/clipped_ppo_agent.py:157-207) driven with a stand-in
+    value network, ActorCriticAgent.get_general_advantage_estimation_values
+    (agents/actor_critic_agent.py:111-125) and Episode.update_discounted_rewards
+    (core_types.py:771-801)."""
+    from rl_coach.agents.clipped_ppo_agent import ClippedPPOAgent
+    from rl_coach.agents.policy_optimization_agent import PolicyGradientRescaler
+    from rl_coach.core_types import Batch, Episode
+    out = {}
+
+    class Fake(ClippedPPOAgent):
+        def __init__(self, values, discount, lam, batch_size):
+            self._values = values
+            wrapper = _Obj(input_embedders_parameters={'observation': None}, batch_size=batch_size)
+            self.ap = _Obj(network_wrappers={'main': wrapper},
+                           algorithm=_Obj(discount=discount, gae_lambda=lam,
+                                          estimate_state_value_using_gae=True))
+            fake = self
+
+            class Net(object):
+                def predict(self_inner, inputs):
+                    idx = inputs['observation'][:, 0].astype(np.int64)
+                    return [fake._values[idx]]
+            self.networks = {'main': _Obj(online_network=Net())}
+            self.state_values = _Obj(add_sample=lambda v: None)
+            self.action_advantages = _Obj(add_sample=lambda v: None)
+            self.policy_gradient_rescaler = PolicyGradientRescaler.GAE
+
+    # Appendix B
+    f = Fake(None, 0.99, 0.95, 64)
+    gae, vt = f.get_general_advantage_estimation_values(np.array([1., 0., 2., -1.]),
+                                                        np.array([.5, .6, .7, .2, 0.]))
+    out["appB_gae"], out["appB_vt"] = gae, vt[:, 0]
+    rng = np.random.RandomState(99)
+    cases = (("small", [5, 1, 3], 0.99, 0.95, 4), ("ppo2048", [32] * 64, 0.99, 0.95, 64),
+             ("ragged", [1000, 1, 257, 64, 726], 0.995, 0.9, 64))
+    for name, ep_lens, disc, lam, bs in cases:
+        T = sum(ep_lens)
+        rewards = rng.randn(T).astype(np.float32)
+        if name == "ppo2048":
+            rewards = rng.choice([-1.0, 0.0, 1.0], size=T, p=[.05, .9, .05]).astype(np.float32)
+        values = rng.randn(T).astype(np.float32)
+        go = np.zeros(T, dtype=bool)
+        go[np.cumsum(ep_lens) - 1] = True
+        trans = [Transition(state={'observation': np.array([i], dtype=np.float64)}, action=0,
+                            reward=float(rewards[i]), next_state={'observation': np.array([i + 1.])},
+                            game_over=bool(go[i])) for i in range(T)]
+        for t in trans:
+            t.n_step_discounted_rewards = 0.0
+        f = Fake(values, disc, lam, bs)
+        f.fill_advantages(Batch(trans))
+        out[name + "_rewards"], out[name + "_values"], out[name + "_go"] = rewards, values, go
+        out[name + "_hp"] = np.array([disc, lam])
+        out[name + "_adv"] = np.array([t.info['advantage'] for t in trans])
+        out[name + "_vt"] = np.array([t.info['gae_based_value_target'] for t in trans])
+        # discounted returns per episode from the reference Episode class
+        rets, start = [], 0
+        for L in ep_lens:
+            ep = Episode(discount=disc)
+            for i in range(start, start + L):
+                ep.insert(trans[i])
+            ep.update_discounted_rewards()
+            rets += [t.n_step_discounted_rewards for t in ep.transitions]
+            start += L
+        out[name + "_returns"] = np.array(rets)
+    ep = Episode(discount=0.99)
+    for r in [1., 0., 2., -1.]:
+        ep.insert(Transition(state={'observation': np.zeros(1)}, action=0, reward=r,
+                             next_state={'observation': np.zeros(1)}, game_over=False))
+    ep.update_discounted_rewards()
+    out["appB_returns"] = np.array([t.n_step_discounted_rewards for t in ep.transitions])
+    _save("gae", **out)
+
+
+# ------------------------------------------------------------------------------------- targets
+def gen_targets():
+    """learn_from_batch target arithmetic of DQN / DDQN / DDPG / TD3 with stand-in networks."""
+    from unittest import mock
+    from rl_coach.agents.dqn_agent import DQNAgent
+    from rl_coach.agents.ddqn_agent import DDQNAgent
+    from rl_coach.agents.ddpg_agent import DDPGAgent
+    from rl_coach.agents.td3_agent import TD3Agent
+    from rl_coach.core_types import Batch
+    from rl_coach.spaces import BoxActionSpace
+    rng = np.random.RandomState(31)
+    out = {}
+
+    def make_batch(B, obs_dim, actions, rewards, go):
+        tr = [Transition(state={'observation': rng.randn(obs_dim)}, action=actions[i],
+                         reward=float(rewards[i]), next_state={'observation': rng.randn(obs_dim)},
+                         game_over=bool(go[i])) for i in range(B)]
+        return Batch(tr)
+
+    for cls, name in ((DQNAgent, "dqn"), (DDQNAgent, "ddqn")):
+        B, A = 32, 4
+        q_next_t = rng.randn(B, A).astype(np.float32)
+        q_next_o = rng.randn(B, A).astype(np.float32)
+        q_onl = rng.randn(B, A).astype(np.float32)
+        q_next_t[3] = q_next_t[3, 0]                          # ties -> first argmax
+        actions = rng.randint(0, A, size=B)
+        rewards = rng.choice([-1.0, 0.0, 1.0], size=B).astype(np.float32)
+        go = rng.rand(B) < 0.2
+        captured = {}
+
+        class Fake(cls):
+            def __init__(self):
+                pass
+        f = Fake()
+        wrapper = _Obj(input_embedders_parameters={'observation': None})
+        f.ap = _Obj(network_wrappers={'main': wrapper}, algorithm=_Obj(discount=0.99))
+        f.q_values = _Obj(add_sample=lambda v: None)
+        f.memory = object()
+        online = _Obj(predict=lambda inputs: q_next_o.copy())     # DDQN: online net on next states
+        main = _Obj(target_network=object(), online_network=online,
+                    parallel_prediction=lambda pairs: (q_next_t.copy(), q_onl.copy()))
+
+        def train(states, targets, importance_weights=None):
+            captured['targets'] = np.array(targets)
+            return 0.0, [0.0], 0.0
+        main.train_and_sync_networks = train
+        f.networks = {'main': main}
+        orig = f.update_transition_priorities_and_get_weights
+
+        def upd(errs, batch):
+            captured['errors'] = np.array(errs, dtype=np.float64)
+            return None
+        f.update_transition_priorities_and_get_weights = upd
+        f.learn_from_batch(make_batch(B, 4, actions, rewards, go))
+        out[name + "_q_next_t"], out[name + "_q_next_o"], out[name + "_q_onl"] = q_next_t, q_next_o, q_onl
+        out[name + "_actions"], out[name + "_rewards"], out[name + "_go"] = actions, rewards, go
+        out[name + "_targets"], out[name + "_errors"] = captured['targets'], captured['errors']
+
+    # DDPG / TD3 TD targets
+    for cls, name in ((DDPGAgent, "ddpg"), (TD3Agent, "td3")):
+        B, A = 100, 6
+        next_actions = np.tanh(rng.randn(B, A)).astype(np.float32)
+        q_next = rng.randn(B, 1).astype(np.float32) * 5
+        rewards = rng.randn(B).astype(np.float32)
+        go = rng.rand(B) < 0.1
+        captured = {}
+
+        class Fake(cls):
+            def __init__(self):
+                pass
+        f = Fake()
+        f.ap = _Obj(network_wrappers={'actor': _Obj(input_embedders_parameters={'observation': None}),
+                                      'critic': _Obj(input_embedders_parameters={'observation': None,
+                                                                                 'action': None})},
+                    algorithm=_Obj(discount=0.99, use_non_zero_discount_for_terminal_states=False,
+                                   clip_critic_targets=(-3.0, 3.0) if name == "ddpg" else None,
+                                   policy_noise=0.2, noise_clipping=0.5,
+                                   update_policy_every_x_episode_steps=2))
+        f.TD_targets_signal = _Obj(add_sample=lambda v: None)
+        f.training_iteration = 1                              # odd -> TD3 skips the actor update
+        f.spaces = _Obj(action=BoxActionSpace(A, -0.8, 0.8))
+        actor = mock.MagicMock()
+        actor.parallel_prediction = lambda pairs: (next_actions.copy(), next_actions.copy())
+        actor.has_global = False
+        critic = mock.MagicMock()
+
+        def critic_target_predict(inputs):
+            captured['critic_next_action'] = np.array(inputs['action'])
+            return [q_next, q_next, q_next, q_next]
+        critic.target_network.predict = critic_target_predict
+        critic.online_network.predict = lambda *a, **k: np.zeros((B, A), dtype=np.float32)
+
+        def train(inputs, targets, **kw):
+            captured['targets'] = np.array(targets)
+            return 0.0, [0.0], 0.0
+        critic.train_and_sync_networks = train
+        actor.online_network.predict = lambda *a, **k: []
+        f.networks = {'actor': actor, 'critic': critic}
+        np.random.seed(77)
+        noise = np.random.normal(0, 0.2, next_actions.shape)
+        np.random.seed(77)
+        actions = rng.uniform(-0.8, 0.8, size=(B, A))
+        f.learn_from_batch(make_batch(B, 17, list(actions), rewards, go))
+        out[name + "_next_actions"], out[name + "_q_next"] = next_actions, q_next
+        out[name + "_rewards"], out[name + "_go"] = rewards, go
+        out[name + "_targets"] = captured['targets']
+        if name == "td3":
+            out["td3_noise"] = noise
+            out["td3_smoothed"] = captured['critic_next_action']
+    _save("targets", **out)
+
+
+GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
+          "targets": gen_targets}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,132 @@
+"""K2/K3 filters: RGB->Y->uint8, running-stats normalisation, reward rescale / clipping.
+
+Mirrors rl_coach/tests/filters/observation/test_observation_{rgb_to_y,to_uint8}_filter.py and
+rl_coach/tests/filters/reward/test_reward_{clipping,rescale}_filter.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import filters as F
+from tests.util import dev_tensor
+
+
+def test_oracle_rgb_to_y_uint8_matches_reference(golden):
+    g = golden("filters")
+    y = F.rgb_to_y(g["rgb"])
+    assert np.array_equal(y, g["y"])
+    assert np.array_equal(F.to_uint8(y, 0, 255), g["y_u8"])
+    # reference unit test: 10x10x3 ones*255*... -> mean preserved (test_observation_rgb_to_y_filter.py)
+    ones = np.ones((10, 20, 3)) * 100.0
+    np.testing.assert_allclose(F.rgb_to_y(ones), 99.99, rtol=1e-12)
+    # to_uint8 truncation test (test_observation_to_uint8_filter.py:14-32)
+    obs = np.random.RandomState(0).rand(5, 5) * 100 - 50
+    assert np.array_equal(F.to_uint8(obs, -100, 100), ((obs + 100) / 200 * 255).astype('uint8'))
+
+
+def test_oracle_reward_filters_match_reference(golden):
+    g = golden("filters")
+    for name in ("clip11", "clip0hi", "clip0lo"):
+        lo, hi = g[name + "_bounds"]
+        lo = int(lo) if lo == int(lo) else lo
+        assert [F.reward_clip(r, lo, hi) for r in g["rewards"]] == g[name].tolist()
+    assert [F.reward_rescale(r, 5) for r in g["rewards"]] == g["rescale5"].tolist()
+    # reference unit test values (test_reward_clipping_filter.py:22-42)
+    assert F.reward_clip(100, 2, 10) == 10 and F.reward_clip(-10, 2, 10) == 2 and F.reward_clip(5, 2, 10) == 5
+
+
+def test_oracle_running_stats_match_reference(golden):
+    g = golden("filters")
+    st = F.RunningStatsOracle((2,))
+    st.push(np.array([[1, 2], [3, 6], [5, 10]]))
+    assert np.array_equal(st._mean, g["rsB_mean"]) and np.array_equal(st._std, g["rsB_std"])
+    assert np.array_equal(st.normalize(np.array([[1.0, 2.0]])), g["rsB_norm"])
+    np.testing.assert_allclose(st._mean, [2.9900332226, 5.9800664452], rtol=1e-9)
+    st = F.RunningStatsOracle((17,))
+    for k in range(3):
+        st.push(g["rs_push%d" % k])
+        assert np.array_equal(st._mean, g["rs_mean"][k]) and np.array_equal(st._std, g["rs_std"][k])
+    assert np.array_equal(st.normalize(g["rs_probe"]), g["rs_norm"])
+
+
+# ------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_rgb_to_y_uint8_bit_exact(golden, rlx, dev):
+    import torch
+    g = golden("filters")
+    rgb = g["rgb"]
+    out = torch.empty(rgb.shape[:-1], dtype=torch.uint8, device=dev)
+    rlx.rgb_to_y_u8(dev_tensor(rgb, dev), out, rgb.size // 3, 0.0, 255.0, 0)
+    assert np.array_equal(out.cpu().numpy(), g["y_u8"])
+    # every (r,g,b) byte pattern on a grid + odd pixel count (tail path), against the oracle
+    rng = np.random.RandomState(2)
+    big = rng.randint(0, 256, size=(210 * 160 * 7 + 3, 3)).astype(np.uint8)
+    out = torch.empty(len(big), dtype=torch.uint8, device=dev)
+    rlx.rgb_to_y_u8(dev_tensor(big, dev), out, len(big), 0.0, 255.0, 0)
+    assert np.array_equal(out.cpu().numpy(), F.to_uint8(F.rgb_to_y(big), 0, 255))
+
+
+@pytest.mark.gpu
+def test_hip_running_stats_bit_exact(golden, rlx, dev):
+    import torch
+    g = golden("filters")
+    D = 17
+    s = torch.zeros(D, dtype=torch.float64, device=dev)
+    q = torch.full((D,), 1e-2, dtype=torch.float64, device=dev)
+    cnt = torch.full((1,), 1e-2, dtype=torch.float64, device=dev)
+    mean = torch.zeros(D, dtype=torch.float64, device=dev)
+    std = torch.zeros(D, dtype=torch.float64, device=dev)
+    for k in range(3):
+        x = g["rs_push%d" % k]
+        rlx.running_stats_push(dev_tensor(x, dev), 0, len(x), D, s, q, cnt, mean, std, 1e-2, 0)
+        assert np.array_equal(s.cpu().numpy(), g["rs_sum"][k])
+        assert np.array_equal(q.cpu().numpy(), g["rs_sq"][k])
+        assert cnt.item() == g["rs_count"][k]
+        assert np.array_equal(mean.cpu().numpy(), g["rs_mean"][k])
+        assert np.array_equal(std.cpu().numpy(), g["rs_std"][k])
+    probe = g["rs_probe"]
+    o64 = torch.empty(probe.shape, dtype=torch.float64, device=dev)
+    o32 = torch.empty(probe.shape, dtype=torch.float32, device=dev)
+    rlx.running_stats_normalize(dev_tensor(probe, dev), 0, len(probe), D, mean, std, -5.0, 5.0, o32, o64, 0)
+    assert np.array_equal(o64.cpu().numpy(), g["rs_norm"])
+    assert np.array_equal(o32.cpu().numpy(), g["rs_norm"].astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,D,f64", [(2048, 376, False), (64, 4, True), (1, 1, False), (100000, 17, False)])
+def test_hip_running_stats_vs_oracle(rlx, dev, n, D, f64):
+    import torch
+    rng = np.random.RandomState(n + D)
+    x = (rng.randn(n, D) * 3 + 1).astype(np.float64 if f64 else np.float32)
+    o = F.RunningStatsOracle((D,))
+    o.push(x)
+    s = torch.zeros(D, dtype=torch.float64, device=dev)
+    q = torch.full((D,), 1e-2, dtype=torch.float64, device=dev)
+    cnt = torch.full((1,), 1e-2, dtype=torch.float64, device=dev)
+    mean = torch.zeros(D, dtype=torch.float64, device=dev)
+    std = torch.zeros(D, dtype=torch.float64, device=dev)
+    rlx.running_stats_push(dev_tensor(x, dev), int(f64), n, D, s, q, cnt, mean, std, 1e-2, 0)
+    if D > 1:          # numpy adds rows sequentially for axis-0 sums of (n, D>1) arrays -> bit-exact
+        assert np.array_equal(mean.cpu().numpy(), o._mean)
+        assert np.array_equal(std.cpu().numpy(), o._std)
+    else:              # (n,1): numpy may sum pairwise
+        np.testing.assert_allclose(mean.cpu().numpy(), o._mean, rtol=1e-13)
+        np.testing.assert_allclose(std.cpu().numpy(), o._std, rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_reward_filters_match_reference(golden, rlx, dev):
+    import torch
+    from coach_amd._rlx import RlxError
+    g = golden("filters")
+    r = dev_tensor(g["rewards"], dev, np.float32)
+    out = torch.empty_like(r)
+    for name in ("clip11", "clip0hi", "clip0lo"):
+        lo, hi = g[name + "_bounds"]
+        rlx.reward_filter(r, out, len(g["rewards"]), 1.0, 1, lo, hi, 0)
+        assert np.array_equal(out.cpu().numpy(), g[name].astype(np.float32)), name
+    rlx.reward_filter(r, out, len(g["rewards"]), 5.0, 0, 0.0, 0.0, 0)
+    assert np.array_equal(out.cpu().numpy(), g["rescale5"].astype(np.float32))
+    with pytest.raises(RlxError, match="can not be set to 0"):
+        rlx.reward_filter(r, out, 7, 0.0, 0, 0.0, 0.0, 0)
+    with pytest.raises(RlxError, match="clipping low"):
+        rlx.reward_filter(r, out, 7, 1.0, 1, 2.0, 1.0, 0)

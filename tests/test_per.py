@@ -153,8 +153,13 @@ class _HipBackend:
         return self.list_len
 
     def store(self, n=1):
-        self.rlx.per_store(self.sum, self.min, self.max, self.cap, self.next_leaf, n, self.alpha,
-                           self.maxp, self.status, 0)
+        if self.exact:      # host mirrors maximal_priority -> libm pow, bit-identical leaves
+            p = self.maxp.item()
+            self.rlx.per_store_value(self.sum, self.min, self.max, self.cap, self.next_leaf, n,
+                                     p ** self.alpha, p, self.maxp, self.status, 0)
+        else:
+            self.rlx.per_store(self.sum, self.min, self.max, self.cap, self.next_leaf, n,
+                               self.alpha, self.maxp, self.status, 0)
         self.next_leaf = (self.next_leaf + n) % self.cap
         self.list_len = min(self.list_len + 2 * n, self.cap)       # double-store quirk
 

@@ -1,0 +1,270 @@
+"""K1/K4 replay storage: uniform replay index semantics and the frame-dedup stacking ring.
+
+Mirrors rl_coach/tests/memories (FIFO / sample semantics) and
+rl_coach/tests/filters/observation/test_observation_stacking_filter.py:27-78.
+"""
+import numpy as np
+import pytest
+
+from oracle.replay import StackingOracle, UniformReplayOracle
+from tests.util import columns, dev_tensor, status_tensor
+
+
+# ------------------------------------------------------------------------------------ CPU
+def test_oracle_er_appendix_b(golden):
+    g = golden("er")
+    m = UniformReplayOracle(1000)
+    for i in range(50):
+        m.store((float(i),))
+    np.random.seed(7)
+    idx = m.sample_indices(8)
+    assert m.gather(idx)[0].tolist() == g["appB_rewards"].tolist() == [47, 4, 25, 3, 19, 23, 39, 28]
+
+
+def test_oracle_er_fifo_trace(golden):
+    g = golden("er")
+    cap, n, B, every, seed = g["fifo_meta"].tolist()
+    np.random.seed(seed)
+    m = UniformReplayOracle(cap)
+    k = 0
+    for i in range(n):
+        m.store((float(i),))
+        if i % every == every - 1:
+            assert m.num_transitions() == g["fifo_counts"][k]
+            assert m.gather(m.sample_indices(B))[0].tolist() == g["fifo_rewards"][k].tolist()
+            k += 1
+
+
+@pytest.mark.parametrize("name,stack", [("s4", 4), ("s3", 3)])
+def test_oracle_stacking_matches_reference(golden, name, stack):
+    g = golden("stack")
+    f = StackingOracle(stack)
+    for fr, first, ref in zip(g[name + "_frames"], g[name + "_first"], g[name + "_stacks"]):
+        if first:
+            f.reset()
+        assert np.array_equal(f.filter(fr), ref)
+
+
+def test_oracle_stacking_reference_unit_test():
+    # rl_coach/tests/filters/observation/test_observation_stacking_filter.py:27-53
+    f = StackingOracle(4)
+    out = f.filter(np.ones((20, 30)))
+    assert out.shape == (20, 30, 4) and np.all(out == 1)
+    for i in range(3):
+        out = f.filter(np.ones((20, 30)) * (i + 2))
+    assert [out[0, 0, k] for k in range(4)] == [1, 2, 3, 4]
+    out = f.filter(np.ones((20, 30)) * 5)
+    assert [out[0, 0, k] for k in range(4)] == [2, 3, 4, 5]
+    f.reset()
+    out = f.filter(np.ones((20, 30)) * 9)
+    assert np.all(out == 9)
+
+
+# ------------------------------------------------------------------------------------ GPU
+class _HipUniformReplay:
+    """Ring-buffer version of ExperienceReplay over rlx_copy_columns."""
+
+    def __init__(self, rlx, dev, cap, dims, dtypes):
+        import torch
+        self.rlx, self.dev, self.cap = rlx, dev, cap
+        self.cols = [torch.zeros((cap,) + d, dtype=t, device=dev) for d, t in zip(dims, dtypes)]
+        self.count = 0            # total ever stored
+        self.status = status_tensor(dev)
+
+    def num_transitions(self):
+        return min(self.count, self.cap)
+
+    def store_batch(self, arrays):
+        n = len(arrays[0])
+        srcs = [dev_tensor(a, self.dev, c.cpu().numpy().dtype) for a, c in zip(arrays, self.cols)]
+        self.rlx.copy_columns(columns(list(zip(srcs, self.cols))), len(srcs), None, None, 0,
+                              self.count % self.cap, n, self.cap, n, self.status, 0)
+        self.count += n
+
+    def gather(self, logical_idx):
+        import torch
+        head = self.count % self.cap if self.count > self.cap else 0     # oldest row
+        phys = (np.asarray(logical_idx) + head) % self.cap
+        idx = dev_tensor(phys, self.dev, np.int32)
+        outs = [torch.empty((len(phys),) + tuple(c.shape[1:]), dtype=c.dtype, device=self.dev)
+                for c in self.cols]
+        self.rlx.copy_columns(columns(list(zip(self.cols, outs))), len(outs), idx, None, 0, 0,
+                              self.cap, len(phys), len(phys), self.status, 0)
+        assert int(self.status.item()) == 0
+        return [o.cpu().numpy() for o in outs]
+
+
+@pytest.mark.gpu
+def test_hip_er_fifo_trace(golden, rlx, dev):
+    import torch
+    g = golden("er")
+    cap, n, B, every, seed = g["fifo_meta"].tolist()
+    np.random.seed(seed)
+    m = _HipUniformReplay(rlx, dev, cap, [(), (3,)], [torch.float32, torch.float32])
+    k = 0
+    for i in range(n):
+        m.store_batch([np.array([i], dtype=np.float32), np.full((1, 3), i, dtype=np.float32)])
+        if i % every == every - 1:
+            assert m.num_transitions() == g["fifo_counts"][k]
+            idx = np.random.randint(m.num_transitions(), size=B)       # experience_replay.py:81
+            r, o = m.gather(idx)
+            assert r.tolist() == g["fifo_rewards"][k].tolist()
+            assert np.array_equal(o, np.repeat(r[:, None], 3, 1))
+            k += 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obs_dim,act_dim,n_env,cap,B", [(17, 6, 256, 4096, 100), (376, 17, 512, 2048, 256),
+                                                         (4, 1, 1, 37, 32)])
+def test_hip_er_vs_oracle_vector_env(rlx, dev, obs_dim, act_dim, n_env, cap, B):
+    """Vectorised stores (n_env rows per call, wrapping) against the list-based oracle; covers the
+    C4/C5 shapes (odd row sizes -> 4-byte path, 16-byte path)."""
+    import torch
+    rng = np.random.RandomState(obs_dim)
+    o = UniformReplayOracle(cap)
+    h = _HipUniformReplay(rlx, dev, cap, [(obs_dim,), (act_dim,), (), (obs_dim,), ()],
+                          [torch.float32, torch.float32, torch.float32, torch.float32, torch.uint8])
+    steps = (3 * cap) // n_env + 2 if n_env > 1 else 60
+    for s in range(steps):
+        obs = rng.randn(n_env, obs_dim).astype(np.float32)
+        act = rng.randn(n_env, act_dim).astype(np.float32)
+        rew = rng.randn(n_env).astype(np.float32)
+        nxt = rng.randn(n_env, obs_dim).astype(np.float32)
+        done = (rng.rand(n_env) < 0.1).astype(np.uint8)
+        for e in range(n_env):
+            o.store((obs[e], act[e], rew[e], nxt[e], done[e]))
+        h.store_batch([obs, act, rew, nxt, done])
+        if s % 5 == 4 or s == steps - 1:
+            assert h.num_transitions() == o.num_transitions()
+            idx = rng.randint(o.num_transitions(), size=B)
+            for a, b in zip(h.gather(idx), o.gather(idx)):
+                assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_hip_copy_columns_reports_bad_index(rlx, dev):
+    import torch
+    src = torch.arange(40, dtype=torch.float32, device=dev).reshape(10, 4)
+    dst = torch.zeros(2, 4, dtype=torch.float32, device=dev)
+    st = status_tensor(dev)
+    idx = dev_tensor([3, 10], dev, np.int32)                    # 10 is out of range
+    rlx.copy_columns(columns([(src, dst)]), 1, idx, None, 0, 0, 10, 2, 2, st, 0)
+    assert int(st.item()) == 1
+    assert dst[0].tolist() == src[3].tolist()
+
+
+class _HipImageReplay:
+    def __init__(self, rlx, dev, n_env, frame_shape, stack, cap, ring_frames):
+        import torch
+        self.rlx, self.dev, self.n_env, self.stack, self.cap = rlx, dev, n_env, stack, cap
+        self.fb = int(np.prod(frame_shape))
+        self.frame_shape = frame_shape
+        self.F = ring_frames
+        self.ring = torch.zeros(n_env, ring_frames, self.fb, dtype=torch.uint8, device=dev)
+        self.fpos = torch.zeros(n_env, dtype=torch.int32, device=dev)
+        self.epoff = torch.zeros(n_env, dtype=torch.int32, device=dev)
+        self.t_fpos = torch.zeros(cap, dtype=torch.int32, device=dev)
+        self.t_epoff = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.cursor = 0
+        self.status = status_tensor(dev)
+
+    def reset(self, frames):
+        self.rlx.imgreplay_reset(self.ring, self.fpos, self.epoff, dev_tensor(frames, self.dev),
+                                 self.n_env, self.F, self.fb, 0)
+
+    def append(self, next_frames, reset_frames, done):
+        self.rlx.imgreplay_append(self.ring, self.fpos, self.epoff, self.t_fpos, self.t_epoff,
+                                  dev_tensor(next_frames, self.dev),
+                                  dev_tensor(reset_frames, self.dev),
+                                  dev_tensor(done, self.dev, np.uint8), self.n_env, self.F, self.fb,
+                                  self.stack, self.cursor, self.cap, 1, 0)
+        self.cursor += self.n_env
+
+    def current(self):
+        import torch
+        out = torch.empty(self.n_env, self.fb, self.stack, dtype=torch.uint8, device=self.dev)
+        self.rlx.imgreplay_gather(self.ring, None, None, self.fpos, self.epoff, None, self.n_env,
+                                  self.n_env, self.F, self.fb, self.stack, self.cap, out, None,
+                                  self.status, 0)
+        return out.cpu().numpy().reshape((self.n_env,) + self.frame_shape + (self.stack,))
+
+    def gather(self, rows):
+        import torch
+        B = len(rows)
+        s = torch.empty(B, self.fb, self.stack, dtype=torch.uint8, device=self.dev)
+        n = torch.empty(B, self.fb, self.stack, dtype=torch.uint8, device=self.dev)
+        self.rlx.imgreplay_gather(self.ring, self.t_fpos, self.t_epoff, None, None,
+                                  dev_tensor(rows, self.dev, np.int32), B, self.n_env, self.F,
+                                  self.fb, self.stack, self.cap, s, n, self.status, 0)
+        assert int(self.status.item()) == 0
+        shp = (B,) + self.frame_shape + (self.stack,)
+        return s.cpu().numpy().reshape(shp), n.cpu().numpy().reshape(shp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,stack", [("s4", 4), ("s3", 3)])
+def test_hip_stacking_matches_reference_trace(golden, rlx, dev, name, stack):
+    """Single env: replay the reference filter's frames through the ring; current stacked state
+    and the stored (state, next_state) pairs must equal the reference's LazyStack arrays."""
+    g = golden("stack")
+    frames, first, ref = g[name + "_frames"], g[name + "_first"], g[name + "_stacks"]
+    shape = frames.shape[1:]
+    T = len(frames)
+    m = _HipImageReplay(rlx, dev, 1, shape, stack, 64, 2 * T + 8)
+    expect = []                         # (state stack, next stack) per stored transition
+    i = 0
+    m.reset(frames[0:1])
+    assert np.array_equal(m.current()[0], ref[0])
+    while i + 1 < T:
+        if first[i + 1]:                # frames[i] was terminal's obs; i+1 is a reset frame
+            i += 1
+            continue
+        terminal = (i + 2 < T and first[i + 2]) or False
+        nxt = frames[i + 1:i + 2]
+        rst = frames[i + 2:i + 3] if terminal else nxt
+        m.append(nxt, rst, [1 if terminal else 0])
+        expect.append((ref[i], ref[i + 1]))
+        i += 1
+        cur = m.current()[0]
+        assert np.array_equal(cur, ref[i + 1] if terminal else ref[i])
+    s, n = m.gather(np.arange(len(expect)))
+    for k, (es, en) in enumerate(expect):
+        assert np.array_equal(s[k], es), k
+        assert np.array_equal(n[k], en), k
+
+
+@pytest.mark.gpu
+def test_hip_image_replay_vs_oracle_atari_shape(rlx, dev):
+    """C2/C3 shape: 84x84 frames, stack 4, several envs with different episode lengths, ring wrap."""
+    rng = np.random.RandomState(3)
+    n_env, L, steps, cap = 5, [7, 3, 11, 1, 5], 40, 5 * 16
+    F = 16 + 16 // 1 + 8
+    m = _HipImageReplay(rlx, dev, n_env, (84, 84), 4, cap, F)
+    oracles = [StackingOracle(4) for _ in range(n_env)]
+    f0 = rng.randint(0, 256, size=(n_env, 84, 84)).astype(np.uint8)
+    cur = [o.filter(f) for o, f in zip(oracles, f0)]
+    m.reset(f0)
+    t_in_ep = [0] * n_env
+    table = {}
+    for s in range(steps):
+        nxt = rng.randint(0, 256, size=(n_env, 84, 84)).astype(np.uint8)
+        rst = rng.randint(0, 256, size=(n_env, 84, 84)).astype(np.uint8)
+        done = np.array([t_in_ep[e] == L[e] - 1 for e in range(n_env)], dtype=np.uint8)
+        for e in range(n_env):
+            ns = oracles[e].filter(nxt[e])
+            table[(s * n_env + e) % cap] = (cur[e], ns)
+            if done[e]:
+                oracles[e].reset()
+                cur[e] = oracles[e].filter(rst[e])
+                t_in_ep[e] = 0
+            else:
+                cur[e] = ns
+                t_in_ep[e] += 1
+        m.append(nxt, rst, done)
+        assert np.array_equal(m.current(), np.array(cur))
+    live = sorted(table)[-min(len(table), cap - n_env * 2):]     # rows whose frames are still in the ring
+    rows = rng.choice(live, size=32)
+    hs, hn = m.gather(rows)
+    for k, r in enumerate(rows):
+        assert np.array_equal(hs[k], table[r][0])
+        assert np.array_equal(hn[k], table[r][1])
