@@ -175,3 +175,78 @@ def current_stream():
     """hipStream_t of torch's current stream, as an int usable for the `stream` parameters."""
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------- ABI structures
+class Column(ctypes.Structure):
+    """rlx_column (include/rlx.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_longlong)]
+
+
+def make_columns(pairs):
+    """[(src_tensor, dst_tensor), ...] -> rlx_column[]; rows run along dim 0 of every tensor."""
+    arr = (Column * len(pairs))()
+    for i, (s, d) in enumerate(pairs):
+        rb = (s[0].numel() if s.dim() > 1 else 1) * s.element_size()
+        arr[i] = Column(s.data_ptr(), d.data_ptr(), rb)
+    return arr
+
+
+class GemmDesc(ctypes.Structure):
+    """rlx_gemm_desc (include/rlx.h) — field order must match the header."""
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("a_row_tab", ctypes.c_void_p), ("a_k_tab", ctypes.c_void_p),
+        ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("deriv_aux", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+        ("a_row_stride", ctypes.c_longlong), ("a_k_stride", ctypes.c_longlong),
+        ("a_batch_stride", ctypes.c_longlong),
+        ("b_k_stride", ctypes.c_longlong), ("b_n_stride", ctypes.c_longlong),
+        ("b_batch_stride", ctypes.c_longlong),
+        ("ldc", ctypes.c_longlong), ("c_batch_stride", ctypes.c_longlong),
+        ("bias_batch_stride", ctypes.c_longlong),
+        ("aux_ld", ctypes.c_longlong), ("aux_batch_stride", ctypes.c_longlong),
+        ("workspace_floats", ctypes.c_longlong),
+        ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int),
+        ("a_is_u8", ctypes.c_int), ("a_vec_along_k", ctypes.c_int), ("a_tab_vec_ok", ctypes.c_int),
+        ("activation", ctypes.c_int), ("deriv_kind", ctypes.c_int), ("accumulate", ctypes.c_int),
+        ("a_div", ctypes.c_float),
+    ]
+
+
+ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+
+
+def _ptr(t):
+    return None if t is None else (t.data_ptr() if hasattr(t, "data_ptr") else t)
+
+
+def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0,
+         a_vec_along_k=1, a_tab_vec_ok=0, b_strides=None, ldc=None, bias=None, activation=None,
+         deriv_aux=None, aux_ld=None, deriv_kind=None, accumulate=False, batch=1,
+         a_batch_stride=0, b_batch_stride=0, c_batch_stride=0, bias_batch_stride=0,
+         aux_batch_stride=0, workspace=None, stream=None):
+    """Thin wrapper building an rlx_gemm_desc.  a_strides=(row, k), b_strides=(k, n) in elements."""
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch = int(M), int(N), int(K), int(batch)
+    d.A, d.B, d.C = _ptr(A), _ptr(B), _ptr(C)
+    if a_tabs is not None:
+        d.a_row_tab, d.a_k_tab = _ptr(a_tabs[0]), _ptr(a_tabs[1])
+        d.a_row_stride, d.a_k_stride = 0, 0
+    else:
+        rs, ks = a_strides if a_strides is not None else (K, 1)
+        d.a_row_stride, d.a_k_stride = int(rs), int(ks)
+    ks, ns = b_strides if b_strides is not None else (N, 1)
+    d.b_k_stride, d.b_n_stride = int(ks), int(ns)
+    d.a_batch_stride, d.b_batch_stride = int(a_batch_stride), int(b_batch_stride)
+    d.ldc = int(N if ldc is None else ldc)
+    d.c_batch_stride, d.bias_batch_stride = int(c_batch_stride), int(bias_batch_stride)
+    d.bias, d.deriv_aux = _ptr(bias), _ptr(deriv_aux)
+    d.aux_ld = int(N if aux_ld is None else aux_ld)
+    d.aux_batch_stride = int(aux_batch_stride)
+    d.workspace = _ptr(workspace)
+    d.workspace_floats = int(workspace.numel()) if workspace is not None else 0
+    d.a_is_u8, d.a_div = int(bool(a_u8)), float(a_div)
+    d.a_vec_along_k, d.a_tab_vec_ok = int(a_vec_along_k), int(a_tab_vec_ok)
+    d.activation, d.deriv_kind = ACT[activation], ACT[deriv_kind]
+    d.accumulate = int(bool(accumulate))
+    lib().gemm(ctypes.byref(d), current_stream() if stream is None else stream)

@@ -1,0 +1,479 @@
+// fp32 MFMA GEMM family for the policy / value / Q networks on gfx950.
+//
+// Replaces the TensorFlow ops behind rl_coach/architectures/tensorflow_components/layers.py:
+//   Dense  -> tf.layers.dense  (:168-185)       y = act(x W + b),           W stored [in, out]
+//   Conv2d -> tf.layers.conv2d (:108-121)       VALID padding, NHWC, kernel stored [KH,KW,Cin,Cout]
+// and their gradients (tf.gradients in tensorflow_components/architecture.py:187-220).
+//
+// One kernel template covers every product the learner needs:
+//     C[M,N] = epilogue( A[M,K] * B[K,N] )
+//   forward      (NN): A = activations (row-major, or an implicit-im2col gather), B = W[K,N]
+//   weight grad  (TN): A = X^T (X row-major or gathered), B = dY[M,N], reduction over the batch
+//   input grad   (NT): A = dY, B = W^T (W row-major [K,N] read with swapped strides)
+// Operand elements are addressed as  base[ offO(outer) + offR(red) ]  where each offset is either
+// index*stride or a lookup in a small int32 table: a convolution's im2col matrix is separable,
+//   addr(m,k) = rowbase[m] + koff[k],  rowbase = ((b*H + oy*s)*W + ox*s)*C,  koff = (ky*W + kx)*C + c
+// so the conv never materialises its patches (the uint8 frame stack is converted on the fly:
+// value = byte / a_div, ObservationEmbedder input_rescaling, embedders/embedder.py:107-108).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32 products, fp32 accumulate, bitwise a k-ordered
+// fmaf chain (cdna_hip_programming.md §3); peak 157.3 TFLOP/s.  A workgroup is 4 waves, each owning
+// one 32x32 accumulator tile (64x64 or 128x32 per workgroup); K is staged through LDS in slabs of
+// 32 as As[k][m], Bs[k][n] (row pitch +1 word -> the transposing stores are conflict-free, the
+// MFMA operand reads are 32 consecutive words per half-wave).  Small M*N with long K (the FC layer,
+// every weight gradient) is split along K over blockIdx.z into a workspace and reduced
+// deterministically by splitk_reduce_kernel, which also applies bias / activation.
+// blockIdx.z also carries a batch index (the two separate Clipped-PPO towers run as one launch).
+#include "rlx_common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int kThreads = 256;
+
+struct OperandDev {
+    const void *base;
+    const int *tab_o;   // outer-index offset table (elements) or null
+    const int *tab_r;   // reduction-index offset table or null
+    long long stride_o, stride_r, batch_stride;
+    int vec_ok;         // 16-byte (4-byte for u8) vector loads are legal for this launch
+};
+
+struct GemmDev {
+    OperandDev a, b;
+    float *c;
+    long long ldc, c_batch_stride;
+    const float *bias;
+    long long bias_batch_stride;
+    const float *aux;           // epilogue multiplies by act'(aux[m][n])
+    long long aux_ld, aux_batch_stride;
+    float *ws;                  // split-K partials [batch][split][M][N]
+    int M, N, K;
+    int splits, kchunk;
+    int act, deriv, accumulate;
+    float a_div;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == RLX_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == RLX_ACT_TANH) return tanhf(v);
+    return v;
+}
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_deriv(float y, int kind) {
+    if (kind == RLX_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (kind == RLX_ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+// Loads 4 logically consecutive elements (along the vector dimension) of an operand tile.
+//   VEC_RED = true : the 4 elements run along the reduction index r (o fixed)
+//   VEC_RED = false: along the outer index o (r fixed)
+template <bool VEC_RED, bool U8>
+__device__ __forceinline__ float4 load4(const OperandDev &op, const unsigned char *base, int o,
+                                        int r, int o_lim, int r_lim, float div) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o >= o_lim || r >= r_lim) return v;
+    const long long off_o = op.tab_o ? (long long)op.tab_o[o] : (long long)o * op.stride_o;
+    const long long off_r = op.tab_r ? (long long)op.tab_r[r] : (long long)r * op.stride_r;
+    const int remaining = VEC_RED ? (r_lim - r) : (o_lim - o);
+    if (op.vec_ok && remaining >= 4) {
+        if (U8) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(base + off_o + off_r);
+            v.x = (float)(w & 0xffu) / div;
+            v.y = (float)((w >> 8) & 0xffu) / div;
+            v.z = (float)((w >> 16) & 0xffu) / div;
+            v.w = (float)(w >> 24) / div;
+        } else {
+            v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + off_o + off_r);
+        }
+        return v;
+    }
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < remaining) {
+            long long off;
+            if (VEC_RED)
+                off = off_o + (op.tab_r ? (long long)op.tab_r[r + i] : (long long)(r + i) * op.stride_r);
+            else
+                off = (op.tab_o ? (long long)op.tab_o[o + i] : (long long)(o + i) * op.stride_o) + off_r;
+            t[i] = U8 ? (float)base[off] / div : reinterpret_cast<const float *>(base)[off];
+        }
+    }
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+template <int BM, int BN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED>
+__global__ void __launch_bounds__(kThreads) gemm_kernel(const GemmDev g) {
+    constexpr int WN = BN / 32;                      // waves along N
+    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+    constexpr int NA = BM * BK / 4 / kThreads;       // float4 loads per thread for A
+    constexpr int NB = BN * BK / 4 / kThreads;
+    __shared__ float As[BK * LDA_S];
+    __shared__ float Bs[BK * LDB_S];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bz = blockIdx.z;
+    const int batch = bz / g.splits, split = bz - batch * g.splits;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    const unsigned char *abase = static_cast<const unsigned char *>(g.a.base) +
+                                 (size_t)batch * g.a.batch_stride * (A_U8 ? 1 : 4);
+    const unsigned char *bbase = static_cast<const unsigned char *>(g.b.base) +
+                                 (size_t)batch * g.b.batch_stride * 4;
+
+    float4 ra[NA], rb[NB];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int v = tid + p * kThreads;
+            if (A_VEC_RED) {
+                const int row = v / (BK / 4), kq = (v % (BK / 4)) * 4;
+                ra[p] = load4<true, A_U8>(g.a, abase, m0 + row, k0 + kq, g.M, kend, g.a_div);
+            } else {
+                const int kr = v / (BM / 4), mq = (v % (BM / 4)) * 4;
+                ra[p] = load4<false, A_U8>(g.a, abase, m0 + mq, k0 + kr, g.M, kend, g.a_div);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int v = tid + p * kThreads;
+            if (B_VEC_RED) {
+                const int col = v / (BK / 4), kq = (v % (BK / 4)) * 4;
+                rb[p] = load4<true, false>(g.b, bbase, n0 + col, k0 + kq, g.N, kend, 1.f);
+            } else {
+                const int kr = v / (BN / 4), nq = (v % (BN / 4)) * 4;
+                rb[p] = load4<false, false>(g.b, bbase, n0 + nq, k0 + kr, g.N, kend, 1.f);
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int v = tid + p * kThreads;
+            if (A_VEC_RED) {
+                const int row = v / (BK / 4), kq = (v % (BK / 4)) * 4;
+                As[(kq + 0) * LDA_S + row] = ra[p].x;
+                As[(kq + 1) * LDA_S + row] = ra[p].y;
+                As[(kq + 2) * LDA_S + row] = ra[p].z;
+                As[(kq + 3) * LDA_S + row] = ra[p].w;
+            } else {
+                const int kr = v / (BM / 4), mq = (v % (BM / 4)) * 4;
+                float *d = &As[kr * LDA_S + mq];
+                d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int v = tid + p * kThreads;
+            if (B_VEC_RED) {
+                const int col = v / (BK / 4), kq = (v % (BK / 4)) * 4;
+                Bs[(kq + 0) * LDB_S + col] = rb[p].x;
+                Bs[(kq + 1) * LDB_S + col] = rb[p].y;
+                Bs[(kq + 2) * LDB_S + col] = rb[p].z;
+                Bs[(kq + 3) * LDB_S + col] = rb[p].w;
+            } else {
+                const int kr = v / (BN / 4), nq = (v % (BN / 4)) * 4;
+                float *d = &Bs[kr * LDB_S + nq];
+                d[0] = rb[p].x; d[1] = rb[p].y; d[2] = rb[p].z; d[3] = rb[p].w;
+            }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    if (kbeg < kend) {
+        load_tiles(kbeg);
+        store_tiles();
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            const bool more = k0 + BK < kend;
+            if (more) load_tiles(k0 + BK);          // global loads fly while the MFMAs run
+            const float *ap = &As[hi * LDA_S + wm * 32 + l31];
+            const float *bp = &Bs[hi * LDB_S + wn * 32 + l31];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a = ap[kk * LDA_S];
+                const float b = bp[kk * LDB_S];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tiles();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = n0 + wn * 32 + l31;
+    if (col >= g.N) return;
+    if (g.splits > 1) {
+        float *ws = g.ws + ((size_t)batch * g.splits + split) * (size_t)g.M * g.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < g.M) ws[(size_t)row * g.N + col] = acc[r];
+        }
+        return;
+    }
+    float *c = g.c + (size_t)batch * g.c_batch_stride;
+    const float bias = g.bias ? g.bias[(size_t)batch * g.bias_batch_stride + col] : 0.f;
+    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < g.M) {
+            float v = apply_act(acc[r] + bias, g.act);
+            if (aux) v *= act_deriv(aux[(size_t)row * g.aux_ld + col], g.deriv);
+            float *dst = &c[(size_t)row * g.ldc + col];
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const GemmDev g) {
+    const long long mn = (long long)g.M * g.N;
+    const int batch = blockIdx.y;
+    const float *ws = g.ws + (size_t)batch * g.splits * mn;
+    float *c = g.c + (size_t)batch * g.c_batch_stride;
+    const float *bias = g.bias ? g.bias + (size_t)batch * g.bias_batch_stride : nullptr;
+    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < mn;
+         i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < g.splits; ++k) s += ws[(size_t)k * mn + i];   // fixed order
+        const int row = (int)(i / g.N), col = (int)(i - (long long)row * g.N);
+        float v = apply_act(s + (bias ? bias[col] : 0.f), g.act);
+        if (aux) v *= act_deriv(aux[(size_t)row * g.aux_ld + col], g.deriv);
+        float *dst = &c[(size_t)row * g.ldc + col];
+        *dst = g.accumulate ? *dst + v : v;
+    }
+}
+
+// Column sums for bias gradients: out[n] = sum_m x[m][n]  (deterministic two-stage reduction).
+__global__ void colsum_partial_kernel(const float *__restrict__ x, int M, int N, long long ld,
+                                      int rows_per_block, float *__restrict__ part) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ld + n];
+    part[(size_t)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_final_kernel(const float *__restrict__ part, int nparts, int N,
+                                    float *__restrict__ out, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// im2col offset tables (see header comment).
+__global__ void conv_tables_kernel(int *__restrict__ rowbase, int *__restrict__ koff, int batch,
+                                   int H, int W, int C, int KH, int KW, int stride, int OH, int OW) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = batch * OH * OW, K = KH * KW * C;
+    if (t < M) {
+        const int ox = t % OW, oy = (t / OW) % OH, b = t / (OW * OH);
+        rowbase[t] = ((b * H + oy * stride) * W + ox * stride) * C;
+    }
+    if (t < K) {
+        const int c = t % C, kx = (t / C) % KW, ky = t / (C * KW);
+        koff[t] = (ky * W + kx) * C + c;
+    }
+}
+
+// col2im as a gather: dX[b,iy,ix,c] = sum over the (ky,kx) whose output position exists of
+// dcol[(b,oy,ox)][(ky,kx,c)], multiplied by act'(x) of the layer that produced x.
+__global__ void col2im_kernel(const float *__restrict__ dcol, float *__restrict__ dx,
+                              const float *__restrict__ x_out, int deriv, int batch, int H, int W,
+                              int C, int KH, int KW, int stride, int OH, int OW) {
+    const long long total = (long long)batch * H * W * C;
+    const int K = KH * KW * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int ix = (int)((t / C) % W);
+        const int iy = (int)((t / ((long long)C * W)) % H);
+        const int b = (int)(t / ((long long)C * W * H));
+        float s = 0.f;
+        for (int ky = iy % stride; ky < KH; ky += stride) {
+            const int oy = (iy - ky) / stride;
+            if (iy < ky || oy >= OH) continue;
+            for (int kx = ix % stride; kx < KW; kx += stride) {
+                const int ox = (ix - kx) / stride;
+                if (ix < kx || ox >= OW) continue;
+                s += dcol[((size_t)(b * OH + oy) * OW + ox) * K + (ky * KW + kx) * C + c];
+            }
+        }
+        if (x_out) s *= act_deriv(x_out[t], deriv);
+        dx[t] = s;
+    }
+}
+
+template <int BM, int BN>
+int launch_variant(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, dim3 grid,
+                   hipStream_t s) {
+#define RLX_GEMM_CASE(AV, AU, BV)                                                        \
+    if (a_vec_red == AV && a_u8 == AU && b_vec_red == BV) {                              \
+        gemm_kernel<BM, BN, AV, AU, BV><<<grid, kThreads, 0, s>>>(g);                    \
+        return 0;                                                                        \
+    }
+    RLX_GEMM_CASE(true, false, false)
+    RLX_GEMM_CASE(true, false, true)
+    RLX_GEMM_CASE(false, false, false)
+    RLX_GEMM_CASE(false, false, true)
+    RLX_GEMM_CASE(true, true, false)
+    RLX_GEMM_CASE(false, true, false)
+#undef RLX_GEMM_CASE
+    return -1;
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host) {
+    RLX_REQUIRE(floats_host && M > 0 && N > 0 && K > 0 && batch > 0,
+                "rlx_gemm_workspace_floats: bad arguments");
+    // upper bound used by rlx_gemm's split heuristic (at most 64 splits)
+    *floats_host = (long long)M * N * batch * 64;
+    return RLX_OK;
+}
+
+int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
+    RLX_REQUIRE(d_host != nullptr, "rlx_gemm: null descriptor");
+    const rlx_gemm_desc &d = *d_host;
+    RLX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0,
+                "rlx_gemm: bad shape M=%d N=%d K=%d batch=%d", d.M, d.N, d.K, d.batch);
+    RLX_REQUIRE(d.A && d.B && d.C, "rlx_gemm: null operand");
+    RLX_REQUIRE(d.a_row_tab || d.a_k_tab || d.a_row_stride == 1 || d.a_k_stride == 1,
+                "rlx_gemm: A must be contiguous along one index");
+    RLX_REQUIRE(d.b_k_stride == 1 || d.b_n_stride == 1, "rlx_gemm: B must be contiguous along one index");
+    RLX_REQUIRE(!d.a_is_u8 || d.a_div != 0.f, "rlx_gemm: a_div must be non-zero for uint8 input");
+    RLX_REQUIRE(d.activation >= 0 && d.activation <= 2 && d.deriv_kind >= 0 && d.deriv_kind <= 2,
+                "rlx_gemm: unknown activation");
+
+    GemmDev g;
+    g.M = d.M; g.N = d.N; g.K = d.K;
+    g.a.base = d.A; g.a.tab_o = d.a_row_tab; g.a.tab_r = d.a_k_tab;
+    g.a.stride_o = d.a_row_stride; g.a.stride_r = d.a_k_stride; g.a.batch_stride = d.a_batch_stride;
+    g.b.base = d.B; g.b.tab_o = nullptr; g.b.tab_r = nullptr;
+    g.b.stride_o = d.b_n_stride; g.b.stride_r = d.b_k_stride; g.b.batch_stride = d.b_batch_stride;
+    g.c = d.C; g.ldc = d.ldc; g.c_batch_stride = d.c_batch_stride;
+    g.bias = d.bias; g.bias_batch_stride = d.bias_batch_stride;
+    g.aux = d.deriv_aux; g.aux_ld = d.aux_ld; g.aux_batch_stride = d.aux_batch_stride;
+    g.act = d.activation; g.deriv = d.deriv_kind; g.accumulate = d.accumulate;
+    g.a_div = d.a_is_u8 ? d.a_div : 1.f;
+
+    // vector dimension of each operand: the index whose stride is 1 (tables: declared by caller)
+    const bool a_vec_red = d.a_row_tab || d.a_k_tab ? (d.a_vec_along_k != 0) : (d.a_k_stride == 1);
+    const bool b_vec_red = d.b_k_stride == 1 && d.b_n_stride != 1;
+    const int a_elem = d.a_is_u8 ? 1 : 4;
+    if (d.a_row_tab || d.a_k_tab) {
+        g.a.vec_ok = d.a_tab_vec_ok != 0;
+    } else {
+        const long long other = a_vec_red ? d.a_row_stride : d.a_k_stride;
+        g.a.vec_ok = (((uintptr_t)d.A) % (4 * a_elem) == 0) && (other % 4 == 0) &&
+                     ((d.a_batch_stride % 4) == 0);
+    }
+    {
+        const long long other = b_vec_red ? d.b_n_stride : d.b_k_stride;
+        g.b.vec_ok = aligned16(d.B) && (other % 4 == 0) && ((d.b_batch_stride % 4) == 0);
+    }
+
+    // tile shape: narrow-N problems use 128x32 workgroup tiles
+    const bool narrow = d.N <= 32;
+    const int BM = narrow ? 128 : 64, BN = narrow ? 32 : 64;
+    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.batch;
+    // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split
+    int splits = 1;
+    if (d.workspace && tiles < 2 * rlx::kCUs) {
+        const int want = (2 * rlx::kCUs + tiles - 1) / tiles;
+        const int max_by_k = d.K / (2 * BK);
+        splits = want < max_by_k ? want : max_by_k;
+        if (splits > 64) splits = 64;
+        if (splits < 1) splits = 1;
+        while (splits > 1 && (long long)d.M * d.N * d.batch * splits > d.workspace_floats) --splits;
+    }
+    int kchunk = ((d.K + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (d.K + kchunk - 1) / kchunk;
+    g.splits = splits;
+    g.kchunk = kchunk;
+    g.ws = d.workspace;
+
+    hipStream_t s = rlx::as_stream(stream);
+    dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * splits);
+    int rc = narrow ? launch_variant<128, 32>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, grid, s)
+                    : launch_variant<64, 64>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, grid, s);
+    RLX_REQUIRE(rc == 0, "rlx_gemm: unsupported operand combination (uint8 A with transposed B)");
+    RLX_LAUNCH_CHECK();
+    if (splits > 1) {
+        const long long mn = (long long)d.M * d.N;
+        dim3 rgrid(rlx::grid_for(mn, 256, 1024), d.batch);
+        splitk_reduce_kernel<<<rgrid, 256, 0, s>>>(g);
+        RLX_LAUNCH_CHECK();
+    }
+    return RLX_OK;
+}
+
+int rlx_colsum(const float *x, int M, int N, long long ld, float *out, int accumulate,
+               float *workspace, long long workspace_floats, void *stream) {
+    RLX_REQUIRE(x && out && workspace, "rlx_colsum: null pointer");
+    RLX_REQUIRE(M > 0 && N > 0 && ld >= N, "rlx_colsum: bad shape");
+    int parts = (M + 255) / 256;
+    if (parts > 256) parts = 256;
+    while (parts > 1 && (long long)parts * N > workspace_floats) --parts;
+    RLX_REQUIRE((long long)parts * N <= workspace_floats, "rlx_colsum: workspace too small");
+    const int rows_per_block = (M + parts - 1) / parts;
+    parts = (M + rows_per_block - 1) / rows_per_block;
+    hipStream_t s = rlx::as_stream(stream);
+    dim3 grid((N + 63) / 64, parts);
+    colsum_partial_kernel<<<grid, 64, 0, s>>>(x, M, N, ld, rows_per_block, workspace);
+    RLX_LAUNCH_CHECK();
+    colsum_final_kernel<<<(N + 63) / 64, 64, 0, s>>>(workspace, parts, N, out, accumulate);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_conv_tables(int *rowbase, int *koff, int batch, int H, int W, int C, int KH, int KW,
+                    int stride, void *stream) {
+    RLX_REQUIRE(rowbase && koff, "rlx_conv_tables: null pointer");
+    RLX_REQUIRE(batch > 0 && H >= KH && W >= KW && C > 0 && KH > 0 && KW > 0 && stride > 0,
+                "rlx_conv_tables: bad convolution geometry");
+    const int OH = (H - KH) / stride + 1, OW = (W - KW) / stride + 1;   // VALID padding
+    const int M = batch * OH * OW, K = KH * KW * C;
+    RLX_REQUIRE((long long)batch * H * W * C < (1LL << 31), "rlx_conv_tables: input too large for int32 offsets");
+    const int n = M > K ? M : K;
+    conv_tables_kernel<<<(n + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
+        rowbase, koff, batch, H, W, C, KH, KW, stride, OH, OW);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_col2im(const float *dcol, float *dx, const float *x_out, int deriv_kind, int batch, int H,
+               int W, int C, int KH, int KW, int stride, void *stream) {
+    RLX_REQUIRE(dcol && dx, "rlx_col2im: null pointer");
+    RLX_REQUIRE(batch > 0 && H >= KH && W >= KW && C > 0 && stride > 0, "rlx_col2im: bad geometry");
+    const int OH = (H - KH) / stride + 1, OW = (W - KW) / stride + 1;
+    const long long total = (long long)batch * H * W * C;
+    col2im_kernel<<<rlx::grid_for(total, 256), 256, 0, rlx::as_stream(stream)>>>(
+        dcol, dx, x_out, deriv_kind, batch, H, W, C, KH, KW, stride, OH, OW);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+}  // extern "C"

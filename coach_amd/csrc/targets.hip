@@ -9,6 +9,7 @@
 //
 // The reference does this arithmetic in fp64 (python floats / numpy promote the fp32 network
 // outputs) and casts to fp32 when the result is fed back to the network; the kernels do the same.
+// Compiled with -ffp-contract=off so the fp64 expressions round like numpy (no FMA).
 // Elementwise, HBM-bound, a few hundred bytes per launch at the BASELINE batch sizes: the point
 // of these kernels is that Q values never leave the device between the two network passes.
 #include "rlx_common.hpp"

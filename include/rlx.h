@@ -163,6 +163,47 @@ int rlx_reward_filter(const float *rewards, float *out, long long n, double resc
                       int has_clip, double clipping_low, double clipping_high,
                       void *stream);   /* filters/reward/reward_rescale_filter.py:37-39, reward_clipping_filter.py:41-49 */
 
+/* ------------------------------------------- dense / conv layers (fp32 MFMA) -- */
+enum { RLX_ACT_NONE = 0, RLX_ACT_RELU = 1, RLX_ACT_TANH = 2 };
+
+/* C[M,N] (+)= epilogue(A[M,K] * B[K,N]) for `batch` independent problems (strided).
+ * A(m,k) = A[off_m + off_k] with off_* = index*stride or a lookup in an int32 table (implicit
+ * im2col: rlx_conv_tables); one of the two indices must be contiguous in groups of 4.
+ * epilogue: v = act(acc + bias[n]); if deriv_aux: v *= act'(deriv_aux[m][n]) (derivative written in
+ * terms of the activation OUTPUT); C = accumulate ? C + v : v.
+ * Replaces tf.layers.dense / tf.layers.conv2d and their gradients
+ * (architectures/tensorflow_components/layers.py:108-121,168-185). */
+typedef struct rlx_gemm_desc {
+    const void *A;            /* float (or uint8 when a_is_u8) */
+    const int *a_row_tab;     /* offset per m (elements) or NULL -> m * a_row_stride */
+    const int *a_k_tab;       /* offset per k or NULL -> k * a_k_stride            */
+    const float *B;
+    float *C;
+    const float *bias;        /* [N] or NULL */
+    const float *deriv_aux;   /* [M, aux_ld] or NULL */
+    float *workspace;         /* split-K partials, or NULL to forbid splitting */
+    long long a_row_stride, a_k_stride, a_batch_stride;
+    long long b_k_stride, b_n_stride, b_batch_stride;
+    long long ldc, c_batch_stride, bias_batch_stride;
+    long long aux_ld, aux_batch_stride;
+    long long workspace_floats;
+    int M, N, K, batch;
+    int a_is_u8;              /* A holds bytes; value = byte / a_div (embedders/embedder.py:107-108) */
+    int a_vec_along_k;        /* with tables: 1 = 4 consecutive k are contiguous, 0 = 4 consecutive m */
+    int a_tab_vec_ok;         /* with tables: groups of 4 are contiguous AND 16-byte (4-byte for u8) aligned */
+    int activation, deriv_kind, accumulate;
+    float a_div;
+} rlx_gemm_desc;
+
+int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
+int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host);
+int rlx_colsum(const float *x, int M, int N, long long ld, float *out, int accumulate,
+               float *workspace, long long workspace_floats, void *stream);  /* bias gradients */
+int rlx_conv_tables(int *rowbase, int *koff, int batch, int H, int W, int C, int KH, int KW,
+                    int stride, void *stream);      /* VALID-padding NHWC im2col offsets */
+int rlx_col2im(const float *dcol, float *dx, const float *x_out, int deriv_kind, int batch, int H,
+               int W, int C, int KH, int KW, int stride, void *stream); /* conv input gradient */
+
 #ifdef __cplusplus
 }
 #endif

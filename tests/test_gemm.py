@@ -1,0 +1,183 @@
+"""fp32 MFMA GEMM family (dense NN/TN/NT, implicit-im2col conv, uint8 input, split-K, batched
+towers) against fp64 numpy.  Tolerance: fp32 accumulation over K terms -> rtol 2e-5 * sqrt(K)-ish,
+stated per test."""
+import numpy as np
+import pytest
+
+from tests.util import dev_tensor
+
+
+def _tol(K):
+    return dict(rtol=2e-5, atol=2e-6 * max(1.0, np.sqrt(K)))
+
+
+SHAPES = [  # (M, N, K) — the BASELINE layer shapes plus ragged edges
+    (64, 512, 3136), (64, 6, 512), (64, 1, 512), (100, 400, 23), (100, 300, 400), (256, 256, 376),
+    (256, 34, 256), (32, 2, 512), (1, 1, 1), (33, 65, 31), (129, 33, 130), (25600, 32, 256),
+    (5184, 64, 512), (7, 700, 9),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_nn_bias_act(rlx, dev, M, N, K):
+    import torch
+    from coach_amd._rlx import gemm
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(M, K).astype(np.float32)
+    B = (rng.randn(K, N) / np.sqrt(K)).astype(np.float32)
+    bias = rng.randn(N).astype(np.float32)
+    ws = torch.empty(1 << 22, dtype=torch.float32, device=dev)
+    for act, f in (("none", lambda x: x), ("relu", lambda x: np.maximum(x, 0)), ("tanh", np.tanh)):
+        C = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+        gemm(M, N, K, dev_tensor(A, dev), dev_tensor(B, dev), C, bias=dev_tensor(bias, dev),
+             activation=act, workspace=ws)
+        ref = f(A.astype(np.float64) @ B.astype(np.float64) + bias)
+        np.testing.assert_allclose(C.cpu().numpy(), ref, **_tol(K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(64, 512, 3136), (100, 400, 23), (25600, 32, 256), (33, 65, 31), (5184, 64, 512)])
+def test_gemm_weight_and_input_grads(rlx, dev, M, N, K):
+    """dW = X^T dY (TN, reduction over the batch M, split-K) and dX = (dY W^T) * act'(X) (NT)."""
+    import torch
+    from coach_amd._rlx import gemm
+    rng = np.random.RandomState(M * 3 + N)
+    X = np.tanh(rng.randn(M, K)).astype(np.float32)        # an activation output
+    W = (rng.randn(K, N) / np.sqrt(K)).astype(np.float32)
+    dY = rng.randn(M, N).astype(np.float32)
+    ws = torch.empty(1 << 23, dtype=torch.float32, device=dev)
+    Xd, Wd, dYd = dev_tensor(X, dev), dev_tensor(W, dev), dev_tensor(dY, dev)
+    dW = torch.empty(K, N, dtype=torch.float32, device=dev)
+    # C[K,N] = A[K,M] * B[M,N] with A(k,m) = X[m,k]: row stride 1, k stride K
+    gemm(K, N, M, Xd, dYd, dW, a_strides=(1, K), workspace=ws)
+    np.testing.assert_allclose(dW.cpu().numpy(), X.astype(np.float64).T @ dY.astype(np.float64),
+                               rtol=2e-5, atol=2e-6 * np.sqrt(M) * 4)
+    dX = torch.empty(M, K, dtype=torch.float32, device=dev)
+    # C[M,K] = A[M,N] * B[N,K] with B(n,k) = W[k,n]: k(red)=n stride 1, n(out)=k stride N
+    gemm(M, K, N, dYd, Wd, dX, b_strides=(1, N), deriv_aux=Xd, aux_ld=K, deriv_kind="tanh", workspace=ws)
+    ref = (dY.astype(np.float64) @ W.astype(np.float64).T) * (1 - X.astype(np.float64) ** 2)
+    np.testing.assert_allclose(dX.cpu().numpy(), ref, **_tol(N))
+    # accumulate=True adds onto the previous contents
+    gemm(M, K, N, dYd, Wd, dX, b_strides=(1, N), deriv_aux=Xd, aux_ld=K, deriv_kind="tanh",
+         workspace=ws, accumulate=True)
+    np.testing.assert_allclose(dX.cpu().numpy(), 2 * ref, **_tol(N))
+    db = torch.empty(N, dtype=torch.float32, device=dev)
+    rlx.colsum(dYd, M, N, N, db, 0, ws, ws.numel(), 0)
+    np.testing.assert_allclose(db.cpu().numpy(), dY.astype(np.float64).sum(0), rtol=2e-5,
+                               atol=2e-6 * np.sqrt(M) * 4)
+
+
+def _im2col(x, KH, KW, s):
+    B, H, W, C = x.shape
+    OH, OW = (H - KH) // s + 1, (W - KW) // s + 1
+    cols = np.zeros((B, OH, OW, KH, KW, C), dtype=x.dtype)
+    for ky in range(KH):
+        for kx in range(KW):
+            cols[:, :, :, ky, kx, :] = x[:, ky:ky + s * OH:s, kx:kx + s * OW:s, :]
+    return cols.reshape(B * OH * OW, KH * KW * C), OH, OW
+
+
+CONVS = [  # (B, H, W, C, KH, KW, stride, Cout, u8)
+    (8, 84, 84, 4, 8, 8, 4, 32, True),      # Atari conv1 on the uint8 frame stack
+    (8, 20, 20, 32, 4, 4, 2, 64, False),    # conv2
+    (8, 9, 9, 64, 3, 3, 1, 64, False),      # conv3
+    (3, 11, 13, 4, 3, 5, 2, 7, True),       # ragged
+    (2, 7, 7, 8, 7, 7, 1, 5, False),        # single output position
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C,KH,KW,s,Co,u8", CONVS)
+def test_conv_forward_backward_implicit_im2col(rlx, dev, B, H, W, C, KH, KW, s, Co, u8):
+    import torch
+    from coach_amd._rlx import gemm
+    rng = np.random.RandomState(H * W + C)
+    if u8:
+        x = rng.randint(0, 256, size=(B, H, W, C)).astype(np.uint8)
+        xf = x.astype(np.float32) / np.float32(255.0)
+    else:
+        x = np.tanh(rng.randn(B, H, W, C)).astype(np.float32)
+        xf = x
+    K = KH * KW * C
+    Wt = (rng.randn(K, Co) / np.sqrt(K)).astype(np.float32)
+    bias = rng.randn(Co).astype(np.float32)
+    cols, OH, OW = _im2col(xf.astype(np.float64), KH, KW, s)
+    M = B * OH * OW
+    rowbase = torch.empty(M, dtype=torch.int32, device=dev)
+    koff = torch.empty(K, dtype=torch.int32, device=dev)
+    rlx.conv_tables(rowbase, koff, B, H, W, C, KH, KW, s, 0)
+    ws = torch.empty(1 << 22, dtype=torch.float32, device=dev)
+    xd, Wd = dev_tensor(x, dev), dev_tensor(Wt, dev)
+    y = torch.empty(M, Co, dtype=torch.float32, device=dev)
+    vec_ok = int(C % 4 == 0)
+    gemm(M, Co, K, xd, Wd, y, a_tabs=(rowbase, koff), a_u8=u8, a_div=255.0, a_vec_along_k=1,
+         a_tab_vec_ok=vec_ok, bias=dev_tensor(bias, dev), activation="relu", workspace=ws)
+    ref_y = np.maximum(cols @ Wt.astype(np.float64) + bias, 0)
+    np.testing.assert_allclose(y.cpu().numpy(), ref_y, **_tol(K))
+    # weight gradient: dW[K,Co] = cols^T dY, A(k_out, m) gathered: outer tab = koff, red tab = rowbase
+    dY = rng.randn(M, Co).astype(np.float32)
+    dYd = dev_tensor(dY, dev)
+    dW = torch.empty(K, Co, dtype=torch.float32, device=dev)
+    gemm(K, Co, M, xd, dYd, dW, a_tabs=(koff, rowbase), a_u8=u8, a_div=255.0, a_vec_along_k=0,
+         a_tab_vec_ok=vec_ok, workspace=ws)
+    np.testing.assert_allclose(dW.cpu().numpy(), cols.T @ dY.astype(np.float64), rtol=3e-5,
+                               atol=4e-6 * np.sqrt(M) * 4)
+    if not u8:
+        # input gradient: dcol = dY W^T, then col2im gather with the previous layer's tanh'
+        dcol = torch.empty(M, K, dtype=torch.float32, device=dev)
+        gemm(M, K, Co, dYd, Wd, dcol, b_strides=(1, Co), workspace=ws)
+        dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+        rlx.col2im(dcol, dx, xd, 2, B, H, W, C, KH, KW, s, 0)
+        dcol_ref = (dY.astype(np.float64) @ Wt.astype(np.float64).T).reshape(B, OH, OW, KH, KW, C)
+        dx_ref = np.zeros((B, H, W, C))
+        for ky in range(KH):
+            for kx in range(KW):
+                dx_ref[:, ky:ky + s * OH:s, kx:kx + s * OW:s, :] += dcol_ref[:, :, :, ky, kx, :]
+        dx_ref *= 1 - x.astype(np.float64) ** 2
+        np.testing.assert_allclose(dx.cpu().numpy(), dx_ref, **_tol(Co * 16))
+
+
+@pytest.mark.gpu
+def test_gemm_matches_torch_fp32_reference(rlx, dev):
+    """Same op in plain PyTorch fp32 on the GPU (rocBLAS): agreement at fp32-roundoff level."""
+    import torch
+    from coach_amd._rlx import gemm
+    torch.manual_seed(0)
+    A = torch.randn(64, 3136, device=dev)
+    B = torch.randn(3136, 512, device=dev) / 56
+    C = torch.empty(64, 512, device=dev)
+    ws = torch.empty(1 << 22, dtype=torch.float32, device=dev)
+    gemm(64, 512, 3136, A, B, C, workspace=ws)
+    torch.testing.assert_close(C, A @ B, rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_gemm_batched_towers(rlx, dev):
+    """Two independent towers (Clipped-PPO value / policy copies) in one launch: shared input,
+    per-tower weights, biases and outputs addressed through batch strides."""
+    import torch
+    from coach_amd._rlx import gemm
+    rng = np.random.RandomState(4)
+    M, N, K = 64, 512, 3136
+    A = rng.randn(M, K).astype(np.float32)
+    W = (rng.randn(2, K, N) / 56).astype(np.float32)
+    b = rng.randn(2, N).astype(np.float32)
+    C = torch.empty(2, M, N, dtype=torch.float32, device=dev)
+    ws = torch.empty(1 << 22, dtype=torch.float32, device=dev)
+    gemm(M, N, K, dev_tensor(A, dev), dev_tensor(W, dev), C, bias=dev_tensor(b, dev), activation="tanh",
+         batch=2, a_batch_stride=0, b_batch_stride=K * N, c_batch_stride=M * N, bias_batch_stride=N,
+         workspace=ws)
+    for t in range(2):
+        np.testing.assert_allclose(C[t].cpu().numpy(), np.tanh(A.astype(np.float64) @ W[t] + b[t]), **_tol(K))
+
+
+@pytest.mark.gpu
+def test_gemm_rejects_bad_arguments(rlx, dev):
+    import torch
+    from coach_amd._rlx import RlxError, gemm
+    t = torch.zeros(4, 4, device=dev)
+    with pytest.raises(RlxError, match="bad shape"):
+        gemm(0, 4, 4, t, t, t)
+    with pytest.raises(RlxError, match="contiguous"):
+        gemm(4, 4, 4, t, t, t, a_strides=(8, 2))
