@@ -279,6 +279,14 @@ __global__ void colsum_final_kernel(const float *__restrict__ part, int nparts, 
     out[n] = accumulate ? out[n] + s : s;
 }
 
+// dz = dy * act'(y) in place (the activation derivative written through its output).
+__global__ void act_backward_kernel(float *__restrict__ dy, const float *__restrict__ y, long long n,
+                                    int kind) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        dy[i] *= act_deriv(y[i], kind);
+}
+
 // im2col offset tables (see header comment).
 __global__ void conv_tables_kernel(int *__restrict__ rowbase, int *__restrict__ koff, int batch,
                                    int H, int W, int C, int KH, int KW, int stride, int OH, int OW) {
@@ -445,6 +453,15 @@ int rlx_colsum(const float *x, int M, int N, long long ld, float *out, int accum
     colsum_partial_kernel<<<grid, 64, 0, s>>>(x, M, N, ld, rows_per_block, workspace);
     RLX_LAUNCH_CHECK();
     colsum_final_kernel<<<(N + 63) / 64, 64, 0, s>>>(workspace, parts, N, out, accumulate);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_act_backward(float *dy, const float *y, long long n, int kind, void *stream) {
+    RLX_REQUIRE(dy && y && n > 0, "rlx_act_backward: bad arguments");
+    RLX_REQUIRE(kind >= 0 && kind <= 2, "rlx_act_backward: unknown activation %d", kind);
+    if (kind == RLX_ACT_NONE) return RLX_OK;
+    act_backward_kernel<<<rlx::grid_for(n, 256), 256, 0, rlx::as_stream(stream)>>>(dy, y, n, kind);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -1,0 +1,217 @@
+// K9 — head losses and their gradients w.r.t. the head outputs, fused into one launch per head.
+//
+// Replaces the TensorFlow graph pieces in rl_coach/architectures/tensorflow_components/heads/:
+//   * Head.set_loss            head.py:143-186   loss_h = mean_b( loss_weight * w_b * sum_dims l(target, out) )
+//     with l = tf.losses.mean_squared_error (q_head.py, v_head.py:43-52) or tf.losses.huber_loss
+//     (delta = 1; q_head.py when replace_mse_with_huber_loss)
+//   * PPOHead._build_module    ppo_head.py:52-98 + _build_discrete_net :100-116
+//     (Categorical log-prob, likelihood ratio, clipped surrogate, entropy bonus, KL fetch)
+// plus tf.gradients of those losses down to the head's dense output (architecture.py:187-194).
+//
+// TensorFlow is not vendored in the reference tree and cannot be installed here: these formulas
+// are restated from the head sources above and pinned only by the reference's MXNet-twin
+// known-answer tests (tests/architectures/mxnet_components/heads/test_ppo_head.py:141-183,363-376)
+// -> "parity unpinned" for TF's exact op-level rounding.
+//
+// One workgroup handles the whole minibatch (B <= 1024 rows x A actions): per-sample math in
+// registers, the batch means by an LDS tree reduction, gradients written once.  Latency-bound
+// (a few KB); the point is that logits, targets and gradients never leave HBM/L2.
+#include "rlx_common.hpp"
+
+namespace {
+
+constexpr int kMaxBlock = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int d = nt >> 1; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
+        __syncthreads();
+    }
+    float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// kind 0: mean squared error (t - o)^2;  kind 1: huber, delta = 1.
+// out/target [B, D]; weights [B] or null; grad = d loss / d out.  scalars[0] = loss.
+__global__ void __launch_bounds__(kMaxBlock)
+regression_loss_kernel(const float *__restrict__ out, const float *__restrict__ target,
+                       const float *__restrict__ weights, int batch, int dim, long long ld_out,
+                       long long ld_target, int kind, float loss_weight, float grad_scale,
+                       float *__restrict__ grad, long long ld_grad, float *__restrict__ scalars) {
+    __shared__ float red[kMaxBlock];
+    float local = 0.f;
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+        const float w = loss_weight * (weights ? weights[b] : 1.f);
+        float row = 0.f;
+        for (int j = 0; j < dim; ++j) {
+            const float e = out[(size_t)b * ld_out + j] - target[(size_t)b * ld_target + j];
+            float l, g;
+            if (kind == 0) {
+                l = e * e;
+                g = 2.f * e;
+            } else {
+                const float a = fabsf(e);
+                l = a <= 1.f ? 0.5f * e * e : a - 0.5f;
+                g = fminf(fmaxf(e, -1.f), 1.f);
+            }
+            row += l;
+            if (grad) grad[(size_t)b * ld_grad + j] = grad_scale * w * g / (float)batch;
+        }
+        local += w * row;
+    }
+    const float s = block_sum(local, red);
+    if (threadIdx.x == 0 && scalars) scalars[0] = s / (float)batch;
+}
+
+// Row-wise softmax (tf.nn.softmax, ppo_head.py:108): probs = exp(z - max) / sum.
+__global__ void softmax_kernel(const float *__restrict__ logits, int batch, int n, long long ld,
+                               float *__restrict__ probs, long long ld_out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const float *z = logits + (size_t)b * ld;
+    float mx = z[0];
+    for (int j = 1; j < n; ++j) mx = fmaxf(mx, z[j]);
+    float s = 0.f;
+    for (int j = 0; j < n; ++j) s += expf(z[j] - mx);
+    for (int j = 0; j < n; ++j) probs[(size_t)b * ld_out + j] = expf(z[j] - mx) / s;
+}
+
+// Discrete Clipped-PPO head.  scalars: [0] surrogate loss, [1] mean entropy, [2] mean KL(old||new),
+// [3] total head loss = surrogate - beta * entropy.
+__global__ void __launch_bounds__(kMaxBlock)
+ppo_discrete_loss_kernel(const float *__restrict__ logits, long long ld, const int *__restrict__ actions,
+                         const float *__restrict__ advantages, const float *__restrict__ old_probs,
+                         long long ld_old, int batch, int n, float clip_eps, float beta,
+                         float grad_scale, float *__restrict__ dlogits, long long ld_grad,
+                         float *__restrict__ scalars, float *__restrict__ ratio_out,
+                         float *__restrict__ clipped_out, int *__restrict__ status) {
+    __shared__ float red[kMaxBlock];
+    float l_sur = 0.f, l_ent = 0.f, l_kl = 0.f;
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+        const float *z = logits + (size_t)b * ld;
+        const float *po = old_probs + (size_t)b * ld_old;
+        float mx = z[0];
+        for (int j = 1; j < n; ++j) mx = fmaxf(mx, z[j]);
+        float se = 0.f, so = 0.f;
+        for (int j = 0; j < n; ++j) {
+            se += expf(z[j] - mx);
+            so += po[j];
+        }
+        const float lse = mx + logf(se);          // log-sum-exp of the new logits
+        const float lso = logf(so);               // Categorical(probs=p) renormalises: log p - log sum p
+        const int a = actions[b];
+        if (a < 0 || a >= n) {
+            atomicOr(status, 1);
+            continue;
+        }
+        float ent = 0.f, kl = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float lp = z[j] - lse;
+            const float p = expf(lp);
+            const float lpo = logf(po[j]) - lso;
+            ent -= p * lp;                                            // distribution.entropy()
+            kl += (po[j] / so) * (lpo - lp);                          // kl_divergence(old, new)
+        }
+        const float logp = z[a] - lse;                                // log_prob(actions)  (:60)
+        const float logp_old = logf(po[a]) - lso;                     // (:61)
+        const float ratio = expf(logp - logp_old);                    // (:79)
+        const float lo = 1.f - clip_eps, hi = 1.f + clip_eps;         // (:83-84)
+        const float clipped = fminf(fmaxf(ratio, lo), hi);            // (:85)
+        const float adv = advantages[b];
+        const float s1 = ratio * adv, s2 = clipped * adv;
+        l_sur += fminf(s1, s2);                                       // (:86-87)
+        l_ent += ent;
+        l_kl += kl;
+        if (ratio_out) ratio_out[b] = ratio;
+        if (clipped_out) clipped_out[b] = clipped;
+        if (dlogits) {
+            // d(-mean min(s1,s2))/d logp : tf.minimum routes the gradient to s1 when s1 <= s2,
+            // otherwise to s2, whose clip passes gradient only inside [lo, hi].
+            float g_logp;
+            if (s1 <= s2)
+                g_logp = -adv * ratio;
+            else
+                g_logp = (ratio >= lo && ratio <= hi) ? -adv * ratio : 0.f;
+            g_logp /= (float)batch;
+            const float gb = beta / (float)batch;
+            for (int j = 0; j < n; ++j) {
+                const float lp = z[j] - lse;
+                const float p = expf(lp);
+                float g = g_logp * ((j == a ? 1.f : 0.f) - p);        // d logp / d z_j
+                g += gb * p * (lp + ent);                             // d(-beta*H)/d z_j
+                dlogits[(size_t)b * ld_grad + j] = grad_scale * g;
+            }
+        }
+    }
+    const float sur = block_sum(l_sur, red);
+    const float ent = block_sum(l_ent, red);
+    const float kl = block_sum(l_kl, red);
+    if (threadIdx.x == 0 && scalars) {
+        const float inv = 1.f / (float)batch;
+        scalars[0] = -sur * inv;                                      // surrogate_loss (:91)
+        scalars[1] = ent * inv;                                       // entropy (:62)
+        scalars[2] = kl * inv;                                        // kl_divergence (:66)
+        scalars[3] = -sur * inv - beta * ent * inv;                   // + entropy_regularization (:95-96)
+    }
+}
+
+inline int block_for(int batch) {
+    int t = 64;
+    while (t < batch && t < kMaxBlock) t <<= 1;
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlx_regression_loss(const float *out, long long ld_out, const float *target,
+                        long long ld_target, const float *importance_weights, int batch, int dim,
+                        int kind, float loss_weight, float grad_scale, float *grad,
+                        long long ld_grad, float *loss_scalar, void *stream) {
+    RLX_REQUIRE(out && target, "rlx_regression_loss: null pointer");
+    RLX_REQUIRE(batch > 0 && dim > 0 && ld_out >= dim && ld_target >= dim,
+                "rlx_regression_loss: bad shape (batch=%d dim=%d)", batch, dim);
+    RLX_REQUIRE(kind == 0 || kind == 1, "rlx_regression_loss: kind must be 0 (mse) or 1 (huber)");
+    RLX_REQUIRE(!grad || ld_grad >= dim, "rlx_regression_loss: bad gradient pitch");
+    regression_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
+        out, target, importance_weights, batch, dim, ld_out, ld_target, kind, loss_weight, grad_scale,
+        grad, ld_grad, loss_scalar);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_softmax(const float *logits, long long ld, int batch, int n, float *probs,
+                long long ld_out, void *stream) {
+    RLX_REQUIRE(logits && probs, "rlx_softmax: null pointer");
+    RLX_REQUIRE(batch > 0 && n > 0 && ld >= n && ld_out >= n, "rlx_softmax: bad shape");
+    softmax_kernel<<<(batch + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(logits, batch, n, ld, probs,
+                                                                       ld_out);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
+                          const float *advantages, const float *old_probs, long long ld_old,
+                          int batch, int n_actions, float clip_epsilon, float beta_entropy,
+                          float grad_scale, float *dlogits, long long ld_grad, float *scalars,
+                          float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
+                          void *stream) {
+    RLX_REQUIRE(logits && actions && advantages && old_probs && status,
+                "rlx_ppo_discrete_loss: null pointer");
+    RLX_REQUIRE(batch > 0 && n_actions > 0 && ld >= n_actions && ld_old >= n_actions,
+                "rlx_ppo_discrete_loss: bad shape");
+    RLX_REQUIRE(!dlogits || ld_grad >= n_actions, "rlx_ppo_discrete_loss: bad gradient pitch");
+    ppo_discrete_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
+        logits, ld, actions, advantages, old_probs, ld_old, batch, n_actions, clip_epsilon,
+        beta_entropy, grad_scale, dlogits, ld_grad, scalars, likelihood_ratio,
+        clipped_likelihood_ratio, status);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+// K11 — optimiser, target-network mixing and gradient-norm kernels over FLAT parameter buffers.
+//
+// Every network keeps its weights, gradients and Adam moments in one contiguous fp32 buffer each,
+// so an update is one launch (and the data-parallel gradient exchange one RCCL all-reduce).
+//
+// Replaces, in the reference (paths under rl_coach/architectures/tensorflow_components/):
+//   * tf.train.AdamOptimizer       general_network.py:390-394 (beta1/beta2/epsilon from
+//     base_parameters.py:297-299).  TensorFlow 1.x is a pip dependency absent from
+//     /root/reference (setup.py:69): the update is restated from TF 1.14's published ApplyAdam
+//     kernel (tensorflow/core/kernels/training_ops.cc):
+//         alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+//         m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2)
+//         var -= (m * alpha) / (sqrt(v) + epsilon)          ("epsilon hat" outside the sqrt)
+//     with beta^t carried as fp32 running products (beta1_power / beta2_power variables).
+//   * TensorFlowArchitecture.set_weights    architecture.py:598-607
+//         w_target = rate * w_online + (1 - rate) * w_target   (done on the HOST in the reference)
+//   * tf.global_norm of the gradients       architecture.py:194
+//   * apply_gradients' optional 1/num_workers scaling   architecture.py:485-488
+//
+// HBM-bound: Adam reads g, m, v, w and writes m, v, w = 28 B/parameter; mixing 12 B/parameter.
+// float4 accesses, grid-stride, <= 2048 workgroups.  Compiled with -ffp-contract=off so that the
+// mixing rounds like numpy's two products + add.
+#include "rlx_common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// state[0] = beta1_power, state[1] = beta2_power (fp32, device).
+__global__ void adam_tf1_kernel(float *__restrict__ w, const float *__restrict__ g,
+                                float *__restrict__ m, float *__restrict__ v, long long n,
+                                float lr, float beta1, float beta2, float eps,
+                                const float *__restrict__ state, float grad_scale) {
+    const float b1p = state[0], b2p = state[1];
+    const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 gw = reinterpret_cast<const float4 *>(g)[i];
+        float4 mw = reinterpret_cast<float4 *>(m)[i];
+        float4 vw = reinterpret_cast<float4 *>(v)[i];
+        float4 ww = reinterpret_cast<float4 *>(w)[i];
+        float *gp = &gw.x, *mp = &mw.x, *vp = &vw.x, *wp = &ww.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = gp[k] * grad_scale;
+            mp[k] += (gr - mp[k]) * omb1;
+            vp[k] += (gr * gr - vp[k]) * omb2;
+            wp[k] -= (mp[k] * alpha) / (sqrtf(vp[k]) + eps);
+        }
+        reinterpret_cast<float4 *>(m)[i] = mw;
+        reinterpret_cast<float4 *>(v)[i] = vw;
+        reinterpret_cast<float4 *>(w)[i] = ww;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gr = g[i] * grad_scale;
+        m[i] += (gr - m[i]) * omb1;
+        v[i] += (gr * gr - v[i]) * omb2;
+        w[i] -= (m[i] * alpha) / (sqrtf(v[i]) + eps);
+    }
+}
+
+__global__ void adam_advance_kernel(float *state, float beta1, float beta2) {
+    state[0] *= beta1;       // AdamOptimizer._finish: beta1_power *= beta1
+    state[1] *= beta2;
+}
+
+__global__ void mix_kernel(float *__restrict__ target, const float *__restrict__ online, long long n,
+                           float rate, float one_minus_rate) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 o = reinterpret_cast<const float4 *>(online)[i];
+        float4 t = reinterpret_cast<float4 *>(target)[i];
+        t.x = rate * o.x + one_minus_rate * t.x;
+        t.y = rate * o.y + one_minus_rate * t.y;
+        t.z = rate * o.z + one_minus_rate * t.z;
+        t.w = rate * o.w + one_minus_rate * t.w;
+        reinterpret_cast<float4 *>(target)[i] = t;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        target[i] = rate * online[i] + one_minus_rate * target[i];
+}
+
+// sum of squares, two deterministic stages: per-workgroup partials then one workgroup.
+__global__ void sumsq_partial_kernel(const float *__restrict__ x, long long n, float *__restrict__ part) {
+    __shared__ float red[kBlock];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        s += x[i] * x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = kBlock >> 1; d > 0; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void sumsq_final_kernel(const float *__restrict__ part, int nparts, float *__restrict__ out) {
+    __shared__ float red[kBlock];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = kBlock >> 1; d > 0; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sqrtf(red[0]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlx_adam_init(float *m, float *v, long long n, float *state, float beta1, float beta2,
+                  void *stream) {
+    RLX_REQUIRE(m && v && state && n > 0, "rlx_adam_init: bad arguments");
+    hipStream_t s = rlx::as_stream(stream);
+    RLX_HIP(hipMemsetAsync(m, 0, sizeof(float) * n, s));
+    RLX_HIP(hipMemsetAsync(v, 0, sizeof(float) * n, s));
+    const float init[2] = {beta1, beta2};       // beta powers start at beta^1
+    RLX_HIP(hipMemcpyAsync(state, init, sizeof(init), hipMemcpyHostToDevice, s));
+    return RLX_OK;
+}
+
+int rlx_adam_tf1(float *weights, const float *grads, float *m, float *v, long long n,
+                 float learning_rate, float beta1, float beta2, float epsilon, float *state,
+                 float grad_scale, void *stream) {
+    RLX_REQUIRE(weights && grads && m && v && state, "rlx_adam_tf1: null pointer");
+    RLX_REQUIRE(n > 0, "rlx_adam_tf1: empty parameter buffer");
+    RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                "rlx_adam_tf1: buffers must be 16-byte aligned");
+    hipStream_t s = rlx::as_stream(stream);
+    adam_tf1_kernel<<<rlx::grid_for(n / 4 + 1, kBlock), kBlock, 0, s>>>(
+        weights, grads, m, v, n, learning_rate, beta1, beta2, epsilon, state, grad_scale);
+    RLX_LAUNCH_CHECK();
+    adam_advance_kernel<<<1, 1, 0, s>>>(state, beta1, beta2);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_mix_weights(float *target, const float *online, long long n, double rate, void *stream) {
+    RLX_REQUIRE(target && online && n > 0, "rlx_mix_weights: bad arguments");
+    RLX_REQUIRE((((uintptr_t)target | (uintptr_t)online) & 15) == 0,
+                "rlx_mix_weights: buffers must be 16-byte aligned");
+    // new_rate * new_weight + (1 - new_rate) * old_weights: python floats meet fp32 arrays, so
+    // both coefficients are rounded to fp32 first (architecture.py:604-605).
+    mix_kernel<<<rlx::grid_for(n / 4 + 1, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
+        target, online, n, (float)rate, (float)(1.0 - rate));
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,
+                    long long workspace_floats, void *stream) {
+    RLX_REQUIRE(x && norm_out && workspace && n > 0, "rlx_global_norm: bad arguments");
+    int parts = rlx::grid_for(n, kBlock, 1024);
+    if (parts > workspace_floats) parts = (int)workspace_floats;
+    RLX_REQUIRE(parts >= 1, "rlx_global_norm: workspace too small");
+    hipStream_t s = rlx::as_stream(stream);
+    sumsq_partial_kernel<<<parts, kBlock, 0, s>>>(x, n, workspace);
+    RLX_LAUNCH_CHECK();
+    sumsq_final_kernel<<<1, kBlock, 0, s>>>(workspace, parts, norm_out);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+}  // extern "C"

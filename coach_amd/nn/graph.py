@@ -1,0 +1,335 @@
+"""Layer graph executed through the C ABI (librlx.so): the MI355X backend behind the reference's
+``Architecture`` plug point (rl_coach/architectures/architecture.py:26-237).
+
+Design (MI355X-first, not a translation of the TF1 graph/session code):
+  * every network keeps weights / gradients / Adam moments in ONE flat fp32 HBM buffer each
+    (16-byte aligned tensors): Adam, target mixing, gradient norm and the data-parallel RCCL
+    all-reduce are each a single launch over that buffer;
+  * identical towers (Clipped-PPO's ``use_separate_networks_per_head`` value / policy copies,
+    clipped_ppo_agent.py:50; TD3's twin critic streams) run as ONE batched GEMM launch per layer
+    (blockIdx.z = tower) instead of one launch per copy;
+  * convolutions are implicit-im2col GEMMs reading the uint8 frame stack directly;
+  * PyTorch is used only to own device memory and streams.
+
+Semantics restated from rl_coach/architectures/tensorflow_components/
+(general_network.py:228-405, layers.py:108-185, embedders/embedder.py:100-125,
+middlewares/fc_middleware.py:40-70): activation after every layer, VALID conv padding, NHWC,
+Xavier-uniform kernels, zero biases (layers.py:180-181).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _rlx
+
+ALIGN = 4  # floats (16 bytes)
+
+
+def _align(n):
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+class FlatParams:
+    """Named fp32 tensors carved out of one flat buffer; `towers` identical copies are laid out
+    tower-major so that tensor `name` of tower t sits at offset(name) + t * tower_stride."""
+
+    def __init__(self):
+        self.entries = {}       # name -> (offset, shape, towers, tower_stride)
+        self.size = 0
+        self.weights = self.grads = None
+
+    def add_group(self, specs, towers=1):
+        per_tower = sum(_align(int(np.prod(s))) for _, s in specs)
+        base, off = self.size, 0
+        for name, shape in specs:
+            if name in self.entries:
+                raise ValueError("duplicate parameter name %s" % name)
+            self.entries[name] = (base + off, tuple(shape), towers, per_tower)
+            off += _align(int(np.prod(shape)))
+        self.size += per_tower * towers
+        return per_tower
+
+    def finalize(self, device):
+        self.weights = torch.zeros(self.size, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.size, dtype=torch.float32, device=device)
+        return self
+
+    def view(self, buf, name, tower=0):
+        off, shape, towers, stride = self.entries[name]
+        n = int(np.prod(shape))
+        return buf[off + tower * stride: off + tower * stride + n].view(*shape)
+
+    def w(self, name, tower=0, buf=None):
+        return self.view(self.weights if buf is None else buf, name, tower)
+
+    def g(self, name, tower=0):
+        return self.view(self.grads, name, tower)
+
+    def stride(self, name):
+        return self.entries[name][3]
+
+    def named_arrays(self, buf=None):
+        """{name: [numpy array per tower]} — used by the parity tests to feed the oracle."""
+        out = {}
+        for name, (off, shape, towers, stride) in self.entries.items():
+            out[name] = [self.view(self.weights if buf is None else buf, name, t).cpu().numpy().copy()
+                         for t in range(towers)]
+        return out
+
+
+def xavier_uniform(rng, fan_in, fan_out, shape):
+    """tf.glorot_uniform_initializer (the variable-scope default, tensorflow_components/
+    architecture.py:100): U(-l, l), l = sqrt(6 / (fan_in + fan_out))."""
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+def normalized_columns(std):
+    """heads/head.py:27-33 — consumes the GLOBAL np.random stream exactly like the reference."""
+    def init(shape):
+        out = np.random.randn(*shape).astype(np.float32)
+        out *= std / np.sqrt(np.square(out).sum(axis=0, keepdims=True))
+        return out
+    return init
+
+
+class Workspace:
+    def __init__(self, device, floats=1 << 24):
+        self.splitk = torch.empty(floats, dtype=torch.float32, device=device)
+        self.small = torch.empty(1 << 18, dtype=torch.float32, device=device)
+
+
+class Context:
+    """Scratch owned by one network: cached activation / gradient buffers, conv offset tables."""
+
+    def __init__(self, device, ws=None):
+        self.device = device
+        self.lib = _rlx.lib()
+        self.ws = ws or Workspace(device)
+        self.cache = {}
+        self.buffers = {}
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def buffer(self, name, shape, dtype=torch.float32, tag=""):
+        key = (name, tuple(shape), dtype, tag)
+        buf = self.buffers.get(key)
+        if buf is None:
+            buf = torch.empty(shape, dtype=dtype, device=self.device)
+            self.buffers[key] = buf
+        return buf
+
+
+class Tensor:
+    """An activation `data` [towers, rows, cols]; towers == 0 marks an input shared by all towers.
+    For NHWC images `rows` counts samples and cols = H*W*C."""
+
+    def __init__(self, data, rows, cols, towers, u8=False, div=1.0, grad_key=None):
+        self.data, self.rows, self.cols, self.towers = data, rows, cols, towers
+        self.u8, self.div = u8, div
+        self.grad = None
+        self.grad_key = grad_key            # (ctx, name, tag): gradient lives in a cached buffer
+
+    def tower_stride(self):
+        return 0 if self.towers == 0 else self.rows * self.cols
+
+    def ensure_grad(self):
+        if self.grad is None:
+            if self.grad_key is not None:
+                ctx, name, tag = self.grad_key
+                self.grad = ctx.buffer(name + ":grad", tuple(self.data.shape), tag=tag)
+            else:
+                self.grad = torch.empty(self.data.shape, dtype=torch.float32, device=self.data.device)
+        return self.grad
+
+    def tower(self, t):
+        """One tower as a single-tower tensor; data and gradient alias this tensor's memory."""
+        g = self.ensure_grad()
+        v = Tensor(self.data[t:t + 1], self.rows, self.cols, 1)
+        v.grad = g[t:t + 1]
+        return v
+
+
+def input_tensor(data, rows, cols, u8=False, div=1.0):
+    return Tensor(data, rows, cols, 0, u8=u8, div=div)
+
+
+class Layer:
+    def _range(self, t0, nt):
+        nt = self.T - t0 if nt is None else nt
+        assert 0 <= t0 and t0 + nt <= self.T
+        return t0, nt
+
+
+class Dense(Layer):
+    """y = act(x W + b), tf.layers.dense (layers.py:168-185).  `towers` copies in one launch."""
+
+    def __init__(self, params, name, in_features, units, activation=None, towers=1, init=None):
+        self.name, self.K, self.N, self.act, self.T = name, in_features, units, activation, towers
+        self.init, self.params = init, params
+        self.kname, self.bname = name + "/kernel", name + "/bias"
+        params.add_group([(self.kname, (in_features, units)), (self.bname, (units,))], towers)
+
+    def initialize(self, rng):
+        for t in range(self.T):
+            w = self.init((self.K, self.N)) if self.init is not None else \
+                xavier_uniform(rng, self.K, self.N, (self.K, self.N))
+            self.params.w(self.kname, t).copy_(torch.from_numpy(np.ascontiguousarray(w)))
+
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None):
+        t0, T = self._range(t0, nt)
+        M = x.rows
+        assert x.cols == self.K, (self.name, x.cols, self.K)
+        assert x.towers in (0, T), (self.name, x.towers, T)
+        y = ctx.buffer(self.name, (T, M, self.N), tag=tag)
+        p = self.params
+        _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
+                  bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
+                  a_batch_stride=x.tower_stride(), b_batch_stride=p.stride(self.kname),
+                  c_batch_stride=M * self.N, bias_batch_stride=p.stride(self.bname),
+                  workspace=ctx.ws.splitk)
+        return Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag))
+
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None):
+        """y.grad holds dL/dy (post-activation); writes dW, db and (optionally) x.grad."""
+        t0, T = self._range(t0, nt)
+        M, p = x.rows, self.params
+        dz = y.grad
+        if self.act is not None:                      # dz = dy * act'(y), in place
+            ctx.lib.act_backward(dz, y.data, dz.numel(), _rlx.ACT[self.act], ctx.stream)
+        # dW[K,N] = x^T dz : A(k, m) = x[m, k]
+        _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
+                  a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
+                  c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk)
+        for t in range(T):
+            ctx.lib.colsum(dz[t], M, self.N, self.N, p.g(self.bname, t0 + t), 0, ctx.ws.small,
+                           ctx.ws.small.numel(), ctx.stream)
+        if need_dx:
+            assert x.towers == T, "input gradients need a per-tower input"
+            dx = x.ensure_grad()
+            # dx[M,K] = dz W^T : B(n, k) = W[k, n]
+            _rlx.gemm(M, self.K, self.N, dz, p.w(self.kname, t0, weights), dx, b_strides=(1, self.N),
+                      batch=T, a_batch_stride=M * self.N, b_batch_stride=p.stride(self.kname),
+                      c_batch_stride=M * self.K, workspace=ctx.ws.splitk)
+
+
+class Conv2d(Layer):
+    """tf.layers.conv2d, VALID, NHWC (layers.py:108-121) as an implicit-im2col GEMM."""
+
+    def __init__(self, params, name, in_hwc, filters, kernel, stride, activation=None, towers=1):
+        self.name, self.T, self.act, self.params = name, towers, activation, params
+        self.H, self.W, self.C = in_hwc
+        self.KH = self.KW = kernel
+        self.S, self.Co = stride, filters
+        self.OH = (self.H - kernel) // stride + 1
+        self.OW = (self.W - kernel) // stride + 1
+        self.K = kernel * kernel * self.C
+        self.kname, self.bname = name + "/kernel", name + "/bias"
+        params.add_group([(self.kname, (self.K, filters)), (self.bname, (filters,))], towers)
+
+    @property
+    def out_hwc(self):
+        return (self.OH, self.OW, self.Co)
+
+    def initialize(self, rng):
+        fan_in, fan_out = self.K, self.KH * self.KW * self.Co
+        for t in range(self.T):
+            w = xavier_uniform(rng, fan_in, fan_out, (self.K, self.Co))
+            self.params.w(self.kname, t).copy_(torch.from_numpy(w))
+
+    def _tables(self, ctx, B):
+        key = ("convtab", self.name, B)
+        if key not in ctx.cache:
+            rb = torch.empty(B * self.OH * self.OW, dtype=torch.int32, device=ctx.device)
+            ko = torch.empty(self.K, dtype=torch.int32, device=ctx.device)
+            ctx.lib.conv_tables(rb, ko, B, self.H, self.W, self.C, self.KH, self.KW, self.S, ctx.stream)
+            ctx.cache[key] = (rb, ko)
+        return ctx.cache[key]
+
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None):
+        t0, T = self._range(t0, nt)
+        B, p = x.rows, self.params
+        assert x.cols == self.H * self.W * self.C, (self.name, x.cols)
+        assert x.towers in (0, T)
+        M = B * self.OH * self.OW
+        rb, ko = self._tables(ctx, B)
+        y = ctx.buffer(self.name, (T, M, self.Co), tag=tag)
+        _rlx.gemm(M, self.Co, self.K, x.data, p.w(self.kname, t0, weights), y, a_tabs=(rb, ko),
+                  a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=int(self.C % 4 == 0),
+                  bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
+                  a_batch_stride=x.tower_stride(), b_batch_stride=p.stride(self.kname),
+                  c_batch_stride=M * self.Co, bias_batch_stride=p.stride(self.bname),
+                  workspace=ctx.ws.splitk)
+        # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
+        return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag))
+
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None):
+        t0, T = self._range(t0, nt)
+        B, p = x.rows, self.params
+        M = B * self.OH * self.OW
+        rb, ko = self._tables(ctx, B)
+        dz = y.grad
+        if self.act is not None:
+            ctx.lib.act_backward(dz, y.data, dz.numel(), _rlx.ACT[self.act], ctx.stream)
+        dz = dz.view(T, M, self.Co)
+        # dW[K,Co] = cols^T dz : A(k, m) gathered with outer table = koff, reduction table = rowbase
+        _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
+                  a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
+                  a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
+                  c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk)
+        for t in range(T):
+            ctx.lib.colsum(dz[t], M, self.Co, self.Co, p.g(self.bname, t0 + t), 0, ctx.ws.small,
+                           ctx.ws.small.numel(), ctx.stream)
+        if need_dx:
+            assert x.towers == T
+            dcol = ctx.buffer(self.name + "/dcol", (T, M, self.K))
+            _rlx.gemm(M, self.K, self.Co, dz, p.w(self.kname, t0, weights), dcol, b_strides=(1, self.Co),
+                      batch=T, a_batch_stride=M * self.Co, b_batch_stride=p.stride(self.kname),
+                      c_batch_stride=M * self.K, workspace=ctx.ws.splitk)
+            dx = x.ensure_grad()
+            # (the producer's activation derivative is applied by ITS backward)
+            ctx.lib.col2im(dcol, dx, None, 0, T * B, self.H, self.W, self.C, self.KH, self.KW, self.S,
+                           ctx.stream)
+
+
+class Sequential:
+    """A chain of Dense / Conv2d layers replicated over `towers` identical copies."""
+
+    def __init__(self, layers):
+        self.layers = layers
+
+    def initialize(self, rng):
+        for l in self.layers:
+            l.initialize(rng)
+
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None):
+        acts = [x]
+        for l in self.layers:
+            acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt))
+        return acts
+
+    def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None):
+        for i in reversed(range(len(self.layers))):
+            self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),
+                                    weights=weights, t0=t0, nt=nt)
+
+
+class AdamState:
+    """tf.train.AdamOptimizer slots for one flat parameter buffer (general_network.py:390-394)."""
+
+    def __init__(self, params, lr, beta1=0.9, beta2=0.99, epsilon=1e-4):
+        dev = params.weights.device
+        self.params, self.lr, self.beta1, self.beta2, self.eps = params, lr, beta1, beta2, epsilon
+        self.m = torch.empty_like(params.weights)
+        self.v = torch.empty_like(params.weights)
+        self.state = torch.empty(2, dtype=torch.float32, device=dev)
+        _rlx.lib().adam_init(self.m, self.v, params.size, self.state, beta1, beta2, _rlx.current_stream())
+
+    def step(self, grad_scale=1.0, lr=None):
+        p = self.params
+        _rlx.lib().adam_tf1(p.weights, p.grads, self.m, self.v, p.size, self.lr if lr is None else lr,
+                            self.beta1, self.beta2, self.eps, self.state, grad_scale,
+                            _rlx.current_stream())

@@ -1,0 +1,191 @@
+"""Device-resident networks of the hot-path agents, assembled from nn.graph layers.
+
+Topologies follow rl_coach/architectures/tensorflow_components:
+  embedders/image_embedder.py:57-63   Medium = conv 32x8x8/4, 64x4x4/2, 64x3x3/1
+  embedders/vector_embedder.py:51-60  Medium = Dense 256, Shallow = Dense 128
+  middlewares/fc_middleware.py:40-52  Medium = Dense 512, Shallow = Dense 64
+  heads/q_head.py, v_head.py:43-48 (normalized-columns init, std 1.0), ppo_head.py:100-116
+and the per-agent network parameters (agents/dqn_agent.py:43-56, clipped_ppo_agent.py:41-58).
+"""
+import numpy as np
+import torch
+
+from .. import _rlx
+from . import graph as G
+
+IMAGE_EMBEDDER = {"Medium": [(32, 8, 4), (64, 4, 2), (64, 3, 1)], "Shallow": [(32, 3, 1)]}
+VECTOR_EMBEDDER = {"Medium": [256], "Shallow": [128], "Empty": []}
+FC_MIDDLEWARE = {"Medium": [512], "Shallow": [64], "Empty": []}
+
+
+def build_torso(params, prefix, obs_shape, activation, towers, embedder="Medium", middleware="Medium"):
+    """input embedder + FC middleware.  obs_shape (H, W, C) -> image embedder on uint8 frames
+    (input / 255, embedder_parameters.py:33-36), (D,) -> vector embedder."""
+    layers = []
+    if len(obs_shape) == 3:
+        hwc = tuple(obs_shape)
+        convs = IMAGE_EMBEDDER[embedder] if isinstance(embedder, str) else embedder
+        for i, (f, k, s) in enumerate(convs):
+            c = G.Conv2d(params, "%s/embedder/conv%d" % (prefix, i), hwc, f, k, s, activation, towers)
+            layers.append(c)
+            hwc = c.out_hwc
+        feat = hwc[0] * hwc[1] * hwc[2]
+    else:
+        feat = int(obs_shape[0])
+        dense = VECTOR_EMBEDDER[embedder] if isinstance(embedder, str) else embedder
+        for i, u in enumerate(dense):
+            layers.append(G.Dense(params, "%s/embedder/dense%d" % (prefix, i), feat, u, activation, towers))
+            feat = u
+    mids = FC_MIDDLEWARE[middleware] if isinstance(middleware, str) else middleware
+    for i, u in enumerate(mids):
+        layers.append(G.Dense(params, "%s/middleware/dense%d" % (prefix, i), feat, u, activation, towers))
+        feat = u
+    return G.Sequential(layers), feat
+
+
+class _NetBase:
+    def _finish(self, device, seed, lr, beta1, beta2, eps, has_target=True):
+        self.device = device
+        self.params.finalize(device)
+        rng = np.random.RandomState(seed)
+        for m in self.modules:
+            m.initialize(rng)
+        self.ctx = G.Context(device)
+        self.lib = self.ctx.lib
+        self.adam = G.AdamState(self.params, lr, beta1, beta2, eps)
+        self.target = self.params.weights.clone() if has_target else None
+        self.norm = torch.zeros(1, dtype=torch.float32, device=device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def obs_tensor(self, obs, B):
+        if self.image:
+            return G.input_tensor(obs, B, int(np.prod(self.obs_shape)), u8=True, div=255.0)
+        return G.input_tensor(obs, B, int(self.obs_shape[0]))
+
+    def update_target(self, rate=1.0):
+        """NetworkWrapper.update_target_network (network_wrapper.py:109-116): w_t <- rate*w_o + (1-rate)*w_t."""
+        self.lib.mix_weights(self.target, self.params.weights, self.params.size, float(rate), self.ctx.stream)
+
+    def grad_norm(self):
+        self.lib.global_norm(self.params.grads, self.params.size, self.norm, self.ctx.ws.small,
+                             self.ctx.ws.small.numel(), self.ctx.stream)
+        return self.norm
+
+    def apply_gradients(self, grad_scale=1.0):
+        self.adam.step(grad_scale)
+
+    def check_status(self):
+        s = int(self.status.item())
+        if s:
+            self.status.zero_()
+            raise ValueError("device kernel reported invalid input (status bits %d)" % s)
+
+
+class ClippedPPONet(_NetBase):
+    """ClippedPPONetworkParameters (agents/clipped_ppo_agent.py:41-58): two full copies of
+    embedder + middleware (use_separate_networks_per_head), head 0 = VHead, head 1 = PPOHead
+    (discrete).  tower 0 = value, tower 1 = policy."""
+
+    def __init__(self, device, obs_shape, n_actions, activation="tanh", embedder="Medium",
+                 middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
+                 optimizer_epsilon=1e-4, clip_likelihood_ratio_using_epsilon=0.2, beta_entropy=0.01,
+                 seed=0):
+        self.obs_shape, self.image, self.A = tuple(obs_shape), len(obs_shape) == 3, n_actions
+        self.clip_eps, self.beta = clip_likelihood_ratio_using_epsilon, beta_entropy
+        self.params = G.FlatParams()
+        self.torso, feat = build_torso(self.params, "main", obs_shape, activation, 2, embedder, middleware)
+        self.v_head = G.Dense(self.params, "main/v_head/dense", feat, 1, None, 1,
+                              init=G.normalized_columns(1.0))                   # v_head.py:43-48
+        self.pi_head = G.Dense(self.params, "main/ppo_head/policy_fc", feat, n_actions, None, 1)
+        self.modules = [self.torso, self.v_head, self.pi_head]
+        self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
+        self.scalars = torch.zeros(8, dtype=torch.float32, device=device)
+
+    # ---- inference -------------------------------------------------------------------------
+    def policy_probs(self, obs, B, use_target=False, tag="act", out=None):
+        """softmax(policy_fc(policy tower(obs)))  — target weights = the frozen 'old policy'."""
+        w = self.target if use_target else None
+        acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w, t0=1, nt=1)
+        logits = self.pi_head.forward(self.ctx, acts[-1], tag=tag, weights=w)
+        probs = out if out is not None else self.ctx.buffer("probs", (B, self.A), tag=tag)
+        self.lib.softmax(logits.data, self.A, B, self.A, probs, self.A, self.ctx.stream)
+        return probs
+
+    def values(self, obs, B, tag="val", out=None):
+        """V(s) from the value tower of the online network (fill_advantages :161-170)."""
+        acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, t0=0, nt=1)
+        v = self.v_head.forward(self.ctx, acts[-1], tag=tag)
+        if out is not None:
+            out.copy_(v.data.view(-1))
+            return out
+        return v.data.view(-1)
+
+    # ---- one minibatch of ClippedPPOAgent.train_network (:226-266) ---------------------------
+    def train_minibatch(self, obs, B, actions, advantages, value_targets, old_probs,
+                        clip_rescaler=1.0, grad_scale=1.0, ratio_out=None, clipped_out=None):
+        ctx = self.ctx
+        acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
+        mid = acts[-1]
+        mid.ensure_grad()
+        xv, xp = mid.tower(0), mid.tower(1)
+        v = self.v_head.forward(ctx, xv, tag="train")
+        logits = self.pi_head.forward(ctx, xp, tag="train")
+        dv, dlogits = v.ensure_grad(), logits.ensure_grad()
+        # head 0: VHead, MSE(target, V), loss weight 1 (head.py:172-181)
+        self.lib.regression_loss(v.data, 1, value_targets, 1, None, B, 1, 0, 1.0, 1.0, dv, 1,
+                                 self.scalars[4:5], ctx.stream)
+        # head 1: PPOHead clipped surrogate (+ entropy bonus)
+        self.lib.ppo_discrete_loss(logits.data, self.A, actions, advantages, old_probs, self.A, B,
+                                   self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
+                                   self.A, self.scalars[0:4], ratio_out, clipped_out, self.status,
+                                   ctx.stream)
+        self.v_head.backward(ctx, xv, v)
+        self.pi_head.backward(ctx, xp, logits)
+        self.torso.backward(ctx, acts)
+        self.grad_norm()
+        self.apply_gradients(grad_scale)
+        # scalars: [surrogate, entropy, kl, policy head total, value loss]
+        return self.scalars
+
+
+class DQNNet(_NetBase):
+    """DQNNetworkParameters (agents/dqn_agent.py:43-56): embedder -> FC middleware -> QHead;
+    MSE or Huber loss, importance weights from prioritized replay."""
+
+    def __init__(self, device, obs_shape, n_actions, activation="relu", embedder="Medium",
+                 middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
+                 optimizer_epsilon=1e-4, replace_mse_with_huber_loss=True, seed=0):
+        self.obs_shape, self.image, self.A = tuple(obs_shape), len(obs_shape) == 3, n_actions
+        self.huber = replace_mse_with_huber_loss
+        self.params = G.FlatParams()
+        self.torso, feat = build_torso(self.params, "main", obs_shape, activation, 1, embedder, middleware)
+        self.q_head = G.Dense(self.params, "main/q_head/dense", feat, n_actions, None, 1)
+        self.modules = [self.torso, self.q_head]
+        self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def q_values(self, obs, B, use_target=False, tag="q"):
+        w = self.target if use_target else None
+        acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w)
+        return self.q_head.forward(self.ctx, acts[-1], tag=tag, weights=w)
+
+    def learn_from_batch(self, obs, next_obs, B, actions, rewards, game_overs, discount,
+                         importance_weights=None, td_errors=None, double_dqn=False, grad_scale=1.0):
+        """DQNAgent.learn_from_batch (agents/dqn_agent.py:81-113), all on device."""
+        ctx = self.ctx
+        q_next = self.q_values(next_obs, B, use_target=True, tag="next_t").data.view(B, self.A)
+        sel = self.q_values(next_obs, B, tag="next_o").data.view(B, self.A) if double_dqn else None
+        acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
+        q = self.q_head.forward(ctx, acts[-1], tag="train")
+        targets = ctx.buffer("td_targets", (B, self.A))
+        targets.copy_(q.data.view(B, self.A))
+        self.lib.dqn_targets(q_next, sel, targets, actions, rewards, game_overs, float(discount), B,
+                             self.A, td_errors, self.status, ctx.stream)
+        dq = q.ensure_grad()
+        self.lib.regression_loss(q.data, self.A, targets, self.A, importance_weights, B, self.A,
+                                 1 if self.huber else 0, 1.0, 1.0, dq, self.A, self.loss, ctx.stream)
+        self.q_head.backward(ctx, acts[-1], q)
+        self.torso.backward(ctx, acts)
+        self.grad_norm()
+        self.apply_gradients(grad_scale)
+        return self.loss

@@ -199,10 +199,64 @@ int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
 int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host);
 int rlx_colsum(const float *x, int M, int N, long long ld, float *out, int accumulate,
                float *workspace, long long workspace_floats, void *stream);  /* bias gradients */
+int rlx_act_backward(float *dy, const float *y, long long n, int kind, void *stream); /* dy *= act'(y) */
 int rlx_conv_tables(int *rowbase, int *koff, int batch, int H, int W, int C, int KH, int KW,
                     int stride, void *stream);      /* VALID-padding NHWC im2col offsets */
 int rlx_col2im(const float *dcol, float *dx, const float *x_out, int deriv_kind, int batch, int H,
                int W, int C, int KH, int KW, int stride, void *stream); /* conv input gradient */
+
+/* -------------------------------------------------------- head losses (K9) -- */
+/* loss = mean_b(loss_weight * w_b * sum_j l(target, out)); kind 0 = MSE, 1 = Huber(delta 1).
+ * grad (optional) = grad_scale * d loss / d out.  heads/head.py:143-186, q_head.py, v_head.py:43-52 */
+int rlx_regression_loss(const float *out, long long ld_out, const float *target,
+                        long long ld_target, const float *importance_weights, int batch, int dim,
+                        int kind, float loss_weight, float grad_scale, float *grad,
+                        long long ld_grad, float *loss_scalar, void *stream);
+int rlx_softmax(const float *logits, long long ld, int batch, int n, float *probs,
+                long long ld_out, void *stream);                    /* heads/ppo_head.py:108 */
+/* scalars[4] = {surrogate loss, mean entropy, mean KL(old||new), total head loss}.
+ * clip_epsilon = clip_likelihood_ratio_using_epsilon * clip_param_rescaler.  heads/ppo_head.py:52-116 */
+int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
+                          const float *advantages, const float *old_probs, long long ld_old,
+                          int batch, int n_actions, float clip_epsilon, float beta_entropy,
+                          float grad_scale, float *dlogits, long long ld_grad, float *scalars,
+                          float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
+                          void *stream);
+
+/* ------------------------------------------ optimiser / target mixing (K11) -- */
+/* state = {beta1_power, beta2_power} (2 device floats).  tf.train.AdamOptimizer as built in
+ * architectures/tensorflow_components/general_network.py:390-394. */
+int rlx_adam_init(float *m, float *v, long long n, float *state, float beta1, float beta2,
+                  void *stream);
+int rlx_adam_tf1(float *weights, const float *grads, float *m, float *v, long long n,
+                 float learning_rate, float beta1, float beta2, float epsilon, float *state,
+                 float grad_scale, void *stream);
+int rlx_mix_weights(float *target, const float *online, long long n, double rate,
+                    void *stream);   /* architectures/tensorflow_components/architecture.py:598-607 */
+int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,
+                    long long workspace_floats, void *stream);      /* tf.global_norm, architecture.py:194 */
+
+/* -------------------------------------------------------- exploration policies -- */
+int rlx_categorical_sample(const float *probs, long long ld, const double *uniforms, int n_env,
+                           int n_actions, int *actions, void *stream); /* exploration_policies/categorical.py:45-48 */
+int rlx_egreedy(const float *q_values, long long ld, const double *explore_uniforms,
+                const int *random_actions, const double *tie_break_uniforms, double epsilon,
+                int n_env, int n_actions, int *actions, void *stream); /* exploration_policies/e_greedy.py:84-101 */
+int rlx_gaussian_action(const float *mean, const float *std_per_dim, const float *std_per_sample,
+                        const double *standard_normals, const float *action_low,
+                        const float *action_high, int n_env, int action_dim, float *actions,
+                        void *stream);                              /* exploration_policies/additive_noise.py:75-111 */
+
+/* ------------------------------------------------ synthetic vector environment -- */
+/* Device-resident stand-in for Environment.step (environments/environment.py:276-327) on the
+ * BASELINE workloads: fixed-length episodes, Philox4x32-10 observations/rewards keyed by
+ * (seed, env id) and counted by (episode, step).  kind 0 = uint8 image frames, 1 = fp32 vectors.
+ * episode/step: int32[n_env] state.  reset_obs[e] is written only where game_over[e] is set. */
+int rlx_synth_env_reset(int kind, void *obs, int *episode, int *step, int n_env, int obs_elems,
+                        unsigned int seed, unsigned int env_id0, void *stream);
+int rlx_synth_env_step(int kind, void *next_obs, void *reset_obs, float *reward,
+                       unsigned char *game_over, int *episode, int *step, int n_env, int obs_elems,
+                       int episode_len, unsigned int seed, unsigned int env_id0, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,154 @@
+"""Network arithmetic — numpy fp32 restatement of the TensorFlow backend's layers.
+
+PARITY UNPINNED for TF's op-level rounding (TensorFlow 1.x is not in /root/reference and cannot be
+installed).  Topology / semantics follow rl_coach/architectures/tensorflow_components/:
+layers.py:108-121 (conv2d VALID NHWC), :168-185 (dense), embedders/embedder.py:107-121 (input /
+255, activation after every layer, flatten), general_network.py:228-405.  Cross-checked in
+tests/test_nn.py against torch.nn.functional on CPU (an independent implementation).
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def act(x, kind):
+    if kind == "relu":
+        return np.maximum(x, F32(0))
+    if kind == "tanh":
+        return np.tanh(x)
+    return x
+
+
+def act_grad(y, kind):
+    if kind == "relu":
+        return (y > 0).astype(F32)
+    if kind == "tanh":
+        return F32(1) - y * y
+    return np.ones_like(y)
+
+
+def im2col(x, k, s):
+    B, H, W, C = x.shape
+    OH, OW = (H - k) // s + 1, (W - k) // s + 1
+    cols = np.empty((B, OH, OW, k, k, C), dtype=x.dtype)
+    for ky in range(k):
+        for kx in range(k):
+            cols[:, :, :, ky, kx, :] = x[:, ky:ky + s * OH:s, kx:kx + s * OW:s, :]
+    return cols.reshape(B * OH * OW, k * k * C), OH, OW
+
+
+def col2im(dcols, shape, k, s):
+    B, H, W, C = shape
+    OH, OW = (H - k) // s + 1, (W - k) // s + 1
+    d = dcols.reshape(B, OH, OW, k, k, C)
+    dx = np.zeros(shape, dtype=dcols.dtype)
+    for ky in range(k):
+        for kx in range(k):
+            dx[:, ky:ky + s * OH:s, kx:kx + s * OW:s, :] += d[:, :, :, ky, kx, :]
+    return dx
+
+
+class Dense:
+    def __init__(self, W, b, activation=None):
+        self.W, self.b, self.act = W.astype(F32), b.astype(F32), activation
+
+    def forward(self, x):
+        self.x = x
+        self.y = act(x @ self.W + self.b, self.act)
+        return self.y
+
+    def backward(self, dy):
+        dz = dy * act_grad(self.y, self.act)
+        self.dW = self.x.T @ dz
+        self.db = dz.sum(0)
+        return dz @ self.W.T
+
+
+class Conv:
+    def __init__(self, W, b, hwc, kernel, stride, activation=None):
+        self.W, self.b, self.act = W.astype(F32), b.astype(F32), activation
+        self.hwc, self.k, self.s = hwc, kernel, stride
+
+    def forward(self, x):                       # x: [B, H*W*C] flat or [B,H,W,C]
+        B = x.shape[0]
+        x = x.reshape((B,) + tuple(self.hwc))
+        self.xshape = x.shape
+        self.cols, OH, OW = im2col(x, self.k, self.s)
+        self.y = act(self.cols @ self.W + self.b, self.act)
+        self.out_shape = (B, OH * OW * self.W.shape[1])
+        return self.y.reshape(self.out_shape)    # flatten (h, w, c)
+
+    def backward(self, dy):
+        dz = dy.reshape(self.y.shape) * act_grad(self.y, self.act)
+        self.dW = self.cols.T @ dz
+        self.db = dz.sum(0)
+        return col2im(dz @ self.W.T, self.xshape, self.k, self.s).reshape(self.xshape[0], -1)
+
+
+class Chain:
+    def __init__(self, layers):
+        self.layers = layers
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l.forward(x)
+        return x
+
+    def backward(self, dy):
+        for l in reversed(self.layers):
+            dy = l.backward(dy)
+        return dy
+
+
+def build_chain(arrays, prefix, tower, obs_shape, activation, image_convs=((32, 8, 4), (64, 4, 2), (64, 3, 1))):
+    """Rebuild one tower of nn.networks.build_torso from {name: [array per tower]}."""
+    layers = []
+    i = 0
+    hwc = tuple(obs_shape) if len(obs_shape) == 3 else None
+    while "%s/embedder/conv%d/kernel" % (prefix, i) in arrays:
+        f, k, s = image_convs[i]
+        n = "%s/embedder/conv%d" % (prefix, i)
+        layers.append(Conv(arrays[n + "/kernel"][tower], arrays[n + "/bias"][tower], hwc, k, s, activation))
+        hwc = ((hwc[0] - k) // s + 1, (hwc[1] - k) // s + 1, f)
+        i += 1
+    for part in ("embedder", "middleware"):
+        i = 0
+        while "%s/%s/dense%d/kernel" % (prefix, part, i) in arrays:
+            n = "%s/%s/dense%d" % (prefix, part, i)
+            layers.append(Dense(arrays[n + "/kernel"][tower], arrays[n + "/bias"][tower], activation))
+            i += 1
+    return Chain(layers)
+
+
+def prep_obs(obs, image):
+    """ObservationEmbedder input rescaling: images / 255 (embedder.py:107-108)."""
+    obs = np.asarray(obs)
+    if image:
+        return (obs.astype(F32) / F32(255.0)).reshape(obs.shape[0], -1)
+    return obs.astype(F32).reshape(obs.shape[0], -1)
+
+
+def softmax(z):
+    z = z - z.max(-1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(-1, keepdims=True)
+
+
+class PerTensorAdam:
+    """tf.train.AdamOptimizer applied tensor by tensor (elementwise, so identical to one flat pass)."""
+
+    def __init__(self, lr, beta1=0.9, beta2=0.99, eps=1e-4):
+        from .optim import AdamTF1
+        self._mk = lambda n: AdamTF1(n, lr, beta1, beta2, eps)
+        self.slots = {}
+
+    def step(self, key, w, g, grad_scale=1.0):
+        if key not in self.slots:
+            self.slots[key] = self._mk(w.size)
+        flat = w.reshape(-1)
+        self.slots[key].step(flat, g.reshape(-1), grad_scale)
+        return w
+
+
+def layer_params(chain):
+    return [(l, "kernel", "bias") for l in chain.layers]
