@@ -1,0 +1,300 @@
+"""Clipped PPO on one MI355X: vectorised rollout + GAE + clipped-surrogate updates, all in HBM.
+
+Host-side mirror of rl_coach/agents/clipped_ppo_agent.py (parameter classes :41-131 keep the
+reference's names, fields and defaults; ClippedPPOAgent keeps train / fill_advantages /
+train_network / post_training_commands / choose_action) driving librlx kernels instead of
+numpy + TF sessions.  What changes, and why it is still the same algorithm:
+
+  * N envs step in lockstep (the reference has one env per process, level_manager.py:215-269);
+    the training set is the concatenation of the N completed episodes, exactly what
+    EpisodicExperienceReplay.transitions holds after N episodes.
+  * the old-policy forward pass (target network) is evaluated once per training phase instead of
+    once per minibatch (the reference's own TODO, clipped_ppo_agent.py:236-241): the target weights
+    are frozen during train_network, so the values are identical.
+  * host RNG draws (np.random for action sampling, random.shuffle for minibatch order) are made by
+    the same generators in the same order as the reference and shipped to the device.
+"""
+import random
+
+import numpy as np
+import torch
+
+from .. import _rlx
+from ..core_types import EnvironmentSteps, RunPhase
+from ..memories.episodic_rollout_buffer import DeviceEpisodicRolloutBuffer
+from ..nn.networks import ClippedPPONet
+from ..schedules import ConstantSchedule
+
+
+class ClippedPPONetworkParameters(object):               # clipped_ppo_agent.py:41-58
+    def __init__(self):
+        self.activation_function = 'tanh'
+        self.embedder_scheme = 'Medium'
+        self.middleware_scheme = 'Medium'
+        self.batch_size = 64
+        self.optimizer_type = 'Adam'
+        self.learning_rate = 0.00025                     # base_parameters.py NetworkParameters default
+        self.adam_optimizer_beta1 = 0.9
+        self.adam_optimizer_beta2 = 0.99
+        self.optimizer_epsilon = 0.0001
+        self.clip_gradients = None
+        self.use_separate_networks_per_head = True
+        self.async_training = False
+        self.l2_regularization = 0
+        self.create_target_network = True
+        self.shared_optimizer = True
+        self.scale_down_gradients_by_number_of_workers_for_sync_training = True
+
+
+class ClippedPPOAlgorithmParameters(object):             # clipped_ppo_agent.py:61-118
+    def __init__(self):
+        self.discount = 0.99
+        self.num_episodes_in_experience_replay = 1000000
+        self.gae_lambda = 0.95
+        self.use_kl_regularization = False
+        self.clip_likelihood_ratio_using_epsilon = 0.2
+        self.estimate_state_value_using_gae = True
+        self.beta_entropy = 0.01
+        self.num_consecutive_playing_steps = EnvironmentSteps(2048)
+        self.num_consecutive_training_steps = 1
+        self.optimization_epochs = 10
+        self.clipping_decay_schedule = ConstantSchedule(1)
+        self.act_for_full_episodes = True
+        self.reward_clipping = (-1.0, 1.0)               # Atari input filter (gym_environment.py:106-113)
+        self.reward_rescale = 1.0
+
+
+class ClippedPPOAgentParameters(object):                 # clipped_ppo_agent.py:121-131
+    def __init__(self):
+        self.algorithm = ClippedPPOAlgorithmParameters()
+        self.network_wrappers = {"main": ClippedPPONetworkParameters()}
+        self.seed = 0
+
+    @property
+    def path(self):
+        return 'coach_amd.agents.clipped_ppo_agent:ClippedPPOAgent'
+
+
+class ClippedPPOAgent(object):
+    def __init__(self, agent_parameters, environment, device=None, dist=None):
+        self.ap = agent_parameters
+        self.env = environment
+        self.device = device or environment.device
+        self.dist = dist                                  # coach_amd.distributed.GradientSync or None
+        self.lib = _rlx.lib()
+        alg, net = self.ap.algorithm, self.ap.network_wrappers["main"]
+        ep = environment.p
+        self.n_env, self.A = ep.num_envs, ep.num_actions
+        self.image = ep.kind == "image"
+        self.stack = 4
+        self.L = ep.episode_length
+        obs_shape = tuple(ep.observation_shape) + (self.stack,) if self.image else tuple(ep.observation_shape)
+        # seeds: host generators exactly like Agent.__init__ (agents/agent.py:49-55)
+        if self.ap.seed is not None:
+            random.seed(self.ap.seed)
+            np.random.seed(self.ap.seed)
+        self.networks = {"main": ClippedPPONet(
+            self.device, obs_shape, self.A, activation=net.activation_function,
+            embedder=net.embedder_scheme, middleware=net.middleware_scheme,
+            learning_rate=net.learning_rate, adam_beta1=net.adam_optimizer_beta1,
+            adam_beta2=net.adam_optimizer_beta2, optimizer_epsilon=net.optimizer_epsilon,
+            clip_likelihood_ratio_using_epsilon=alg.clip_likelihood_ratio_using_epsilon,
+            beta_entropy=alg.beta_entropy, seed=self.ap.seed or 0)}
+        # act_for_full_episodes: train once >= num_consecutive_playing_steps were played AND every
+        # env's episode is complete (agents/agent.py:681-699); with fixed-length episodes that is a
+        # whole number of episodes per env.
+        per_env = -(-alg.num_consecutive_playing_steps.num_steps // self.n_env)
+        self.steps_per_phase = -(-per_env // self.L) * self.L
+        self.memory = DeviceEpisodicRolloutBuffer(
+            self.device, self.n_env, self.steps_per_phase,
+            frame_shape=ep.observation_shape if self.image else None, stack=self.stack,
+            obs_dim=None if self.image else int(ep.observation_shape[0]))
+        dev, n = self.device, self.n_env
+        self.actions = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.filtered_reward = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.ep_return = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.ep_len = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.ep_acc = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.lib.episode_stats_init(self.ep_return, self.ep_len, n, self.ep_acc, _rlx.current_stream())
+        self.phase = RunPhase.TRAIN
+        self.total_steps_counter = 0
+        self.last_training_phase_step = 0
+        self.training_iteration = 0
+        self.signals = {}
+        self._alloc_training_buffers()
+        self.memory.reset(self.env.reset_internal_state())
+
+    # ------------------------------------------------------------------------------- buffers
+    def _alloc_training_buffers(self):
+        dev, B = self.device, self.ap.network_wrappers["main"].batch_size
+        cap = self.memory.cap
+        f32, f64 = torch.float32, torch.float64
+        self.ds_reward = torch.empty(cap, dtype=f32, device=dev)
+        self.ds_done = torch.empty(cap, dtype=torch.uint8, device=dev)
+        self.ds_action = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.ds_value = torch.empty(cap, dtype=f32, device=dev)
+        self.ds_adv64 = torch.empty(cap, dtype=f64, device=dev)
+        self.ds_adv = torch.empty(cap, dtype=f32, device=dev)
+        self.ds_vtarget = torch.empty(cap, dtype=f32, device=dev)
+        self.ds_old_probs = torch.empty(cap, self.A, dtype=f32, device=dev)
+        self.adv_stats = torch.empty(2, dtype=f64, device=dev)
+        obs_tail = self.memory.cur_state.shape[1:]
+        self.chunk = 256
+        self.chunk_obs = torch.empty((self.chunk,) + tuple(obs_tail), dtype=self.memory.cur_state.dtype,
+                                     device=dev)
+        self.mb_obs = torch.empty((B,) + tuple(obs_tail), dtype=self.memory.cur_state.dtype, device=dev)
+        self.mb_rows = torch.empty(B, dtype=torch.int32, device=dev)
+        self.mb_idx = torch.empty(B, dtype=torch.int32, device=dev)
+        self.mb_action = torch.empty(B, dtype=torch.int32, device=dev)
+        self.mb_adv = torch.empty(B, dtype=f32, device=dev)
+        self.mb_vtarget = torch.empty(B, dtype=f32, device=dev)
+        self.mb_old = torch.empty(B, self.A, dtype=f32, device=dev)
+        self.mb_ratio = torch.empty(B, dtype=f32, device=dev)
+        self.mb_clipped = torch.empty(B, dtype=f32, device=dev)
+        self.uniforms = torch.empty(self.n_env, dtype=f64, device=dev)
+
+    # --------------------------------------------------------------------------------- acting
+    def choose_action(self, states):
+        """ClippedPPOAgent.choose_action (:352-354) + Categorical.get_action (categorical.py:45-48)
+        for every env: probabilities from the ONLINE policy tower, then np.random.choice."""
+        self.ap.algorithm.clipping_decay_schedule.step()
+        net = self.networks["main"]
+        probs = net.policy_probs(states, self.n_env)
+        if self.phase == RunPhase.TRAIN:
+            # one uniform per env, in env order: what n_env sequential np.random.choice calls consume
+            u = np.random.random_sample(self.n_env)
+            self.uniforms.copy_(torch.from_numpy(u), non_blocking=True)
+            self.lib.categorical_sample(probs, self.A, self.uniforms, self.n_env, self.A, self.actions,
+                                        _rlx.current_stream())
+        else:
+            self.actions.copy_(probs.argmax(dim=1).to(torch.int32))
+        return self.actions
+
+    def act(self):
+        """One vector step: observe -> act -> env.step (LevelManager.step, level_manager.py:215-269)."""
+        s = _rlx.current_stream()
+        states = self.memory.current_states()
+        actions = self.choose_action(states)
+        next_obs, reset_obs, reward, game_over = self.env.step(actions)
+        alg = self.ap.algorithm
+        has_clip = alg.reward_clipping is not None
+        lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
+        self.lib.reward_filter(reward, self.filtered_reward, self.n_env, alg.reward_rescale,
+                               int(has_clip), lo, hi, s)
+        self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,
+                                    self.n_env, self.ep_acc, None, None, s)
+        self.memory.store_step(actions, self.filtered_reward, game_over, next_obs, reset_obs)
+        self.total_steps_counter += self.n_env
+        return self.n_env
+
+    # ------------------------------------------------------------------------------- training
+    def _should_train(self):
+        """agents/agent.py:662-699 with act_for_full_episodes: enough steps AND episodes complete."""
+        steps = self.ap.algorithm.num_consecutive_playing_steps.num_steps
+        enough = (self.total_steps_counter - self.last_training_phase_step) >= steps
+        complete = self.memory.steps > 0 and self.memory.steps % self.L == 0
+        if enough and complete and self.memory.num_transitions() > 0:
+            self.last_training_phase_step = self.total_steps_counter
+            return True
+        return False
+
+    def fill_advantages(self):
+        """clipped_ppo_agent.py:157-207 on device: V(s) for the whole dataset in chunks, segmented
+        GAE scan per episode, (adv - mean) / std."""
+        mem, net, alg = self.memory, self.networks["main"], self.ap.algorithm
+        n = mem.num_transitions()
+        rows = mem.dataset_rows()
+        s = _rlx.current_stream()
+        mem.gather_columns(rows, n, [(mem.reward, self.ds_reward), (mem.game_over, self.ds_done),
+                                     (mem.action, self.ds_action)])
+        for c0 in range(0, n, self.chunk):
+            m = min(self.chunk, n - c0)
+            obs = mem.gather_states(rows[c0:c0 + m], m, self.chunk_obs[:m])
+            net.values(obs, m, out=self.ds_value[c0:c0 + m])
+        self.lib.gae(self.ds_reward, self.ds_value, self.ds_done, None, mem.n_env, mem.steps,
+                     alg.discount, alg.gae_lambda, self.ds_adv64, self.ds_vtarget, s)
+        self.lib.standardize(self.ds_adv64, n, self.ds_adv, None, self.adv_stats, s)
+
+    def _old_policy(self, n, rows):
+        """target_network.predict(states)[1:] for the whole dataset (:238-241, hoisted)."""
+        net, mem = self.networks["main"], self.memory
+        for c0 in range(0, n, self.chunk):
+            m = min(self.chunk, n - c0)
+            obs = mem.gather_states(rows[c0:c0 + m], m, self.chunk_obs[:m])
+            net.policy_probs(obs, m, use_target=True, tag="old", out=self.ds_old_probs[c0:c0 + m])
+
+    def train_network(self, order, epochs):
+        """clipped_ppo_agent.py:209-308.  `order`: dataset indices after the reference's
+        `dataset[:num_steps]; shuffle(dataset)`; every epoch re-shuffles (Batch.shuffle, core_types.py:452-468)."""
+        net, mem, alg = self.networks["main"], self.memory, self.ap.algorithm
+        B = self.ap.network_wrappers["main"].batch_size
+        rows_all = mem.dataset_rows()
+        n = len(order)
+        results = []
+        world = self.dist.world_size if self.dist else 1
+        scale = 1.0 / world if self.ap.network_wrappers["main"]. \
+            scale_down_gradients_by_number_of_workers_for_sync_training else 1.0
+        for j in range(epochs):
+            batch_order = list(range(n))
+            random.shuffle(batch_order)                                   # Batch.shuffle
+            order = [order[i] for i in batch_order]
+            perm = torch.from_numpy(np.asarray(order, dtype=np.int32)).to(self.device, non_blocking=True)
+            epoch_scalars = []
+            for i in range(-(-n // B)):                                   # math.ceil (:232)
+                idx = perm[i * B:(i + 1) * B]
+                m = idx.numel()
+                self._train_minibatch(net, mem, rows_all, idx, m, alg, scale)
+                epoch_scalars.append(net.scalars.clone())
+            results.append(torch.stack(epoch_scalars).mean(0))
+        return results
+
+    def _train_minibatch(self, net, mem, rows_all, idx, m, alg, scale):
+        s = _rlx.current_stream()
+        rows = self.mb_rows[:m]
+        # dataset index -> storage row, then one launch gathers the per-transition columns
+        self.lib.copy_columns(_rlx.make_columns([(rows_all, rows)]), 1, idx, None, 0, 0,
+                              rows_all.numel(), m, m, mem.status, s)
+        self.lib.copy_columns(_rlx.make_columns([(self.ds_action, self.mb_action), (self.ds_adv, self.mb_adv),
+                                                 (self.ds_vtarget, self.mb_vtarget),
+                                                 (self.ds_old_probs, self.mb_old)]), 4, idx, None, 0, 0,
+                              self.ds_adv.numel(), m, m, mem.status, s)
+        obs = mem.gather_states(rows, m, self.mb_obs[:m])
+        if self.dist is not None:
+            return self.dist.train_minibatch(net, obs, m, self.mb_action, self.mb_adv, self.mb_vtarget,
+                                             self.mb_old, alg.clipping_decay_schedule.current_value, scale)
+        net.train_minibatch(obs, m, self.mb_action, self.mb_adv, self.mb_vtarget, self.mb_old,
+                            clip_rescaler=alg.clipping_decay_schedule.current_value, grad_scale=1.0,
+                            ratio_out=self.mb_ratio, clipped_out=self.mb_clipped)
+
+    def post_training_commands(self):
+        self.memory.clean()                                               # :310-312
+
+    def train(self):
+        """ClippedPPOAgent.train (:314-344)."""
+        if not self._should_train():
+            return None
+        alg = self.ap.algorithm
+        net = self.networks["main"]
+        results = None
+        for _ in range(alg.num_consecutive_training_steps):
+            net.update_target(1.0)                                        # networks['main'].sync() (:326)
+            self.fill_advantages()
+            n_all = self.memory.num_transitions()
+            n = min(n_all, alg.num_consecutive_playing_steps.num_steps)   # dataset[:num_steps] (:330-331)
+            order = list(range(n))
+            random.shuffle(order)                                         # shuffle(dataset) (:332)
+            self._old_policy(n_all, self.memory.dataset_rows())
+            results = self.train_network(order, alg.optimization_epochs)
+        self.post_training_commands()
+        self.training_iteration += 1
+        last = results[-1]
+        self.signals = {"Surrogate loss": last[0], "Entropy": last[1], "KL Divergence": last[2],
+                        "Value Loss": last[4]}
+        return results
+
+    # ------------------------------------------------------------------------------ reporting
+    def episode_statistics(self):
+        a = self.ep_acc.cpu().numpy()
+        n = max(a[0], 1.0)
+        return {"episodes": int(a[0]), "mean_return": a[1] / n, "max_return": a[3], "min_return": a[4],
+                "mean_length": a[5] / n}

@@ -1,0 +1,125 @@
+"""On-policy rollout storage in HBM — the role EpisodicExperienceReplay plays for Clipped PPO
+(rl_coach/memories/episodic/episodic_experience_replay.py:102-130,240-317,412-426: the whole buffer
+is the training set, `transitions` is the concatenation of the stored episodes, clean() after each
+training phase).
+
+Layout (struct of arrays, one row per transition, written time-major: row = step * n_env + env):
+  image observations : frame-dedup ring u8 [n_env][ring_frames][H*W] + (t_fpos, t_epoff) per row
+                       (rlx_imgreplay_*; a stacked state is materialised only when gathered)
+  vector observations: f32 [capacity][D]
+  action i32 / f32[A], reward f32, game_over u8
+The DATASET order the agent trains on is episode-major like the reference's `transitions` list:
+dataset index i = env * steps + step  ->  row(i) = step * n_env + env   (`dataset_rows`).
+"""
+import numpy as np
+import torch
+
+from .. import _rlx
+
+
+class DeviceEpisodicRolloutBuffer(object):
+    def __init__(self, device, n_env, max_steps_per_env, frame_shape=None, stack=4, obs_dim=None,
+                 action_dim=None):
+        self.device, self.n_env, self.T = device, n_env, max_steps_per_env
+        self.lib = _rlx.lib()
+        self.cap = n_env * max_steps_per_env
+        self.image = frame_shape is not None
+        self.stack = stack
+        if self.image:
+            self.frame_shape = tuple(frame_shape)
+            self.fb = int(np.prod(frame_shape))
+            # every step adds a frame, every episode end one more (the post-reset frame)
+            self.F = 2 * max_steps_per_env + stack + 4
+            self.ring = torch.zeros(n_env, self.F, self.fb, dtype=torch.uint8, device=device)
+            self.fpos = torch.zeros(n_env, dtype=torch.int32, device=device)
+            self.epoff = torch.zeros(n_env, dtype=torch.int32, device=device)
+            self.t_fpos = torch.zeros(self.cap, dtype=torch.int32, device=device)
+            self.t_epoff = torch.zeros(self.cap, dtype=torch.uint8, device=device)
+            self.cur_state = torch.empty((n_env,) + self.frame_shape + (stack,), dtype=torch.uint8,
+                                         device=device)
+        else:
+            self.obs_dim = obs_dim
+            self.obs = torch.zeros(self.cap, obs_dim, dtype=torch.float32, device=device)
+            self.cur_state = torch.empty(n_env, obs_dim, dtype=torch.float32, device=device)
+        self.action = torch.zeros(self.cap, dtype=torch.int32, device=device) if action_dim is None \
+            else torch.zeros(self.cap, action_dim, dtype=torch.float32, device=device)
+        self.reward = torch.zeros(self.cap, dtype=torch.float32, device=device)
+        self.game_over = torch.zeros(self.cap, dtype=torch.uint8, device=device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.steps = 0
+        self._rows_cache = {}
+
+    # ---- Memory interface (memories/memory.py:41-77) ------------------------------------------
+    def num_transitions(self):
+        return self.steps * self.n_env
+
+    def length(self):
+        return self.n_env if self.steps > 0 else 0
+
+    def clean(self):                                     # :412-426
+        self.steps = 0
+
+    # ---- rollout side -------------------------------------------------------------------------
+    def reset(self, first_obs):
+        """First observation of every env: the stacking filter replicates it (:90-91)."""
+        s = _rlx.current_stream()
+        if self.image:
+            self.lib.imgreplay_reset(self.ring, self.fpos, self.epoff, first_obs, self.n_env, self.F,
+                                     self.fb, s)
+        else:
+            self.cur_state.copy_(first_obs)
+
+    def current_states(self):
+        """Stacked state of every env (policy input).  28 224 B per env for Atari."""
+        if self.image:
+            self.lib.imgreplay_gather(self.ring, None, None, self.fpos, self.epoff, None, self.n_env,
+                                      self.n_env, self.F, self.fb, self.stack, self.cap,
+                                      self.cur_state, None, self.status, _rlx.current_stream())
+        return self.cur_state
+
+    def store_step(self, actions, rewards, game_overs, next_obs, reset_obs):
+        """Agent.observe/observe_transition for n_env transitions (agents/agent.py:905-973)."""
+        if self.steps >= self.T:
+            raise ValueError("rollout buffer is full (%d steps per env)" % self.T)
+        s = _rlx.current_stream()
+        row0 = self.steps * self.n_env
+        pairs = [(actions, self.action), (rewards, self.reward), (game_overs, self.game_over)]
+        if not self.image:
+            pairs.append((self.cur_state, self.obs))
+        self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), None, None, 0, row0, self.n_env,
+                              self.cap, self.n_env, self.status, s)
+        if self.image:
+            self.lib.imgreplay_append(self.ring, self.fpos, self.epoff, self.t_fpos, self.t_epoff,
+                                      next_obs, reset_obs, game_overs, self.n_env, self.F, self.fb,
+                                      self.stack, row0, self.cap, 1, s)
+        else:
+            # next state of a finished episode is the post-reset observation
+            self.cur_state.copy_(torch.where(game_overs.view(-1, 1).bool(), reset_obs, next_obs))
+        self.steps += 1
+
+    # ---- training side ------------------------------------------------------------------------
+    def dataset_rows(self):
+        """int32[n_env * steps]: storage row of dataset element i (episode-major order)."""
+        key = self.steps
+        if key not in self._rows_cache:
+            e = np.arange(self.n_env)[:, None]
+            t = np.arange(self.steps)[None, :]
+            rows = (t * self.n_env + e).reshape(-1).astype(np.int32)
+            self._rows_cache[key] = torch.from_numpy(rows).to(self.device)
+        return self._rows_cache[key]
+
+    def gather_states(self, rows, n, out):
+        """Stacked states (or vectors) of the given storage rows -> out [n, ...]."""
+        s = _rlx.current_stream()
+        if self.image:
+            self.lib.imgreplay_gather(self.ring, self.t_fpos, self.t_epoff, None, None, rows, n,
+                                      self.n_env, self.F, self.fb, self.stack, self.cap, out, None,
+                                      self.status, s)
+        else:
+            self.lib.copy_columns(_rlx.make_columns([(self.obs, out)]), 1, rows, None, 0, 0, self.cap,
+                                  n, n, self.status, s)
+        return out
+
+    def gather_columns(self, rows, n, pairs):
+        self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), rows, None, 0, 0, self.cap, n, n,
+                              self.status, _rlx.current_stream())

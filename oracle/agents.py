@@ -144,3 +144,101 @@ class DQNOracle(_Base):
         norm = self.global_norm()
         self.adam_step(grad_scale)
         return dict(loss=loss, td_errors=td_errors, td_targets=td_targets, norm=norm)
+
+
+class ClippedPPOAgentOracle:
+    """Whole Clipped-PPO iteration on the CPU for N lockstep envs: the reference's
+    LevelManager.step loop (level_manager.py:215-269) + ClippedPPOAgent.train
+    (clipped_ppo_agent.py:314-344) around oracle components.  Host RNG usage is the reference's:
+    np.random.choice per acting env (exploration_policies/categorical.py:48), random.shuffle for the
+    dataset and per-epoch Batch.shuffle."""
+
+    def __init__(self, arrays, env, n_actions, stack=4, discount=0.99, gae_lambda=0.95, batch_size=64,
+                 playing_steps=2048, epochs=10, clip_eps=0.2, beta_entropy=0.01, lr=2.5e-4,
+                 reward_clip=(-1.0, 1.0), adam=(0.9, 0.99, 1e-4)):
+        from .replay import StackingOracle
+        self.env, self.A = env, n_actions
+        self.image = env.kind == 0
+        self.n_env = env.n_env
+        self.frame_shape = None
+        obs_shape = None
+        self.stackers = [StackingOracle(stack) for _ in range(self.n_env)] if self.image else None
+        self.stack = stack
+        self.discount, self.lam, self.B = discount, gae_lambda, batch_size
+        self.playing_steps, self.epochs = playing_steps, epochs
+        self.reward_clip = reward_clip
+        self._net_args = (arrays, n_actions, lr, adam, clip_eps, beta_entropy)
+        self.net = None
+        self.transitions = [[] for _ in range(self.n_env)]     # per env: (state, action, reward, done)
+        self.cur = None
+        self.losses = []
+
+    def _ensure_net(self, obs_shape):
+        if self.net is None:
+            arrays, A, lr, adam, clip_eps, beta = self._net_args
+            self.net = ClippedPPOOracle(arrays, obs_shape, A, lr=lr, beta1=adam[0], beta2=adam[1],
+                                        eps=adam[2], clip_eps=clip_eps, beta_entropy=beta)
+
+    def reset(self, frame_hw=None):
+        first = self.env.reset()
+        if self.image:
+            first = first.reshape((self.n_env,) + tuple(frame_hw))
+            self.frame_hw = tuple(frame_hw)
+            self.cur = [s.filter(f) for s, f in zip(self.stackers, first)]
+            self._ensure_net(self.frame_hw + (self.stack,))
+        else:
+            self.cur = [f for f in first]
+            self._ensure_net((first.shape[1],))
+
+    def act(self):
+        from . import filters as Fl
+        from .explore import categorical_choice
+        states = np.stack(self.cur)
+        probs = self.net.policy_probs(states)
+        actions = [categorical_choice(probs[e], np.random.random_sample()) for e in range(self.n_env)]
+        nxt, rst, rew, done = self.env.step()
+        for e in range(self.n_env):
+            r = float(rew[e])
+            if self.reward_clip is not None:
+                r = Fl.reward_clip(r, *self.reward_clip)
+            self.transitions[e].append((self.cur[e], actions[e], r, bool(done[e])))
+            if self.image:
+                ns = self.stackers[e].filter(nxt[e].reshape(self.frame_hw))
+                if done[e]:
+                    self.stackers[e].reset()
+                    ns = self.stackers[e].filter(rst[e].reshape(self.frame_hw))
+                self.cur[e] = ns
+            else:
+                self.cur[e] = rst[e] if done[e] else nxt[e]
+        return actions, probs
+
+    def train(self):
+        import random
+        from . import returns as R
+        data = [t for e in range(self.n_env) for t in self.transitions[e]]     # episode-major
+        states = np.stack([t[0] for t in data])
+        actions = np.array([t[1] for t in data])
+        rewards = np.array([t[2] for t in data], dtype=np.float64)
+        dones = np.array([t[3] for t in data])
+        frozen = self.net.clone_policy()                                       # networks['main'].sync()
+        values = np.concatenate([self.net.values(states[i:i + self.B]) for i in range(0, len(data), self.B)])
+        adv, vt, _ = R.fill_advantages(rewards, values, dones, self.discount, self.lam)
+        self.dbg = dict(values=values, adv=adv, vt=vt, rewards=rewards, dones=dones, actions=actions)
+        n = min(len(data), self.playing_steps)
+        order = list(range(n))
+        random.shuffle(order)
+        out = []
+        for j in range(self.epochs):
+            bo = list(range(n))
+            random.shuffle(bo)
+            order = [order[i] for i in bo]
+            ep = []
+            for i in range(-(-n // self.B)):
+                idx = order[i * self.B:(i + 1) * self.B]
+                old = self.net.policy_probs(states[idx], frozen)
+                r = self.net.train_minibatch(states[idx], actions[idx], adv[idx].astype(F32),
+                                             vt[idx].astype(F32), old)
+                ep.append([r["surrogate"], r["entropy"], r["kl"], r["total"], r["value_loss"]])
+            out.append(np.mean(np.array(ep, dtype=np.float64), 0))
+        self.transitions = [[] for _ in range(self.n_env)]
+        return out
