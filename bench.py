@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json headline metric on the C2 workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one Clipped-PPO iteration of the hot path on every rank: 2048 env-steps (64 synthetic
+Atari-like envs x 32 steps, 84x84x4 uint8 stacked observations) through the vectorised
+env-step / filter / store loop, then GAE + 10 epochs x 32 minibatches of 64 (320 gradient updates)
+— SURVEY.md §8 config C2, clipped_ppo_agent.py defaults.  value = env-steps/s summed over ranks
+(weak scaling: every rank owns its own 64-env vector; the only exchange is the gradient all-reduce).
+Inputs are generated on the device (Philox), nothing is staged over PCIe in the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+N_ENV, EP_LEN, PLAYING_STEPS, BATCH, EPOCHS, N_ACTIONS = 64, 32, 2048, 64, 10, 6
+FRAME = (84, 84)
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+
+
+def build_agent(device, dist, seed=0):
+    from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
+    from coach_amd.core_types import EnvironmentSteps
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    ep = SyntheticVectorEnvironmentParameters("image", N_ENV, FRAME, N_ACTIONS, episode_length=EP_LEN,
+                                              seed=1234)
+    env = SyntheticVectorEnvironment(ep, device, rank=dist.rank)
+    ap = ClippedPPOAgentParameters()
+    ap.seed = seed
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(PLAYING_STEPS)
+    ap.algorithm.optimization_epochs = EPOCHS
+    ap.network_wrappers["main"].batch_size = BATCH
+    return ClippedPPOAgent(ap, env, device, dist=dist)
+
+
+def one_step(agent):
+    res = None
+    while res is None:
+        agent.act()
+        res = agent.train()
+    return res
+
+
+# ------------------------------------------------------------------------------------- roofline
+def gemm_roofline(agent, reps=20):
+    """Per-launch timing of the dominant kernel family (gemm_kernel<...>, fp32 MFMA) with HIP events
+    on the launch stream: every GEMM descriptor issued by one minibatch update is recorded, then
+    each is launched `reps` times back to back between one event pair."""
+    import ctypes
+    from coach_amd import _rlx
+    lib = _rlx.lib()
+    recorded = []
+    orig = lib.raw("rlx_gemm")
+    saved_graphs = agent.use_graphs
+    agent.use_graphs = False
+    _rlx.GEMM_HOOK = recorded.append
+    try:
+        # one eager minibatch update on the buffers left over from the last training phase
+        agent._minibatch_fb(BATCH, 1.0)
+        agent._minibatch_finish(1.0)
+    finally:
+        _rlx.GEMM_HOOK = None
+        agent.use_graphs = saved_graphs
+    torch.cuda.synchronize()
+    stream = _rlx.current_stream()
+    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+    lib.event_create(ctypes.byref(ev0))
+    lib.event_create(ctypes.byref(ev1))
+    total_ms, total_flops, per_shape = 0.0, 0.0, []
+    for d in recorded:
+        for _ in range(3):
+            orig(ctypes.byref(d), stream)
+        lib.event_record(ev0, stream)
+        for _ in range(reps):
+            orig(ctypes.byref(d), stream)
+        lib.event_record(ev1, stream)
+        ms = ctypes.c_float()
+        lib.event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
+        flops = 2.0 * d.M * d.N * d.K * d.batch
+        total_ms += ms.value / reps
+        total_flops += flops
+        per_shape.append({"M": d.M, "N": d.N, "K": d.K, "batch": d.batch, "us": 1e3 * ms.value / reps,
+                          "tflops": flops / (ms.value / reps * 1e-3) / 1e12})
+    lib.event_destroy(ev0)
+    lib.event_destroy(ev1)
+    n = len(recorded)
+    achieved = total_flops / (total_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_kernel<BM,BN,...> (fp32 MFMA 32x32x2), %d launches per minibatch update" % n,
+            "flops_per_launch": total_flops / n, "avg_launch_us": round(1e3 * total_ms / n, 2),
+            "gemm_us_per_update": round(1e3 * total_ms, 1)}, per_shape
+
+
+# ---------------------------------------------------------------------------------- cpu baseline
+def cpu_baseline(budget_s=20.0):
+    """The oracle (numpy restatement of the reference's CPU path) on a bounded sample of the same
+    workload: a few vector env-steps, value chunks and minibatch updates are timed and scaled to one
+    full iteration (32 steps, 32 value chunks of 64, 320 updates incl. the per-minibatch old-policy
+    pass the reference performs)."""
+    import random
+    from oracle.agents import ClippedPPOAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    from coach_amd.nn import graph as G, networks as NW
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    # same topology / init as the HIP net, built on the host without touching the GPU library
+    params = G.FlatParams()
+    torso, feat = NW.build_torso(params, "main", FRAME + (4,), "tanh", 2)
+    vh = G.Dense(params, "main/v_head/dense", feat, 1, None, 1, init=G.normalized_columns(1.0))
+    ph = G.Dense(params, "main/ppo_head/policy_fc", feat, N_ACTIONS, None, 1)
+    params.finalize("cpu")
+    rng = np.random.RandomState(0)
+    for m in (torso, vh, ph):
+        m.initialize(rng)
+    arrays = params.named_arrays()
+    env = SynthVecEnv(0, N_ENV, FRAME[0] * FRAME[1], EP_LEN, 1234)
+    o = ClippedPPOAgentOracle(arrays, env, N_ACTIONS, batch_size=BATCH, playing_steps=PLAYING_STEPS,
+                              epochs=EPOCHS)
+    random.seed(0)
+    np.random.seed(0)
+    o.reset(FRAME)
+    t0 = time.perf_counter()
+    n_act = 0
+    while n_act < 2 or (time.perf_counter() - t0 < 0.2 * budget_s and n_act < 8):
+        o.act()
+        n_act += 1
+    t_act = (time.perf_counter() - t0) / n_act
+    states = np.stack(o.cur)
+    t0 = time.perf_counter()
+    o.net.values(states)
+    t_val = time.perf_counter() - t0
+    frozen = o.net.clone_policy()
+    acts = np.random.randint(0, N_ACTIONS, size=BATCH)
+    adv = np.random.randn(BATCH).astype(np.float32)
+    vt = np.random.randn(BATCH).astype(np.float32)
+    t0 = time.perf_counter()
+    n_mb = 0
+    while n_mb < 2 or (time.perf_counter() - t0 < 0.6 * budget_s and n_mb < 12):
+        old = o.net.policy_probs(states, frozen)
+        o.net.train_minibatch(states, acts, adv, vt, old)
+        n_mb += 1
+    t_mb = (time.perf_counter() - t0) / n_mb
+    n_updates = EPOCHS * (PLAYING_STEPS // BATCH)
+    t_iter = EP_LEN * t_act + (PLAYING_STEPS // BATCH) * t_val + n_updates * t_mb
+    return {"value": round(PLAYING_STEPS / t_iter, 2), "unit": "env-steps/s", "cores": int(cores),
+            "kind": "port",
+            "sample": "oracle/ (numpy fp32 restatement of rl_coach's CPU path): %d vector env-steps "
+                      "(64 envs), 1 value chunk and %d minibatch updates timed, scaled to one full "
+                      "iteration (32 steps + 32 value chunks + 320 updates); %.3f s/step, %.3f s/chunk, "
+                      "%.3f s/update" % (n_act, n_mb, t_act, t_val, t_mb),
+            "grad_updates_per_s": round(n_updates / t_iter, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="print the per-GEMM-shape table to stderr")
+    args = ap.parse_args()
+
+    from coach_amd.distributed import GradientSync
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = GradientSync()
+    if dist.world_size != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
+                         % (args.gpus, dist.world_size))
+    agent = build_agent(device, dist)
+    for _ in range(args.warmup):
+        one_step(agent)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_step(agent)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    agent.networks["main"].check_status()
+
+    n_updates = EPOCHS * (PLAYING_STEPS // BATCH)
+    env_steps = dist.world_size * PLAYING_STEPS * args.steps
+    out = {
+        "metric": "env-steps/sec (+ grad-updates/sec) on Atari-like Clipped-PPO, 64 vectorized envs/GPU",
+        "value": round(env_steps / elapsed, 1), "unit": "env-steps/s", "n_gpus": dist.world_size,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "grad_updates_per_s": round(n_updates * args.steps / elapsed, 1),
+        "config": {"workload": "C2: Atari-Pong-like Clipped-PPO, %d vectorized envs/GPU, 84x84x4 uint8 obs, "
+                               "GAE(0.99,0.95), rollout %d env-steps (episodes of %d), %d epochs x %d "
+                               "minibatches of %d, fp32 conv torso x2 (value/policy), TF1-Adam"
+                               % (N_ENV, PLAYING_STEPS, EP_LEN, EPOCHS, PLAYING_STEPS // BATCH, BATCH),
+                   "global_env_steps_per_step": dist.world_size * PLAYING_STEPS,
+                   "parallelism": "dp%d (env vectors sharded per GPU, flat fp32 gradient all-reduce)"
+                                  % dist.world_size,
+                   "hip_graphs": bool(agent.use_graphs)},
+        "final_losses": {k: float(v) for k, v in agent.signals.items()},
+    }
+    if dist.rank == 0 and not args.no_roofline:
+        roof, shapes = gemm_roofline(agent)
+        out["roofline"] = roof
+        if args.shapes:
+            for s in shapes:
+                print(json.dumps(s), file=sys.stderr)
+    if dist.rank == 0 and dist.world_size == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    dist.barrier()
+    if dist.rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

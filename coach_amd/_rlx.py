@@ -214,6 +214,7 @@ class GemmDesc(ctypes.Structure):
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+GEMM_HOOK = None   # bench.py sets this to record the descriptors issued by one update
 
 
 def _ptr(t):
@@ -249,4 +250,6 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
     d.a_vec_along_k, d.a_tab_vec_ok = int(a_vec_along_k), int(a_tab_vec_ok)
     d.activation, d.deriv_kind = ACT[activation], ACT[deriv_kind]
     d.accumulate = int(bool(accumulate))
+    if GEMM_HOOK is not None:
+        GEMM_HOOK(GemmDesc.from_buffer_copy(d))
     lib().gemm(ctypes.byref(d), current_stream() if stream is None else stream)

@@ -13,7 +13,11 @@ numpy + TF sessions.  What changes, and why it is still the same algorithm:
     are frozen during train_network, so the values are identical.
   * host RNG draws (np.random for action sampling, random.shuffle for minibatch order) are made by
     the same generators in the same order as the reference and shipped to the device.
+  * the per-step and per-minibatch launch sequences are launch-bound (tens of ~10 us kernels), so
+    each is captured once into a hipGraph (torch.cuda.CUDAGraph on the current stream) and
+    replayed; RLX_NO_GRAPHS=1 runs the same calls eagerly.
 """
+import os
 import random
 
 import numpy as np
@@ -75,13 +79,23 @@ class ClippedPPOAgentParameters(object):                 # clipped_ppo_agent.py:
         return 'coach_amd.agents.clipped_ppo_agent:ClippedPPOAgent'
 
 
+def _capture(fn):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
 class ClippedPPOAgent(object):
-    def __init__(self, agent_parameters, environment, device=None, dist=None):
+    def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         self.ap = agent_parameters
         self.env = environment
         self.device = device or environment.device
-        self.dist = dist                                  # coach_amd.distributed.GradientSync or None
+        self.dist = dist if (dist is not None and dist.enabled) else None
         self.lib = _rlx.lib()
+        if use_graphs is None:
+            use_graphs = os.environ.get("RLX_NO_GRAPHS", "0") != "1"
+        self.use_graphs = use_graphs
         alg, net = self.ap.algorithm, self.ap.network_wrappers["main"]
         ep = environment.p
         self.n_env, self.A = ep.num_envs, ep.num_actions
@@ -89,7 +103,8 @@ class ClippedPPOAgent(object):
         self.stack = 4
         self.L = ep.episode_length
         obs_shape = tuple(ep.observation_shape) + (self.stack,) if self.image else tuple(ep.observation_shape)
-        # seeds: host generators exactly like Agent.__init__ (agents/agent.py:49-55)
+        # seeds: host generators exactly like Agent.__init__ (agents/agent.py:49-55); every rank
+        # builds identical initial weights, env streams differ through env_id0
         if self.ap.seed is not None:
             random.seed(self.ap.seed)
             np.random.seed(self.ap.seed)
@@ -100,6 +115,10 @@ class ClippedPPOAgent(object):
             adam_beta2=net.adam_optimizer_beta2, optimizer_epsilon=net.optimizer_epsilon,
             clip_likelihood_ratio_using_epsilon=alg.clip_likelihood_ratio_using_epsilon,
             beta_entropy=alg.beta_entropy, seed=self.ap.seed or 0)}
+        if self.dist is not None and self.ap.seed is not None:
+            # rank-offset sampling seed (coach.py:746 seed + task_index) AFTER the shared weight init
+            random.seed(self.ap.seed + self.dist.rank)
+            np.random.seed(self.ap.seed + self.dist.rank)
         # act_for_full_episodes: train once >= num_consecutive_playing_steps were played AND every
         # env's episode is complete (agents/agent.py:681-699); with fixed-length episodes that is a
         # whole number of episodes per env.
@@ -121,6 +140,8 @@ class ClippedPPOAgent(object):
         self.last_training_phase_step = 0
         self.training_iteration = 0
         self.signals = {}
+        self._graphs = {}
+        self._warm = set()
         self._alloc_training_buffers()
         self.memory.reset(self.env.reset_internal_state())
 
@@ -138,52 +159,78 @@ class ClippedPPOAgent(object):
         self.ds_vtarget = torch.empty(cap, dtype=f32, device=dev)
         self.ds_old_probs = torch.empty(cap, self.A, dtype=f32, device=dev)
         self.adv_stats = torch.empty(2, dtype=f64, device=dev)
-        obs_tail = self.memory.cur_state.shape[1:]
+        obs_tail = tuple(self.memory.cur_state.shape[1:])
+        odt = self.memory.cur_state.dtype
         self.chunk = 256
-        self.chunk_obs = torch.empty((self.chunk,) + tuple(obs_tail), dtype=self.memory.cur_state.dtype,
-                                     device=dev)
-        self.mb_obs = torch.empty((B,) + tuple(obs_tail), dtype=self.memory.cur_state.dtype, device=dev)
+        self.chunk_obs = torch.empty((self.chunk,) + obs_tail, dtype=odt, device=dev)
+        self.mb_obs = torch.empty((B,) + obs_tail, dtype=odt, device=dev)
         self.mb_rows = torch.empty(B, dtype=torch.int32, device=dev)
-        self.mb_idx = torch.empty(B, dtype=torch.int32, device=dev)
+        self.mb_idx = torch.zeros(B, dtype=torch.int32, device=dev)
         self.mb_action = torch.empty(B, dtype=torch.int32, device=dev)
         self.mb_adv = torch.empty(B, dtype=f32, device=dev)
         self.mb_vtarget = torch.empty(B, dtype=f32, device=dev)
         self.mb_old = torch.empty(B, self.A, dtype=f32, device=dev)
         self.mb_ratio = torch.empty(B, dtype=f32, device=dev)
         self.mb_clipped = torch.empty(B, dtype=f32, device=dev)
-        self.uniforms = torch.empty(self.n_env, dtype=f64, device=dev)
+        self.scalar_acc = torch.zeros(8, dtype=f32, device=dev)
+        # one uniform per (step, env): what the phase's np.random.choice calls consume
+        self.uniforms_all = torch.zeros(self.steps_per_phase, self.n_env, dtype=f64, device=dev)
+        self.uniforms_host = torch.zeros(self.steps_per_phase, self.n_env, dtype=f64).pin_memory() \
+            if torch.cuda.is_available() else torch.zeros(self.steps_per_phase, self.n_env, dtype=f64)
+
+    # ------------------------------------------------------------------------------ graph util
+    def _run(self, key, fn):
+        """Run `fn` (pure device work on static buffers): eagerly the first time (allocates cached
+        buffers / offset tables), captured into a hipGraph the second time, replayed afterwards."""
+        if not self.use_graphs:
+            return fn()
+        g = self._graphs.get(key)
+        if g is not None:
+            return g.replay()
+        if key not in self._warm:
+            self._warm.add(key)
+            return fn()
+        torch.cuda.synchronize()
+        self._graphs[key] = _capture(fn)
+        return self._graphs[key].replay()
 
     # --------------------------------------------------------------------------------- acting
-    def choose_action(self, states):
-        """ClippedPPOAgent.choose_action (:352-354) + Categorical.get_action (categorical.py:45-48)
-        for every env: probabilities from the ONLINE policy tower, then np.random.choice."""
-        self.ap.algorithm.clipping_decay_schedule.step()
-        net = self.networks["main"]
-        probs = net.policy_probs(states, self.n_env)
-        if self.phase == RunPhase.TRAIN:
-            # one uniform per env, in env order: what n_env sequential np.random.choice calls consume
-            u = np.random.random_sample(self.n_env)
-            self.uniforms.copy_(torch.from_numpy(u), non_blocking=True)
-            self.lib.categorical_sample(probs, self.A, self.uniforms, self.n_env, self.A, self.actions,
-                                        _rlx.current_stream())
-        else:
-            self.actions.copy_(probs.argmax(dim=1).to(torch.int32))
-        return self.actions
-
-    def act(self):
-        """One vector step: observe -> act -> env.step (LevelManager.step, level_manager.py:215-269)."""
+    def _act_device(self, step):
+        """Device work of one vector step: stacked states -> online policy tower -> categorical
+        sample -> env step -> reward filter -> episode stats -> store."""
         s = _rlx.current_stream()
-        states = self.memory.current_states()
-        actions = self.choose_action(states)
-        next_obs, reset_obs, reward, game_over = self.env.step(actions)
         alg = self.ap.algorithm
+        states = self.memory.current_states()
+        probs = self.networks["main"].policy_probs(states, self.n_env)
+        if self.phase == RunPhase.TRAIN:
+            self.lib.categorical_sample(probs, self.A, self.uniforms_all[step], self.n_env, self.A,
+                                        self.actions, s)                    # categorical.py:45-48
+        else:
+            self.actions.copy_(probs.argmax(dim=1).to(torch.int32))         # :50-56
+        next_obs, reset_obs, reward, game_over = self.env.step(self.actions)
         has_clip = alg.reward_clipping is not None
         lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
         self.lib.reward_filter(reward, self.filtered_reward, self.n_env, alg.reward_rescale,
                                int(has_clip), lo, hi, s)
         self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,
                                     self.n_env, self.ep_acc, None, None, s)
-        self.memory.store_step(actions, self.filtered_reward, game_over, next_obs, reset_obs)
+        self.memory.store_step_at(step, self.actions, self.filtered_reward, game_over, next_obs, reset_obs)
+
+    def act(self):
+        """One vector step: observe -> act -> env.step (LevelManager.step, level_manager.py:215-269)."""
+        step = self.memory.steps
+        if step >= self.memory.T:
+            raise ValueError("rollout buffer is full; call train()")
+        if step == 0 and self.phase == RunPhase.TRAIN:
+            # draws of the whole phase, in the order n_env sequential np.random.choice calls per step
+            # would make them (nothing else consumes np.random while acting)
+            u = np.random.random_sample((self.steps_per_phase, self.n_env))
+            self.uniforms_host.copy_(torch.from_numpy(u))
+            self.uniforms_all.copy_(self.uniforms_host, non_blocking=True)
+        self.ap.algorithm.clipping_decay_schedule.step()                    # choose_action (:352-354)
+        self._run(("act", step, self.phase), lambda: self._act_device(step))
+        self.memory.steps += 1
+        self.env.total_steps += self.n_env
         self.total_steps_counter += self.n_env
         return self.n_env
 
@@ -198,12 +245,8 @@ class ClippedPPOAgent(object):
             return True
         return False
 
-    def fill_advantages(self):
-        """clipped_ppo_agent.py:157-207 on device: V(s) for the whole dataset in chunks, segmented
-        GAE scan per episode, (adv - mean) / std."""
+    def _fill_advantages_device(self, n, rows):
         mem, net, alg = self.memory, self.networks["main"], self.ap.algorithm
-        n = mem.num_transitions()
-        rows = mem.dataset_rows()
         s = _rlx.current_stream()
         mem.gather_columns(rows, n, [(mem.reward, self.ds_reward), (mem.game_over, self.ds_done),
                                      (mem.action, self.ds_action)])
@@ -211,46 +254,26 @@ class ClippedPPOAgent(object):
             m = min(self.chunk, n - c0)
             obs = mem.gather_states(rows[c0:c0 + m], m, self.chunk_obs[:m])
             net.values(obs, m, out=self.ds_value[c0:c0 + m])
-        self.lib.gae(self.ds_reward, self.ds_value, self.ds_done, None, mem.n_env, mem.steps,
+        self.lib.gae(self.ds_reward, self.ds_value, self.ds_done, None, mem.n_env, n // mem.n_env,
                      alg.discount, alg.gae_lambda, self.ds_adv64, self.ds_vtarget, s)
         self.lib.standardize(self.ds_adv64, n, self.ds_adv, None, self.adv_stats, s)
-
-    def _old_policy(self, n, rows):
-        """target_network.predict(states)[1:] for the whole dataset (:238-241, hoisted)."""
-        net, mem = self.networks["main"], self.memory
+        # old policy = target network, frozen for the whole phase (:238-241, hoisted out of the loop)
         for c0 in range(0, n, self.chunk):
             m = min(self.chunk, n - c0)
             obs = mem.gather_states(rows[c0:c0 + m], m, self.chunk_obs[:m])
             net.policy_probs(obs, m, use_target=True, tag="old", out=self.ds_old_probs[c0:c0 + m])
 
-    def train_network(self, order, epochs):
-        """clipped_ppo_agent.py:209-308.  `order`: dataset indices after the reference's
-        `dataset[:num_steps]; shuffle(dataset)`; every epoch re-shuffles (Batch.shuffle, core_types.py:452-468)."""
-        net, mem, alg = self.networks["main"], self.memory, self.ap.algorithm
-        B = self.ap.network_wrappers["main"].batch_size
-        rows_all = mem.dataset_rows()
-        n = len(order)
-        results = []
-        world = self.dist.world_size if self.dist else 1
-        scale = 1.0 / world if self.ap.network_wrappers["main"]. \
-            scale_down_gradients_by_number_of_workers_for_sync_training else 1.0
-        for j in range(epochs):
-            batch_order = list(range(n))
-            random.shuffle(batch_order)                                   # Batch.shuffle
-            order = [order[i] for i in batch_order]
-            perm = torch.from_numpy(np.asarray(order, dtype=np.int32)).to(self.device, non_blocking=True)
-            epoch_scalars = []
-            for i in range(-(-n // B)):                                   # math.ceil (:232)
-                idx = perm[i * B:(i + 1) * B]
-                m = idx.numel()
-                self._train_minibatch(net, mem, rows_all, idx, m, alg, scale)
-                epoch_scalars.append(net.scalars.clone())
-            results.append(torch.stack(epoch_scalars).mean(0))
-        return results
+    def fill_advantages(self):
+        """clipped_ppo_agent.py:157-207 on device: V(s) for the whole dataset in chunks, segmented
+        GAE scan per episode, (adv - mean) / std; plus the old-policy probabilities."""
+        n = self.memory.num_transitions()
+        rows = self.memory.dataset_rows()
+        self._run(("fill", n), lambda: self._fill_advantages_device(n, rows))
 
-    def _train_minibatch(self, net, mem, rows_all, idx, m, alg, scale):
-        s = _rlx.current_stream()
-        rows = self.mb_rows[:m]
+    def _gather_minibatch(self, m):
+        mem, s = self.memory, _rlx.current_stream()
+        rows_all = mem.dataset_rows()
+        idx, rows = self.mb_idx[:m], self.mb_rows[:m]
         # dataset index -> storage row, then one launch gathers the per-transition columns
         self.lib.copy_columns(_rlx.make_columns([(rows_all, rows)]), 1, idx, None, 0, 0,
                               rows_all.numel(), m, m, mem.status, s)
@@ -258,13 +281,51 @@ class ClippedPPOAgent(object):
                                                  (self.ds_vtarget, self.mb_vtarget),
                                                  (self.ds_old_probs, self.mb_old)]), 4, idx, None, 0, 0,
                               self.ds_adv.numel(), m, m, mem.status, s)
-        obs = mem.gather_states(rows, m, self.mb_obs[:m])
-        if self.dist is not None:
-            return self.dist.train_minibatch(net, obs, m, self.mb_action, self.mb_adv, self.mb_vtarget,
-                                             self.mb_old, alg.clipping_decay_schedule.current_value, scale)
-        net.train_minibatch(obs, m, self.mb_action, self.mb_adv, self.mb_vtarget, self.mb_old,
-                            clip_rescaler=alg.clipping_decay_schedule.current_value, grad_scale=1.0,
-                            ratio_out=self.mb_ratio, clipped_out=self.mb_clipped)
+        return mem.gather_states(rows, m, self.mb_obs[:m])
+
+    def _minibatch_fb(self, m, clip_rescaler):
+        obs = self._gather_minibatch(m)
+        self.networks["main"].forward_backward(obs, m, self.mb_action, self.mb_adv, self.mb_vtarget,
+                                               self.mb_old, clip_rescaler, self.mb_ratio, self.mb_clipped)
+
+    def _minibatch_finish(self, scale):
+        net = self.networks["main"]
+        net.finish_update(scale)
+        self.scalar_acc[:5].add_(net.scalars[:5])
+        self.scalar_acc[5:6].add_(net.norm)
+
+    def train_network(self, order, epochs):
+        """clipped_ppo_agent.py:209-308.  `order`: dataset indices after the reference's
+        `dataset[:num_steps]; shuffle(dataset)`; every epoch re-shuffles (Batch.shuffle,
+        core_types.py:452-468).  Returns the per-epoch means of
+        [surrogate, entropy, kl, policy-head total, value loss, grad norm]."""
+        alg = self.ap.algorithm
+        netp = self.ap.network_wrappers["main"]
+        B = netp.batch_size
+        n = len(order)
+        clip = float(alg.clipping_decay_schedule.current_value)
+        scale = self.dist.grad_scale(netp.scale_down_gradients_by_number_of_workers_for_sync_training) \
+            if self.dist else 1.0
+        results = []
+        for j in range(epochs):
+            batch_order = list(range(n))
+            random.shuffle(batch_order)                                   # Batch.shuffle
+            order = [order[i] for i in batch_order]
+            perm = torch.from_numpy(np.asarray(order, dtype=np.int32)).to(self.device, non_blocking=True)
+            self.scalar_acc.zero_()
+            nmb = -(-n // B)                                              # math.ceil (:232)
+            for i in range(nmb):
+                m = min(B, n - i * B)
+                self.mb_idx[:m].copy_(perm[i * B:i * B + m])
+                if self.dist is None:
+                    self._run(("mb", m, clip, scale), lambda: (self._minibatch_fb(m, clip),
+                                                               self._minibatch_finish(scale)))
+                else:
+                    self._run(("mb_fb", m, clip), lambda: self._minibatch_fb(m, clip))
+                    self.dist.all_reduce_sum(self.networks["main"].params.grads)
+                    self._run(("mb_fin", scale), lambda: self._minibatch_finish(scale))
+            results.append(self.scalar_acc / nmb)
+        return results
 
     def post_training_commands(self):
         self.memory.clean()                                               # :310-312
@@ -279,17 +340,15 @@ class ClippedPPOAgent(object):
         for _ in range(alg.num_consecutive_training_steps):
             net.update_target(1.0)                                        # networks['main'].sync() (:326)
             self.fill_advantages()
-            n_all = self.memory.num_transitions()
-            n = min(n_all, alg.num_consecutive_playing_steps.num_steps)   # dataset[:num_steps] (:330-331)
-            order = list(range(n))
+            n = min(self.memory.num_transitions(), alg.num_consecutive_playing_steps.num_steps)
+            order = list(range(n))                                        # dataset[:num_steps] (:330-331)
             random.shuffle(order)                                         # shuffle(dataset) (:332)
-            self._old_policy(n_all, self.memory.dataset_rows())
             results = self.train_network(order, alg.optimization_epochs)
         self.post_training_commands()
         self.training_iteration += 1
         last = results[-1]
         self.signals = {"Surrogate loss": last[0], "Entropy": last[1], "KL Divergence": last[2],
-                        "Value Loss": last[4]}
+                        "Value Loss": last[4], "Grads (unclipped)": last[5]}
         return results
 
     # ------------------------------------------------------------------------------ reporting

@@ -56,5 +56,4 @@ class SyntheticVectorEnvironment(object):
         self.lib.synth_env_step(self.kind, self.next_obs, self.reset_obs, self.reward, self.game_over,
                                 self.episode, self.step_in_episode, self.n, self.obs_elems,
                                 self.p.episode_length, self.seed, self.env_id0, _rlx.current_stream())
-        self.total_steps += self.n
         return self.next_obs, self.reset_obs, self.reward, self.game_over

@@ -81,8 +81,13 @@ class DeviceEpisodicRolloutBuffer(object):
         """Agent.observe/observe_transition for n_env transitions (agents/agent.py:905-973)."""
         if self.steps >= self.T:
             raise ValueError("rollout buffer is full (%d steps per env)" % self.T)
+        self.store_step_at(self.steps, actions, rewards, game_overs, next_obs, reset_obs)
+        self.steps += 1
+
+    def store_step_at(self, step, actions, rewards, game_overs, next_obs, reset_obs):
+        """Device work of store_step for an explicit step index (hipGraph-capturable: no host state)."""
         s = _rlx.current_stream()
-        row0 = self.steps * self.n_env
+        row0 = step * self.n_env
         pairs = [(actions, self.action), (rewards, self.reward), (game_overs, self.game_over)]
         if not self.image:
             pairs.append((self.cur_state, self.obs))
@@ -95,7 +100,6 @@ class DeviceEpisodicRolloutBuffer(object):
         else:
             # next state of a finished episode is the post-reset observation
             self.cur_state.copy_(torch.where(game_overs.view(-1, 1).bool(), reset_obs, next_obs))
-        self.steps += 1
 
     # ---- training side ------------------------------------------------------------------------
     def dataset_rows(self):

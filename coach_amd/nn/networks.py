@@ -121,8 +121,10 @@ class ClippedPPONet(_NetBase):
         return v.data.view(-1)
 
     # ---- one minibatch of ClippedPPOAgent.train_network (:226-266) ---------------------------
-    def train_minibatch(self, obs, B, actions, advantages, value_targets, old_probs,
-                        clip_rescaler=1.0, grad_scale=1.0, ratio_out=None, clipped_out=None):
+    def forward_backward(self, obs, B, actions, advantages, value_targets, old_probs,
+                         clip_rescaler=1.0, ratio_out=None, clipped_out=None):
+        """accumulate_gradients (tensorflow_components/architecture.py:312-385): forward both towers,
+        head losses, backward; leaves d total_loss / d theta in params.grads."""
         ctx = self.ctx
         acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
         mid = acts[-1]
@@ -142,8 +144,17 @@ class ClippedPPONet(_NetBase):
         self.v_head.backward(ctx, xv, v)
         self.pi_head.backward(ctx, xp, logits)
         self.torso.backward(ctx, acts)
+
+    def finish_update(self, grad_scale=1.0):
+        """apply_gradients (architecture.py:469-521): global norm fetch + Adam."""
         self.grad_norm()
         self.apply_gradients(grad_scale)
+
+    def train_minibatch(self, obs, B, actions, advantages, value_targets, old_probs,
+                        clip_rescaler=1.0, grad_scale=1.0, ratio_out=None, clipped_out=None):
+        self.forward_backward(obs, B, actions, advantages, value_targets, old_probs, clip_rescaler,
+                              ratio_out, clipped_out)
+        self.finish_update(grad_scale)
         # scalars: [surrogate, entropy, kl, policy head total, value loss]
         return self.scalars
 
