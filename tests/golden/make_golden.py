@@ -403,8 +403,69 @@ def gen_targets():
     _save("targets", **out)
 
 
+# --------------------------------------------------------------------------------- exploration
+def gen_explore():
+    """Categorical / EGreedy / AdditiveNoise .get_action under a seeded np.random, together with the
+    raw draws each call consumed (exploration_policies/{categorical,e_greedy,additive_noise}.py)."""
+    from rl_coach.core_types import RunPhase
+    from rl_coach.exploration_policies.additive_noise import AdditiveNoise
+    from rl_coach.exploration_policies.categorical import Categorical
+    from rl_coach.exploration_policies.e_greedy import EGreedy
+    from rl_coach.schedules import ConstantSchedule, LinearSchedule
+    from rl_coach.spaces import BoxActionSpace, DiscreteActionSpace
+    out = {}
+    rng = np.random.RandomState(8)
+    # --- categorical: one np.random.choice per call
+    A = 6
+    pol = Categorical(DiscreteActionSpace(A))
+    pol.change_phase(RunPhase.TRAIN)
+    logits = rng.randn(200, A).astype(np.float32)
+    probs = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+    probs = probs.astype(np.float32)
+    np.random.seed(3)
+    u = np.random.random_sample(200)
+    np.random.seed(3)
+    out["cat_probs"], out["cat_u"] = probs, u
+    out["cat_actions"] = np.array([pol.get_action(p)[0] for p in probs])
+    # --- e-greedy (discrete): per call: [choice if exploring | A tie-break randoms], then a new rand()
+    A = 4
+    pol = EGreedy(DiscreteActionSpace(A), LinearSchedule(0.5, 0.1, 100), 0.05)
+    pol.change_phase(RunPhase.TRAIN)
+    q = rng.randn(300, A).astype(np.float32)
+    q[5] = q[5, 0]                      # full tie
+    q[9, 2] = q[9].max()                # partial tie
+    np.random.seed(4)
+    pol.current_random_value = np.random.rand()
+    acts, eps, explore_u, rand_act, tie = [], [], [], [], []
+    for i in range(300):
+        e = pol.epsilon_schedule.current_value
+        eps.append(e); explore_u.append(pol.current_random_value)
+        st = np.random.get_state()
+        if pol.current_random_value < e:
+            rand_act.append(np.random.choice(A)); tie.append(np.zeros(A))
+        else:
+            rand_act.append(-1); tie.append(np.random.random(A))
+        np.random.set_state(st)
+        acts.append(pol.get_action(q[i])[0])
+    out["eg_q"], out["eg_actions"], out["eg_eps"] = q, np.array(acts), np.array(eps)
+    out["eg_explore_u"], out["eg_rand_act"], out["eg_tie"] = np.array(explore_u), np.array(rand_act), np.array(tie)
+    # --- additive gaussian noise (continuous)
+    D = 6
+    space = BoxActionSpace(D, -1.0, 1.0)
+    pol = AdditiveNoise(space, ConstantSchedule(0.1), 0.05)
+    pol.change_phase(RunPhase.TRAIN)
+    mean = np.tanh(rng.randn(50, D)).astype(np.float32)
+    np.random.seed(6)
+    z = np.random.standard_normal((50, D))
+    np.random.seed(6)
+    out["an_mean"], out["an_z"] = mean, z
+    out["an_std"] = 0.1 * (space.high - space.low)
+    out["an_actions"] = np.array([pol.get_action(m) for m in mean])
+    _save("explore", **out)
+
+
 GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets}
+          "targets": gen_targets, "explore": gen_explore}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,151 @@
+"""Exploration policies, the synthetic vector env and the head-loss kernels."""
+import numpy as np
+import pytest
+
+from oracle import explore as E
+from oracle import losses as L
+from oracle import nn as N
+from oracle import synth_env as S
+from tests.util import dev_tensor, status_tensor
+
+
+# ------------------------------------------------------------------------------------ CPU
+def test_oracle_exploration_matches_reference(golden):
+    g = golden("explore")
+    acts = [E.categorical_choice(p, u) for p, u in zip(g["cat_probs"], g["cat_u"])]
+    assert acts == g["cat_actions"].tolist()
+    acts = [E.egreedy_choice(q, u, ra, tie, eps) for q, u, ra, tie, eps in
+            zip(g["eg_q"], g["eg_explore_u"], g["eg_rand_act"], g["eg_tie"], g["eg_eps"])]
+    assert acts == g["eg_actions"].tolist()
+    a = E.gaussian_action(g["an_mean"], g["an_std"], g["an_z"])
+    assert np.array_equal(a, g["an_actions"])
+
+
+def test_oracle_philox_known_answers():
+    """Random123 kat_vectors, philox4x32 with 10 rounds."""
+    def run(c, k):
+        r = S.philox4x32_10(*[np.array([x], dtype=np.uint64) for x in c], k[0], np.array([k[1]], dtype=np.uint64))
+        return [int(x[0]) for x in r]
+    assert run((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run((0xffffffff,) * 4, (0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_oracle_synth_env_statistics():
+    env = S.SynthVecEnv(0, 3, 84 * 84, 5, 7)
+    first = env.reset()
+    assert first.shape == (3, 7056) and first.dtype == np.uint8
+    assert 120 < first.mean() < 135                       # uniform bytes
+    dones = []
+    for _ in range(11):
+        nxt, rst, rew, done = env.step()
+        dones.append(done.copy())
+        assert set(np.unique(rew)) <= {-1.0, 0.0, 1.0}
+    assert np.array(dones)[:, 0].tolist() == [False] * 4 + [True] + [False] * 4 + [True] + [False]
+    v = S.SynthVecEnv(1, 2, 4096, 4, 7).reset()
+    assert abs(v.std() - 1.0) < 0.05 and abs(v.mean()) < 0.05
+
+
+# ------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_exploration_matches_reference(golden, rlx, dev):
+    import torch
+    g = golden("explore")
+    n, A = g["cat_probs"].shape
+    acts = torch.empty(n, dtype=torch.int32, device=dev)
+    rlx.categorical_sample(dev_tensor(g["cat_probs"], dev), A, dev_tensor(g["cat_u"], dev), n, A, acts, 0)
+    assert acts.cpu().numpy().tolist() == g["cat_actions"].tolist()
+    # e-greedy: epsilon changes per call in the trace -> one launch per distinct epsilon value
+    q = g["eg_q"]
+    n, A = q.shape
+    out = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        a = torch.empty(1, dtype=torch.int32, device=dev)
+        rlx.egreedy(dev_tensor(q[i:i + 1], dev), A, dev_tensor(g["eg_explore_u"][i:i + 1], dev),
+                    dev_tensor(np.maximum(g["eg_rand_act"][i:i + 1], 0), dev, np.int32),
+                    dev_tensor(g["eg_tie"][i:i + 1], dev), float(g["eg_eps"][i]), 1, A, a, 0)
+        out[i] = a.item()
+    assert out.tolist() == g["eg_actions"].tolist()
+    mean = g["an_mean"]
+    B, D = mean.shape
+    o = torch.empty(B, D, dtype=torch.float32, device=dev)
+    rlx.gaussian_action(dev_tensor(mean, dev), dev_tensor(g["an_std"], dev, np.float32), None,
+                        dev_tensor(g["an_z"], dev), None, None, B, D, o, 0)
+    np.testing.assert_allclose(o.cpu().numpy(), g["an_actions"].astype(np.float32), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n_env,obs_elems,L", [(0, 5, 84 * 84, 4), (1, 7, 17, 3), (1, 3, 376, 1000)])
+def test_hip_synth_env_bit_exact_with_oracle(rlx, dev, kind, n_env, obs_elems, L):
+    import torch
+    dt = torch.uint8 if kind == 0 else torch.float32
+    obs = torch.empty(n_env, obs_elems, dtype=dt, device=dev)
+    nxt, rst = torch.empty_like(obs), torch.zeros_like(obs)
+    rew = torch.empty(n_env, dtype=torch.float32, device=dev)
+    done = torch.empty(n_env, dtype=torch.uint8, device=dev)
+    ep = torch.empty(n_env, dtype=torch.int32, device=dev)
+    t = torch.empty(n_env, dtype=torch.int32, device=dev)
+    o = S.SynthVecEnv(kind, n_env, obs_elems, L, 1234, env_id0=64)
+    rlx.synth_env_reset(kind, obs, ep, t, n_env, obs_elems, 1234, 64, 0)
+    assert np.array_equal(obs.cpu().numpy(), o.reset())
+    for s in range(9):
+        rlx.synth_env_step(kind, nxt, rst, rew, done, ep, t, n_env, obs_elems, L, 1234, 64, 0)
+        on, orst, orew, odone = o.step()
+        assert np.array_equal(nxt.cpu().numpy(), on)
+        assert np.array_equal(rew.cpu().numpy(), orew)
+        assert np.array_equal(done.cpu().numpy().astype(bool), odone)
+        d = odone
+        assert np.array_equal(rst.cpu().numpy()[d], orst[d])
+        assert np.array_equal(ep.cpu().numpy(), o.ep) and np.array_equal(t.cpu().numpy(), o.t)
+
+
+@pytest.mark.gpu
+def test_hip_loss_kernels_vs_oracle_and_reference_kat(rlx, dev):
+    import torch
+    rng = np.random.RandomState(12)
+    # reference KAT (mxnet test_ppo_head.py:363-376): surrogate = -0.142857153
+    new = np.array([[0.9, 0.1], [0.2, 0.8], [0.4, 0.6]], dtype=np.float32)
+    old = np.array([[0.7, 0.3], [0.2, 0.8], [0.4, 0.6]], dtype=np.float32)
+    sc = torch.zeros(4, dtype=torch.float32, device=dev)
+    st = status_tensor(dev)
+    rlx.ppo_discrete_loss(dev_tensor(np.log(new), dev), 2, dev_tensor([0, 1, 0], dev, np.int32),
+                          dev_tensor([-2, 2, 1], dev, np.float32), dev_tensor(old, dev), 2, 3, 2, 0.2, 0.0, 1.0,
+                          None, 2, sc, None, None, st, 0)
+    np.testing.assert_allclose(sc[0].item(), -0.142857153, rtol=2e-6)
+    for B, A, beta in ((64, 6, 0.01), (1, 2, 0.0), (1000, 18, 0.05)):
+        logits = rng.randn(B, A).astype(np.float32)
+        oldp = N.softmax(logits + 0.5 * rng.randn(B, A).astype(np.float32))
+        acts = rng.randint(0, A, size=B)
+        adv = rng.randn(B).astype(np.float32)
+        ref = L.ppo_discrete_loss(logits, acts, adv, oldp, 0.2, beta)
+        dl = torch.empty(B, A, dtype=torch.float32, device=dev)
+        ratio = torch.empty(B, dtype=torch.float32, device=dev)
+        clipped = torch.empty(B, dtype=torch.float32, device=dev)
+        rlx.ppo_discrete_loss(dev_tensor(logits, dev), A, dev_tensor(acts, dev, np.int32), dev_tensor(adv, dev),
+                              dev_tensor(oldp, dev), A, B, A, 0.2, beta, 1.0, dl, A, sc, ratio, clipped, st, 0)
+        np.testing.assert_allclose(sc.cpu().numpy(), [ref["surrogate"], ref["entropy"], ref["kl"], ref["total"]],
+                                   rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(dl.cpu().numpy(), ref["dlogits"], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(ratio.cpu().numpy(), ref["ratio"], rtol=1e-5)
+        np.testing.assert_allclose(clipped.cpu().numpy(), ref["clipped"], rtol=1e-5)
+        probs = torch.empty(B, A, dtype=torch.float32, device=dev)
+        rlx.softmax(dev_tensor(logits, dev), A, B, A, probs, A, 0)
+        np.testing.assert_allclose(probs.cpu().numpy(), N.softmax(logits), rtol=1e-5, atol=1e-8)
+    for kind, name in ((0, "mse"), (1, "huber")):
+        B, D = 33, 5
+        out = (rng.randn(B, D) * 2).astype(np.float32)
+        tgt = rng.randn(B, D).astype(np.float32)
+        w = rng.rand(B).astype(np.float32)
+        ref_l, ref_g = L.regression_head_loss(out, tgt, w, name, 0.5)
+        g = torch.empty(B, D, dtype=torch.float32, device=dev)
+        l = torch.zeros(1, dtype=torch.float32, device=dev)
+        rlx.regression_loss(dev_tensor(out, dev), D, dev_tensor(tgt, dev), D, dev_tensor(w, dev), B, D, kind,
+                            0.5, 1.0, g, D, l, 0)
+        np.testing.assert_allclose(l.item(), ref_l, rtol=1e-5)
+        np.testing.assert_allclose(g.cpu().numpy(), ref_g, rtol=1e-5, atol=1e-8)
+    assert int(st.item()) == 0
+    rlx.ppo_discrete_loss(dev_tensor(np.log(new), dev), 2, dev_tensor([0, 5, 0], dev, np.int32),
+                          dev_tensor([-2, 2, 1], dev, np.float32), dev_tensor(old, dev), 2, 3, 2, 0.2, 0.0, 1.0,
+                          None, 2, sc, None, None, st, 0)
+    assert int(st.item()) == 1
