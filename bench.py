@@ -65,6 +65,8 @@ def gemm_roofline(agent, reps=20):
     saved_graphs = agent.use_graphs
     agent.use_graphs = False
     _rlx.GEMM_HOOK = recorded.append
+    saved_steps = agent.memory.steps
+    agent.memory.steps = agent.steps_per_phase      # the (cleaned) rollout's rows are still in HBM
     try:
         # one eager minibatch update on the buffers left over from the last training phase
         agent._minibatch_fb(BATCH, 1.0)
@@ -72,6 +74,7 @@ def gemm_roofline(agent, reps=20):
     finally:
         _rlx.GEMM_HOOK = None
         agent.use_graphs = saved_graphs
+        agent.memory.steps = saved_steps
     torch.cuda.synchronize()
     stream = _rlx.current_stream()
     ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()

@@ -198,6 +198,7 @@ class GemmDesc(ctypes.Structure):
         ("A", ctypes.c_void_p), ("a_row_tab", ctypes.c_void_p), ("a_k_tab", ctypes.c_void_p),
         ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
         ("deriv_aux", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+        ("colsum_out", ctypes.c_void_p),
         ("a_row_stride", ctypes.c_longlong), ("a_k_stride", ctypes.c_longlong),
         ("a_batch_stride", ctypes.c_longlong),
         ("b_k_stride", ctypes.c_longlong), ("b_n_stride", ctypes.c_longlong),
@@ -205,7 +206,7 @@ class GemmDesc(ctypes.Structure):
         ("ldc", ctypes.c_longlong), ("c_batch_stride", ctypes.c_longlong),
         ("bias_batch_stride", ctypes.c_longlong),
         ("aux_ld", ctypes.c_longlong), ("aux_batch_stride", ctypes.c_longlong),
-        ("workspace_floats", ctypes.c_longlong),
+        ("workspace_floats", ctypes.c_longlong), ("colsum_batch_stride", ctypes.c_longlong),
         ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int),
         ("a_is_u8", ctypes.c_int), ("a_vec_along_k", ctypes.c_int), ("a_tab_vec_ok", ctypes.c_int),
         ("activation", ctypes.c_int), ("deriv_kind", ctypes.c_int), ("accumulate", ctypes.c_int),
@@ -225,7 +226,7 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
          a_vec_along_k=1, a_tab_vec_ok=0, b_strides=None, ldc=None, bias=None, activation=None,
          deriv_aux=None, aux_ld=None, deriv_kind=None, accumulate=False, batch=1,
          a_batch_stride=0, b_batch_stride=0, c_batch_stride=0, bias_batch_stride=0,
-         aux_batch_stride=0, workspace=None, stream=None):
+         aux_batch_stride=0, workspace=None, colsum_out=None, colsum_batch_stride=0, stream=None):
     """Thin wrapper building an rlx_gemm_desc.  a_strides=(row, k), b_strides=(k, n) in elements."""
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = int(M), int(N), int(K), int(batch)
@@ -245,6 +246,7 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
     d.aux_ld = int(N if aux_ld is None else aux_ld)
     d.aux_batch_stride = int(aux_batch_stride)
     d.workspace = _ptr(workspace)
+    d.colsum_out, d.colsum_batch_stride = _ptr(colsum_out), int(colsum_batch_stride)
     d.workspace_floats = int(workspace.numel()) if workspace is not None else 0
     d.a_is_u8, d.a_div = int(bool(a_u8)), float(a_div)
     d.a_vec_along_k, d.a_tab_vec_ok = int(a_vec_along_k), int(a_tab_vec_ok)

@@ -50,6 +50,9 @@ struct GemmDev {
     const float *aux;           // epilogue multiplies by act'(aux[m][n])
     long long aux_ld, aux_batch_stride;
     float *ws;                  // split-K partials [batch][split][M][N]
+    float *colsum;              // optional: colsum[n] = sum_k B[k][n] (bias gradient), per batch
+    float *ws_colsum;           // split-K partials of the column sums [batch][split][N]
+    long long colsum_batch_stride;
     int M, N, K;
     int splits, kchunk;
     int act, deriv, accumulate;
@@ -190,6 +193,10 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(const GemmDev g) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // bias gradient rides along: the first row of workgroups also sums the columns of every B slab
+    // it stages (db = 1^T dz costs no extra HBM traffic and no extra launch)
+    const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
+    float csum = 0.f;
 
     if (kbeg < kend) {
         load_tiles(kbeg);
@@ -206,12 +213,25 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(const GemmDev g) {
                 const float b = bp[kk * LDB_S];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
+            if (do_colsum) {
+                float sc = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) sc += Bs[kk * LDB_S + tid];
+                csum += sc;
+            }
             __syncthreads();
             if (more) {
                 store_tiles();
                 __syncthreads();
             }
         }
+    }
+
+    if (do_colsum && n0 + tid < g.N) {
+        if (g.splits > 1)
+            g.ws_colsum[((size_t)batch * g.splits + split) * g.N + n0 + tid] = csum;
+        else
+            g.colsum[(size_t)batch * g.colsum_batch_stride + n0 + tid] = csum;
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -257,6 +277,13 @@ __global__ void splitk_reduce_kernel(const GemmDev g) {
         if (aux) v *= act_deriv(aux[(size_t)row * g.aux_ld + col], g.deriv);
         float *dst = &c[(size_t)row * g.ldc + col];
         *dst = g.accumulate ? *dst + v : v;
+    }
+    if (g.colsum) {
+        for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < g.N; n += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int k = 0; k < g.splits; ++k) s += g.ws_colsum[((size_t)batch * g.splits + k) * g.N + n];
+            g.colsum[(size_t)batch * g.colsum_batch_stride + n] = s;
+        }
     }
 }
 
@@ -358,7 +385,7 @@ int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_
     RLX_REQUIRE(floats_host && M > 0 && N > 0 && K > 0 && batch > 0,
                 "rlx_gemm_workspace_floats: bad arguments");
     // upper bound used by rlx_gemm's split heuristic (at most 64 splits)
-    *floats_host = (long long)M * N * batch * 64;
+    *floats_host = ((long long)M * N + N) * batch * 64;   /* + column-sum partials */
     return RLX_OK;
 }
 
@@ -386,6 +413,7 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     g.aux = d.deriv_aux; g.aux_ld = d.aux_ld; g.aux_batch_stride = d.aux_batch_stride;
     g.act = d.activation; g.deriv = d.deriv_kind; g.accumulate = d.accumulate;
     g.a_div = d.a_is_u8 ? d.a_div : 1.f;
+    g.colsum = d.colsum_out; g.colsum_batch_stride = d.colsum_batch_stride; g.ws_colsum = nullptr;
 
     // vector dimension of each operand: the index whose stride is 1 (tables: declared by caller)
     const bool a_vec_red = d.a_row_tab || d.a_k_tab ? (d.a_vec_along_k != 0) : (d.a_k_stride == 1);
@@ -415,13 +443,14 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
         splits = want < max_by_k ? want : max_by_k;
         if (splits > 64) splits = 64;
         if (splits < 1) splits = 1;
-        while (splits > 1 && (long long)d.M * d.N * d.batch * splits > d.workspace_floats) --splits;
+        while (splits > 1 && ((long long)d.M * d.N + d.N) * d.batch * splits > d.workspace_floats) --splits;
     }
     int kchunk = ((d.K + splits - 1) / splits + BK - 1) / BK * BK;
     splits = (d.K + kchunk - 1) / kchunk;
     g.splits = splits;
     g.kchunk = kchunk;
     g.ws = d.workspace;
+    if (splits > 1) g.ws_colsum = d.workspace + (size_t)d.M * d.N * d.batch * splits;
 
     hipStream_t s = rlx::as_stream(stream);
     dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * splits);

@@ -201,12 +201,11 @@ class Dense(Layer):
         if self.act is not None:                      # dz = dy * act'(y), in place
             ctx.lib.act_backward(dz, y.data, dz.numel(), _rlx.ACT[self.act], ctx.stream)
         # dW[K,N] = x^T dz : A(k, m) = x[m, k]
+        # (db = column sums of dz, accumulated by the same launch from the staged B slabs)
         _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
                   a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
-                  c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk)
-        for t in range(T):
-            ctx.lib.colsum(dz[t], M, self.N, self.N, p.g(self.bname, t0 + t), 0, ctx.ws.small,
-                           ctx.ws.small.numel(), ctx.stream)
+                  c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
+                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
         if need_dx:
             assert x.towers == T, "input gradients need a per-tower input"
             dx = x.ensure_grad()
@@ -279,10 +278,8 @@ class Conv2d(Layer):
         _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
                   a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
                   a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
-                  c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk)
-        for t in range(T):
-            ctx.lib.colsum(dz[t], M, self.Co, self.Co, p.g(self.bname, t0 + t), 0, ctx.ws.small,
-                           ctx.ws.small.numel(), ctx.stream)
+                  c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
+                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
         if need_dx:
             assert x.towers == T
             dcol = ctx.buffer(self.name + "/dcol", (T, M, self.K))

@@ -182,11 +182,13 @@ typedef struct rlx_gemm_desc {
     const float *bias;        /* [N] or NULL */
     const float *deriv_aux;   /* [M, aux_ld] or NULL */
     float *workspace;         /* split-K partials, or NULL to forbid splitting */
+    float *colsum_out;        /* optional [N]: sum_k B[k][n] (the bias gradient rides on the dW GEMM) */
     long long a_row_stride, a_k_stride, a_batch_stride;
     long long b_k_stride, b_n_stride, b_batch_stride;
     long long ldc, c_batch_stride, bias_batch_stride;
     long long aux_ld, aux_batch_stride;
     long long workspace_floats;
+    long long colsum_batch_stride;
     int M, N, K, batch;
     int a_is_u8;              /* A holds bytes; value = byte / a_div (embedders/embedder.py:107-108) */
     int a_vec_along_k;        /* with tables: 1 = 4 consecutive k are contiguous, 0 = 4 consecutive m */
