@@ -1,0 +1,260 @@
+"""Shared machinery of the off-policy vector agents: N lockstep envs per GPU, device replay,
+training cadence, target-network cadence, episode statistics, hipGraph replay of the update.
+
+Mirrors the scheduling half of rl_coach/agents/agent.py for N envs stepping in lockstep:
+  * Agent.act (:775-840): HEATUP draws uniform random actions (:838-840), TRAIN asks the agent;
+  * Agent.observe / observe_transition (:905-973): reward filters, episode accumulation, store;
+  * Agent._should_train / train (:662-770): a training phase every
+    ``num_consecutive_playing_steps`` env-steps, ``num_consecutive_training_steps`` sampled batches
+    per phase; target-network cadence by EnvironmentSteps or TrainingSteps (:640-660).
+One vector step advances the step counters by n_env, so a vector step opens
+n_env / num_consecutive_playing_steps training phases — the updates-per-env-step ratio of the
+reference is preserved; with n_env = 1 the call order, including every host RNG
+draw, is the reference's.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+from .. import _rlx
+from ..core_types import EnvironmentSteps, RunPhase, TrainingSteps
+
+
+def capture(fn):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
+class GraphRunner(object):
+    """Run a pure-device call sequence eagerly once (allocations), capture it into a hipGraph the
+    second time, replay afterwards.  RLX_NO_GRAPHS=1 keeps everything eager."""
+
+    def _init_graphs(self, use_graphs=None):
+        if use_graphs is None:
+            use_graphs = os.environ.get("RLX_NO_GRAPHS", "0") != "1"
+        self.use_graphs = use_graphs
+        self._graphs, self._warm = {}, set()
+
+    def _run(self, key, fn):
+        if not self.use_graphs:
+            return fn()
+        g = self._graphs.get(key)
+        if g is not None:
+            return g.replay()
+        if key not in self._warm:
+            self._warm.add(key)
+            return fn()
+        torch.cuda.synchronize()
+        self._graphs[key] = capture(fn)
+        return self._graphs[key].replay()
+
+
+class AlgorithmParameters(object):                       # base_parameters.py:170-230 (hot-path fields)
+    def __init__(self):
+        self.discount = 0.99
+        self.num_consecutive_playing_steps = EnvironmentSteps(1)
+        self.num_consecutive_training_steps = 1
+        self.heatup_using_network_decisions = False
+        self.num_steps_between_copying_online_weights_to_target = TrainingSteps(0)
+        self.rate_for_copying_weights_to_target = 1.0
+        self.act_for_full_episodes = False
+        self.reward_clipping = None                      # RewardClippingFilter bounds or None
+        self.reward_rescale = 1.0                        # RewardRescaleFilter factor
+
+
+class VectorOffPolicyAgent(GraphRunner):
+    continuous = False
+
+    def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
+        self.ap = agent_parameters
+        self.env = environment
+        self.device = device or environment.device
+        self.dist = dist if (dist is not None and dist.enabled) else None
+        self.lib = _rlx.lib()
+        self._init_graphs(use_graphs)
+        ep = environment.p
+        self.n_env = ep.num_envs
+        self.image = ep.kind == "image"
+        self.stack = 4 if self.image else None
+        self.L = ep.episode_length
+        if self.ap.seed is not None:                     # agents/agent.py:49-55
+            random.seed(self.ap.seed)
+            np.random.seed(self.ap.seed)
+        self.phase = RunPhase.HEATUP
+        self.total_steps_counter = 0
+        self.training_iteration = 0
+        self.last_training_phase_step = 0
+        self.last_target_network_update_step = 0
+        self.current_episode_steps_counter = 0
+        dev, n = self.device, self.n_env
+        self.filtered_reward = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.ep_return = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.ep_len = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.ep_acc = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.lib.episode_stats_init(self.ep_return, self.ep_len, n, self.ep_acc, _rlx.current_stream())
+        self.signals = {}
+        self._pins = {}
+        self.debug_draws = None          # tests set these to lists to record every replay draw /
+        self.debug_losses = None         # every update's loss (forces a sync per update)
+
+    # ------------------------------------------------------------------ helpers for subclasses
+    def _finish_init(self):
+        """after the networks exist: rank-offset sampling seed (coach.py:746) and the first obs."""
+        if self.dist is not None and self.ap.seed is not None:
+            random.seed(self.ap.seed + self.dist.rank)
+            np.random.seed(self.ap.seed + self.dist.rank)
+        self.memory.reset(self.env.reset_internal_state())
+
+    def _make_memory(self, action_dim=None):
+        mp = self.ap.memory
+        from ..memories.non_episodic.prioritized_experience_replay import (
+            PrioritizedExperienceReplay, PrioritizedExperienceReplayParameters)
+        from ..memories.non_episodic.experience_replay import ExperienceReplay
+        ep = self.env.p
+        kw = dict(device=self.device, n_env=self.n_env, observation_shape=ep.observation_shape,
+                  stack=self.stack, action_dim=action_dim, min_episode_length=self.L)
+        if isinstance(mp, PrioritizedExperienceReplayParameters):
+            return PrioritizedExperienceReplay(mp.max_size, mp.alpha, mp.beta, mp.epsilon,
+                                               mp.allow_duplicates_in_batch_sampling,
+                                               exact_pow=getattr(mp, "exact_pow", False), **kw)
+        return ExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling, **kw)
+
+    def _to_device(self, key, array, dtype):
+        """host draws -> device through a cached pinned staging buffer."""
+        a = np.ascontiguousarray(array)
+        ent = self._pins.get(key)
+        if ent is None or ent[0].shape != a.shape:
+            host = torch.zeros(a.shape, dtype=dtype)
+            if torch.cuda.is_available():
+                host = host.pin_memory()
+            ent = (host, torch.zeros(a.shape, dtype=dtype, device=self.device))
+            self._pins[key] = ent
+        ent[0].copy_(torch.from_numpy(a))
+        ent[1].copy_(ent[0], non_blocking=True)
+        return ent[1]
+
+    # --------------------------------------------------------------------------------- acting
+    def random_actions(self):
+        raise NotImplementedError
+
+    def choose_action(self, states):
+        raise NotImplementedError
+
+    def act(self):
+        """One vector step of LevelManager.step (level_manager.py:215-269) for n_env envs."""
+        alg = self.ap.algorithm
+        s = _rlx.current_stream()
+        states = self.memory.current_states()
+        if self.phase == RunPhase.HEATUP and not alg.heatup_using_network_decisions:
+            actions = self.random_actions()                                    # agent.py:838-840
+        else:
+            actions = self.choose_action(states)
+        next_obs, reset_obs, reward, game_over = self.env.step(actions)
+        has_clip = alg.reward_clipping is not None
+        lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
+        self.lib.reward_filter(reward, self.filtered_reward, self.n_env, alg.reward_rescale,
+                               int(has_clip), lo, hi, s)
+        record = self.phase != RunPhase.TEST
+        if record:
+            self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,
+                                        self.n_env, self.ep_acc, None, None, s)
+        self.memory.store(actions, self.filtered_reward, self._stored_game_over(game_over), next_obs,
+                          reset_obs, record=record)
+        self.env.total_steps += self.n_env
+        self.current_episode_steps_counter += 1
+        episode_ended = self.current_episode_steps_counter >= self.L
+        if episode_ended:
+            self.current_episode_steps_counter = 0
+            self.handle_episode_ended()
+        if self.phase != RunPhase.TEST:                                        # agent.py:832-834
+            self.total_steps_counter += self.n_env
+        return episode_ended
+
+    def _stored_game_over(self, game_over):
+        return game_over
+
+    def handle_episode_ended(self):
+        pass
+
+    # ------------------------------------------------------------------------------- training
+    def _should_update_online_weights_to_target(self):                        # agent.py:640-660
+        m = self.ap.algorithm.num_steps_between_copying_online_weights_to_target
+        counter = self.training_iteration if isinstance(m, TrainingSteps) else self.total_steps_counter
+        if not isinstance(m, (TrainingSteps, EnvironmentSteps)):
+            raise ValueError("The num_steps_between_copying_online_weights_to_target parameter should be "
+                             "either EnvironmentSteps or TrainingSteps. Instead it is {}".format(type(m)))
+        if (counter - self.last_target_network_update_step) >= m.num_steps:
+            self.last_target_network_update_step = counter
+            return True
+        return False
+
+    def _training_phases_due(self):
+        """agent.py:662-699 for a step counter that advances n_env at a time."""
+        steps = self.ap.algorithm.num_consecutive_playing_steps.num_steps
+        if self.memory.num_transitions() <= 0:
+            return 0
+        gap = self.total_steps_counter - self.last_training_phase_step
+        if gap < steps:
+            return 0
+        # the reference opens ONE phase per check and resets the marker to the current step
+        # (:673-677); a vector step is n_env checks' worth of env-steps
+        due = min(gap // steps, max(1, self.n_env // steps))
+        self.last_training_phase_step = self.total_steps_counter
+        return due
+
+    def update_target_networks(self, rate):
+        for net in self.networks.values():
+            if net.target is not None:
+                net.update_target(rate)
+
+    def train(self):
+        """Agent.train (agent.py:701-770): returns the summed loss of the phases run (device
+        scalar) or None when no phase was due."""
+        if self.phase != RunPhase.TRAIN:
+            return None
+        phases = self._training_phases_due()
+        if phases == 0:
+            return None
+        alg = self.ap.algorithm
+        B = self.batch_size
+        total = None
+        for _ in range(phases):
+            # every batch of the phase is drawn first (agent.py:726), then learned from in turn; a
+            # collated DeviceBatch aliases the memory's static buffers, so collation is per batch
+            draws = [self.memory.draw(B) for _ in range(self._training_steps_this_phase())]
+            for d in draws:
+                self.training_iteration += 1
+                batch = self.memory.collate(d, B)
+                if self.debug_draws is not None:      # sampled logical indices / PER leaves
+                    self.debug_draws.append(batch.info("idx").cpu().numpy().copy()
+                                            if "idx" in batch._info else np.asarray(d).copy())
+                loss = self.learn_from_batch(batch)
+                if self.debug_losses is not None:
+                    self.debug_losses.append(float(loss.sum().item()))
+                total = loss if total is None else total + loss
+                if any(n.target is not None for n in self.networks.values()) and \
+                        self._should_update_online_weights_to_target():
+                    self.update_target_networks(alg.rate_for_copying_weights_to_target)
+        return total
+
+    def _training_steps_this_phase(self):
+        return self.ap.algorithm.num_consecutive_training_steps
+
+    def learn_from_batch(self, batch):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------------------ reporting
+    def episode_statistics(self):
+        a = self.ep_acc.cpu().numpy()
+        n = max(a[0], 1.0)
+        return {"episodes": int(a[0]), "mean_return": a[1] / n, "max_return": a[3], "min_return": a[4],
+                "mean_length": a[5] / n}
+
+    def check_status(self):
+        self.memory.check_status()
+        for net in self.networks.values():
+            net.check_status()

@@ -1,0 +1,71 @@
+"""Epsilon-greedy for N lockstep envs — mirror of rl_coach/exploration_policies/e_greedy.py
+(EGreedyParameters :28-46, EGreedy.get_action :84-101, step_epsilon :112-117).
+
+Every env keeps its own ``current_random_value`` exactly like one reference policy instance; the
+host makes each env's draws from the global legacy np.random stream in env order
+(explore: ``action_space.sample()`` = np.random.choice(n); greedy: np.random.random(n) for the
+tie-break; then np.random.rand() for the next step), the device applies them to the Q values
+(rlx_egreedy).
+"""
+import numpy as np
+import torch
+
+from .. import _rlx
+from ..core_types import RunPhase
+from ..schedules import LinearSchedule
+
+
+class EGreedyParameters(object):                         # e_greedy.py:28-46
+    def __init__(self):
+        self.epsilon_schedule = LinearSchedule(0.5, 0.01, 50000)
+        self.evaluation_epsilon = 0.05
+
+    @property
+    def path(self):
+        return 'coach_amd.exploration_policies.e_greedy:EGreedy'
+
+
+class EGreedy(object):
+    def __init__(self, num_actions, n_env, device, params):
+        self.A, self.n_env, self.device = num_actions, n_env, device
+        self.epsilon_schedule = params.epsilon_schedule
+        self.evaluation_epsilon = params.evaluation_epsilon
+        self.phase = RunPhase.HEATUP
+        self.lib = _rlx.lib()
+        self.current_random_value = np.array([np.random.rand() for _ in range(n_env)])   # :82
+        pin = torch.cuda.is_available()
+        mk = lambda shape, dt: (torch.zeros(shape, dtype=dt).pin_memory() if pin else torch.zeros(shape, dtype=dt))
+        self._h = dict(u=mk((n_env,), torch.float64), ra=mk((n_env,), torch.int32),
+                       tie=mk((n_env, num_actions), torch.float64))
+        self._d = {k: torch.zeros_like(v, device=device) for k, v in self._h.items()}
+
+    def epsilon(self):
+        return self.evaluation_epsilon if self.phase == RunPhase.TEST else self.epsilon_schedule.current_value
+
+    def draw(self):
+        """Host draws of one vector step, env by env, in the reference's per-call order."""
+        eps = self.epsilon()
+        u = self.current_random_value.copy()
+        ra = np.zeros(self.n_env, dtype=np.int32)
+        tie = np.zeros((self.n_env, self.A))
+        nxt = np.empty(self.n_env)
+        for e in range(self.n_env):
+            if u[e] < eps:
+                ra[e] = np.random.choice(self.A)                  # action_space.sample() (:89)
+            else:
+                tie[e] = np.random.random(self.A)                 # :93
+            if self.phase == RunPhase.TRAIN:
+                self.epsilon_schedule.step()                      # step_epsilon (:112-117)
+            nxt[e] = np.random.rand()
+        self.current_random_value = nxt
+        return eps, u, ra, tie
+
+    def get_action(self, q_values, draws, out_actions):
+        eps, u, ra, tie = draws
+        h, d = self._h, self._d
+        h["u"].copy_(torch.from_numpy(u)); h["ra"].copy_(torch.from_numpy(ra)); h["tie"].copy_(torch.from_numpy(tie))
+        for k in h:
+            d[k].copy_(h[k], non_blocking=True)
+        self.lib.egreedy(q_values, self.A, d["u"], d["ra"], d["tie"], float(eps), self.n_env, self.A,
+                         out_actions, _rlx.current_stream())
+        return out_actions

@@ -1,0 +1,227 @@
+"""Uniform experience replay in HBM — the ``ExperienceReplay`` plug point
+(rl_coach/memories/non_episodic/experience_replay.py:28-150) for N lockstep envs per GPU.
+
+The reference keeps a Python list of Transition objects (append + ``del list[0]`` FIFO) and samples
+``np.random.randint(num_transitions, size=B)`` on the global legacy RandomState (:81).  Here:
+
+  * rows live in a struct-of-arrays ring; logical index i of the reference's list (i-th oldest) is
+    physical row (head + i) % capacity, so the SAME host draw selects the SAME transition;
+  * the host makes the draw with the same generator (bit-exact index selection), ships B int32 and
+    one launch (rlx_copy_columns / rlx_imgreplay_gather) collates the whole Batch
+    (core_types.py:488-649) on the device;
+  * ``store`` takes the n_env transitions of one vector step, in env order — what n_env sequential
+    ``store(transition)`` calls would append.
+
+Image observations use the frame-dedup ring of rlx_imgreplay_* (each 84x84 frame stored once per
+env; a 4-stack is materialised only when gathered): a 1 M-transition Atari buffer is
+~7-14 GB of HBM instead of 56 GB of stacked states.
+"""
+import numpy as np
+import torch
+
+from ... import _rlx
+from ...core_types import DeviceBatch
+from ..memory import Memory, MemoryGranularity, MemoryParameters
+
+
+class ExperienceReplayParameters(MemoryParameters):      # experience_replay.py:28-36
+    def __init__(self):
+        super().__init__()
+        self.max_size = (MemoryGranularity.Transitions, 1000000)
+        self.allow_duplicates_in_batch_sampling = True
+
+    @property
+    def path(self):
+        return 'coach_amd.memories.non_episodic.experience_replay:ExperienceReplay'
+
+
+class ExperienceReplay(Memory):
+    def __init__(self, max_size, allow_duplicates_in_batch_sampling=True, device=None, n_env=1,
+                 observation_shape=None, stack=None, action_dim=None, min_episode_length=1):
+        """
+        :param max_size: (MemoryGranularity.Transitions, n)                    (reference signature)
+        :param allow_duplicates_in_batch_sampling: sample with replacement      (reference signature)
+        :param n_env: envs stepping in lockstep (a vector step stores n_env rows)
+        :param observation_shape: (D,) vector observations, or (H, W) frames when `stack` is given
+        :param stack: frames per stacked image state (ObservationStackingFilter), None for vectors
+        :param action_dim: None = discrete (int32), else continuous fp32[action_dim]
+        :param min_episode_length: bounds the frames an env adds per stored step (1 + 1/L)
+        """
+        super().__init__(max_size)
+        if max_size[0] != MemoryGranularity.Transitions:                        # :48-49
+            raise ValueError("Experience replay size can only be configured in terms of transitions")
+        if device is None or observation_shape is None:
+            raise ValueError("the device replay needs a device and an observation shape")
+        self.lib = _rlx.lib()
+        self.device, self.n_env = device, int(n_env)
+        self.allow_duplicates_in_batch_sampling = allow_duplicates_in_batch_sampling
+        cap = int(max_size[1])
+        if cap <= 0 or cap % self.n_env:
+            raise ValueError("replay capacity %d must be a positive multiple of the %d lockstep envs"
+                             % (cap, self.n_env))
+        self.cap = cap
+        self.image = stack is not None
+        self.stack = stack
+        dev = device
+        if self.image:
+            self.frame_shape = tuple(observation_shape)
+            self.fb = int(np.prod(observation_shape))
+            per_env = cap // self.n_env
+            self.F = per_env + per_env // max(1, int(min_episode_length)) + stack + 4
+            self.ring = torch.zeros(self.n_env, self.F, self.fb, dtype=torch.uint8, device=dev)
+            self.fpos = torch.zeros(self.n_env, dtype=torch.int32, device=dev)
+            self.epoff = torch.zeros(self.n_env, dtype=torch.int32, device=dev)
+            self.t_fpos = torch.zeros(cap, dtype=torch.int32, device=dev)
+            self.t_epoff = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            self.cur_state = torch.empty((self.n_env,) + self.frame_shape + (stack,),
+                                         dtype=torch.uint8, device=dev)
+            self.state_shape = self.frame_shape + (stack,)
+            self.state_dtype = torch.uint8
+        else:
+            self.obs_dim = int(observation_shape[0])
+            self.obs = torch.zeros(cap, self.obs_dim, dtype=torch.float32, device=dev)
+            self.next_obs = torch.zeros(cap, self.obs_dim, dtype=torch.float32, device=dev)
+            self.cur_state = torch.empty(self.n_env, self.obs_dim, dtype=torch.float32, device=dev)
+            self.state_shape = (self.obs_dim,)
+            self.state_dtype = torch.float32
+        self.action_dim = action_dim
+        self.action = torch.zeros(cap, dtype=torch.int32, device=dev) if action_dim is None else \
+            torch.zeros(cap, action_dim, dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(cap, dtype=torch.float32, device=dev)
+        self.game_over = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cursor = 0          # physical row the next vector step is written to
+        self.count = 0           # len(self.transitions) of the reference
+        self._batches = {}
+        self._pinned = {}
+
+    # ---------------------------------------------------------------- Memory interface (:56-69)
+    def length(self):
+        return self.num_transitions()
+
+    def num_transitions(self):
+        return self.count
+
+    def clean(self):
+        self.cursor = 0
+        self.count = 0
+
+    def head(self):
+        """physical row of logical index 0 (the oldest stored transition)."""
+        return (self.cursor - self.count) % self.cap
+
+    # ------------------------------------------------------------------------------ rollout side
+    def reset(self, first_obs):
+        s = _rlx.current_stream()
+        if self.image:
+            self.lib.imgreplay_reset(self.ring, self.fpos, self.epoff, first_obs, self.n_env, self.F,
+                                     self.fb, s)
+        else:
+            self.cur_state.copy_(first_obs)
+
+    def current_states(self):
+        if self.image:
+            self.lib.imgreplay_gather(self.ring, None, None, self.fpos, self.epoff, None, self.n_env,
+                                      self.n_env, self.F, self.fb, self.stack, self.cap,
+                                      self.cur_state, None, self.status, _rlx.current_stream())
+        return self.cur_state
+
+    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True):
+        """n_env transitions (state = current state of every env), then advance the env states.
+        Reference: ExperienceReplay.store + _enforce_max_length (:117-150) called n_env times.
+        record=False only advances the observation state (evaluation episodes are not stored)."""
+        s = _rlx.current_stream()
+        row0 = self.cursor
+        if record:
+            pairs = [(actions, self.action), (rewards, self.reward), (game_overs, self.game_over)]
+            if not self.image:
+                pairs += [(self.cur_state, self.obs), (next_obs, self.next_obs)]
+            self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), None, None, 0, row0,
+                                  self.n_env, self.cap, self.n_env, self.status, s)
+        if self.image:
+            self.lib.imgreplay_append(self.ring, self.fpos, self.epoff, self.t_fpos, self.t_epoff,
+                                      next_obs, reset_obs, game_overs, self.n_env, self.F, self.fb,
+                                      self.stack, row0, self.cap, int(record), s)
+        else:
+            # the next state of a finished episode is the post-reset observation
+            self.lib.select_rows(game_overs, reset_obs, next_obs, self.cur_state, self.n_env,
+                                 self.obs_dim * 4, s)
+        if record:
+            self.cursor = (self.cursor + self.n_env) % self.cap
+            self.count = min(self.count + self.n_env, self.cap)
+
+    # ----------------------------------------------------------------------------- training side
+    def sample_indices(self, size):
+        """The reference's draw (:80-86) on the global legacy np.random stream -> LOGICAL indices."""
+        if self.allow_duplicates_in_batch_sampling:
+            return np.random.randint(self.num_transitions(), size=size)
+        if self.num_transitions() >= size:
+            return np.random.choice(self.num_transitions(), size=size, replace=False)
+        raise ValueError("The replay buffer cannot be sampled since there are not enough transitions "
+                         "yet. There are currently {} transitions".format(self.num_transitions()))
+
+    def physical_rows(self, logical_idx):
+        return ((self.head() + np.asarray(logical_idx, dtype=np.int64)) % self.cap).astype(np.int32)
+
+    def _batch_buffers(self, size):
+        b = self._batches.get(size)
+        if b is None:
+            dev = self.device
+            b = dict(
+                rows=torch.zeros(size, dtype=torch.int32, device=dev),
+                state=torch.empty((size,) + self.state_shape, dtype=self.state_dtype, device=dev),
+                next_state=torch.empty((size,) + self.state_shape, dtype=self.state_dtype, device=dev),
+                action=torch.empty((size,) if self.action_dim is None else (size, self.action_dim),
+                                   dtype=self.action.dtype, device=dev),
+                reward=torch.empty(size, dtype=torch.float32, device=dev),
+                game_over=torch.empty(size, dtype=torch.uint8, device=dev))
+            self._batches[size] = b
+            host = torch.zeros(size, dtype=torch.int32)
+            self._pinned[size] = host.pin_memory() if torch.cuda.is_available() else host
+        return b
+
+    def gather(self, rows_host, size):
+        """Collate the Batch of the given PHYSICAL rows (one H2D copy of B int32 + 2 launches)."""
+        b = self._batch_buffers(size)
+        pin = self._pinned[size]
+        pin.copy_(torch.from_numpy(np.ascontiguousarray(rows_host, dtype=np.int32)))
+        b["rows"].copy_(pin, non_blocking=True)
+        self.gather_device(b["rows"], size, b)
+        return b
+
+    def gather_device(self, rows, size, b):
+        s = _rlx.current_stream()
+        pairs = [(self.action, b["action"]), (self.reward, b["reward"]), (self.game_over, b["game_over"])]
+        if not self.image:
+            pairs += [(self.obs, b["state"]), (self.next_obs, b["next_state"])]
+        self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), rows, None, 0, 0, self.cap, size,
+                              size, self.status, s)
+        if self.image:
+            self.lib.imgreplay_gather(self.ring, self.t_fpos, self.t_epoff, None, None, rows, size,
+                                      self.n_env, self.F, self.fb, self.stack, self.cap, b["state"],
+                                      b["next_state"], self.status, s)
+
+    def draw(self, size):
+        """The host-RNG half of sample(): made for every batch of a training phase up front, in the
+        reference's order ([sample(B) for _ in range(num_consecutive_training_steps)], agent.py:726)."""
+        return self.sample_indices(size)
+
+    def collate(self, drawn, size):
+        """The device half of sample(): gather the Batch of a draw."""
+        b = self.gather(self.physical_rows(drawn), size)
+        return DeviceBatch(size, {"observation": b["state"]}, {"observation": b["next_state"]},
+                           b["action"], b["reward"], b["game_over"], info={"logical_idx": drawn})
+
+    def sample(self, size):
+        """ExperienceReplay.sample (:71-90) -> DeviceBatch (the Batch the agent would build)."""
+        return self.collate(self.draw(size), size)
+
+    def get(self, index):
+        b = self.gather(self.physical_rows([index]), 1)
+        return {k: v.clone() for k, v in b.items() if k != "rows"}
+
+    def check_status(self):
+        s = int(self.status.item())
+        if s:
+            self.status.zero_()
+            raise IndexError("replay kernel reported an out-of-range row (status bits %d)" % s)

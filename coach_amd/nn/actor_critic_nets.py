@@ -1,0 +1,289 @@
+"""Device-resident networks of the continuous-control agents (DDPG, TD3, SAC).
+
+Topologies (paths under rl_coach/):
+  DDPG actor   agents/ddpg_agent.py:55-70    obs -> embedder -> FC middleware -> DDPGActorHead
+               (heads/ddpg_actor_head.py:48-56: Dense(A) -> tanh -> * max_abs_range)
+  DDPG critic  agents/ddpg_agent.py:36-52    merged = concat(sorted inputs: action, observation
+               embedding) (general_network.py:251,270-277) -> FC middleware -> DDPGVHead Dense(1)
+               (normalized-columns init, heads/ddpg_v_head.py + v_head.py:43-48)
+  TD3 critic   agents/td3_agent.py:36-51     num_streams = 2 FC middlewares on the same merged
+               input, TD3VHead (heads/td3_v_head.py:40-60): Dense(1) per stream, outputs
+               [Q1, Q2, min(Q1,Q2), mean(Q1)], loss = sum_i mean((target - Q_i)^2)
+  SAC policy   agents/soft_actor_critic_agent.py:87-100 + heads/sac_head.py:60-97
+  SAC V        :57-69 + heads/v_head.py (xavier init)
+  SAC Q        :72-84 + heads/sac_q_head.py:46-96: per Q_i relu(W_o s) + relu(W_a a) -> Dense -> Dense(1)
+The twin streams / twin Q networks run as two towers of ONE batched GEMM launch per layer.
+"""
+import numpy as np
+import torch
+
+from .. import _rlx
+from . import graph as G
+from .networks import _NetBase
+
+
+def _mlp(params, prefix, in_features, sizes, activation, towers=1):
+    layers, feat = [], in_features
+    for i, u in enumerate(sizes):
+        layers.append(G.Dense(params, "%s/dense%d" % (prefix, i), feat, u, activation, towers))
+        feat = u
+    return G.Sequential(layers), feat
+
+
+class _ACBase(_NetBase):
+    image = False
+
+    def _obs(self, obs, B):
+        return G.input_tensor(obs, B, self.obs_dim)
+
+
+class ActorNet(_ACBase):
+    """DDPG / TD3 actor: obs -> embedder -> middleware -> Dense(A) -> tanh -> * output_scale."""
+
+    def __init__(self, device, obs_dim, action_dim, output_scale, embedder=(400,), middleware=(300,),
+                 activation="relu", learning_rate=1e-4, adam_beta1=0.9, adam_beta2=0.999,
+                 optimizer_epsilon=1e-8, seed=0):
+        self.obs_dim, self.A = obs_dim, action_dim
+        self.params = G.FlatParams()
+        self.emb, feat = _mlp(self.params, "actor/embedder", obs_dim, embedder, activation)
+        self.mid, feat = _mlp(self.params, "actor/middleware", feat, middleware, activation)
+        self.head = G.Dense(self.params, "actor/ddpg_actor_head/fc_mean", feat, action_dim, "tanh")
+        self.modules = [self.emb, self.mid, self.head]
+        self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
+        self.scale = torch.as_tensor(np.broadcast_to(np.asarray(output_scale, dtype=np.float32),
+                                                     (action_dim,)).copy(), device=device)
+        self._uniform_scale = float(self.scale[0].item()) if bool((self.scale == self.scale[0]).all()) \
+            else None
+        if self._uniform_scale is None:
+            raise NotImplementedError("per-dimension output scale is not implemented")
+
+    def forward(self, obs, B, use_target=False, tag="a", out=None):
+        w = self.target if use_target else None
+        ctx = self.ctx
+        acts = self.emb.forward(ctx, self._obs(obs, B), tag=tag, weights=w)
+        acts2 = self.mid.forward(ctx, acts[-1], tag=tag, weights=w)
+        y = self.head.forward(ctx, acts2[-1], tag=tag, weights=w)
+        out = out if out is not None else ctx.buffer("actions", (B, self.A), tag=tag)
+        self.lib.copy_2d(y.data, self.A, out, self.A, B, self.A, self._uniform_scale, ctx.stream)
+        return out, (acts, acts2, y)
+
+    def backward(self, saved, action_grad, B, grad_scale=1.0):
+        """weighted_gradients[0] with gradients_weights_ph = action_grad (ddpg_agent.py:183-186):
+        d sum(action * action_grad) / d theta -> params.grads."""
+        acts, acts2, y = saved
+        ctx = self.ctx
+        dy = y.ensure_grad()
+        self.lib.copy_2d(action_grad, self.A, dy, self.A, B, self.A, self._uniform_scale * grad_scale,
+                         ctx.stream)
+        self.head.backward(ctx, acts2[-1], y)
+        self.mid.backward(ctx, acts2, need_input_grad=len(self.emb.layers) > 0)
+        self.emb.backward(ctx, acts)
+
+
+class CriticNet(_ACBase):
+    """DDPG critic (streams = 1) / TD3 twin critic (streams = 2)."""
+
+    def __init__(self, device, obs_dim, action_dim, obs_embedder=(400,), middleware=(300,), streams=1,
+                 activation="relu", head_init="normalized_columns", learning_rate=1e-3, adam_beta1=0.9,
+                 adam_beta2=0.999, optimizer_epsilon=1e-8, seed=0):
+        self.obs_dim, self.A, self.T = obs_dim, action_dim, streams
+        self.params = G.FlatParams()
+        self.emb, efeat = _mlp(self.params, "critic/embedder", obs_dim, obs_embedder, activation)
+        if streams > 1 and len(obs_embedder) > 0:
+            raise NotImplementedError("a trainable observation embedder below several middleware "
+                                      "streams needs summed input gradients")
+        self.efeat = efeat
+        self.merged = action_dim + efeat                    # sorted inputs: 'action' < 'observation'
+        self.mid, feat = _mlp(self.params, "critic/middleware", self.merged, middleware, activation,
+                              towers=streams)
+        init = G.normalized_columns(1.0) if head_init == "normalized_columns" else None
+        self.head = G.Dense(self.params, "critic/v_head/output", feat, 1, None, streams, init=init)
+        self.modules = [self.emb, self.mid, self.head]
+        self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
+        self.loss = torch.zeros(4, dtype=torch.float32, device=device)
+
+    def forward(self, obs, actions, B, use_target=False, tag="q"):
+        """-> q [streams, B] and the saved activations."""
+        w = self.target if use_target else None
+        ctx = self.ctx
+        eacts = self.emb.forward(ctx, self._obs(obs, B), tag=tag, weights=w)
+        merged = ctx.buffer("critic/merged", (1, B, self.merged), tag=tag)
+        m2 = merged.view(B, self.merged)
+        self.lib.copy_2d(actions, self.A, m2, self.merged, B, self.A, 1.0, ctx.stream)
+        self.lib.copy_2d(eacts[-1].data, self.efeat, m2.data_ptr() + 4 * self.A, self.merged, B,
+                         self.efeat, 1.0, ctx.stream)
+        x = G.Tensor(merged, B, self.merged, 0 if self.T > 1 else 1, grad_key=(ctx, "critic/merged", tag))
+        macts = self.mid.forward(ctx, x, tag=tag, weights=w)
+        q = self.head.forward(ctx, macts[-1], tag=tag, weights=w)
+        return q.data.view(self.T, B), (eacts, macts, q, merged)
+
+    def train_backward(self, saved, targets, B):
+        """accumulate_gradients for the critic loss sum_i mean((target - Q_i)^2)."""
+        eacts, macts, q, merged = saved
+        ctx = self.ctx
+        dq = q.ensure_grad()
+        for t in range(self.T):
+            self.lib.regression_loss(q.data[t], 1, targets, 1, None, B, 1, 0, 1.0, 1.0, dq[t], 1,
+                                     self.loss[t:t + 1], ctx.stream)
+        self.head.backward(ctx, macts[-1], q)
+        need_in = len(self.emb.layers) > 0
+        self.mid.backward(ctx, macts, need_input_grad=need_in)
+        if need_in:
+            g = macts[0].grad.view(B, self.merged)
+            eg = eacts[-1].ensure_grad().view(B, self.efeat)
+            self.lib.copy_2d(g.data_ptr() + 4 * self.A, self.merged, eg, self.efeat, B, self.efeat, 1.0,
+                             ctx.stream)
+            self.emb.backward(ctx, eacts)
+
+    def action_gradient(self, saved, B, out, scale=1.0):
+        """gradients_wrt_inputs[...]['action'] of mean_b(Q_1) (ddpg_agent.py:171-173,
+        td3_agent.py:194-198): backward through stream 0 only, no weight gradients."""
+        eacts, macts, q, merged = saved
+        ctx = self.ctx
+        dq = q.ensure_grad()
+        dq[0].fill_(1.0 / B)
+        x1 = G.Tensor(merged, B, self.merged, 1, grad_key=(ctx, "critic/merged", "agrad"))
+        acts = [x1] + [a.tower(0) for a in macts[1:]]
+        self.head.backward(ctx, acts[-1], q.tower(0), need_dx=True, t0=0, nt=1, need_dw=False)
+        self.mid.backward(ctx, acts, need_input_grad=True, t0=0, nt=1, need_dw=False)
+        g = x1.grad.view(B, self.merged)
+        self.lib.copy_2d(g, self.merged, out, self.A, B, self.A, float(scale), ctx.stream)
+        return out
+
+
+class SACPolicyNet(_ACBase):
+    def __init__(self, device, obs_dim, action_dim, embedder=(256,), middleware=(256,),
+                 learning_rate=3e-4, adam_beta1=0.9, adam_beta2=0.99, optimizer_epsilon=1e-4, seed=0):
+        self.obs_dim, self.A = obs_dim, action_dim
+        self.params = G.FlatParams()
+        self.emb, feat = _mlp(self.params, "policy/embedder", obs_dim, embedder, "relu")
+        self.mid, feat = _mlp(self.params, "policy/middleware", feat, middleware, "relu")
+        self.head = G.Dense(self.params, "policy/sac_policy_head/policy_mu_logsig", feat, 2 * action_dim, None)
+        self.modules = [self.emb, self.mid, self.head]
+        self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon,
+                     has_target=False)
+
+    def forward(self, obs, B, normals, tag="pi", want=("actions", "logprob")):
+        ctx = self.ctx
+        acts = self.emb.forward(ctx, self._obs(obs, B), tag=tag)
+        acts2 = self.mid.forward(ctx, acts[-1], tag=tag)
+        y = self.head.forward(ctx, acts2[-1], tag=tag)
+        o = {k: ctx.buffer("sac/" + k, (B, self.A) if k != "logprob" else (B,), tag=tag)
+             for k in ("mean", "log_std", "raw_actions", "actions", "logprob")}
+        self.lib.sac_policy_head(y.data, 2 * self.A, normals, B, self.A, o["mean"], o["log_std"],
+                                 o["raw_actions"], o["actions"], o["logprob"], ctx.stream)
+        return o, (acts, acts2, y, normals)
+
+    def backward(self, saved, B, logprob_mean_weight=0.0, action_weights=None, action_weight_scale=1.0):
+        acts, acts2, y, normals = saved
+        ctx = self.ctx
+        dy = y.ensure_grad()
+        self.lib.sac_policy_head_backward(y.data, 2 * self.A, normals, B, self.A, float(logprob_mean_weight),
+                                          action_weights, float(action_weight_scale), dy, 2 * self.A,
+                                          ctx.stream)
+        self.head.backward(ctx, acts2[-1], y)
+        self.mid.backward(ctx, acts2, need_input_grad=len(self.emb.layers) > 0)
+        self.emb.backward(ctx, acts)
+
+
+class SACValueNet(_ACBase):
+    def __init__(self, device, obs_dim, embedder=(256,), middleware=(256,), learning_rate=3e-4,
+                 adam_beta1=0.9, adam_beta2=0.99, optimizer_epsilon=1e-4, seed=0):
+        self.obs_dim = obs_dim
+        self.params = G.FlatParams()
+        self.emb, feat = _mlp(self.params, "v/embedder", obs_dim, embedder, "relu")
+        self.mid, feat = _mlp(self.params, "v/middleware", feat, middleware, "relu")
+        self.head = G.Dense(self.params, "v/v_values_head/output", feat, 1, None)      # xavier
+        self.modules = [self.emb, self.mid, self.head]
+        self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def forward(self, obs, B, use_target=False, tag="v"):
+        w = self.target if use_target else None
+        ctx = self.ctx
+        acts = self.emb.forward(ctx, self._obs(obs, B), tag=tag, weights=w)
+        acts2 = self.mid.forward(ctx, acts[-1], tag=tag, weights=w)
+        v = self.head.forward(ctx, acts2[-1], tag=tag, weights=w)
+        return v.data.view(B), (acts, acts2, v)
+
+    def train_backward(self, saved, targets, B):
+        acts, acts2, v = saved
+        ctx = self.ctx
+        dv = v.ensure_grad()
+        self.lib.regression_loss(v.data, 1, targets, 1, None, B, 1, 0, 1.0, 1.0, dv, 1, self.loss, ctx.stream)
+        self.head.backward(ctx, acts2[-1], v)
+        self.mid.backward(ctx, acts2, need_input_grad=len(self.emb.layers) > 0)
+        self.emb.backward(ctx, acts)
+
+
+class SACQNet(_ACBase):
+    """Twin Q head (heads/sac_q_head.py:46-96) as two towers; empty embedder / middleware."""
+
+    def __init__(self, device, obs_dim, action_dim, layers=(256, 256), learning_rate=3e-4,
+                 adam_beta1=0.9, adam_beta2=0.99, optimizer_epsilon=1e-4, seed=0):
+        self.obs_dim, self.A = obs_dim, action_dim
+        self.params = G.FlatParams()
+        P = self.params
+        self.obs_fc = G.Dense(P, "q/q_head/obs_fc", obs_dim, layers[0], "relu", 2)
+        self.act_fc = G.Dense(P, "q/q_head/act_fc", action_dim, layers[0], "relu", 2)
+        self.fcs, feat = [], layers[0]
+        for i, u in enumerate(layers[1:]):
+            self.fcs.append(G.Dense(P, "q/q_head/fc%d" % (i + 1), feat, u, "relu", 2))
+            feat = u
+        self.out = G.Dense(P, "q/q_head/q_output", feat, 1, None, 2)
+        self.modules = [self.obs_fc, self.act_fc] + self.fcs + [self.out]
+        self.h0 = layers[0]
+        self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon,
+                     has_target=False)
+        self.loss = torch.zeros(2, dtype=torch.float32, device=device)
+
+    def forward(self, obs, actions, B, tag="q"):
+        ctx = self.ctx
+        a2 = ctx.buffer("q/actions2", (2, B, self.A), tag=tag)          # per-tower copy of the action
+        a2[0].copy_(actions)
+        a2[1].copy_(actions)
+        xa = G.Tensor(a2, B, self.A, 2, grad_key=(ctx, "q/actions2", tag))
+        ho = self.obs_fc.forward(ctx, self._obs(obs, B), tag=tag)
+        ha = self.act_fc.forward(ctx, xa, tag=tag)
+        h = ctx.buffer("q/sum", (2, B, self.h0), tag=tag)
+        self.lib.axpby(h, 1.0, ho.data, 1.0, ha.data, h.numel(), ctx.stream)
+        acts = [G.Tensor(h, B, self.h0, 2, grad_key=(ctx, "q/sum", tag))]
+        for l in self.fcs:
+            acts.append(l.forward(ctx, acts[-1], tag=tag))
+        q = self.out.forward(ctx, acts[-1], tag=tag)
+        return q.data.view(2, B), (ho, ha, xa, acts, q, obs)
+
+    def _backward(self, saved, B, need_dw, need_action_grad):
+        ho, ha, xa, acts, q, obs = saved
+        ctx = self.ctx
+        kw = {"need_dw": need_dw}
+        self.out.backward(ctx, acts[-1], q, **kw)
+        for i in reversed(range(len(self.fcs))):
+            self.fcs[i].backward(ctx, acts[i], acts[i + 1], **kw)
+        dh = acts[0].grad
+        ho.ensure_grad().copy_(dh)
+        ha.ensure_grad().copy_(dh)
+        if need_dw:
+            self.obs_fc.backward(ctx, self._obs(obs, B), ho, need_dx=False)
+        self.act_fc.backward(ctx, xa, ha, need_dx=need_action_grad, **kw)
+
+    def train_backward(self, saved, targets, B):
+        """loss = 0.5*mean((q1 - y)^2) + 0.5*mean((q2 - y)^2)  (sac_q_head.py:91-95)."""
+        q = saved[4]
+        dq = q.ensure_grad()
+        for t in range(2):
+            self.lib.regression_loss(q.data[t], 1, targets, 1, None, B, 1, 0, 0.5, 1.0, dq[t], 1,
+                                     self.loss[t:t + 1], self.ctx.stream)
+        self._backward(saved, B, True, False)
+
+    def action_gradient(self, saved, B, out):
+        """gradients_wrt_inputs[1]['output_0_0'] = d mean(min(q1,q2)) / d action (:216-217)."""
+        xa, q = saved[2], saved[4]
+        ctx = self.ctx
+        dq = q.ensure_grad()
+        qv = q.data.view(2, B)
+        self.lib.min_pair(qv[0], qv[1], None, dq.view(2, B)[0], dq.view(2, B)[1], 1.0 / B, B, ctx.stream)
+        self._backward(saved, B, False, True)
+        g = xa.grad
+        self.lib.axpby(out, 1.0, g[0], 1.0, g[1], B * self.A, ctx.stream)
+        return out

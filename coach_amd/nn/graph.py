@@ -193,19 +193,21 @@ class Dense(Layer):
                   workspace=ctx.ws.splitk)
         return Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag))
 
-    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None):
-        """y.grad holds dL/dy (post-activation); writes dW, db and (optionally) x.grad."""
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True):
+        """y.grad holds dL/dy (post-activation); writes dW, db and (optionally) x.grad.
+        need_dw=False only propagates to the input (gradients_wrt_inputs, architecture.py:187-220)."""
         t0, T = self._range(t0, nt)
         M, p = x.rows, self.params
         dz = y.grad
         if self.act is not None:                      # dz = dy * act'(y), in place
-            ctx.lib.act_backward(dz, y.data, dz.numel(), _rlx.ACT[self.act], ctx.stream)
+            ctx.lib.act_backward(dz, y.data, T * M * self.N, _rlx.ACT[self.act], ctx.stream)
         # dW[K,N] = x^T dz : A(k, m) = x[m, k]
         # (db = column sums of dz, accumulated by the same launch from the staged B slabs)
-        _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
-                  a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
-                  c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
-                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
+        if need_dw:
+            _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
+                      a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
+                      c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
+                      colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
         if need_dx:
             assert x.towers == T, "input gradients need a per-tower input"
             dx = x.ensure_grad()
@@ -265,7 +267,7 @@ class Conv2d(Layer):
         # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
         return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag))
 
-    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None):
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True):
         t0, T = self._range(t0, nt)
         B, p = x.rows, self.params
         M = B * self.OH * self.OW
@@ -275,11 +277,12 @@ class Conv2d(Layer):
             ctx.lib.act_backward(dz, y.data, dz.numel(), _rlx.ACT[self.act], ctx.stream)
         dz = dz.view(T, M, self.Co)
         # dW[K,Co] = cols^T dz : A(k, m) gathered with outer table = koff, reduction table = rowbase
-        _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
-                  a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
-                  a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
-                  c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
-                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
+        if need_dw:
+            _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
+                      a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
+                      a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
+                      c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
+                      colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
         if need_dx:
             assert x.towers == T
             dcol = ctx.buffer(self.name + "/dcol", (T, M, self.K))
@@ -308,10 +311,11 @@ class Sequential:
             acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt))
         return acts
 
-    def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None):
+    def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None, need_dw=True):
         for i in reversed(range(len(self.layers))):
+            kw = {} if need_dw else {"need_dw": False}
             self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),
-                                    weights=weights, t0=t0, nt=nt)
+                                    weights=weights, t0=t0, nt=nt, **kw)
 
 
 class AdamState:

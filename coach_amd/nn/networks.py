@@ -181,7 +181,8 @@ class DQNNet(_NetBase):
         return self.q_head.forward(self.ctx, acts[-1], tag=tag, weights=w)
 
     def learn_from_batch(self, obs, next_obs, B, actions, rewards, game_overs, discount,
-                         importance_weights=None, td_errors=None, double_dqn=False, grad_scale=1.0):
+                         importance_weights=None, td_errors=None, double_dqn=False, grad_scale=1.0,
+                         sync=None):
         """DQNAgent.learn_from_batch (agents/dqn_agent.py:81-113), all on device."""
         ctx = self.ctx
         q_next = self.q_values(next_obs, B, use_target=True, tag="next_t").data.view(B, self.A)
@@ -197,6 +198,8 @@ class DQNNet(_NetBase):
                                  1 if self.huber else 0, 1.0, 1.0, dq, self.A, self.loss, ctx.stream)
         self.q_head.backward(ctx, acts[-1], q)
         self.torso.backward(ctx, acts)
+        if sync is not None:                          # data-parallel: ONE all-reduce of the flat buffer
+            sync.all_reduce_sum(self.params.grads)
         self.grad_norm()
         self.apply_gradients(grad_scale)
         return self.loss

@@ -238,6 +238,31 @@ int rlx_mix_weights(float *target, const float *online, long long n, double rate
 int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,
                     long long workspace_floats, void *stream);      /* tf.global_norm, architecture.py:194 */
 
+/* ------------------------------------ continuous-control agents (DDPG / TD3 / SAC) -- */
+/* dst[r][c] = scale * src[r][c]: concat / slice / negate / DDPGActorHead output_scale
+ * (general_network.py:270-277, heads/ddpg_actor_head.py:48-56). */
+int rlx_copy_2d(const float *src, long long src_ld, float *dst, long long dst_ld, int rows, int cols,
+                float scale, void *stream);
+int rlx_axpby(float *out, float a, const float *x, float b, const float *y, long long n,
+              void *stream);                   /* out = a*x + b*y (y may be NULL); heads/sac_q_head.py:63-67 */
+/* out_min = min(q1,q2); grad_i = grad_scale * d sum(min)/d q_i (tf.minimum: ties go to q1).
+ * heads/sac_q_head.py:84-88, heads/td3_v_head.py:54-58 */
+int rlx_min_pair(const float *q1, const float *q2, float *out_min, float *grad1, float *grad2,
+                 float grad_scale, int n, void *stream);
+int rlx_select_rows(const unsigned char *mask, const void *if_set, const void *if_clear, void *out,
+                    int n, long long row_bytes, void *stream);   /* out[r] = mask[r] ? if_set[r] : if_clear[r] */
+/* SACPolicyHead (heads/sac_head.py:60-97): mu_logsig [batch, 2*action_dim] is the head's dense
+ * output; standard_normals [batch, action_dim] are host draws (fp64).  Any output may be NULL. */
+int rlx_sac_policy_head(const float *mu_logsig, long long ld, const double *standard_normals, int batch,
+                        int action_dim, float *out_mean, float *out_log_std, float *out_raw_actions,
+                        float *out_actions, float *out_logprob, void *stream);
+/* d/d mu_logsig of  logprob_mean_weight * mean_b(logprob_b) + action_weight_scale *
+ * sum(action_weights * actions)  (weighted_gradients[5] / [3], soft_actor_critic_agent.py:210-229). */
+int rlx_sac_policy_head_backward(const float *mu_logsig, long long ld, const double *standard_normals,
+                                 int batch, int action_dim, float logprob_mean_weight,
+                                 const float *action_weights, float action_weight_scale,
+                                 float *d_mu_logsig, long long ld_grad, void *stream);
+
 /* -------------------------------------------------------- exploration policies -- */
 int rlx_categorical_sample(const float *probs, long long ld, const double *uniforms, int n_env,
                            int n_actions, int *actions, void *stream); /* exploration_policies/categorical.py:45-48 */

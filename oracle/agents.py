@@ -242,3 +242,145 @@ class ClippedPPOAgentOracle:
             out.append(np.mean(np.array(ep, dtype=np.float64), 0))
         self.transitions = [[] for _ in range(self.n_env)]
         return out
+
+
+class _VectorLoopOracle:
+    """N lockstep envs around the reference's per-env logic: observation stacking (image) or raw
+    vectors, reward filter, replay payload ring.  Mirrors coach_amd/agents/vector_agent.py, which in
+    turn mirrors LevelManager.step / Agent.observe (level_manager.py:215-269, agent.py:905-973)."""
+
+    def _init_loop(self, env, stack, capacity, per=None, reward_clip=None, reward_rescale=1.0):
+        from .replay import StackingOracle
+        from .per import PrioritizedReplayOracle
+        self.env, self.n_env = env, env.n_env
+        self.image = env.kind == 0
+        self.stackers = [StackingOracle(stack) for _ in range(self.n_env)] if self.image else None
+        self.reward_clip, self.reward_rescale = reward_clip, reward_rescale
+        self.per = PrioritizedReplayOracle(capacity, **per) if per is not None else None
+        self.cap = self.per.power_of_2_size if self.per is not None else capacity
+        self.rows = [None] * self.cap            # payload ring (physical rows)
+        self.cursor, self.count = 0, 0
+        self.total_steps, self.last_train, self.last_target, self.training_iteration = 0, 0, 0, 0
+        self.sampled = []                        # logical / leaf indices of every sampled batch
+
+    def reset(self, frame_hw=None):
+        first = self.env.reset()
+        if self.image:
+            self.frame_hw = tuple(frame_hw)
+            first = first.reshape((self.n_env,) + self.frame_hw)
+            self.cur = [s.filter(f) for s, f in zip(self.stackers, first)]
+        else:
+            self.cur = [f.copy() for f in first]
+
+    def _filter_reward(self, r):
+        from . import filters as Fl
+        r = float(r) * self.reward_rescale if self.reward_rescale != 1.0 else float(r)
+        if self.reward_clip is not None:
+            r = Fl.reward_clip(r, *self.reward_clip)
+        return np.float32(r)
+
+    def _step_envs(self, actions, record=True):
+        nxt, rst, rew, done = self.env.step()
+        for e in range(self.n_env):
+            r = self._filter_reward(rew[e])
+            if self.image:
+                ns = self.stackers[e].filter(nxt[e].reshape(self.frame_hw))
+            else:
+                ns = nxt[e].copy()
+            if record:
+                self.rows[self.cursor] = (self.cur[e], actions[e], r, bool(done[e]), ns)
+                self.cursor = (self.cursor + 1) % self.cap
+                self.count = min(self.count + 1, self.cap)
+                if self.per is not None:
+                    self.per.store()
+            if done[e]:
+                if self.image:
+                    self.stackers[e].reset()
+                    ns = self.stackers[e].filter(rst[e].reshape(self.frame_hw))
+                else:
+                    ns = rst[e].copy()
+            self.cur[e] = ns
+        self.total_steps += self.n_env
+        return done
+
+    def _num_transitions(self):
+        return self.per.num_transitions() if self.per is not None else self.count
+
+    def _gather(self, phys):
+        cols = list(zip(*[self.rows[i] for i in phys]))
+        return [np.stack(cols[0]), np.array(cols[1]), np.array(cols[2], dtype=F32),
+                np.array(cols[3]), np.stack(cols[4])]
+
+    def _draw(self, B):
+        import random
+        if self.per is not None:
+            u = np.array([random.random() for _ in range(B)])
+            return (u, self.per.beta)
+        return np.random.randint(self.count, size=B)
+
+    def _collate(self, d, B):
+        if self.per is not None:
+            idx, w = self.per.sample(B, d[0])
+            self.sampled.append(idx.copy())
+            return self._gather(idx), idx, w
+        self.sampled.append(np.asarray(d).copy())
+        head = (self.cursor - self.count) % self.cap
+        return self._gather((head + d) % self.cap), d, None
+
+
+class DQNAgentOracle(_VectorLoopOracle):
+    """The DQN loop on the CPU (dqn_agent.py:81-113 + agent.py scheduling) for N lockstep envs."""
+
+    def __init__(self, arrays, env, n_actions, obs_shape, stack=4, capacity=1024, per=None,
+                 batch_size=32, discount=0.99, playing_steps=4, target_every=10000, huber=True,
+                 double_dqn=False, lr=2.5e-4, adam=(0.9, 0.99, 1e-4), activation="relu",
+                 epsilon_schedule=None, reward_clip=None):
+        self._init_loop(env, stack, capacity, per, reward_clip)
+        self.A, self.B, self.discount = n_actions, batch_size, discount
+        self.playing_steps, self.target_every, self.double = playing_steps, target_every, double_dqn
+        self.net = DQNOracle(arrays, obs_shape, n_actions, activation, lr, adam[0], adam[1], adam[2], huber)
+        self.eps_sched = epsilon_schedule
+        self.cur_rand = np.array([np.random.rand() for _ in range(self.n_env)])
+        self.losses = []
+
+    def heatup_step(self):
+        acts = [int(np.random.choice(self.A)) for _ in range(self.n_env)]
+        self._step_envs(acts)
+        return acts
+
+    def act(self):
+        from .explore import egreedy_choice
+        q = self.net.q(np.stack(self.cur))
+        eps = self.eps_sched.current_value
+        acts = []
+        for e in range(self.n_env):
+            u = self.cur_rand[e]
+            if u < eps:
+                a = int(np.random.choice(self.A))
+            else:
+                a = egreedy_choice(q[e], u, 0, np.random.random(self.A), eps)
+            self.eps_sched.step()
+            self.cur_rand[e] = np.random.rand()
+            acts.append(a)
+        self._step_envs(acts)
+        self.last_q = q
+        return acts
+
+    def train(self):
+        gap = self.total_steps - self.last_train
+        if gap < self.playing_steps or self._num_transitions() <= 0:
+            return
+        phases = min(gap // self.playing_steps, max(1, self.n_env // self.playing_steps))
+        self.last_train = self.total_steps
+        for _ in range(phases):
+            d = self._draw(self.B)
+            (s, a, r, done, ns), idx, w = self._collate(d, self.B)
+            self.training_iteration += 1
+            res = self.net.learn_from_batch(s, ns, a, r, done, self.discount,
+                                            None if w is None else w.astype(F32), self.double)
+            if self.per is not None:
+                self.per.update_priorities(idx.tolist(), [float(x) for x in res["td_errors"]])
+            self.losses.append(res["loss"])
+            if self.total_steps - self.last_target >= self.target_every:
+                self.last_target = self.total_steps
+                self.net.update_target(1.0)
