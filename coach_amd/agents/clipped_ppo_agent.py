@@ -25,7 +25,7 @@ import torch
 
 from .. import _rlx
 from ..core_types import EnvironmentSteps, RunPhase
-from ..memories.episodic_rollout_buffer import DeviceEpisodicRolloutBuffer
+from ..memories.episodic.episodic_rollout_buffer import DeviceEpisodicRolloutBuffer
 from ..nn.networks import ClippedPPONet
 from ..schedules import ConstantSchedule
 

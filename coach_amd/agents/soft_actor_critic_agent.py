@@ -1,0 +1,202 @@
+"""Soft Actor-Critic on one MI355X — host-side mirror of
+rl_coach/agents/soft_actor_critic_agent.py (parameter classes :57-141,
+SoftActorCriticAgent.learn_from_batch :168-280, choose_action :296-322) for the C5 workload
+(Humanoid-like: obs 376, act 17, B = 256, 512 envs / GPU).
+
+The reference runs ~9 separate sess.run passes per update; the order is kept because it is
+observable: the policy gradient is applied BEFORE the V and Q targets are formed,
+and V's target reuses the first pass's sampled actions / log-probs.  Every sess.run of the TF graph
+re-samples the policy noise, so the three policy passes (outputs, d mean(logp)/d phi, d a/d phi
+weighted by dQ/da) see three independent noise draws; `resample_noise_per_pass=False` fuses them
+into one pass on one draw (1 forward + 1 backward instead of 3 + 2).  TF's own random stream
+cannot be reproduced: the standard normals come from the host's np.random stream.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import _rlx
+from ..core_types import EnvironmentSteps, RunPhase
+from ..memories.non_episodic.experience_replay import ExperienceReplayParameters
+from ..nn.actor_critic_nets import SACPolicyNet, SACQNet, SACValueNet
+from .vector_agent import AlgorithmParameters, VectorOffPolicyAgent
+
+
+class _SACNetParams(object):
+    def __init__(self):
+        self.optimizer_type = 'Adam'
+        self.batch_size = 256
+        self.learning_rate = 0.0003
+        self.adam_optimizer_beta1 = 0.9                  # NetworkParameters defaults (base_parameters.py:297-299)
+        self.adam_optimizer_beta2 = 0.99
+        self.optimizer_epsilon = 0.0001
+        self.scale_down_gradients_by_number_of_workers_for_sync_training = True
+
+
+class SACValueNetworkParameters(_SACNetParams):          # :57-69
+    def __init__(self):
+        super().__init__()
+        self.embedder_scheme = (256,)
+        self.middleware_scheme = (256,)                  # Mujoco_SAC preset
+        self.create_target_network = True
+
+
+class SACCriticNetworkParameters(_SACNetParams):         # :72-84
+    def __init__(self):
+        super().__init__()
+        self.network_layers_sizes = (256, 256)           # SACQHeadParameters
+        self.create_target_network = False
+
+
+class SACPolicyNetworkParameters(_SACNetParams):         # :87-100
+    def __init__(self):
+        super().__init__()
+        self.embedder_scheme = (256,)
+        self.middleware_scheme = (256,)
+        self.create_target_network = False
+
+
+class SoftActorCriticAlgorithmParameters(AlgorithmParameters):   # :103-126
+    def __init__(self):
+        super().__init__()
+        self.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(1)
+        self.rate_for_copying_weights_to_target = 0.005
+        self.use_deterministic_for_evaluation = True
+        self.reward_rescale = 5.0                        # Mujoco_SAC preset: RewardRescaleFilter(5)
+        self.resample_noise_per_pass = True
+
+
+class SoftActorCriticAgentParameters(object):            # :129-141
+    def __init__(self):
+        self.algorithm = SoftActorCriticAlgorithmParameters()
+        self.memory = ExperienceReplayParameters()
+        self.network_wrappers = OrderedDict([("policy", SACPolicyNetworkParameters()),
+                                             ("q", SACCriticNetworkParameters()),
+                                             ("v", SACValueNetworkParameters())])
+        self.seed = 0
+
+    @property
+    def path(self):
+        return 'coach_amd.agents.soft_actor_critic_agent:SoftActorCriticAgent'
+
+
+class SoftActorCriticAgent(VectorOffPolicyAgent):
+    continuous = True
+
+    def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
+        super().__init__(agent_parameters, environment, device, dist, use_graphs)
+        if self.image:
+            raise ValueError("SAC works only for continuous control problems")
+        ep = environment.p
+        pn, qn, vn = (self.ap.network_wrappers[k] for k in ("policy", "q", "v"))
+        self.obs_dim, self.A = int(ep.observation_shape[0]), int(ep.action_dim)
+        self.batch_size = pn.batch_size
+        self.low = np.broadcast_to(np.asarray(ep.action_low, dtype=np.float32), (self.A,)).copy()
+        self.high = np.broadcast_to(np.asarray(ep.action_high, dtype=np.float32), (self.A,)).copy()
+        seed, dev = self.ap.seed or 0, self.device
+        adam = lambda n: (n.learning_rate, n.adam_optimizer_beta1, n.adam_optimizer_beta2, n.optimizer_epsilon)
+        self.networks = OrderedDict([
+            ("policy", SACPolicyNet(dev, self.obs_dim, self.A, pn.embedder_scheme, pn.middleware_scheme,
+                                    *adam(pn), seed=seed)),
+            ("q", SACQNet(dev, self.obs_dim, self.A, qn.network_layers_sizes, *adam(qn), seed=seed + 1)),
+            ("v", SACValueNet(dev, self.obs_dim, vn.embedder_scheme, vn.middleware_scheme, *adam(vn),
+                              seed=seed + 2))])
+        self.memory = self._make_memory(action_dim=self.A)
+        B = self.batch_size
+        f32 = torch.float32
+        self.actions = torch.zeros(self.n_env, self.A, dtype=f32, device=dev)
+        self.act_normals = torch.zeros(self.n_env, self.A, dtype=torch.float64, device=dev)
+        self.normals = torch.zeros(3, B, self.A, dtype=torch.float64, device=dev)
+        self.log_target = torch.zeros(B, dtype=f32, device=dev)
+        self.dq_da = torch.zeros(B, self.A, dtype=f32, device=dev)
+        self.value_targets = torch.zeros(B, dtype=f32, device=dev)
+        self.td_targets = torch.zeros(B, dtype=f32, device=dev)
+        self.grad_a = torch.zeros_like(self.networks["policy"].params.grads)
+        self.policy_grads_sumabs = torch.zeros(1, dtype=f32, device=dev)
+        self._finish_init()
+
+    # --------------------------------------------------------------------------------- acting
+    def random_actions(self):
+        a = np.random.uniform(self.low, self.high, (self.n_env, self.A)).astype(np.float32)
+        self.actions.copy_(self._to_device("rand_act", a, torch.float32))
+        return self.actions
+
+    def choose_action(self, states):
+        """choose_action (:296-322): the squashed sample, or the (un-squashed) mean in TEST."""
+        alg = self.ap.algorithm
+        det = self.phase == RunPhase.TEST and alg.use_deterministic_for_evaluation
+        z = np.random.standard_normal((self.n_env, self.A))
+        self.act_normals.copy_(self._to_device("act_z", z, torch.float64))
+        self._run(("pi", det), lambda: self._pi_forward(states, det))
+        return self.actions
+
+    def _pi_forward(self, states, deterministic):
+        o, _ = self.networks["policy"].forward(states, self.n_env, self.act_normals, tag="act")
+        self.actions.copy_(o["mean"] if deterministic else o["actions"])
+
+    # ------------------------------------------------------------------------------- training
+    def _sync(self, net):
+        if self.dist is not None:
+            self.dist.all_reduce_sum(net.params.grads)
+
+    def _scale(self, name):
+        netp = self.ap.network_wrappers[name]
+        return self.dist.grad_scale(netp.scale_down_gradients_by_number_of_workers_for_sync_training) \
+            if self.dist else 1.0
+
+    def _learn_device(self, b):
+        pol, q, v = self.networks["policy"], self.networks["q"], self.networks["v"]
+        alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
+        s, ns = b._states["observation"], b._next_states["observation"]
+        resample = alg.resample_noise_per_pass
+        # (1) policy outputs on the first noise draw (:186-190)
+        o, p_saved = pol.forward(s, B, self.normals[0], tag="train0")
+        # (2) Q(s, sampled actions): log_target = min(Q1, Q2) (:198-200)
+        qv, q_saved = q.forward(s, o["actions"], B, tag="pi")
+        self.lib.min_pair(qv[0], qv[1], self.log_target, None, None, 0.0, B, s_)
+        # (3) d mean(Q_min) / d a at the sampled actions (:216-217)
+        q.action_gradient(q_saved, B, self.dq_da)
+        if resample:
+            # weighted_gradients[5] (mean log-prob, weight 1) on a fresh draw (:210-213)
+            _, sv1 = pol.forward(s, B, self.normals[1], tag="train1")
+            pol.backward(sv1, B, logprob_mean_weight=1.0)
+            self.grad_a.copy_(pol.params.grads)
+            # weighted_gradients[3] (actions, weights dq_da) on another fresh draw (:221-224)
+            _, sv2 = pol.forward(s, B, self.normals[2], tag="train2")
+            pol.backward(sv2, B, action_weights=self.dq_da, action_weight_scale=1.0)
+            # policy_grads = dlogp_dphi - dq_dphi (:227)
+            self.lib.axpby(pol.params.grads, 1.0, self.grad_a, -1.0, pol.params.grads, pol.params.size, s_)
+        else:
+            pol.backward(p_saved, B, logprob_mean_weight=1.0, action_weights=self.dq_da,
+                         action_weight_scale=-1.0)
+        self._sync(pol)
+        pol.apply_gradients(self._scale("policy"))                               # :229
+        # (4) V: targets = log_target - logp of the FIRST pass (:244), train_on_batch (:250)
+        self.lib.sac_value_targets(self.log_target, o["logprob"], B, self.value_targets, s_)
+        _, v_saved = v.forward(s, B, tag="train")
+        v.train_backward(v_saved, self.value_targets, B)
+        self._sync(v)
+        v.apply_gradients(self._scale("v"))
+        # (5) Q: y = r + (1 - done) gamma V_target(s') (:259-266), train_on_batch (:268)
+        v_next, _ = v.forward(ns, B, use_target=True, tag="next")
+        self.lib.ac_td_targets(b.rewards(), b.game_overs(), v_next, 1, float(alg.discount), 0, 0, 0.0, 0.0,
+                               B, self.td_targets, s_)
+        _, q_saved = q.forward(s, b.actions(), B, tag="train")
+        q.train_backward(q_saved, self.td_targets, B)
+        self._sync(q)
+        q.grad_norm()
+        q.apply_gradients(self._scale("q"))
+
+    def learn_from_batch(self, batch):
+        B = self.batch_size
+        z = np.random.standard_normal((3, B, self.A))
+        self.normals.copy_(self._to_device("sac_z", z, torch.float64))
+        if self.dist is None:
+            self._run(("learn",), lambda: self._learn_device(batch))
+        else:
+            self._learn_device(batch)
+        qn = self.networks["q"]
+        self.signals = {"Loss": qn.loss.sum(), "Grads (unclipped)": qn.norm,
+                        "V loss": self.networks["v"].loss}
+        return qn.loss.sum()

@@ -1,0 +1,140 @@
+"""TD3 on one MI355X — host-side mirror of rl_coach/agents/td3_agent.py (parameter classes
+:36-131, TD3Agent.learn_from_batch :148-209, train :211-213,
+update_transition_before_adding_to_replay_buffer :215-227) for the C4 workload
+(HalfCheetah-like: obs 17, act 6, B = 100, 256 envs / GPU).
+
+Twin critic streams run as two towers of one batched GEMM per layer.  Reference quirks kept:
+  * training happens at episode end, ``current_episode_steps_counter`` updates in a row (:211-213);
+  * game_over is cleared when the episode ended on the time limit (:215-227) — always the case for
+    the fixed-length synthetic episodes;
+  * the actor gradient is d mean_b(Q1) / d a (carries the 1/B factor, td3_v_head.py:57-58);
+  * actor update and soft target update every 2nd training iteration (:186, TrainingSteps(2)).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import _rlx
+from ..core_types import EnvironmentSteps, TrainingSteps
+from ..exploration_policies.additive_noise import AdditiveNoiseParameters
+from ..memories.episodic.episodic_experience_replay import EpisodicExperienceReplayParameters
+from .ddpg_agent import DDPGActorNetworkParameters, DDPGAgent, DDPGCriticNetworkParameters
+from .vector_agent import AlgorithmParameters
+
+
+class TD3CriticNetworkParameters(DDPGCriticNetworkParameters):   # td3_agent.py:36-51 + Mujoco_TD3 preset
+    def __init__(self, num_q_networks=2):
+        super().__init__()
+        self.observation_embedder_scheme = ()
+        self.action_embedder_scheme = ()
+        self.middleware_scheme = (400, 300)
+        self.num_streams = num_q_networks
+        self.head_initializer = "xavier"
+        self.batch_size = 100
+        self.learning_rate = 0.001
+
+
+class TD3ActorNetworkParameters(DDPGActorNetworkParameters):     # td3_agent.py:54-68
+    def __init__(self):
+        super().__init__()
+        self.batch_size = 100
+        self.learning_rate = 0.001
+
+
+class TD3AlgorithmParameters(AlgorithmParameters):               # td3_agent.py:71-111
+    def __init__(self):
+        super().__init__()
+        self.rate_for_copying_weights_to_target = 0.005
+        self.use_target_network_for_evaluation = False
+        self.action_penalty = 0
+        self.clip_critic_targets = None
+        self.use_non_zero_discount_for_terminal_states = False
+        self.act_for_full_episodes = True
+        self.update_policy_every_x_episode_steps = 2
+        self.num_steps_between_copying_online_weights_to_target = \
+            TrainingSteps(self.update_policy_every_x_episode_steps)
+        self.policy_noise = 0.2
+        self.noise_clipping = 0.5
+        self.num_q_networks = 2
+        self.num_consecutive_playing_steps = EnvironmentSteps(1)
+        self.clear_game_over_on_time_limit = True
+
+
+class TD3AgentExplorationParameters(AdditiveNoiseParameters):    # td3_agent.py:114-117
+    def __init__(self):
+        super().__init__()
+        self.noise_as_percentage_from_action_space = False
+
+
+class TD3AgentParameters(object):                                # td3_agent.py:120-131
+    def __init__(self):
+        alg = TD3AlgorithmParameters()
+        self.algorithm = alg
+        self.exploration = TD3AgentExplorationParameters()
+        self.memory = EpisodicExperienceReplayParameters()
+        self.network_wrappers = OrderedDict([("actor", TD3ActorNetworkParameters()),
+                                             ("critic", TD3CriticNetworkParameters(alg.num_q_networks))])
+        self.seed = 0
+
+    @property
+    def path(self):
+        return 'coach_amd.agents.td3_agent:TD3Agent'
+
+
+class TD3Agent(DDPGAgent):
+    def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
+        super().__init__(agent_parameters, environment, device, dist, use_graphs)
+        B, dev = self.batch_size, self.device
+        self.noise = torch.zeros(B, self.A, dtype=torch.float64, device=dev)
+        self.smoothed = torch.zeros(B, self.A, dtype=torch.float32, device=dev)
+        self.q_min = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.zero_go = torch.zeros(self.n_env, dtype=torch.uint8, device=dev)
+
+    def _stored_game_over(self, game_over):
+        # the synthetic episodes end on their time limit -> game_over False (:215-227)
+        return self.zero_go if self.ap.algorithm.clear_game_over_on_time_limit else game_over
+
+    def _training_steps_this_phase(self):
+        return self.last_episode_steps                                        # :211-213
+
+    def _critic_device(self, b):
+        actor, critic = self.networks["actor"], self.networks["critic"]
+        alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
+        s, ns = b._states["observation"], b._next_states["observation"]
+        next_actions, _ = actor.forward(ns, B, use_target=True, tag="next")
+        self._actions_mean, self._a_saved = actor.forward(s, B, tag="train")
+        # target-policy smoothing (:162-165)
+        self.lib.td3_smooth_actions(next_actions, self.noise, float(alg.noise_clipping), self.d_low,
+                                    self.d_high, B, self.A, self.smoothed, s_)
+        q_next, _ = critic.forward(ns, self.smoothed, B, use_target=True, tag="next")
+        self.lib.min_pair(q_next[0], q_next[1], self.q_min, None, None, 0.0, B, s_)   # output #2 (:168)
+        self._td_targets(b, self.q_min)
+        _, c_saved = critic.forward(s, b.actions(), B, tag="train")
+        critic.train_backward(c_saved, self.td_targets, B)
+        self._sync(critic)
+        critic.grad_norm()
+        critic.apply_gradients(self._scale("critic"))
+
+    def _actor_device(self, b):
+        actor, critic = self.networks["actor"], self.networks["critic"]
+        B = self.batch_size
+        s = b._states["observation"]
+        _, c_saved = critic.forward(s, self._actions_mean, B, tag="agrad")     # :188-192, output #3
+        critic.action_gradient(c_saved, B, self.neg_action_grad, scale=-1.0)
+        actor.backward(self._a_saved, self.neg_action_grad, B)
+        self._sync(actor)
+        actor.apply_gradients(self._scale("actor"))
+
+    def learn_from_batch(self, batch):
+        alg, B = self.ap.algorithm, self.batch_size
+        z = np.random.normal(0, alg.policy_noise, (B, self.A))                  # :162 (host stream)
+        self.noise.copy_(self._to_device("td3_noise", z, torch.float64))
+        graph = self.dist is None
+        run = self._run if graph else (lambda k, f: f())
+        run(("critic",), lambda: self._critic_device(batch))
+        if self.training_iteration % alg.update_policy_every_x_episode_steps == 0:   # :186
+            run(("actor",), lambda: self._actor_device(batch))
+        critic = self.networks["critic"]
+        self.signals = {"Loss": critic.loss[:2].sum(), "Grads (unclipped)": critic.norm}
+        return critic.loss[:2].sum()

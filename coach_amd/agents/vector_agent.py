@@ -114,6 +114,8 @@ class VectorOffPolicyAgent(GraphRunner):
         from ..memories.non_episodic.prioritized_experience_replay import (
             PrioritizedExperienceReplay, PrioritizedExperienceReplayParameters)
         from ..memories.non_episodic.experience_replay import ExperienceReplay
+        from ..memories.episodic.episodic_experience_replay import (
+            EpisodicExperienceReplay, EpisodicExperienceReplayParameters)
         ep = self.env.p
         kw = dict(device=self.device, n_env=self.n_env, observation_shape=ep.observation_shape,
                   stack=self.stack, action_dim=action_dim, min_episode_length=self.L)
@@ -121,6 +123,8 @@ class VectorOffPolicyAgent(GraphRunner):
             return PrioritizedExperienceReplay(mp.max_size, mp.alpha, mp.beta, mp.epsilon,
                                                mp.allow_duplicates_in_batch_sampling,
                                                exact_pow=getattr(mp, "exact_pow", False), **kw)
+        if isinstance(mp, EpisodicExperienceReplayParameters):
+            return EpisodicExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling, **kw)
         return ExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling, **kw)
 
     def _to_device(self, key, array, dtype):
@@ -162,13 +166,18 @@ class VectorOffPolicyAgent(GraphRunner):
         if record:
             self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,
                                         self.n_env, self.ep_acc, None, None, s)
-        self.memory.store(actions, self.filtered_reward, self._stored_game_over(game_over), next_obs,
-                          reset_obs, record=record)
+        stored = self._stored_game_over(game_over)
+        self.memory.store(actions, self.filtered_reward, stored, next_obs, reset_obs, record=record,
+                          dones=None if stored is game_over else game_over)
         self.env.total_steps += self.n_env
         self.current_episode_steps_counter += 1
         episode_ended = self.current_episode_steps_counter >= self.L
+        self._episode_just_ended = episode_ended
         if episode_ended:
+            self.last_episode_steps = self.current_episode_steps_counter
             self.current_episode_steps_counter = 0
+            if hasattr(self.memory, "close_last_episode") and record:
+                self.memory.close_last_episode()
             self.handle_episode_ended()
         if self.phase != RunPhase.TEST:                                        # agent.py:832-834
             self.total_steps_counter += self.n_env
@@ -200,6 +209,8 @@ class VectorOffPolicyAgent(GraphRunner):
         gap = self.total_steps_counter - self.last_training_phase_step
         if gap < steps:
             return 0
+        if self.ap.algorithm.act_for_full_episodes and not getattr(self, "_episode_just_ended", False):
+            return 0                                   # wait_for_full_episode (agent.py:692-693)
         # the reference opens ONE phase per check and resets the marker to the current step
         # (:673-677); a vector step is n_env checks' worth of env-steps
         due = min(gap // steps, max(1, self.n_env // steps))

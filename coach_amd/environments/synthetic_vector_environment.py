@@ -14,9 +14,10 @@ from .. import _rlx
 
 class SyntheticVectorEnvironmentParameters(object):
     def __init__(self, kind="image", num_envs=64, observation_shape=(84, 84), num_actions=6,
-                 action_dim=None, episode_length=32, seed=1234):
+                 action_dim=None, episode_length=32, seed=1234, action_low=-1.0, action_high=1.0):
         self.kind, self.num_envs, self.observation_shape = kind, num_envs, tuple(observation_shape)
         self.num_actions, self.action_dim = num_actions, action_dim
+        self.action_low, self.action_high = action_low, action_high      # BoxActionSpace bounds
         self.episode_length, self.seed = episode_length, seed
 
     @property

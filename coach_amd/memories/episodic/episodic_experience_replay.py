@@ -1,0 +1,57 @@
+"""Episodic replay as used by DDPG / TD3 — the sampling half of
+rl_coach/memories/episodic/episodic_experience_replay.py (:102-130: uniform over the transitions of
+COMPLETE episodes, ``np.random.randint(num_transitions_in_complete_episodes(), size=B)``).
+
+N lockstep envs with fixed-length episodes: a vector step appends n_env transitions in env order
+(what n_env sequential ``store`` calls do, :240-262), and all n_env running episodes complete
+together, so "transitions in complete episodes" is the stored count at the last episode boundary.
+Eviction is the transition ring of the parent class (the reference evicts whole oldest episodes,
+:300-317; identical whenever the capacity is a multiple of n_env * episode_length).
+"""
+import numpy as np
+
+from ..memory import MemoryGranularity
+from ..non_episodic.experience_replay import ExperienceReplay, ExperienceReplayParameters
+
+
+class EpisodicExperienceReplayParameters(ExperienceReplayParameters):        # :32-42
+    def __init__(self):
+        super().__init__()
+        self.max_size = (MemoryGranularity.Transitions, 1000000)
+        self.n_step = -1
+
+    @property
+    def path(self):
+        return 'coach_amd.memories.episodic.episodic_experience_replay:EpisodicExperienceReplay'
+
+
+class EpisodicExperienceReplay(ExperienceReplay):
+    def __init__(self, max_size, allow_duplicates_in_batch_sampling=True, **device_kwargs):
+        super().__init__(max_size, allow_duplicates_in_batch_sampling, **device_kwargs)
+        self._open = 0            # transitions of the episodes still running (newest rows)
+
+    def clean(self):
+        super().clean()
+        self._open = 0
+
+    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True, dones=None):
+        super().store(actions, rewards, game_overs, next_obs, reset_obs, record, dones)
+        if record:
+            self._open = min(self._open + self.n_env, self.cap)
+
+    def close_last_episode(self):
+        """All n_env lockstep episodes ended (EpisodicExperienceReplay.close_last_episode, :264-298)."""
+        self._open = 0
+
+    def num_complete_episodes(self):
+        return 0 if self.count - self._open <= 0 else 1          # only its truthiness is used (:112)
+
+    def num_transitions_in_complete_episodes(self):               # :84-88
+        return self.count - self._open
+
+    def sample_indices(self, size):
+        if self.num_transitions_in_complete_episodes() < 1:
+            raise ValueError("The episodic replay buffer cannot be sampled since there are no complete "
+                             "episodes yet. There is currently 1 episodes with {} transitions"
+                             .format(self._open))
+        return np.random.randint(self.num_transitions_in_complete_episodes(), size=size)   # :121

@@ -14,7 +14,7 @@ dataset index i = env * steps + step  ->  row(i) = step * n_env + env   (`datase
 import numpy as np
 import torch
 
-from .. import _rlx
+from ... import _rlx
 
 
 class DeviceEpisodicRolloutBuffer(object):

@@ -126,14 +126,19 @@ class ExperienceReplay(Memory):
                                       self.cur_state, None, self.status, _rlx.current_stream())
         return self.cur_state
 
-    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True):
+    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True, dones=None):
         """n_env transitions (state = current state of every env), then advance the env states.
         Reference: ExperienceReplay.store + _enforce_max_length (:117-150) called n_env times.
-        record=False only advances the observation state (evaluation episodes are not stored)."""
+        record=False only advances the observation state (evaluation episodes are not stored).
+        dones: the env's true episode-end flags when the STORED game_over differs from them (TD3
+        clears game_over on time-limit terminations, td3_agent.py:215-227)."""
         s = _rlx.current_stream()
         row0 = self.cursor
+        stored_go = game_overs
+        if dones is not None:
+            game_overs = dones
         if record:
-            pairs = [(actions, self.action), (rewards, self.reward), (game_overs, self.game_over)]
+            pairs = [(actions, self.action), (rewards, self.reward), (stored_go, self.game_over)]
             if not self.image:
                 pairs += [(self.cur_state, self.obs), (next_obs, self.next_obs)]
             self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), None, None, 0, row0,

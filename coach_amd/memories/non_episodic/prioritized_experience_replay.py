@@ -82,11 +82,11 @@ class PrioritizedExperienceReplay(ExperienceReplay):
         self.lib.per_init(self.sum_tree, self.min_tree, self.max_tree, self.power_of_2_size,
                           self.max_priority, _rlx.current_stream())
 
-    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True):
+    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True, dones=None):
         """n_env x PrioritizedExperienceReplay.store (:264-283): payload row == leaf index."""
         leaf0 = self.next_leaf_idx_to_write
         assert leaf0 == self.cursor or not record
-        super().store(actions, rewards, game_overs, next_obs, reset_obs, record)
+        super().store(actions, rewards, game_overs, next_obs, reset_obs, record, dones)
         if not record:
             return
         self.lib.per_store(self.sum_tree, self.min_tree, self.max_tree, self.power_of_2_size, leaf0,

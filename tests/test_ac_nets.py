@@ -1,0 +1,236 @@
+"""Continuous-control updates (DDPG / TD3 / SAC): oracle vs torch autograd on the CPU (the oracle's
+hand-written backward passes are checked against an independent implementation), and the HIP
+networks vs the oracle on the GPU — a few consecutive learn_from_batch steps from identical
+weights and identical batches / noise.  Tolerances: fp32 accumulation order only (rtol 2e-4 on
+losses and targets, atol 2e-5 on weights after 4 updates)."""
+import numpy as np
+import pytest
+
+from oracle import ac_nets as O
+
+F32 = np.float32
+
+
+def _rand_arrays(rng, spec):
+    """{name: (in, out, towers)} -> named_arrays-like dict with xavier-ish weights."""
+    out = {}
+    for name, (i, o, t) in spec.items():
+        out[name + "/kernel"] = [rng.uniform(-1, 1, (i, o)).astype(F32) * F32(np.sqrt(3.0 / i)) for _ in range(t)]
+        out[name + "/bias"] = [rng.uniform(-0.1, 0.1, (o,)).astype(F32) for _ in range(t)]
+    return out
+
+
+def _batch(rng, B, D, A):
+    s = rng.randn(B, D).astype(F32)
+    a = rng.uniform(-1, 1, (B, A)).astype(F32)
+    r = rng.randn(B).astype(F32)
+    done = (rng.rand(B) < 0.2)
+    ns = rng.randn(B, D).astype(F32)
+    return s, a, r, done, ns
+
+
+# ------------------------------------------------------------------ oracle vs torch autograd (CPU)
+def test_oracle_sac_policy_backward_matches_torch():
+    import torch
+    rng = np.random.RandomState(0)
+    B, D, A = 6, 5, 3
+    arrays = _rand_arrays(rng, {"policy/embedder/dense0": (D, 8, 1), "policy/middleware/dense0": (8, 8, 1),
+                                "policy/sac_policy_head/policy_mu_logsig": (8, 2 * A, 1)})
+    pol = O.SACPolicyOracle(arrays)
+    s = rng.randn(B, D).astype(F32)
+    eps = rng.randn(B, A)
+    w = rng.randn(B, A).astype(F32)
+    o = pol.forward(s, eps)
+    pol.backward(logp_weight=1.0, action_weights=w, action_weight_scale=-1.0)
+    # torch: same graph through the reparameterised sample
+    W = {k: torch.tensor(v[0], requires_grad=True) for k, v in arrays.items()}
+    x = torch.tensor(s)
+    for n in ("policy/embedder/dense0", "policy/middleware/dense0"):
+        x = torch.relu(x @ W[n + "/kernel"] + W[n + "/bias"])
+    y = x @ W["policy/sac_policy_head/policy_mu_logsig/kernel"] + W["policy/sac_policy_head/policy_mu_logsig/bias"]
+    mu, ls = y[:, :A], torch.clamp(y[:, A:], -20, 2)
+    raw = mu + torch.exp(ls) * torch.tensor(eps, dtype=torch.float32)
+    act = torch.tanh(raw)
+    dist = torch.distributions.Normal(mu, torch.exp(ls))
+    logp = dist.log_prob(raw).sum(1) - torch.log(1 - act ** 2 + float(O.EPS32)).sum(1)
+    np.testing.assert_allclose(o["logprob"], logp.detach().numpy(), rtol=2e-5, atol=2e-5)
+    obj = logp.mean() - (act * torch.tensor(w)).sum()
+    obj.backward()
+    g = pol.grads()
+    for name, d in g.items():
+        np.testing.assert_allclose(d[0], W[name].grad.numpy(), rtol=2e-4, atol=2e-6, err_msg=name)
+
+
+def test_oracle_td3_critic_and_action_gradient_match_torch():
+    import torch
+    rng = np.random.RandomState(1)
+    B, D, A = 7, 4, 2
+    arrays = _rand_arrays(rng, {"critic/middleware/dense0": (D + A, 8, 2), "critic/middleware/dense1": (8, 6, 2),
+                                "critic/v_head/output": (6, 1, 2)})
+    c = O.CriticOracle(arrays, streams=2)
+    s, a, r, done, ns = _batch(rng, B, D, A)
+    y = rng.randn(B).astype(F32)
+    q = c.forward(s, a)
+    losses = c.train_backward(y)
+    W = {k: [torch.tensor(x, requires_grad=True) for x in v] for k, v in arrays.items()}
+    at = torch.tensor(a, requires_grad=True)
+
+    def tq(t):
+        h = torch.cat([at, torch.tensor(s)], 1)
+        for n in ("critic/middleware/dense0", "critic/middleware/dense1"):
+            h = torch.relu(h @ W[n + "/kernel"][t] + W[n + "/bias"][t])
+        return (h @ W["critic/v_head/output/kernel"][t] + W["critic/v_head/output/bias"][t])[:, 0]
+    loss = sum(((torch.tensor(y) - tq(t)) ** 2).mean() for t in range(2))
+    loss.backward()
+    np.testing.assert_allclose(float(sum(losses)), float(loss), rtol=1e-5)
+    for name, d in c.grads().items():
+        for t in range(2):
+            np.testing.assert_allclose(d[t], W[name][t].grad.numpy(), rtol=2e-4, atol=2e-6, err_msg=name)
+    c.forward(s, a)
+    g = c.action_gradient(A)
+    at.grad = None
+    tq(0).mean().backward()
+    np.testing.assert_allclose(g, at.grad.numpy(), rtol=2e-4, atol=2e-7)
+
+
+def test_oracle_sac_q_action_gradient_matches_torch():
+    import torch
+    rng = np.random.RandomState(2)
+    B, D, A = 9, 5, 3
+    arrays = _rand_arrays(rng, {"q/q_head/obs_fc": (D, 8, 2), "q/q_head/act_fc": (A, 8, 2),
+                                "q/q_head/fc1": (8, 8, 2), "q/q_head/q_output": (8, 1, 2)})
+    qn = O.SACQOracle(arrays)
+    s, a, r, done, ns = _batch(rng, B, D, A)
+    q = qn.forward(s, a)
+    g = qn.action_gradient(q)
+    W = {k: [torch.tensor(x) for x in v] for k, v in arrays.items()}
+    at = torch.tensor(a, requires_grad=True)
+    qs = []
+    for t in range(2):
+        h = torch.relu(torch.tensor(s) @ W["q/q_head/obs_fc/kernel"][t] + W["q/q_head/obs_fc/bias"][t]) + \
+            torch.relu(at @ W["q/q_head/act_fc/kernel"][t] + W["q/q_head/act_fc/bias"][t])
+        h = torch.relu(h @ W["q/q_head/fc1/kernel"][t] + W["q/q_head/fc1/bias"][t])
+        qs.append((h @ W["q/q_head/q_output/kernel"][t] + W["q/q_head/q_output/bias"][t])[:, 0])
+    torch.minimum(qs[0], qs[1]).mean().backward()
+    np.testing.assert_allclose(g, at.grad.numpy(), rtol=2e-4, atol=2e-7)
+
+
+# ----------------------------------------------------------------------------- HIP vs oracle (GPU)
+def _t(x, dev, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x), device=dev) if dtype is None else \
+        torch.as_tensor(np.ascontiguousarray(x).astype(dtype), device=dev)
+
+
+def _check_weights(net, onet, atol=2e-5):
+    w = net.params.named_arrays()
+    for name, towers in onet.weights().items():
+        for t, arr in towers.items():
+            np.testing.assert_allclose(w[name][t], arr, rtol=0, atol=atol, err_msg="%s[%d]" % (name, t))
+
+
+class _B:
+    """minimal DeviceBatch stand-in"""
+    def __init__(self, dev, batch):
+        import torch
+        s, a, r, done, ns = batch
+        self._states = {"observation": _t(s, dev)}
+        self._next_states = {"observation": _t(ns, dev)}
+        self._a, self._r, self._d = _t(a, dev), _t(r, dev), _t(done.astype(np.uint8), dev)
+
+    def actions(self): return self._a
+    def rewards(self): return self._r
+    def game_overs(self): return self._d
+
+
+def _agent(dev, cls, params, D, A, B, n_env=4):
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    ep = SyntheticVectorEnvironmentParameters("vector", n_env, (D,), None, action_dim=A, episode_length=8, seed=5)
+    env = SyntheticVectorEnvironment(ep, dev)
+    for n in params.network_wrappers.values():
+        n.batch_size = B
+    params.memory.max_size = (MemoryGranularity.Transitions, 256)
+    return cls(params, env, dev, use_graphs=False)
+
+
+@pytest.mark.gpu
+def test_ddpg_update_matches_oracle(dev):
+    from coach_amd.agents.ddpg_agent import DDPGAgent, DDPGAgentParameters
+    D, A, B = 11, 3, 32
+    ag = _agent(dev, DDPGAgent, DDPGAgentParameters(), D, A, B)
+    actor, critic = ag.networks["actor"], ag.networks["critic"]
+    oa = O.ActorOracle(actor.params.named_arrays(), 1.0, lr=1e-4)
+    oc = O.CriticOracle(critic.params.named_arrays(), streams=1, lr=1e-3)
+    rng = np.random.RandomState(3)
+    for it in range(4):
+        batch = _batch(rng, B, D, A)
+        r = O.ddpg_update(oa, oc, batch)
+        ag._learn_device(_B(dev, batch))
+        np.testing.assert_allclose(ag.td_targets.cpu().numpy(), r["targets"], rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(-ag.neg_action_grad.cpu().numpy(), r["action_grad"], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(float(critic.loss[0]), r["loss"], rtol=2e-4)
+        np.testing.assert_allclose(float(critic.norm), r["norm"], rtol=2e-4)
+        ag.update_target_networks(0.001); oa.mix_target(0.001); oc.mix_target(0.001)
+    _check_weights(actor, oa)
+    _check_weights(critic, oc)
+    ag.check_status()
+
+
+@pytest.mark.gpu
+def test_td3_update_matches_oracle(dev):
+    import torch
+    from coach_amd.agents.td3_agent import TD3Agent, TD3AgentParameters
+    D, A, B = 17, 6, 100
+    ag = _agent(dev, TD3Agent, TD3AgentParameters(), D, A, B)
+    actor, critic = ag.networks["actor"], ag.networks["critic"]
+    oa = O.ActorOracle(actor.params.named_arrays(), 1.0, lr=1e-3)
+    oc = O.CriticOracle(critic.params.named_arrays(), streams=2, lr=1e-3)
+    rng = np.random.RandomState(4)
+    for it in range(1, 5):
+        batch = _batch(rng, B, D, A)
+        noise = rng.normal(0, 0.2, (B, A))
+        r = O.td3_update(oa, oc, batch, noise, it, ag.low, ag.high)
+        db = _B(dev, batch)
+        ag.noise.copy_(_t(noise, dev))
+        ag._critic_device(db)
+        if it % 2 == 0:
+            ag._actor_device(db)
+            ag.update_target_networks(0.005); oa.mix_target(0.005); oc.mix_target(0.005)
+        np.testing.assert_allclose(ag.td_targets.cpu().numpy(), r["targets"], rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(float(critic.loss[:2].sum()), r["loss"], rtol=2e-4)
+    _check_weights(actor, oa)
+    _check_weights(critic, oc)
+    ag.check_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resample", [True, False])
+def test_sac_update_matches_oracle(dev, resample):
+    from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgent, SoftActorCriticAgentParameters
+    D, A, B = 23, 5, 64
+    p = SoftActorCriticAgentParameters()
+    p.algorithm.resample_noise_per_pass = resample
+    ag = _agent(dev, SoftActorCriticAgent, p, D, A, B)
+    pol, qn, vn = ag.networks["policy"], ag.networks["q"], ag.networks["v"]
+    op = O.SACPolicyOracle(pol.params.named_arrays())
+    oq = O.SACQOracle(qn.params.named_arrays())
+    ov = O.SACValueOracle(vn.params.named_arrays())
+    rng = np.random.RandomState(5)
+    for it in range(4):
+        batch = _batch(rng, B, D, A)
+        z = rng.standard_normal((3, B, A))
+        r = O.sac_update(op, oq, ov, batch, z, resample=resample)
+        ag.normals.copy_(_t(z, dev))
+        ag._learn_device(_B(dev, batch))
+        np.testing.assert_allclose(ag.dq_da.cpu().numpy(), r["dq_da"], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(ag.value_targets.cpu().numpy(), r["value_targets"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(ag.td_targets.cpu().numpy(), r["td_targets"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(float(qn.loss.sum()), r["loss"], rtol=3e-4)
+        np.testing.assert_allclose(float(vn.loss), r["v_loss"], rtol=3e-4)
+        ag.update_target_networks(0.005); ov.mix_target(0.005)
+    _check_weights(pol, op, atol=5e-5)
+    _check_weights(qn, oq, atol=5e-5)
+    _check_weights(vn, ov, atol=5e-5)
+    ag.check_status()
