@@ -174,9 +174,9 @@ class ClippedPPOAgent(object):
         self.mb_clipped = torch.empty(B, dtype=f32, device=dev)
         self.scalar_acc = torch.zeros(8, dtype=f32, device=dev)
         # one uniform per (step, env): what the phase's np.random.choice calls consume
-        self.uniforms_all = torch.zeros(self.steps_per_phase, self.n_env, dtype=f64, device=dev)
-        self.uniforms_host = torch.zeros(self.steps_per_phase, self.n_env, dtype=f64).pin_memory() \
-            if torch.cuda.is_available() else torch.zeros(self.steps_per_phase, self.n_env, dtype=f64)
+        from ..staging import Stager
+        self._uniforms = Stager((self.steps_per_phase, self.n_env), f64, dev, depth=4)
+        self.uniforms_all = self._uniforms.dst
 
     # ------------------------------------------------------------------------------ graph util
     def _run(self, key, fn):
@@ -225,8 +225,7 @@ class ClippedPPOAgent(object):
             # draws of the whole phase, in the order n_env sequential np.random.choice calls per step
             # would make them (nothing else consumes np.random while acting)
             u = np.random.random_sample((self.steps_per_phase, self.n_env))
-            self.uniforms_host.copy_(torch.from_numpy(u))
-            self.uniforms_all.copy_(self.uniforms_host, non_blocking=True)
+            self._uniforms.push(u)
         self.ap.algorithm.clipping_decay_schedule.step()                    # choose_action (:352-354)
         self._run(("act", step, self.phase), lambda: self._act_device(step))
         self.memory.steps += 1

@@ -97,7 +97,8 @@ class VectorOffPolicyAgent(GraphRunner):
         self.ep_acc = torch.zeros(8, dtype=torch.float64, device=dev)
         self.lib.episode_stats_init(self.ep_return, self.ep_len, n, self.ep_acc, _rlx.current_stream())
         self.signals = {}
-        self._pins = {}
+        from ..staging import StagerCache
+        self._stagers = StagerCache(self.device)
         self.debug_draws = None          # tests set these to lists to record every replay draw /
         self.debug_losses = None         # every update's loss (forces a sync per update)
 
@@ -128,18 +129,8 @@ class VectorOffPolicyAgent(GraphRunner):
         return ExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling, **kw)
 
     def _to_device(self, key, array, dtype):
-        """host draws -> device through a cached pinned staging buffer."""
-        a = np.ascontiguousarray(array)
-        ent = self._pins.get(key)
-        if ent is None or ent[0].shape != a.shape:
-            host = torch.zeros(a.shape, dtype=dtype)
-            if torch.cuda.is_available():
-                host = host.pin_memory()
-            ent = (host, torch.zeros(a.shape, dtype=dtype, device=self.device))
-            self._pins[key] = ent
-        ent[0].copy_(torch.from_numpy(a))
-        ent[1].copy_(ent[0], non_blocking=True)
-        return ent[1]
+        """host draws -> a static device buffer through a ring of pinned staging slots."""
+        return self._stagers.push(key, array, dtype)
 
     # --------------------------------------------------------------------------------- acting
     def random_actions(self):

@@ -37,10 +37,9 @@ class AdditiveNoise(object):
         self.d_low = torch.from_numpy(self.low).to(device)
         self.d_high = torch.from_numpy(self.high).to(device)
         self.d_std = torch.zeros(self.A, dtype=torch.float32, device=device)
-        pin = torch.cuda.is_available()
-        self.h_z = torch.zeros(n_env, self.A, dtype=torch.float64)
-        self.h_z = self.h_z.pin_memory() if pin else self.h_z
-        self.d_z = torch.zeros(n_env, self.A, dtype=torch.float64, device=device)
+        from ..staging import Stager
+        self._z = Stager((n_env, self.A), torch.float64, device)
+        self.d_z = self._z.dst
 
     def current_std(self):
         noise = self.evaluation_noise if self.phase == RunPhase.TEST else self.noise_schedule.current_value
@@ -57,8 +56,7 @@ class AdditiveNoise(object):
             z = np.random.standard_normal((self.n_env, self.A))              # np.random.normal (:106)
         else:
             z = np.zeros((self.n_env, self.A))
-        self.h_z.copy_(torch.from_numpy(z))
-        self.d_z.copy_(self.h_z, non_blocking=True)
+        self._z.push(z)
         self.d_std.copy_(torch.from_numpy(std), non_blocking=True)
         self.lib.gaussian_action(action_means, self.d_std, None, self.d_z, self.d_low, self.d_high,
                                  self.n_env, self.A, out_actions, _rlx.current_stream())

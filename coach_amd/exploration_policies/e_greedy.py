@@ -33,11 +33,9 @@ class EGreedy(object):
         self.phase = RunPhase.HEATUP
         self.lib = _rlx.lib()
         self.current_random_value = np.array([np.random.rand() for _ in range(n_env)])   # :82
-        pin = torch.cuda.is_available()
-        mk = lambda shape, dt: (torch.zeros(shape, dtype=dt).pin_memory() if pin else torch.zeros(shape, dtype=dt))
-        self._h = dict(u=mk((n_env,), torch.float64), ra=mk((n_env,), torch.int32),
-                       tie=mk((n_env, num_actions), torch.float64))
-        self._d = {k: torch.zeros_like(v, device=device) for k, v in self._h.items()}
+        from ..staging import Stager
+        self._st = dict(u=Stager((n_env,), torch.float64, device), ra=Stager((n_env,), torch.int32, device),
+                        tie=Stager((n_env, num_actions), torch.float64, device))
 
     def epsilon(self):
         return self.evaluation_epsilon if self.phase == RunPhase.TEST else self.epsilon_schedule.current_value
@@ -62,10 +60,8 @@ class EGreedy(object):
 
     def get_action(self, q_values, draws, out_actions):
         eps, u, ra, tie = draws
-        h, d = self._h, self._d
-        h["u"].copy_(torch.from_numpy(u)); h["ra"].copy_(torch.from_numpy(ra)); h["tie"].copy_(torch.from_numpy(tie))
-        for k in h:
-            d[k].copy_(h[k], non_blocking=True)
+        st = self._st
+        d = dict(u=st["u"].push(u), ra=st["ra"].push(ra), tie=st["tie"].push(tie))
         self.lib.egreedy(q_values, self.A, d["u"], d["ra"], d["tie"], float(eps), self.n_env, self.A,
                          out_actions, _rlx.current_stream())
         return out_actions

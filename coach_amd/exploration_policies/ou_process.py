@@ -37,9 +37,9 @@ class OUProcess(object):
         self.d_low = torch.from_numpy(self.low).to(device)
         self.d_high = torch.from_numpy(self.high).to(device)
         self.d_one = torch.ones(self.A, dtype=torch.float32, device=device)
-        self.h_z = torch.zeros(n_env, self.A, dtype=torch.float64)
-        self.h_z = self.h_z.pin_memory() if torch.cuda.is_available() else self.h_z
-        self.d_z = torch.zeros(n_env, self.A, dtype=torch.float64, device=device)
+        from ..staging import Stager
+        self._z = Stager((n_env, self.A), torch.float64, device)
+        self.d_z = self._z.dst
 
     def reset(self):
         self.state = np.zeros((self.n_env, self.A))
@@ -53,8 +53,7 @@ class OUProcess(object):
 
     def get_action(self, action_means, out_actions):
         noise = self.noise() if self.phase == RunPhase.TRAIN else np.zeros((self.n_env, self.A))
-        self.h_z.copy_(torch.from_numpy(noise))
-        self.d_z.copy_(self.h_z, non_blocking=True)
+        self._z.push(noise)
         self.lib.gaussian_action(action_means, self.d_one, None, self.d_z, self.d_low, self.d_high,
                                  self.n_env, self.A, out_actions, _rlx.current_stream())
         return out_actions

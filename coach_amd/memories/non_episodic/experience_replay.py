@@ -180,17 +180,17 @@ class ExperienceReplay(Memory):
                                    dtype=self.action.dtype, device=dev),
                 reward=torch.empty(size, dtype=torch.float32, device=dev),
                 game_over=torch.empty(size, dtype=torch.uint8, device=dev))
+            from ...staging import Stager
+            st = Stager((size,), torch.int32, dev)
+            b["rows"] = st.dst
             self._batches[size] = b
-            host = torch.zeros(size, dtype=torch.int32)
-            self._pinned[size] = host.pin_memory() if torch.cuda.is_available() else host
+            self._pinned[size] = st
         return b
 
     def gather(self, rows_host, size):
         """Collate the Batch of the given PHYSICAL rows (one H2D copy of B int32 + 2 launches)."""
         b = self._batch_buffers(size)
-        pin = self._pinned[size]
-        pin.copy_(torch.from_numpy(np.ascontiguousarray(rows_host, dtype=np.int32)))
-        b["rows"].copy_(pin, non_blocking=True)
+        self._pinned[size].push(np.asarray(rows_host, dtype=np.int32))
         self.gather_device(b["rows"], size, b)
         return b
 

@@ -97,10 +97,10 @@ class PrioritizedExperienceReplay(ExperienceReplay):
     def _per_buffers(self, size):
         p = self._per.get(size)
         if p is None:
+            from ...staging import Stager
             dev = self.device
-            host = torch.zeros(size, dtype=torch.float64)
-            p = dict(u=torch.zeros(size, dtype=torch.float64, device=dev),
-                     u_host=host.pin_memory() if torch.cuda.is_available() else host,
+            st = Stager((size,), torch.float64, dev)
+            p = dict(u=st.dst, u_stage=st,
                      idx=torch.zeros(size, dtype=torch.int32, device=dev),
                      weight=torch.zeros(size, dtype=torch.float64, device=dev),
                      weight32=torch.zeros(size, dtype=torch.float32, device=dev))
@@ -127,8 +127,7 @@ class PrioritizedExperienceReplay(ExperienceReplay):
         u, n_transitions, beta = drawn
         p = self._per_buffers(size)
         b = self._batch_buffers(size)
-        p["u_host"].copy_(torch.from_numpy(u))
-        p["u"].copy_(p["u_host"], non_blocking=True)
+        p["u_stage"].push(u)
         s = _rlx.current_stream()
         self.lib.per_sample(self.sum_tree, self.min_tree, self.power_of_2_size, p["u"], size,
                             n_transitions, beta, p["idx"], p["weight"], None, s)

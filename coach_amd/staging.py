@@ -1,0 +1,58 @@
+"""Host -> device staging of small per-step payloads (replay indices, RNG draws).
+
+The destination is ONE static device buffer (hipGraph replays read it), the source is a ring of
+pinned host buffers: the H2D copy is asynchronous, so the host may run many steps ahead of the GPU
+— a pinned slot is only rewritten after the event recorded behind its last copy has completed.
+(Rewriting a single pinned buffer while an earlier async copy from it is still queued silently
+ships the NEW contents twice.)
+"""
+import numpy as np
+import torch
+
+
+class Stager(object):
+    def __init__(self, shape, dtype, device, depth=16):
+        self.device = device
+        self.dst = torch.zeros(shape, dtype=dtype, device=device)
+        self.cuda = torch.cuda.is_available() and torch.device(device).type == "cuda"
+        self.depth = depth if self.cuda else 1
+        self.slots, self.events = [], []
+        for _ in range(self.depth):
+            h = torch.zeros(shape, dtype=dtype)
+            self.slots.append(h.pin_memory() if self.cuda else h)
+            self.events.append(None)
+        self.i = 0
+
+    def push(self, array):
+        """copy a numpy array (same shape) to the static device buffer; returns that buffer."""
+        i = self.i
+        self.i = (i + 1) % self.depth
+        ev = self.events[i]
+        if ev is not None:
+            ev.synchronize()                      # the copy that last used this slot is done
+        self.slots[i].copy_(torch.from_numpy(np.ascontiguousarray(array)).view_as(self.slots[i]))
+        self.dst.copy_(self.slots[i], non_blocking=True)
+        if self.cuda:
+            if ev is None:
+                ev = torch.cuda.Event()
+                self.events[i] = ev
+            ev.record()
+        return self.dst
+
+
+class StagerCache(object):
+    """{key: Stager} created on first use from the pushed array's shape."""
+
+    def __init__(self, device):
+        self.device, self._s = device, {}
+
+    def push(self, key, array, dtype):
+        a = np.asarray(array)
+        st = self._s.get((key, a.shape))
+        if st is None:
+            st = Stager(a.shape, dtype, self.device)
+            self._s[(key, a.shape)] = st
+        return st.push(a.astype(_NP[dtype], copy=False))
+
+
+_NP = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32, torch.uint8: np.uint8}

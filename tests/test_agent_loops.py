@@ -1,0 +1,81 @@
+"""Whole act/train loops of the off-policy agents: the hipGraph-replayed path must reproduce the
+eager path bit for bit (same kernels, same order), the training cadence must follow the reference's
+rules (agent.py:662-770, td3_agent.py:211-213), and the status words stay clean."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(dev, name, use_graphs, n_env=8, L=5):
+    from coach_amd.core_types import EnvironmentSteps
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    if name == "dqn":
+        from coach_amd.agents.dqn_agent import DQNAgent as C, DQNAgentParameters as P
+        ep = SyntheticVectorEnvironmentParameters("vector", n_env, (6,), 4, episode_length=L, seed=9)
+    else:
+        ep = SyntheticVectorEnvironmentParameters("vector", n_env, (9,), None, action_dim=3, episode_length=L, seed=9)
+        if name == "ddpg":
+            from coach_amd.agents.ddpg_agent import DDPGAgent as C, DDPGAgentParameters as P
+        elif name == "td3":
+            from coach_amd.agents.td3_agent import TD3Agent as C, TD3AgentParameters as P
+        else:
+            from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgent as C, \
+                SoftActorCriticAgentParameters as P
+    p = P()
+    p.seed = 11
+    for n in p.network_wrappers.values():
+        n.batch_size = 16
+    p.memory.max_size = (MemoryGranularity.Transitions, 160)
+    if name == "dqn":
+        p.algorithm.num_consecutive_playing_steps = EnvironmentSteps(4)
+        p.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(32)
+    env = SyntheticVectorEnvironment(ep, dev)
+    return C(p, env, dev, use_graphs=use_graphs)
+
+
+def _drive(agent, heatup, steps):
+    from coach_amd.core_types import RunPhase
+    random.seed(1); np.random.seed(1)
+    agent.phase = RunPhase.HEATUP
+    for _ in range(heatup):
+        agent.act()
+    agent.phase = RunPhase.TRAIN
+    updates = []
+    for _ in range(steps):
+        agent.act()
+        before = agent.training_iteration
+        agent.train()
+        updates.append(agent.training_iteration - before)
+    agent.check_status()
+    return updates
+
+
+@pytest.mark.parametrize("name", ["dqn", "ddpg", "td3", "sac"])
+def test_graph_replay_equals_eager(dev, name):
+    import torch
+    a = _mk(dev, name, True)
+    ua = _drive(a, 5, 12)
+    b = _mk(dev, name, False)
+    ub = _drive(b, 5, 12)
+    assert ua == ub
+    n_env, L = 8, 5
+    if name == "dqn":
+        assert ua == [n_env // 4] * 12                       # one phase per 4 env-steps
+    elif name == "td3":
+        # trains only when the lockstep episodes end: n_env phases x L updates (td3_agent.py:211-213)
+        assert sum(ua) == (17 // L - 5 // L) * n_env * L and set(ua) == {0, n_env * L}
+    else:
+        assert ua == [n_env] * 12                            # EnvironmentSteps(1): one phase per env-step
+    for k in a.networks:
+        wa, wb = a.networks[k].params.weights, b.networks[k].params.weights
+        assert torch.equal(wa, wb), k
+        assert torch.isfinite(wa).all()
+        if a.networks[k].target is not None:
+            assert torch.equal(a.networks[k].target, b.networks[k].target)
+    st = a.episode_statistics()
+    assert st["episodes"] == (17 // L) * n_env and st["mean_length"] == L
