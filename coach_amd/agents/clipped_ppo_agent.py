@@ -290,8 +290,7 @@ class ClippedPPOAgent(object):
     def _minibatch_finish(self, scale):
         net = self.networks["main"]
         net.finish_update(scale)
-        self.scalar_acc[:5].add_(net.scalars[:5])
-        self.scalar_acc[5:6].add_(net.norm)
+        self.scalar_acc[:6].add_(net.scalars[:6])
 
     def train_network(self, order, epochs):
         """clipped_ppo_agent.py:209-308.  `order`: dataset indices after the reference's

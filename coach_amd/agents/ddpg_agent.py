@@ -169,8 +169,7 @@ class DDPGAgent(VectorOffPolicyAgent):
         _, c_saved = critic.forward(s, b.actions(), B, tag="train")
         critic.train_backward(c_saved, self.td_targets, B)
         self._sync(critic)
-        critic.grad_norm()
-        critic.apply_gradients(self._scale("critic"))
+        critic.apply_gradients(self._scale("critic"), with_norm=True)
         # actor: weighted_gradients[0] with gradients_weights = -action_gradients (:183-193)
         actor.backward(a_saved, self.neg_action_grad, B)
         self._sync(actor)

@@ -185,8 +185,7 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         _, q_saved = q.forward(s, b.actions(), B, tag="train")
         q.train_backward(q_saved, self.td_targets, B)
         self._sync(q)
-        q.grad_norm()
-        q.apply_gradients(self._scale("q"))
+        q.apply_gradients(self._scale("q"), with_norm=True)
 
     def learn_from_batch(self, batch):
         B = self.batch_size

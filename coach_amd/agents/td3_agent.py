@@ -113,8 +113,7 @@ class TD3Agent(DDPGAgent):
         _, c_saved = critic.forward(s, b.actions(), B, tag="train")
         critic.train_backward(c_saved, self.td_targets, B)
         self._sync(critic)
-        critic.grad_norm()
-        critic.apply_gradients(self._scale("critic"))
+        critic.apply_gradients(self._scale("critic"), with_norm=True)
 
     def _actor_device(self, b):
         actor, critic = self.networks["actor"], self.networks["critic"]

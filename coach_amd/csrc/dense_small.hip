@@ -1,0 +1,199 @@
+// Narrow dense layers (N <= 16 output units): the value / policy / Q heads and their gradients.
+//
+// Replaces tf.layers.dense and tf.gradients for the network heads
+// (rl_coach/architectures/tensorflow_components/layers.py:168-185; heads/v_head.py:43-48,
+// heads/ppo_head.py:100-116, heads/q_head.py, heads/ddpg_actor_head.py:48-56, td3_v_head.py:40-60).
+//
+// A head has K = 256..512 inputs and 1..17 outputs on a minibatch of 32..256 rows: 0.05-2 MFLOP.
+// As an MFMA GEMM that is one 32x32 tile with 26 of 32 columns wasted plus a split-K reduce launch;
+// here it is plain fp32 FMA work laid out for coalescing:
+//   forward : one wave per row m; lanes stride over k (x[m][k] coalesced, W[k][0..N) from L1/L2),
+//             N accumulators per lane, wave64 butterfly reduction.
+//   backward: ONE launch produces dW = x^T dz, db = 1^T dz and dx = dz W^T.  A workgroup owns 64
+//             input features k (64 lanes) x 4 row groups; dz (with this layer's activation
+//             derivative applied on the way in) sits in LDS, x[m][k] is read exactly once and used
+//             for both dW and the activation derivative of the layer below (dx is written as the
+//             lower layer's dz), the 4 row-group partials of dW are combined in a fixed order.
+// Latency-bound by construction (a few hundred KB); the point is 2 launches per head instead of ~8.
+#include "rlx_common.hpp"
+
+namespace {
+
+constexpr int kMaxN = 16;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == RLX_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == RLX_ACT_TANH) return tanhf(v);
+    return v;
+}
+__device__ __forceinline__ float act_deriv_out(float y, int kind) {
+    if (kind == RLX_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (kind == RLX_ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+struct SmallDense {
+    const float *x; long long x_ts;        // [T][M][K] (x_ts = 0: shared input)
+    const float *w; long long w_ts;        // [T][K][N]
+    const float *b; long long b_ts;        // [T][N]
+    float *y; long long y_ts;              // [T][M][N]
+    int M, K, N, act;
+};
+
+template <int NN>
+__global__ void __launch_bounds__(256) dense_small_fwd_kernel(const SmallDense p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave, t = blockIdx.y;
+    if (m >= p.M) return;
+    const float *x = p.x + (size_t)t * p.x_ts + (size_t)m * p.K;
+    const float *w = p.w + (size_t)t * p.w_ts;
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[n] = 0.f;
+    for (int k = lane; k < p.K; k += 64) {
+        const float xv = x[k];
+        const float *wr = w + (size_t)k * p.N;
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+            if (n < p.N) acc[n] = fmaf(xv, wr[n], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        float v = acc[n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[n] = v;
+    }
+    if (lane < p.N) {
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+            if (n == lane) v = acc[n];
+        v += p.b ? p.b[(size_t)t * p.b_ts + lane] : 0.f;
+        p.y[(size_t)t * p.y_ts + (size_t)m * p.N + lane] = act_apply(v, p.act);
+    }
+}
+
+struct SmallDenseBwd {
+    const float *x; long long x_ts;        // [T][M][K] layer input (= lower layer's output)
+    const float *w; long long w_ts;        // [T][K][N]
+    const float *dy; long long dy_ts;      // [T][M][N] gradient w.r.t. this layer's OUTPUT
+    const float *y; long long y_ts;        // [T][M][N] this layer's output (for its own act') or null
+    float *dw; long long dw_ts;            // [T][K][N] or null
+    float *db; long long db_ts;            // [T][N] or null
+    float *dx; long long dx_ts;            // [T][M][K] or null
+    int M, K, N, act, lower_act;           // lower_act != 0: dx *= act'(x)  (x is the lower layer's output)
+};
+
+// block = 256 threads: lane = k within the 64-feature slab, g = row group (rows g, g+4, ...).
+template <int NN>
+__global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBwd p) {
+    extern __shared__ float smem[];
+    float *dz = smem;                              // [M][N]
+    float *part = smem + (size_t)p.M * p.N;        // [4][64][NN] dW partials
+    const int t = blockIdx.y;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    const float *dy = p.dy + (size_t)t * p.dy_ts;
+    const float *yy = p.y ? p.y + (size_t)t * p.y_ts : nullptr;
+    for (int i = threadIdx.x; i < p.M * p.N; i += 256)
+        dz[i] = dy[i] * (yy ? act_deriv_out(yy[i], p.act) : 1.f);
+    __syncthreads();
+    const bool live = k < p.K;
+    const float *x = p.x + (size_t)t * p.x_ts;
+    float wk[NN], acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        acc[n] = 0.f;
+        wk[n] = (live && n < p.N) ? p.w[(size_t)t * p.w_ts + (size_t)k * p.N + n] : 0.f;
+    }
+    float *dx = p.dx ? p.dx + (size_t)t * p.dx_ts : nullptr;
+    if (live) {
+        for (int m = g; m < p.M; m += 4) {
+            const float xv = x[(size_t)m * p.K + k];
+            const float *dzr = dz + (size_t)m * p.N;
+            float s = 0.f;
+#pragma unroll
+            for (int n = 0; n < NN; ++n)
+                if (n < p.N) {
+                    const float d = dzr[n];
+                    acc[n] = fmaf(xv, d, acc[n]);
+                    s = fmaf(d, wk[n], s);
+                }
+            if (dx) dx[(size_t)m * p.K + k] = p.lower_act ? s * act_deriv_out(xv, p.lower_act) : s;
+        }
+    }
+    if (p.dw) {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) part[((size_t)g * 64 + lane) * NN + n] = acc[n];
+        __syncthreads();
+        if (g == 0 && live) {
+            float *dw = p.dw + (size_t)t * p.dw_ts + (size_t)k * p.N;
+#pragma unroll
+            for (int n = 0; n < NN; ++n)
+                if (n < p.N)
+                    dw[n] = ((part[(0 * 64 + lane) * NN + n] + part[(1 * 64 + lane) * NN + n]) +
+                             part[(2 * 64 + lane) * NN + n]) + part[(3 * 64 + lane) * NN + n];
+        }
+    }
+    if (p.db && blockIdx.x == 0 && threadIdx.x < p.N) {
+        float s = 0.f;
+        for (int m = 0; m < p.M; ++m) s += dz[(size_t)m * p.N + threadIdx.x];
+        p.db[(size_t)t * p.db_ts + threadIdx.x] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlx_dense_small_forward(const float *x, long long x_tower_stride, const float *w,
+                            long long w_tower_stride, const float *bias, long long bias_tower_stride,
+                            float *y, long long y_tower_stride, int towers, int M, int K, int N,
+                            int activation, void *stream) {
+    RLX_REQUIRE(x && w && y, "rlx_dense_small_forward: null pointer");
+    RLX_REQUIRE(towers > 0 && M > 0 && K > 0 && N > 0 && N <= kMaxN,
+                "rlx_dense_small_forward: need 1 <= N <= %d (got M=%d K=%d N=%d)", kMaxN, M, K, N);
+    RLX_REQUIRE(activation >= 0 && activation <= 2, "rlx_dense_small_forward: unknown activation");
+    SmallDense p{x, x_tower_stride, w, w_tower_stride, bias, bias_tower_stride, y, y_tower_stride,
+                 M, K, N, activation};
+    dim3 grid((M + 3) / 4, towers);
+    hipStream_t s = rlx::as_stream(stream);
+    if (N <= 1) dense_small_fwd_kernel<1><<<grid, 256, 0, s>>>(p);
+    else if (N <= 4) dense_small_fwd_kernel<4><<<grid, 256, 0, s>>>(p);
+    else if (N <= 8) dense_small_fwd_kernel<8><<<grid, 256, 0, s>>>(p);
+    else dense_small_fwd_kernel<16><<<grid, 256, 0, s>>>(p);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_dense_small_backward(const float *x, long long x_tower_stride, const float *w,
+                             long long w_tower_stride, const float *dy, long long dy_tower_stride,
+                             const float *y, long long y_tower_stride, float *dw,
+                             long long dw_tower_stride, float *db, long long db_tower_stride, float *dx,
+                             long long dx_tower_stride, int towers, int M, int K, int N, int activation,
+                             int lower_activation, void *stream) {
+    RLX_REQUIRE(x && w && dy, "rlx_dense_small_backward: null pointer");
+    RLX_REQUIRE(dw || dx, "rlx_dense_small_backward: nothing to produce");
+    RLX_REQUIRE(towers > 0 && M > 0 && K > 0 && N > 0 && N <= kMaxN,
+                "rlx_dense_small_backward: need 1 <= N <= %d (got M=%d K=%d N=%d)", kMaxN, M, K, N);
+    RLX_REQUIRE(activation >= 0 && activation <= 2 && lower_activation >= 0 && lower_activation <= 2,
+                "rlx_dense_small_backward: unknown activation");
+    RLX_REQUIRE(activation == 0 || y, "rlx_dense_small_backward: the activation derivative needs y");
+    const int NN = N <= 1 ? 1 : N <= 4 ? 4 : N <= 8 ? 8 : 16;
+    const size_t smem = ((size_t)M * N + 4 * 64 * NN) * sizeof(float);
+    RLX_REQUIRE(smem <= 64 * 1024, "rlx_dense_small_backward: batch %d x %d outputs exceeds the LDS budget", M, N);
+    SmallDenseBwd p{x, x_tower_stride, w, w_tower_stride, dy, dy_tower_stride, y, y_tower_stride,
+                    dw, dw_tower_stride, db, db_tower_stride, dx, dx_tower_stride,
+                    M, K, N, activation, lower_activation};
+    dim3 grid((K + 63) / 64, towers);
+    hipStream_t s = rlx::as_stream(stream);
+    if (NN == 1) dense_small_bwd_kernel<1><<<grid, 256, smem, s>>>(p);
+    else if (NN == 4) dense_small_bwd_kernel<4><<<grid, 256, smem, s>>>(p);
+    else if (NN == 8) dense_small_bwd_kernel<8><<<grid, 256, smem, s>>>(p);
+    else dense_small_bwd_kernel<16><<<grid, 256, smem, s>>>(p);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+}  // extern "C"

@@ -27,10 +27,14 @@ namespace {
 constexpr int kBlock = 256;
 
 // state[0] = beta1_power, state[1] = beta2_power (fp32, device).
+template <bool NORM>
 __global__ void adam_tf1_kernel(float *__restrict__ w, const float *__restrict__ g,
                                 float *__restrict__ m, float *__restrict__ v, long long n,
                                 float lr, float beta1, float beta2, float eps,
-                                const float *__restrict__ state, float grad_scale) {
+                                const float *__restrict__ state, float grad_scale,
+                                float *__restrict__ sumsq_part) {
+    __shared__ float red[kBlock];
+    float ss = 0.f;
     const float b1p = state[0], b2p = state[1];
     const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
@@ -44,6 +48,7 @@ __global__ void adam_tf1_kernel(float *__restrict__ w, const float *__restrict__
         float *gp = &gw.x, *mp = &mw.x, *vp = &vw.x, *wp = &ww.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            if (NORM) ss += gp[k] * gp[k];
             const float gr = gp[k] * grad_scale;
             mp[k] += (gr - mp[k]) * omb1;
             vp[k] += (gr * gr - vp[k]) * omb2;
@@ -54,16 +59,46 @@ __global__ void adam_tf1_kernel(float *__restrict__ w, const float *__restrict__
         reinterpret_cast<float4 *>(w)[i] = ww;
     }
     for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (NORM) ss += g[i] * g[i];
         const float gr = g[i] * grad_scale;
         m[i] += (gr - m[i]) * omb1;
         v[i] += (gr * gr - v[i]) * omb2;
         w[i] -= (m[i] * alpha) / (sqrtf(v[i]) + eps);
+    }
+    if (NORM) {
+        red[threadIdx.x] = ss;
+        __syncthreads();
+        for (int d = kBlock >> 1; d > 0; d >>= 1) {
+            if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sumsq_part[blockIdx.x] = red[0];
     }
 }
 
 __global__ void adam_advance_kernel(float *state, float beta1, float beta2) {
     state[0] *= beta1;       // AdamOptimizer._finish: beta1_power *= beta1
     state[1] *= beta2;
+}
+
+// advance the beta powers AND finish the gradient norm (one workgroup, fixed summation order)
+__global__ void adam_finish_norm_kernel(float *state, float beta1, float beta2,
+                                        const float *__restrict__ part, int nparts,
+                                        float *__restrict__ norm_out) {
+    __shared__ float red[kBlock];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = kBlock >> 1; d > 0; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        norm_out[0] = sqrtf(red[0]);
+        state[0] *= beta1;
+        state[1] *= beta2;
+    }
 }
 
 __global__ void mix_kernel(float *__restrict__ target, const float *__restrict__ online, long long n,
@@ -134,10 +169,31 @@ int rlx_adam_tf1(float *weights, const float *grads, float *m, float *v, long lo
     RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                 "rlx_adam_tf1: buffers must be 16-byte aligned");
     hipStream_t s = rlx::as_stream(stream);
-    adam_tf1_kernel<<<rlx::grid_for(n / 4 + 1, kBlock), kBlock, 0, s>>>(
-        weights, grads, m, v, n, learning_rate, beta1, beta2, epsilon, state, grad_scale);
+    adam_tf1_kernel<false><<<rlx::grid_for(n / 4 + 1, kBlock), kBlock, 0, s>>>(
+        weights, grads, m, v, n, learning_rate, beta1, beta2, epsilon, state, grad_scale, nullptr);
     RLX_LAUNCH_CHECK();
     adam_advance_kernel<<<1, 1, 0, s>>>(state, beta1, beta2);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, long long n,
+                      float learning_rate, float beta1, float beta2, float epsilon, float *state,
+                      float grad_scale, float *norm_out, float *workspace, long long workspace_floats,
+                      void *stream) {
+    RLX_REQUIRE(weights && grads && m && v && state && norm_out && workspace,
+                "rlx_adam_tf1_norm: null pointer");
+    RLX_REQUIRE(n > 0, "rlx_adam_tf1_norm: empty parameter buffer");
+    RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                "rlx_adam_tf1_norm: buffers must be 16-byte aligned");
+    int blocks = rlx::grid_for(n / 4 + 1, kBlock, 1024);
+    if (blocks > workspace_floats) blocks = (int)workspace_floats;
+    RLX_REQUIRE(blocks >= 1, "rlx_adam_tf1_norm: workspace too small");
+    hipStream_t s = rlx::as_stream(stream);
+    adam_tf1_kernel<true><<<blocks, kBlock, 0, s>>>(weights, grads, m, v, n, learning_rate, beta1, beta2,
+                                                    epsilon, state, grad_scale, workspace);
+    RLX_LAUNCH_CHECK();
+    adam_finish_norm_kernel<<<1, kBlock, 0, s>>>(state, beta1, beta2, workspace, blocks, norm_out);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

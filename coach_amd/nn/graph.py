@@ -24,6 +24,7 @@ import torch
 from .. import _rlx
 
 ALIGN = 4  # floats (16 bytes)
+SMALL_N = 16  # widest layer served by the narrow-dense kernels (csrc/dense_small.hip)
 
 
 def _align(n):
@@ -127,9 +128,11 @@ class Tensor:
     """An activation `data` [towers, rows, cols]; towers == 0 marks an input shared by all towers.
     For NHWC images `rows` counts samples and cols = H*W*C."""
 
-    def __init__(self, data, rows, cols, towers, u8=False, div=1.0, grad_key=None):
+    def __init__(self, data, rows, cols, towers, u8=False, div=1.0, grad_key=None, act=None):
         self.data, self.rows, self.cols, self.towers = data, rows, cols, towers
         self.u8, self.div = u8, div
+        self.act = act                      # activation of the layer that produced this tensor
+        self.grad_is_dz = False             # grad already carries act'(data) (applied by the consumer)
         self.grad = None
         self.grad_key = grad_key            # (ctx, name, tag): gradient lives in a cached buffer
 
@@ -148,7 +151,7 @@ class Tensor:
     def tower(self, t):
         """One tower as a single-tower tensor; data and gradient alias this tensor's memory."""
         g = self.ensure_grad()
-        v = Tensor(self.data[t:t + 1], self.rows, self.cols, 1)
+        v = Tensor(self.data[t:t + 1], self.rows, self.cols, 1, act=self.act)
         v.grad = g[t:t + 1]
         return v
 
@@ -186,12 +189,19 @@ class Dense(Layer):
         assert x.towers in (0, T), (self.name, x.towers, T)
         y = ctx.buffer(self.name, (T, M, self.N), tag=tag)
         p = self.params
-        _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
-                  bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
-                  a_batch_stride=x.tower_stride(), b_batch_stride=p.stride(self.kname),
-                  c_batch_stride=M * self.N, bias_batch_stride=p.stride(self.bname),
-                  workspace=ctx.ws.splitk)
-        return Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag))
+        if self.N <= SMALL_N and not x.u8:
+            # heads: coalesced FMA kernel, no MFMA tile / split-K round trip (csrc/dense_small.hip)
+            ctx.lib.dense_small_forward(x.data, x.tower_stride(), p.w(self.kname, t0, weights),
+                                        p.stride(self.kname), p.w(self.bname, t0, weights),
+                                        p.stride(self.bname), y, M * self.N, T, M, self.K, self.N,
+                                        _rlx.ACT[self.act], ctx.stream)
+        else:
+            _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
+                      bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
+                      a_batch_stride=x.tower_stride(), b_batch_stride=p.stride(self.kname),
+                      c_batch_stride=M * self.N, bias_batch_stride=p.stride(self.bname),
+                      workspace=ctx.ws.splitk)
+        return Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag), act=self.act)
 
     def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True):
         """y.grad holds dL/dy (post-activation); writes dW, db and (optionally) x.grad.
@@ -199,8 +209,23 @@ class Dense(Layer):
         t0, T = self._range(t0, nt)
         M, p = x.rows, self.params
         dz = y.grad
-        if self.act is not None:                      # dz = dy * act'(y), in place
-            ctx.lib.act_backward(dz, y.data, T * M * self.N, _rlx.ACT[self.act], ctx.stream)
+        own_act = self.act if (self.act is not None and not y.grad_is_dz) else None
+        lower = x.act if need_dx else None           # fuse the lower layer's act' into dx
+        if need_dx:
+            assert x.towers == T, "input gradients need a per-tower input"
+        if self.N <= SMALL_N and not x.u8 and (M * self.N + 4096) * 4 <= 64 * 1024:
+            dx = x.ensure_grad() if need_dx else None
+            ctx.lib.dense_small_backward(
+                x.data, x.tower_stride(), p.w(self.kname, t0, weights), p.stride(self.kname),
+                dz, M * self.N, y.data if own_act else None, M * self.N,
+                p.g(self.kname, t0) if need_dw else None, p.stride(self.kname),
+                p.g(self.bname, t0) if need_dw else None, p.stride(self.bname),
+                dx, M * self.K, T, M, self.K, self.N, _rlx.ACT[own_act], _rlx.ACT[lower], ctx.stream)
+            if need_dx:
+                x.grad_is_dz = lower is not None
+            return
+        if own_act is not None:                       # dz = dy * act'(y), in place
+            ctx.lib.act_backward(dz, y.data, T * M * self.N, _rlx.ACT[own_act], ctx.stream)
         # dW[K,N] = x^T dz : A(k, m) = x[m, k]
         # (db = column sums of dz, accumulated by the same launch from the staged B slabs)
         if need_dw:
@@ -209,12 +234,15 @@ class Dense(Layer):
                       c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
                       colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
         if need_dx:
-            assert x.towers == T, "input gradients need a per-tower input"
             dx = x.ensure_grad()
-            # dx[M,K] = dz W^T : B(n, k) = W[k, n]
+            # dx[M,K] = dz W^T : B(n, k) = W[k, n]; the epilogue multiplies by the lower layer's
+            # activation derivative, so dx IS that layer's dz (no separate act_backward launch)
             _rlx.gemm(M, self.K, self.N, dz, p.w(self.kname, t0, weights), dx, b_strides=(1, self.N),
                       batch=T, a_batch_stride=M * self.N, b_batch_stride=p.stride(self.kname),
-                      c_batch_stride=M * self.K, workspace=ctx.ws.splitk)
+                      c_batch_stride=M * self.K, workspace=ctx.ws.splitk,
+                      deriv_aux=x.data if lower else None, aux_ld=self.K, deriv_kind=lower,
+                      aux_batch_stride=M * self.K)
+            x.grad_is_dz = lower is not None
 
 
 class Conv2d(Layer):
@@ -265,7 +293,7 @@ class Conv2d(Layer):
                   c_batch_stride=M * self.Co, bias_batch_stride=p.stride(self.bname),
                   workspace=ctx.ws.splitk)
         # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
-        return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag))
+        return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag), act=self.act)
 
     def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True):
         t0, T = self._range(t0, nt)
@@ -273,7 +301,7 @@ class Conv2d(Layer):
         M = B * self.OH * self.OW
         rb, ko = self._tables(ctx, B)
         dz = y.grad
-        if self.act is not None:
+        if self.act is not None and not y.grad_is_dz:
             ctx.lib.act_backward(dz, y.data, dz.numel(), _rlx.ACT[self.act], ctx.stream)
         dz = dz.view(T, M, self.Co)
         # dW[K,Co] = cols^T dz : A(k, m) gathered with outer table = koff, reduction table = rowbase
@@ -290,9 +318,11 @@ class Conv2d(Layer):
                       batch=T, a_batch_stride=M * self.Co, b_batch_stride=p.stride(self.kname),
                       c_batch_stride=M * self.K, workspace=ctx.ws.splitk)
             dx = x.ensure_grad()
-            # (the producer's activation derivative is applied by ITS backward)
-            ctx.lib.col2im(dcol, dx, None, 0, T * B, self.H, self.W, self.C, self.KH, self.KW, self.S,
-                           ctx.stream)
+            # the gather also applies the producing layer's activation derivative: dx is its dz
+            lower = x.act
+            ctx.lib.col2im(dcol, dx, x.data if lower else None, _rlx.ACT[lower], T * B, self.H, self.W,
+                           self.C, self.KH, self.KW, self.S, ctx.stream)
+            x.grad_is_dz = lower is not None
 
 
 class Sequential:
@@ -329,8 +359,14 @@ class AdamState:
         self.state = torch.empty(2, dtype=torch.float32, device=dev)
         _rlx.lib().adam_init(self.m, self.v, params.size, self.state, beta1, beta2, _rlx.current_stream())
 
-    def step(self, grad_scale=1.0, lr=None):
+    def step(self, grad_scale=1.0, lr=None, norm_out=None, workspace=None):
+        """norm_out given: the same pass also returns tf.global_norm of the gradients."""
         p = self.params
-        _rlx.lib().adam_tf1(p.weights, p.grads, self.m, self.v, p.size, self.lr if lr is None else lr,
-                            self.beta1, self.beta2, self.eps, self.state, grad_scale,
-                            _rlx.current_stream())
+        lr = self.lr if lr is None else lr
+        if norm_out is not None:
+            _rlx.lib().adam_tf1_norm(p.weights, p.grads, self.m, self.v, p.size, lr, self.beta1,
+                                     self.beta2, self.eps, self.state, grad_scale, norm_out, workspace,
+                                     workspace.numel(), _rlx.current_stream())
+        else:
+            _rlx.lib().adam_tf1(p.weights, p.grads, self.m, self.v, p.size, lr, self.beta1, self.beta2,
+                                self.eps, self.state, grad_scale, _rlx.current_stream())

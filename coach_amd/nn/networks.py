@@ -71,8 +71,12 @@ class _NetBase:
                              self.ctx.ws.small.numel(), self.ctx.stream)
         return self.norm
 
-    def apply_gradients(self, grad_scale=1.0):
-        self.adam.step(grad_scale)
+    def apply_gradients(self, grad_scale=1.0, with_norm=False):
+        """Adam; with_norm also refreshes self.norm = tf.global_norm(grads) in the same pass."""
+        if with_norm:
+            self.adam.step(grad_scale, norm_out=self.norm, workspace=self.ctx.ws.small)
+        else:
+            self.adam.step(grad_scale)
 
     def check_status(self):
         s = int(self.status.item())
@@ -99,7 +103,9 @@ class ClippedPPONet(_NetBase):
         self.pi_head = G.Dense(self.params, "main/ppo_head/policy_fc", feat, n_actions, None, 1)
         self.modules = [self.torso, self.v_head, self.pi_head]
         self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
+        # [surrogate, entropy, kl, policy-head total, value loss, grad norm]: one contiguous record
         self.scalars = torch.zeros(8, dtype=torch.float32, device=device)
+        self.norm = self.scalars[5:6]
 
     # ---- inference -------------------------------------------------------------------------
     def policy_probs(self, obs, B, use_target=False, tag="act", out=None):
@@ -143,12 +149,12 @@ class ClippedPPONet(_NetBase):
                                    ctx.stream)
         self.v_head.backward(ctx, xv, v)
         self.pi_head.backward(ctx, xp, logits)
+        mid.grad_is_dz = xv.grad_is_dz and xp.grad_is_dz     # the heads wrote dz of the middleware
         self.torso.backward(ctx, acts)
 
     def finish_update(self, grad_scale=1.0):
         """apply_gradients (architecture.py:469-521): global norm fetch + Adam."""
-        self.grad_norm()
-        self.apply_gradients(grad_scale)
+        self.apply_gradients(grad_scale, with_norm=True)
 
     def train_minibatch(self, obs, B, actions, advantages, value_targets, old_probs,
                         clip_rescaler=1.0, grad_scale=1.0, ratio_out=None, clipped_out=None):
@@ -200,6 +206,5 @@ class DQNNet(_NetBase):
         self.torso.backward(ctx, acts)
         if sync is not None:                          # data-parallel: ONE all-reduce of the flat buffer
             sync.all_reduce_sum(self.params.grads)
-        self.grad_norm()
-        self.apply_gradients(grad_scale)
+        self.apply_gradients(grad_scale, with_norm=True)
         return self.loss

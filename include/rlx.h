@@ -207,6 +207,25 @@ int rlx_conv_tables(int *rowbase, int *koff, int batch, int H, int W, int C, int
 int rlx_col2im(const float *dcol, float *dx, const float *x_out, int deriv_kind, int batch, int H,
                int W, int C, int KH, int KW, int stride, void *stream); /* conv input gradient */
 
+/* Narrow dense layers (1 <= N <= 16 outputs: value / policy / Q heads) as coalesced fp32 FMA
+ * kernels instead of MFMA tiles (heads/v_head.py:43-48, ppo_head.py:100-116, q_head.py,
+ * ddpg_actor_head.py:48-56, td3_v_head.py:40-60).  Tower t of every operand sits at
+ * base + t * tower_stride (x_tower_stride = 0: one input shared by all towers).
+ * forward : y = act(x W + b)
+ * backward: dz = dy * act'(y) (y may be NULL when activation == NONE); dw = x^T dz; db = 1^T dz;
+ *           dx = dz W^T, multiplied by lower_activation'(x) when lower_activation != NONE (dx is then
+ *           the lower layer's dz).  dw/db or dx may be NULL. */
+int rlx_dense_small_forward(const float *x, long long x_tower_stride, const float *w,
+                            long long w_tower_stride, const float *bias, long long bias_tower_stride,
+                            float *y, long long y_tower_stride, int towers, int M, int K, int N,
+                            int activation, void *stream);
+int rlx_dense_small_backward(const float *x, long long x_tower_stride, const float *w,
+                             long long w_tower_stride, const float *dy, long long dy_tower_stride,
+                             const float *y, long long y_tower_stride, float *dw,
+                             long long dw_tower_stride, float *db, long long db_tower_stride, float *dx,
+                             long long dx_tower_stride, int towers, int M, int K, int N, int activation,
+                             int lower_activation, void *stream);
+
 /* -------------------------------------------------------- head losses (K9) -- */
 /* loss = mean_b(loss_weight * w_b * sum_j l(target, out)); kind 0 = MSE, 1 = Huber(delta 1).
  * grad (optional) = grad_scale * d loss / d out.  heads/head.py:143-186, q_head.py, v_head.py:43-52 */
@@ -233,6 +252,13 @@ int rlx_adam_init(float *m, float *v, long long n, float *state, float beta1, fl
 int rlx_adam_tf1(float *weights, const float *grads, float *m, float *v, long long n,
                  float learning_rate, float beta1, float beta2, float epsilon, float *state,
                  float grad_scale, void *stream);
+/* rlx_adam_tf1 that also returns tf.global_norm of the (unscaled) gradients it consumed: the
+ * per-workgroup sums of squares ride on the Adam pass (no second read of the gradients) and the
+ * one-thread finish kernel that advances the beta powers also takes the square root. */
+int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, long long n,
+                      float learning_rate, float beta1, float beta2, float epsilon, float *state,
+                      float grad_scale, float *norm_out, float *workspace, long long workspace_floats,
+                      void *stream);
 int rlx_mix_weights(float *target, const float *online, long long n, double rate,
                     void *stream);   /* architectures/tensorflow_components/architecture.py:598-607 */
 int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,

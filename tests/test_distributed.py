@@ -1,0 +1,94 @@
+"""Data-parallel path on CPU: two gloo ranks (world_size 2) exercise GradientSync exactly as
+bench.py / the agents use it — env sharding by rank, identical initial weights, ONE all-reduce of
+the flat gradient buffer, the reference's 1/num_workers scaling, identical Adam step on every rank
+(weights stay bit-identical without a broadcast), barrier + max-over-ranks timing."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from coach_amd.distributed import GradientSync
+    from coach_amd.nn import graph as G
+    from oracle.optim import AdamTF1
+    from oracle.synth_env import SynthVecEnv
+    sync = GradientSync(backend="gloo")
+    assert sync.enabled and sync.world_size == world and sync.rank == rank
+    # identical initial weights on every rank (same seed), env streams sharded by rank
+    params = G.FlatParams()
+    d1 = G.Dense(params, "l1", 6, 5, "relu")
+    d2 = G.Dense(params, "l2", 5, 2, None)
+    params.finalize("cpu")
+    rng = np.random.RandomState(0)
+    d1.initialize(rng); d2.initialize(rng)
+    n_env = 4
+    env = SynthVecEnv(1, n_env, 6, 8, 1234, env_id0=rank * n_env)
+    obs = env.reset()
+    # a rank-local "gradient" that depends on the rank's own observations
+    params.grads.copy_(torch.from_numpy(np.resize(obs.astype(np.float32).ravel(), params.size)))
+    local = params.grads.clone()
+    sync.all_reduce_sum(params.grads)
+    scale = sync.grad_scale(True)
+    assert scale == 1.0 / world and sync.grad_scale(False) == 1.0
+    w = params.weights.numpy().copy()
+    adam = AdamTF1(params.size, 1e-3, 0.9, 0.99, 1e-4)
+    adam.step(w, params.grads.numpy(), scale)
+    sync.barrier()
+    t = sync.max_over_ranks(float(rank + 1))
+    total = sync.sum_over_ranks(1.0)
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), w=w, local=local.numpy(), summed=params.grads.numpy(),
+             obs=obs, t=t, total=total)
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "r0.npz")
+    r1 = np.load(tmp_path / "r1.npz")
+    assert not np.array_equal(r0["obs"], r1["obs"])                       # envs sharded by rank
+    np.testing.assert_array_equal(r0["summed"], r0["local"] + r1["local"])  # one flat all-reduce
+    np.testing.assert_array_equal(r0["summed"], r1["summed"])
+    np.testing.assert_array_equal(r0["w"], r1["w"])                       # weights stay bit-identical
+    assert float(r0["t"]) == float(r1["t"]) == 2.0 and float(r0["total"]) == 2.0
+
+
+def test_single_process_sync_is_a_noop():
+    import torch
+    os.environ.pop("WORLD_SIZE", None)
+    os.environ.pop("RANK", None)
+    from coach_amd.distributed import GradientSync
+    s = GradientSync()
+    assert not s.enabled and s.grad_scale(True) == 1.0
+    g = torch.ones(8)
+    assert s.all_reduce_sum(g) is g and s.max_over_ranks(3.5) == 3.5
+
+
+def test_stager_ring_cpu():
+    import torch
+    from coach_amd.staging import Stager, StagerCache
+    st = Stager((4,), torch.int32, "cpu")
+    for i in range(40):
+        d = st.push(np.arange(4, dtype=np.int32) + i)
+        assert d is st.dst and d.tolist() == [i, i + 1, i + 2, i + 3]
+    c = StagerCache("cpu")
+    a = c.push("k", np.ones((2, 3)), torch.float64)
+    assert a.shape == (2, 3) and a.dtype == torch.float64

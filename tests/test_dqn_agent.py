@@ -89,8 +89,9 @@ def test_dqn_agent_matches_oracle(dev, kind, per, double):
     a_or = run(o, False)
     a_hip = run(agent, True)
     agent.check_status()
-    np.testing.assert_array_equal(a_hip, a_or)               # exploration decisions bit-exact
     assert len(agent.debug_draws) == len(o.sampled) > 20
+    if not per:
+        np.testing.assert_array_equal(a_hip, a_or)           # exploration decisions bit-exact
     if per:
         # End to end the PER trees cannot stay bit-identical: priorities are |TD errors| of fp32
         # networks whose accumulation order differs, and one borderline leaf
@@ -103,6 +104,8 @@ def test_dqn_agent_matches_oracle(dev, kind, per, double):
                 break
             same += 1
         assert same >= 6, "PER leaves diverged after %d batches" % same
+        steps_same = 6 + same // 2                           # 2 updates per training vector step
+        np.testing.assert_array_equal(a_hip[:steps_same], a_or[:steps_same])
         np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], rtol=5e-3)
         return
     for d, s_ in zip(agent.debug_draws, o.sampled):
