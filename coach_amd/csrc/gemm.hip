@@ -25,6 +25,7 @@
 // deterministically by splitk_reduce_kernel, which also applies bias / activation.
 // blockIdx.z also carries a batch index (the two separate Clipped-PPO towers run as one launch).
 #include "rlx_common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -261,6 +262,262 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(const GemmDev g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fast path.  Same tiling and arithmetic as gemm_kernel, restructured around what the profile of
+// the generic kernel showed (profiles/r01_*): its bounds-checked loader compiles to one
+// exec-masked region per load, so every global load waited for the previous one (~3.8 us per
+// K-slab against 0.43 us of MFMA work).  Here, under launch-time guarantees checked by rlx_gemm
+// (vector groups full and aligned: extents along the vector dimension are multiples of 4):
+//   * all addresses are branch-free: out-of-range outer indices are clamped (their products land in
+//     rows/columns the epilogue never stores), out-of-range reduction indices are clamped and the
+//     loaded value multiplied by 0;
+//   * offsets of the outer index (and im2col row/patch tables) are computed once before the K loop;
+//     reduction-index table entries are prefetched one slab ahead of the data they address;
+//   * the NA + NB 16-byte loads of slab k+2 are issued back to back before the MFMAs of slab k
+//     (two register sets), stored to the other LDS buffer after them: one barrier per slab;
+//   * uint8 frames are converted through a 256-entry LDS table of byte / a_div (exact fp32
+//     quotients, no per-element division).
+struct Raw4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ void load_raw(Raw4 &r, const unsigned char *base, long long off) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(base) + off);
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+}
+struct Raw1 { uint32_t x; };
+__device__ __forceinline__ void load_raw(Raw1 &r, const unsigned char *base, long long off) {
+    r.x = *reinterpret_cast<const uint32_t *>(base + off);
+}
+__device__ __forceinline__ float4 raw_to_float4(const Raw4 &r, const float *) {
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z),
+                       __uint_as_float(r.w));
+}
+__device__ __forceinline__ float4 raw_to_float4(const Raw1 &r, const float *lut) {
+    const uint32_t w = r.x;
+    return make_float4(lut[w & 0xffu], lut[(w >> 8) & 0xffu], lut[(w >> 16) & 0xffu], lut[w >> 24]);
+}
+template <bool U8> struct ARaw { typedef Raw4 type; };
+template <> struct ARaw<true> { typedef Raw1 type; };
+
+template <int BM, int BN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
+__global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
+    constexpr int WN = BN / 32;
+    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+    constexpr int NA = BM * BK / 4 / kThreads;
+    constexpr int NB = BN * BK / 4 / kThreads;
+    constexpr int A_BUF = BK * LDA_S, B_BUF = BK * LDB_S;
+    __shared__ float As[2 * A_BUF];
+    __shared__ float Bs[2 * B_BUF];
+    __shared__ float lut[A_U8 ? 256 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bz = blockIdx.z;
+    const int batch = bz / g.splits, split = bz - batch * g.splits;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    if (A_U8) {
+        lut[tid] = (float)tid / g.a_div;        // kThreads == 256
+        __syncthreads();
+    }
+
+    const unsigned char *abase = static_cast<const unsigned char *>(g.a.base) +
+                                 (size_t)batch * g.a.batch_stride * (A_U8 ? 1 : 4);
+    const float *bbase = static_cast<const float *>(g.b.base) + (size_t)batch * g.b.batch_stride;
+
+    // ---- loop-invariant parts of the operand addresses
+    // A, vector along the reduction index: thread owns k-group kq of rows (row_p); else vector along
+    // the outer index: thread owns outer group mq of reduction rows (kr_p).
+    long long a_off_o[A_VEC_RED ? NA : 1];
+    int a_kq = 0, a_kr[NA];
+    if (A_VEC_RED) {
+        a_kq = (tid % (BK / 4)) * 4;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int row = min(m0 + (tid + p * kThreads) / (BK / 4), g.M - 1);
+            a_off_o[p] = A_TAB ? (long long)g.a.tab_o[row] : (long long)row * g.a.stride_o;
+        }
+    } else {
+        const int mq = min(m0 + (tid % (BM / 4)) * 4, g.M - 4);
+        a_off_o[0] = A_TAB ? (long long)g.a.tab_o[mq] : (long long)mq * g.a.stride_o;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) a_kr[p] = (tid + p * kThreads) / (BM / 4);
+    }
+    long long b_off_o[B_VEC_RED ? NB : 1];
+    int b_kq = 0, b_kr[NB];
+    if (B_VEC_RED) {
+        b_kq = (tid % (BK / 4)) * 4;
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int col = min(n0 + (tid + p * kThreads) / (BK / 4), g.N - 1);
+            b_off_o[p] = (long long)col * g.b.stride_o;
+        }
+    } else {
+        const int nq = min(n0 + (tid % (BN / 4)) * 4, g.N - 4);
+        b_off_o[0] = (long long)nq * g.b.stride_o;
+#pragma unroll
+        for (int p = 0; p < NB; ++p) b_kr[p] = (tid + p * kThreads) / (BN / 4);
+    }
+
+    // reduction-index offsets of A for one slab (table lookups are the only dependent loads)
+    constexpr int NR = A_VEC_RED ? 1 : NA;
+    auto a_red_offsets = [&](int k0, long long (&off)[NR], float (&msk)[NR]) {
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int r = k0 + (A_VEC_RED ? a_kq : a_kr[p]);
+            const int rc = min(r, kend - (A_VEC_RED ? 4 : 1));
+            msk[p] = r < kend ? 1.f : 0.f;
+            off[p] = A_TAB ? (long long)g.a.tab_r[rc] : (long long)rc * g.a.stride_r;
+        }
+    };
+    typedef typename ARaw<A_U8>::type a_raw_t;
+    auto load_a = [&](const long long (&off)[NR], a_raw_t (&ra)[NA]) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const long long o = (A_VEC_RED ? a_off_o[p] : a_off_o[0]) + off[A_VEC_RED ? 0 : p];
+            load_raw(ra[p], abase, o);
+        }
+    };
+    auto load_b = [&](int k0, float4 (&rb)[NB], float (&msk)[NB]) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int r = k0 + (B_VEC_RED ? b_kq : b_kr[p]);
+            const int rc = min(r, kend - (B_VEC_RED ? 4 : 1));
+            msk[p] = r < kend ? 1.f : 0.f;
+            const long long o = (B_VEC_RED ? b_off_o[p] : b_off_o[0]) + (long long)rc * g.b.stride_r;
+            rb[p] = *reinterpret_cast<const float4 *>(bbase + o);
+        }
+    };
+    auto store = [&](int buf, const a_raw_t (&ra)[NA], const float (&ma)[NR], const float4 (&rb)[NB],
+                     const float (&mb)[NB]) {
+        float *as = As + buf * A_BUF, *bs = Bs + buf * B_BUF;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            float4 v;
+            const float mk = ma[A_VEC_RED ? 0 : p];
+            v = raw_to_float4(ra[p], lut);
+            v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
+            if (A_VEC_RED) {
+                const int row = (tid + p * kThreads) / (BK / 4);
+                as[(a_kq + 0) * LDA_S + row] = v.x;
+                as[(a_kq + 1) * LDA_S + row] = v.y;
+                as[(a_kq + 2) * LDA_S + row] = v.z;
+                as[(a_kq + 3) * LDA_S + row] = v.w;
+            } else {
+                float *d = &as[a_kr[p] * LDA_S + (tid % (BM / 4)) * 4];
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            float4 v = rb[p];
+            const float mk = mb[p];
+            v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
+            if (B_VEC_RED) {
+                const int col = (tid + p * kThreads) / (BK / 4);
+                bs[(b_kq + 0) * LDB_S + col] = v.x;
+                bs[(b_kq + 1) * LDB_S + col] = v.y;
+                bs[(b_kq + 2) * LDB_S + col] = v.z;
+                bs[(b_kq + 3) * LDB_S + col] = v.w;
+            } else {
+                float *d = &bs[b_kr[p] * LDB_S + (tid % (BN / 4)) * 4];
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
+    float csum = 0.f;
+
+    if (kbeg < kend) {
+        // two register sets; a set = raw operand data + masks of one slab, plus (ao, ma) which hold
+        // the A reduction offsets / mask of the slab that will be loaded INTO this set next
+        a_raw_t ra0[NA], ra1[NA];
+        float4 rb0[NB], rb1[NB];
+        long long ao0[NR], ao1[NR];
+        float ma0[NR], ma1[NR], mb0[NB], mb1[NB];
+        const int nslab = (kend - kbeg + BK - 1) / BK;
+        // prologue: slab 0 -> LDS buffer 0; slab 1 in flight in set 1; offsets of slab 2 in (ao0, ma0)
+        a_red_offsets(kbeg, ao0, ma0);
+        load_a(ao0, ra0);
+        load_b(kbeg, rb0, mb0);
+        a_red_offsets(kbeg + BK, ao1, ma1);
+        store(0, ra0, ma0, rb0, mb0);
+        load_a(ao1, ra1);
+        load_b(kbeg + BK, rb1, mb1);
+        a_red_offsets(kbeg + 2 * BK, ao0, ma0);
+        __syncthreads();
+        // step s: LDS[s&1] = slab s; set N holds slab s+1 (in flight); (ao_F, ma_F) address slab s+2
+        auto step = [&](int s, a_raw_t (&ra_n)[NA], long long (&ao_n)[NR], float (&ma_n)[NR],
+                        float4 (&rb_n)[NB], float (&mb_n)[NB], a_raw_t (&ra_f)[NA],
+                        long long (&ao_f)[NR], float4 (&rb_f)[NB], float (&mb_f)[NB]) {
+            const int cur = s & 1;
+            if (s + 2 < nslab) {                     // slab s+2: issued before this slab's MFMAs
+                load_a(ao_f, ra_f);
+                load_b(kbeg + (s + 2) * BK, rb_f, mb_f);
+            }
+            const float *ap = As + cur * A_BUF + hi * LDA_S + wm * 32 + l31;
+            const float *bp = Bs + cur * B_BUF + hi * LDB_S + wn * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a = ap[kk * LDA_S];
+                const float b = bp[kk * LDB_S];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            if (do_colsum) {
+                const float *bc = Bs + cur * B_BUF;
+                float sc = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) sc += bc[kk * LDB_S + tid];
+                csum += sc;
+            }
+            if (s + 1 < nslab) store(cur ^ 1, ra_n, ma_n, rb_n, mb_n);      // slab s+1 -> other buffer
+            if (s + 3 < nslab) a_red_offsets(kbeg + (s + 3) * BK, ao_n, ma_n);
+            __syncthreads();
+        };
+        for (int s = 0; s < nslab; s += 2) {
+            step(s, ra1, ao1, ma1, rb1, mb1, ra0, ao0, rb0, mb0);
+            if (s + 1 < nslab) step(s + 1, ra0, ao0, ma0, rb0, mb0, ra1, ao1, rb1, mb1);
+        }
+    }
+
+    if (do_colsum && n0 + tid < g.N) {
+        if (g.splits > 1)
+            g.ws_colsum[((size_t)batch * g.splits + split) * g.N + n0 + tid] = csum;
+        else
+            g.colsum[(size_t)batch * g.colsum_batch_stride + n0 + tid] = csum;
+    }
+
+    const int col = n0 + wn * 32 + l31;
+    if (col >= g.N) return;
+    if (g.splits > 1) {
+        float *ws = g.ws + ((size_t)batch * g.splits + split) * (size_t)g.M * g.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < g.M) ws[(size_t)row * g.N + col] = acc[r];
+        }
+        return;
+    }
+    float *c = g.c + (size_t)batch * g.c_batch_stride;
+    const float bias = g.bias ? g.bias[(size_t)batch * g.bias_batch_stride + col] : 0.f;
+    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < g.M) {
+            float v = apply_act(acc[r] + bias, g.act);
+            if (aux) v *= act_deriv(aux[(size_t)row * g.aux_ld + col], g.deriv);
+            float *dst = &c[(size_t)row * g.ldc + col];
+            *dst = g.accumulate ? *dst + v : v;
+        }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const GemmDev g) {
     const long long mn = (long long)g.M * g.N;
     const int batch = blockIdx.y;
@@ -375,7 +632,36 @@ int launch_variant(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, 
     return -1;
 }
 
+template <int BM, int BN>
+int launch_fast(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, bool a_tab, dim3 grid,
+                hipStream_t s) {
+#define RLX_FAST_CASE(AV, AU, BV, AT)                                                    \
+    if (a_vec_red == AV && a_u8 == AU && b_vec_red == BV && a_tab == AT) {               \
+        gemm_fast_kernel<BM, BN, AV, AU, BV, AT><<<grid, kThreads, 0, s>>>(g);           \
+        return 0;                                                                        \
+    }
+    RLX_FAST_CASE(true, false, false, false)
+    RLX_FAST_CASE(true, false, true, false)
+    RLX_FAST_CASE(false, false, false, false)
+    RLX_FAST_CASE(false, false, true, false)
+    RLX_FAST_CASE(true, false, false, true)
+    RLX_FAST_CASE(false, false, false, true)
+    RLX_FAST_CASE(true, true, false, true)
+    RLX_FAST_CASE(false, true, false, true)
+#undef RLX_FAST_CASE
+    return -1;
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// RLX_GEMM_GENERIC=1 forces the bounds-checked kernel (used by the tests to cross-check the paths)
+inline bool rlx_force_generic_gemm() {
+    static const bool v = [] {
+        const char *e = getenv("RLX_GEMM_GENERIC");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
 
 }  // namespace
 
@@ -454,7 +740,18 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
 
     hipStream_t s = rlx::as_stream(stream);
     dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * splits);
-    int rc = narrow ? launch_variant<128, 32>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, grid, s)
+    // fast path: every 4-element vector group of both operands is full, in range and aligned
+    const bool a_tab = d.a_row_tab && d.a_k_tab;
+    const bool fast = !rlx_force_generic_gemm() && g.a.vec_ok && g.b.vec_ok &&
+                      (a_tab || (!d.a_row_tab && !d.a_k_tab)) &&
+                      (a_vec_red ? d.K % 4 == 0 : (d.M % 4 == 0 && d.M >= 4)) &&
+                      (b_vec_red ? d.K % 4 == 0 : (d.N % 4 == 0 && d.N >= 4)) && d.K >= 4;
+    int rc = -1;
+    if (fast)
+        rc = narrow ? launch_fast<128, 32>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, a_tab, grid, s)
+                    : launch_fast<64, 64>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, a_tab, grid, s);
+    if (rc != 0)
+        rc = narrow ? launch_variant<128, 32>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, grid, s)
                     : launch_variant<64, 64>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, grid, s);
     RLX_REQUIRE(rc == 0, "rlx_gemm: unsupported operand combination (uint8 A with transposed B)");
     RLX_LAUNCH_CHECK();
