@@ -544,6 +544,69 @@ __global__ void splitk_reduce_kernel(const GemmDev g) {
     }
 }
 
+// Vectorised split-K reduction (N % 4 == 0, M*N < 2^31): a workgroup = 64 float4 output groups x 4
+// split groups; split group q sums partials q, q+4, q+8, ... in increasing order, the four group
+// sums are combined as ((s0 + s1) + s2) + s3 — a fixed order, so the result is reproducible.
+// 32-bit index arithmetic (the generic kernel's 64-bit divisions cost more than its memory traffic).
+__global__ void __launch_bounds__(256) splitk_reduce4_kernel(const GemmDev g) {
+    __shared__ float4 part[4][64];
+    const int mn4 = (g.M * g.N) >> 2;
+    const int batch = blockIdx.y;
+    const int ox = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int gid = blockIdx.x * 64 + ox;
+    const size_t mn = (size_t)g.M * g.N;
+    const float4 *ws = reinterpret_cast<const float4 *>(g.ws + (size_t)batch * g.splits * mn);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gid < mn4) {
+        int k = q;
+        for (; k + 12 < g.splits; k += 16) {           // 4 independent loads in flight per thread
+            const float4 a = ws[(size_t)k * mn4 + gid];
+            const float4 b = ws[(size_t)(k + 4) * mn4 + gid];
+            const float4 c = ws[(size_t)(k + 8) * mn4 + gid];
+            const float4 d = ws[(size_t)(k + 12) * mn4 + gid];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+            s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+        }
+        for (; k < g.splits; k += 4) {
+            const float4 a = ws[(size_t)k * mn4 + gid];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
+    part[q][ox] = s;
+    __syncthreads();
+    if (q == 0 && gid < mn4) {
+        const float4 p1 = part[1][ox], p2 = part[2][ox], p3 = part[3][ox];
+        float v[4] = {((s.x + p1.x) + p2.x) + p3.x, ((s.y + p1.y) + p2.y) + p3.y,
+                      ((s.z + p1.z) + p2.z) + p3.z, ((s.w + p1.w) + p2.w) + p3.w};
+        const int i = gid << 2;
+        const int row = i / g.N, col = i - row * g.N;
+        float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc + col;
+        const float *bias = g.bias ? g.bias + (size_t)batch * g.bias_batch_stride + col : nullptr;
+        const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld + col
+                                 : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = apply_act(v[j] + (bias ? bias[j] : 0.f), g.act);
+            if (aux) t *= act_deriv(aux[j], g.deriv);
+            v[j] = g.accumulate ? c[j] + t : t;
+        }
+        if ((g.ldc & 3) == 0 && (((uintptr_t)c) & 15) == 0) {
+            *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
+        }
+    }
+    if (g.colsum && blockIdx.x == 0) {
+        for (int n = threadIdx.x; n < g.N; n += 256) {
+            float t = 0.f;
+            for (int k = 0; k < g.splits; ++k) t += g.ws_colsum[((size_t)batch * g.splits + k) * g.N + n];
+            g.colsum[(size_t)batch * g.colsum_batch_stride + n] = t;
+        }
+    }
+}
+
 // Column sums for bias gradients: out[n] = sum_m x[m][n]  (deterministic two-stage reduction).
 __global__ void colsum_partial_kernel(const float *__restrict__ x, int M, int N, long long ld,
                                       int rows_per_block, float *__restrict__ part) {
@@ -588,29 +651,49 @@ __global__ void conv_tables_kernel(int *__restrict__ rowbase, int *__restrict__ 
 
 // col2im as a gather: dX[b,iy,ix,c] = sum over the (ky,kx) whose output position exists of
 // dcol[(b,oy,ox)][(ky,kx,c)], multiplied by act'(x) of the layer that produced x.
+// VEC = 4: one thread per 4 channels (C % 4 == 0), 16-byte loads; 32-bit index arithmetic.
+template <int VEC>
 __global__ void col2im_kernel(const float *__restrict__ dcol, float *__restrict__ dx,
                               const float *__restrict__ x_out, int deriv, int batch, int H, int W,
                               int C, int KH, int KW, int stride, int OH, int OW) {
-    const long long total = (long long)batch * H * W * C;
+    const int CV = C / VEC;
+    const int total = batch * H * W * CV;
     const int K = KH * KW * C;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(t % C);
-        const int ix = (int)((t / C) % W);
-        const int iy = (int)((t / ((long long)C * W)) % H);
-        const int b = (int)(t / ((long long)C * W * H));
-        float s = 0.f;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int c = (t % CV) * VEC;
+        const int p = t / CV;
+        const int ix = p % W;
+        const int q = p / W;
+        const int iy = q % H;
+        const int b = q / H;
+        float s[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[j] = 0.f;
         for (int ky = iy % stride; ky < KH; ky += stride) {
             const int oy = (iy - ky) / stride;
             if (iy < ky || oy >= OH) continue;
             for (int kx = ix % stride; kx < KW; kx += stride) {
                 const int ox = (ix - kx) / stride;
                 if (ix < kx || ox >= OW) continue;
-                s += dcol[((size_t)(b * OH + oy) * OW + ox) * K + (ky * KW + kx) * C + c];
+                const float *src = dcol + ((size_t)(b * OH + oy) * OW + ox) * K + (ky * KW + kx) * C + c;
+                if (VEC == 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src);
+                    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+                } else {
+                    s[0] += src[0];
+                }
             }
         }
-        if (x_out) s *= act_deriv(x_out[t], deriv);
-        dx[t] = s;
+        const size_t o = (size_t)p * C + c;
+        if (x_out) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] *= act_deriv(x_out[o + j], deriv);
+        }
+        if (VEC == 4) {
+            *reinterpret_cast<float4 *>(dx + o) = make_float4(s[0], s[1], s[2], s[3]);
+        } else {
+            dx[o] = s[0];
+        }
     }
 }
 
@@ -721,9 +804,10 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     const bool narrow = d.N <= 32;
     const int BM = narrow ? 128 : 64, BN = narrow ? 32 : 64;
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.batch;
-    // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split
+    // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split; a launch that
+    // already covers every CU is left alone (its reduce pass would cost more than the imbalance)
     int splits = 1;
-    if (d.workspace && tiles < 2 * rlx::kCUs) {
+    if (d.workspace && tiles <= rlx::kCUs) {
         const int want = (2 * rlx::kCUs + tiles - 1) / tiles;
         const int max_by_k = d.K / (2 * BK);
         splits = want < max_by_k ? want : max_by_k;
@@ -757,8 +841,13 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     RLX_LAUNCH_CHECK();
     if (splits > 1) {
         const long long mn = (long long)d.M * d.N;
-        dim3 rgrid(rlx::grid_for(mn, 256, 1024), d.batch);
-        splitk_reduce_kernel<<<rgrid, 256, 0, s>>>(g);
+        if (d.N % 4 == 0 && mn < (1LL << 31) && aligned16(g.ws)) {
+            dim3 rgrid((unsigned)((mn / 4 + 63) / 64), d.batch);
+            splitk_reduce4_kernel<<<rgrid, 256, 0, s>>>(g);
+        } else {
+            dim3 rgrid(rlx::grid_for(mn, 256, 1024), d.batch);
+            splitk_reduce_kernel<<<rgrid, 256, 0, s>>>(g);
+        }
         RLX_LAUNCH_CHECK();
     }
     return RLX_OK;
@@ -813,8 +902,15 @@ int rlx_col2im(const float *dcol, float *dx, const float *x_out, int deriv_kind,
     RLX_REQUIRE(batch > 0 && H >= KH && W >= KW && C > 0 && stride > 0, "rlx_col2im: bad geometry");
     const int OH = (H - KH) / stride + 1, OW = (W - KW) / stride + 1;
     const long long total = (long long)batch * H * W * C;
-    col2im_kernel<<<rlx::grid_for(total, 256), 256, 0, rlx::as_stream(stream)>>>(
-        dcol, dx, x_out, deriv_kind, batch, H, W, C, KH, KW, stride, OH, OW);
+    RLX_REQUIRE(total < (1LL << 31) && (long long)batch * OH * OW * KH * KW * C < (1LL << 40),
+                "rlx_col2im: tensor too large for 32-bit indexing");
+    const bool vec = C % 4 == 0 && (((uintptr_t)dcol | (uintptr_t)dx | (uintptr_t)x_out) & 15) == 0;
+    if (vec)
+        col2im_kernel<4><<<rlx::grid_for(total / 4, 256, 8192), 256, 0, rlx::as_stream(stream)>>>(
+            dcol, dx, x_out, deriv_kind, batch, H, W, C, KH, KW, stride, OH, OW);
+    else
+        col2im_kernel<1><<<rlx::grid_for(total, 256, 8192), 256, 0, rlx::as_stream(stream)>>>(
+            dcol, dx, x_out, deriv_kind, batch, H, W, C, KH, KW, stride, OH, OW);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
