@@ -99,9 +99,23 @@ def gemm_roofline(agent, reps=20):
     lib.event_destroy(ev1)
     n = len(recorded)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
+    # HBM-side bytes per GEMM launch (incl. its split-K reduce): PMC passes cannot run inside this
+    # process, so the figure is the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of
+    # the same 11 launches (tools/ppo_update_once.py -> profiles/r01_pmc_gemm_traffic.json)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as f:
+            pm = json.load(f)
+        if pm.get("gemm_launches") == n:
+            traffic = round(pm["traffic_bytes_per_gemm_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_kernel<BM,BN,...> (fp32 MFMA 32x32x2), %d launches per minibatch update" % n,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "bytes per GEMM launch (2 x FETCH_SIZE + WRITE_SIZE, PMC pass of "
+                            "tools/ppo_update_once.py; algorithmic operand bytes are 11.9e6 per launch)",
+            "kernel": "gemm_fast_kernel<BM,BN,...> + splitk_reduce4 (fp32 MFMA 32x32x2), %d launches "
+                      "per minibatch update" % n,
             "flops_per_launch": total_flops / n, "avg_launch_us": round(1e3 * total_ms / n, 2),
             "gemm_us_per_update": round(1e3 * total_ms, 1)}, per_shape
 
