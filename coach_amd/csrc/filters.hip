@@ -115,6 +115,43 @@ __global__ void reward_filter_kernel(const float *__restrict__ in, float *__rest
     }
 }
 
+// K2 (a4) — ObservationRescaleToSizeFilter: skimage.transform.resize(obs, out_shape, order=1,
+// mode='reflect', anti_aliasing=False, preserve_range=True).astype('uint8')
+// (filters/observation/observation_rescale_to_size_filter.py:62-79).  scikit-image is an
+// un-vendored dependency (requirements.txt:9, >= 0.13): restated from its published warp path
+// (transform/_warps.py resize -> warp with scale = in/out, output pixel o samples the input at
+// (o + 0.5) * scale - 0.5; _shared/interpolation.pxd bilinear_interpolation: floor/ceil neighbours,
+// top/bottom blends in fp64).  For down-scaling every sample coordinate lies inside the image, so
+// the 'reflect' boundary mode never engages; coordinates are clamped for safety.  Parity unpinned
+// beyond the reference's all-ones test (tests/filters/observation/test_observation_rescale_to_size_filter.py:16-47).
+__global__ void resize_bilinear_u8_kernel(const unsigned char *__restrict__ in,
+                                          unsigned char *__restrict__ out, int n, int H, int W, int C,
+                                          int OH, int OW) {
+    const long long total = (long long)n * OH * OW * C;
+    const double sr = (double)H / (double)OH, sc = (double)W / (double)OW;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int ox = (int)((t / C) % OW);
+        const int oy = (int)((t / ((long long)C * OW)) % OH);
+        const int b = (int)(t / ((long long)C * OW * OH));
+        double r = ((double)oy + 0.5) * sr - 0.5;
+        double q = ((double)ox + 0.5) * sc - 0.5;
+        r = fmin(fmax(r, 0.0), (double)(H - 1));
+        q = fmin(fmax(q, 0.0), (double)(W - 1));
+        const int r0 = (int)floor(r), r1 = (int)ceil(r);
+        const int c0 = (int)floor(q), c1 = (int)ceil(q);
+        const double dr = r - (double)r0, dc = q - (double)c0;
+        const unsigned char *img = in + (size_t)b * H * W * C;
+        const double p00 = img[((size_t)r0 * W + c0) * C + c], p01 = img[((size_t)r0 * W + c1) * C + c];
+        const double p10 = img[((size_t)r1 * W + c0) * C + c], p11 = img[((size_t)r1 * W + c1) * C + c];
+        const double top = (1 - dc) * p00 + dc * p01;
+        const double bottom = (1 - dc) * p10 + dc * p11;
+        const double v = (1 - dr) * top + dr * bottom;
+        out[t] = (unsigned char)(int)v;                                    // astype('uint8')
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -183,6 +220,17 @@ int rlx_reward_filter(const float *rewards, float *out, long long n, double resc
     const int use_lo = has_clip && clipping_low != 0.0;
     reward_filter_kernel<<<rlx::grid_for(n, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
         rewards, out, n, rescale_factor, use_hi, clipping_high, use_lo, clipping_low);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_resize_bilinear_u8(const unsigned char *in, unsigned char *out, int n, int H, int W, int C,
+                           int OH, int OW, void *stream) {
+    RLX_REQUIRE(in && out, "rlx_resize_bilinear_u8: null pointer");
+    RLX_REQUIRE(n > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "rlx_resize_bilinear_u8: bad shape");
+    const long long total = (long long)n * OH * OW * C;
+    resize_bilinear_u8_kernel<<<rlx::grid_for(total, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
+        in, out, n, H, W, C, OH, OW);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

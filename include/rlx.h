@@ -151,6 +151,9 @@ int rlx_sac_value_targets(const float *q_min, const float *sampled_logprob, int 
 int rlx_rgb_to_y_u8(const unsigned char *rgb, unsigned char *out, long long n_pixels,
                     double input_low, double input_high,
                     void *stream);   /* filters/observation/observation_rgb_to_y_filter.py:41-47 + observation_to_uint8_filter.py:51-60 */
+int rlx_resize_bilinear_u8(const unsigned char *in, unsigned char *out, int n, int H, int W, int C,
+                           int OH, int OW,
+                           void *stream);   /* filters/observation/observation_rescale_to_size_filter.py:62-79 (skimage resize, order 1) */
 int rlx_running_stats_push(const void *samples, int samples_are_f64, long long n, int dim,
                            double *sum, double *sum_squares, double *count, double *mean,
                            double *std, double epsilon,
