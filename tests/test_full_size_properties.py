@@ -1,0 +1,146 @@
+"""BASELINE.json's FULL sizes, checked through size-independent properties (the CPU oracle cannot
+finish these sizes in seconds):
+  * PER at capacity 2^20: after bulk store + 64 batched priority updates every internal node equals
+    the combination of its children (sum / min / max heap invariants, bit for bit in fp64), sampled
+    leaves are in range, lie in their own stratum of the cumulative distribution, and the importance
+    weights reproduce (N * P)^-beta / max_w from the tree itself;
+  * image replay at 2^20 transitions / 64 envs: a gathered stacked state equals the frames the
+    synthetic env generated for exactly those (env, episode, step) coordinates (store -> gather round
+    trip against the counter-based generator), including the first-frame replication at episode starts;
+  * GAE over a 2048 x 64 rollout: linearity in the rewards, the lambda = 1 identity
+    advantage + V = discounted return, and idempotent standardisation (mean 0 / std 1).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_per_tree_invariants_at_2_pow_20(rlx, dev):
+    import torch
+    cap, B = 1 << 20, 32
+    n = 2 * cap - 1
+    trees = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3)]
+    maxp = torch.zeros(1, dtype=torch.float64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    rlx.per_init(*trees, cap, maxp, 0)
+    for start in range(0, cap, 1 << 16):                       # 1M stores, 65536 per launch
+        rlx.per_store(*trees, cap, start, 1 << 16, 0.6, maxp, status, 0)
+    rng = np.random.RandomState(0)
+    for _ in range(64):
+        idx = torch.from_numpy(rng.randint(0, cap, size=B).astype(np.int32)).to(dev)
+        err = torch.from_numpy(np.abs(rng.randn(B)) * 3).to(dev)
+        rlx.per_update(*trees, cap, idx, err, B, 0.6, 1e-6, maxp, status, 0)
+    assert int(status.item()) == 0
+    s, mn, mx = [t.cpu().numpy() for t in trees]
+    parents = np.arange(cap - 1)
+    np.testing.assert_array_equal(s[parents], s[2 * parents + 1] + s[2 * parents + 2])
+    np.testing.assert_array_equal(mn[parents], np.minimum(mn[2 * parents + 1], mn[2 * parents + 2]))
+    np.testing.assert_array_equal(mx[parents], np.maximum(mx[2 * parents + 1], mx[2 * parents + 2]))
+    assert float(maxp.item()) == mx[0]
+    # stratified sampling: leaf i's cumulative interval must contain the drawn value
+    u = rng.random_sample(B)
+    oi = torch.empty(B, dtype=torch.int32, device=dev)
+    ow = torch.empty(B, dtype=torch.float64, device=dev)
+    op = torch.empty(B, dtype=torch.float64, device=dev)
+    rlx.per_sample(trees[0], trees[1], cap, torch.from_numpy(u).to(dev), B, float(cap), 0.4, oi, ow, op, 0)
+    leaves = s[cap - 1:]
+    cum = np.concatenate([[0.0], np.cumsum(leaves)])
+    total = s[0]
+    seg = total / B
+    idx = oi.cpu().numpy()
+    assert ((idx >= 0) & (idx < cap)).all()
+    vals = seg * np.arange(B) + (seg * (np.arange(B) + 1) - seg * np.arange(B)) * u
+    tol = 1e-6 * total                                         # cumsum order differs from the tree's
+    assert (cum[idx] - tol <= vals).all() and (vals <= cum[idx + 1] + tol).all()
+    np.testing.assert_array_equal(op.cpu().numpy(), leaves[idx])
+    w = (cap * leaves[idx] / total) ** -0.4 / ((mn[0] / total * cap) ** -0.4)
+    np.testing.assert_allclose(ow.cpu().numpy(), w, rtol=1e-13)
+
+
+def test_image_replay_round_trip_at_1m_transitions(dev):
+    import torch
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    from coach_amd.memories.non_episodic.experience_replay import ExperienceReplay
+    from oracle.synth_env import SynthVecEnv
+    n_env, L, steps = 64, 37, 150
+    ep = SyntheticVectorEnvironmentParameters("image", n_env, (84, 84), 4, episode_length=L, seed=99)
+    env = SyntheticVectorEnvironment(ep, dev)
+    mem = ExperienceReplay((MemoryGranularity.Transitions, 1 << 20), device=dev, n_env=n_env,
+                           observation_shape=(84, 84), stack=4, action_dim=None, min_episode_length=L)
+    assert mem.ring.numel() < 9e9                               # ~7.7 GB for 1M stacked-4 transitions
+    mem.reset(env.reset_internal_state())
+    acts = torch.zeros(n_env, dtype=torch.int32, device=dev)
+    for t in range(steps):
+        nxt, rst, rew, done = env.step(acts)
+        mem.store(acts, rew, done, nxt, rst)
+    mem.check_status()
+    assert mem.num_transitions() == steps * n_env
+    # frames straight from the generator: frame(env, episode, step), reset frame = (episode+1, 0)
+    o = SynthVecEnv(0, n_env, 84 * 84, L, 99)
+    frames = {}                                                 # (t) -> obs of every env BEFORE step t
+    cur = o.reset().reshape(n_env, 84, 84)
+    hist = [cur]
+    epi_start = [0]
+    for t in range(steps):
+        nx, rs, _, dn = o.step()
+        if dn.all():
+            cur = rs.reshape(n_env, 84, 84)
+            epi_start.append(t + 1)
+        else:
+            cur = nx.reshape(n_env, 84, 84)
+        hist.append(cur)
+        frames[t] = nx.reshape(n_env, 84, 84)
+    rng = np.random.RandomState(5)
+    logical = rng.randint(0, steps * n_env, size=48)
+    b = mem.gather(mem.physical_rows(logical), 48)
+    st, ns = b["state"].cpu().numpy(), b["next_state"].cpu().numpy()
+    for j, i in enumerate(logical):
+        t, e = divmod(int(i), n_env)
+        start = max(s for s in epi_start if s <= t)
+        exp = np.stack([hist[max(t - k, start)][e] for k in (3, 2, 1, 0)], axis=-1)
+        np.testing.assert_array_equal(st[j], exp, err_msg="state of transition %d" % i)
+        nxt = frames[t][e]                                       # the true next frame (also at episode end)
+        expn = np.stack([hist[max(t - 2, start)][e], hist[max(t - 1, start)][e], hist[t][e], nxt], axis=-1)
+        np.testing.assert_array_equal(ns[j], expn, err_msg="next_state of transition %d" % i)
+
+
+def test_gae_properties_at_rollout_size(rlx, dev):
+    import torch
+    n_seq, T = 64, 2048
+    rng = np.random.RandomState(1)
+    r1 = rng.randn(n_seq * T).astype(np.float32)
+    r2 = rng.randn(n_seq * T).astype(np.float32)
+    v = rng.randn(n_seq * T).astype(np.float32)
+    done = np.zeros(n_seq * T, dtype=np.uint8)
+    done[np.arange(1, n_seq * T // 256 + 1) * 256 - 1] = 1       # episodes of 256 steps
+
+    def gae(r, val, lam):
+        adv = torch.empty(n_seq * T, dtype=torch.float64, device=dev)
+        vt = torch.empty(n_seq * T, dtype=torch.float32, device=dev)
+        rlx.gae(torch.from_numpy(r).to(dev), torch.from_numpy(val).to(dev), torch.from_numpy(done).to(dev),
+                None, n_seq, T, 0.99, lam, adv, vt, 0)
+        return adv.cpu().numpy(), vt.cpu().numpy()
+    zero = np.zeros_like(v)
+    a1, _ = gae(r1, zero, 0.95)
+    a2, _ = gae(r2, zero, 0.95)
+    a12, _ = gae((r1.astype(np.float64) + r2).astype(np.float32), zero, 0.95)
+    np.testing.assert_allclose(a12, a1 + a2, rtol=0, atol=2e-5)  # linear in the rewards (fp32 input rounding)
+    # lambda = 1: advantage + V == discounted return to the episode end
+    a, vt = gae(r1, v, 1.0)
+    ret64 = torch.empty(n_seq * T, dtype=torch.float64, device=dev)
+    rlx.discounted_returns(torch.from_numpy(r1).to(dev), torch.from_numpy(done).to(dev), n_seq, T, 0.99,
+                           ret64, None, 0)
+    np.testing.assert_allclose(a + v, ret64.cpu().numpy(), rtol=0, atol=1e-9)
+    # standardisation: mean 0, population std 1, idempotent
+    x = torch.from_numpy(a).to(dev)
+    o64 = torch.empty_like(x)
+    ms = torch.empty(2, dtype=torch.float64, device=dev)
+    rlx.standardize(x, n_seq * T, None, o64, ms, 0)
+    y = o64.cpu().numpy()
+    assert abs(y.mean()) < 1e-12 and abs(y.std() - 1) < 1e-12
+    o2 = torch.empty_like(x)
+    rlx.standardize(o64, n_seq * T, None, o2, ms, 0)
+    np.testing.assert_allclose(o2.cpu().numpy(), y, rtol=0, atol=1e-12)
