@@ -249,6 +249,23 @@ class VectorOffPolicyAgent(GraphRunner):
     def learn_from_batch(self, batch):
         raise NotImplementedError
 
+    def evaluate_episodes(self, episodes_per_env=1):
+        """GraphManager.evaluate (graph_manager.py:491-523) for the env vector: TEST-phase acting (no
+        exploration noise beyond evaluation_epsilon, nothing stored, counters frozen) for whole
+        episodes; returns the mean undiscounted episode reward over envs."""
+        import torch
+        prev = self.phase
+        self.phase = RunPhase.TEST
+        total = torch.zeros(self.n_env, dtype=torch.float64, device=self.device)
+        # finish the running episodes first so that evaluation episodes start at a reset
+        while self.current_episode_steps_counter != 0:
+            self.act()
+        for _ in range(episodes_per_env * self.L):
+            self.act()
+            total += self.env.reward.double()
+        self.phase = prev
+        return float(total.mean().item()) / episodes_per_env
+
     # ------------------------------------------------------------------------------ reporting
     def episode_statistics(self):
         a = self.ep_acc.cpu().numpy()
