@@ -57,6 +57,7 @@ struct GemmDev {
     int M, N, K;
     int splits, kchunk;
     int act, deriv, accumulate;
+    int vec_epi;                // fast kernel: 16-byte epilogue accesses are legal for this launch
     float a_div;
 };
 
@@ -298,15 +299,21 @@ __device__ __forceinline__ float4 raw_to_float4(const Raw1 &r, const float *lut)
 template <bool U8> struct ARaw { typedef Raw4 type; };
 template <> struct ARaw<true> { typedef Raw1 type; };
 
-template <int BM, int BN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
+// TM x TN accumulator tiles of 32x32 per wave (wave tile 32*TM x 32*TN): with 2x2 the LDS operand
+// reads per MFMA halve and a workgroup carries 4x the MFMA work per prologue/epilogue — what the
+// short-K (K = 64) input-gradient GEMMs need.
+template <int BM, int BN, int TM, int TN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
 __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
-    constexpr int WN = BN / 32;
+    constexpr int WN = BN / (32 * TN);
+    static_assert((BM / (32 * TM)) * WN == 4, "a workgroup is 4 waves");
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
     constexpr int NA = BM * BK / 4 / kThreads;
     constexpr int NB = BN * BK / 4 / kThreads;
     constexpr int A_BUF = BK * LDA_S, B_BUF = BK * LDB_S;
-    __shared__ float As[2 * A_BUF];
-    __shared__ float Bs[2 * B_BUF];
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF + 2 * B_BUF];
+    float *const As = smem;
+    float *const Bs = smem + 2 * A_BUF;
+    static_assert(4 * 32 * 33 <= 2 * A_BUF + 2 * B_BUF, "epilogue staging fits in the operand buffers");
     __shared__ float lut[A_U8 ? 256 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -427,9 +434,13 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
     float csum = 0.f;
 
@@ -460,13 +471,20 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
                 load_a(ao_f, ra_f);
                 load_b(kbeg + (s + 2) * BK, rb_f, mb_f);
             }
-            const float *ap = As + cur * A_BUF + hi * LDA_S + wm * 32 + l31;
-            const float *bp = Bs + cur * B_BUF + hi * LDB_S + wn * 32 + l31;
+            const float *ap = As + cur * A_BUF + hi * LDA_S + wm * (32 * TM) + l31;
+            const float *bp = Bs + cur * B_BUF + hi * LDB_S + wn * (32 * TN) + l31;
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
-                const float a = ap[kk * LDA_S];
-                const float b = bp[kk * LDB_S];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = ap[kk * LDA_S + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = bp[kk * LDB_S + 32 * j];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             if (do_colsum) {
                 const float *bc = Bs + cur * B_BUF;
@@ -492,28 +510,79 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
             g.colsum[(size_t)batch * g.colsum_batch_stride + n0 + tid] = csum;
     }
 
-    const int col = n0 + wn * 32 + l31;
-    if (col >= g.N) return;
-    if (g.splits > 1) {
-        float *ws = g.ws + ((size_t)batch * g.splits + split) * (size_t)g.M * g.N;
+    float *c = g.c + (size_t)batch * g.c_batch_stride;
+    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
+    float *ws = g.splits > 1 ? g.ws + ((size_t)batch * g.splits + split) * (size_t)g.M * g.N : nullptr;
+    if (g.vec_epi) {
+        // 16-byte epilogue: every accumulator tile goes through a wave-private 32x33 LDS patch so
+        // that a lane owns 4 consecutive columns of a row (float4 loads of the derivative operand,
+        // float4 stores; a wave instruction covers 8 rows x 128 B) instead of 16 scalar accesses.
+        float *stage = smem + wid * (32 * 33);
+        float *dst_base = ws ? ws : c;
+        const long long ld = ws ? (long long)g.N : g.ldc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (row < g.M) ws[(size_t)row * g.N + col] = acc[r];
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[i][j][r];
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int rl = idx >> 3, c4 = (idx & 7) * 4;
+                    const int row = m0 + wm * (32 * TM) + 32 * i + rl;
+                    const int col = n0 + wn * (32 * TN) + 32 * j + c4;
+                    if (row >= g.M || col >= g.N) continue;
+                    const float *sp = stage + rl * 33 + c4;
+                    float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                    float *dst = dst_base + (size_t)row * ld + col;
+                    if (!ws) {
+                        if (g.bias) {
+                            const float4 bv = *reinterpret_cast<const float4 *>(
+                                g.bias + (size_t)batch * g.bias_batch_stride + col);
+                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        }
+                        v.x = apply_act(v.x, g.act); v.y = apply_act(v.y, g.act);
+                        v.z = apply_act(v.z, g.act); v.w = apply_act(v.w, g.act);
+                        if (aux) {
+                            const float4 av = *reinterpret_cast<const float4 *>(aux + (size_t)row * g.aux_ld + col);
+                            v.x *= act_deriv(av.x, g.deriv); v.y *= act_deriv(av.y, g.deriv);
+                            v.z *= act_deriv(av.z, g.deriv); v.w *= act_deriv(av.w, g.deriv);
+                        }
+                        if (g.accumulate) {
+                            const float4 ov = *reinterpret_cast<const float4 *>(dst);
+                            v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+                        }
+                    }
+                    *reinterpret_cast<float4 *>(dst) = v;
+                }
+            }
         }
         return;
     }
-    float *c = g.c + (size_t)batch * g.c_batch_stride;
-    const float bias = g.bias ? g.bias[(size_t)batch * g.bias_batch_stride + col] : 0.f;
-    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < g.M) {
-            float v = apply_act(acc[r] + bias, g.act);
-            if (aux) v *= act_deriv(aux[(size_t)row * g.aux_ld + col], g.deriv);
-            float *dst = &c[(size_t)row * g.ldc + col];
-            *dst = g.accumulate ? *dst + v : v;
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (32 * TN) + 32 * j + l31;
+        if (col >= g.N) continue;
+        const float bias = (!ws && g.bias) ? g.bias[(size_t)batch * g.bias_batch_stride + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= g.M) continue;
+                if (ws) {
+                    ws[(size_t)row * g.N + col] = acc[i][j][r];
+                } else {
+                    float v = apply_act(acc[i][j][r] + bias, g.act);
+                    if (aux) v *= act_deriv(aux[(size_t)row * g.aux_ld + col], g.deriv);
+                    float *dst = &c[(size_t)row * g.ldc + col];
+                    *dst = g.accumulate ? *dst + v : v;
+                }
+            }
         }
     }
 }
@@ -715,12 +784,12 @@ int launch_variant(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, 
     return -1;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int TM, int TN>
 int launch_fast(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, bool a_tab, dim3 grid,
                 hipStream_t s) {
 #define RLX_FAST_CASE(AV, AU, BV, AT)                                                    \
     if (a_vec_red == AV && a_u8 == AU && b_vec_red == BV && a_tab == AT) {               \
-        gemm_fast_kernel<BM, BN, AV, AU, BV, AT><<<grid, kThreads, 0, s>>>(g);           \
+        gemm_fast_kernel<BM, BN, TM, TN, AV, AU, BV, AT><<<grid, kThreads, 0, s>>>(g);   \
         return 0;                                                                        \
     }
     RLX_FAST_CASE(true, false, false, false)
@@ -736,6 +805,17 @@ int launch_fast(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, boo
 }
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// RLX_GEMM_BIG_TILES=1 lets large-M*N launches use 128x128 / 128x64 workgroup tiles (2x2 / 2x1
+// accumulators per wave).  Off by default: at the C2 shapes the short-K GEMMs that qualify are
+// epilogue-bound and measured 15-40 % slower with them (profiles/r01 history in DESIGN.md).
+inline bool rlx_big_tiles() {
+    static const bool v = [] {
+        const char *e = getenv("RLX_GEMM_BIG_TILES");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
 
 // RLX_GEMM_GENERIC=1 forces the bounds-checked kernel (used by the tests to cross-check the paths)
 inline bool rlx_force_generic_gemm() {
@@ -800,10 +880,24 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
         g.b.vec_ok = aligned16(d.B) && (other % 4 == 0) && ((d.b_batch_stride % 4) == 0);
     }
 
-    // tile shape: narrow-N problems use 128x32 workgroup tiles
+    // fast path: every 4-element vector group of both operands is full, in range and aligned
+    const bool a_tab = d.a_row_tab && d.a_k_tab;
+    const bool fast = !rlx_force_generic_gemm() && g.a.vec_ok && g.b.vec_ok &&
+                      (a_tab || (!d.a_row_tab && !d.a_k_tab)) &&
+                      (a_vec_red ? d.K % 4 == 0 : (d.M % 4 == 0 && d.M >= 4)) &&
+                      (b_vec_red ? d.K % 4 == 0 : (d.N % 4 == 0 && d.N >= 4)) && d.K >= 4;
+    // tile shape: narrow-N problems use 128x32 workgroup tiles; when the grid still covers the chip
+    // with them, the fast path takes 2x2 / 2x1 accumulator tiles per wave (128x128 / 128x64)
     const bool narrow = d.N <= 32;
-    const int BM = narrow ? 128 : 64, BN = narrow ? 32 : 64;
-    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.batch;
+    int BM = narrow ? 128 : 64, BN = narrow ? 32 : 64;
+    auto tiles_of = [&](int bm, int bn) {
+        return (long long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch;
+    };
+    if (fast && !narrow && !d.a_is_u8 && rlx_big_tiles()) {
+        if (tiles_of(128, 128) >= rlx::kCUs) { BM = 128; BN = 128; }
+        else if (tiles_of(128, 64) >= rlx::kCUs) { BM = 128; BN = 64; }
+    }
+    const int tiles = (int)tiles_of(BM, BN);
     // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split; a launch that
     // already covers every CU is left alone (its reduce pass would cost more than the imbalance)
     int splits = 1;
@@ -822,21 +916,27 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     g.ws = d.workspace;
     if (splits > 1) g.ws_colsum = d.workspace + (size_t)d.M * d.N * d.batch * splits;
 
+    g.vec_epi = d.N % 4 == 0 &&
+                (splits > 1 ? aligned16(d.workspace) && ((long long)d.M * d.N) % 4 == 0
+                            : (aligned16(d.C) && d.ldc % 4 == 0 && d.c_batch_stride % 4 == 0 &&
+                               (!d.bias || (aligned16(d.bias) && d.bias_batch_stride % 4 == 0)) &&
+                               (!d.deriv_aux || (aligned16(d.deriv_aux) && d.aux_ld % 4 == 0 &&
+                                                 d.aux_batch_stride % 4 == 0))));
     hipStream_t s = rlx::as_stream(stream);
     dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * splits);
-    // fast path: every 4-element vector group of both operands is full, in range and aligned
-    const bool a_tab = d.a_row_tab && d.a_k_tab;
-    const bool fast = !rlx_force_generic_gemm() && g.a.vec_ok && g.b.vec_ok &&
-                      (a_tab || (!d.a_row_tab && !d.a_k_tab)) &&
-                      (a_vec_red ? d.K % 4 == 0 : (d.M % 4 == 0 && d.M >= 4)) &&
-                      (b_vec_red ? d.K % 4 == 0 : (d.N % 4 == 0 && d.N >= 4)) && d.K >= 4;
     int rc = -1;
-    if (fast)
-        rc = narrow ? launch_fast<128, 32>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, a_tab, grid, s)
-                    : launch_fast<64, 64>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, a_tab, grid, s);
-    if (rc != 0)
+    if (fast) {
+        const bool u8 = d.a_is_u8 != 0;
+        if (BM == 128 && BN == 128) rc = launch_fast<128, 128, 2, 2>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
+        else if (BM == 128 && BN == 64) rc = launch_fast<128, 64, 2, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
+        else if (narrow) rc = launch_fast<128, 32, 1, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
+        else rc = launch_fast<64, 64, 1, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
+    }
+    if (rc != 0) {
+        RLX_REQUIRE(BM * BN == 4096, "rlx_gemm: internal tile selection error");
         rc = narrow ? launch_variant<128, 32>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, grid, s)
                     : launch_variant<64, 64>(g, a_vec_red, d.a_is_u8 != 0, b_vec_red, grid, s);
+    }
     RLX_REQUIRE(rc == 0, "rlx_gemm: unsupported operand combination (uint8 A with transposed B)");
     RLX_LAUNCH_CHECK();
     if (splits > 1) {
