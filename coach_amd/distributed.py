@@ -25,7 +25,8 @@ class GradientSync(object):
         self.enabled = self.world_size > 1
         if self.enabled and not dist.is_initialized():
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = os.environ.get("RLX_DIST_BACKEND") or \
+                    ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
@@ -35,6 +36,14 @@ class GradientSync(object):
         if self.enabled:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         return flat
+
+    def all_reduce_sum_async(self, flat):
+        """Start an in-place sum on RCCL's stream (it first waits for the work already queued on the
+        current stream); `.wait()` on the returned handle makes the current stream wait for it.
+        Used to overlap the all-reduce of the early-finished gradients with the rest of backward."""
+        if not self.enabled:
+            return None
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def grad_scale(self, scale_down_by_workers):
         return 1.0 / self.world_size if (self.enabled and scale_down_by_workers) else 1.0

@@ -341,8 +341,12 @@ class Sequential:
             acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt))
         return acts
 
-    def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None, need_dw=True):
-        for i in reversed(range(len(self.layers))):
+    def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None, need_dw=True,
+                 layers=None):
+        """layers=(lo, hi): only layers lo <= i < hi (the data-parallel path runs the last layers
+        first, starts their gradient all-reduce, then the rest)."""
+        lo, hi = layers if layers is not None else (0, len(self.layers))
+        for i in reversed(range(lo, hi)):
             kw = {} if need_dw else {"need_dw": False}
             self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),
                                     weights=weights, t0=t0, nt=nt, **kw)

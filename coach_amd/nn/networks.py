@@ -127,10 +127,24 @@ class ClippedPPONet(_NetBase):
         return v.data.view(-1)
 
     # ---- one minibatch of ClippedPPOAgent.train_network (:226-266) ---------------------------
+    def late_gradient_offset(self):
+        """Offset in the flat buffers where the parameters whose gradients are produced FIRST in the
+        backward pass start (FC middleware + heads: 95 % of the bytes).  [offset, size) can be
+        all-reduced while the convolution gradients [0, offset) are still being computed."""
+        return self.params.entries[self.torso.layers[self._split_layer()].kname][0]
+
+    def _split_layer(self):
+        from .graph import Conv2d
+        for i, l in enumerate(self.torso.layers):
+            if not isinstance(l, Conv2d):
+                return i
+        return 0
+
     def forward_backward(self, obs, B, actions, advantages, value_targets, old_probs,
-                         clip_rescaler=1.0, ratio_out=None, clipped_out=None):
+                         clip_rescaler=1.0, ratio_out=None, clipped_out=None, stop_after_dense=False):
         """accumulate_gradients (tensorflow_components/architecture.py:312-385): forward both towers,
-        head losses, backward; leaves d total_loss / d theta in params.grads."""
+        head losses, backward; leaves d total_loss / d theta in params.grads.
+        stop_after_dense: stop once the dense layers' gradients are final (backward_rest() resumes)."""
         ctx = self.ctx
         acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
         mid = acts[-1]
@@ -150,7 +164,17 @@ class ClippedPPONet(_NetBase):
         self.v_head.backward(ctx, xv, v)
         self.pi_head.backward(ctx, xp, logits)
         mid.grad_is_dz = xv.grad_is_dz and xp.grad_is_dz     # the heads wrote dz of the middleware
-        self.torso.backward(ctx, acts)
+        if stop_after_dense:
+            k = self._split_layer()
+            self.torso.backward(ctx, acts, layers=(k, len(self.torso.layers)))
+            self._resume = (acts, k)
+        else:
+            self.torso.backward(ctx, acts)
+
+    def backward_rest(self):
+        acts, k = self._resume
+        if k > 0:
+            self.torso.backward(self.ctx, acts, layers=(0, k))
 
     def finish_update(self, grad_scale=1.0):
         """apply_gradients (architecture.py:469-521): global norm fetch + Adam."""

@@ -92,3 +92,33 @@ def test_stager_ring_cpu():
     c = StagerCache("cpu")
     a = c.push("k", np.ones((2, 3)), torch.float64)
     assert a.shape == (2, 3) and a.dtype == torch.float64
+
+
+def _worker_async(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from coach_amd.distributed import GradientSync
+    sync = GradientSync(backend="gloo")
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    off = 300
+    w1 = sync.all_reduce_sum_async(g[off:])          # "late" bucket first, while the rest is "computed"
+    g[:off] += 5.0
+    w2 = sync.all_reduce_sum_async(g[:off])
+    w1.wait(); w2.wait()
+    np.save(os.path.join(out_dir, "a%d.npy" % rank), g.numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_async_all_reduce_gloo(tmp_path):
+    """The overlap path of ClippedPPOAgent.train_network: two async all-reduces over disjoint slices
+    of the flat gradient buffer, waited on before the optimizer step."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_async, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a0, a1 = np.load(tmp_path / "a0.npy"), np.load(tmp_path / "a1.npy")
+    base = np.arange(1000, dtype=np.float32)
+    exp = base * 3
+    exp[:300] += 10.0
+    np.testing.assert_array_equal(a0, exp)
+    np.testing.assert_array_equal(a1, exp)
