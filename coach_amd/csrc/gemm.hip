@@ -817,6 +817,14 @@ inline bool rlx_big_tiles() {
     return v;
 }
 
+inline int rlx_split_min_k() {
+    static const int v = [] {
+        const char *e = getenv("RLX_GEMM_SPLIT_MIN_K");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 // RLX_GEMM_GENERIC=1 forces the bounds-checked kernel (used by the tests to cross-check the paths)
 inline bool rlx_force_generic_gemm() {
     static const bool v = [] {
@@ -900,8 +908,10 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     const int tiles = (int)tiles_of(BM, BN);
     // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split; a launch that
     // already covers every CU is left alone (its reduce pass would cost more than the imbalance)
+    // (RLX_GEMM_SPLIT_MIN_K raises the shortest K that may be split; measured on C2 / C3, splitting
+    // every under-filled launch is fastest: 118 vs 129 ms and 325 vs 383 ms per bench step.)
     int splits = 1;
-    if (d.workspace && tiles <= rlx::kCUs) {
+    if (d.workspace && tiles <= rlx::kCUs && d.K >= rlx_split_min_k()) {
         const int want = (2 * rlx::kCUs + tiles - 1) / tiles;
         const int max_by_k = d.K / (2 * BK);
         splits = want < max_by_k ? want : max_by_k;
