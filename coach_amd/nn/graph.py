@@ -17,6 +17,7 @@ middlewares/fc_middleware.py:40-70): activation after every layer, VALID conv pa
 Xavier-uniform kernels, zero biases (layers.py:180-181).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -98,6 +99,7 @@ def normalized_columns(std):
 class Workspace:
     def __init__(self, device, floats=1 << 24):
         self.splitk = torch.empty(floats, dtype=torch.float32, device=device)
+        self.splitk_side = torch.empty(floats, dtype=torch.float32, device=device)   # side-stream GEMMs
         self.small = torch.empty(1 << 18, dtype=torch.float32, device=device)
 
 
@@ -110,10 +112,32 @@ class Context:
         self.ws = ws or Workspace(device)
         self.cache = {}
         self.buffers = {}
+        # opt-in (RLX_OVERLAP=1): measured slower inside hipGraph replays on MI355X / ROCm 7.2
+        # (C2 126 vs 116 ms, C3 376 vs 318 ms per bench step) — the cross-stream edges cost more
+        # than the concurrency returns at these launch sizes
+        self.overlap = os.environ.get("RLX_OVERLAP", "0") == "1" and torch.cuda.is_available()
+        self.side = torch.cuda.Stream(device=device) if self.overlap else None
+        self._forked = False
 
     @property
     def stream(self):
         return torch.cuda.current_stream().cuda_stream
+
+    # Weight-gradient GEMMs are off the backward critical path (only the optimizer needs them): with
+    # RLX_OVERLAP=1 they run on a second HIP stream, concurrently with the input-gradient chain of
+    # the layers below.  Fork/join are plain event waits and are captured by hipGraphs.
+    def on_side(self, fn):
+        if not self.overlap:
+            return fn(self.ws.splitk)
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            fn(self.ws.splitk_side)
+        self._forked = True
+
+    def join(self):
+        if self._forked:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._forked = False
 
     def buffer(self, name, shape, dtype=torch.float32, tag=""):
         key = (name, tuple(shape), dtype, tag)
@@ -203,9 +227,10 @@ class Dense(Layer):
                       workspace=ctx.ws.splitk)
         return Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag), act=self.act)
 
-    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True):
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
         """y.grad holds dL/dy (post-activation); writes dW, db and (optionally) x.grad.
-        need_dw=False only propagates to the input (gradients_wrt_inputs, architecture.py:187-220)."""
+        need_dw=False only propagates to the input (gradients_wrt_inputs, architecture.py:187-220).
+        overlap: issue the dW GEMM on the context's side stream (the caller joins)."""
         t0, T = self._range(t0, nt)
         M, p = x.rows, self.params
         dz = y.grad
@@ -229,10 +254,15 @@ class Dense(Layer):
         # dW[K,N] = x^T dz : A(k, m) = x[m, k]
         # (db = column sums of dz, accumulated by the same launch from the staged B slabs)
         if need_dw:
-            _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
-                      a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
-                      c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
-                      colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
+            def dw(ws):
+                _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
+                          a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
+                          c_batch_stride=p.stride(self.kname), workspace=ws,
+                          colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
+            if overlap and need_dx:
+                ctx.on_side(dw)
+            else:
+                dw(ctx.ws.splitk)
         if need_dx:
             dx = x.ensure_grad()
             # dx[M,K] = dz W^T : B(n, k) = W[k, n]; the epilogue multiplies by the lower layer's
@@ -295,7 +325,7 @@ class Conv2d(Layer):
         # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
         return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag), act=self.act)
 
-    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True):
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
         t0, T = self._range(t0, nt)
         B, p = x.rows, self.params
         M = B * self.OH * self.OW
@@ -306,11 +336,16 @@ class Conv2d(Layer):
         dz = dz.view(T, M, self.Co)
         # dW[K,Co] = cols^T dz : A(k, m) gathered with outer table = koff, reduction table = rowbase
         if need_dw:
-            _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
-                      a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
-                      a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
-                      c_batch_stride=p.stride(self.kname), workspace=ctx.ws.splitk,
-                      colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
+            def dw(ws):
+                _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
+                          a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
+                          a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
+                          c_batch_stride=p.stride(self.kname), workspace=ws,
+                          colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
+            if overlap:
+                ctx.on_side(dw)          # also when this is the first layer: it overlaps the layers above
+            else:
+                dw(ctx.ws.splitk)
         if need_dx:
             assert x.towers == T
             dcol = ctx.buffer(self.name + "/dcol", (T, M, self.K))
@@ -347,9 +382,10 @@ class Sequential:
         first, starts their gradient all-reduce, then the rest)."""
         lo, hi = layers if layers is not None else (0, len(self.layers))
         for i in reversed(range(lo, hi)):
-            kw = {} if need_dw else {"need_dw": False}
+            kw = {"overlap": True} if need_dw else {"need_dw": False}
             self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),
                                     weights=weights, t0=t0, nt=nt, **kw)
+        ctx.join()                       # weight gradients issued on the side stream are complete
 
 
 class AdamState:
