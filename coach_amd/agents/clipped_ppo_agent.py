@@ -66,6 +66,9 @@ class ClippedPPOAlgorithmParameters(object):             # clipped_ppo_agent.py:
         self.act_for_full_episodes = True
         self.reward_clipping = (-1.0, 1.0)               # Atari input filter (gym_environment.py:106-113)
         self.reward_rescale = 1.0
+        # pre_network_filter = ObservationNormalizationFilter (presets/Mujoco_ClippedPPO.py): running
+        # statistics updated on the whole rollout at train time (update_pre_network_filters_state_on_train)
+        self.normalize_observations = False
 
 
 class ClippedPPOAgentParameters(object):                 # clipped_ppo_agent.py:121-131
@@ -98,7 +101,8 @@ class ClippedPPOAgent(object):
         self.use_graphs = use_graphs
         alg, net = self.ap.algorithm, self.ap.network_wrappers["main"]
         ep = environment.p
-        self.n_env, self.A = ep.num_envs, ep.num_actions
+        self.continuous = ep.action_dim is not None      # BoxActionSpace -> continuous PPO head
+        self.n_env, self.A = ep.num_envs, (ep.action_dim if self.continuous else ep.num_actions)
         self.image = ep.kind == "image"
         self.stack = 4
         self.L = ep.episode_length
@@ -114,7 +118,7 @@ class ClippedPPOAgent(object):
             learning_rate=net.learning_rate, adam_beta1=net.adam_optimizer_beta1,
             adam_beta2=net.adam_optimizer_beta2, optimizer_epsilon=net.optimizer_epsilon,
             clip_likelihood_ratio_using_epsilon=alg.clip_likelihood_ratio_using_epsilon,
-            beta_entropy=alg.beta_entropy, seed=self.ap.seed or 0)}
+            beta_entropy=alg.beta_entropy, seed=self.ap.seed or 0, continuous=self.continuous)}
         if self.dist is not None and self.ap.seed is not None:
             # rank-offset sampling seed (coach.py:746 seed + task_index) AFTER the shared weight init
             random.seed(self.ap.seed + self.dist.rank)
@@ -127,9 +131,22 @@ class ClippedPPOAgent(object):
         self.memory = DeviceEpisodicRolloutBuffer(
             self.device, self.n_env, self.steps_per_phase,
             frame_shape=ep.observation_shape if self.image else None, stack=self.stack,
-            obs_dim=None if self.image else int(ep.observation_shape[0]))
+            obs_dim=None if self.image else int(ep.observation_shape[0]),
+            action_dim=self.A if self.continuous else None)
         dev, n = self.device, self.n_env
-        self.actions = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.actions = torch.zeros((n, self.A), dtype=torch.float32, device=dev) if self.continuous else \
+            torch.zeros(n, dtype=torch.int32, device=dev)
+        self.norm = None
+        if alg.normalize_observations:
+            if self.image:
+                raise ValueError("ObservationNormalizationFilter applies to vector observations")
+            from ..filters.observation import ObservationNormalizationFilter
+            self.norm = ObservationNormalizationFilter(int(ep.observation_shape[0]), dev)
+            self.act_obs = torch.empty(n, int(ep.observation_shape[0]), dtype=torch.float32, device=dev)
+        if self.continuous:
+            lo = np.broadcast_to(np.asarray(ep.action_low, dtype=np.float32), (self.A,)).copy()
+            hi = np.broadcast_to(np.asarray(ep.action_high, dtype=np.float32), (self.A,)).copy()
+            self.d_low, self.d_high = torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev)
         self.filtered_reward = torch.zeros(n, dtype=torch.float32, device=dev)
         self.ep_return = torch.zeros(n, dtype=torch.float64, device=dev)
         self.ep_len = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -152,12 +169,18 @@ class ClippedPPOAgent(object):
         f32, f64 = torch.float32, torch.float64
         self.ds_reward = torch.empty(cap, dtype=f32, device=dev)
         self.ds_done = torch.empty(cap, dtype=torch.uint8, device=dev)
-        self.ds_action = torch.empty(cap, dtype=torch.int32, device=dev)
+        act_shape = (cap, self.A) if self.continuous else (cap,)
+        self.ds_action = torch.empty(act_shape, dtype=self.actions.dtype, device=dev)
         self.ds_value = torch.empty(cap, dtype=f32, device=dev)
         self.ds_adv64 = torch.empty(cap, dtype=f64, device=dev)
         self.ds_adv = torch.empty(cap, dtype=f32, device=dev)
         self.ds_vtarget = torch.empty(cap, dtype=f32, device=dev)
-        self.ds_old_probs = torch.empty(cap, self.A, dtype=f32, device=dev)
+        self.ds_old_probs = torch.empty(cap, self.A, dtype=f32, device=dev)     # discrete: probs; continuous: mean
+        self.ds_old_std = torch.empty(cap, self.A, dtype=f32, device=dev) if self.continuous else None
+        if self.norm is not None:
+            D = self.memory.obs_dim
+            self.ds_obs_raw = torch.empty(cap, D, dtype=f32, device=dev)
+            self.ds_obs = torch.empty(cap, D, dtype=f32, device=dev)
         self.adv_stats = torch.empty(2, dtype=f64, device=dev)
         obs_tail = tuple(self.memory.cur_state.shape[1:])
         odt = self.memory.cur_state.dtype
@@ -166,16 +189,19 @@ class ClippedPPOAgent(object):
         self.mb_obs = torch.empty((B,) + obs_tail, dtype=odt, device=dev)
         self.mb_rows = torch.empty(B, dtype=torch.int32, device=dev)
         self.mb_idx = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.mb_action = torch.empty(B, dtype=torch.int32, device=dev)
+        self.mb_action = torch.empty((B, self.A) if self.continuous else (B,), dtype=self.actions.dtype, device=dev)
+        self.mb_old_std = torch.empty(B, self.A, dtype=f32, device=dev) if self.continuous else None
         self.mb_adv = torch.empty(B, dtype=f32, device=dev)
         self.mb_vtarget = torch.empty(B, dtype=f32, device=dev)
         self.mb_old = torch.empty(B, self.A, dtype=f32, device=dev)
         self.mb_ratio = torch.empty(B, dtype=f32, device=dev)
         self.mb_clipped = torch.empty(B, dtype=f32, device=dev)
         self.scalar_acc = torch.zeros(8, dtype=f32, device=dev)
-        # one uniform per (step, env): what the phase's np.random.choice calls consume
+        # one uniform per (step, env): what the phase's np.random.choice calls consume (continuous:
+        # A standard normals per (step, env) behind np.random.normal(mean, std), additive_noise.py:106)
         from ..staging import Stager
-        self._uniforms = Stager((self.steps_per_phase, self.n_env), f64, dev, depth=4)
+        shape = (self.steps_per_phase, self.n_env, self.A) if self.continuous else (self.steps_per_phase, self.n_env)
+        self._uniforms = Stager(shape, f64, dev, depth=4)
         self.uniforms_all = self._uniforms.dst
 
     # ------------------------------------------------------------------------------ graph util
@@ -201,12 +227,22 @@ class ClippedPPOAgent(object):
         s = _rlx.current_stream()
         alg = self.ap.algorithm
         states = self.memory.current_states()
-        probs = self.networks["main"].policy_probs(states, self.n_env)
-        if self.phase == RunPhase.TRAIN:
-            self.lib.categorical_sample(probs, self.A, self.uniforms_all[step], self.n_env, self.A,
-                                        self.actions, s)                    # categorical.py:45-48
+        if self.norm is not None:          # run_pre_network_filter_for_inference (:346-350): no state update
+            states = self.norm.filter(states, update_internal_state=False, out=self.act_obs)
+        if self.continuous:
+            mean, std = self.networks["main"].policy_mean_std(states, self.n_env)
+            if self.phase == RunPhase.TRAIN:                                # additive_noise.py:99-106
+                self.lib.gaussian_action(mean, None, std, self.uniforms_all[step], self.d_low, self.d_high,
+                                         self.n_env, self.A, self.actions, s)
+            else:
+                self.actions.copy_(mean)
         else:
-            self.actions.copy_(probs.argmax(dim=1).to(torch.int32))         # :50-56
+            probs = self.networks["main"].policy_probs(states, self.n_env)
+            if self.phase == RunPhase.TRAIN:
+                self.lib.categorical_sample(probs, self.A, self.uniforms_all[step], self.n_env, self.A,
+                                            self.actions, s)                # categorical.py:45-48
+            else:
+                self.actions.copy_(probs.argmax(dim=1).to(torch.int32))     # :50-56
         next_obs, reset_obs, reward, game_over = self.env.step(self.actions)
         has_clip = alg.reward_clipping is not None
         lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
@@ -224,7 +260,10 @@ class ClippedPPOAgent(object):
         if step == 0 and self.phase == RunPhase.TRAIN:
             # draws of the whole phase, in the order n_env sequential np.random.choice calls per step
             # would make them (nothing else consumes np.random while acting)
-            u = np.random.random_sample((self.steps_per_phase, self.n_env))
+            if self.continuous:
+                u = np.random.standard_normal((self.steps_per_phase, self.n_env, self.A))
+            else:
+                u = np.random.random_sample((self.steps_per_phase, self.n_env))
             self._uniforms.push(u)
         self.ap.algorithm.clipping_decay_schedule.step()                    # choose_action (:352-354)
         self._run(("act", step, self.phase), lambda: self._act_device(step))
@@ -249,18 +288,30 @@ class ClippedPPOAgent(object):
         s = _rlx.current_stream()
         mem.gather_columns(rows, n, [(mem.reward, self.ds_reward), (mem.game_over, self.ds_done),
                                      (mem.action, self.ds_action)])
+        if self.norm is not None:
+            # pre_network_filter over the whole dataset, statistics updated first (:320-322)
+            mem.gather_states(rows, n, self.ds_obs_raw[:n])
+            self.norm.filter(self.ds_obs_raw[:n], update_internal_state=True, out=self.ds_obs[:n])
+
+        def chunk_obs(c0, m):
+            if self.norm is not None:
+                return self.ds_obs[c0:c0 + m]
+            return mem.gather_states(rows[c0:c0 + m], m, self.chunk_obs[:m])
         for c0 in range(0, n, self.chunk):
             m = min(self.chunk, n - c0)
-            obs = mem.gather_states(rows[c0:c0 + m], m, self.chunk_obs[:m])
-            net.values(obs, m, out=self.ds_value[c0:c0 + m])
+            net.values(chunk_obs(c0, m), m, out=self.ds_value[c0:c0 + m])
         self.lib.gae(self.ds_reward, self.ds_value, self.ds_done, None, mem.n_env, n // mem.n_env,
                      alg.discount, alg.gae_lambda, self.ds_adv64, self.ds_vtarget, s)
         self.lib.standardize(self.ds_adv64, n, self.ds_adv, None, self.adv_stats, s)
         # old policy = target network, frozen for the whole phase (:238-241, hoisted out of the loop)
         for c0 in range(0, n, self.chunk):
             m = min(self.chunk, n - c0)
-            obs = mem.gather_states(rows[c0:c0 + m], m, self.chunk_obs[:m])
-            net.policy_probs(obs, m, use_target=True, tag="old", out=self.ds_old_probs[c0:c0 + m])
+            if self.continuous:
+                net.policy_mean_std(chunk_obs(c0, m), m, use_target=True, tag="old",
+                                    out_mean=self.ds_old_probs[c0:c0 + m], out_std=self.ds_old_std[c0:c0 + m])
+            else:
+                net.policy_probs(chunk_obs(c0, m), m, use_target=True, tag="old",
+                                 out=self.ds_old_probs[c0:c0 + m])
 
     def fill_advantages(self):
         """clipped_ppo_agent.py:157-207 on device: V(s) for the whole dataset in chunks, segmented
@@ -276,16 +327,23 @@ class ClippedPPOAgent(object):
         # dataset index -> storage row, then one launch gathers the per-transition columns
         self.lib.copy_columns(_rlx.make_columns([(rows_all, rows)]), 1, idx, None, 0, 0,
                               rows_all.numel(), m, m, mem.status, s)
-        self.lib.copy_columns(_rlx.make_columns([(self.ds_action, self.mb_action), (self.ds_adv, self.mb_adv),
-                                                 (self.ds_vtarget, self.mb_vtarget),
-                                                 (self.ds_old_probs, self.mb_old)]), 4, idx, None, 0, 0,
-                              self.ds_adv.numel(), m, m, mem.status, s)
+        cols = [(self.ds_action, self.mb_action), (self.ds_adv, self.mb_adv), (self.ds_vtarget, self.mb_vtarget),
+                (self.ds_old_probs, self.mb_old)]
+        if self.continuous:
+            cols.append((self.ds_old_std, self.mb_old_std))
+        if self.norm is not None:
+            cols.append((self.ds_obs, self.mb_obs))           # normalised observations, dataset order
+        self.lib.copy_columns(_rlx.make_columns(cols), len(cols), idx, None, 0, 0, self.ds_adv.numel(), m, m,
+                              mem.status, s)
+        if self.norm is not None:
+            return self.mb_obs[:m]
         return mem.gather_states(rows, m, self.mb_obs[:m])
 
     def _minibatch_fb(self, m, clip_rescaler, stop_after_dense=False):
         obs = self._gather_minibatch(m)
+        old = (self.mb_old, self.mb_old_std) if self.continuous else self.mb_old
         self.networks["main"].forward_backward(obs, m, self.mb_action, self.mb_adv, self.mb_vtarget,
-                                               self.mb_old, clip_rescaler, self.mb_ratio, self.mb_clipped,
+                                               old, clip_rescaler, self.mb_ratio, self.mb_clipped,
                                                stop_after_dense=stop_after_dense)
 
     def _minibatch_finish(self, scale):

@@ -68,6 +68,12 @@ __global__ void select_rows_kernel(const unsigned char *__restrict__ mask,
     }
 }
 
+// out[b][a] = exp(log_std[a]): tf.tile(tf.exp(policy_logstd), [batch, 1])  (ppo_head.py:139)
+__global__ void exp_rows_kernel(const float *__restrict__ log_std, float *__restrict__ out, int batch, int A) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < batch * A) out[t] = expf(log_std[t % A]);
+}
+
 constexpr float kLogSigCapMin = -20.f, kLogSigCapMax = 2.f;       // sac_head.py:26-27
 constexpr float kEpsF32 = 1.1920928955078125e-07f;                 // np.finfo(np.float32).eps (utils.py:38)
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
@@ -146,6 +152,14 @@ int rlx_copy_2d(const float *src, long long src_ld, float *dst, long long dst_ld
     RLX_REQUIRE(rows > 0 && cols > 0 && src_ld >= cols && dst_ld >= cols, "rlx_copy_2d: bad shape");
     copy_2d_kernel<<<rlx::grid_for((long long)rows * cols, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
         src, src_ld, dst, dst_ld, rows, cols, scale);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_exp_rows(const float *log_std, float *out, int batch, int action_dim, void *stream) {
+    RLX_REQUIRE(log_std && out && batch > 0 && action_dim > 0, "rlx_exp_rows: bad arguments");
+    const int n = batch * action_dim;
+    exp_rows_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(log_std, out, batch, action_dim);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

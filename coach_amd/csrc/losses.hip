@@ -159,6 +159,82 @@ ppo_discrete_loss_kernel(const float *__restrict__ logits, long long ld, const i
     }
 }
 
+// Continuous Clipped-PPO head (ppo_head.py:118-144 + :58-98): policy = MultivariateNormalDiag(mean,
+// exp(log_std) + eps) with ONE state-independent log_std vector; old policy = MVN(old_mean,
+// old_std + eps) where old_std is the network's policy_std output.  eps = np.finfo(float32).eps.
+// scalars as the discrete kernel.  d_log_std[a] (sum over the batch) is reduced in the workgroup.
+__global__ void __launch_bounds__(kMaxBlock)
+ppo_continuous_loss_kernel(const float *__restrict__ mean, long long ld, const float *__restrict__ log_std,
+                           const float *__restrict__ actions, const float *__restrict__ advantages,
+                           const float *__restrict__ old_mean, const float *__restrict__ old_std,
+                           long long ld_old, int batch, int A, float clip_eps, float beta,
+                           float grad_scale, float *__restrict__ dmean, long long ld_grad,
+                           float *__restrict__ dlog_std, float *__restrict__ scalars,
+                           float *__restrict__ ratio_out, float *__restrict__ clipped_out) {
+    __shared__ float red[kMaxBlock];
+    constexpr float kEps = 1.1920928955078125e-07f, kHalfLog2Pi = 0.91893853320467274178f;
+    float l_sur = 0.f, l_kl = 0.f;
+    float ent = 0.f;                                   // identical for every sample
+    for (int a = 0; a < A; ++a) ent += 0.5f + kHalfLog2Pi + logf(expf(log_std[a]) + kEps);
+    float my_glp = 0.f;                                 // batch <= blockDim: one sample per thread
+    const int b = threadIdx.x;
+    if (b < batch) {
+        const float *mu = mean + (size_t)b * ld, *x = actions + (size_t)b * A;
+        const float *mo = old_mean + (size_t)b * ld_old, *so = old_std + (size_t)b * ld_old;
+        float logp = 0.f, logp_old = 0.f, kl = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float sd = expf(log_std[a]) + kEps, sdo = so[a] + kEps;
+            const float z = (x[a] - mu[a]) / sd, zo = (x[a] - mo[a]) / sdo;
+            logp += -0.5f * z * z - logf(sd) - kHalfLog2Pi;
+            logp_old += -0.5f * zo * zo - logf(sdo) - kHalfLog2Pi;
+            const float dm = mo[a] - mu[a];
+            kl += logf(sd / sdo) + (sdo * sdo + dm * dm) / (2.f * sd * sd) - 0.5f;
+        }
+        const float ratio = expf(logp - logp_old);
+        const float lo = 1.f - clip_eps, hi = 1.f + clip_eps;
+        const float clipped = fminf(fmaxf(ratio, lo), hi);
+        const float adv = advantages[b];
+        const float s1 = ratio * adv, s2 = clipped * adv;
+        l_sur = fminf(s1, s2);
+        l_kl = kl;
+        if (ratio_out) ratio_out[b] = ratio;
+        if (clipped_out) clipped_out[b] = clipped;
+        if (dmean) {
+            float g_logp = (s1 <= s2 || (ratio >= lo && ratio <= hi)) ? -adv * ratio : 0.f;
+            g_logp *= grad_scale / (float)batch;
+            my_glp = g_logp;
+            for (int a = 0; a < A; ++a) {
+                const float sd = expf(log_std[a]) + kEps;
+                dmean[(size_t)b * ld_grad + a] = g_logp * (x[a] - mu[a]) / (sd * sd);
+            }
+        }
+    }
+    const float sur = block_sum(l_sur, red);
+    const float kls = block_sum(l_kl, red);
+    if (dlog_std) {
+        // d loss / d log_std[a] = sum_b g_logp_b * (d^2 / sd^3 - 1 / sd) * exp(log_std) - beta * dH/d log_std:
+        // one fixed-order workgroup reduction per action dimension (reproducible, no atomics)
+        for (int a = 0; a < A; ++a) {
+            const float e = expf(log_std[a]);
+            const float sd = e + kEps;
+            float part = 0.f;
+            if (b < batch) {
+                const float d = actions[(size_t)b * A + a] - mean[(size_t)b * ld + a];
+                part = my_glp * (d * d / (sd * sd * sd) - 1.f / sd) * e;
+            }
+            const float tot = block_sum(part, red);
+            if (threadIdx.x == 0) dlog_std[a] = tot - grad_scale * beta * e / sd;
+        }
+    }
+    if (threadIdx.x == 0 && scalars) {
+        const float inv = 1.f / (float)batch;
+        scalars[0] = -sur * inv;
+        scalars[1] = ent;
+        scalars[2] = kls * inv;
+        scalars[3] = -sur * inv - beta * ent;
+    }
+}
+
 inline int block_for(int batch) {
     int t = 64;
     while (t < batch && t < kMaxBlock) t <<= 1;
@@ -210,6 +286,26 @@ int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
         logits, ld, actions, advantages, old_probs, ld_old, batch, n_actions, clip_epsilon,
         beta_entropy, grad_scale, dlogits, ld_grad, scalars, likelihood_ratio,
         clipped_likelihood_ratio, status);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_ppo_continuous_loss(const float *mean, long long ld, const float *log_std, const float *actions,
+                            const float *advantages, const float *old_mean, const float *old_std,
+                            long long ld_old, int batch, int action_dim, float clip_epsilon,
+                            float beta_entropy, float grad_scale, float *dmean, long long ld_grad,
+                            float *dlog_std, float *scalars, float *likelihood_ratio,
+                            float *clipped_likelihood_ratio, void *stream) {
+    RLX_REQUIRE(mean && log_std && actions && advantages && old_mean && old_std,
+                "rlx_ppo_continuous_loss: null pointer");
+    RLX_REQUIRE(batch > 0 && batch <= kMaxBlock && action_dim > 0 && ld >= action_dim && ld_old >= action_dim,
+                "rlx_ppo_continuous_loss: bad shape (minibatch must be <= %d rows)", kMaxBlock);
+    RLX_REQUIRE((dmean == nullptr) == (dlog_std == nullptr) && (!dmean || ld_grad >= action_dim),
+                "rlx_ppo_continuous_loss: give both gradient outputs or neither");
+    ppo_continuous_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
+        mean, ld, log_std, actions, advantages, old_mean, old_std, ld_old, batch, action_dim, clip_epsilon,
+        beta_entropy, grad_scale, dmean, ld_grad, dlog_std, scalars, likelihood_ratio,
+        clipped_likelihood_ratio);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

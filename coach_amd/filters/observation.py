@@ -80,14 +80,15 @@ class ObservationNormalizationFilter(ObservationFilter):
         self.mean = torch.zeros(dim, dtype=f64, device=device)
         self.std = torch.full((dim,), float(np.sqrt(epsilon)), dtype=f64, device=device)
 
-    def filter(self, observation, update_internal_state=True):
+    def filter(self, observation, update_internal_state=True, out=None):
         n = observation.shape[0]
         is64 = observation.dtype == torch.float64
         s = _rlx.current_stream()
         if update_internal_state:
             _rlx.lib().running_stats_push(observation, int(is64), n, self.dim, self.sum, self.sum_squares,
                                           self.count, self.mean, self.std, self.eps, s)
-        out = torch.empty(n, self.dim, dtype=torch.float32, device=observation.device)
+        if out is None:
+            out = torch.empty(n, self.dim, dtype=torch.float32, device=observation.device)
         _rlx.lib().running_stats_normalize(observation, int(is64), n, self.dim, self.mean, self.std,
                                            self.clip[0], self.clip[1], out, None, s)
         return out

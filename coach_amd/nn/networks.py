@@ -93,14 +93,22 @@ class ClippedPPONet(_NetBase):
     def __init__(self, device, obs_shape, n_actions, activation="tanh", embedder="Medium",
                  middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
                  optimizer_epsilon=1e-4, clip_likelihood_ratio_using_epsilon=0.2, beta_entropy=0.01,
-                 seed=0):
+                 seed=0, continuous=False):
+        """continuous: n_actions is the action dimension; the head is ppo_head.py:118-144 (policy_mean
+        Dense with normalized-columns(0.01) init + one state-independent policy_log_std vector)."""
         self.obs_shape, self.image, self.A = tuple(obs_shape), len(obs_shape) == 3, n_actions
         self.clip_eps, self.beta = clip_likelihood_ratio_using_epsilon, beta_entropy
+        self.continuous = continuous
         self.params = G.FlatParams()
         self.torso, feat = build_torso(self.params, "main", obs_shape, activation, 2, embedder, middleware)
         self.v_head = G.Dense(self.params, "main/v_head/dense", feat, 1, None, 1,
                               init=G.normalized_columns(1.0))                   # v_head.py:43-48
-        self.pi_head = G.Dense(self.params, "main/ppo_head/policy_fc", feat, n_actions, None, 1)
+        if continuous:
+            self.pi_head = G.Dense(self.params, "main/ppo_head/policy_mean", feat, n_actions, None, 1,
+                                   init=G.normalized_columns(0.01))
+            self.params.add_group([("main/ppo_head/policy_log_std", (n_actions,))])   # zeros (:133-137)
+        else:
+            self.pi_head = G.Dense(self.params, "main/ppo_head/policy_fc", feat, n_actions, None, 1)
         self.modules = [self.torso, self.v_head, self.pi_head]
         self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
         # [surrogate, entropy, kl, policy-head total, value loss, grad norm]: one contiguous record
@@ -116,6 +124,20 @@ class ClippedPPONet(_NetBase):
         probs = out if out is not None else self.ctx.buffer("probs", (B, self.A), tag=tag)
         self.lib.softmax(logits.data, self.A, B, self.A, probs, self.A, self.ctx.stream)
         return probs
+
+    def policy_mean_std(self, obs, B, use_target=False, tag="act", out_mean=None, out_std=None):
+        """Continuous head outputs [policy_mean, policy_std] (ppo_head.py:139-144): std = exp(log_std)
+        tiled over the batch (the +eps is added where the distribution is built)."""
+        w = self.target if use_target else None
+        acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w, t0=1, nt=1)
+        mean = self.pi_head.forward(self.ctx, acts[-1], tag=tag, weights=w).data.view(B, self.A)
+        std = out_std if out_std is not None else self.ctx.buffer("policy_std", (B, self.A), tag=tag)
+        ls = self.params.w("main/ppo_head/policy_log_std", 0, w)
+        self.lib.exp_rows(ls, std, B, self.A, self.ctx.stream)
+        if out_mean is not None:
+            out_mean.copy_(mean)
+            mean = out_mean
+        return mean, std
 
     def values(self, obs, B, tag="val", out=None):
         """V(s) from the value tower of the online network (fill_advantages :161-170)."""
@@ -157,10 +179,18 @@ class ClippedPPONet(_NetBase):
         self.lib.regression_loss(v.data, 1, value_targets, 1, None, B, 1, 0, 1.0, 1.0, dv, 1,
                                  self.scalars[4:5], ctx.stream)
         # head 1: PPOHead clipped surrogate (+ entropy bonus)
-        self.lib.ppo_discrete_loss(logits.data, self.A, actions, advantages, old_probs, self.A, B,
-                                   self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
-                                   self.A, self.scalars[0:4], ratio_out, clipped_out, self.status,
-                                   ctx.stream)
+        if self.continuous:
+            old_mean, old_std = old_probs                          # [policy_mean, policy_std] of the old policy
+            self.lib.ppo_continuous_loss(logits.data, self.A, self.params.w("main/ppo_head/policy_log_std"),
+                                         actions, advantages, old_mean, old_std, self.A, B, self.A,
+                                         self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits, self.A,
+                                         self.params.g("main/ppo_head/policy_log_std"), self.scalars[0:4],
+                                         ratio_out, clipped_out, ctx.stream)
+        else:
+            self.lib.ppo_discrete_loss(logits.data, self.A, actions, advantages, old_probs, self.A, B,
+                                       self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
+                                       self.A, self.scalars[0:4], ratio_out, clipped_out, self.status,
+                                       ctx.stream)
         self.v_head.backward(ctx, xv, v)
         self.pi_head.backward(ctx, xp, logits)
         mid.grad_is_dz = xv.grad_is_dz and xp.grad_is_dz     # the heads wrote dz of the middleware

@@ -247,6 +247,16 @@ int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
                           float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
                           void *stream);
 
+/* Continuous policy (heads/ppo_head.py:118-144): MultivariateNormalDiag(mean, exp(log_std) + eps),
+ * log_std one state-independent vector [action_dim]; old_std is the old network's policy_std output.
+ * dlog_std[action_dim] receives the batch-summed gradient.  scalars as rlx_ppo_discrete_loss. */
+int rlx_ppo_continuous_loss(const float *mean, long long ld, const float *log_std, const float *actions,
+                            const float *advantages, const float *old_mean, const float *old_std,
+                            long long ld_old, int batch, int action_dim, float clip_epsilon,
+                            float beta_entropy, float grad_scale, float *dmean, long long ld_grad,
+                            float *dlog_std, float *scalars, float *likelihood_ratio,
+                            float *clipped_likelihood_ratio, void *stream);
+
 /* ------------------------------------------ optimiser / target mixing (K11) -- */
 /* state = {beta1_power, beta2_power} (2 device floats).  tf.train.AdamOptimizer as built in
  * architectures/tensorflow_components/general_network.py:390-394. */
@@ -272,6 +282,8 @@ int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspa
  * (general_network.py:270-277, heads/ddpg_actor_head.py:48-56). */
 int rlx_copy_2d(const float *src, long long src_ld, float *dst, long long dst_ld, int rows, int cols,
                 float scale, void *stream);
+int rlx_exp_rows(const float *log_std, float *out, int batch, int action_dim,
+                 void *stream);                /* policy_std = tile(exp(policy_logstd)), heads/ppo_head.py:139 */
 int rlx_axpby(float *out, float a, const float *x, float b, const float *y, long long n,
               void *stream);                   /* out = a*x + b*y (y may be NULL); heads/sac_q_head.py:63-67 */
 /* out_min = min(q1,q2); grad_i = grad_scale * d sum(min)/d q_i (tf.minimum: ties go to q1).

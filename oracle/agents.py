@@ -66,22 +66,26 @@ class ClippedPPOOracle(_Base):
     """Two separate towers (value, policy) + VHead + discrete PPOHead (clipped_ppo_agent.py:41-58)."""
 
     def __init__(self, arrays, obs_shape, n_actions, activation="tanh", lr=2.5e-4, beta1=0.9,
-                 beta2=0.99, eps=1e-4, clip_eps=0.2, beta_entropy=0.01):
+                 beta2=0.99, eps=1e-4, clip_eps=0.2, beta_entropy=0.01, continuous=False):
         self.image = len(obs_shape) == 3
         self.A, self.clip_eps, self.beta = n_actions, clip_eps, beta_entropy
+        self.continuous = continuous
         cp = lambda a: {k: [x.copy() for x in v] for k, v in a.items()}
         arrays = cp(arrays)
         self.v_tower = N.build_chain(arrays, "main", 0, obs_shape, activation)
         self.p_tower = N.build_chain(arrays, "main", 1, obs_shape, activation)
         self.v_head = N.Dense(arrays["main/v_head/dense/kernel"][0], arrays["main/v_head/dense/bias"][0])
-        self.p_head = N.Dense(arrays["main/ppo_head/policy_fc/kernel"][0],
-                              arrays["main/ppo_head/policy_fc/bias"][0])
+        hn = "main/ppo_head/policy_mean" if continuous else "main/ppo_head/policy_fc"
+        self.p_head = N.Dense(arrays[hn + "/kernel"][0], arrays[hn + "/bias"][0])
         tn = _chain_names(arrays, "main")
         self.chains = [("main", 0, self.v_tower), ("main", 1, self.p_tower),
                        ("vh", 0, N.Chain([self.v_head])), ("ph", 0, N.Chain([self.p_head]))]
         self.names = {("main", 0): tn, ("main", 1): tn, ("vh", 0): ["main/v_head/dense"],
-                      ("ph", 0): ["main/ppo_head/policy_fc"]}
+                      ("ph", 0): [hn]}
         self.adam = N.PerTensorAdam(lr, beta1, beta2, eps)
+        if continuous:                                   # policy_log_std variable (ppo_head.py:133-137)
+            self.log_std = arrays["main/ppo_head/policy_log_std"][0].astype(F32).copy()
+            self.d_log_std = np.zeros_like(self.log_std)
 
     def clone_policy(self):
         """Frozen copy of (policy tower, head) = the target network's 'old policy' (:238-241)."""
@@ -95,17 +99,38 @@ class ClippedPPOOracle(_Base):
     def values(self, obs):
         return self.v_head.forward(self.v_tower.forward(N.prep_obs(obs, self.image)))[:, 0]
 
+    def policy_mean_std(self, obs, frozen=None):
+        """continuous head outputs [policy_mean, policy_std]; frozen = (tower, head, log_std)."""
+        tower, head, ls = frozen if frozen is not None else (self.p_tower, self.p_head, self.log_std)
+        mean = head.forward(tower.forward(N.prep_obs(obs, self.image)))
+        return mean, np.tile(np.exp(ls)[None], (mean.shape[0], 1)).astype(F32)
+
+    def clone_policy_continuous(self):
+        import copy
+        return copy.deepcopy((self.p_tower, self.p_head, self.log_std))
+
     def train_minibatch(self, obs, actions, advantages, value_targets, old_probs, clip_rescaler=1.0,
                         grad_scale=1.0):
         x = N.prep_obs(obs, self.image)
         v = self.v_head.forward(self.v_tower.forward(x))
         logits = self.p_head.forward(self.p_tower.forward(x))
         vloss, dv = L.regression_head_loss(v, np.asarray(value_targets, dtype=F32).reshape(-1, 1), None, "mse")
-        pl = L.ppo_discrete_loss(logits, actions, advantages, old_probs, self.clip_eps * clip_rescaler, self.beta)
+        if self.continuous:
+            pl = L.ppo_continuous_loss(logits, self.log_std, actions, advantages, old_probs[0], old_probs[1],
+                                       self.clip_eps * clip_rescaler, self.beta)
+            dhead = pl["dmean"]
+            self.d_log_std = pl["dlog_std"]
+        else:
+            pl = L.ppo_discrete_loss(logits, actions, advantages, old_probs, self.clip_eps * clip_rescaler, self.beta)
+            dhead = pl["dlogits"]
         self.v_tower.backward(self.v_head.backward(dv))
-        self.p_tower.backward(self.p_head.backward(pl["dlogits"]))
+        self.p_tower.backward(self.p_head.backward(dhead))
         norm = self.global_norm()
+        if self.continuous:
+            norm = np.sqrt(norm ** 2 + float(np.sum(self.d_log_std.astype(np.float64) ** 2)))
         self.adam_step(grad_scale)
+        if self.continuous:
+            self.adam.step(("log_std", 0, "k"), self.log_std, self.d_log_std, grad_scale)
         return dict(value_loss=vloss, norm=norm, **pl)
 
 

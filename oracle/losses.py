@@ -86,3 +86,36 @@ def ppo_discrete_loss(logits, actions, advantages, old_probs, clip_eps, beta):
     g = g + (beta / B) * p * (lp_all + ent[:, None])
     return dict(surrogate=np.float32(surrogate), entropy=np.float32(ent.mean()), kl=np.float32(kl.mean()),
                 total=np.float32(total), ratio=ratio, clipped=clipped, dlogits=g.astype(np.float32))
+
+
+def ppo_continuous_loss(mean, log_std, actions, advantages, old_mean, old_std, clip_eps, beta):
+    """Continuous PPOHead (ppo_head.py:118-144 + :58-98): MultivariateNormalDiag(mean, exp(log_std) + eps)
+    against MVN(old_mean, old_std + eps).  Returns loss terms, fetches and the gradients w.r.t. the
+    policy_mean output [B, A] and the log_std variable [A]."""
+    F = np.float32
+    eps = np.finfo(np.float32).eps
+    mu, x = np.asarray(mean, dtype=F), np.asarray(actions, dtype=F)
+    mo, so = np.asarray(old_mean, dtype=F), np.asarray(old_std, dtype=F) + eps
+    ls = np.asarray(log_std, dtype=F).reshape(-1)
+    B, A = mu.shape
+    e = np.exp(ls)
+    sd = e + eps
+    c = F(0.91893853320467274178)
+    logp = (-0.5 * ((x - mu) / sd) ** 2 - np.log(sd) - c).sum(1)
+    logp_old = (-0.5 * ((x - mo) / so) ** 2 - np.log(so) - c).sum(1)
+    ratio = np.exp(logp - logp_old)
+    lo, hi = 1 - clip_eps, 1 + clip_eps
+    clipped = np.clip(ratio, lo, hi)
+    adv = np.asarray(advantages, dtype=F)
+    s1, s2 = ratio * adv, clipped * adv
+    surrogate = -np.mean(np.minimum(s1, s2))
+    ent = (0.5 + c + np.log(sd)).sum()
+    kl = (np.log(sd / so) + (so ** 2 + (mo - mu) ** 2) / (2 * sd ** 2) - 0.5).sum(1)
+    total = surrogate - beta * ent
+    use = (s1 <= s2) | ((ratio >= lo) & (ratio <= hi))
+    g_logp = np.where(use, -adv * ratio, 0.0) / B
+    d = x - mu
+    dmean = g_logp[:, None] * d / sd ** 2
+    dls = (g_logp[:, None] * (d ** 2 / sd ** 3 - 1 / sd) * e).sum(0) - beta * e / sd
+    return dict(surrogate=F(surrogate), entropy=F(ent), kl=F(kl.mean()), total=F(total), ratio=ratio,
+                clipped=clipped, dmean=dmean.astype(F), dlog_std=dls.astype(F))

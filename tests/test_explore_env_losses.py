@@ -149,3 +149,61 @@ def test_hip_loss_kernels_vs_oracle_and_reference_kat(rlx, dev):
                           dev_tensor([-2, 2, 1], dev, np.float32), dev_tensor(old, dev), 2, 3, 2, 0.2, 0.0, 1.0,
                           None, 2, sc, None, None, st, 0)
     assert int(st.item()) == 1
+
+
+def test_oracle_ppo_continuous_loss_matches_torch_autograd():
+    """The MultivariateNormalDiag surrogate / entropy / KL and their gradients against torch
+    distributions + autograd (an independent implementation of ppo_head.py:58-98,118-144)."""
+    import torch
+    from oracle.losses import ppo_continuous_loss
+    rng = np.random.RandomState(3)
+    B, A = 12, 4
+    mean = rng.randn(B, A).astype(np.float32) * 0.5
+    ls = (rng.randn(A) * 0.3).astype(np.float32)
+    x = rng.randn(B, A).astype(np.float32)
+    adv = rng.randn(B).astype(np.float32)
+    om = mean + rng.randn(B, A).astype(np.float32) * 0.1
+    os_ = np.exp(ls + rng.randn(A).astype(np.float32) * 0.05)[None].repeat(B, 0).astype(np.float32)
+    r = ppo_continuous_loss(mean, ls, x, adv, om, os_, 0.2, 0.01)
+    eps = float(np.finfo(np.float32).eps)
+    tm = torch.tensor(mean, requires_grad=True)
+    tl = torch.tensor(ls, requires_grad=True)
+    new = torch.distributions.Normal(tm, torch.exp(tl) + eps)
+    old = torch.distributions.Normal(torch.tensor(om), torch.tensor(os_) + eps)
+    tx = torch.tensor(x)
+    ratio = torch.exp(new.log_prob(tx).sum(1) - old.log_prob(tx).sum(1))
+    ta = torch.tensor(adv)
+    sur = -torch.minimum(ratio * ta, torch.clamp(ratio, 0.8, 1.2) * ta).mean()
+    ent = new.entropy().sum(1).mean()
+    kl = torch.distributions.kl_divergence(old, new).sum(1).mean()
+    (sur - 0.01 * ent).backward()
+    np.testing.assert_allclose(r["surrogate"], float(sur.detach()), rtol=2e-5)
+    np.testing.assert_allclose(r["entropy"], float(ent.detach()), rtol=2e-6)
+    np.testing.assert_allclose(r["kl"], float(kl.detach()), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(r["dmean"], tm.grad.numpy(), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(r["dlog_std"], tl.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,A", [(64, 6), (100, 17), (7, 1)])
+def test_ppo_continuous_loss_kernel_matches_oracle(rlx, dev, B, A):
+    import torch
+    from oracle.losses import ppo_continuous_loss
+    from tests.util import dev_tensor
+    rng = np.random.RandomState(B + A)
+    mean = rng.randn(B, A).astype(np.float32) * 0.5
+    ls = (rng.randn(A) * 0.3).astype(np.float32)
+    x = rng.randn(B, A).astype(np.float32)
+    adv = rng.randn(B).astype(np.float32)
+    om = mean + rng.randn(B, A).astype(np.float32) * 0.1
+    os_ = np.exp(ls + rng.randn(A).astype(np.float32) * 0.05)[None].repeat(B, 0).astype(np.float32)
+    r = ppo_continuous_loss(mean, ls, x, adv, om, os_, 0.2, 0.01)
+    dm = torch.zeros(B, A, device=dev); dl = torch.zeros(A, device=dev)
+    sc = torch.zeros(4, device=dev); ra = torch.zeros(B, device=dev); cl = torch.zeros(B, device=dev)
+    rlx.ppo_continuous_loss(dev_tensor(mean, dev), A, dev_tensor(ls, dev), dev_tensor(x, dev), dev_tensor(adv, dev),
+                            dev_tensor(om, dev), dev_tensor(os_, dev), A, B, A, 0.2, 0.01, 1.0, dm, A, dl, sc, ra, cl, 0)
+    np.testing.assert_allclose(sc.cpu().numpy(), [r["surrogate"], r["entropy"], r["kl"], r["total"]], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(ra.cpu().numpy(), r["ratio"], rtol=2e-4)
+    np.testing.assert_allclose(cl.cpu().numpy(), r["clipped"], rtol=2e-4)
+    np.testing.assert_allclose(dm.cpu().numpy(), r["dmean"], rtol=5e-4, atol=1e-7)
+    np.testing.assert_allclose(dl.cpu().numpy(), r["dlog_std"], rtol=2e-3, atol=2e-6)

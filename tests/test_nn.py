@@ -216,3 +216,42 @@ def test_hip_adam_mix_norm_vs_oracle(rlx, dev):
     assert np.array_equal(t.cpu().numpy(), np.float32(0.005) * g + np.float32(1 - 0.005) * w)
     rlx.mix_weights(t, gd, n, 1.0, 0)
     assert np.array_equal(t.cpu().numpy(), g)
+
+
+@pytest.mark.gpu
+def test_hip_clipped_ppo_continuous_net_vs_oracle(rlx, dev):
+    """Mujoco_ClippedPPO head (ppo_head.py:118-144): policy_mean Dense + state-independent log_std."""
+    import torch
+    from coach_amd.nn.networks import ClippedPPONet
+    from oracle.agents import ClippedPPOOracle
+    from tests.util import dev_tensor
+    np.random.seed(9)
+    rng = np.random.RandomState(2)
+    D, A, B = 17, 6, 64
+    net = ClippedPPONet(dev, (D,), A, seed=3, continuous=True, beta_entropy=0.01)
+    net.params.w("main/ppo_head/policy_log_std").copy_(dev_tensor(rng.randn(A) * 0.2, dev, np.float32))
+    o = ClippedPPOOracle(net.params.named_arrays(), (D,), A, continuous=True)
+    obs = rng.randn(B, D).astype(np.float32)
+    obs_d = dev_tensor(obs, dev)
+    frozen = o.clone_policy_continuous()
+    net.update_target(1.0)
+    for step in range(3):
+        actions = rng.randn(B, A).astype(np.float32)
+        adv = rng.randn(B).astype(np.float32)
+        vt = rng.randn(B).astype(np.float32)
+        om, os_ = net.policy_mean_std(obs_d, B, use_target=True, tag="old")
+        rm, rs = o.policy_mean_std(obs, frozen)
+        np.testing.assert_allclose(om.cpu().numpy(), rm, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(os_.cpu().numpy(), rs, rtol=1e-6)
+        sc = net.train_minibatch(obs_d, B, dev_tensor(actions, dev), dev_tensor(adv, dev), dev_tensor(vt, dev),
+                                 (om, os_)).cpu().numpy()
+        ref = o.train_minibatch(obs, actions, adv, vt, (rm, rs))
+        np.testing.assert_allclose(sc[:5], [ref["surrogate"], ref["entropy"], ref["kl"], ref["total"],
+                                            ref["value_loss"]], rtol=5e-4, atol=2e-6)
+        np.testing.assert_allclose(net.norm.item(), ref["norm"], rtol=1e-3)
+        np.testing.assert_allclose(net.params.w("main/ppo_head/policy_log_std").cpu().numpy(), o.log_std,
+                                   rtol=1e-4, atol=2e-6)
+        w, wo = net.params.named_arrays(), o.weights()
+        for name, towers in wo.items():
+            for t, arr in towers.items():
+                np.testing.assert_allclose(w[name][t], arr, rtol=1e-3, atol=2e-5, err_msg=name)

@@ -81,3 +81,49 @@ def test_ppo_advantages_match_oracle_on_c2_shape(rlx, dev):
     np.testing.assert_allclose(agent.ds_adv[:n].cpu().numpy(), adv, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(agent.ds_vtarget[:n].cpu().numpy(), vt, rtol=1e-5, atol=1e-6)
     assert set(np.unique(rew)) <= {-1.0, 0.0, 1.0}
+
+
+@pytest.mark.gpu
+def test_continuous_ppo_with_observation_normalization(dev):
+    """Mujoco_ClippedPPO-style agent: continuous head, AdditiveNoise sampling from the policy std,
+    ObservationNormalizationFilter as pre-network filter.  hipGraph replay must equal eager execution
+    bit for bit; the running statistics must have seen every transition of every rollout once."""
+    import random
+    import torch
+    from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
+    from coach_amd.core_types import EnvironmentSteps
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+
+    def run(use_graphs):
+        ep = SyntheticVectorEnvironmentParameters("vector", 8, (11,), None, action_dim=3, episode_length=8, seed=3)
+        env = SyntheticVectorEnvironment(ep, dev)
+        ap = ClippedPPOAgentParameters()
+        ap.seed = 6
+        ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(64)
+        ap.algorithm.optimization_epochs = 3
+        ap.algorithm.reward_clipping = None
+        ap.algorithm.normalize_observations = True
+        net = ap.network_wrappers["main"]
+        net.batch_size, net.embedder_scheme, net.middleware_scheme = 16, [64], [64]
+        agent = ClippedPPOAgent(ap, env, dev, use_graphs=use_graphs)
+        random.seed(1); np.random.seed(1)
+        out = []
+        for _ in range(3):
+            res = None
+            while res is None:
+                agent.act()
+                res = agent.train()
+            out.append(torch.stack(res).cpu().numpy())
+        agent.networks["main"].check_status()
+        return agent, np.array(out)
+
+    a, ra = run(True)
+    b, rb = run(False)
+    np.testing.assert_array_equal(ra, rb)
+    assert np.isfinite(ra).all()
+    assert torch.equal(a.networks["main"].params.weights, b.networks["main"].params.weights)
+    assert abs(float(a.norm.count.item()) - (3 * 64 + 1e-2)) < 1e-9
+    ls = a.networks["main"].params.w("main/ppo_head/policy_log_std").cpu().numpy()
+    assert np.abs(ls).max() > 0 and np.isfinite(ls).all()           # the log-std variable is being trained
+    assert a.actions.dtype == torch.float32 and float(a.actions.abs().max()) <= 1.0
