@@ -1,0 +1,123 @@
+"""Checkpoint / resume of a device agent — the naming of rl_coach/checkpoint.py and
+graph_manager.py:616-658 (`<id>_Step-<n>.ckpt`, latest name recorded in `.coach_checkpoint`), holding
+what a bit-exact resume of the hot path needs: every network's flat weight / target / Adam buffers,
+the replay contents and cursors, filter statistics, schedules, step counters and the host RNG states
+(`random`, legacy `np.random`) whose draws select replay indices and exploration actions.
+"""
+import os
+import pickle
+import random
+import re
+
+import numpy as np
+import torch
+
+STATE_FILE = ".coach_checkpoint"                          # checkpoint.py CheckpointStateFile
+_NAME = re.compile(r"^(\d+)_Step-(\d+)\.ckpt$")
+
+
+def _tensors_of(obj, names):
+    return {n: getattr(obj, n).detach().cpu() for n in names if isinstance(getattr(obj, n, None), torch.Tensor)}
+
+
+_MEMORY_TENSORS = ["ring", "fpos", "epoff", "t_fpos", "t_epoff", "cur_state", "obs", "next_obs", "action",
+                   "reward", "game_over", "sum_tree", "min_tree", "max_tree", "max_priority"]
+_MEMORY_SCALARS = ["cursor", "count", "steps", "_open", "_list_len", "next_leaf_idx_to_write"]
+_AGENT_SCALARS = ["total_steps_counter", "training_iteration", "last_training_phase_step",
+                  "last_target_network_update_step", "current_episode_steps_counter", "last_episode_steps",
+                  "_episode_just_ended"]
+
+
+def agent_state(agent):
+    st = {"networks": {}, "memory": {}, "agent": {}, "host_rng": (random.getstate(), np.random.get_state())}
+    for name, net in agent.networks.items():
+        st["networks"][name] = {
+            "weights": net.params.weights.cpu(), "target": None if net.target is None else net.target.cpu(),
+            "adam_m": net.adam.m.cpu(), "adam_v": net.adam.v.cpu(), "adam_state": net.adam.state.cpu()}
+    mem = agent.memory
+    st["memory"]["tensors"] = _tensors_of(mem, _MEMORY_TENSORS)
+    st["memory"]["scalars"] = {k: getattr(mem, k) for k in _MEMORY_SCALARS if hasattr(mem, k)}
+    st["agent"]["scalars"] = {k: getattr(agent, k) for k in _AGENT_SCALARS if hasattr(agent, k)}
+    # uniforms_all: the exploration draws of the running PPO phase (made at its first step)
+    st["agent"]["tensors"] = _tensors_of(agent, ["ep_return", "ep_len", "ep_acc", "uniforms_all"])
+    st["env"] = {"tensors": _tensors_of(agent.env, ["obs", "episode", "step_in_episode"]),
+                 "total_steps": agent.env.total_steps}
+    pol = getattr(agent, "exploration_policy", None)
+    if pol is not None:
+        st["exploration"] = pickle.dumps({k: v for k, v in pol.__dict__.items()
+                                          if isinstance(v, (int, float, np.ndarray)) or hasattr(v, "current_value")})
+    for k in ("beta",):
+        if hasattr(mem, k):
+            st["memory"][k] = pickle.dumps(getattr(mem, k))
+    if getattr(agent, "norm", None) is not None:
+        st["filter"] = _tensors_of(agent.norm, ["sum", "sum_squares", "count", "mean", "std"])
+    alg = agent.ap.algorithm
+    if hasattr(alg, "clipping_decay_schedule"):
+        st["clipping_decay_schedule"] = pickle.dumps(alg.clipping_decay_schedule)
+    return st
+
+
+def load_agent_state(agent, st):
+    for name, net in agent.networks.items():
+        s = st["networks"][name]
+        net.params.weights.copy_(s["weights"])
+        if net.target is not None:
+            net.target.copy_(s["target"])
+        net.adam.m.copy_(s["adam_m"]); net.adam.v.copy_(s["adam_v"]); net.adam.state.copy_(s["adam_state"])
+    mem = agent.memory
+    for k, t in st["memory"]["tensors"].items():
+        getattr(mem, k).copy_(t)
+    for k, v in st["memory"]["scalars"].items():
+        setattr(mem, k, v)
+    if "beta" in st["memory"]:
+        mem.beta = pickle.loads(st["memory"]["beta"])
+    for k, v in st["agent"]["scalars"].items():
+        setattr(agent, k, v)
+    for k, t in st["agent"]["tensors"].items():
+        getattr(agent, k).copy_(t)
+    for k, t in st["env"]["tensors"].items():
+        getattr(agent.env, k).copy_(t)
+    agent.env.total_steps = st["env"]["total_steps"]
+    if "exploration" in st and getattr(agent, "exploration_policy", None) is not None:
+        agent.exploration_policy.__dict__.update(pickle.loads(st["exploration"]))
+    if "filter" in st and getattr(agent, "norm", None) is not None:
+        for k, t in st["filter"].items():
+            getattr(agent.norm, k).copy_(t)
+    if "clipping_decay_schedule" in st:
+        agent.ap.algorithm.clipping_decay_schedule = pickle.loads(st["clipping_decay_schedule"])
+    random.setstate(st["host_rng"][0])
+    np.random.set_state(st["host_rng"][1])
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+
+
+def save_checkpoint(agent, checkpoint_dir, checkpoint_id=0):
+    """graph_manager.save_checkpoint (:616-637): `<id>_Step-<total_steps>.ckpt` + state file."""
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    name = "{}_Step-{}.ckpt".format(checkpoint_id, agent.total_steps_counter)
+    tmp = os.path.join(checkpoint_dir, name + ".tmp")
+    torch.save(agent_state(agent), tmp)
+    os.replace(tmp, os.path.join(checkpoint_dir, name))              # atomic publish
+    with open(os.path.join(checkpoint_dir, STATE_FILE), "w") as f:
+        f.write(name)
+    return name
+
+
+def latest_checkpoint(checkpoint_dir):
+    """checkpoint.py get_checkpoint_state: the state file if present, else the highest id on disk."""
+    sf = os.path.join(checkpoint_dir, STATE_FILE)
+    if os.path.exists(sf):
+        name = open(sf).read().strip()
+        if os.path.exists(os.path.join(checkpoint_dir, name)):
+            return name
+    found = sorted((int(m.group(1)), int(m.group(2)), f) for f in os.listdir(checkpoint_dir)
+                   for m in [_NAME.match(f)] if m)
+    return found[-1][2] if found else None
+
+
+def restore_checkpoint(agent, checkpoint_dir, name=None):
+    name = name or latest_checkpoint(checkpoint_dir)
+    if name is None:
+        raise ValueError("No checkpoint to restore in: {}".format(checkpoint_dir))   # graph_manager.py:577-579
+    st = torch.load(os.path.join(checkpoint_dir, name), map_location="cpu", weights_only=False)
+    load_agent_state(agent, st)
+    return name
