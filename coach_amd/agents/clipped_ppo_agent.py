@@ -324,10 +324,9 @@ class ClippedPPOAgent(object):
         mem, s = self.memory, _rlx.current_stream()
         rows_all = mem.dataset_rows()
         idx, rows = self.mb_idx[:m], self.mb_rows[:m]
-        # dataset index -> storage row, then one launch gathers the per-transition columns
-        self.lib.copy_columns(_rlx.make_columns([(rows_all, rows)]), 1, idx, None, 0, 0,
-                              rows_all.numel(), m, m, mem.status, s)
-        cols = [(self.ds_action, self.mb_action), (self.ds_adv, self.mb_adv), (self.ds_vtarget, self.mb_vtarget),
+        # one launch gathers the per-transition columns AND translates dataset index -> storage row
+        # (rows_all is one more 4-byte column over the same index)
+        cols = [(rows_all, rows), (self.ds_action, self.mb_action), (self.ds_adv, self.mb_adv), (self.ds_vtarget, self.mb_vtarget),
                 (self.ds_old_probs, self.mb_old)]
         if self.continuous:
             cols.append((self.ds_old_std, self.mb_old_std))
@@ -348,8 +347,7 @@ class ClippedPPOAgent(object):
 
     def _minibatch_finish(self, scale):
         net = self.networks["main"]
-        net.finish_update(scale)
-        self.scalar_acc[:6].add_(net.scalars[:6])
+        net.finish_update(scale, signal_acc=self.scalar_acc)
 
     def train_network(self, order, epochs):
         """clipped_ppo_agent.py:209-308.  `order`: dataset indices after the reference's

@@ -84,7 +84,8 @@ __global__ void adam_advance_kernel(float *state, float beta1, float beta2) {
 // advance the beta powers AND finish the gradient norm (one workgroup, fixed summation order)
 __global__ void adam_finish_norm_kernel(float *state, float beta1, float beta2,
                                         const float *__restrict__ part, int nparts,
-                                        float *__restrict__ norm_out) {
+                                        float *__restrict__ norm_out, const float *acc_src,
+                                        float *acc_dst, int n_acc) {
     __shared__ float red[kBlock];
     float s = 0.f;
     for (int i = threadIdx.x; i < nparts; i += kBlock) s += part[i];
@@ -98,6 +99,9 @@ __global__ void adam_finish_norm_kernel(float *state, float beta1, float beta2,
         norm_out[0] = sqrtf(red[0]);
         state[0] *= beta1;
         state[1] *= beta2;
+        // running sums of the per-update signals (loss terms + the norm just written) for the
+        // per-epoch means the agent logs: saves a separate elementwise launch per update
+        for (int i = 0; i < n_acc; ++i) acc_dst[i] += acc_src[i];
     }
 }
 
@@ -180,10 +184,12 @@ int rlx_adam_tf1(float *weights, const float *grads, float *m, float *v, long lo
 int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, long long n,
                       float learning_rate, float beta1, float beta2, float epsilon, float *state,
                       float grad_scale, float *norm_out, float *workspace, long long workspace_floats,
-                      void *stream) {
+                      const float *acc_src, float *acc_dst, int n_acc, void *stream) {
     RLX_REQUIRE(weights && grads && m && v && state && norm_out && workspace,
                 "rlx_adam_tf1_norm: null pointer");
     RLX_REQUIRE(n > 0, "rlx_adam_tf1_norm: empty parameter buffer");
+    RLX_REQUIRE(n_acc == 0 || (acc_src && acc_dst && n_acc > 0 && n_acc <= 64),
+                "rlx_adam_tf1_norm: bad signal accumulation arguments");
     RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                 "rlx_adam_tf1_norm: buffers must be 16-byte aligned");
     int blocks = rlx::grid_for(n / 4 + 1, kBlock, 1024);
@@ -193,7 +199,8 @@ int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, lo
     adam_tf1_kernel<true><<<blocks, kBlock, 0, s>>>(weights, grads, m, v, n, learning_rate, beta1, beta2,
                                                     epsilon, state, grad_scale, workspace);
     RLX_LAUNCH_CHECK();
-    adam_finish_norm_kernel<<<1, kBlock, 0, s>>>(state, beta1, beta2, workspace, blocks, norm_out);
+    adam_finish_norm_kernel<<<1, kBlock, 0, s>>>(state, beta1, beta2, workspace, blocks, norm_out, acc_src,
+                                                 acc_dst, n_acc);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -71,10 +71,10 @@ class _NetBase:
                              self.ctx.ws.small.numel(), self.ctx.stream)
         return self.norm
 
-    def apply_gradients(self, grad_scale=1.0, with_norm=False):
+    def apply_gradients(self, grad_scale=1.0, with_norm=False, acc=None):
         """Adam; with_norm also refreshes self.norm = tf.global_norm(grads) in the same pass."""
         if with_norm:
-            self.adam.step(grad_scale, norm_out=self.norm, workspace=self.ctx.ws.small)
+            self.adam.step(grad_scale, norm_out=self.norm, workspace=self.ctx.ws.small, acc=acc)
         else:
             self.adam.step(grad_scale)
 
@@ -206,9 +206,11 @@ class ClippedPPONet(_NetBase):
         if k > 0:
             self.torso.backward(self.ctx, acts, layers=(0, k))
 
-    def finish_update(self, grad_scale=1.0):
-        """apply_gradients (architecture.py:469-521): global norm fetch + Adam."""
-        self.apply_gradients(grad_scale, with_norm=True)
+    def finish_update(self, grad_scale=1.0, signal_acc=None):
+        """apply_gradients (architecture.py:469-521): global norm fetch + Adam (+ the running sums of
+        [surrogate, entropy, kl, policy total, value loss, grad norm] into signal_acc)."""
+        self.apply_gradients(grad_scale, with_norm=True,
+                             acc=(self.scalars, signal_acc, 6) if signal_acc is not None else None)
 
     def train_minibatch(self, obs, B, actions, advantages, value_targets, old_probs,
                         clip_rescaler=1.0, grad_scale=1.0, ratio_out=None, clipped_out=None):

@@ -267,11 +267,13 @@ int rlx_adam_tf1(float *weights, const float *grads, float *m, float *v, long lo
                  float grad_scale, void *stream);
 /* rlx_adam_tf1 that also returns tf.global_norm of the (unscaled) gradients it consumed: the
  * per-workgroup sums of squares ride on the Adam pass (no second read of the gradients) and the
- * one-thread finish kernel that advances the beta powers also takes the square root. */
+ * one-thread finish kernel that advances the beta powers also takes the square root and, when
+ * n_acc > 0, adds acc_src[0..n_acc) (loss terms / the norm just written) onto the running sums
+ * acc_dst (the per-epoch signal means of agents/agent.py:743-767, utils.py:162-212). */
 int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, long long n,
                       float learning_rate, float beta1, float beta2, float epsilon, float *state,
                       float grad_scale, float *norm_out, float *workspace, long long workspace_floats,
-                      void *stream);
+                      const float *acc_src, float *acc_dst, int n_acc, void *stream);
 int rlx_mix_weights(float *target, const float *online, long long n, double rate,
                     void *stream);   /* architectures/tensorflow_components/architecture.py:598-607 */
 int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,
