@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) dense_small_fwd_kernel(const SmallDense p
     float acc[NN];
 #pragma unroll
     for (int n = 0; n < NN; ++n) acc[n] = 0.f;
+#pragma unroll 4
     for (int k = lane; k < p.K; k += 64) {
         const float xv = x[k];
         const float *wr = w + (size_t)k * p.N;
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBw
     }
     float *dx = p.dx ? p.dx + (size_t)t * p.dx_ts : nullptr;
     if (live) {
+#pragma unroll 4
         for (int m = g; m < p.M; m += 4) {
             const float xv = x[(size_t)m * p.K + k];
             const float *dzr = dz + (size_t)m * p.N;

@@ -613,12 +613,15 @@ __global__ void splitk_reduce_kernel(const GemmDev g) {
     }
 }
 
-// Vectorised split-K reduction (N % 4 == 0, M*N < 2^31): a workgroup = 64 float4 output groups x 4
-// split groups; split group q sums partials q, q+4, q+8, ... in increasing order, the four group
-// sums are combined as ((s0 + s1) + s2) + s3 — a fixed order, so the result is reproducible.
+// Vectorised split-K reduction (N % 4 == 0, M*N < 2^31): a workgroup = 64 float4 output groups x SG
+// split groups; split group q sums partials q, q+SG, q+2SG, ... in increasing order, the group sums
+// are combined in the fixed order ((s0 + s1) + s2) + ... — the result is reproducible.  SG = 4 for
+// few splits, 16 for the long-K weight gradients (29-62 splits of a small M*N: without the wider
+// split parallelism 64 workgroups chased 16 dependent loads each, 18 us for 4 MB).
 // 32-bit index arithmetic (the generic kernel's 64-bit divisions cost more than its memory traffic).
-__global__ void __launch_bounds__(256) splitk_reduce4_kernel(const GemmDev g) {
-    __shared__ float4 part[4][64];
+template <int SG>
+__global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g) {
+    __shared__ float4 part[SG][64];
     const int mn4 = (g.M * g.N) >> 2;
     const int batch = blockIdx.y;
     const int ox = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -628,17 +631,17 @@ __global__ void __launch_bounds__(256) splitk_reduce4_kernel(const GemmDev g) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gid < mn4) {
         int k = q;
-        for (; k + 12 < g.splits; k += 16) {           // 4 independent loads in flight per thread
+        for (; k + 3 * SG < g.splits; k += 4 * SG) {    // 4 independent loads in flight per thread
             const float4 a = ws[(size_t)k * mn4 + gid];
-            const float4 b = ws[(size_t)(k + 4) * mn4 + gid];
-            const float4 c = ws[(size_t)(k + 8) * mn4 + gid];
-            const float4 d = ws[(size_t)(k + 12) * mn4 + gid];
+            const float4 b = ws[(size_t)(k + SG) * mn4 + gid];
+            const float4 c = ws[(size_t)(k + 2 * SG) * mn4 + gid];
+            const float4 d = ws[(size_t)(k + 3 * SG) * mn4 + gid];
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
             s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
             s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
             s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
         }
-        for (; k < g.splits; k += 4) {
+        for (; k < g.splits; k += SG) {
             const float4 a = ws[(size_t)k * mn4 + gid];
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
         }
@@ -646,9 +649,12 @@ __global__ void __launch_bounds__(256) splitk_reduce4_kernel(const GemmDev g) {
     part[q][ox] = s;
     __syncthreads();
     if (q == 0 && gid < mn4) {
-        const float4 p1 = part[1][ox], p2 = part[2][ox], p3 = part[3][ox];
-        float v[4] = {((s.x + p1.x) + p2.x) + p3.x, ((s.y + p1.y) + p2.y) + p3.y,
-                      ((s.z + p1.z) + p2.z) + p3.z, ((s.w + p1.w) + p2.w) + p3.w};
+        float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int t = 1; t < SG; ++t) {
+            const float4 p = part[t][ox];
+            v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+        }
         const int i = gid << 2;
         const int row = i / g.N, col = i - row * g.N;
         float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc + col;
@@ -668,10 +674,22 @@ __global__ void __launch_bounds__(256) splitk_reduce4_kernel(const GemmDev g) {
         }
     }
     if (g.colsum && blockIdx.x == 0) {
-        for (int n = threadIdx.x; n < g.N; n += 256) {
+        // bias-gradient partials [split][N]: same split-parallel scheme, 64 columns at a time
+        float *cpart = reinterpret_cast<float *>(&part[0][0]);      // [SG][64] floats
+        for (int n0 = 0; n0 < g.N; n0 += 64) {
+            __syncthreads();
+            const int n = n0 + ox;
             float t = 0.f;
-            for (int k = 0; k < g.splits; ++k) t += g.ws_colsum[((size_t)batch * g.splits + k) * g.N + n];
-            g.colsum[(size_t)batch * g.colsum_batch_stride + n] = t;
+            if (n < g.N)
+                for (int k = q; k < g.splits; k += SG)
+                    t += g.ws_colsum[((size_t)batch * g.splits + k) * g.N + n];
+            cpart[q * 64 + ox] = t;
+            __syncthreads();
+            if (q == 0 && n < g.N) {
+#pragma unroll
+                for (int u = 1; u < SG; ++u) t += cpart[u * 64 + ox];
+                g.colsum[(size_t)batch * g.colsum_batch_stride + n] = t;
+            }
         }
     }
 }
@@ -953,7 +971,10 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
         const long long mn = (long long)d.M * d.N;
         if (d.N % 4 == 0 && mn < (1LL << 31) && aligned16(g.ws)) {
             dim3 rgrid((unsigned)((mn / 4 + 63) / 64), d.batch);
-            splitk_reduce4_kernel<<<rgrid, 256, 0, s>>>(g);
+            if (splits > 16)
+                splitk_reduce4_kernel<16><<<rgrid, 1024, 0, s>>>(g);
+            else
+                splitk_reduce4_kernel<4><<<rgrid, 256, 0, s>>>(g);
         } else {
             dim3 rgrid(rlx::grid_for(mn, 256, 1024), d.batch);
             splitk_reduce_kernel<<<rgrid, 256, 0, s>>>(g);
