@@ -7,8 +7,9 @@
 // A head has K = 256..512 inputs and 1..17 outputs on a minibatch of 32..256 rows: 0.05-2 MFLOP.
 // As an MFMA GEMM that is one 32x32 tile with 26 of 32 columns wasted plus a split-K reduce launch;
 // here it is plain fp32 FMA work laid out for coalescing:
-//   forward : one wave per row m; lanes stride over k (x[m][k] coalesced, W[k][0..N) from L1/L2),
-//             N accumulators per lane, wave64 butterfly reduction.
+//   forward : one workgroup per row m, a quarter of K per wave; lanes stride over k (x[m][k]
+//             coalesced, W[k][0..N) from L1/L2), N accumulators per lane, wave64 butterfly reduction,
+//             the four wave partials combined through LDS.
 //   backward: ONE launch produces dW = x^T dz, db = 1^T dz and dx = dz W^T.  A workgroup owns 64
 //             input features k (64 lanes) x 4 row groups; dz (with this layer's activation
 //             derivative applied on the way in) sits in LDS, x[m][k] is read exactly once and used
@@ -40,18 +41,21 @@ struct SmallDense {
     int M, K, N, act;
 };
 
+// One workgroup per row m: its 4 waves each take a quarter of K (lanes stride over k), butterfly-reduce
+// their N accumulators and combine the four partials through LDS in a fixed order.
 template <int NN>
 __global__ void __launch_bounds__(256) dense_small_fwd_kernel(const SmallDense p) {
+    __shared__ float part[4][NN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = blockIdx.x * 4 + wave, t = blockIdx.y;
-    if (m >= p.M) return;
+    const int m = blockIdx.x, t = blockIdx.y;
     const float *x = p.x + (size_t)t * p.x_ts + (size_t)m * p.K;
     const float *w = p.w + (size_t)t * p.w_ts;
     float acc[NN];
 #pragma unroll
     for (int n = 0; n < NN; ++n) acc[n] = 0.f;
-#pragma unroll 4
-    for (int k = lane; k < p.K; k += 64) {
+    const int kq = (p.K + 3) / 4;
+    const int k1 = min(p.K, (wave + 1) * kq);
+    for (int k = wave * kq + lane; k < k1; k += 64) {
         const float xv = x[k];
         const float *wr = w + (size_t)k * p.N;
 #pragma unroll
@@ -63,15 +67,14 @@ __global__ void __launch_bounds__(256) dense_small_fwd_kernel(const SmallDense p
         float v = acc[n];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        acc[n] = v;
+        if (lane == 0) part[wave][n] = v;
     }
-    if (lane < p.N) {
-        float v = 0.f;
-#pragma unroll
-        for (int n = 0; n < NN; ++n)
-            if (n == lane) v = acc[n];
-        v += p.b ? p.b[(size_t)t * p.b_ts + lane] : 0.f;
-        p.y[(size_t)t * p.y_ts + (size_t)m * p.N + lane] = act_apply(v, p.act);
+    __syncthreads();
+    if (threadIdx.x < p.N) {
+        const int n = threadIdx.x;
+        float v = ((part[0][n] + part[1][n]) + part[2][n]) + part[3][n];
+        v += p.b ? p.b[(size_t)t * p.b_ts + n] : 0.f;
+        p.y[(size_t)t * p.y_ts + (size_t)m * p.N + n] = act_apply(v, p.act);
     }
 }
 
@@ -86,15 +89,18 @@ struct SmallDenseBwd {
     int M, K, N, act, lower_act;           // lower_act != 0: dx *= act'(x)  (x is the lower layer's output)
 };
 
-// block = 256 threads: lane = k within the 64-feature slab, g = row group (rows g, g+4, ...).
+// block = 256 threads: lane = k within the kKL-feature slab, g = row group (rows g, g+kRG, ...).
+// 32 features x 8 row groups: twice the workgroups and half the per-thread row loop of a 64 x 4
+// split (these launches are a handful of workgroups; latency, not bandwidth, sets their time).
+constexpr int kKL = 32, kRG = 8;
 template <int NN>
 __global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBwd p) {
     extern __shared__ float smem[];
     float *dz = smem;                              // [M][N]
-    float *part = smem + (size_t)p.M * p.N;        // [4][64][NN] dW partials
+    float *part = smem + (size_t)p.M * p.N;        // [kRG][kKL][NN] dW partials
     const int t = blockIdx.y;
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x % kKL, g = threadIdx.x / kKL;
+    const int k = blockIdx.x * kKL + lane;
     const float *dy = p.dy + (size_t)t * p.dy_ts;
     const float *yy = p.y ? p.y + (size_t)t * p.y_ts : nullptr;
     for (int i = threadIdx.x; i < p.M * p.N; i += 256)
@@ -110,8 +116,7 @@ __global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBw
     }
     float *dx = p.dx ? p.dx + (size_t)t * p.dx_ts : nullptr;
     if (live) {
-#pragma unroll 4
-        for (int m = g; m < p.M; m += 4) {
+        for (int m = g; m < p.M; m += kRG) {
             const float xv = x[(size_t)m * p.K + k];
             const float *dzr = dz + (size_t)m * p.N;
             float s = 0.f;
@@ -127,15 +132,18 @@ __global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBw
     }
     if (p.dw) {
 #pragma unroll
-        for (int n = 0; n < NN; ++n) part[((size_t)g * 64 + lane) * NN + n] = acc[n];
+        for (int n = 0; n < NN; ++n) part[((size_t)g * kKL + lane) * NN + n] = acc[n];
         __syncthreads();
         if (g == 0 && live) {
             float *dw = p.dw + (size_t)t * p.dw_ts + (size_t)k * p.N;
 #pragma unroll
             for (int n = 0; n < NN; ++n)
-                if (n < p.N)
-                    dw[n] = ((part[(0 * 64 + lane) * NN + n] + part[(1 * 64 + lane) * NN + n]) +
-                             part[(2 * 64 + lane) * NN + n]) + part[(3 * 64 + lane) * NN + n];
+                if (n < p.N) {
+                    float v = part[lane * NN + n];
+#pragma unroll
+                    for (int u = 1; u < kRG; ++u) v += part[(u * kKL + lane) * NN + n];   // fixed order
+                    dw[n] = v;
+                }
         }
     }
     if (p.db && blockIdx.x == 0 && threadIdx.x < p.N) {
@@ -159,7 +167,7 @@ int rlx_dense_small_forward(const float *x, long long x_tower_stride, const floa
     RLX_REQUIRE(activation >= 0 && activation <= 2, "rlx_dense_small_forward: unknown activation");
     SmallDense p{x, x_tower_stride, w, w_tower_stride, bias, bias_tower_stride, y, y_tower_stride,
                  M, K, N, activation};
-    dim3 grid((M + 3) / 4, towers);
+    dim3 grid(M, towers);
     hipStream_t s = rlx::as_stream(stream);
     if (N <= 1) dense_small_fwd_kernel<1><<<grid, 256, 0, s>>>(p);
     else if (N <= 4) dense_small_fwd_kernel<4><<<grid, 256, 0, s>>>(p);
@@ -183,12 +191,12 @@ int rlx_dense_small_backward(const float *x, long long x_tower_stride, const flo
                 "rlx_dense_small_backward: unknown activation");
     RLX_REQUIRE(activation == 0 || y, "rlx_dense_small_backward: the activation derivative needs y");
     const int NN = N <= 1 ? 1 : N <= 4 ? 4 : N <= 8 ? 8 : 16;
-    const size_t smem = ((size_t)M * N + 4 * 64 * NN) * sizeof(float);
+    const size_t smem = ((size_t)M * N + kRG * kKL * NN) * sizeof(float);
     RLX_REQUIRE(smem <= 64 * 1024, "rlx_dense_small_backward: batch %d x %d outputs exceeds the LDS budget", M, N);
     SmallDenseBwd p{x, x_tower_stride, w, w_tower_stride, dy, dy_tower_stride, y, y_tower_stride,
                     dw, dw_tower_stride, db, db_tower_stride, dx, dx_tower_stride,
                     M, K, N, activation, lower_activation};
-    dim3 grid((K + 63) / 64, towers);
+    dim3 grid((K + kKL - 1) / kKL, towers);
     hipStream_t s = rlx::as_stream(stream);
     if (NN == 1) dense_small_bwd_kernel<1><<<grid, 256, smem, s>>>(p);
     else if (NN == 4) dense_small_bwd_kernel<4><<<grid, 256, smem, s>>>(p);

@@ -238,7 +238,9 @@ class Dense(Layer):
         lower = x.act if need_dx else None           # fuse the lower layer's act' into dx
         if need_dx:
             assert x.towers == T, "input gradients need a per-tower input"
-        if self.N <= SMALL_N and not x.u8 and (M * self.N + 4096) * 4 <= 64 * 1024:
+        # one launch for dW + db + dx while the batch is small; beyond ~1k outputs its few workgroups
+        # lose to the GEMM path (M=256, N=16: 56 us measured vs ~30)
+        if self.N <= SMALL_N and not x.u8 and M * self.N <= 1024:
             dx = x.ensure_grad() if need_dx else None
             ctx.lib.dense_small_backward(
                 x.data, x.tower_stride(), p.w(self.kname, t0, weights), p.stride(self.kname),
