@@ -110,7 +110,7 @@ class DQNAgent(VectorOffPolicyAgent):
                              b.actions(), b.rewards(), b.game_overs(), self.ap.algorithm.discount,
                              importance_weights=weights, td_errors=self.td_errors,
                              double_dqn=self.double_dqn, grad_scale=self._grad_scale(),
-                             sync=self.dist)
+                             sync=self.dist, states_pair=b._info.get("states_pair"))
 
     def _grad_scale(self):
         netp = self.ap.network_wrappers["main"]

@@ -172,10 +172,12 @@ class ExperienceReplay(Memory):
         b = self._batches.get(size)
         if b is None:
             dev = self.device
+            # states and next_states of a batch are two halves of ONE buffer, so that the online
+            # network on s and the target network on s' can run as two towers of the same launches
+            both = torch.empty((2, size) + self.state_shape, dtype=self.state_dtype, device=dev)
             b = dict(
                 rows=torch.zeros(size, dtype=torch.int32, device=dev),
-                state=torch.empty((size,) + self.state_shape, dtype=self.state_dtype, device=dev),
-                next_state=torch.empty((size,) + self.state_shape, dtype=self.state_dtype, device=dev),
+                state=both[0], next_state=both[1], states_pair=both,
                 action=torch.empty((size,) if self.action_dim is None else (size, self.action_dim),
                                    dtype=self.action.dtype, device=dev),
                 reward=torch.empty(size, dtype=torch.float32, device=dev),
@@ -215,7 +217,8 @@ class ExperienceReplay(Memory):
         """The device half of sample(): gather the Batch of a draw."""
         b = self.gather(self.physical_rows(drawn), size)
         return DeviceBatch(size, {"observation": b["state"]}, {"observation": b["next_state"]},
-                           b["action"], b["reward"], b["game_over"], info={"logical_idx": drawn})
+                           b["action"], b["reward"], b["game_over"],
+                           info={"logical_idx": drawn, "states_pair": b["states_pair"]})
 
     def sample(self, size):
         """ExperienceReplay.sample (:71-90) -> DeviceBatch (the Batch the agent would build)."""
@@ -223,7 +226,7 @@ class ExperienceReplay(Memory):
 
     def get(self, index):
         b = self.gather(self.physical_rows([index]), 1)
-        return {k: v.clone() for k, v in b.items() if k != "rows"}
+        return {k: v.clone() for k, v in b.items() if k not in ("rows", "states_pair")}
 
     def check_status(self):
         s = int(self.status.item())

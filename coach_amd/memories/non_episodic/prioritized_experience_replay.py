@@ -135,7 +135,8 @@ class PrioritizedExperienceReplay(ExperienceReplay):
         p["weight32"].copy_(p["weight"])                   # importance weights feed an fp32 placeholder
         return DeviceBatch(size, {"observation": b["state"]}, {"observation": b["next_state"]},
                            b["action"], b["reward"], b["game_over"],
-                           info={"idx": p["idx"], "weight": p["weight"], "weight32": p["weight32"]})
+                           info={"idx": p["idx"], "weight": p["weight"], "weight32": p["weight32"],
+                                 "states_pair": b["states_pair"]})
 
     def sample(self, size):
         """PrioritizedExperienceReplay.sample (:219-262): stratified draws, one per segment."""

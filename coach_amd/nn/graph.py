@@ -53,7 +53,13 @@ class FlatParams:
         return per_tower
 
     def finalize(self, device):
-        self.weights = torch.zeros(self.size, dtype=torch.float32, device=device)
+        # online and target copies live in ONE allocation [2, size]: a "paired" forward pass runs the
+        # online network on s and the target network on s' as two towers of the same launches
+        # (weight tower stride = size), which is what NetworkWrapper.parallel_prediction
+        # (network_wrapper.py:188-213) asks the backend for
+        self.both = torch.zeros(2, self.size, dtype=torch.float32, device=device)
+        self.weights = self.both[0]
+        self.target_weights = self.both[1]
         self.grads = torch.zeros(self.size, dtype=torch.float32, device=device)
         return self
 
@@ -175,9 +181,13 @@ class Tensor:
     def tower(self, t):
         """One tower as a single-tower tensor; data and gradient alias this tensor's memory."""
         g = self.ensure_grad()
-        v = Tensor(self.data[t:t + 1], self.rows, self.cols, 1, act=self.act)
+        v = Tensor(self.data[t:t + 1], self.rows, self.cols, 1, u8=self.u8, div=self.div, act=self.act)
         v.grad = g[t:t + 1]
         return v
+
+    def tower_view(self, t):
+        """tower t without touching gradients (inputs)."""
+        return Tensor(self.data[t:t + 1], self.rows, self.cols, 1, u8=self.u8, div=self.div, act=self.act)
 
 
 def input_tensor(data, rows, cols, u8=False, div=1.0):
@@ -206,24 +216,29 @@ class Dense(Layer):
                 xavier_uniform(rng, self.K, self.N, (self.K, self.N))
             self.params.w(self.kname, t).copy_(torch.from_numpy(np.ascontiguousarray(w)))
 
-    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None):
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
+        """pair=True (single-tower layers): tower 0 = online weights, tower 1 = target weights."""
         t0, T = self._range(t0, nt)
+        p = self.params
+        wstride, bstride = p.stride(self.kname), p.stride(self.bname)
+        if pair:
+            assert self.T == 1 and weights is None
+            T, wstride, bstride = 2, p.size, p.size
         M = x.rows
         assert x.cols == self.K, (self.name, x.cols, self.K)
         assert x.towers in (0, T), (self.name, x.towers, T)
         y = ctx.buffer(self.name, (T, M, self.N), tag=tag)
-        p = self.params
         if self.N <= SMALL_N and not x.u8:
             # heads: coalesced FMA kernel, no MFMA tile / split-K round trip (csrc/dense_small.hip)
             ctx.lib.dense_small_forward(x.data, x.tower_stride(), p.w(self.kname, t0, weights),
-                                        p.stride(self.kname), p.w(self.bname, t0, weights),
-                                        p.stride(self.bname), y, M * self.N, T, M, self.K, self.N,
+                                        wstride, p.w(self.bname, t0, weights),
+                                        bstride, y, M * self.N, T, M, self.K, self.N,
                                         _rlx.ACT[self.act], ctx.stream)
         else:
             _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
                       bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
-                      a_batch_stride=x.tower_stride(), b_batch_stride=p.stride(self.kname),
-                      c_batch_stride=M * self.N, bias_batch_stride=p.stride(self.bname),
+                      a_batch_stride=x.tower_stride(), b_batch_stride=wstride,
+                      c_batch_stride=M * self.N, bias_batch_stride=bstride,
                       workspace=ctx.ws.splitk)
         return Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag), act=self.act)
 
@@ -310,9 +325,13 @@ class Conv2d(Layer):
             ctx.cache[key] = (rb, ko)
         return ctx.cache[key]
 
-    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None):
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
         t0, T = self._range(t0, nt)
         B, p = x.rows, self.params
+        wstride, bstride = p.stride(self.kname), p.stride(self.bname)
+        if pair:
+            assert self.T == 1 and weights is None
+            T, wstride, bstride = 2, p.size, p.size
         assert x.cols == self.H * self.W * self.C, (self.name, x.cols)
         assert x.towers in (0, T)
         M = B * self.OH * self.OW
@@ -321,8 +340,8 @@ class Conv2d(Layer):
         _rlx.gemm(M, self.Co, self.K, x.data, p.w(self.kname, t0, weights), y, a_tabs=(rb, ko),
                   a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=int(self.C % 4 == 0),
                   bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
-                  a_batch_stride=x.tower_stride(), b_batch_stride=p.stride(self.kname),
-                  c_batch_stride=M * self.Co, bias_batch_stride=p.stride(self.bname),
+                  a_batch_stride=x.tower_stride(), b_batch_stride=wstride,
+                  c_batch_stride=M * self.Co, bias_batch_stride=bstride,
                   workspace=ctx.ws.splitk)
         # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
         return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag), act=self.act)
@@ -372,10 +391,11 @@ class Sequential:
         for l in self.layers:
             l.initialize(rng)
 
-    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None):
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
         acts = [x]
+        kw = {"pair": True} if pair else {}
         for l in self.layers:
-            acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt))
+            acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, **kw))
         return acts
 
     def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None, need_dw=True,

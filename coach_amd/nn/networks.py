@@ -53,7 +53,11 @@ class _NetBase:
         self.ctx = G.Context(device)
         self.lib = self.ctx.lib
         self.adam = G.AdamState(self.params, lr, beta1, beta2, eps)
-        self.target = self.params.weights.clone() if has_target else None
+        if has_target:
+            self.target = self.params.target_weights
+            self.target.copy_(self.params.weights)
+        else:
+            self.target = None
         self.norm = torch.zeros(1, dtype=torch.float32, device=device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
 
@@ -244,13 +248,25 @@ class DQNNet(_NetBase):
 
     def learn_from_batch(self, obs, next_obs, B, actions, rewards, game_overs, discount,
                          importance_weights=None, td_errors=None, double_dqn=False, grad_scale=1.0,
-                         sync=None):
+                         sync=None, states_pair=None):
         """DQNAgent.learn_from_batch (agents/dqn_agent.py:81-113), all on device."""
         ctx = self.ctx
-        q_next = self.q_values(next_obs, B, use_target=True, tag="next_t").data.view(B, self.A)
         sel = self.q_values(next_obs, B, tag="next_o").data.view(B, self.A) if double_dqn else None
-        acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
-        q = self.q_head.forward(ctx, acts[-1], tag="train")
+        if states_pair is not None:
+            # parallel_prediction (dqn_agent.py:86-89): online(s) and target(s') as two towers of the
+            # same launches — the replay collates states / next_states into one [2, B, ...] buffer
+            cols = int(np.prod(self.obs_shape))
+            both = states_pair.view(2, B, cols)
+            x = G.Tensor(both, B, cols, 2, u8=self.image, div=255.0 if self.image else 1.0)
+            acts2 = self.torso.forward(ctx, x, tag="pair", pair=True)
+            q2 = self.q_head.forward(ctx, acts2[-1], tag="pair", pair=True)
+            q_next = q2.data[1].view(B, self.A)
+            acts = [x.tower_view(0)] + [a.tower(0) for a in acts2[1:]]
+            q = q2.tower(0)
+        else:
+            q_next = self.q_values(next_obs, B, use_target=True, tag="next_t").data.view(B, self.A)
+            acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
+            q = self.q_head.forward(ctx, acts[-1], tag="train")
         targets = ctx.buffer("td_targets", (B, self.A))
         targets.copy_(q.data.view(B, self.A))
         self.lib.dqn_targets(q_next, sel, targets, actions, rewards, game_overs, float(discount), B,
