@@ -211,6 +211,9 @@ class GemmDesc(ctypes.Structure):
         ("a_is_u8", ctypes.c_int), ("a_vec_along_k", ctypes.c_int), ("a_tab_vec_ok", ctypes.c_int),
         ("activation", ctypes.c_int), ("deriv_kind", ctypes.c_int), ("accumulate", ctypes.c_int),
         ("a_div", ctypes.c_float),
+        ("batch_inner", ctypes.c_int),
+        ("a_batch_stride2", ctypes.c_longlong), ("b_batch_stride2", ctypes.c_longlong),
+        ("bias_batch_stride2", ctypes.c_longlong),
     ]
 
 
@@ -226,7 +229,8 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
          a_vec_along_k=1, a_tab_vec_ok=0, b_strides=None, ldc=None, bias=None, activation=None,
          deriv_aux=None, aux_ld=None, deriv_kind=None, accumulate=False, batch=1,
          a_batch_stride=0, b_batch_stride=0, c_batch_stride=0, bias_batch_stride=0,
-         aux_batch_stride=0, workspace=None, colsum_out=None, colsum_batch_stride=0, stream=None):
+         aux_batch_stride=0, workspace=None, colsum_out=None, colsum_batch_stride=0, stream=None,
+         batch_inner=0, a_batch_stride2=0, b_batch_stride2=0, bias_batch_stride2=0):
     """Thin wrapper building an rlx_gemm_desc.  a_strides=(row, k), b_strides=(k, n) in elements."""
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = int(M), int(N), int(K), int(batch)
@@ -252,6 +256,9 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
     d.a_vec_along_k, d.a_tab_vec_ok = int(a_vec_along_k), int(a_tab_vec_ok)
     d.activation, d.deriv_kind = ACT[activation], ACT[deriv_kind]
     d.accumulate = int(bool(accumulate))
+    d.batch_inner = int(batch_inner)
+    d.a_batch_stride2, d.b_batch_stride2 = int(a_batch_stride2), int(b_batch_stride2)
+    d.bias_batch_stride2 = int(bias_batch_stride2)
     if GEMM_HOOK is not None:
         GEMM_HOOK(GemmDesc.from_buffer_copy(d))
     lib().gemm(ctypes.byref(d), current_stream() if stream is None else stream)

@@ -158,15 +158,15 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         # (3) d mean(Q_min) / d a at the sampled actions (:216-217)
         q.action_gradient(q_saved, B, self.dq_da)
         if resample:
-            # weighted_gradients[5] (mean log-prob, weight 1) on a fresh draw (:210-213)
-            _, sv1 = pol.forward(s, B, self.normals[1], tag="train1")
-            pol.backward(sv1, B, logprob_mean_weight=1.0)
-            self.grad_a.copy_(pol.params.grads)
-            # weighted_gradients[3] (actions, weights dq_da) on another fresh draw (:221-224)
-            _, sv2 = pol.forward(s, B, self.normals[2], tag="train2")
-            pol.backward(sv2, B, action_weights=self.dq_da, action_weight_scale=1.0)
-            # policy_grads = dlogp_dphi - dq_dphi (:227)
-            self.lib.axpby(pol.params.grads, 1.0, self.grad_a, -1.0, pol.params.grads, pol.params.size, s_)
+            # The three sess.run passes of the reference re-evaluate the SAME deterministic torso
+            # (same weights, same states) and only re-sample the head's noise, so their gradients
+            # w.r.t. the head output can be summed before ONE backward pass through the torso:
+            # weighted_gradients[5] (mean log-prob, weight 1) on draw 1 (:210-213) minus
+            # weighted_gradients[3] (actions, weights dq_da) on draw 2 (:221-227)
+            pol.head_gradient(p_saved, B, self.normals[1], logprob_mean_weight=1.0)
+            pol.head_gradient(p_saved, B, self.normals[2], action_weights=self.dq_da,
+                              action_weight_scale=-1.0, accumulate=True)
+            pol.backward_torso(p_saved)
         else:
             pol.backward(p_saved, B, logprob_mean_weight=1.0, action_weights=self.dq_da,
                          action_weight_scale=-1.0)
@@ -174,12 +174,19 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         pol.apply_gradients(self._scale("policy"))                               # :229
         # (4) V: targets = log_target - logp of the FIRST pass (:244), train_on_batch (:250)
         self.lib.sac_value_targets(self.log_target, o["logprob"], B, self.value_targets, s_)
-        _, v_saved = v.forward(s, B, tag="train")
+        obs2 = b._info.get("states_pair") if hasattr(b, "_info") else None
+        if obs2 is not None:
+            # V_online(s) of this training pass and V_target(s') of the Q targets share their launches
+            v2, v_saved = v.forward_pair(obs2, B)
+            v_next = v2[1]
+        else:
+            _, v_saved = v.forward(s, B, tag="train")
         v.train_backward(v_saved, self.value_targets, B)
         self._sync(v)
         v.apply_gradients(self._scale("v"))
         # (5) Q: y = r + (1 - done) gamma V_target(s') (:259-266), train_on_batch (:268)
-        v_next, _ = v.forward(ns, B, use_target=True, tag="next")
+        if obs2 is None:
+            v_next, _ = v.forward(ns, B, use_target=True, tag="next")
         self.lib.ac_td_targets(b.rewards(), b.game_overs(), v_next, 1, float(alg.discount), 0, 0, 0.0, 0.0,
                                B, self.td_targets, s_)
         _, q_saved = q.forward(s, b.actions(), B, tag="train")

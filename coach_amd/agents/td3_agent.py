@@ -90,6 +90,7 @@ class TD3Agent(DDPGAgent):
         self.smoothed = torch.zeros(B, self.A, dtype=torch.float32, device=dev)
         self.q_min = torch.zeros(B, dtype=torch.float32, device=dev)
         self.zero_go = torch.zeros(self.n_env, dtype=torch.uint8, device=dev)
+        self.act2 = torch.zeros(2, B, self.A, dtype=torch.float32, device=dev)   # (batch actions, smoothed a')
 
     def _stored_game_over(self, game_over):
         # the synthetic episodes end on their time limit -> game_over False (:215-227)
@@ -98,7 +99,28 @@ class TD3Agent(DDPGAgent):
     def _training_steps_this_phase(self):
         return self.last_episode_steps                                        # :211-213
 
+    def _critic_device_paired(self, b, obs2):
+        """The same update with every online / target pass pair sharing its launches: actor online(s)
+        + target(s'), then critic online(s, a) + target(s', a') (the online critic pass does not
+        depend on the TD targets, only its loss does)."""
+        actor, critic = self.networks["actor"], self.networks["critic"]
+        alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
+        a2, self._a_saved = actor.forward_pair(obs2, B)
+        self._actions_mean = a2[0]
+        self.act2[0].copy_(b.actions())
+        self.lib.td3_smooth_actions(a2[1], self.noise, float(alg.noise_clipping), self.d_low, self.d_high,
+                                    B, self.A, self.act2[1], s_)                    # :162-165
+        q2, c_saved = critic.forward_pair(obs2, self.act2, B)
+        self.lib.min_pair(q2[1][0], q2[1][1], self.q_min, None, None, 0.0, B, s_)      # output #2 (:168)
+        self._td_targets(b, self.q_min)
+        critic.train_backward(c_saved, self.td_targets, B)
+        self._sync(critic)
+        critic.apply_gradients(self._scale("critic"), with_norm=True)
+
     def _critic_device(self, b):
+        obs2 = b._info.get("states_pair") if hasattr(b, "_info") else None
+        if obs2 is not None and self.networks["critic"].T == 2:
+            return self._critic_device_paired(b, obs2)
         actor, critic = self.networks["actor"], self.networks["critic"]
         alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
         s, ns = b._states["observation"], b._next_states["observation"]

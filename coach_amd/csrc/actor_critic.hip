@@ -115,7 +115,7 @@ __global__ void sac_policy_head_backward_kernel(const float *__restrict__ mu_log
                                                 float logp_weight,
                                                 const float *__restrict__ act_weight,
                                                 float act_weight_scale, float *__restrict__ d_out,
-                                                long long ld_out) {
+                                                long long ld_out, int accumulate) {
     const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
     if (t_ >= batch * A) return;
     const int b = t_ / A, a = t_ - b * A;
@@ -138,8 +138,9 @@ __global__ void sac_policy_head_backward_kernel(const float *__restrict__ mu_log
     float d_mu = g_raw;
     float d_ls = g_raw * sd * e + w_lp * (-1.f);
     if (!inside) d_ls = 0.f;
-    d_out[(size_t)b * ld_out + a] = d_mu;
-    d_out[(size_t)b * ld_out + A + a] = d_ls;
+    float *o = d_out + (size_t)b * ld_out;
+    o[a] = accumulate ? o[a] + d_mu : d_mu;
+    o[A + a] = accumulate ? o[A + a] + d_ls : d_ls;
 }
 
 }  // namespace
@@ -207,14 +208,14 @@ int rlx_sac_policy_head(const float *mu_logsig, long long ld, const double *stan
 int rlx_sac_policy_head_backward(const float *mu_logsig, long long ld, const double *standard_normals,
                                  int batch, int action_dim, float logprob_mean_weight,
                                  const float *action_weights, float action_weight_scale,
-                                 float *d_mu_logsig, long long ld_grad, void *stream) {
+                                 float *d_mu_logsig, long long ld_grad, int accumulate, void *stream) {
     RLX_REQUIRE(mu_logsig && standard_normals && d_mu_logsig, "rlx_sac_policy_head_backward: null pointer");
     RLX_REQUIRE(batch > 0 && action_dim > 0 && ld >= 2 * action_dim && ld_grad >= 2 * action_dim,
                 "rlx_sac_policy_head_backward: bad shape");
     const int n = batch * action_dim;
     sac_policy_head_backward_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
         mu_logsig, ld, standard_normals, batch, action_dim, logprob_mean_weight, action_weights,
-        action_weight_scale, d_mu_logsig, ld_grad);
+        action_weight_scale, d_mu_logsig, ld_grad, accumulate);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -38,7 +38,7 @@ struct OperandDev {
     const void *base;
     const int *tab_o;   // outer-index offset table (elements) or null
     const int *tab_r;   // reduction-index offset table or null
-    long long stride_o, stride_r, batch_stride;
+    long long stride_o, stride_r, batch_stride, batch_stride2;
     int vec_ok;         // 16-byte (4-byte for u8) vector loads are legal for this launch
 };
 
@@ -47,7 +47,8 @@ struct GemmDev {
     float *c;
     long long ldc, c_batch_stride;
     const float *bias;
-    long long bias_batch_stride;
+    long long bias_batch_stride, bias_batch_stride2;
+    int inner;                  // batch index b = bo * inner + bi: operand offset = bo * stride2 + bi * stride
     const float *aux;           // epilogue multiplies by act'(aux[m][n])
     long long aux_ld, aux_batch_stride;
     float *ws;                  // split-K partials [batch][split][M][N]
@@ -60,6 +61,12 @@ struct GemmDev {
     int vec_epi;                // fast kernel: 16-byte epilogue accesses are legal for this launch
     float a_div;
 };
+
+// two-level batch offset (paired online/target passes over multi-stream layers): b = bo * inner + bi
+__device__ __forceinline__ long long batch_off(int batch, int inner, long long stride, long long stride2) {
+    const int bo = batch / inner;
+    return (long long)bo * stride2 + (long long)(batch - bo * inner) * stride;
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == RLX_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -130,9 +137,9 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(const GemmDev g) {
     const int kend = min(g.K, kbeg + g.kchunk);
 
     const unsigned char *abase = static_cast<const unsigned char *>(g.a.base) +
-                                 (size_t)batch * g.a.batch_stride * (A_U8 ? 1 : 4);
+                                 batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2) * (A_U8 ? 1 : 4);
     const unsigned char *bbase = static_cast<const unsigned char *>(g.b.base) +
-                                 (size_t)batch * g.b.batch_stride * 4;
+                                 batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2) * 4;
 
     float4 ra[NA], rb[NB];
     auto load_tiles = [&](int k0) {
@@ -249,7 +256,7 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(const GemmDev g) {
         return;
     }
     float *c = g.c + (size_t)batch * g.c_batch_stride;
-    const float bias = g.bias ? g.bias[(size_t)batch * g.bias_batch_stride + col] : 0.f;
+    const float bias = g.bias ? g.bias[batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col] : 0.f;
     const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -330,8 +337,8 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
     }
 
     const unsigned char *abase = static_cast<const unsigned char *>(g.a.base) +
-                                 (size_t)batch * g.a.batch_stride * (A_U8 ? 1 : 4);
-    const float *bbase = static_cast<const float *>(g.b.base) + (size_t)batch * g.b.batch_stride;
+                                 batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2) * (A_U8 ? 1 : 4);
+    const float *bbase = static_cast<const float *>(g.b.base) + batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2);
 
     // ---- loop-invariant parts of the operand addresses
     // A, vector along the reduction index: thread owns k-group kq of rows (row_p); else vector along
@@ -542,7 +549,7 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
                     if (!ws) {
                         if (g.bias) {
                             const float4 bv = *reinterpret_cast<const float4 *>(
-                                g.bias + (size_t)batch * g.bias_batch_stride + col);
+                                g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col);
                             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                         }
                         v.x = apply_act(v.x, g.act); v.y = apply_act(v.y, g.act);
@@ -567,7 +574,7 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (32 * TN) + 32 * j + l31;
         if (col >= g.N) continue;
-        const float bias = (!ws && g.bias) ? g.bias[(size_t)batch * g.bias_batch_stride + col] : 0.f;
+        const float bias = (!ws && g.bias) ? g.bias[batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -592,7 +599,7 @@ __global__ void splitk_reduce_kernel(const GemmDev g) {
     const int batch = blockIdx.y;
     const float *ws = g.ws + (size_t)batch * g.splits * mn;
     float *c = g.c + (size_t)batch * g.c_batch_stride;
-    const float *bias = g.bias ? g.bias + (size_t)batch * g.bias_batch_stride : nullptr;
+    const float *bias = g.bias ? g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) : nullptr;
     const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < mn;
          i += (long long)gridDim.x * blockDim.x) {
@@ -658,7 +665,7 @@ __global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g
         const int i = gid << 2;
         const int row = i / g.N, col = i - row * g.N;
         float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc + col;
-        const float *bias = g.bias ? g.bias + (size_t)batch * g.bias_batch_stride + col : nullptr;
+        const float *bias = g.bias ? g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col : nullptr;
         const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld + col
                                  : nullptr;
 #pragma unroll
@@ -885,6 +892,11 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     g.b.stride_o = d.b_n_stride; g.b.stride_r = d.b_k_stride; g.b.batch_stride = d.b_batch_stride;
     g.c = d.C; g.ldc = d.ldc; g.c_batch_stride = d.c_batch_stride;
     g.bias = d.bias; g.bias_batch_stride = d.bias_batch_stride;
+    g.inner = d.batch_inner > 0 ? d.batch_inner : (1 << 30);
+    g.a.batch_stride2 = d.a_batch_stride2; g.b.batch_stride2 = d.b_batch_stride2;
+    g.bias_batch_stride2 = d.bias_batch_stride2;
+    RLX_REQUIRE(d.batch_inner <= 0 || d.batch % d.batch_inner == 0,
+                "rlx_gemm: batch %d is not a multiple of batch_inner %d", d.batch, d.batch_inner);
     g.aux = d.deriv_aux; g.aux_ld = d.aux_ld; g.aux_batch_stride = d.aux_batch_stride;
     g.act = d.activation; g.deriv = d.deriv_kind; g.accumulate = d.accumulate;
     g.a_div = d.a_is_u8 ? d.a_div : 1.f;
@@ -899,11 +911,12 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     } else {
         const long long other = a_vec_red ? d.a_row_stride : d.a_k_stride;
         g.a.vec_ok = (((uintptr_t)d.A) % (4 * a_elem) == 0) && (other % 4 == 0) &&
-                     ((d.a_batch_stride % 4) == 0);
+                     ((d.a_batch_stride % 4) == 0) && ((d.a_batch_stride2 % 4) == 0);
     }
     {
         const long long other = b_vec_red ? d.b_n_stride : d.b_k_stride;
-        g.b.vec_ok = aligned16(d.B) && (other % 4 == 0) && ((d.b_batch_stride % 4) == 0);
+        g.b.vec_ok = aligned16(d.B) && (other % 4 == 0) && ((d.b_batch_stride % 4) == 0) &&
+                     ((d.b_batch_stride2 % 4) == 0);
     }
 
     // fast path: every 4-element vector group of both operands is full, in range and aligned
@@ -947,7 +960,7 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     g.vec_epi = d.N % 4 == 0 &&
                 (splits > 1 ? aligned16(d.workspace) && ((long long)d.M * d.N) % 4 == 0
                             : (aligned16(d.C) && d.ldc % 4 == 0 && d.c_batch_stride % 4 == 0 &&
-                               (!d.bias || (aligned16(d.bias) && d.bias_batch_stride % 4 == 0)) &&
+                               (!d.bias || (aligned16(d.bias) && d.bias_batch_stride % 4 == 0 && d.bias_batch_stride2 % 4 == 0)) &&
                                (!d.deriv_aux || (aligned16(d.deriv_aux) && d.aux_ld % 4 == 0 &&
                                                  d.aux_batch_stride % 4 == 0))));
     hipStream_t s = rlx::as_stream(stream);

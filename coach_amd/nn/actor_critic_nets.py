@@ -67,6 +67,22 @@ class ActorNet(_ACBase):
         self.lib.copy_2d(y.data, self.A, out, self.A, B, self.A, self._uniform_scale, ctx.stream)
         return out, (acts, acts2, y)
 
+    def forward_pair(self, obs2, B, tag="pair"):
+        """actor.parallel_prediction([(target, next_states), (online, states)]) (ddpg_agent.py:146-149,
+        td3_agent.py:157-160) as ONE pass: obs2 [2, B, D] = (states, next_states); returns actions
+        [2, B, A] (row 0: online mu(s), row 1: target mu(s')) and the online activations for backward."""
+        ctx = self.ctx
+        x = G.Tensor(obs2.view(2, B, self.obs_dim), B, self.obs_dim, 2)
+        acts = self.emb.forward(ctx, x, tag=tag, pair=True)
+        acts2 = self.mid.forward(ctx, acts[-1], tag=tag, pair=True)
+        y = self.head.forward(ctx, acts2[-1], tag=tag, pair=True)
+        out = ctx.buffer("actions2", (2, B, self.A), tag=tag)
+        self.lib.copy_2d(y.data, self.A, out, self.A, 2 * B, self.A, self._uniform_scale, ctx.stream)
+        on = lambda ts: [ts[0].slice_towers(0, 1, with_grad=False)] + [t.slice_towers(0, 1) for t in ts[1:]]
+        acts_o = on(acts)
+        acts2_o = [acts_o[-1]] + [t.slice_towers(0, 1) for t in acts2[1:]]
+        return out, (acts_o, acts2_o, y.slice_towers(0, 1))
+
     def backward(self, saved, action_grad, B, grad_scale=1.0):
         """weighted_gradients[0] with gradients_weights_ph = action_grad (ddpg_agent.py:183-186):
         d sum(action * action_grad) / d theta -> params.grads."""
@@ -116,6 +132,28 @@ class CriticNet(_ACBase):
         macts = self.mid.forward(ctx, x, tag=tag, weights=w)
         q = self.head.forward(ctx, macts[-1], tag=tag, weights=w)
         return q.data.view(self.T, B), (eacts, macts, q, merged)
+
+    def forward_pair(self, obs2, actions2, B, tag="pair"):
+        """Online critic on (s, a) and target critic on (s', a') in one pass: obs2 [2, B, D],
+        actions2 [2, B, A].  Returns q [2, streams, B] (row 0 online, row 1 target) and the ONLINE
+        activations for train_backward."""
+        ctx, T = self.ctx, self.T
+        x = G.Tensor(obs2.view(2, B, self.obs_dim), B, self.obs_dim, 2)
+        eacts = self.emb.forward(ctx, x, tag=tag, pair=True)
+        merged = ctx.buffer("critic/merged2", (2, B, self.merged), tag=tag)
+        m2 = merged.view(2 * B, self.merged)
+        self.lib.copy_2d(actions2, self.A, m2, self.merged, 2 * B, self.A, 1.0, ctx.stream)
+        self.lib.copy_2d(eacts[-1].data, self.efeat, m2.data_ptr() + 4 * self.A, self.merged, 2 * B,
+                         self.efeat, 1.0, ctx.stream)
+        xm = G.Tensor(merged, B, self.merged, 2, grad_key=(ctx, "critic/merged2", tag))
+        macts = self.mid.forward(ctx, xm, tag=tag, pair=True)
+        q = self.head.forward(ctx, macts[-1], tag=tag, pair=True)
+        # online halves: merged tower 0 (one tower per copy), activations towers [0, T)
+        m_on = xm.slice_towers(0, 1)
+        m_on.towers = 0 if T > 1 else 1                       # shared by the T streams, as in forward()
+        macts_o = [m_on] + [t.slice_towers(0, T) for t in macts[1:]]
+        eacts_o = [eacts[0].slice_towers(0, 1, with_grad=False)] + [t.slice_towers(0, 1) for t in eacts[1:]]
+        return q.data.view(2, T, B), (eacts_o, macts_o, q.slice_towers(0, T), merged[0:1])
 
     def train_backward(self, saved, targets, B):
         """accumulate_gradients for the critic loss sum_i mean((target - Q_i)^2)."""
@@ -174,13 +212,36 @@ class SACPolicyNet(_ACBase):
                                  o["raw_actions"], o["actions"], o["logprob"], ctx.stream)
         return o, (acts, acts2, y, normals)
 
+    def resample(self, saved, B, normals, tag):
+        """Outputs of another sess.run of the head on the SAME torso output with fresh noise."""
+        y, ctx = saved[2], self.ctx
+        o = {k: ctx.buffer("sac/" + k, (B, self.A) if k != "logprob" else (B,), tag=tag)
+             for k in ("mean", "log_std", "raw_actions", "actions", "logprob")}
+        self.lib.sac_policy_head(y.data, 2 * self.A, normals, B, self.A, o["mean"], o["log_std"],
+                                 o["raw_actions"], o["actions"], o["logprob"], ctx.stream)
+        return o
+
+    def head_gradient(self, saved, B, normals=None, logprob_mean_weight=0.0, action_weights=None,
+                      action_weight_scale=1.0, accumulate=False):
+        """d(...)/d mu_logsig of one pass (its own noise draw) into the head's gradient buffer."""
+        y = saved[2]
+        dy = y.ensure_grad()
+        self.lib.sac_policy_head_backward(y.data, 2 * self.A, normals if normals is not None else saved[3],
+                                          B, self.A, float(logprob_mean_weight), action_weights,
+                                          float(action_weight_scale), dy, 2 * self.A, int(accumulate),
+                                          self.ctx.stream)
+
+    def backward_torso(self, saved):
+        acts, acts2, y, _ = saved
+        ctx = self.ctx
+        self.head.backward(ctx, acts2[-1], y)
+        self.mid.backward(ctx, acts2, need_input_grad=len(self.emb.layers) > 0)
+        self.emb.backward(ctx, acts)
+
     def backward(self, saved, B, logprob_mean_weight=0.0, action_weights=None, action_weight_scale=1.0):
         acts, acts2, y, normals = saved
         ctx = self.ctx
-        dy = y.ensure_grad()
-        self.lib.sac_policy_head_backward(y.data, 2 * self.A, normals, B, self.A, float(logprob_mean_weight),
-                                          action_weights, float(action_weight_scale), dy, 2 * self.A,
-                                          ctx.stream)
+        self.head_gradient(saved, B, None, logprob_mean_weight, action_weights, action_weight_scale)
         self.head.backward(ctx, acts2[-1], y)
         self.mid.backward(ctx, acts2, need_input_grad=len(self.emb.layers) > 0)
         self.emb.backward(ctx, acts)
@@ -205,6 +266,17 @@ class SACValueNet(_ACBase):
         acts2 = self.mid.forward(ctx, acts[-1], tag=tag, weights=w)
         v = self.head.forward(ctx, acts2[-1], tag=tag, weights=w)
         return v.data.view(B), (acts, acts2, v)
+
+    def forward_pair(self, obs2, B, tag="pair"):
+        """V_online(s) (for the training pass) and V_target(s') (for the Q targets) in one pass."""
+        ctx = self.ctx
+        x = G.Tensor(obs2.view(2, B, self.obs_dim), B, self.obs_dim, 2)
+        acts = self.emb.forward(ctx, x, tag=tag, pair=True)
+        acts2 = self.mid.forward(ctx, acts[-1], tag=tag, pair=True)
+        v = self.head.forward(ctx, acts2[-1], tag=tag, pair=True)
+        acts_o = [acts[0].slice_towers(0, 1, with_grad=False)] + [t.slice_towers(0, 1) for t in acts[1:]]
+        acts2_o = [acts_o[-1]] + [t.slice_towers(0, 1) for t in acts2[1:]]
+        return v.data.view(2, B), (acts_o, acts2_o, v.slice_towers(0, 1))
 
     def train_backward(self, saved, targets, B):
         acts, acts2, v = saved

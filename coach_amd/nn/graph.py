@@ -185,6 +185,13 @@ class Tensor:
         v.grad = g[t:t + 1]
         return v
 
+    def slice_towers(self, t0, n, with_grad=True):
+        """towers [t0, t0 + n) as a tensor of n towers aliasing this one (data and gradient)."""
+        v = Tensor(self.data[t0:t0 + n], self.rows, self.cols, n, u8=self.u8, div=self.div, act=self.act)
+        if with_grad:
+            v.grad = self.ensure_grad()[t0:t0 + n]
+        return v
+
     def tower_view(self, t):
         """tower t without touching gradients (inputs)."""
         return Tensor(self.data[t:t + 1], self.rows, self.cols, 1, u8=self.u8, div=self.div, act=self.act)
@@ -217,29 +224,45 @@ class Dense(Layer):
             self.params.w(self.kname, t).copy_(torch.from_numpy(np.ascontiguousarray(w)))
 
     def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
-        """pair=True (single-tower layers): tower 0 = online weights, tower 1 = target weights."""
+        """pair=True: the online and the target copy of the layer in one launch — towers [0, T) use
+        the online weights, [T, 2T) the target weights (FlatParams.both); x carries either one tower
+        per copy (shared by the T streams of a copy) or one per (copy, stream)."""
         t0, T = self._range(t0, nt)
         p = self.params
-        wstride, bstride = p.stride(self.kname), p.stride(self.bname)
-        if pair:
-            assert self.T == 1 and weights is None
-            T, wstride, bstride = 2, p.size, p.size
         M = x.rows
         assert x.cols == self.K, (self.name, x.cols, self.K)
-        assert x.towers in (0, T), (self.name, x.towers, T)
-        y = ctx.buffer(self.name, (T, M, self.N), tag=tag)
+        wstride, bstride = p.stride(self.kname), p.stride(self.bname)
+        kw = {}
+        if pair:
+            assert weights is None and t0 == 0 and T == self.T
+            if x.towers == 2 * T:
+                a_stride, a_stride2 = M * self.K, T * M * self.K
+            else:
+                assert x.towers == 2, (self.name, x.towers)
+                a_stride, a_stride2 = 0, M * self.K
+            kw = dict(batch_inner=T, a_batch_stride2=a_stride2, b_batch_stride2=p.size, bias_batch_stride2=p.size)
+            TT = 2 * T
+        else:
+            assert x.towers in (0, T), (self.name, x.towers, T)
+            a_stride, TT = x.tower_stride(), T
+        y = ctx.buffer(self.name, (TT, M, self.N), tag=tag)
         if self.N <= SMALL_N and not x.u8:
             # heads: coalesced FMA kernel, no MFMA tile / split-K round trip (csrc/dense_small.hip)
-            ctx.lib.dense_small_forward(x.data, x.tower_stride(), p.w(self.kname, t0, weights),
-                                        wstride, p.w(self.bname, t0, weights),
-                                        bstride, y, M * self.N, T, M, self.K, self.N,
-                                        _rlx.ACT[self.act], ctx.stream)
+            for c in range(2 if pair else 1):                 # copy c: online / target weights
+                woff = c * p.size * 4
+                xoff = c * (a_stride2 if pair else 0) * 4
+                ctx.lib.dense_small_forward(x.data.data_ptr() + xoff, a_stride,
+                                            p.w(self.kname, t0, weights).data_ptr() + woff, wstride,
+                                            p.w(self.bname, t0, weights).data_ptr() + woff, bstride,
+                                            y.data_ptr() + c * T * M * self.N * 4, M * self.N, T, M, self.K,
+                                            self.N, _rlx.ACT[self.act], ctx.stream)
         else:
             _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
-                      bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
-                      a_batch_stride=x.tower_stride(), b_batch_stride=wstride,
+                      bias=p.w(self.bname, t0, weights), activation=self.act, batch=TT,
+                      a_batch_stride=a_stride, b_batch_stride=wstride,
                       c_batch_stride=M * self.N, bias_batch_stride=bstride,
-                      workspace=ctx.ws.splitk)
+                      workspace=ctx.ws.splitk, **kw)
+        T = TT
         return Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag), act=self.act)
 
     def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):

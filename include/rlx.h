@@ -198,6 +198,11 @@ typedef struct rlx_gemm_desc {
     int a_tab_vec_ok;         /* with tables: groups of 4 are contiguous AND 16-byte (4-byte for u8) aligned */
     int activation, deriv_kind, accumulate;
     float a_div;
+    /* two-level batch addressing of A, B and bias (0 = off): batch index b = bo * batch_inner + bi,
+     * operand offset = bo * *_batch_stride2 + bi * *_batch_stride.  Lets the online and the target
+     * copy of a multi-stream layer run as one launch (network_wrapper.py:188-213 parallel_prediction). */
+    int batch_inner;
+    long long a_batch_stride2, b_batch_stride2, bias_batch_stride2;
 } rlx_gemm_desc;
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
@@ -300,11 +305,13 @@ int rlx_sac_policy_head(const float *mu_logsig, long long ld, const double *stan
                         int action_dim, float *out_mean, float *out_log_std, float *out_raw_actions,
                         float *out_actions, float *out_logprob, void *stream);
 /* d/d mu_logsig of  logprob_mean_weight * mean_b(logprob_b) + action_weight_scale *
- * sum(action_weights * actions)  (weighted_gradients[5] / [3], soft_actor_critic_agent.py:210-229). */
+ * sum(action_weights * actions)  (weighted_gradients[5] / [3], soft_actor_critic_agent.py:210-229);
+ * accumulate != 0 adds onto d_mu_logsig (the passes of one update share the deterministic torso
+ * output, so their head gradients can be summed before ONE backward pass through the torso). */
 int rlx_sac_policy_head_backward(const float *mu_logsig, long long ld, const double *standard_normals,
                                  int batch, int action_dim, float logprob_mean_weight,
                                  const float *action_weights, float action_weight_scale,
-                                 float *d_mu_logsig, long long ld_grad, void *stream);
+                                 float *d_mu_logsig, long long ld_grad, int accumulate, void *stream);
 
 /* -------------------------------------------------------- exploration policies -- */
 int rlx_categorical_sample(const float *probs, long long ld, const double *uniforms, int n_env,

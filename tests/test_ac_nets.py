@@ -131,11 +131,17 @@ def _check_weights(net, onet, atol=2e-5):
 
 class _B:
     """minimal DeviceBatch stand-in"""
-    def __init__(self, dev, batch):
+    def __init__(self, dev, batch, paired=False):
         import torch
         s, a, r, done, ns = batch
-        self._states = {"observation": _t(s, dev)}
-        self._next_states = {"observation": _t(ns, dev)}
+        self._info = {}
+        if paired:
+            both = _t(np.stack([s, ns]), dev)
+            self._info["states_pair"] = both
+            self._states, self._next_states = {"observation": both[0]}, {"observation": both[1]}
+        else:
+            self._states = {"observation": _t(s, dev)}
+            self._next_states = {"observation": _t(ns, dev)}
         self._a, self._r, self._d = _t(a, dev), _t(r, dev), _t(done.astype(np.uint8), dev)
 
     def actions(self): return self._a
@@ -179,7 +185,8 @@ def test_ddpg_update_matches_oracle(dev):
 
 
 @pytest.mark.gpu
-def test_td3_update_matches_oracle(dev):
+@pytest.mark.parametrize("paired", [False, True])
+def test_td3_update_matches_oracle(dev, paired):
     import torch
     from coach_amd.agents.td3_agent import TD3Agent, TD3AgentParameters
     D, A, B = 17, 6, 100
@@ -192,7 +199,7 @@ def test_td3_update_matches_oracle(dev):
         batch = _batch(rng, B, D, A)
         noise = rng.normal(0, 0.2, (B, A))
         r = O.td3_update(oa, oc, batch, noise, it, ag.low, ag.high)
-        db = _B(dev, batch)
+        db = _B(dev, batch, paired)
         ag.noise.copy_(_t(noise, dev))
         ag._critic_device(db)
         if it % 2 == 0:
@@ -206,8 +213,8 @@ def test_td3_update_matches_oracle(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("resample", [True, False])
-def test_sac_update_matches_oracle(dev, resample):
+@pytest.mark.parametrize("resample,paired", [(True, False), (False, False), (True, True)])
+def test_sac_update_matches_oracle(dev, resample, paired):
     from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgent, SoftActorCriticAgentParameters
     D, A, B = 23, 5, 64
     p = SoftActorCriticAgentParameters()
@@ -223,7 +230,7 @@ def test_sac_update_matches_oracle(dev, resample):
         z = rng.standard_normal((3, B, A))
         r = O.sac_update(op, oq, ov, batch, z, resample=resample)
         ag.normals.copy_(_t(z, dev))
-        ag._learn_device(_B(dev, batch))
+        ag._learn_device(_B(dev, batch, paired))
         np.testing.assert_allclose(ag.dq_da.cpu().numpy(), r["dq_da"], rtol=2e-3, atol=1e-7)
         np.testing.assert_allclose(ag.value_targets.cpu().numpy(), r["value_targets"], rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(ag.td_targets.cpu().numpy(), r["td_targets"], rtol=2e-4, atol=2e-5)
