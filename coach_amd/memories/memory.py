@@ -1,44 +1,47 @@
-"""Memory base types — mirror of rl_coach/memories/memory.py:24-77 (MemoryGranularity, the Memory
-method set the agents call: store / sample / length / num_transitions / clean / get)."""
-from enum import Enum
+"""What every device replay has in common: the size unit enum the presets use
+(`(MemoryGranularity.Transitions, n)`, rl_coach/memories/memory.py:24-26) and the handful of calls the
+agents make on a memory (`store`, `sample`, `num_transitions`, `length`, `clean`; memory.py:41-77).
+The reference's memory *backend* hook (Redis pub/sub of transitions) is out of scope."""
+import enum
 
 
-class MemoryGranularity(Enum):                           # memory.py:24-26
+class MemoryGranularity(enum.Enum):
     Transitions = 0
     Episodes = 1
 
 
-class MemoryParameters(object):                          # memory.py:29-38
-    def __init__(self):
-        self.max_size = None
-        self.shared_memory = False
-        self.load_memory_from_file_path = None
+class MemoryParameters(object):
+    """Parameter holder resolved through `path`, like every rl_coach Parameters object."""
+    max_size = None
 
     @property
     def path(self):
         return 'coach_amd.memories.memory:Memory'
 
 
-class Memory(object):                                    # memory.py:41-77
+class Memory(object):
+    """Capacity bookkeeping; the storage itself lives in the subclasses' device tensors."""
+
     def __init__(self, max_size):
-        self.max_size = max_size
-        self._length = 0
-        self.memory_backend = None
+        unit, amount = max_size
+        if not isinstance(unit, MemoryGranularity):
+            raise ValueError("max_size must be (MemoryGranularity, count), got {!r}".format(max_size))
+        self.max_size = (unit, int(amount))
 
-    def store(self, obj):
-        raise NotImplementedError("")
+    def _unsupported(self, what):
+        raise NotImplementedError("{} does not implement {}".format(type(self).__name__, what))
 
-    def get(self, index):
-        raise NotImplementedError("")
-
-    def length(self):
-        raise NotImplementedError("")
+    def store(self, *columns, **kw):
+        self._unsupported("store")
 
     def sample(self, size):
-        raise NotImplementedError("")
-
-    def clean(self):
-        raise NotImplementedError("")
+        self._unsupported("sample")
 
     def num_transitions(self):
-        raise NotImplementedError("")
+        self._unsupported("num_transitions")
+
+    def length(self):
+        return self.num_transitions()
+
+    def clean(self):
+        self._unsupported("clean")
