@@ -1,5 +1,11 @@
-"""rl_coach/presets/CartPole_DQN.py on the device engine: same agent / schedule parameters; the gym
-CartPole-v0 level is replaced by the synthetic vector environment (gym is not installable here)."""
+"""CartPole DQN (BASELINE config C1) for the device engine.
+
+Hyper-parameters are the ones of rl_coach/presets/CartPole_DQN.py (discount .99, target copy every
+100 env-steps, one update per env-step, lr 2.5e-4, MSE loss, 40 k-transition uniform replay,
+epsilon 1 -> 0.01 over 10 k steps, 1 000 heat-up steps); the gym CartPole-v0 level is replaced by the
+synthetic vector environment because gym cannot be installed in this image.
+`make(num_envs=...)` builds the same experiment with more lockstep envs per GPU.
+"""
 from coach_amd.agents.dqn_agent import DQNAgentParameters
 from coach_amd.core_types import EnvironmentEpisodes, EnvironmentSteps
 from coach_amd.environments.synthetic_vector_environment import SyntheticVectorEnvironmentParameters
@@ -7,23 +13,31 @@ from coach_amd.graph_managers.basic_rl_graph_manager import BasicRLGraphManager,
 from coach_amd.memories.memory import MemoryGranularity
 from coach_amd.schedules import LinearSchedule
 
-schedule_params = ScheduleParameters()
-schedule_params.improve_steps = EnvironmentSteps(10000)          # reference: TrainingSteps(1e10), stopped by the CLI
-schedule_params.steps_between_evaluation_periods = EnvironmentEpisodes(10)
-schedule_params.evaluation_steps = EnvironmentEpisodes(1)
-schedule_params.heatup_steps = EnvironmentSteps(1000)
+EPISODE_LENGTH = 200          # CartPole-v0 time limit
+HYPER = dict(discount=0.99, target_copy_every=100, env_steps_per_update=1, learning_rate=2.5e-4,
+             replay_transitions=40000, epsilon=(1.0, 0.01, 10000), heatup_steps=1000,
+             improve_steps=10000, episodes_between_evaluations=10)
 
-agent_params = DQNAgentParameters()
-agent_params.algorithm.discount = 0.99
-agent_params.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(100)
-agent_params.algorithm.num_consecutive_playing_steps = EnvironmentSteps(1)
-agent_params.network_wrappers['main'].learning_rate = 0.00025
-agent_params.network_wrappers['main'].replace_mse_with_huber_loss = False
-agent_params.memory.max_size = (MemoryGranularity.Transitions, 40000)
-agent_params.exploration.epsilon_schedule = LinearSchedule(1.0, 0.01, 10000)
 
-env_params = SyntheticVectorEnvironmentParameters("vector", 1, (4,), 2, episode_length=200, seed=1234)
-schedule_params.steps_between_evaluation_periods = EnvironmentSteps(10 * 200)
+def make(num_envs=1, seed=1234, **overrides):
+    h = dict(HYPER, **overrides)
+    agent = DQNAgentParameters()
+    alg, net = agent.algorithm, agent.network_wrappers['main']
+    alg.discount = h["discount"]
+    alg.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(h["target_copy_every"])
+    alg.num_consecutive_playing_steps = EnvironmentSteps(h["env_steps_per_update"])
+    net.learning_rate = h["learning_rate"]
+    net.replace_mse_with_huber_loss = False
+    agent.memory.max_size = (MemoryGranularity.Transitions, h["replay_transitions"])
+    agent.exploration.epsilon_schedule = LinearSchedule(*h["epsilon"])
+    env = SyntheticVectorEnvironmentParameters("vector", num_envs, (4,), 2, episode_length=EPISODE_LENGTH,
+                                               seed=seed)
+    sched = ScheduleParameters()
+    sched.heatup_steps = EnvironmentSteps(h["heatup_steps"])
+    sched.improve_steps = EnvironmentSteps(h["improve_steps"])
+    sched.steps_between_evaluation_periods = EnvironmentSteps(h["episodes_between_evaluations"] * EPISODE_LENGTH)
+    sched.evaluation_steps = EnvironmentEpisodes(1)
+    return BasicRLGraphManager(agent_params=agent, env_params=env, schedule_params=sched)
 
-graph_manager = BasicRLGraphManager(agent_params=agent_params, env_params=env_params,
-                                    schedule_params=schedule_params)
+
+graph_manager = make()

@@ -1,40 +1,38 @@
-"""rl_coach/presets/Mujoco_ClippedPPO.py on the device engine: continuous Clipped-PPO head
-(MultivariateNormalDiag with a state-independent log-std), observation normalisation as the
-pre-network filter, lr 3e-4, beta_entropy 0, clipping decayed to 0 over 1M steps; the MuJoCo level is
-replaced by the synthetic vector environment (HalfCheetah-like shapes)."""
+"""Continuous-control Clipped PPO for the device engine, with the hyper-parameters of
+rl_coach/presets/Mujoco_ClippedPPO.py: tanh 64-64 value and policy towers, lr 3e-4, Adam beta2 .999 /
+eps 1e-5, batch 64, 10 epochs per 2048-step rollout, GAE(.99, .95), no entropy bonus, clip .2 decayed
+to 0 over 1 M steps, observation normalisation as the pre-network filter.  The MuJoCo level is
+replaced by the synthetic vector environment (HalfCheetah-like shapes: obs 17, act 6)."""
 from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgentParameters
 from coach_amd.core_types import EnvironmentEpisodes, EnvironmentSteps
 from coach_amd.environments.synthetic_vector_environment import SyntheticVectorEnvironmentParameters
 from coach_amd.graph_managers.basic_rl_graph_manager import BasicRLGraphManager, ScheduleParameters
 from coach_amd.schedules import LinearSchedule
 
-schedule_params = ScheduleParameters()
-schedule_params.improve_steps = EnvironmentSteps(10 * 2048)
-schedule_params.steps_between_evaluation_periods = EnvironmentSteps(2048)
-schedule_params.evaluation_steps = EnvironmentEpisodes(0)
-schedule_params.heatup_steps = EnvironmentSteps(0)
+ROLLOUT = 2048
 
-agent_params = ClippedPPOAgentParameters()
-net = agent_params.network_wrappers['main']
-net.learning_rate = 0.0003
-net.activation_function = 'tanh'
-net.embedder_scheme = [64]                      # input_embedders_parameters['observation'].scheme = [Dense(64)]
-net.middleware_scheme = [64]                    # middleware_parameters.scheme = [Dense(64)]
-net.batch_size = 64
-net.optimizer_epsilon = 1e-5
-net.adam_optimizer_beta2 = 0.999
-agent_params.algorithm.clip_likelihood_ratio_using_epsilon = 0.2
-agent_params.algorithm.clipping_decay_schedule = LinearSchedule(1.0, 0, 1000000)
-agent_params.algorithm.beta_entropy = 0
-agent_params.algorithm.gae_lambda = 0.95
-agent_params.algorithm.discount = 0.99
-agent_params.algorithm.optimization_epochs = 10
-agent_params.algorithm.num_consecutive_playing_steps = EnvironmentSteps(2048)
-agent_params.algorithm.reward_clipping = None
-agent_params.algorithm.normalize_observations = True
 
-env_params = SyntheticVectorEnvironmentParameters("vector", 64, (17,), None, action_dim=6, episode_length=32,
-                                                  seed=1234)
+def make(num_envs=64, obs_dim=17, action_dim=6, episode_length=32, iterations=10, seed=1234):
+    agent = ClippedPPOAgentParameters()
+    net, alg = agent.network_wrappers['main'], agent.algorithm
+    for key, value in dict(learning_rate=3e-4, activation_function='tanh', embedder_scheme=[64],
+                           middleware_scheme=[64], batch_size=64, optimizer_epsilon=1e-5,
+                           adam_optimizer_beta2=0.999).items():
+        setattr(net, key, value)
+    for key, value in dict(clip_likelihood_ratio_using_epsilon=0.2, beta_entropy=0, gae_lambda=0.95,
+                           discount=0.99, optimization_epochs=10, reward_clipping=None,
+                           normalize_observations=True).items():
+        setattr(alg, key, value)
+    alg.clipping_decay_schedule = LinearSchedule(1.0, 0, 1000000)
+    alg.num_consecutive_playing_steps = EnvironmentSteps(ROLLOUT)
+    env = SyntheticVectorEnvironmentParameters("vector", num_envs, (obs_dim,), None, action_dim=action_dim,
+                                               episode_length=episode_length, seed=seed)
+    sched = ScheduleParameters()
+    sched.heatup_steps = EnvironmentSteps(0)
+    sched.improve_steps = EnvironmentSteps(iterations * ROLLOUT)
+    sched.steps_between_evaluation_periods = EnvironmentSteps(ROLLOUT)
+    sched.evaluation_steps = EnvironmentEpisodes(0)
+    return BasicRLGraphManager(agent_params=agent, env_params=env, schedule_params=sched)
 
-graph_manager = BasicRLGraphManager(agent_params=agent_params, env_params=env_params,
-                                    schedule_params=schedule_params)
+
+graph_manager = make()
