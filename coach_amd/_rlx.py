@@ -217,6 +217,22 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class SmallDenseProblem(ctypes.Structure):
+    """rlx_small_dense_problem (include/rlx.h) — field order must match the header."""
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("x_tower_stride", ctypes.c_longlong),
+        ("w", ctypes.c_void_p), ("w_tower_stride", ctypes.c_longlong),
+        ("bias", ctypes.c_void_p), ("bias_tower_stride", ctypes.c_longlong),
+        ("y", ctypes.c_void_p), ("y_tower_stride", ctypes.c_longlong),
+        ("dy", ctypes.c_void_p), ("dy_tower_stride", ctypes.c_longlong),
+        ("dw", ctypes.c_void_p), ("dw_tower_stride", ctypes.c_longlong),
+        ("db", ctypes.c_void_p), ("db_tower_stride", ctypes.c_longlong),
+        ("dx", ctypes.c_void_p), ("dx_tower_stride", ctypes.c_longlong),
+        ("towers", ctypes.c_int), ("M", ctypes.c_int), ("K", ctypes.c_int), ("N", ctypes.c_int),
+        ("activation", ctypes.c_int), ("lower_activation", ctypes.c_int),
+    ]
+
+
 ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
 GEMM_HOOK = None   # bench.py sets this to record the descriptors issued by one update
 

@@ -153,6 +153,116 @@ __global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBw
     }
 }
 
+// ---- several narrow layers in ONE launch (blockIdx.z = problem): the value and the policy head of
+// Clipped PPO read different towers, have different widths (1 and A) and separate parameter groups,
+// but the same depth in the dependency chain — one dispatch instead of two, forward and backward.
+constexpr int kMaxProblems = 4;
+struct MultiFwd { SmallDense p[kMaxProblems]; int towers[kMaxProblems]; int n; };
+struct MultiBwd { SmallDenseBwd p[kMaxProblems]; int towers[kMaxProblems]; int n; };
+
+template <int NN>
+__global__ void __launch_bounds__(256) dense_small_fwd_multi_kernel(const MultiFwd m) {
+    const SmallDense &p = m.p[blockIdx.z];
+    if ((int)blockIdx.x >= p.M || (int)blockIdx.y >= m.towers[blockIdx.z]) return;   // whole workgroup exits
+    __shared__ float part[4][NN];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x, t = blockIdx.y;
+    const float *x = p.x + (size_t)t * p.x_ts + (size_t)row * p.K;
+    const float *w = p.w + (size_t)t * p.w_ts;
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[n] = 0.f;
+    const int kq = (p.K + 3) / 4;
+    const int k1 = min(p.K, (wave + 1) * kq);
+    for (int k = wave * kq + lane; k < k1; k += 64) {
+        const float xv = x[k];
+        const float *wr = w + (size_t)k * p.N;
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+            if (n < p.N) acc[n] = fmaf(xv, wr[n], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        float v = acc[n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) part[wave][n] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.N) {
+        const int n = threadIdx.x;
+        float v = ((part[0][n] + part[1][n]) + part[2][n]) + part[3][n];
+        v += p.b ? p.b[(size_t)t * p.b_ts + n] : 0.f;
+        p.y[(size_t)t * p.y_ts + (size_t)row * p.N + n] = act_apply(v, p.act);
+    }
+}
+
+template <int NN>
+__device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int kblock, int t, float *smem) {
+    float *dz = smem;
+    float *part = smem + (size_t)p.M * p.N;
+    const int lane = threadIdx.x % kKL, g = threadIdx.x / kKL;
+    const int k = kblock * kKL + lane;
+    const float *dy = p.dy + (size_t)t * p.dy_ts;
+    const float *yy = p.y ? p.y + (size_t)t * p.y_ts : nullptr;
+    for (int i = threadIdx.x; i < p.M * p.N; i += 256)
+        dz[i] = dy[i] * (yy ? act_deriv_out(yy[i], p.act) : 1.f);
+    __syncthreads();
+    const bool live = k < p.K;
+    const float *x = p.x + (size_t)t * p.x_ts;
+    float wk[NN], acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        acc[n] = 0.f;
+        wk[n] = (live && n < p.N) ? p.w[(size_t)t * p.w_ts + (size_t)k * p.N + n] : 0.f;
+    }
+    float *dx = p.dx ? p.dx + (size_t)t * p.dx_ts : nullptr;
+    if (live) {
+        for (int mm = g; mm < p.M; mm += kRG) {
+            const float xv = x[(size_t)mm * p.K + k];
+            const float *dzr = dz + (size_t)mm * p.N;
+            float s = 0.f;
+#pragma unroll
+            for (int n = 0; n < NN; ++n)
+                if (n < p.N) {
+                    const float d = dzr[n];
+                    acc[n] = fmaf(xv, d, acc[n]);
+                    s = fmaf(d, wk[n], s);
+                }
+            if (dx) dx[(size_t)mm * p.K + k] = p.lower_act ? s * act_deriv_out(xv, p.lower_act) : s;
+        }
+    }
+    if (p.dw) {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) part[((size_t)g * kKL + lane) * NN + n] = acc[n];
+        __syncthreads();
+        if (g == 0 && live) {
+            float *dw = p.dw + (size_t)t * p.dw_ts + (size_t)k * p.N;
+#pragma unroll
+            for (int n = 0; n < NN; ++n)
+                if (n < p.N) {
+                    float v = part[lane * NN + n];
+#pragma unroll
+                    for (int u = 1; u < kRG; ++u) v += part[(u * kKL + lane) * NN + n];
+                    dw[n] = v;
+                }
+        }
+    }
+    if (p.db && kblock == 0 && (int)threadIdx.x < p.N) {
+        float s = 0.f;
+        for (int mm = 0; mm < p.M; ++mm) s += dz[(size_t)mm * p.N + threadIdx.x];
+        p.db[(size_t)t * p.db_ts + threadIdx.x] = s;
+    }
+}
+
+template <int NN>
+__global__ void __launch_bounds__(256) dense_small_bwd_multi_kernel(const MultiBwd m) {
+    extern __shared__ float smem[];
+    const SmallDenseBwd &p = m.p[blockIdx.z];
+    if ((int)blockIdx.x * kKL >= p.K || (int)blockIdx.y >= m.towers[blockIdx.z]) return;
+    dense_small_bwd_body<NN>(p, blockIdx.x, blockIdx.y, smem);
+}
+
 }  // namespace
 
 extern "C" {
@@ -202,6 +312,78 @@ int rlx_dense_small_backward(const float *x, long long x_tower_stride, const flo
     else if (NN == 4) dense_small_bwd_kernel<4><<<grid, 256, smem, s>>>(p);
     else if (NN == 8) dense_small_bwd_kernel<8><<<grid, 256, smem, s>>>(p);
     else dense_small_bwd_kernel<16><<<grid, 256, smem, s>>>(p);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+static int nn_class(int N) { return N <= 1 ? 1 : N <= 4 ? 4 : N <= 8 ? 8 : 16; }
+
+int rlx_dense_small_forward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream) {
+    RLX_REQUIRE(problems_host && n_problems >= 1 && n_problems <= kMaxProblems,
+                "rlx_dense_small_forward_multi: need 1..%d problems", kMaxProblems);
+    MultiFwd m;
+    m.n = n_problems;
+    int max_m = 0, max_t = 0, nn = 1;
+    for (int i = 0; i < n_problems; ++i) {
+        const rlx_small_dense_problem &q = problems_host[i];
+        RLX_REQUIRE(q.x && q.w && q.y, "rlx_dense_small_forward_multi: null pointer in problem %d", i);
+        RLX_REQUIRE(q.towers > 0 && q.M > 0 && q.K > 0 && q.N > 0 && q.N <= kMaxN,
+                    "rlx_dense_small_forward_multi: problem %d needs 1 <= N <= %d", i, kMaxN);
+        RLX_REQUIRE(q.activation >= 0 && q.activation <= 2, "rlx_dense_small_forward_multi: unknown activation");
+        m.p[i] = SmallDense{q.x, q.x_tower_stride, q.w, q.w_tower_stride, q.bias, q.bias_tower_stride,
+                            q.y, q.y_tower_stride, q.M, q.K, q.N, q.activation};
+        m.towers[i] = q.towers;
+        if (q.M > max_m) max_m = q.M;
+        if (q.towers > max_t) max_t = q.towers;
+        if (nn_class(q.N) > nn) nn = nn_class(q.N);
+    }
+    dim3 grid(max_m, max_t, n_problems);
+    hipStream_t s = rlx::as_stream(stream);
+    if (nn == 1) dense_small_fwd_multi_kernel<1><<<grid, 256, 0, s>>>(m);
+    else if (nn == 4) dense_small_fwd_multi_kernel<4><<<grid, 256, 0, s>>>(m);
+    else if (nn == 8) dense_small_fwd_multi_kernel<8><<<grid, 256, 0, s>>>(m);
+    else dense_small_fwd_multi_kernel<16><<<grid, 256, 0, s>>>(m);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_dense_small_backward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream) {
+    RLX_REQUIRE(problems_host && n_problems >= 1 && n_problems <= kMaxProblems,
+                "rlx_dense_small_backward_multi: need 1..%d problems", kMaxProblems);
+    MultiBwd m;
+    m.n = n_problems;
+    int max_kb = 0, max_t = 0, nn = 1;
+    size_t smem = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const rlx_small_dense_problem &q = problems_host[i];
+        RLX_REQUIRE(q.x && q.w && q.dy && (q.dw || q.dx),
+                    "rlx_dense_small_backward_multi: null pointer in problem %d", i);
+        RLX_REQUIRE(q.towers > 0 && q.M > 0 && q.K > 0 && q.N > 0 && q.N <= kMaxN,
+                    "rlx_dense_small_backward_multi: problem %d needs 1 <= N <= %d", i, kMaxN);
+        RLX_REQUIRE(q.activation >= 0 && q.activation <= 2 && q.lower_activation >= 0 && q.lower_activation <= 2,
+                    "rlx_dense_small_backward_multi: unknown activation");
+        RLX_REQUIRE(q.activation == 0 || q.y, "rlx_dense_small_backward_multi: the activation derivative needs y");
+        m.p[i] = SmallDenseBwd{q.x, q.x_tower_stride, q.w, q.w_tower_stride, q.dy, q.dy_tower_stride,
+                               q.activation ? q.y : nullptr, q.y_tower_stride, q.dw, q.dw_tower_stride, q.db,
+                               q.db_tower_stride, q.dx, q.dx_tower_stride, q.M, q.K, q.N, q.activation,
+                               q.lower_activation};
+        m.towers[i] = q.towers;
+        const int kb = (q.K + kKL - 1) / kKL;
+        if (kb > max_kb) max_kb = kb;
+        if (q.towers > max_t) max_t = q.towers;
+        if (nn_class(q.N) > nn) nn = nn_class(q.N);
+    }
+    for (int i = 0; i < n_problems; ++i) {
+        const size_t need = ((size_t)problems_host[i].M * problems_host[i].N + (size_t)kRG * kKL * nn) * sizeof(float);
+        if (need > smem) smem = need;
+    }
+    RLX_REQUIRE(smem <= 64 * 1024, "rlx_dense_small_backward_multi: batch x outputs exceeds the LDS budget");
+    dim3 grid(max_kb, max_t, n_problems);
+    hipStream_t s = rlx::as_stream(stream);
+    if (nn == 1) dense_small_bwd_multi_kernel<1><<<grid, 256, smem, s>>>(m);
+    else if (nn == 4) dense_small_bwd_multi_kernel<4><<<grid, 256, smem, s>>>(m);
+    else if (nn == 8) dense_small_bwd_multi_kernel<8><<<grid, 256, smem, s>>>(m);
+    else dense_small_bwd_multi_kernel<16><<<grid, 256, smem, s>>>(m);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -404,6 +404,51 @@ class Conv2d(Layer):
             x.grad_is_dz = lower is not None
 
 
+def small_dense_forward_multi(ctx, items, tag=""):
+    """[(Dense layer, input Tensor)] -> [output Tensor], all layers in ONE launch (each N <= SMALL_N)."""
+    import ctypes
+    arr = (_rlx.SmallDenseProblem * len(items))()
+    outs = []
+    for i, (l, x) in enumerate(items):
+        assert l.N <= SMALL_N and not x.u8 and x.cols == l.K and x.towers in (0, l.T)
+        M, p = x.rows, l.params
+        y = ctx.buffer(l.name, (l.T, M, l.N), tag=tag)
+        q = arr[i]
+        q.x, q.x_tower_stride = x.data.data_ptr(), x.tower_stride()
+        q.w, q.w_tower_stride = p.w(l.kname).data_ptr(), p.stride(l.kname)
+        q.bias, q.bias_tower_stride = p.w(l.bname).data_ptr(), p.stride(l.bname)
+        q.y, q.y_tower_stride = y.data_ptr(), M * l.N
+        q.towers, q.M, q.K, q.N, q.activation = l.T, M, l.K, l.N, _rlx.ACT[l.act]
+        outs.append(Tensor(y, M, l.N, l.T, grad_key=(ctx, l.name, tag), act=l.act))
+    ctx.lib.dense_small_forward_multi(ctypes.byref(arr), len(items), ctx.stream)
+    return outs
+
+
+def small_dense_backward_multi(ctx, items):
+    """[(Dense layer, input Tensor x, output Tensor y with y.grad set)]: dW, db and dx (with the lower
+    layer's activation derivative) of every layer in ONE launch."""
+    import ctypes
+    arr = (_rlx.SmallDenseProblem * len(items))()
+    for i, (l, x, y) in enumerate(items):
+        M, p = x.rows, l.params
+        assert l.N <= SMALL_N and M * l.N <= 1024 and x.towers == l.T
+        own = l.act if (l.act is not None and not y.grad_is_dz) else None
+        lower = x.act
+        dx = x.ensure_grad()
+        q = arr[i]
+        q.x, q.x_tower_stride = x.data.data_ptr(), x.tower_stride()
+        q.w, q.w_tower_stride = p.w(l.kname).data_ptr(), p.stride(l.kname)
+        q.dy, q.dy_tower_stride = y.grad.data_ptr(), M * l.N
+        q.y, q.y_tower_stride = (y.data.data_ptr() if own else None), M * l.N
+        q.dw, q.dw_tower_stride = p.g(l.kname).data_ptr(), p.stride(l.kname)
+        q.db, q.db_tower_stride = p.g(l.bname).data_ptr(), p.stride(l.bname)
+        q.dx, q.dx_tower_stride = dx.data_ptr(), M * l.K
+        q.towers, q.M, q.K, q.N = l.T, M, l.K, l.N
+        q.activation, q.lower_activation = _rlx.ACT[own], _rlx.ACT[lower]
+        x.grad_is_dz = lower is not None
+    ctx.lib.dense_small_backward_multi(ctypes.byref(arr), len(items), ctx.stream)
+
+
 class Sequential:
     """A chain of Dense / Conv2d layers replicated over `towers` identical copies."""
 

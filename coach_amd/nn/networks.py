@@ -176,8 +176,12 @@ class ClippedPPONet(_NetBase):
         mid = acts[-1]
         mid.ensure_grad()
         xv, xp = mid.tower(0), mid.tower(1)
-        v = self.v_head.forward(ctx, xv, tag="train")
-        logits = self.pi_head.forward(ctx, xp, tag="train")
+        fused_heads = self.pi_head.N <= G.SMALL_N and B * self.pi_head.N <= 1024
+        if fused_heads:        # value + policy head in one launch (forward here, backward below)
+            v, logits = G.small_dense_forward_multi(ctx, [(self.v_head, xv), (self.pi_head, xp)], tag="train")
+        else:
+            v = self.v_head.forward(ctx, xv, tag="train")
+            logits = self.pi_head.forward(ctx, xp, tag="train")
         dv, dlogits = v.ensure_grad(), logits.ensure_grad()
         # head 0: VHead, MSE(target, V), loss weight 1 (head.py:172-181)
         self.lib.regression_loss(v.data, 1, value_targets, 1, None, B, 1, 0, 1.0, 1.0, dv, 1,
@@ -195,8 +199,11 @@ class ClippedPPONet(_NetBase):
                                        self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
                                        self.A, self.scalars[0:4], ratio_out, clipped_out, self.status,
                                        ctx.stream)
-        self.v_head.backward(ctx, xv, v)
-        self.pi_head.backward(ctx, xp, logits)
+        if fused_heads:
+            G.small_dense_backward_multi(ctx, [(self.v_head, xv, v), (self.pi_head, xp, logits)])
+        else:
+            self.v_head.backward(ctx, xv, v)
+            self.pi_head.backward(ctx, xp, logits)
         mid.grad_is_dz = xv.grad_is_dz and xp.grad_is_dz     # the heads wrote dz of the middleware
         if stop_after_dense:
             k = self._split_layer()

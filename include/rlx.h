@@ -234,6 +234,24 @@ int rlx_dense_small_backward(const float *x, long long x_tower_stride, const flo
                              long long dx_tower_stride, int towers, int M, int K, int N, int activation,
                              int lower_activation, void *stream);
 
+/* Up to 4 narrow layers of the same depth in ONE launch (e.g. the value and the policy head of
+ * Clipped PPO, clipped_ppo_agent.py:41-58: separate towers, widths 1 and A).  Field meaning as the
+ * single-layer calls; `y` is the forward output, and in backward the layer output needed for the
+ * activation derivative (may be NULL when activation == NONE). */
+typedef struct rlx_small_dense_problem {
+    const float *x; long long x_tower_stride;
+    const float *w; long long w_tower_stride;
+    const float *bias; long long bias_tower_stride;
+    float *y; long long y_tower_stride;
+    const float *dy; long long dy_tower_stride;
+    float *dw; long long dw_tower_stride;
+    float *db; long long db_tower_stride;
+    float *dx; long long dx_tower_stride;
+    int towers, M, K, N, activation, lower_activation;
+} rlx_small_dense_problem;
+int rlx_dense_small_forward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
+int rlx_dense_small_backward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
+
 /* -------------------------------------------------------- head losses (K9) -- */
 /* loss = mean_b(loss_weight * w_b * sum_j l(target, out)); kind 0 = MSE, 1 = Huber(delta 1).
  * grad (optional) = grad_scale * d loss / d out.  heads/head.py:143-186, q_head.py, v_head.py:43-52 */
