@@ -164,6 +164,7 @@ class ClippedPPOAgent(object):
 
     # ------------------------------------------------------------------------------- buffers
     def _alloc_training_buffers(self):
+        from ..staging import Stager
         dev, B = self.device, self.ap.network_wrappers["main"].batch_size
         cap = self.memory.cap
         f32, f64 = torch.float32, torch.float64
@@ -188,7 +189,10 @@ class ClippedPPOAgent(object):
         self.chunk_obs = torch.empty((self.chunk,) + obs_tail, dtype=odt, device=dev)
         self.mb_obs = torch.empty((B,) + obs_tail, dtype=odt, device=dev)
         self.mb_rows = torch.empty(B, dtype=torch.int32, device=dev)
-        self.mb_idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        # the epoch's shuffled dataset order lives in ONE static device buffer; minibatch i of the
+        # epoch reads its slice in place (its hipGraph is keyed by i), so there is no per-minibatch copy
+        self._perm = Stager((cap,), torch.int32, dev, depth=4)
+        self.perm_dev = self._perm.dst
         self.mb_action = torch.empty((B, self.A) if self.continuous else (B,), dtype=self.actions.dtype, device=dev)
         self.mb_old_std = torch.empty(B, self.A, dtype=f32, device=dev) if self.continuous else None
         self.mb_adv = torch.empty(B, dtype=f32, device=dev)
@@ -199,7 +203,6 @@ class ClippedPPOAgent(object):
         self.scalar_acc = torch.zeros(8, dtype=f32, device=dev)
         # one uniform per (step, env): what the phase's np.random.choice calls consume (continuous:
         # A standard normals per (step, env) behind np.random.normal(mean, std), additive_noise.py:106)
-        from ..staging import Stager
         shape = (self.steps_per_phase, self.n_env, self.A) if self.continuous else (self.steps_per_phase, self.n_env)
         self._uniforms = Stager(shape, f64, dev, depth=4)
         self.uniforms_all = self._uniforms.dst
@@ -320,10 +323,11 @@ class ClippedPPOAgent(object):
         rows = self.memory.dataset_rows()
         self._run(("fill", n), lambda: self._fill_advantages_device(n, rows))
 
-    def _gather_minibatch(self, m):
+    def _gather_minibatch(self, m, i=0):
         mem, s = self.memory, _rlx.current_stream()
         rows_all = mem.dataset_rows()
-        idx, rows = self.mb_idx[:m], self.mb_rows[:m]
+        B = self.ap.network_wrappers["main"].batch_size
+        idx, rows = self.perm_dev[i * B:i * B + m], self.mb_rows[:m]
         # one launch gathers the per-transition columns AND translates dataset index -> storage row
         # (rows_all is one more 4-byte column over the same index)
         cols = [(rows_all, rows), (self.ds_action, self.mb_action), (self.ds_adv, self.mb_adv), (self.ds_vtarget, self.mb_vtarget),
@@ -338,8 +342,8 @@ class ClippedPPOAgent(object):
             return self.mb_obs[:m]
         return mem.gather_states(rows, m, self.mb_obs[:m])
 
-    def _minibatch_fb(self, m, clip_rescaler, stop_after_dense=False):
-        obs = self._gather_minibatch(m)
+    def _minibatch_fb(self, m, clip_rescaler, stop_after_dense=False, i=0):
+        obs = self._gather_minibatch(m, i)
         old = (self.mb_old, self.mb_old_std) if self.continuous else self.mb_old
         self.networks["main"].forward_backward(obs, m, self.mb_action, self.mb_adv, self.mb_vtarget,
                                                old, clip_rescaler, self.mb_ratio, self.mb_clipped,
@@ -366,17 +370,18 @@ class ClippedPPOAgent(object):
             batch_order = list(range(n))
             random.shuffle(batch_order)                                   # Batch.shuffle
             order = [order[i] for i in batch_order]
-            perm = torch.from_numpy(np.asarray(order, dtype=np.int32)).to(self.device, non_blocking=True)
+            full = np.zeros(self.perm_dev.numel(), dtype=np.int32)
+            full[:n] = order
+            self._perm.push(full)
             self.scalar_acc.zero_()
             nmb = -(-n // B)                                              # math.ceil (:232)
             for i in range(nmb):
                 m = min(B, n - i * B)
-                self.mb_idx[:m].copy_(perm[i * B:i * B + m])
                 if self.dist is None:
-                    self._run(("mb", m, clip, scale), lambda: (self._minibatch_fb(m, clip),
-                                                               self._minibatch_finish(scale)))
+                    self._run(("mb", m, clip, scale, i), lambda: (self._minibatch_fb(m, clip, i=i),
+                                                                  self._minibatch_finish(scale)))
                 elif os.environ.get("RLX_SYNC_ALLREDUCE", "0") == "1":
-                    self._run(("mb_fb", m, clip), lambda: self._minibatch_fb(m, clip))
+                    self._run(("mb_fb", m, clip, i), lambda: self._minibatch_fb(m, clip, i=i))
                     self.dist.all_reduce_sum(self.networks["main"].params.grads)
                     self._run(("mb_fin", scale), lambda: self._minibatch_finish(scale))
                 else:
@@ -384,7 +389,7 @@ class ClippedPPOAgent(object):
                     # backward starts; their all-reduce runs on RCCL's stream underneath it
                     net = self.networks["main"]
                     grads, off = net.params.grads, net.late_gradient_offset()
-                    self._run(("mb_p1", m, clip), lambda: self._minibatch_fb(m, clip, True))
+                    self._run(("mb_p1", m, clip, i), lambda: self._minibatch_fb(m, clip, True, i=i))
                     w1 = self.dist.all_reduce_sum_async(grads[off:])
                     self._run(("mb_p2", m), net.backward_rest)
                     w2 = self.dist.all_reduce_sum_async(grads[:off]) if off > 0 else None

@@ -37,8 +37,8 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 
 // kind 0: mean squared error (t - o)^2;  kind 1: huber, delta = 1.
 // out/target [B, D]; weights [B] or null; grad = d loss / d out.  scalars[0] = loss.
-__global__ void __launch_bounds__(kMaxBlock)
-regression_loss_kernel(const float *__restrict__ out, const float *__restrict__ target,
+__device__ __forceinline__ void
+regression_loss_body(const float *__restrict__ out, const float *__restrict__ target,
                        const float *__restrict__ weights, int batch, int dim, long long ld_out,
                        long long ld_target, int kind, float loss_weight, float grad_scale,
                        float *__restrict__ grad, long long ld_grad, float *__restrict__ scalars) {
@@ -82,8 +82,8 @@ __global__ void softmax_kernel(const float *__restrict__ logits, int batch, int 
 
 // Discrete Clipped-PPO head.  scalars: [0] surrogate loss, [1] mean entropy, [2] mean KL(old||new),
 // [3] total head loss = surrogate - beta * entropy.
-__global__ void __launch_bounds__(kMaxBlock)
-ppo_discrete_loss_kernel(const float *__restrict__ logits, long long ld, const int *__restrict__ actions,
+__device__ __forceinline__ void
+ppo_discrete_loss_body(const float *__restrict__ logits, long long ld, const int *__restrict__ actions,
                          const float *__restrict__ advantages, const float *__restrict__ old_probs,
                          long long ld_old, int batch, int n, float clip_eps, float beta,
                          float grad_scale, float *__restrict__ dlogits, long long ld_grad,
@@ -157,6 +157,43 @@ ppo_discrete_loss_kernel(const float *__restrict__ logits, long long ld, const i
         scalars[2] = kl * inv;                                        // kl_divergence (:66)
         scalars[3] = -sur * inv - beta * ent * inv;                   // + entropy_regularization (:95-96)
     }
+}
+
+__global__ void __launch_bounds__(kMaxBlock)
+regression_loss_kernel(const float *__restrict__ out, const float *__restrict__ target,
+                       const float *__restrict__ weights, int batch, int dim, long long ld_out,
+                       long long ld_target, int kind, float loss_weight, float grad_scale,
+                       float *__restrict__ grad, long long ld_grad, float *__restrict__ scalars) {
+    regression_loss_body(out, target, weights, batch, dim, ld_out, ld_target, kind, loss_weight, grad_scale,
+                         grad, ld_grad, scalars);
+}
+
+__global__ void __launch_bounds__(kMaxBlock)
+ppo_discrete_loss_kernel(const float *__restrict__ logits, long long ld, const int *__restrict__ actions,
+                         const float *__restrict__ advantages, const float *__restrict__ old_probs,
+                         long long ld_old, int batch, int n, float clip_eps, float beta,
+                         float grad_scale, float *__restrict__ dlogits, long long ld_grad,
+                         float *__restrict__ scalars, float *__restrict__ ratio_out,
+                         float *__restrict__ clipped_out, int *__restrict__ status) {
+    ppo_discrete_loss_body(logits, ld, actions, advantages, old_probs, ld_old, batch, n, clip_eps, beta,
+                           grad_scale, dlogits, ld_grad, scalars, ratio_out, clipped_out, status);
+}
+
+// Both heads of Clipped PPO in one launch: workgroup 0 = PPOHead, workgroup 1 = VHead (MSE, weight 1).
+struct PpoValueLossArgs {
+    const float *logits; long long ld; const int *actions; const float *advantages;
+    const float *old_probs; long long ld_old; int batch, n; float clip_eps, beta, grad_scale;
+    float *dlogits; long long ld_grad; float *scalars; float *ratio_out; float *clipped_out; int *status;
+    const float *v; const float *v_target; float *dv; float *v_scalar;
+};
+__global__ void __launch_bounds__(kMaxBlock) ppo_value_losses_kernel(const PpoValueLossArgs a) {
+    if (blockIdx.x == 0)
+        ppo_discrete_loss_body(a.logits, a.ld, a.actions, a.advantages, a.old_probs, a.ld_old, a.batch, a.n,
+                               a.clip_eps, a.beta, a.grad_scale, a.dlogits, a.ld_grad, a.scalars,
+                               a.ratio_out, a.clipped_out, a.status);
+    else
+        regression_loss_body(a.v, a.v_target, nullptr, a.batch, 1, 1, 1, 0, 1.f, a.grad_scale, a.dv, 1,
+                             a.v_scalar);
 }
 
 // Continuous Clipped-PPO head (ppo_head.py:118-144 + :58-98): policy = MultivariateNormalDiag(mean,
@@ -306,6 +343,26 @@ int rlx_ppo_continuous_loss(const float *mean, long long ld, const float *log_st
         mean, ld, log_std, actions, advantages, old_mean, old_std, ld_old, batch, action_dim, clip_epsilon,
         beta_entropy, grad_scale, dmean, ld_grad, dlog_std, scalars, likelihood_ratio,
         clipped_likelihood_ratio);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_ppo_discrete_value_losses(const float *logits, long long ld, const int *actions,
+                                  const float *advantages, const float *old_probs, long long ld_old,
+                                  int batch, int n_actions, float clip_epsilon, float beta_entropy,
+                                  float grad_scale, float *dlogits, long long ld_grad, float *scalars,
+                                  float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
+                                  const float *values, const float *value_targets, float *dvalues,
+                                  float *value_loss_scalar, void *stream) {
+    RLX_REQUIRE(logits && actions && advantages && old_probs && status && values && value_targets,
+                "rlx_ppo_discrete_value_losses: null pointer");
+    RLX_REQUIRE(batch > 0 && n_actions > 0 && ld >= n_actions && ld_old >= n_actions,
+                "rlx_ppo_discrete_value_losses: bad shape");
+    RLX_REQUIRE(!dlogits || ld_grad >= n_actions, "rlx_ppo_discrete_value_losses: bad gradient pitch");
+    PpoValueLossArgs a{logits, ld, actions, advantages, old_probs, ld_old, batch, n_actions, clip_epsilon,
+                       beta_entropy, grad_scale, dlogits, ld_grad, scalars, likelihood_ratio,
+                       clipped_likelihood_ratio, status, values, value_targets, dvalues, value_loss_scalar};
+    ppo_value_losses_kernel<<<2, block_for(batch), 0, rlx::as_stream(stream)>>>(a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -184,8 +184,15 @@ class ClippedPPONet(_NetBase):
             logits = self.pi_head.forward(ctx, xp, tag="train")
         dv, dlogits = v.ensure_grad(), logits.ensure_grad()
         # head 0: VHead, MSE(target, V), loss weight 1 (head.py:172-181)
-        self.lib.regression_loss(v.data, 1, value_targets, 1, None, B, 1, 0, 1.0, 1.0, dv, 1,
-                                 self.scalars[4:5], ctx.stream)
+        if not self.continuous:
+            # ... and head 1, the discrete PPOHead clipped surrogate (+ entropy bonus), in one launch
+            self.lib.ppo_discrete_value_losses(logits.data, self.A, actions, advantages, old_probs, self.A, B,
+                                               self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
+                                               self.A, self.scalars[0:4], ratio_out, clipped_out, self.status,
+                                               v.data, value_targets, dv, self.scalars[4:5], ctx.stream)
+        else:
+            self.lib.regression_loss(v.data, 1, value_targets, 1, None, B, 1, 0, 1.0, 1.0, dv, 1,
+                                     self.scalars[4:5], ctx.stream)
         # head 1: PPOHead clipped surrogate (+ entropy bonus)
         if self.continuous:
             old_mean, old_std = old_probs                          # [policy_mean, policy_std] of the old policy
@@ -194,11 +201,7 @@ class ClippedPPONet(_NetBase):
                                          self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits, self.A,
                                          self.params.g("main/ppo_head/policy_log_std"), self.scalars[0:4],
                                          ratio_out, clipped_out, ctx.stream)
-        else:
-            self.lib.ppo_discrete_loss(logits.data, self.A, actions, advantages, old_probs, self.A, B,
-                                       self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
-                                       self.A, self.scalars[0:4], ratio_out, clipped_out, self.status,
-                                       ctx.stream)
+
         if fused_heads:
             G.small_dense_backward_multi(ctx, [(self.v_head, xv, v), (self.pi_head, xp, logits)])
         else:

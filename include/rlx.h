@@ -270,6 +270,16 @@ int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
                           float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
                           void *stream);
 
+/* rlx_ppo_discrete_loss and the VHead MSE loss (rlx_regression_loss, dim 1, weight 1) of the same
+ * minibatch in ONE launch: values / value_targets / dvalues are [batch]. */
+int rlx_ppo_discrete_value_losses(const float *logits, long long ld, const int *actions,
+                                  const float *advantages, const float *old_probs, long long ld_old,
+                                  int batch, int n_actions, float clip_epsilon, float beta_entropy,
+                                  float grad_scale, float *dlogits, long long ld_grad, float *scalars,
+                                  float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
+                                  const float *values, const float *value_targets, float *dvalues,
+                                  float *value_loss_scalar, void *stream);
+
 /* Continuous policy (heads/ppo_head.py:118-144): MultivariateNormalDiag(mean, exp(log_std) + eps),
  * log_std one state-independent vector [action_dim]; old_std is the old network's policy_std output.
  * dlog_std[action_dim] receives the batch-summed gradient.  scalars as rlx_ppo_discrete_loss. */
