@@ -84,7 +84,9 @@ class ClippedPPOAgentParameters(object):                 # clipped_ppo_agent.py:
 
 def _capture(fn):
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    # thread_local: with data parallelism RCCL's watchdog thread polls events while we capture; only
+    # calls made by THIS thread may invalidate the capture
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         fn()
     return g
 

@@ -24,7 +24,9 @@ from ..core_types import EnvironmentSteps, RunPhase, TrainingSteps
 
 def capture(fn):
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    # thread_local: with data parallelism RCCL's watchdog thread polls events while we capture; only
+    # calls made by THIS thread may invalidate the capture
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         fn()
     return g
 
