@@ -120,7 +120,7 @@ class DQNAgent(VectorOffPolicyAgent):
     def learn_from_batch(self, batch):
         """DQNAgent.learn_from_batch (dqn_agent.py:81-113)."""
         per = isinstance(self.memory, PrioritizedExperienceReplay)
-        weights = batch.info("weight32") if per else None
+        weights = batch.info("weight") if per else None           # fp64, as rlx_per_sample wrote them
         if self.dist is None:
             self._run(("learn", per), lambda: self._learn_device(batch, weights))
         else:

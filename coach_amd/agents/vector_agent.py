@@ -216,8 +216,8 @@ class VectorOffPolicyAgent(GraphRunner):
                 net.update_target(rate)
 
     def train(self):
-        """Agent.train (agent.py:701-770): returns the summed loss of the phases run (device
-        scalar) or None when no phase was due."""
+        """Agent.train (agent.py:701-770): returns the loss of the last update run (device scalar)
+        or None when no training phase was due."""
         if self.phase != RunPhase.TRAIN:
             return None
         phases = self._training_phases_due()
@@ -225,7 +225,7 @@ class VectorOffPolicyAgent(GraphRunner):
             return None
         alg = self.ap.algorithm
         B = self.batch_size
-        total = None
+        losses = []
         for _ in range(phases):
             # every batch of the phase is drawn first (agent.py:726), then learned from in turn; a
             # collated DeviceBatch aliases the memory's static buffers, so collation is per batch
@@ -239,11 +239,12 @@ class VectorOffPolicyAgent(GraphRunner):
                 loss = self.learn_from_batch(batch)
                 if self.debug_losses is not None:
                     self.debug_losses.append(float(loss.sum().item()))
-                total = loss if total is None else total + loss
+                losses.append(loss)
                 if any(n.target is not None for n in self.networks.values()) and \
                         self._should_update_online_weights_to_target():
                     self.update_target_networks(alg.rate_for_copying_weights_to_target)
-        return total
+        # the loss of the last update of the phase(s) (a device scalar; no per-update host sync or add)
+        return losses[-1] if losses else None
 
     def _training_steps_this_phase(self):
         return self.ap.algorithm.num_consecutive_training_steps

@@ -52,6 +52,59 @@ __global__ void dqn_targets_kernel(const float *__restrict__ q_next, const float
     td_targets[o] = (float)new_target;                                          // (:103)
 }
 
+// DQN learn_from_batch from the Q values to the head gradient in ONE launch (dqn_agent.py:92-113 +
+// heads/q_head.py loss, head.py:172-181): greedy next action, fp64 TD target, |TD error| for the
+// prioritized replay, and — because TD_targets equals Q_online except at the taken action — the
+// MSE / Huber loss and its gradient, which are non-zero only at [b, a_b]:
+//   loss = mean_b( w_b * l(y_b, Q(s_b, a_b)) ),   dQ[b][a_b] = grad_scale * w_b * l'(.) / B.
+// One workgroup (B <= 1024): per-sample work in registers, the batch mean by a fixed-order LDS tree.
+__global__ void __launch_bounds__(1024)
+dqn_head_loss_kernel(const float *__restrict__ q, long long ld_q, const float *__restrict__ q_next,
+                     const float *__restrict__ q_sel, long long ld_next, const int *__restrict__ actions,
+                     const float *__restrict__ rewards, const unsigned char *__restrict__ dones,
+                     const double *__restrict__ weights, double discount, int batch, int n_actions,
+                     int huber, float grad_scale, float *__restrict__ dq, long long ld_dq,
+                     double *__restrict__ td_errors, float *__restrict__ td_targets, long long ld_t,
+                     float *__restrict__ loss, int *__restrict__ status) {
+    __shared__ float red[1024];
+    const int i = threadIdx.x;
+    float term = 0.f;
+    if (i < batch) {
+        const float *qs = q_sel + (size_t)i * ld_next;
+        int best = 0;
+        float bv = qs[0];
+        for (int a = 1; a < n_actions; ++a)
+            if (qs[a] > bv) { bv = qs[a]; best = a; }            // np.argmax: first maximum
+        const int act = actions[i];
+        if (act < 0 || act >= n_actions) {
+            atomicOr(status, 1);
+        } else {
+            const double qn = (double)q_next[(size_t)i * ld_next + best];
+            const double y = (double)rewards[i] + (1.0 - (dones[i] ? 1.0 : 0.0)) * discount * qn;   // :100-101
+            const float qa = q[(size_t)i * ld_q + act];
+            if (td_errors) td_errors[i] = fabs(y - (double)qa);                                     // :102
+            const float y32 = (float)y;                                                             // :103
+            const float e = qa - y32;
+            const float w = weights ? (float)weights[i] : 1.f;   // fp64 PER weights fed to an fp32 placeholder
+            float l, g;
+            if (!huber) { l = e * e; g = 2.f * e; }
+            else { const float ae = fabsf(e); l = ae <= 1.f ? 0.5f * e * e : ae - 0.5f; g = fminf(fmaxf(e, -1.f), 1.f); }
+            term = w * l;
+            for (int a = 0; a < n_actions; ++a) {
+                dq[(size_t)i * ld_dq + a] = a == act ? grad_scale * w * g / (float)batch : 0.f;
+                if (td_targets) td_targets[(size_t)i * ld_t + a] = a == act ? y32 : q[(size_t)i * ld_q + a];
+            }
+        }
+    }
+    red[i] = term;
+    __syncthreads();
+    for (int d = blockDim.x >> 1; d > 0; d >>= 1) {
+        if (i < d) red[i] += red[i + d];
+        __syncthreads();
+    }
+    if (i == 0 && loss) loss[0] = red[0] / (float)batch;
+}
+
 // TD = r + (1 - done) * discount * q      (or r + discount * q), optionally clipped.
 __global__ void ac_targets_kernel(const float *__restrict__ rewards,
                                   const unsigned char *__restrict__ dones,
@@ -111,6 +164,29 @@ int rlx_dqn_targets(const float *q_next_target, const float *q_next_selector, fl
     dqn_targets_kernel<<<(batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
         q_next_target, q_next_selector, td_targets, actions, rewards, game_overs, discount, batch,
         n_actions, td_errors, status);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_dqn_head_loss(const float *q_online, long long ld_q, const float *q_next_target,
+                      const float *q_next_selector, long long ld_next, const int *actions,
+                      const float *rewards, const unsigned char *game_overs,
+                      const double *importance_weights, double discount, int batch, int n_actions,
+                      int huber, float grad_scale, float *dq, long long ld_dq, double *td_errors,
+                      float *td_targets, long long ld_targets, float *loss_scalar, int *status,
+                      void *stream) {
+    RLX_REQUIRE(q_online && q_next_target && actions && rewards && game_overs && dq && status,
+                "rlx_dqn_head_loss: null pointer");
+    RLX_REQUIRE(batch > 0 && batch <= 1024 && n_actions > 0 && ld_q >= n_actions && ld_next >= n_actions &&
+                    ld_dq >= n_actions,
+                "rlx_dqn_head_loss: bad sizes (batch=%d <= 1024, actions=%d)", batch, n_actions);
+    if (!q_next_selector) q_next_selector = q_next_target;
+    int threads = 64;
+    while (threads < batch) threads <<= 1;
+    dqn_head_loss_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
+        q_online, ld_q, q_next_target, q_next_selector, ld_next, actions, rewards, game_overs,
+        importance_weights, discount, batch, n_actions, huber, grad_scale, dq, ld_dq, td_errors,
+        td_targets, ld_targets, loss_scalar, status);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

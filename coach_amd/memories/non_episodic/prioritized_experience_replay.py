@@ -132,10 +132,9 @@ class PrioritizedExperienceReplay(ExperienceReplay):
         self.lib.per_sample(self.sum_tree, self.min_tree, self.power_of_2_size, p["u"], size,
                             n_transitions, beta, p["idx"], p["weight"], None, s)
         self.gather_device(p["idx"], size, b)
-        p["weight32"].copy_(p["weight"])                   # importance weights feed an fp32 placeholder
         return DeviceBatch(size, {"observation": b["state"]}, {"observation": b["next_state"]},
                            b["action"], b["reward"], b["game_over"],
-                           info={"idx": p["idx"], "weight": p["weight"], "weight32": p["weight32"],
+                           info={"idx": p["idx"], "weight": p["weight"],
                                  "states_pair": b["states_pair"]})
 
     def sample(self, size):

@@ -248,14 +248,21 @@ class Dense(Layer):
         y = ctx.buffer(self.name, (TT, M, self.N), tag=tag)
         if self.N <= SMALL_N and not x.u8:
             # heads: coalesced FMA kernel, no MFMA tile / split-K round trip (csrc/dense_small.hip)
-            for c in range(2 if pair else 1):                 # copy c: online / target weights
-                woff = c * p.size * 4
-                xoff = c * (a_stride2 if pair else 0) * 4
-                ctx.lib.dense_small_forward(x.data.data_ptr() + xoff, a_stride,
-                                            p.w(self.kname, t0, weights).data_ptr() + woff, wstride,
-                                            p.w(self.bname, t0, weights).data_ptr() + woff, bstride,
-                                            y.data_ptr() + c * T * M * self.N * 4, M * self.N, T, M, self.K,
-                                            self.N, _rlx.ACT[self.act], ctx.stream)
+            if not pair:
+                ctx.lib.dense_small_forward(x.data, a_stride, p.w(self.kname, t0, weights), wstride,
+                                            p.w(self.bname, t0, weights), bstride, y, M * self.N, T, M,
+                                            self.K, self.N, _rlx.ACT[self.act], ctx.stream)
+            else:                                             # online and target copy: 2 problems, 1 launch
+                import ctypes
+                arr = (_rlx.SmallDenseProblem * 2)()
+                for c in range(2):
+                    q = arr[c]
+                    q.x, q.x_tower_stride = x.data.data_ptr() + c * a_stride2 * 4, a_stride
+                    q.w, q.w_tower_stride = p.w(self.kname).data_ptr() + c * p.size * 4, wstride
+                    q.bias, q.bias_tower_stride = p.w(self.bname).data_ptr() + c * p.size * 4, bstride
+                    q.y, q.y_tower_stride = y.data_ptr() + c * T * M * self.N * 4, M * self.N
+                    q.towers, q.M, q.K, q.N, q.activation = T, M, self.K, self.N, _rlx.ACT[self.act]
+                ctx.lib.dense_small_forward_multi(ctypes.byref(arr), 2, ctx.stream)
         else:
             _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
                       bias=p.w(self.bname, t0, weights), activation=self.act, batch=TT,

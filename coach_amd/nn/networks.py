@@ -277,13 +277,15 @@ class DQNNet(_NetBase):
             q_next = self.q_values(next_obs, B, use_target=True, tag="next_t").data.view(B, self.A)
             acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
             q = self.q_head.forward(ctx, acts[-1], tag="train")
-        targets = ctx.buffer("td_targets", (B, self.A))
-        targets.copy_(q.data.view(B, self.A))
-        self.lib.dqn_targets(q_next, sel, targets, actions, rewards, game_overs, float(discount), B,
-                             self.A, td_errors, self.status, ctx.stream)
         dq = q.ensure_grad()
-        self.lib.regression_loss(q.data, self.A, targets, self.A, importance_weights, B, self.A,
-                                 1 if self.huber else 0, 1.0, 1.0, dq, self.A, self.loss, ctx.stream)
+        # TD targets, |TD errors|, QHead loss and its gradient in one launch (importance weights are
+        # the fp64 weights of the prioritized replay, or fp32 -> converted, or None)
+        w = importance_weights
+        if w is not None and w.dtype != torch.float64:
+            w = w.double()
+        self.lib.dqn_head_loss(q.data, self.A, q_next, sel, self.A, actions, rewards, game_overs, w,
+                               float(discount), B, self.A, int(self.huber), 1.0, dq, self.A, td_errors,
+                               None, self.A, self.loss, self.status, ctx.stream)
         self.q_head.backward(ctx, acts[-1], q)
         self.torso.backward(ctx, acts)
         if sync is not None:                          # data-parallel: ONE all-reduce of the flat buffer

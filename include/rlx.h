@@ -137,6 +137,18 @@ int rlx_dqn_targets(const float *q_next_target, const float *q_next_selector, fl
                     const int *actions, const float *rewards, const unsigned char *game_overs,
                     double discount, int batch, int n_actions, double *td_errors, int *status,
                     void *stream);                                   /* agents/dqn_agent.py:92-103 */
+/* The same targets, the QHead loss (MSE / Huber, importance weighted) and its gradient w.r.t.
+ * Q_online in ONE launch: TD_targets equals Q_online except at the taken action, so loss and gradient
+ * live at [b, actions[b]] only (dqn_agent.py:92-113, heads/q_head.py, head.py:172-181).
+ * importance_weights: the fp64 weights of rlx_per_sample (rounded to fp32 like the TF placeholder) or
+ * NULL.  td_errors / td_targets / loss_scalar are optional outputs. */
+int rlx_dqn_head_loss(const float *q_online, long long ld_q, const float *q_next_target,
+                      const float *q_next_selector, long long ld_next, const int *actions,
+                      const float *rewards, const unsigned char *game_overs,
+                      const double *importance_weights, double discount, int batch, int n_actions,
+                      int huber, float grad_scale, float *dq, long long ld_dq, double *td_errors,
+                      float *td_targets, long long ld_targets, float *loss_scalar, int *status,
+                      void *stream);
 int rlx_ac_td_targets(const float *rewards, const unsigned char *game_overs, const float *q_next,
                       int q_stride, double discount, int use_non_zero_discount_for_terminal_states,
                       int has_clip, double clip_low, double clip_high, int batch,
