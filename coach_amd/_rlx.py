@@ -214,6 +214,7 @@ class GemmDesc(ctypes.Structure):
         ("batch_inner", ctypes.c_int),
         ("a_batch_stride2", ctypes.c_longlong), ("b_batch_stride2", ctypes.c_longlong),
         ("bias_batch_stride2", ctypes.c_longlong),
+        ("n_fold", ctypes.c_int),
     ]
 
 
@@ -246,7 +247,7 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
          deriv_aux=None, aux_ld=None, deriv_kind=None, accumulate=False, batch=1,
          a_batch_stride=0, b_batch_stride=0, c_batch_stride=0, bias_batch_stride=0,
          aux_batch_stride=0, workspace=None, colsum_out=None, colsum_batch_stride=0, stream=None,
-         batch_inner=0, a_batch_stride2=0, b_batch_stride2=0, bias_batch_stride2=0):
+         batch_inner=0, a_batch_stride2=0, b_batch_stride2=0, bias_batch_stride2=0, n_fold=0):
     """Thin wrapper building an rlx_gemm_desc.  a_strides=(row, k), b_strides=(k, n) in elements."""
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = int(M), int(N), int(K), int(batch)
@@ -275,6 +276,7 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
     d.batch_inner = int(batch_inner)
     d.a_batch_stride2, d.b_batch_stride2 = int(a_batch_stride2), int(b_batch_stride2)
     d.bias_batch_stride2 = int(bias_batch_stride2)
+    d.n_fold = int(n_fold)
     if GEMM_HOOK is not None:
         GEMM_HOOK(GemmDesc.from_buffer_copy(d))
     lib().gemm(ctypes.byref(d), current_stream() if stream is None else stream)

@@ -59,6 +59,8 @@ struct GemmDev {
     int splits, kchunk;
     int act, deriv, accumulate;
     int vec_epi;                // fast kernel: 16-byte epilogue accesses are legal for this launch
+    int fold;                   // > 0: column n belongs to tower n / fold (its B, C, bias, colsum live at
+                                // tower * batch_stride + n % fold): towers that share A run as ONE GEMM
     float a_div;
 };
 
@@ -369,7 +371,8 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
         }
     } else {
         const int nq = min(n0 + (tid % (BN / 4)) * 4, g.N - 4);
-        b_off_o[0] = (long long)nq * g.b.stride_o;
+        b_off_o[0] = g.fold ? (long long)(nq / g.fold) * g.b.batch_stride + (long long)(nq % g.fold) * g.b.stride_o
+                            : (long long)nq * g.b.stride_o;
 #pragma unroll
         for (int p = 0; p < NB; ++p) b_kr[p] = (tid + p * kThreads) / (BN / 4);
     }
@@ -511,10 +514,13 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
     }
 
     if (do_colsum && n0 + tid < g.N) {
+        const int n = n0 + tid;
         if (g.splits > 1)
-            g.ws_colsum[((size_t)batch * g.splits + split) * g.N + n0 + tid] = csum;
+            g.ws_colsum[((size_t)batch * g.splits + split) * g.N + n] = csum;
+        else if (g.fold)
+            g.colsum[(size_t)(n / g.fold) * g.colsum_batch_stride + n % g.fold] = csum;
         else
-            g.colsum[(size_t)batch * g.colsum_batch_stride + n0 + tid] = csum;
+            g.colsum[(size_t)batch * g.colsum_batch_stride + n] = csum;
     }
 
     float *c = g.c + (size_t)batch * g.c_batch_stride;
@@ -546,9 +552,12 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
                     const float *sp = stage + rl * 33 + c4;
                     float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
                     float *dst = dst_base + (size_t)row * ld + col;
+                    const int tw = (!ws && g.fold) ? col / g.fold : 0, cl = (!ws && g.fold) ? col % g.fold : col;
+                    if (!ws && g.fold) dst = g.c + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
                     if (!ws) {
                         if (g.bias) {
                             const float4 bv = *reinterpret_cast<const float4 *>(
+                                g.fold ? g.bias + (size_t)tw * g.bias_batch_stride + cl :
                                 g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col);
                             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                         }
@@ -664,8 +673,11 @@ __global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g
         }
         const int i = gid << 2;
         const int row = i / g.N, col = i - row * g.N;
-        float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc + col;
-        const float *bias = g.bias ? g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col : nullptr;
+        const int tw = g.fold ? col / g.fold : batch, cl = g.fold ? col % g.fold : col;
+        float *c = g.c + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
+        const float *bias = !g.bias ? nullptr
+                            : g.fold ? g.bias + (size_t)tw * g.bias_batch_stride + cl
+                                     : g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col;
         const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld + col
                                  : nullptr;
 #pragma unroll
@@ -695,7 +707,10 @@ __global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g
             if (q == 0 && n < g.N) {
 #pragma unroll
                 for (int u = 1; u < SG; ++u) t += cpart[u * 64 + ox];
-                g.colsum[(size_t)batch * g.colsum_batch_stride + n] = t;
+                if (g.fold)
+                    g.colsum[(size_t)(n / g.fold) * g.colsum_batch_stride + n % g.fold] = t;
+                else
+                    g.colsum[(size_t)batch * g.colsum_batch_stride + n] = t;
             }
         }
     }
@@ -892,6 +907,7 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     g.b.stride_o = d.b_n_stride; g.b.stride_r = d.b_k_stride; g.b.batch_stride = d.b_batch_stride;
     g.c = d.C; g.ldc = d.ldc; g.c_batch_stride = d.c_batch_stride;
     g.bias = d.bias; g.bias_batch_stride = d.bias_batch_stride;
+    g.fold = d.n_fold > 0 ? d.n_fold : 0;
     g.inner = d.batch_inner > 0 ? d.batch_inner : (1 << 30);
     g.a.batch_stride2 = d.a_batch_stride2; g.b.batch_stride2 = d.b_batch_stride2;
     g.bias_batch_stride2 = d.bias_batch_stride2;
@@ -965,6 +981,25 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
                                                  d.aux_batch_stride % 4 == 0))));
     hipStream_t s = rlx::as_stream(stream);
     dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * splits);
+    if (g.fold) {
+        // towers folded into N: only the fast kernel with 16-byte epilogue and the float4 reduce know the
+        // column -> (tower, column) mapping; anything else runs the equivalent batched problem
+        // (one tower per batch index, A shared through a zero batch stride)
+        const bool fold_ok = fast && g.vec_epi && !b_vec_red && d.batch == 1 && d.N % g.fold == 0 &&
+                             g.fold % 4 == 0 && !d.deriv_aux && !d.accumulate && d.batch_inner <= 0 &&
+                             d.b_batch_stride % 4 == 0 && d.c_batch_stride % 4 == 0 &&
+                             d.bias_batch_stride % 4 == 0 && (long long)d.M * d.N < (1LL << 31);
+        if (!fold_ok) {
+            RLX_REQUIRE(d.batch == 1 && d.N % g.fold == 0, "rlx_gemm: n_fold=%d needs batch 1 and N %% n_fold == 0",
+                        g.fold);
+            rlx_gemm_desc t = d;
+            t.batch = d.N / g.fold;
+            t.N = g.fold;
+            t.n_fold = 0;
+            t.a_batch_stride = 0;
+            return rlx_gemm(&t, stream);
+        }
+    }
     int rc = -1;
     if (fast) {
         const bool u8 = d.a_is_u8 != 0;

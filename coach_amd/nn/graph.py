@@ -26,6 +26,9 @@ from .. import _rlx
 
 ALIGN = 4  # floats (16 bytes)
 SMALL_N = 16  # widest layer served by the narrow-dense kernels (csrc/dense_small.hip)
+# towers that read the same input run their first layer as ONE GEMM over the concatenated output
+# columns (rlx_gemm_desc.n_fold); RLX_NO_FOLD=1 restores one batched problem per tower
+FOLD_SHARED_INPUT = os.environ.get("RLX_NO_FOLD", "0") != "1"
 
 
 def _align(n):
@@ -263,6 +266,12 @@ class Dense(Layer):
                     q.y, q.y_tower_stride = y.data_ptr() + c * T * M * self.N * 4, M * self.N
                     q.towers, q.M, q.K, q.N, q.activation = T, M, self.K, self.N, _rlx.ACT[self.act]
                 ctx.lib.dense_small_forward_multi(ctypes.byref(arr), 2, ctx.stream)
+        elif not pair and x.towers == 0 and T > 1 and self.N % 4 == 0 and FOLD_SHARED_INPUT:
+            # the T towers read the SAME input: one GEMM over T*N columns loads (gathers) it once
+            _rlx.gemm(M, T * self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
+                      b_strides=(self.N, 1), ldc=self.N, bias=p.w(self.bname, t0, weights),
+                      activation=self.act, batch=1, b_batch_stride=wstride, c_batch_stride=M * self.N,
+                      bias_batch_stride=bstride, workspace=ctx.ws.splitk, n_fold=self.N)
         else:
             _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
                       bias=p.w(self.bname, t0, weights), activation=self.act, batch=TT,
@@ -301,7 +310,15 @@ class Dense(Layer):
         # dW[K,N] = x^T dz : A(k, m) = x[m, k]
         # (db = column sums of dz, accumulated by the same launch from the staged B slabs)
         if need_dw:
+            fold = x.towers == 0 and T > 1 and self.N % 4 == 0 and FOLD_SHARED_INPUT
+
             def dw(ws):
+                if fold:       # shared input: dW of all towers = x^T [dz_0 | dz_1 | ...] in one GEMM
+                    _rlx.gemm(self.K, T * self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K),
+                              b_strides=(self.N, 1), ldc=self.N, batch=1, b_batch_stride=M * self.N,
+                              c_batch_stride=p.stride(self.kname), workspace=ws, colsum_out=p.g(self.bname, t0),
+                              colsum_batch_stride=p.stride(self.bname), n_fold=self.N)
+                    return
                 _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
                           a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
                           c_batch_stride=p.stride(self.kname), workspace=ws,
@@ -367,12 +384,21 @@ class Conv2d(Layer):
         M = B * self.OH * self.OW
         rb, ko = self._tables(ctx, B)
         y = ctx.buffer(self.name, (T, M, self.Co), tag=tag)
-        _rlx.gemm(M, self.Co, self.K, x.data, p.w(self.kname, t0, weights), y, a_tabs=(rb, ko),
-                  a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=int(self.C % 4 == 0),
-                  bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
-                  a_batch_stride=x.tower_stride(), b_batch_stride=wstride,
-                  c_batch_stride=M * self.Co, bias_batch_stride=bstride,
-                  workspace=ctx.ws.splitk)
+        if not pair and x.towers == 0 and T > 1 and self.Co % 4 == 0 and self.C % 4 == 0 and FOLD_SHARED_INPUT:
+            # the towers convolve the SAME frames: one implicit-im2col GEMM over T*Co output channels
+            # gathers (and converts) every patch once instead of T times
+            _rlx.gemm(M, T * self.Co, self.K, x.data, p.w(self.kname, t0, weights), y, a_tabs=(rb, ko),
+                      a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=1, b_strides=(self.Co, 1),
+                      ldc=self.Co, bias=p.w(self.bname, t0, weights), activation=self.act, batch=1,
+                      b_batch_stride=wstride, c_batch_stride=M * self.Co, bias_batch_stride=bstride,
+                      workspace=ctx.ws.splitk, n_fold=self.Co)
+        else:
+            _rlx.gemm(M, self.Co, self.K, x.data, p.w(self.kname, t0, weights), y, a_tabs=(rb, ko),
+                      a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=int(self.C % 4 == 0),
+                      bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
+                      a_batch_stride=x.tower_stride(), b_batch_stride=wstride,
+                      c_batch_stride=M * self.Co, bias_batch_stride=bstride,
+                      workspace=ctx.ws.splitk)
         # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
         return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag), act=self.act)
 
@@ -387,7 +413,17 @@ class Conv2d(Layer):
         dz = dz.view(T, M, self.Co)
         # dW[K,Co] = cols^T dz : A(k, m) gathered with outer table = koff, reduction table = rowbase
         if need_dw:
+            fold = x.towers == 0 and T > 1 and self.Co % 4 == 0 and self.C % 4 == 0 and FOLD_SHARED_INPUT
+
             def dw(ws):
+                if fold:
+                    _rlx.gemm(self.K, T * self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb),
+                              a_u8=x.u8, a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=1, b_strides=(self.Co, 1),
+                              ldc=self.Co, batch=1, b_batch_stride=M * self.Co,
+                              c_batch_stride=p.stride(self.kname), workspace=ws,
+                              colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
+                              n_fold=self.Co)
+                    return
                 _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
                           a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
                           a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,

@@ -215,6 +215,11 @@ typedef struct rlx_gemm_desc {
      * copy of a multi-stream layer run as one launch (network_wrapper.py:188-213 parallel_prediction). */
     int batch_inner;
     long long a_batch_stride2, b_batch_stride2, bias_batch_stride2;
+    /* n_fold > 0 (with batch == 1): N counts the columns of N / n_fold towers that SHARE the A operand;
+     * column n uses tower n / n_fold: B, C, bias and colsum_out are addressed at
+     * tower * *_batch_stride + (n % n_fold).  The separate value / policy networks of Clipped PPO
+     * (clipped_ppo_agent.py:50) read the same observation: their first layer gathers it once. */
+    int n_fold;
 } rlx_gemm_desc;
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);

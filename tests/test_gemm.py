@@ -181,3 +181,33 @@ def test_gemm_rejects_bad_arguments(rlx, dev):
         gemm(0, 4, 4, t, t, t)
     with pytest.raises(RlxError, match="contiguous"):
         gemm(4, 4, 4, t, t, t, a_strides=(8, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,T", [(256, 64, 32, 2), (100, 23, 20, 2), (4096, 128, 64, 3)])
+def test_gemm_n_fold_shared_input(rlx, dev, M, K, N, T):
+    """rlx_gemm_desc.n_fold: T towers reading the SAME A as one GEMM over T*N columns (forward with
+    bias + activation, and the weight gradient with column sums) — including a shape the fast path
+    cannot take (K = 23), which must fall back to the equivalent batched problem."""
+    import torch
+    from coach_amd._rlx import gemm
+    rng = np.random.RandomState(M + K)
+    A = rng.randn(M, K).astype(np.float32)
+    W = (rng.randn(T, K, N) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(T, N).astype(np.float32)
+    ws = torch.empty(1 << 22, dtype=torch.float32, device=dev)
+    Ad, Wd, bd = (torch.from_numpy(x).to(dev) for x in (A, W, b))
+    y = torch.empty(T, M, N, device=dev)
+    gemm(M, T * N, K, Ad, Wd, y, b_strides=(N, 1), ldc=N, bias=bd, activation="tanh", batch=1,
+         b_batch_stride=K * N, c_batch_stride=M * N, bias_batch_stride=N, workspace=ws, n_fold=N)
+    ref = np.tanh(np.einsum("mk,tkn->tmn", A.astype(np.float64), W.astype(np.float64)) + b[:, None, :])
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    dz = torch.from_numpy(rng.randn(T, M, N).astype(np.float32)).to(dev)
+    dW = torch.empty(T, K, N, device=dev)
+    db = torch.empty(T, N, device=dev)
+    gemm(K, T * N, M, Ad, dz, dW, a_strides=(1, K), b_strides=(N, 1), ldc=N, batch=1, b_batch_stride=M * N,
+         c_batch_stride=K * N, workspace=ws, colsum_out=db, colsum_batch_stride=N, n_fold=N)
+    dzn = dz.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(dW.cpu().numpy(), np.einsum("mk,tmn->tkn", A.astype(np.float64), dzn),
+                               rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), dzn.sum(1), rtol=2e-4, atol=2e-4)
