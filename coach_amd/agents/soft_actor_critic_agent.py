@@ -112,7 +112,6 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         self.dq_da = torch.zeros(B, self.A, dtype=f32, device=dev)
         self.value_targets = torch.zeros(B, dtype=f32, device=dev)
         self.td_targets = torch.zeros(B, dtype=f32, device=dev)
-        self.grad_a = torch.zeros_like(self.networks["policy"].params.grads)
         self.policy_grads_sumabs = torch.zeros(1, dtype=f32, device=dev)
         self._finish_init()
 
