@@ -107,6 +107,92 @@ def build_off_policy(name, device, dist):
     return SoftActorCriticAgent(ap, env, device, dist=dist)
 
 
+def cpu_baseline_off_policy(name, budget_s=8.0):
+    """The oracle's update step (numpy restatement of the reference agent's learn_from_batch) timed
+    on a bounded number of repetitions; env-steps/s follows from the workload's updates-per-env-step
+    ratio (acting cost is not included: an upper bound on the CPU path)."""
+    import numpy as np
+    from coach_amd.nn import graph as G, networks as NW, actor_critic_nets as AC
+    rng = np.random.RandomState(0)
+
+    def arrays_of(build):
+        params = G.FlatParams()
+        mods = build(params)
+        params.finalize("cpu")
+        r = np.random.RandomState(0)
+        for m in mods:
+            m.initialize(r)
+        return params.named_arrays()
+
+    def timed(fn):
+        t0, n = time.perf_counter(), 0
+        while n < 2 or (time.perf_counter() - t0 < budget_s and n < 200):
+            fn(); n += 1
+        return (time.perf_counter() - t0) / n, n
+
+    if name in ("c1", "c3"):
+        from oracle.agents import DQNOracle
+        shape, A, B = ((4,), 2, 32) if name == "c1" else (FRAME + (4,), 4, 32)
+
+        def build(p):
+            torso, feat = NW.build_torso(p, "main", shape, "relu", 1)
+            return [torso, G.Dense(p, "main/q_head/dense", feat, A, None, 1)]
+        o = DQNOracle(arrays_of(build), shape, A, huber=(name == "c3"))
+        obs = rng.randint(0, 256, size=(B,) + shape).astype(np.uint8) if name == "c3" else rng.randn(B, 4).astype(np.float32)
+        a, r, d = rng.randint(0, A, B), rng.randn(B).astype(np.float32), rng.rand(B) < 0.1
+        t, n = timed(lambda: o.learn_from_batch(obs, obs, a, r, d, 0.99))
+        per_step = 1.0 if name == "c1" else 0.25
+    elif name == "c4":
+        from oracle import ac_nets as O
+        D, A, B = 17, 6, 100
+
+        def ba(p):
+            e, f = AC._mlp(p, "actor/embedder", D, (400,), "relu"); m, f = AC._mlp(p, "actor/middleware", f, (300,), "relu")
+            return [e, m, G.Dense(p, "actor/ddpg_actor_head/fc_mean", f, A, "tanh")]
+
+        def bc(p):
+            m, f = AC._mlp(p, "critic/middleware", D + A, (400, 300), "relu", towers=2)
+            return [m, G.Dense(p, "critic/v_head/output", f, 1, None, 2)]
+        oa, oc = O.ActorOracle(arrays_of(ba), 1.0, lr=1e-3), O.CriticOracle(arrays_of(bc), streams=2)
+        batch = (rng.randn(B, D).astype(np.float32), rng.uniform(-1, 1, (B, A)).astype(np.float32),
+                 rng.randn(B).astype(np.float32), np.zeros(B, bool), rng.randn(B, D).astype(np.float32))
+        it = [0]
+
+        def f():
+            it[0] += 1
+            O.td3_update(oa, oc, batch, rng.normal(0, 0.2, (B, A)), it[0], -np.ones(A, np.float32), np.ones(A, np.float32))
+        t, n = timed(f)
+        per_step = 1.0
+    else:
+        from oracle import ac_nets as O
+        D, A, B = 376, 17, 256
+
+        def mlp2(prefix, head, n_out):
+            def b(p):
+                e, f = AC._mlp(p, prefix + "/embedder", D, (256,), "relu"); m, f = AC._mlp(p, prefix + "/middleware", f, (256,), "relu")
+                return [e, m, G.Dense(p, head, f, n_out, None)]
+            return b
+
+        def bq(p):
+            return [G.Dense(p, "q/q_head/obs_fc", D, 256, "relu", 2), G.Dense(p, "q/q_head/act_fc", A, 256, "relu", 2),
+                    G.Dense(p, "q/q_head/fc1", 256, 256, "relu", 2), G.Dense(p, "q/q_head/q_output", 256, 1, None, 2)]
+        op = O.SACPolicyOracle(arrays_of(mlp2("policy", "policy/sac_policy_head/policy_mu_logsig", 2 * A)))
+        ov = O.SACValueOracle(arrays_of(mlp2("v", "v/v_values_head/output", 1)))
+        oq = O.SACQOracle(arrays_of(bq))
+        batch = (rng.randn(B, D).astype(np.float32), rng.uniform(-1, 1, (B, A)).astype(np.float32),
+                 rng.randn(B).astype(np.float32), np.zeros(B, bool), rng.randn(B, D).astype(np.float32))
+        t, n = timed(lambda: O.sac_update(op, oq, ov, batch, rng.standard_normal((3, B, A))))
+        per_step = 1.0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p_.get("num_threads", 1) for p_ in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": round(1.0 / (t * per_step), 2), "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+            "grad_updates_per_s": round(1.0 / t, 2),
+            "sample": "oracle/ update step (numpy): %d repetitions, %.4f s per update; acting cost not included" % (n, t)}
+
+
 def run_off_policy(args, device, dist):
     from coach_amd.core_types import RunPhase
     desc, n_env, vsteps, heat = OFF_POLICY[args.workload]
@@ -139,6 +225,8 @@ def run_off_policy(args, device, dist):
            "config": {"workload": desc, "env_steps_per_step_per_gpu": n_env * vsteps,
                       "parallelism": "dp%d" % dist.world_size, "hip_graphs": bool(agent.use_graphs)},
            "episode_stats": {k: (v if np.isfinite(v) else None) for k, v in agent.episode_statistics().items()}}
+    if dist.rank == 0 and dist.world_size == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_off_policy(args.workload)
     if dist.rank == 0:
         print(json.dumps(out))
 
