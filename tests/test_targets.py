@@ -72,3 +72,35 @@ def test_hip_ac_targets_match_reference(golden, rlx, dev):
     rlx.td3_smooth_actions(dev_tensor(na, dev), dev_tensor(g["td3_noise"], dev), 0.5, lo, hi, B, A, out, 0)
     ref = np.clip(na + g["td3_noise"].clip(-0.5, 0.5), np.float32(-0.8), np.float32(0.8))
     assert np.array_equal(out.cpu().numpy(), ref.astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dqn", "ddqn"])
+@pytest.mark.parametrize("huber", [0, 1])
+def test_hip_dqn_head_loss_matches_reference_targets_and_oracle_loss(golden, rlx, dev, name, huber):
+    """The fused launch (targets + |TD error| + QHead loss + gradient): TD targets / errors bit-exact
+    against the fixtures produced by the reference's DQNAgent / DDQNAgent.learn_from_batch, loss and
+    gradient against the oracle's head loss on those targets (importance weights in fp64)."""
+    import torch
+    from oracle.losses import regression_head_loss
+    g = golden("targets")
+    q = g[name + "_q_onl"]
+    B, A = q.shape
+    rng = np.random.RandomState(B)
+    w = rng.rand(B) + 0.1
+    dq = torch.empty(B, A, device=dev)
+    tt = torch.empty(B, A, device=dev)
+    err = torch.empty(B, dtype=torch.float64, device=dev)
+    loss = torch.zeros(1, device=dev)
+    st = status_tensor(dev)
+    sel = dev_tensor(g[name + "_q_next_o"], dev) if name == "ddqn" else None
+    rlx.dqn_head_loss(dev_tensor(q, dev), A, dev_tensor(g[name + "_q_next_t"], dev), sel, A,
+                      dev_tensor(g[name + "_actions"], dev, np.int32), dev_tensor(g[name + "_rewards"], dev),
+                      dev_tensor(g[name + "_go"], dev, np.uint8), dev_tensor(w, dev), 0.99, B, A, huber, 1.0, dq, A,
+                      err, tt, A, loss, st, 0)
+    assert int(st.item()) == 0
+    assert np.array_equal(tt.cpu().numpy(), g[name + "_targets"])      # fp32, bit-exact
+    assert np.array_equal(err.cpu().numpy(), g[name + "_errors"])      # fp64, bit-exact
+    ref_loss, ref_dq = regression_head_loss(q, g[name + "_targets"], w.astype(np.float32), "huber" if huber else "mse")
+    np.testing.assert_allclose(float(loss.item()), ref_loss, rtol=1e-6)
+    np.testing.assert_allclose(dq.cpu().numpy(), ref_dq, rtol=1e-6, atol=1e-9)
