@@ -603,6 +603,113 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Thin GEMM: small M*N with a short reduction (the MLP layers of DQN / TD3 / SAC at B = 32..256, the
+// FC input gradient of the conv nets).  The tiled kernels above cover such a problem with a handful of
+// 64x64 workgroups and recover parallelism by splitting K over workgroups — which costs a second
+// (reduce) launch, and a launch is ~5 us here.  This kernel splits K over the 4 WAVES of a workgroup
+// instead: a workgroup owns one 32x32 output tile, every 128-wide K slab is staged once in LDS, wave w
+// multiplies sub-slab [32w, 32w+32), and the four partial tiles are summed through LDS in a fixed
+// order (reproducible) before the bias / activation / derivative epilogue.  One launch, 4x the
+// workgroups of the 64x64 tiling.  Scalar (4-byte) operand loads with clamped indices: no alignment
+// or divisibility requirements.
+template <bool A_CONTIG_K, bool B_CONTIG_N>
+__global__ void __launch_bounds__(kThreads) gemm_thin_kernel(const GemmDev g) {
+    constexpr int KS = 128, LD = 33, NE = 32 * KS / kThreads;      // 16 elements per thread per operand
+    __shared__ float As[KS * LD];
+    __shared__ float Bs[KS * LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int batch = blockIdx.z;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const float *abase = static_cast<const float *>(g.a.base) + batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2);
+    const float *bbase = static_cast<const float *>(g.b.base) + batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2);
+
+    // element e = tid + p*256 of a 32 x 128 operand tile: (outer, k) with the contiguous index fastest
+    int a_o[NE], a_k[NE], b_o[NE], b_k[NE];
+    long long a_oo[NE], b_oo[NE];
+#pragma unroll
+    for (int p = 0; p < NE; ++p) {
+        const int e = tid + p * kThreads;
+        a_k[p] = A_CONTIG_K ? e % KS : e / 32;
+        a_o[p] = A_CONTIG_K ? e / KS : e % 32;
+        b_k[p] = B_CONTIG_N ? e / 32 : e % KS;
+        b_o[p] = B_CONTIG_N ? e % 32 : e / KS;
+        a_oo[p] = (long long)min(m0 + a_o[p], g.M - 1) * g.a.stride_o;
+        b_oo[p] = (long long)min(n0 + b_o[p], g.N - 1) * g.b.stride_o;
+    }
+    float ra[NE], rb[NE];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < NE; ++p) {
+            const int ka = k0 + a_k[p], kb = k0 + b_k[p];
+            const float va = abase[a_oo[p] + (long long)min(ka, g.K - 1) * g.a.stride_r];
+            const float vb = bbase[b_oo[p] + (long long)min(kb, g.K - 1) * g.b.stride_r];
+            ra[p] = ka < g.K ? va : 0.f;
+            rb[p] = kb < g.K ? vb : 0.f;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int p = 0; p < NE; ++p) {
+            As[a_k[p] * LD + a_o[p]] = ra[p];
+            Bs[b_k[p] * LD + b_o[p]] = rb[p];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0 && tid < 32;
+    float csum = 0.f;
+    load(0);
+    store();
+    __syncthreads();
+    for (int k0 = 0; k0 < g.K; k0 += KS) {
+        const bool more = k0 + KS < g.K;
+        if (more) load(k0 + KS);
+        const float *ap = As + (w * 32 + hi) * LD + l31;
+        const float *bp = Bs + (w * 32 + hi) * LD + l31;
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * LD], bp[kk * LD], acc, 0, 0, 0);
+        if (do_colsum) {
+            float sc = 0.f;
+            for (int kk = 0; kk < KS; ++kk) sc += Bs[kk * LD + tid];
+            csum += sc;
+        }
+        __syncthreads();
+        if (more) {
+            store();
+            __syncthreads();
+        }
+    }
+    if (do_colsum && n0 + tid < g.N) g.colsum[(size_t)batch * g.colsum_batch_stride + n0 + tid] = csum;
+
+    // ---- the four K-quarter partials -> LDS (As is exactly 4 x 32 x 33 floats), fixed-order sum
+    float *stage = As + w * (32 * LD);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * LD + l31] = acc[r];
+    __syncthreads();
+    const int rl = tid >> 3, c4 = (tid & 7) * 4;
+    const int row = m0 + rl;
+    if (row >= g.M) return;
+    float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc;
+    const float *bias = g.bias ? g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) : nullptr;
+    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + c4 + j;
+        if (col >= g.N) continue;
+        const int o = rl * LD + c4 + j;
+        float v = ((As[o] + As[32 * LD + o]) + As[2 * 32 * LD + o]) + As[3 * 32 * LD + o];
+        v = apply_act(v + (bias ? bias[col] : 0.f), g.act);
+        if (aux) v *= act_deriv(aux[col], g.deriv);
+        c[col] = g.accumulate ? c[col] + v : v;
+    }
+}
+
 __global__ void splitk_reduce_kernel(const GemmDev g) {
     const long long mn = (long long)g.M * g.N;
     const int batch = blockIdx.y;
@@ -865,6 +972,14 @@ inline int rlx_split_min_k() {
     return v;
 }
 
+inline bool rlx_no_thin_gemm() {
+    static const bool v = [] {
+        const char *e = getenv("RLX_NO_THIN_GEMM");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 // RLX_GEMM_GENERIC=1 forces the bounds-checked kernel (used by the tests to cross-check the paths)
 inline bool rlx_force_generic_gemm() {
     static const bool v = [] {
@@ -933,6 +1048,23 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
         const long long other = b_vec_red ? d.b_n_stride : d.b_k_stride;
         g.b.vec_ok = aligned16(d.B) && (other % 4 == 0) && ((d.b_batch_stride % 4) == 0) &&
                      ((d.b_batch_stride2 % 4) == 0);
+    }
+
+    // thin path: few output tiles and a short reduction -> one launch with K split over the waves
+    if (!rlx_no_thin_gemm() && !d.a_row_tab && !d.a_k_tab && !d.a_is_u8 && d.n_fold <= 0 && d.K <= 1024) {
+        const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
+        if (t64 <= 64 && (long long)d.N * d.K <= (1 << 18)) {      // MLP-sized weights only: the scalar loads lose on wide B
+            const bool a_ck = d.a_k_stride == 1, b_cn = d.b_n_stride == 1;
+            dim3 tgrid((d.N + 31) / 32, (d.M + 31) / 32, d.batch);
+            g.splits = 1; g.kchunk = d.K; g.ws = nullptr; g.vec_epi = 0; g.fold = 0;
+            hipStream_t ts = rlx::as_stream(stream);
+            if (a_ck && b_cn) gemm_thin_kernel<true, true><<<tgrid, kThreads, 0, ts>>>(g);
+            else if (a_ck) gemm_thin_kernel<true, false><<<tgrid, kThreads, 0, ts>>>(g);
+            else if (b_cn) gemm_thin_kernel<false, true><<<tgrid, kThreads, 0, ts>>>(g);
+            else gemm_thin_kernel<false, false><<<tgrid, kThreads, 0, ts>>>(g);
+            RLX_LAUNCH_CHECK();
+            return RLX_OK;
+        }
     }
 
     // fast path: every 4-element vector group of both operands is full, in range and aligned

@@ -211,3 +211,39 @@ def test_gemm_n_fold_shared_input(rlx, dev, M, K, N, T):
     np.testing.assert_allclose(dW.cpu().numpy(), np.einsum("mk,tmn->tkn", A.astype(np.float64), dzn),
                                rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(db.cpu().numpy(), dzn.sum(1), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(32, 256, 256), (100, 300, 400), (37, 45, 130), (256, 64, 1000), (5, 3, 1)])
+def test_gemm_thin_all_layouts(rlx, dev, M, N, K):
+    """MLP-sized problems take the single-launch thin kernel (K split over the waves of a workgroup):
+    all four operand layouts, two towers with two-level batch offsets, bias + activation, derivative
+    epilogue, accumulate, and the fused column sums of B, against fp64 numpy."""
+    import torch
+    from coach_amd._rlx import gemm
+    rng = np.random.RandomState(M * 7 + N + K)
+    T = 2
+    A = rng.randn(T, M, K).astype(np.float32)
+    B = (rng.randn(T, K, N) / np.sqrt(K)).astype(np.float32)
+    bias = rng.randn(T, N).astype(np.float32)
+    aux = np.tanh(rng.randn(T, M, N)).astype(np.float32)
+    ref = np.einsum("tmk,tkn->tmn", A.astype(np.float64), B.astype(np.float64))
+    ws = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+    for a_t in (False, True):
+        for b_t in (False, True):
+            Ad = dev_tensor(np.ascontiguousarray(A.transpose(0, 2, 1)) if a_t else A, dev)
+            Bd = dev_tensor(np.ascontiguousarray(B.transpose(0, 2, 1)) if b_t else B, dev)
+            C = torch.full((T, M, N), 3.0, dtype=torch.float32, device=dev)
+            cs = torch.empty(T, N, dtype=torch.float32, device=dev)
+            kw = dict(a_strides=(1, M) if a_t else (K, 1), b_strides=(1, K) if b_t else (N, 1), batch=T,
+                      a_batch_stride=M * K, b_batch_stride=K * N, c_batch_stride=M * N, workspace=ws)
+            gemm(M, N, K, Ad, Bd, C, bias=dev_tensor(bias, dev), bias_batch_stride=N, activation="relu",
+                 colsum_out=cs, colsum_batch_stride=N, **kw)
+            np.testing.assert_allclose(C.cpu().numpy(), np.maximum(ref + bias[:, None, :], 0), **_tol(K))
+            np.testing.assert_allclose(cs.cpu().numpy(), B.astype(np.float64).sum(1), rtol=2e-5,
+                                       atol=2e-6 * np.sqrt(K) * 4)
+            gemm(M, N, K, Ad, Bd, C, deriv_aux=dev_tensor(aux, dev), aux_ld=N, aux_batch_stride=M * N,
+                 deriv_kind="tanh", **kw)
+            gemm(M, N, K, Ad, Bd, C, deriv_aux=dev_tensor(aux, dev), aux_ld=N, aux_batch_stride=M * N,
+                 deriv_kind="tanh", accumulate=True, **kw)
+            np.testing.assert_allclose(C.cpu().numpy(), 2 * ref * (1 - aux.astype(np.float64) ** 2), **_tol(K))
