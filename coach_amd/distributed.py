@@ -22,7 +22,8 @@ class GradientSync(object):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.enabled = self.world_size > 1
+        # RLX_FORCE_DIST=1: take the collective path even at world size 1 (exercises RCCL on a 1-GPU box)
+        self.enabled = self.world_size > 1 or os.environ.get("RLX_FORCE_DIST", "0") == "1"
         if self.enabled and not dist.is_initialized():
             if backend is None:
                 backend = os.environ.get("RLX_DIST_BACKEND") or \

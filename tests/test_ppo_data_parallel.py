@@ -19,10 +19,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, sync_mode):
+def _worker(rank, world, port, out_dir, sync_mode, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), RLX_DIST_BACKEND="gloo", RLX_SYNC_ALLREDUCE=sync_mode)
+                      MASTER_PORT=str(port), RLX_DIST_BACKEND=backend, RLX_SYNC_ALLREDUCE=sync_mode,
+                      RLX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
     from coach_amd.core_types import EnvironmentSteps
@@ -31,7 +32,7 @@ def _worker(rank, world, port, out_dir, sync_mode):
         SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
     dev = torch.device("cuda:0")
     dist = GradientSync()
-    assert dist.enabled and dist.world_size == 2
+    assert dist.enabled and dist.world_size == world
     ep = SyntheticVectorEnvironmentParameters("image", 8, (44, 44), 4, episode_length=8, seed=21)
     env = SyntheticVectorEnvironment(ep, dev, rank=dist.rank)
     ap = ClippedPPOAgentParameters()
@@ -64,6 +65,19 @@ def test_two_rank_ppo_iteration(tmp_path):
     np.testing.assert_array_equal(w[("0", 0)], w[("1", 0)])  # overlap == blocking
     o0, o1 = np.load(tmp_path / "obs_0_0.npy"), np.load(tmp_path / "obs_0_1.npy")
     assert not np.array_equal(o0, o1)                        # different env shards per rank
+
+
+@pytest.mark.timeout(600)
+def test_rccl_path_world_size_one(tmp_path):
+    """The real RCCL (backend "nccl") collectives at world size 1, where the sum is the identity: the
+    overlapped two-bucket async all-reduce between hipGraph replays must give exactly the weights of
+    the blocking all-reduce (stream ordering between torch's stream, the graphs and RCCL's stream)."""
+    import torch.multiprocessing as mp
+    for mode in ("1", "0"):
+        mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), mode, "nccl"), nprocs=1, join=True)
+    w1, w0 = (np.load(tmp_path / ("w_%s_0.npy" % m)) for m in "10")
+    assert np.isfinite(w0).all()
+    np.testing.assert_array_equal(w0, w1)
 
 
 def test_split_backward_equals_full(dev):
