@@ -296,7 +296,7 @@ class ClippedPPOAgent(object):
         if self.norm is not None:
             # pre_network_filter over the whole dataset, statistics updated first (:320-322)
             mem.gather_states(rows, n, self.ds_obs_raw[:n])
-            self.norm.filter(self.ds_obs_raw[:n], update_internal_state=True, out=self.ds_obs[:n])
+            self.norm.filter(self.ds_obs_raw[:n], update_internal_state=self.dist is None, out=self.ds_obs[:n])
 
         def chunk_obs(c0, m):
             if self.norm is not None:
@@ -323,6 +323,10 @@ class ClippedPPOAgent(object):
         GAE scan per episode, (adv - mean) / std; plus the old-policy probabilities."""
         n = self.memory.num_transitions()
         rows = self.memory.dataset_rows()
+        if self.norm is not None and self.dist is not None:
+            # shared running statistics: the collective stays outside the captured graph
+            self.memory.gather_states(rows, n, self.ds_obs_raw[:n])
+            self.norm.push_shared(self.ds_obs_raw[:n], self.dist)
         self._run(("fill", n), lambda: self._fill_advantages_device(n, rows))
 
     def _gather_minibatch(self, m, i=0):

@@ -86,6 +86,26 @@ __global__ void running_stats_push_kernel(const T *__restrict__ samples, long lo
 
 __global__ void running_stats_count_kernel(double *count, double n) { *count += n; }
 
+// count is updated by thread (0,0) AFTER every thread of the (single) workgroup has read it
+__global__ void running_stats_merge_kernel(const double *__restrict__ delta, int dim,
+                                           double *__restrict__ sum, double *__restrict__ sumsq,
+                                           double *__restrict__ count, double *__restrict__ mean,
+                                           double *__restrict__ stdv, double epsilon) {
+    const double cnt = *count + delta[2 * dim];
+    __syncthreads();
+    for (int j = threadIdx.x; j < dim; j += blockDim.x) {
+        const double new_sum = sum[j] + delta[j];
+        const double new_sq = sumsq[j] + delta[dim + j];
+        const double m = new_sum / cnt;
+        const double var = (new_sq - cnt * (m * m)) / fmax(cnt - 1.0, 1.0);
+        sum[j] = new_sum;
+        sumsq[j] = new_sq;
+        mean[j] = m;
+        stdv[j] = sqrt(fmax(var, epsilon));
+    }
+    if (threadIdx.x == 0) *count = cnt;
+}
+
 template <typename T>
 __global__ void running_stats_normalize_kernel(const T *__restrict__ x, long long total, int dim,
                                                const double *__restrict__ mean,
@@ -187,6 +207,16 @@ int rlx_running_stats_push(const void *samples, int samples_are_f64, long long n
             static_cast<const float *>(samples), n, dim, sum, sum_squares, count, mean, std, epsilon);
     RLX_LAUNCH_CHECK();
     running_stats_count_kernel<<<1, 1, 0, s>>>(count, (double)n);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_running_stats_merge(const double *delta, int dim, double *sum, double *sum_squares,
+                            double *count, double *mean, double *std, double epsilon, void *stream) {
+    RLX_REQUIRE(delta && sum && sum_squares && count && mean && std, "rlx_running_stats_merge: null pointer");
+    RLX_REQUIRE(dim > 0, "rlx_running_stats_merge: dim=%d", dim);
+    running_stats_merge_kernel<<<1, 256, 0, rlx::as_stream(stream)>>>(delta, dim, sum, sum_squares, count,
+                                                                      mean, std, epsilon);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

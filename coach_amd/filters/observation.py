@@ -80,6 +80,20 @@ class ObservationNormalizationFilter(ObservationFilter):
         self.mean = torch.zeros(dim, dtype=f64, device=device)
         self.std = torch.full((dim,), float(np.sqrt(epsilon)), dtype=f64, device=device)
 
+    def push_shared(self, observation, dist):
+        """Data-parallel state update: every rank's batch enters every rank's statistics (the reference
+        publishes each push to the other workers, shared_running_stats.py:46-67).  One all-reduce of
+        [sum | sum_squares | count] = 2*dim+1 doubles; not capturable in a hipGraph."""
+        n, D = observation.shape[0], self.dim
+        s = _rlx.current_stream()
+        delta = torch.zeros(2 * D + 1, dtype=torch.float64, device=self.device)
+        scratch = torch.empty(2 * D, dtype=torch.float64, device=self.device)
+        _rlx.lib().running_stats_push(observation, int(observation.dtype == torch.float64), n, D, delta[:D],
+                                      delta[D:2 * D], delta[2 * D:], scratch[:D], scratch[D:], self.eps, s)
+        dist.all_reduce_sum(delta)
+        _rlx.lib().running_stats_merge(delta, D, self.sum, self.sum_squares, self.count, self.mean, self.std,
+                                       self.eps, s)
+
     def filter(self, observation, update_internal_state=True, out=None):
         n = observation.shape[0]
         is64 = observation.dtype == torch.float64

@@ -170,6 +170,12 @@ int rlx_running_stats_push(const void *samples, int samples_are_f64, long long n
                            double *sum, double *sum_squares, double *count, double *mean,
                            double *std, double epsilon,
                            void *stream);                            /* utilities/shared_running_stats.py:130-140 */
+/* Data-parallel running statistics (the reference shares them between workers through Redis pub/sub,
+ * utilities/shared_running_stats.py:46-67): `delta` = [sum(dim) | sum_squares(dim) | count(1)] summed
+ * over all ranks (one all-reduce of 2*dim+1 doubles) is added to the running totals and mean / std
+ * are recomputed with the formulas of :137-140. */
+int rlx_running_stats_merge(const double *delta, int dim, double *sum, double *sum_squares,
+                            double *count, double *mean, double *std, double epsilon, void *stream);
 int rlx_running_stats_normalize(const void *x, int x_is_f64, long long n, int dim,
                                 const double *mean, const double *std, double clip_low,
                                 double clip_high, float *out32, double *out64,
