@@ -386,13 +386,22 @@ class ClippedPPOAgent(object):
                 if self.dist is None:
                     self._run(("mb", m, clip, scale, i), lambda: (self._minibatch_fb(m, clip, i=i),
                                                                   self._minibatch_finish(scale)))
-                elif os.environ.get("RLX_SYNC_ALLREDUCE", "0") == "1":
-                    self._run(("mb_fb", m, clip, i), lambda: self._minibatch_fb(m, clip, i=i))
+                elif os.environ.get("RLX_SYNC_ALLREDUCE", "1") == "1":
+                    # default: one blocking all-reduce per minibatch between two graph segments; the Adam
+                    # step of minibatch i-1 rides in the same graph as forward/backward of minibatch i
+                    if i == 0:
+                        self._run(("mb_fb", m, clip, i), lambda: self._minibatch_fb(m, clip, i=i))
+                    else:
+                        self._run(("mb_fin_fb", m, clip, scale, i),
+                                  lambda: (self._minibatch_finish(scale), self._minibatch_fb(m, clip, i=i)))
                     self.dist.all_reduce_sum(self.networks["main"].params.grads)
-                    self._run(("mb_fin", scale), lambda: self._minibatch_finish(scale))
+                    if i == nmb - 1:
+                        self._run(("mb_fin", scale), lambda: self._minibatch_finish(scale))
                 else:
-                    # overlap: the FC + head gradients (95 % of the 13.5 MB) are final before the conv
-                    # backward starts; their all-reduce runs on RCCL's stream underneath it
+                    # RLX_SYNC_ALLREDUCE=0 — overlap: the FC + head gradients (95 % of the 13.5 MB) are final
+                    # before the conv backward starts; their all-reduce runs on RCCL's stream underneath
+                    # it.  Costs a third graph segment and a second collective per minibatch (+50 us
+                    # measured at world size 1), which eats what it hides at 13.5 MB — opt-in.
                     net = self.networks["main"]
                     grads, off = net.params.grads, net.late_gradient_offset()
                     self._run(("mb_p1", m, clip, i), lambda: self._minibatch_fb(m, clip, True, i=i))
