@@ -151,8 +151,7 @@ class DDPGAgent(VectorOffPolicyAgent):
                                _rlx.current_stream())
 
     def _sync(self, net):
-        if self.dist is not None:
-            self.dist.all_reduce_sum(net.params.grads)
+        self._allreduce(net.params.grads)
 
     def _learn_device(self, b):
         actor, critic = self.networks["actor"], self.networks["critic"]
@@ -181,10 +180,7 @@ class DDPGAgent(VectorOffPolicyAgent):
             if self.dist else 1.0
 
     def learn_from_batch(self, batch):
-        if self.dist is None:
-            self._run(("learn",), lambda: self._learn_device(batch))
-        else:
-            self._learn_device(batch)
+        self._run(("learn",), lambda: self._learn_device(batch))
         critic = self.networks["critic"]
         self.signals = {"Loss": critic.loss[0], "Grads (unclipped)": critic.norm}
         return critic.loss[:critic.T].sum()

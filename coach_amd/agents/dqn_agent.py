@@ -110,7 +110,7 @@ class DQNAgent(VectorOffPolicyAgent):
                              b.actions(), b.rewards(), b.game_overs(), self.ap.algorithm.discount,
                              importance_weights=weights, td_errors=self.td_errors,
                              double_dqn=self.double_dqn, grad_scale=self._grad_scale(),
-                             sync=self.dist, states_pair=b._info.get("states_pair"))
+                             sync=self if self.dist is not None else None, states_pair=b._info.get("states_pair"))
 
     def _grad_scale(self):
         netp = self.ap.network_wrappers["main"]
@@ -121,10 +121,7 @@ class DQNAgent(VectorOffPolicyAgent):
         """DQNAgent.learn_from_batch (dqn_agent.py:81-113)."""
         per = isinstance(self.memory, PrioritizedExperienceReplay)
         weights = batch.info("weight") if per else None           # fp64, as rlx_per_sample wrote them
-        if self.dist is None:
-            self._run(("learn", per), lambda: self._learn_device(batch, weights))
-        else:
-            self._learn_device(batch, weights)
+        self._run(("learn", per), lambda: self._learn_device(batch, weights))
         if per:                                   # update_transition_priorities_and_get_weights
             self.memory.update_priorities(batch.info("idx"), self.td_errors)
         loss = self.networks["main"].loss

@@ -136,8 +136,7 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
 
     # ------------------------------------------------------------------------------- training
     def _sync(self, net):
-        if self.dist is not None:
-            self.dist.all_reduce_sum(net.params.grads)
+        self._allreduce(net.params.grads)
 
     def _scale(self, name):
         netp = self.ap.network_wrappers[name]
@@ -197,10 +196,7 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         B = self.batch_size
         z = np.random.standard_normal((3, B, self.A))
         self.normals.copy_(self._to_device("sac_z", z, torch.float64))
-        if self.dist is None:
-            self._run(("learn",), lambda: self._learn_device(batch))
-        else:
-            self._learn_device(batch)
+        self._run(("learn",), lambda: self._learn_device(batch))
         qn = self.networks["q"]
         self.signals = {"Loss": qn.loss.sum(), "Grads (unclipped)": qn.norm,
                         "V loss": self.networks["v"].loss}

@@ -151,8 +151,7 @@ class TD3Agent(DDPGAgent):
         alg, B = self.ap.algorithm, self.batch_size
         z = np.random.normal(0, alg.policy_noise, (B, self.A))                  # :162 (host stream)
         self.noise.copy_(self._to_device("td3_noise", z, torch.float64))
-        graph = self.dist is None
-        run = self._run if graph else (lambda k, f: f())
+        run = self._run
         run(("critic",), lambda: self._critic_device(batch))
         if self.training_iteration % alg.update_policy_every_x_episode_steps == 0:   # :186
             run(("actor",), lambda: self._actor_device(batch))

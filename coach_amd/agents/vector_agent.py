@@ -31,9 +31,68 @@ def capture(fn):
     return g
 
 
+class _SegmentedCapture(object):
+    """A call sequence with collectives in it: every stretch between two all-reduces becomes its own
+    hipGraph; the collectives stay eager calls between the replays (RCCL is not captured)."""
+
+    def __init__(self):
+        self.items, self._g, self._ctx = [], None, None
+
+    def begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(self._g, capture_error_mode="thread_local")
+        self._ctx.__enter__()
+
+    def end(self, *exc):
+        self._ctx.__exit__(*(exc or (None, None, None)))
+        self.items.append(("graph", self._g))
+
+    def split(self, flat):
+        self.end()
+        self.items.append(("all_reduce", flat))
+        self.begin()
+
+
 class GraphRunner(object):
     """Run a pure-device call sequence eagerly once (allocations), capture it into a hipGraph the
-    second time, replay afterwards.  RLX_NO_GRAPHS=1 keeps everything eager."""
+    second time, replay afterwards.  RLX_NO_GRAPHS=1 keeps everything eager.  With data parallelism
+    (`self.dist`) the sequence is cut at every `_allreduce` call into graph segments."""
+
+    _segcap = None
+
+    def _allreduce(self, flat):
+        """Sum `flat` over the ranks: an eager collective, or a segment boundary while capturing."""
+        if self._segcap is not None:
+            self._segcap.split(flat)
+        elif getattr(self, "dist", None) is not None:
+            self.dist.all_reduce_sum(flat)
+
+    all_reduce_sum = _allreduce          # the `sync` object handed to network-level updates
+
+    def _run_segmented(self, key, fn):
+        segs = self._graphs.get(key)
+        if segs is None:
+            if key not in self._warm:
+                self._warm.add(key)
+                return fn()
+            torch.cuda.synchronize()
+            cap = self._segcap = _SegmentedCapture()
+            cap.begin()
+            try:
+                fn()
+            except BaseException:
+                import sys
+                self._segcap = None
+                cap.end(*sys.exc_info())
+                raise
+            self._segcap = None
+            cap.end()
+            segs = self._graphs[key] = cap.items
+        for kind, obj in segs:
+            if kind == "graph":
+                obj.replay()
+            else:
+                self.dist.all_reduce_sum(obj)
 
     def _init_graphs(self, use_graphs=None):
         if use_graphs is None:
@@ -44,6 +103,8 @@ class GraphRunner(object):
     def _run(self, key, fn):
         if not self.use_graphs:
             return fn()
+        if getattr(self, "dist", None) is not None:
+            return self._run_segmented(key, fn)
         g = self._graphs.get(key)
         if g is not None:
             return g.replay()

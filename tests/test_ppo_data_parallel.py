@@ -129,6 +129,72 @@ def test_two_rank_shared_observation_statistics(tmp_path):
     np.testing.assert_allclose(r0["std"], std, rtol=1e-12)
 
 
+def _off_policy_worker(rank, world, port, out_dir, name, graphs):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), RLX_DIST_BACKEND="gloo")
+    import random
+    import torch
+    from coach_amd.core_types import EnvironmentSteps
+    from coach_amd.distributed import GradientSync
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters as EP)
+    from coach_amd.memories.memory import MemoryGranularity
+    dev = torch.device("cuda:0")
+    dist = GradientSync()
+    if name == "dqn":
+        from coach_amd.agents.dqn_agent import DQNAgent, DQNAgentParameters
+        ap = DQNAgentParameters()
+        ap.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(40)
+        env = SyntheticVectorEnvironment(EP("vector", 4, (4,), 2, episode_length=10, seed=5), dev, rank=rank)
+        cls, nets = DQNAgent, ("main",)
+    elif name == "td3":
+        from coach_amd.agents.td3_agent import TD3Agent, TD3AgentParameters
+        ap = TD3AgentParameters()
+        env = SyntheticVectorEnvironment(EP("vector", 4, (17,), None, action_dim=6, episode_length=10, seed=5),
+                                         dev, rank=rank)
+        cls, nets = TD3Agent, ("actor", "critic")
+    else:
+        from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgent, SoftActorCriticAgentParameters
+        ap = SoftActorCriticAgentParameters()
+        env = SyntheticVectorEnvironment(EP("vector", 4, (23,), None, action_dim=5, episode_length=10, seed=5),
+                                         dev, rank=rank)
+        cls, nets = SoftActorCriticAgent, ("policy", "v", "q")
+    ap.seed = 3
+    ap.memory.max_size = (MemoryGranularity.Transitions, 4096)
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(1)
+    from coach_amd.core_types import RunPhase
+    agent = cls(ap, env, dev, dist=dist, use_graphs=graphs)
+    agent.phase = RunPhase.HEATUP
+    for _ in range(80):
+        agent.act()
+    agent.phase = RunPhase.TRAIN
+    for _ in range(12):
+        agent.act()
+        agent.train()
+    agent.check_status()
+    assert agent.training_iteration > 20
+    w = np.concatenate([agent.networks[n].params.weights.cpu().numpy().ravel() for n in nets])
+    np.save(os.path.join(out_dir, "%s_%d_%d.npy" % (name, int(graphs), rank)), w)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["dqn", "td3", "sac"])
+def test_two_rank_off_policy_graph_segments(tmp_path, name):
+    """Data-parallel off-policy updates: the update is captured as hipGraph segments cut at every
+    gradient all-reduce.  Segmented replay == eager execution bit for bit; the ranks (different env
+    shards, different replay draws) hold identical weights after every update without a broadcast."""
+    import torch.multiprocessing as mp
+    for graphs in (True, False):
+        mp.spawn(_off_policy_worker, args=(2, _free_port(), str(tmp_path), name, graphs), nprocs=2, join=True)
+    w = {(g, r): np.load(tmp_path / ("%s_%d_%d.npy" % (name, g, r))) for g in (0, 1) for r in (0, 1)}
+    assert np.isfinite(w[(1, 0)]).all()
+    np.testing.assert_array_equal(w[(1, 0)], w[(1, 1)])
+    np.testing.assert_array_equal(w[(0, 0)], w[(0, 1)])
+    np.testing.assert_array_equal(w[(1, 0)], w[(0, 0)])
+
+
 @pytest.mark.timeout(600)
 def test_rccl_path_world_size_one(tmp_path):
     """The real RCCL (backend "nccl") collectives at world size 1, where the sum is the identity: the
