@@ -93,66 +93,6 @@ struct SmallDenseBwd {
 // 32 features x 8 row groups: twice the workgroups and half the per-thread row loop of a 64 x 4
 // split (these launches are a handful of workgroups; latency, not bandwidth, sets their time).
 constexpr int kKL = 32, kRG = 8;
-template <int NN>
-__global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBwd p) {
-    extern __shared__ float smem[];
-    float *dz = smem;                              // [M][N]
-    float *part = smem + (size_t)p.M * p.N;        // [kRG][kKL][NN] dW partials
-    const int t = blockIdx.y;
-    const int lane = threadIdx.x % kKL, g = threadIdx.x / kKL;
-    const int k = blockIdx.x * kKL + lane;
-    const float *dy = p.dy + (size_t)t * p.dy_ts;
-    const float *yy = p.y ? p.y + (size_t)t * p.y_ts : nullptr;
-    for (int i = threadIdx.x; i < p.M * p.N; i += 256)
-        dz[i] = dy[i] * (yy ? act_deriv_out(yy[i], p.act) : 1.f);
-    __syncthreads();
-    const bool live = k < p.K;
-    const float *x = p.x + (size_t)t * p.x_ts;
-    float wk[NN], acc[NN];
-#pragma unroll
-    for (int n = 0; n < NN; ++n) {
-        acc[n] = 0.f;
-        wk[n] = (live && n < p.N) ? p.w[(size_t)t * p.w_ts + (size_t)k * p.N + n] : 0.f;
-    }
-    float *dx = p.dx ? p.dx + (size_t)t * p.dx_ts : nullptr;
-    if (live) {
-        for (int m = g; m < p.M; m += kRG) {
-            const float xv = x[(size_t)m * p.K + k];
-            const float *dzr = dz + (size_t)m * p.N;
-            float s = 0.f;
-#pragma unroll
-            for (int n = 0; n < NN; ++n)
-                if (n < p.N) {
-                    const float d = dzr[n];
-                    acc[n] = fmaf(xv, d, acc[n]);
-                    s = fmaf(d, wk[n], s);
-                }
-            if (dx) dx[(size_t)m * p.K + k] = p.lower_act ? s * act_deriv_out(xv, p.lower_act) : s;
-        }
-    }
-    if (p.dw) {
-#pragma unroll
-        for (int n = 0; n < NN; ++n) part[((size_t)g * kKL + lane) * NN + n] = acc[n];
-        __syncthreads();
-        if (g == 0 && live) {
-            float *dw = p.dw + (size_t)t * p.dw_ts + (size_t)k * p.N;
-#pragma unroll
-            for (int n = 0; n < NN; ++n)
-                if (n < p.N) {
-                    float v = part[lane * NN + n];
-#pragma unroll
-                    for (int u = 1; u < kRG; ++u) v += part[(u * kKL + lane) * NN + n];   // fixed order
-                    dw[n] = v;
-                }
-        }
-    }
-    if (p.db && blockIdx.x == 0 && threadIdx.x < p.N) {
-        float s = 0.f;
-        for (int m = 0; m < p.M; ++m) s += dz[(size_t)m * p.N + threadIdx.x];
-        p.db[(size_t)t * p.db_ts + threadIdx.x] = s;
-    }
-}
-
 // ---- several narrow layers in ONE launch (blockIdx.z = problem): the value and the policy head of
 // Clipped PPO read different towers, have different widths (1 and A) and separate parameter groups,
 // but the same depth in the dependency chain — one dispatch instead of two, forward and backward.
@@ -199,37 +139,56 @@ __global__ void __launch_bounds__(256) dense_small_fwd_multi_kernel(const MultiF
 
 template <int NN>
 __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int kblock, int t, float *smem) {
-    float *dz = smem;
-    float *part = smem + (size_t)p.M * p.N;
+    float *dz = smem;                              // [M][N]
+    float *part = smem + (size_t)p.M * p.N;        // [kRG][kKL][NN] dW partials
     const int lane = threadIdx.x % kKL, g = threadIdx.x / kKL;
     const int k = kblock * kKL + lane;
     const float *dy = p.dy + (size_t)t * p.dy_ts;
     const float *yy = p.y ? p.y + (size_t)t * p.y_ts : nullptr;
     for (int i = threadIdx.x; i < p.M * p.N; i += 256)
         dz[i] = dy[i] * (yy ? act_deriv_out(yy[i], p.act) : 1.f);
-    __syncthreads();
     const bool live = k < p.K;
-    const float *x = p.x + (size_t)t * p.x_ts;
+    const float *__restrict__ x = p.x + (size_t)t * p.x_ts;
     float wk[NN], acc[NN];
 #pragma unroll
     for (int n = 0; n < NN; ++n) {
         acc[n] = 0.f;
         wk[n] = (live && n < p.N) ? p.w[(size_t)t * p.w_ts + (size_t)k * p.N + n] : 0.f;
     }
-    float *dx = p.dx ? p.dx + (size_t)t * p.dx_ts : nullptr;
-    if (live) {
-        for (int mm = g; mm < p.M; mm += kRG) {
-            const float xv = x[(size_t)mm * p.K + k];
-            const float *dzr = dz + (size_t)mm * p.N;
-            float s = 0.f;
+    float *__restrict__ dx = p.dx ? p.dx + (size_t)t * p.dx_ts : nullptr;
+    // rows g, g+8, ... in chunks of kCH: every x load of a chunk is issued before the first use (one
+    // exposed memory latency per chunk instead of one per row); the first chunk's loads are in flight
+    // while dz is being staged
+    constexpr int kCH = 8;
+    float xv[kCH];
+    auto load_chunk = [&](int m0) {
 #pragma unroll
-            for (int n = 0; n < NN; ++n)
-                if (n < p.N) {
-                    const float d = dzr[n];
-                    acc[n] = fmaf(xv, d, acc[n]);
-                    s = fmaf(d, wk[n], s);
+        for (int u = 0; u < kCH; ++u) {
+            const int mm = m0 + u * kRG;
+            xv[u] = (live && mm < p.M) ? x[(size_t)mm * p.K + k] : 0.f;
+        }
+    };
+    load_chunk(g);
+    __syncthreads();
+    for (int m0 = g; m0 < p.M; m0 += kRG * kCH) {
+        if (m0 != g) load_chunk(m0);
+        if (live) {
+#pragma unroll
+            for (int u = 0; u < kCH; ++u) {
+                const int mm = m0 + u * kRG;
+                if (mm < p.M) {
+                    const float *dzr = dz + (size_t)mm * p.N;
+                    float s = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                        if (n < p.N) {
+                            const float d = dzr[n];
+                            acc[n] = fmaf(xv[u], d, acc[n]);
+                            s = fmaf(d, wk[n], s);
+                        }
+                    if (dx) dx[(size_t)mm * p.K + k] = p.lower_act ? s * act_deriv_out(xv[u], p.lower_act) : s;
                 }
-            if (dx) dx[(size_t)mm * p.K + k] = p.lower_act ? s * act_deriv_out(xv, p.lower_act) : s;
+            }
         }
     }
     if (p.dw) {
@@ -243,16 +202,29 @@ __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int
                 if (n < p.N) {
                     float v = part[lane * NN + n];
 #pragma unroll
-                    for (int u = 1; u < kRG; ++u) v += part[(u * kKL + lane) * NN + n];
+                    for (int u = 1; u < kRG; ++u) v += part[(u * kKL + lane) * NN + n];   // fixed order
                     dw[n] = v;
                 }
         }
     }
-    if (p.db && kblock == 0 && (int)threadIdx.x < p.N) {
+    if (p.db && kblock == 0) {
+        // bias gradient: column n is summed by R threads of one wave (rows r, r + R, ...), combined by a
+        // fixed-order butterfly inside the wave
+        constexpr int R = NN >= 4 ? 256 / NN : 64;        // 64 / 64 / 32 / 16 lanes for NN = 1 / 4 / 8 / 16
+        const int n = threadIdx.x / R, r = threadIdx.x % R;
         float s = 0.f;
-        for (int mm = 0; mm < p.M; ++mm) s += dz[(size_t)mm * p.N + threadIdx.x];
-        p.db[(size_t)t * p.db_ts + threadIdx.x] = s;
+        if (n < p.N)
+            for (int mm = r; mm < p.M; mm += R) s += dz[(size_t)mm * p.N + n];
+#pragma unroll
+        for (int o = R / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, R);
+        if (r == 0 && n < p.N) p.db[(size_t)t * p.db_ts + n] = s;
     }
+}
+
+template <int NN>
+__global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBwd p) {
+    extern __shared__ float smem[];
+    dense_small_bwd_body<NN>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 template <int NN>
