@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from .. import _rlx
+from ..architectures.head_parameters import DuelingQHeadParameters, QHeadParameters
 from ..core_types import EnvironmentSteps, RunPhase
 from ..exploration_policies.e_greedy import EGreedy, EGreedyParameters
 from ..memories.non_episodic.experience_replay import ExperienceReplayParameters
@@ -45,6 +46,8 @@ class DQNNetworkParameters(object):                      # dqn_agent.py:43-53 + 
         self.adam_optimizer_beta2 = 0.99
         self.optimizer_epsilon = 0.0001
         self.scale_down_gradients_by_number_of_workers_for_sync_training = True
+        self.heads_parameters = [QHeadParameters()]      # [DuelingQHeadParameters()] for dueling DQN
+        self.clip_gradients = None                       # ClipByGlobalNorm threshold (base_parameters.py)
 
 
 class DQNAgentParameters(object):                        # dqn_agent.py:56-66
@@ -76,7 +79,11 @@ class DQNAgent(VectorOffPolicyAgent):
             embedder=net.embedder_scheme, middleware=net.middleware_scheme,
             learning_rate=net.learning_rate, adam_beta1=net.adam_optimizer_beta1,
             adam_beta2=net.adam_optimizer_beta2, optimizer_epsilon=net.optimizer_epsilon,
-            replace_mse_with_huber_loss=net.replace_mse_with_huber_loss, seed=self.ap.seed or 0)}
+            replace_mse_with_huber_loss=net.replace_mse_with_huber_loss, seed=self.ap.seed or 0,
+            dueling=isinstance(net.heads_parameters[0], DuelingQHeadParameters),
+            head_activation=net.heads_parameters[0].activation_function,
+            head_gradient_rescale=net.heads_parameters[0].rescale_gradient_from_head_by_factor,
+            clip_gradients=net.clip_gradients)}
         self.memory = self._make_memory(action_dim=None)
         self.exploration_policy = EGreedy(self.A, self.n_env, self.device, self.ap.exploration)
         self.actions = torch.zeros(self.n_env, dtype=torch.int32, device=self.device)

@@ -150,6 +150,13 @@ __global__ void sumsq_final_kernel(const float *__restrict__ part, int nparts, f
     if (threadIdx.x == 0) out[0] = sqrtf(red[0]);
 }
 
+__global__ void clip_by_global_norm_kernel(float *__restrict__ g, long long n, const float *__restrict__ norm,
+                                           float clip) {
+    const float scale = clip * fminf(1.0f / *norm, 1.0f / clip);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= scale;
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,6 +234,16 @@ int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspa
     sumsq_partial_kernel<<<parts, kBlock, 0, s>>>(x, n, workspace);
     RLX_LAUNCH_CHECK();
     sumsq_final_kernel<<<1, kBlock, 0, s>>>(workspace, parts, norm_out);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_clip_by_global_norm(float *grads, long long n, const float *global_norm, float clip_norm,
+                            void *stream) {
+    RLX_REQUIRE(grads && global_norm && n > 0, "rlx_clip_by_global_norm: bad arguments");
+    RLX_REQUIRE(clip_norm > 0.f, "rlx_clip_by_global_norm: clip_norm must be positive (got %g)", (double)clip_norm);
+    clip_by_global_norm_kernel<<<rlx::grid_for(n, kBlock, 1024), kBlock, 0, rlx::as_stream(stream)>>>(
+        grads, n, global_norm, clip_norm);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

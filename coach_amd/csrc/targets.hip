@@ -148,6 +148,31 @@ __global__ void sac_value_targets_kernel(const float *__restrict__ q_min,
     out[i] = q_min[i] - logprob[i];          // both fp32 numpy arrays in the reference
 }
 
+// DuelingQHead (dueling_q_head.py:33-48): one thread per sample, A is a handful of actions.
+__global__ void dueling_combine_kernel(const float *__restrict__ v, const float *__restrict__ adv, int B, int A,
+                                       float *__restrict__ q) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *a = adv + (size_t)b * A;
+    float s = 0.f;
+    for (int i = 0; i < A; ++i) s += a[i];
+    const float mean = s / (float)A;                 // tf.reduce_mean(axis=1, keepdims=True)
+    const float sv = v[b];
+    for (int i = 0; i < A; ++i) q[(size_t)b * A + i] = sv + (a[i] - mean);
+}
+
+__global__ void dueling_combine_bwd_kernel(const float *__restrict__ dq, int B, int A, float *__restrict__ dv,
+                                           float *__restrict__ dadv) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *g = dq + (size_t)b * A;
+    float s = 0.f;
+    for (int i = 0; i < A; ++i) s += g[i];
+    dv[b] = s;                                       // V is broadcast over the actions
+    const float mean = s / (float)A;
+    for (int i = 0; i < A; ++i) dadv[(size_t)b * A + i] = g[i] - mean;
+}
+
 }  // namespace
 
 extern "C" {
@@ -187,6 +212,27 @@ int rlx_dqn_head_loss(const float *q_online, long long ld_q, const float *q_next
         q_online, ld_q, q_next_target, q_next_selector, ld_next, actions, rewards, game_overs,
         importance_weights, discount, batch, n_actions, huber, grad_scale, dq, ld_dq, td_errors,
         td_targets, ld_targets, loss_scalar, status);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_dueling_combine(const float *state_value, const float *action_advantage, int batch,
+                        int n_actions, float *q, void *stream) {
+    RLX_REQUIRE(state_value && action_advantage && q, "rlx_dueling_combine: null pointer");
+    RLX_REQUIRE(batch > 0 && n_actions > 0, "rlx_dueling_combine: bad sizes (batch=%d actions=%d)", batch, n_actions);
+    dueling_combine_kernel<<<(batch + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(state_value, action_advantage,
+                                                                                  batch, n_actions, q);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_dueling_combine_backward(const float *dq, int batch, int n_actions, float *dstate_value,
+                                 float *daction_advantage, void *stream) {
+    RLX_REQUIRE(dq && dstate_value && daction_advantage, "rlx_dueling_combine_backward: null pointer");
+    RLX_REQUIRE(batch > 0 && n_actions > 0, "rlx_dueling_combine_backward: bad sizes (batch=%d actions=%d)", batch,
+                n_actions);
+    dueling_combine_bwd_kernel<<<(batch + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(dq, batch, n_actions,
+                                                                                      dstate_value, daction_advantage);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

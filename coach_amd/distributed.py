@@ -51,7 +51,10 @@ class GradientSync(object):
 
     def barrier(self):
         if self.enabled:
-            dist.barrier()
+            if dist.get_backend() == "nccl":      # name the device: no guessing from the rank number
+                dist.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                dist.barrier()
 
     def max_over_ranks(self, value):
         if not self.enabled:

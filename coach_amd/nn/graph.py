@@ -290,11 +290,12 @@ class Dense(Layer):
         dz = y.grad
         own_act = self.act if (self.act is not None and not y.grad_is_dz) else None
         lower = x.act if need_dx else None           # fuse the lower layer's act' into dx
-        if need_dx:
+        shared_dx = need_dx and x.towers == 0 and T > 1     # T streams fed by ONE input: dx sums them
+        if need_dx and not shared_dx:
             assert x.towers == T, "input gradients need a per-tower input"
         # one launch for dW + db + dx while the batch is small; beyond ~1k outputs its few workgroups
         # lose to the GEMM path (M=256, N=16: 56 us measured vs ~30)
-        if self.N <= SMALL_N and not x.u8 and M * self.N <= 1024:
+        if self.N <= SMALL_N and not x.u8 and M * self.N <= 1024 and not shared_dx:
             dx = x.ensure_grad() if need_dx else None
             ctx.lib.dense_small_backward(
                 x.data, x.tower_stride(), p.w(self.kname, t0, weights), p.stride(self.kname),
@@ -327,7 +328,15 @@ class Dense(Layer):
                 ctx.on_side(dw)
             else:
                 dw(ctx.ws.splitk)
-        if need_dx:
+        if shared_dx:
+            # dx = sum_t dz_t W_t^T, each term already multiplied by the lower layer's act'(x)
+            dx = x.ensure_grad()
+            for t in range(T):
+                _rlx.gemm(M, self.K, self.N, dz[t], p.w(self.kname, t0 + t, weights), dx, b_strides=(1, self.N),
+                          workspace=ctx.ws.splitk, deriv_aux=x.data if lower else None, aux_ld=self.K,
+                          deriv_kind=lower, accumulate=t > 0)
+            x.grad_is_dz = lower is not None
+        elif need_dx:
             dx = x.ensure_grad()
             # dx[M,K] = dz W^T : B(n, k) = W[k, n]; the epilogue multiplies by the lower layer's
             # activation derivative, so dx IS that layer's dz (no separate act_backward launch)
@@ -447,8 +456,9 @@ class Conv2d(Layer):
             x.grad_is_dz = lower is not None
 
 
-def small_dense_forward_multi(ctx, items, tag=""):
-    """[(Dense layer, input Tensor)] -> [output Tensor], all layers in ONE launch (each N <= SMALL_N)."""
+def small_dense_forward_multi(ctx, items, tag="", weights=None):
+    """[(Dense layer, input Tensor)] -> [output Tensor], all layers in ONE launch (each N <= SMALL_N).
+    weights: parameter buffer to read instead of the online weights (the target copy)."""
     import ctypes
     arr = (_rlx.SmallDenseProblem * len(items))()
     outs = []
@@ -458,8 +468,8 @@ def small_dense_forward_multi(ctx, items, tag=""):
         y = ctx.buffer(l.name, (l.T, M, l.N), tag=tag)
         q = arr[i]
         q.x, q.x_tower_stride = x.data.data_ptr(), x.tower_stride()
-        q.w, q.w_tower_stride = p.w(l.kname).data_ptr(), p.stride(l.kname)
-        q.bias, q.bias_tower_stride = p.w(l.bname).data_ptr(), p.stride(l.bname)
+        q.w, q.w_tower_stride = p.w(l.kname, 0, weights).data_ptr(), p.stride(l.kname)
+        q.bias, q.bias_tower_stride = p.w(l.bname, 0, weights).data_ptr(), p.stride(l.bname)
         q.y, q.y_tower_stride = y.data_ptr(), M * l.N
         q.towers, q.M, q.K, q.N, q.activation = l.T, M, l.K, l.N, _rlx.ACT[l.act]
         outs.append(Tensor(y, M, l.N, l.T, grad_key=(ctx, l.name, tag), act=l.act))

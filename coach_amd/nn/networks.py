@@ -82,6 +82,18 @@ class _NetBase:
         else:
             self.adam.step(grad_scale)
 
+    clip_gradients = None
+
+    def clip_by_global_norm(self):
+        """clip_gradients (ClipByGlobalNorm, architecture.py:196-200): self.norm <- tf.global_norm of
+        the raw gradients, then the gradient buffer is rescaled in place.  False when clipping is off."""
+        if not self.clip_gradients:
+            return False
+        self.grad_norm()
+        self.lib.clip_by_global_norm(self.params.grads, self.params.size, self.norm,
+                                     float(self.clip_gradients), self.ctx.stream)
+        return True
+
     def check_status(self):
         s = int(self.status.item())
         if s:
@@ -241,19 +253,65 @@ class DQNNet(_NetBase):
 
     def __init__(self, device, obs_shape, n_actions, activation="relu", embedder="Medium",
                  middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
-                 optimizer_epsilon=1e-4, replace_mse_with_huber_loss=True, seed=0):
+                 optimizer_epsilon=1e-4, replace_mse_with_huber_loss=True, seed=0, dueling=False,
+                 head_activation="relu", head_gradient_rescale=1.0, clip_gradients=None):
         self.obs_shape, self.image, self.A = tuple(obs_shape), len(obs_shape) == 3, n_actions
         self.huber = replace_mse_with_huber_loss
+        self.dueling = dueling
+        self.head_gradient_rescale = float(head_gradient_rescale)
+        self.clip_gradients = clip_gradients
         self.params = G.FlatParams()
         self.torso, feat = build_torso(self.params, "main", obs_shape, activation, 1, embedder, middleware)
-        self.q_head = G.Dense(self.params, "main/q_head/dense", feat, n_actions, None, 1)
-        self.modules = [self.torso, self.q_head]
+        if dueling:
+            # DuelingQHead (heads/dueling_q_head.py:33-48): state-value and action-advantage streams,
+            # each Dense(512, act) -> Dense(1 | A); the two fc1 layers are towers of one launch
+            hn = "main/dueling_q_values_head"
+            self.stream_fc = G.Dense(self.params, hn + "/fc1", feat, 512, head_activation, 2)
+            self.v_out = G.Dense(self.params, hn + "/state_value/fc2", 512, 1, None, 1)
+            self.a_out = G.Dense(self.params, hn + "/action_advantage/fc2", 512, n_actions, None, 1)
+            self.modules = [self.torso, self.stream_fc, self.v_out, self.a_out]
+        else:
+            self.q_head = G.Dense(self.params, "main/q_head/dense", feat, n_actions, None, 1)
+            self.modules = [self.torso, self.q_head]
         self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
         self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def _dueling_forward(self, feat, B, tag, weights=None, train=False):
+        """-> (q Tensor [1, B, A], saved) ; saved = tensors the backward pass needs."""
+        ctx = self.ctx
+        shared = G.Tensor(feat.data, feat.rows, feat.cols, 0, act=feat.act)      # one input, two streams
+        h = self.stream_fc.forward(ctx, shared, tag=tag, weights=weights)
+        hv, ha = (h.tower(0), h.tower(1)) if train else (h.tower_view(0), h.tower_view(1))
+        if self.A <= G.SMALL_N:
+            v, adv = G.small_dense_forward_multi(ctx, [(self.v_out, hv), (self.a_out, ha)], tag=tag,
+                                                 weights=weights)
+        else:
+            v = self.v_out.forward(ctx, hv, tag=tag, weights=weights)
+            adv = self.a_out.forward(ctx, ha, tag=tag, weights=weights)
+        qbuf = ctx.buffer("main/dueling_q_values_head/output", (1, B, self.A), tag=tag)
+        self.lib.dueling_combine(v.data, adv.data, B, self.A, qbuf, ctx.stream)
+        q = G.Tensor(qbuf, B, self.A, 1, grad_key=(ctx, "main/dueling_q_values_head/output", tag))
+        return q, (shared, h, hv, ha, v, adv)
+
+    def _dueling_backward(self, feat, q, saved, B):
+        ctx = self.ctx
+        shared, h, hv, ha, v, adv = saved
+        self.lib.dueling_combine_backward(q.grad, B, self.A, v.ensure_grad(), adv.ensure_grad(), ctx.stream)
+        if self.A <= G.SMALL_N and B * self.A <= 1024:
+            G.small_dense_backward_multi(ctx, [(self.v_out, hv, v), (self.a_out, ha, adv)])
+        else:
+            self.v_out.backward(ctx, hv, v)
+            self.a_out.backward(ctx, ha, adv)
+        h.grad_is_dz = hv.grad_is_dz and ha.grad_is_dz
+        shared.grad = feat.ensure_grad()
+        self.stream_fc.backward(ctx, shared, h)
+        feat.grad_is_dz = shared.grad_is_dz
 
     def q_values(self, obs, B, use_target=False, tag="q"):
         w = self.target if use_target else None
         acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w)
+        if self.dueling:
+            return self._dueling_forward(acts[-1], B, tag, w)[0]
         return self.q_head.forward(self.ctx, acts[-1], tag=tag, weights=w)
 
     def learn_from_batch(self, obs, next_obs, B, actions, rewards, game_overs, discount,
@@ -262,7 +320,7 @@ class DQNNet(_NetBase):
         """DQNAgent.learn_from_batch (agents/dqn_agent.py:81-113), all on device."""
         ctx = self.ctx
         sel = self.q_values(next_obs, B, tag="next_o").data.view(B, self.A) if double_dqn else None
-        if states_pair is not None:
+        if states_pair is not None and not self.dueling:
             # parallel_prediction (dqn_agent.py:86-89): online(s) and target(s') as two towers of the
             # same launches — the replay collates states / next_states into one [2, B, ...] buffer
             cols = int(np.prod(self.obs_shape))
@@ -276,7 +334,10 @@ class DQNNet(_NetBase):
         else:
             q_next = self.q_values(next_obs, B, use_target=True, tag="next_t").data.view(B, self.A)
             acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
-            q = self.q_head.forward(ctx, acts[-1], tag="train")
+            if self.dueling:
+                q, saved = self._dueling_forward(acts[-1], B, "train", train=True)
+            else:
+                q = self.q_head.forward(ctx, acts[-1], tag="train")
         dq = q.ensure_grad()
         # TD targets, |TD errors|, QHead loss and its gradient in one launch (importance weights are
         # the fp64 weights of the prioritized replay, or fp32 -> converted, or None)
@@ -286,9 +347,16 @@ class DQNNet(_NetBase):
         self.lib.dqn_head_loss(q.data, self.A, q_next, sel, self.A, actions, rewards, game_overs, w,
                                float(discount), B, self.A, int(self.huber), 1.0, dq, self.A, td_errors,
                                None, self.A, self.loss, self.status, ctx.stream)
-        self.q_head.backward(ctx, acts[-1], q)
+        if self.dueling:
+            self._dueling_backward(acts[-1], q, saved, B)
+        else:
+            self.q_head.backward(ctx, acts[-1], q)
+        if self.head_gradient_rescale != 1.0:         # rescale_gradient_from_head_by_factor
+            g = acts[-1].grad
+            self.lib.axpby(g, self.head_gradient_rescale, g, 0.0, None, g.numel(), ctx.stream)
         self.torso.backward(ctx, acts)
+        clipped = self.clip_by_global_norm()          # this worker's gradient, before it is shared
         if sync is not None:                          # data-parallel: ONE all-reduce of the flat buffer
             sync.all_reduce_sum(self.params.grads)
-        self.apply_gradients(grad_scale, with_norm=True)
+        self.apply_gradients(grad_scale, with_norm=not clipped)
         return self.loss

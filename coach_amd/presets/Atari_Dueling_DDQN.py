@@ -1,0 +1,40 @@
+"""Atari Dueling Double-DQN on the device engine.
+
+Agent hyper-parameters are those of rl_coach/presets/Atari_Dueling_DDQN.py: DDQN agent, Adam with
+learning rate 1e-4, Empty middleware (the dueling streams sit directly on the 3136 convolution
+features), DuelingQHead with the head gradient rescaled by 1/sqrt(2), gradients clipped to global
+norm 10.  The ALE level is replaced by synthetic Atari-like frames (gym / ALE are not installable
+here); `make(num_envs=...)` sets the number of lockstep environments per GPU, and the schedule is
+shortened from the reference's 50 M-step `atari_schedule` to a smoke-sized run.
+"""
+import math
+
+from coach_amd.agents.dqn_agent import DDQNAgentParameters
+from coach_amd.architectures.head_parameters import DuelingQHeadParameters
+from coach_amd.core_types import EnvironmentEpisodes, EnvironmentSteps
+from coach_amd.environments.synthetic_vector_environment import SyntheticVectorEnvironmentParameters
+from coach_amd.graph_managers.basic_rl_graph_manager import BasicRLGraphManager, ScheduleParameters
+from coach_amd.memories.memory import MemoryGranularity
+
+
+def make(num_envs=32, seed=1234, replay_transitions=1 << 17, heatup_steps=2048, improve_steps=8192,
+         episode_length=1024):
+    agent = DDQNAgentParameters()
+    net = agent.network_wrappers['main']
+    net.learning_rate = 0.0001
+    net.middleware_scheme = 'Empty'
+    net.heads_parameters = [DuelingQHeadParameters(rescale_gradient_from_head_by_factor=1 / math.sqrt(2))]
+    net.clip_gradients = 10
+    agent.algorithm.reward_clipping = (-1.0, 1.0)
+    agent.memory.max_size = (MemoryGranularity.Transitions, replay_transitions)
+    env = SyntheticVectorEnvironmentParameters("image", num_envs, (84, 84), 4, episode_length=episode_length,
+                                               seed=seed)
+    sched = ScheduleParameters()
+    sched.heatup_steps = EnvironmentSteps(heatup_steps)
+    sched.improve_steps = EnvironmentSteps(improve_steps)
+    sched.steps_between_evaluation_periods = EnvironmentSteps(improve_steps)
+    sched.evaluation_steps = EnvironmentEpisodes(0)
+    return BasicRLGraphManager(agent_params=agent, env_params=env, schedule_params=sched)
+
+
+graph_manager = make()

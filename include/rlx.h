@@ -149,6 +149,13 @@ int rlx_dqn_head_loss(const float *q_online, long long ld_q, const float *q_next
                       int huber, float grad_scale, float *dq, long long ld_dq, double *td_errors,
                       float *td_targets, long long ld_targets, float *loss_scalar, int *status,
                       void *stream);
+/* DuelingQHead merge (architectures/tensorflow_components/heads/dueling_q_head.py:33-48):
+ * q[b,a] = V[b] + (A[b,a] - mean_a A[b,:]); the backward entry point maps dL/dq to dL/dV (row sums)
+ * and dL/dA (dq - row mean). */
+int rlx_dueling_combine(const float *state_value, const float *action_advantage, int batch,
+                        int n_actions, float *q, void *stream);
+int rlx_dueling_combine_backward(const float *dq, int batch, int n_actions, float *dstate_value,
+                                 float *daction_advantage, void *stream);
 int rlx_ac_td_targets(const float *rewards, const unsigned char *game_overs, const float *q_next,
                       int q_stride, double discount, int use_non_zero_discount_for_terminal_states,
                       int has_clip, double clip_low, double clip_high, int batch,
@@ -334,6 +341,12 @@ int rlx_mix_weights(float *target, const float *online, long long n, double rate
                     void *stream);   /* architectures/tensorflow_components/architecture.py:598-607 */
 int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,
                     long long workspace_floats, void *stream);      /* tf.global_norm, architecture.py:194 */
+
+/* tf.clip_by_global_norm (architectures/tensorflow_components/architecture.py:196-200, clip method
+ * ClipByGlobalNorm): grads *= clip_norm * min(1 / global_norm, 1 / clip_norm), in place; global_norm is
+ * the device scalar rlx_global_norm wrote. */
+int rlx_clip_by_global_norm(float *grads, long long n, const float *global_norm, float clip_norm,
+                            void *stream);
 
 /* ------------------------------------ continuous-control agents (DDPG / TD3 / SAC) -- */
 /* dst[r][c] = scale * src[r][c]: concat / slice / negate / DDPGActorHead output_scale

@@ -136,15 +136,26 @@ class ClippedPPOOracle(_Base):
 
 class DQNOracle(_Base):
     def __init__(self, arrays, obs_shape, n_actions, activation="relu", lr=2.5e-4, beta1=0.9,
-                 beta2=0.99, eps=1e-4, huber=True):
+                 beta2=0.99, eps=1e-4, huber=True, dueling=False, head_gradient_rescale=1.0,
+                 clip_gradients=None):
         import copy
         self.image = len(obs_shape) == 3
         self.A, self.huber = n_actions, huber
+        self.head_gradient_rescale, self.clip_gradients = head_gradient_rescale, clip_gradients
         arrays = {k: [x.copy() for x in v] for k, v in arrays.items()}
         self.tower = N.build_chain(arrays, "main", 0, obs_shape, activation)
-        self.head = N.Dense(arrays["main/q_head/dense/kernel"][0], arrays["main/q_head/dense/bias"][0])
-        self.chains = [("main", 0, self.tower), ("qh", 0, N.Chain([self.head]))]
-        self.names = {("main", 0): _chain_names(arrays, "main"), ("qh", 0): ["main/q_head/dense"]}
+        if dueling:
+            hn = "main/dueling_q_values_head"
+            self.head = N.DuelingHead(arrays, activation, hn)
+            h = self.head
+            self.chains = [("main", 0, self.tower), ("d0", 0, N.Chain([h.v1])), ("d0", 1, N.Chain([h.a1])),
+                           ("dv", 0, N.Chain([h.v2])), ("da", 0, N.Chain([h.a2]))]
+            self.names = {("main", 0): _chain_names(arrays, "main"), ("d0", 0): [hn + "/fc1"], ("d0", 1): [hn + "/fc1"],
+                          ("dv", 0): [hn + "/state_value/fc2"], ("da", 0): [hn + "/action_advantage/fc2"]}
+        else:
+            self.head = N.Dense(arrays["main/q_head/dense/kernel"][0], arrays["main/q_head/dense/bias"][0])
+            self.chains = [("main", 0, self.tower), ("qh", 0, N.Chain([self.head]))]
+            self.names = {("main", 0): _chain_names(arrays, "main"), ("qh", 0): ["main/q_head/dense"]}
         self.adam = N.PerTensorAdam(lr, beta1, beta2, eps)
         self.target = copy.deepcopy((self.tower, self.head))
 
@@ -154,7 +165,8 @@ class DQNOracle(_Base):
 
     def update_target(self, rate=1.0):
         from .optim import mix_weights
-        for (lt, lo) in zip(self.target[0].layers + [self.target[1]], self.tower.layers + [self.head]):
+        heads = lambda h: h.layers if hasattr(h, "layers") else [h]
+        for (lt, lo) in zip(self.target[0].layers + heads(self.target[1]), self.tower.layers + heads(self.head)):
             lt.W[...] = mix_weights(lt.W, lo.W, F32(rate))
             lt.b[...] = mix_weights(lt.b, lo.b, F32(rate))
 
@@ -165,8 +177,15 @@ class DQNOracle(_Base):
         q = self.q(obs)
         td_targets, td_errors = T.dqn_targets(q_next, q, actions, rewards, game_overs, discount, q_next_o)
         loss, dq = L.regression_head_loss(q, td_targets, weights, "huber" if self.huber else "mse")
-        self.tower.backward(self.head.backward(dq))
+        # rescale_gradient_from_head_by_factor (general_network.py:296-303)
+        self.tower.backward(self.head.backward(dq) * F32(self.head_gradient_rescale))
         norm = self.global_norm()
+        if self.clip_gradients:                      # tf.clip_by_global_norm (architecture.py:196-200)
+            c = F32(self.clip_gradients)
+            scale = c * min(F32(1.0) / F32(norm), F32(1.0) / c)
+            for _, _, l in self._all_layers():
+                l.dW = (l.dW * scale).astype(F32)
+                l.db = (l.db * scale).astype(F32)
         self.adam_step(grad_scale)
         return dict(loss=loss, td_errors=td_errors, td_targets=td_targets, norm=norm)
 

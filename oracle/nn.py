@@ -100,6 +100,33 @@ class Chain:
         return dy
 
 
+class DuelingHead:
+    """DuelingQHead (architectures/tensorflow_components/heads/dueling_q_head.py:33-48): state-value
+    stream Dense(512, act) -> Dense(1), action-advantage stream Dense(512, act) -> Dense(A),
+    q = V + (A - mean_a A).  Exposed as a 4-layer list [v1, a1, v2, a2] for Adam / norm bookkeeping."""
+
+    def __init__(self, arrays, activation="relu", prefix="main/dueling_q_values_head"):
+        k, b = prefix + "/fc1/kernel", prefix + "/fc1/bias"
+        self.v1 = Dense(arrays[k][0], arrays[b][0], activation)
+        self.a1 = Dense(arrays[k][1], arrays[b][1], activation)
+        self.v2 = Dense(arrays[prefix + "/state_value/fc2/kernel"][0], arrays[prefix + "/state_value/fc2/bias"][0])
+        self.a2 = Dense(arrays[prefix + "/action_advantage/fc2/kernel"][0],
+                        arrays[prefix + "/action_advantage/fc2/bias"][0])
+        self.layers = [self.v1, self.a1, self.v2, self.a2]
+
+    def forward(self, x):
+        v = self.v2.forward(self.v1.forward(x))
+        a = self.a2.forward(self.a1.forward(x))
+        mean = (a.sum(1, keepdims=True, dtype=F32) / F32(a.shape[1])).astype(F32)
+        return (v + (a - mean)).astype(F32)
+
+    def backward(self, dq):
+        dq = dq.astype(F32)
+        s = dq.sum(1, keepdims=True, dtype=F32)
+        dv, da = s, (dq - s / F32(dq.shape[1])).astype(F32)
+        return self.v1.backward(self.v2.backward(dv)) + self.a1.backward(self.a2.backward(da))
+
+
 def build_chain(arrays, prefix, tower, obs_shape, activation, image_convs=((32, 8, 4), (64, 4, 2), (64, 3, 1))):
     """Rebuild one tower of nn.networks.build_torso from {name: [array per tower]}."""
     layers = []

@@ -39,6 +39,49 @@ def test_oracle_conv_dense_match_torch_autograd():
     np.testing.assert_allclose(chain.layers[0].db, bct.grad.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_oracle_dueling_head_matches_torch_autograd():
+    """DuelingQHead restatement (dueling_q_head.py:33-48) + rescale_gradient_from_head_by_factor +
+    tf.clip_by_global_norm against torch autograd on the same weights."""
+    import torch
+    rng = np.random.RandomState(5)
+    B, F_, A = 6, 10, 4
+    names = {"main/dueling_q_values_head/fc1": ((F_, 512), 2),
+             "main/dueling_q_values_head/state_value/fc2": ((512, 1), 1),
+             "main/dueling_q_values_head/action_advantage/fc2": ((512, A), 1)}
+    arrays = {}
+    for n, (shape, towers) in names.items():
+        arrays[n + "/kernel"] = [(rng.randn(*shape) / np.sqrt(shape[0])).astype(np.float32) for _ in range(towers)]
+        arrays[n + "/bias"] = [(rng.randn(shape[1]) * 0.1).astype(np.float32) for _ in range(towers)]
+    head = N.DuelingHead(arrays, "relu")
+    x = rng.randn(B, F_).astype(np.float32)
+    q = head.forward(x)
+    dq = rng.randn(B, A).astype(np.float32)
+    f = 1 / np.sqrt(2)
+    dx = head.backward(dq) * np.float32(f)
+    t = {k: [torch.tensor(a, requires_grad=True) for a in v] for k, v in arrays.items()}
+    xt = torch.tensor(x, requires_grad=True)
+    xin = (1 - f) * xt.detach() + f * xt                            # general_network.py:296-303
+    hn = "main/dueling_q_values_head"
+    hv = torch.relu(xin @ t[hn + "/fc1/kernel"][0] + t[hn + "/fc1/bias"][0])
+    ha = torch.relu(xin @ t[hn + "/fc1/kernel"][1] + t[hn + "/fc1/bias"][1])
+    v = hv @ t[hn + "/state_value/fc2/kernel"][0] + t[hn + "/state_value/fc2/bias"][0]
+    a = ha @ t[hn + "/action_advantage/fc2/kernel"][0] + t[hn + "/action_advantage/fc2/bias"][0]
+    qt = v + (a - a.mean(1, keepdim=True))
+    qt.backward(torch.tensor(dq))
+    np.testing.assert_allclose(q, qt.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(head.a1.dW, t[hn + "/fc1/kernel"][1].grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(head.v2.dW, t[hn + "/state_value/fc2/kernel"][0].grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(head.a2.db, t[hn + "/action_advantage/fc2/bias"][0].grad.numpy(), rtol=1e-4, atol=1e-6)
+    # clip_by_global_norm as the oracle agent applies it
+    params = [p for v in t.values() for p in v]
+    norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)))
+    torch.nn.utils.clip_grad_norm_(params, 0.5 * norm)               # forces a scale of 0.5
+    c = np.float32(0.5 * norm)
+    scale = c * min(np.float32(1) / np.float32(norm), np.float32(1) / c)
+    np.testing.assert_allclose(head.a1.dW * scale, t[hn + "/fc1/kernel"][1].grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
 def test_oracle_ppo_loss_known_answers():
     """Reference KATs: rl_coach/tests/architectures/mxnet_components/heads/test_ppo_head.py
     :141-156 (log-prob, entropy), :160-170 (KL), :363-376 (clipped surrogate = -0.142857153)."""
@@ -184,6 +227,52 @@ def test_hip_dqn_net_vs_oracle(rlx, dev, obs_shape, B, huber, ddqn):
             o.update_target(0.25)
     tgt = net.params.named_arrays(net.target)
     np.testing.assert_allclose(tgt["main/q_head/dense/kernel"][0], o.target[1].W, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obs_shape,B,middleware,clip", [((6,), 32, "Medium", None), ((44, 44, 4), 8, "Empty", 0.05)])
+def test_hip_dueling_dqn_net_vs_oracle(rlx, dev, obs_shape, B, middleware, clip):
+    """Dueling DDQN as presets/Atari_Dueling_DDQN.py configures it: DuelingQHead on an Empty middleware,
+    head gradient rescaled by 1/sqrt(2), gradients clipped by global norm — HIP network vs the oracle."""
+    import torch
+    from coach_amd.nn.networks import DQNNet
+    from oracle.agents import DQNOracle
+    from tests.util import dev_tensor
+    rng = np.random.RandomState(13)
+    A, f = 5, 1 / np.sqrt(2)
+    net = DQNNet(dev, obs_shape, A, middleware=middleware, seed=2, dueling=True, head_gradient_rescale=f,
+                 clip_gradients=clip)
+    o = DQNOracle(net.params.named_arrays(), obs_shape, A, dueling=True, head_gradient_rescale=f,
+                  clip_gradients=clip)
+    image = len(obs_shape) == 3
+    gen = (lambda: rng.randint(0, 256, size=(B,) + obs_shape).astype(np.uint8)) if image else \
+        (lambda: rng.randn(B, *obs_shape).astype(np.float32))
+    probe = gen()
+    np.testing.assert_allclose(net.q_values(dev_tensor(probe, dev), B).data.view(B, A).cpu().numpy(),
+                               o.q(probe), rtol=1e-4, atol=1e-5)
+    for step in range(3):
+        obs, nxt = gen(), gen()
+        actions = rng.randint(0, A, size=B)
+        rewards = rng.choice([-1.0, 0.0, 1.0], size=B).astype(np.float32)
+        go = rng.rand(B) < 0.2
+        err = torch.empty(B, dtype=torch.float64, device=dev)
+        loss = net.learn_from_batch(dev_tensor(obs, dev), dev_tensor(nxt, dev), B,
+                                    dev_tensor(actions, dev, np.int32), dev_tensor(rewards, dev),
+                                    dev_tensor(go, dev, np.uint8), 0.99, td_errors=err, double_dqn=True)
+        ref = o.learn_from_batch(obs, nxt, actions, rewards, go, 0.99, None, True)
+        net.check_status()
+        np.testing.assert_allclose(loss.item(), ref["loss"], rtol=5e-4, atol=1e-6)
+        np.testing.assert_allclose(err.cpu().numpy(), ref["td_errors"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(net.norm.item(), ref["norm"], rtol=1e-3)
+        if clip:
+            assert ref["norm"] > clip                        # the clip is active in this case
+        _cmp_named(_grads_named(net), o.grads(), rtol=2e-3, atol=2e-5 * max(1.0, min(ref["norm"], clip or 1e9)))
+        _cmp_named(net.params.named_arrays(), o.weights(), rtol=1e-3, atol=2e-5)
+        if step == 1:
+            net.update_target(0.25)
+            o.update_target(0.25)
+    tgt = net.params.named_arrays(net.target)
+    np.testing.assert_allclose(tgt["main/dueling_q_values_head/fc1/kernel"][1], o.target[1].a1.W, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.gpu
