@@ -121,3 +121,29 @@ def restore_checkpoint(agent, checkpoint_dir, name=None):
     st = torch.load(os.path.join(checkpoint_dir, name), map_location="cpu", weights_only=False)
     load_agent_state(agent, st)
     return name
+
+
+class NetworkSaver(object):
+    """What Architecture.collect_savers hands to the graph manager (saver.py Saver): saves / restores
+    ONE device network (weights, target weights, Adam slots) at `<checkpoint prefix>.<path>.pt`."""
+
+    def __init__(self, path, net):
+        self.path, self.net = path, net
+
+    def _file(self, save_path):
+        return "{}.{}.pt".format(save_path, self.path)
+
+    def save(self, sess, save_path):
+        net = self.net
+        torch.save({"weights": net.params.weights.cpu(), "target": None if net.target is None else net.target.cpu(),
+                    "adam_m": net.adam.m.cpu(), "adam_v": net.adam.v.cpu(), "adam_state": net.adam.state.cpu()},
+                   self._file(save_path))
+        return [self._file(save_path)]
+
+    def restore(self, sess, restore_path):
+        st = torch.load(self._file(restore_path), map_location="cpu", weights_only=False)
+        net = self.net
+        net.params.weights.copy_(st["weights"])
+        if net.target is not None and st["target"] is not None:
+            net.target.copy_(st["target"])
+        net.adam.m.copy_(st["adam_m"]); net.adam.v.copy_(st["adam_v"]); net.adam.state.copy_(st["adam_state"])

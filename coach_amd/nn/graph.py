@@ -542,16 +542,18 @@ class AdamState:
         self.state = torch.empty(2, dtype=torch.float32, device=dev)
         _rlx.lib().adam_init(self.m, self.v, params.size, self.state, beta1, beta2, _rlx.current_stream())
 
-    def step(self, grad_scale=1.0, lr=None, norm_out=None, workspace=None, acc=None):
+    def step(self, grad_scale=1.0, lr=None, norm_out=None, workspace=None, acc=None, grads=None):
         """norm_out given: the same pass also returns tf.global_norm of the gradients; acc =
-        (src, dst, n): the finish kernel adds src[:n] onto dst[:n] (signal accumulation)."""
+        (src, dst, n): the finish kernel adds src[:n] onto dst[:n] (signal accumulation); grads: a
+        flat gradient buffer to consume instead of params.grads."""
         p = self.params
         lr = self.lr if lr is None else lr
+        g = p.grads if grads is None else grads
         if norm_out is not None:
-            _rlx.lib().adam_tf1_norm(p.weights, p.grads, self.m, self.v, p.size, lr, self.beta1,
+            _rlx.lib().adam_tf1_norm(p.weights, g, self.m, self.v, p.size, lr, self.beta1,
                                      self.beta2, self.eps, self.state, grad_scale, norm_out, workspace,
                                      workspace.numel(), acc[0] if acc else None, acc[1] if acc else None,
                                      int(acc[2]) if acc else 0, _rlx.current_stream())
         else:
-            _rlx.lib().adam_tf1(p.weights, p.grads, self.m, self.v, p.size, lr, self.beta1, self.beta2,
+            _rlx.lib().adam_tf1(p.weights, g, self.m, self.v, p.size, lr, self.beta1, self.beta2,
                                 self.eps, self.state, grad_scale, _rlx.current_stream())

@@ -314,6 +314,35 @@ class DQNNet(_NetBase):
             return self._dueling_forward(acts[-1], B, tag, w)[0]
         return self.q_head.forward(self.ctx, acts[-1], tag=tag, weights=w)
 
+    def _backward_from_q(self, acts, q, saved, B):
+        ctx = self.ctx
+        if self.dueling:
+            self._dueling_backward(acts[-1], q, saved, B)
+        else:
+            self.q_head.backward(ctx, acts[-1], q)
+        if self.head_gradient_rescale != 1.0:         # rescale_gradient_from_head_by_factor
+            g = acts[-1].grad
+            self.lib.axpby(g, self.head_gradient_rescale, g, 0.0, None, g.numel(), ctx.stream)
+        self.torso.backward(ctx, acts)
+
+    def accumulate_regression(self, obs, B, targets, importance_weights=None):
+        """Architecture.accumulate_gradients for this network: forward, the head loss of head.py:143-186
+        against explicit [B, A] targets, backward; leaves the gradients in params.grads (clipped when
+        clip_gradients is set), the loss in self.loss and tf.global_norm of the raw gradients in self.norm."""
+        ctx = self.ctx
+        acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
+        saved = None
+        if self.dueling:
+            q, saved = self._dueling_forward(acts[-1], B, "train", train=True)
+        else:
+            q = self.q_head.forward(ctx, acts[-1], tag="train")
+        self.lib.regression_loss(q.data, self.A, targets, self.A, importance_weights, B, self.A, int(self.huber),
+                                 1.0, 1.0, q.ensure_grad(), self.A, self.loss, ctx.stream)
+        self._backward_from_q(acts, q, saved, B)
+        if not self.clip_by_global_norm():
+            self.grad_norm()
+        return self.loss
+
     def learn_from_batch(self, obs, next_obs, B, actions, rewards, game_overs, discount,
                          importance_weights=None, td_errors=None, double_dqn=False, grad_scale=1.0,
                          sync=None, states_pair=None):
@@ -347,14 +376,7 @@ class DQNNet(_NetBase):
         self.lib.dqn_head_loss(q.data, self.A, q_next, sel, self.A, actions, rewards, game_overs, w,
                                float(discount), B, self.A, int(self.huber), 1.0, dq, self.A, td_errors,
                                None, self.A, self.loss, self.status, ctx.stream)
-        if self.dueling:
-            self._dueling_backward(acts[-1], q, saved, B)
-        else:
-            self.q_head.backward(ctx, acts[-1], q)
-        if self.head_gradient_rescale != 1.0:         # rescale_gradient_from_head_by_factor
-            g = acts[-1].grad
-            self.lib.axpby(g, self.head_gradient_rescale, g, 0.0, None, g.numel(), ctx.stream)
-        self.torso.backward(ctx, acts)
+        self._backward_from_q(acts, q, saved if self.dueling else None, B)
         clipped = self.clip_by_global_norm()          # this worker's gradient, before it is shared
         if sync is not None:                          # data-parallel: ONE all-reduce of the flat buffer
             sync.all_reduce_sum(self.params.grads)

@@ -1,0 +1,131 @@
+"""The reference's backend interface (architectures/architecture.py:26-237, network_wrapper.py) on the
+HIP networks.  The update below is written the way DQNAgent.learn_from_batch (dqn_agent.py:81-113)
+writes it against a NetworkWrapper — parallel_prediction, a python TD-target loop,
+train_and_sync_networks — and is checked against the CPU oracle of the same update."""
+import numpy as np
+import pytest
+
+
+def _params(dueling=False, clip=None):
+    from coach_amd.agents.dqn_agent import DQNAgentParameters
+    from coach_amd.architectures.head_parameters import DuelingQHeadParameters
+    ap = DQNAgentParameters()
+    ap.seed = 5
+    net = ap.network_wrappers["main"]
+    net.batch_size = 16
+    net.clip_gradients = clip
+    if dueling:
+        net.heads_parameters = [DuelingQHeadParameters()]
+    return ap
+
+
+def _spaces(obs_shape, A):
+    from coach_amd.spaces import DiscreteActionSpace, ObservationSpace, SpacesDefinition, StateSpace
+    return SpacesDefinition(StateSpace({"observation": ObservationSpace(obs_shape)}), None, DiscreteActionSpace(A))
+
+
+def test_interface_surface_cpu():
+    """Every method of the reference's Architecture / NetworkWrapper exists with the reference's
+    argument names (no GPU needed)."""
+    import inspect
+    from coach_amd.architectures.architecture import Architecture
+    from coach_amd.architectures.hip_architecture import HipArchitecture
+    from coach_amd.architectures.network_wrapper import NetworkWrapper
+    expected = {
+        "predict": ["inputs", "outputs", "squeeze_output", "initial_feed_dict"],
+        "train_on_batch": ["inputs", "targets", "scaler", "additional_fetches", "importance_weights"],
+        "accumulate_gradients": ["inputs", "targets", "additional_fetches", "importance_weights", "no_accumulation"],
+        "apply_gradients": ["gradients", "scaler"], "apply_and_reset_gradients": ["gradients", "scaler"],
+        "set_weights": ["weights", "rate"], "get_weights": [], "reset_accumulated_gradients": [],
+        "get_variable_value": ["variable"], "set_variable_value": ["assign_op", "value", "placeholder"],
+        "collect_savers": ["parent_path_suffix"]}
+    for cls in (Architecture, HipArchitecture):
+        for name, args in expected.items():
+            assert list(inspect.signature(getattr(cls, name)).parameters)[1:] == args, (cls.__name__, name)
+        assert list(inspect.signature(cls.parallel_predict).parameters) == ["sess", "network_input_tuples"]
+        assert list(inspect.signature(cls.construct).parameters)[:2] == ["variable_scope", "devices"]
+    for m in ("sync", "update_target_network", "update_online_network", "apply_gradients_to_online_network",
+              "train_and_sync_networks", "apply_gradients_and_sync_networks", "parallel_prediction",
+              "set_is_training", "set_session"):
+        assert callable(getattr(NetworkWrapper, m))
+    with pytest.raises(NotImplementedError):
+        NetworkWrapper(_params(), has_target=True, has_global=True, name="main", spaces=_spaces((4,), 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obs_shape,dueling,clip", [((6,), False, None), ((44, 44, 4), True, 0.05)])
+def test_dqn_update_through_network_wrapper(dev, obs_shape, dueling, clip, tmp_path):
+    import torch
+    from coach_amd.architectures.network_wrapper import NetworkWrapper
+    from oracle.agents import DQNOracle
+    A, B, discount = 3, 16, 0.99
+    ap = _params(dueling, clip)
+    nw = NetworkWrapper(ap, has_target=True, has_global=False, name="main", spaces=_spaces(obs_shape, A),
+                        worker_device=dev)
+    online, target = nw.online_network, nw.target_network
+    nw.sync()
+    o = DQNOracle(online.net.params.named_arrays(), obs_shape, A, dueling=dueling, clip_gradients=clip)
+    rng = np.random.RandomState(3)
+    image = len(obs_shape) == 3
+    gen = (lambda: rng.randint(0, 256, size=(B,) + obs_shape).astype(np.uint8)) if image else \
+        (lambda: rng.randn(B, *obs_shape).astype(np.float32))
+    for step in range(3):
+        s, ns = gen(), gen()
+        actions = rng.randint(0, A, size=B)
+        rewards = rng.choice([-1.0, 0.0, 1.0], size=B).astype(np.float32)
+        game_overs = (rng.rand(B) < 0.2).astype(np.float32)
+        weights = rng.rand(B).astype(np.float32) if step == 1 else None
+        # ---- DQNAgent.learn_from_batch, verbatim in structure (dqn_agent.py:84-111)
+        q_st_plus_1, TD_targets = nw.parallel_prediction([
+            (target, {"observation": ns}), (online, {"observation": s})])
+        assert isinstance(TD_targets, np.ndarray) and TD_targets.shape == (B, A)
+        selected_actions = np.argmax(q_st_plus_1, 1)
+        np.testing.assert_allclose(TD_targets, o.q(s), rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(q_st_plus_1, o.q(ns, target=True), rtol=1e-3, atol=1e-4)
+        for i in range(B):
+            new_target = rewards[i] + (1.0 - game_overs[i]) * discount * q_st_plus_1[i][selected_actions[i]]
+            TD_targets[i, actions[i]] = new_target
+        result = nw.train_and_sync_networks({"observation": s}, TD_targets, importance_weights=weights)
+        total_loss, losses, unclipped_grads = result[:3]
+        # ---- oracle of the same update
+        ref = o.learn_from_batch(s, ns, actions, rewards, game_overs.astype(bool), discount, weights, False)
+        np.testing.assert_allclose(total_loss, ref["loss"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(unclipped_grads, ref["norm"], rtol=2e-3)
+        named = online.net.params.named_arrays()
+        for name, per_tower in o.weights().items():
+            for t, w in per_tower.items():
+                np.testing.assert_allclose(named[name][t], w, rtol=1e-3, atol=3e-5, err_msg=name)
+        if step == 1:
+            nw.update_target_network(0.25)
+            o.update_target(0.25)
+    # predict: fresh numpy array, squeeze semantics, target view differs from online after training
+    probe = gen()
+    q = online.predict({"observation": probe})
+    assert isinstance(q, np.ndarray) and q.shape == (B, A)
+    assert isinstance(online.predict({"observation": probe}, squeeze_output=False), list)
+    np.testing.assert_allclose(q, o.q(probe), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(target.predict({"observation": probe}), o.q(probe, target=True), rtol=1e-3, atol=1e-4)
+    # accumulate twice == 2 x gradient; apply_gradients multiplies by scaler
+    online.reset_accumulated_gradients()
+    online.accumulate_gradients({"observation": probe}, [q + 1.0])
+    g1 = online.accumulated_gradients.clone()
+    online.accumulate_gradients({"observation": probe}, [q + 1.0])
+    torch.testing.assert_close(online.accumulated_gradients, 2 * g1, rtol=1e-5, atol=1e-7)
+    # errors are Python exceptions, as in the reference
+    with pytest.raises(ValueError):
+        online.predict({"observation": probe, "measurements": probe})
+    with pytest.raises(ValueError):
+        online.accumulate_gradients({"observation": probe}, [q[:, :1]])
+    with pytest.raises(ValueError):
+        target.accumulate_gradients({"observation": probe}, [q])
+    # variables and savers
+    assert online.get_variable_value("learning_rate") == np.float32(ap.network_wrappers["main"].learning_rate)
+    online.set_variable_value("learning_rate", 1e-5, None)
+    assert online.current_learning_rate == 1e-5
+    saver = online.collect_savers("agent")[0]
+    saver.save(None, str(tmp_path / "0_Step-3.ckpt"))
+    before = online.get_weights().clone()
+    online.train_on_batch({"observation": probe}, [q + 1.0])
+    assert not torch.equal(before, online.get_weights())
+    saver.restore(None, str(tmp_path / "0_Step-3.ckpt"))
+    assert torch.equal(before, online.get_weights())
