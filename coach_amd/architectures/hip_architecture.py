@@ -1,8 +1,13 @@
-"""`Architecture` on librlx: the value-network family of the hot path (embedder -> FC middleware ->
-QHead or DuelingQHead, MSE / Huber regression against explicit targets), i.e. what
-GeneralTensorFlowNetwork builds for DQN / DDQN (architectures/tensorflow_components/general_network.py:
-228-405) behind the calls of architecture.py:26-237 and tensorflow_components/architecture.py:312-385,
-469-521, 598-607.
+"""`Architecture` on librlx for the two network families of the BASELINE configs C1-C3, i.e. what
+GeneralTensorFlowNetwork builds (architectures/tensorflow_components/general_network.py:228-405) behind
+the calls of architecture.py:26-237 and tensorflow_components/architecture.py:312-385, 469-521, 598-607:
+  * DQN / DDQN: embedder -> FC middleware -> QHead or DuelingQHead, MSE / Huber regression against
+    explicit [B, A] targets (`DQNNetworkParameters`);
+  * Clipped PPO: two separate embedder + middleware copies, head 0 = VHead, head 1 = PPOHead, fed the way
+    ClippedPPOAgent.train_network feeds it (clipped_ppo_agent.py:226-266): inputs 'observation',
+    'output_1_0' = actions, 'output_1_1' [, 'output_1_2'] = old policy distribution, the last
+    'output_1_n' = clip_param_rescaler; targets [value targets, advantages]; additional_fetches taken
+    from `online_network.output_heads[1]` (`ClippedPPONetworkParameters`).
 
 One device network (`coach_amd.nn.networks.DQNNet`) holds the online and the target weights in one
 allocation; the `…/online` and `…/target` HipArchitecture objects of a NetworkWrapper are two views of
@@ -15,7 +20,8 @@ import numpy as np
 import torch
 
 from .. import _rlx
-from ..nn.networks import DQNNet
+from ..nn import graph as G
+from ..nn.networks import ClippedPPONet, DQNNet
 from .architecture import Architecture
 from .head_parameters import DuelingQHeadParameters
 
@@ -23,6 +29,14 @@ from .head_parameters import DuelingQHeadParameters
 def squeeze_list(var):
     """utils.py squeeze_list: a one-element list is returned as its element."""
     return var[0] if isinstance(var, (list, tuple)) and len(var) == 1 else var
+
+
+class _HeadFetches(object):
+    """`online_network.output_heads[i].<name>`: the handles agents put into additional_fetches."""
+
+    def __init__(self, head_idx, names):
+        for n in names:
+            setattr(self, n, "output_heads/%d/%s" % (head_idx, n))
 
 
 class HipArchitecture(Architecture):
@@ -45,7 +59,21 @@ class HipArchitecture(Architecture):
         self.network_is_local, self.network_is_trainable = network_is_local, network_is_trainable
         self.is_target = shared_with is not None
         np_ = self.network_parameters
-        if shared_with is None:
+        self.kind = "ppo" if type(np_).__name__ == "ClippedPPONetworkParameters" else "q"
+        if shared_with is None and self.kind == "ppo":
+            obs_shape = tuple(int(x) for x in spaces.state['observation'].shape)
+            alg = agent_parameters.algorithm
+            continuous = not hasattr(spaces.action, "actions")
+            n_act = int(spaces.action.shape[0]) if continuous else len(spaces.action.actions)
+            self.net = ClippedPPONet(
+                self.device, obs_shape, n_act, activation=np_.activation_function,
+                embedder=np_.embedder_scheme, middleware=np_.middleware_scheme,
+                learning_rate=np_.learning_rate, adam_beta1=np_.adam_optimizer_beta1,
+                adam_beta2=np_.adam_optimizer_beta2, optimizer_epsilon=np_.optimizer_epsilon,
+                clip_likelihood_ratio_using_epsilon=alg.clip_likelihood_ratio_using_epsilon,
+                beta_entropy=alg.beta_entropy, seed=getattr(agent_parameters, "seed", 0) or 0,
+                continuous=continuous)
+        elif shared_with is None:
             obs_shape = tuple(int(x) for x in spaces.state['observation'].shape)
             head = np_.heads_parameters[0]
             self.net = DQNNet(
@@ -61,6 +89,12 @@ class HipArchitecture(Architecture):
         else:
             self.net = shared_with.net                    # the target view of the same device network
         self.inputs = ['observation']
+        if self.kind == "ppo":
+            n_dist = 2 if self.net.continuous else 1           # old policy: [probs] or [mean, std]
+            self.inputs += ['output_1_%d' % i for i in range(n_dist + 2)]
+            self.output_heads = [_HeadFetches(0, ['output']),
+                                 _HeadFetches(1, ['kl_divergence', 'entropy', 'likelihood_ratio',
+                                                  'clipped_likelihood_ratio', 'output'])]
         self.accumulated_gradients = None
         self.sess = None
         self.current_learning_rate = self.learning_rate
@@ -91,10 +125,24 @@ class HipArchitecture(Architecture):
         return obs, B
 
     # ------------------------------------------------------------------------------ inference
+    def _forward(self, obs, B, tag):
+        """Queue the forward pass; returns device views of every head output."""
+        net = self.net
+        if self.kind == "q":
+            return [net.q_values(obs, B, use_target=self.is_target, tag=tag).data.view(B, net.A)]
+        w = net.target if self.is_target else None
+        acts = net.torso.forward(net.ctx, net.obs_tensor(obs, B), tag=tag + "v", weights=w, t0=0, nt=1)
+        v = net.v_head.forward(net.ctx, acts[-1], tag=tag + "v", weights=w).data.view(B, 1)
+        if net.continuous:
+            mean, std = net.policy_mean_std(obs, B, use_target=self.is_target, tag=tag)
+            return [v, mean, std]
+        return [v, net.policy_probs(obs, B, use_target=self.is_target, tag=tag)]
+
     def predict(self, inputs, outputs=None, squeeze_output=True, initial_feed_dict=None):
+        """Q network: [q (B, A)]; Clipped PPO: [V (B, 1), policy probabilities (B, A)] or
+        [V, policy_mean, policy_std] (general_network.py outputs: one entry per head output)."""
         obs, B = self._observation(inputs)
-        q = self.net.q_values(obs, B, use_target=self.is_target, tag="predict%d" % B)
-        out = [q.data.view(B, self.net.A).cpu().numpy()]
+        out = [t.cpu().numpy() for t in self._forward(obs, B, "predict%d" % B)]
         return squeeze_list(out) if squeeze_output else out
 
     @staticmethod
@@ -104,9 +152,9 @@ class HipArchitecture(Architecture):
         queued = []
         for net, inputs in network_input_tuples:
             obs, B = net._observation(inputs)
-            q = net.net.q_values(obs, B, use_target=net.is_target, tag="pp%d_%d" % (len(queued), B))
-            queued.append((q, B, net.net.A))
-        return tuple(q.data.view(B, A).cpu().numpy() for q, B, A in queued)
+            queued.append(net._forward(obs, B, "pp%d_%d" % (len(queued), B)))
+        out = [squeeze_list([t.cpu().numpy() for t in outs]) for outs in queued]
+        return tuple(out)
 
     # ------------------------------------------------------------------------------- training
     def reset_accumulated_gradients(self):
@@ -121,6 +169,8 @@ class HipArchitecture(Architecture):
             raise ValueError("{} is not trainable".format(self.name))
         if self.accumulated_gradients is None:
             self.reset_accumulated_gradients()
+        if self.kind == "ppo":
+            return self._accumulate_ppo(inputs, targets, additional_fetches or [], no_accumulation)
         obs, B = self._observation(inputs)
         target = targets[0] if isinstance(targets, (list, tuple)) else targets
         target = self._to_device(target, torch.float32).contiguous()
@@ -135,14 +185,61 @@ class HipArchitecture(Architecture):
                 raise ValueError("importance_weights must hold one value per sample")
         net = self.net
         net.accumulate_regression(obs, B, target, w)
+        self._accumulate(no_accumulation)
+        total_loss = float(net.loss.item())
+        net.check_status()
+        return total_loss, [total_loss], float(net.norm.item()), []
+
+    def _accumulate(self, no_accumulation):
+        net = self.net
         lib, s, n = net.lib, _rlx.current_stream(), net.params.size
         if no_accumulation:
             lib.axpby(self.accumulated_gradients, 1.0, net.params.grads, 0.0, None, n, s)
         else:
             lib.axpby(self.accumulated_gradients, 1.0, self.accumulated_gradients, 1.0, net.params.grads, n, s)
-        total_loss = float(net.loss.item())
+
+    def _accumulate_ppo(self, inputs, targets, additional_fetches, no_accumulation):
+        """The feed of ClippedPPOAgent.train_network (clipped_ppo_agent.py:226-266)."""
+        net = self.net
+        obs, B = self._observation(inputs)
+        n_dist = 2 if net.continuous else 1
+        for k in ['output_1_%d' % i for i in range(n_dist + 1)]:
+            if k not in inputs:
+                raise ValueError("the PPO head needs the input {}".format(k))
+        if not isinstance(targets, (list, tuple)) or len(targets) != 2:
+            raise ValueError("targets must be [value targets, advantages]")
+        f32 = torch.float32
+        actions = self._to_device(inputs['output_1_0'], f32 if net.continuous else torch.int32).contiguous()
+        old = [self._to_device(inputs['output_1_%d' % (i + 1)], f32).contiguous() for i in range(n_dist)]
+        rescaler = float(np.asarray(inputs.get('output_1_%d' % (n_dist + 1), 1.0)).reshape(-1)[0])
+        value_targets = self._to_device(targets[0], f32).reshape(-1).contiguous()
+        advantages = self._to_device(targets[1], f32).reshape(-1).contiguous()
+        if value_targets.numel() != B or advantages.numel() != B or actions.shape[0] != B or \
+                any(tuple(o.shape) != (B, net.A) for o in old):
+            raise ValueError("targets / head inputs do not match the batch size {}".format(B))
+        ratio = torch.empty(B, dtype=f32, device=self.device)
+        clipped = torch.empty(B, dtype=f32, device=self.device)
+        net.forward_backward(obs, B, actions, advantages, value_targets, tuple(old) if net.continuous else old[0],
+                             rescaler, ratio, clipped)
+        net.grad_norm()
+        self._accumulate(no_accumulation)
+        sc = net.scalars.cpu().numpy()      # [surrogate, entropy, kl, policy-head total, value loss, grad norm]
         net.check_status()
-        return total_loss, [total_loss], float(net.norm.item()), []
+        values = {"kl_divergence": sc[2], "entropy": sc[1], "likelihood_ratio": None,
+                  "clipped_likelihood_ratio": None}
+        fetched = []
+        for f in additional_fetches:
+            name = str(f).split('/')[-1]
+            if name not in values:
+                raise ValueError("unknown fetch {}".format(f))
+            if name == "likelihood_ratio":
+                fetched.append(ratio.cpu().numpy())
+            elif name == "clipped_likelihood_ratio":
+                fetched.append(clipped.cpu().numpy())
+            else:
+                fetched.append(values[name])
+        losses = [float(sc[4]), float(sc[3])]                   # head 0 (V), head 1 (PPO)
+        return float(sc[4] + sc[3]), losses, float(sc[5]), fetched
 
     def apply_gradients(self, gradients, scaler=1.):
         """The gradients are MULTIPLIED by scaler (tensorflow_components/architecture.py:469-521)."""
@@ -171,7 +268,7 @@ class HipArchitecture(Architecture):
         self.net.lib.mix_weights(own, weights, own.numel(), float(rate), _rlx.current_stream())
 
     def get_variable_value(self, variable):
-        """variable: 'learning_rate' or a parameter name ('main/q_head/dense/kernel')."""
+        """variable: 'learning_rate' or a parameter name ('main/q_head/dense/kernel'; tower 0)."""
         if variable == 'learning_rate':
             return np.float32(self.current_learning_rate)
         return self.net.params.w(variable, 0, self._weights_buffer()).cpu().numpy()
