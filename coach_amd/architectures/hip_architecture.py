@@ -7,7 +7,14 @@ the calls of architecture.py:26-237 and tensorflow_components/architecture.py:31
     ClippedPPOAgent.train_network feeds it (clipped_ppo_agent.py:226-266): inputs 'observation',
     'output_1_0' = actions, 'output_1_1' [, 'output_1_2'] = old policy distribution, the last
     'output_1_n' = clip_param_rescaler; targets [value targets, advantages]; additional_fetches taken
-    from `online_network.output_heads[1]` (`ClippedPPONetworkParameters`).
+    from `online_network.output_heads[1]` (`ClippedPPONetworkParameters`);
+  * DDPG / TD3 actor (`*ActorNetworkParameters`): predict -> actions; predict(outputs=
+    weighted_gradients[0], initial_feed_dict={gradients_weights_ph[0]: w}) -> d sum(actions * w)/d theta
+    (ddpg_agent.py:183-193);
+  * DDPG / TD3 critic (`*CriticNetworkParameters`, inputs 'observation' + 'action'): predict ->
+    [Q, mean Q] or [Q1, Q2, min(Q1, Q2), mean Q1]; predict(outputs=gradients_wrt_inputs[k]['action']) with
+    k = the mean output -> d mean(Q1)/d action (ddpg_agent.py:169-173, td3_agent.py:194-198);
+    accumulate_gradients(inputs, TD targets) for the loss sum_i mean((y - Q_i)^2).
 
 One device network (`coach_amd.nn.networks.DQNNet`) holds the online and the target weights in one
 allocation; the `…/online` and `…/target` HipArchitecture objects of a NetworkWrapper are two views of
@@ -21,6 +28,7 @@ import torch
 
 from .. import _rlx
 from ..nn import graph as G
+from ..nn.actor_critic_nets import ActorNet, CriticNet
 from ..nn.networks import ClippedPPONet, DQNNet
 from .architecture import Architecture
 from .head_parameters import DuelingQHeadParameters
@@ -59,8 +67,23 @@ class HipArchitecture(Architecture):
         self.network_is_local, self.network_is_trainable = network_is_local, network_is_trainable
         self.is_target = shared_with is not None
         np_ = self.network_parameters
-        self.kind = "ppo" if type(np_).__name__ == "ClippedPPONetworkParameters" else "q"
-        if shared_with is None and self.kind == "ppo":
+        cname = type(np_).__name__
+        self.kind = "ppo" if cname == "ClippedPPONetworkParameters" else \
+            "actor" if "Actor" in cname else "critic" if "Critic" in cname else "q"
+        seed = getattr(agent_parameters, "seed", 0) or 0
+        if shared_with is None and self.kind in ("actor", "critic"):
+            obs_dim = int(spaces.state['observation'].shape[0])
+            A = int(spaces.action.shape[0])
+            adam = (np_.learning_rate, np_.adam_optimizer_beta1, np_.adam_optimizer_beta2, np_.optimizer_epsilon)
+            if self.kind == "actor":
+                scale = float(np.maximum(np.abs(spaces.action.low), np.abs(spaces.action.high)).max())
+                self.net = ActorNet(self.device, obs_dim, A, scale, np_.observation_embedder_scheme,
+                                    np_.middleware_scheme, np_.activation_function, *adam, seed)
+            else:                                           # the agents seed the critic with seed + 1
+                self.net = CriticNet(self.device, obs_dim, A, np_.observation_embedder_scheme,
+                                     np_.middleware_scheme, np_.num_streams, np_.activation_function,
+                                     np_.head_initializer, *adam, seed + 1)
+        elif shared_with is None and self.kind == "ppo":
             obs_shape = tuple(int(x) for x in spaces.state['observation'].shape)
             alg = agent_parameters.algorithm
             continuous = not hasattr(spaces.action, "actions")
@@ -89,6 +112,14 @@ class HipArchitecture(Architecture):
         else:
             self.net = shared_with.net                    # the target view of the same device network
         self.inputs = ['observation']
+        if self.kind == "actor":
+            self.gradients_weights_ph = ["gradients_weights_ph/0"]
+            self.weighted_gradients = ["weighted_gradients/0"]
+        if self.kind == "critic":
+            self.inputs = ['observation', 'action']
+            n_out = 2 if self.net.T == 1 else 4            # [Q, mean Q] | [Q1, Q2, min, mean Q1]
+            self.gradients_wrt_inputs = [{k: "gradients_wrt_inputs/%d/%s" % (i, k) for k in self.inputs}
+                                         for i in range(n_out)]
         if self.kind == "ppo":
             n_dist = 2 if self.net.continuous else 1           # old policy: [probs] or [mean, std]
             self.inputs += ['output_1_%d' % i for i in range(n_dist + 2)]
@@ -119,10 +150,19 @@ class HipArchitecture(Architecture):
         obs = inputs['observation']
         B = int(obs.shape[0])
         obs = self._to_device(obs, torch.uint8 if self.net.image else torch.float32).contiguous()
-        if tuple(obs.shape[1:]) != tuple(self.net.obs_shape):
+        shape = tuple(getattr(self.net, "obs_shape", None) or (self.net.obs_dim,))
+        if tuple(obs.shape[1:]) != shape:
             raise ValueError("observation shape {} does not match the network input {}"
-                             .format(tuple(obs.shape[1:]), tuple(self.net.obs_shape)))
+                             .format(tuple(obs.shape[1:]), shape))
         return obs, B
+
+    def _action(self, inputs, B):
+        if 'action' not in inputs:
+            raise ValueError("the critic needs the input action")
+        a = self._to_device(inputs['action'], torch.float32).contiguous()
+        if tuple(a.shape) != (B, self.net.A):
+            raise ValueError("action shape {} does not match {}".format(tuple(a.shape), (B, self.net.A)))
+        return a
 
     # ------------------------------------------------------------------------------ inference
     def _forward(self, obs, B, tag):
@@ -130,6 +170,8 @@ class HipArchitecture(Architecture):
         net = self.net
         if self.kind == "q":
             return [net.q_values(obs, B, use_target=self.is_target, tag=tag).data.view(B, net.A)]
+        if self.kind == "actor":
+            return [net.forward(obs, B, use_target=self.is_target, tag=tag)[0]]
         w = net.target if self.is_target else None
         acts = net.torso.forward(net.ctx, net.obs_tensor(obs, B), tag=tag + "v", weights=w, t0=0, nt=1)
         v = net.v_head.forward(net.ctx, acts[-1], tag=tag + "v", weights=w).data.view(B, 1)
@@ -142,8 +184,48 @@ class HipArchitecture(Architecture):
         """Q network: [q (B, A)]; Clipped PPO: [V (B, 1), policy probabilities (B, A)] or
         [V, policy_mean, policy_std] (general_network.py outputs: one entry per head output)."""
         obs, B = self._observation(inputs)
+        if self.kind == "critic":
+            return self._critic_predict(obs, self._action(inputs, B), B, outputs, squeeze_output)
+        if outputs is not None:
+            if self.kind != "actor" or squeeze_list(outputs) != self.weighted_gradients[0]:
+                raise NotImplementedError("outputs={} is not a fetch of this network".format(outputs))
+            return self._actor_weighted_gradients(obs, B, initial_feed_dict or {})
         out = [t.cpu().numpy() for t in self._forward(obs, B, "predict%d" % B)]
         return squeeze_list(out) if squeeze_output else out
+
+    def _critic_outputs(self, q, B):
+        """q [T, B] device -> [Q, mean Q] (DDPGVHead) or [Q1, Q2, min(Q1, Q2), mean Q1] (TD3VHead)."""
+        q = q.cpu().numpy()
+        if self.net.T == 1:
+            return [q[0].reshape(B, 1), q[0].mean()]
+        return [q[0].reshape(B, 1), q[1].reshape(B, 1), np.minimum(q[0], q[1]).reshape(B, 1), q[0].mean()]
+
+    def _critic_predict(self, obs, actions, B, outputs, squeeze_output):
+        net = self.net
+        if outputs is None:
+            q, _ = net.forward(obs, actions, B, use_target=self.is_target, tag="predict%d" % B)
+            out = self._critic_outputs(q, B)
+            return squeeze_list(out) if squeeze_output else out
+        mean_output = len(self.gradients_wrt_inputs) - 1
+        if squeeze_list(outputs) != self.gradients_wrt_inputs[mean_output]['action'] or self.is_target:
+            raise NotImplementedError("only gradients_wrt_inputs[{}]['action'] of the online critic is "
+                                      "available (d mean(Q1) / d action)".format(mean_output))
+        _, saved = net.forward(obs, actions, B, tag="agrad")
+        g = torch.empty(B, net.A, dtype=torch.float32, device=self.device)
+        net.action_gradient(saved, B, g, scale=1.0)
+        return g.cpu().numpy()
+
+    def _actor_weighted_gradients(self, obs, B, feed):
+        net = self.net
+        if self.is_target or self.gradients_weights_ph[0] not in feed:
+            raise ValueError("weighted_gradients needs initial_feed_dict[gradients_weights_ph[0]] on the "
+                             "online actor")
+        w = self._to_device(np.asarray(feed[self.gradients_weights_ph[0]], dtype=np.float32)).contiguous()
+        if tuple(w.shape) != (B, net.A):
+            raise ValueError("gradient weights shape {} does not match {}".format(tuple(w.shape), (B, net.A)))
+        _, saved = net.forward(obs, B, tag="wgrad")
+        net.backward(saved, w, B)
+        return net.params.grads.clone()
 
     @staticmethod
     def parallel_predict(sess, network_input_tuples):
@@ -152,8 +234,16 @@ class HipArchitecture(Architecture):
         queued = []
         for net, inputs in network_input_tuples:
             obs, B = net._observation(inputs)
-            queued.append(net._forward(obs, B, "pp%d_%d" % (len(queued), B)))
-        out = [squeeze_list([t.cpu().numpy() for t in outs]) for outs in queued]
+            if net.kind == "critic":
+                q, _ = net.net.forward(obs, net._action(inputs, B), B, use_target=net.is_target,
+                                       tag="pp%d_%d" % (len(queued), B))
+                queued.append((net, q, B))
+            else:
+                queued.append((net, net._forward(obs, B, "pp%d_%d" % (len(queued), B)), B))
+        out = []
+        for net, res, B in queued:
+            out.append(squeeze_list(net._critic_outputs(res, B) if net.kind == "critic"
+                                    else [t.cpu().numpy() for t in res]))
         return tuple(out)
 
     # ------------------------------------------------------------------------------- training
@@ -171,6 +261,11 @@ class HipArchitecture(Architecture):
             self.reset_accumulated_gradients()
         if self.kind == "ppo":
             return self._accumulate_ppo(inputs, targets, additional_fetches or [], no_accumulation)
+        if self.kind == "actor":
+            raise NotImplementedError("the actor has no loss head: its gradients come from "
+                                      "predict(outputs=weighted_gradients[0])")
+        if self.kind == "critic":
+            return self._accumulate_critic(inputs, targets, no_accumulation)
         obs, B = self._observation(inputs)
         target = targets[0] if isinstance(targets, (list, tuple)) else targets
         target = self._to_device(target, torch.float32).contiguous()
@@ -189,6 +284,21 @@ class HipArchitecture(Architecture):
         total_loss = float(net.loss.item())
         net.check_status()
         return total_loss, [total_loss], float(net.norm.item()), []
+
+    def _accumulate_critic(self, inputs, targets, no_accumulation):
+        net = self.net
+        obs, B = self._observation(inputs)
+        actions = self._action(inputs, B)
+        target = targets[0] if isinstance(targets, (list, tuple)) else targets
+        target = self._to_device(target, torch.float32).reshape(-1).contiguous()
+        if target.numel() != B:
+            raise ValueError("TD targets must hold one value per sample")
+        _, saved = net.forward(obs, actions, B, tag="train")
+        net.train_backward(saved, target, B)
+        net.grad_norm()
+        self._accumulate(no_accumulation)
+        losses = [float(x) for x in net.loss[:net.T].cpu().numpy()]
+        return float(sum(losses)), losses, float(net.norm.item()), []
 
     def _accumulate(self, no_accumulation):
         net = self.net

@@ -40,6 +40,10 @@ class NetworkWrapper(object):
         if self.global_network:
             self.online_network.set_weights(self.global_network.get_weights(), rate)
 
+    def apply_gradients_to_global_network(self, gradients=None):
+        """No global network here: the update lands on the online network (shared_optimizer = False path)."""
+        self.apply_gradients_to_online_network(gradients)
+
     def apply_gradients_to_online_network(self, gradients=None):
         if gradients is None:
             gradients = self.online_network.accumulated_gradients

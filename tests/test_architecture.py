@@ -189,3 +189,106 @@ def test_clipped_ppo_minibatch_through_network_wrapper(dev):
     np.testing.assert_allclose(v_online[:, 0], o.values(states["observation"]), rtol=1e-3, atol=1e-4)
     with pytest.raises(ValueError):
         nw.train_and_sync_networks(states, [value_targets, advantages])          # head inputs missing
+
+
+def _box_spaces(D, A):
+    from coach_amd.spaces import BoxActionSpace, ObservationSpace, SpacesDefinition, StateSpace
+    return SpacesDefinition(StateSpace({"observation": ObservationSpace((D,))}), None, BoxActionSpace((A,), -1.0, 1.0))
+
+
+def _ac_batch(rng, B, D, A):
+    s = rng.randn(B, D).astype(np.float32)
+    ns = rng.randn(B, D).astype(np.float32)
+    a = rng.uniform(-1, 1, (B, A)).astype(np.float32)
+    r = rng.randn(B).astype(np.float32)
+    done = rng.rand(B) < 0.15
+    return s, a, r, done, ns
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["ddpg", "td3"])
+def test_ddpg_td3_update_through_network_wrappers(dev, algo):
+    """DDPGAgent.learn_from_batch (ddpg_agent.py:137-195) / TD3Agent.learn_from_batch
+    (td3_agent.py:148-209) written against two NetworkWrappers exactly as the reference writes them —
+    parallel_prediction, gradients_wrt_inputs[k]['action'], train_and_sync_networks,
+    weighted_gradients / gradients_weights_ph — checked against the CPU oracle of the same update."""
+    import copy
+    from coach_amd.architectures.network_wrapper import NetworkWrapper
+    from oracle import ac_nets as O
+    if algo == "ddpg":
+        from coach_amd.agents.ddpg_agent import DDPGAgentParameters as P
+        D, A, B, lr_actor, streams, tau = 11, 3, 32, 1e-4, 1, 0.001
+    else:
+        from coach_amd.agents.td3_agent import TD3AgentParameters as P
+        D, A, B, lr_actor, streams, tau = 17, 6, 100, 1e-3, 2, 0.005
+    ap = P()
+    ap.seed = 2
+    spaces = _box_spaces(D, A)
+    networks = {n: NetworkWrapper(ap, has_target=True, has_global=False, name=n, spaces=spaces, worker_device=dev)
+                for n in ("actor", "critic")}
+    actor, critic = networks["actor"], networks["critic"]
+    for nw in networks.values():
+        nw.sync()
+    oa = O.ActorOracle(actor.online_network.net.params.named_arrays(), 1.0, lr=lr_actor)
+    oc = O.CriticOracle(critic.online_network.net.params.named_arrays(), streams=streams, lr=1e-3)
+    discount = ap.algorithm.discount
+    rng = np.random.RandomState(6)
+    for training_iteration in range(1, 5):
+        s, a, r, done, ns = _ac_batch(rng, B, D, A)
+        states, next_states = {"observation": s}, {"observation": ns}
+        rewards, game_overs = np.expand_dims(r, -1), np.expand_dims(done.astype(np.float32), -1)
+        # ------------------------------------------------------------ reference text starts here
+        next_actions, actions_mean = actor.parallel_prediction([
+            (actor.target_network, next_states), (actor.online_network, states)])
+        if algo == "td3":
+            noise_raw = rng.normal(0, ap.algorithm.policy_noise, next_actions.shape)
+            noise = noise_raw.clip(-ap.algorithm.noise_clipping, ap.algorithm.noise_clipping)
+            next_actions = np.clip(next_actions + noise, -1.0, 1.0)        # clip_action_to_space
+        critic_inputs = copy.copy(next_states)
+        critic_inputs['action'] = next_actions
+        q_st_plus_1 = critic.target_network.predict(critic_inputs)[0 if algo == "ddpg" else 2]
+        TD_targets = rewards + (1.0 - game_overs) * discount * q_st_plus_1
+        if algo == "ddpg":
+            critic_inputs = copy.copy(states)
+            critic_inputs['action'] = actions_mean
+            action_gradients = critic.online_network.predict(
+                critic_inputs, outputs=critic.online_network.gradients_wrt_inputs[1]['action'])
+        critic_inputs = copy.copy(states)
+        critic_inputs['action'] = a
+        result = critic.train_and_sync_networks(critic_inputs, TD_targets)
+        total_loss, losses, unclipped_grads = result[:3]
+        update_actor = algo == "ddpg" or training_iteration % ap.algorithm.update_policy_every_x_episode_steps == 0
+        if update_actor:
+            if algo == "td3":
+                critic_inputs = copy.copy(states)
+                critic_inputs['action'] = actions_mean
+                action_gradients = critic.online_network.predict(
+                    critic_inputs, outputs=critic.online_network.gradients_wrt_inputs[3]['action'])
+            initial_feed_dict = {actor.online_network.gradients_weights_ph[0]: -action_gradients}
+            gradients = actor.online_network.predict(states, outputs=actor.online_network.weighted_gradients[0],
+                                                     initial_feed_dict=initial_feed_dict)
+            actor.apply_gradients_to_online_network(gradients)
+        # ------------------------------------------------------------ oracle of the same update
+        if algo == "ddpg":
+            ref = O.ddpg_update(oa, oc, (s, a, r, done, ns), discount)
+            np.testing.assert_allclose(action_gradients, ref["action_grad"], rtol=2e-3, atol=1e-7)
+        else:
+            ref = O.td3_update(oa, oc, (s, a, r, done, ns), noise_raw, training_iteration,
+                               np.full(A, -1.0, np.float32), np.full(A, 1.0, np.float32), discount)
+        np.testing.assert_allclose(TD_targets[:, 0], ref["targets"], rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(total_loss, ref["loss"], rtol=5e-4)
+        assert len(losses) == streams
+        np.testing.assert_allclose(unclipped_grads, ref["norm"], rtol=5e-4)
+        if update_actor:
+            for nw, onet in ((actor, oa), (critic, oc)):
+                nw.update_target_network(tau)
+                onet.mix_target(tau)
+    for nw, onet in ((actor, oa), (critic, oc)):
+        named = nw.online_network.net.params.named_arrays()
+        for name, towers in onet.weights().items():
+            for t, arr in towers.items():
+                np.testing.assert_allclose(named[name][t], arr, rtol=0, atol=3e-5, err_msg="%s[%d]" % (name, t))
+    with pytest.raises(NotImplementedError):
+        actor.online_network.accumulate_gradients(states, [a])
+    with pytest.raises(ValueError):
+        critic.online_network.predict(states)                                   # 'action' missing
