@@ -14,7 +14,15 @@ the calls of architecture.py:26-237 and tensorflow_components/architecture.py:31
   * DDPG / TD3 critic (`*CriticNetworkParameters`, inputs 'observation' + 'action'): predict ->
     [Q, mean Q] or [Q1, Q2, min(Q1, Q2), mean Q1]; predict(outputs=gradients_wrt_inputs[k]['action']) with
     k = the mean output -> d mean(Q1)/d action (ddpg_agent.py:169-173, td3_agent.py:194-198);
-    accumulate_gradients(inputs, TD targets) for the loss sum_i mean((y - Q_i)^2).
+    accumulate_gradients(inputs, TD targets) for the loss sum_i mean((y - Q_i)^2);
+  * SAC (soft_actor_critic_agent.py:168-280): the policy network (`SACPolicyNetworkParameters`: predict ->
+    [mu, log_std, raw actions, actions, logprob, mean logprob] with a FRESH noise draw per call, like
+    every sess.run of the TF graph; weighted_gradients[5] / [3] with gradients_weights_ph[5] / [3]), the
+    twin-Q network (`SACCriticNetworkParameters`, inputs 'observation' + 'output_0_0': predict ->
+    [min(Q1, Q2), its mean], outputs=[q_head.q1_output, q_head.q2_output],
+    gradients_wrt_inputs[1]['output_0_0'], train_on_batch with q1_loss / q2_loss fetches) and the value
+    network (`SACValueNetworkParameters`).  Gradients of the policy network are handed out as a list of
+    per-variable tensors, because the agent text combines them variable by variable.
 
 One device network (`coach_amd.nn.networks.DQNNet`) holds the online and the target weights in one
 allocation; the `…/online` and `…/target` HipArchitecture objects of a NetworkWrapper are two views of
@@ -28,7 +36,7 @@ import torch
 
 from .. import _rlx
 from ..nn import graph as G
-from ..nn.actor_critic_nets import ActorNet, CriticNet
+from ..nn.actor_critic_nets import ActorNet, CriticNet, SACPolicyNet, SACQNet, SACValueNet
 from ..nn.networks import ClippedPPONet, DQNNet
 from .architecture import Architecture
 from .head_parameters import DuelingQHeadParameters
@@ -68,10 +76,24 @@ class HipArchitecture(Architecture):
         self.is_target = shared_with is not None
         np_ = self.network_parameters
         cname = type(np_).__name__
-        self.kind = "ppo" if cname == "ClippedPPONetworkParameters" else \
+        sac = {"SACPolicyNetworkParameters": "sac_policy", "SACCriticNetworkParameters": "sac_q",
+               "SACValueNetworkParameters": "sac_v"}
+        self.kind = sac[cname] if cname in sac else "ppo" if cname == "ClippedPPONetworkParameters" else \
             "actor" if "Actor" in cname else "critic" if "Critic" in cname else "q"
         seed = getattr(agent_parameters, "seed", 0) or 0
-        if shared_with is None and self.kind in ("actor", "critic"):
+        if shared_with is None and self.kind in sac.values():
+            obs_dim = int(spaces.state['observation'].shape[0])
+            A = int(spaces.action.shape[0])
+            adam = (np_.learning_rate, np_.adam_optimizer_beta1, np_.adam_optimizer_beta2, np_.optimizer_epsilon)
+            if self.kind == "sac_policy":                   # the agent's seeds: policy, q + 1, v + 2
+                self.net = SACPolicyNet(self.device, obs_dim, A, np_.embedder_scheme, np_.middleware_scheme,
+                                        *adam, seed=seed)
+            elif self.kind == "sac_q":
+                self.net = SACQNet(self.device, obs_dim, A, np_.network_layers_sizes, *adam, seed=seed + 1)
+            else:
+                self.net = SACValueNet(self.device, obs_dim, np_.embedder_scheme, np_.middleware_scheme, *adam,
+                                       seed=seed + 2)
+        elif shared_with is None and self.kind in ("actor", "critic"):
             obs_dim = int(spaces.state['observation'].shape[0])
             A = int(spaces.action.shape[0])
             adam = (np_.learning_rate, np_.adam_optimizer_beta1, np_.adam_optimizer_beta2, np_.optimizer_epsilon)
@@ -120,6 +142,14 @@ class HipArchitecture(Architecture):
             n_out = 2 if self.net.T == 1 else 4            # [Q, mean Q] | [Q1, Q2, min, mean Q1]
             self.gradients_wrt_inputs = [{k: "gradients_wrt_inputs/%d/%s" % (i, k) for k in self.inputs}
                                          for i in range(n_out)]
+        if self.kind == "sac_policy":
+            self.gradients_weights_ph = ["gradients_weights_ph/%d" % i for i in range(6)]
+            self.weighted_gradients = ["weighted_gradients/%d" % i for i in range(6)]
+        if self.kind == "sac_q":
+            self.inputs = ['observation', 'output_0_0']
+            self.output_heads = [_HeadFetches(0, ['q1_output', 'q2_output', 'q1_loss', 'q2_loss', 'q_output'])]
+            self.gradients_wrt_inputs = [{k: "gradients_wrt_inputs/%d/%s" % (i, k) for k in self.inputs}
+                                         for i in range(2)]           # outputs: [q_output, q_output_mean]
         if self.kind == "ppo":
             n_dist = 2 if self.net.continuous else 1           # old policy: [probs] or [mean, std]
             self.inputs += ['output_1_%d' % i for i in range(n_dist + 2)]
@@ -156,10 +186,10 @@ class HipArchitecture(Architecture):
                              .format(tuple(obs.shape[1:]), shape))
         return obs, B
 
-    def _action(self, inputs, B):
-        if 'action' not in inputs:
-            raise ValueError("the critic needs the input action")
-        a = self._to_device(inputs['action'], torch.float32).contiguous()
+    def _action(self, inputs, B, key='action'):
+        if key not in inputs:
+            raise ValueError("the critic needs the input {}".format(key))
+        a = self._to_device(inputs[key], torch.float32).contiguous()
         if tuple(a.shape) != (B, self.net.A):
             raise ValueError("action shape {} does not match {}".format(tuple(a.shape), (B, self.net.A)))
         return a
@@ -172,6 +202,8 @@ class HipArchitecture(Architecture):
             return [net.q_values(obs, B, use_target=self.is_target, tag=tag).data.view(B, net.A)]
         if self.kind == "actor":
             return [net.forward(obs, B, use_target=self.is_target, tag=tag)[0]]
+        if self.kind == "sac_v":
+            return [net.forward(obs, B, use_target=self.is_target, tag=tag)[0].view(B, 1)]
         w = net.target if self.is_target else None
         acts = net.torso.forward(net.ctx, net.obs_tensor(obs, B), tag=tag + "v", weights=w, t0=0, nt=1)
         v = net.v_head.forward(net.ctx, acts[-1], tag=tag + "v", weights=w).data.view(B, 1)
@@ -186,12 +218,97 @@ class HipArchitecture(Architecture):
         obs, B = self._observation(inputs)
         if self.kind == "critic":
             return self._critic_predict(obs, self._action(inputs, B), B, outputs, squeeze_output)
+        if self.kind == "sac_q":
+            return self._sac_q_predict(obs, self._action(inputs, B, 'output_0_0'), B, outputs, squeeze_output)
+        if self.kind == "sac_policy":
+            return self._sac_policy_predict(obs, B, outputs, initial_feed_dict or {}, squeeze_output)
         if outputs is not None:
             if self.kind != "actor" or squeeze_list(outputs) != self.weighted_gradients[0]:
                 raise NotImplementedError("outputs={} is not a fetch of this network".format(outputs))
             return self._actor_weighted_gradients(obs, B, initial_feed_dict or {})
         out = [t.cpu().numpy() for t in self._forward(obs, B, "predict%d" % B)]
         return squeeze_list(out) if squeeze_output else out
+
+    # ---- SAC ---------------------------------------------------------------------------------
+    def _grad_list(self):
+        """params.grads as a list of per-variable tensors (views of one fresh flat copy)."""
+        p = self.net.params
+        flat = p.grads.clone()
+        return [p.view(flat, name) for name in p.entries]
+
+    def _sac_policy_predict(self, obs, B, outputs, feed, squeeze_output):
+        net = self.net
+        # every call is one sess.run of a graph with a sampling op in it: a fresh N(0, 1) draw
+        normals = self._to_device(np.random.standard_normal((B, net.A)), torch.float64).contiguous()
+        tag = "predict%d" % B
+        if outputs is None:
+            o, _ = net.forward(obs, B, normals, tag=tag)
+            lp = o["logprob"].cpu().numpy()
+            out = [o["mean"].cpu().numpy(), o["log_std"].cpu().numpy(), o["raw_actions"].cpu().numpy(),
+                   o["actions"].cpu().numpy(), lp, lp.mean()]
+            return squeeze_list(out) if squeeze_output else out
+        fetch = squeeze_list(outputs)
+        if fetch not in (self.weighted_gradients[5], self.weighted_gradients[3]):
+            raise NotImplementedError("only weighted_gradients[5] (mean log-prob) and [3] (actions) exist")
+        idx = 5 if fetch == self.weighted_gradients[5] else 3
+        if self.gradients_weights_ph[idx] not in feed:
+            raise ValueError("weighted_gradients[{0}] needs initial_feed_dict[gradients_weights_ph[{0}]]".format(idx))
+        w = feed[self.gradients_weights_ph[idx]]
+        _, saved = net.forward(obs, B, normals, tag="wgrad")
+        if idx == 5:
+            net.backward(saved, B, logprob_mean_weight=float(np.asarray(w)))
+        else:
+            wd = self._to_device(np.asarray(w, dtype=np.float32)).contiguous()
+            if tuple(wd.shape) != (B, net.A):
+                raise ValueError("gradient weights shape {} does not match {}".format(tuple(wd.shape), (B, net.A)))
+            net.backward(saved, B, action_weights=wd)
+        return self._grad_list()
+
+    def _sac_q_predict(self, obs, actions, B, outputs, squeeze_output):
+        net, head = self.net, self.output_heads[0]
+        if outputs is None or isinstance(outputs, (list, tuple)):
+            q, _ = net.forward(obs, actions, B, tag="predict%d" % B)
+            q = q.cpu().numpy()
+            if outputs is None:
+                qmin = np.minimum(q[0], q[1])
+                out = [qmin.reshape(B, 1), qmin.mean()]
+                return squeeze_list(out) if squeeze_output else out
+            table = {head.q1_output: q[0].reshape(B, 1), head.q2_output: q[1].reshape(B, 1),
+                     head.q_output: np.minimum(q[0], q[1]).reshape(B, 1)}
+            if any(f not in table for f in outputs):
+                raise NotImplementedError("unknown fetch in {}".format(outputs))
+            return [table[f] for f in outputs]
+        if outputs != self.gradients_wrt_inputs[1]['output_0_0']:
+            raise NotImplementedError("only gradients_wrt_inputs[1]['output_0_0'] (d mean(min Q) / d action) exists")
+        _, saved = net.forward(obs, actions, B, tag="agrad")
+        g = torch.empty(B, net.A, dtype=torch.float32, device=self.device)
+        net.action_gradient(saved, B, g)
+        return g.cpu().numpy()
+
+    def _accumulate_sac(self, inputs, targets, additional_fetches, no_accumulation):
+        net = self.net
+        obs, B = self._observation(inputs)
+        target = targets[0] if isinstance(targets, (list, tuple)) else targets
+        target = self._to_device(target, torch.float32).reshape(-1).contiguous()
+        if target.numel() != B:
+            raise ValueError("targets must hold one value per sample")
+        if self.kind == "sac_q":
+            _, saved = net.forward(obs, self._action(inputs, B, 'output_0_0'), B, tag="train")
+        else:
+            _, saved = net.forward(obs, B, tag="train")
+        net.train_backward(saved, target, B)
+        net.grad_norm()
+        self._accumulate(no_accumulation)
+        loss = net.loss.cpu().numpy()
+        fetched = []
+        if self.kind == "sac_q":
+            head = self.output_heads[0]
+            table = {head.q1_loss: loss[0], head.q2_loss: loss[1]}
+            if any(f not in table for f in additional_fetches):
+                raise ValueError("unknown fetch in {}".format(additional_fetches))
+            fetched = [table[f] for f in additional_fetches]
+        total = float(loss.sum())
+        return total, [total], float(net.norm.item()), fetched
 
     def _critic_outputs(self, q, B):
         """q [T, B] device -> [Q, mean Q] (DDPGVHead) or [Q1, Q2, min(Q1, Q2), mean Q1] (TD3VHead)."""
@@ -266,6 +383,11 @@ class HipArchitecture(Architecture):
                                       "predict(outputs=weighted_gradients[0])")
         if self.kind == "critic":
             return self._accumulate_critic(inputs, targets, no_accumulation)
+        if self.kind == "sac_policy":
+            raise NotImplementedError("the SAC policy has no loss head: its gradients come from "
+                                      "predict(outputs=weighted_gradients[k])")
+        if self.kind in ("sac_q", "sac_v"):
+            return self._accumulate_sac(inputs, targets, additional_fetches or [], no_accumulation)
         obs, B = self._observation(inputs)
         target = targets[0] if isinstance(targets, (list, tuple)) else targets
         target = self._to_device(target, torch.float32).contiguous()
@@ -353,7 +475,16 @@ class HipArchitecture(Architecture):
 
     def apply_gradients(self, gradients, scaler=1.):
         """The gradients are MULTIPLIED by scaler (tensorflow_components/architecture.py:469-521)."""
-        if not isinstance(gradients, torch.Tensor) or gradients.numel() != self.net.params.size:
+        p = self.net.params
+        if isinstance(gradients, (list, tuple)):
+            # per-variable tensors (the SAC policy text combines gradients variable by variable)
+            if len(gradients) != len(p.entries) or any(e[2] != 1 for e in p.entries.values()):
+                raise ValueError("a gradient list must hold one tensor per variable of a single-tower network")
+            for name, g in zip(p.entries, gradients):
+                dst = p.g(name)
+                dst.copy_(self._to_device(g, torch.float32).reshape(dst.shape))
+            gradients = p.grads
+        if not isinstance(gradients, torch.Tensor) or gradients.numel() != p.size:
             raise ValueError("gradients must be the accumulated_gradients buffer of an identical network")
         self.net.adam.step(float(scaler), lr=self.current_learning_rate, grads=gradients)
 

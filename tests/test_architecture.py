@@ -292,3 +292,85 @@ def test_ddpg_td3_update_through_network_wrappers(dev, algo):
         actor.online_network.accumulate_gradients(states, [a])
     with pytest.raises(ValueError):
         critic.online_network.predict(states)                                   # 'action' missing
+
+
+@pytest.mark.gpu
+def test_sac_update_through_network_wrappers(dev):
+    """SoftActorCriticAgent.learn_from_batch (soft_actor_critic_agent.py:168-280) written against three
+    NetworkWrappers as the reference writes it — three policy sess.run passes with fresh noise each,
+    weighted_gradients[5] / [3], gradients_wrt_inputs[1]['output_0_0'], per-variable gradient
+    arithmetic, train_on_batch with q1_loss / q2_loss fetches — checked against the CPU oracle."""
+    import copy
+    from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgentParameters
+    from coach_amd.architectures.network_wrapper import NetworkWrapper
+    from oracle import ac_nets as O
+    D, A, B = 23, 5, 64
+    ap = SoftActorCriticAgentParameters()
+    ap.seed = 7
+    spaces = _box_spaces(D, A)
+    networks = {n: NetworkWrapper(ap, has_target=(n == "v"), has_global=False, name=n, spaces=spaces, worker_device=dev)
+                for n in ("policy", "q", "v")}
+    networks["v"].sync()
+    op = O.SACPolicyOracle(networks["policy"].online_network.net.params.named_arrays())
+    oq = O.SACQOracle(networks["q"].online_network.net.params.named_arrays())
+    ov = O.SACValueOracle(networks["v"].online_network.net.params.named_arrays())
+    discount = ap.algorithm.discount
+    rng = np.random.RandomState(8)
+    for it in range(3):
+        s, a, r, done, ns = _ac_batch(rng, B, D, A)
+        np.random.seed(100 + it)
+        z = np.random.standard_normal((3, B, A))          # the three draws the text below makes
+        ref = O.sac_update(op, oq, ov, (s, a, r, done, ns), z, discount, resample=True)
+        np.random.seed(100 + it)
+        batch_states, batch_next_states = {"observation": s}, {"observation": ns}
+        rewards, game_overs = np.expand_dims(r, -1), np.expand_dims(done.astype(np.float32), -1)
+        # ------------------------------------------------------------ reference text starts here
+        value_network = networks['v']
+        q_network = networks['q'].online_network
+        q_head = q_network.output_heads[0]
+        policy_network = networks['policy'].online_network
+        policy_inputs = copy.copy(batch_states)
+        policy_results = policy_network.predict(policy_inputs)
+        policy_mu, policy_std, sampled_raw_actions, sampled_actions, sampled_actions_logprob, \
+            sampled_actions_logprob_mean = policy_results
+        q_inputs = copy.copy(batch_states)
+        q_inputs['output_0_0'] = sampled_actions
+        log_target = q_network.predict(q_inputs)[0].squeeze()
+        q1_vals, q2_vals = q_network.predict(q_inputs, outputs=[q_head.q1_output, q_head.q2_output])
+        initial_feed_dict = {policy_network.gradients_weights_ph[5]: np.array(1.0)}
+        dlogp_dphi = policy_network.predict(policy_inputs, outputs=policy_network.weighted_gradients[5],
+                                            initial_feed_dict=initial_feed_dict)
+        dq_da = q_network.predict(q_inputs, outputs=q_network.gradients_wrt_inputs[1]['output_0_0'])
+        initial_feed_dict = {policy_network.gradients_weights_ph[3]: dq_da}
+        dq_dphi = policy_network.predict(policy_inputs, outputs=policy_network.weighted_gradients[3],
+                                         initial_feed_dict=initial_feed_dict)
+        policy_grads = [dlogp_dphi[l] - dq_dphi[l] for l in range(len(dlogp_dphi))]
+        policy_network.apply_gradients(policy_grads)
+        value_inputs = copy.copy(batch_states)
+        value_targets = log_target - sampled_actions_logprob
+        value_loss = value_network.online_network.train_on_batch(value_inputs, value_targets[:, None])[0]
+        q_inputs['output_0_0'] = a
+        value_inputs = copy.copy(batch_next_states)
+        v_target_next_state = value_network.target_network.predict(value_inputs)
+        TD_targets = rewards + (1.0 - game_overs) * discount * v_target_next_state
+        result = q_network.train_on_batch(q_inputs, TD_targets, additional_fetches=[q_head.q1_loss, q_head.q2_loss])
+        total_loss, losses, unclipped_grads = result[:3]
+        q1_loss, q2_loss = result[3]
+        # ------------------------------------------------------------ against the oracle
+        assert len(dlogp_dphi) == len(policy_network.net.params.entries) and policy_mu.shape == (B, A)
+        np.testing.assert_allclose(np.minimum(q1_vals, q2_vals)[:, 0], log_target, rtol=1e-6)
+        np.testing.assert_allclose(sampled_actions_logprob, ref["logprob"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(dq_da, ref["dq_da"], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(value_targets, ref["value_targets"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(TD_targets[:, 0], ref["td_targets"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(value_loss, ref["v_loss"], rtol=3e-4)
+        np.testing.assert_allclose(total_loss, ref["loss"], rtol=3e-4)
+        np.testing.assert_allclose(q1_loss + q2_loss, ref["loss"], rtol=3e-4)
+        np.testing.assert_allclose(unclipped_grads, ref["norm"], rtol=5e-4)
+        value_network.update_target_network(0.005)
+        ov.mix_target(0.005)
+    for name, onet in (("policy", op), ("q", oq), ("v", ov)):
+        named = networks[name].online_network.net.params.named_arrays()
+        for pname, towers in onet.weights().items():
+            for t, arr in towers.items():
+                np.testing.assert_allclose(named[pname][t], arr, rtol=0, atol=5e-5, err_msg="%s[%d]" % (pname, t))
