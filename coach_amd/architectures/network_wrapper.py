@@ -1,7 +1,8 @@
 """NetworkWrapper (rl_coach/architectures/network_wrapper.py:30-240) over HipArchitecture: the online
 network, the optional slow target network, and the calls the agents make on the pair.  The global
 (parameter-server) network of the reference's multi-process mode does not exist here — data parallelism
-is one gradient all-reduce per update (coach_amd.distributed)."""
+is one gradient all-reduce per update (coach_amd.distributed) — so `global_network` is always None and
+every "…to_global_network" call lands on the online network."""
 from .hip_architecture import HipArchitecture
 
 
@@ -11,71 +12,73 @@ class NetworkWrapper(object):
         if has_global:
             raise NotImplementedError("has_global: the shared parameter-server network is replaced by "
                                       "GradientSync (one flat all-reduce per update)")
-        self.ap = agent_parameters
-        self.network_parameters = self.ap.network_wrappers[name]
-        self.has_target, self.has_global, self.name = has_target, has_global, name
-        self.sess = None
+        self.ap, self.name = agent_parameters, name
+        self.network_parameters = agent_parameters.network_wrappers[name]
+        self.has_target, self.has_global = bool(has_target), False
+        self.sess = self.global_network = None
         scope = "{}/{}".format(getattr(agent_parameters, "full_name_id", "agent"), name)
-        devices = [worker_device] if worker_device is not None else []
-        self.global_network = None
-        self.online_network = HipArchitecture.construct(
-            scope, devices, agent_parameters=agent_parameters, name='{}/online'.format(name), spaces=spaces,
-            global_network=None, network_is_local=True, network_is_trainable=True)
-        self.target_network = None
-        if has_target:
-            self.target_network = HipArchitecture.construct(
-                scope, devices, agent_parameters=agent_parameters, name='{}/target'.format(name), spaces=spaces,
-                global_network=None, network_is_local=True, network_is_trainable=False,
-                shared_with=self.online_network)
+
+        def build(role, trainable, **extra):
+            return HipArchitecture.construct(
+                scope, [worker_device] if worker_device is not None else [], agent_parameters=agent_parameters,
+                name="%s/%s" % (name, role), spaces=spaces, global_network=None, network_is_local=True,
+                network_is_trainable=trainable, **extra)
+
+        self.online_network = build("online", True)
+        # the target network is a second view of the SAME device allocation ([2, size] weights)
+        self.target_network = build("target", False, shared_with=self.online_network) if has_target else None
+
+    def _members(self):
+        return [n for n in (self.online_network, self.target_network) if n is not None]
+
+    # ---- weight movement ------------------------------------------------------------------
+    def update_target_network(self, rate=1.0):
+        """online >>> target: target = rate * online + (1 - rate) * target."""
+        tgt = self.target_network
+        if tgt is not None:
+            tgt.set_weights(self.online_network.get_weights(), rate)
+
+    def update_online_network(self, rate=1.0):
+        """global >>> online; a no-op without a global network."""
 
     def sync(self):
         self.update_online_network()
         self.update_target_network()
 
-    def update_target_network(self, rate=1.0):
-        if self.target_network:
-            self.target_network.set_weights(self.online_network.get_weights(), rate)
-
-    def update_online_network(self, rate=1.0):
-        if self.global_network:
-            self.online_network.set_weights(self.global_network.get_weights(), rate)
-
-    def apply_gradients_to_global_network(self, gradients=None):
-        """No global network here: the update lands on the online network (shared_optimizer = False path)."""
-        self.apply_gradients_to_online_network(gradients)
-
+    # ---- training --------------------------------------------------------------------------
     def apply_gradients_to_online_network(self, gradients=None):
-        if gradients is None:
-            gradients = self.online_network.accumulated_gradients
-        self.online_network.apply_gradients(gradients)
+        net = self.online_network
+        net.apply_gradients(net.accumulated_gradients if gradients is None else gradients)
 
-    def train_and_sync_networks(self, inputs, targets, additional_fetches=[], importance_weights=None):
-        result = self.online_network.accumulate_gradients(inputs, targets, additional_fetches=additional_fetches,
-                                                          importance_weights=importance_weights,
-                                                          no_accumulation=True)
-        self.apply_gradients_and_sync_networks(reset_gradients=False)
-        return result
+    apply_gradients_to_global_network = apply_gradients_to_online_network
 
     def apply_gradients_and_sync_networks(self, reset_gradients=True):
-        if reset_gradients:
-            self.online_network.apply_and_reset_gradients(self.online_network.accumulated_gradients)
-        else:
-            self.online_network.apply_gradients(self.online_network.accumulated_gradients)
+        net = self.online_network
+        step = net.apply_and_reset_gradients if reset_gradients else net.apply_gradients
+        step(net.accumulated_gradients)
 
+    def train_and_sync_networks(self, inputs, targets, additional_fetches=[], importance_weights=None):
+        """accumulate (overwriting) + apply; returns accumulate_gradients' tuple
+        (total_loss, losses, norm_unclipped_grads, fetched)."""
+        out = self.online_network.accumulate_gradients(
+            inputs, targets, additional_fetches=additional_fetches, importance_weights=importance_weights,
+            no_accumulation=True)
+        self.apply_gradients_and_sync_networks(reset_gradients=False)
+        return out
+
+    # ---- inference / bookkeeping --------------------------------------------------------------
     def parallel_prediction(self, network_input_tuples):
-        return type(self.online_network).parallel_predict(self.sess, network_input_tuples)
+        return HipArchitecture.parallel_predict(self.sess, network_input_tuples)
 
     def set_is_training(self, state):
-        self.online_network.set_is_training(state)
-        if self.has_target:
-            self.target_network.set_is_training(state)
+        for n in self._members():
+            n.set_is_training(state)
 
     def set_session(self, sess):
         self.sess = sess
-        self.online_network.set_session(sess)
-        if self.target_network:
-            self.target_network.set_session(sess)
+        for n in self._members():
+            n.set_session(sess)
 
     def __str__(self):
-        sub = ["online network"] + (["target network"] if self.target_network else [])
-        return "Network: {}, Copies: {} ({})".format(self.name, len(sub), ' | '.join(sub))
+        roles = ["online network"] + (["target network"] if self.target_network is not None else [])
+        return "Network: {}, Copies: {} ({})".format(self.name, len(roles), ' | '.join(roles))
