@@ -2,7 +2,10 @@
 rl_coach/agents/{ddpg,td3,soft_actor_critic}_agent.py learn_from_batch around the TF heads
 (heads/ddpg_actor_head.py:48-56, ddpg_v_head.py, td3_v_head.py:40-60, sac_head.py:60-97,
 sac_q_head.py:46-96, v_head.py:43-52).  PARITY UNPINNED for TF's op-level rounding (TensorFlow is
-absent); cross-checked against torch autograd in tests/test_ac_nets.py.  TEST INFRASTRUCTURE ONLY.
+absent); cross-checked against torch autograd in tests/test_ac_nets.py.  The update LOGIC of
+ddpg_update / td3_update / sac_update (pass order, targets, gradient signs and weights, actor cadence) is
+pinned: tests/test_update_pins.py compares them with fixtures made by running the reference's own
+learn_from_batch on oracle-backed stand-ins (tests/golden/_oracle_backend.py).  TEST INFRASTRUCTURE ONLY.
 """
 import copy
 

@@ -5,6 +5,10 @@ bench.py's cpu_baseline leg.
 Follows rl_coach/agents/clipped_ppo_agent.py:209-308 (train_network minibatch), :157-207
 (fill_advantages, via oracle.returns) and rl_coach/agents/dqn_agent.py:81-113.
 Network numerics are PARITY UNPINNED (TensorFlow absent), see oracle/nn.py.
+The update LOGIC (pass order, targets, shuffles) of DQNOracle.learn_from_batch and
+ClippedPPOAgentOracle.train is pinned: tests/test_update_pins.py compares them with fixtures made by
+running the reference's DQNAgent.learn_from_batch / ClippedPPOAgent.train on oracle-backed stand-ins
+(tests/golden/_oracle_backend.py).
 """
 import numpy as np
 

@@ -464,8 +464,235 @@ def gen_explore():
     _save("explore", **out)
 
 
+# ------------------------------------------------------------------- whole agent updates
+def _rand_arrays(rng, spec):
+    """{name: (in, out, towers)} -> {name/kernel|bias: [array per tower]}."""
+    out = {}
+    for name, (i, o, t) in spec.items():
+        out[name + "/kernel"] = [(rng.uniform(-1, 1, (i, o)) * np.sqrt(3.0 / i)).astype(np.float32) for _ in range(t)]
+        out[name + "/bias"] = [rng.uniform(-0.1, 0.1, (o,)).astype(np.float32) for _ in range(t)]
+    return out
+
+
+def _flat(prefix, weights, out):
+    for name, towers in weights.items():
+        for t, arr in towers.items():
+            out["%s|%s|%d" % (prefix, name, t)] = np.array(arr)
+
+
+def gen_updates():
+    """The REFERENCE's learn_from_batch of DDPG / TD3 / SAC / DQN (agents/{ddpg,td3,soft_actor_critic,
+    dqn}_agent.py) executed here against oracle-backed network stand-ins (_oracle_backend.py): stores the
+    initial weights, every batch / noise draw and the weights after three updates.
+    tests/test_update_pins.py re-runs the oracle's own whole-update functions from the same inputs."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle import ac_nets as O
+    from oracle.agents import DQNOracle
+    from rl_coach.agents.ddpg_agent import DDPGAgent
+    from rl_coach.agents.dqn_agent import DQNAgent
+    from rl_coach.agents.soft_actor_critic_agent import SoftActorCriticAgent
+    from rl_coach.agents.td3_agent import TD3Agent
+    from rl_coach.core_types import Batch
+    from rl_coach.spaces import BoxActionSpace
+    out = {}
+    sink = _Obj(add_sample=lambda v: None)
+
+    def make_batch(rng, B, D, A, discrete=None):
+        s, ns = rng.randn(B, D).astype(np.float32), rng.randn(B, D).astype(np.float32)
+        a = rng.randint(0, discrete, size=B) if discrete else rng.uniform(-1, 1, (B, A)).astype(np.float32)
+        r = rng.randn(B).astype(np.float32)
+        done = rng.rand(B) < 0.15
+        tr = [Transition(state={'observation': s[i]}, action=a[i], reward=float(r[i]),
+                         next_state={'observation': ns[i]}, game_over=bool(done[i])) for i in range(B)]
+        return Batch(tr), (s, a, r, done, ns)
+
+    def fake(cls):
+        class Fake(cls):
+            def __init__(self):
+                pass
+        return Fake()
+
+    keys = lambda *names: _Obj(input_embedders_parameters={n: None for n in names})
+
+    # ---------------- DDPG and TD3
+    for name, cls, streams, D, A, B in (("ddpg", DDPGAgent, 1, 11, 3, 32), ("td3", TD3Agent, 2, 17, 6, 48)):
+        rng = np.random.RandomState(41 + streams)
+        spec = {"actor/embedder/dense0": (D, 24, 1), "actor/middleware/dense0": (24, 16, 1),
+                "actor/ddpg_actor_head/fc_mean": (16, A, 1)}
+        a_arrays = _rand_arrays(rng, spec)
+        if streams == 1:
+            spec = {"critic/embedder/dense0": (D, 20, 1), "critic/middleware/dense0": (20 + A, 16, 1),
+                    "critic/v_head/output": (16, 1, 1)}
+        else:
+            spec = {"critic/middleware/dense0": (D + A, 24, 2), "critic/middleware/dense1": (24, 16, 2),
+                    "critic/v_head/output": (16, 1, 2)}
+        c_arrays = _rand_arrays(rng, spec)
+        actor = O.ActorOracle(copy.deepcopy(a_arrays), 1.0, lr=1e-3)
+        critic = O.CriticOracle(copy.deepcopy(c_arrays), streams=streams, lr=1e-3)
+        for k, v in list(a_arrays.items()) + list(c_arrays.items()):
+            for t, arr in enumerate(v):
+                out["%s|init|%s|%d" % (name, k, t)] = arr
+        f = fake(cls)
+        f.ap = _Obj(network_wrappers={'actor': keys('observation'), 'critic': keys('observation', 'action')},
+                    algorithm=_Obj(discount=0.99, use_non_zero_discount_for_terminal_states=False,
+                                   clip_critic_targets=None, policy_noise=0.2, noise_clipping=0.5,
+                                   update_policy_every_x_episode_steps=2))
+        f.TD_targets_signal = sink
+        f.spaces = _Obj(action=BoxActionSpace(A, -1.0, 1.0))
+        f.networks = {'actor': OB.ActorWrapper(actor), 'critic': OB.CriticWrapper(critic, A)}
+        for it in range(1, 4):
+            f.training_iteration = it
+            batch, arrays = make_batch(rng, B, D, A)
+            np.random.seed(500 + it)
+            noise = np.random.normal(0, 0.2, (B, A))            # what TD3's learn_from_batch will draw
+            np.random.seed(500 + it)
+            res = f.learn_from_batch(batch)
+            for k, v in zip(("s", "a", "r", "done", "ns"), arrays):
+                out["%s|batch%d|%s" % (name, it, k)] = v
+            out["%s|noise%d" % (name, it)] = noise
+            out["%s|loss%d" % (name, it)] = np.float64(res[0])
+            if name == "ddpg" or it % 2 == 0:                   # the agents' target cadence, simplified
+                actor.mix_target(0.01); critic.mix_target(0.01)
+        _flat(name + "|final|actor", actor.weights(), out)
+        _flat(name + "|final|critic", critic.weights(), out)
+
+    # ---------------- SAC
+    D, A, B = 13, 4, 40
+    rng = np.random.RandomState(47)
+    p_arr = _rand_arrays(rng, {"policy/embedder/dense0": (D, 24, 1), "policy/middleware/dense0": (24, 16, 1),
+                               "policy/sac_policy_head/policy_mu_logsig": (16, 2 * A, 1)})
+    q_arr = _rand_arrays(rng, {"q/q_head/obs_fc": (D, 16, 2), "q/q_head/act_fc": (A, 16, 2),
+                               "q/q_head/fc1": (16, 16, 2), "q/q_head/q_output": (16, 1, 2)})
+    v_arr = _rand_arrays(rng, {"v/embedder/dense0": (D, 24, 1), "v/middleware/dense0": (24, 16, 1),
+                               "v/v_values_head/output": (16, 1, 1)})
+    pol, qn, vn = O.SACPolicyOracle(copy.deepcopy(p_arr)), O.SACQOracle(copy.deepcopy(q_arr)), \
+        O.SACValueOracle(copy.deepcopy(v_arr))
+    for arrs in (p_arr, q_arr, v_arr):
+        for k, v in arrs.items():
+            for t, arr in enumerate(v):
+                out["sac|init|%s|%d" % (k, t)] = arr
+    f = fake(SoftActorCriticAgent)
+    f.ap = _Obj(network_wrappers={n: keys('observation') for n in ('policy', 'q', 'v')},
+                algorithm=_Obj(discount=0.99))
+    for sig in ("policy_means", "policy_logsig", "policy_logprob_sampled", "q1_values", "q2_values",
+                "policy_grads", "v_onl_ys", "v_tgt_ns", "TD_err1", "TD_err2"):
+        setattr(f, sig, sink)
+    pw = OB.SACPolicyWrapper(pol, A)
+    f.networks = {'policy': pw, 'q': OB.SACQWrapper(qn), 'v': OB.SACValueWrapper(vn)}
+    for it in range(1, 4):
+        batch, arrays = make_batch(rng, B, D, A)
+        np.random.seed(600 + it)
+        pw.normals = []
+        res = f.learn_from_batch(batch)
+        assert len(pw.normals) == 3                              # three policy sess.run passes
+        for k, v in zip(("s", "a", "r", "done", "ns"), arrays):
+            out["sac|batch%d|%s" % (it, k)] = v
+        out["sac|normals%d" % it] = np.stack(pw.normals)
+        out["sac|loss%d" % it] = np.float64(res[0])
+        vn.mix_target(0.005)
+    for nm, net in (("policy", pol), ("q", qn), ("v", vn)):
+        _flat("sac|final|" + nm, net.weights(), out)
+
+    # ---------------- DQN (Huber loss, uniform replay: no importance weights)
+    D, A, B = 6, 3, 32
+    rng = np.random.RandomState(53)
+    d_arr = _rand_arrays(rng, {"main/embedder/dense0": (D, 24, 1), "main/middleware/dense0": (24, 16, 1),
+                               "main/q_head/dense": (16, A, 1)})
+    dq = DQNOracle(copy.deepcopy(d_arr), (D,), A, lr=1e-3)
+    for k, v in d_arr.items():
+        out["dqn|init|%s|0" % k] = v[0]
+    f = fake(DQNAgent)
+    f.ap = _Obj(network_wrappers={'main': keys('observation')}, algorithm=_Obj(discount=0.99))
+    f.q_values = sink
+    f.memory = object()
+    f.update_transition_priorities_and_get_weights = lambda errs, batch: None
+    f.networks = {'main': OB.DQNWrapper(dq)}
+    for it in range(1, 4):
+        batch, arrays = make_batch(rng, B, D, A, discrete=A)
+        res = f.learn_from_batch(batch)
+        for k, v in zip(("s", "a", "r", "done", "ns"), arrays):
+            out["dqn|batch%d|%s" % (it, k)] = v
+        out["dqn|loss%d" % it] = np.float64(res[0])
+        if it == 2:
+            dq.update_target(1.0)
+    _flat("dqn|final|main", dq.weights(), out)
+    _save("updates", **out)
+
+
+def gen_ppo_update():
+    """The REFERENCE's ClippedPPOAgent.train (agents/clipped_ppo_agent.py:314-344: sync, fill_advantages,
+    dataset shuffle, train_network with per-epoch Batch.shuffle) executed here on an oracle-backed
+    network stand-in; tests/test_update_pins.py re-runs oracle.agents.ClippedPPOAgentOracle.train from
+    the same transitions, weights and `random` seed."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle.agents import ClippedPPOOracle
+    from rl_coach.agents.clipped_ppo_agent import ClippedPPOAgent
+    from rl_coach.agents.policy_optimization_agent import PolicyGradientRescaler
+    from rl_coach.core_types import EnvironmentSteps
+    from rl_coach.spaces import DiscreteActionSpace
+    D, A, B, n_env, L, epochs = 9, 4, 16, 6, 8, 3
+    rng = np.random.RandomState(61)
+    arrays = _rand_arrays(rng, {"main/embedder/dense0": (D, 24, 2), "main/middleware/dense0": (24, 16, 2),
+                                "main/v_head/dense": (16, 1, 1), "main/ppo_head/policy_fc": (16, A, 1)})
+    net = ClippedPPOOracle(copy.deepcopy(arrays), (D,), A, lr=1e-3, clip_eps=0.2, beta_entropy=0.01)
+    out = {}
+    for k, v in arrays.items():
+        for t, arr in enumerate(v):
+            out["ppo|init|%s|%d" % (k, t)] = arr
+    T = n_env * L
+    states = rng.randn(T, D).astype(np.float32)
+    actions = rng.randint(0, A, size=T)
+    rewards = rng.choice([-1.0, 0.0, 1.0], size=T).astype(np.float32)
+    go = np.zeros(T, dtype=bool)
+    go[np.arange(n_env) * L + L - 1] = True                      # episode-major, one episode per env
+    trans = [Transition(state={'observation': states[i]}, action=int(actions[i]), reward=float(rewards[i]),
+                        next_state={'observation': states[min(i + 1, T - 1)]}, game_over=bool(go[i]))
+             for i in range(T)]
+    for t in trans:
+        t.n_step_discounted_rewards = 0.0
+
+    class Fake(ClippedPPOAgent):
+        def __init__(self):
+            pass
+    f = Fake()
+    sink = _Obj(add_sample=lambda v: None)
+    wrapper = _Obj(input_embedders_parameters={'observation': None}, batch_size=B, learning_rate_decay_rate=0,
+                   learning_rate=1e-3)
+    f.ap = _Obj(network_wrappers={'main': wrapper},
+                algorithm=_Obj(discount=0.99, gae_lambda=0.95, estimate_state_value_using_gae=True,
+                               update_pre_network_filters_state_on_train=False,
+                               num_consecutive_training_steps=1,
+                               num_consecutive_playing_steps=EnvironmentSteps(T), optimization_epochs=epochs,
+                               clipping_decay_schedule=ConstantSchedule(1)))
+    f.policy_gradient_rescaler = PolicyGradientRescaler.GAE
+    f.spaces = _Obj(action=DiscreteActionSpace(A))
+    for sig in ("state_values", "action_advantages", "unclipped_grads", "value_targets", "likelihood_ratio",
+                "clipped_likelihood_ratio", "value_loss", "policy_loss", "loss", "curr_learning_rate", "entropy",
+                "kl_divergence"):
+        setattr(f, sig, sink)
+    f.memory = _Obj(transitions=trans)
+    f.pre_network_filter = _Obj(filter=lambda dataset, deep_copy=False, update_internal_state=False: dataset)
+    f._should_train = lambda: True
+    f.post_training_commands = lambda: None
+    f.update_log = lambda: None
+    f.training_iteration = 0
+    f.networks = {'main': OB.PPOWrapper(net)}
+    random.seed(71)
+    f.train()
+    out["ppo|states"], out["ppo|actions"], out["ppo|rewards"], out["ppo|go"] = states, actions, rewards, go
+    out["ppo|hp"] = np.array([D, A, B, n_env, L, epochs, 71])
+    out["ppo|adv"] = np.array([t.info['advantage'] for t in trans])       # (dataset was shuffled in place:
+    out["ppo|adv_state0"] = np.array([t.state['observation'][0] for t in trans])   # keyed by state[0])
+    _flat("ppo|final", net.weights(), out)
+    _save("ppo_update", **out)
+
+
 GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,128 @@
+"""Whole-update pins: the oracle's update functions (`ddpg_update`, `td3_update`, `sac_update`,
+`DQNOracle.learn_from_batch`) against fixtures produced by the REFERENCE's own
+`learn_from_batch` code (agents/{ddpg,td3,soft_actor_critic,dqn}_agent.py) executing in the build
+container on oracle-backed network stand-ins (tests/golden/make_golden.py `updates`,
+tests/golden/_oracle_backend.py).  Both sides share the oracle's layer arithmetic, so what is pinned
+is everything the agent code decides: which network sees which input, the order of the passes, the TD /
+value targets, the sign and weighting of the policy gradients, when the actor is updated.
+Tolerance: 1e-6 absolute on weights after three updates (fp32; the reference mixes in float64 scalars)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ac_nets as O
+from oracle.agents import DQNOracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(HERE, "golden", "updates.npz"))
+
+
+def _arrays(fx, prefix):
+    out = {}
+    for k in fx.files:
+        if k.startswith(prefix + "|init|"):
+            _, _, name, t = k.split("|")
+            out.setdefault(name, {})[int(t)] = fx[k]
+    return {name: [towers[t] for t in sorted(towers)] for name, towers in out.items()}
+
+
+def _select(arrays, root):
+    return {k: v for k, v in arrays.items() if k.startswith(root)}
+
+
+def _batch(fx, prefix, it):
+    return tuple(fx["%s|batch%d|%s" % (prefix, it, k)] for k in ("s", "a", "r", "done", "ns"))
+
+
+def _check_final(fx, prefix, net, atol=1e-6):
+    n = 0
+    for name, towers in net.weights().items():
+        for t, arr in towers.items():
+            np.testing.assert_allclose(arr, fx["%s|%s|%d" % (prefix, name, t)], rtol=0, atol=atol,
+                                       err_msg="%s %s[%d]" % (prefix, name, t))
+            n += 1
+    assert n > 0
+
+
+@pytest.mark.parametrize("name,streams", [("ddpg", 1), ("td3", 2)])
+def test_ddpg_td3_update_equals_reference_learn_from_batch(fx, name, streams):
+    arrays = _arrays(fx, name)
+    actor = O.ActorOracle(_select(arrays, "actor/"), 1.0, lr=1e-3)
+    critic = O.CriticOracle(_select(arrays, "critic/"), streams=streams, lr=1e-3)
+    A = fx["%s|batch1|a" % name].shape[1]
+    for it in range(1, 4):
+        batch = _batch(fx, name, it)
+        if name == "ddpg":
+            r = O.ddpg_update(actor, critic, batch, 0.99)
+        else:
+            r = O.td3_update(actor, critic, batch, fx["td3|noise%d" % it], it, np.full(A, -1.0, np.float32),
+                             np.full(A, 1.0, np.float32), 0.99, noise_clipping=0.5, policy_every=2)
+        np.testing.assert_allclose(r["loss"], float(fx["%s|loss%d" % (name, it)]), rtol=1e-5)
+        if name == "ddpg" or it % 2 == 0:
+            actor.mix_target(0.01); critic.mix_target(0.01)
+    _check_final(fx, name + "|final|actor", actor)
+    _check_final(fx, name + "|final|critic", critic)
+
+
+def test_sac_update_equals_reference_learn_from_batch(fx):
+    arrays = _arrays(fx, "sac")
+    pol = O.SACPolicyOracle(_select(arrays, "policy/"))
+    qn = O.SACQOracle(_select(arrays, "q/"))
+    vn = O.SACValueOracle(_select(arrays, "v/"))
+    for it in range(1, 4):
+        r = O.sac_update(pol, qn, vn, _batch(fx, "sac", it), fx["sac|normals%d" % it], 0.99, resample=True)
+        np.testing.assert_allclose(r["loss"], float(fx["sac|loss%d" % it]), rtol=1e-5)
+        vn.mix_target(0.005)
+    _check_final(fx, "sac|final|policy", pol)
+    _check_final(fx, "sac|final|q", qn)
+    _check_final(fx, "sac|final|v", vn)
+
+
+def test_dqn_update_equals_reference_learn_from_batch(fx):
+    arrays = _arrays(fx, "dqn")
+    D, A = fx["dqn|batch1|s"].shape[1], int(arrays["main/q_head/dense/kernel"][0].shape[1])
+    o = DQNOracle(arrays, (D,), A, lr=1e-3)
+    for it in range(1, 4):
+        s, a, r, done, ns = _batch(fx, "dqn", it)
+        res = o.learn_from_batch(s, ns, a, r, done, 0.99, None, False)
+        np.testing.assert_allclose(res["loss"], float(fx["dqn|loss%d" % it]), rtol=1e-5)
+        if it == 2:
+            o.update_target(1.0)
+    _check_final(fx, "dqn|final|main", o)
+
+
+def test_clipped_ppo_train_equals_reference_train():
+    """ClippedPPOAgentOracle.train vs the reference's ClippedPPOAgent.train (clipped_ppo_agent.py:314-344)
+    run on the oracle-backed stand-in: same transitions, weights and `random` seed -> same dataset
+    shuffle, same per-epoch Batch.shuffle, same standardised advantages, same weights after
+    epochs x minibatches updates."""
+    import random
+    from oracle.agents import ClippedPPOAgentOracle
+    fx = np.load(os.path.join(HERE, "golden", "ppo_update.npz"))
+    D, A, B, n_env, L, epochs, seed = (int(x) for x in fx["ppo|hp"])
+    arrays = _arrays(fx, "ppo")
+
+    class Env(object):
+        kind, n_env = 1, 0
+    Env.n_env = n_env
+    o = ClippedPPOAgentOracle(arrays, Env(), A, discount=0.99, gae_lambda=0.95, batch_size=B,
+                              playing_steps=n_env * L, epochs=epochs, clip_eps=0.2, beta_entropy=0.01, lr=1e-3,
+                              reward_clip=None)
+    o._ensure_net((D,))
+    s, a, r, go = fx["ppo|states"], fx["ppo|actions"], fx["ppo|rewards"], fx["ppo|go"]
+    for e in range(n_env):
+        o.transitions[e] = [(s[i], int(a[i]), float(r[i]), bool(go[i])) for i in range(e * L, (e + 1) * L)]
+    random.seed(seed)
+    res = o.train()
+    assert len(res) == epochs
+    # standardised advantages, matched through the first state component (the reference shuffled its
+    # dataset in place)
+    by_key = {float(k): v for k, v in zip(fx["ppo|adv_state0"], fx["ppo|adv"])}
+    ref_adv = np.array([by_key[float(x)] for x in s[:, 0]])
+    np.testing.assert_allclose(o.dbg["adv"], ref_adv, rtol=1e-6, atol=1e-7)
+    _check_final(fx, "ppo|final", o.net, atol=2e-6)
