@@ -1,8 +1,10 @@
-"""The Clipped-PPO data-parallel path end to end on ONE GPU box: two ranks (both on cuda:0, gloo
-backend because RCCL refuses two ranks on one device) run a full iteration with rank-sharded envs.
-Checks: weights stay bit-identical across ranks without a broadcast; the overlapped two-bucket
+"""The data-parallel paths end to end on ONE GPU box: two ranks (both on cuda:0, gloo backend because
+RCCL refuses two ranks on one device) with rank-sharded envs.
+Clipped PPO: weights stay bit-identical across ranks without a broadcast; the overlapped two-bucket
 all-reduce (FC + heads first, convs later) gives exactly the weights of the single blocking
-all-reduce; splitting the backward pass does not change the gradients."""
+all-reduce; splitting the backward pass does not change the gradients; observation running statistics
+are shared between the ranks.  DQN / TD3 / SAC: the update captured as hipGraph segments cut at every
+gradient all-reduce equals eager execution bit for bit.  Real RCCL (backend "nccl") at world size 1."""
 import os
 import socket
 import sys
