@@ -691,8 +691,65 @@ def gen_ppo_update():
     _save("ppo_update", **out)
 
 
+def gen_cadence():
+    """Agent.train scheduling (agents/agent.py:640-784: _should_train, num_consecutive_training_steps,
+    _should_update_online_weights_to_target) of the REFERENCE, one env stepping: per env-step, how many
+    learn_from_batch calls and target copies happen.  tests/test_update_pins.py replays the same step
+    sequence through the oracle agent loop (oracle.agents.DQNAgentOracle.train, n_env = 1)."""
+    from rl_coach.agents.dqn_agent import DQNAgent
+    from rl_coach.core_types import EnvironmentSteps, TrainingSteps
+    out = {}
+    cases = {"p1_t10": (1, ("env", 10), 1), "p4_t10": (4, ("env", 10), 1), "p3_t7": (3, ("env", 7), 1),
+             "p2_tt3_c2": (2, ("train", 3), 2)}
+    for name, (playing, (tk, tn), consecutive) in cases.items():
+        class Fake(DQNAgent):
+            def __init__(self):
+                pass
+
+            def call_memory(self, func, args=()):
+                return {'num_transitions': self.n_stored, 'sample': [_transition(0)] * 4}[func]
+
+            def learn_from_batch(self, batch):
+                self.learned += 1
+                return 0.0, [], 0.0
+        f = Fake()
+        sink = _Obj(add_sample=lambda v: None)
+        f.ap = _Obj(is_batch_rl_training=False, visualization=_Obj(dump_csv=False),
+                    network_wrappers={'main': _Obj(batch_size=4, learning_rate_decay_rate=0, learning_rate=1e-3)},
+                    algorithm=_Obj(act_for_full_episodes=False,
+                                   num_consecutive_playing_steps=EnvironmentSteps(playing),
+                                   num_consecutive_training_steps=consecutive,
+                                   num_steps_between_copying_online_weights_to_target=
+                                   EnvironmentSteps(tn) if tk == "env" else TrainingSteps(tn),
+                                   rate_for_copying_weights_to_target=1.0,
+                                   update_pre_network_filters_state_on_train=False))
+        copies = []
+        net = _Obj(has_target=True, set_is_training=lambda s: None,
+                   update_target_network=lambda rate: copies.append(1))
+        f.networks = {'main': net}
+        f.pre_network_filter = None
+        f.unclipped_grads = f.curr_learning_rate = f.loss = sink
+        f.agent_logger = _Obj(create_signal_value=lambda *a, **k: None)
+        f.imitation = False
+        f.post_training_commands = lambda: None
+        f.total_steps_counter = f.last_training_phase_step = f.training_iteration = 0
+        f.last_target_network_update_step = 0
+        f.learned, f.n_stored = 0, 0
+        learned, copied = [], []
+        for t in range(1, 61):
+            f.total_steps_counter += 1
+            f.n_stored += 1
+            a, b = f.learned, len(copies)
+            f.train()
+            learned.append(f.learned - a)
+            copied.append(len(copies) - b)
+        out[name + "|learned"], out[name + "|copied"] = np.array(learned), np.array(copied)
+        out[name + "|cfg"] = np.array([playing, 0 if tk == "env" else 1, tn, consecutive])
+    _save("cadence", **out)
+
+
 GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

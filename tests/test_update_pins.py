@@ -126,3 +126,107 @@ def test_clipped_ppo_train_equals_reference_train():
     ref_adv = np.array([by_key[float(x)] for x in s[:, 0]])
     np.testing.assert_allclose(o.dbg["adv"], ref_adv, rtol=1e-6, atol=1e-7)
     _check_final(fx, "ppo|final", o.net, atol=2e-6)
+
+
+def _cadence_cases():
+    fx = np.load(os.path.join(HERE, "golden", "cadence.npz"))
+    names = sorted({k.split("|")[0] for k in fx.files})
+    return fx, names
+
+
+def test_product_training_cadence_equals_reference_agent_train():
+    """The HOST scheduling of the device agents (coach_amd/agents/vector_agent.py: _training_phases_due,
+    num_consecutive_training_steps, _should_update_online_weights_to_target) with one env, against the
+    reference's Agent.train (agent.py:640-784) executed on the same 60-step sequence: identical
+    number of updates and target copies at every env-step.  Runs on CPU: memory, networks and
+    learn_from_batch are counters."""
+    from coach_amd.agents.vector_agent import VectorOffPolicyAgent
+    from coach_amd.core_types import EnvironmentSteps, RunPhase, TrainingSteps
+    fx, names = _cadence_cases()
+    assert len(names) == 4
+    for name in names:
+        playing, tkind, tn, consecutive = (int(x) for x in fx[name + "|cfg"])
+
+        class Alg(object):
+            act_for_full_episodes = False
+            num_consecutive_playing_steps = EnvironmentSteps(playing)
+            num_consecutive_training_steps = consecutive
+            num_steps_between_copying_online_weights_to_target = TrainingSteps(tn) if tkind else EnvironmentSteps(tn)
+            rate_for_copying_weights_to_target = 1.0
+
+        class Ap(object):
+            algorithm = Alg()
+
+        class Memory(object):
+            stored = 0
+            def num_transitions(self): return self.stored
+            def draw(self, B): return [0] * B
+            def collate(self, d, B): return object()
+
+        class Net(object):
+            target, copies = object(), 0
+            def update_target(self, rate): self.copies += 1
+
+        class Agent(VectorOffPolicyAgent):
+            def __init__(self):                       # no device state: scheduling logic only
+                self.ap, self.memory, self.networks = Ap(), Memory(), {"main": Net()}
+                self.n_env, self.batch_size, self.phase = 1, 4, RunPhase.TRAIN
+                self.total_steps_counter = self.last_training_phase_step = self.training_iteration = 0
+                self.last_target_network_update_step = 0
+                self.debug_draws = self.debug_losses = None
+                self.learned = 0
+
+            def learn_from_batch(self, batch):
+                self.learned += 1
+                return 0.0
+        ag = Agent()
+        learned, copied = [], []
+        for t in range(60):
+            ag.total_steps_counter += 1
+            ag.memory.stored += 1
+            a, b = ag.learned, ag.networks["main"].copies
+            ag.train()
+            learned.append(ag.learned - a)
+            copied.append(ag.networks["main"].copies - b)
+        np.testing.assert_array_equal(learned, fx[name + "|learned"], err_msg=name)
+        np.testing.assert_array_equal(copied, fx[name + "|copied"], err_msg=name)
+
+
+def test_oracle_loop_cadence_equals_reference_agent_train():
+    """oracle.agents.DQNAgentOracle.train (n_env = 1) on the same sequences (env-step target cadence)."""
+    from oracle.agents import DQNAgentOracle
+    fx, names = _cadence_cases()
+    checked = 0
+    for name in names:
+        playing, tkind, tn, consecutive = (int(x) for x in fx[name + "|cfg"])
+        if tkind or consecutive != 1:
+            continue                                   # the oracle loop models EnvironmentSteps cadence
+        o = DQNAgentOracle.__new__(DQNAgentOracle)
+        o.n_env, o.per, o.B, o.discount, o.double = 1, None, 4, 0.99, False
+        o.playing_steps, o.target_every = playing, tn
+        o.total_steps = o.last_train = o.last_target = o.training_iteration = 0
+        o.count, o.losses = 0, []
+        counts = {"learn": 0, "copy": 0}
+
+        class Net(object):
+            def learn_from_batch(self, *a):
+                counts["learn"] += 1
+                return dict(loss=0.0, td_errors=np.zeros(4))
+
+            def update_target(self, rate):
+                counts["copy"] += 1
+        o.net = Net()
+        o._draw = lambda B: [0] * B
+        o._collate = lambda d, B: ((None,) * 5, None, None)
+        learned, copied = [], []
+        for t in range(60):
+            o.total_steps += 1
+            o.count += 1
+            a, b = counts["learn"], counts["copy"]
+            o.train()
+            learned.append(counts["learn"] - a)
+            copied.append(counts["copy"] - b)
+        np.testing.assert_array_equal(learned, fx[name + "|learned"], err_msg=name)
+        np.testing.assert_array_equal(copied, fx[name + "|copied"], err_msg=name)
+        checked += 1
+    assert checked == 3
