@@ -137,6 +137,13 @@ class DQNAgent(VectorOffPolicyAgent):
 
 
 class DDQNAgentParameters(DQNAgentParameters):           # ddqn_agent.py:24-34
+    def __init__(self):
+        super().__init__()
+        # Double DQN's own defaults: slower target copies, lower final / evaluation epsilon
+        self.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(30000)
+        self.exploration.epsilon_schedule = LinearSchedule(1, 0.01, 1000000)
+        self.exploration.evaluation_epsilon = 0.001
+
     @property
     def path(self):
         return 'coach_amd.agents.dqn_agent:DDQNAgent'

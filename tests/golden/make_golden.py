@@ -748,8 +748,50 @@ def gen_cadence():
     _save("cadence", **out)
 
 
+def gen_defaults():
+    """Default hyper-parameters of the reference's AgentParameters classes (algorithm + every network
+    wrapper + exploration), instantiated here under the import stubs -> tests/golden/defaults.json.
+    tests/test_update_pins.py compares every field the device agents' parameter classes also carry."""
+    import json
+    from rl_coach.agents.clipped_ppo_agent import ClippedPPOAgentParameters
+    from rl_coach.agents.ddpg_agent import DDPGAgentParameters
+    from rl_coach.agents.ddqn_agent import DDQNAgentParameters
+    from rl_coach.agents.dqn_agent import DQNAgentParameters
+    from rl_coach.agents.soft_actor_critic_agent import SoftActorCriticAgentParameters
+    from rl_coach.agents.td3_agent import TD3AgentParameters
+
+    def scalars(o):
+        out = {}
+        for k, v in (vars(o).items() if hasattr(o, "__dict__") else ()):
+            if k.startswith('_'):
+                continue
+            if isinstance(v, (int, float, bool, str, type(None))):
+                out[k] = v
+            elif hasattr(v, 'num_steps'):
+                out[k] = [type(v).__name__, v.num_steps]
+            elif isinstance(v, (tuple, list)) and all(isinstance(x, (int, float)) for x in v):
+                out[k] = list(v)
+            elif hasattr(v, 'current_value') and hasattr(v, 'initial_value'):
+                out[k] = ["schedule", type(v).__name__, float(v.initial_value),
+                          float(getattr(v, 'final_value', v.initial_value)),
+                          int(getattr(v, 'decay_steps', 0) or 0)]
+        return out
+    out = {}
+    for P in (DQNAgentParameters, DDQNAgentParameters, ClippedPPOAgentParameters, DDPGAgentParameters,
+              TD3AgentParameters, SoftActorCriticAgentParameters):
+        ap = P()
+        out[P.__name__] = {"algorithm": scalars(ap.algorithm),
+                           "networks": {n: scalars(w) for n, w in ap.network_wrappers.items()},
+                           "exploration": dict(scalars(ap.exploration), **{"class": type(ap.exploration).__name__}),
+                           "memory": dict(scalars(ap.memory), **{"class": type(ap.memory).__name__})}
+    path = os.path.join(HERE, "defaults.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote %s" % path)
+
+
 GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -230,3 +230,57 @@ def test_oracle_loop_cadence_equals_reference_agent_train():
         np.testing.assert_array_equal(copied, fx[name + "|copied"], err_msg=name)
         checked += 1
     assert checked == 3
+
+
+def _mine(obj):
+    """Scalar / step / schedule fields of one of the device agents' parameter objects, in the fixture's form."""
+    out = {}
+    for k, v in vars(obj).items():
+        if isinstance(v, (int, float, bool, str, type(None))):
+            out[k] = v
+        elif hasattr(v, "num_steps"):
+            out[k] = [type(v).__name__, v.num_steps]
+        elif isinstance(v, (tuple, list)) and all(isinstance(x, (int, float)) for x in v):
+            out[k] = list(v)
+        elif hasattr(v, "current_value") and hasattr(v, "initial_value"):
+            out[k] = ["schedule", type(v).__name__, float(v.initial_value),
+                      float(getattr(v, "final_value", v.initial_value)), int(getattr(v, "decay_steps", 0) or 0)]
+    return out
+
+
+def test_default_hyperparameters_equal_reference():
+    """Every hyper-parameter the device agents' parameter classes carry under the reference's name has
+    the reference's default (fixture: the reference's AgentParameters classes instantiated in the build
+    container, tests/golden/defaults.json).  Fields this engine adds (reward_clipping, reward_rescale,
+    resample_noise_per_pass, ...) have no counterpart and are not compared."""
+    import json
+    from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgentParameters
+    from coach_amd.agents.ddpg_agent import DDPGAgentParameters
+    from coach_amd.agents.dqn_agent import DDQNAgentParameters, DQNAgentParameters
+    from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgentParameters
+    from coach_amd.agents.td3_agent import TD3AgentParameters
+    ref = json.load(open(os.path.join(HERE, "golden", "defaults.json")))
+    # the network shapes are given as tuples of layer widths here and as scheme enums in the reference
+    skip = {"embedder_scheme", "middleware_scheme", "observation_embedder_scheme", "action_embedder_scheme"}
+    compared, bad = 0, []
+    for P in (DQNAgentParameters, DDQNAgentParameters, ClippedPPOAgentParameters, DDPGAgentParameters,
+              TD3AgentParameters, SoftActorCriticAgentParameters):
+        ap, r = P(), ref[P.__name__]
+        groups = [("algorithm", _mine(ap.algorithm), r["algorithm"])]
+        for n, w in ap.network_wrappers.items():
+            groups.append(("networks/" + n, _mine(w), r["networks"][n]))
+        if getattr(ap, "exploration", None) is not None and r["exploration"]["class"] != "dict":
+            groups.append(("exploration", _mine(ap.exploration), r["exploration"]))
+        if getattr(ap, "memory", None) is not None:
+            groups.append(("memory", _mine(ap.memory), r["memory"]))
+        for gname, mine, theirs in groups:
+            for k, v in mine.items():
+                if k in skip or k not in theirs:
+                    continue
+                compared += 1
+                same = v == theirs[k] or (isinstance(v, float) and isinstance(theirs[k], (int, float)) and
+                                          abs(v - theirs[k]) <= 1e-12 * max(1.0, abs(v)))
+                if not same:
+                    bad.append("%s.%s.%s: here %r, reference %r" % (P.__name__, gname, k, v, theirs[k]))
+    assert not bad, "\n".join(bad)
+    assert compared >= 120, compared
