@@ -89,6 +89,8 @@ def build_off_policy(name, device, dist):
         ap = DQNAgentParameters()
         ap.memory = PrioritizedExperienceReplayParameters()
         ap.memory.max_size = (MemoryGranularity.Transitions, 1 << 20)
+        from coach_amd.schedules import LinearSchedule
+        ap.memory.beta = LinearSchedule(0.4, 1.0, 12500000)                    # presets/Atari_DQN_with_PER.py
         ap.algorithm.reward_clipping = (-1.0, 1.0)
         env = SyntheticVectorEnvironment(EP("image", n_env, FRAME, 4, episode_length=1024, seed=1234), device, rank=dist.rank)
         return DQNAgent(ap, env, device, dist=dist)

@@ -790,8 +790,62 @@ def gen_defaults():
     print("wrote %s" % path)
 
 
+def gen_presets():
+    """The agent hyper-parameters of the reference PRESETS this engine mirrors, read from the preset
+    modules imported here under the stubs (rl_coach/presets/{CartPole_DQN, Atari_Dueling_DDQN,
+    Mujoco_ClippedPPO, Atari_DQN_with_PER, Mujoco_TD3, Mujoco_SAC}.py) -> tests/golden/presets.json."""
+    import importlib
+    import json
+
+    def scalars(o):
+        out = {}
+        for k, v in (vars(o).items() if hasattr(o, "__dict__") else ()):
+            if k.startswith('_'):
+                continue
+            if isinstance(v, (int, float, bool, str, type(None))):
+                out[k] = v
+            elif hasattr(v, 'num_steps'):
+                out[k] = [type(v).__name__, v.num_steps]
+            elif isinstance(v, (tuple, list)) and all(isinstance(x, (int, float)) for x in v):
+                out[k] = list(v)
+            elif hasattr(v, 'current_value') and hasattr(v, 'initial_value'):
+                out[k] = ["schedule", type(v).__name__, float(v.initial_value),
+                          float(getattr(v, 'final_value', v.initial_value)),
+                          int(getattr(v, 'decay_steps', 0) or 0)]
+        return out
+    out = {}
+    for name in ("CartPole_DQN", "Atari_Dueling_DDQN", "Mujoco_ClippedPPO", "Atari_DQN_with_PER", "Mujoco_TD3",
+                 "Mujoco_SAC"):
+        gm = importlib.import_module("rl_coach.presets." + name).graph_manager
+        ap = gm.agent_params
+        nets = {}
+        for n, w in ap.network_wrappers.items():
+            nets[n] = scalars(w)
+            heads = getattr(w, "heads_parameters", None) or []
+            nets[n]["heads"] = [[type(h).__name__, float(getattr(h, "rescale_gradient_from_head_by_factor", 1.0))]
+                                for h in heads]
+            def widths(scheme):           # a scheme is an enum member or an explicit list of layers
+                if isinstance(scheme, (list, tuple)):
+                    return [getattr(l, "units", getattr(l, "num_filters", None)) for l in scheme]
+                return str(scheme)
+            nets[n]["middleware_layers"] = widths(getattr(getattr(w, "middleware_parameters", None), "scheme", None))
+            emb = getattr(w, "input_embedders_parameters", {}) or {}
+            nets[n]["embedder_layers"] = {k: widths(getattr(e, "scheme", None)) for k, e in emb.items()}
+            nets[n]["embedder_activation"] = {k: getattr(e, "activation_function", None) for k, e in emb.items()}
+            nets[n]["middleware_activation"] = getattr(getattr(w, "middleware_parameters", None),
+                                                       "activation_function", None)
+        out[name] = {"agent_class": type(ap).__name__, "algorithm": scalars(ap.algorithm), "networks": nets,
+                     "exploration": dict(scalars(ap.exploration), **{"class": type(ap.exploration).__name__}),
+                     "memory": dict(scalars(ap.memory), **{"class": type(ap.memory).__name__}),
+                     "schedule": scalars(gm.schedule_params) if hasattr(gm, "schedule_params") else {}}
+    path = os.path.join(HERE, "presets.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote %s" % path)
+
+
 GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

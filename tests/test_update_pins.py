@@ -284,3 +284,82 @@ def test_default_hyperparameters_equal_reference():
                     bad.append("%s.%s.%s: here %r, reference %r" % (P.__name__, gname, k, v, theirs[k]))
     assert not bad, "\n".join(bad)
     assert compared >= 120, compared
+
+
+def _layers(v):
+    """A network shape as the fixture writes it: 'Medium' / 'Empty' scheme names or a list of widths."""
+    if isinstance(v, str):
+        return v.split(".")[-1]
+    return [int(x) for x in v]
+
+
+def _compare_agent_params(ap, ref, label, bad, extra_skip=()):
+    skip = {"embedder_scheme", "middleware_scheme", "observation_embedder_scheme", "action_embedder_scheme"} | set(extra_skip)
+    n = 0
+    groups = [("algorithm", _mine(ap.algorithm), ref["algorithm"])]
+    for name, w in ap.network_wrappers.items():
+        groups.append(("networks/" + name, _mine(w), ref["networks"][name]))
+    if getattr(ap, "exploration", None) is not None and ref["exploration"]["class"] != "dict":
+        groups.append(("exploration", _mine(ap.exploration), ref["exploration"]))
+    if getattr(ap, "memory", None) is not None:
+        groups.append(("memory", _mine(ap.memory), ref["memory"]))
+    for gname, mine, theirs in groups:
+        for k, v in mine.items():
+            if k in skip or k not in theirs:
+                continue
+            n += 1
+            same = v == theirs[k] or (isinstance(v, float) and isinstance(theirs[k], (int, float)) and
+                                      abs(v - theirs[k]) <= 1e-12 * max(1.0, abs(v)))
+            if not same:
+                bad.append("%s.%s.%s: here %r, reference %r" % (label, gname, k, v, theirs[k]))
+    return n
+
+
+def test_presets_equal_reference_presets():
+    """The agent hyper-parameters of this package's presets against the reference preset modules
+    (imported in the build container -> tests/golden/presets.json): CartPole_DQN, Atari_Dueling_DDQN,
+    Mujoco_ClippedPPO preset for preset; Atari_DQN_with_PER / Mujoco_TD3 / Mujoco_SAC (the BASELINE
+    configs C3 / C4 / C5, which bench.py builds from the parameter classes' defaults) against those
+    defaults.  Environment and schedule sizes are this engine's (synthetic envs, smoke-sized runs)."""
+    import importlib
+    import json
+    from coach_amd.agents.dqn_agent import DQNAgentParameters
+    from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgentParameters
+    from coach_amd.agents.td3_agent import TD3AgentParameters
+    from coach_amd.memories.non_episodic.prioritized_experience_replay import PrioritizedExperienceReplayParameters
+    ref = json.load(open(os.path.join(HERE, "golden", "presets.json")))
+    bad, n = [], 0
+    for name in ("CartPole_DQN", "Atari_Dueling_DDQN", "Mujoco_ClippedPPO"):
+        ap = importlib.import_module("coach_amd.presets." + name).graph_manager.agent_params
+        r = ref[name]
+        assert type(ap).__name__ == r["agent_class"], name
+        n += _compare_agent_params(ap, r, name, bad)
+        for wname, w in ap.network_wrappers.items():
+            rn = r["networks"][wname]
+            # network shape: scheme names or explicit widths, under this package's attribute names
+            if hasattr(w, "middleware_scheme"):
+                n += 1
+                if _layers(w.middleware_scheme) != _layers(rn["middleware_layers"]):
+                    bad.append("%s.%s middleware: here %r, reference %r" % (name, wname, w.middleware_scheme, rn["middleware_layers"]))
+            if hasattr(w, "embedder_scheme"):
+                n += 1
+                if _layers(w.embedder_scheme) != _layers(rn["embedder_layers"]["observation"]):
+                    bad.append("%s.%s embedder: here %r, reference %r" % (name, wname, w.embedder_scheme, rn["embedder_layers"]["observation"]))
+            n += 1
+            if w.activation_function != rn["middleware_activation"]:
+                bad.append("%s.%s activation: here %r, reference %r" % (name, wname, w.activation_function, rn["middleware_activation"]))
+            if hasattr(w, "heads_parameters"):
+                n += 1
+                mine = [[type(h).__name__, float(h.rescale_gradient_from_head_by_factor)] for h in w.heads_parameters]
+                if mine != rn["heads"]:
+                    bad.append("%s.%s heads: here %r, reference %r" % (name, wname, mine, rn["heads"]))
+    from coach_amd.schedules import LinearSchedule
+    ap = DQNAgentParameters()
+    ap.memory = PrioritizedExperienceReplayParameters()
+    assert _mine(ap.memory)["beta"] == ["schedule", "ConstantSchedule", 0.4, 0.4, 0]      # the class default ...
+    ap.memory.beta = LinearSchedule(0.4, 1.0, 12500000)         # ... annealed by the preset (as bench.py c3 sets it)
+    for label, params, rname in (("C3", ap, "Atari_DQN_with_PER"), ("C4", TD3AgentParameters(), "Mujoco_TD3"),
+                                 ("C5", SoftActorCriticAgentParameters(), "Mujoco_SAC")):
+        n += _compare_agent_params(params, ref[rname], label + "/" + rname, bad)
+    assert not bad, "\n".join(bad)
+    assert n >= 150, n
