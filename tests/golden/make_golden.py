@@ -745,6 +745,26 @@ def gen_cadence():
             copied.append(len(copies) - b)
         out[name + "|learned"], out[name + "|copied"] = np.array(learned), np.array(copied)
         out[name + "|cfg"] = np.array([playing, 0 if tk == "env" else 1, tn, consecutive])
+
+    # act_for_full_episodes (Clipped PPO, TD3): a phase opens only when the running episode is complete
+    for name, playing, L in (("full_p20_L8", 20, 8), ("full_p16_L16", 16, 16), ("full_p5_L3", 5, 3)):
+        class FakeFull(DQNAgent):
+            def __init__(self):
+                pass
+
+            def call_memory(self, func, args=()):
+                return self.n_stored
+        f = FakeFull()
+        f.ap = _Obj(algorithm=_Obj(act_for_full_episodes=True, num_consecutive_playing_steps=EnvironmentSteps(playing)))
+        f.total_steps_counter = f.last_training_phase_step = f.n_stored = 0
+        opened = []
+        for t in range(1, 81):
+            f.total_steps_counter += 1
+            f.n_stored += 1
+            f.current_episode_buffer = _Obj(is_complete=(t % L == 0))
+            opened.append(int(f._should_train()))
+        out[name + "|opened"] = np.array(opened)
+        out[name + "|cfg"] = np.array([playing, L])
     _save("cadence", **out)
 
 

@@ -130,7 +130,7 @@ def test_clipped_ppo_train_equals_reference_train():
 
 def _cadence_cases():
     fx = np.load(os.path.join(HERE, "golden", "cadence.npz"))
-    names = sorted({k.split("|")[0] for k in fx.files})
+    names = sorted({k.split("|")[0] for k in fx.files if not k.startswith("full_")})
     return fx, names
 
 
@@ -363,3 +363,37 @@ def test_presets_equal_reference_presets():
         n += _compare_agent_params(params, ref[rname], label + "/" + rname, bad)
     assert not bad, "\n".join(bad)
     assert n >= 150, n
+
+
+def test_ppo_should_train_equals_reference_with_full_episodes():
+    """ClippedPPOAgent._should_train of the device agent (enough env-steps AND the lockstep episodes
+    complete) against the reference's Agent._should_train with act_for_full_episodes = True
+    (agent.py:662-699) on 80-step sequences with episodes of fixed length L, one env."""
+    from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
+    from coach_amd.core_types import EnvironmentSteps
+    fx = np.load(os.path.join(HERE, "golden", "cadence.npz"))
+    names = sorted({k.split("|")[0] for k in fx.files if k.startswith("full_")})
+    assert len(names) == 3
+    for name in names:
+        playing, L = (int(x) for x in fx[name + "|cfg"])
+
+        class Memory(object):
+            steps = 0
+            def num_transitions(self): return self.steps
+
+        class Alg(object):
+            num_consecutive_playing_steps = EnvironmentSteps(playing)
+
+        class Ap(object):
+            algorithm = Alg()
+        ag = ClippedPPOAgent.__new__(ClippedPPOAgent)
+        ag.ap, ag.memory, ag.L = Ap(), Memory(), L
+        ag.total_steps_counter = ag.last_training_phase_step = 0
+        opened = []
+        for t in range(80):
+            ag.total_steps_counter += 1
+            ag.memory.steps += 1
+            opened.append(int(ag._should_train()))
+            if opened[-1]:
+                ag.memory.steps = 0                      # post_training_commands: memory.clean()
+        np.testing.assert_array_equal(opened, fx[name + "|opened"], err_msg=name)
