@@ -21,6 +21,34 @@ def test_oracle_exploration_matches_reference(golden):
     assert np.array_equal(a, g["an_actions"])
 
 
+def test_product_egreedy_host_draws_match_reference(golden):
+    """coach_amd EGreedy.draw() — the HOST half of the device policy (the order in which the legacy
+    np.random stream is consumed, the epsilon schedule stepping) — replayed against the reference's
+    EGreedy.get_action run under the same seed (fixture `explore`): epsilon, the explore draw, the random
+    action / tie-break randoms of every call are bit-identical, hence so are the actions (the device half,
+    rlx_egreedy, is checked against the same fixture in the GPU test below)."""
+    from coach_amd.core_types import RunPhase
+    from coach_amd.exploration_policies.e_greedy import EGreedy
+    from coach_amd.schedules import LinearSchedule
+    g = golden("explore")
+    A = g["eg_q"].shape[1]
+    pol = EGreedy.__new__(EGreedy)                       # no device members: draw() is host-only
+    pol.A, pol.n_env, pol.phase = A, 1, RunPhase.TRAIN
+    pol.epsilon_schedule, pol.evaluation_epsilon = LinearSchedule(0.5, 0.1, 100), 0.05
+    np.random.seed(4)
+    pol.current_random_value = np.array([np.random.rand()])
+    acts = []
+    for i in range(len(g["eg_q"])):
+        eps, u, ra, tie = pol.draw()
+        assert eps == g["eg_eps"][i] and u[0] == g["eg_explore_u"][i], i
+        if u[0] < eps:
+            assert ra[0] == g["eg_rand_act"][i], i
+        else:
+            assert np.array_equal(tie[0], g["eg_tie"][i]), i
+        acts.append(E.egreedy_choice(g["eg_q"][i], u[0], ra[0], tie[0], eps))
+    assert acts == g["eg_actions"].tolist()
+
+
 def test_oracle_philox_known_answers():
     """Random123 kat_vectors, philox4x32 with 10 rounds."""
     def run(c, k):
