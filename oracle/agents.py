@@ -327,7 +327,25 @@ class _VectorLoopOracle:
             r = Fl.reward_clip(r, *self.reward_clip)
         return np.float32(r)
 
+    # reference_order: reproduce WHEN the reference makes a transition visible to sampling.  In
+    # LevelManager.step (level_manager.py:231-267) the response of env.step is observed — turned into a
+    # Transition and stored (agent.py:905-973) — at the START of the next step, after the train() call
+    # of the current one; only a terminal response is observed immediately.  So when Agent.train samples
+    # after step k, the transition of step k is not in the memory yet (unless it ended the episode).
+    # False (default) stores every transition at once, which is what the device agents do.
+    reference_order = False
+
+    def _store_row(self, row):
+        self.rows[self.cursor] = row
+        self.cursor = (self.cursor + 1) % self.cap
+        self.count = min(self.count + 1, self.cap)
+        if self.per is not None:
+            self.per.store()
+
     def _step_envs(self, actions, record=True):
+        for row in getattr(self, "_held", ()):           # the previous step's responses are observed now
+            self._store_row(row)
+        self._held = []
         nxt, rst, rew, done = self.env.step()
         for e in range(self.n_env):
             r = self._filter_reward(rew[e])
@@ -336,11 +354,11 @@ class _VectorLoopOracle:
             else:
                 ns = nxt[e].copy()
             if record:
-                self.rows[self.cursor] = (self.cur[e], actions[e], r, bool(done[e]), ns)
-                self.cursor = (self.cursor + 1) % self.cap
-                self.count = min(self.count + 1, self.cap)
-                if self.per is not None:
-                    self.per.store()
+                row = (self.cur[e], actions[e], r, bool(done[e]), ns)
+                if self.reference_order and not done[e]:
+                    self._held.append(row)
+                else:
+                    self._store_row(row)
             if done[e]:
                 if self.image:
                     self.stackers[e].reset()

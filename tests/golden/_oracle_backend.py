@@ -182,7 +182,7 @@ class DQNWrapper(_Wrapper):
             def __init__(self, target):
                 self.target = target
 
-            def predict(self, inputs):
+            def predict(self, inputs, outputs=None):
                 return w.o.q(_obs(inputs), target=self.target)
 
         self.online_network, self.target_network = Net(False), Net(True)

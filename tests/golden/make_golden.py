@@ -864,8 +864,107 @@ def gen_presets():
     print("wrote %s" % path)
 
 
+def gen_loop():
+    """The REAL reference agent — `DQNAgent(DQNAgentParameters())` constructed by its own __init__
+    (memory, exploration policy, filters, signals), with only `create_networks` overridden to return
+    the oracle-backed stand-in — driven through the reference's step cycle (LevelManager.step
+    level_manager.py:215-269: observe -> act -> env.step, terminal response observed at once;
+    GraphManager.train_and_act: train() after every step) on the synthetic env, uniform and
+    prioritized replay.  Stores every action, the number of transitions visible at every train() call,
+    a key of every sampled transition and the final weights; tests/test_update_pins.py replays
+    oracle.agents.DQNAgentOracle (reference_order=True) under the same seeds."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle.agents import DQNOracle
+    from oracle.synth_env import SynthVecEnv
+    from rl_coach.agents.dqn_agent import DQNAgent, DQNAgentParameters
+    from rl_coach.base_parameters import TaskParameters
+    from rl_coach.core_types import EnvResponse, EnvironmentSteps, RunPhase
+    from rl_coach.filters.filter import NoInputFilter, NoOutputFilter
+    from rl_coach.memories.non_episodic.prioritized_experience_replay import PrioritizedExperienceReplayParameters
+    from rl_coach.schedules import LinearSchedule
+    from rl_coach.spaces import DiscreteActionSpace, RewardSpace, SpacesDefinition, StateSpace, VectorObservationSpace
+    D, A, L, B, CAP, HEATUP, TRAIN, SEED = 4, 3, 7, 8, 32, 12, 120, 5
+    out = {"hp": np.array([D, A, L, B, CAP, HEATUP, TRAIN, SEED])}
+    rng = np.random.RandomState(0)
+    arrays = {}
+    for name, (i, o) in {"main/embedder/dense0": (D, 16), "main/middleware/dense0": (16, 12),
+                         "main/q_head/dense": (12, A)}.items():
+        arrays[name + "/kernel"] = [rng.uniform(-.5, .5, (i, o)).astype(np.float32)]
+        arrays[name + "/bias"] = [np.zeros(o, np.float32)]
+        out["init|%s/kernel" % name], out["init|%s/bias" % name] = arrays[name + "/kernel"][0], arrays[name + "/bias"][0]
+    for variant in ("uniform", "per"):
+        ap = DQNAgentParameters()
+        ap.task_parameters = TaskParameters()
+        ap.name = "agent"
+        ap.visualization.dump_csv = False
+        ap.is_a_highest_level_agent = False
+        ap.input_filter, ap.output_filter, ap.pre_network_filter = NoInputFilter(), NoOutputFilter(), NoInputFilter()
+        if variant == "per":
+            ap.memory = PrioritizedExperienceReplayParameters()           # alpha .6, constant beta .4
+        ap.network_wrappers['main'].batch_size = B
+        ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(1)
+        ap.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(10)
+        ap.memory.max_size = (MemoryGranularity.Transitions, CAP)
+        ap.exploration.epsilon_schedule = LinearSchedule(1.0, 0.1, 50)
+        holder = {}
+
+        class Agent(DQNAgent):
+            def create_networks(self):
+                net = DQNOracle(copy.deepcopy(arrays), (D,), A, lr=1e-3, huber=False)
+                holder["net"] = net
+                w = OB.DQNWrapper(net)
+                w.has_target = True
+                w.set_is_training = lambda s: None
+                w.update_target_network = lambda rate=1.0: net.update_target(rate)
+                for n in (w.online_network, w.target_network):
+                    n.reset_internal_memory = lambda: None
+                return {'main': w}
+        agent = Agent(ap)
+        agent.set_environment_parameters(SpacesDefinition(
+            state=StateSpace({'observation': VectorObservationSpace(D)}), goal=None,
+            action=DiscreteActionSpace(A), reward=RewardSpace(1)))
+        env = SynthVecEnv(1, 1, D, L, 99)
+        random.seed(SEED)
+        np.random.seed(SEED)
+        agent.exploration_policy.current_random_value = np.random.rand()      # e_greedy.py:82, after seeding
+        actions, visible, keys = [], [], []
+        sample = agent.memory.sample
+
+        def logged_sample(size):
+            b = sample(size)
+            keys.append([float(t.state['observation'][0]) for t in b])
+            visible.append(agent.memory.num_transitions())
+            return b
+        agent.memory.sample = logged_sample
+        resp = EnvResponse(next_state={'observation': env.reset()[0].copy()}, reward=0, game_over=False)
+        agent.reset_internal_state()
+        reset_required, first = False, None
+        for step in range(HEATUP + TRAIN):
+            agent.phase = RunPhase.HEATUP if step < HEATUP else RunPhase.TRAIN
+            if reset_required:
+                agent.reset_internal_state()
+                resp = EnvResponse(next_state={'observation': first.copy()}, reward=0, game_over=False)
+                reset_required = False
+            agent.observe(resp)
+            actions.append(int(agent.act().action))
+            nxt, rst, rew, done = env.step()
+            resp = EnvResponse(next_state={'observation': nxt[0].copy()}, reward=float(rew[0]), game_over=bool(done[0]))
+            if resp.game_over:
+                agent.observe(resp)
+                agent.handle_episode_ended()
+                reset_required, first = True, rst[0]
+            if step >= HEATUP:
+                agent.train()
+        out[variant + "|actions"], out[variant + "|visible"] = np.array(actions), np.array(visible)
+        out[variant + "|keys"] = np.array(keys)
+        _flat(variant + "|final", holder["net"].weights(), out)
+    _save("loop", **out)
+
+
 GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -397,3 +397,46 @@ def test_ppo_should_train_equals_reference_with_full_episodes():
             if opened[-1]:
                 ag.memory.steps = 0                      # post_training_commands: memory.clean()
         np.testing.assert_array_equal(opened, fx[name + "|opened"], err_msg=name)
+
+
+@pytest.mark.parametrize("variant", ["uniform", "per"])
+def test_oracle_agent_loop_equals_real_reference_agent_loop(variant):
+    """oracle.agents.DQNAgentOracle (n_env = 1, reference_order = True) against the REAL reference
+    DQNAgent object — built by its own __init__, with its own ExperienceReplay /
+    PrioritizedExperienceReplay, EGreedy and Agent.observe / act / train, only the network replaced by
+    the oracle stand-in — stepped through the reference's cycle for 12 heat-up + 120 training steps with
+    a 32-transition buffer (so the FIFO wraps): every action, the number of transitions visible at every
+    train(), every sampled transition and the final weights agree."""
+    import random
+    from coach_amd.schedules import LinearSchedule
+    from oracle.agents import DQNAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    fx = np.load(os.path.join(HERE, "golden", "loop.npz"))
+    D, A, L, B, CAP, HEATUP, TRAIN, SEED = (int(x) for x in fx["hp"])
+    arrays = {k[len("init|"):]: [fx[k]] for k in fx.files if k.startswith("init|")}
+    random.seed(SEED)
+    np.random.seed(SEED)
+    o = DQNAgentOracle(arrays, SynthVecEnv(1, 1, D, L, 99), A, (D,), capacity=CAP, per={} if variant == "per" else None,
+                       batch_size=B, playing_steps=1, target_every=10, huber=False, lr=1e-3,
+                       epsilon_schedule=LinearSchedule(1.0, 0.1, 50))
+    o.reference_order = True
+    o.reset()
+    actions, visible, keys = [], [], []
+    collate = o._collate
+
+    def logged(d, B_):
+        out = collate(d, B_)
+        keys.append([float(s[0]) for s in out[0][0]])
+        visible.append(o._num_transitions())
+        return out
+    o._collate = logged
+    for step in range(HEATUP + TRAIN):
+        a = o.heatup_step() if step < HEATUP else o.act()
+        actions.append(int(a[0]))
+        if step >= HEATUP:
+            o.train()
+    np.testing.assert_array_equal(actions, fx[variant + "|actions"])
+    np.testing.assert_array_equal(visible, fx[variant + "|visible"])
+    np.testing.assert_array_equal(np.array(keys), fx[variant + "|keys"])
+    _check_final(fx, variant + "|final", o.net, atol=1e-6)
+    assert max(visible) == CAP                                   # the buffer did wrap
