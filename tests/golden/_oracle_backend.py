@@ -213,9 +213,12 @@ class PPOWrapper(_Wrapper):
         class Online(object):
             output_heads = [object(), Head()]
 
-            def predict(self, inputs):
+            def predict(self, inputs, outputs=None):
                 s = _obs(inputs)
                 return [w.o.values(s)[:, None], w.o.policy_probs(s)]
+
+            def reset_internal_memory(self):
+                pass
 
         class Target(object):
             def predict(self, inputs):

@@ -963,8 +963,87 @@ def gen_loop():
     _save("loop", **out)
 
 
+def gen_ppo_loop():
+    """The REAL reference `ClippedPPOAgent(ClippedPPOAgentParameters())` (own __init__: episodic memory,
+    Categorical exploration, episode buffers, _should_train with act_for_full_episodes, train ->
+    fill_advantages -> train_network), network = oracle stand-in, stepped through the reference cycle for
+    three rollouts; tests/test_update_pins.py replays oracle.agents.ClippedPPOAgentOracle (act + train)."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle.agents import ClippedPPOOracle
+    from oracle.synth_env import SynthVecEnv
+    from rl_coach.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
+    from rl_coach.base_parameters import TaskParameters
+    from rl_coach.core_types import EnvResponse, EnvironmentSteps, RunPhase
+    from rl_coach.filters.filter import NoInputFilter, NoOutputFilter
+    from rl_coach.spaces import DiscreteActionSpace, RewardSpace, SpacesDefinition, StateSpace, VectorObservationSpace
+    D, A, L, B, PLAY, EPOCHS, STEPS, SEED = 5, 4, 8, 8, 16, 2, 48, 9
+    out = {"hp": np.array([D, A, L, B, PLAY, EPOCHS, STEPS, SEED])}
+    rng = np.random.RandomState(1)
+    arrays = _rand_arrays(rng, {"main/embedder/dense0": (D, 20, 2), "main/middleware/dense0": (20, 12, 2),
+                                "main/v_head/dense": (12, 1, 1), "main/ppo_head/policy_fc": (12, A, 1)})
+    for k, v in arrays.items():
+        for t, arr in enumerate(v):
+            out["init|%s|%d" % (k, t)] = arr
+    ap = ClippedPPOAgentParameters()
+    ap.task_parameters = TaskParameters()
+    ap.name = "agent"
+    ap.visualization.dump_csv = False
+    ap.is_a_highest_level_agent = False
+    ap.input_filter, ap.output_filter, ap.pre_network_filter = NoInputFilter(), NoOutputFilter(), NoInputFilter()
+    ap.network_wrappers['main'].batch_size = B
+    ap.network_wrappers['main'].learning_rate = 1e-3
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(PLAY)
+    ap.algorithm.optimization_epochs = EPOCHS
+    holder = {}
+
+    class Agent(ClippedPPOAgent):
+        def create_networks(self):
+            net = ClippedPPOOracle(copy.deepcopy(arrays), (D,), A, lr=1e-3,
+                                   clip_eps=self.ap.algorithm.clip_likelihood_ratio_using_epsilon,
+                                   beta_entropy=self.ap.algorithm.beta_entropy)
+            holder["net"] = net
+            w = OB.PPOWrapper(net)
+            w.has_target = True
+            return {'main': w}
+    agent = Agent(ap)
+    agent.set_environment_parameters(SpacesDefinition(
+        state=StateSpace({'observation': VectorObservationSpace(D)}), goal=None,
+        action=DiscreteActionSpace(A), reward=RewardSpace(1)))
+    agent.update_log = lambda: None
+    env = SynthVecEnv(1, 1, D, L, 77)
+    random.seed(SEED)
+    np.random.seed(SEED)
+    actions, trained_at = [], []
+    resp = EnvResponse(next_state={'observation': env.reset()[0].copy()}, reward=0, game_over=False)
+    agent.reset_internal_state()
+    agent.phase = RunPhase.TRAIN
+    reset_required, first = False, None
+    for step in range(STEPS):
+        if reset_required:
+            agent.reset_internal_state()
+            resp = EnvResponse(next_state={'observation': first.copy()}, reward=0, game_over=False)
+            reset_required = False
+        agent.observe(resp)
+        actions.append(int(agent.act().action))
+        nxt, rst, rew, done = env.step()
+        resp = EnvResponse(next_state={'observation': nxt[0].copy()}, reward=float(rew[0]), game_over=bool(done[0]))
+        if resp.game_over:
+            agent.observe(resp)
+            agent.handle_episode_ended()
+            reset_required, first = True, rst[0]
+        before = agent.training_iteration
+        agent.train()
+        if agent.training_iteration != before:
+            trained_at.append(step)
+    out["actions"], out["trained_at"] = np.array(actions), np.array(trained_at)
+    _flat("final", holder["net"].weights(), out)
+    _save("ppo_loop", **out)
+
+
 GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

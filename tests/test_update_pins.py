@@ -440,3 +440,39 @@ def test_oracle_agent_loop_equals_real_reference_agent_loop(variant):
     np.testing.assert_array_equal(np.array(keys), fx[variant + "|keys"])
     _check_final(fx, variant + "|final", o.net, atol=1e-6)
     assert max(visible) == CAP                                   # the buffer did wrap
+
+
+def test_oracle_ppo_agent_loop_equals_real_reference_agent_loop():
+    """oracle.agents.ClippedPPOAgentOracle (act + train, n_env = 1) against the REAL reference
+    ClippedPPOAgent object (own __init__, EpisodicExperienceReplay, Categorical exploration,
+    _should_train with act_for_full_episodes, train -> fill_advantages -> train_network; network = oracle
+    stand-in) over three rollouts: every sampled action, the steps at which training ran and the final
+    weights agree."""
+    import random
+    from oracle.agents import ClippedPPOAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    fx = np.load(os.path.join(HERE, "golden", "ppo_loop.npz"))
+    D, A, L, B, PLAY, EPOCHS, STEPS, SEED = (int(x) for x in fx["hp"])
+    arrays = {}
+    for k in fx.files:
+        if k.startswith("init|"):
+            _, name, t = k.split("|")
+            arrays.setdefault(name, {})[int(t)] = fx[k]
+    arrays = {n: [tw[t] for t in sorted(tw)] for n, tw in arrays.items()}
+    random.seed(SEED)
+    np.random.seed(SEED)
+    o = ClippedPPOAgentOracle(arrays, SynthVecEnv(1, 1, D, L, 77), A, batch_size=B, playing_steps=PLAY, epochs=EPOCHS,
+                              lr=1e-3, reward_clip=None)
+    o.reset()
+    actions, trained_at, since = [], [], 0
+    for step in range(STEPS):
+        a, _ = o.act()
+        actions.append(int(a[0]))
+        since += 1
+        if since >= PLAY and (step + 1) % L == 0:                 # enough steps and the episode is complete
+            o.train()
+            trained_at.append(step)
+            since = 0
+    np.testing.assert_array_equal(actions, fx["actions"])
+    np.testing.assert_array_equal(trained_at, fx["trained_at"])
+    _check_final(fx, "final", o.net, atol=2e-6)
