@@ -258,7 +258,12 @@ class VectorOffPolicyAgent(GraphRunner):
     def _training_phases_due(self):
         """agent.py:662-699 for a step counter that advances n_env at a time."""
         steps = self.ap.algorithm.num_consecutive_playing_steps.num_steps
-        if self.memory.num_transitions() <= 0:
+        # what the reference's memory holds at this point: an episodic memory receives an episode only
+        # when it ends (agent.py:576-584), so its num_transitions() counts complete episodes
+        mem = self.memory
+        stored = mem.num_transitions_in_complete_episodes() if hasattr(mem, "num_transitions_in_complete_episodes") \
+            else mem.num_transitions()
+        if stored <= 0:
             return 0
         gap = self.total_steps_counter - self.last_training_phase_step
         if gap < steps:

@@ -765,6 +765,26 @@ def gen_cadence():
             opened.append(int(f._should_train()))
         out[name + "|opened"] = np.array(opened)
         out[name + "|cfg"] = np.array([playing, L])
+
+    # episodic memory (DDPG): the memory receives an episode only when it ends, so nothing can be sampled
+    # — and no phase opens — before the first episode is complete
+    for name, playing, L in (("episodic_p1_L6", 1, 6), ("episodic_p4_L10", 4, 10)):
+        class FakeEp(DQNAgent):
+            def __init__(self):
+                pass
+
+            def call_memory(self, func, args=()):
+                return self.n_complete
+        f = FakeEp()
+        f.ap = _Obj(algorithm=_Obj(act_for_full_episodes=False, num_consecutive_playing_steps=EnvironmentSteps(playing)))
+        f.total_steps_counter = f.last_training_phase_step = f.n_complete = 0
+        opened = []
+        for t in range(1, 41):
+            f.total_steps_counter += 1
+            f.n_complete = L * (t // L)
+            opened.append(int(f._should_train()))
+        out[name + "|opened"] = np.array(opened)
+        out[name + "|cfg"] = np.array([playing, L])
     _save("cadence", **out)
 
 

@@ -130,7 +130,7 @@ def test_clipped_ppo_train_equals_reference_train():
 
 def _cadence_cases():
     fx = np.load(os.path.join(HERE, "golden", "cadence.npz"))
-    names = sorted({k.split("|")[0] for k in fx.files if not k.startswith("full_")})
+    names = sorted({k.split("|")[0] for k in fx.files if not k.startswith(("full_", "episodic_"))})
     return fx, names
 
 
@@ -476,3 +476,37 @@ def test_oracle_ppo_agent_loop_equals_real_reference_agent_loop():
     np.testing.assert_array_equal(actions, fx["actions"])
     np.testing.assert_array_equal(trained_at, fx["trained_at"])
     _check_final(fx, "final", o.net, atol=2e-6)
+
+
+def test_product_training_waits_for_a_complete_episode_with_episodic_memory():
+    """DDPG-style scheduling: an episodic memory holds only complete episodes (agent.py:576-584), so the
+    reference opens no training phase before the first episode has ended; the device agents' host
+    scheduling (_training_phases_due) against the reference's _should_train on the same sequences."""
+    from coach_amd.agents.vector_agent import VectorOffPolicyAgent
+    from coach_amd.core_types import EnvironmentSteps
+    fx = np.load(os.path.join(HERE, "golden", "cadence.npz"))
+    names = sorted({k.split("|")[0] for k in fx.files if k.startswith("episodic_")})
+    assert len(names) == 2
+    for name in names:
+        playing, L = (int(x) for x in fx[name + "|cfg"])
+
+        class Memory(object):
+            count = 0
+            def num_transitions(self): return self.count
+            def num_transitions_in_complete_episodes(self): return L * (self.count // L)
+
+        class Alg(object):
+            act_for_full_episodes = False
+            num_consecutive_playing_steps = EnvironmentSteps(playing)
+
+        class Ap(object):
+            algorithm = Alg()
+        ag = VectorOffPolicyAgent.__new__(VectorOffPolicyAgent)
+        ag.ap, ag.memory, ag.n_env = Ap(), Memory(), 1
+        ag.total_steps_counter = ag.last_training_phase_step = 0
+        opened = []
+        for t in range(40):
+            ag.total_steps_counter += 1
+            ag.memory.count += 1
+            opened.append(int(ag._training_phases_due() > 0))
+        np.testing.assert_array_equal(opened, fx[name + "|opened"], err_msg=name)
