@@ -186,7 +186,7 @@ class VectorOffPolicyAgent(GraphRunner):
         if isinstance(mp, PrioritizedExperienceReplayParameters):
             return PrioritizedExperienceReplay(mp.max_size, mp.alpha, mp.beta, mp.epsilon,
                                                mp.allow_duplicates_in_batch_sampling,
-                                               exact_pow=getattr(mp, "exact_pow", False), **kw)
+                                               exact_pow=getattr(mp, "exact_pow", "device"), **kw)
         if isinstance(mp, EpisodicExperienceReplayParameters):
             return EpisodicExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling, **kw)
         return ExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling, **kw)
@@ -203,9 +203,18 @@ class VectorOffPolicyAgent(GraphRunner):
         raise NotImplementedError
 
     def act(self):
-        """One vector step of LevelManager.step (level_manager.py:215-269) for n_env envs."""
+        """One vector step of LevelManager.step (level_manager.py:215-269) for n_env envs.
+
+        Order of the reference, kept: (1) observe the PREVIOUS response — its transition enters the
+        memory now, after the train() that followed the previous step (:236-238); (2) choose an action;
+        (3) env.step; (4) a terminal response is observed at once (:260-264), a non-terminal one waits
+        for the next call.  The rows of this step are written to the ring immediately either way; only
+        their visibility to sampling is deferred (memory.commit_pending)."""
         alg = self.ap.algorithm
         s = _rlx.current_stream()
+        record = self.phase != RunPhase.TEST
+        if record:
+            self.memory.commit_pending()
         states = self.memory.current_states()
         if self.phase == RunPhase.HEATUP and not alg.heatup_using_network_decisions:
             actions = self.random_actions()                                    # agent.py:838-840
@@ -216,16 +225,16 @@ class VectorOffPolicyAgent(GraphRunner):
         lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
         self.lib.reward_filter(reward, self.filtered_reward, self.n_env, alg.reward_rescale,
                                int(has_clip), lo, hi, s)
-        record = self.phase != RunPhase.TEST
         if record:
             self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,
                                         self.n_env, self.ep_acc, None, None, s)
-        stored = self._stored_game_over(game_over)
-        self.memory.store(actions, self.filtered_reward, stored, next_obs, reset_obs, record=record,
-                          dones=None if stored is game_over else game_over)
         self.env.total_steps += self.n_env
         self.current_episode_steps_counter += 1
         episode_ended = self.current_episode_steps_counter >= self.L
+        stored = self._stored_game_over(game_over)
+        self.memory.store(actions, self.filtered_reward, stored, next_obs, reset_obs, record=record,
+                          dones=None if stored is game_over else game_over,
+                          defer=not episode_ended, episode_end=episode_ended)
         self._episode_just_ended = episode_ended
         if episode_ended:
             self.last_episode_steps = self.current_episode_steps_counter
@@ -318,21 +327,46 @@ class VectorOffPolicyAgent(GraphRunner):
     def learn_from_batch(self, batch):
         raise NotImplementedError
 
+    def reset_internal_state(self):
+        """GraphManager.reset_internal_state(force_environment_reset=True) + Agent.reset_internal_state
+        (graph_manager.py:411-424, agent.py:603-629): every env starts a new episode NOW.  The response
+        of the last step was never observed, so its transition is never stored; an episodic memory
+        loses the whole unfinished episode (it lived in current_episode_buffer); the per-episode
+        accumulators restart."""
+        mem = self.memory
+        if hasattr(mem, "drop_open_episode"):
+            mem.drop_open_episode()
+        else:
+            mem.drop_pending()
+        self.current_episode_steps_counter = 0
+        self._episode_just_ended = False
+        self.lib.episode_stats_init(self.ep_return, self.ep_len, self.n_env, None, _rlx.current_stream())
+        pol = getattr(self, "exploration_policy", None)
+        if pol is not None and hasattr(pol, "reset"):
+            pol.reset()
+        return self.env.reset_internal_state()
+
     def evaluate_episodes(self, episodes_per_env=1):
-        """GraphManager.evaluate (graph_manager.py:491-523) for the env vector: TEST-phase acting (no
-        exploration noise beyond evaluation_epsilon, nothing stored, counters frozen) for whole
-        episodes; returns the mean undiscounted episode reward over envs."""
-        import torch
+        """GraphManager.evaluate (graph_manager.py:491-523) for the env vector: every level is reset,
+        then whole episodes are played in TEST phase (greedy / evaluation_epsilon acting, nothing
+        stored, training counters frozen); training resumes from a fresh reset afterwards (the last
+        evaluation episode ended, so reset_required is set).  The memory is not touched: evaluation
+        frames go to a scratch stack (memory.begin_evaluation).  Returns the mean undiscounted episode
+        reward over envs."""
         prev = self.phase
+        first = self.reset_internal_state()
+        self.memory.begin_evaluation(first)
         self.phase = RunPhase.TEST
         total = torch.zeros(self.n_env, dtype=torch.float64, device=self.device)
-        # finish the running episodes first so that evaluation episodes start at a reset
-        while self.current_episode_steps_counter != 0:
-            self.act()
-        for _ in range(episodes_per_env * self.L):
-            self.act()
-            total += self.env.reward.double()
-        self.phase = prev
+        try:
+            for _ in range(episodes_per_env * self.L):
+                self.act()
+                total += self.env.reward.double()
+        finally:
+            self.phase = prev
+            self.current_episode_steps_counter = 0
+            self._episode_just_ended = False
+            self.memory.end_evaluation(self.env.reset_internal_state())
         return float(total.mean().item()) / episodes_per_env
 
     # ------------------------------------------------------------------------------ reporting

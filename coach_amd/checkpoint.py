@@ -22,7 +22,8 @@ def _tensors_of(obj, names):
 
 _MEMORY_TENSORS = ["ring", "fpos", "epoff", "t_fpos", "t_epoff", "cur_state", "obs", "next_obs", "action",
                    "reward", "game_over", "sum_tree", "min_tree", "max_tree", "max_priority"]
-_MEMORY_SCALARS = ["cursor", "count", "steps", "_open", "_list_len", "next_leaf_idx_to_write"]
+_MEMORY_SCALARS = ["cursor", "count", "pending", "committed_total", "steps", "_open", "_list_len",
+                   "next_leaf_idx_to_write", "_frames_total", "_episode_steps", "_step_frames"]
 _AGENT_SCALARS = ["total_steps_counter", "training_iteration", "last_training_phase_step",
                   "last_target_network_update_step", "current_episode_steps_counter", "last_episode_steps",
                   "_episode_just_ended"]
@@ -36,8 +37,10 @@ def agent_state(agent):
             "adam_m": net.adam.m.cpu(), "adam_v": net.adam.v.cpu(), "adam_state": net.adam.state.cpu()}
     mem = agent.memory
     st["memory"]["tensors"] = _tensors_of(mem, _MEMORY_TENSORS)
-    st["memory"]["scalars"] = {k: getattr(mem, k) for k in _MEMORY_SCALARS if hasattr(mem, k)}
+    st["memory"]["scalars"] = {k: (getattr(mem, k).copy() if isinstance(getattr(mem, k), np.ndarray)
+                                   else getattr(mem, k)) for k in _MEMORY_SCALARS if hasattr(mem, k)}
     st["agent"]["scalars"] = {k: getattr(agent, k) for k in _AGENT_SCALARS if hasattr(agent, k)}
+    st["agent"]["phase"] = agent.phase.name                   # RunPhase of the agent (and its policy)
     # uniforms_all: the exploration draws of the running PPO phase (made at its first step)
     st["agent"]["tensors"] = _tensors_of(agent, ["ep_return", "ep_len", "ep_acc", "uniforms_all"])
     st["env"] = {"tensors": _tensors_of(agent.env, ["obs", "episode", "step_in_episode"]),
@@ -73,6 +76,11 @@ def load_agent_state(agent, st):
         mem.beta = pickle.loads(st["memory"]["beta"])
     for k, v in st["agent"]["scalars"].items():
         setattr(agent, k, v)
+    if "phase" in st["agent"]:
+        from .core_types import RunPhase
+        agent.phase = RunPhase[st["agent"]["phase"]]
+        if getattr(agent, "exploration_policy", None) is not None:
+            agent.exploration_policy.phase = agent.phase
     for k, t in st["agent"]["tensors"].items():
         getattr(agent, k).copy_(t)
     for k, t in st["env"]["tensors"].items():
@@ -90,15 +98,28 @@ def load_agent_state(agent, st):
     torch.cuda.synchronize() if torch.cuda.is_available() else None
 
 
+def _rank_dir(agent, checkpoint_dir):
+    """Replay shard, env shard and host RNG state are per rank: under data parallelism every rank
+    writes (and restores) its own `rank<r>/` sub-directory; a single process uses the directory itself."""
+    dist = getattr(agent, "dist", None)
+    if dist is not None and getattr(dist, "world_size", 1) > 1:
+        return os.path.join(checkpoint_dir, "rank%d" % dist.rank)
+    return checkpoint_dir
+
+
 def save_checkpoint(agent, checkpoint_dir, checkpoint_id=0):
-    """graph_manager.save_checkpoint (:616-637): `<id>_Step-<total_steps>.ckpt` + state file."""
+    """graph_manager.save_checkpoint (:616-637): `<id>_Step-<total_steps>.ckpt` + state file; both are
+    published atomically (write to a temporary name, then os.replace)."""
+    checkpoint_dir = _rank_dir(agent, checkpoint_dir)
     os.makedirs(checkpoint_dir, exist_ok=True)
     name = "{}_Step-{}.ckpt".format(checkpoint_id, agent.total_steps_counter)
     tmp = os.path.join(checkpoint_dir, name + ".tmp")
     torch.save(agent_state(agent), tmp)
-    os.replace(tmp, os.path.join(checkpoint_dir, name))              # atomic publish
-    with open(os.path.join(checkpoint_dir, STATE_FILE), "w") as f:
+    os.replace(tmp, os.path.join(checkpoint_dir, name))
+    tmp = os.path.join(checkpoint_dir, STATE_FILE + ".tmp")
+    with open(tmp, "w") as f:
         f.write(name)
+    os.replace(tmp, os.path.join(checkpoint_dir, STATE_FILE))
     return name
 
 
@@ -115,6 +136,9 @@ def latest_checkpoint(checkpoint_dir):
 
 
 def restore_checkpoint(agent, checkpoint_dir, name=None):
+    """Checkpoints are trusted input (they are pickles, like the reference's own filter / schedule
+    pickles): only restore files this engine wrote."""
+    checkpoint_dir = _rank_dir(agent, checkpoint_dir)
     name = name or latest_checkpoint(checkpoint_dir)
     if name is None:
         raise ValueError("No checkpoint to restore in: {}".format(checkpoint_dir))   # graph_manager.py:577-579

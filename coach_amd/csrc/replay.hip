@@ -234,21 +234,33 @@ __global__ void img_gather_generic_kernel(const unsigned char *__restrict__ ring
     }
 }
 
-// First frame of the very first episode (and external resets): ring row 0, episode offset 0.
-__global__ void img_reset_kernel(unsigned char *__restrict__ ring, int *__restrict__ fpos,
-                                 int *__restrict__ epoff,
+// First frame of a new episode in every env (the very first one, or a reset in the middle of an
+// episode — GraphManager.reset_internal_state(force_environment_reset=True) before an evaluation).
+// The frame goes BEHIND the newest frame of the env, never to a fixed row: stored transitions
+// address absolute ring rows, so restarting at row 0 would overwrite the frames of live transitions.
+// An episode that has not stepped yet (epoff == 0: nothing refers to its first frame) is restarted
+// in place, so repeated resets do not consume ring rows.  On a fresh ring (fpos = epoff = 0) this is
+// row 0.  Second, tiny launch: the position update (the copy blocks all read fpos/epoff).
+__global__ void img_reset_kernel(unsigned char *__restrict__ ring, const int *__restrict__ fpos,
+                                 const int *__restrict__ epoff,
                                  const unsigned char *__restrict__ first_frame, int ring_frames,
                                  int frame_bytes) {
     const int e = blockIdx.y;
     const int words = frame_bytes >> 2;
+    const int p = epoff[e] == 0 ? fpos[e] : (fpos[e] + 1) % ring_frames;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(first_frame + (size_t)e * frame_bytes);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(ring + (size_t)e * ring_frames * frame_bytes);
+    uint32_t *dst =
+        reinterpret_cast<uint32_t *>(ring + ((size_t)e * ring_frames + p) * frame_bytes);
     for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x)
         dst[w] = src[w];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        fpos[e] = 0;
-        epoff[e] = 0;
-    }
+}
+
+__global__ void img_reset_advance_kernel(int *__restrict__ fpos, int *__restrict__ epoff, int n_env,
+                                         int ring_frames) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_env) return;
+    if (epoff[e] != 0) fpos[e] = (fpos[e] + 1) % ring_frames;
+    epoff[e] = 0;
 }
 
 }  // namespace
@@ -308,9 +320,12 @@ int rlx_imgreplay_reset(unsigned char *ring, int *env_fpos, int *env_epoff,
                 "rlx_imgreplay_reset: frame_bytes must be a positive multiple of 4 (got %d)",
                 frame_bytes);
     dim3 grid(rlx::grid_for(frame_bytes / 4, kBlock, 8), n_env);
-    img_reset_kernel<<<grid, kBlock, 0, rlx::as_stream(stream)>>>(ring, env_fpos, env_epoff,
-                                                                  first_frame, ring_frames,
-                                                                  frame_bytes);
+    hipStream_t s = rlx::as_stream(stream);
+    img_reset_kernel<<<grid, kBlock, 0, s>>>(ring, env_fpos, env_epoff, first_frame, ring_frames,
+                                             frame_bytes);
+    RLX_LAUNCH_CHECK();
+    img_reset_advance_kernel<<<(n_env + 63) / 64, 64, 0, s>>>(env_fpos, env_epoff, n_env,
+                                                              ring_frames);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

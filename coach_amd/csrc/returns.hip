@@ -270,10 +270,11 @@ int rlx_standardize(const double *x, long long n, float *out32, double *out64, d
 }
 
 int rlx_episode_stats_init(double *ep_return, int *ep_len, int n_env, double *acc, void *stream) {
-    RLX_REQUIRE(ep_return && ep_len && acc && n_env > 0, "rlx_episode_stats_init: bad arguments");
+    RLX_REQUIRE(ep_return && ep_len && n_env > 0, "rlx_episode_stats_init: bad arguments");
     hipStream_t s = rlx::as_stream(stream);
     RLX_HIP(hipMemsetAsync(ep_return, 0, sizeof(double) * n_env, s));
     RLX_HIP(hipMemsetAsync(ep_len, 0, sizeof(int) * n_env, s));
+    if (!acc) return RLX_OK;      // acc == NULL: only the running episodes restart (a forced reset)
     const double inf = __builtin_huge_val();
     const double init[8] = {0, 0, 0, -inf, inf, 0, -inf, inf};
     RLX_HIP(hipMemcpyAsync(acc, init, sizeof(init), hipMemcpyHostToDevice, s));

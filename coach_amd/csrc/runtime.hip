@@ -14,7 +14,7 @@ void set_error(const char *fmt, ...) {
 
 extern "C" {
 
-int rlx_abi_version(void) { return 3; }   // 2: adam_tf1_norm / sac head accumulate; 3: gemm desc batch_inner, n_fold
+int rlx_abi_version(void) { return 4; }   // 2: adam_tf1_norm / sac head accumulate; 3: gemm desc batch_inner, n_fold; 4: per_sample payload rows, libm pow
 const char *rlx_last_error(void) { return rlx::g_err; }
 const char *rlx_build_arch(void) { return "gfx950"; }
 

@@ -18,6 +18,7 @@
 // 8*log2(cap) per draw and 3*log2(cap)*(16 read + 8 write) per updated priority
 // (SURVEY.md §8(d)).
 #include "rlx_common.hpp"
+#include "libm_pow.hpp"
 #include <cmath>
 
 namespace {
@@ -67,7 +68,9 @@ per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__r
         if (ring) {
             leaf = (start_leaf + i) & (cap - 1);
             p = stored_priority;
-            pa = (mode == 1) ? pow(p, alpha) : eps;
+            int odd = 0;
+            pa = (mode == 1) ? rlx::libm_pow(p, alpha, &odd) : eps;    // maximal_priority ** alpha (:274)
+            if (odd) atomicOr(status, 4);
         } else {
             leaf = idx[i];
             if (leaf < 0 || leaf >= cap) {          // reference raises ValueError (:123-126)
@@ -81,7 +84,9 @@ per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__r
                     live = false;
                 }
                 p = e + eps;
-                pa = pow(p, alpha);
+                int odd = 0;
+                pa = rlx::libm_pow(p, alpha, &odd);                   // priority ** self.alpha (:197)
+                if (odd) atomicOr(status, 4);
             } else {
                 pa = leaf_pa[i];
                 p = leaf_p[i];
@@ -126,14 +131,16 @@ __global__ void per_sample_kernel(const double *__restrict__ sum, const double *
                                   int cap, const double *__restrict__ u, int batch,
                                   double n_transitions, double beta, int *__restrict__ out_idx,
                                   double *__restrict__ out_weight,
-                                  double *__restrict__ out_priority) {
+                                  double *__restrict__ out_priority, long long stored_total,
+                                  long long payload_rows, int *__restrict__ out_rows) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch) return;
     const int n_nodes = 2 * cap - 1;
     const double total = sum[0];
     const double segment_size = total / (double)batch;                   // (:232)
     const double min_probability = mn[0] / total;                        // (:235)
-    const double max_weight = pow(min_probability * n_transitions, -beta);  // (:236)
+    int odd = 0;                                  // (an empty tree gives inf/nan here, as in the reference)
+    const double max_weight = rlx::libm_pow(min_probability * n_transitions, -beta, &odd);  // (:236)
     const double a = segment_size * (double)i;                           // (:240)
     const double b = segment_size * (double)(i + 1);                     // (:241)
     double val = a + (b - a) * u[i];                                     // random.uniform
@@ -151,10 +158,28 @@ __global__ void per_sample_kernel(const double *__restrict__ sum, const double *
     }
     const double leaf_value = sum[node];
     const double priority = leaf_value / total;                          // (:247)
-    const double weight = pow(n_transitions * priority, -beta);          // (:248)
+    const double weight = rlx::libm_pow(n_transitions * priority, -beta, &odd);   // (:248)
     out_idx[i] = node - cap + 1;
     out_weight[i] = weight / max_weight;                                 // (:249)
     if (out_priority) out_priority[i] = leaf_value;
+    if (out_rows) {
+        // The payload ring may have more rows than the tree has leaves (rows of a step that is
+        // written but not visible yet).  Transition number g (0-based, in store order) owns leaf
+        // g % cap and payload row g % payload_rows; the live owner of a leaf is the newest such g.
+        const long long leaf = node - cap + 1;
+        const long long back = ((stored_total - 1 - leaf) % cap + cap) % cap;
+        const long long g = stored_total - 1 - back;
+        out_rows[i] = g < 0 ? -1 : (int)(g % payload_rows);      // -1: a leaf that was never stored
+    }
+}
+
+__global__ void libm_pow_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                double *__restrict__ out, int n, int *__restrict__ status) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int odd = 0;
+    out[i] = rlx::libm_pow(x[i], y[i], &odd);
+    if (odd) atomicOr(status, 4);
 }
 
 inline int ilog2(int v) {
@@ -240,17 +265,31 @@ int rlx_per_store_value(double *sum_tree, double *min_tree, double *max_tree, in
                          status, stream, "rlx_per_store_value");
 }
 
+int rlx_libm_pow(const double *x, const double *y, double *out, int n, int *status,
+                 void *stream) {
+    RLX_REQUIRE(x && y && out && status && n >= 0, "rlx_libm_pow: null pointer");
+    if (n == 0) return RLX_OK;
+    libm_pow_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(x, y, out, n,
+                                                                                     status);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
 int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,
                    const double *uniforms, int batch, double num_transitions, double beta,
-                   int *out_idx, double *out_weight, double *out_priority, void *stream) {
+                   int *out_idx, double *out_weight, double *out_priority, long long stored_total,
+                   long long payload_rows, int *out_rows, void *stream) {
     RLX_REQUIRE(sum_tree && min_tree && uniforms && out_idx && out_weight,
                 "rlx_per_sample: null pointer");
     RLX_REQUIRE(is_pow2(capacity), "rlx_per_sample: capacity %d is not a power of two", capacity);
     RLX_REQUIRE(batch > 0, "rlx_per_sample: batch must be positive");
+    RLX_REQUIRE(!out_rows || (stored_total >= 0 && payload_rows >= capacity),
+                "rlx_per_sample: the payload ring (%lld rows) is smaller than the tree (%d leaves)",
+                payload_rows, capacity);
     int threads = 64;
     per_sample_kernel<<<(batch + threads - 1) / threads, threads, 0, rlx::as_stream(stream)>>>(
         sum_tree, min_tree, capacity, uniforms, batch, num_transitions, beta, out_idx, out_weight,
-        out_priority);
+        out_priority, stored_total, payload_rows, out_rows);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

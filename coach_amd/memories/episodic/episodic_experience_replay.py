@@ -34,10 +34,19 @@ class EpisodicExperienceReplay(ExperienceReplay):
         super().clean()
         self._open = 0
 
-    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True, dones=None):
-        super().store(actions, rewards, game_overs, next_obs, reset_obs, record, dones)
-        if record:
-            self._open = min(self._open + self.n_env, self.cap)
+    def _became_visible(self, n):
+        super()._became_visible(n)
+        self._open = min(self._open + n, self.cap)
+
+    def drop_open_episode(self):
+        """Agent.reset_internal_state in the middle of an episode replaces current_episode_buffer
+        (agent.py:413-414): the transitions of the unfinished episode never reach the memory."""
+        self.drop_pending()
+        if self._open:
+            self.cursor = (self.cursor - self._open) % self.rows
+            self.count -= self._open
+            self.committed_total -= self._open
+            self._open = 0
 
     def close_last_episode(self):
         """All n_env lockstep episodes ended (EpisodicExperienceReplay.close_last_episode, :264-298)."""

@@ -15,6 +15,19 @@ The reference keeps a Python list of Transition objects (append + ``del list[0]`
 Image observations use the frame-dedup ring of rlx_imgreplay_* (each 84x84 frame stored once per
 env; a 4-stack is materialised only when gathered): a 1 M-transition Atari buffer is
 ~7-14 GB of HBM instead of 56 GB of stacked states.
+
+WHEN a transition becomes visible.  In the reference the response of env.step at step k is observed
+— turned into a Transition and stored — at the START of step k+1, after the train() call of step k
+(level_manager.py:236-251, agent.py:905-973); only a terminal response is observed at once
+(level_manager.py:260-264).  ``store(..., defer=True)`` reproduces that without a second copy: the
+ring has n_env rows more than the capacity, the rows of the step are written at once (the acting path
+needs nothing from them) but stay outside the sampled window — `num_transitions()`, the FIFO head and
+every eviction lag — until `commit_pending()` (called at the start of the next vector step) moves the
+window over them.  `drop_pending()` is the reference's reset in the middle of an episode: the last
+response was never observed, so its transition never existed.
+
+Evaluation (TEST phase) never touches the memory in the reference; here `begin_evaluation()` switches
+the acting state to a scratch stack of its own, so evaluation frames never enter the replay ring.
 """
 import numpy as np
 import torch
@@ -60,40 +73,54 @@ class ExperienceReplay(Memory):
             raise ValueError("replay capacity %d must be a positive multiple of the %d lockstep envs"
                              % (cap, self.n_env))
         self.cap = cap
+        # physical rows: the capacity plus one vector step that is written but not visible yet
+        rows = self.rows = cap + self.n_env
         self.image = stack is not None
         self.stack = stack
         dev = device
         if self.image:
             self.frame_shape = tuple(observation_shape)
             self.fb = int(np.prod(observation_shape))
-            per_env = cap // self.n_env
-            self.F = per_env + per_env // max(1, int(min_episode_length)) + stack + 4
+            per_env = rows // self.n_env
+            # frames an env can add while `per_env` of its transitions are alive: one per step, one
+            # more per episode end (the post-reset frame), + the stack of the oldest state + slack
+            self.F = per_env + per_env // max(1, int(min_episode_length)) + stack + 6
             self.ring = torch.zeros(self.n_env, self.F, self.fb, dtype=torch.uint8, device=dev)
             self.fpos = torch.zeros(self.n_env, dtype=torch.int32, device=dev)
             self.epoff = torch.zeros(self.n_env, dtype=torch.int32, device=dev)
-            self.t_fpos = torch.zeros(cap, dtype=torch.int32, device=dev)
-            self.t_epoff = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            self.t_fpos = torch.zeros(rows, dtype=torch.int32, device=dev)
+            self.t_epoff = torch.zeros(rows, dtype=torch.uint8, device=dev)
             self.cur_state = torch.empty((self.n_env,) + self.frame_shape + (stack,),
                                          dtype=torch.uint8, device=dev)
             self.state_shape = self.frame_shape + (stack,)
             self.state_dtype = torch.uint8
         else:
             self.obs_dim = int(observation_shape[0])
-            self.obs = torch.zeros(cap, self.obs_dim, dtype=torch.float32, device=dev)
-            self.next_obs = torch.zeros(cap, self.obs_dim, dtype=torch.float32, device=dev)
+            self.obs = torch.zeros(rows, self.obs_dim, dtype=torch.float32, device=dev)
+            self.next_obs = torch.zeros(rows, self.obs_dim, dtype=torch.float32, device=dev)
             self.cur_state = torch.empty(self.n_env, self.obs_dim, dtype=torch.float32, device=dev)
             self.state_shape = (self.obs_dim,)
             self.state_dtype = torch.float32
         self.action_dim = action_dim
-        self.action = torch.zeros(cap, dtype=torch.int32, device=dev) if action_dim is None else \
-            torch.zeros(cap, action_dim, dtype=torch.float32, device=dev)
-        self.reward = torch.zeros(cap, dtype=torch.float32, device=dev)
-        self.game_over = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.action = torch.zeros(rows, dtype=torch.int32, device=dev) if action_dim is None else \
+            torch.zeros(rows, action_dim, dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(rows, dtype=torch.float32, device=dev)
+        self.game_over = torch.zeros(rows, dtype=torch.uint8, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.cursor = 0          # physical row the next vector step is written to
-        self.count = 0           # len(self.transitions) of the reference
+        self.count = 0           # len(self.transitions) of the reference (the VISIBLE transitions)
+        self.pending = 0         # rows written at [cursor - pending, cursor) that are not visible yet
+        self.committed_total = 0  # transitions ever made visible (PER: leaf = this % capacity)
+        self._evaluating = False
+        self._eval = None
         self._batches = {}
         self._pinned = {}
+        # host mirror of the frame ring's fill (image mode): frames an env has appended so far, the
+        # value of that counter at every stored vector step, steps of the running episode — enough
+        # to PROVE before every write that no frame of a visible transition is overwritten
+        self._frames_total = 0
+        self._step_frames = np.zeros(rows // self.n_env, dtype=np.int64)
+        self._episode_steps = 0
 
     # ---------------------------------------------------------------- Memory interface (:56-69)
     def length(self):
@@ -105,55 +132,136 @@ class ExperienceReplay(Memory):
     def clean(self):
         self.cursor = 0
         self.count = 0
+        self.pending = 0
+        self.committed_total = 0
 
     def head(self):
-        """physical row of logical index 0 (the oldest stored transition)."""
-        return (self.cursor - self.count) % self.cap
+        """physical row of logical index 0 (the oldest VISIBLE transition)."""
+        return (self.cursor - self.pending - self.count) % self.rows
+
+    # ------------------------------------------------------------- visibility (see module doc)
+    def commit_pending(self):
+        """The observe() at the start of the next step: the held rows enter the sampled window and
+        the oldest rows beyond the capacity leave it (_enforce_max_length, :141-150)."""
+        n = self.pending
+        if n:
+            self.pending = 0
+            self._became_visible(n)
+
+    def drop_pending(self):
+        """Reset before the held response was observed: its transitions are never stored."""
+        if self.pending:
+            self.cursor = (self.cursor - self.pending) % self.rows
+            self.pending = 0
+
+    def _became_visible(self, n):
+        self.count = min(self.count + n, self.cap)
+        self.committed_total += n
 
     # ------------------------------------------------------------------------------ rollout side
     def reset(self, first_obs):
+        """First observation of a new episode in every env (an episode start, not a stored step)."""
         s = _rlx.current_stream()
         if self.image:
-            self.lib.imgreplay_reset(self.ring, self.fpos, self.epoff, first_obs, self.n_env, self.F,
-                                     self.fb, s)
+            ring, fpos, epoff, F = self._stack_state()
+            self.lib.imgreplay_reset(ring, fpos, epoff, first_obs, self.n_env, F, self.fb, s)
+            if not self._evaluating:
+                if self._episode_steps:          # an un-stepped episode is restarted in place
+                    self._frames_total += 1
+                self._episode_steps = 0
         else:
             self.cur_state.copy_(first_obs)
 
+    def _account_frames(self, row0, episode_end):
+        """Raise BEFORE the append that would overwrite a frame some visible transition still needs
+        (more episode starts than `min_episode_length` promised — e.g. many aborted episodes)."""
+        self._step_frames[row0 // self.n_env] = self._frames_total
+        self._frames_total += 2 if episode_end else 1
+        self._episode_steps = 0 if episode_end else self._episode_steps + 1
+        if self.count:
+            oldest = self._step_frames[self.head() // self.n_env]
+            if self._frames_total - oldest + self.stack > self.F:
+                raise RuntimeError(
+                    "image replay frame ring overrun: %d frames are alive but the ring holds %d per env "
+                    "(episodes shorter than min_episode_length=%s?)"
+                    % (self._frames_total - oldest + self.stack, self.F, "configured"))
+
+    def _stack_state(self):
+        """(ring, fpos, epoff, ring_frames) the ACTING path reads and advances: the replay ring while
+        training / heating up, a scratch ring of stack + 4 frames per env while evaluating."""
+        if not self._evaluating:
+            return self.ring, self.fpos, self.epoff, self.F
+        if self._eval is None:
+            dev, Fe = self.device, self.stack + 4
+            self._eval = (torch.zeros(self.n_env, Fe, self.fb, dtype=torch.uint8, device=dev),
+                          torch.zeros(self.n_env, dtype=torch.int32, device=dev),
+                          torch.zeros(self.n_env, dtype=torch.int32, device=dev), Fe)
+        return self._eval
+
+    def begin_evaluation(self, first_obs):
+        """GraphManager.evaluate resets every level before it acts in TEST phase
+        (graph_manager.py:505-507): the running training episode is abandoned — its last response is
+        never observed — and nothing evaluation does reaches the memory."""
+        self.drop_pending()
+        self._evaluating = True
+        self.reset(first_obs)
+
+    def end_evaluation(self, first_obs):
+        """Back to training: the next training step starts a fresh episode from `first_obs`."""
+        self._evaluating = False
+        self.reset(first_obs)
+
     def current_states(self):
         if self.image:
-            self.lib.imgreplay_gather(self.ring, None, None, self.fpos, self.epoff, None, self.n_env,
-                                      self.n_env, self.F, self.fb, self.stack, self.cap,
+            ring, fpos, epoff, F = self._stack_state()
+            self.lib.imgreplay_gather(ring, None, None, fpos, epoff, None, self.n_env,
+                                      self.n_env, F, self.fb, self.stack, self.rows,
                                       self.cur_state, None, self.status, _rlx.current_stream())
         return self.cur_state
 
-    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True, dones=None):
+    def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True, dones=None,
+              defer=False, episode_end=False):
         """n_env transitions (state = current state of every env), then advance the env states.
         Reference: ExperienceReplay.store + _enforce_max_length (:117-150) called n_env times.
         record=False only advances the observation state (evaluation episodes are not stored).
         dones: the env's true episode-end flags when the STORED game_over differs from them (TD3
-        clears game_over on time-limit terminations, td3_agent.py:215-227)."""
+        clears game_over on time-limit terminations, td3_agent.py:215-227).
+        defer=True: the rows are written now but become visible at the next commit_pending() (the
+        reference observes a non-terminal response at the start of the NEXT step).
+        episode_end: host copy of "the episodes ended on this step" (lockstep envs), used only for
+        the frame-ring accounting of image observations."""
         s = _rlx.current_stream()
+        if record:
+            self.commit_pending()
         row0 = self.cursor
         stored_go = game_overs
         if dones is not None:
             game_overs = dones
+        if record and self._evaluating:
+            raise RuntimeError("the replay memory is not written during evaluation")
+        if record and self.image:
+            self._account_frames(row0, episode_end)
         if record:
             pairs = [(actions, self.action), (rewards, self.reward), (stored_go, self.game_over)]
             if not self.image:
                 pairs += [(self.cur_state, self.obs), (next_obs, self.next_obs)]
             self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), None, None, 0, row0,
-                                  self.n_env, self.cap, self.n_env, self.status, s)
+                                  self.n_env, self.rows, self.n_env, self.status, s)
         if self.image:
-            self.lib.imgreplay_append(self.ring, self.fpos, self.epoff, self.t_fpos, self.t_epoff,
-                                      next_obs, reset_obs, game_overs, self.n_env, self.F, self.fb,
-                                      self.stack, row0, self.cap, int(record), s)
+            ring, fpos, epoff, F = self._stack_state()
+            self.lib.imgreplay_append(ring, fpos, epoff, self.t_fpos, self.t_epoff,
+                                      next_obs, reset_obs, game_overs, self.n_env, F, self.fb,
+                                      self.stack, row0, self.rows, int(record), s)
         else:
             # the next state of a finished episode is the post-reset observation
             self.lib.select_rows(game_overs, reset_obs, next_obs, self.cur_state, self.n_env,
                                  self.obs_dim * 4, s)
         if record:
-            self.cursor = (self.cursor + self.n_env) % self.cap
-            self.count = min(self.count + self.n_env, self.cap)
+            self.cursor = (self.cursor + self.n_env) % self.rows
+            if defer:
+                self.pending = self.n_env
+            else:
+                self._became_visible(self.n_env)
 
     # ----------------------------------------------------------------------------- training side
     def sample_indices(self, size):
@@ -166,7 +274,7 @@ class ExperienceReplay(Memory):
                          "yet. There are currently {} transitions".format(self.num_transitions()))
 
     def physical_rows(self, logical_idx):
-        return ((self.head() + np.asarray(logical_idx, dtype=np.int64)) % self.cap).astype(np.int32)
+        return ((self.head() + np.asarray(logical_idx, dtype=np.int64)) % self.rows).astype(np.int32)
 
     def _batch_buffers(self, size):
         b = self._batches.get(size)
@@ -201,11 +309,11 @@ class ExperienceReplay(Memory):
         pairs = [(self.action, b["action"]), (self.reward, b["reward"]), (self.game_over, b["game_over"])]
         if not self.image:
             pairs += [(self.obs, b["state"]), (self.next_obs, b["next_state"])]
-        self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), rows, None, 0, 0, self.cap, size,
+        self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), rows, None, 0, 0, self.rows, size,
                               size, self.status, s)
         if self.image:
             self.lib.imgreplay_gather(self.ring, self.t_fpos, self.t_epoff, None, None, rows, size,
-                                      self.n_env, self.F, self.fb, self.stack, self.cap, b["state"],
+                                      self.n_env, self.F, self.fb, self.stack, self.rows, b["state"],
                                       b["next_state"], self.status, s)
 
     def draw(self, size):

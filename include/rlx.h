@@ -51,7 +51,11 @@ int rlx_event_elapsed_ms(void *start, void *stop, float *ms_host); /* syncs on s
  * capacity must be a power of two (:176-179).  max_priority is one device double
  * mirroring PrioritizedExperienceReplay.maximal_priority (:186,:201).  `status` is a
  * device int the kernels OR error bits into (1 = leaf index out of range -> the
- * reference's ValueError at :123-126; 2 = negative error -> ValueError at :195). */
+ * reference's ValueError at :123-126; 2 = negative error -> ValueError at :195;
+ * 4 = a priority outside the domain of the bit-exact pow, see rlx_libm_pow).
+ * Every `p ** alpha` / `(N*P) ** -beta` below is evaluated with rlx::libm_pow
+ * (csrc/libm_pow.hpp): glibc's pow algorithm on glibc's tables, so leaves and importance
+ * weights are bit-identical to the reference's CPython `**` (= libm pow) — no host round trip. */
 int rlx_per_init(double *sum_tree, double *min_tree, double *max_tree, int capacity,
                  double *max_priority, void *stream);               /* SegmentTree.__init__ :59-67 */
 int rlx_per_store(double *sum_tree, double *min_tree, double *max_tree, int capacity,
@@ -69,8 +73,16 @@ int rlx_per_update_leaves(double *sum_tree, double *min_tree, double *max_tree, 
                           double *max_priority, int *status, void *stream); /* same, host-computed p**alpha */
 int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,
                    const double *uniforms, int batch, double num_transitions, double beta,
-                   int *out_idx, double *out_weight, double *out_priority,
-                   void *stream);                                    /* .sample :229-255; uniforms[i] = random.random() */
+                   int *out_idx, double *out_weight, double *out_priority, long long stored_total,
+                   long long payload_rows, int *out_rows,
+                   void *stream);                                    /* .sample :229-255; uniforms[i] = random.random();
+                                                                        out_rows (optional): payload-ring row of every sampled
+                                                                        leaf when the ring holds payload_rows >= capacity rows
+                                                                        and stored_total transitions were stored so far */
+
+int rlx_libm_pow(const double *x, const double *y, double *out, int n, int *status,
+                 void *stream);  /* out[i] = x[i] ** y[i] as the host libm rounds it (test hook of
+                                    the priority arithmetic above; status bit 4 = outside its domain) */
 
 /* ------------------------------------------------- replay storage (K1 / K4) -- */
 /* A column of a struct-of-arrays transition store: `row_bytes` bytes per transition. */

@@ -52,9 +52,9 @@ def test_argument_validation_matches_reference_error_cases():
     with pytest.raises(_rlx.RlxError, match="power of 2"):
         lib.per_init(fake, fake, fake, 5, fake, None)
     with pytest.raises(_rlx.RlxError, match="power of two"):
-        lib.per_sample(fake, fake, 6, fake, 4, 8.0, 0.4, fake, fake, None, None)
+        lib.per_sample(fake, fake, 6, fake, 4, 8.0, 0.4, fake, fake, None, 0, 0, None, None)
     with pytest.raises(_rlx.RlxError, match="batch"):
-        lib.per_sample(fake, fake, 8, fake, 0, 8.0, 0.4, fake, fake, None, None)
+        lib.per_sample(fake, fake, 8, fake, 0, 8.0, 0.4, fake, fake, None, 0, 0, None, None)
     with pytest.raises(_rlx.RlxError, match="out of range"):
         lib.per_store(fake, fake, fake, 8, 9, 1, 0.6, fake, fake, None)
     # GEMM descriptor checks

