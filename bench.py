@@ -2,7 +2,9 @@
 """bench.py — BASELINE.json headline metric on the C2 workload.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    --gpus N ...`, or from a bare shell — bench.py then re-executes itself under torch.distributed.run
+    with N ranks on 127.0.0.1; rank 0 prints the one JSON line either way)
 
 One "step" = one Clipped-PPO iteration of the hot path on every rank: 2048 env-steps (64 synthetic
 Atari-like envs x 32 steps, 84x84x4 uint8 stacked observations) through the vectorised
@@ -195,10 +197,40 @@ def cpu_baseline_off_policy(name, budget_s=8.0):
             "sample": "oracle/ update step (numpy): %d repetitions, %.4f s per update; acting cost not included" % (n, t)}
 
 
+def prefill_c3(agent):
+    """the C3 replay is PRE-FILLED — 2^20 transitions, priorities |N(0,1)| + 1e-6 — before
+    anything is timed, so that the sampled payload gather walks 7.4 GB of frames instead of a
+    cache-resident corner of the ring.  The rows come from real env steps (fixed action, no host draws:
+    np.random is left untouched), the priorities from one rlx_per_update per 1024 leaves."""
+    from coach_amd.core_types import RunPhase
+    mem = agent.memory
+    cap = mem.power_of_2_size
+    agent.phase = RunPhase.HEATUP
+    agent.actions.zero_()
+    saved = agent.random_actions
+    agent.random_actions = lambda: agent.actions
+    try:
+        for _ in range(cap // agent.n_env + 1):          # + 1: the last step's rows become visible
+            agent.act()
+    finally:
+        agent.random_actions = saved
+    assert mem.count == cap and mem.num_transitions() == cap
+    g = torch.Generator(device="cpu").manual_seed(0)
+    err = torch.randn(cap, generator=g, dtype=torch.float64).abs().to(agent.device)
+    idx = torch.arange(cap, dtype=torch.int32, device=agent.device)
+    for i in range(0, cap, 1024):
+        mem.update_priorities(idx[i:i + 1024], err[i:i + 1024])    # p = |N(0,1)| + epsilon (1e-6)
+    mem.check_status()
+    torch.cuda.synchronize()
+
+
 def run_off_policy(args, device, dist):
     from coach_amd.core_types import RunPhase
     desc, n_env, vsteps, heat = OFF_POLICY[args.workload]
     agent = build_off_policy(args.workload, device, dist)
+    if args.workload == "c3" and not args.no_prefill:
+        prefill_c3(agent)
+        desc += "; replay pre-filled with 2^20 transitions, priorities |N(0,1)|+1e-6"
     agent.phase = RunPhase.HEATUP
     for _ in range(heat):
         agent.act()
@@ -364,6 +396,33 @@ def cpu_baseline(budget_s=20.0):
             "grad_updates_per_s": round(n_updates / t_iter, 3)}
 
 
+def dry_run(args):
+    """The multi-rank contract without the hot path: rendezvous (gloo), K timed no-op steps bracketed by
+    barriers, max-over-ranks time, whole-job sum, ONE JSON line from rank 0."""
+    from coach_amd.distributed import GradientSync
+    dist = GradientSync(backend="gloo")
+    if dist.world_size != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, dist.world_size))
+    flat = torch.ones(1024)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if dist.enabled:
+            dist.all_reduce_sum(flat)
+            flat /= dist.world_size
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    units = dist.sum_over_ranks(args.steps)
+    if dist.rank == 0:
+        print(json.dumps({"metric": "dry-run steps/s", "value": round(units / max(elapsed, 1e-9), 1), "unit": "steps/s",
+                          "n_gpus": dist.world_size, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "config": {"workload": "dry run (no kernels)", "parallelism": "dp%d" % dist.world_size},
+                          "allreduce_check": float(flat[0])}))
+    dist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,9 +433,25 @@ def main():
     ap.add_argument("--shapes", action="store_true", help="print the per-GEMM-shape table to stderr")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json config (default c2 = the headline metric's configuration)")
+    ap.add_argument("--no-prefill", action="store_true", help="c3: skip the 2^20-transition pre-fill")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction plumbing only (no GPU, gloo): what the CPU "
+                         "test of the N-rank entry point runs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher — one rank per GPU on this node
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     from coach_amd.distributed import GradientSync
+    if args.dry_run:
+        return dry_run(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -384,8 +459,7 @@ def main():
     device = torch.device("cuda", local_rank)
     dist = GradientSync()
     if dist.world_size != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
-                         % (args.gpus, dist.world_size))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, dist.world_size))
     if args.workload != "c2":
         run_off_policy(args, device, dist)
         dist.barrier()

@@ -28,7 +28,9 @@ def _build(dev, kind, per, double, n_env=4, cap=256, B=16, ep_len=8):
         PrioritizedExperienceReplayParameters
     from coach_amd.schedules import LinearSchedule
     A = 3
-    shape = (44, 44) if kind == "image" else (8,)
+    full = kind == "image84"          # the BASELINE C3 observation: 84x84 frames, 4-stack
+    kind = "image" if full else kind
+    shape = ((84, 84) if full else (44, 44)) if kind == "image" else (8,)
     ep = SyntheticVectorEnvironmentParameters(kind, n_env, shape, A, episode_length=ep_len, seed=77)
     env = SyntheticVectorEnvironment(ep, dev)
     ap = (DDQNAgentParameters if double else DQNAgentParameters)()
@@ -60,11 +62,15 @@ def _build(dev, kind, per, double, n_env=4, cap=256, B=16, ep_len=8):
 
 
 @pytest.mark.parametrize("kind,per,double", [("vector", False, False), ("vector", True, True),
-                                              ("image", False, False), ("image", True, False)])
+                                              ("image", False, False), ("image", True, False),
+                                              ("image84", True, False)])
 def test_dqn_agent_matches_oracle(dev, kind, per, double):
     import torch
     from coach_amd.core_types import RunPhase
-    agent, o = _build(dev, kind, per, double)
+    if kind == "image84":      # C3's shape end to end (84x84x4 uint8, PER): smaller batch, same loop
+        agent, o = _build(dev, kind, per, double, n_env=2, cap=128, B=8)
+    else:
+        agent, o = _build(dev, kind, per, double)
     # the oracle consumed the same draws for its exploration state as the agent's __init__
     np.testing.assert_array_equal(agent.exploration_policy.current_random_value, o.cur_rand)
     state = (random.getstate(), np.random.get_state())
