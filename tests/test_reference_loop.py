@@ -47,7 +47,7 @@ def _agent(dev, fx, variant):
     import torch
     for k in fx.files:
         if k.startswith("init|"):
-            params.w(k[len("init|"):]).copy_(torch.from_numpy(fx[k]).to(dev).reshape(-1))
+            params.w(k[len("init|"):]).copy_(torch.from_numpy(fx[k]).to(dev))
     agent.networks["main"].update_target(1.0)
     return agent, (HEATUP, TRAIN, SEED, CAP)
 

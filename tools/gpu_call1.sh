@@ -4,7 +4,7 @@ set -u
 O=gpurun_out/r02_call1
 mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/pytest.txt
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -60 > $O/pytest.txt
 echo "pytest rc=$?" >> $O/pytest.txt
 timeout 300 python bench.py --steps 10 --warmup 3 --shapes > $O/bench_c2.json 2> $O/bench_c2.err
 for w in c1 c3 c4 c5; do
