@@ -39,7 +39,7 @@ _CTYPE = {
     "size_t": ctypes.c_size_t,
 }
 
-_VALUE_RETURNING = {"rlx_abi_version"}  # return a value, not an rlx_status
+_VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
 
@@ -232,6 +232,18 @@ class SmallDenseProblem(ctypes.Structure):
         ("towers", ctypes.c_int), ("M", ctypes.c_int), ("K", ctypes.c_int), ("N", ctypes.c_int),
         ("activation", ctypes.c_int), ("lower_activation", ctypes.c_int),
     ]
+
+
+class MlpDqnDesc(ctypes.Structure):
+    """rlx_mlp_dqn_desc (include/rlx.h) — field order must match the header."""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "weights", "target_weights", "adam_m", "adam_v", "adam_state", "states", "next_states", "actions",
+        "rewards", "game_overs", "importance_weights", "workspace", "sync_words", "loss_out", "norm_out",
+        "td_errors", "status")] + [(n, ctypes.c_longlong) for n in (
+            "workspace_floats", "off_w1", "off_b1", "off_w2", "off_b2", "off_w3", "off_b3")] + [
+        ("discount", ctypes.c_double)] + [(n, ctypes.c_int) for n in (
+            "batch", "obs_dim", "h1", "h2", "n_actions", "huber", "double_dqn")] + [(n, ctypes.c_float) for n in (
+                "learning_rate", "beta1", "beta2", "epsilon", "grad_scale")]
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}

@@ -275,6 +275,55 @@ class DQNNet(_NetBase):
             self.modules = [self.torso, self.q_head]
         self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
         self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+        self._fused = self._fused_mlp_setup()
+
+    # ---------------------------------------------------------------- fused small-MLP update (one launch)
+    def _fused_mlp_setup(self):
+        """obs -> Dense(relu) -> Dense(relu) -> Dense(A) Q networks (CartPole_DQN's shape) qualify for
+        rlx_mlp_dqn_update: the whole learn_from_batch in ONE launch (csrc/mlp_fused.hip).
+        RLX_NO_FUSED_MLP=1 keeps the layer-by-layer path (the tests cross-check the two)."""
+        import os
+        if os.environ.get("RLX_NO_FUSED_MLP", "0") == "1" or self.image or self.dueling:
+            return None
+        ls = self.torso.layers
+        if len(ls) != 2 or any(not isinstance(l, G.Dense) or l.act != "relu" or l.T != 1 for l in ls):
+            return None
+        if self.head_gradient_rescale != 1.0 or self.clip_gradients:
+            return None
+        d0, h1, h2 = ls[0].K, ls[0].N, ls[1].N
+        if not self.lib.rlx_mlp_dqn_supported(1, d0, h1, h2, self.A):
+            return None
+        import ctypes
+        n = ctypes.c_longlong()
+        self.lib.mlp_dqn_workspace_floats(h1, h2, self.A, ctypes.byref(n))
+        off = lambda name: self.params.entries[name][0]
+        return dict(dims=(d0, h1, h2), ws=torch.zeros(n.value, dtype=torch.float32, device=self.device),
+                    sync=torch.zeros(4, dtype=torch.int32, device=self.device),
+                    offs=(off(ls[0].kname), off(ls[0].bname), off(ls[1].kname), off(ls[1].bname),
+                          off(self.q_head.kname), off(self.q_head.bname)))
+
+    def _fused_learn(self, obs, next_obs, B, actions, rewards, game_overs, discount, w, td_errors, double_dqn,
+                     grad_scale):
+        f = self._fused
+        d = _rlx.MlpDqnDesc()
+        d.weights, d.target_weights = self.params.weights.data_ptr(), self.target.data_ptr()
+        d.adam_m, d.adam_v, d.adam_state = self.adam.m.data_ptr(), self.adam.v.data_ptr(), self.adam.state.data_ptr()
+        d.states, d.next_states = obs.data_ptr(), next_obs.data_ptr()
+        d.actions, d.rewards, d.game_overs = actions.data_ptr(), rewards.data_ptr(), game_overs.data_ptr()
+        d.importance_weights = None if w is None else w.data_ptr()
+        d.workspace, d.workspace_floats, d.sync_words = f["ws"].data_ptr(), f["ws"].numel(), f["sync"].data_ptr()
+        d.loss_out, d.norm_out = self.loss.data_ptr(), self.norm.data_ptr()
+        d.td_errors = None if td_errors is None else td_errors.data_ptr()
+        d.status = self.status.data_ptr()
+        d.off_w1, d.off_b1, d.off_w2, d.off_b2, d.off_w3, d.off_b3 = f["offs"]
+        d.discount = float(discount)
+        d.batch, (d.obs_dim, d.h1, d.h2), d.n_actions = int(B), f["dims"], self.A
+        d.huber, d.double_dqn = int(self.huber), int(bool(double_dqn))
+        a = self.adam
+        d.learning_rate, d.beta1, d.beta2, d.epsilon, d.grad_scale = a.lr, a.beta1, a.beta2, a.eps, float(grad_scale)
+        import ctypes
+        self.lib.mlp_dqn_update(ctypes.byref(d), self.ctx.stream)
+        return self.loss
 
     def _dueling_forward(self, feat, B, tag, weights=None, train=False):
         """-> (q Tensor [1, B, A], saved) ; saved = tensors the backward pass needs."""
@@ -348,6 +397,12 @@ class DQNNet(_NetBase):
                          sync=None, states_pair=None):
         """DQNAgent.learn_from_batch (agents/dqn_agent.py:81-113), all on device."""
         ctx = self.ctx
+        if self._fused is not None and sync is None and B <= 32 and obs.is_contiguous() and next_obs.is_contiguous():
+            w = importance_weights
+            if w is not None and w.dtype != torch.float64:
+                w = w.double()
+            return self._fused_learn(obs, next_obs, B, actions, rewards, game_overs, discount, w, td_errors,
+                                     double_dqn, grad_scale)
         sel = self.q_values(next_obs, B, tag="next_o").data.view(B, self.A) if double_dqn else None
         if states_pair is not None and not self.dueling:
             # parallel_prediction (dqn_agent.py:86-89): online(s) and target(s') as two towers of the

@@ -257,6 +257,32 @@ int rlx_conv_tables(int *rowbase, int *koff, int batch, int H, int W, int C, int
 int rlx_col2im(const float *dcol, float *dx, const float *x_out, int deriv_kind, int batch, int H,
                int W, int C, int KH, int KW, int stride, void *stream); /* conv input gradient */
 
+/* Fused small-MLP DQN update: DQNAgent.learn_from_batch (agents/dqn_agent.py:81-113) for a vector-observation
+ * Q network  obs -> Dense(h1, relu) -> Dense(h2, relu) -> Dense(n_actions)  in ONE launch: online / target (/ Double
+ * DQN selector) forward passes, TD targets, |TD errors|, MSE or Huber loss with importance weights
+ * (heads/q_head.py, head.py:143-186), backward, TF1 Adam (general_network.py:390-394) and tf.global_norm.
+ * h2 / 32 workgroups each own a 32-column slice of the wide layer; two in-kernel exchanges (csrc/mlp_fused.hip).
+ * All pointers are device pointers; weights / target_weights / adam_m / adam_v are the network's flat buffers and
+ * off_* the element offsets of the six tensors ([obs,h1] [h1] [h1,h2] [h2] [h2,A] [A], row-major) inside them.
+ * sync_words: 3 zero-initialised uint32 owned by this network (the kernel leaves them zero).  status bits: 1 = action
+ * out of range, 8 = an in-kernel barrier timed out (results invalid). */
+typedef struct rlx_mlp_dqn_desc {
+    float *weights; const float *target_weights; float *adam_m; float *adam_v; float *adam_state;
+    const float *states; const float *next_states; const int *actions; const float *rewards;
+    const unsigned char *game_overs; const double *importance_weights;   /* fp64 [batch] or NULL */
+    float *workspace; unsigned int *sync_words;
+    float *loss_out; float *norm_out; double *td_errors; int *status;
+    long long workspace_floats;
+    long long off_w1, off_b1, off_w2, off_b2, off_w3, off_b3;
+    double discount;
+    int batch, obs_dim, h1, h2, n_actions;
+    int huber, double_dqn;
+    float learning_rate, beta1, beta2, epsilon, grad_scale;
+} rlx_mlp_dqn_desc;
+int rlx_mlp_dqn_supported(int batch, int obs_dim, int h1, int h2, int n_actions);   /* 1 / 0 (a value, not a status) */
+int rlx_mlp_dqn_workspace_floats(int h1, int h2, int n_actions, long long *floats_host);
+int rlx_mlp_dqn_update(const rlx_mlp_dqn_desc *desc_host, void *stream);
+
 /* Narrow dense layers (1 <= N <= 16 outputs: value / policy / Q heads) as coalesced fp32 FMA
  * kernels instead of MFMA tiles (heads/v_head.py:43-48, ppo_head.py:100-116, q_head.py,
  * ddpg_actor_head.py:48-56, td3_v_head.py:40-60).  Tower t of every operand sits at

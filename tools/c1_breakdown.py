@@ -1,0 +1,44 @@
+"""Where does a C1 env-step go?  Host-side wall time of act() / train() with and without a device
+sync after each, for the fused and the layer-by-layer update (RLX_NO_FUSED_MLP=1).  Run on the GPU box."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from coach_amd.core_types import RunPhase
+from coach_amd.distributed import GradientSync
+
+dev = torch.device("cuda", 0)
+agent = bench.build_off_policy("c1", dev, GradientSync())
+agent.phase = RunPhase.HEATUP
+for _ in range(64):
+    agent.act()
+agent.phase = RunPhase.TRAIN
+for _ in range(300):
+    agent.act(); agent.train()
+torch.cuda.synchronize()
+N = 2000
+for sync in (False, True):
+    ta = tt = 0.0
+    t_all = time.perf_counter()
+    for _ in range(N):
+        t0 = time.perf_counter()
+        agent.act()
+        if sync: torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        agent.train()
+        if sync: torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        ta += t1 - t0; tt += t2 - t1
+    torch.cuda.synchronize()
+    tot = time.perf_counter() - t_all
+    print("fused=%s sync=%s: act %.1f us, train %.1f us, step %.1f us" % (agent.networks["main"]._fused is not None, sync, 1e6 * ta / N, 1e6 * tt / N, 1e6 * tot / N))
+# the update alone: N replays back to back
+b = agent.memory.sample(32)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    agent.learn_from_batch(b)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("learn_from_batch x%d: host %.1f us per call, host+drain %.1f us per call" % (N, 1e6 * (t1 - t0) / N, 1e6 * (t2 - t0) / N))
