@@ -506,6 +506,19 @@ def main():
                 print(json.dumps(s), file=sys.stderr)
     if dist.rank == 0 and dist.world_size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+        # the REFERENCE's own ClippedPPOAgent code path (kind "reference") cannot run here — /root/reference
+        # exists only in the build container — so its committed timing rides along with its provenance
+        # (tools/time_reference_cpu_c2.py: real rl_coach agent / memory / filters, numpy network stand-in)
+        ref = {}
+        for key, fn in (("one_core", "r02_cpu_reference_c2_1core.json"), ("all_cores", "r02_cpu_reference_c2.json")):
+            try:
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    r = json.load(f)
+                ref[key] = {k: r[k] for k in ("value", "unit", "grad_updates_per_s", "cores", "kind", "where", "sample")}
+            except (OSError, ValueError, KeyError):
+                pass
+        if ref:
+            out["cpu_baseline"]["reference"] = ref
     dist.barrier()
     if dist.rank == 0:
         print(json.dumps(out))
