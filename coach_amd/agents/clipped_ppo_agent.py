@@ -30,7 +30,10 @@ from ..nn.networks import ClippedPPONet
 from ..schedules import ConstantSchedule
 
 
-class ClippedPPONetworkParameters(object):               # clipped_ppo_agent.py:41-58
+from ..architectures.scheme_views import SchemeViews
+
+
+class ClippedPPONetworkParameters(SchemeViews):               # clipped_ppo_agent.py:41-58
     def __init__(self):
         self.activation_function = 'tanh'
         self.embedder_scheme = 'Medium'

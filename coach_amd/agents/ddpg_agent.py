@@ -18,10 +18,14 @@ from ..exploration_policies.ou_process import OUProcess, OUProcessParameters
 from ..exploration_policies.additive_noise import AdditiveNoise, AdditiveNoiseParameters
 from ..memories.episodic.episodic_experience_replay import EpisodicExperienceReplayParameters
 from ..nn.actor_critic_nets import ActorNet, CriticNet
+from ..architectures.scheme_views import SchemeViews
 from .vector_agent import AlgorithmParameters, VectorOffPolicyAgent
 
 
-class DDPGCriticNetworkParameters(object):               # ddpg_agent.py:36-52 (+ Mujoco_DDPG preset schemes)
+class DDPGCriticNetworkParameters(SchemeViews):           # ddpg_agent.py:36-52 (+ Mujoco_DDPG preset schemes)
+    _EMBEDDER_FIELDS = {"observation": "observation_embedder_scheme", "action": "action_embedder_scheme"}
+    _TUPLE_SCHEMES = True
+
     def __init__(self):
         self.observation_embedder_scheme = (400,)
         self.action_embedder_scheme = ()
@@ -39,7 +43,10 @@ class DDPGCriticNetworkParameters(object):               # ddpg_agent.py:36-52 (
         self.scale_down_gradients_by_number_of_workers_for_sync_training = False
 
 
-class DDPGActorNetworkParameters(object):                # ddpg_agent.py:55-70
+class DDPGActorNetworkParameters(SchemeViews):            # ddpg_agent.py:55-70
+    _EMBEDDER_FIELDS = {"observation": "observation_embedder_scheme"}
+    _TUPLE_SCHEMES = True
+
     def __init__(self):
         self.observation_embedder_scheme = (400,)
         self.middleware_scheme = (300,)

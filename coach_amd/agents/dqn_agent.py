@@ -14,6 +14,7 @@ import torch
 
 from .. import _rlx
 from ..architectures.head_parameters import DuelingQHeadParameters, QHeadParameters
+from ..architectures.scheme_views import SchemeViews
 from ..core_types import EnvironmentSteps, RunPhase
 from ..exploration_policies.e_greedy import EGreedy, EGreedyParameters
 from ..memories.non_episodic.experience_replay import ExperienceReplayParameters
@@ -32,7 +33,7 @@ class DQNAlgorithmParameters(AlgorithmParameters):       # dqn_agent.py:33-40
         self.supports_parameter_noise = True
 
 
-class DQNNetworkParameters(object):                      # dqn_agent.py:43-53 + NetworkParameters defaults
+class DQNNetworkParameters(SchemeViews):                      # dqn_agent.py:43-53 + NetworkParameters defaults
     def __init__(self):
         self.activation_function = 'relu'
         self.embedder_scheme = 'Medium'

@@ -20,11 +20,15 @@ from .. import _rlx
 from ..core_types import EnvironmentSteps, RunPhase
 from ..memories.non_episodic.experience_replay import ExperienceReplayParameters
 from ..nn.actor_critic_nets import SACPolicyNet, SACQNet, SACValueNet
+from ..architectures.scheme_views import SchemeViews
 from .vector_agent import AlgorithmParameters, VectorOffPolicyAgent
 
 
-class _SACNetParams(object):
+class _SACNetParams(SchemeViews):
+    _TUPLE_SCHEMES = True
+
     def __init__(self):
+        self.activation_function = 'relu'
         self.optimizer_type = 'Adam'
         self.batch_size = 256
         self.learning_rate = 0.0003
@@ -47,6 +51,21 @@ class SACCriticNetworkParameters(_SACNetParams):         # :72-84
         super().__init__()
         self.network_layers_sizes = (256, 256)           # SACQHeadParameters
         self.create_target_network = False
+
+    @property
+    def heads_parameters(self):
+        """[SACQHeadParameters]: presets set heads_parameters[0].network_layers_sizes (Mujoco_SAC.py)."""
+        owner = self
+
+        class _Head(object):
+            @property
+            def network_layers_sizes(self):
+                return owner.network_layers_sizes
+
+            @network_layers_sizes.setter
+            def network_layers_sizes(self, value):
+                owner.network_layers_sizes = tuple(value)
+        return [_Head()]
 
 
 class SACPolicyNetworkParameters(_SACNetParams):         # :87-100

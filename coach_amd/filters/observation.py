@@ -70,9 +70,13 @@ class ObservationNormalizationFilter(ObservationFilter):
     """observation_normalization_filter.py:71-78 + NumpySharedRunningStats
     (utilities/shared_running_stats.py:115-164): fp64 running sum / sum of squares on the device."""
 
-    def __init__(self, dim, device, clip_min=-5.0, clip_max=5.0, epsilon=1e-2):
-        self.dim, self.device, self.eps = dim, device, epsilon
+    def __init__(self, dim=None, device=None, clip_min=-5.0, clip_max=5.0, epsilon=1e-2, name='observation_stats'):
+        """dim / device None: a preset-level declaration (`ObservationNormalizationFilter(name=...)` in
+        Mujoco_ClippedPPO.py); the agent builds the bound instance once the observation space is known."""
+        self.dim, self.device, self.eps, self.name = dim, device, epsilon, name
         self.clip = (clip_min, clip_max)
+        if dim is None:
+            return
         f64 = torch.float64
         self.sum = torch.zeros(dim, dtype=f64, device=device)
         self.sum_squares = torch.full((dim,), epsilon, dtype=f64, device=device)

@@ -50,9 +50,17 @@ class CsvLogger(object):
 
 
 class BasicRLGraphManager(object):
-    def __init__(self, agent_params, env_params, schedule_params, device=None, dist=None, csv_path=None):
+    def __init__(self, agent_params, env_params, schedule_params, vis_params=None, preset_validation_params=None,
+                 name='simple_rl_graph', device=None, dist=None, csv_path=None):
+        """Reference signature (basic_rl_graph_manager.py:35-42: agent_params, env_params, schedule_params,
+        vis_params, preset_validation_params, name) + where to run (device, dist) and where to log."""
         import torch
+        from ..base_parameters import PresetValidationParameters, VisualizationParameters
         self.agent_params, self.env_params, self.schedule = agent_params, env_params, schedule_params
+        self.schedule_params = schedule_params
+        self.visualization_parameters = vis_params or VisualizationParameters()
+        self.preset_validation_params = preset_validation_params or PresetValidationParameters()
+        self.name = name
         self.device = device or torch.device("cuda", 0)
         self.dist = dist
         self.environment = self.agent = None
@@ -65,6 +73,8 @@ class BasicRLGraphManager(object):
     # ------------------------------------------------------------------ graph creation (:62-78)
     def create_graph(self):
         rank = self.dist.rank if self.dist is not None else 0
+        from ..compat import resolve_reference_style
+        resolve_reference_style(self.agent_params, self.env_params)
         self.environment = dynamic_import(self.env_params.path)(self.env_params, self.device, rank=rank)
         self.agent = dynamic_import(self.agent_params.path)(self.agent_params, self.environment, self.device,
                                                             dist=self.dist)
