@@ -145,7 +145,11 @@ class DDPGAgent(VectorOffPolicyAgent):
 
     def handle_episode_ended(self):
         if hasattr(self.exploration_policy, "reset"):
-            self.exploration_policy.reset()                                   # Agent.reset_internal_state
+            ended = np.nonzero(self._episode_steps == 0)[0] if self._episode_just_ended else None
+            try:                                                              # Agent.reset_internal_state, per env
+                self.exploration_policy.reset(ended)
+            except TypeError:
+                self.exploration_policy.reset()
 
     # ------------------------------------------------------------------------------- training
     def _td_targets(self, b, q_next):

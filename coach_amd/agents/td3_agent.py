@@ -97,7 +97,9 @@ class TD3Agent(DDPGAgent):
         return self.zero_go if self.ap.algorithm.clear_game_over_on_time_limit else game_over
 
     def _training_steps_this_phase(self):
-        return self.last_episode_steps                                        # :211-213
+        # current_episode_steps_counter updates in a row at each episode end (:211-213): the phases of a vector
+        # step take the lengths of the episodes that just finished, in env order
+        return self._phase_episode_lengths.pop(0)
 
     def _critic_device_paired(self, b, obs2):
         """The same update with every online / target pass pair sharing its launches: actor online(s)

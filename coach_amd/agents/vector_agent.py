@@ -152,7 +152,10 @@ class VectorOffPolicyAgent(GraphRunner):
         self.training_iteration = 0
         self.last_training_phase_step = 0
         self.last_target_network_update_step = 0
-        self.current_episode_steps_counter = 0
+        self.current_episode_steps_counter = 0                  # steps of env 0's running episode
+        self._episode_steps = np.zeros(self.n_env, dtype=np.int64)     # ... of every env's
+        self._unconsumed_episode_lengths = []                   # finished episodes no training phase has used yet
+        self._episode_just_ended = False
         dev, n = self.device, self.n_env
         self.filtered_reward = torch.zeros(n, dtype=torch.float32, device=dev)
         self.ep_return = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -188,7 +191,9 @@ class VectorOffPolicyAgent(GraphRunner):
                                                mp.allow_duplicates_in_batch_sampling,
                                                exact_pow=getattr(mp, "exact_pow", "device"), **kw)
         if isinstance(mp, EpisodicExperienceReplayParameters):
-            return EpisodicExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling, **kw)
+            return EpisodicExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling,
+                                            n_step=getattr(mp, "n_step", -1), discount=self.ap.algorithm.discount,
+                                            max_episode_length=self.L, **kw)
         return ExperienceReplay(mp.max_size, mp.allow_duplicates_in_batch_sampling, **kw)
 
     def _to_device(self, key, array, dtype):
@@ -229,22 +234,32 @@ class VectorOffPolicyAgent(GraphRunner):
             self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,
                                         self.n_env, self.ep_acc, None, None, s)
         self.env.total_steps += self.n_env
-        self.current_episode_steps_counter += 1
-        episode_ended = self.current_episode_steps_counter >= self.L
+        # which envs finished: a host fact (the env front end's `dones_host`; lockstep envs without one end
+        # together after L steps) — no device sync
+        self._episode_steps += 1
+        dones_host = getattr(self.env, "dones_host", None)
+        if dones_host is None:
+            dones_host = self._episode_steps >= self.L
+        ended = np.nonzero(dones_host)[0]
+        any_ended, all_ended = ended.size > 0, ended.size == self.n_env
         stored = self._stored_game_over(game_over)
+        # a terminal response is observed at once; the others at the start of the next step.  With several envs
+        # the rows of a step become visible together, at once only when EVERY env's episode ended on it.
         self.memory.store(actions, self.filtered_reward, stored, next_obs, reset_obs, record=record,
                           dones=None if stored is game_over else game_over,
-                          defer=not episode_ended, episode_end=episode_ended)
-        self._episode_just_ended = episode_ended
-        if episode_ended:
-            self.last_episode_steps = self.current_episode_steps_counter
-            self.current_episode_steps_counter = 0
-            if hasattr(self.memory, "close_last_episode") and record:
-                self.memory.close_last_episode()
+                          defer=not all_ended, episode_end=any_ended, dones_host=dones_host)
+        self._episode_just_ended = any_ended
+        self.current_episode_steps_counter = int(self._episode_steps[0]) if not dones_host[0] else 0
+        if any_ended:
+            self.ended_episode_lengths = self._episode_steps[ended].copy()    # one entry per finished env
+            self.last_episode_steps = int(self.ended_episode_lengths[-1])
+            self._episode_steps[ended] = 0
+            if record:
+                self._unconsumed_episode_lengths.extend(int(x) for x in self.ended_episode_lengths)
             self.handle_episode_ended()
         if self.phase != RunPhase.TEST:                                        # agent.py:832-834
             self.total_steps_counter += self.n_env
-        return episode_ended
+        return all_ended
 
     def _stored_game_over(self, game_over):
         return game_over
@@ -277,8 +292,15 @@ class VectorOffPolicyAgent(GraphRunner):
         gap = self.total_steps_counter - self.last_training_phase_step
         if gap < steps:
             return 0
-        if self.ap.algorithm.act_for_full_episodes and not getattr(self, "_episode_just_ended", False):
-            return 0                                   # wait_for_full_episode (agent.py:692-693)
+        if self.ap.algorithm.act_for_full_episodes:
+            # wait_for_full_episode (agent.py:692-693): one phase per episode that finished since the last
+            # phase; each env's finished episode is one reference episode end
+            if not self._unconsumed_episode_lengths:
+                return 0
+            self._phase_episode_lengths = self._unconsumed_episode_lengths
+            self._unconsumed_episode_lengths = []
+            self.last_training_phase_step = self.total_steps_counter
+            return len(self._phase_episode_lengths)
         # the reference opens ONE phase per check and resets the marker to the current step
         # (:673-677); a vector step is n_env checks' worth of env-steps
         due = min(gap // steps, max(1, self.n_env // steps))
@@ -339,6 +361,7 @@ class VectorOffPolicyAgent(GraphRunner):
         else:
             mem.drop_pending()
         self.current_episode_steps_counter = 0
+        self._episode_steps[:] = 0
         self._episode_just_ended = False
         self.lib.episode_stats_init(self.ep_return, self.ep_len, self.n_env, None, _rlx.current_stream())
         pol = getattr(self, "exploration_policy", None)
@@ -358,13 +381,22 @@ class VectorOffPolicyAgent(GraphRunner):
         self.memory.begin_evaluation(first)
         self.phase = RunPhase.TEST
         total = torch.zeros(self.n_env, dtype=torch.float64, device=self.device)
+        finished = np.zeros(self.n_env, dtype=np.int64)          # evaluation episodes completed per env
         try:
-            for _ in range(episodes_per_env * self.L):
+            while (finished < episodes_per_env).any():
                 self.act()
-                total += self.env.reward.double()
+                active = finished < episodes_per_env                      # envs still inside their quota
+                if active.all():
+                    total += self.env.reward.double()
+                else:
+                    total += self.env.reward.double() * torch.from_numpy(active.astype(np.float64)).to(self.device)
+                dh = getattr(self.env, "dones_host", None)
+                finished += (dh if dh is not None else np.full(self.n_env, self._episode_just_ended)).astype(np.int64)
         finally:
             self.phase = prev
             self.current_episode_steps_counter = 0
+            self._episode_steps[:] = 0
+            self._unconsumed_episode_lengths = []
             self._episode_just_ended = False
             self.memory.end_evaluation(self.env.reset_internal_state())
         return float(total.mean().item()) / episodes_per_env

@@ -21,12 +21,14 @@ def _tensors_of(obj, names):
 
 
 _MEMORY_TENSORS = ["ring", "fpos", "epoff", "t_fpos", "t_epoff", "cur_state", "obs", "next_obs", "action",
-                   "reward", "game_over", "sum_tree", "min_tree", "max_tree", "max_priority"]
+                   "reward", "game_over", "sum_tree", "min_tree", "max_tree", "max_priority",
+                   "n_step_discounted_rewards"]
 _MEMORY_SCALARS = ["cursor", "count", "pending", "committed_total", "steps", "_open", "_list_len",
-                   "next_leaf_idx_to_write", "_frames_total", "_episode_steps", "_step_frames"]
+                   "next_leaf_idx_to_write", "_frames_total", "_episode_steps", "_step_frames",
+                   "_gstep", "_ep_start", "_episodes", "_episode_first_step", "_order", "_order_head", "_order_len"]
 _AGENT_SCALARS = ["total_steps_counter", "training_iteration", "last_training_phase_step",
                   "last_target_network_update_step", "current_episode_steps_counter", "last_episode_steps",
-                  "_episode_just_ended"]
+                  "_episode_just_ended", "_episode_steps", "_unconsumed_episode_lengths"]
 
 
 def agent_state(agent):
@@ -37,9 +39,9 @@ def agent_state(agent):
             "adam_m": net.adam.m.cpu(), "adam_v": net.adam.v.cpu(), "adam_state": net.adam.state.cpu()}
     mem = agent.memory
     st["memory"]["tensors"] = _tensors_of(mem, _MEMORY_TENSORS)
-    st["memory"]["scalars"] = {k: (getattr(mem, k).copy() if isinstance(getattr(mem, k), np.ndarray)
-                                   else getattr(mem, k)) for k in _MEMORY_SCALARS if hasattr(mem, k)}
-    st["agent"]["scalars"] = {k: getattr(agent, k) for k in _AGENT_SCALARS if hasattr(agent, k)}
+    import copy
+    st["memory"]["scalars"] = {k: copy.deepcopy(getattr(mem, k)) for k in _MEMORY_SCALARS if hasattr(mem, k)}
+    st["agent"]["scalars"] = {k: copy.deepcopy(getattr(agent, k)) for k in _AGENT_SCALARS if hasattr(agent, k)}
     st["agent"]["phase"] = agent.phase.name                   # RunPhase of the agent (and its policy)
     # uniforms_all: the exploration draws of the running PPO phase (made at its first step)
     st["agent"]["tensors"] = _tensors_of(agent, ["ep_return", "ep_len", "ep_acc", "uniforms_all"])
@@ -70,12 +72,13 @@ def load_agent_state(agent, st):
     mem = agent.memory
     for k, t in st["memory"]["tensors"].items():
         getattr(mem, k).copy_(t)
+    import copy
     for k, v in st["memory"]["scalars"].items():
-        setattr(mem, k, v)
+        setattr(mem, k, copy.deepcopy(v))
     if "beta" in st["memory"]:
         mem.beta = pickle.loads(st["memory"]["beta"])
     for k, v in st["agent"]["scalars"].items():
-        setattr(agent, k, v)
+        setattr(agent, k, copy.deepcopy(v))
     if "phase" in st["agent"]:
         from .core_types import RunPhase
         agent.phase = RunPhase[st["agent"]["phase"]]

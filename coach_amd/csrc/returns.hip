@@ -233,6 +233,30 @@ episode_stats_kernel(const float *__restrict__ reward, const unsigned char *__re
 
 }  // namespace
 
+namespace {
+// Episode.update_discounted_rewards (core_types.py:771-801) for ONE completed episode whose T transitions sit in a
+// time-major ring (row of step k = ((s0 + k) mod ring_steps) * n_env + env).  The reference adds
+// current_discount * rewards[i:] for i = 1 .. n-1 onto a float64 copy of the rewards, current_discount growing by
+// repeated multiplication: out[t] = ((r[t] + g1 r[t+1]) + g2 r[t+2]) + ...  with g_j = g_{j-1} * discount — the same
+// order and the same products here, so the column is bit-identical to the reference's n_step_discounted_rewards.
+// (-ffp-contract=off: no fused multiply-add.)  O(T * n) like the reference; one thread per transition.
+__global__ void episode_nstep_returns_kernel(const float *__restrict__ rewards, double *__restrict__ out,
+                                             long long s0, int T, int env, int n_env, long long ring_steps,
+                                             double discount, int n_step) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int n = (n_step == -1 || n_step > T) ? T : n_step;
+    auto row = [&](int k) { return ((s0 + k) % ring_steps) * n_env + env; };
+    double acc = (double)rewards[row(t)];
+    double g = discount;
+    for (int j = 1; j < n; ++j) {
+        if (t + j < T) acc += g * (double)rewards[row(t + j)];
+        g *= discount;
+    }
+    out[row(t)] = acc;
+}
+}  // namespace
+
 extern "C" {
 
 int rlx_gae(const float *rewards, const float *values, const unsigned char *game_overs,
@@ -256,6 +280,19 @@ int rlx_discounted_returns(const float *rewards, const unsigned char *game_overs
     reverse_scan_kernel<<<n_seq, kScanBlock, 0, rlx::as_stream(stream)>>>(
         rewards, nullptr, game_overs, nullptr, seq_len, discount, discount, 1, returns64,
         returns32);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_episode_nstep_returns(const float *rewards, double *out, long long first_step, int length, int env,
+                              int n_env, long long ring_steps, double discount, int n_step, void *stream) {
+    RLX_REQUIRE(rewards && out, "rlx_episode_nstep_returns: null pointer");
+    RLX_REQUIRE(length > 0 && n_env > 0 && env >= 0 && env < n_env && ring_steps >= length && first_step >= 0,
+                "rlx_episode_nstep_returns: bad episode geometry (length=%d ring_steps=%lld)", length, ring_steps);
+    RLX_REQUIRE(n_step == -1 || n_step >= 1,
+                "n-step should be an integer with value >= 1, or set to -1 for always setting to episode length.");
+    episode_nstep_returns_kernel<<<(length + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
+        rewards, out, first_step, length, env, n_env, ring_steps, discount, n_step);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

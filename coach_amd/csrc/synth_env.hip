@@ -90,10 +90,11 @@ __global__ void env_reset_kernel(int kind, void *obs, int *ep, int *t, int n_env
 
 __global__ void env_step_kernel(int kind, void *next_obs, void *reset_obs, float *reward,
                                 unsigned char *done, const int *ep_in, const int *t_in, int n_env,
-                                int obs_elems, int episode_len, uint32_t seed, uint32_t env_id0) {
+                                int obs_elems, int episode_len, const int *__restrict__ len_per_env,
+                                uint32_t seed, uint32_t env_id0) {
     const int e = blockIdx.y;
     const uint32_t ep = (uint32_t)ep_in[e], t = (uint32_t)t_in[e];
-    const bool is_done = (int)t + 1 >= episode_len;
+    const bool is_done = (int)t + 1 >= (len_per_env ? len_per_env[e] : episode_len);
     const size_t esz = kind == 0 ? 1 : 4;
     const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
     write_obs(kind, static_cast<char *>(next_obs) + (size_t)e * obs_elems * esz, obs_elems, seed,
@@ -137,9 +138,29 @@ int rlx_synth_env_reset(int kind, void *obs, int *episode, int *step, int n_env,
     return RLX_OK;
 }
 
+static int synth_step(int kind, void *next_obs, void *reset_obs, float *reward, unsigned char *game_over,
+                      int *episode, int *step, int n_env, int obs_elems, int episode_len,
+                      const int *len_per_env, unsigned int seed, unsigned int env_id0, void *stream);
+
 int rlx_synth_env_step(int kind, void *next_obs, void *reset_obs, float *reward,
                        unsigned char *game_over, int *episode, int *step, int n_env, int obs_elems,
                        int episode_len, unsigned int seed, unsigned int env_id0, void *stream) {
+    return synth_step(kind, next_obs, reset_obs, reward, game_over, episode, step, n_env, obs_elems, episode_len,
+                      nullptr, seed, env_id0, stream);
+}
+
+int rlx_synth_env_step_lengths(int kind, void *next_obs, void *reset_obs, float *reward,
+                               unsigned char *game_over, int *episode, int *step, int n_env, int obs_elems,
+                               const int *episode_len_per_env, unsigned int seed, unsigned int env_id0,
+                               void *stream) {
+    RLX_REQUIRE(episode_len_per_env, "rlx_synth_env_step_lengths: null length table");
+    return synth_step(kind, next_obs, reset_obs, reward, game_over, episode, step, n_env, obs_elems, 1,
+                      episode_len_per_env, seed, env_id0, stream);
+}
+
+static int synth_step(int kind, void *next_obs, void *reset_obs, float *reward, unsigned char *game_over,
+                      int *episode, int *step, int n_env, int obs_elems, int episode_len,
+                      const int *len_per_env, unsigned int seed, unsigned int env_id0, void *stream) {
     RLX_REQUIRE(next_obs && reset_obs && reward && game_over && episode && step,
                 "rlx_synth_env_step: null pointer");
     RLX_REQUIRE(kind == 0 || kind == 1, "rlx_synth_env_step: kind must be 0 (image) or 1 (vector)");
@@ -149,7 +170,7 @@ int rlx_synth_env_step(int kind, void *next_obs, void *reset_obs, float *reward,
     const int work = kind == 0 ? obs_elems / 16 : obs_elems;
     dim3 grid(rlx::grid_for(work, 64, 16), n_env);
     env_step_kernel<<<grid, 64, 0, s>>>(kind, next_obs, reset_obs, reward, game_over, episode, step,
-                                        n_env, obs_elems, episode_len, seed, env_id0);
+                                        n_env, obs_elems, episode_len, len_per_env, seed, env_id0);
     RLX_LAUNCH_CHECK();
     env_advance_kernel<<<(n_env + 63) / 64, 64, 0, s>>>(episode, step, game_over, n_env);
     RLX_LAUNCH_CHECK();

@@ -41,8 +41,12 @@ class OUProcess(object):
         self._z = Stager((n_env, self.A), torch.float64, device)
         self.d_z = self._z.dst
 
-    def reset(self):
-        self.state = np.zeros((self.n_env, self.A))
+    def reset(self, envs=None):
+        """envs: indices of the envs whose episode ended (every env's process restarts when None)."""
+        if envs is None or not hasattr(self, "state"):
+            self.state = np.zeros((self.n_env, self.A))
+        else:
+            self.state[np.asarray(envs)] = 0.0
 
     def noise(self):
         for e in range(self.n_env):                                           # :61-65 per env

@@ -74,7 +74,7 @@ class ExperienceReplay(Memory):
                              % (cap, self.n_env))
         self.cap = cap
         # physical rows: the capacity plus one vector step that is written but not visible yet
-        rows = self.rows = cap + self.n_env
+        rows = self.rows = self._physical_rows(cap, self.n_env)
         self.image = stack is not None
         self.stack = stack
         dev = device
@@ -121,6 +121,13 @@ class ExperienceReplay(Memory):
         self._frames_total = 0
         self._step_frames = np.zeros(rows // self.n_env, dtype=np.int64)
         self._episode_steps = 0
+
+    def _physical_rows(self, cap, n_env):
+        return cap + n_env
+
+    def _extra_gather_columns(self):
+        """[(stored column, batch-buffer key)] a subclass wants collated with the Batch (same launch)."""
+        return []
 
     # ---------------------------------------------------------------- Memory interface (:56-69)
     def length(self):
@@ -220,7 +227,7 @@ class ExperienceReplay(Memory):
         return self.cur_state
 
     def store(self, actions, rewards, game_overs, next_obs, reset_obs, record=True, dones=None,
-              defer=False, episode_end=False):
+              defer=False, episode_end=False, dones_host=None):
         """n_env transitions (state = current state of every env), then advance the env states.
         Reference: ExperienceReplay.store + _enforce_max_length (:117-150) called n_env times.
         record=False only advances the observation state (evaluation episodes are not stored).
@@ -309,6 +316,7 @@ class ExperienceReplay(Memory):
         pairs = [(self.action, b["action"]), (self.reward, b["reward"]), (self.game_over, b["game_over"])]
         if not self.image:
             pairs += [(self.obs, b["state"]), (self.next_obs, b["next_state"])]
+        pairs += [(src, b[key]) for src, key in self._extra_gather_columns()]
         self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), rows, None, 0, 0, self.rows, size,
                               size, self.status, s)
         if self.image:

@@ -133,6 +133,11 @@ int rlx_gae(const float *rewards, const float *values, const unsigned char *game
 int rlx_discounted_returns(const float *rewards, const unsigned char *game_overs, int n_seq,
                            long long seq_len, double discount, double *returns64,
                            float *returns32, void *stream);          /* core_types.py:771-801 (n_step = -1) */
+int rlx_episode_nstep_returns(const float *rewards, double *out, long long first_step, int length, int env,
+                              int n_env, long long ring_steps, double discount, int n_step,
+                              void *stream);   /* core_types.py:771-801 for any n_step, ONE completed episode stored
+                                                  time-major (row = ((first_step + k) mod ring_steps) * n_env + env);
+                                                  fp64, the reference's summation order (bit-identical column) */
 int rlx_standardize(const double *x, long long n, float *out32, double *out64, double *mean_std,
                     void *stream);                                   /* clipped_ppo_agent.py:201 (no epsilon) */
 int rlx_episode_stats_init(double *ep_return, int *ep_len, int n_env, double *acc, void *stream);
@@ -436,6 +441,13 @@ int rlx_synth_env_reset(int kind, void *obs, int *episode, int *step, int n_env,
 int rlx_synth_env_step(int kind, void *next_obs, void *reset_obs, float *reward,
                        unsigned char *game_over, int *episode, int *step, int n_env, int obs_elems,
                        int episode_len, unsigned int seed, unsigned int env_id0, void *stream);
+
+/* the same with a time limit per env (device int32[n_env]): envs whose episodes end on different steps, the
+ * case a real simulator front end produces (environment.py:276-327 episode bookkeeping is per env) */
+int rlx_synth_env_step_lengths(int kind, void *next_obs, void *reset_obs, float *reward,
+                               unsigned char *game_over, int *episode, int *step, int n_env, int obs_elems,
+                               const int *episode_len_per_env, unsigned int seed, unsigned int env_id0,
+                               void *stream);
 
 #ifdef __cplusplus
 }

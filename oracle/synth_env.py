@@ -59,8 +59,9 @@ def reward(kind, seed, env, ep, t):
 
 
 class SynthVecEnv:
-    def __init__(self, kind, n_env, obs_elems, episode_len, seed, env_id0=0):
+    def __init__(self, kind, n_env, obs_elems, episode_len, seed, env_id0=0, episode_lengths=None):
         self.kind, self.n_env, self.obs_elems, self.L = kind, n_env, obs_elems, episode_len
+        self.lengths = [episode_len] * n_env if episode_lengths is None else list(episode_lengths)
         self.seed, self.env_id0 = seed, env_id0
         self.ep = np.zeros(n_env, dtype=np.int64)
         self.t = np.zeros(n_env, dtype=np.int64)
@@ -75,7 +76,7 @@ class SynthVecEnv:
         nxt, rst, rew, done = [], [], [], []
         for e in range(self.n_env):
             ep, t = int(self.ep[e]), int(self.t[e])
-            d = t + 1 >= self.L
+            d = t + 1 >= self.lengths[e]
             nxt.append(observation(self.kind, self.seed, self.env_id0 + e, ep, t + 1, self.obs_elems))
             rst.append(observation(self.kind, self.seed, self.env_id0 + e, ep + 1, 0, self.obs_elems)
                        if d else nxt[-1])

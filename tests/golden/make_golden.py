@@ -31,9 +31,9 @@ def _save(name, **arrays):
     print("wrote %s (%d arrays, %.1f KiB)" % (path, len(arrays), os.path.getsize(path) / 1024))
 
 
-def _transition(i):
+def _transition(i, game_over=False):
     return Transition(state={'observation': np.array([i])}, action=0, reward=float(i),
-                      next_state={'observation': np.array([i + 1])}, game_over=False)
+                      next_state={'observation': np.array([i + 1])}, game_over=game_over)
 
 
 # ----------------------------------------------------------------------------------------- PER
@@ -139,6 +139,45 @@ def gen_er():
     out["fifo_counts"] = np.array(counts)
     out["fifo_rewards"] = np.array(sampled)
     _save("er", **out)
+
+
+def gen_episodic():
+    """EpisodicExperienceReplay.store_episode / close_last_episode / _enforce_max_length / sample
+    (memories/episodic/episodic_experience_replay.py:102-130,240-317) with Episode's n-step discounted returns
+    (core_types.py:771-820): episodes of different lengths handed over one at a time (what Agent.handle_episode_ended
+    does with current_episode_buffer), whole-episode eviction once max_size transitions are exceeded, uniform draws
+    over the flat transitions list.  Stored per variant: the rewards, the episode lengths, after EVERY store_episode
+    the memory's counters, the rewards / n_step_discounted_rewards of all transitions it holds, and one sampled batch."""
+    from rl_coach.core_types import Episode
+    from rl_coach.memories.episodic.episodic_experience_replay import EpisodicExperienceReplay
+    out = {}
+    for name, n_step, max_size, lens in (("to_end", -1, (MemoryGranularity.Transitions, 40), [5, 9, 1, 12, 7, 3, 16, 4, 8]),
+                                         ("n3", 3, (MemoryGranularity.Transitions, 30), [6, 2, 11, 4, 9, 5, 13]),
+                                         ("episodes", -1, (MemoryGranularity.Episodes, 3), [4, 6, 2, 8, 3])):
+        rng = np.random.RandomState(len(lens))
+        np.random.seed(100 + len(lens))
+        m = EpisodicExperienceReplay(max_size, n_step=n_step)
+        rewards = rng.uniform(-2, 2, size=sum(lens))
+        counters, held_r, held_nsr, sampled = [], [], [], []
+        k = 0
+        for L in lens:
+            ep = Episode(discount=0.97, n_step=n_step)
+            for t in range(L):
+                ep.insert(_transition(float(rewards[k]), game_over=(t == L - 1)))
+                k += 1
+            m.store_episode(ep)
+            counters.append([m.num_transitions(), m.num_transitions_in_complete_episodes(), m.num_complete_episodes(),
+                             m.length()])
+            held_r.append(np.array([t.reward for t in m.transitions]))
+            held_nsr.append(np.array([t.n_step_discounted_rewards for t in m.transitions]))
+            sampled.append(np.array([t.reward for t in m.sample(6)]))
+        out[name + "_meta"] = np.array([n_step, int(max_size[0] == MemoryGranularity.Episodes), max_size[1], 100 + len(lens)])
+        out[name + "_lens"], out[name + "_rewards"] = np.array(lens), rewards
+        out[name + "_counters"] = np.array(counters)
+        out[name + "_sampled"] = np.array(sampled)
+        for i, (a, b) in enumerate(zip(held_r, held_nsr)):
+            out["%s_held_r_%d" % (name, i)], out["%s_held_nsr_%d" % (name, i)] = a, b
+    _save("episodic", **out)
 
 
 # ------------------------------------------------------------------------------------ stacking
@@ -1062,7 +1101,7 @@ def gen_ppo_loop():
     _save("ppo_loop", **out)
 
 
-GROUPS = {"per": gen_per, "er": gen_er, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
+GROUPS = {"per": gen_per, "er": gen_er, "episodic": gen_episodic, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
           "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop}
 
 if __name__ == "__main__":

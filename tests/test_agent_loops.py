@@ -79,3 +79,58 @@ def test_graph_replay_equals_eager(dev, name):
             assert torch.equal(a.networks[k].target, b.networks[k].target)
     st = a.episode_statistics()
     assert st["episodes"] == (17 // L) * n_env and st["mean_length"] == L
+
+
+@pytest.mark.parametrize("name", ["td3", "dqn"])
+def test_envs_with_different_episode_lengths(dev, name):
+    """Envs of one vector finishing their episodes on different steps (a real simulator's behaviour): episode
+    statistics are per env, TD3 trains `episode length` updates for every env that finishes (td3_agent.py:211-213),
+    its episodic memory lists exactly the complete episodes, and graph replay still equals eager execution."""
+    import torch
+    from coach_amd.core_types import RunPhase
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    lens = [5, 3, 4, 5]
+    outs = []
+    for graphs in (True, False):
+        if name == "td3":
+            from coach_amd.agents.td3_agent import TD3Agent as C, TD3AgentParameters as P
+            ep = SyntheticVectorEnvironmentParameters("vector", 4, (9,), None, action_dim=3, episode_length=5, seed=9,
+                                                      episode_lengths=lens)
+        else:
+            from coach_amd.agents.dqn_agent import DQNAgent as C, DQNAgentParameters as P
+            ep = SyntheticVectorEnvironmentParameters("vector", 4, (6,), 4, episode_length=5, seed=9, episode_lengths=lens)
+        p = P()
+        p.seed = 11
+        for n in p.network_wrappers.values():
+            n.batch_size = 16
+        p.memory.max_size = (MemoryGranularity.Transitions, 160)
+        agent = C(p, SyntheticVectorEnvironment(ep, dev), dev, use_graphs=graphs)
+        random.seed(1); np.random.seed(1)
+        agent.phase = RunPhase.HEATUP
+        for _ in range(6):
+            agent.act()
+        agent.phase = RunPhase.TRAIN
+        updates = []
+        for _ in range(24):
+            agent.act()
+            before = agent.training_iteration
+            agent.train()
+            updates.append(agent.training_iteration - before)
+        agent.check_status()
+        outs.append((updates, {k: n.params.weights.clone() for k, n in agent.networks.items()}, agent))
+    (ua, wa, a), (ub, wb, _) = outs
+    assert ua == ub
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]) and torch.isfinite(wa[k]).all()
+    steps = np.arange(7, 31)                                            # global step index of the 24 training steps
+    if name == "td3":
+        expect = [sum(L for L in lens if s % L == 0) for s in steps]    # every finishing env trains its length
+        assert ua == expect
+        done_by_30 = sum(30 // L for L in lens)
+        assert a.memory.num_complete_episodes() == done_by_30
+        assert a.memory.num_transitions() == sum((30 // L) * L for L in lens)
+    st = a.episode_statistics()
+    assert st["episodes"] == sum(30 // L for L in lens)
+    assert abs(st["mean_length"] - sum((30 // L) * L for L in lens) / st["episodes"]) < 1e-12
