@@ -254,7 +254,7 @@ class VectorOffPolicyAgent(GraphRunner):
             self.ended_episode_lengths = self._episode_steps[ended].copy()    # one entry per finished env
             self.last_episode_steps = int(self.ended_episode_lengths[-1])
             self._episode_steps[ended] = 0
-            if record:
+            if self.phase == RunPhase.TRAIN:       # heat-up episode ends open no training phase later
                 self._unconsumed_episode_lengths.extend(int(x) for x in self.ended_episode_lengths)
             self.handle_episode_ended()
         if self.phase != RunPhase.TEST:                                        # agent.py:832-834

@@ -46,7 +46,8 @@ def agent_state(agent):
     # uniforms_all: the exploration draws of the running PPO phase (made at its first step)
     st["agent"]["tensors"] = _tensors_of(agent, ["ep_return", "ep_len", "ep_acc", "uniforms_all"])
     st["env"] = {"tensors": _tensors_of(agent.env, ["obs", "episode", "step_in_episode"]),
-                 "total_steps": agent.env.total_steps}
+                 "total_steps": agent.env.total_steps,
+                 "host": {k: getattr(agent.env, k).copy() for k in ("t_host", "dones_host") if hasattr(agent.env, k)}}
     pol = getattr(agent, "exploration_policy", None)
     if pol is not None:
         st["exploration"] = pickle.dumps({k: v for k, v in pol.__dict__.items()
@@ -89,6 +90,8 @@ def load_agent_state(agent, st):
     for k, t in st["env"]["tensors"].items():
         getattr(agent.env, k).copy_(t)
     agent.env.total_steps = st["env"]["total_steps"]
+    for k, v in st["env"].get("host", {}).items():
+        getattr(agent.env, k)[...] = v
     if "exploration" in st and getattr(agent, "exploration_policy", None) is not None:
         agent.exploration_policy.__dict__.update(pickle.loads(st["exploration"]))
     if "filter" in st and getattr(agent, "norm", None) is not None:

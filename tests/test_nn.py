@@ -200,6 +200,8 @@ def test_hip_dqn_net_vs_oracle(rlx, dev, obs_shape, B, huber, ddqn):
     rng = np.random.RandomState(11)
     A = 4
     net = DQNNet(dev, obs_shape, A, replace_mse_with_huber_loss=huber, seed=1)
+    net._fused = None        # this test reads the materialised gradients: the layer-by-layer path (the one-launch
+    #                          update never writes them; tests/test_mlp_fused.py compares the two paths)
     o = DQNOracle(net.params.named_arrays(), obs_shape, A, huber=huber)
     image = len(obs_shape) == 3
     gen = (lambda: rng.randint(0, 256, size=(B,) + obs_shape).astype(np.uint8)) if image else \
