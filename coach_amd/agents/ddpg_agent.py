@@ -89,6 +89,7 @@ class DDPGAgentParameters(object):                       # ddpg_agent.py:114-122
 
 class DDPGAgent(VectorOffPolicyAgent):
     continuous = True
+    SIGNAL_NAMES = VectorOffPolicyAgent.SIGNAL_NAMES + ["Q", "TD targets", "actions"]   # ddpg_agent.py:129-131
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         super().__init__(agent_parameters, environment, device, dist, use_graphs)

@@ -68,6 +68,7 @@ class DQNAgentParameters(object):                        # dqn_agent.py:56-66
 
 class DQNAgent(VectorOffPolicyAgent):
     double_dqn = False
+    SIGNAL_NAMES = VectorOffPolicyAgent.SIGNAL_NAMES + ["Q"]            # value_optimization_agent.py:36
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         super().__init__(agent_parameters, environment, device, dist, use_graphs)

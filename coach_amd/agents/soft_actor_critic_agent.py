@@ -101,6 +101,9 @@ class SoftActorCriticAgentParameters(object):            # :129-141
 
 
 class SoftActorCriticAgent(VectorOffPolicyAgent):
+    SIGNAL_NAMES = VectorOffPolicyAgent.SIGNAL_NAMES + [                  # soft_actor_critic_agent.py:151-162
+        "Policy_mu_avg", "Policy_logsig", "Policy_logp_sampled", "Policy_grads_sumabs", "Q1", "TD err1", "Q2",
+        "TD err2", "V_tgt_ns", "V_onl_ys", "actions"]
     continuous = True
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):

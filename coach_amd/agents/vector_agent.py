@@ -131,6 +131,9 @@ class AlgorithmParameters(object):                       # base_parameters.py:17
 
 class VectorOffPolicyAgent(GraphRunner):
     continuous = False
+    # signals every agent registers (agent.py:187-192), in registration order; subclasses append their own.
+    # 'Reward' / 'Shaped Reward' are per-step signals and have no episode columns.
+    SIGNAL_NAMES = ["Loss", "Learning Rate", "Grads (unclipped)", "Discounted Return"]
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         self.ap = agent_parameters
@@ -163,6 +166,9 @@ class VectorOffPolicyAgent(GraphRunner):
         self.ep_acc = torch.zeros(8, dtype=torch.float64, device=dev)
         self.lib.episode_stats_init(self.ep_return, self.ep_len, n, self.ep_acc, _rlx.current_stream())
         self.signals = {}
+        self.signal_stats = None         # DeviceSignals once enable_signal_statistics() is called (CSV logging)
+        self.last_return = torch.zeros(n, dtype=torch.float64, device=dev)     # return of each env's last episode
+        self._episode_log = []           # (env, length, pinned copy of last_return, event) per finished episode
         from ..staging import StagerCache
         self._stagers = StagerCache(self.device)
         self.debug_draws = None          # tests set these to lists to record every replay draw /
@@ -232,7 +238,7 @@ class VectorOffPolicyAgent(GraphRunner):
                                int(has_clip), lo, hi, s)
         if record:
             self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,
-                                        self.n_env, self.ep_acc, None, None, s)
+                                        self.n_env, self.ep_acc, self.last_return, None, s)
         self.env.total_steps += self.n_env
         # which envs finished: a host fact (the env front end's `dones_host`; lockstep envs without one end
         # together after L steps) — no device sync
@@ -256,6 +262,8 @@ class VectorOffPolicyAgent(GraphRunner):
             self._episode_steps[ended] = 0
             if self.phase == RunPhase.TRAIN:       # heat-up episode ends open no training phase later
                 self._unconsumed_episode_lengths.extend(int(x) for x in self.ended_episode_lengths)
+            if record and self.signal_stats is not None:
+                self._note_finished_episodes(ended)
             self.handle_episode_ended()
         if self.phase != RunPhase.TEST:                                        # agent.py:832-834
             self.total_steps_counter += self.n_env
@@ -263,6 +271,46 @@ class VectorOffPolicyAgent(GraphRunner):
 
     def _stored_game_over(self, game_over):
         return game_over
+
+    # ------------------------------------------------------------------- signals / episode log
+    def enable_signal_statistics(self):
+        """Collect what Agent.update_log writes per episode (agent.py:509-556): the statistics of every registered
+        signal and each finished episode's reward and length.  Off by default: it costs one small launch per update
+        and one device->host copy per logged episode."""
+        if self.signal_stats is None:
+            from ..signals import DeviceSignals
+            self.signal_stats = DeviceSignals(self.SIGNAL_NAMES, self.device)
+        return self.signal_stats
+
+    def _note_finished_episodes(self, ended):
+        """asynchronous copy of the finished envs' episode returns; read when the rows are written."""
+        host = torch.empty(self.n_env, dtype=torch.float64, pin_memory=True)
+        host.copy_(self.last_return, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        alg = self.ap.algorithm
+        for e, length in zip(ended.tolist(), self.ended_episode_lengths.tolist()):
+            self._episode_log.append((int(e), int(length), host, ev))
+            # handle_episode_ended: every transition's n-step discounted return is a 'Discounted Return' sample
+            dr = self.memory.episode_discounted_returns(int(e), int(length), alg.discount, getattr(alg, "n_step", -1))
+            self.signal_stats.accumulate({"Discounted Return": dr})
+
+    def pop_finished_episodes(self):
+        """[(env, length, total shaped reward)] of the episodes finished since the last call."""
+        out = []
+        for e, length, host, ev in self._episode_log:
+            ev.synchronize()
+            out.append((e, length, float(host[e])))
+        self._episode_log = []
+        return out
+
+    def _accumulate_signals(self):
+        st = self.signal_stats
+        st.accumulate({k: (v if v.dim() else v.view(1)) for k, v in self.signals.items()
+                       if isinstance(v, torch.Tensor)})
+        lr = getattr(next(iter(self.ap.network_wrappers.values())), "learning_rate", None)
+        if lr is not None:
+            st.add_host_sample("Learning Rate", lr)                  # curr_learning_rate.add_sample (agent.py:753-754)
 
     def handle_episode_ended(self):
         pass
@@ -334,12 +382,15 @@ class VectorOffPolicyAgent(GraphRunner):
                     self.debug_draws.append(batch.info("idx").cpu().numpy().copy()
                                             if "idx" in batch._info else np.asarray(d).copy())
                 loss = self.learn_from_batch(batch)
+                if self.signal_stats is not None:
+                    self._accumulate_signals()
                 if self.debug_losses is not None:
                     self.debug_losses.append(float(loss.sum().item()))
                 losses.append(loss)
                 if any(n.target is not None for n in self.networks.values()) and \
                         self._should_update_online_weights_to_target():
                     self.update_target_networks(alg.rate_for_copying_weights_to_target)
+                    self._target_updated_since_log = True      # 'Update Target Network' column (agent.py:760)
         # the loss of the last update of the phase(s) (a device scalar; no per-update host sync or add)
         return losses[-1] if losses else None
 

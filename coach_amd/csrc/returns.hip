@@ -234,6 +234,65 @@ episode_stats_kernel(const float *__restrict__ reward, const unsigned char *__re
 }  // namespace
 
 namespace {
+// Signal statistics (utils.py:162-212 `Signal`: a list of samples per episode, get_mean / get_stdev / get_max /
+// get_min at log time, agent.py:548-552).  Device form: one fp64 record per signal,
+//   {count, sum, sum of squares, max, min},
+// that every update folds its new samples into; the host reads the few records once per logged episode.
+// One workgroup per launch, up to 8 sources, each reduced in a fixed order (reproducible).
+struct SignalSources {
+    const void *ptr[8];
+    int n[8];
+    int is_f64[8];
+    int row[8];
+    int count;
+};
+
+__global__ void __launch_bounds__(256) signals_accumulate_kernel(SignalSources src, double *__restrict__ table) {
+    __shared__ double red[3][256];
+    __shared__ double ext[2][256];
+    const int tid = threadIdx.x;
+    for (int s = 0; s < src.count; ++s) {
+        double sum = 0.0, sq = 0.0, mx = -__builtin_huge_val(), mn = __builtin_huge_val();
+        for (int i = tid; i < src.n[s]; i += 256) {
+            const double v = src.is_f64[s] ? static_cast<const double *>(src.ptr[s])[i]
+                                           : (double)static_cast<const float *>(src.ptr[s])[i];
+            sum += v;
+            sq += v * v;
+            mx = v > mx ? v : mx;
+            mn = v < mn ? v : mn;
+        }
+        red[0][tid] = sum; red[1][tid] = sq; ext[0][tid] = mx; ext[1][tid] = mn;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) {
+            if (tid < d) {
+                red[0][tid] += red[0][tid + d];
+                red[1][tid] += red[1][tid + d];
+                ext[0][tid] = ext[0][tid + d] > ext[0][tid] ? ext[0][tid + d] : ext[0][tid];
+                ext[1][tid] = ext[1][tid + d] < ext[1][tid] ? ext[1][tid + d] : ext[1][tid];
+            }
+            __syncthreads();
+        }
+        if (tid == 0 && src.n[s] > 0) {
+            double *r = table + 5 * src.row[s];
+            r[0] += (double)src.n[s];
+            r[1] += red[0][0];
+            r[2] += red[1][0];
+            r[3] = ext[0][0] > r[3] ? ext[0][0] : r[3];
+            r[4] = ext[1][0] < r[4] ? ext[1][0] : r[4];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void signals_reset_kernel(double *table, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    double *r = table + 5 * i;
+    r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = -__builtin_huge_val(); r[4] = __builtin_huge_val();
+}
+}  // namespace
+
+namespace {
 // Episode.update_discounted_rewards (core_types.py:771-801) for ONE completed episode whose T transitions sit in a
 // time-major ring (row of step k = ((s0 + k) mod ring_steps) * n_env + env).  The reference adds
 // current_discount * rewards[i:] for i = 1 .. n-1 onto a float64 copy of the rewards, current_discount growing by
@@ -241,8 +300,8 @@ namespace {
 // order and the same products here, so the column is bit-identical to the reference's n_step_discounted_rewards.
 // (-ffp-contract=off: no fused multiply-add.)  O(T * n) like the reference; one thread per transition.
 __global__ void episode_nstep_returns_kernel(const float *__restrict__ rewards, double *__restrict__ out,
-                                             long long s0, int T, int env, int n_env, long long ring_steps,
-                                             double discount, int n_step) {
+                                             double *__restrict__ compact, long long s0, int T, int env,
+                                             int n_env, long long ring_steps, double discount, int n_step) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const int n = (n_step == -1 || n_step > T) ? T : n_step;
@@ -253,7 +312,8 @@ __global__ void episode_nstep_returns_kernel(const float *__restrict__ rewards, 
         if (t + j < T) acc += g * (double)rewards[row(t + j)];
         g *= discount;
     }
-    out[row(t)] = acc;
+    if (out) out[row(t)] = acc;
+    if (compact) compact[t] = acc;
 }
 }  // namespace
 
@@ -284,15 +344,43 @@ int rlx_discounted_returns(const float *rewards, const unsigned char *game_overs
     return RLX_OK;
 }
 
-int rlx_episode_nstep_returns(const float *rewards, double *out, long long first_step, int length, int env,
-                              int n_env, long long ring_steps, double discount, int n_step, void *stream) {
-    RLX_REQUIRE(rewards && out, "rlx_episode_nstep_returns: null pointer");
+int rlx_signals_reset(double *table, int n_signals, void *stream) {
+    RLX_REQUIRE(table && n_signals > 0, "rlx_signals_reset: bad arguments");
+    signals_reset_kernel<<<(n_signals + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(table, n_signals);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_signals_accumulate(const rlx_signal_source *sources_host, int n_sources, double *table, int n_signals,
+                           void *stream) {
+    RLX_REQUIRE(sources_host && table && n_sources > 0 && n_sources <= 8 && n_signals > 0,
+                "rlx_signals_accumulate: 1..8 sources, got %d", n_sources);
+    SignalSources src;
+    src.count = n_sources;
+    for (int i = 0; i < n_sources; ++i) {
+        RLX_REQUIRE(sources_host[i].values && sources_host[i].n >= 0 && sources_host[i].signal >= 0 &&
+                        sources_host[i].signal < n_signals,
+                    "rlx_signals_accumulate: source %d is invalid", i);
+        src.ptr[i] = sources_host[i].values;
+        src.n[i] = sources_host[i].n;
+        src.is_f64[i] = sources_host[i].is_f64;
+        src.row[i] = sources_host[i].signal;
+    }
+    signals_accumulate_kernel<<<1, 256, 0, rlx::as_stream(stream)>>>(src, table);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_episode_nstep_returns(const float *rewards, double *out, double *compact_out, long long first_step,
+                              int length, int env, int n_env, long long ring_steps, double discount, int n_step,
+                              void *stream) {
+    RLX_REQUIRE(rewards && (out || compact_out), "rlx_episode_nstep_returns: null pointer");
     RLX_REQUIRE(length > 0 && n_env > 0 && env >= 0 && env < n_env && ring_steps >= length && first_step >= 0,
                 "rlx_episode_nstep_returns: bad episode geometry (length=%d ring_steps=%lld)", length, ring_steps);
     RLX_REQUIRE(n_step == -1 || n_step >= 1,
                 "n-step should be an integer with value >= 1, or set to -1 for always setting to episode length.");
     episode_nstep_returns_kernel<<<(length + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
-        rewards, out, first_step, length, env, n_env, ring_steps, discount, n_step);
+        rewards, out, compact_out, first_step, length, env, n_env, ring_steps, discount, n_step);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -28,20 +28,32 @@ def dynamic_import(path):
 
 
 class CsvLogger(object):
-    """The columns of the reference's experiment CSV that the hot path produces (logger.py:291-335)."""
-    COLUMNS = ["Episode #", "Training Iter", "In Heatup", "ER #Transitions", "Total steps", "Epsilon",
-               "Training Reward", "Evaluation Reward", "Episode Length", "Update Target Network",
-               "Loss/Mean", "Wall-Clock Time"]
+    """The experiment CSV of the reference (logger.py:189-335): index column 'Episode #', the fixed columns
+    Agent.update_log creates (agent.py:520-546, in that order) and four statistics columns per registered signal
+    (:548-552).  tests/golden/csv_columns.json holds the column lists the real reference agents produce."""
+    FIXED = ["Training Iter", "Epoch", "In Heatup", "ER #Transitions", "ER #Episodes", "Episode Length",
+             "Total steps", "Epsilon", "Shaped Training Reward", "Training Reward", "Update Target Network",
+             "Wall-Clock Time", "Evaluation Reward", "Shaped Evaluation Reward", "Success Rate",
+             "Inverse Propensity Score", "Direct Method Reward", "Doubly Robust", "Weighted Importance Sampling",
+             "Sequential Doubly Robust"]
+    INDEX = "Episode #"
 
-    def __init__(self, path=None):
+    def __init__(self, path=None, signal_names=()):
         self.path, self.rows = path, []
-        self._t0 = time.time()
-        if path:
-            with open(path, "w", newline="") as f:
+        self._t0 = None
+        self.set_signals(signal_names)
+
+    def set_signals(self, signal_names):
+        self.COLUMNS = [self.INDEX] + self.FIXED + ["%s/%s" % (n, s) for n in signal_names
+                                                    for s in ("Mean", "Stdev", "Max", "Min")]
+        if self.path:
+            with open(self.path, "w", newline="") as f:
                 csv.writer(f).writerow(self.COLUMNS)
 
     def write(self, **kw):
-        kw["Wall-Clock Time"] = time.time() - self._t0
+        if self._t0 is None:
+            self._t0 = time.time()                       # the wall clock starts with the first row (logger.py:240-246)
+        kw.setdefault("Wall-Clock Time", time.time() - self._t0)
         row = [kw.get(c, "") for c in self.COLUMNS]
         self.rows.append(dict(zip(self.COLUMNS, row)))
         if self.path:
@@ -78,6 +90,9 @@ class BasicRLGraphManager(object):
         self.environment = dynamic_import(self.env_params.path)(self.env_params, self.device, rank=rank)
         self.agent = dynamic_import(self.agent_params.path)(self.agent_params, self.environment, self.device,
                                                             dist=self.dist)
+        if self.visualization_parameters.dump_csv and hasattr(self.agent, "enable_signal_statistics"):
+            self.agent.enable_signal_statistics()
+            self.logger.set_signals(self.agent.SIGNAL_NAMES)
         return self
 
     def verify_graph_was_created(self):
@@ -98,26 +113,48 @@ class BasicRLGraphManager(object):
         return n
 
     def _log_finished_episodes(self):
-        st = None
-        done_groups = 0
-        L = getattr(self.agent, "L", None)
-        steps = self.total_steps_counters[RunPhase.HEATUP] + self.total_steps_counters[RunPhase.TRAIN]
-        if L:
-            done_groups = steps // (L * self.agent.n_env)
-        if done_groups > self._episodes_logged and self.phase != RunPhase.TEST:
-            st = self.agent.episode_statistics()
-            self._episodes_logged = done_groups
-            sig = self.agent.signals
+        """Agent.update_log for every episode that finished on the last vector step (agent.py:509-556): one CSV row
+        per episode — each env's episode is one 'Episode #' — with the episode's length and reward and the statistics
+        of the signals accumulated since the previous row."""
+        agent = self.agent
+        if self.phase == RunPhase.TEST or not getattr(agent, "_episode_just_ended", False):
+            return
+        if getattr(agent, "signal_stats", None) is None:            # agents without the per-episode log (PPO)
+            st = agent.episode_statistics()
+            self._episodes_logged = st["episodes"]
+            sig = agent.signals
             loss = next((float(sig[k]) for k in ("Loss", "Surrogate loss") if k in sig), "")
-            eps = ""
-            if hasattr(self.agent, "exploration_policy") and hasattr(self.agent.exploration_policy, "epsilon"):
-                eps = self.agent.exploration_policy.epsilon()
-            self.logger.write(**{"Episode #": st["episodes"], "Training Iter": self.agent.training_iteration,
+            self.logger.write(**{"Episode #": st["episodes"], "Training Iter": agent.training_iteration, "Epoch": 0,
                                  "In Heatup": int(self.phase == RunPhase.HEATUP),
-                                 "ER #Transitions": self.agent.memory.num_transitions(),
-                                 "Total steps": self.agent.total_steps_counter, "Epsilon": eps,
+                                 "ER #Transitions": agent.memory.num_transitions(),
+                                 "Total steps": agent.total_steps_counter,
                                  "Training Reward": st["mean_return"], "Episode Length": st["mean_length"],
                                  "Loss/Mean": loss})
+            return
+        finished = agent.pop_finished_episodes()
+        if not finished:
+            return
+        stats = agent.signal_stats.flush()
+        eps = ""
+        pol = getattr(agent, "exploration_policy", None)
+        if pol is not None and hasattr(pol, "epsilon"):
+            eps = pol.epsilon()
+        elif pol is not None and hasattr(pol, "noise_schedule"):
+            eps = pol.noise_schedule.current_value
+        train = self.phase == RunPhase.TRAIN
+        for env, length, ret in finished:
+            self._episodes_logged += 1
+            row = {"Episode #": self._episodes_logged, "Training Iter": agent.training_iteration, "Epoch": 0,
+                   "In Heatup": int(self.phase == RunPhase.HEATUP),
+                   "ER #Transitions": agent.memory.num_transitions(), "ER #Episodes": agent.memory.length(),
+                   "Episode Length": length, "Total steps": agent.total_steps_counter, "Epsilon": eps,
+                   "Shaped Training Reward": ret if train else float("nan"),
+                   "Training Reward": ret if train else float("nan"),
+                   "Update Target Network": int(getattr(agent, "_target_updated_since_log", False))}
+            row.update(stats)
+            stats = {k: "" for k in stats}                   # the statistics belong to the first row of the step
+            self.logger.write(**row)
+        agent._target_updated_since_log = False
 
     def heatup(self, steps):                                                   # :400-424
         self.verify_graph_was_created()
@@ -148,8 +185,8 @@ class BasicRLGraphManager(object):
         reward = self.agent.evaluate_episodes(steps.num_steps)
         self.total_steps_counters[RunPhase.TEST] += self.environment.total_steps - before
         self.logger.write(**{"Episode #": self._episodes_logged, "Training Iter": self.agent.training_iteration,
-                             "In Heatup": 0, "Total steps": self.agent.total_steps_counter,
-                             "Evaluation Reward": reward})
+                             "Epoch": 0, "In Heatup": 0, "Total steps": self.agent.total_steps_counter,
+                             "Evaluation Reward": reward, "Shaped Evaluation Reward": reward})
         return reward
 
     def improve(self):                                                         # :525-556

@@ -157,7 +157,7 @@ class EpisodicExperienceReplay(ExperienceReplay):
         self._order_len += T
         self._episodes.append(T)
         self._episode_first_step.append(s0)
-        self.lib.episode_nstep_returns(self.reward, self.n_step_discounted_rewards, s0, T, e, self.n_env,
+        self.lib.episode_nstep_returns(self.reward, self.n_step_discounted_rewards, None, s0, T, e, self.n_env,
                                        self._ring_steps, self.discount, self.n_step, _rlx.current_stream())
         # _enforce_max_length: whole oldest episodes leave (:300-317)
         if self.max_episodes is not None:
@@ -214,6 +214,9 @@ class EpisodicExperienceReplay(ExperienceReplay):
                            b["action"], b["reward"], b["game_over"],
                            info={"logical_idx": drawn, "states_pair": b["states_pair"],
                                  "n_step_discounted_rewards": b["n_step_discounted_rewards"]})
+
+    def _steps_written_now(self):
+        return self._gstep
 
     def episode_lengths(self):
         return list(self._episodes)

@@ -111,6 +111,7 @@ class ExperienceReplay(Memory):
         self.count = 0           # len(self.transitions) of the reference (the VISIBLE transitions)
         self.pending = 0         # rows written at [cursor - pending, cursor) that are not visible yet
         self.committed_total = 0  # transitions ever made visible (PER: leaf = this % capacity)
+        self._steps_written = 0   # vector steps written (cursor = steps_written * n_env mod rows)
         self._evaluating = False
         self._eval = None
         self._batches = {}
@@ -141,10 +142,27 @@ class ExperienceReplay(Memory):
         self.count = 0
         self.pending = 0
         self.committed_total = 0
+        self._steps_written = 0
 
     def head(self):
         """physical row of logical index 0 (the oldest VISIBLE transition)."""
         return (self.cursor - self.pending - self.count) % self.rows
+
+    def _steps_written_now(self):
+        """vector steps whose rows were written into the time-major ring so far (modulo nothing)."""
+        return self._steps_written
+
+    def episode_discounted_returns(self, env, length, discount, n_step=-1):
+        """Episode.update_discounted_rewards (core_types.py:771-801) over env's `length` most recently stored
+        transitions — the samples of the 'Discounted Return' signal (agent.py:565-566) — as a device fp64 vector."""
+        if length > self.rows // self.n_env:
+            raise ValueError("the episode is longer than the replay ring")
+        if getattr(self, "_dr_scratch", None) is None or self._dr_scratch.numel() < length:
+            self._dr_scratch = torch.empty(max(length, 1024), dtype=torch.float64, device=self.device)
+        self.lib.episode_nstep_returns(self.reward, None, self._dr_scratch, self._steps_written_now() - length, length,
+                                       env, self.n_env, self.rows // self.n_env, float(discount), int(n_step),
+                                       _rlx.current_stream())
+        return self._dr_scratch[:length]
 
     # ------------------------------------------------------------- visibility (see module doc)
     def commit_pending(self):
@@ -159,6 +177,7 @@ class ExperienceReplay(Memory):
         """Reset before the held response was observed: its transitions are never stored."""
         if self.pending:
             self.cursor = (self.cursor - self.pending) % self.rows
+            self._steps_written -= self.pending // self.n_env
             self.pending = 0
 
     def _became_visible(self, n):
@@ -265,6 +284,7 @@ class ExperienceReplay(Memory):
                                  self.obs_dim * 4, s)
         if record:
             self.cursor = (self.cursor + self.n_env) % self.rows
+            self._steps_written += 1
             if defer:
                 self.pending = self.n_env
             else:

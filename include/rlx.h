@@ -133,11 +133,25 @@ int rlx_gae(const float *rewards, const float *values, const unsigned char *game
 int rlx_discounted_returns(const float *rewards, const unsigned char *game_overs, int n_seq,
                            long long seq_len, double discount, double *returns64,
                            float *returns32, void *stream);          /* core_types.py:771-801 (n_step = -1) */
-int rlx_episode_nstep_returns(const float *rewards, double *out, long long first_step, int length, int env,
-                              int n_env, long long ring_steps, double discount, int n_step,
+/* Signal statistics (utils.py:162-212, agent.py:548-552): table = fp64 [n_signals][5] = {count, sum, sum of
+ * squares, max, min}; accumulate folds up to 8 device arrays (fp32 or fp64) into their signals' records in ONE
+ * launch; the host reads the table when it logs an episode and resets it. */
+typedef struct rlx_signal_source {
+    const void *values;   /* device array */
+    int n;                /* samples */
+    int is_f64;           /* element type: 0 = float, 1 = double */
+    int signal;           /* table row */
+} rlx_signal_source;
+int rlx_signals_reset(double *table, int n_signals, void *stream);
+int rlx_signals_accumulate(const rlx_signal_source *sources_host, int n_sources, double *table, int n_signals,
+                           void *stream);
+int rlx_episode_nstep_returns(const float *rewards, double *out, double *compact_out, long long first_step,
+                              int length, int env, int n_env, long long ring_steps, double discount, int n_step,
                               void *stream);   /* core_types.py:771-801 for any n_step, ONE completed episode stored
                                                   time-major (row = ((first_step + k) mod ring_steps) * n_env + env);
-                                                  fp64, the reference's summation order (bit-identical column) */
+                                                  fp64, the reference's summation order (bit-identical).  out: a
+                                                  column indexed like `rewards` (or NULL); compact_out: [length]
+                                                  (or NULL) — the 'Discounted Return' signal's samples */
 int rlx_standardize(const double *x, long long n, float *out32, double *out64, double *mean_std,
                     void *stream);                                   /* clipped_ppo_agent.py:201 (no epsilon) */
 int rlx_episode_stats_init(double *ep_return, int *ep_len, int n_env, double *acc, void *stream);

@@ -1101,7 +1101,77 @@ def gen_ppo_loop():
     _save("ppo_loop", **out)
 
 
-GROUPS = {"per": gen_per, "er": gen_er, "episodic": gen_episodic, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
+def gen_csv_columns():
+    """What Agent.update_log (agent.py:509-556) writes: the CSV column list of the REAL reference DQNAgent (own
+    __init__, registered signals) after one update_log call, the values of the statistics columns for known
+    samples, and `Signal` (utils.py:162-212) statistics of random sample streams (scalars and arrays mixed)."""
+    import copy
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle.agents import DQNOracle
+    from rl_coach.agents.dqn_agent import DQNAgent, DQNAgentParameters
+    from rl_coach.base_parameters import TaskParameters
+    from rl_coach.core_types import RunPhase
+    from rl_coach.filters.filter import NoInputFilter, NoOutputFilter
+    from rl_coach.spaces import DiscreteActionSpace, RewardSpace, SpacesDefinition, StateSpace, VectorObservationSpace
+    from rl_coach.utils import Signal
+    D, A = 4, 3
+    rng = np.random.RandomState(0)
+    arrays = {}
+    for name, (i, o) in {"main/embedder/dense0": (D, 16), "main/middleware/dense0": (16, 12), "main/q_head/dense": (12, A)}.items():
+        arrays[name + "/kernel"] = [rng.uniform(-.5, .5, (i, o)).astype(np.float32)]
+        arrays[name + "/bias"] = [np.zeros(o, np.float32)]
+    ap = DQNAgentParameters()
+    ap.task_parameters = TaskParameters()
+    ap.name = "agent"
+    ap.visualization.dump_csv = False
+    ap.is_a_highest_level_agent = False
+    ap.input_filter, ap.output_filter, ap.pre_network_filter = NoInputFilter(), NoOutputFilter(), NoInputFilter()
+
+    class Agent(DQNAgent):
+        def create_networks(self):
+            net = DQNOracle(copy.deepcopy(arrays), (D,), A, lr=1e-3, huber=False)
+            w = OB.DQNWrapper(net)
+            w.has_target = True
+            for n in (w.online_network, w.target_network):
+                n.reset_internal_memory = lambda: None
+            return {'main': w}
+    agent = Agent(ap)
+    agent.set_environment_parameters(SpacesDefinition(state=StateSpace({'observation': VectorObservationSpace(D)}), goal=None,
+                                                      action=DiscreteActionSpace(A), reward=RewardSpace(1)))
+    agent.get_current_time = lambda: 1
+    agent.agent_logger.dump_output_csv = lambda *a, **k: None
+    agent.reset_internal_state()
+    agent.phase = RunPhase.TRAIN
+    for v in (0.5, 0.25, 2.0):
+        agent.loss.add_sample(v)
+    agent.q_values.add_sample(np.array([1.0, -1.0, 3.0]))
+    agent.update_log()
+    data = agent.agent_logger.data
+    out = {"dqn_index": agent.agent_logger.index_name if hasattr(agent.agent_logger, "index_name") else "Episode #",
+           "dqn_columns": list(data.columns),
+           "dqn_row": {k: (v if isinstance(v, str) else float(v)) for k, v in data.iloc[0].to_dict().items()},
+           "signal_cases": []}
+    for case in range(4):
+        s = Signal("x")
+        samples = []
+        for _ in range(rng.randint(1, 9)):
+            if rng.rand() < 0.5:
+                v = rng.randn(rng.randint(1, 40)).astype(np.float32 if case % 2 else np.float64)
+                s.add_sample(v) if case >= 2 else [s.add_sample(float(x)) for x in v]
+            else:
+                v = np.array([rng.randn()])
+                s.add_sample(v) if case >= 2 else s.add_sample(float(v[0]))
+            samples.append([float(x) for x in v])
+        out["signal_cases"].append({"samples": samples, "f32": bool(case % 2), "mean": float(s.get_mean()),
+                                    "stdev": float(s.get_stdev()), "max": float(s.get_max()), "min": float(s.get_min())})
+    with open(os.path.join(HERE, "csv_columns.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote csv_columns.json")
+
+
+GROUPS = {"csv_columns": gen_csv_columns, "per": gen_per, "er": gen_er, "episodic": gen_episodic, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
           "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop}
 
 if __name__ == "__main__":
