@@ -134,6 +134,7 @@ class VectorOffPolicyAgent(GraphRunner):
     # signals every agent registers (agent.py:187-192), in registration order; subclasses append their own.
     # 'Reward' / 'Shaped Reward' are per-step signals and have no episode columns.
     SIGNAL_NAMES = ["Loss", "Learning Rate", "Grads (unclipped)", "Discounted Return"]
+    signal_stats = None              # DeviceSignals once enable_signal_statistics() is called (CSV logging)
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         self.ap = agent_parameters
@@ -166,7 +167,6 @@ class VectorOffPolicyAgent(GraphRunner):
         self.ep_acc = torch.zeros(8, dtype=torch.float64, device=dev)
         self.lib.episode_stats_init(self.ep_return, self.ep_len, n, self.ep_acc, _rlx.current_stream())
         self.signals = {}
-        self.signal_stats = None         # DeviceSignals once enable_signal_statistics() is called (CSV logging)
         self.last_return = torch.zeros(n, dtype=torch.float64, device=dev)     # return of each env's last episode
         self._episode_log = []           # (env, length, pinned copy of last_return, event) per finished episode
         from ..staging import StagerCache

@@ -33,13 +33,16 @@ def test_device_signal_statistics_match_the_reference_signal_class(dev):
         batch = {}
         for i, c in enumerate(cases):
             if r < len(c["samples"]):
-                dt = torch.float32 if c["f32"] else torch.float64
-                batch["s%d" % i] = torch.tensor(c["samples"][r], dtype=dt, device=dev)
+                v = np.array(c["samples"][r])
+                as32 = bool(np.all(v.astype(np.float32).astype(np.float64) == v))     # an fp32 sample array
+                batch["s%d" % i] = torch.tensor(v, dtype=torch.float32 if as32 else torch.float64, device=dev)
         sig.accumulate(batch)
     out = sig.flush()
     for i, c in enumerate(cases):
-        np.testing.assert_allclose(out["s%d/Mean" % i], c["mean"], rtol=1e-12, atol=1e-15)
-        np.testing.assert_allclose(out["s%d/Stdev" % i], c["stdev"], rtol=1e-9, atol=1e-12)
+        # np.mean / np.std of float32 samples accumulate in float32 (pairwise); the device records are fp64
+        rt = 2e-6 if c["f32"] else 1e-12
+        np.testing.assert_allclose(out["s%d/Mean" % i], c["mean"], rtol=rt, atol=1e-7 if c["f32"] else 1e-15)
+        np.testing.assert_allclose(out["s%d/Stdev" % i], c["stdev"], rtol=max(rt, 1e-9), atol=1e-12)
         assert out["s%d/Max" % i] == c["max"] and out["s%d/Min" % i] == c["min"]
     assert [out["never fed/" + s] for s in ("Mean", "Stdev", "Max", "Min")] == ["", "", "", ""]   # Signal.get_* on no samples
     again = sig.flush()                                       # flushed records are empty again
@@ -101,5 +104,7 @@ def test_graph_manager_writes_one_reference_style_row_per_episode(dev, tmp_path)
     np.testing.assert_allclose(float(first["Discounted Return/Mean"]), dr.mean(), rtol=1e-9)
     np.testing.assert_allclose(float(first["Discounted Return/Max"]), dr.max(), rtol=1e-12)
     trained = [r for r in table if not int(r["In Heatup"])]
-    assert trained and all(r["Loss/Mean"] != "" for r in trained if r["Discounted Return/Mean"] != "")
-    assert all(float(r["Learning Rate/Mean"]) == 0.00025 for r in trained if r["Learning Rate/Mean"] != "")
+    # (the first TRAIN-phase row is written before the first update: train() follows act())
+    with_stats = [r for r in trained if r["Discounted Return/Mean"] != ""]
+    assert with_stats and all(r["Loss/Mean"] != "" for r in with_stats[1:])
+    assert all(abs(float(r["Learning Rate/Mean"]) - 0.00025) < 1e-15 for r in trained if r["Learning Rate/Mean"] != "")
