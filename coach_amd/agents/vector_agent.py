@@ -191,7 +191,8 @@ class VectorOffPolicyAgent(GraphRunner):
             EpisodicExperienceReplay, EpisodicExperienceReplayParameters)
         ep = self.env.p
         kw = dict(device=self.device, n_env=self.n_env, observation_shape=ep.observation_shape,
-                  stack=self.stack, action_dim=action_dim, min_episode_length=self.L)
+                  stack=self.stack, action_dim=action_dim,
+                  min_episode_length=getattr(ep, "min_episode_length", self.L))
         if isinstance(mp, PrioritizedExperienceReplayParameters):
             return PrioritizedExperienceReplay(mp.max_size, mp.alpha, mp.beta, mp.epsilon,
                                                mp.allow_duplicates_in_batch_sampling,

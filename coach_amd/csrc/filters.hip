@@ -174,6 +174,38 @@ __global__ void resize_bilinear_u8_kernel(const unsigned char *__restrict__ in,
 
 }  // namespace
 
+namespace {
+// MaxOverFramesAndFrameskipEnvWrapper.step's `np.max(self.observations_stack, axis=0)`
+// (environments/gym_environment.py:148-175): element-wise maximum of the K newest raw frames of every env.
+// in: u8 [n_env][K][frame_bytes] (the host repeats a frame when an episode ended before K frames were
+// collected: max with a duplicate changes nothing), out: u8 [n_env][frame_bytes].  HBM-bound, 16-byte accesses.
+__device__ __forceinline__ uint32_t max_u8x4(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int s = 0; s < 32; s += 8) {
+        const uint32_t x = (a >> s) & 0xffu, y = (b >> s) & 0xffu;
+        r |= (x > y ? x : y) << s;
+    }
+    return r;
+}
+__global__ void max_over_frames_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__ out,
+                                       int K, long long frame_bytes) {
+    const int e = blockIdx.y;
+    const long long words = frame_bytes >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + (size_t)e * K * frame_bytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)e * frame_bytes);
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < words;
+         w += (long long)gridDim.x * blockDim.x) {
+        uint4 m = src[w];
+        for (int k = 1; k < K; ++k) {
+            const uint4 v = src[(size_t)k * words + w];
+            m.x = max_u8x4(m.x, v.x); m.y = max_u8x4(m.y, v.y); m.z = max_u8x4(m.z, v.z); m.w = max_u8x4(m.w, v.w);
+        }
+        dst[w] = m;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int rlx_rgb_to_y_u8(const unsigned char *rgb, unsigned char *out, long long n_pixels,
@@ -234,6 +266,18 @@ int rlx_running_stats_normalize(const void *x, int x_is_f64, long long n, int di
     else
         running_stats_normalize_kernel<float><<<rlx::grid_for(total, kBlock), kBlock, 0, s>>>(
             static_cast<const float *>(x), total, dim, mean, std, clip_low, clip_high, out32, out64);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_max_over_frames_u8(const unsigned char *frames, unsigned char *out, int n_env, int n_frames,
+                           long long frame_bytes, void *stream) {
+    RLX_REQUIRE(frames && out, "rlx_max_over_frames_u8: null pointer");
+    RLX_REQUIRE(n_env > 0 && n_frames >= 1 && frame_bytes > 0 && frame_bytes % 16 == 0 &&
+                    (((uintptr_t)frames | (uintptr_t)out) & 15) == 0,
+                "rlx_max_over_frames_u8: frames must be 16-byte aligned multiples of 16 bytes (got %lld)", frame_bytes);
+    dim3 grid(rlx::grid_for(frame_bytes / 16, 256, 64), n_env);
+    max_over_frames_kernel<<<grid, 256, 0, rlx::as_stream(stream)>>>(frames, out, n_frames, frame_bytes);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

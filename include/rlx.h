@@ -204,6 +204,9 @@ int rlx_rgb_to_y_u8(const unsigned char *rgb, unsigned char *out, long long n_pi
 int rlx_resize_bilinear_u8(const unsigned char *in, unsigned char *out, int n, int H, int W, int C,
                            int OH, int OW,
                            void *stream);   /* filters/observation/observation_rescale_to_size_filter.py:62-79 (skimage resize, order 1) */
+int rlx_max_over_frames_u8(const unsigned char *frames, unsigned char *out, int n_env, int n_frames,
+                           long long frame_bytes,
+                           void *stream);   /* environments/gym_environment.py:148-175: np.max over the newest frames of a frame-skip step */
 int rlx_running_stats_push(const void *samples, int samples_are_f64, long long n, int dim,
                            double *sum, double *sum_squares, double *count, double *mean,
                            double *std, double epsilon,
