@@ -236,10 +236,15 @@ def run_off_policy(args, device, dist):
         agent.act()
     agent.phase = RunPhase.TRAIN
 
+    fused_step = getattr(agent, "step_and_train", None)      # act() + train() as one record + one graph replay
+
     def step():
         for _ in range(vsteps):
-            agent.act()
-            agent.train()
+            if fused_step is not None:
+                fused_step()
+            else:
+                agent.act()
+                agent.train()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()

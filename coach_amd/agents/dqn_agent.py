@@ -15,7 +15,7 @@ import torch
 from .. import _rlx
 from ..architectures.head_parameters import DuelingQHeadParameters, QHeadParameters
 from ..architectures.scheme_views import SchemeViews
-from ..core_types import EnvironmentSteps, RunPhase
+from ..core_types import DeviceBatch, EnvironmentSteps, RunPhase
 from ..exploration_policies.e_greedy import EGreedy, EGreedyParameters
 from ..memories.non_episodic.experience_replay import ExperienceReplayParameters
 from ..memories.non_episodic.prioritized_experience_replay import PrioritizedExperienceReplay
@@ -136,6 +136,122 @@ class DQNAgent(VectorOffPolicyAgent):
         loss = self.networks["main"].loss
         self.signals = {"Loss": loss, "Grads (unclipped)": self.networks["main"].norm}
         return loss
+
+
+    # ------------------------------------------------------------- one staged record + one graph per env-step
+    # A 1-env, batch-32 CartPole step is ~16 launches of 2-35 us kernels: issued one by one the loop is HOST-bound
+    # (profiles/r02_c1_host_gpu_breakdown.txt: act() 113 us + train() 45 us of Python / launch overhead against
+    # ~90 us of GPU time).  Everything the host decides in a step — the epsilon-greedy draws, where the transition
+    # is stored, which transitions are sampled — is DATA: it is packed into one record, shipped with ONE async
+    # copy, and the whole step (Q forward, action selection, env step, reward filter, episode statistics, store,
+    # gather, update[s]) replays as ONE hipGraph that reads the record.  Call order, host RNG consumption and
+    # every kernel are those of act() + train(): the results are bit-identical (tests/test_dqn_agent.py).
+    def _step_graph_ok(self):
+        from ..memories.non_episodic.experience_replay import ExperienceReplay
+        return (self.use_graphs and self.dist is None and self.phase == RunPhase.TRAIN and not self.image
+                and type(self.memory) is ExperienceReplay and self.signal_stats is None
+                and self.debug_draws is None and self.debug_losses is None
+                and hasattr(self.env, "launch_step") and hasattr(self.env, "host_tick"))
+
+    def _step_record(self, k):
+        """device record of one step with k updates and its typed views (layout fixed per k)."""
+        rec = self._records.get(k) if hasattr(self, "_records") else None
+        if rec is None:
+            if not hasattr(self, "_records"):
+                self._records = {}
+            from ..staging import Stager
+            n, A, B = self.n_env, self.A, self.batch_size
+            off, lay = 0, {}
+            for name, count, dt, size in (("u", n, torch.float64, 8), ("tie", n * A, torch.float64, 8),
+                                          ("ra", n, torch.int32, 4), ("dst", n, torch.int32, 4),
+                                          ("rows", max(k, 1) * B, torch.int32, 4)):
+                off = (off + 15) // 16 * 16
+                lay[name] = (off, count, dt, size)
+                off += count * size
+            st = Stager(((off + 15) // 16 * 16,), torch.uint8, self.device, depth=32)
+            views = {name: st.dst[o:o + c * sz].view(dt) for name, (o, c, dt, sz) in lay.items()}
+            views["tie"] = views["tie"].view(n, A)
+            views["rows"] = views["rows"].view(max(k, 1), B)
+            rec = self._records[k] = dict(stager=st, lay=lay, views=views, host=np.zeros(st.dst.numel(), np.uint8))
+        return rec
+
+    def _step_body(self, k, start, with_act):
+        """the device work of one step: [act, env, store] then updates start .. start+k-1 of the record."""
+        v = self._step_record(self._rec_k)["views"]
+        mem, s, alg = self.memory, _rlx.current_stream(), self.ap.algorithm
+        if with_act:
+            self._q_forward(mem.current_states())
+            self.lib.egreedy(self._q_act, self.A, v["u"], v["ra"], v["tie"], 0.0, self.n_env, self.A, self.actions, s)
+            self.env.launch_step()
+            env = self.env
+            has_clip = alg.reward_clipping is not None
+            lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
+            self.lib.reward_filter(env.reward, self.filtered_reward, self.n_env, alg.reward_rescale, int(has_clip),
+                                   lo, hi, s)
+            self.lib.episode_stats_step(self.filtered_reward, env.game_over, self.ep_return, self.ep_len, self.n_env,
+                                        self.ep_acc, self.last_return, None, s)
+            mem.store_device(self.actions, self.filtered_reward, env.game_over, env.next_obs, env.reset_obs, v["dst"])
+        B = self.batch_size
+        b = mem._batch_buffers(B)
+        for j in range(start, start + k):
+            mem.gather_device(v["rows"][j], B, b)
+            batch = DeviceBatch(B, {"observation": b["state"]}, {"observation": b["next_state"]}, b["action"],
+                                b["reward"], b["game_over"], info={"states_pair": b["states_pair"]})
+            self._learn_device(batch, None)
+
+    def step_and_train(self):
+        """One TRAIN-phase vector step: act() then train(), as one record + one graph replay when the
+        configuration allows (uniform vector replay, one GPU), else exactly those two calls."""
+        if not self._step_graph_ok():
+            self.act()
+            return self.train()
+        mem, pol, n, B, alg = self.memory, self.exploration_policy, self.n_env, self.batch_size, self.ap.algorithm
+        # ---- host half of act(): same order of host RNG draws and bookkeeping
+        mem.commit_pending()
+        pol.phase = self.phase
+        eps, u, ra, tie = pol.draw()
+        self.env.host_tick()
+        dones_host, ended, any_ended, all_ended = self._episode_ends_host()
+        row0 = mem.reserve_step(defer=not all_ended)
+        self._after_step_host(dones_host, ended, any_ended, all_ended, True)
+        # ---- host half of train(): the draws of every update of every phase, target-copy positions
+        phases = self._training_phases_due()
+        draws, target_after = [], []
+        for _ in range(phases):
+            phase_draws = [mem.physical_rows(mem.draw(B)) for _ in range(self._training_steps_this_phase())]
+            for d in phase_draws:
+                self.training_iteration += 1
+                draws.append(d)
+                if self.networks["main"].target is not None and self._should_update_online_weights_to_target():
+                    target_after.append(len(draws))            # copy online -> target after this many updates
+        k = len(draws)
+        rec = self._step_record(k)
+        self._rec_k = k
+        host, lay = rec["host"], rec["lay"]
+
+        def put(name, arr, dt):
+            o, c, _, sz = lay[name]
+            host[o:o + c * sz] = np.ascontiguousarray(arr, dtype=dt).reshape(-1).view(np.uint8)
+        put("u", np.where(u < eps, -1.0, 2.0), np.float64)      # explore iff u < epsilon: decided here, epsilon = 0 there
+        put("tie", tie, np.float64)
+        put("ra", ra, np.int32)
+        put("dst", (row0 + np.arange(n)) % mem.rows, np.int32)
+        if k:
+            put("rows", np.stack(draws), np.int32)
+        rec["stager"].push(host)
+        # ---- device: one replay (split only where a target copy falls between two updates of the step)
+        cuts = [c for c in target_after if c < k]
+        start = 0
+        for i, end in enumerate(cuts + [k]):
+            with_act = i == 0
+            key = ("step", k, start, end - start, with_act)
+            self._run(key, lambda s_=start, e_=end, w_=with_act: self._step_body(e_ - s_, s_, w_))
+            if end in target_after:
+                self.update_target_networks(alg.rate_for_copying_weights_to_target)
+            start = end
+        loss = self.networks["main"].loss
+        self.signals = {"Loss": loss, "Grads (unclipped)": self.networks["main"].norm}
+        return loss if k else None
 
 
 class DDQNAgentParameters(DQNAgentParameters):           # ddqn_agent.py:24-34

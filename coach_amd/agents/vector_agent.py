@@ -240,21 +240,27 @@ class VectorOffPolicyAgent(GraphRunner):
         if record:
             self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,
                                         self.n_env, self.ep_acc, self.last_return, None, s)
-        self.env.total_steps += self.n_env
-        # which envs finished: a host fact (the env front end's `dones_host`; lockstep envs without one end
-        # together after L steps) — no device sync
-        self._episode_steps += 1
-        dones_host = getattr(self.env, "dones_host", None)
-        if dones_host is None:
-            dones_host = self._episode_steps >= self.L
-        ended = np.nonzero(dones_host)[0]
-        any_ended, all_ended = ended.size > 0, ended.size == self.n_env
+        dones_host, ended, any_ended, all_ended = self._episode_ends_host()
         stored = self._stored_game_over(game_over)
         # a terminal response is observed at once; the others at the start of the next step.  With several envs
         # the rows of a step become visible together, at once only when EVERY env's episode ended on it.
         self.memory.store(actions, self.filtered_reward, stored, next_obs, reset_obs, record=record,
                           dones=None if stored is game_over else game_over,
                           defer=not all_ended, episode_end=any_ended, dones_host=dones_host)
+        return self._after_step_host(dones_host, ended, any_ended, all_ended, record)
+
+    def _episode_ends_host(self):
+        """which envs finished on the step just taken: a host fact (the env front end's `dones_host`; lockstep envs
+        without one end together after L steps) — no device sync."""
+        self.env.total_steps += self.n_env
+        self._episode_steps += 1
+        dones_host = getattr(self.env, "dones_host", None)
+        if dones_host is None:
+            dones_host = self._episode_steps >= self.L
+        ended = np.nonzero(dones_host)[0]
+        return dones_host, ended, ended.size > 0, ended.size == self.n_env
+
+    def _after_step_host(self, dones_host, ended, any_ended, all_ended, record):
         self._episode_just_ended = any_ended
         self.current_episode_steps_counter = int(self._episode_steps[0]) if not dones_host[0] else 0
         if any_ended:

@@ -72,6 +72,18 @@ class SyntheticVectorEnvironment(object):
         return self.obs
 
     def step(self, actions=None):
+        self.launch_step()
+        self.host_tick()
+        return self.next_obs, self.reset_obs, self.reward, self.game_over
+
+    def host_tick(self):
+        """advance the host mirror of the episode clocks (which envs finished: `dones_host`)."""
+        self.t_host += 1
+        np.greater_equal(self.t_host, self.lengths_host, out=self.dones_host)
+        self.t_host[self.dones_host] = 0
+
+    def launch_step(self):
+        """the device half of step(): pure launches on static buffers (hipGraph-capturable)."""
         if self.lengths is None:
             self.lib.synth_env_step(self.kind, self.next_obs, self.reset_obs, self.reward, self.game_over,
                                     self.episode, self.step_in_episode, self.n, self.obs_elems,
@@ -80,7 +92,3 @@ class SyntheticVectorEnvironment(object):
             self.lib.synth_env_step_lengths(self.kind, self.next_obs, self.reset_obs, self.reward, self.game_over,
                                             self.episode, self.step_in_episode, self.n, self.obs_elems,
                                             self.lengths, self.seed, self.env_id0, _rlx.current_stream())
-        self.t_host += 1
-        np.greater_equal(self.t_host, self.lengths_host, out=self.dones_host)
-        self.t_host[self.dones_host] = 0
-        return self.next_obs, self.reset_obs, self.reward, self.game_over

@@ -290,6 +290,29 @@ class ExperienceReplay(Memory):
             else:
                 self._became_visible(self.n_env)
 
+    def reserve_step(self, defer):
+        """The HOST half of store(): where the rows of this vector step go (-> row0) and how the sampled window
+        moves.  The device half may then run from a captured graph whose destination rows arrive as data."""
+        self.commit_pending()
+        row0 = self.cursor
+        self.cursor = (self.cursor + self.n_env) % self.rows
+        self._steps_written += 1
+        if defer:
+            self.pending = self.n_env
+        else:
+            self._became_visible(self.n_env)
+        return row0
+
+    def store_device(self, actions, rewards, game_overs, next_obs, reset_obs, dst_rows):
+        """The DEVICE half of store() for vector observations with the destination rows as a device int32[n_env]
+        (staged with the step's other host draws): pure launches on static buffers."""
+        s = _rlx.current_stream()
+        pairs = [(actions, self.action), (rewards, self.reward), (game_overs, self.game_over),
+                 (self.cur_state, self.obs), (next_obs, self.next_obs)]
+        self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), None, dst_rows, 0, 0, self.n_env, self.rows,
+                              self.n_env, self.status, s)
+        self.lib.select_rows(game_overs, reset_obs, next_obs, self.cur_state, self.n_env, self.obs_dim * 4, s)
+
     # ----------------------------------------------------------------------------- training side
     def sample_indices(self, size):
         """The reference's draw (:80-86) on the global legacy np.random stream -> LOGICAL indices."""

