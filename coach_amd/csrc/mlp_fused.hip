@@ -49,6 +49,7 @@ struct MlpDqnDev {
     const unsigned char *dones;
     const double *iw;         // importance weights or null
     float *ws_q, *ws_dh1, *ws_norm;
+    long long *stamps;        // [12] s_memtime of workgroup 0 at the phase boundaries (tools/mlp_fused_phases.py)
     unsigned *sync;           // [3]: barrier 1, barrier 2, finish ticket (all zero between launches)
     float *loss, *norm;
     double *td;
@@ -225,6 +226,9 @@ __global__ void __launch_bounds__(kThreads) mlp_dqn_update_kernel(const MlpDqnDe
     const int B = p.B, D0 = p.D0, H1 = p.H1, H2 = p.H2, A = p.A;
     const int D0p = (D0 + 1) & ~1;
     const int col0 = 32 * g;
+    int stamp_i = 0;
+#define RLX_STAMP() do { if (g == 0 && tid == 0) p.stamps[stamp_i] = (long long)__builtin_readcyclecounter(); ++stamp_i; } while (0)
+    RLX_STAMP();                                                   // 0: start
 
     // ---- LDS carve
     float *xs0 = smem;                       // [D0p][LD]   states, k-major
@@ -261,6 +265,7 @@ __global__ void __launch_bounds__(kThreads) mlp_dqn_update_kernel(const MlpDqnDe
     }
     const float b1p = p.adam_state[0], b2p = p.adam_state[1];
     __syncthreads();
+    RLX_STAMP();                                                   // 1: inputs staged
 
     float *wsq = p.ws_q + (size_t)g * 3 * 32 * A;
     // ---- target network on s'
@@ -270,6 +275,7 @@ __global__ void __launch_bounds__(kThreads) mlp_dqn_update_kernel(const MlpDqnDe
     dense2(h1b, w2s, p.wt, p.o_b2, col0, H1, red, h2b, tid, w, l31, hi);
     q_partial(h2b, w3s + 32 * kMaxA, A, wsq + 1 * 32 * A, tid);
     __syncthreads();
+    RLX_STAMP();                                                   // 2: target tower done
     // ---- online network: s' (Double DQN action selection, ddqn_agent.py:43) and s
     load_w2_slice(p.w, p.o_w2, col0, H1, H2, w2s, tid);
     if (p.ddqn) {
@@ -282,8 +288,10 @@ __global__ void __launch_bounds__(kThreads) mlp_dqn_update_kernel(const MlpDqnDe
     __syncthreads();
     dense2(h1a, w2s, p.w, p.o_b2, col0, H1, red, h2a, tid, w, l31, hi);
     q_partial(h2a, w3s, A, wsq, tid);
+    RLX_STAMP();                                                   // 3: online towers done
 
     grid_barrier(&p.sync[0], (unsigned)G, p.status);          // ---- exchange 1: head partial sums
+    RLX_STAMP();                                                   // 4: barrier 1 passed
 
     const int towers = p.ddqn ? 3 : 2;
     for (int e = tid; e < towers * 32 * A; e += kThreads) {
@@ -331,6 +339,7 @@ __global__ void __launch_bounds__(kThreads) mlp_dqn_update_kernel(const MlpDqnDe
         __syncthreads();
     }
     if (g == 0 && tid == 0 && p.loss) p.loss[0] = lred[0] / (float)B;
+    RLX_STAMP();                                                   // 5: loss / dQ
 
     Adam ad;
     ad.alpha = p.lr * sqrtf(1.f - b2p) / (1.f - b1p);
@@ -399,7 +408,9 @@ __global__ void __launch_bounds__(kThreads) mlp_dqn_update_kernel(const MlpDqnDe
         ad.step16(idx, acc);
     }
 
+    RLX_STAMP();                                                   // 6: backward of the wide layer + its Adam
     grid_barrier(&p.sync[1], (unsigned)G, p.status);          // ---- exchange 2: dh1 partials (reduce-scatter)
+    RLX_STAMP();                                                   // 7: barrier 2 passed
 
     const int S1 = H1 / G, i0 = g * S1;               // this workgroup's slice of the first layer
     float *dz1 = red;                                  // [32][S1]
@@ -421,6 +432,7 @@ __global__ void __launch_bounds__(kThreads) mlp_dqn_update_kernel(const MlpDqnDe
         }
     }
 
+    RLX_STAMP();                                                   // 8: first layer's gradient + Adam
     // ---- tf.global_norm partial; the last workgroup to take a ticket finishes norm + Adam state and re-arms
     __syncthreads();
     lred[tid] = ad.ss;
@@ -446,6 +458,8 @@ __global__ void __launch_bounds__(kThreads) mlp_dqn_update_kernel(const MlpDqnDe
             __hip_atomic_store(&p.sync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    RLX_STAMP();                                                   // 9: end
+#undef RLX_STAMP
 }
 
 inline size_t lds_floats(int D0, int H1) {
@@ -469,7 +483,7 @@ int rlx_mlp_dqn_supported(int batch, int obs_dim, int h1, int h2, int n_actions)
 int rlx_mlp_dqn_workspace_floats(int h1, int h2, int n_actions, long long *floats_host) {
     RLX_REQUIRE(floats_host && h1 > 0 && h2 >= 32 && n_actions > 0, "rlx_mlp_dqn_workspace_floats: bad arguments");
     const long long G = h2 / 32;
-    *floats_host = G * 3 * 32 * n_actions + G * 32 * h1 + G + 16;
+    *floats_host = G * 3 * 32 * n_actions + G * 32 * h1 + G + 2 + 32;     /* + 12 int64 phase stamps */
     return RLX_OK;
 }
 
@@ -494,6 +508,7 @@ int rlx_mlp_dqn_update(const rlx_mlp_dqn_desc *d_host, void *stream) {
     p.ws_q = d.workspace;
     p.ws_dh1 = p.ws_q + (size_t)G * 3 * 32 * d.n_actions;
     p.ws_norm = p.ws_dh1 + (size_t)G * 32 * d.h1;
+    p.stamps = reinterpret_cast<long long *>(p.ws_norm + ((G + 1) & ~1) + (((uintptr_t)(p.ws_norm + ((G + 1) & ~1))) & 4 ? 1 : 0));
     p.sync = d.sync_words;
     p.loss = d.loss_out; p.norm = d.norm_out; p.td = d.td_errors; p.status = d.status;
     p.o_w1 = d.off_w1; p.o_b1 = d.off_b1; p.o_w2 = d.off_w2; p.o_b2 = d.off_b2; p.o_w3 = d.off_w3; p.o_b3 = d.off_b3;
