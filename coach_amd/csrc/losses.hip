@@ -16,24 +16,10 @@
 // One workgroup handles the whole minibatch (B <= 1024 rows x A actions): per-sample math in
 // registers, the batch means by an LDS tree reduction, gradients written once.  Latency-bound
 // (a few KB); the point is that logits, targets and gradients never leave HBM/L2.
-#include "rlx_common.hpp"
+#include "losses_body.hpp"
 
 namespace {
-
-constexpr int kMaxBlock = 1024;
-
-__device__ __forceinline__ float block_sum(float v, float *red) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    red[tid] = v;
-    __syncthreads();
-    for (int d = nt >> 1; d > 0; d >>= 1) {
-        if (tid < d) red[tid] += red[tid + d];
-        __syncthreads();
-    }
-    float r = red[0];
-    __syncthreads();
-    return r;
-}
+using namespace rlx_losses;
 
 // kind 0: mean squared error (t - o)^2;  kind 1: huber, delta = 1.
 // out/target [B, D]; weights [B] or null; grad = d loss / d out.  scalars[0] = loss.
@@ -92,60 +78,16 @@ ppo_discrete_loss_body(const float *__restrict__ logits, long long ld, const int
     __shared__ float red[kMaxBlock];
     float l_sur = 0.f, l_ent = 0.f, l_kl = 0.f;
     for (int b = threadIdx.x; b < batch; b += blockDim.x) {
-        const float *z = logits + (size_t)b * ld;
-        const float *po = old_probs + (size_t)b * ld_old;
-        float mx = z[0];
-        for (int j = 1; j < n; ++j) mx = fmaxf(mx, z[j]);
-        float se = 0.f, so = 0.f;
-        for (int j = 0; j < n; ++j) {
-            se += expf(z[j] - mx);
-            so += po[j];
-        }
-        const float lse = mx + logf(se);          // log-sum-exp of the new logits
-        const float lso = logf(so);               // Categorical(probs=p) renormalises: log p - log sum p
-        const int a = actions[b];
-        if (a < 0 || a >= n) {
+        PpoRowTerms t;
+        if (!ppo_discrete_row(logits + (size_t)b * ld, old_probs + (size_t)b * ld_old, actions[b], n, advantages[b],
+                              clip_eps, beta, grad_scale, batch, dlogits ? dlogits + (size_t)b * ld_grad : nullptr,
+                              ratio_out ? ratio_out + b : nullptr, clipped_out ? clipped_out + b : nullptr, t)) {
             atomicOr(status, 1);
             continue;
         }
-        float ent = 0.f, kl = 0.f;
-        for (int j = 0; j < n; ++j) {
-            const float lp = z[j] - lse;
-            const float p = expf(lp);
-            const float lpo = logf(po[j]) - lso;
-            ent -= p * lp;                                            // distribution.entropy()
-            kl += (po[j] / so) * (lpo - lp);                          // kl_divergence(old, new)
-        }
-        const float logp = z[a] - lse;                                // log_prob(actions)  (:60)
-        const float logp_old = logf(po[a]) - lso;                     // (:61)
-        const float ratio = expf(logp - logp_old);                    // (:79)
-        const float lo = 1.f - clip_eps, hi = 1.f + clip_eps;         // (:83-84)
-        const float clipped = fminf(fmaxf(ratio, lo), hi);            // (:85)
-        const float adv = advantages[b];
-        const float s1 = ratio * adv, s2 = clipped * adv;
-        l_sur += fminf(s1, s2);                                       // (:86-87)
-        l_ent += ent;
-        l_kl += kl;
-        if (ratio_out) ratio_out[b] = ratio;
-        if (clipped_out) clipped_out[b] = clipped;
-        if (dlogits) {
-            // d(-mean min(s1,s2))/d logp : tf.minimum routes the gradient to s1 when s1 <= s2,
-            // otherwise to s2, whose clip passes gradient only inside [lo, hi].
-            float g_logp;
-            if (s1 <= s2)
-                g_logp = -adv * ratio;
-            else
-                g_logp = (ratio >= lo && ratio <= hi) ? -adv * ratio : 0.f;
-            g_logp /= (float)batch;
-            const float gb = beta / (float)batch;
-            for (int j = 0; j < n; ++j) {
-                const float lp = z[j] - lse;
-                const float p = expf(lp);
-                float g = g_logp * ((j == a ? 1.f : 0.f) - p);        // d logp / d z_j
-                g += gb * p * (lp + ent);                             // d(-beta*H)/d z_j
-                dlogits[(size_t)b * ld_grad + j] = grad_scale * g;
-            }
-        }
+        l_sur += t.sur;
+        l_ent += t.ent;
+        l_kl += t.kl;
     }
     const float sur = block_sum(l_sur, red);
     const float ent = block_sum(l_ent, red);

@@ -1,0 +1,80 @@
+// Per-sample arithmetic of the head losses (see losses.hip), shared with the fused Clipped-PPO heads kernel
+// (ppo_heads_fused.hip): one definition, one rounding.
+#pragma once
+#include "rlx_common.hpp"
+
+namespace rlx_losses {
+
+constexpr int kMaxBlock = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int d = nt >> 1; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
+        __syncthreads();
+    }
+    float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// One sample of the discrete Clipped-PPO head (ppo_head.py:52-116): its surrogate / entropy / KL terms and the
+// gradient of the head loss w.r.t. its logits.  Returns false for an out-of-range action.
+struct PpoRowTerms { float sur, ent, kl; };
+__device__ __forceinline__ bool
+ppo_discrete_row(const float *__restrict__ z, const float *__restrict__ po, int a, int n, float adv, float clip_eps,
+                 float beta, float grad_scale, int batch, float *__restrict__ dlogits_row,
+                 float *__restrict__ ratio_dst, float *__restrict__ clipped_dst, PpoRowTerms &out) {
+    float mx = z[0];
+    for (int j = 1; j < n; ++j) mx = fmaxf(mx, z[j]);
+    float se = 0.f, so = 0.f;
+    for (int j = 0; j < n; ++j) {
+        se += expf(z[j] - mx);
+        so += po[j];
+    }
+    const float lse = mx + logf(se);          // log-sum-exp of the new logits
+    const float lso = logf(so);               // Categorical(probs=p) renormalises: log p - log sum p
+    if (a < 0 || a >= n) return false;
+    float ent = 0.f, kl = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float lp = z[j] - lse;
+        const float p = expf(lp);
+        const float lpo = logf(po[j]) - lso;
+        ent -= p * lp;                                            // distribution.entropy()
+        kl += (po[j] / so) * (lpo - lp);                          // kl_divergence(old, new)
+    }
+    const float logp = z[a] - lse;                                // log_prob(actions)  (:60)
+    const float logp_old = logf(po[a]) - lso;                     // (:61)
+    const float ratio = expf(logp - logp_old);                    // (:79)
+    const float lo = 1.f - clip_eps, hi = 1.f + clip_eps;         // (:83-84)
+    const float clipped = fminf(fmaxf(ratio, lo), hi);            // (:85)
+    const float s1 = ratio * adv, s2 = clipped * adv;
+    out.sur = fminf(s1, s2);                                      // (:86-87)
+    out.ent = ent;
+    out.kl = kl;
+    if (ratio_dst) *ratio_dst = ratio;
+    if (clipped_dst) *clipped_dst = clipped;
+    if (dlogits_row) {
+        // d(-mean min(s1,s2))/d logp : tf.minimum routes the gradient to s1 when s1 <= s2,
+        // otherwise to s2, whose clip passes gradient only inside [lo, hi].
+        float g_logp;
+        if (s1 <= s2)
+            g_logp = -adv * ratio;
+        else
+            g_logp = (ratio >= lo && ratio <= hi) ? -adv * ratio : 0.f;
+        g_logp /= (float)batch;
+        const float gb = beta / (float)batch;
+        for (int j = 0; j < n; ++j) {
+            const float lp = z[j] - lse;
+            const float p = expf(lp);
+            float g = g_logp * ((j == a ? 1.f : 0.f) - p);        // d logp / d z_j
+            g += gb * p * (lp + ent);                             // d(-beta*H)/d z_j
+            dlogits_row[j] = grad_scale * g;
+        }
+    }
+    return true;
+}
+
+}  // namespace rlx_losses

@@ -477,6 +477,45 @@ def small_dense_forward_multi(ctx, items, tag="", weights=None):
     return outs
 
 
+def ppo_discrete_heads_fused(ctx, v_item, pi_item, actions, advantages, old_probs, value_targets, clip_eps, beta,
+                             scalars, value_scalar, status, ratio_out=None, clipped_out=None, tag=""):
+    """Value head + policy head forward, both losses, both backward passes in ONE launch
+    (rlx_ppo_discrete_heads_fused).  items = (Dense layer, input Tensor).  -> (v Tensor, logits Tensor) with .grad
+    holding the loss gradients, like small_dense_forward_multi + the loss launch + small_dense_backward_multi."""
+    import ctypes
+    arr = (_rlx.SmallDenseProblem * 2)()
+    outs = []
+    for i, (l, x) in enumerate((v_item, pi_item)):
+        assert l.N <= SMALL_N and not x.u8 and x.cols == l.K and x.towers == l.T == 1 and l.act is None
+        M, p = x.rows, l.params
+        y = ctx.buffer(l.name, (l.T, M, l.N), tag=tag)
+        t = Tensor(y, M, l.N, l.T, grad_key=(ctx, l.name, tag), act=l.act)
+        dy, dx = t.ensure_grad(), x.ensure_grad()
+        q = arr[i]
+        q.x, q.x_tower_stride = x.data.data_ptr(), x.tower_stride()
+        q.w, q.w_tower_stride = p.w(l.kname).data_ptr(), p.stride(l.kname)
+        q.bias, q.bias_tower_stride = p.w(l.bname).data_ptr(), p.stride(l.bname)
+        q.y, q.y_tower_stride = y.data_ptr(), M * l.N
+        q.dy, q.dy_tower_stride = dy.data_ptr(), M * l.N
+        q.dw, q.dw_tower_stride = p.g(l.kname).data_ptr(), p.stride(l.kname)
+        q.db, q.db_tower_stride = p.g(l.bname).data_ptr(), p.stride(l.bname)
+        q.dx, q.dx_tower_stride = dx.data_ptr(), M * l.K
+        q.towers, q.M, q.K, q.N = 1, M, l.K, l.N
+        q.activation, q.lower_activation = 0, _rlx.ACT[x.act]
+        x.grad_is_dz = x.act is not None
+        outs.append(t)
+    M = v_item[1].rows
+    scratch = ctx.buffer("ppo_heads_fused/terms", (M, 4), tag=tag)
+    key = ("ppo_heads_fused/sync", (2,), torch.int32, tag)
+    sync = ctx.buffers.get(key)
+    if sync is None:                                     # the kernel leaves the two words zero
+        sync = ctx.buffers[key] = torch.zeros(2, dtype=torch.int32, device=ctx.device)
+    ctx.lib.ppo_discrete_heads_fused(ctypes.byref(arr), actions, advantages, old_probs, old_probs.shape[-1],
+                                     value_targets, float(clip_eps), float(beta), 1.0, scalars, value_scalar,
+                                     ratio_out, clipped_out, scratch, sync, status, ctx.stream)
+    return outs
+
+
 def small_dense_backward_multi(ctx, items):
     """[(Dense layer, input Tensor x, output Tensor y with y.grad set)]: dW, db and dx (with the lower
     layer's activation derivative) of every layer in ONE launch."""

@@ -115,6 +115,12 @@ class ClippedPPONet(_NetBase):
         self.obs_shape, self.image, self.A = tuple(obs_shape), len(obs_shape) == 3, n_actions
         self.clip_eps, self.beta = clip_likelihood_ratio_using_epsilon, beta_entropy
         self.continuous = continuous
+        import os
+        # RLX_FUSED_HEADS=1: heads forward / losses / heads backward as ONE launch with an in-kernel barrier
+        # (csrc/ppo_heads_fused.hip).  Bit-identical, but measured SLOWER on MI355X (C2: 93.9 vs 89.4 ms per
+        # iteration, profiles/r02_ab_fused_heads.txt): each of the three kernels is ~1-3 us of work behind a ~4 us
+        # launch, and the barrier plus the serialised per-row phase cost more than the two boundaries saved.  Opt-in.
+        self._heads_one_launch = os.environ.get("RLX_FUSED_HEADS", "0") == "1"
         self.params = G.FlatParams()
         self.torso, feat = build_torso(self.params, "main", obs_shape, activation, 2, embedder, middleware)
         self.v_head = G.Dense(self.params, "main/v_head/dense", feat, 1, None, 1,
@@ -189,14 +195,22 @@ class ClippedPPONet(_NetBase):
         mid.ensure_grad()
         xv, xp = mid.tower(0), mid.tower(1)
         fused_heads = self.pi_head.N <= G.SMALL_N and B * self.pi_head.N <= 1024
-        if fused_heads:        # value + policy head in one launch (forward here, backward below)
+        one_launch = fused_heads and not self.continuous and B <= 256 and self._heads_one_launch
+        if one_launch:         # forward, both head losses and backward of both heads: ONE launch
+            v, logits = G.ppo_discrete_heads_fused(ctx, (self.v_head, xv), (self.pi_head, xp), actions, advantages,
+                                                   old_probs, value_targets, self.clip_eps * clip_rescaler, self.beta,
+                                                   self.scalars[0:4], self.scalars[4:5], self.status, ratio_out,
+                                                   clipped_out, tag="train")
+        elif fused_heads:      # value + policy head in one launch (forward here, backward below)
             v, logits = G.small_dense_forward_multi(ctx, [(self.v_head, xv), (self.pi_head, xp)], tag="train")
         else:
             v = self.v_head.forward(ctx, xv, tag="train")
             logits = self.pi_head.forward(ctx, xp, tag="train")
         dv, dlogits = v.ensure_grad(), logits.ensure_grad()
         # head 0: VHead, MSE(target, V), loss weight 1 (head.py:172-181)
-        if not self.continuous:
+        if one_launch:
+            pass
+        elif not self.continuous:
             # ... and head 1, the discrete PPOHead clipped surrogate (+ entropy bonus), in one launch
             self.lib.ppo_discrete_value_losses(logits.data, self.A, actions, advantages, old_probs, self.A, B,
                                                self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
@@ -214,7 +228,9 @@ class ClippedPPONet(_NetBase):
                                          self.params.g("main/ppo_head/policy_log_std"), self.scalars[0:4],
                                          ratio_out, clipped_out, ctx.stream)
 
-        if fused_heads:
+        if one_launch:
+            pass
+        elif fused_heads:
             G.small_dense_backward_multi(ctx, [(self.v_head, xv, v), (self.pi_head, xp, logits)])
         else:
             self.v_head.backward(ctx, xv, v)

@@ -340,6 +340,19 @@ typedef struct rlx_small_dense_problem {
     int towers, M, K, N, activation, lower_activation;
 } rlx_small_dense_problem;
 int rlx_dense_small_forward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
+/* Both heads of discrete Clipped PPO in ONE launch (clipped_ppo_agent.py:209-308 per minibatch): heads_host[0] = the
+ * value head (N = 1), heads_host[1] = the policy head; forward (y), head losses (v_head.py:43-52, ppo_head.py:52-116,
+ * head.py:143-186) with their gradients written to dy, and the heads' backward pass (dw, db, dx with lower_activation').
+ * scalars[0:4] = surrogate, entropy, KL, policy-head total; value_loss_scalar[0] = value loss.  row_terms: [M][4]
+ * scratch; sync_words: 2 zero-initialised uint32 (left zero).  Bit-identical to rlx_dense_small_forward_multi +
+ * rlx_ppo_discrete_value_losses + rlx_dense_small_backward_multi.  status bits: 1 = action out of range, 8 = barrier
+ * timeout. */
+int rlx_ppo_discrete_heads_fused(const rlx_small_dense_problem *heads_host, const int *actions,
+                                 const float *advantages, const float *old_probs, long long ld_old,
+                                 const float *value_targets, float clip_epsilon, float beta_entropy, float grad_scale,
+                                 float *scalars, float *value_loss_scalar, float *likelihood_ratio,
+                                 float *clipped_likelihood_ratio, float *row_terms, unsigned int *sync_words,
+                                 int *status, void *stream);
 int rlx_dense_small_backward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
 
 /* -------------------------------------------------------- head losses (K9) -- */
