@@ -224,6 +224,46 @@ def prefill_c3(agent):
     torch.cuda.synchronize()
 
 
+# algorithmic flops of one update as the REFERENCE executes it (2 * MACs, forward + backward = 3x
+# forward, every pass the reference runs), and the dominant kernel family of each workload
+UPDATE_FLOPS = {"c1": 43e6, "c3": 3.0e9, "c4": 0.34e9, "c5": 2.3e9}
+LAUNCH_FLOOR_US = 1.7      # a dependent trivial kernel inside a hipGraph on MI355X (profiles/r02_launch_cost_microbench.txt)
+
+
+def update_roofline(agent, workload, reps=200):
+    """The off-policy workloads are LATENCY-bound: one update is a chain of dependent small launches.
+    Reported: the update's duration measured live with device events over `reps` back-to-back replays of the captured
+    update on one sampled batch, the library calls one eager update makes, and what that implies —
+    achieved = algorithmic flops / measured duration against the fp32 MFMA peak, and the floor launches x 1.7 us."""
+    from coach_amd import _rlx
+    B = agent.batch_size
+    batch = agent.memory.sample(B)
+    saved = agent.use_graphs
+    agent.use_graphs = False
+    c0 = _rlx.CALL_COUNT
+    agent.learn_from_batch(batch)
+    calls = _rlx.CALL_COUNT - c0
+    agent.use_graphs = saved
+    for _ in range(3):
+        agent.learn_from_batch(batch)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        agent.learn_from_batch(batch)
+    e1.record()
+    e1.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    flops = UPDATE_FLOPS[workload]
+    achieved = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), "traffic": None,
+            "kernel": "one gradient update (learn_from_batch: forward passes, targets, loss, backward, Adam) as captured",
+            "update_us": round(us, 2), "update_flops": flops, "library_calls_per_update": calls,
+            "latency_model": {"launch_floor_us": LAUNCH_FLOOR_US, "floor_us": round(calls * LAUNCH_FLOOR_US, 1),
+                              "note": "latency-bound: the floor of `calls` dependent launches, not the MFMA rate, "
+                                      "bounds this update (a call may launch 1-2 kernels)"}}
+
+
 def run_off_policy(args, device, dist):
     from coach_amd.core_types import RunPhase
     desc, n_env, vsteps, heat = OFF_POLICY[args.workload]
@@ -264,8 +304,17 @@ def run_off_policy(args, device, dist):
            "config": {"workload": desc, "env_steps_per_step_per_gpu": n_env * vsteps,
                       "parallelism": "dp%d" % dist.world_size, "hip_graphs": bool(agent.use_graphs)},
            "episode_stats": {k: (v if np.isfinite(v) else None) for k, v in agent.episode_statistics().items()}}
+    if dist.rank == 0 and not args.no_roofline and dist.world_size == 1:
+        out["roofline"] = update_roofline(agent, args.workload)
     if dist.rank == 0 and dist.world_size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_off_policy(args.workload)
+        if args.workload == "c1":       # the reference's own per-step code, timed in the build container
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_cpu_reference_c1_container.json")) as f:
+                    r = json.load(f)
+                out["cpu_baseline"]["reference"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "where", "sample")}
+            except (OSError, ValueError, KeyError):
+                pass
     if dist.rank == 0:
         print(json.dumps(out))
 

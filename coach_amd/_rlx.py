@@ -146,6 +146,8 @@ class _Lib:
             return fn
 
         def call(*args):
+            global CALL_COUNT
+            CALL_COUNT += 1
             if len(args) != nparams:
                 raise TypeError("%s expects %d arguments, got %d" % (full, nparams, len(args)))
             rc = fn(*[_as_arg(a) for a in args])
@@ -248,6 +250,7 @@ class MlpDqnDesc(ctypes.Structure):
 
 ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
 GEMM_HOOK = None   # bench.py sets this to record the descriptors issued by one update
+CALL_COUNT = 0     # librlx entry points called so far (bench.py: launches of one eager update)
 
 
 def _ptr(t):

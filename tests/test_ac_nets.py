@@ -213,10 +213,12 @@ def test_td3_update_matches_oracle(dev, paired):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("resample,paired", [(True, False), (False, False), (True, True)])
-def test_sac_update_matches_oracle(dev, resample, paired):
+@pytest.mark.parametrize("resample,paired,dims", [(True, False, (23, 5, 64)), (False, False, (23, 5, 64)),
+                                                  (True, True, (23, 5, 64)),
+                                                  (True, True, (376, 17, 256))])      # BASELINE C5: Humanoid SAC
+def test_sac_update_matches_oracle(dev, resample, paired, dims):
     from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgent, SoftActorCriticAgentParameters
-    D, A, B = 23, 5, 64
+    D, A, B = dims
     p = SoftActorCriticAgentParameters()
     p.algorithm.resample_noise_per_pass = resample
     ag = _agent(dev, SoftActorCriticAgent, p, D, A, B)
