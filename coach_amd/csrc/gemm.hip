@@ -62,6 +62,7 @@ struct GemmDev {
     int fold;                   // > 0: column n belongs to tower n / fold (its B, C, bias, colsum live at
                                 // tower * batch_stride + n % fold): towers that share A run as ONE GEMM
     float a_div;
+    unsigned long long *stamps; // diagnostics (rlx_gemm_debug_stamps): [workgroup][4] wall-clock ticks, or null
 };
 
 // two-level batch offset (paired online/target passes over multi-stream layers): b = bo * inner + bi
@@ -333,6 +334,10 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
+    // phase stamps of every workgroup (entry, first slab staged, main loop done, exit) — tools/gemm_timeline.py
+    unsigned long long *const stamp = g.stamps && tid == 0
+        ? g.stamps + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
+    if (stamp) stamp[0] = wall_clock64();
     if (A_U8) {
         lut[tid] = (float)tid / g.a_div;        // kThreads == 256
         __syncthreads();
@@ -472,6 +477,7 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
         load_b(kbeg + BK, rb1, mb1);
         a_red_offsets(kbeg + 2 * BK, ao0, ma0);
         __syncthreads();
+        if (stamp) stamp[1] = wall_clock64();
         // step s: LDS[s&1] = slab s; set N holds slab s+1 (in flight); (ao_F, ma_F) address slab s+2
         auto step = [&](int s, a_raw_t (&ra_n)[NA], long long (&ao_n)[NR], float (&ma_n)[NR],
                         float4 (&rb_n)[NB], float (&mb_n)[NB], a_raw_t (&ra_f)[NA],
@@ -513,6 +519,7 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
         }
     }
 
+    if (stamp) stamp[2] = wall_clock64();
     if (do_colsum && n0 + tid < g.N) {
         const int n = n0 + tid;
         if (g.splits > 1)
@@ -577,6 +584,7 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
                 }
             }
         }
+        if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
         return;
     }
 #pragma unroll
@@ -601,6 +609,7 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
             }
         }
     }
+    if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
 }
 
 
@@ -972,6 +981,20 @@ inline int rlx_split_min_k() {
     return v;
 }
 
+// RLX_GEMM_SPLIT_WGS_PER_CU / RLX_GEMM_SPLIT_MAX_TILES: experiment knobs of the split-K heuristic (defaults 2 / 256)
+inline int rlx_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+inline int rlx_split_wgs_per_cu() {
+    static const int v = rlx_env_int("RLX_GEMM_SPLIT_WGS_PER_CU", 2);
+    return v;
+}
+inline int rlx_split_max_tiles() {
+    static const int v = rlx_env_int("RLX_GEMM_SPLIT_MAX_TILES", rlx::kCUs);
+    return v;
+}
+
 inline bool rlx_no_thin_gemm() {
     static const bool v = [] {
         const char *e = getenv("RLX_NO_THIN_GEMM");
@@ -989,9 +1012,40 @@ inline bool rlx_force_generic_gemm() {
     return v;
 }
 
+// diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
+struct StampCall { int M, N, K, batch, splits, gx, gy, gz; long long offset; };
+struct StampState {
+    unsigned long long *buf = nullptr;
+    long long capacity = 0, cursor = 0;
+    int ncalls = 0;
+    StampCall calls[512];
+};
+StampState g_stamps;
+
 }  // namespace
 
 extern "C" {
+
+int rlx_gemm_debug_stamps(void *buffer, long long capacity_u64) {
+    g_stamps.buf = static_cast<unsigned long long *>(buffer);
+    g_stamps.capacity = buffer ? capacity_u64 : 0;
+    g_stamps.cursor = 0;
+    g_stamps.ncalls = 0;
+    return RLX_OK;
+}
+
+int rlx_gemm_debug_calls(long long *out_host, int max_calls, int *n_calls_host) {
+    RLX_REQUIRE(out_host && n_calls_host && max_calls >= 0, "rlx_gemm_debug_calls: bad arguments");
+    const int n = g_stamps.ncalls < max_calls ? g_stamps.ncalls : max_calls;
+    for (int i = 0; i < n; ++i) {
+        const StampCall &c = g_stamps.calls[i];
+        long long *o = out_host + 9 * i;
+        o[0] = c.M; o[1] = c.N; o[2] = c.K; o[3] = c.batch; o[4] = c.splits;
+        o[5] = c.gx; o[6] = c.gy; o[7] = c.gz; o[8] = c.offset;
+    }
+    *n_calls_host = n;
+    return RLX_OK;
+}
 
 int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host) {
     RLX_REQUIRE(floats_host && M > 0 && N > 0 && K > 0 && batch > 0,
@@ -1032,6 +1086,7 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     g.act = d.activation; g.deriv = d.deriv_kind; g.accumulate = d.accumulate;
     g.a_div = d.a_is_u8 ? d.a_div : 1.f;
     g.colsum = d.colsum_out; g.colsum_batch_stride = d.colsum_batch_stride; g.ws_colsum = nullptr;
+    g.stamps = nullptr;
 
     // vector dimension of each operand: the index whose stride is 1 (tables: declared by caller)
     const bool a_vec_red = d.a_row_tab || d.a_k_tab ? (d.a_vec_along_k != 0) : (d.a_k_stride == 1);
@@ -1090,8 +1145,8 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     // (RLX_GEMM_SPLIT_MIN_K raises the shortest K that may be split; measured on C2 / C3, splitting
     // every under-filled launch is fastest: 118 vs 129 ms and 325 vs 383 ms per bench step.)
     int splits = 1;
-    if (d.workspace && tiles <= rlx::kCUs && d.K >= rlx_split_min_k()) {
-        const int want = (2 * rlx::kCUs + tiles - 1) / tiles;
+    if (d.workspace && tiles <= rlx_split_max_tiles() && d.K >= rlx_split_min_k()) {
+        const int want = (rlx_split_wgs_per_cu() * rlx::kCUs + tiles - 1) / tiles;
         const int max_by_k = d.K / (2 * BK);
         splits = want < max_by_k ? want : max_by_k;
         if (splits > 64) splits = 64;
@@ -1130,6 +1185,15 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
             t.n_fold = 0;
             t.a_batch_stride = 0;
             return rlx_gemm(&t, stream);
+        }
+    }
+    if (g_stamps.buf && fast) {
+        const long long need = 4LL * grid.x * grid.y * grid.z;
+        if (g_stamps.cursor + need <= g_stamps.capacity && g_stamps.ncalls < 512) {
+            g.stamps = g_stamps.buf + g_stamps.cursor;
+            g_stamps.calls[g_stamps.ncalls++] = {d.M, d.N, d.K, d.batch, splits, (int)grid.x, (int)grid.y,
+                                                 (int)grid.z, g_stamps.cursor};
+            g_stamps.cursor += need;
         }
     }
     int rc = -1;

@@ -271,6 +271,12 @@ typedef struct rlx_gemm_desc {
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
 int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host);
+/* Diagnostics (tools/gemm_timeline.py): while a device buffer of `capacity_u64` 64-bit words is registered, every
+ * tiled-kernel launch of rlx_gemm records, per workgroup, four wall-clock ticks (10 ns: entry, first slab staged,
+ * main loop done, exit) in its own region of the buffer; rlx_gemm_debug_calls lists the regions as rows of
+ * {M, N, K, batch, splits, grid.x, grid.y, grid.z, offset}.  buffer == NULL switches the stamps off (the default). */
+int rlx_gemm_debug_stamps(void *buffer, long long capacity_u64);
+int rlx_gemm_debug_calls(long long *out_host, int max_calls, int *n_calls_host);
 int rlx_colsum(const float *x, int M, int N, long long ld, float *out, int accumulate,
                float *workspace, long long workspace_floats, void *stream);  /* bias gradients */
 int rlx_act_backward(float *dy, const float *y, long long n, int kind, void *stream); /* dy *= act'(y) */

@@ -348,4 +348,4 @@ def sac_update(pol, q, v, batch, normals, discount=0.99, resample=True):
     y = T.ac_td_targets(r, done, v_next[:, None], discount).astype(F32)[:, 0]
     q_losses, norm = q.train(s, a, y)
     return dict(loss=float(sum(q_losses)), v_loss=float(v_loss), value_targets=value_targets, td_targets=y,
-                dq_da=dq_da, logprob=o["logprob"], norm=norm)
+                dq_da=dq_da, logprob=o["logprob"], norm=norm, actions=o["actions"])

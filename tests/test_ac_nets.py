@@ -229,12 +229,22 @@ def test_sac_update_matches_oracle(dev, resample, paired, dims):
     rng = np.random.RandomState(5)
     for it in range(4):
         batch = _batch(rng, B, D, A)
+        if D > 100:
+            # 376 unit-variance inputs through a freshly initialised policy give log-std outputs of +-2 and
+            # pre-tanh actions of +-20: log(1 - tanh^2 + 1e-6) is then decided by the last bit of tanh.  Normalised
+            # observations (what the reference's Humanoid preset feeds, ObservationNormalizationFilter) keep it sane.
+            batch = (batch[0] * np.float32(0.05),) + tuple(batch[1:4]) + (batch[4] * np.float32(0.05),)
         z = rng.standard_normal((3, B, A))
         r = O.sac_update(op, oq, ov, batch, z, resample=resample)
         ag.normals.copy_(_t(z, dev))
         ag._learn_device(_B(dev, batch, paired))
         np.testing.assert_allclose(ag.dq_da.cpu().numpy(), r["dq_da"], rtol=2e-3, atol=1e-7)
-        np.testing.assert_allclose(ag.value_targets.cpu().numpy(), r["value_targets"], rtol=2e-4, atol=2e-5)
+        # the log-probability's conditioning: d log(1 - t^2 + eps) = 2 |t| dt / (1 - t^2 + eps), dt = 2 ulp of tanh
+        t = r["actions"].astype(np.float64)
+        cond = (2 * np.abs(t) * 2.4e-7 / (1 - t * t + 1e-6)).sum(axis=1)
+        vt = ag.value_targets.cpu().numpy()
+        assert np.all(np.abs(vt - r["value_targets"]) <= 2e-4 * np.abs(r["value_targets"]) + 2e-5 + cond), \
+            np.abs(vt - r["value_targets"]).max()
         np.testing.assert_allclose(ag.td_targets.cpu().numpy(), r["td_targets"], rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(float(qn.loss.sum()), r["loss"], rtol=3e-4)
         np.testing.assert_allclose(float(vn.loss), r["v_loss"], rtol=3e-4)
