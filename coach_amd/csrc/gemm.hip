@@ -33,6 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 constexpr int kThreads = 256;
+constexpr int kTabChunk = 2048;     // longest K chunk of a table-addressed (implicit im2col) launch of the fast kernel
 
 struct OperandDev {
     const void *base;
@@ -312,8 +313,9 @@ template <> struct ARaw<true> { typedef Raw1 type; };
 // TM x TN accumulator tiles of 32x32 per wave (wave tile 32*TM x 32*TN): with 2x2 the LDS operand
 // reads per MFMA halve and a workgroup carries 4x the MFMA work per prologue/epilogue — what the
 // short-K (K = 64) input-gradient GEMMs need.
+// (one accumulator tile per wave: at most 168 registers, so that three workgroups share a CU)
 template <int BM, int BN, int TM, int TN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
-__global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
+__global__ void __launch_bounds__(kThreads, (TM * TN == 1 ? 3 : 1)) gemm_fast_kernel(const GemmDev g) {
     constexpr int WN = BN / (32 * TN);
     static_assert((BM / (32 * TM)) * WN == 4, "a workgroup is 4 waves");
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
@@ -325,6 +327,7 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
     float *const Bs = smem + 2 * A_BUF;
     static_assert(4 * 32 * 33 <= 2 * A_BUF + 2 * B_BUF, "epilogue staging fits in the operand buffers");
     __shared__ float lut[A_U8 ? 256 : 1];
+    __shared__ int tab_s[A_TAB ? kTabChunk : 1];     // reduction-index offsets of this workgroup's K chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -382,15 +385,18 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
         for (int p = 0; p < NB; ++p) b_kr[p] = (tid + p * kThreads) / (BN / 4);
     }
 
-    // reduction-index offsets of A for one slab (table lookups are the only dependent loads)
+    // reduction-index offsets of A for one slab.  Table lookups would be DEPENDENT global loads, and waiting for
+    // one drains the whole in-order load queue (s_waitcnt vmcnt) — the operand loads in flight included — so the
+    // main loop reads the chunk's offsets from LDS (staged once per workgroup; LDS has its own counter); only the
+    // two slabs the prologue loads look their offsets up in global memory, all at once.
     constexpr int NR = A_VEC_RED ? 1 : NA;
-    auto a_red_offsets = [&](int k0, long long (&off)[NR], float (&msk)[NR]) {
+    auto a_red_offsets = [&](int k0, long long (&off)[NR], float (&msk)[NR], bool from_lds) {
 #pragma unroll
         for (int p = 0; p < NR; ++p) {
             const int r = k0 + (A_VEC_RED ? a_kq : a_kr[p]);
             const int rc = min(r, kend - (A_VEC_RED ? 4 : 1));
             msk[p] = r < kend ? 1.f : 0.f;
-            off[p] = A_TAB ? (long long)g.a.tab_r[rc] : (long long)rc * g.a.stride_r;
+            off[p] = A_TAB ? (long long)(from_lds ? tab_s[rc - kbeg] : g.a.tab_r[rc]) : (long long)rc * g.a.stride_r;
         }
     };
     typedef typename ARaw<A_U8>::type a_raw_t;
@@ -460,33 +466,31 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
     float csum = 0.f;
 
     if (kbeg < kend) {
-        // two register sets; a set = raw operand data + masks of one slab, plus (ao, ma) which hold
-        // the A reduction offsets / mask of the slab that will be loaded INTO this set next
+        // Two register sets, each = the raw operand data + masks of one slab.  Loads are issued two slabs ahead of
+        // their use and UNCONDITIONALLY inside the steady-state loop, so that the compiler knows how many are in
+        // flight and waits with vmcnt(loads of one slab) — not vmcnt(0) — before a set is staged into LDS
+        // (measured with rlx_gemm_debug_stamps: with conditional loads / table lookups in the loop every slab step
+        // exposed a full load latency, 1.1-1.5 us per step against 0.43 us of MFMA issue).
         a_raw_t ra0[NA], ra1[NA];
         float4 rb0[NB], rb1[NB];
         long long ao0[NR], ao1[NR];
         float ma0[NR], ma1[NR], mb0[NB], mb1[NB];
         const int nslab = (kend - kbeg + BK - 1) / BK;
-        // prologue: slab 0 -> LDS buffer 0; slab 1 in flight in set 1; offsets of slab 2 in (ao0, ma0)
-        a_red_offsets(kbeg, ao0, ma0);
+        // prologue: slabs 0 and 1 requested back to back; slab 0 -> LDS buffer 0
+        a_red_offsets(kbeg, ao0, ma0, false);
+        a_red_offsets(kbeg + BK, ao1, ma1, false);
+        if (A_TAB) {
+            for (int i = tid; i < kend - kbeg; i += kThreads) tab_s[i] = g.a.tab_r[kbeg + i];
+        }
         load_a(ao0, ra0);
         load_b(kbeg, rb0, mb0);
-        a_red_offsets(kbeg + BK, ao1, ma1);
-        store(0, ra0, ma0, rb0, mb0);
         load_a(ao1, ra1);
         load_b(kbeg + BK, rb1, mb1);
-        a_red_offsets(kbeg + 2 * BK, ao0, ma0);
+        store(0, ra0, ma0, rb0, mb0);
         __syncthreads();
         if (stamp) stamp[1] = wall_clock64();
-        // step s: LDS[s&1] = slab s; set N holds slab s+1 (in flight); (ao_F, ma_F) address slab s+2
-        auto step = [&](int s, a_raw_t (&ra_n)[NA], long long (&ao_n)[NR], float (&ma_n)[NR],
-                        float4 (&rb_n)[NB], float (&mb_n)[NB], a_raw_t (&ra_f)[NA],
-                        long long (&ao_f)[NR], float4 (&rb_f)[NB], float (&mb_f)[NB]) {
-            const int cur = s & 1;
-            if (s + 2 < nslab) {                     // slab s+2: issued before this slab's MFMAs
-                load_a(ao_f, ra_f);
-                load_b(kbeg + (s + 2) * BK, rb_f, mb_f);
-            }
+        // step s: LDS[s&1] = slab s; set N holds slab s+1 (in flight); set F is free and receives slab s+2
+        auto mfma_slab = [&](int cur) {
             const float *ap = As + cur * A_BUF + hi * LDA_S + wm * (32 * TM) + l31;
             const float *bp = Bs + cur * B_BUF + hi * LDB_S + wn * (32 * TN) + l31;
 #pragma unroll
@@ -509,13 +513,43 @@ __global__ void __launch_bounds__(kThreads) gemm_fast_kernel(const GemmDev g) {
                 for (int kk = 0; kk < BK; ++kk) sc += bc[kk * LDB_S + tid];
                 csum += sc;
             }
-            if (s + 1 < nslab) store(cur ^ 1, ra_n, ma_n, rb_n, mb_n);      // slab s+1 -> other buffer
-            if (s + 3 < nslab) a_red_offsets(kbeg + (s + 3) * BK, ao_n, ma_n);
+        };
+        // full step: request slab s+2, multiply slab s, stage slab s+1
+        auto full = [&](int s, a_raw_t (&ra_n)[NA], float (&ma_n)[NR], float4 (&rb_n)[NB], float (&mb_n)[NB],
+                        a_raw_t (&ra_f)[NA], long long (&ao_f)[NR], float (&ma_f)[NR], float4 (&rb_f)[NB],
+                        float (&mb_f)[NB]) {
+            a_red_offsets(kbeg + (s + 2) * BK, ao_f, ma_f, true);
+            load_a(ao_f, ra_f);
+            load_b(kbeg + (s + 2) * BK, rb_f, mb_f);
+            __builtin_amdgcn_sched_barrier(0);        // keep the requests AHEAD of this slab's MFMAs
+            mfma_slab(s & 1);
+            store((s & 1) ^ 1, ra_n, ma_n, rb_n, mb_n);
             __syncthreads();
         };
-        for (int s = 0; s < nslab; s += 2) {
-            step(s, ra1, ao1, ma1, rb1, mb1, ra0, ao0, rb0, mb0);
-            if (s + 1 < nslab) step(s + 1, ra0, ao0, ma0, rb0, mb0, ra1, ao1, rb1, mb1);
+        // tail step: nothing left to request
+        auto tail = [&](int s, bool stage_next, a_raw_t (&ra_n)[NA], float (&ma_n)[NR], float4 (&rb_n)[NB],
+                        float (&mb_n)[NB]) {
+            mfma_slab(s & 1);
+            if (stage_next) {
+                store((s & 1) ^ 1, ra_n, ma_n, rb_n, mb_n);
+                __syncthreads();
+            }
+        };
+        int s = 0;
+        for (; s + 3 < nslab; s += 2) {              // slabs s+2 and s+3 exist
+            full(s, ra1, ma1, rb1, mb1, ra0, ao0, ma0, rb0, mb0);
+            full(s + 1, ra0, ma0, rb0, mb0, ra1, ao1, ma1, rb1, mb1);
+        }
+        const int left = nslab - s;                  // 1, 2 or 3 slabs; s is even
+        if (left == 3) {
+            full(s, ra1, ma1, rb1, mb1, ra0, ao0, ma0, rb0, mb0);
+            tail(s + 1, true, ra0, ma0, rb0, mb0);
+            tail(s + 2, false, ra1, ma1, rb1, mb1);
+        } else if (left == 2) {
+            tail(s, true, ra1, ma1, rb1, mb1);
+            tail(s + 1, false, ra0, ma0, rb0, mb0);
+        } else {
+            tail(s, false, ra1, ma1, rb1, mb1);
         }
     }
 
@@ -1124,7 +1158,7 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
 
     // fast path: every 4-element vector group of both operands is full, in range and aligned
     const bool a_tab = d.a_row_tab && d.a_k_tab;
-    const bool fast = !rlx_force_generic_gemm() && g.a.vec_ok && g.b.vec_ok &&
+    bool fast = !rlx_force_generic_gemm() && g.a.vec_ok && g.b.vec_ok &&
                       (a_tab || (!d.a_row_tab && !d.a_k_tab)) &&
                       (a_vec_red ? d.K % 4 == 0 : (d.M % 4 == 0 && d.M >= 4)) &&
                       (b_vec_red ? d.K % 4 == 0 : (d.N % 4 == 0 && d.N >= 4)) && d.K >= 4;
@@ -1155,6 +1189,13 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     }
     int kchunk = ((d.K + splits - 1) / splits + BK - 1) / BK * BK;
     splits = (d.K + kchunk - 1) / kchunk;
+    if (fast && a_tab && kchunk > kTabChunk) {
+        // the fast kernel stages a chunk's im2col offsets in LDS; a longer chunk (no workspace to split K into) takes
+        // the bounds-checked kernel
+        fast = false;
+        BM = narrow ? 128 : 64;
+        BN = narrow ? 32 : 64;
+    }
     g.splits = splits;
     g.kchunk = kchunk;
     g.ws = d.workspace;
