@@ -39,7 +39,7 @@ _CTYPE = {
     "size_t": ctypes.c_size_t,
 }
 
-_VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported"}  # return a value, not an rlx_status
+_VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
 
@@ -246,6 +246,17 @@ class MlpDqnDesc(ctypes.Structure):
         ("discount", ctypes.c_double)] + [(n, ctypes.c_int) for n in (
             "batch", "obs_dim", "h1", "h2", "n_actions", "huber", "double_dqn")] + [(n, ctypes.c_float) for n in (
                 "learning_rate", "beta1", "beta2", "epsilon", "grad_scale")]
+
+
+class ObserveDesc(ctypes.Structure):
+    """rlx_observe_desc (include/rlx.h) — field order must match the header."""
+    P, LL, D, I = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_double, ctypes.c_int
+    _fields_ = [("reward", P), ("filtered_reward", P), ("reward_rescale", D), ("has_clip", I), ("clip_low", D),
+                ("clip_high", D), ("game_over", P), ("stored_game_over", P), ("ep_return", P), ("ep_len", P),
+                ("acc", P), ("last_return", P), ("last_len", P), ("actions", P), ("action_row_bytes", LL),
+                ("cur_state", P), ("next_obs", P), ("reset_obs", P), ("obs_row_bytes", LL), ("mem_action", P),
+                ("mem_reward", P), ("mem_game_over", P), ("mem_obs", P), ("mem_next_obs", P), ("dst_rows", P),
+                ("mem_rows", LL), ("status", P), ("n_env", I)]
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}

@@ -104,9 +104,19 @@ class DQNAgent(VectorOffPolicyAgent):
         net = self.networks["main"]
         self.exploration_policy.phase = self.phase
         draws = self.exploration_policy.draw()                       # host RNG, per env, in order
+        if net.can_act_fused(self.n_env):
+            # small MLP, a few envs: Q(s) and the epsilon-greedy choice are ONE launch
+            eps, d = self.exploration_policy.stage(draws)
+            net.q_act(states, self.n_env, d["u"], d["ra"], d["tie"], eps, self._q_buf(), self.actions)
+            return self.actions
         self._run(("q", self.n_env), lambda: self._q_forward(states))
         self.exploration_policy.get_action(self._q_act, draws, self.actions)
         return self.actions
+
+    def _q_buf(self):
+        if getattr(self, "_q_act", None) is None or self._q_act.shape != (self.n_env, self.A):
+            self._q_act = torch.zeros(self.n_env, self.A, dtype=torch.float32, device=self.device)
+        return self._q_act
 
     def _q_forward(self, states):
         q = self.networks["main"].q_values(states, self.n_env, tag="act")
@@ -175,22 +185,49 @@ class DQNAgent(VectorOffPolicyAgent):
             rec = self._records[k] = dict(stager=st, lay=lay, views=views, host=np.zeros(st.dst.numel(), np.uint8))
         return rec
 
+    def _observe_device(self, dst_rows):
+        """reward filter, episode totals, the transition store (rows dst_rows) and the envs' next current state: one
+        launch for a few vector-observation envs (rlx_observe_step), else the four launches it stands for."""
+        mem, env, alg, s = self.memory, self.env, self.ap.algorithm, _rlx.current_stream()
+        has_clip = alg.reward_clipping is not None
+        lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
+        if self.n_env * mem.obs_dim * 4 <= (1 << 16):
+            import ctypes
+            d = _rlx.ObserveDesc()
+            p = lambda t: t.data_ptr()
+            d.reward, d.filtered_reward = p(env.reward), p(self.filtered_reward)
+            d.reward_rescale, d.has_clip, d.clip_low, d.clip_high = float(alg.reward_rescale), int(has_clip), lo, hi
+            d.game_over = d.stored_game_over = p(env.game_over)
+            d.ep_return, d.ep_len, d.acc = p(self.ep_return), p(self.ep_len), p(self.ep_acc)
+            d.last_return, d.last_len = p(self.last_return), None
+            d.actions, d.action_row_bytes = p(self.actions), self.actions.element_size() * (self.actions[0].numel())
+            d.cur_state, d.next_obs, d.reset_obs = p(mem.cur_state), p(env.next_obs), p(env.reset_obs)
+            d.obs_row_bytes = mem.obs_dim * 4
+            d.mem_action, d.mem_reward, d.mem_game_over = p(mem.action), p(mem.reward), p(mem.game_over)
+            d.mem_obs, d.mem_next_obs = p(mem.obs), p(mem.next_obs)
+            d.dst_rows, d.mem_rows, d.status, d.n_env = p(dst_rows), mem.rows, p(mem.status), self.n_env
+            self.lib.observe_step(ctypes.byref(d), s)
+            return
+        self.lib.reward_filter(env.reward, self.filtered_reward, self.n_env, alg.reward_rescale, int(has_clip),
+                               lo, hi, s)
+        self.lib.episode_stats_step(self.filtered_reward, env.game_over, self.ep_return, self.ep_len, self.n_env,
+                                    self.ep_acc, self.last_return, None, s)
+        mem.store_device(self.actions, self.filtered_reward, env.game_over, env.next_obs, env.reset_obs, dst_rows)
+
     def _step_body(self, k, start, with_act):
         """the device work of one step: [act, env, store] then updates start .. start+k-1 of the record."""
         v = self._step_record(self._rec_k)["views"]
         mem, s, alg = self.memory, _rlx.current_stream(), self.ap.algorithm
         if with_act:
-            self._q_forward(mem.current_states())
-            self.lib.egreedy(self._q_act, self.A, v["u"], v["ra"], v["tie"], 0.0, self.n_env, self.A, self.actions, s)
+            net = self.networks["main"]
+            if net.can_act_fused(self.n_env):
+                net.q_act(mem.current_states(), self.n_env, v["u"], v["ra"], v["tie"], 0.0, self._q_buf(), self.actions)
+            else:
+                self._q_forward(mem.current_states())
+                self.lib.egreedy(self._q_act, self.A, v["u"], v["ra"], v["tie"], 0.0, self.n_env, self.A,
+                                 self.actions, s)
             self.env.launch_step()
-            env = self.env
-            has_clip = alg.reward_clipping is not None
-            lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
-            self.lib.reward_filter(env.reward, self.filtered_reward, self.n_env, alg.reward_rescale, int(has_clip),
-                                   lo, hi, s)
-            self.lib.episode_stats_step(self.filtered_reward, env.game_over, self.ep_return, self.ep_len, self.n_env,
-                                        self.ep_acc, self.last_return, None, s)
-            mem.store_device(self.actions, self.filtered_reward, env.game_over, env.next_obs, env.reset_obs, v["dst"])
+            self._observe_device(v["dst"])
         B = self.batch_size
         b = mem._batch_buffers(B)
         for j in range(start, start + k):

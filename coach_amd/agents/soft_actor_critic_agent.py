@@ -174,9 +174,13 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         o, p_saved = pol.forward(s, B, self.normals[0], tag="train0")
         # (2) Q(s, sampled actions): log_target = min(Q1, Q2) (:198-200)
         qv, q_saved = q.forward(s, o["actions"], B, tag="pi")
-        self.lib.min_pair(qv[0], qv[1], self.log_target, None, None, 0.0, B, s_)
+        # min(Q1, Q2), the V targets of (4) = log_target - logp of this first pass (:244) and d mean(min) / d Q_i
+        # for (3): one launch
+        dqv = q_saved[4].ensure_grad().view(2, B)
+        self.lib.sac_min_targets(qv[0], qv[1], o["logprob"], 1.0 / B, B, self.log_target, self.value_targets,
+                                 dqv[0], dqv[1], s_)
         # (3) d mean(Q_min) / d a at the sampled actions (:216-217)
-        q.action_gradient(q_saved, B, self.dq_da)
+        q.action_gradient(q_saved, B, self.dq_da, dq_done=True)
         if resample:
             # The three sess.run passes of the reference re-evaluate the SAME deterministic torso
             # (same weights, same states) and only re-sample the head's noise, so their gradients
@@ -192,8 +196,7 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
                          action_weight_scale=-1.0)
         self._sync(pol)
         pol.apply_gradients(self._scale("policy"))                               # :229
-        # (4) V: targets = log_target - logp of the FIRST pass (:244), train_on_batch (:250)
-        self.lib.sac_value_targets(self.log_target, o["logprob"], B, self.value_targets, s_)
+        # (4) V: train_on_batch on the targets computed above (:250)
         obs2 = b._info.get("states_pair") if hasattr(b, "_info") else None
         if obs2 is not None:
             # V_online(s) of this training pass and V_target(s') of the Q targets share their launches
@@ -207,19 +210,20 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         # (5) Q: y = r + (1 - done) gamma V_target(s') (:259-266), train_on_batch (:268)
         if obs2 is None:
             v_next, _ = v.forward(ns, B, use_target=True, tag="next")
-        self.lib.ac_td_targets(b.rewards(), b.game_overs(), v_next, 1, float(alg.discount), 0, 0, 0.0, 0.0,
-                               B, self.td_targets, s_)
-        _, q_saved = q.forward(s, b.actions(), B, tag="train")
-        q.train_backward(q_saved, self.td_targets, B)
+        qt, q_saved = q.forward(s, b.actions(), B, tag="train")
+        # TD targets and both Q losses (0.5 * mse each, sac_q_head.py:91-95) + their sum: one launch
+        self.lib.ac_critic_losses(v_next, None, b.rewards(), b.game_overs(), float(alg.discount), 0, 0, 0.0, 0.0,
+                                  qt, 2, B, 0.5, None, self.td_targets, q_saved[4].ensure_grad(), q.loss, s_)
+        q.train_backward(q_saved, None, B)
         self._sync(q)
         q.apply_gradients(self._scale("q"), with_norm=True)
 
     def learn_from_batch(self, batch):
         B = self.batch_size
         z = np.random.standard_normal((3, B, self.A))
-        self.normals.copy_(self._to_device("sac_z", z, torch.float64))
+        self.normals = self._to_device("sac_z", z, torch.float64)     # the staging buffer is the operand
         self._run(("learn",), lambda: self._learn_device(batch))
         qn = self.networks["q"]
-        self.signals = {"Loss": qn.loss.sum(), "Grads (unclipped)": qn.norm,
+        self.signals = {"Loss": qn.loss[2], "Grads (unclipped)": qn.norm,
                         "V loss": self.networks["v"].loss}
-        return qn.loss.sum()
+        return qn.loss[2]

@@ -109,15 +109,25 @@ class TD3Agent(DDPGAgent):
         alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
         a2, self._a_saved = actor.forward_pair(obs2, B)
         self._actions_mean = a2[0]
-        self.act2[0].copy_(b.actions())
-        self.lib.td3_smooth_actions(a2[1], self.noise, float(alg.noise_clipping), self.d_low, self.d_high,
-                                    B, self.A, self.act2[1], s_)                    # :162-165
-        q2, c_saved = critic.forward_pair(obs2, self.act2, B)
-        self.lib.min_pair(q2[1][0], q2[1][1], self.q_min, None, None, 0.0, B, s_)      # output #2 (:168)
-        self._td_targets(b, self.q_min)
-        critic.train_backward(c_saved, self.td_targets, B)
+        # merged critic inputs of both passes + the observation half of the action-gradient pass: one launch
+        # (target-policy smoothing :162-165 included)
+        merged2 = critic.merged_pair_buffer(B)
+        self._agrad_merged = critic.merged_buffer(B, "agrad")
+        o2 = obs2.view(2, B, critic.obs_dim)
+        self.lib.ac_merge_inputs(b.actions(), o2[0], a2[1], self.noise, float(alg.noise_clipping), self.d_low,
+                                 self.d_high, o2[1], B, self.A, critic.obs_dim, merged2, self._agrad_merged, s_)
+        q2, c_saved = critic.forward_pair_merged(merged2, B)
+        # min(Q1', Q2') (output #2, :168), TD targets (:171-180) and both streams' losses: one launch
+        clip = alg.clip_critic_targets
+        self.lib.ac_critic_losses(q2[1][0], q2[1][1], b.rewards(), b.game_overs(), float(alg.discount),
+                                  int(bool(alg.use_non_zero_discount_for_terminal_states)), int(clip is not None),
+                                  float(clip[0]) if clip else 0.0, float(clip[1]) if clip else 0.0, q2[0],
+                                  critic.T, B, 1.0, self.q_min, self.td_targets, c_saved[2].ensure_grad(),
+                                  critic.loss, s_)
+        critic.train_backward(c_saved, self.td_targets, B, losses_done=True)
         self._sync(critic)
         critic.apply_gradients(self._scale("critic"), with_norm=True)
+        self._loss_total = critic.loss[critic.T]                 # written by the loss launch: no reduction launch
 
     def _critic_device(self, b):
         obs2 = b._info.get("states_pair") if hasattr(b, "_info") else None
@@ -125,6 +135,7 @@ class TD3Agent(DDPGAgent):
             return self._critic_device_paired(b, obs2)
         actor, critic = self.networks["actor"], self.networks["critic"]
         alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
+        self._agrad_merged = None
         s, ns = b._states["observation"], b._next_states["observation"]
         next_actions, _ = actor.forward(ns, B, use_target=True, tag="next")
         self._actions_mean, self._a_saved = actor.forward(s, B, tag="train")
@@ -138,25 +149,37 @@ class TD3Agent(DDPGAgent):
         critic.train_backward(c_saved, self.td_targets, B)
         self._sync(critic)
         critic.apply_gradients(self._scale("critic"), with_norm=True)
+        self._loss_total = None
 
     def _actor_device(self, b):
         actor, critic = self.networks["actor"], self.networks["critic"]
         B = self.batch_size
         s = b._states["observation"]
-        _, c_saved = critic.forward(s, self._actions_mean, B, tag="agrad")     # :188-192, output #3
-        critic.action_gradient(c_saved, B, self.neg_action_grad, scale=-1.0)
-        actor.backward(self._a_saved, self.neg_action_grad, B)
+        if self._agrad_merged is not None:
+            # [mu(s) | s]: the observation columns were written with the critic inputs, the action columns now
+            m = self._agrad_merged
+            self.lib.copy_2d(self._actions_mean, self.A, m, critic.merged, B, self.A, 1.0, _rlx.current_stream())
+            _, c_saved = critic.forward_merged(m, B, tag="agrad")              # :188-192, output #3
+            # - d mean(Q1) / d action, scaled to the actor's tanh output, straight into the actor head's gradient
+            critic.action_gradient(c_saved, B, actor.head_grad(self._a_saved), scale=-actor._uniform_scale)
+            actor.backward(self._a_saved, None, B)
+        else:
+            _, c_saved = critic.forward(s, self._actions_mean, B, tag="agrad")
+            critic.action_gradient(c_saved, B, self.neg_action_grad, scale=-1.0)
+            actor.backward(self._a_saved, self.neg_action_grad, B)
         self._sync(actor)
         actor.apply_gradients(self._scale("actor"))
 
     def learn_from_batch(self, batch):
         alg, B = self.ap.algorithm, self.batch_size
         z = np.random.normal(0, alg.policy_noise, (B, self.A))                  # :162 (host stream)
-        self.noise.copy_(self._to_device("td3_noise", z, torch.float64))
+        # the staging buffer IS the noise operand (a static device tensor): no device-to-device copy behind the upload
+        self.noise = self._to_device("td3_noise", z, torch.float64)
         run = self._run
         run(("critic",), lambda: self._critic_device(batch))
         if self.training_iteration % alg.update_policy_every_x_episode_steps == 0:   # :186
             run(("actor",), lambda: self._actor_device(batch))
         critic = self.networks["critic"]
-        self.signals = {"Loss": critic.loss[:2].sum(), "Grads (unclipped)": critic.norm}
-        return critic.loss[:2].sum()
+        loss = self._loss_total if self._loss_total is not None else critic.loss[:2].sum()
+        self.signals = {"Loss": loss, "Grads (unclipped)": critic.norm}
+        return loss

@@ -567,7 +567,7 @@ class SACQArchitecture(HipArchitecture):
         table = {head.q1_loss: loss[0], head.q2_loss: loss[1]}
         if any(f not in table for f in additional_fetches):
             raise ValueError("unknown fetch in {}".format(additional_fetches))
-        total = float(loss.sum())
+        total = float(loss[:2].sum())
         return total, [total], float(net.norm.item()), [table[f] for f in additional_fetches]
 
 

@@ -56,6 +56,23 @@ __global__ void min_pair_kernel(const float *__restrict__ q1, const float *__res
     if (g2) g2[i] = first ? 0.f : grad_scale;
 }
 
+// min_pair + sac_value_targets in one launch: out_min = min(q1, q2), value_targets = out_min - logprob (fp32, as the
+// numpy arrays of soft_actor_critic_agent.py:244), g_i = grad_scale * d sum(min) / d q_i.
+__global__ void sac_min_targets_kernel(const float *__restrict__ q1, const float *__restrict__ q2,
+                                       const float *__restrict__ logprob, float grad_scale, int n,
+                                       float *__restrict__ out_min, float *__restrict__ value_targets,
+                                       float *__restrict__ g1, float *__restrict__ g2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = q1[i], b = q2[i];
+    const bool first = a <= b;
+    const float m = first ? a : b;
+    out_min[i] = m;
+    value_targets[i] = m - logprob[i];
+    g1[i] = first ? grad_scale : 0.f;
+    g2[i] = first ? 0.f : grad_scale;
+}
+
 __global__ void select_rows_kernel(const unsigned char *__restrict__ mask,
                                    const unsigned char *__restrict__ if_set,
                                    const unsigned char *__restrict__ if_clear,
@@ -177,6 +194,16 @@ int rlx_min_pair(const float *q1, const float *q2, float *out_min, float *grad1,
     RLX_REQUIRE(q1 && q2 && n > 0, "rlx_min_pair: bad arguments");
     min_pair_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
         q1, q2, out_min, grad1, grad2, grad_scale, n);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_sac_min_targets(const float *q1, const float *q2, const float *sampled_logprob, float grad_scale, int n,
+                        float *out_min, float *value_targets, float *grad1, float *grad2, void *stream) {
+    RLX_REQUIRE(q1 && q2 && sampled_logprob && out_min && value_targets && grad1 && grad2 && n > 0,
+                "rlx_sac_min_targets: bad arguments");
+    sac_min_targets_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
+        q1, q2, sampled_logprob, grad_scale, n, out_min, value_targets, grad1, grad2);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

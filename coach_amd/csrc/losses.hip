@@ -110,6 +110,55 @@ regression_loss_kernel(const float *__restrict__ out, const float *__restrict__ 
                          grad, ld_grad, scalars);
 }
 
+// TD targets + the critic regression losses of an actor-critic update in ONE launch (one workgroup, batch <= 1024):
+//   q_next = min(q_next1, q_next2)  (TD3 output #2, td3_agent.py:168; q_next2 null: q_next1 as is)
+//   y      = r + (1 - done) * discount * q_next   in fp64, optional clip, cast to fp32   (ac_targets_kernel)
+//   stream t: loss_t = loss_weight * mean((q_t - y)^2), dq_t = d loss_t / d q_t             (regression_loss_body)
+//   loss[n_streams] = loss_0 + loss_1 + ...  (the logged total, added in stream order)
+// — the arithmetic of min_pair + rlx_ac_td_targets + n_streams x rlx_regression_loss, which it replaces.
+struct AcCriticLossArgs {
+    const float *q_next1, *q_next2, *rewards;
+    const unsigned char *dones;
+    double discount, clip_lo, clip_hi;
+    int nonzero_terminal_discount, has_clip;
+    const float *q;
+    int n_streams, batch;
+    float loss_weight;
+    float *q_min_out, *td_targets, *dq, *loss;
+};
+__global__ void __launch_bounds__(kMaxBlock) ac_critic_losses_kernel(const AcCriticLossArgs a) {
+    __shared__ float y_s[kMaxBlock];
+    for (int i = threadIdx.x; i < a.batch; i += blockDim.x) {
+        float qn = a.q_next1[i];
+        if (a.q_next2) {
+            const float b = a.q_next2[i];
+            qn = qn <= b ? qn : b;
+        }
+        if (a.q_min_out) a.q_min_out[i] = qn;
+        const double q = (double)qn;
+        double t;
+        if (a.nonzero_terminal_discount)
+            t = (double)a.rewards[i] + a.discount * q;
+        else
+            t = (double)a.rewards[i] + (1.0 - (a.dones[i] ? 1.0 : 0.0)) * a.discount * q;
+        if (a.has_clip) t = fmin(fmax(t, a.clip_lo), a.clip_hi);
+        const float y = (float)t;
+        y_s[i] = y;
+        a.td_targets[i] = y;
+    }
+    __syncthreads();
+    float total = 0.f;
+    for (int t = 0; t < a.n_streams; ++t) {
+        regression_loss_body(a.q + (size_t)t * a.batch, y_s, nullptr, a.batch, 1, 1, 1, 0, a.loss_weight, 1.f,
+                             a.dq + (size_t)t * a.batch, 1, a.loss + t);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            total += a.loss[t];
+            if (t == a.n_streams - 1) a.loss[a.n_streams] = total;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kMaxBlock)
 ppo_discrete_loss_kernel(const float *__restrict__ logits, long long ld, const int *__restrict__ actions,
                          const float *__restrict__ advantages, const float *__restrict__ old_probs,
@@ -236,6 +285,26 @@ int rlx_regression_loss(const float *out, long long ld_out, const float *target,
     regression_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
         out, target, importance_weights, batch, dim, ld_out, ld_target, kind, loss_weight, grad_scale,
         grad, ld_grad, loss_scalar);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_ac_critic_losses(const float *q_next1, const float *q_next2, const float *rewards,
+                         const unsigned char *game_overs, double discount,
+                         int use_non_zero_discount_for_terminal_states, int has_clip, double clip_low,
+                         double clip_high, const float *q, int n_streams, int batch, float loss_weight,
+                         float *q_min_out, float *td_targets, float *dq, float *loss, void *stream) {
+    RLX_REQUIRE(q_next1 && rewards && game_overs && q && td_targets && dq && loss,
+                "rlx_ac_critic_losses: null pointer");
+    RLX_REQUIRE(batch > 0 && batch <= kMaxBlock && n_streams >= 1 && n_streams <= 4,
+                "rlx_ac_critic_losses: bad sizes (batch=%d <= %d, n_streams=%d <= 4)", batch, kMaxBlock, n_streams);
+    AcCriticLossArgs a;
+    a.q_next1 = q_next1; a.q_next2 = q_next2; a.rewards = rewards; a.dones = game_overs;
+    a.discount = discount; a.clip_lo = clip_low; a.clip_hi = clip_high;
+    a.nonzero_terminal_discount = use_non_zero_discount_for_terminal_states; a.has_clip = has_clip;
+    a.q = q; a.n_streams = n_streams; a.batch = batch; a.loss_weight = loss_weight;
+    a.q_min_out = q_min_out; a.td_targets = td_targets; a.dq = dq; a.loss = loss;
+    ac_critic_losses_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

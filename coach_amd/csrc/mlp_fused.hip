@@ -468,9 +468,184 @@ inline size_t lds_floats(int D0, int H1) {
            2 * kMaxA + kThreads + 2 * 32 * kMaxA;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Acting with the same small MLP: Q(s) for a handful of envs and the epsilon-greedy choice, one launch of one
+// workgroup (choose_action, agents/dqn_agent.py + exploration_policies/e_greedy.py:84-101).  A thread owns one hidden
+// unit: the weight rows are read coalesced ([in][out] storage), every dot product runs in index order (plain fp32
+// fmaf chain); the action values are one wave per (env, action) with a fixed shuffle tree.  The greedy choice
+// restates egreedy_kernel (explore.hip) on the values still in LDS.
+constexpr int kActEnvs = 8;
+constexpr int kActThreads = 1024;
+// slices of the wide layer's reduction index: as many as the threads allow, at most 2048 / H2 (LDS for the partials)
+__host__ __device__ inline int act_slices(int threads, int n_env, int h2) {
+    int s = threads / (h2 >> 2);
+    const int cap = 8192 / (n_env * h2);          // 32 KB of partial sums
+    if (s > cap) s = cap;
+    return s > 0 ? s : 1;
+}
+inline size_t act_lds_floats(int n_env, int h1, int h2) {
+    return (size_t)kActEnvs * (16 + h1 + h2 + kMaxA) + (size_t)n_env * act_slices(kActThreads, n_env, h2) * h2;
+}
+
+struct MlpActDev {
+    const float *w; long long o_w1, o_b1, o_w2, o_b2, o_w3, o_b3;
+    const float *states;
+    const double *explore_u; const int *random_act; const double *tie_rand; double epsilon;
+    float *q_out; int *actions;
+    int n_env, D, H1, H2, A;
+};
+
+template <int E>
+__global__ void __launch_bounds__(1024) mlp_q_act_kernel(const MlpActDev p) {
+    extern __shared__ float sm[];
+    float *xs = sm;                                  // [E][D]
+    float *h1s = xs + kActEnvs * 16;                 // [E][H1]
+    float *h2s = h1s + kActEnvs * p.H1;              // [E][H2]
+    float *qs = h2s + kActEnvs * p.H2;               // [E][A]
+    float *parts = qs + kActEnvs * kMaxA;            // [E][S][H2], S * H2 / 4 <= threads
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < E * p.D; i += nt) xs[i] = p.states[i];
+    __syncthreads();
+    const float *W1 = p.w + p.o_w1, *b1 = p.w + p.o_b1, *W2 = p.w + p.o_w2, *b2 = p.w + p.o_b2;
+    const float *W3 = p.w + p.o_w3, *b3 = p.w + p.o_b3;
+    for (int j = tid; j < p.H1; j += nt) {
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        for (int k = 0; k < p.D; ++k) {
+            const float wv = W1[(size_t)k * p.H1 + j];
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = fmaf(xs[e * p.D + k], wv, acc[e]);
+        }
+        const float bv = b1[j];
+#pragma unroll
+        for (int e = 0; e < E; ++e) h1s[e * p.H1 + j] = fmaxf(acc[e] + bv, 0.f);
+    }
+    __syncthreads();
+    // the wide layer: H1 x H2 weights through ONE compute unit.  A thread owns 4 adjacent hidden units (16-byte
+    // weight loads, coalesced over the threads) and one of S slices of the reduction index; the S partial sums of
+    // a unit meet in LDS and are added in slice order.
+    {
+        const int groups = p.H2 >> 2;
+        const int S = act_slices(nt, E, p.H2);
+        const int chunk = (((p.H1 + S - 1) / S) + 3) & ~3;
+        for (int t = tid; t < S * groups; t += nt) {
+            const int part = t / groups, c4 = (t - part * groups) << 2;
+            const int k0 = part * chunk, k1 = min(p.H1, k0 + chunk);
+            float4 acc[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+            for (int k = k0; k < k1; k += 4) {
+                float4 wv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wv[i] = *reinterpret_cast<const float4 *>(W2 + (size_t)(k + i) * p.H2 + c4);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float4 h = *reinterpret_cast<const float4 *>(h1s + e * p.H1 + k);
+                    const float hv[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[e].x = fmaf(hv[i], wv[i].x, acc[e].x);
+                        acc[e].y = fmaf(hv[i], wv[i].y, acc[e].y);
+                        acc[e].z = fmaf(hv[i], wv[i].z, acc[e].z);
+                        acc[e].w = fmaf(hv[i], wv[i].w, acc[e].w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) *reinterpret_cast<float4 *>(parts + (size_t)(e * S + part) * p.H2 + c4) = acc[e];
+        }
+        __syncthreads();
+        for (int j = tid; j < p.H2; j += nt) {
+            const float bv = b2[j];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float v = parts[(size_t)(e * S) * p.H2 + j];
+                for (int q = 1; q < S; ++q) v += parts[(size_t)(e * S + q) * p.H2 + j];
+                h2s[e * p.H2 + j] = fmaxf(v + bv, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int o = wave; o < E * p.A; o += nw) {
+        const int e = o / p.A, a = o - e * p.A;
+        float part = 0.f;
+        for (int k = lane; k < p.H2; k += 64) part = fmaf(h2s[e * p.H2 + k], W3[(size_t)k * p.A + a], part);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) {
+            const float v = part + b3[a];
+            qs[o] = v;
+            if (p.q_out) p.q_out[o] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < E && p.actions) {
+        const int e = tid;
+        if (p.explore_u[e] < p.epsilon) {
+            p.actions[e] = p.random_act[e];
+        } else {
+            const float *qe = qs + e * p.A;
+            float mx = qe[0];
+            for (int a = 1; a < p.A; ++a) mx = fmaxf(mx, qe[a]);
+            const float tol = 1e-8f + 1e-5f * fabsf(mx);
+            int best = 0;
+            double bv = -1.0;
+            for (int a = 0; a < p.A; ++a) {
+                const bool close = fabsf(qe[a] - mx) <= tol;
+                const double v = close ? p.tie_rand[(size_t)e * p.A + a] : 0.0;
+                if (v > bv) {
+                    bv = v;
+                    best = a;
+                }
+            }
+            p.actions[e] = best;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rlx_mlp_q_act_supported(int n_env, int obs_dim, int h1, int h2, int n_actions) {
+    if (n_env < 1 || n_env > kActEnvs || obs_dim < 1 || obs_dim > 16 || n_actions < 1 || n_actions > kMaxA) return 0;
+    if (h1 < 4 || h2 < 4 || h1 > 1024 || h2 > 1024 || h1 % 4 || h2 % 4) return 0;
+    return act_lds_floats(n_env, h1, h2) * sizeof(float) <= 64 * 1024 ? 1 : 0;      /* the default dynamic-LDS limit */
+}
+
+int rlx_mlp_q_act(const float *weights, long long off_w1, long long off_b1, long long off_w2, long long off_b2,
+                  long long off_w3, long long off_b3, const float *states, int n_env, int obs_dim, int h1, int h2,
+                  int n_actions, const double *explore_uniforms, const int *random_actions,
+                  const double *tie_break_uniforms, double epsilon, float *q_out, int *actions, void *stream) {
+    RLX_REQUIRE(weights && states && (q_out || actions), "rlx_mlp_q_act: null pointer");
+    RLX_REQUIRE(rlx_mlp_q_act_supported(n_env, obs_dim, h1, h2, n_actions),
+                "rlx_mlp_q_act: unsupported shape (n_env=%d obs=%d h1=%d h2=%d A=%d)", n_env, obs_dim, h1, h2, n_actions);
+    RLX_REQUIRE(!actions || (explore_uniforms && random_actions && tie_break_uniforms),
+                "rlx_mlp_q_act: the epsilon-greedy choice needs the host draws");
+    MlpActDev p;
+    p.w = weights; p.o_w1 = off_w1; p.o_b1 = off_b1; p.o_w2 = off_w2; p.o_b2 = off_b2; p.o_w3 = off_w3; p.o_b3 = off_b3;
+    p.states = states; p.explore_u = explore_uniforms; p.random_act = random_actions; p.tie_rand = tie_break_uniforms;
+    p.epsilon = epsilon; p.q_out = q_out; p.actions = actions;
+    p.n_env = n_env; p.D = obs_dim; p.H1 = h1; p.H2 = h2; p.A = n_actions;
+    const size_t lds = sizeof(float) * act_lds_floats(n_env, h1, h2);
+    hipStream_t st = rlx::as_stream(stream);
+    switch (n_env) {
+        case 1: mlp_q_act_kernel<1><<<1, kActThreads, lds, st>>>(p); break;
+        case 2: mlp_q_act_kernel<2><<<1, kActThreads, lds, st>>>(p); break;
+        case 3: mlp_q_act_kernel<3><<<1, kActThreads, lds, st>>>(p); break;
+        case 4: mlp_q_act_kernel<4><<<1, kActThreads, lds, st>>>(p); break;
+        case 5: mlp_q_act_kernel<5><<<1, kActThreads, lds, st>>>(p); break;
+        case 6: mlp_q_act_kernel<6><<<1, kActThreads, lds, st>>>(p); break;
+        case 7: mlp_q_act_kernel<7><<<1, kActThreads, lds, st>>>(p); break;
+        default: mlp_q_act_kernel<8><<<1, kActThreads, lds, st>>>(p); break;
+    }
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
 
 int rlx_mlp_dqn_supported(int batch, int obs_dim, int h1, int h2, int n_actions) {
     if (batch < 1 || batch > 32 || obs_dim < 1 || obs_dim > 16 || n_actions < 1 || n_actions > kMaxA) return 0;

@@ -173,11 +173,11 @@ standardize_kernel(const double *__restrict__ x, long long n, float *__restrict_
 
 // K12: per-env running episode totals, segmented at game_over.
 // acc[0..7] = {episodes, sum_return, sumsq_return, max_return, min_return, sum_len, max_len, min_len}
-__global__ void __launch_bounds__(1024)
-episode_stats_kernel(const float *__restrict__ reward, const unsigned char *__restrict__ done,
-                     double *__restrict__ ep_return, int *__restrict__ ep_len, int n_env,
-                     double *__restrict__ acc, double *__restrict__ last_return,
-                     int *__restrict__ last_len) {
+// (one workgroup; ends with every thread past its last barrier)
+__device__ __forceinline__ void
+episode_stats_body(const float *__restrict__ reward, const unsigned char *__restrict__ done,
+                   double *__restrict__ ep_return, int *__restrict__ ep_len, int n_env,
+                   double *__restrict__ acc, double *__restrict__ last_return, int *__restrict__ last_len) {
     __shared__ double s_cnt[1024], s_sum[1024], s_sq[1024], s_max[1024], s_min[1024];
     __shared__ double s_len[1024], s_lmax[1024], s_lmin[1024];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -228,6 +228,79 @@ episode_stats_kernel(const float *__restrict__ reward, const unsigned char *__re
         acc[5] += s_len[0];
         acc[6] = fmax(acc[6], s_lmax[0]);
         acc[7] = fmin(acc[7], s_lmin[0]);
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+episode_stats_kernel(const float *__restrict__ reward, const unsigned char *__restrict__ done,
+                     double *__restrict__ ep_return, int *__restrict__ ep_len, int n_env,
+                     double *__restrict__ acc, double *__restrict__ last_return,
+                     int *__restrict__ last_len) {
+    episode_stats_body(reward, done, ep_return, ep_len, n_env, acc, last_return, last_len);
+}
+
+// What an agent does with an environment response, for a handful of vector-observation envs, in ONE launch of one
+// workgroup: reward filter (rlx_reward_filter) -> episode totals (rlx_episode_stats_step) -> the transition store
+// (rlx_copy_columns: action, filtered reward, game_over, current state, next state -> replay row dst_rows[e]) ->
+// the envs' new current state (rlx_select_rows: reset observation where the episode ended).  Same arithmetic and
+// the same order as the four launches it replaces; the phases are separated by workgroup barriers.
+struct ObserveArgs {
+    const float *reward_in; float *reward_out; double rescale; int use_hi; double hi; int use_lo; double lo;
+    const unsigned char *done, *stored_done;
+    double *ep_return; int *ep_len; double *acc; double *last_return; int *last_len;
+    const unsigned char *actions; long long action_row_bytes;
+    unsigned char *cur_state; const unsigned char *next_obs, *reset_obs; long long obs_row_bytes;
+    unsigned char *mem_action, *mem_reward, *mem_done, *mem_obs, *mem_next_obs;
+    const int *dst_rows; long long mem_rows; int *status; int n_env;
+};
+
+__device__ __forceinline__ void observe_copy_rows(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
+                                                  long long row_bytes, int n, const int *__restrict__ dst_rows,
+                                                  long long dst_limit, int *__restrict__ status) {
+    const bool words = ((row_bytes | (long long)(uintptr_t)src | (long long)(uintptr_t)dst) & 3) == 0;
+    const long long per_row = words ? row_bytes >> 2 : row_bytes;
+    for (long long t = threadIdx.x; t < per_row * n; t += blockDim.x) {
+        const long long r = t / per_row, e = t - r * per_row;
+        const long long d = dst_rows ? (long long)dst_rows[r] : r;
+        if (d < 0 || d >= dst_limit) {
+            if (e == 0) atomicOr(status, 1);
+            continue;
+        }
+        if (words)
+            reinterpret_cast<uint32_t *>(dst)[d * per_row + e] = reinterpret_cast<const uint32_t *>(src)[r * per_row + e];
+        else
+            dst[d * per_row + e] = src[r * per_row + e];
+    }
+}
+
+__global__ void __launch_bounds__(1024) observe_step_kernel(const ObserveArgs a) {
+    for (int e = threadIdx.x; e < a.n_env; e += blockDim.x) {
+        double r = (double)a.reward_in[e] * a.rescale;
+        if (a.use_hi) r = fmin(r, a.hi);
+        if (a.use_lo) r = fmax(r, a.lo);
+        a.reward_out[e] = (float)r;
+    }
+    __syncthreads();
+    episode_stats_body(a.reward_out, a.done, a.ep_return, a.ep_len, a.n_env, a.acc, a.last_return, a.last_len);
+    if (a.mem_obs) {
+        observe_copy_rows(a.actions, a.mem_action, a.action_row_bytes, a.n_env, a.dst_rows, a.mem_rows, a.status);
+        observe_copy_rows(reinterpret_cast<const unsigned char *>(a.reward_out), a.mem_reward, 4, a.n_env, a.dst_rows,
+                          a.mem_rows, a.status);
+        observe_copy_rows(a.stored_done, a.mem_done, 1, a.n_env, a.dst_rows, a.mem_rows, a.status);
+        observe_copy_rows(a.cur_state, a.mem_obs, a.obs_row_bytes, a.n_env, a.dst_rows, a.mem_rows, a.status);
+        observe_copy_rows(a.next_obs, a.mem_next_obs, a.obs_row_bytes, a.n_env, a.dst_rows, a.mem_rows, a.status);
+    }
+    __syncthreads();
+    const bool words = ((a.obs_row_bytes | (long long)(uintptr_t)a.cur_state | (long long)(uintptr_t)a.next_obs |
+                         (long long)(uintptr_t)a.reset_obs) & 3) == 0;
+    const long long per_row = words ? a.obs_row_bytes >> 2 : a.obs_row_bytes;
+    for (long long t = threadIdx.x; t < per_row * a.n_env; t += blockDim.x) {
+        const long long r = t / per_row;
+        if (words)
+            reinterpret_cast<uint32_t *>(a.cur_state)[t] =
+                a.done[r] ? reinterpret_cast<const uint32_t *>(a.reset_obs)[t] : reinterpret_cast<const uint32_t *>(a.next_obs)[t];
+        else
+            a.cur_state[t] = a.done[r] ? a.reset_obs[t] : a.next_obs[t];
     }
 }
 
@@ -416,6 +489,47 @@ int rlx_episode_stats_step(const float *reward, const unsigned char *game_over, 
     while (threads < n_env && threads < 1024) threads <<= 1;
     episode_stats_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
         reward, game_over, ep_return, ep_len, n_env, acc, last_return, last_len);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_observe_step(const rlx_observe_desc *d, void *stream) {
+    RLX_REQUIRE(d, "rlx_observe_step: null descriptor");
+    RLX_REQUIRE(d->n_env > 0 && d->n_env <= 1024, "rlx_observe_step: 1 <= n_env <= 1024 (got %d)", d->n_env);
+    RLX_REQUIRE(d->reward && d->filtered_reward && d->game_over && d->ep_return && d->ep_len && d->acc,
+                "rlx_observe_step: null reward / episode-statistics pointer");
+    RLX_REQUIRE(d->cur_state && d->next_obs && d->reset_obs && d->obs_row_bytes > 0,
+                "rlx_observe_step: null observation pointer");
+    RLX_REQUIRE((long long)d->n_env * d->obs_row_bytes <= (1 << 20),
+                "rlx_observe_step: one workgroup moves the observations; %lld bytes is too much",
+                (long long)d->n_env * d->obs_row_bytes);
+    const bool store = d->mem_obs != nullptr;
+    RLX_REQUIRE(!store || (d->actions && d->action_row_bytes > 0 && d->mem_action && d->mem_reward && d->mem_game_over &&
+                           d->mem_next_obs && d->stored_game_over && d->mem_rows > 0 && d->status),
+                "rlx_observe_step: incomplete replay columns");
+    ObserveArgs a;
+    a.reward_in = d->reward; a.reward_out = d->filtered_reward; a.rescale = d->reward_rescale;
+    // `if self.clipping_high:` / `if self.clipping_low:` — a bound equal to 0 is not applied (rlx_reward_filter)
+    a.use_hi = d->has_clip && d->clip_high != 0.0; a.hi = d->clip_high;
+    a.use_lo = d->has_clip && d->clip_low != 0.0; a.lo = d->clip_low;
+    a.done = d->game_over; a.stored_done = d->stored_game_over;
+    a.ep_return = d->ep_return; a.ep_len = d->ep_len; a.acc = d->acc; a.last_return = d->last_return;
+    a.last_len = d->last_len;
+    a.actions = static_cast<const unsigned char *>(d->actions); a.action_row_bytes = d->action_row_bytes;
+    a.cur_state = static_cast<unsigned char *>(d->cur_state);
+    a.next_obs = static_cast<const unsigned char *>(d->next_obs);
+    a.reset_obs = static_cast<const unsigned char *>(d->reset_obs);
+    a.obs_row_bytes = d->obs_row_bytes;
+    a.mem_action = static_cast<unsigned char *>(d->mem_action);
+    a.mem_reward = reinterpret_cast<unsigned char *>(d->mem_reward);
+    a.mem_done = d->mem_game_over;
+    a.mem_obs = static_cast<unsigned char *>(d->mem_obs);
+    a.mem_next_obs = static_cast<unsigned char *>(d->mem_next_obs);
+    a.dst_rows = d->dst_rows; a.mem_rows = d->mem_rows; a.status = d->status; a.n_env = d->n_env;
+    int threads = 64;
+    const long long work = (long long)d->n_env * (d->obs_row_bytes / 4 + 1);
+    while (threads < work && threads < 1024) threads <<= 1;
+    observe_step_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -88,10 +88,12 @@ __global__ void env_reset_kernel(int kind, void *obs, int *ep, int *t, int n_env
     }
 }
 
+// advance != 0 (only when one workgroup serves an env, gridDim.x == 1): the env's episode / step counters are
+// advanced here, after every thread has read them, instead of by a second launch.
 __global__ void env_step_kernel(int kind, void *next_obs, void *reset_obs, float *reward,
-                                unsigned char *done, const int *ep_in, const int *t_in, int n_env,
+                                unsigned char *done, int *ep_in, int *t_in, int n_env,
                                 int obs_elems, int episode_len, const int *__restrict__ len_per_env,
-                                uint32_t seed, uint32_t env_id0) {
+                                uint32_t seed, uint32_t env_id0, int advance) {
     const int e = blockIdx.y;
     const uint32_t ep = (uint32_t)ep_in[e], t = (uint32_t)t_in[e];
     const bool is_done = (int)t + 1 >= (len_per_env ? len_per_env[e] : episode_len);
@@ -105,6 +107,13 @@ __global__ void env_step_kernel(int kind, void *next_obs, void *reset_obs, float
     if (first == 0) {
         reward[e] = reward_of(kind, seed, env_id0 + e, ep, t);
         done[e] = is_done ? 1 : 0;
+    }
+    if (advance) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ep_in[e] = is_done ? (int)ep + 1 : (int)ep;
+            t_in[e] = is_done ? 0 : (int)t + 1;
+        }
     }
 }
 
@@ -169,11 +178,14 @@ static int synth_step(int kind, void *next_obs, void *reset_obs, float *reward, 
     hipStream_t s = rlx::as_stream(stream);
     const int work = kind == 0 ? obs_elems / 16 : obs_elems;
     dim3 grid(rlx::grid_for(work, 64, 16), n_env);
+    const int fused = grid.x == 1;
     env_step_kernel<<<grid, 64, 0, s>>>(kind, next_obs, reset_obs, reward, game_over, episode, step,
-                                        n_env, obs_elems, episode_len, len_per_env, seed, env_id0);
+                                        n_env, obs_elems, episode_len, len_per_env, seed, env_id0, fused);
     RLX_LAUNCH_CHECK();
-    env_advance_kernel<<<(n_env + 63) / 64, 64, 0, s>>>(episode, step, game_over, n_env);
-    RLX_LAUNCH_CHECK();
+    if (!fused) {
+        env_advance_kernel<<<(n_env + 63) / 64, 64, 0, s>>>(episode, step, game_over, n_env);
+        RLX_LAUNCH_CHECK();
+    }
     return RLX_OK;
 }
 

@@ -139,6 +139,42 @@ __global__ void td3_smooth_kernel(const float *__restrict__ next_actions,
     out[t] = (float)v;
 }
 
+// The two critic inputs of a DDPG / TD3 update, merged = concat(action, observation) (general_network.py:251,270-277),
+// in one launch: row block 0 = [batch actions | s], row block 1 = [smoothed target actions | s'] — what
+// td3_smooth_kernel + three strided copies produced.  noise == null: the target actions are taken as they are (DDPG).
+__global__ void ac_merge_inputs_kernel(const float *__restrict__ actions, const float *__restrict__ obs,
+                                       const float *__restrict__ next_actions, const double *__restrict__ noise,
+                                       double noise_clip, const float *__restrict__ low,
+                                       const float *__restrict__ high, const float *__restrict__ next_obs,
+                                       int batch, int A, int D, float *__restrict__ merged2,
+                                       float *__restrict__ merged_obs_only) {
+    const int W = A + D;
+    const long long total = (merged_obs_only ? 3LL : 2LL) * batch * W;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int half = (int)(t / ((long long)batch * W));
+        const int r = (int)((t / W) % batch), c = (int)(t % W);
+        if (half == 2) {                    // third block: only the observation columns ([. | s], actions filled later)
+            if (c >= A) merged_obs_only[(size_t)r * W + c] = obs[(size_t)r * D + (c - A)];
+            continue;
+        }
+        float v;
+        if (c >= A) {
+            v = (half ? next_obs : obs)[(size_t)r * D + (c - A)];
+        } else if (!half) {
+            v = actions[(size_t)r * A + c];
+        } else if (!noise) {
+            v = next_actions[(size_t)r * A + c];
+        } else {
+            const double nz = fmin(fmax(noise[(size_t)r * A + c], -noise_clip), noise_clip);
+            double x = (double)next_actions[(size_t)r * A + c] + nz;
+            x = fmin(fmax(x, (double)low[c]), (double)high[c]);
+            v = (float)x;
+        }
+        merged2[t] = v;
+    }
+}
+
 // value_targets = min(Q1,Q2)(s, a~pi) - log pi(a|s)     soft_actor_critic_agent.py:244
 __global__ void sac_value_targets_kernel(const float *__restrict__ q_min,
                                          const float *__restrict__ logprob, int batch,
@@ -259,6 +295,21 @@ int rlx_td3_smooth_actions(const float *next_actions, const double *noise, doubl
     int n = batch * action_dim;
     td3_smooth_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
         next_actions, noise, noise_clipping, action_low, action_high, batch, action_dim, out);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_ac_merge_inputs(const float *actions, const float *obs, const float *next_actions, const double *noise,
+                        double noise_clipping, const float *action_low, const float *action_high,
+                        const float *next_obs, int batch, int action_dim, int obs_dim, float *merged2,
+                        float *merged_obs_only, void *stream) {
+    RLX_REQUIRE(actions && obs && next_actions && next_obs && merged2, "rlx_ac_merge_inputs: null pointer");
+    RLX_REQUIRE(!noise || (action_low && action_high), "rlx_ac_merge_inputs: smoothing needs the action bounds");
+    RLX_REQUIRE(batch > 0 && action_dim > 0 && obs_dim > 0, "rlx_ac_merge_inputs: bad sizes");
+    const long long total = 3LL * batch * (action_dim + obs_dim);
+    ac_merge_inputs_kernel<<<rlx::grid_for(total, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
+        actions, obs, next_actions, noise, noise_clipping, action_low, action_high, next_obs, batch, action_dim,
+        obs_dim, merged2, merged_obs_only);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -58,10 +58,14 @@ class EGreedy(object):
         self.current_random_value = nxt
         return eps, u, ra, tie
 
-    def get_action(self, q_values, draws, out_actions):
+    def stage(self, draws):
+        """ship one step's host draws -> (epsilon, {u, ra, tie} static device buffers)."""
         eps, u, ra, tie = draws
         st = self._st
-        d = dict(u=st["u"].push(u), ra=st["ra"].push(ra), tie=st["tie"].push(tie))
+        return float(eps), dict(u=st["u"].push(u), ra=st["ra"].push(ra), tie=st["tie"].push(tie))
+
+    def get_action(self, q_values, draws, out_actions):
+        eps, d = self.stage(draws)
         self.lib.egreedy(q_values, self.A, d["u"], d["ra"], d["tie"], float(eps), self.n_env, self.A,
                          out_actions, _rlx.current_stream())
         return out_actions

@@ -63,6 +63,8 @@ class ActorNet(_ACBase):
         acts = self.emb.forward(ctx, self._obs(obs, B), tag=tag, weights=w)
         acts2 = self.mid.forward(ctx, acts[-1], tag=tag, weights=w)
         y = self.head.forward(ctx, acts2[-1], tag=tag, weights=w)
+        if out is None and self._uniform_scale == 1.0:
+            return y.data.view(B, self.A), (acts, acts2, y)        # tanh output IS the action: no scaling launch
         out = out if out is not None else ctx.buffer("actions", (B, self.A), tag=tag)
         self.lib.copy_2d(y.data, self.A, out, self.A, B, self.A, self._uniform_scale, ctx.stream)
         return out, (acts, acts2, y)
@@ -76,8 +78,11 @@ class ActorNet(_ACBase):
         acts = self.emb.forward(ctx, x, tag=tag, pair=True)
         acts2 = self.mid.forward(ctx, acts[-1], tag=tag, pair=True)
         y = self.head.forward(ctx, acts2[-1], tag=tag, pair=True)
-        out = ctx.buffer("actions2", (2, B, self.A), tag=tag)
-        self.lib.copy_2d(y.data, self.A, out, self.A, 2 * B, self.A, self._uniform_scale, ctx.stream)
+        if self._uniform_scale == 1.0:
+            out = y.data.view(2, B, self.A)
+        else:
+            out = ctx.buffer("actions2", (2, B, self.A), tag=tag)
+            self.lib.copy_2d(y.data, self.A, out, self.A, 2 * B, self.A, self._uniform_scale, ctx.stream)
         on = lambda ts: [ts[0].slice_towers(0, 1, with_grad=False)] + [t.slice_towers(0, 1) for t in ts[1:]]
         acts_o = on(acts)
         acts2_o = [acts_o[-1]] + [t.slice_towers(0, 1) for t in acts2[1:]]
@@ -89,11 +94,17 @@ class ActorNet(_ACBase):
         acts, acts2, y = saved
         ctx = self.ctx
         dy = y.ensure_grad()
-        self.lib.copy_2d(action_grad, self.A, dy, self.A, B, self.A, self._uniform_scale * grad_scale,
-                         ctx.stream)
+        if action_grad is not None:          # None: the caller wrote d loss / d tanh-output into head_grad(saved)
+            self.lib.copy_2d(action_grad, self.A, dy, self.A, B, self.A, self._uniform_scale * grad_scale,
+                             ctx.stream)
         self.head.backward(ctx, acts2[-1], y)
         self.mid.backward(ctx, acts2, need_input_grad=len(self.emb.layers) > 0)
         self.emb.backward(ctx, acts)
+
+
+    def head_grad(self, saved):
+        """the buffer backward() reads d(loss)/d(head output) from — [B, A], gradient w.r.t. the UNSCALED tanh output."""
+        return saved[2].ensure_grad()
 
 
 class CriticNet(_ACBase):
@@ -155,14 +166,45 @@ class CriticNet(_ACBase):
         eacts_o = [eacts[0].slice_towers(0, 1, with_grad=False)] + [t.slice_towers(0, 1) for t in eacts[1:]]
         return q.data.view(2, T, B), (eacts_o, macts_o, q.slice_towers(0, T), merged[0:1])
 
-    def train_backward(self, saved, targets, B):
-        """accumulate_gradients for the critic loss sum_i mean((target - Q_i)^2)."""
+    def merged_pair_buffer(self, B, tag="pair"):
+        """[2, B, A + D]: (s, a) rows for the online pass, (s', a') rows for the target pass (no observation
+        embedder: the merged input is concat(action, observation))."""
+        assert len(self.emb.layers) == 0
+        return self.ctx.buffer("critic/merged2", (2, B, self.merged), tag=tag)
+
+    def merged_buffer(self, B, tag):
+        return self.ctx.buffer("critic/merged", (1, B, self.merged), tag=tag)
+
+    def forward_pair_merged(self, merged, B, tag="pair"):
+        """forward_pair on inputs already merged by rlx_ac_merge_inputs (merged_pair_buffer)."""
+        ctx, T = self.ctx, self.T
+        xm = G.Tensor(merged, B, self.merged, 2, grad_key=(ctx, "critic/merged2", tag))
+        macts = self.mid.forward(ctx, xm, tag=tag, pair=True)
+        q = self.head.forward(ctx, macts[-1], tag=tag, pair=True)
+        m_on = xm.slice_towers(0, 1)
+        m_on.towers = 0 if T > 1 else 1
+        macts_o = [m_on] + [t.slice_towers(0, T) for t in macts[1:]]
+        return q.data.view(2, T, B), ([], macts_o, q.slice_towers(0, T), merged[0:1])
+
+    def forward_merged(self, merged, B, use_target=False, tag="q"):
+        """forward on an input already merged: merged [1, B, A + D] from merged_buffer(B, tag)."""
+        w = self.target if use_target else None
+        ctx = self.ctx
+        x = G.Tensor(merged, B, self.merged, 0 if self.T > 1 else 1, grad_key=(ctx, "critic/merged", tag))
+        macts = self.mid.forward(ctx, x, tag=tag, weights=w)
+        q = self.head.forward(ctx, macts[-1], tag=tag, weights=w)
+        return q.data.view(self.T, B), ([], macts, q, merged)
+
+    def train_backward(self, saved, targets, B, losses_done=False):
+        """accumulate_gradients for the critic loss sum_i mean((target - Q_i)^2).
+        losses_done: rlx_ac_critic_losses already wrote the loss and d loss / d Q_i into q's gradient."""
         eacts, macts, q, merged = saved
         ctx = self.ctx
         dq = q.ensure_grad()
-        for t in range(self.T):
-            self.lib.regression_loss(q.data[t], 1, targets, 1, None, B, 1, 0, 1.0, 1.0, dq[t], 1,
-                                     self.loss[t:t + 1], ctx.stream)
+        if not losses_done:
+            for t in range(self.T):
+                self.lib.regression_loss(q.data[t], 1, targets, 1, None, B, 1, 0, 1.0, 1.0, dq[t], 1,
+                                         self.loss[t:t + 1], ctx.stream)
         self.head.backward(ctx, macts[-1], q)
         need_in = len(self.emb.layers) > 0
         self.mid.backward(ctx, macts, need_input_grad=need_in)
@@ -179,7 +221,12 @@ class CriticNet(_ACBase):
         eacts, macts, q, merged = saved
         ctx = self.ctx
         dq = q.ensure_grad()
-        dq[0].fill_(1.0 / B)
+        # d mean_b(Q_1) / d Q_1 = 1/B: a constant the backward pass only reads (the head has no activation), so the
+        # cached gradient buffer of this pass is filled once per batch size
+        key = ("agrad_filled", dq.data_ptr(), B)
+        if ctx.cache.get(key) is None:
+            dq[0].fill_(1.0 / B)
+            ctx.cache[key] = True
         x1 = G.Tensor(merged, B, self.merged, 1, grad_key=(ctx, "critic/merged", "agrad"))
         acts = [x1] + [a.tower(0) for a in macts[1:]]
         self.head.backward(ctx, acts[-1], q.tower(0), need_dx=True, t0=0, nt=1, need_dw=False)
@@ -307,14 +354,12 @@ class SACQNet(_ACBase):
         self.h0 = layers[0]
         self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon,
                      has_target=False)
-        self.loss = torch.zeros(2, dtype=torch.float32, device=device)
+        self.loss = torch.zeros(3, dtype=torch.float32, device=device)       # q1 loss, q2 loss, their sum
 
     def forward(self, obs, actions, B, tag="q"):
         ctx = self.ctx
-        a2 = ctx.buffer("q/actions2", (2, B, self.A), tag=tag)          # per-tower copy of the action
-        a2[0].copy_(actions)
-        a2[1].copy_(actions)
-        xa = G.Tensor(a2, B, self.A, 2, grad_key=(ctx, "q/actions2", tag))
+        # both Q towers read the SAME action batch: a shared (tower-less) input, like the observation
+        xa = G.Tensor(actions.view(1, B, self.A), B, self.A, 0, grad_key=(ctx, "q/actions", tag))
         ho = self.obs_fc.forward(ctx, self._obs(obs, B), tag=tag)
         ha = self.act_fc.forward(ctx, xa, tag=tag)
         h = ctx.buffer("q/sum", (2, B, self.h0), tag=tag)
@@ -333,29 +378,33 @@ class SACQNet(_ACBase):
         for i in reversed(range(len(self.fcs))):
             self.fcs[i].backward(ctx, acts[i], acts[i + 1], **kw)
         dh = acts[0].grad
-        ho.ensure_grad().copy_(dh)
-        ha.ensure_grad().copy_(dh)
+        # h = relu(obs_fc) + relu(act_fc): each branch multiplies dh by ITS relu mask in place, so the two need
+        # separate buffers only when both are propagated (training pass)
         if need_dw:
+            ho.ensure_grad().copy_(dh)
             self.obs_fc.backward(ctx, self._obs(obs, B), ho, need_dx=False)
+        ha.grad = dh
         self.act_fc.backward(ctx, xa, ha, need_dx=need_action_grad, **kw)
 
     def train_backward(self, saved, targets, B):
         """loss = 0.5*mean((q1 - y)^2) + 0.5*mean((q2 - y)^2)  (sac_q_head.py:91-95)."""
         q = saved[4]
         dq = q.ensure_grad()
-        for t in range(2):
-            self.lib.regression_loss(q.data[t], 1, targets, 1, None, B, 1, 0, 0.5, 1.0, dq[t], 1,
-                                     self.loss[t:t + 1], self.ctx.stream)
+        if targets is not None:        # None: rlx_ac_critic_losses already wrote the losses and dq
+            for t in range(2):
+                self.lib.regression_loss(q.data[t], 1, targets, 1, None, B, 1, 0, 0.5, 1.0, dq[t], 1,
+                                         self.loss[t:t + 1], self.ctx.stream)
         self._backward(saved, B, True, False)
 
-    def action_gradient(self, saved, B, out):
-        """gradients_wrt_inputs[1]['output_0_0'] = d mean(min(q1,q2)) / d action (:216-217)."""
+    def action_gradient(self, saved, B, out, dq_done=False):
+        """gradients_wrt_inputs[1]['output_0_0'] = d mean(min(q1,q2)) / d action (:216-217) -> out [B, A].
+        dq_done: the caller (rlx_sac_min_targets) already wrote d mean(min) / d q_i into q's gradient."""
         xa, q = saved[2], saved[4]
         ctx = self.ctx
         dq = q.ensure_grad()
-        qv = q.data.view(2, B)
-        self.lib.min_pair(qv[0], qv[1], None, dq.view(2, B)[0], dq.view(2, B)[1], 1.0 / B, B, ctx.stream)
+        if not dq_done:
+            qv = q.data.view(2, B)
+            self.lib.min_pair(qv[0], qv[1], None, dq.view(2, B)[0], dq.view(2, B)[1], 1.0 / B, B, ctx.stream)
+        xa.grad = out.view(1, B, self.A)            # the shared input's gradient sums the towers (Dense.backward)
         self._backward(saved, B, False, True)
-        g = xa.grad
-        self.lib.axpby(out, 1.0, g[0], 1.0, g[1], B * self.A, ctx.stream)
         return out

@@ -292,6 +292,7 @@ class DQNNet(_NetBase):
         self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
         self.loss = torch.zeros(1, dtype=torch.float32, device=device)
         self._fused = self._fused_mlp_setup()
+        self._act = self._act_setup()
 
     # ---------------------------------------------------------------- fused small-MLP update (one launch)
     def _fused_mlp_setup(self):
@@ -317,6 +318,33 @@ class DQNNet(_NetBase):
                     sync=torch.zeros(4, dtype=torch.int32, device=self.device),
                     offs=(off(ls[0].kname), off(ls[0].bname), off(ls[1].kname), off(ls[1].bname),
                           off(self.q_head.kname), off(self.q_head.bname)))
+
+    def _act_setup(self):
+        """the same network shape qualifies for rlx_mlp_q_act: Q(s) of a few envs + the epsilon-greedy choice as one
+        launch (RLX_NO_FUSED_ACT=1 keeps the layer launches + rlx_egreedy)."""
+        import os
+        if os.environ.get("RLX_NO_FUSED_ACT", "0") == "1" or self.image or self.dueling:
+            return None
+        ls = self.torso.layers
+        if len(ls) != 2 or any(not isinstance(l, G.Dense) or l.act != "relu" or l.T != 1 for l in ls):
+            return None
+        if getattr(self.q_head, "act", None) is not None:
+            return None
+        off = lambda name: self.params.entries[name][0]
+        return dict(dims=(ls[0].K, ls[0].N, ls[1].N),
+                    offs=(off(ls[0].kname), off(ls[0].bname), off(ls[1].kname), off(ls[1].bname),
+                          off(self.q_head.kname), off(self.q_head.bname)))
+
+    def can_act_fused(self, n_env):
+        a = self._act
+        return a is not None and bool(self.lib.rlx_mlp_q_act_supported(int(n_env), *a["dims"], self.A))
+
+    def q_act(self, states, n_env, explore_u, random_act, tie_rand, epsilon, q_out, actions, use_target=False):
+        """q_out [n_env, A] = Q(states); actions = rlx_egreedy on them (actions None: values only)."""
+        a = self._act
+        w = self.target if use_target else self.params.weights
+        self.lib.mlp_q_act(w, *a["offs"], states, int(n_env), *a["dims"], self.A, explore_u, random_act, tie_rand,
+                           float(epsilon), q_out, actions, self.ctx.stream)
 
     def _fused_learn(self, obs, next_obs, B, actions, rewards, game_overs, discount, w, td_errors, double_dqn,
                      grad_scale):

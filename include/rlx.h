@@ -159,6 +159,30 @@ int rlx_episode_stats_step(const float *reward, const unsigned char *game_over, 
                            int *ep_len, int n_env, double *acc, double *last_return,
                            int *last_len, void *stream);             /* agents/agent.py:558-601,509-556 totals */
 
+/* Everything an agent does with one environment response (Agent.observe, agents/agent.py:905-973: reward filters,
+ * episode totals, the transition store, the next current state) for up to 1024 vector-observation envs as ONE
+ * launch: rlx_reward_filter -> rlx_episode_stats_step -> rlx_copy_columns (action, filtered reward, stored_game_over,
+ * current state, next state -> replay row dst_rows[e]) -> rlx_select_rows (cur_state <- reset_obs where game_over).
+ * mem_obs == NULL skips the store (evaluation).  Identical arithmetic to the four entry points it replaces. */
+typedef struct rlx_observe_desc {
+    const float *reward;                 /* [n_env] env rewards                                  */
+    float *filtered_reward;              /* [n_env] out                                          */
+    double reward_rescale;
+    int has_clip;
+    double clip_low, clip_high;
+    const unsigned char *game_over;      /* [n_env] episode ends (statistics, next current state) */
+    const unsigned char *stored_game_over; /* [n_env] what the replay records (TD3 clears time-limit ends) */
+    double *ep_return; int *ep_len; double *acc; double *last_return; int *last_len;   /* rlx_episode_stats_step */
+    const void *actions; long long action_row_bytes;
+    void *cur_state; const void *next_obs; const void *reset_obs; long long obs_row_bytes;
+    void *mem_action; float *mem_reward; unsigned char *mem_game_over; void *mem_obs; void *mem_next_obs;
+    const int *dst_rows;                 /* [n_env] device: replay row of every env's transition  */
+    long long mem_rows;
+    int *status;                         /* bit 1: destination row out of range                   */
+    int n_env;
+} rlx_observe_desc;
+int rlx_observe_step(const rlx_observe_desc *desc_host, void *stream);
+
 /* --------------------------------------------------- agent targets (K7 / K10) -- */
 /* td_targets holds Q_online(s,.) on entry (fp32 [batch, n_actions]); column actions[i] of row i is
  * replaced by r + (1-done)*discount*Q_target(s', argmax_a q_next_selector(s',a)); td_errors (fp64,
@@ -191,6 +215,24 @@ int rlx_ac_td_targets(const float *rewards, const unsigned char *game_overs, con
                       int q_stride, double discount, int use_non_zero_discount_for_terminal_states,
                       int has_clip, double clip_low, double clip_high, int batch,
                       float *td_targets, void *stream);              /* agents/ddpg_agent.py:156-164, td3_agent.py:171-180, soft_actor_critic_agent.py:265-266 */
+/* One launch for min(q_next1, q_next2) (q_next2 NULL: q_next1), rlx_ac_td_targets and the mean-squared-error
+ * loss + gradient of n_streams critic outputs q [n_streams][batch] against those targets (rlx_regression_loss with
+ * loss_weight, grad_scale 1): loss[t] per stream, loss[n_streams] = their sum in stream order (the logged total
+ * critic loss, td3_agent.py:176-180 / sac_q_head.py:91-95).  q_min_out may be NULL.  batch <= 1024. */
+int rlx_ac_critic_losses(const float *q_next1, const float *q_next2, const float *rewards,
+                         const unsigned char *game_overs, double discount,
+                         int use_non_zero_discount_for_terminal_states, int has_clip, double clip_low,
+                         double clip_high, const float *q, int n_streams, int batch, float loss_weight,
+                         float *q_min_out, float *td_targets, float *dq, float *loss, void *stream);
+/* The critic's merged inputs (concat(action, observation embedding), general_network.py:251,270-277) of the online
+ * pass on (s, a) and the target pass on (s', a'): merged2 [2][batch][action_dim + obs_dim]; a' = next_actions with
+ * the TD3 target-policy smoothing of rlx_td3_smooth_actions when noise != NULL.  merged_obs_only (may be NULL)
+ * [batch][action_dim + obs_dim]: only its observation columns are written (the input of the action-gradient pass,
+ * whose action columns the caller fills with the online actor's output). */
+int rlx_ac_merge_inputs(const float *actions, const float *obs, const float *next_actions, const double *noise,
+                        double noise_clipping, const float *action_low, const float *action_high,
+                        const float *next_obs, int batch, int action_dim, int obs_dim, float *merged2,
+                        float *merged_obs_only, void *stream);
 int rlx_td3_smooth_actions(const float *next_actions, const double *noise, double noise_clipping,
                            const float *action_low, const float *action_high, int batch,
                            int action_dim, float *out, void *stream); /* agents/td3_agent.py:162-165 */
@@ -310,6 +352,15 @@ typedef struct rlx_mlp_dqn_desc {
 int rlx_mlp_dqn_supported(int batch, int obs_dim, int h1, int h2, int n_actions);   /* 1 / 0 (a value, not a status) */
 int rlx_mlp_dqn_workspace_floats(int h1, int h2, int n_actions, long long *floats_host);
 int rlx_mlp_dqn_update(const rlx_mlp_dqn_desc *desc_host, void *stream);
+/* Acting with the same network: q_out [n_env][n_actions] = Q(states) (may be NULL) and, when actions != NULL, the
+ * epsilon-greedy choice of rlx_egreedy on those values — one launch of one workgroup for n_env <= 8 envs
+ * (agents/dqn_agent.py choose_action + exploration_policies/e_greedy.py:84-101).  Weights at the element offsets
+ * off_* of the flat parameter buffer, [in][out] storage. */
+int rlx_mlp_q_act_supported(int n_env, int obs_dim, int h1, int h2, int n_actions);   /* 1 / 0 (a value) */
+int rlx_mlp_q_act(const float *weights, long long off_w1, long long off_b1, long long off_w2, long long off_b2,
+                  long long off_w3, long long off_b3, const float *states, int n_env, int obs_dim, int h1, int h2,
+                  int n_actions, const double *explore_uniforms, const int *random_actions,
+                  const double *tie_break_uniforms, double epsilon, float *q_out, int *actions, void *stream);
 
 /* Narrow dense layers (1 <= N <= 16 outputs: value / policy / Q heads) as coalesced fp32 FMA
  * kernels instead of MFMA tiles (heads/v_head.py:43-48, ppo_head.py:100-116, q_head.py,
@@ -440,6 +491,10 @@ int rlx_axpby(float *out, float a, const float *x, float b, const float *y, long
  * heads/sac_q_head.py:84-88, heads/td3_v_head.py:54-58 */
 int rlx_min_pair(const float *q1, const float *q2, float *out_min, float *grad1, float *grad2,
                  float grad_scale, int n, void *stream);
+/* rlx_min_pair + rlx_sac_value_targets in one launch (soft_actor_critic_agent.py:198-200,216-217,244):
+ * out_min = min(q1, q2), value_targets = out_min - sampled_logprob, grad_i = grad_scale * d sum(min) / d q_i. */
+int rlx_sac_min_targets(const float *q1, const float *q2, const float *sampled_logprob, float grad_scale, int n,
+                        float *out_min, float *value_targets, float *grad1, float *grad2, void *stream);
 int rlx_select_rows(const unsigned char *mask, const void *if_set, const void *if_clear, void *out,
                     int n, long long row_bytes, void *stream);   /* out[r] = mask[r] ? if_set[r] : if_clear[r] */
 /* SACPolicyHead (heads/sac_head.py:60-97): mu_logsig [batch, 2*action_dim] is the head's dense

@@ -246,7 +246,8 @@ def test_sac_update_matches_oracle(dev, resample, paired, dims):
         assert np.all(np.abs(vt - r["value_targets"]) <= 2e-4 * np.abs(r["value_targets"]) + 2e-5 + cond), \
             np.abs(vt - r["value_targets"]).max()
         np.testing.assert_allclose(ag.td_targets.cpu().numpy(), r["td_targets"], rtol=2e-4, atol=2e-5)
-        np.testing.assert_allclose(float(qn.loss.sum()), r["loss"], rtol=3e-4)
+        np.testing.assert_allclose(float(qn.loss[:2].sum()), r["loss"], rtol=3e-4)
+        assert float(qn.loss[2]) == float(qn.loss[0] + qn.loss[1])
         np.testing.assert_allclose(float(vn.loss), r["v_loss"], rtol=3e-4)
         ag.update_target_networks(0.005); ov.mix_target(0.005)
     _check_weights(pol, op, atol=5e-5)
