@@ -95,6 +95,9 @@ def _capture(fn):
 
 
 class ClippedPPOAgent(object):
+    ragged = False          # envs end their episodes on different steps (set per instance from the env)
+    _device_env = True
+
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         self.ap = agent_parameters
         self.env = environment
@@ -133,6 +136,16 @@ class ClippedPPOAgent(object):
         # whole number of episodes per env.
         per_env = -(-alg.num_consecutive_playing_steps.num_steps // self.n_env)
         self.steps_per_phase = -(-per_env // self.L) * self.L
+        # Envs that end their episodes on DIFFERENT steps (per-env time limits, emulators): the rule above becomes
+        # "train once the complete episodes hold num_consecutive_playing_steps transitions" (for one env: the
+        # reference's rule), which takes at most ceil(steps / n_env) + longest episode - 1 vector steps.
+        self._device_env = hasattr(environment, "launch_step") and hasattr(environment, "host_tick")
+        lens = getattr(environment, "lengths_host", None)
+        self.ragged = getattr(environment, "dones_host", None) is not None and \
+            (lens is None or getattr(environment, "lengths", None) is not None)     # per-env limits were declared
+        if self.ragged:
+            longest = int(max(lens)) if lens is not None else int(self.L)
+            self.steps_per_phase = per_env + longest
         self.memory = DeviceEpisodicRolloutBuffer(
             self.device, self.n_env, self.steps_per_phase,
             frame_shape=ep.observation_shape if self.image else None, stack=self.stack,
@@ -209,7 +222,11 @@ class ClippedPPOAgent(object):
         # one uniform per (step, env): what the phase's np.random.choice calls consume (continuous:
         # A standard normals per (step, env) behind np.random.normal(mean, std), additive_noise.py:106)
         shape = (self.steps_per_phase, self.n_env, self.A) if self.continuous else (self.steps_per_phase, self.n_env)
-        self._uniforms = Stager(shape, f64, dev, depth=4)
+        if self.ragged:
+            # a phase's length is not known in advance: the draws of ONE step are shipped per step, so that the host
+            # stream is consumed exactly as n_env sequential np.random calls per step would
+            shape = (1,) + shape[1:]
+        self._uniforms = Stager(shape, f64, dev, depth=32 if self.ragged else 4)
         self.uniforms_all = self._uniforms.dst
 
     # ------------------------------------------------------------------------------ graph util
@@ -240,18 +257,24 @@ class ClippedPPOAgent(object):
         if self.continuous:
             mean, std = self.networks["main"].policy_mean_std(states, self.n_env)
             if self.phase == RunPhase.TRAIN:                                # additive_noise.py:99-106
-                self.lib.gaussian_action(mean, None, std, self.uniforms_all[step], self.d_low, self.d_high,
+                self.lib.gaussian_action(mean, None, std, self.uniforms_all[0 if self.ragged else step], self.d_low, self.d_high,
                                          self.n_env, self.A, self.actions, s)
             else:
                 self.actions.copy_(mean)
         else:
             probs = self.networks["main"].policy_probs(states, self.n_env)
             if self.phase == RunPhase.TRAIN:
-                self.lib.categorical_sample(probs, self.A, self.uniforms_all[step], self.n_env, self.A,
+                self.lib.categorical_sample(probs, self.A, self.uniforms_all[0 if self.ragged else step], self.n_env, self.A,
                                             self.actions, s)                # categorical.py:45-48
             else:
                 self.actions.copy_(probs.argmax(dim=1).to(torch.int32))     # :50-56
-        next_obs, reset_obs, reward, game_over = self.env.step(self.actions)
+        if self._device_env:
+            # device-resident env: the launch is part of the (captured) step, its host clock ticks in act()
+            self.env.launch_step()
+            env = self.env
+            next_obs, reset_obs, reward, game_over = env.next_obs, env.reset_obs, env.reward, env.game_over
+        else:
+            next_obs, reset_obs, reward, game_over = self.env.step(self.actions)
         has_clip = alg.reward_clipping is not None
         lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
         self.lib.reward_filter(reward, self.filtered_reward, self.n_env, alg.reward_rescale,
@@ -265,7 +288,10 @@ class ClippedPPOAgent(object):
         step = self.memory.steps
         if step >= self.memory.T:
             raise ValueError("rollout buffer is full; call train()")
-        if step == 0 and self.phase == RunPhase.TRAIN:
+        if self.ragged and self.phase == RunPhase.TRAIN:
+            self._uniforms.push(np.random.standard_normal((1, self.n_env, self.A)) if self.continuous
+                                else np.random.random_sample((1, self.n_env)))
+        elif step == 0 and self.phase == RunPhase.TRAIN:
             # draws of the whole phase, in the order n_env sequential np.random.choice calls per step
             # would make them (nothing else consumes np.random while acting)
             if self.continuous:
@@ -274,8 +300,14 @@ class ClippedPPOAgent(object):
                 u = np.random.random_sample((self.steps_per_phase, self.n_env))
             self._uniforms.push(u)
         self.ap.algorithm.clipping_decay_schedule.step()                    # choose_action (:352-354)
-        self._run(("act", step, self.phase), lambda: self._act_device(step))
+        if self._device_env:
+            self._run(("act", step, self.phase), lambda: self._act_device(step))
+            self.env.host_tick()
+        else:
+            self._act_device(step)            # CPU emulators behind the env: not a pure device step, never captured
         self.memory.steps += 1
+        if self.ragged:
+            self.memory.note_episode_ends(self.env.dones_host)
         self.env.total_steps += self.n_env
         self.total_steps_counter += self.n_env
         return self.n_env
@@ -284,6 +316,15 @@ class ClippedPPOAgent(object):
     def _should_train(self):
         """agents/agent.py:662-699 with act_for_full_episodes: enough steps AND episodes complete."""
         steps = self.ap.algorithm.num_consecutive_playing_steps.num_steps
+        if self.ragged:
+            done = self.memory.num_transitions_in_complete_episodes()
+            if done >= steps or (self.memory.steps >= self.memory.T and done > 0):
+                self.last_training_phase_step = self.total_steps_counter
+                return True
+            if self.memory.steps >= self.memory.T:
+                raise ValueError("no episode completed within %d vector steps: an episode is longer than the "
+                                 "environment's declared maximum" % self.memory.T)
+            return False
         enough = (self.total_steps_counter - self.last_training_phase_step) >= steps
         complete = self.memory.steps > 0 and self.memory.steps % self.L == 0
         if enough and complete and self.memory.num_transitions() > 0:
@@ -308,7 +349,10 @@ class ClippedPPOAgent(object):
         for c0 in range(0, n, self.chunk):
             m = min(self.chunk, n - c0)
             net.values(chunk_obs(c0, m), m, out=self.ds_value[c0:c0 + m])
-        self.lib.gae(self.ds_reward, self.ds_value, self.ds_done, None, mem.n_env, n // mem.n_env,
+        # lockstep: n_env sequences of equal length; ragged: the complete episodes back to back — ONE sequence, the scan
+        # restarts at every game_over and every listed episode ends with one
+        n_seq = 1 if self.ragged else mem.n_env
+        self.lib.gae(self.ds_reward, self.ds_value, self.ds_done, None, n_seq, n // n_seq,
                      alg.discount, alg.gae_lambda, self.ds_adv64, self.ds_vtarget, s)
         self.lib.standardize(self.ds_adv64, n, self.ds_adv, None, self.adv_stats, s)
         # old policy = target network, frozen for the whole phase (:238-241, hoisted out of the loop)

@@ -10,6 +10,11 @@ Layout (struct of arrays, one row per transition, written time-major: row = step
   action i32 / f32[A], reward f32, game_over u8
 The DATASET order the agent trains on is episode-major like the reference's `transitions` list:
 dataset index i = env * steps + step  ->  row(i) = step * n_env + env   (`dataset_rows`).
+
+Envs whose episodes end on different steps (`note_episode_ends` is then called after every step with the env front
+end's host-side `dones`): the dataset is the list of COMPLETE episodes in the order they completed (ties in env
+order — the order `store_episode` calls would arrive, episodic_experience_replay.py:264-317); the transitions of
+the still-open episodes are not part of it (num_transitions_in_complete_episodes, :84-88) and go with clean().
 """
 import numpy as np
 import torch
@@ -48,16 +53,42 @@ class DeviceEpisodicRolloutBuffer(object):
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.steps = 0
         self._rows_cache = {}
+        # ragged mode (note_episode_ends): host table of the complete episodes + ONE static device row list
+        self.ragged = False
+        self._episodes = []                                   # (env, first step, end step) in completion order
+        self._ep_start = np.zeros(n_env, dtype=np.int64)
+        self._rows_dev = None
+        self._rows_valid = -1
 
     # ---- Memory interface (memories/memory.py:41-77) ------------------------------------------
     def num_transitions(self):
+        if self.ragged:
+            return self.num_transitions_in_complete_episodes()
+        return self.steps * self.n_env
+
+    def num_transitions_in_complete_episodes(self):      # :84-88
+        if self.ragged:
+            return int(sum(b - a for _, a, b in self._episodes))
         return self.steps * self.n_env
 
     def length(self):
+        if self.ragged:
+            return len(self._episodes)
         return self.n_env if self.steps > 0 else 0
 
     def clean(self):                                     # :412-426
         self.steps = 0
+        self._episodes = []
+        self._ep_start[:] = 0
+        self._rows_valid = -1
+
+    def note_episode_ends(self, dones_host):
+        """after the store of a step: which envs' episodes ended on it (host bool[n_env]).  Switches the buffer to
+        the complete-episodes dataset."""
+        self.ragged = True
+        for e in np.nonzero(dones_host)[0]:
+            self._episodes.append((int(e), int(self._ep_start[e]), int(self.steps)))
+            self._ep_start[e] = self.steps
 
     # ---- rollout side -------------------------------------------------------------------------
     def reset(self, first_obs):
@@ -103,7 +134,22 @@ class DeviceEpisodicRolloutBuffer(object):
 
     # ---- training side ------------------------------------------------------------------------
     def dataset_rows(self):
-        """int32[n_env * steps]: storage row of dataset element i (episode-major order)."""
+        """int32[n_env * steps]: storage row of dataset element i (episode-major order).
+        Ragged mode: a static int32[cap] buffer whose first num_transitions() entries list the complete episodes."""
+        if self.ragged:
+            if self._rows_dev is None:
+                from ...staging import Stager
+                self._rows_stager = Stager((self.cap,), torch.int32, self.device, depth=4)
+                self._rows_dev = self._rows_stager.dst
+            if self._rows_valid != len(self._episodes):
+                rows = np.zeros(self.cap, dtype=np.int32)
+                parts = [np.arange(a, b, dtype=np.int64) * self.n_env + e for e, a, b in self._episodes]
+                if parts:
+                    flat = np.concatenate(parts)
+                    rows[:flat.size] = flat
+                self._rows_stager.push(rows)
+                self._rows_valid = len(self._episodes)
+            return self._rows_dev
         key = self.steps
         if key not in self._rows_cache:
             e = np.arange(self.n_env)[:, None]

@@ -195,15 +195,25 @@ class DQNOracle(_Base):
 
 
 class ClippedPPOAgentOracle:
-    """Whole Clipped-PPO iteration on the CPU for N lockstep envs: the reference's
+    """Whole Clipped-PPO iteration on the CPU for N envs: the reference's
     LevelManager.step loop (level_manager.py:215-269) + ClippedPPOAgent.train
     (clipped_ppo_agent.py:314-344) around oracle components.  Host RNG usage is the reference's:
     np.random.choice per acting env (exploration_policies/categorical.py:48), random.shuffle for the
-    dataset and per-epoch Batch.shuffle."""
+    dataset and per-epoch Batch.shuffle.
+
+    ragged=False: lockstep envs, the caller decides when to train, the dataset is env-major (every env's steps in
+    turn).  ragged=True: envs end their episodes on different steps.  The reference's rule for its one env — train
+    once >= num_consecutive_playing_steps were played AND the episode is complete, on the transitions of complete
+    episodes (agent.py:662-699, episodic_experience_replay.py:84-88) — becomes: train once the COMPLETE episodes
+    hold that many transitions; the dataset lists the episodes in the order they completed (ties in env order, as
+    `store_episode` calls would arrive), the open tails of the other envs are dropped with memory.clean()."""
 
     def __init__(self, arrays, env, n_actions, stack=4, discount=0.99, gae_lambda=0.95, batch_size=64,
                  playing_steps=2048, epochs=10, clip_eps=0.2, beta_entropy=0.01, lr=2.5e-4,
-                 reward_clip=(-1.0, 1.0), adam=(0.9, 0.99, 1e-4)):
+                 reward_clip=(-1.0, 1.0), adam=(0.9, 0.99, 1e-4), ragged=False):
+        self.ragged = ragged
+        self.episodes = []                                     # (env, first index, end index) in completion order
+        self.ep_start = [0] * env.n_env
         from .replay import StackingOracle
         self.env, self.A = env, n_actions
         self.image = env.kind == 0
@@ -250,6 +260,9 @@ class ClippedPPOAgentOracle:
             if self.reward_clip is not None:
                 r = Fl.reward_clip(r, *self.reward_clip)
             self.transitions[e].append((self.cur[e], actions[e], r, bool(done[e])))
+            if done[e]:
+                self.episodes.append((e, self.ep_start[e], len(self.transitions[e])))
+                self.ep_start[e] = len(self.transitions[e])
             if self.image:
                 ns = self.stackers[e].filter(nxt[e].reshape(self.frame_hw))
                 if done[e]:
@@ -260,10 +273,20 @@ class ClippedPPOAgentOracle:
                 self.cur[e] = rst[e] if done[e] else nxt[e]
         return actions, probs
 
+    def complete_transitions(self):
+        return sum(b - a for _, a, b in self.episodes)
+
+    def should_train(self):
+        """ragged mode: the complete episodes hold >= num_consecutive_playing_steps transitions."""
+        return self.complete_transitions() >= self.playing_steps
+
     def train(self):
         import random
         from . import returns as R
-        data = [t for e in range(self.n_env) for t in self.transitions[e]]     # episode-major
+        if self.ragged:
+            data = [t for e, a, b in self.episodes for t in self.transitions[e][a:b]]
+        else:
+            data = [t for e in range(self.n_env) for t in self.transitions[e]]     # episode-major
         states = np.stack([t[0] for t in data])
         actions = np.array([t[1] for t in data])
         rewards = np.array([t[2] for t in data], dtype=np.float64)
@@ -289,6 +312,7 @@ class ClippedPPOAgentOracle:
                 ep.append([r["surrogate"], r["entropy"], r["kl"], r["total"], r["value_loss"]])
             out.append(np.mean(np.array(ep, dtype=np.float64), 0))
         self.transitions = [[] for _ in range(self.n_env)]
+        self.episodes, self.ep_start = [], [0] * self.n_env
         return out
 
 

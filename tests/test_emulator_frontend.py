@@ -113,3 +113,50 @@ def test_dqn_agent_trains_on_the_emulator_front_end(dev):
     st = agent.episode_statistics()
     assert st["episodes"] >= 8 and agent.training_iteration >= 30
     assert torch.isfinite(agent.networks["main"].params.weights).all()
+
+
+@pytest.mark.gpu
+def test_clipped_ppo_trains_on_the_emulator_front_end(dev):
+    """The on-policy agent over the front end: lives are lost on different steps in different envs, so a rollout is
+    the set of COMPLETE episodes (ragged mode of ClippedPPOAgent / DeviceEpisodicRolloutBuffer); the GAE scan over the
+    listed episodes must restart at every episode end and the open tails must not be trained on."""
+    import torch
+    from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
+    from coach_amd.core_types import EnvironmentSteps, RunPhase
+    from coach_amd.environments.emulator_frontend import EmulatorEnvironmentParameters, EmulatorVectorEnvironment
+    from oracle import returns as R
+    p = EmulatorEnvironmentParameters([_emu(s + 20, life_every=17 + 5 * s, lives=2, game_len=70) for s in range(4)], 4,
+                                      random_initialization_steps=3, max_episode_steps=80)
+    env = EmulatorVectorEnvironment(p, dev)
+    ap = ClippedPPOAgentParameters()
+    ap.seed = 0
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(24)
+    ap.algorithm.optimization_epochs = 2
+    ap.network_wrappers["main"].batch_size = 8
+    agent = ClippedPPOAgent(ap, env, dev)
+    assert agent.ragged and not agent._device_env
+    agent.phase = env.phase = RunPhase.TRAIN
+    trained = 0
+    for _ in range(200):
+        agent.act()
+        mem = agent.memory
+        if agent._should_train():
+            n = mem.num_transitions()
+            eps = list(mem._episodes)
+            assert n >= 24 and n == sum(b - a for _, a, b in eps) and len({e for e, _, _ in eps}) >= 1
+            agent.fill_advantages()
+            done = agent.ds_done[:n].cpu().numpy().astype(bool)
+            ends = np.cumsum([b - a for _, a, b in eps]) - 1
+            assert done[ends].all() and done.sum() == len(eps)          # exactly one game_over per listed episode: its last
+            adv, vt, _ = R.fill_advantages(agent.ds_reward[:n].cpu().numpy().astype(np.float64),
+                                           agent.ds_value[:n].cpu().numpy(), done, 0.99, 0.95)
+            np.testing.assert_allclose(agent.ds_adv[:n].cpu().numpy(), adv, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(agent.ds_vtarget[:n].cpu().numpy(), vt, rtol=1e-5, atol=1e-6)
+            agent.last_training_phase_step = 0                           # let train() open the same phase again
+            res = agent.train()
+            assert res is not None and mem.steps == 0 and mem.num_transitions() == 0
+            trained += 1
+            if trained == 3:
+                break
+    assert trained == 3
+    assert torch.isfinite(agent.networks["main"].params.weights).all()

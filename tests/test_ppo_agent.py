@@ -6,12 +6,15 @@ import numpy as np
 import pytest
 
 
-def _make(dev, n_env, L, playing, batch, epochs, seed=0):
+def _make(dev, n_env, L, playing, batch, epochs, seed=0, lengths=None, kind="image"):
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
     from coach_amd.core_types import EnvironmentSteps
     from coach_amd.environments.synthetic_vector_environment import (
         SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
-    ep = SyntheticVectorEnvironmentParameters("image", n_env, (84, 84), 6, episode_length=L, seed=99)
+    shape = (84, 84) if kind == "image" else (7,)
+    ep = SyntheticVectorEnvironmentParameters(kind, n_env, shape, 6, episode_length=L, seed=99)
+    if lengths is not None:
+        ep.episode_lengths = list(lengths)
     env = SyntheticVectorEnvironment(ep, dev)
     ap = ClippedPPOAgentParameters()
     ap.seed = seed
@@ -59,6 +62,54 @@ def test_ppo_iteration_matches_oracle(rlx, dev):
                 np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
     st = agent.episode_statistics()
     assert st["episodes"] == 2 * n_env and st["mean_length"] == L
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,lengths,playing", [("vector", (5, 8, 13, 8), 40), ("image", (3, 7, 4), 18),
+                                                  ("vector", (9,), 20)])
+def test_ppo_with_envs_ending_on_different_steps_matches_oracle(rlx, dev, kind, lengths, playing):
+    """Per-env time limits: episodes end on different steps.  Training starts once the COMPLETE episodes hold
+    `playing` transitions, the dataset lists them in completion order, open tails are dropped — the oracle agent in
+    ragged mode (pinned for one env to the real reference agent's loop, tests/test_update_pins.py) must see the same
+    actions, train at the same steps and reach the same weights."""
+    from oracle.agents import ClippedPPOAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    n_env, batch, epochs = len(lengths), 8, 2
+    agent = _make(dev, n_env, max(lengths), playing, batch, epochs, seed=0, lengths=lengths, kind=kind)
+    assert agent.ragged
+    arrays = agent.networks["main"].params.named_arrays()
+    elems = 84 * 84 if kind == "image" else 7
+    oenv = SynthVecEnv(0 if kind == "image" else 1, n_env, elems, max(lengths), 99, episode_lengths=list(lengths))
+    o = ClippedPPOAgentOracle(arrays, oenv, 6, batch_size=batch, playing_steps=playing, epochs=epochs, ragged=True)
+    o.reset((84, 84) if kind == "image" else None)
+    state = (random.getstate(), np.random.get_state())
+    for it in range(3):
+        random.setstate(state[0]); np.random.set_state(state[1])
+        hip_actions = []
+        while True:
+            agent.act()
+            hip_actions.append(agent.actions.cpu().numpy().copy())
+            n_complete = agent.memory.num_transitions_in_complete_episodes()
+            res = agent.train()
+            if res is not None:
+                break
+        hip_state = (random.getstate(), np.random.get_state())
+        random.setstate(state[0]); np.random.set_state(state[1])
+        for s_ in range(len(hip_actions)):
+            assert not o.should_train(), "the oracle would have trained at step %d" % s_
+            oa, _ = o.act()
+            assert oa == hip_actions[s_].tolist(), "action selection differs at step %d" % s_
+        assert o.should_train() and o.complete_transitions() == n_complete
+        ores = o.train()
+        assert random.getstate() == hip_state[0]
+        assert np.array_equal(np.random.get_state()[1], hip_state[1][1])     # per-step draws: same np.random stream
+        state = hip_state
+        hres = np.array([r.cpu().numpy()[:5] for r in res], dtype=np.float64)
+        np.testing.assert_allclose(hres, np.array(ores), rtol=2e-3, atol=2e-5)
+        hw = agent.networks["main"].params.named_arrays()
+        for name, per_tower in o.net.weights().items():
+            for t, ref in per_tower.items():
+                np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
 
 
 @pytest.mark.gpu

@@ -378,25 +378,29 @@ def test_ppo_should_train_equals_reference_with_full_episodes():
         playing, L = (int(x) for x in fx[name + "|cfg"])
 
         class Memory(object):
-            steps = 0
+            steps, T = 0, 10 ** 9
             def num_transitions(self): return self.steps
+            def num_transitions_in_complete_episodes(self): return L * (self.steps // L)
 
         class Alg(object):
             num_consecutive_playing_steps = EnvironmentSteps(playing)
 
         class Ap(object):
             algorithm = Alg()
-        ag = ClippedPPOAgent.__new__(ClippedPPOAgent)
-        ag.ap, ag.memory, ag.L = Ap(), Memory(), L
-        ag.total_steps_counter = ag.last_training_phase_step = 0
-        opened = []
-        for t in range(80):
-            ag.total_steps_counter += 1
-            ag.memory.steps += 1
-            opened.append(int(ag._should_train()))
-            if opened[-1]:
-                ag.memory.steps = 0                      # post_training_commands: memory.clean()
-        np.testing.assert_array_equal(opened, fx[name + "|opened"], err_msg=name)
+        # lockstep rule, and the rule for envs that end on different steps (complete episodes hold enough
+        # transitions): for one env both are the reference's
+        for ragged in (False, True):
+            ag = ClippedPPOAgent.__new__(ClippedPPOAgent)
+            ag.ap, ag.memory, ag.L, ag.ragged = Ap(), Memory(), L, ragged
+            ag.total_steps_counter = ag.last_training_phase_step = 0
+            opened = []
+            for t in range(80):
+                ag.total_steps_counter += 1
+                ag.memory.steps += 1
+                opened.append(int(ag._should_train()))
+                if opened[-1]:
+                    ag.memory.steps = 0                      # post_training_commands: memory.clean()
+            np.testing.assert_array_equal(opened, fx[name + "|opened"], err_msg="%s ragged=%s" % (name, ragged))
 
 
 @pytest.mark.parametrize("variant", ["uniform", "per"])
@@ -442,7 +446,8 @@ def test_oracle_agent_loop_equals_real_reference_agent_loop(variant):
     assert max(visible) == CAP                                   # the buffer did wrap
 
 
-def test_oracle_ppo_agent_loop_equals_real_reference_agent_loop():
+@pytest.mark.parametrize("ragged", [False, True])
+def test_oracle_ppo_agent_loop_equals_real_reference_agent_loop(ragged):
     """oracle.agents.ClippedPPOAgentOracle (act + train, n_env = 1) against the REAL reference
     ClippedPPOAgent object (own __init__, EpisodicExperienceReplay, Categorical exploration,
     _should_train with act_for_full_episodes, train -> fill_advantages -> train_network; network = oracle
@@ -462,14 +467,16 @@ def test_oracle_ppo_agent_loop_equals_real_reference_agent_loop():
     random.seed(SEED)
     np.random.seed(SEED)
     o = ClippedPPOAgentOracle(arrays, SynthVecEnv(1, 1, D, L, 77), A, batch_size=B, playing_steps=PLAY, epochs=EPOCHS,
-                              lr=1e-3, reward_clip=None)
+                              lr=1e-3, reward_clip=None, ragged=ragged)
     o.reset()
     actions, trained_at, since = [], [], 0
     for step in range(STEPS):
         a, _ = o.act()
         actions.append(int(a[0]))
         since += 1
-        if since >= PLAY and (step + 1) % L == 0:                 # enough steps and the episode is complete
+        # lockstep: enough steps and the episode is complete; ragged: the oracle's own rule (complete episodes hold
+        # enough transitions) — for ONE env the two are the reference's rule
+        if o.should_train() if ragged else (since >= PLAY and (step + 1) % L == 0):
             o.train()
             trained_at.append(step)
             since = 0
