@@ -273,8 +273,9 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
          deriv_aux=None, aux_ld=None, deriv_kind=None, accumulate=False, batch=1,
          a_batch_stride=0, b_batch_stride=0, c_batch_stride=0, bias_batch_stride=0,
          aux_batch_stride=0, workspace=None, colsum_out=None, colsum_batch_stride=0, stream=None,
-         batch_inner=0, a_batch_stride2=0, b_batch_stride2=0, bias_batch_stride2=0, n_fold=0):
-    """Thin wrapper building an rlx_gemm_desc.  a_strides=(row, k), b_strides=(k, n) in elements."""
+         batch_inner=0, a_batch_stride2=0, b_batch_stride2=0, bias_batch_stride2=0, n_fold=0, launch=True):
+    """Thin wrapper building an rlx_gemm_desc.  a_strides=(row, k), b_strides=(k, n) in elements.
+    launch=False: return the descriptor (for gemm_pair) instead of running it."""
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = int(M), int(N), int(K), int(batch)
     d.A, d.B, d.C = _ptr(A), _ptr(B), _ptr(C)
@@ -303,6 +304,24 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
     d.a_batch_stride2, d.b_batch_stride2 = int(a_batch_stride2), int(b_batch_stride2)
     d.bias_batch_stride2 = int(bias_batch_stride2)
     d.n_fold = int(n_fold)
+    if not launch:
+        return d
     if GEMM_HOOK is not None:
         GEMM_HOOK(GemmDesc.from_buffer_copy(d))
     lib().gemm(ctypes.byref(d), current_stream() if stream is None else stream)
+
+
+def gemm_pair_or_single(desc, stream=None):
+    """run one descriptor built with gemm(..., launch=False)."""
+    if GEMM_HOOK is not None:
+        GEMM_HOOK(GemmDesc.from_buffer_copy(desc))
+    lib().gemm(ctypes.byref(desc), current_stream() if stream is None else stream)
+
+
+def gemm_pair(weight_grad, input_grad, stream=None):
+    """two descriptors built with gemm(..., launch=False): a layer's dW and dX products as one launch."""
+    if GEMM_HOOK is not None:
+        GEMM_HOOK(GemmDesc.from_buffer_copy(weight_grad))
+        GEMM_HOOK(GemmDesc.from_buffer_copy(input_grad))
+    lib().gemm_pair(ctypes.byref(weight_grad), ctypes.byref(input_grad),
+                    current_stream() if stream is None else stream)

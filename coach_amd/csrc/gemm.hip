@@ -314,32 +314,39 @@ template <> struct ARaw<true> { typedef Raw1 type; };
 // reads per MFMA halve and a workgroup carries 4x the MFMA work per prologue/epilogue — what the
 // short-K (K = 64) input-gradient GEMMs need.
 // (one accumulator tile per wave: at most 168 registers, so that three workgroups share a CU)
+// The body of one workgroup; (bx, by, bz) of a grid (gdx, gdy, .) are passed in so that ONE launch can carry the
+// workgroups of two independent problems (gemm_fast_pair_kernel).  smem / lut / tab_s: the caller's LDS.
+template <int BM, int BN, int TM, int TN>
+struct FastTile {
+    static constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+    static constexpr int A_BUF = BK * LDA_S, B_BUF = BK * LDB_S;
+    static constexpr int kSmemFloats = 2 * A_BUF + 2 * B_BUF;
+};
+
 template <int BM, int BN, int TM, int TN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
-__global__ void __launch_bounds__(kThreads, (TM * TN == 1 ? 3 : 1)) gemm_fast_kernel(const GemmDev g) {
+__device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, const int by, const int bz,
+                                               const int gdx, const int gdy, float *const smem, float *const lut,
+                                               int *const tab_s) {
     constexpr int WN = BN / (32 * TN);
     static_assert((BM / (32 * TM)) * WN == 4, "a workgroup is 4 waves");
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
     constexpr int NA = BM * BK / 4 / kThreads;
     constexpr int NB = BN * BK / 4 / kThreads;
     constexpr int A_BUF = BK * LDA_S, B_BUF = BK * LDB_S;
-    __shared__ __attribute__((aligned(16))) float smem[2 * A_BUF + 2 * B_BUF];
     float *const As = smem;
     float *const Bs = smem + 2 * A_BUF;
     static_assert(4 * 32 * 33 <= 2 * A_BUF + 2 * B_BUF, "epilogue staging fits in the operand buffers");
-    __shared__ float lut[A_U8 ? 256 : 1];
-    __shared__ int tab_s[A_TAB ? kTabChunk : 1];     // reduction-index offsets of this workgroup's K chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bz = blockIdx.z;
     const int batch = bz / g.splits, split = bz - batch * g.splits;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     // phase stamps of every workgroup (entry, first slab staged, main loop done, exit) — tools/gemm_timeline.py
     unsigned long long *const stamp = g.stamps && tid == 0
-        ? g.stamps + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
+        ? g.stamps + 4 * ((size_t)(bz * gdy + by) * gdx + bx) : nullptr;
     if (stamp) stamp[0] = wall_clock64();
     if (A_U8) {
         lut[tid] = (float)tid / g.a_div;        // kThreads == 256
@@ -462,7 +469,7 @@ __global__ void __launch_bounds__(kThreads, (TM * TN == 1 ? 3 : 1)) gemm_fast_ke
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
+    const bool do_colsum = g.colsum != nullptr && by == 0 && tid < BN;
     float csum = 0.f;
 
     if (kbeg < kend) {
@@ -644,6 +651,40 @@ __global__ void __launch_bounds__(kThreads, (TM * TN == 1 ? 3 : 1)) gemm_fast_ke
         }
     }
     if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
+}
+
+template <int BM, int BN, int TM, int TN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
+__global__ void __launch_bounds__(kThreads, (TM * TN == 1 ? 3 : 1)) gemm_fast_kernel(const GemmDev g) {
+    __shared__ __attribute__((aligned(16))) float smem[FastTile<BM, BN, TM, TN>::kSmemFloats];
+    __shared__ float lut[A_U8 ? 256 : 1];
+    __shared__ int tab_s[A_TAB ? kTabChunk : 1];     // reduction-index offsets of this workgroup's K chunk
+    gemm_fast_body<BM, BN, TM, TN, A_VEC_RED, A_U8, B_VEC_RED, A_TAB>(g, blockIdx.x, blockIdx.y, blockIdx.z,
+                                                                       gridDim.x, gridDim.y, smem, lut, tab_s);
+}
+
+// Two INDEPENDENT problems in one launch — a layer's weight gradient (dW = X^T dY) and its input gradient
+// (dX = dY W^T) read the same dY and feed different consumers: as two launches they run one after the other, each
+// too small to fill the chip (profiles/r02_gemm_timeline_*.txt), as one they share it and one launch boundary
+// disappears.  Workgroups [0, n0) belong to problem 0 (grid g0x x g0y x g0z), the rest to problem 1.
+struct GemmPairDev {
+    GemmDev g[2];
+    int gx[2], gy[2];
+    int n0;
+};
+template <bool A_TAB0>
+__global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmPairDev p) {
+    __shared__ __attribute__((aligned(16))) float smem[FastTile<64, 64, 1, 1>::kSmemFloats];
+    __shared__ float lut[1];
+    __shared__ int tab_s[A_TAB0 ? kTabChunk : 1];
+    int flat = blockIdx.x;
+    const int which = flat >= p.n0;
+    if (which) flat -= p.n0;
+    const int gx = p.gx[which], gy = p.gy[which];
+    const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
+    if (!which)      // weight gradient: A = X^T (vector along the outer index; im2col tables for a convolution)
+        gemm_fast_body<64, 64, 1, 1, false, false, false, A_TAB0>(p.g[0], bx, by, bz, gx, gy, smem, lut, tab_s);
+    else             // input gradient: A = dY (vector along k), B = W^T
+        gemm_fast_body<64, 64, 1, 1, true, false, true, false>(p.g[1], bx, by, bz, gx, gy, smem, lut, tab_s);
 }
 
 
@@ -1089,7 +1130,37 @@ int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_
     return RLX_OK;
 }
 
-int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
+}  // extern "C"
+
+namespace {
+// what rlx_gemm decided for one descriptor: everything a launch needs (gemm_impl in planning mode fills it instead
+// of launching; rlx_gemm_pair launches two plans as one grid)
+struct GemmPlan {
+    bool tiled_fast;            // the fast tiled kernel with 64x64 tiles would run (else: thin / generic / folded paths)
+    GemmDev g;
+    dim3 grid;
+    bool a_vec_red, u8, b_vec_red, a_tab;
+    int splits, M, N, batch;
+};
+
+int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, hipStream_t s) {
+    const long long mn = (long long)M * N;
+    if (N % 4 == 0 && mn < (1LL << 31) && aligned16(g.ws)) {
+        dim3 rgrid((unsigned)((mn / 4 + 63) / 64), batch);
+        if (splits > 16)
+            splitk_reduce4_kernel<16><<<rgrid, 1024, 0, s>>>(g);
+        else
+            splitk_reduce4_kernel<4><<<rgrid, 256, 0, s>>>(g);
+    } else {
+        dim3 rgrid(rlx::grid_for(mn, 256, 1024), batch);
+        splitk_reduce_kernel<<<rgrid, 256, 0, s>>>(g);
+    }
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
+    if (plan) plan->tiled_fast = false;
     RLX_REQUIRE(d_host != nullptr, "rlx_gemm: null descriptor");
     const rlx_gemm_desc &d = *d_host;
     RLX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0,
@@ -1143,6 +1214,7 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     if (!rlx_no_thin_gemm() && !d.a_row_tab && !d.a_k_tab && !d.a_is_u8 && d.n_fold <= 0 && d.K <= 1024) {
         const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
         if (t64 <= 64 && (long long)d.N * d.K <= (1 << 18)) {      // MLP-sized weights only: the scalar loads lose on wide B
+            if (plan) return RLX_OK;
             const bool a_ck = d.a_k_stride == 1, b_cn = d.b_n_stride == 1;
             dim3 tgrid((d.N + 31) / 32, (d.M + 31) / 32, d.batch);
             g.splits = 1; g.kchunk = d.K; g.ws = nullptr; g.vec_epi = 0; g.fold = 0;
@@ -1225,8 +1297,19 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
             t.N = g.fold;
             t.n_fold = 0;
             t.a_batch_stride = 0;
-            return rlx_gemm(&t, stream);
+            if (plan) return RLX_OK;
+            return gemm_impl(&t, stream, nullptr);
         }
+    }
+    if (plan) {
+        if (fast && BM == 64 && BN == 64 && !g.fold) {
+            plan->tiled_fast = true;
+            plan->g = g;
+            plan->grid = grid;
+            plan->a_vec_red = a_vec_red; plan->u8 = d.a_is_u8 != 0; plan->b_vec_red = b_vec_red; plan->a_tab = a_tab;
+            plan->splits = splits; plan->M = d.M; plan->N = d.N; plan->batch = d.batch;
+        }
+        return RLX_OK;
     }
     if (g_stamps.buf && fast) {
         const long long need = 4LL * grid.x * grid.y * grid.z;
@@ -1252,20 +1335,50 @@ int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     }
     RLX_REQUIRE(rc == 0, "rlx_gemm: unsupported operand combination (uint8 A with transposed B)");
     RLX_LAUNCH_CHECK();
-    if (splits > 1) {
-        const long long mn = (long long)d.M * d.N;
-        if (d.N % 4 == 0 && mn < (1LL << 31) && aligned16(g.ws)) {
-            dim3 rgrid((unsigned)((mn / 4 + 63) / 64), d.batch);
-            if (splits > 16)
-                splitk_reduce4_kernel<16><<<rgrid, 1024, 0, s>>>(g);
-            else
-                splitk_reduce4_kernel<4><<<rgrid, 256, 0, s>>>(g);
-        } else {
-            dim3 rgrid(rlx::grid_for(mn, 256, 1024), d.batch);
-            splitk_reduce_kernel<<<rgrid, 256, 0, s>>>(g);
-        }
-        RLX_LAUNCH_CHECK();
+    if (splits > 1) return launch_splitk_reduce(g, d.M, d.N, d.batch, splits, s);
+    return RLX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) { return gemm_impl(d_host, stream, nullptr); }
+
+int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream) {
+    GemmPlan pw, px;
+    int rc = gemm_impl(weight_grad, stream, &pw);
+    if (rc != RLX_OK) return rc;
+    rc = gemm_impl(input_grad, stream, &px);
+    if (rc != RLX_OK) return rc;
+    static const bool off = [] { const char *e = getenv("RLX_NO_GEMM_PAIR"); return e && e[0] == '1'; }();
+    const bool pairable = !off && pw.tiled_fast && px.tiled_fast &&
+                          !pw.a_vec_red && !pw.u8 && !pw.b_vec_red &&                 // X^T dY
+                          px.a_vec_red && !px.u8 && px.b_vec_red && !px.a_tab &&       // dY W^T
+                          true;
+    // both problems may split K: their partials must not share workspace memory
+    const bool ws_clash = pw.splits > 1 && px.splits > 1 && pw.g.ws == px.g.ws;
+    if (!pairable || ws_clash) {
+        rc = gemm_impl(weight_grad, stream, nullptr);
+        if (rc != RLX_OK) return rc;
+        return gemm_impl(input_grad, stream, nullptr);
     }
+    GemmPairDev p;
+    p.g[0] = pw.g; p.g[1] = px.g;
+    p.gx[0] = pw.grid.x; p.gy[0] = pw.grid.y; p.gx[1] = px.grid.x; p.gy[1] = px.grid.y;
+    p.n0 = (int)(pw.grid.x * pw.grid.y * pw.grid.z);
+    const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
+    hipStream_t s = rlx::as_stream(stream);
+    if (pw.a_tab)
+        gemm_fast_pair_kernel<true><<<total, kThreads, 0, s>>>(p);
+    else
+        gemm_fast_pair_kernel<false><<<total, kThreads, 0, s>>>(p);
+    RLX_LAUNCH_CHECK();
+    if (pw.splits > 1) {
+        rc = launch_splitk_reduce(pw.g, pw.M, pw.N, pw.batch, pw.splits, s);
+        if (rc != RLX_OK) return rc;
+    }
+    if (px.splits > 1) return launch_splitk_reduce(px.g, px.M, px.N, px.batch, px.splits, s);
     return RLX_OK;
 }
 

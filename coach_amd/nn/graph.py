@@ -105,6 +105,11 @@ def normalized_columns(std):
     return init
 
 
+# a layer's dW and dX products (independent, same dz) go out as ONE launch (rlx_gemm_pair); the tests switch it off to
+# compare with the two-launch sequence
+PAIR_GRADIENT_GEMMS = True
+
+
 class Workspace:
     def __init__(self, device, floats=1 << 24):
         self.splitk = torch.empty(floats, dtype=torch.float32, device=device)
@@ -287,6 +292,7 @@ class Dense(Layer):
         overlap: issue the dW GEMM on the context's side stream (the caller joins)."""
         t0, T = self._range(t0, nt)
         M, p = x.rows, self.params
+        overlap = overlap and ctx.overlap
         dz = y.grad
         own_act = self.act if (self.act is not None and not y.grad_is_dz) else None
         lower = x.act if need_dx else None           # fuse the lower layer's act' into dx
@@ -313,20 +319,22 @@ class Dense(Layer):
         if need_dw:
             fold = x.towers == 0 and T > 1 and self.N % 4 == 0 and FOLD_SHARED_INPUT
 
-            def dw(ws):
+            def dw(ws, launch=True):
                 if fold:       # shared input: dW of all towers = x^T [dz_0 | dz_1 | ...] in one GEMM
-                    _rlx.gemm(self.K, T * self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K),
-                              b_strides=(self.N, 1), ldc=self.N, batch=1, b_batch_stride=M * self.N,
-                              c_batch_stride=p.stride(self.kname), workspace=ws, colsum_out=p.g(self.bname, t0),
-                              colsum_batch_stride=p.stride(self.bname), n_fold=self.N)
-                    return
-                _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
-                          a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
-                          c_batch_stride=p.stride(self.kname), workspace=ws,
-                          colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
+                    return _rlx.gemm(self.K, T * self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K),
+                                     b_strides=(self.N, 1), ldc=self.N, batch=1, b_batch_stride=M * self.N,
+                                     c_batch_stride=p.stride(self.kname), workspace=ws,
+                                     colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
+                                     n_fold=self.N, launch=launch)
+                return _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
+                                 a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
+                                 c_batch_stride=p.stride(self.kname), workspace=ws,
+                                 colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
+                                 launch=launch)
+            pair_dw = need_dx and not shared_dx and not overlap and PAIR_GRADIENT_GEMMS   # dW rides with the dX launch
             if overlap and need_dx:
                 ctx.on_side(dw)
-            else:
+            elif not pair_dw:
                 dw(ctx.ws.splitk)
         if shared_dx:
             # dx = sum_t dz_t W_t^T, each term already multiplied by the lower layer's act'(x)
@@ -340,11 +348,16 @@ class Dense(Layer):
             dx = x.ensure_grad()
             # dx[M,K] = dz W^T : B(n, k) = W[k, n]; the epilogue multiplies by the lower layer's
             # activation derivative, so dx IS that layer's dz (no separate act_backward launch)
-            _rlx.gemm(M, self.K, self.N, dz, p.w(self.kname, t0, weights), dx, b_strides=(1, self.N),
-                      batch=T, a_batch_stride=M * self.N, b_batch_stride=p.stride(self.kname),
-                      c_batch_stride=M * self.K, workspace=ctx.ws.splitk,
-                      deriv_aux=x.data if lower else None, aux_ld=self.K, deriv_kind=lower,
-                      aux_batch_stride=M * self.K)
+            dxd = _rlx.gemm(M, self.K, self.N, dz, p.w(self.kname, t0, weights), dx, b_strides=(1, self.N),
+                            batch=T, a_batch_stride=M * self.N, b_batch_stride=p.stride(self.kname),
+                            c_batch_stride=M * self.K, workspace=ctx.ws.splitk,
+                            deriv_aux=x.data if lower else None, aux_ld=self.K, deriv_kind=lower,
+                            aux_batch_stride=M * self.K, launch=False)
+            if need_dw and not overlap and PAIR_GRADIENT_GEMMS:
+                # dW and dX are independent products of the same dz: one launch (own split-K workspaces)
+                _rlx.gemm_pair(dw(ctx.ws.splitk_side, launch=False), dxd)
+            else:
+                _rlx.gemm_pair_or_single(dxd)
             x.grad_is_dz = lower is not None
 
 
@@ -414,6 +427,8 @@ class Conv2d(Layer):
     def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
         t0, T = self._range(t0, nt)
         B, p = x.rows, self.params
+        overlap = overlap and ctx.overlap
+        pairing = need_dx and need_dw and not overlap and PAIR_GRADIENT_GEMMS
         M = B * self.OH * self.OW
         rb, ko = self._tables(ctx, B)
         dz = y.grad
@@ -424,30 +439,35 @@ class Conv2d(Layer):
         if need_dw:
             fold = x.towers == 0 and T > 1 and self.Co % 4 == 0 and self.C % 4 == 0 and FOLD_SHARED_INPUT
 
-            def dw(ws):
+            def dw(ws, launch=True):
                 if fold:
-                    _rlx.gemm(self.K, T * self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb),
-                              a_u8=x.u8, a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=1, b_strides=(self.Co, 1),
-                              ldc=self.Co, batch=1, b_batch_stride=M * self.Co,
-                              c_batch_stride=p.stride(self.kname), workspace=ws,
-                              colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
-                              n_fold=self.Co)
-                    return
-                _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
-                          a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
-                          a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
-                          c_batch_stride=p.stride(self.kname), workspace=ws,
-                          colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname))
+                    return _rlx.gemm(self.K, T * self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb),
+                                     a_u8=x.u8, a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=1, b_strides=(self.Co, 1),
+                                     ldc=self.Co, batch=1, b_batch_stride=M * self.Co,
+                                     c_batch_stride=p.stride(self.kname), workspace=ws,
+                                     colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
+                                     n_fold=self.Co, launch=launch)
+                return _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
+                                 a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
+                                 a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
+                                 c_batch_stride=p.stride(self.kname), workspace=ws,
+                                 colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
+                                 launch=launch)
             if overlap:
                 ctx.on_side(dw)          # also when this is the first layer: it overlaps the layers above
-            else:
+            elif not pairing:
                 dw(ctx.ws.splitk)
         if need_dx:
             assert x.towers == T
             dcol = ctx.buffer(self.name + "/dcol", (T, M, self.K))
-            _rlx.gemm(M, self.K, self.Co, dz, p.w(self.kname, t0, weights), dcol, b_strides=(1, self.Co),
-                      batch=T, a_batch_stride=M * self.Co, b_batch_stride=p.stride(self.kname),
-                      c_batch_stride=M * self.K, workspace=ctx.ws.splitk)
+            dxd = _rlx.gemm(M, self.K, self.Co, dz, p.w(self.kname, t0, weights), dcol, b_strides=(1, self.Co),
+                            batch=T, a_batch_stride=M * self.Co, b_batch_stride=p.stride(self.kname),
+                            c_batch_stride=M * self.K, workspace=ctx.ws.splitk, launch=False)
+            if pairing:
+                # dW and dcol are independent products of the same dz: one launch (own split-K workspaces)
+                _rlx.gemm_pair(dw(ctx.ws.splitk_side, launch=False), dxd)
+            else:
+                _rlx.gemm_pair_or_single(dxd)
             dx = x.ensure_grad()
             # the gather also applies the producing layer's activation derivative: dx is its dz
             lower = x.act

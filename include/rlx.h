@@ -313,6 +313,10 @@ typedef struct rlx_gemm_desc {
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
 int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host);
+/* A layer's weight gradient (dW = X^T dY) and input gradient (dX = dY W^T) — two independent products of the same
+ * dY — as ONE launch when both take the 64x64 tiled kernel (two launches otherwise; RLX_NO_GEMM_PAIR=1 forces that).
+ * Each descriptor is exactly what rlx_gemm would get; when both split K they need disjoint workspaces. */
+int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream);
 /* Diagnostics (tools/gemm_timeline.py): while a device buffer of `capacity_u64` 64-bit words is registered, every
  * tiled-kernel launch of rlx_gemm records, per workgroup, four wall-clock ticks (10 ns: entry, first slab staged,
  * main loop done, exit) in its own region of the buffer; rlx_gemm_debug_calls lists the regions as rows of

@@ -247,3 +247,44 @@ def test_gemm_thin_all_layouts(rlx, dev, M, N, K):
             gemm(M, N, K, Ad, Bd, C, deriv_aux=dev_tensor(aux, dev), aux_ld=N, aux_batch_stride=M * N,
                  deriv_kind="tanh", accumulate=True, **kw)
             np.testing.assert_allclose(C.cpu().numpy(), 2 * ref * (1 - aux.astype(np.float64) ** 2), **_tol(K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense", "conv"])
+def test_weight_and_input_gradient_as_one_launch_equals_two(rlx, dev, kind):
+    """rlx_gemm_pair (a layer's dW and dX products in ONE launch) against the two launches it replaces, on the C2
+    layer shapes with two towers: weight gradients, bias gradients and input gradients bit for bit.  The layer's
+    `overlap=True` path with stream overlap switched off issues exactly the old two-launch sequence."""
+    import torch
+    from coach_amd.nn import graph as G
+    rng = np.random.RandomState(3)
+    out = {}
+    for paired in (True, False):
+        params = G.FlatParams()
+        if kind == "dense":
+            B, K, N, T = 64, 3136, 512, 2
+            layer = G.Dense(params, "fc", K, N, "relu", T)
+            x_np = rng.randn(T, B, K).astype(np.float32) if paired else x_np
+        else:
+            B, T = 64, 2
+            layer = G.Conv2d(params, "c3", (9, 9, 64), 64, 3, 1, "relu", T)
+            x_np = np.maximum(rng.randn(T, B, 9 * 9 * 64), 0).astype(np.float32) if paired else x_np
+        params.finalize(dev)
+        layer.initialize(np.random.RandomState(5))
+        ctx = G.Context(dev)
+        assert not ctx.overlap
+        x = G.Tensor(dev_tensor(x_np, dev), B, x_np.shape[2], T, act="relu")
+        y = layer.forward(ctx, x, tag="t")
+        if paired:
+            dy_np = rng.randn(*y.data.shape).astype(np.float32)
+        y.ensure_grad().copy_(dev_tensor(dy_np, dev))
+        G.PAIR_GRADIENT_GEMMS = paired
+        try:
+            layer.backward(ctx, x, y, need_dx=True)
+        finally:
+            G.PAIR_GRADIENT_GEMMS = True
+        torch.cuda.synchronize()
+        out[paired] = (params.grads.clone(), x.grad.clone())
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
+    assert float(out[True][0].abs().sum()) > 0 and float(out[True][1].abs().sum()) > 0
