@@ -698,15 +698,15 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
 // order (reproducible) before the bias / activation / derivative epilogue.  One launch, 4x the
 // workgroups of the 64x64 tiling.  Scalar (4-byte) operand loads with clamped indices: no alignment
 // or divisibility requirements.
+constexpr int kThinKS = 128, kThinLD = 33;
 template <bool A_CONTIG_K, bool B_CONTIG_N>
-__global__ void __launch_bounds__(kThreads) gemm_thin_kernel(const GemmDev g) {
-    constexpr int KS = 128, LD = 33, NE = 32 * KS / kThreads;      // 16 elements per thread per operand
-    __shared__ float As[KS * LD];
-    __shared__ float Bs[KS * LD];
+__device__ __forceinline__ void gemm_thin_body(const GemmDev &g, const int bx, const int by, const int bz,
+                                               float *const As, float *const Bs) {
+    constexpr int KS = kThinKS, LD = kThinLD, NE = 32 * KS / kThreads;      // 16 elements per thread per operand
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int batch = blockIdx.z;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int batch = bz;
+    const int m0 = by * 32, n0 = bx * 32;
     const float *abase = static_cast<const float *>(g.a.base) + batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2);
     const float *bbase = static_cast<const float *>(g.b.base) + batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2);
 
@@ -745,7 +745,7 @@ __global__ void __launch_bounds__(kThreads) gemm_thin_kernel(const GemmDev g) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0 && tid < 32;
+    const bool do_colsum = g.colsum != nullptr && by == 0 && tid < 32;
     float csum = 0.f;
     load(0);
     store();
@@ -792,6 +792,29 @@ __global__ void __launch_bounds__(kThreads) gemm_thin_kernel(const GemmDev g) {
         if (aux) v *= act_deriv(aux[col], g.deriv);
         c[col] = g.accumulate ? c[col] + v : v;
     }
+}
+
+template <bool A_CONTIG_K, bool B_CONTIG_N>
+__global__ void __launch_bounds__(kThreads) gemm_thin_kernel(const GemmDev g) {
+    __shared__ float As[kThinKS * kThinLD];
+    __shared__ float Bs[kThinKS * kThinLD];
+    gemm_thin_body<A_CONTIG_K, B_CONTIG_N>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// dW = X^T dY (A strided along k, B contiguous along n) and dX = dY W^T (A contiguous along k, B strided along n)
+// of an MLP layer as one grid (see gemm_fast_pair_kernel)
+__global__ void __launch_bounds__(kThreads) gemm_thin_pair_kernel(const GemmPairDev p) {
+    __shared__ float As[kThinKS * kThinLD];
+    __shared__ float Bs[kThinKS * kThinLD];
+    int flat = blockIdx.x;
+    const int which = flat >= p.n0;
+    if (which) flat -= p.n0;
+    const int gx = p.gx[which], gy = p.gy[which];
+    const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
+    if (!which)
+        gemm_thin_body<false, true>(p.g[0], bx, by, bz, As, Bs);
+    else
+        gemm_thin_body<true, false>(p.g[1], bx, by, bz, As, Bs);
 }
 
 __global__ void splitk_reduce_kernel(const GemmDev g) {
@@ -1137,6 +1160,7 @@ namespace {
 // of launching; rlx_gemm_pair launches two plans as one grid)
 struct GemmPlan {
     bool tiled_fast;            // the fast tiled kernel with 64x64 tiles would run (else: thin / generic / folded paths)
+    bool thin, a_ck, b_cn;      // the thin kernel would run, with these operand layouts
     GemmDev g;
     dim3 grid;
     bool a_vec_red, u8, b_vec_red, a_tab;
@@ -1160,7 +1184,7 @@ int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, 
 }
 
 int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
-    if (plan) plan->tiled_fast = false;
+    if (plan) plan->tiled_fast = plan->thin = false;
     RLX_REQUIRE(d_host != nullptr, "rlx_gemm: null descriptor");
     const rlx_gemm_desc &d = *d_host;
     RLX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0,
@@ -1213,11 +1237,16 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
     // thin path: few output tiles and a short reduction -> one launch with K split over the waves
     if (!rlx_no_thin_gemm() && !d.a_row_tab && !d.a_k_tab && !d.a_is_u8 && d.n_fold <= 0 && d.K <= 1024) {
         const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
-        if (t64 <= 64 && (long long)d.N * d.K <= (1 << 18)) {      // MLP-sized weights only: the scalar loads lose on wide B
-            if (plan) return RLX_OK;
+        static const int thin_max_tiles = rlx_env_int("RLX_GEMM_THIN_MAX_TILES", 96);
+        if (t64 <= thin_max_tiles && (long long)d.N * d.K <= (1 << 18)) {      // MLP-sized weights only: the scalar loads lose on wide B
             const bool a_ck = d.a_k_stride == 1, b_cn = d.b_n_stride == 1;
             dim3 tgrid((d.N + 31) / 32, (d.M + 31) / 32, d.batch);
             g.splits = 1; g.kchunk = d.K; g.ws = nullptr; g.vec_epi = 0; g.fold = 0;
+            if (plan) {
+                plan->thin = true; plan->a_ck = a_ck; plan->b_cn = b_cn;
+                plan->g = g; plan->grid = tgrid; plan->splits = 1;
+                return RLX_OK;
+            }
             hipStream_t ts = rlx::as_stream(stream);
             if (a_ck && b_cn) gemm_thin_kernel<true, true><<<tgrid, kThreads, 0, ts>>>(g);
             else if (a_ck) gemm_thin_kernel<true, false><<<tgrid, kThreads, 0, ts>>>(g);
@@ -1356,6 +1385,16 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
                           !pw.a_vec_red && !pw.u8 && !pw.b_vec_red &&                 // X^T dY
                           px.a_vec_red && !px.u8 && px.b_vec_red && !px.a_tab &&       // dY W^T
                           true;
+    if (!off && pw.thin && px.thin && !pw.a_ck && pw.b_cn && px.a_ck && !px.b_cn) {
+        GemmPairDev p;
+        p.g[0] = pw.g; p.g[1] = px.g;
+        p.gx[0] = pw.grid.x; p.gy[0] = pw.grid.y; p.gx[1] = px.grid.x; p.gy[1] = px.grid.y;
+        p.n0 = (int)(pw.grid.x * pw.grid.y * pw.grid.z);
+        const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
+        gemm_thin_pair_kernel<<<total, kThreads, 0, rlx::as_stream(stream)>>>(p);
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
+    }
     // both problems may split K: their partials must not share workspace memory
     const bool ws_clash = pw.splits > 1 && px.splits > 1 && pw.g.ws == px.g.ws;
     if (!pairable || ws_clash) {

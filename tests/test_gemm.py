@@ -250,7 +250,7 @@ def test_gemm_thin_all_layouts(rlx, dev, M, N, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["dense", "conv"])
+@pytest.mark.parametrize("kind", ["dense", "conv", "mlp"])
 def test_weight_and_input_gradient_as_one_launch_equals_two(rlx, dev, kind):
     """rlx_gemm_pair (a layer's dW and dX products in ONE launch) against the two launches it replaces, on the C2
     layer shapes with two towers: weight gradients, bias gradients and input gradients bit for bit.  The layer's
@@ -261,8 +261,8 @@ def test_weight_and_input_gradient_as_one_launch_equals_two(rlx, dev, kind):
     out = {}
     for paired in (True, False):
         params = G.FlatParams()
-        if kind == "dense":
-            B, K, N, T = 64, 3136, 512, 2
+        if kind in ("dense", "mlp"):
+            B, K, N, T = (64, 3136, 512, 2) if kind == "dense" else (100, 400, 300, 2)   # C2 FC layer / TD3 critic (thin kernel)
             layer = G.Dense(params, "fc", K, N, "relu", T)
             x_np = rng.randn(T, B, K).astype(np.float32) if paired else x_np
         else:

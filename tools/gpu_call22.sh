@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r02_call22
+mkdir -p $O
+timeout 1200 python -m pytest tests/test_gemm.py tests/test_nn.py tests/test_ac_nets.py tests/test_architecture.py tests/test_agent_loops.py -m gpu -q --tb=short -x 2>&1 | tail -40 > $O/pytest.txt
+tail -20 $O/pytest.txt | cut -c1-250
+for v in 0 1; do
+for w in c4 c5; do
+RLX_NO_GEMM_PAIR=$v timeout 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_${w}_nopair$v.json 2> $O/bench_${w}_nopair$v.err
+python -c "
+import json; d=json.loads(open('$O/bench_${w}_nopair$v.json').read().strip().splitlines()[-1]); print('$w nopair=$v', d['ms_per_step'], d['value'])"
+done; done
