@@ -165,7 +165,9 @@ class DDPGAgent(VectorOffPolicyAgent):
     def _sync(self, net):
         self._allreduce(net.params.grads)
 
-    def _learn_device(self, b):
+    def _learn_device(self, b, mix=None):
+        """mix: rate of the soft target update due right after this update — each network's Adam pass applies it to its
+        own target (neither target is read again before the update ends)."""
         actor, critic = self.networks["actor"], self.networks["critic"]
         B = self.batch_size
         s, ns = b._states["observation"], b._next_states["observation"]
@@ -180,11 +182,11 @@ class DDPGAgent(VectorOffPolicyAgent):
         _, c_saved = critic.forward(s, b.actions(), B, tag="train")
         critic.train_backward(c_saved, self.td_targets, B)
         self._sync(critic)
-        critic.apply_gradients(self._scale("critic"), with_norm=True)
+        critic.apply_gradients(self._scale("critic"), with_norm=True, mix_rate=mix)
         # actor: weighted_gradients[0] with gradients_weights = -action_gradients (:183-193)
         actor.backward(a_saved, self.neg_action_grad, B)
         self._sync(actor)
-        actor.apply_gradients(self._scale("actor"))
+        actor.apply_gradients(self._scale("actor"), mix_rate=mix)
 
     def _scale(self, name):
         netp = self.ap.network_wrappers[name]
@@ -192,7 +194,10 @@ class DDPGAgent(VectorOffPolicyAgent):
             if self.dist else 1.0
 
     def learn_from_batch(self, batch):
-        self._run(("learn",), lambda: self._learn_device(batch))
+        mix = self._mix_rate
+        self._run(("learn", mix), lambda: self._learn_device(batch, mix))
+        if mix is not None:
+            self._mixed = self._mixed | {"actor", "critic"}
         critic = self.networks["critic"]
         self.signals = {"Loss": critic.loss[0], "Grads (unclipped)": critic.norm}
         return critic.loss[:critic.T].sum()

@@ -165,7 +165,7 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         return self.dist.grad_scale(netp.scale_down_gradients_by_number_of_workers_for_sync_training) \
             if self.dist else 1.0
 
-    def _learn_device(self, b):
+    def _learn_device(self, b, mix=None):
         pol, q, v = self.networks["policy"], self.networks["q"], self.networks["v"]
         alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
         s, ns = b._states["observation"], b._next_states["observation"]
@@ -206,7 +206,9 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
             _, v_saved = v.forward(s, B, tag="train")
         v.train_backward(v_saved, self.value_targets, B)
         self._sync(v)
-        v.apply_gradients(self._scale("v"))
+        # a soft update of V's target due after this update rides in V's Adam pass — only when V_target(s') was
+        # already evaluated above (paired pass); otherwise it is still needed unmixed below
+        v.apply_gradients(self._scale("v"), mix_rate=mix if obs2 is not None else None)
         # (5) Q: y = r + (1 - done) gamma V_target(s') (:259-266), train_on_batch (:268)
         if obs2 is None:
             v_next, _ = v.forward(ns, B, use_target=True, tag="next")
@@ -222,7 +224,11 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         B = self.batch_size
         z = np.random.standard_normal((3, B, self.A))
         self.normals = self._to_device("sac_z", z, torch.float64)     # the staging buffer is the operand
-        self._run(("learn",), lambda: self._learn_device(batch))
+        mix = self._mix_rate
+        self._run(("learn", mix), lambda: self._learn_device(batch, mix))
+        paired = hasattr(batch, "_info") and batch._info.get("states_pair") is not None
+        if mix is not None and paired:                  # (decided here, not in the captured body: replays skip that)
+            self._mixed = self._mixed | {"v"}
         qn = self.networks["q"]
         self.signals = {"Loss": qn.loss[2], "Grads (unclipped)": qn.norm,
                         "V loss": self.networks["v"].loss}

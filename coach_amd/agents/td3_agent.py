@@ -101,7 +101,7 @@ class TD3Agent(DDPGAgent):
         # step take the lengths of the episodes that just finished, in env order
         return self._phase_episode_lengths.pop(0)
 
-    def _critic_device_paired(self, b, obs2):
+    def _critic_device_paired(self, b, obs2, mix=None):
         """The same update with every online / target pass pair sharing its launches: actor online(s)
         + target(s'), then critic online(s, a) + target(s', a') (the online critic pass does not
         depend on the TD targets, only its loss does)."""
@@ -126,13 +126,15 @@ class TD3Agent(DDPGAgent):
                                   critic.loss, s_)
         critic.train_backward(c_saved, self.td_targets, B, losses_done=True)
         self._sync(critic)
-        critic.apply_gradients(self._scale("critic"), with_norm=True)
+        critic.apply_gradients(self._scale("critic"), with_norm=True, mix_rate=mix)
         self._loss_total = critic.loss[critic.T]                 # written by the loss launch: no reduction launch
 
-    def _critic_device(self, b):
+    def _critic_device(self, b, mix=None):
+        """mix: rate of the soft target update due after this update, applied by the critic's Adam pass itself (nothing
+        reads the critic's target between its Adam step and the end of the update)."""
         obs2 = b._info.get("states_pair") if hasattr(b, "_info") else None
         if obs2 is not None and self.networks["critic"].T == 2:
-            return self._critic_device_paired(b, obs2)
+            return self._critic_device_paired(b, obs2, mix)
         actor, critic = self.networks["actor"], self.networks["critic"]
         alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
         self._agrad_merged = None
@@ -148,10 +150,10 @@ class TD3Agent(DDPGAgent):
         _, c_saved = critic.forward(s, b.actions(), B, tag="train")
         critic.train_backward(c_saved, self.td_targets, B)
         self._sync(critic)
-        critic.apply_gradients(self._scale("critic"), with_norm=True)
+        critic.apply_gradients(self._scale("critic"), with_norm=True, mix_rate=mix)
         self._loss_total = None
 
-    def _actor_device(self, b):
+    def _actor_device(self, b, mix=None):
         actor, critic = self.networks["actor"], self.networks["critic"]
         B = self.batch_size
         s = b._states["observation"]
@@ -168,7 +170,7 @@ class TD3Agent(DDPGAgent):
             critic.action_gradient(c_saved, B, self.neg_action_grad, scale=-1.0)
             actor.backward(self._a_saved, self.neg_action_grad, B)
         self._sync(actor)
-        actor.apply_gradients(self._scale("actor"))
+        actor.apply_gradients(self._scale("actor"), mix_rate=mix)
 
     def learn_from_batch(self, batch):
         alg, B = self.ap.algorithm, self.batch_size
@@ -176,9 +178,14 @@ class TD3Agent(DDPGAgent):
         # the staging buffer IS the noise operand (a static device tensor): no device-to-device copy behind the upload
         self.noise = self._to_device("td3_noise", z, torch.float64)
         run = self._run
-        run(("critic",), lambda: self._critic_device(batch))
+        mix = self._mix_rate
+        run(("critic", mix), lambda: self._critic_device(batch, mix))
         if self.training_iteration % alg.update_policy_every_x_episode_steps == 0:   # :186
-            run(("actor",), lambda: self._actor_device(batch))
+            run(("actor", mix), lambda: self._actor_device(batch, mix))
+            if mix is not None:
+                self._mixed = self._mixed | {"actor"}
+        if mix is not None:
+            self._mixed = self._mixed | {"critic"}
         critic = self.networks["critic"]
         loss = self._loss_total if self._loss_total is not None else critic.loss[:2].sum()
         self.signals = {"Loss": loss, "Grads (unclipped)": critic.norm}

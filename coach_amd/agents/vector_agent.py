@@ -362,6 +362,9 @@ class VectorOffPolicyAgent(GraphRunner):
         self.last_training_phase_step = self.total_steps_counter
         return due
 
+    _mix_rate = None          # set around learn_from_batch when a soft target update follows the update
+    _mixed = frozenset()
+
     def update_target_networks(self, rate):
         for net in self.networks.values():
             if net.target is not None:
@@ -388,16 +391,24 @@ class VectorOffPolicyAgent(GraphRunner):
                 if self.debug_draws is not None:      # sampled logical indices / PER leaves
                     self.debug_draws.append(batch.info("idx").cpu().numpy().copy()
                                             if "idx" in batch._info else np.asarray(d).copy())
+                # is a target update due after this update (agent.py:640-660)?  Known before it runs: a network whose
+                # Adam step is part of the update mixes its target in the same pass (learn_from_batch records which)
+                mix = any(n.target is not None for n in self.networks.values()) and \
+                    self._should_update_online_weights_to_target()
+                self._mix_rate = alg.rate_for_copying_weights_to_target if mix else None
+                self._mixed = set()
                 loss = self.learn_from_batch(batch)
                 if self.signal_stats is not None:
                     self._accumulate_signals()
                 if self.debug_losses is not None:
                     self.debug_losses.append(float(loss.sum().item()))
                 losses.append(loss)
-                if any(n.target is not None for n in self.networks.values()) and \
-                        self._should_update_online_weights_to_target():
-                    self.update_target_networks(alg.rate_for_copying_weights_to_target)
+                if mix:
+                    for name, net in self.networks.items():
+                        if net.target is not None and name not in self._mixed:
+                            net.update_target(self._mix_rate)
                     self._target_updated_since_log = True      # 'Update Target Network' column (agent.py:760)
+                self._mix_rate = None
         # the loss of the last update of the phase(s) (a device scalar; no per-update host sync or add)
         return losses[-1] if losses else None
 

@@ -76,6 +76,76 @@ __global__ void adam_tf1_kernel(float *__restrict__ w, const float *__restrict__
     }
 }
 
+
+// Adam (+ per-block partial sums of squares for tf.global_norm) (+ the soft target update in the same elementwise pass).
+// Without the norm the beta-power advance needs no second launch: the block that finishes LAST (a relaxed agent-scope
+// ticket — nothing is published, so no fence) writes the advanced powers; every block read them at its start and has
+// finished.  With the norm the partial sums would have to be PUBLISHED to that block, and a release fence behind
+// 28 B/parameter of stores costs far more than the finish launch it saves (measured: C2 +29 us per update, C3 +68 us,
+// gpurun_out/r02_call24) — there adam_finish_norm_kernel stays a second launch (TICKET = false).
+template <bool NORM, bool MIX, bool TICKET>
+__global__ void __launch_bounds__(kBlock)
+adam_step_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                 long long n, float lr, float beta1, float beta2, float eps, float *state, float grad_scale,
+                 float *__restrict__ sumsq_part, float *__restrict__ target, float rate, float one_minus_rate,
+                 unsigned int *ticket) {
+    __shared__ float red[kBlock];
+    float ss = 0.f;
+    const float b1p = state[0], b2p = state[1];
+    const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 gw = reinterpret_cast<const float4 *>(g)[i];
+        float4 mw = reinterpret_cast<float4 *>(m)[i];
+        float4 vw = reinterpret_cast<float4 *>(v)[i];
+        float4 ww = reinterpret_cast<float4 *>(w)[i];
+        float4 tw = MIX ? reinterpret_cast<float4 *>(target)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float *gp = &gw.x, *mp = &mw.x, *vp = &vw.x, *wp = &ww.x, *tp = &tw.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (NORM) ss += gp[k] * gp[k];
+            const float gr = gp[k] * grad_scale;
+            mp[k] += (gr - mp[k]) * omb1;
+            vp[k] += (gr * gr - vp[k]) * omb2;
+            wp[k] -= (mp[k] * alpha) / (sqrtf(vp[k]) + eps);
+            if (MIX) tp[k] = rate * wp[k] + one_minus_rate * tp[k];
+        }
+        reinterpret_cast<float4 *>(m)[i] = mw;
+        reinterpret_cast<float4 *>(v)[i] = vw;
+        reinterpret_cast<float4 *>(w)[i] = ww;
+        if (MIX) reinterpret_cast<float4 *>(target)[i] = tw;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (NORM) ss += g[i] * g[i];
+        const float gr = g[i] * grad_scale;
+        m[i] += (gr - m[i]) * omb1;
+        v[i] += (gr * gr - v[i]) * omb2;
+        w[i] -= (m[i] * alpha) / (sqrtf(v[i]) + eps);
+        if (MIX) target[i] = rate * w[i] + one_minus_rate * target[i];
+    }
+    if (NORM) {
+        red[threadIdx.x] = ss;
+        __syncthreads();
+        for (int d = kBlock >> 1; d > 0; d >>= 1) {
+            if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sumsq_part[blockIdx.x] = red[0];
+    }
+    if (!TICKET) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            state[0] = b1p * beta1;       // AdamOptimizer._finish: beta1_power *= beta1
+            state[1] = b2p * beta2;
+            *ticket = 0u;                 // re-armed for the next launch on the stream
+        }
+    }
+}
+
 __global__ void adam_advance_kernel(float *state, float beta1, float beta2) {
     state[0] *= beta1;       // AdamOptimizer._finish: beta1_power *= beta1
     state[1] *= beta2;
@@ -209,6 +279,42 @@ int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, lo
     adam_finish_norm_kernel<<<1, kBlock, 0, s>>>(state, beta1, beta2, workspace, blocks, norm_out, acc_src,
                                                  acc_dst, n_acc);
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
+                      float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
+                      float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
+                      float *target, double mix_rate, unsigned int *ticket, void *stream) {
+    RLX_REQUIRE(weights && grads && m && v && state && ticket, "rlx_adam_tf1_step: null pointer");
+    RLX_REQUIRE(n > 0, "rlx_adam_tf1_step: empty parameter buffer");
+    RLX_REQUIRE(!norm_out || workspace, "rlx_adam_tf1_step: the gradient norm needs a workspace");
+    RLX_REQUIRE(n_acc == 0 || (acc_src && acc_dst && n_acc > 0 && n_acc <= 64),
+                "rlx_adam_tf1_step: bad signal accumulation arguments");
+    RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) == 0,
+                "rlx_adam_tf1_step: buffers must be 16-byte aligned");
+    int blocks = rlx::grid_for(n / 4 + 1, kBlock, 1024);
+    if (norm_out && blocks > workspace_floats) blocks = (int)workspace_floats;
+    RLX_REQUIRE(blocks >= 1, "rlx_adam_tf1_step: workspace too small");
+    hipStream_t s = rlx::as_stream(stream);
+    const float rate = (float)mix_rate, omr = (float)(1.0 - mix_rate);
+#define RLX_ADAM_STEP(NORM, MIX, TICKET)                                                                      \
+    adam_step_kernel<NORM, MIX, TICKET><<<blocks, kBlock, 0, s>>>(weights, grads, m, v, n, learning_rate, beta1,  \
+                                                                  beta2, epsilon, state, grad_scale, workspace, \
+                                                                  target, rate, omr, ticket)
+    if (norm_out && target) RLX_ADAM_STEP(true, true, false);
+    else if (norm_out) RLX_ADAM_STEP(true, false, false);
+    else if (target) RLX_ADAM_STEP(false, true, true);
+    else RLX_ADAM_STEP(false, false, true);
+#undef RLX_ADAM_STEP
+    RLX_LAUNCH_CHECK();
+    if (norm_out) {
+        adam_finish_norm_kernel<<<1, kBlock, 0, s>>>(state, beta1, beta2, workspace, blocks, norm_out, acc_src,
+                                                     acc_dst, n_acc);
+        RLX_LAUNCH_CHECK();
+    } else if (n_acc > 0) {
+        RLX_REQUIRE(false, "rlx_adam_tf1_step: signal sums ride with the norm finish (give norm_out)");
+    }
     return RLX_OK;
 }
 

@@ -599,15 +599,28 @@ class AdamState:
         self.m = torch.empty_like(params.weights)
         self.v = torch.empty_like(params.weights)
         self.state = torch.empty(2, dtype=torch.float32, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # rlx_adam_tf1_step's last-arriver word
+        self.one_launch = os.environ.get("RLX_ADAM_TWO_LAUNCHES", "0") != "1"
         _rlx.lib().adam_init(self.m, self.v, params.size, self.state, beta1, beta2, _rlx.current_stream())
 
-    def step(self, grad_scale=1.0, lr=None, norm_out=None, workspace=None, acc=None, grads=None):
+    def step(self, grad_scale=1.0, lr=None, norm_out=None, workspace=None, acc=None, grads=None, mix_target=None,
+             mix_rate=0.0):
         """norm_out given: the same pass also returns tf.global_norm of the gradients; acc =
-        (src, dst, n): the finish kernel adds src[:n] onto dst[:n] (signal accumulation); grads: a
-        flat gradient buffer to consume instead of params.grads."""
+        (src, dst, n): the finish adds src[:n] onto dst[:n] (signal accumulation); grads: a
+        flat gradient buffer to consume instead of params.grads; mix_target: the target copy of the weights, updated
+        as rate * w_new + (1 - rate) * target in the same pass (a soft target update due right after this step)."""
         p = self.params
         lr = self.lr if lr is None else lr
         g = p.grads if grads is None else grads
+        if self.one_launch:
+            _rlx.lib().adam_tf1_step(p.weights, g, self.m, self.v, p.size, lr, self.beta1, self.beta2, self.eps,
+                                     self.state, grad_scale, norm_out, workspace if norm_out is not None else None,
+                                     workspace.numel() if norm_out is not None else 0,
+                                     acc[0] if acc else None, acc[1] if acc else None, int(acc[2]) if acc else 0,
+                                     mix_target, float(mix_rate), self.ticket, _rlx.current_stream())
+            return
+        if mix_target is not None:
+            raise ValueError("the two-launch Adam path does not fuse the target update")
         if norm_out is not None:
             _rlx.lib().adam_tf1_norm(p.weights, g, self.m, self.v, p.size, lr, self.beta1,
                                      self.beta2, self.eps, self.state, grad_scale, norm_out, workspace,

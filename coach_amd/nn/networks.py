@@ -75,12 +75,20 @@ class _NetBase:
                              self.ctx.ws.small.numel(), self.ctx.stream)
         return self.norm
 
-    def apply_gradients(self, grad_scale=1.0, with_norm=False, acc=None):
-        """Adam; with_norm also refreshes self.norm = tf.global_norm(grads) in the same pass."""
+    def apply_gradients(self, grad_scale=1.0, with_norm=False, acc=None, mix_rate=None):
+        """Adam; with_norm also refreshes self.norm = tf.global_norm(grads) in the same pass; mix_rate (a soft
+        target update is due right after this step): the target weights are mixed in the same pass."""
+        kw = {}
+        if mix_rate is not None and self.target is not None and self.adam.one_launch:
+            kw = dict(mix_target=self.target, mix_rate=float(mix_rate))
+        elif mix_rate is not None and self.target is not None:
+            kw = {}
         if with_norm:
-            self.adam.step(grad_scale, norm_out=self.norm, workspace=self.ctx.ws.small, acc=acc)
+            self.adam.step(grad_scale, norm_out=self.norm, workspace=self.ctx.ws.small, acc=acc, **kw)
         else:
-            self.adam.step(grad_scale)
+            self.adam.step(grad_scale, **kw)
+        if mix_rate is not None and self.target is not None and not kw:
+            self.update_target(mix_rate)
 
     clip_gradients = None
 

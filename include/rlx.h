@@ -471,6 +471,16 @@ int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, lo
                       float learning_rate, float beta1, float beta2, float epsilon, float *state,
                       float grad_scale, float *norm_out, float *workspace, long long workspace_floats,
                       const float *acc_src, float *acc_dst, int n_acc, void *stream);
+/* rlx_adam_tf1 / rlx_adam_tf1_norm with (target != NULL) the soft target update
+ * target = rate * w_new + (1 - rate) * target (rlx_mix_weights' arithmetic) in the same elementwise pass.  Without
+ * norm_out it is ONE launch: the last workgroup to finish (device ticket, no fence) advances the beta powers; with
+ * norm_out the norm / beta-power / signal-sum finish stays a second small launch (publishing the partial sums from
+ * every workgroup costs more than that launch).  ticket: one zero-initialised 32-bit device word owned by this
+ * optimiser; the kernel re-arms it. */
+int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
+                      float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
+                      float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
+                      float *target, double mix_rate, unsigned int *ticket, void *stream);
 int rlx_mix_weights(float *target, const float *online, long long n, double rate,
                     void *stream);   /* architectures/tensorflow_components/architecture.py:598-607 */
 int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,

@@ -188,3 +188,45 @@ def test_sac_min_targets_equals_min_pair_and_value_targets(dev):
     lib.sac_min_targets(q1, q2, lp, 1.0 / B, B, m_b, vt_b, g1_b, g2_b, s_)
     for a, b in ((m_a, m_b), (g1_a, g1_b), (g2_a, g2_b), (vt_a, vt_b)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,with_norm,with_mix", [(3_400_000, True, False), (130_001, True, True), (70_000, False, True),
+                                                   (257, False, False)])
+def test_adam_step_one_launch_equals_adam_finish_and_mix(dev, n, with_norm, with_mix):
+    """rlx_adam_tf1_step (Adam + norm + beta-power advance by the last workgroup to finish, + the soft target update in
+    the same pass) against rlx_adam_tf1(_norm) followed by rlx_mix_weights: weights, slots, beta powers, norm, signal
+    sums and target bit for bit, over several steps (the ticket re-arms itself)."""
+    import torch
+    from coach_amd import _rlx
+    lib, s_ = _rlx.lib(), _rlx.current_stream()
+    rng = np.random.RandomState(n % 1000)
+    w0 = rng.randn(n).astype(np.float32)
+    t0 = rng.randn(n).astype(np.float32)
+
+    def fresh():
+        st = dict(w=_t(w0, dev), t=_t(t0, dev), m=torch.empty(n, dtype=torch.float32, device=dev),
+                  v=torch.empty(n, dtype=torch.float32, device=dev), state=torch.empty(2, dtype=torch.float32, device=dev),
+                  norm=torch.zeros(1, dtype=torch.float32, device=dev), acc=torch.zeros(3, dtype=torch.float32, device=dev))
+        lib.adam_init(st["m"], st["v"], n, st["state"], 0.9, 0.99, s_)
+        return st
+    a, b = fresh(), fresh()
+    ws_a = torch.empty(1 << 12, dtype=torch.float32, device=dev)
+    ws_b = torch.empty(1 << 12, dtype=torch.float32, device=dev)
+    ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+    for step in range(4):
+        g = _t((rng.randn(n) * 0.1).astype(np.float32), dev)
+        src = _t(rng.randn(3).astype(np.float32), dev)
+        if with_norm:
+            lib.adam_tf1_norm(a["w"], g, a["m"], a["v"], n, 1e-3, 0.9, 0.99, 1e-4, a["state"], 0.5, a["norm"], ws_a,
+                              ws_a.numel(), src, a["acc"], 3, s_)
+        else:
+            lib.adam_tf1(a["w"], g, a["m"], a["v"], n, 1e-3, 0.9, 0.99, 1e-4, a["state"], 0.5, s_)
+        if with_mix:
+            lib.mix_weights(a["t"], a["w"], n, 0.005, s_)
+        lib.adam_tf1_step(b["w"], g, b["m"], b["v"], n, 1e-3, 0.9, 0.99, 1e-4, b["state"], 0.5,
+                          b["norm"] if with_norm else None, ws_b if with_norm else None, ws_b.numel() if with_norm else 0,
+                          src if with_norm else None, b["acc"] if with_norm else None, 3 if with_norm else 0,
+                          b["t"] if with_mix else None, 0.005, ticket, s_)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (step, k)
+        assert int(ticket.item()) == 0
