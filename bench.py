@@ -348,41 +348,49 @@ def gemm_roofline(agent, reps=20):
     lib.event_create(ctypes.byref(ev0))
     lib.event_create(ctypes.byref(ev1))
     total_ms, total_flops, per_shape = 0.0, 0.0, []
+    pair = lib.raw("rlx_gemm_pair")
+    n_products = 0
     for d in recorded:
+        # a recorded tuple is a layer's dW + dX pair: ONE launch (rlx_gemm_pair), timed as such
+        descs = d if isinstance(d, tuple) else (d,)
+        run = (lambda: pair(ctypes.byref(descs[0]), ctypes.byref(descs[1]), stream)) if len(descs) == 2 else \
+            (lambda: orig(ctypes.byref(descs[0]), stream))
         for _ in range(3):
-            orig(ctypes.byref(d), stream)
+            run()
         lib.event_record(ev0, stream)
         for _ in range(reps):
-            orig(ctypes.byref(d), stream)
+            run()
         lib.event_record(ev1, stream)
         ms = ctypes.c_float()
         lib.event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
-        flops = 2.0 * d.M * d.N * d.K * d.batch
+        flops = sum(2.0 * x.M * x.N * x.K * x.batch for x in descs)
         total_ms += ms.value / reps
         total_flops += flops
-        per_shape.append({"M": d.M, "N": d.N, "K": d.K, "batch": d.batch, "us": 1e3 * ms.value / reps,
-                          "tflops": flops / (ms.value / reps * 1e-3) / 1e12})
+        n_products += len(descs)
+        per_shape.append({"products": [{"M": x.M, "N": x.N, "K": x.K, "batch": x.batch} for x in descs],
+                          "us": 1e3 * ms.value / reps, "tflops": flops / (ms.value / reps * 1e-3) / 1e12})
     lib.event_destroy(ev0)
     lib.event_destroy(ev1)
     n = len(recorded)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     # HBM-side bytes per GEMM launch (incl. its split-K reduce): PMC passes cannot run inside this
     # process, so the figure is the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of
-    # the same 11 launches (tools/ppo_update_once.py -> profiles/r01_pmc_gemm_traffic.json)
+    # the same launches (tools/ppo_update_once.py + tools/pmc_summary.py -> profiles/r02_pmc_gemm_traffic.json)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")) as f:
             pm = json.load(f)
-        if pm.get("gemm_launches") == n:
-            traffic = round(pm["traffic_bytes_per_gemm_launch"])
+        if pm.get("gemm_launches") == n and pm.get("gemm_products") == n_products:
+            traffic = round(pm["traffic_bytes_per_update"] / n)
     except (OSError, ValueError, KeyError):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "bytes per GEMM launch (2 x FETCH_SIZE + WRITE_SIZE, PMC pass of "
-                            "tools/ppo_update_once.py; algorithmic operand bytes are 11.9e6 per launch)",
-            "kernel": "gemm_fast_kernel<BM,BN,...> + splitk_reduce4 (fp32 MFMA 32x32x2), %d launches "
-                      "per minibatch update" % n,
+            "traffic_unit": "bytes per GEMM launch incl. its split-K reduces (2 x FETCH_SIZE + WRITE_SIZE, PMC passes of "
+                            "tools/ppo_update_once.py; algorithmic operand bytes are %.1fe6 per launch)"
+                            % (11.9 * n_products / n),
+            "kernel": "gemm_fast_kernel / gemm_fast_pair_kernel + splitk_reduce4 (fp32 MFMA 32x32x2): %d products in "
+                      "%d launches per minibatch update" % (n_products, n),
             "flops_per_launch": total_flops / n, "avg_launch_us": round(1e3 * total_ms / n, 2),
             "gemm_us_per_update": round(1e3 * total_ms, 1)}, per_shape
 

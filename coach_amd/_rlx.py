@@ -320,8 +320,7 @@ def gemm_pair_or_single(desc, stream=None):
 
 def gemm_pair(weight_grad, input_grad, stream=None):
     """two descriptors built with gemm(..., launch=False): a layer's dW and dX products as one launch."""
-    if GEMM_HOOK is not None:
-        GEMM_HOOK(GemmDesc.from_buffer_copy(weight_grad))
-        GEMM_HOOK(GemmDesc.from_buffer_copy(input_grad))
+    if GEMM_HOOK is not None:       # one entry: the two products go out as one launch
+        GEMM_HOOK((GemmDesc.from_buffer_copy(weight_grad), GemmDesc.from_buffer_copy(input_grad)))
     lib().gemm_pair(ctypes.byref(weight_grad), ctypes.byref(input_grad),
                     current_stream() if stream is None else stream)

@@ -95,6 +95,7 @@ def _capture(fn):
 
 
 class ClippedPPOAgent(object):
+    epoch_graph = os.environ.get("RLX_PPO_MINIBATCH_GRAPHS", "0") != "1"   # one hipGraph per epoch, not per minibatch
     ragged = False          # envs end their episodes on different steps (set per instance from the env)
     _device_env = True
 
@@ -428,6 +429,17 @@ class ClippedPPOAgent(object):
             self._perm.push(full)
             self.scalar_acc.zero_()
             nmb = -(-n // B)                                              # math.ceil (:232)
+            if self.dist is None and self.epoch_graph and not self.ragged:      # (ragged: n differs from phase to phase)
+                # every minibatch of the epoch reads its slice of the ONE static permutation buffer pushed above: the
+                # whole epoch is one captured graph (one launch from the host instead of nmb, one graph instead of one
+                # per minibatch index)
+                def epoch():
+                    for i in range(nmb):
+                        self._minibatch_fb(min(B, n - i * B), clip, i=i)
+                        self._minibatch_finish(scale)
+                self._run(("epoch", n, clip, scale), epoch)
+                results.append(self.scalar_acc / nmb)
+                continue
             for i in range(nmb):
                 m = min(B, n - i * B)
                 if self.dist is None:

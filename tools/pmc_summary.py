@@ -1,0 +1,54 @@
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of tools/ppo_update_once.py (two separate passes) -> the
+per-update HBM traffic of the GEMM family (profiles/r0N_pmc_gemm_traffic.json, read by bench.py `roofline.traffic`).
+The LAST eager minibatch update of the run is summarised: every dispatch after the previous update's
+adam_finish_norm_kernel.  FETCH_SIZE is doubled (gfx950 counts 128-byte requests in 64-byte units,
+MI355X_MICROARCH.md); both counters are in KB.
+
+    python tools/pmc_summary.py gpurun_out/r02_final/pmc_FETCH_SIZE.csv gpurun_out/r02_final/pmc_WRITE_SIZE.csv out.json
+"""
+import csv
+import json
+import sys
+
+
+def last_update(path):
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"]))
+    ends = [i for i, r in enumerate(rows) if "adam_finish_norm_kernel" in r["Kernel_Name"]]
+    return rows[ends[-2] + 1:ends[-1] + 1]
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = last_update(fetch), last_update(write)
+    assert [r["Kernel_Name"] for r in f] == [r["Kernel_Name"] for r in w]
+    gemm = lambda n: "gemm_" in n
+    red = lambda n: "splitk_reduce" in n
+    kernels, fk, wk = [], 0.0, 0.0
+    n_gemm = n_red = 0
+    for a, b in zip(f, w):
+        n = a["Kernel_Name"]
+        if not (gemm(n) or red(n)):
+            continue
+        n_gemm += gemm(n)
+        n_red += red(n)
+        fv, wv = float(a["Counter_Value"]), float(b["Counter_Value"])
+        fk += fv
+        wk += wv
+        kernels.append({"name": n, "FETCH_SIZE_KB": fv, "WRITE_SIZE_KB": wv})
+    products = sum(2 if "pair" in k["name"] else 1 for k in kernels if gemm(k["name"]))
+    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/ppo_update_once.py, "
+                     "last eager minibatch update",
+           "gemm_launches": n_gemm, "gemm_products": products, "reduce_launches": n_red,
+           "FETCH_SIZE_KB_raw": fk, "WRITE_SIZE_KB": wk, "fetch_bytes_corrected": 2 * fk * 1024, "write_bytes": wk * 1024,
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncalibrated",
+           "traffic_bytes_per_update": 2 * fk * 1024 + wk * 1024,
+           "traffic_bytes_per_gemm_launch": (2 * fk * 1024 + wk * 1024) / products,
+           "all_kernels_of_the_update": [{"name": a["Kernel_Name"][:100], "FETCH_SIZE_KB": float(a["Counter_Value"]),
+                                          "WRITE_SIZE_KB": float(b["Counter_Value"])} for a, b in zip(f, w)],
+           "kernels": kernels}
+    json.dump(res, open(out, "w"), indent=1)
+    print({k: v for k, v in res.items() if k not in ("kernels", "all_kernels_of_the_update")})
+
+
+if __name__ == "__main__":
+    main()
