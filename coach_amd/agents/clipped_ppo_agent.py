@@ -416,7 +416,10 @@ class ClippedPPOAgent(object):
         netp = self.ap.network_wrappers["main"]
         B = netp.batch_size
         n = len(order)
-        clip = float(alg.clipping_decay_schedule.current_value)
+        # clip_param_rescaler (:266-268) lives in a device scalar: the captured graphs below do not depend on its value
+        # (a decaying clipping_decay_schedule, presets/Mujoco_ClippedPPO.py, would otherwise re-capture every phase)
+        self.networks["main"].set_clip_rescaler(float(alg.clipping_decay_schedule.current_value))
+        clip = None
         scale = self.dist.grad_scale(netp.scale_down_gradients_by_number_of_workers_for_sync_training) \
             if self.dist else 1.0
         results = []

@@ -165,7 +165,9 @@ ppo_discrete_loss_kernel(const float *__restrict__ logits, long long ld, const i
                          long long ld_old, int batch, int n, float clip_eps, float beta,
                          float grad_scale, float *__restrict__ dlogits, long long ld_grad,
                          float *__restrict__ scalars, float *__restrict__ ratio_out,
-                         float *__restrict__ clipped_out, int *__restrict__ status) {
+                         float *__restrict__ clipped_out, int *__restrict__ status,
+                         const float *__restrict__ clip_scale) {
+    if (clip_scale) clip_eps *= *clip_scale;      // clip_param_rescaler as a device scalar (fp32 product, like TF)
     ppo_discrete_loss_body(logits, ld, actions, advantages, old_probs, ld_old, batch, n, clip_eps, beta,
                            grad_scale, dlogits, ld_grad, scalars, ratio_out, clipped_out, status);
 }
@@ -176,11 +178,12 @@ struct PpoValueLossArgs {
     const float *old_probs; long long ld_old; int batch, n; float clip_eps, beta, grad_scale;
     float *dlogits; long long ld_grad; float *scalars; float *ratio_out; float *clipped_out; int *status;
     const float *v; const float *v_target; float *dv; float *v_scalar;
+    const float *clip_scale;
 };
 __global__ void __launch_bounds__(kMaxBlock) ppo_value_losses_kernel(const PpoValueLossArgs a) {
     if (blockIdx.x == 0)
         ppo_discrete_loss_body(a.logits, a.ld, a.actions, a.advantages, a.old_probs, a.ld_old, a.batch, a.n,
-                               a.clip_eps, a.beta, a.grad_scale, a.dlogits, a.ld_grad, a.scalars,
+                               a.clip_scale ? a.clip_eps * *a.clip_scale : a.clip_eps, a.beta, a.grad_scale, a.dlogits, a.ld_grad, a.scalars,
                                a.ratio_out, a.clipped_out, a.status);
     else
         regression_loss_body(a.v, a.v_target, nullptr, a.batch, 1, 1, 1, 0, 1.f, a.grad_scale, a.dv, 1,
@@ -198,8 +201,10 @@ ppo_continuous_loss_kernel(const float *__restrict__ mean, long long ld, const f
                            long long ld_old, int batch, int A, float clip_eps, float beta,
                            float grad_scale, float *__restrict__ dmean, long long ld_grad,
                            float *__restrict__ dlog_std, float *__restrict__ scalars,
-                           float *__restrict__ ratio_out, float *__restrict__ clipped_out) {
+                           float *__restrict__ ratio_out, float *__restrict__ clipped_out,
+                           const float *__restrict__ clip_scale) {
     __shared__ float red[kMaxBlock];
+    if (clip_scale) clip_eps *= *clip_scale;
     constexpr float kEps = 1.1920928955078125e-07f, kHalfLog2Pi = 0.91893853320467274178f;
     float l_sur = 0.f, l_kl = 0.f;
     float ent = 0.f;                                   // identical for every sample
@@ -324,7 +329,7 @@ int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
                           int batch, int n_actions, float clip_epsilon, float beta_entropy,
                           float grad_scale, float *dlogits, long long ld_grad, float *scalars,
                           float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
-                          void *stream) {
+                          const float *clip_scale, void *stream) {
     RLX_REQUIRE(logits && actions && advantages && old_probs && status,
                 "rlx_ppo_discrete_loss: null pointer");
     RLX_REQUIRE(batch > 0 && n_actions > 0 && ld >= n_actions && ld_old >= n_actions,
@@ -333,7 +338,7 @@ int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
     ppo_discrete_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
         logits, ld, actions, advantages, old_probs, ld_old, batch, n_actions, clip_epsilon,
         beta_entropy, grad_scale, dlogits, ld_grad, scalars, likelihood_ratio,
-        clipped_likelihood_ratio, status);
+        clipped_likelihood_ratio, status, clip_scale);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -343,7 +348,7 @@ int rlx_ppo_continuous_loss(const float *mean, long long ld, const float *log_st
                             long long ld_old, int batch, int action_dim, float clip_epsilon,
                             float beta_entropy, float grad_scale, float *dmean, long long ld_grad,
                             float *dlog_std, float *scalars, float *likelihood_ratio,
-                            float *clipped_likelihood_ratio, void *stream) {
+                            float *clipped_likelihood_ratio, const float *clip_scale, void *stream) {
     RLX_REQUIRE(mean && log_std && actions && advantages && old_mean && old_std,
                 "rlx_ppo_continuous_loss: null pointer");
     RLX_REQUIRE(batch > 0 && batch <= kMaxBlock && action_dim > 0 && ld >= action_dim && ld_old >= action_dim,
@@ -353,7 +358,7 @@ int rlx_ppo_continuous_loss(const float *mean, long long ld, const float *log_st
     ppo_continuous_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
         mean, ld, log_std, actions, advantages, old_mean, old_std, ld_old, batch, action_dim, clip_epsilon,
         beta_entropy, grad_scale, dmean, ld_grad, dlog_std, scalars, likelihood_ratio,
-        clipped_likelihood_ratio);
+        clipped_likelihood_ratio, clip_scale);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -364,7 +369,7 @@ int rlx_ppo_discrete_value_losses(const float *logits, long long ld, const int *
                                   float grad_scale, float *dlogits, long long ld_grad, float *scalars,
                                   float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
                                   const float *values, const float *value_targets, float *dvalues,
-                                  float *value_loss_scalar, void *stream) {
+                                  float *value_loss_scalar, const float *clip_scale, void *stream) {
     RLX_REQUIRE(logits && actions && advantages && old_probs && status && values && value_targets,
                 "rlx_ppo_discrete_value_losses: null pointer");
     RLX_REQUIRE(batch > 0 && n_actions > 0 && ld >= n_actions && ld_old >= n_actions,
@@ -372,7 +377,8 @@ int rlx_ppo_discrete_value_losses(const float *logits, long long ld, const int *
     RLX_REQUIRE(!dlogits || ld_grad >= n_actions, "rlx_ppo_discrete_value_losses: bad gradient pitch");
     PpoValueLossArgs a{logits, ld, actions, advantages, old_probs, ld_old, batch, n_actions, clip_epsilon,
                        beta_entropy, grad_scale, dlogits, ld_grad, scalars, likelihood_ratio,
-                       clipped_likelihood_ratio, status, values, value_targets, dvalues, value_loss_scalar};
+                       clipped_likelihood_ratio, status, values, value_targets, dvalues, value_loss_scalar,
+                       clip_scale};
     ppo_value_losses_kernel<<<2, block_for(batch), 0, rlx::as_stream(stream)>>>(a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;

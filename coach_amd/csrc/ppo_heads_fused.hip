@@ -32,6 +32,7 @@ struct PpoHeadsDev {
     const float *advantages, *old_probs, *value_targets;
     long long ld_old;
     float clip_eps, beta, grad_scale;
+    const float *clip_scale;
     float *scalars, *value_scalar, *ratio_out, *clipped_out;
     float *terms;                 // [M][4] per-row {surrogate, entropy, kl, squared value error}
     unsigned *sync;               // [2]: barrier, finish ticket (zero between launches)
@@ -64,7 +65,8 @@ __global__ void __launch_bounds__(256) ppo_heads_fused_kernel(const PpoHeadsDev 
         if (tid == 64) {                                         // PPOHead
             PpoRowTerms t{0.f, 0.f, 0.f};
             const bool ok = ppo_discrete_row(d.fwd[1].y + (size_t)row * A, d.old_probs + (size_t)row * d.ld_old,
-                                             d.actions[row], A, d.advantages[row], d.clip_eps, d.beta, d.grad_scale, M,
+                                             d.actions[row], A, d.advantages[row],
+                                             d.clip_scale ? d.clip_eps * *d.clip_scale : d.clip_eps, d.beta, d.grad_scale, M,
                                              const_cast<float *>(d.bwd[1].dy) + (size_t)row * A,
                                              d.ratio_out ? d.ratio_out + row : nullptr,
                                              d.clipped_out ? d.clipped_out + row : nullptr, t);
@@ -137,7 +139,7 @@ int rlx_ppo_discrete_heads_fused(const rlx_small_dense_problem *heads_host, cons
                                  const float *value_targets, float clip_epsilon, float beta_entropy, float grad_scale,
                                  float *scalars, float *value_loss_scalar, float *likelihood_ratio,
                                  float *clipped_likelihood_ratio, float *row_terms, unsigned int *sync_words,
-                                 int *status, void *stream) {
+                                 int *status, const float *clip_scale, void *stream) {
     RLX_REQUIRE(heads_host && actions && advantages && old_probs && value_targets && row_terms && sync_words && status,
                 "rlx_ppo_discrete_heads_fused: null pointer");
     const rlx_small_dense_problem &v = heads_host[0], &pi = heads_host[1];
@@ -166,6 +168,7 @@ int rlx_ppo_discrete_heads_fused(const rlx_small_dense_problem *heads_host, cons
     RLX_REQUIRE(G <= 128, "rlx_ppo_discrete_heads_fused: %d workgroups must be resident at once (K too large)", G);
     d.actions = actions; d.advantages = advantages; d.old_probs = old_probs; d.value_targets = value_targets;
     d.ld_old = ld_old; d.clip_eps = clip_epsilon; d.beta = beta_entropy; d.grad_scale = grad_scale;
+    d.clip_scale = clip_scale;
     d.scalars = scalars; d.value_scalar = value_loss_scalar; d.ratio_out = likelihood_ratio;
     d.clipped_out = clipped_likelihood_ratio; d.terms = row_terms; d.sync = sync_words; d.status = status;
     d.kblocks = kblocks;

@@ -498,7 +498,7 @@ def small_dense_forward_multi(ctx, items, tag="", weights=None):
 
 
 def ppo_discrete_heads_fused(ctx, v_item, pi_item, actions, advantages, old_probs, value_targets, clip_eps, beta,
-                             scalars, value_scalar, status, ratio_out=None, clipped_out=None, tag=""):
+                             scalars, value_scalar, status, ratio_out=None, clipped_out=None, tag="", clip_scale=None):
     """Value head + policy head forward, both losses, both backward passes in ONE launch
     (rlx_ppo_discrete_heads_fused).  items = (Dense layer, input Tensor).  -> (v Tensor, logits Tensor) with .grad
     holding the loss gradients, like small_dense_forward_multi + the loss launch + small_dense_backward_multi."""
@@ -532,7 +532,7 @@ def ppo_discrete_heads_fused(ctx, v_item, pi_item, actions, advantages, old_prob
         sync = ctx.buffers[key] = torch.zeros(2, dtype=torch.int32, device=ctx.device)
     ctx.lib.ppo_discrete_heads_fused(ctypes.byref(arr), actions, advantages, old_probs, old_probs.shape[-1],
                                      value_targets, float(clip_eps), float(beta), 1.0, scalars, value_scalar,
-                                     ratio_out, clipped_out, scratch, sync, status, ctx.stream)
+                                     ratio_out, clipped_out, scratch, sync, status, clip_scale, ctx.stream)
     return outs
 
 

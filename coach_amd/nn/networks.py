@@ -122,6 +122,7 @@ class ClippedPPONet(_NetBase):
         Dense with normalized-columns(0.01) init + one state-independent policy_log_std vector)."""
         self.obs_shape, self.image, self.A = tuple(obs_shape), len(obs_shape) == 3, n_actions
         self.clip_eps, self.beta = clip_likelihood_ratio_using_epsilon, beta_entropy
+        self._clip_scale_dev, self._clip_scale_value = None, None
         self.continuous = continuous
         import os
         # RLX_FUSED_HEADS=1: heads forward / losses / heads backward as ONE launch with an in-kernel barrier
@@ -192,12 +193,27 @@ class ClippedPPONet(_NetBase):
                 return i
         return 0
 
+    def set_clip_rescaler(self, value):
+        """clip_param_rescaler (clipped_ppo_agent.py:266-268) as a DEVICE scalar: forward_backward(clip_rescaler=None)
+        then multiplies the clip range by it inside the loss kernel, so a captured graph serves every value of a
+        decaying clipping_decay_schedule."""
+        if self._clip_scale_dev is None:
+            self._clip_scale_dev = torch.ones(1, dtype=torch.float32, device=self.device)
+        if self._clip_scale_value != float(value):
+            self._clip_scale_dev.fill_(float(value))
+            self._clip_scale_value = float(value)
+
     def forward_backward(self, obs, B, actions, advantages, value_targets, old_probs,
                          clip_rescaler=1.0, ratio_out=None, clipped_out=None, stop_after_dense=False):
         """accumulate_gradients (tensorflow_components/architecture.py:312-385): forward both towers,
         head losses, backward; leaves d total_loss / d theta in params.grads.
-        stop_after_dense: stop once the dense layers' gradients are final (backward_rest() resumes)."""
+        stop_after_dense: stop once the dense layers' gradients are final (backward_rest() resumes).
+        clip_rescaler None: the device scalar of set_clip_rescaler."""
         ctx = self.ctx
+        clip_dev = self._clip_scale_dev if clip_rescaler is None else None
+        if clip_rescaler is None:
+            assert clip_dev is not None, "set_clip_rescaler first"
+            clip_rescaler = 1.0
         acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
         mid = acts[-1]
         mid.ensure_grad()
@@ -208,7 +224,7 @@ class ClippedPPONet(_NetBase):
             v, logits = G.ppo_discrete_heads_fused(ctx, (self.v_head, xv), (self.pi_head, xp), actions, advantages,
                                                    old_probs, value_targets, self.clip_eps * clip_rescaler, self.beta,
                                                    self.scalars[0:4], self.scalars[4:5], self.status, ratio_out,
-                                                   clipped_out, tag="train")
+                                                   clipped_out, tag="train", clip_scale=clip_dev)
         elif fused_heads:      # value + policy head in one launch (forward here, backward below)
             v, logits = G.small_dense_forward_multi(ctx, [(self.v_head, xv), (self.pi_head, xp)], tag="train")
         else:
@@ -223,7 +239,7 @@ class ClippedPPONet(_NetBase):
             self.lib.ppo_discrete_value_losses(logits.data, self.A, actions, advantages, old_probs, self.A, B,
                                                self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
                                                self.A, self.scalars[0:4], ratio_out, clipped_out, self.status,
-                                               v.data, value_targets, dv, self.scalars[4:5], ctx.stream)
+                                               v.data, value_targets, dv, self.scalars[4:5], clip_dev, ctx.stream)
         else:
             self.lib.regression_loss(v.data, 1, value_targets, 1, None, B, 1, 0, 1.0, 1.0, dv, 1,
                                      self.scalars[4:5], ctx.stream)
@@ -234,7 +250,7 @@ class ClippedPPONet(_NetBase):
                                          actions, advantages, old_mean, old_std, self.A, B, self.A,
                                          self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits, self.A,
                                          self.params.g("main/ppo_head/policy_log_std"), self.scalars[0:4],
-                                         ratio_out, clipped_out, ctx.stream)
+                                         ratio_out, clipped_out, clip_dev, ctx.stream)
 
         if one_launch:
             pass

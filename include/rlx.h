@@ -413,7 +413,7 @@ int rlx_ppo_discrete_heads_fused(const rlx_small_dense_problem *heads_host, cons
                                  const float *value_targets, float clip_epsilon, float beta_entropy, float grad_scale,
                                  float *scalars, float *value_loss_scalar, float *likelihood_ratio,
                                  float *clipped_likelihood_ratio, float *row_terms, unsigned int *sync_words,
-                                 int *status, void *stream);
+                                 int *status, const float *clip_scale, void *stream);
 int rlx_dense_small_backward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
 
 /* -------------------------------------------------------- head losses (K9) -- */
@@ -426,13 +426,16 @@ int rlx_regression_loss(const float *out, long long ld_out, const float *target,
 int rlx_softmax(const float *logits, long long ld, int batch, int n, float *probs,
                 long long ld_out, void *stream);                    /* heads/ppo_head.py:108 */
 /* scalars[4] = {surrogate loss, mean entropy, mean KL(old||new), total head loss}.
- * clip_epsilon = clip_likelihood_ratio_using_epsilon * clip_param_rescaler.  heads/ppo_head.py:52-116 */
+ * The clip range is clip_epsilon (clip_likelihood_ratio_using_epsilon) times the clip_param_rescaler placeholder
+ * (heads/ppo_head.py:52-116, clipped_ppo_agent.py:266-268): pass the rescaler either folded into clip_epsilon
+ * (clip_scale NULL) or as a DEVICE scalar clip_scale[0] — a captured hipGraph then serves a decaying
+ * clipping_decay_schedule (presets/Mujoco_ClippedPPO.py) without being re-captured for every new value. */
 int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
                           const float *advantages, const float *old_probs, long long ld_old,
                           int batch, int n_actions, float clip_epsilon, float beta_entropy,
                           float grad_scale, float *dlogits, long long ld_grad, float *scalars,
                           float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
-                          void *stream);
+                          const float *clip_scale, void *stream);
 
 /* rlx_ppo_discrete_loss and the VHead MSE loss (rlx_regression_loss, dim 1, weight 1) of the same
  * minibatch in ONE launch: values / value_targets / dvalues are [batch]. */
@@ -442,7 +445,7 @@ int rlx_ppo_discrete_value_losses(const float *logits, long long ld, const int *
                                   float grad_scale, float *dlogits, long long ld_grad, float *scalars,
                                   float *likelihood_ratio, float *clipped_likelihood_ratio, int *status,
                                   const float *values, const float *value_targets, float *dvalues,
-                                  float *value_loss_scalar, void *stream);
+                                  float *value_loss_scalar, const float *clip_scale, void *stream);
 
 /* Continuous policy (heads/ppo_head.py:118-144): MultivariateNormalDiag(mean, exp(log_std) + eps),
  * log_std one state-independent vector [action_dim]; old_std is the old network's policy_std output.
@@ -452,7 +455,7 @@ int rlx_ppo_continuous_loss(const float *mean, long long ld, const float *log_st
                             long long ld_old, int batch, int action_dim, float clip_epsilon,
                             float beta_entropy, float grad_scale, float *dmean, long long ld_grad,
                             float *dlog_std, float *scalars, float *likelihood_ratio,
-                            float *clipped_likelihood_ratio, void *stream);
+                            float *clipped_likelihood_ratio, const float *clip_scale, void *stream);
 
 /* ------------------------------------------ optimiser / target mixing (K11) -- */
 /* state = {beta1_power, beta2_power} (2 device floats).  tf.train.AdamOptimizer as built in

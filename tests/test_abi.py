@@ -82,7 +82,7 @@ def test_argument_validation_matches_reference_error_cases():
         lib.adam_tf1(P(0x1004), fake, fake, fake, 16, 1e-3, 0.9, 0.99, 1e-4, fake, 1.0, None)
     with pytest.raises(_rlx.RlxError, match="minibatch must be"):
         lib.ppo_continuous_loss(fake, 4, fake, fake, fake, fake, fake, 4, 5000, 4, 0.2, 0.0, 1.0, None, 4,
-                                None, None, None, None, None)
+                                None, None, None, None, None, None)
 
 
 def test_wrong_argument_count_is_a_type_error():

@@ -139,7 +139,7 @@ def test_hip_loss_kernels_vs_oracle_and_reference_kat(rlx, dev):
     st = status_tensor(dev)
     rlx.ppo_discrete_loss(dev_tensor(np.log(new), dev), 2, dev_tensor([0, 1, 0], dev, np.int32),
                           dev_tensor([-2, 2, 1], dev, np.float32), dev_tensor(old, dev), 2, 3, 2, 0.2, 0.0, 1.0,
-                          None, 2, sc, None, None, st, 0)
+                          None, 2, sc, None, None, st, None, 0)
     np.testing.assert_allclose(sc[0].item(), -0.142857153, rtol=2e-6)
     for B, A, beta in ((64, 6, 0.01), (1, 2, 0.0), (1000, 18, 0.05)):
         logits = rng.randn(B, A).astype(np.float32)
@@ -150,8 +150,10 @@ def test_hip_loss_kernels_vs_oracle_and_reference_kat(rlx, dev):
         dl = torch.empty(B, A, dtype=torch.float32, device=dev)
         ratio = torch.empty(B, dtype=torch.float32, device=dev)
         clipped = torch.empty(B, dtype=torch.float32, device=dev)
+        # clip range as epsilon x a DEVICE rescaler (0.4 x 0.5 = 0.2 exactly in fp32)
         rlx.ppo_discrete_loss(dev_tensor(logits, dev), A, dev_tensor(acts, dev, np.int32), dev_tensor(adv, dev),
-                              dev_tensor(oldp, dev), A, B, A, 0.2, beta, 1.0, dl, A, sc, ratio, clipped, st, 0)
+                              dev_tensor(oldp, dev), A, B, A, 0.4, beta, 1.0, dl, A, sc, ratio, clipped, st,
+                              dev_tensor(np.array([0.5], dtype=np.float32), dev), 0)
         np.testing.assert_allclose(sc.cpu().numpy(), [ref["surrogate"], ref["entropy"], ref["kl"], ref["total"]],
                                    rtol=2e-4, atol=2e-6)
         np.testing.assert_allclose(dl.cpu().numpy(), ref["dlogits"], rtol=2e-4, atol=1e-7)
@@ -175,7 +177,7 @@ def test_hip_loss_kernels_vs_oracle_and_reference_kat(rlx, dev):
     assert int(st.item()) == 0
     rlx.ppo_discrete_loss(dev_tensor(np.log(new), dev), 2, dev_tensor([0, 5, 0], dev, np.int32),
                           dev_tensor([-2, 2, 1], dev, np.float32), dev_tensor(old, dev), 2, 3, 2, 0.2, 0.0, 1.0,
-                          None, 2, sc, None, None, st, 0)
+                          None, 2, sc, None, None, st, None, 0)
     assert int(st.item()) == 1
 
 
@@ -229,7 +231,7 @@ def test_ppo_continuous_loss_kernel_matches_oracle(rlx, dev, B, A):
     dm = torch.zeros(B, A, device=dev); dl = torch.zeros(A, device=dev)
     sc = torch.zeros(4, device=dev); ra = torch.zeros(B, device=dev); cl = torch.zeros(B, device=dev)
     rlx.ppo_continuous_loss(dev_tensor(mean, dev), A, dev_tensor(ls, dev), dev_tensor(x, dev), dev_tensor(adv, dev),
-                            dev_tensor(om, dev), dev_tensor(os_, dev), A, B, A, 0.2, 0.01, 1.0, dm, A, dl, sc, ra, cl, 0)
+                            dev_tensor(om, dev), dev_tensor(os_, dev), A, B, A, 0.2, 0.01, 1.0, dm, A, dl, sc, ra, cl, None, 0)
     np.testing.assert_allclose(sc.cpu().numpy(), [r["surrogate"], r["entropy"], r["kl"], r["total"]], rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(ra.cpu().numpy(), r["ratio"], rtol=2e-4)
     np.testing.assert_allclose(cl.cpu().numpy(), r["clipped"], rtol=2e-4)

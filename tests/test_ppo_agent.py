@@ -178,3 +178,33 @@ def test_continuous_ppo_with_observation_normalization(dev):
     ls = a.networks["main"].params.w("main/ppo_head/policy_log_std").cpu().numpy()
     assert np.abs(ls).max() > 0 and np.isfinite(ls).all()           # the log-std variable is being trained
     assert a.actions.dtype == torch.float32 and float(a.actions.abs().max()) <= 1.0
+
+
+@pytest.mark.gpu
+def test_decaying_clip_schedule_reuses_the_captured_graphs(rlx, dev):
+    """clipping_decay_schedule = LinearSchedule (presets/Mujoco_ClippedPPO.py): the clip range changes every phase.
+    It reaches the loss kernel through a device scalar, so the epoch / act graphs captured in the first phases are
+    replayed afterwards (no new graph per value), and the results equal the eager run of the same schedule."""
+    import torch
+    from coach_amd.schedules import LinearSchedule
+    runs = {}
+    for graphs in (True, False):
+        random.seed(3); np.random.seed(3)
+        agent = _make(dev, 4, 6, 24, 8, 2, seed=0, kind="vector")
+        agent.use_graphs = graphs
+        agent.ap.algorithm.clipping_decay_schedule = LinearSchedule(1.0, 0.1, 40)
+        sizes, res = [], []
+        for it in range(5):
+            while True:
+                agent.act()
+                r = agent.train()
+                if r is not None:
+                    break
+            res.append(np.array([x.cpu().numpy()[:5] for x in r]))
+            sizes.append(len(agent._graphs))
+        runs[graphs] = (np.array(res), agent.networks["main"].params.weights.clone(), sizes,
+                        float(agent.ap.algorithm.clipping_decay_schedule.current_value))
+    assert runs[True][3] < 0.9                                        # the schedule did decay
+    assert runs[True][2][2] == runs[True][2][-1] > 0                  # no graphs added after the third phase
+    np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=1e-6, atol=1e-7)
+    assert torch.equal(runs[True][1], runs[False][1])
