@@ -130,6 +130,136 @@ __global__ void __launch_bounds__(256) ppo_heads_fused_kernel(const PpoHeadsDev 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same three steps WITHOUT a grid-wide dependency: the value head and the policy head read different towers and
+// have separate losses, so each gets ONE workgroup (grid = 2) that keeps its whole input [M][K] in LDS (M * K <= 32 K
+// floats: C2's 64 x 512), runs forward (a wave per row), the per-row loss terms + batch means (the stand-alone loss
+// kernels' block_sum tree), and the backward pass (a thread per input feature: dW, dx with the tower's activation
+// derivative; db) — three launches' work behind workgroup barriers only.  Summation orders differ from the
+// dense_small kernels' (fp32 noise level differences; the loss scalars' trees are the same).
+template <int NN>
+__global__ void __launch_bounds__(1024) ppo_heads_wg_kernel(const PpoHeadsDev d) {
+    extern __shared__ float sm[];
+    const int h = blockIdx.x;
+    const SmallDense f = d.fwd[h];
+    const SmallDenseBwd bw = d.bwd[h];
+    const int M = f.M, K = f.K, N = f.N, tid = threadIdx.x, nt = blockDim.x;
+    float *xs = sm;                       // [M][K]
+    float *ws = xs + (size_t)M * K;       // [K][NN], zero-padded columns
+    float *ys = ws + (size_t)K * NN;      // [M][NN]: head outputs, then their gradients
+    float *red = ys + (size_t)M * NN;     // [1024]
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(f.x);
+        float4 *dst = reinterpret_cast<float4 *>(xs);
+        for (int i = tid; i < (M * K) >> 2; i += nt) dst[i] = src[i];
+        for (int i = tid; i < K * NN; i += nt) {
+            const int k = i / NN, n = i - k * NN;
+            ws[i] = n < N ? f.w[(size_t)k * N + n] : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- forward: a wave per row, lanes stride over the features
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int row = wave; row < M; row += nw) {
+        float acc[NN];
+#pragma unroll
+        for (int n = 0; n < NN; ++n) acc[n] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float xv = xs[(size_t)row * K + k];
+#pragma unroll
+            for (int n = 0; n < NN; ++n) acc[n] = fmaf(xv, ws[k * NN + n], acc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            float v = acc[n];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0 && n < N) {
+                v += f.b ? f.b[n] : 0.f;
+                ys[row * NN + n] = v;
+                f.y[(size_t)row * N + n] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- per-row loss terms and the gradient w.r.t. the head outputs
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    if (tid < M) {
+        const int row = tid;
+        if (h == 0) {                                            // VHead: MSE(target, V), loss weight 1
+            const float e = ys[row * NN] - d.value_targets[row];
+            const float g = d.grad_scale * (2.f * e) / (float)M;
+            ys[row * NN] = g;
+            const_cast<float *>(bw.dy)[row] = g;
+            t0 = e * e;
+        } else {                                                 // PPOHead
+            float z[NN], dz[NN];
+#pragma unroll
+            for (int n = 0; n < NN; ++n) z[n] = ys[row * NN + n];
+            PpoRowTerms t{0.f, 0.f, 0.f};
+            const bool ok = ppo_discrete_row(z, d.old_probs + (size_t)row * d.ld_old, d.actions[row], N,
+                                             d.advantages[row], d.clip_scale ? d.clip_eps * *d.clip_scale : d.clip_eps,
+                                             d.beta, d.grad_scale, M, dz, d.ratio_out ? d.ratio_out + row : nullptr,
+                                             d.clipped_out ? d.clipped_out + row : nullptr, t);
+            if (!ok) {
+                atomicOr(d.status, 1);
+                t = PpoRowTerms{0.f, 0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < NN; ++n) dz[n] = 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                ys[row * NN + n] = n < N ? dz[n] : 0.f;
+                if (n < N) const_cast<float *>(bw.dy)[(size_t)row * N + n] = dz[n];
+            }
+            t0 = t.sur; t1 = t.ent; t2 = t.kl;
+        }
+    }
+    const float s0 = block_sum(t0, red);
+    if (h == 0) {
+        if (tid == 0 && d.value_scalar) d.value_scalar[0] = s0 / (float)M;
+    } else {
+        const float s1 = block_sum(t1, red);
+        const float s2 = block_sum(t2, red);
+        if (tid == 0 && d.scalars) {
+            const float inv = 1.f / (float)M;
+            d.scalars[0] = -s0 * inv;
+            d.scalars[1] = s1 * inv;
+            d.scalars[2] = s2 * inv;
+            d.scalars[3] = -s0 * inv - d.beta * s1 * inv;
+        }
+    }
+    __syncthreads();
+    // ---- backward: a thread per input feature k: dW[k][:] = sum_b x[b][k] dz[b][:],  dx[b][k] = (dz[b] . W[k]) act'(x)
+    for (int k = tid; k < K; k += nt) {
+        float wv[NN], acc[NN];
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            wv[n] = ws[k * NN + n];
+            acc[n] = 0.f;
+        }
+        for (int b = 0; b < M; ++b) {
+            const float xv = xs[(size_t)b * K + k];
+            float g = 0.f;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                const float dzv = ys[b * NN + n];
+                acc[n] = fmaf(xv, dzv, acc[n]);
+                g = fmaf(dzv, wv[n], g);
+            }
+            if (bw.dx) bw.dx[(size_t)b * K + k] = bw.lower_act ? g * act_deriv_out(xv, bw.lower_act) : g;
+        }
+        if (bw.dw)
+            for (int n = 0; n < N; ++n) bw.dw[(size_t)k * N + n] = acc[n];
+    }
+    if (tid < N && bw.db) {
+        float sdb = 0.f;
+        for (int b = 0; b < M; ++b) sdb += ys[b * NN + tid];
+        bw.db[tid] = sdb;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,6 +293,40 @@ int rlx_ppo_discrete_heads_fused(const rlx_small_dense_problem *heads_host, cons
                                  q.dx_tower_stride, q.M, q.K, q.N, 0, q.lower_activation};
         const int kb = (q.K + kKL - 1) / kKL;
         if (kb > kblocks) kblocks = kb;
+    }
+    d.actions = actions; d.advantages = advantages; d.old_probs = old_probs; d.value_targets = value_targets;
+    d.ld_old = ld_old; d.clip_eps = clip_epsilon; d.beta = beta_entropy; d.grad_scale = grad_scale;
+    d.clip_scale = clip_scale;
+    d.scalars = scalars; d.value_scalar = value_loss_scalar; d.ratio_out = likelihood_ratio;
+    d.clipped_out = clipped_likelihood_ratio; d.terms = row_terms; d.sync = sync_words; d.status = status;
+    d.kblocks = kblocks;
+    {
+        // one workgroup per head, the head's input resident in LDS (no grid-wide dependency): the default
+        static const bool grid_form = [] { const char *e = getenv("RLX_PPO_HEADS_GRID"); return e && e[0] == '1'; }();
+        const int kmax = v.K > pi.K ? v.K : pi.K;
+        const size_t wg_floats = (size_t)v.M * kmax + (size_t)kmax * nn + (size_t)v.M * nn + 1024;
+        const bool aligned = (((uintptr_t)v.x | (uintptr_t)pi.x) & 15) == 0 && ((size_t)v.M * v.K) % 4 == 0 &&
+                             ((size_t)pi.M * pi.K) % 4 == 0;
+        if (!grid_form && aligned && v.M <= 1024 && wg_floats * sizeof(float) <= 160 * 1024) {
+            const size_t lds = wg_floats * sizeof(float);
+            hipStream_t s2 = rlx::as_stream(stream);
+#define RLX_HEADS_WG(NN_)                                                                                       \
+            {                                                                                                    \
+                static size_t configured = 0;                                                                    \
+                if (lds > configured) {                                                                          \
+                    RLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_heads_wg_kernel<NN_>),        \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+                    configured = lds;                                                                            \
+                }                                                                                                \
+                ppo_heads_wg_kernel<NN_><<<2, 1024, lds, s2>>>(d);                                               \
+            }
+            if (nn == 4) RLX_HEADS_WG(4)
+            else if (nn == 8) RLX_HEADS_WG(8)
+            else RLX_HEADS_WG(16)
+#undef RLX_HEADS_WG
+            RLX_LAUNCH_CHECK();
+            return RLX_OK;
+        }
     }
     const int G = 2 * kblocks;
     RLX_REQUIRE(G <= 128, "rlx_ppo_discrete_heads_fused: %d workgroups must be resident at once (K too large)", G);

@@ -129,6 +129,11 @@ class ClippedPPONet(_NetBase):
         # (csrc/ppo_heads_fused.hip).  Bit-identical, but measured SLOWER on MI355X (C2: 93.9 vs 89.4 ms per
         # iteration, profiles/r02_ab_fused_heads.txt): each of the three kernels is ~1-3 us of work behind a ~4 us
         # launch, and the barrier plus the serialised per-row phase cost more than the two boundaries saved.  Opt-in.
+        # A second form without any grid-wide dependency (ppo_heads_wg_kernel: one workgroup per head, the head's
+        # [B][K] input resident in LDS, selected by the library when it fits) is correct to fp32 noise and slower still
+        # (C2 114.0 vs 103.6 ms per iteration on one box, gpurun_out/r02_call30): two workgroups cannot make up in
+        # parallelism what the three small grids have.  RLX_FUSED_HEADS=1 selects it (RLX_PPO_HEADS_GRID=1: the
+        # barrier form).
         self._heads_one_launch = os.environ.get("RLX_FUSED_HEADS", "0") == "1"
         self.params = G.FlatParams()
         self.torso, feat = build_torso(self.params, "main", obs_shape, activation, 2, embedder, middleware)
