@@ -320,6 +320,11 @@ class ClippedPPOAgent(object):
         if self.ragged:
             done = self.memory.num_transitions_in_complete_episodes()
             if done >= steps or (self.memory.steps >= self.memory.T and done > 0):
+                if done < steps and self.dist is not None:
+                    # every rank must run the same number of minibatch collectives per phase
+                    raise ValueError("rollout buffer full with %d < %d complete-episode transitions: with data "
+                                     "parallelism every rank trains on num_consecutive_playing_steps transitions; "
+                                     "declare a longer max episode length" % (done, steps))
                 self.last_training_phase_step = self.total_steps_counter
                 return True
             if self.memory.steps >= self.memory.T:
