@@ -318,6 +318,14 @@ def gemm_pair_or_single(desc, stream=None):
     lib().gemm(ctypes.byref(desc), current_stream() if stream is None else stream)
 
 
+def gemm_chain2(first, second, stream=None):
+    """two descriptors built with gemm(..., launch=False), second.A == first.C: two dense layers as one launch."""
+    if GEMM_HOOK is not None:
+        GEMM_HOOK(GemmDesc.from_buffer_copy(first))
+        GEMM_HOOK(GemmDesc.from_buffer_copy(second))
+    lib().gemm_chain2(ctypes.byref(first), ctypes.byref(second), current_stream() if stream is None else stream)
+
+
 def gemm_pair(weight_grad, input_grad, stream=None):
     """two descriptors built with gemm(..., launch=False): a layer's dW and dX products as one launch."""
     if GEMM_HOOK is not None:       # one entry: the two products go out as one launch

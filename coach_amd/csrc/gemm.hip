@@ -817,6 +817,147 @@ __global__ void __launch_bounds__(kThreads) gemm_thin_pair_kernel(const GemmPair
         gemm_thin_body<true, false>(p.g[1], bx, by, bz, As, Bs);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two consecutive dense layers in ONE launch (the forward pass of the small MLPs of DDPG / TD3 / DQN: obs -> H1 -> H2
+// with a handful of inputs):  y1 = act1(x W1 + b1),  y2 = act2(y1 W2 + b2).
+// A workgroup owns one 32 x 32 tile of y2.  It first computes the 32 rows of y1 it needs — ALL H1 columns, which is
+// cheap because K1 <= 64 — straight into LDS in the k-major layout the second product reads its A operand from
+// (the column-0 workgroups also write y1 to memory: the backward pass needs it), then the thin kernel's second
+// product: the reduction index split over the 4 waves in chunks of 32, partial tiles summed through LDS in the same
+// fixed order.  Same k-order as two gemm_thin_kernel launches: bit-identical outputs.
+struct Chain2Dev {
+    GemmDev g1, g2;           // operands / epilogues of the two layers as rlx_gemm would see them
+    int h1_pad;               // H1 rounded up to a multiple of 32
+};
+constexpr int kChainMaxK1 = 64, kChainMaxH1 = 512;
+
+__global__ void __launch_bounds__(kThreads) gemm_chain2_kernel(const Chain2Dev p) {
+    extern __shared__ float csm[];
+    constexpr int LD = 33;
+    float *xs = csm;                                   // [K1 rounded to even][33]  x tile, k-major
+    float *h1s = xs + kChainMaxK1 * LD;                // [h1_pad][33]              y1 tile, k-major
+    float *stage = h1s + (size_t)p.h1_pad * LD;        // [4][32][33]               the four waves' partial tiles
+    const GemmDev &g1 = p.g1, &g2 = p.g2;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int batch = blockIdx.z;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int K1 = g1.K, H1 = g1.N, N2 = g2.N, M = g1.M;
+    const float *x = static_cast<const float *>(g1.a.base) + batch_off(batch, g1.inner, g1.a.batch_stride, g1.a.batch_stride2);
+    const float *w1 = static_cast<const float *>(g1.b.base) + batch_off(batch, g1.inner, g1.b.batch_stride, g1.b.batch_stride2);
+    const float *b1 = g1.bias ? g1.bias + batch_off(batch, g1.inner, g1.bias_batch_stride, g1.bias_batch_stride2) : nullptr;
+    const float *w2 = static_cast<const float *>(g2.b.base) + batch_off(batch, g2.inner, g2.b.batch_stride, g2.b.batch_stride2);
+    const float *b2 = g2.bias ? g2.bias + batch_off(batch, g2.inner, g2.bias_batch_stride, g2.bias_batch_stride2) : nullptr;
+    float *y1 = g1.c + (size_t)batch * g1.c_batch_stride;
+    float *y2 = g2.c + (size_t)batch * g2.c_batch_stride;
+    const int K1e = (K1 + 1) & ~1;
+    for (int e = tid; e < 32 * K1e; e += kThreads) {                 // x tile: rows clamp, k beyond K1 -> 0
+        const int k = e % K1e, r = e / K1e;
+        const int row = min(m0 + r, M - 1);
+        xs[k * LD + r] = k < K1 ? x[(size_t)row * K1 + k] : 0.f;
+    }
+    __syncthreads();
+    // ---- layer 1: wave w computes the 32-column chunks w, w + 4, ... of y1's 32 rows.  The weight operands of a
+    // chunk (one per k pair and lane) are requested ALL AT ONCE, one chunk ahead of their use: issued one by one in
+    // front of their MFMA every one of them would cost a full memory latency (measured: C4 -21 %).
+    const int chunks = p.h1_pad >> 5;
+    constexpr int kPairs = kChainMaxK1 / 2;                 // k pairs of the longest first reduction
+    const int npairs = K1e >> 1;
+    auto load_w1 = [&](int c, float (&bv)[kPairs]) {
+        const int col = c * 32 + l31;
+        const bool live = c < chunks && col < H1;
+        const float *wp = w1 + col;
+#pragma unroll
+        for (int q = 0; q < kPairs; ++q) {
+            const int k = 2 * q + hi;
+            bv[q] = (live && q < npairs && k < K1) ? wp[(size_t)k * H1] : 0.f;
+        }
+    };
+    {
+        float bva[kPairs], bvb[kPairs];
+        load_w1(w, bva);
+        auto chunk = [&](int c, const float (&bv)[kPairs]) {
+            // k in [0, 32) and [32, 64) accumulate separately and are added once: the thin kernel gives these two
+            // quarters of its 128-wide slab to two waves (bit-identical sums for K1 > 32 too)
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < kPairs; ++q) {
+                if (q < npairs) {
+                    const float av = xs[(2 * q + hi) * LD + l31];
+                    if (q < 16) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[q], acc0, 0, 0, 0);
+                    else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[q], acc1, 0, 0, 0);
+                }
+            }
+            const int col = c * 32 + l31;
+            const float bias = (b1 && col < H1) ? b1[col] : 0.f;
+            const bool write_y1 = blockIdx.x == 0 && col < H1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float v = col < H1 ? apply_act((acc0[r] + acc1[r]) + bias, g1.act) : 0.f;
+                h1s[(size_t)col * LD + rl] = v;
+                if (write_y1 && m0 + rl < M) y1[(size_t)(m0 + rl) * g1.ldc + col] = v;
+            }
+        };
+        for (int c = w; c < chunks; c += 8) {
+            load_w1(c + 4, bvb);
+            chunk(c, bva);
+            if (c + 4 < chunks) {
+                load_w1(c + 8, bva);
+                chunk(c + 4, bvb);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2: K = H1 over the 4 waves in chunks of 32 (chunk c -> wave c % 4: gemm_thin_kernel's assignment),
+    // the weight operands of a chunk requested one chunk ahead
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int col2 = n0 + l31;
+    auto load_w2 = [&](int c, float (&bv)[16]) {
+        const bool live = c < chunks && col2 < N2;
+        const float *bp = w2 + (size_t)(c * 32 + hi) * N2 + col2;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bv[q] = (live && c * 32 + 2 * q + hi < H1) ? bp[(size_t)(2 * q) * N2] : 0.f;
+    };
+    {
+        float bva[16], bvb[16];
+        load_w2(w, bva);
+        auto chunk2 = [&](int c, const float (&bv)[16]) {
+            const float *ap = h1s + (size_t)(c * 32 + hi) * LD + l31;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * q * LD], bv[q], acc, 0, 0, 0);
+        };
+        for (int c = w; c < chunks; c += 8) {
+            load_w2(c + 4, bvb);
+            chunk2(c, bva);
+            if (c + 4 < chunks) {
+                load_w2(c + 8, bva);
+                chunk2(c + 4, bvb);
+            }
+        }
+    }
+    float *st = stage + w * (32 * LD);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * LD + l31] = acc[r];
+    __syncthreads();
+    const int rl = tid >> 3, c4 = (tid & 7) * 4;
+    const int row = m0 + rl;
+    if (row >= M) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + c4 + j;
+        if (col >= N2) continue;
+        const int o = rl * LD + c4 + j;
+        float v = ((stage[o] + stage[32 * LD + o]) + stage[2 * 32 * LD + o]) + stage[3 * 32 * LD + o];
+        v = apply_act(v + (b2 ? b2[col] : 0.f), g2.act);
+        y2[(size_t)row * g2.ldc + col] = v;
+    }
+}
+
 __global__ void splitk_reduce_kernel(const GemmDev g) {
     const long long mn = (long long)g.M * g.N;
     const int batch = blockIdx.y;
@@ -1418,6 +1559,46 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
         if (rc != RLX_OK) return rc;
     }
     if (px.splits > 1) return launch_splitk_reduce(px.g, px.M, px.N, px.batch, px.splits, s);
+    return RLX_OK;
+}
+
+int rlx_gemm_chain2(const rlx_gemm_desc *first, const rlx_gemm_desc *second, void *stream) {
+    GemmPlan p1, p2;
+    int rc = gemm_impl(first, stream, &p1);
+    if (rc != RLX_OK) return rc;
+    rc = gemm_impl(second, stream, &p2);
+    if (rc != RLX_OK) return rc;
+    static const bool off = [] { const char *e = getenv("RLX_NO_GEMM_CHAIN"); return e && e[0] == '1'; }();
+    const rlx_gemm_desc &a = *first, &b = *second;
+    bool ok = !off && p1.thin && p2.thin && p1.a_ck && p1.b_cn && p2.a_ck && p2.b_cn &&
+              a.K <= kChainMaxK1 && a.N <= kChainMaxH1 && b.K == a.N && b.M == a.M && b.batch == a.batch &&
+              a.a_row_stride == a.K && a.b_k_stride == a.N && b.b_k_stride == b.N && a.ldc == a.N &&
+              b.a_row_stride == a.ldc && static_cast<const void *>(b.A) == static_cast<const void *>(a.C) &&
+              !a.deriv_aux && !b.deriv_aux && !a.accumulate && !b.accumulate && !a.colsum_out && !b.colsum_out;
+    for (int i = 0; ok && i < a.batch; ++i) {          // the second layer reads batch entry i of the first's output
+        const int inner = b.batch_inner > 0 ? b.batch_inner : (1 << 30);
+        const int bo = i / inner;
+        const long long off2 = (long long)bo * b.a_batch_stride2 + (long long)(i - bo * inner) * b.a_batch_stride;
+        ok = off2 == (long long)i * a.c_batch_stride;
+    }
+    if (!ok) {
+        rc = gemm_impl(first, stream, nullptr);
+        if (rc != RLX_OK) return rc;
+        return gemm_impl(second, stream, nullptr);
+    }
+    Chain2Dev p;
+    p.g1 = p1.g; p.g2 = p2.g;
+    p.h1_pad = (a.N + 31) / 32 * 32;
+    const size_t lds = sizeof(float) * 33 * (size_t)(kChainMaxK1 + p.h1_pad + 4 * 32);
+    static size_t configured = 0;
+    if (lds > configured) {
+        RLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_chain2_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    dim3 grid((b.N + 31) / 32, (b.M + 31) / 32, b.batch);
+    gemm_chain2_kernel<<<grid, kThreads, lds, rlx::as_stream(stream)>>>(p);
+    RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
 

@@ -57,11 +57,20 @@ class ActorNet(_ACBase):
         if self._uniform_scale is None:
             raise NotImplementedError("per-dimension output scale is not implemented")
 
+    def _torso(self, ctx, x, tag, w, pair):
+        """embedder then middleware; one dense layer each (the presets' shape): the two go out as one launch."""
+        if len(self.emb.layers) == 1 and len(self.mid.layers) == 1:
+            y1, y2 = G.dense_chain2_forward(ctx, self.emb.layers[0], self.mid.layers[0], x, tag=tag, weights=w,
+                                            pair=pair)
+            return [x, y1], [y1, y2]
+        kw = {"pair": True} if pair else {"weights": w}
+        acts = self.emb.forward(ctx, x, tag=tag, **kw)
+        return acts, self.mid.forward(ctx, acts[-1], tag=tag, **kw)
+
     def forward(self, obs, B, use_target=False, tag="a", out=None):
         w = self.target if use_target else None
         ctx = self.ctx
-        acts = self.emb.forward(ctx, self._obs(obs, B), tag=tag, weights=w)
-        acts2 = self.mid.forward(ctx, acts[-1], tag=tag, weights=w)
+        acts, acts2 = self._torso(ctx, self._obs(obs, B), tag, w, False)
         y = self.head.forward(ctx, acts2[-1], tag=tag, weights=w)
         if out is None and self._uniform_scale == 1.0:
             return y.data.view(B, self.A), (acts, acts2, y)        # tanh output IS the action: no scaling launch
@@ -75,8 +84,7 @@ class ActorNet(_ACBase):
         [2, B, A] (row 0: online mu(s), row 1: target mu(s')) and the online activations for backward."""
         ctx = self.ctx
         x = G.Tensor(obs2.view(2, B, self.obs_dim), B, self.obs_dim, 2)
-        acts = self.emb.forward(ctx, x, tag=tag, pair=True)
-        acts2 = self.mid.forward(ctx, acts[-1], tag=tag, pair=True)
+        acts, acts2 = self._torso(ctx, x, tag, None, True)
         y = self.head.forward(ctx, acts2[-1], tag=tag, pair=True)
         if self._uniform_scale == 1.0:
             out = y.data.view(2, B, self.A)

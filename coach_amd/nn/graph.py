@@ -108,6 +108,10 @@ def normalized_columns(std):
 # a layer's dW and dX products (independent, same dz) go out as ONE launch (rlx_gemm_pair); the tests switch it off to
 # compare with the two-launch sequence
 PAIR_GRADIENT_GEMMS = True
+# two consecutive dense layers with a short first reduction as ONE launch (rlx_gemm_chain2): bit-identical to the two
+# thin-kernel launches, and measured SLOWER (C4 3 852 vs 5 841 env-steps/s on one box, gpurun_out/r02_call31: every
+# workgroup recomputes its hidden rows, the kernel needs 410 registers and 80 KB of LDS) — opt-in, RLX_GEMM_CHAIN=1
+CHAIN_DENSE_LAYERS = os.environ.get("RLX_GEMM_CHAIN", "0") == "1"
 
 
 class Workspace:
@@ -231,10 +235,12 @@ class Dense(Layer):
                 xavier_uniform(rng, self.K, self.N, (self.K, self.N))
             self.params.w(self.kname, t).copy_(torch.from_numpy(np.ascontiguousarray(w)))
 
-    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False, launch=True):
         """pair=True: the online and the target copy of the layer in one launch — towers [0, T) use
         the online weights, [T, 2T) the target weights (FlatParams.both); x carries either one tower
-        per copy (shared by the T streams of a copy) or one per (copy, stream)."""
+        per copy (shared by the T streams of a copy) or one per (copy, stream).
+        launch=False: -> (output Tensor, GEMM descriptor not yet run) for dense_chain2_forward; the descriptor is None
+        when the layer took a path that is not a plain batched GEMM (it has then been run)."""
         t0, T = self._range(t0, nt)
         p = self.params
         M = x.rows
@@ -254,6 +260,7 @@ class Dense(Layer):
             assert x.towers in (0, T), (self.name, x.towers, T)
             a_stride, TT = x.tower_stride(), T
         y = ctx.buffer(self.name, (TT, M, self.N), tag=tag)
+        desc = None
         if self.N <= SMALL_N and not x.u8:
             # heads: coalesced FMA kernel, no MFMA tile / split-K round trip (csrc/dense_small.hip)
             if not pair:
@@ -271,20 +278,21 @@ class Dense(Layer):
                     q.y, q.y_tower_stride = y.data_ptr() + c * T * M * self.N * 4, M * self.N
                     q.towers, q.M, q.K, q.N, q.activation = T, M, self.K, self.N, _rlx.ACT[self.act]
                 ctx.lib.dense_small_forward_multi(ctypes.byref(arr), 2, ctx.stream)
-        elif not pair and x.towers == 0 and T > 1 and self.N % 4 == 0 and FOLD_SHARED_INPUT:
+        elif launch and not pair and x.towers == 0 and T > 1 and self.N % 4 == 0 and FOLD_SHARED_INPUT:
             # the T towers read the SAME input: one GEMM over T*N columns loads (gathers) it once
             _rlx.gemm(M, T * self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
                       b_strides=(self.N, 1), ldc=self.N, bias=p.w(self.bname, t0, weights),
                       activation=self.act, batch=1, b_batch_stride=wstride, c_batch_stride=M * self.N,
                       bias_batch_stride=bstride, workspace=ctx.ws.splitk, n_fold=self.N)
         else:
-            _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
-                      bias=p.w(self.bname, t0, weights), activation=self.act, batch=TT,
-                      a_batch_stride=a_stride, b_batch_stride=wstride,
-                      c_batch_stride=M * self.N, bias_batch_stride=bstride,
-                      workspace=ctx.ws.splitk, **kw)
+            desc = _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
+                             bias=p.w(self.bname, t0, weights), activation=self.act, batch=TT,
+                             a_batch_stride=a_stride, b_batch_stride=wstride,
+                             c_batch_stride=M * self.N, bias_batch_stride=bstride,
+                             workspace=ctx.ws.splitk, launch=launch, **kw)
         T = TT
-        return Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag), act=self.act)
+        out = Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag), act=self.act)
+        return out if launch else (out, desc)
 
     def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
         """y.grad holds dL/dy (post-activation); writes dW, db and (optionally) x.grad.
@@ -476,6 +484,22 @@ class Conv2d(Layer):
             x.grad_is_dz = lower is not None
 
 
+def dense_chain2_forward(ctx, l1, l2, x, tag="", weights=None, t0=0, nt=None, pair=False):
+    """y1 = l1(x), y2 = l2(y1) — as ONE launch when the library's rlx_gemm_chain2 takes the pair (short first
+    reduction: the observation layer of the DDPG / TD3 / DQN MLPs), otherwise as the two launches.  -> (y1, y2)."""
+    kw = dict(tag=tag, weights=weights, t0=t0, nt=nt)
+    if pair:
+        kw["pair"] = True
+    if not (isinstance(l1, Dense) and isinstance(l2, Dense)) or x.u8 or l1.K > 64 or l1.N > 512 or \
+            l1.N <= SMALL_N or l2.N <= SMALL_N or not CHAIN_DENSE_LAYERS:
+        y1 = l1.forward(ctx, x, **kw)
+        return y1, l2.forward(ctx, y1, **kw)
+    y1, d1 = l1.forward(ctx, x, launch=False, **kw)
+    y2, d2 = l2.forward(ctx, y1, launch=False, **kw)
+    _rlx.gemm_chain2(d1, d2)
+    return y1, y2
+
+
 def small_dense_forward_multi(ctx, items, tag="", weights=None):
     """[(Dense layer, input Tensor)] -> [output Tensor], all layers in ONE launch (each N <= SMALL_N).
     weights: parameter buffer to read instead of the online weights (the target copy)."""
@@ -574,6 +598,10 @@ class Sequential:
     def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
         acts = [x]
         kw = {"pair": True} if pair else {}
+        if len(self.layers) == 2 and all(isinstance(l, Dense) for l in self.layers):
+            y1, y2 = dense_chain2_forward(ctx, self.layers[0], self.layers[1], x, tag=tag, weights=weights, t0=t0,
+                                          nt=nt, pair=pair)
+            return [x, y1, y2]
         for l in self.layers:
             acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, **kw))
         return acts

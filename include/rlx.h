@@ -317,6 +317,11 @@ int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_
  * dY — as ONE launch when both take the 64x64 tiled kernel (two launches otherwise; RLX_NO_GEMM_PAIR=1 forces that).
  * Each descriptor is exactly what rlx_gemm would get; when both split K they need disjoint workspaces. */
 int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream);
+/* Two consecutive dense layers (second->A == first->C) as ONE launch when the first has a short reduction (K <= 64,
+ * N <= 512: the observation layer of the DDPG / TD3 / DQN MLPs) and both would take the thin kernel: every workgroup
+ * recomputes the rows of the hidden layer it needs in LDS.  Bit-identical to the two launches (which are what runs
+ * otherwise, or with RLX_NO_GEMM_CHAIN=1); the first layer's output is written as well (the backward pass reads it). */
+int rlx_gemm_chain2(const rlx_gemm_desc *first, const rlx_gemm_desc *second, void *stream);
 /* Diagnostics (tools/gemm_timeline.py): while a device buffer of `capacity_u64` 64-bit words is registered, every
  * tiled-kernel launch of rlx_gemm records, per workgroup, four wall-clock ticks (10 ns: entry, first slab staged,
  * main loop done, exit) in its own region of the buffer; rlx_gemm_debug_calls lists the regions as rows of
