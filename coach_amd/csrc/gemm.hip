@@ -829,14 +829,17 @@ struct Chain2Dev {
     GemmDev g1, g2;           // operands / epilogues of the two layers as rlx_gemm would see them
     int h1_pad;               // H1 rounded up to a multiple of 32
 };
-constexpr int kChainMaxK1 = 64, kChainMaxH1 = 512;
+constexpr int kChainMaxK1 = 32, kChainMaxH1 = 512;
 
+// (no lane-dependent branches: every operand load is issued from a clamped, always-valid address and masked by a
+// select — predicated loads compile to an exec-mask branch each, which made the first version of this kernel
+// 10 600 instructions and three times slower than the two launches it replaces)
 __global__ void __launch_bounds__(kThreads) gemm_chain2_kernel(const Chain2Dev p) {
     extern __shared__ float csm[];
     constexpr int LD = 33;
-    float *xs = csm;                                   // [K1 rounded to even][33]  x tile, k-major
-    float *h1s = xs + kChainMaxK1 * LD;                // [h1_pad][33]              y1 tile, k-major
-    float *stage = h1s + (size_t)p.h1_pad * LD;        // [4][32][33]               the four waves' partial tiles
+    float *xs = csm;                                   // [32][33]       x tile, k-major, zero beyond K1
+    float *h1s = xs + kChainMaxK1 * LD;                // [h1_pad][33]   y1 tile, k-major
+    float *stage = h1s + (size_t)p.h1_pad * LD;        // [4][32][33]    the four waves' partial tiles
     const GemmDev &g1 = p.g1, &g2 = p.g2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -850,87 +853,94 @@ __global__ void __launch_bounds__(kThreads) gemm_chain2_kernel(const Chain2Dev p
     const float *b2 = g2.bias ? g2.bias + batch_off(batch, g2.inner, g2.bias_batch_stride, g2.bias_batch_stride2) : nullptr;
     float *y1 = g1.c + (size_t)batch * g1.c_batch_stride;
     float *y2 = g2.c + (size_t)batch * g2.c_batch_stride;
-    const int K1e = (K1 + 1) & ~1;
-    for (int e = tid; e < 32 * K1e; e += kThreads) {                 // x tile: rows clamp, k beyond K1 -> 0
-        const int k = e % K1e, r = e / K1e;
-        const int row = min(m0 + r, M - 1);
-        xs[k * LD + r] = k < K1 ? x[(size_t)row * K1 + k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 32 * 32 / kThreads; ++i) {                   // x tile [32 rows][32 k]
+        const int e = tid + i * kThreads;
+        const int k = e & 31, r = e >> 5;
+        const float v = x[(size_t)min(m0 + r, M - 1) * K1 + min(k, K1 - 1)];
+        xs[k * LD + r] = k < K1 ? v : 0.f;
     }
     __syncthreads();
-    // ---- layer 1: wave w computes the 32-column chunks w, w + 4, ... of y1's 32 rows.  The weight operands of a
-    // chunk (one per k pair and lane) are requested ALL AT ONCE, one chunk ahead of their use: issued one by one in
-    // front of their MFMA every one of them would cost a full memory latency (measured: C4 -21 %).
     const int chunks = p.h1_pad >> 5;
-    constexpr int kPairs = kChainMaxK1 / 2;                 // k pairs of the longest first reduction
-    const int npairs = K1e >> 1;
-    auto load_w1 = [&](int c, float (&bv)[kPairs]) {
+    // ---- layer 1: wave w computes the 32-column chunks w, w + 4, ... of y1's 32 rows; the 16 weight operands of a
+    // chunk are requested together, one chunk ahead of their use
+    auto load_w1 = [&](int c, float (&bv)[16]) {
         const int col = c * 32 + l31;
-        const bool live = c < chunks && col < H1;
-        const float *wp = w1 + col;
+        const float *wp = w1 + min(col, H1 - 1);
+        const bool live = col < H1;
 #pragma unroll
-        for (int q = 0; q < kPairs; ++q) {
+        for (int q = 0; q < 16; ++q) {
             const int k = 2 * q + hi;
-            bv[q] = (live && q < npairs && k < K1) ? wp[(size_t)k * H1] : 0.f;
+            const float v = wp[(size_t)min(k, K1 - 1) * H1];
+            bv[q] = (live && k < K1) ? v : 0.f;
+        }
+    };
+    auto chunk1 = [&](int c, const float (&bv)[16]) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * q + hi) * LD + l31], bv[q], acc, 0, 0, 0);
+        const int col = c * 32 + l31;
+        const bool live = col < H1;
+        const float bias = b1 ? b1[min(col, H1 - 1)] : 0.f;
+        const bool write_y1 = blockIdx.x == 0 && live;
+        float v[16];
+        if (g1.act == RLX_ACT_RELU) {                    // (uniform branches: one activation per launch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float t = acc[r] + bias; v[r] = t > 0.f ? t : 0.f; }
+        } else if (g1.act == RLX_ACT_TANH) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = tanhf(acc[r] + bias);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float o = live ? v[r] : 0.f;
+            h1s[(size_t)col * LD + rl] = o;
+            if (write_y1 && m0 + rl < M) y1[(size_t)(m0 + rl) * g1.ldc + col] = o;
         }
     };
     {
-        float bva[kPairs], bvb[kPairs];
+        float bva[16], bvb[16];
         load_w1(w, bva);
-        auto chunk = [&](int c, const float (&bv)[kPairs]) {
-            // k in [0, 32) and [32, 64) accumulate separately and are added once: the thin kernel gives these two
-            // quarters of its 128-wide slab to two waves (bit-identical sums for K1 > 32 too)
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
-#pragma unroll
-            for (int q = 0; q < kPairs; ++q) {
-                if (q < npairs) {
-                    const float av = xs[(2 * q + hi) * LD + l31];
-                    if (q < 16) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[q], acc0, 0, 0, 0);
-                    else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[q], acc1, 0, 0, 0);
-                }
-            }
-            const int col = c * 32 + l31;
-            const float bias = (b1 && col < H1) ? b1[col] : 0.f;
-            const bool write_y1 = blockIdx.x == 0 && col < H1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float v = col < H1 ? apply_act((acc0[r] + acc1[r]) + bias, g1.act) : 0.f;
-                h1s[(size_t)col * LD + rl] = v;
-                if (write_y1 && m0 + rl < M) y1[(size_t)(m0 + rl) * g1.ldc + col] = v;
-            }
-        };
         for (int c = w; c < chunks; c += 8) {
             load_w1(c + 4, bvb);
-            chunk(c, bva);
+            chunk1(c, bva);
             if (c + 4 < chunks) {
                 load_w1(c + 8, bva);
-                chunk(c + 4, bvb);
+                chunk1(c + 4, bvb);
             }
         }
     }
     __syncthreads();
-    // ---- layer 2: K = H1 over the 4 waves in chunks of 32 (chunk c -> wave c % 4: gemm_thin_kernel's assignment),
-    // the weight operands of a chunk requested one chunk ahead
+    // ---- layer 2: K = H1 over the 4 waves in chunks of 32 (chunk c -> wave c % 4: gemm_thin_kernel's assignment)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int col2 = n0 + l31;
     auto load_w2 = [&](int c, float (&bv)[16]) {
-        const bool live = c < chunks && col2 < N2;
-        const float *bp = w2 + (size_t)(c * 32 + hi) * N2 + col2;
+        const float *bp = w2 + min(col2, N2 - 1);
+        const bool live = col2 < N2;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) bv[q] = (live && c * 32 + 2 * q + hi < H1) ? bp[(size_t)(2 * q) * N2] : 0.f;
+        for (int q = 0; q < 16; ++q) {
+            const int k = c * 32 + 2 * q + hi;
+            const float v = bp[(size_t)min(k, H1 - 1) * N2];
+            bv[q] = (live && k < H1) ? v : 0.f;
+        }
+    };
+    auto chunk2 = [&](int c, const float (&bv)[16]) {
+        const float *ap = h1s + (size_t)(c * 32 + hi) * LD + l31;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * q * LD], bv[q], acc, 0, 0, 0);
     };
     {
         float bva[16], bvb[16];
         load_w2(w, bva);
-        auto chunk2 = [&](int c, const float (&bv)[16]) {
-            const float *ap = h1s + (size_t)(c * 32 + hi) * LD + l31;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * q * LD], bv[q], acc, 0, 0, 0);
-        };
         for (int c = w; c < chunks; c += 8) {
             load_w2(c + 4, bvb);
             chunk2(c, bva);

@@ -109,8 +109,8 @@ def normalized_columns(std):
 # compare with the two-launch sequence
 PAIR_GRADIENT_GEMMS = True
 # two consecutive dense layers with a short first reduction as ONE launch (rlx_gemm_chain2): bit-identical to the two
-# thin-kernel launches, and measured SLOWER (C4 3 852 vs 5 841 env-steps/s on one box, gpurun_out/r02_call31: every
-# workgroup recomputes its hidden rows, the kernel needs 410 registers and 80 KB of LDS) — opt-in, RLX_GEMM_CHAIN=1
+# thin-kernel launches, and measured SLOWER twice (C4 -34 % with predicated loads, -17 % branch-free:
+# profiles/r02_ab_gemm_pair.txt — every column tile recomputes the hidden rows) — opt-in, RLX_GEMM_CHAIN=1
 CHAIN_DENSE_LAYERS = os.environ.get("RLX_GEMM_CHAIN", "0") == "1"
 
 
