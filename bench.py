@@ -308,13 +308,15 @@ def run_off_policy(args, device, dist):
         out["roofline"] = update_roofline(agent, args.workload)
     if dist.rank == 0 and dist.world_size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_off_policy(args.workload)
-        if args.workload == "c1":       # the reference's own per-step code, timed in the build container
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_cpu_reference_c1_container.json")) as f:
-                    r = json.load(f)
-                out["cpu_baseline"]["reference"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "where", "sample")}
-            except (OSError, ValueError, KeyError):
-                pass
+        # the reference's own per-step / per-update code, timed in the build container (tools/time_reference_cpu*.py)
+        ref_file = {"c1": "r01_cpu_reference_c1_container.json"}.get(
+            args.workload, "r02_cpu_reference_%s_container.json" % args.workload)
+        try:
+            with open(os.path.join(ROOT, "profiles", ref_file)) as f:
+                r = json.load(f)
+            out["cpu_baseline"]["reference"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "where", "sample")}
+        except (OSError, ValueError, KeyError):
+            pass
     if dist.rank == 0:
         print(json.dumps(out))
 
