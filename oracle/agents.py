@@ -210,7 +210,13 @@ class ClippedPPOAgentOracle:
 
     def __init__(self, arrays, env, n_actions, stack=4, discount=0.99, gae_lambda=0.95, batch_size=64,
                  playing_steps=2048, epochs=10, clip_eps=0.2, beta_entropy=0.01, lr=2.5e-4,
-                 reward_clip=(-1.0, 1.0), adam=(0.9, 0.99, 1e-4), ragged=False):
+                 reward_clip=(-1.0, 1.0), adam=(0.9, 0.99, 1e-4), ragged=False, continuous=False,
+                 action_low=-1.0, action_high=1.0):
+        # continuous: BoxActionSpace — the head outputs [policy_mean, policy_std] (ppo_head.py:118-144), AdditiveNoise
+        # samples np.random.normal(mean, std) in TRAIN (exploration_policies/additive_noise.py:99-106) and the action
+        # is clipped to the space; the old policy of train_network is (mean, std) of the frozen copy
+        self.continuous = continuous
+        self.low, self.high = action_low, action_high
         self.ragged = ragged
         self.episodes = []                                     # (env, first index, end index) in completion order
         self.ep_start = [0] * env.n_env
@@ -235,7 +241,7 @@ class ClippedPPOAgentOracle:
         if self.net is None:
             arrays, A, lr, adam, clip_eps, beta = self._net_args
             self.net = ClippedPPOOracle(arrays, obs_shape, A, lr=lr, beta1=adam[0], beta2=adam[1],
-                                        eps=adam[2], clip_eps=clip_eps, beta_entropy=beta)
+                                        eps=adam[2], clip_eps=clip_eps, beta_entropy=beta, continuous=self.continuous)
 
     def reset(self, frame_hw=None):
         first = self.env.reset()
@@ -252,8 +258,14 @@ class ClippedPPOAgentOracle:
         from . import filters as Fl
         from .explore import categorical_choice
         states = np.stack(self.cur)
-        probs = self.net.policy_probs(states)
-        actions = [categorical_choice(probs[e], np.random.random_sample()) for e in range(self.n_env)]
+        if self.continuous:
+            mean, std = self.net.policy_mean_std(states)
+            probs = (mean, std)
+            actions = [np.clip(np.random.normal(mean[e].astype(np.float64), std[e].astype(np.float64)),
+                               self.low, self.high).astype(F32) for e in range(self.n_env)]
+        else:
+            probs = self.net.policy_probs(states)
+            actions = [categorical_choice(probs[e], np.random.random_sample()) for e in range(self.n_env)]
         nxt, rst, rew, done = self.env.step()
         for e in range(self.n_env):
             r = float(rew[e])
@@ -291,7 +303,7 @@ class ClippedPPOAgentOracle:
         actions = np.array([t[1] for t in data])
         rewards = np.array([t[2] for t in data], dtype=np.float64)
         dones = np.array([t[3] for t in data])
-        frozen = self.net.clone_policy()                                       # networks['main'].sync()
+        frozen = self.net.clone_policy_continuous() if self.continuous else self.net.clone_policy()   # networks['main'].sync()
         values = np.concatenate([self.net.values(states[i:i + self.B]) for i in range(0, len(data), self.B)])
         adv, vt, _ = R.fill_advantages(rewards, values, dones, self.discount, self.lam)
         self.dbg = dict(values=values, adv=adv, vt=vt, rewards=rewards, dones=dones, actions=actions)
@@ -306,7 +318,8 @@ class ClippedPPOAgentOracle:
             ep = []
             for i in range(-(-n // self.B)):
                 idx = order[i * self.B:(i + 1) * self.B]
-                old = self.net.policy_probs(states[idx], frozen)
+                old = self.net.policy_mean_std(states[idx], frozen) if self.continuous else \
+                    self.net.policy_probs(states[idx], frozen)
                 r = self.net.train_minibatch(states[idx], actions[idx], adv[idx].astype(F32),
                                              vt[idx].astype(F32), old)
                 ep.append([r["surrogate"], r["entropy"], r["kl"], r["total"], r["value_loss"]])

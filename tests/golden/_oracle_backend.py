@@ -243,3 +243,51 @@ class PPOWrapper(_Wrapper):
         table = {"kl": r["kl"], "entropy": r["entropy"], "ratio": r["ratio"], "clipped": r["clipped"]}
         return (float(r["value_loss"]) + float(r["total"]), [float(r["value_loss"]), float(r["total"])], r["norm"],
                 [table[f] for f in additional_fetches])
+
+
+class PPOContinuousWrapper(PPOWrapper):
+    """networks['main'] of ClippedPPOAgent with a BoxActionSpace: the head's outputs are [policy_mean, policy_std], so
+    the old policy travels as TWO inputs (output_1_1, output_1_2) and the clip rescaler moves to output_1_3
+    (clipped_ppo_agent.py:258-268)."""
+
+    def __init__(self, net):
+        PPOWrapper.__init__(self, net)
+        w = self
+
+        class Head(object):
+            kl_divergence, entropy = "kl", "entropy"
+            likelihood_ratio, clipped_likelihood_ratio = "ratio", "clipped"
+
+        class Online(object):
+            output_heads = [object(), Head()]
+
+            def predict(self, inputs, outputs=None):
+                s = _obs(inputs)
+                mean, std = w.o.policy_mean_std(s)
+                return [w.o.values(s)[:, None], mean, std]
+
+            def reset_internal_memory(self):
+                pass
+
+        class Target(object):
+            def predict(self, inputs):
+                s = _obs(inputs)
+                mean, std = w.o.policy_mean_std(s, w.frozen)
+                return [np.zeros((s.shape[0], 1), dtype=F32), mean, std]
+
+        self.online_network, self.target_network = Online(), Target()
+
+    def sync(self):
+        self.frozen = self.o.clone_policy_continuous()
+
+    def train_and_sync_networks(self, inputs, targets, additional_fetches=[]):
+        s = _obs(inputs)
+        value_targets, advantages = targets
+        rescaler = float(inputs['output_1_3'])
+        r = self.o.train_minibatch(s, np.asarray(inputs['output_1_0'], dtype=F32), np.asarray(advantages, dtype=F32),
+                                   np.asarray(value_targets, dtype=F32)[:, 0],
+                                   (np.asarray(inputs['output_1_1'], dtype=F32), np.asarray(inputs['output_1_2'], dtype=F32)),
+                                   rescaler)
+        table = {"kl": r["kl"], "entropy": r["entropy"], "ratio": r["ratio"], "clipped": r["clipped"]}
+        return (float(r["value_loss"]) + float(r["total"]), [float(r["value_loss"]), float(r["total"])], r["norm"],
+                [table[f] for f in additional_fetches])

@@ -664,7 +664,8 @@ def gen_ppo_update():
     """The REFERENCE's ClippedPPOAgent.train (agents/clipped_ppo_agent.py:314-344: sync, fill_advantages,
     dataset shuffle, train_network with per-epoch Batch.shuffle) executed here on an oracle-backed
     network stand-in; tests/test_update_pins.py re-runs oracle.agents.ClippedPPOAgentOracle.train from
-    the same transitions, weights and `random` seed."""
+    the same transitions, weights and `random` seed.  Two cases: "ppo" = DiscreteActionSpace (PPOHead softmax),
+    "ppoc" = BoxActionSpace (PPOHead mean / std: the old policy travels as two inputs, the actions are vectors)."""
     import copy
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     import _oracle_backend as OB
@@ -672,61 +673,68 @@ def gen_ppo_update():
     from rl_coach.agents.clipped_ppo_agent import ClippedPPOAgent
     from rl_coach.agents.policy_optimization_agent import PolicyGradientRescaler
     from rl_coach.core_types import EnvironmentSteps
-    from rl_coach.spaces import DiscreteActionSpace
-    D, A, B, n_env, L, epochs = 9, 4, 16, 6, 8, 3
-    rng = np.random.RandomState(61)
-    arrays = _rand_arrays(rng, {"main/embedder/dense0": (D, 24, 2), "main/middleware/dense0": (24, 16, 2),
-                                "main/v_head/dense": (16, 1, 1), "main/ppo_head/policy_fc": (16, A, 1)})
-    net = ClippedPPOOracle(copy.deepcopy(arrays), (D,), A, lr=1e-3, clip_eps=0.2, beta_entropy=0.01)
+    from rl_coach.spaces import BoxActionSpace, DiscreteActionSpace
     out = {}
-    for k, v in arrays.items():
-        for t, arr in enumerate(v):
-            out["ppo|init|%s|%d" % (k, t)] = arr
-    T = n_env * L
-    states = rng.randn(T, D).astype(np.float32)
-    actions = rng.randint(0, A, size=T)
-    rewards = rng.choice([-1.0, 0.0, 1.0], size=T).astype(np.float32)
-    go = np.zeros(T, dtype=bool)
-    go[np.arange(n_env) * L + L - 1] = True                      # episode-major, one episode per env
-    trans = [Transition(state={'observation': states[i]}, action=int(actions[i]), reward=float(rewards[i]),
-                        next_state={'observation': states[min(i + 1, T - 1)]}, game_over=bool(go[i]))
-             for i in range(T)]
-    for t in trans:
-        t.n_step_discounted_rewards = 0.0
+    for prefix, continuous, seed0 in (("ppo", False, 61), ("ppoc", True, 62)):
+        D, A, B, n_env, L, epochs = (9, 4, 16, 6, 8, 3) if not continuous else (7, 3, 8, 4, 6, 2)
+        rng = np.random.RandomState(seed0)
+        head = "main/ppo_head/policy_mean" if continuous else "main/ppo_head/policy_fc"
+        arrays = _rand_arrays(rng, {"main/embedder/dense0": (D, 24, 2), "main/middleware/dense0": (24, 16, 2),
+                                    "main/v_head/dense": (16, 1, 1), head: (16, A, 1)})
+        if continuous:
+            arrays["main/ppo_head/policy_log_std"] = [rng.uniform(-0.5, 0.1, (A,)).astype(np.float32)]
+        net = ClippedPPOOracle(copy.deepcopy(arrays), (D,), A, lr=1e-3, clip_eps=0.2, beta_entropy=0.01,
+                               continuous=continuous)
+        for k, v in arrays.items():
+            for t, arr in enumerate(v):
+                out["%s|init|%s|%d" % (prefix, k, t)] = arr
+        T = n_env * L
+        states = rng.randn(T, D).astype(np.float32)
+        actions = rng.uniform(-1, 1, (T, A)).astype(np.float32) if continuous else rng.randint(0, A, size=T)
+        rewards = rng.choice([-1.0, 0.0, 1.0], size=T).astype(np.float32)
+        go = np.zeros(T, dtype=bool)
+        go[np.arange(n_env) * L + L - 1] = True                      # episode-major, one episode per env
+        trans = [Transition(state={'observation': states[i]}, action=actions[i] if continuous else int(actions[i]),
+                            reward=float(rewards[i]), next_state={'observation': states[min(i + 1, T - 1)]},
+                            game_over=bool(go[i]))
+                 for i in range(T)]
+        for t in trans:
+            t.n_step_discounted_rewards = 0.0
 
-    class Fake(ClippedPPOAgent):
-        def __init__(self):
-            pass
-    f = Fake()
-    sink = _Obj(add_sample=lambda v: None)
-    wrapper = _Obj(input_embedders_parameters={'observation': None}, batch_size=B, learning_rate_decay_rate=0,
-                   learning_rate=1e-3)
-    f.ap = _Obj(network_wrappers={'main': wrapper},
-                algorithm=_Obj(discount=0.99, gae_lambda=0.95, estimate_state_value_using_gae=True,
-                               update_pre_network_filters_state_on_train=False,
-                               num_consecutive_training_steps=1,
-                               num_consecutive_playing_steps=EnvironmentSteps(T), optimization_epochs=epochs,
-                               clipping_decay_schedule=ConstantSchedule(1)))
-    f.policy_gradient_rescaler = PolicyGradientRescaler.GAE
-    f.spaces = _Obj(action=DiscreteActionSpace(A))
-    for sig in ("state_values", "action_advantages", "unclipped_grads", "value_targets", "likelihood_ratio",
-                "clipped_likelihood_ratio", "value_loss", "policy_loss", "loss", "curr_learning_rate", "entropy",
-                "kl_divergence"):
-        setattr(f, sig, sink)
-    f.memory = _Obj(transitions=trans)
-    f.pre_network_filter = _Obj(filter=lambda dataset, deep_copy=False, update_internal_state=False: dataset)
-    f._should_train = lambda: True
-    f.post_training_commands = lambda: None
-    f.update_log = lambda: None
-    f.training_iteration = 0
-    f.networks = {'main': OB.PPOWrapper(net)}
-    random.seed(71)
-    f.train()
-    out["ppo|states"], out["ppo|actions"], out["ppo|rewards"], out["ppo|go"] = states, actions, rewards, go
-    out["ppo|hp"] = np.array([D, A, B, n_env, L, epochs, 71])
-    out["ppo|adv"] = np.array([t.info['advantage'] for t in trans])       # (dataset was shuffled in place:
-    out["ppo|adv_state0"] = np.array([t.state['observation'][0] for t in trans])   # keyed by state[0])
-    _flat("ppo|final", net.weights(), out)
+        class Fake(ClippedPPOAgent):
+            def __init__(self):
+                pass
+        f = Fake()
+        sink = _Obj(add_sample=lambda v: None)
+        wrapper = _Obj(input_embedders_parameters={'observation': None}, batch_size=B, learning_rate_decay_rate=0,
+                       learning_rate=1e-3)
+        f.ap = _Obj(network_wrappers={'main': wrapper},
+                    algorithm=_Obj(discount=0.99, gae_lambda=0.95, estimate_state_value_using_gae=True,
+                                   update_pre_network_filters_state_on_train=False,
+                                   num_consecutive_training_steps=1,
+                                   num_consecutive_playing_steps=EnvironmentSteps(T), optimization_epochs=epochs,
+                                   clipping_decay_schedule=ConstantSchedule(1)))
+        f.policy_gradient_rescaler = PolicyGradientRescaler.GAE
+        f.spaces = _Obj(action=BoxActionSpace(A, -1.0, 1.0) if continuous else DiscreteActionSpace(A))
+        for sig in ("state_values", "action_advantages", "unclipped_grads", "value_targets", "likelihood_ratio",
+                    "clipped_likelihood_ratio", "value_loss", "policy_loss", "loss", "curr_learning_rate", "entropy",
+                    "kl_divergence"):
+            setattr(f, sig, sink)
+        f.memory = _Obj(transitions=trans)
+        f.pre_network_filter = _Obj(filter=lambda dataset, deep_copy=False, update_internal_state=False: dataset)
+        f._should_train = lambda: True
+        f.post_training_commands = lambda: None
+        f.update_log = lambda: None
+        f.training_iteration = 0
+        f.networks = {'main': (OB.PPOContinuousWrapper if continuous else OB.PPOWrapper)(net)}
+        random.seed(71)
+        f.train()
+        out[prefix + "|states"], out[prefix + "|actions"], out[prefix + "|rewards"], out[prefix + "|go"] = \
+            states, actions, rewards, go
+        out[prefix + "|hp"] = np.array([D, A, B, n_env, L, epochs, 71])
+        out[prefix + "|adv"] = np.array([t.info['advantage'] for t in trans])       # (dataset was shuffled in place:
+        out[prefix + "|adv_state0"] = np.array([t.state['observation'][0] for t in trans])   # keyed by state[0])
+        _flat(prefix + "|final", net.weights(), out)
     _save("ppo_update", **out)
 
 

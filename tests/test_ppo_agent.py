@@ -208,3 +208,58 @@ def test_decaying_clip_schedule_reuses_the_captured_graphs(rlx, dev):
     assert runs[True][2][2] == runs[True][2][-1] > 0                  # no graphs added after the third phase
     np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=1e-6, atol=1e-7)
     assert torch.equal(runs[True][1], runs[False][1])
+
+
+@pytest.mark.gpu
+def test_continuous_ppo_iteration_matches_oracle(rlx, dev):
+    """Mujoco_ClippedPPO-style loop (BoxActionSpace, PPOHead mean / std, actions = clip(N(mean, std))) against the oracle
+    agent in continuous mode — whose train() is pinned to the REAL reference agent's train on a BoxActionSpace
+    (tests/test_update_pins.py, fixture ppoc).  Same host streams: the sampled actions, the per-epoch results and the
+    weights (policy_log_std included) after two iterations."""
+    from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
+    from coach_amd.core_types import EnvironmentSteps
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from oracle.agents import ClippedPPOAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    n_env, L, D, A, playing, batch, epochs = 4, 6, 7, 3, 24, 8, 2
+    ep = SyntheticVectorEnvironmentParameters("vector", n_env, (D,), None, action_dim=A, episode_length=L, seed=99)
+    env = SyntheticVectorEnvironment(ep, dev)
+    ap = ClippedPPOAgentParameters()
+    ap.seed = 0
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(playing)
+    ap.algorithm.optimization_epochs = epochs
+    ap.algorithm.reward_clipping = None
+    net = ap.network_wrappers["main"]
+    net.batch_size, net.embedder_scheme, net.middleware_scheme = batch, [32], [32]
+    agent = ClippedPPOAgent(ap, env, dev)
+    assert agent.continuous
+    arrays = agent.networks["main"].params.named_arrays()
+    o = ClippedPPOAgentOracle(arrays, SynthVecEnv(1, n_env, D, L, 99), A, batch_size=batch, playing_steps=playing,
+                              epochs=epochs, reward_clip=None, continuous=True)
+    o.reset()
+    state = (random.getstate(), np.random.get_state())
+    for it in range(2):
+        random.setstate(state[0]); np.random.set_state(state[1])
+        hip_actions = []
+        while True:
+            agent.act()
+            hip_actions.append(agent.actions.cpu().numpy().copy())
+            res = agent.train()
+            if res is not None:
+                break
+        hip_state = (random.getstate(), np.random.get_state())
+        random.setstate(state[0]); np.random.set_state(state[1])
+        for s_ in range(len(hip_actions)):
+            oa, _ = o.act()
+            np.testing.assert_allclose(hip_actions[s_], np.stack(oa), rtol=2e-5, atol=2e-6,
+                                       err_msg="sampled actions differ at step %d" % s_)
+        ores = o.train()
+        assert random.getstate() == hip_state[0]
+        state = hip_state
+        hres = np.array([r.cpu().numpy()[:5] for r in res], dtype=np.float64)
+        np.testing.assert_allclose(hres, np.array(ores), rtol=2e-3, atol=2e-5)
+        hw = agent.networks["main"].params.named_arrays()
+        for name, per_tower in o.net.weights().items():
+            for t, ref in per_tower.items():
+                np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)

@@ -96,36 +96,40 @@ def test_dqn_update_equals_reference_learn_from_batch(fx):
     _check_final(fx, "dqn|final|main", o)
 
 
-def test_clipped_ppo_train_equals_reference_train():
+@pytest.mark.parametrize("prefix", ["ppo", "ppoc"])
+def test_clipped_ppo_train_equals_reference_train(prefix):
     """ClippedPPOAgentOracle.train vs the reference's ClippedPPOAgent.train (clipped_ppo_agent.py:314-344)
     run on the oracle-backed stand-in: same transitions, weights and `random` seed -> same dataset
     shuffle, same per-epoch Batch.shuffle, same standardised advantages, same weights after
-    epochs x minibatches updates."""
+    epochs x minibatches updates.  "ppo": DiscreteActionSpace; "ppoc": BoxActionSpace (old policy = mean and std of
+    the frozen copy, vector actions, the clip rescaler on input output_1_3)."""
     import random
     from oracle.agents import ClippedPPOAgentOracle
     fx = np.load(os.path.join(HERE, "golden", "ppo_update.npz"))
-    D, A, B, n_env, L, epochs, seed = (int(x) for x in fx["ppo|hp"])
-    arrays = _arrays(fx, "ppo")
+    D, A, B, n_env, L, epochs, seed = (int(x) for x in fx[prefix + "|hp"])
+    arrays = _arrays(fx, prefix)
+    continuous = prefix == "ppoc"
 
     class Env(object):
         kind, n_env = 1, 0
     Env.n_env = n_env
     o = ClippedPPOAgentOracle(arrays, Env(), A, discount=0.99, gae_lambda=0.95, batch_size=B,
                               playing_steps=n_env * L, epochs=epochs, clip_eps=0.2, beta_entropy=0.01, lr=1e-3,
-                              reward_clip=None)
+                              reward_clip=None, continuous=continuous)
     o._ensure_net((D,))
-    s, a, r, go = fx["ppo|states"], fx["ppo|actions"], fx["ppo|rewards"], fx["ppo|go"]
+    s, a, r, go = fx[prefix + "|states"], fx[prefix + "|actions"], fx[prefix + "|rewards"], fx[prefix + "|go"]
     for e in range(n_env):
-        o.transitions[e] = [(s[i], int(a[i]), float(r[i]), bool(go[i])) for i in range(e * L, (e + 1) * L)]
+        o.transitions[e] = [(s[i], a[i] if continuous else int(a[i]), float(r[i]), bool(go[i]))
+                            for i in range(e * L, (e + 1) * L)]
     random.seed(seed)
     res = o.train()
     assert len(res) == epochs
     # standardised advantages, matched through the first state component (the reference shuffled its
     # dataset in place)
-    by_key = {float(k): v for k, v in zip(fx["ppo|adv_state0"], fx["ppo|adv"])}
+    by_key = {float(k): v for k, v in zip(fx[prefix + "|adv_state0"], fx[prefix + "|adv"])}
     ref_adv = np.array([by_key[float(x)] for x in s[:, 0]])
     np.testing.assert_allclose(o.dbg["adv"], ref_adv, rtol=1e-6, atol=1e-7)
-    _check_final(fx, "ppo|final", o.net, atol=2e-6)
+    _check_final(fx, prefix + "|final", o.net, atol=2e-6)
 
 
 def _cadence_cases():
