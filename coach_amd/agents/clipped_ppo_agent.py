@@ -258,7 +258,9 @@ class ClippedPPOAgent(object):
         if self.continuous:
             mean, std = self.networks["main"].policy_mean_std(states, self.n_env)
             if self.phase == RunPhase.TRAIN:                                # additive_noise.py:99-106
-                self.lib.gaussian_action(mean, None, std, self.uniforms_all[0 if self.ragged else step], self.d_low, self.d_high,
+                # (not clipped: the transition keeps the sampled action, agent.py:935 — the likelihood ratio is taken at it —
+                # and the environment clips what it executes, environments/environment.py:283)
+                self.lib.gaussian_action(mean, None, std, self.uniforms_all[0 if self.ragged else step], None, None,
                                          self.n_env, self.A, self.actions, s)
             else:
                 self.actions.copy_(mean)

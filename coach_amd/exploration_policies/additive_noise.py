@@ -3,7 +3,9 @@ rl_coach/exploration_policies/additive_noise.py (AdditiveNoiseParameters :28-38,
 
 ``np.random.normal(mean, std)`` of the legacy generator is mean + std * z with z the next values of
 its standard-normal stream, so the host draws z [n_env, A] in env order (identical to n_env
-sequential get_action calls) and the device forms and clips the actions (rlx_gaussian_action).
+sequential get_action calls) and the device forms the actions (rlx_gaussian_action).  They are NOT clipped here: the
+reference's transition records the noisy action as the policy returned it (agent.py:854,935) and it is the
+ENVIRONMENT that clips what it executes (environments/environment.py:283, gym_environment.py:434).
 """
 import numpy as np
 import torch
@@ -58,6 +60,6 @@ class AdditiveNoise(object):
             z = np.zeros((self.n_env, self.A))
         self._z.push(z)
         self.d_std.copy_(torch.from_numpy(std), non_blocking=True)
-        self.lib.gaussian_action(action_means, self.d_std, None, self.d_z, self.d_low, self.d_high,
+        self.lib.gaussian_action(action_means, self.d_std, None, self.d_z, None, None,
                                  self.n_env, self.A, out_actions, _rlx.current_stream())
         return out_actions

@@ -2,7 +2,8 @@
 rl_coach/exploration_policies/ou_process.py (OUProcessParameters :28-38, noise :61-65,
 get_action :67-73): dx = theta (mu - x) dt + sigma sqrt(dt) N(0,1); action = mean + x.
 The O(n_env * A) state update stays on the host (fp64, the reference's arithmetic and RNG stream);
-the device adds it to the policy output and clips (rlx_gaussian_action with std = 1, z = noise)."""
+the device adds it to the policy output (rlx_gaussian_action with std = 1, z = noise; no clipping: the environment
+clips what it executes, environments/environment.py:283, the transition keeps the noisy action, agent.py:935)."""
 import numpy as np
 import torch
 
@@ -58,6 +59,6 @@ class OUProcess(object):
     def get_action(self, action_means, out_actions):
         noise = self.noise() if self.phase == RunPhase.TRAIN else np.zeros((self.n_env, self.A))
         self._z.push(noise)
-        self.lib.gaussian_action(action_means, self.d_one, None, self.d_z, self.d_low, self.d_high,
+        self.lib.gaussian_action(action_means, self.d_one, None, self.d_z, None, None,
                                  self.n_env, self.A, out_actions, _rlx.current_stream())
         return out_actions

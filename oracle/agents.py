@@ -213,8 +213,8 @@ class ClippedPPOAgentOracle:
                  reward_clip=(-1.0, 1.0), adam=(0.9, 0.99, 1e-4), ragged=False, continuous=False,
                  action_low=-1.0, action_high=1.0):
         # continuous: BoxActionSpace — the head outputs [policy_mean, policy_std] (ppo_head.py:118-144), AdditiveNoise
-        # samples np.random.normal(mean, std) in TRAIN (exploration_policies/additive_noise.py:99-106) and the action
-        # is clipped to the space; the old policy of train_network is (mean, std) of the frozen copy
+        # samples np.random.normal(mean, std) in TRAIN (exploration_policies/additive_noise.py:99-106); the old policy of
+        # train_network is (mean, std) of the frozen copy
         self.continuous = continuous
         self.low, self.high = action_low, action_high
         self.ragged = ragged
@@ -261,8 +261,10 @@ class ClippedPPOAgentOracle:
         if self.continuous:
             mean, std = self.net.policy_mean_std(states)
             probs = (mean, std)
-            actions = [np.clip(np.random.normal(mean[e].astype(np.float64), std[e].astype(np.float64)),
-                               self.low, self.high).astype(F32) for e in range(self.n_env)]
+            # the recorded action is the sample itself (agent.py:854,935); the ENVIRONMENT clips what it executes
+            # (environments/environment.py:283)
+            actions = [np.random.normal(mean[e].astype(np.float64), std[e].astype(np.float64)).astype(F32)
+                       for e in range(self.n_env)]
         else:
             probs = self.net.policy_probs(states)
             actions = [categorical_choice(probs[e], np.random.random_sample()) for e in range(self.n_env)]

@@ -177,7 +177,7 @@ def test_continuous_ppo_with_observation_normalization(dev):
     assert abs(float(a.norm.count.item()) - (3 * 64 + 1e-2)) < 1e-9
     ls = a.networks["main"].params.w("main/ppo_head/policy_log_std").cpu().numpy()
     assert np.abs(ls).max() > 0 and np.isfinite(ls).all()           # the log-std variable is being trained
-    assert a.actions.dtype == torch.float32 and float(a.actions.abs().max()) <= 1.0
+    assert a.actions.dtype == torch.float32 and bool(torch.isfinite(a.actions).all())
 
 
 @pytest.mark.gpu
