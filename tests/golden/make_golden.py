@@ -500,6 +500,19 @@ def gen_explore():
     out["an_mean"], out["an_z"] = mean, z
     out["an_std"] = 0.1 * (space.high - space.low)
     out["an_actions"] = np.array([pol.get_action(m) for m in mean])
+    # ---- OUProcess (ou_process.py:41-77, DDPG's default exploration): correlated noise, restart at reset()
+    from rl_coach.exploration_policies.ou_process import OUProcess
+    space = BoxActionSpace(3, -1.0, 1.0)
+    pol = OUProcess(space, mu=0, theta=0.15, sigma=0.2, dt=0.01)
+    pol.change_phase(RunPhase.TRAIN)
+    ou_mean = np.tanh(rng.randn(40, 3)).astype(np.float32)
+    np.random.seed(8)
+    acts = []
+    for i, m in enumerate(ou_mean):
+        if i == 25:
+            pol.reset()                                   # an episode ended: Agent.reset_internal_state
+        acts.append(pol.get_action(m).copy())
+    out["ou_mean"], out["ou_actions"], out["ou_reset_at"] = ou_mean, np.array(acts), np.array(25)
     _save("explore", **out)
 
 

@@ -50,6 +50,26 @@ def test_product_egreedy_host_draws_match_reference(golden):
     assert acts == g["eg_actions"].tolist()
 
 
+def test_product_ou_process_host_noise_matches_reference(golden):
+    """coach_amd OUProcess — the HOST half (the correlated noise state, np.random.randn consumption, restart at an
+    episode end) — against the reference's OUProcess.get_action under the same seed (fixture `explore`): action =
+    policy mean + noise, bit for bit in fp64 (the device half is rlx_gaussian_action with std 1, checked below)."""
+    from coach_amd.core_types import RunPhase
+    from coach_amd.exploration_policies.ou_process import OUProcess
+    g = golden("explore")
+    A = g["ou_mean"].shape[1]
+    pol = OUProcess.__new__(OUProcess)                  # no device members: noise() is host-only
+    pol.A, pol.n_env, pol.phase = A, 1, RunPhase.TRAIN
+    pol.mu, pol.theta, pol.sigma, pol.dt = 0.0 * np.ones(A), 0.15, 0.2 * np.ones(A), 0.01
+    pol.state = np.zeros((1, A))
+    np.random.seed(8)
+    for i, m in enumerate(g["ou_mean"]):
+        if i == int(g["ou_reset_at"]):
+            pol.reset([0])
+        noise = pol.noise()[0]
+        assert np.array_equal(m + noise, g["ou_actions"][i]), i
+
+
 def test_product_egreedy_draws_for_several_envs_are_sequential_calls():
     """n_env envs = n_env sequential get_action calls of the reference policy object: every call sees the epsilon the
     previous call's step_epsilon left behind, and consumes the shared np.random stream in call order."""
