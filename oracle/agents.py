@@ -507,14 +507,14 @@ class TD3AgentOracle:
 
     def __init__(self, actor_arrays, critic_arrays, env, action_dim, batch_size=100, low=-1.0, high=1.0,
                  exploration_std=0.1, policy_noise=0.2, noise_clipping=0.5, policy_every=2, tau=0.005, discount=0.99,
-                 max_size=1000000, lr_actor=1e-3, lr_critic=1e-3, max_episode_steps=None):
+                 max_size=1000000, lr_actor=1e-3, lr_critic=1e-3, max_episode_steps=None, streams=2):
         from . import ac_nets as O
         from .replay import EpisodicReplayOracle
         self.env, self.n_env, self.A, self.B = env, env.n_env, action_dim, batch_size
         self.low = np.broadcast_to(np.asarray(low, dtype=F32), (action_dim,)).copy()
         self.high = np.broadcast_to(np.asarray(high, dtype=F32), (action_dim,)).copy()
         self.actor = O.ActorOracle(actor_arrays, 1.0, lr=lr_actor)
-        self.critic = O.CriticOracle(critic_arrays, streams=2, lr=lr_critic)
+        self.critic = O.CriticOracle(critic_arrays, streams=streams, lr=lr_critic)
         self.memory = EpisodicReplayOracle(max_size, n_step=-1, discount=discount)
         self.std, self.policy_noise, self.noise_clipping = exploration_std, policy_noise, noise_clipping
         self.policy_every, self.tau, self.discount = policy_every, tau, discount
@@ -550,6 +550,7 @@ class TD3AgentOracle:
         if train:
             for T_ in lengths:                                                # one phase per finished episode
                 self._train_phase(T_)
+        return ended
 
     def heatup_step(self):
         """BoxActionSpace.sample (spaces.py:151-162) per env; no training."""
@@ -583,3 +584,58 @@ class TD3AgentOracle:
                 self.last_target_update = self.training_iteration
                 self.actor.mix_target(self.tau)
                 self.critic.mix_target(self.tau)
+
+
+class DDPGAgentOracle(TD3AgentOracle):
+    """Whole DDPG loop (agents/ddpg_agent.py): like TD3AgentOracle with
+      * OUProcess exploration (exploration_policies/ou_process.py:41-77), one correlated-noise state per env, restarted
+        when the env's episode ends (Agent.reset_internal_state -> exploration_policy.reset(), agent.py:603-624);
+      * the stored game_over as the environment gave it (only TD3 clears time-limit ends);
+      * ONE update per env-step as soon as the episodic memory holds a complete episode (num_consecutive_playing_steps
+        = EnvironmentSteps(1), agent.py:662-699), single-stream critic with an observation embedder (ddpg_update);
+      * both target networks mixed after EVERY update (num_steps_between_copying_online_weights_to_target =
+        EnvironmentSteps(1), rate 0.001).
+    Pinned for one env to the REAL reference DDPGAgent's loop (tests/golden/ddpg_loop.npz)."""
+
+    def __init__(self, actor_arrays, critic_arrays, env, action_dim, batch_size=64, low=-1.0, high=1.0, theta=0.15,
+                 sigma=0.2, dt=0.01, mu=0.0, tau=0.001, discount=0.99, max_size=1000000, lr_actor=1e-4, lr_critic=1e-3):
+        from . import ac_nets as O
+        TD3AgentOracle.__init__(self, actor_arrays, critic_arrays, env, action_dim, batch_size, low, high, tau=tau,
+                                discount=discount, max_size=max_size, lr_actor=lr_actor, lr_critic=lr_critic, streams=1)
+        self.theta, self.sigma, self.dt, self.mu = theta, sigma * np.ones(action_dim), dt, mu * np.ones(action_dim)
+        self.ou = np.zeros((self.n_env, action_dim))
+
+    def _limit(self, e):
+        return -1                                            # game_over is stored as given
+
+    def act(self):
+        mean = self.actor.forward(np.stack(self.cur).astype(F32))
+        acts = []
+        for e in range(self.n_env):                          # OUProcess.noise + get_action (:61-77), env by env
+            x = self.ou[e]
+            dx = self.theta * (self.mu - x) * self.dt + self.sigma * np.random.randn(self.A) * np.sqrt(self.dt)
+            self.ou[e] = x + dx
+            acts.append(mean[e] + self.ou[e])
+        self.recorded_actions.append(np.array(acts))
+        for e in self._step_envs(acts, False):               # the finished envs' processes restart
+            self.ou[e] = 0.0
+        # one training step per vector step once a complete episode is stored (n_env playing steps, one update each)
+        if self.memory.num_transitions() > 0:
+            for _ in range(self.n_env):
+                self._train_phase(1)
+        return acts
+
+    def _train_phase(self, steps):
+        from . import ac_nets as O
+        draws = [self.memory.sample_indices(self.B) for _ in range(steps)]
+        for idx in draws:
+            self.training_iteration += 1
+            rows = [self.memory.rows[i] for i in idx]
+            self.sampled.append(np.asarray(idx))
+            batch = (np.stack([r[0] for r in rows]).astype(F32), np.stack([r[1] for r in rows]).astype(F32),
+                     np.array([r[2] for r in rows], dtype=F32), np.array([r[3] for r in rows]),
+                     np.stack([r[4] for r in rows]).astype(F32))
+            r = O.ddpg_update(self.actor, self.critic, batch, self.discount)
+            self.losses.append(r["loss"])
+            self.actor.mix_target(self.tau)
+            self.critic.mix_target(self.tau)

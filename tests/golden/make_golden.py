@@ -1139,6 +1139,97 @@ def gen_td3_loop():
     _save("td3_loop", **out)
 
 
+def gen_ddpg_loop():
+    """The REAL reference `DDPGAgent(DDPGAgentParameters())` (own __init__: EpisodicExperienceReplay, OUProcess
+    exploration restarted at every episode start, one update per env-step once a complete episode is stored, target
+    networks mixed after every update) with oracle-backed actor / critic stand-ins, stepped like gen_td3_loop.
+    tests/test_update_pins.py replays oracle.agents.DDPGAgentOracle under the same seeds."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle import ac_nets as O
+    from oracle.synth_env import SynthVecEnv
+    from rl_coach.agents.ddpg_agent import DDPGAgent, DDPGAgentParameters
+    from rl_coach.base_parameters import TaskParameters
+    from rl_coach.core_types import EnvResponse, RunPhase
+    from rl_coach.filters.filter import NoInputFilter, NoOutputFilter
+    from rl_coach.spaces import BoxActionSpace, RewardSpace, SpacesDefinition, StateSpace, VectorObservationSpace
+    D, A, L, B, HEATUP, TRAIN, SEED = 5, 2, 6, 8, 9, 27, 17
+    out = {"hp": np.array([D, A, L, B, HEATUP, TRAIN, SEED])}
+    rng = np.random.RandomState(4)
+    a_arrays = _rand_arrays(rng, {"actor/embedder/dense0": (D, 20, 1), "actor/middleware/dense0": (20, 12, 1),
+                                  "actor/ddpg_actor_head/fc_mean": (12, A, 1)})
+    c_arrays = _rand_arrays(rng, {"critic/embedder/dense0": (D, 18, 1), "critic/middleware/dense0": (18 + A, 12, 1),
+                                  "critic/v_head/output": (12, 1, 1)})
+    for k, v in list(a_arrays.items()) + list(c_arrays.items()):
+        for t, arr in enumerate(v):
+            out["init|%s|%d" % (k, t)] = arr
+    ap = DDPGAgentParameters()
+    ap.task_parameters = TaskParameters()
+    ap.name = "agent"
+    ap.visualization.dump_csv = False
+    ap.is_a_highest_level_agent = False
+    ap.input_filter, ap.output_filter, ap.pre_network_filter = NoInputFilter(), NoOutputFilter(), NoInputFilter()
+    for n in ap.network_wrappers.values():
+        n.batch_size = B
+    holder = {}
+
+    class Agent(DDPGAgent):
+        def create_networks(self):
+            actor = O.ActorOracle(copy.deepcopy(a_arrays), 1.0, lr=1e-4)
+            critic = O.CriticOracle(copy.deepcopy(c_arrays), streams=1, lr=1e-3)
+            holder["actor"], holder["critic"] = actor, critic
+            wa, wc = OB.ActorWrapper(actor), OB.CriticWrapper(critic, A)
+            for w, net in ((wa, actor), (wc, critic)):
+                w.has_target = True
+                w.set_is_training = lambda s: None
+                w.update_target_network = (lambda rate=1.0, net=net: net.mix_target(rate))
+                for nn in (w.online_network, w.target_network):
+                    nn.reset_internal_memory = lambda: None
+            return {'actor': wa, 'critic': wc}
+    agent = Agent(ap)
+    agent.set_environment_parameters(SpacesDefinition(
+        state=StateSpace({'observation': VectorObservationSpace(D)}), goal=None,
+        action=BoxActionSpace(A, -1.0, 1.0), reward=RewardSpace(1)))
+    env = SynthVecEnv(1, 1, D, L, 56)
+    random.seed(SEED)
+    np.random.seed(SEED)
+    actions, iters, keys = [], [], []
+    sample = agent.memory.sample
+
+    def logged_sample(size):
+        b = sample(size)
+        keys.append([float(t.state['observation'][0]) for t in b])
+        return b
+    agent.memory.sample = logged_sample
+    resp = EnvResponse(next_state={'observation': env.reset()[0].copy()}, reward=0, game_over=False)
+    agent.reset_internal_state()
+    reset_required, first = False, None
+    for step in range(HEATUP + TRAIN):
+        agent.phase = RunPhase.HEATUP if step < HEATUP else RunPhase.TRAIN
+        agent.exploration_policy.change_phase(agent.phase)
+        if reset_required:
+            agent.reset_internal_state()
+            resp = EnvResponse(next_state={'observation': first.copy()}, reward=0, game_over=False)
+            reset_required = False
+        agent.observe(resp)
+        actions.append(np.array(agent.act().action, dtype=np.float64))
+        nxt, rst, rew, done = env.step()
+        resp = EnvResponse(next_state={'observation': nxt[0].copy()}, reward=float(rew[0]), game_over=bool(done[0]))
+        if resp.game_over:
+            agent.observe(resp)
+            agent.handle_episode_ended()
+            reset_required, first = True, rst[0]
+        if step >= HEATUP:
+            agent.train()
+        iters.append(agent.training_iteration)
+    out["actions"], out["iters"] = np.array(actions), np.array(iters)
+    out["keys"] = np.array(keys)
+    _flat("final|actor", holder["actor"].weights(), out)
+    _flat("final|critic", holder["critic"].weights(), out)
+    _save("ddpg_loop", **out)
+
+
 def gen_ppo_loop():
     """The REAL reference `ClippedPPOAgent(ClippedPPOAgentParameters())` (own __init__: episodic memory,
     Categorical exploration, episode buffers, _should_train with act_for_full_episodes, train ->
@@ -1289,7 +1380,7 @@ def gen_csv_columns():
 
 
 GROUPS = {"csv_columns": gen_csv_columns, "per": gen_per, "er": gen_er, "episodic": gen_episodic, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -563,3 +563,36 @@ def test_oracle_td3_agent_loop_equals_real_reference_agent_loop():
     np.testing.assert_array_equal(keys, fx["keys"])
     _check_final(fx, "final|actor", o.actor, atol=2e-6)
     _check_final(fx, "final|critic", o.critic, atol=2e-6)
+
+
+def test_oracle_ddpg_agent_loop_equals_real_reference_agent_loop():
+    """oracle.agents.DDPGAgentOracle (n_env = 1) against the REAL reference DDPGAgent object (own __init__,
+    EpisodicExperienceReplay, OUProcess exploration restarted per episode, one update per env-step, targets mixed after
+    every update): recorded actions, training iterations, sampled transitions, final weights."""
+    import random
+    from oracle.agents import DDPGAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    fx = np.load(os.path.join(HERE, "golden", "ddpg_loop.npz"))
+    D, A, L, B, HEATUP, TRAIN, SEED = (int(x) for x in fx["hp"])
+    arrays = {}
+    for k in fx.files:
+        if k.startswith("init|"):
+            _, name, t = k.split("|")
+            arrays.setdefault(name, {})[int(t)] = fx[k]
+    arrays = {n: [tw[t] for t in sorted(tw)] for n, tw in arrays.items()}
+    a_arr = {k: v for k, v in arrays.items() if k.startswith("actor/")}
+    c_arr = {k: v for k, v in arrays.items() if k.startswith("critic/")}
+    random.seed(SEED)
+    np.random.seed(SEED)
+    o = DDPGAgentOracle(a_arr, c_arr, SynthVecEnv(1, 1, D, L, 56), A, batch_size=B)
+    o.reset()
+    iters = []
+    for step in range(HEATUP + TRAIN):
+        o.heatup_step() if step < HEATUP else o.act()
+        iters.append(o.training_iteration)
+    np.testing.assert_array_equal(np.array(o.recorded_actions)[:, 0], fx["actions"])
+    np.testing.assert_array_equal(iters, fx["iters"])
+    keys = np.array([[float(o.memory.rows[i][0][0]) for i in idx] for idx in o.sampled])
+    np.testing.assert_array_equal(keys, fx["keys"])
+    _check_final(fx, "final|actor", o.actor, atol=2e-6)
+    _check_final(fx, "final|critic", o.critic, atol=2e-6)
