@@ -371,7 +371,10 @@ class _VectorLoopOracle:
     # Transition and stored (agent.py:905-973) — at the START of the next step, after the train() call
     # of the current one; only a terminal response is observed immediately.  So when Agent.train samples
     # after step k, the transition of step k is not in the memory yet (unless it ended the episode).
-    # False (default) stores every transition at once, which is what the device agents do.
+    # True is what the device agents do (VectorOffPolicyAgent.act -> memory.commit_pending); False stores every
+    # transition at once (the simpler order some unit tests of the replay pieces use).  With more than one env (no
+    # reference counterpart) the n_env rows of a vector step become visible together, in env order: at once only
+    # when every env's episode ended on that step.
     reference_order = False
 
     def _store_row(self, row):
@@ -394,7 +397,7 @@ class _VectorLoopOracle:
                 ns = nxt[e].copy()
             if record:
                 row = (self.cur[e], actions[e], r, bool(done[e]), ns)
-                if self.reference_order and not done[e]:
+                if self.reference_order and not all(done):       # a vector step's rows become visible together
                     self._held.append(row)
                 else:
                     self._store_row(row)
@@ -489,6 +492,59 @@ class DQNAgentOracle(_VectorLoopOracle):
             if self.total_steps - self.last_target >= self.target_every:
                 self.last_target = self.total_steps
                 self.net.update_target(1.0)
+
+
+class SACAgentOracle(_VectorLoopOracle):
+    """Whole Soft Actor-Critic loop on the CPU (agents/soft_actor_critic_agent.py + agent.py scheduling) for N lockstep
+    envs: heat-up with BoxActionSpace.sample, then the squashed policy SAMPLE as the action (choose_action :296-322; the
+    graph's sampling op = one np.random.standard_normal draw per policy pass), non-episodic ExperienceReplay with
+    duplicates allowed (np.random.randint over the visible transitions), one update per env-step as soon as anything is
+    stored (num_consecutive_playing_steps = EnvironmentSteps(1)), three more noise draws inside learn_from_batch
+    (oracle.ac_nets.sac_update), V target mixed after EVERY update (EnvironmentSteps(1), rate 0.005).  Pinned for one
+    env, `reference_order = True`, to the REAL reference SoftActorCriticAgent's loop (tests/golden/sac_loop.npz)."""
+
+    def __init__(self, policy_arrays, q_arrays, v_arrays, env, action_dim, batch_size=256, low=-1.0, high=1.0,
+                 capacity=1000000, discount=0.99, tau=0.005, reward_rescale=1.0, lr=3e-4):
+        from . import ac_nets as O
+        self._init_loop(env, 1, capacity, reward_rescale=reward_rescale)
+        self.A, self.B, self.discount, self.tau = action_dim, batch_size, discount, tau
+        self.low = np.broadcast_to(np.asarray(low, dtype=F32), (action_dim,)).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=F32), (action_dim,)).copy()
+        self.policy = O.SACPolicyOracle(policy_arrays, lr=lr)
+        self.q = O.SACQOracle(q_arrays, lr=lr)
+        self.v = O.SACValueOracle(v_arrays, lr=lr)
+        self.losses, self.recorded_actions, self.visible, self.sampled_keys = [], [], [], []
+
+    def heatup_step(self):
+        acts = [np.random.uniform(self.low, self.high, self.A).astype(F32) for _ in range(self.n_env)]
+        self.recorded_actions.append(np.array(acts))
+        self._step_envs(acts)
+        return acts
+
+    def act(self):
+        z = np.random.standard_normal((self.n_env, self.A))
+        o = self.policy.forward(np.stack(self.cur).astype(F32), z)
+        acts = [o["actions"][e].astype(F32) for e in range(self.n_env)]
+        self.recorded_actions.append(np.array(acts))
+        self._step_envs(acts)
+        self.train()
+        return acts
+
+    def train(self):
+        from . import ac_nets as O
+        if self._num_transitions() <= 0:
+            return
+        for _ in range(self.n_env):                          # one phase (one update) per env-step played
+            d = self._draw(self.B)
+            self.visible.append(self._num_transitions())
+            (s, a, r, done, ns), _, _ = self._collate(d, self.B)
+            self.sampled_keys.append(np.asarray(s)[:, 0].astype(np.float64))
+            self.training_iteration += 1
+            normals = np.stack([np.random.standard_normal((self.B, self.A)) for _ in range(3)])
+            res = O.sac_update(self.policy, self.q, self.v, (s.astype(F32), np.asarray(a, dtype=F32), r, done,
+                                                             ns.astype(F32)), normals, self.discount)
+            self.losses.append(res["loss"])
+            self.v.mix_target(self.tau)
 
 
 class TD3AgentOracle:

@@ -95,15 +95,21 @@ class SACPolicyWrapper(_Wrapper):
         def grads():
             return [g for _, _, l in w.o.layers for g in (l.dW.copy(), l.db.copy())]
 
+        class Head(object):
+            policy_mean, actions = "mean", "actions"
+
         class Online(object):
             gradients_weights_ph = ["gw%d" % i for i in range(6)]
             weighted_gradients = ["wg%d" % i for i in range(6)]
+            output_heads = [Head()]
 
             def predict(self, inputs, outputs=None, initial_feed_dict=None):
                 s = _obs(inputs)
                 z = np.random.standard_normal((s.shape[0], w.A))       # the graph's sampling op
                 w.normals.append(z)
                 o = w.o.forward(s, z)
+                if outputs == ["mean", "actions"]:                     # choose_action (:312-313)
+                    return [o["mean"], o["actions"]]
                 if outputs is None:
                     return [o["mean"], o["log_std"], o["raw_actions"], o["actions"], o["logprob"],
                             o["logprob"].mean()]

@@ -1230,6 +1230,104 @@ def gen_ddpg_loop():
     _save("ddpg_loop", **out)
 
 
+def gen_sac_loop():
+    """The REAL reference `SoftActorCriticAgent(SoftActorCriticAgentParameters())` (own __init__: non-episodic
+    ExperienceReplay, heat-up with random actions, then the squashed policy SAMPLE as the action, one update per
+    env-step as soon as the memory holds a batch, V target mixed after every update) with oracle-backed policy / twin-Q
+    / V stand-ins, stepped like gen_td3_loop.  TF's sampling op is the stand-in's np.random.standard_normal draw (one
+    per sess.run of the policy graph: 1 at acting, 3 in learn_from_batch).  tests/test_update_pins.py replays
+    oracle.agents.SACAgentOracle under the same seeds."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle import ac_nets as O
+    from oracle.synth_env import SynthVecEnv
+    from rl_coach.agents.soft_actor_critic_agent import SoftActorCriticAgent, SoftActorCriticAgentParameters
+    from rl_coach.base_parameters import TaskParameters
+    from rl_coach.core_types import EnvResponse, RunPhase
+    from rl_coach.filters.filter import NoInputFilter, NoOutputFilter
+    from rl_coach.spaces import BoxActionSpace, RewardSpace, SpacesDefinition, StateSpace, VectorObservationSpace
+    D, A, L, B, HEATUP, TRAIN, SEED = 6, 3, 7, 8, 6, 30, 23
+    out = {"hp": np.array([D, A, L, B, HEATUP, TRAIN, SEED])}
+    rng = np.random.RandomState(5)
+    p_arr = _rand_arrays(rng, {"policy/embedder/dense0": (D, 20, 1), "policy/middleware/dense0": (20, 12, 1),
+                               "policy/sac_policy_head/policy_mu_logsig": (12, 2 * A, 1)})
+    q_arr = _rand_arrays(rng, {"q/q_head/obs_fc": (D, 14, 2), "q/q_head/act_fc": (A, 14, 2),
+                               "q/q_head/fc1": (14, 14, 2), "q/q_head/q_output": (14, 1, 2)})
+    v_arr = _rand_arrays(rng, {"v/embedder/dense0": (D, 20, 1), "v/middleware/dense0": (20, 12, 1),
+                               "v/v_values_head/output": (12, 1, 1)})
+    for arrs in (p_arr, q_arr, v_arr):
+        for k, v in arrs.items():
+            for t, arr in enumerate(v):
+                out["init|%s|%d" % (k, t)] = arr
+    ap = SoftActorCriticAgentParameters()
+    ap.task_parameters = TaskParameters()
+    ap.name = "agent"
+    ap.visualization.dump_csv = False
+    ap.is_a_highest_level_agent = False
+    ap.input_filter, ap.output_filter, ap.pre_network_filter = NoInputFilter(), NoOutputFilter(), NoInputFilter()
+    for n in ap.network_wrappers.values():
+        n.batch_size = B
+    holder = {}
+
+    class Agent(SoftActorCriticAgent):
+        def create_networks(self):
+            pol, qn, vn = O.SACPolicyOracle(copy.deepcopy(p_arr)), O.SACQOracle(copy.deepcopy(q_arr)), \
+                O.SACValueOracle(copy.deepcopy(v_arr))
+            holder["policy"], holder["q"], holder["v"] = pol, qn, vn
+            ws = {'policy': OB.SACPolicyWrapper(pol, A), 'q': OB.SACQWrapper(qn), 'v': OB.SACValueWrapper(vn)}
+            for name, w in ws.items():
+                w.has_target = name == 'v'
+                w.set_is_training = lambda s: None
+                w.update_target_network = lambda rate=1.0: None          # no target network: nothing to mix
+                nets = [w.online_network] + ([w.target_network] if name == 'v' else [])
+                for nn in nets:
+                    nn.reset_internal_memory = lambda: None
+            ws['v'].update_target_network = lambda rate=1.0: vn.mix_target(rate)
+            return ws
+    agent = Agent(ap)
+    agent.set_environment_parameters(SpacesDefinition(
+        state=StateSpace({'observation': VectorObservationSpace(D)}), goal=None,
+        action=BoxActionSpace(A, -1.0, 1.0), reward=RewardSpace(1)))
+    env = SynthVecEnv(1, 1, D, L, 57)
+    random.seed(SEED)
+    np.random.seed(SEED)
+    actions, iters, keys, visible = [], [], [], []
+    sample = agent.memory.sample
+
+    def logged_sample(size):
+        b = sample(size)
+        keys.append([float(t.state['observation'][0]) for t in b])
+        visible.append(agent.memory.num_transitions())
+        return b
+    agent.memory.sample = logged_sample
+    resp = EnvResponse(next_state={'observation': env.reset()[0].copy()}, reward=0, game_over=False)
+    agent.reset_internal_state()
+    reset_required, first = False, None
+    for step in range(HEATUP + TRAIN):
+        agent.phase = RunPhase.HEATUP if step < HEATUP else RunPhase.TRAIN
+        if reset_required:
+            agent.reset_internal_state()
+            resp = EnvResponse(next_state={'observation': first.copy()}, reward=0, game_over=False)
+            reset_required = False
+        agent.observe(resp)
+        actions.append(np.array(agent.act().action, dtype=np.float64))
+        nxt, rst, rew, done = env.step()
+        resp = EnvResponse(next_state={'observation': nxt[0].copy()}, reward=float(rew[0]), game_over=bool(done[0]))
+        if resp.game_over:
+            agent.observe(resp)
+            agent.handle_episode_ended()
+            reset_required, first = True, rst[0]
+        if step >= HEATUP:
+            agent.train()
+        iters.append(agent.training_iteration)
+    out["actions"], out["iters"] = np.array(actions), np.array(iters)
+    out["keys"], out["visible"] = np.array(keys), np.array(visible)
+    for nm in ("policy", "q", "v"):
+        _flat("final|" + nm, holder[nm].weights(), out)
+    _save("sac_loop", **out)
+
+
 def gen_ppo_loop():
     """The REAL reference `ClippedPPOAgent(ClippedPPOAgentParameters())` (own __init__: episodic memory,
     Categorical exploration, episode buffers, _should_train with act_for_full_episodes, train ->
@@ -1380,7 +1478,7 @@ def gen_csv_columns():
 
 
 GROUPS = {"csv_columns": gen_csv_columns, "per": gen_per, "er": gen_er, "episodic": gen_episodic, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop, "sac_loop": gen_sac_loop}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

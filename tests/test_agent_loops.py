@@ -255,3 +255,75 @@ def test_td3_and_ddpg_loops_match_the_reference_pinned_oracles(dev, name, length
         for name, per_tower in orc.weights().items():
             for t, ref in per_tower.items():
                 np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=6e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("lengths", [(6,), (5, 7, 4)])
+def test_sac_loop_matches_the_reference_pinned_oracle(dev, lengths):
+    """The device SAC agent's whole loop for N envs with different episode lengths against
+    oracle.agents.SACAgentOracle in the reference's store order (pinned for one env to the REAL reference
+    SoftActorCriticAgent's loop, tests/golden/sac_loop.npz): same host streams -> the recorded actions, the training
+    iteration after every step, the transitions visible at every update and every sampled index agree; the weights to
+    what fp32 accumulation order allows.  Rewards go through the preset's RewardRescaleFilter(5)."""
+    from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgent, SoftActorCriticAgentParameters
+    from coach_amd.core_types import RunPhase
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    from oracle.agents import SACAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    n_env, D, A, B, HEATUP, TRAIN = len(lengths), 9, 3, 16, 5, 20
+    ep = SyntheticVectorEnvironmentParameters("vector", n_env, (D,), None, action_dim=A, episode_length=max(lengths),
+                                              seed=9)
+    if n_env > 1:
+        ep.episode_lengths = list(lengths)
+    env = SyntheticVectorEnvironment(ep, dev)
+    p = SoftActorCriticAgentParameters()
+    p.seed = 11
+    for n in p.network_wrappers.values():
+        n.batch_size = B
+    p.network_wrappers["policy"].embedder_scheme, p.network_wrappers["policy"].middleware_scheme = (24,), (16,)
+    p.network_wrappers["v"].embedder_scheme, p.network_wrappers["v"].middleware_scheme = (24,), (16,)
+    p.network_wrappers["q"].network_layers_sizes = (16, 16)
+    p.memory.max_size = (MemoryGranularity.Transitions, 48)             # the ring wraps during the run
+    agent = SoftActorCriticAgent(p, env, dev)
+    agent.debug_draws = []
+    arr = {k: agent.networks[k].params.named_arrays() for k in ("policy", "q", "v")}
+    o = SACAgentOracle(arr["policy"], arr["q"], arr["v"],
+                       SynthVecEnv(1, n_env, D, max(lengths), 9, episode_lengths=list(lengths)), A, batch_size=B,
+                       capacity=48, reward_rescale=5.0)
+    o.reference_order = True
+    o.reset()
+    state = (random.getstate(), np.random.get_state())
+    acts, iters, visible = [], [], []
+    collate = agent.memory.collate
+
+    def logged(d, B_):
+        visible.append(agent.memory.num_transitions())
+        return collate(d, B_)
+    agent.memory.collate = logged
+    for step in range(HEATUP + TRAIN):
+        agent.phase = RunPhase.HEATUP if step < HEATUP else RunPhase.TRAIN
+        agent.act()
+        acts.append(agent.actions.cpu().numpy().copy())
+        if step >= HEATUP:
+            agent.train()
+        iters.append(agent.training_iteration)
+    agent.check_status()
+    hip_state = (random.getstate(), np.random.get_state())
+    random.setstate(state[0]); np.random.set_state(state[1])
+    o_iters = []
+    for step in range(HEATUP + TRAIN):
+        o.heatup_step() if step < HEATUP else o.act()
+        o_iters.append(o.training_iteration)
+    assert np.array_equal(np.random.get_state()[1], hip_state[1][1])           # identical host RNG consumption
+    assert iters == o_iters and iters[-1] == TRAIN * n_env
+    assert visible == o.visible and max(visible) == 48
+    assert len(agent.debug_draws) == len(o.sampled)
+    for d, s_ in zip(agent.debug_draws, o.sampled):
+        np.testing.assert_array_equal(d, s_)
+    np.testing.assert_allclose(np.array(acts), np.array(o.recorded_actions), rtol=1e-4, atol=1e-5)
+    for net, orc in ((agent.networks["policy"], o.policy), (agent.networks["q"], o.q), (agent.networks["v"], o.v)):
+        hw = net.params.named_arrays()
+        for name, per_tower in orc.weights().items():
+            for t, ref in per_tower.items():
+                np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=6e-5, err_msg=name)

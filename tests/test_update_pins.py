@@ -596,3 +596,38 @@ def test_oracle_ddpg_agent_loop_equals_real_reference_agent_loop():
     np.testing.assert_array_equal(keys, fx["keys"])
     _check_final(fx, "final|actor", o.actor, atol=2e-6)
     _check_final(fx, "final|critic", o.critic, atol=2e-6)
+
+
+def test_oracle_sac_agent_loop_equals_real_reference_agent_loop():
+    """oracle.agents.SACAgentOracle (n_env = 1, reference_order = True) against the REAL reference SoftActorCriticAgent
+    object (own __init__, ExperienceReplay, heat-up, sampled actions, one update per env-step with the transitions
+    visible at that train(), V target mixed after every update): recorded actions, training iterations, visible
+    transitions, sampled transitions, final weights."""
+    import random
+    from oracle.agents import SACAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    fx = np.load(os.path.join(HERE, "golden", "sac_loop.npz"))
+    D, A, L, B, HEATUP, TRAIN, SEED = (int(x) for x in fx["hp"])
+    arrays = {}
+    for k in fx.files:
+        if k.startswith("init|"):
+            _, name, t = k.split("|")
+            arrays.setdefault(name, {})[int(t)] = fx[k]
+    arrays = {n: [tw[t] for t in sorted(tw)] for n, tw in arrays.items()}
+    sub = lambda pre: {k: v for k, v in arrays.items() if k.startswith(pre)}
+    random.seed(SEED)
+    np.random.seed(SEED)
+    o = SACAgentOracle(sub("policy/"), sub("q/"), sub("v/"), SynthVecEnv(1, 1, D, L, 57), A, batch_size=B)
+    o.reference_order = True
+    o.reset()
+    iters = []
+    for step in range(HEATUP + TRAIN):
+        o.heatup_step() if step < HEATUP else o.act()
+        iters.append(o.training_iteration)
+    np.testing.assert_array_equal(iters, fx["iters"])
+    np.testing.assert_array_equal(o.visible, fx["visible"])
+    np.testing.assert_array_equal(np.array(o.sampled_keys), fx["keys"])
+    np.testing.assert_allclose(np.array(o.recorded_actions)[:, 0], fx["actions"], rtol=0, atol=1e-7)
+    _check_final(fx, "final|policy", o.policy, atol=2e-6)
+    _check_final(fx, "final|q", o.q, atol=2e-6)
+    _check_final(fx, "final|v", o.v, atol=2e-6)
