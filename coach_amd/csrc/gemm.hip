@@ -699,35 +699,6 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
 // workgroups of the 64x64 tiling.  Scalar (4-byte) operand loads with clamped indices: no alignment
 // or divisibility requirements.
 constexpr int kThinKS = 128, kThinLD = 33;
-// the four K-quarter partial tiles of the waves -> LDS (As is exactly 4 x 32 x 33 floats), summed in a fixed order, then
-// the bias / activation / derivative epilogue (shared by both thin kernels)
-__device__ __forceinline__ void thin_epilogue(const GemmDev &g, const f32x16 &acc, float *const As, const int batch,
-                                              const int m0, const int n0) {
-    constexpr int LD = 33;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    float *stage = As + w * (32 * LD);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * LD + l31] = acc[r];
-    __syncthreads();
-    const int rl = tid >> 3, c4 = (tid & 7) * 4;
-    const int row = m0 + rl;
-    if (row >= g.M) return;
-    float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc;
-    const float *bias = g.bias ? g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) : nullptr;
-    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld : nullptr;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + c4 + j;
-        if (col >= g.N) continue;
-        const int o = rl * LD + c4 + j;
-        float v = ((As[o] + As[32 * LD + o]) + As[2 * 32 * LD + o]) + As[3 * 32 * LD + o];
-        v = apply_act(v + (bias ? bias[col] : 0.f), g.act);
-        if (aux) v *= act_deriv(aux[col], g.deriv);
-        c[col] = g.accumulate ? c[col] + v : v;
-    }
-}
-
 template <bool A_CONTIG_K, bool B_CONTIG_N>
 __device__ __forceinline__ void gemm_thin_body(const GemmDev &g, const int bx, const int by, const int bz,
                                                float *const As, float *const Bs) {
@@ -800,7 +771,27 @@ __device__ __forceinline__ void gemm_thin_body(const GemmDev &g, const int bx, c
     }
     if (do_colsum && n0 + tid < g.N) g.colsum[(size_t)batch * g.colsum_batch_stride + n0 + tid] = csum;
 
-    thin_epilogue(g, acc, As, batch, m0, n0);
+    // ---- the four K-quarter partials -> LDS (As is exactly 4 x 32 x 33 floats), fixed-order sum
+    float *stage = As + w * (32 * LD);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * LD + l31] = acc[r];
+    __syncthreads();
+    const int rl = tid >> 3, c4 = (tid & 7) * 4;
+    const int row = m0 + rl;
+    if (row >= g.M) return;
+    float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc;
+    const float *bias = g.bias ? g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) : nullptr;
+    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + c4 + j;
+        if (col >= g.N) continue;
+        const int o = rl * LD + c4 + j;
+        float v = ((As[o] + As[32 * LD + o]) + As[2 * 32 * LD + o]) + As[3 * 32 * LD + o];
+        v = apply_act(v + (bias ? bias[col] : 0.f), g.act);
+        if (aux) v *= act_deriv(aux[col], g.deriv);
+        c[col] = g.accumulate ? c[col] + v : v;
+    }
 }
 
 template <bool A_CONTIG_K, bool B_CONTIG_N>
@@ -824,162 +815,6 @@ __global__ void __launch_bounds__(kThreads) gemm_thin_pair_kernel(const GemmPair
         gemm_thin_body<false, true>(p.g[0], bx, by, bz, As, Bs);
     else
         gemm_thin_body<true, false>(p.g[1], bx, by, bz, As, Bs);
-}
-
-// ---- thin GEMM with every operand load in flight at once (K <= 512).
-// gemm_thin_body above is bound by LATENCY, not by work: each 128-wide K slab is one global-load round trip (32 scalar
-// loads per thread with 64-bit index arithmetic) that the 16 MFMAs of the previous slab cannot cover, so a layer with
-// K = 400 pays four round trips in series (8.4 us measured at 100 x 300 x 400).  Here the whole reduction — NS <= 4 slabs,
-// known at launch — is requested in the prologue, 16-byte loads where the operand allows them (8 loads per thread per
-// slab, 32 in flight: under the 6-bit vmcnt), and the slabs then go through the same LDS tile, the same wave / MFMA
-// assignment of the reduction index and the same epilogue: bit-identical results, one round trip.
-template <bool CONTIG_K>
-__device__ __forceinline__ void thin_issue(const float *const base, const long long stride_o, const long long stride_r,
-                                           const int o0, const int O, const int K, const int k0, const int vec,
-                                           float (&r)[16]) {
-    const int tid = threadIdx.x;
-    if (vec) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + p * kThreads;                    // float4 index in the 32 x 128 tile, contiguous index fastest
-            const int o = CONTIG_K ? f >> 5 : (f & 7) << 2;
-            const int k = k0 + (CONTIG_K ? (f & 31) << 2 : f >> 3);
-            const bool ok = k < K;
-            const int oc = CONTIG_K ? min(o0 + o, O - 1) : min(o0 + o, O - 4);
-            const float4 v = *reinterpret_cast<const float4 *>(base + (long long)oc * stride_o +
-                                                               (long long)(ok ? k : 0) * stride_r);
-            r[4 * p + 0] = ok ? v.x : 0.f;
-            r[4 * p + 1] = ok ? v.y : 0.f;
-            r[4 * p + 2] = ok ? v.z : 0.f;
-            r[4 * p + 3] = ok ? v.w : 0.f;
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int e = tid + p * kThreads;
-            const int k = k0 + (CONTIG_K ? e % kThinKS : e / 32);
-            const int o = CONTIG_K ? e / kThinKS : e % 32;
-            const float v = base[(long long)min(o0 + o, O - 1) * stride_o + (long long)min(k, K - 1) * stride_r];
-            r[p] = k < K ? v : 0.f;
-        }
-    }
-}
-
-template <bool CONTIG_K>
-__device__ __forceinline__ void thin_stage(float *const S, const int vec, const float (&r)[16]) {
-    constexpr int LD = kThinLD;
-    const int tid = threadIdx.x;
-    if (vec) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + p * kThreads;
-            const int o = CONTIG_K ? f >> 5 : (f & 7) << 2;
-            const int k = CONTIG_K ? (f & 31) << 2 : f >> 3;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) S[(CONTIG_K ? (k + j) * LD + o : k * LD + o + j)] = r[4 * p + j];
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int e = tid + p * kThreads;
-            S[(CONTIG_K ? e % kThinKS : e / 32) * LD + (CONTIG_K ? e / kThinKS : e % 32)] = r[p];
-        }
-    }
-}
-
-template <bool A_CONTIG_K, bool B_CONTIG_N, int NS>
-__device__ __forceinline__ void gemm_thin_pf_body(const GemmDev &g, const int bx, const int by, const int bz,
-                                                  float *const As, float *const Bs) {
-    constexpr int KS = kThinKS, LD = kThinLD;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int batch = bz;
-    const int m0 = by * 32, n0 = bx * 32;
-    const float *abase = static_cast<const float *>(g.a.base) + batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2);
-    const float *bbase = static_cast<const float *>(g.b.base) + batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2);
-    const int av = g.a.vec_ok, bv = g.b.vec_ok;
-    float ra[NS][16], rb[NS][16];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        thin_issue<A_CONTIG_K>(abase, g.a.stride_o, g.a.stride_r, m0, g.M, g.K, s * KS, av, ra[s]);
-        thin_issue<!B_CONTIG_N>(bbase, g.b.stride_o, g.b.stride_r, n0, g.N, g.K, s * KS, bv, rb[s]);
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const bool do_colsum = g.colsum != nullptr && by == 0 && tid < 32;
-    float csum = 0.f;
-    const float *ap = As + (w * 32 + hi) * LD + l31;
-    const float *bp = Bs + (w * 32 + hi) * LD + l31;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (s) __syncthreads();                                  // every wave is done with the previous slab
-        thin_stage<A_CONTIG_K>(As, av, ra[s]);
-        thin_stage<!B_CONTIG_N>(Bs, bv, rb[s]);
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 32; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * LD], bp[kk * LD], acc, 0, 0, 0);
-        if (do_colsum) {
-            float sc = 0.f;
-            for (int kk = 0; kk < KS; ++kk) sc += Bs[kk * LD + tid];
-            csum += sc;
-        }
-    }
-    __syncthreads();
-    if (do_colsum && n0 + tid < g.N) g.colsum[(size_t)batch * g.colsum_batch_stride + n0 + tid] = csum;
-    thin_epilogue(g, acc, As, batch, m0, n0);
-}
-
-template <bool A_CONTIG_K, bool B_CONTIG_N, int NS>
-__global__ void __launch_bounds__(kThreads) gemm_thin_pf_kernel(const GemmDev g) {
-    __shared__ float As[kThinKS * kThinLD];
-    __shared__ float Bs[kThinKS * kThinLD];
-    gemm_thin_pf_body<A_CONTIG_K, B_CONTIG_N, NS>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
-}
-
-template <bool A_CONTIG_K, bool B_CONTIG_N>
-__device__ __forceinline__ void gemm_thin_pf_any(const GemmDev &g, const int bx, const int by, const int bz,
-                                                 float *const As, float *const Bs) {
-    const int ns = (g.K + kThinKS - 1) / kThinKS;                // launch-uniform
-    if (ns <= 1) gemm_thin_pf_body<A_CONTIG_K, B_CONTIG_N, 1>(g, bx, by, bz, As, Bs);
-    else if (ns == 2) gemm_thin_pf_body<A_CONTIG_K, B_CONTIG_N, 2>(g, bx, by, bz, As, Bs);
-    else if (ns == 3) gemm_thin_pf_body<A_CONTIG_K, B_CONTIG_N, 3>(g, bx, by, bz, As, Bs);
-    else if (ns == 4) gemm_thin_pf_body<A_CONTIG_K, B_CONTIG_N, 4>(g, bx, by, bz, As, Bs);
-    else gemm_thin_body<A_CONTIG_K, B_CONTIG_N>(g, bx, by, bz, As, Bs);
-}
-
-// dW = X^T dY and dX = dY W^T of an MLP layer as one grid, every load in flight (see gemm_thin_pair_kernel)
-__global__ void __launch_bounds__(kThreads) gemm_thin_pf_pair_kernel(const GemmPairDev p) {
-    __shared__ float As[kThinKS * kThinLD];
-    __shared__ float Bs[kThinKS * kThinLD];
-    int flat = blockIdx.x;
-    const int which = flat >= p.n0;
-    if (which) flat -= p.n0;
-    const int gx = p.gx[which], gy = p.gy[which];
-    const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
-    if (!which)
-        gemm_thin_pf_any<false, true>(p.g[0], bx, by, bz, As, Bs);
-    else
-        gemm_thin_pf_any<true, false>(p.g[1], bx, by, bz, As, Bs);
-}
-
-static bool rlx_thin_prefetch_all() {
-    static const bool on = [] {
-        const char *e = getenv("RLX_THIN_NO_PREFETCH_ALL");
-        return !(e && e[0] == '1');
-    }();
-    return on;
-}
-
-template <bool A_CONTIG_K, bool B_CONTIG_N>
-static void launch_thin(const GemmDev &g, dim3 grid, hipStream_t s, bool prefetch_all) {
-    const int ns = (g.K + kThinKS - 1) / kThinKS;
-    if (!prefetch_all || ns > 4) gemm_thin_kernel<A_CONTIG_K, B_CONTIG_N><<<grid, kThreads, 0, s>>>(g);
-    else if (ns <= 1) gemm_thin_pf_kernel<A_CONTIG_K, B_CONTIG_N, 1><<<grid, kThreads, 0, s>>>(g);
-    else if (ns == 2) gemm_thin_pf_kernel<A_CONTIG_K, B_CONTIG_N, 2><<<grid, kThreads, 0, s>>>(g);
-    else if (ns == 3) gemm_thin_pf_kernel<A_CONTIG_K, B_CONTIG_N, 3><<<grid, kThreads, 0, s>>>(g);
-    else gemm_thin_pf_kernel<A_CONTIG_K, B_CONTIG_N, 4><<<grid, kThreads, 0, s>>>(g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1558,20 +1393,16 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
             const bool a_ck = d.a_k_stride == 1, b_cn = d.b_n_stride == 1;
             dim3 tgrid((d.N + 31) / 32, (d.M + 31) / 32, d.batch);
             g.splits = 1; g.kchunk = d.K; g.ws = nullptr; g.vec_epi = 0; g.fold = 0;
-            // 16-byte operand loads of the prefetch-all kernel: along the contiguous index, whole groups in range
-            g.a.vec_ok = g.a.vec_ok && (a_ck ? d.K % 4 == 0 : (d.a_row_stride == 1 && d.M % 4 == 0 && d.M >= 4));
-            g.b.vec_ok = g.b.vec_ok && (b_cn ? (d.N % 4 == 0 && d.N >= 4) : (d.b_k_stride == 1 && d.K % 4 == 0));
             if (plan) {
                 plan->thin = true; plan->a_ck = a_ck; plan->b_cn = b_cn;
                 plan->g = g; plan->grid = tgrid; plan->splits = 1;
                 return RLX_OK;
             }
             hipStream_t ts = rlx::as_stream(stream);
-            const bool pf = rlx_thin_prefetch_all();
-            if (a_ck && b_cn) launch_thin<true, true>(g, tgrid, ts, pf);
-            else if (a_ck) launch_thin<true, false>(g, tgrid, ts, pf);
-            else if (b_cn) launch_thin<false, true>(g, tgrid, ts, pf);
-            else launch_thin<false, false>(g, tgrid, ts, pf);
+            if (a_ck && b_cn) gemm_thin_kernel<true, true><<<tgrid, kThreads, 0, ts>>>(g);
+            else if (a_ck) gemm_thin_kernel<true, false><<<tgrid, kThreads, 0, ts>>>(g);
+            else if (b_cn) gemm_thin_kernel<false, true><<<tgrid, kThreads, 0, ts>>>(g);
+            else gemm_thin_kernel<false, false><<<tgrid, kThreads, 0, ts>>>(g);
             RLX_LAUNCH_CHECK();
             return RLX_OK;
         }
@@ -1711,8 +1542,7 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
         p.gx[0] = pw.grid.x; p.gy[0] = pw.grid.y; p.gx[1] = px.grid.x; p.gy[1] = px.grid.y;
         p.n0 = (int)(pw.grid.x * pw.grid.y * pw.grid.z);
         const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
-        if (rlx_thin_prefetch_all()) gemm_thin_pf_pair_kernel<<<total, kThreads, 0, rlx::as_stream(stream)>>>(p);
-        else gemm_thin_pair_kernel<<<total, kThreads, 0, rlx::as_stream(stream)>>>(p);
+        gemm_thin_pair_kernel<<<total, kThreads, 0, rlx::as_stream(stream)>>>(p);
         RLX_LAUNCH_CHECK();
         return RLX_OK;
     }

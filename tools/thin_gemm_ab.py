@@ -1,8 +1,9 @@
 """A/B of the thin GEMM kernels on the MLP layer shapes of C4 (TD3, B = 100, 400-300) and C5 (SAC, B = 256, 256-256):
 forward (X W + b, relu), input gradient (dY W^T), weight gradient (X^T dY) and the dW / dX pair launch.
 
-    python tools/thin_gemm_ab.py                       # prefetch-all kernels (default)
-    RLX_THIN_NO_PREFETCH_ALL=1 python tools/thin_gemm_ab.py
+    python tools/thin_gemm_ab.py
+(the prefetch-all variant this was written to compare — commit d1470f9, RLX_THIN_NO_PREFETCH_ALL / RLX_THIN_DBG — measured no
+faster and was removed; the record is profiles/r02_ab_thin_prefetch_all.txt)
 
 Prints one JSON line per shape: average device time per launch over a captured graph of 200 back-to-back launches
 (launch overhead amortised the way the update graphs amortise it) and a checksum of the output bits — the two variants
