@@ -709,6 +709,23 @@ __device__ __forceinline__ void gemm_thin_body(const GemmDev &g, const int bx, c
     const int m0 = by * 32, n0 = bx * 32;
     const float *abase = static_cast<const float *>(g.a.base) + batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2);
     const float *bbase = static_cast<const float *>(g.b.base) + batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2);
+    // epilogue operands (bias, activation-derivative input) requested FIRST: their round trip hides behind the
+    // reduction instead of sitting, exposed, between the last MFMA and the stores
+    const int rl = tid >> 3, c4 = (tid & 7) * 4;
+    const int row = m0 + rl;
+    float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_aux[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float *bias = g.bias ? g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) : nullptr;
+        const float *aux = g.aux && row < g.M ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + c4 + j;
+            if (col < g.N) {
+                if (bias) e_bias[j] = bias[col];
+                if (aux) e_aux[j] = aux[col];
+            }
+        }
+    }
 
     // element e = tid + p*256 of a 32 x 128 operand tile: (outer, k) with the contiguous index fastest
     int a_o[NE], a_k[NE], b_o[NE], b_k[NE];
@@ -776,20 +793,16 @@ __device__ __forceinline__ void gemm_thin_body(const GemmDev &g, const int bx, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * LD + l31] = acc[r];
     __syncthreads();
-    const int rl = tid >> 3, c4 = (tid & 7) * 4;
-    const int row = m0 + rl;
     if (row >= g.M) return;
     float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc;
-    const float *bias = g.bias ? g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) : nullptr;
-    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + c4 + j;
         if (col >= g.N) continue;
         const int o = rl * LD + c4 + j;
         float v = ((As[o] + As[32 * LD + o]) + As[2 * 32 * LD + o]) + As[3 * 32 * LD + o];
-        v = apply_act(v + (bias ? bias[col] : 0.f), g.act);
-        if (aux) v *= act_deriv(aux[col], g.deriv);
+        v = apply_act(v + e_bias[j], g.act);
+        if (g.aux) v *= act_deriv(e_aux[j], g.deriv);
         c[col] = g.accumulate ? c[col] + v : v;
     }
 }
