@@ -585,6 +585,26 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+                // the tile's bias (one float4 per lane: the column group does not depend on `it`) and its four
+                // activation-derivative float4s are requested BEFORE the staging barriers: one round trip that the
+                // staging covers, instead of one per `it` exposed between an LDS read and a store the compiler may not
+                // move a load across
+                const int ecol = n0 + wn * (32 * TN) + 32 * j + (lane & 7) * 4;
+                const bool ecol_ok = ecol < g.N;
+                const int etw = (!ws && g.fold) ? ecol / g.fold : 0, ecl = (!ws && g.fold) ? ecol % g.fold : ecol;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 av4[4];
+                if (!ws && g.bias && ecol_ok)
+                    bv = *reinterpret_cast<const float4 *>(
+                        g.fold ? g.bias + (size_t)etw * g.bias_batch_stride + ecl :
+                        g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + ecol);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int erow = m0 + wm * (32 * TM) + 32 * i + ((it * 64 + lane) >> 3);
+                    av4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!ws && aux && ecol_ok && erow < g.M)
+                        av4[it] = *reinterpret_cast<const float4 *>(aux + (size_t)erow * g.aux_ld + ecol);
+                }
                 __syncthreads();
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -600,19 +620,16 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
                     const float *sp = stage + rl * 33 + c4;
                     float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
                     float *dst = dst_base + (size_t)row * ld + col;
-                    const int tw = (!ws && g.fold) ? col / g.fold : 0, cl = (!ws && g.fold) ? col % g.fold : col;
+                    const int tw = etw, cl = ecl;
                     if (!ws && g.fold) dst = g.c + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
                     if (!ws) {
                         if (g.bias) {
-                            const float4 bv = *reinterpret_cast<const float4 *>(
-                                g.fold ? g.bias + (size_t)tw * g.bias_batch_stride + cl :
-                                g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col);
                             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                         }
                         v.x = apply_act(v.x, g.act); v.y = apply_act(v.y, g.act);
                         v.z = apply_act(v.z, g.act); v.w = apply_act(v.w, g.act);
                         if (aux) {
-                            const float4 av = *reinterpret_cast<const float4 *>(aux + (size_t)row * g.aux_ld + col);
+                            const float4 av = av4[it];
                             v.x *= act_deriv(av.x, g.deriv); v.y *= act_deriv(av.y, g.deriv);
                             v.z *= act_deriv(av.z, g.deriv); v.w *= act_deriv(av.w, g.deriv);
                         }
@@ -1023,6 +1040,27 @@ __global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g
     const size_t mn = (size_t)g.M * g.N;
     const float4 *ws = reinterpret_cast<const float4 *>(g.ws + (size_t)batch * g.splits * mn);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the epilogue operands of the finishing threads (bias, activation-derivative input, the accumulate target) are
+    // requested before the partials: one more load in flight instead of a round trip after the sum
+    float eb[4] = {0.f, 0.f, 0.f, 0.f}, ea[4] = {0.f, 0.f, 0.f, 0.f}, ec[4] = {0.f, 0.f, 0.f, 0.f};
+    float *c = nullptr;
+    if (q == 0 && gid < mn4) {
+        const int i = gid << 2;
+        const int row = i / g.N, col = i - row * g.N;
+        const int tw = g.fold ? col / g.fold : batch, cl = g.fold ? col % g.fold : col;
+        c = g.c + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
+        const float *bias = !g.bias ? nullptr
+                            : g.fold ? g.bias + (size_t)tw * g.bias_batch_stride + cl
+                                     : g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col;
+        const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld + col
+                                 : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (bias) eb[j] = bias[j];
+            if (aux) ea[j] = aux[j];
+            if (g.accumulate) ec[j] = c[j];
+        }
+    }
     if (gid < mn4) {
         int k = q;
         for (; k + 3 * SG < g.splits; k += 4 * SG) {    // 4 independent loads in flight per thread
@@ -1049,20 +1087,11 @@ __global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g
             const float4 p = part[t][ox];
             v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
         }
-        const int i = gid << 2;
-        const int row = i / g.N, col = i - row * g.N;
-        const int tw = g.fold ? col / g.fold : batch, cl = g.fold ? col % g.fold : col;
-        float *c = g.c + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
-        const float *bias = !g.bias ? nullptr
-                            : g.fold ? g.bias + (size_t)tw * g.bias_batch_stride + cl
-                                     : g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col;
-        const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld + col
-                                 : nullptr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float t = apply_act(v[j] + (bias ? bias[j] : 0.f), g.act);
-            if (aux) t *= act_deriv(aux[j], g.deriv);
-            v[j] = g.accumulate ? c[j] + t : t;
+            float t = apply_act(v[j] + eb[j], g.act);
+            if (g.aux) t *= act_deriv(ea[j], g.deriv);
+            v[j] = g.accumulate ? ec[j] + t : t;
         }
         if ((g.ldc & 3) == 0 && (((uintptr_t)c) & 15) == 0) {
             *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
