@@ -26,7 +26,8 @@ class DDPGCriticNetworkParameters(SchemeViews):           # ddpg_agent.py:36-52 
     _EMBEDDER_FIELDS = {"observation": "observation_embedder_scheme", "action": "action_embedder_scheme"}
     _TUPLE_SCHEMES = True
 
-    def __init__(self):
+    def __init__(self, use_batchnorm=False):
+        self.batchnorm = bool(use_batchnorm)             # observation embedder + middleware (ddpg_agent.py:37-45)
         self.observation_embedder_scheme = (400,)
         self.action_embedder_scheme = ()
         self.middleware_scheme = (300,)
@@ -47,7 +48,8 @@ class DDPGActorNetworkParameters(SchemeViews):            # ddpg_agent.py:55-70
     _EMBEDDER_FIELDS = {"observation": "observation_embedder_scheme"}
     _TUPLE_SCHEMES = True
 
-    def __init__(self):
+    def __init__(self, use_batchnorm=False):
+        self.batchnorm = bool(use_batchnorm)             # embedder, middleware and the actor head (ddpg_agent.py:56-60)
         self.observation_embedder_scheme = (400,)
         self.middleware_scheme = (300,)
         self.activation_function = 'relu'
@@ -73,13 +75,13 @@ class DDPGAlgorithmParameters(AlgorithmParameters):      # ddpg_agent.py:73-111
         self.use_non_zero_discount_for_terminal_states = False
 
 
-class DDPGAgentParameters(object):                       # ddpg_agent.py:114-122
-    def __init__(self):
+class DDPGAgentParameters(object):                       # ddpg_agent.py:111-122
+    def __init__(self, use_batchnorm=False):
         self.algorithm = DDPGAlgorithmParameters()
         self.exploration = OUProcessParameters()
         self.memory = EpisodicExperienceReplayParameters()
-        self.network_wrappers = OrderedDict([("actor", DDPGActorNetworkParameters()),
-                                             ("critic", DDPGCriticNetworkParameters())])
+        self.network_wrappers = OrderedDict([("actor", DDPGActorNetworkParameters(use_batchnorm=use_batchnorm)),
+                                             ("critic", DDPGCriticNetworkParameters(use_batchnorm=use_batchnorm))])
         self.seed = 0
 
     @property
@@ -105,11 +107,13 @@ class DDPGAgent(VectorOffPolicyAgent):
         seed = self.ap.seed or 0
         actor = ActorNet(self.device, self.obs_dim, self.A, scale, an.observation_embedder_scheme,
                          an.middleware_scheme, an.activation_function, an.learning_rate,
-                         an.adam_optimizer_beta1, an.adam_optimizer_beta2, an.optimizer_epsilon, seed)
+                         an.adam_optimizer_beta1, an.adam_optimizer_beta2, an.optimizer_epsilon, seed,
+                         batchnorm=bool(getattr(an, "batchnorm", False)))
         critic = CriticNet(self.device, self.obs_dim, self.A, cn.observation_embedder_scheme,
                            cn.middleware_scheme, cn.num_streams, cn.activation_function,
                            cn.head_initializer, cn.learning_rate, cn.adam_optimizer_beta1,
-                           cn.adam_optimizer_beta2, cn.optimizer_epsilon, seed + 1)
+                           cn.adam_optimizer_beta2, cn.optimizer_epsilon, seed + 1,
+                           batchnorm=bool(getattr(cn, "batchnorm", False)))
         self.networks = OrderedDict([("actor", actor), ("critic", critic)])
         self.memory = self._make_memory(action_dim=self.A)
         self.exploration_policy = self._make_exploration()
@@ -195,7 +199,15 @@ class DDPGAgent(VectorOffPolicyAgent):
 
     def learn_from_batch(self, batch):
         mix = self._mix_rate
-        self._run(("learn", mix), lambda: self._learn_device(batch, mix))
+        # Agent.train brackets its updates with set_is_training(True / False) on every network, targets included
+        # (agent.py:716,779): batch-norm layers normalise with batch statistics inside, the moving averages when acting
+        for net in self.networks.values():
+            net.set_is_training(True)
+        try:
+            self._run(("learn", mix), lambda: self._learn_device(batch, mix))
+        finally:
+            for net in self.networks.values():
+                net.set_is_training(False)
         if mix is not None:
             self._mixed = self._mixed | {"actor", "critic"}
         critic = self.networks["critic"]

@@ -22,12 +22,22 @@ from . import graph as G
 from .networks import _NetBase
 
 
-def _mlp(params, prefix, in_features, sizes, activation, towers=1):
+def _mlp(params, prefix, in_features, sizes, activation, towers=1, batchnorm=False):
+    """batchnorm: Dense -> BatchnormActivationDropout(batchnorm, activation) per layer (embedder.py:70-78,
+    fc_middleware.py with FCMiddlewareParameters(batchnorm=True))."""
     layers, feat = [], in_features
     for i, u in enumerate(sizes):
-        layers.append(G.Dense(params, "%s/dense%d" % (prefix, i), feat, u, activation, towers))
+        layers.append(G.Dense(params, "%s/dense%d" % (prefix, i), feat, u, None if batchnorm else activation, towers))
+        if batchnorm:
+            if towers != 1:
+                raise NotImplementedError("batch normalisation under several middleware streams")
+            layers.append(G.BatchNorm(params, "%s/batchnorm%d" % (prefix, i), u, activation))
         feat = u
     return G.Sequential(layers), feat
+
+
+def _bn_layers(*sequences):
+    return [l for s in sequences for l in (s.layers if hasattr(s, "layers") else [s]) if isinstance(l, G.BatchNorm)]
 
 
 class _ACBase(_NetBase):
@@ -42,13 +52,19 @@ class ActorNet(_ACBase):
 
     def __init__(self, device, obs_dim, action_dim, output_scale, embedder=(400,), middleware=(300,),
                  activation="relu", learning_rate=1e-4, adam_beta1=0.9, adam_beta2=0.999,
-                 optimizer_epsilon=1e-8, seed=0):
+                 optimizer_epsilon=1e-8, seed=0, batchnorm=False):
+        """batchnorm: DDPGActorNetworkParameters(use_batchnorm=True) (ddpg_agent.py:55-60): batch normalisation after
+        the embedder's and the middleware's dense layers and between fc_mean and its tanh (ddpg_actor_head.py:48-56)."""
         self.obs_dim, self.A = obs_dim, action_dim
         self.params = G.FlatParams()
-        self.emb, feat = _mlp(self.params, "actor/embedder", obs_dim, embedder, activation)
-        self.mid, feat = _mlp(self.params, "actor/middleware", feat, middleware, activation)
-        self.head = G.Dense(self.params, "actor/ddpg_actor_head/fc_mean", feat, action_dim, "tanh")
-        self.modules = [self.emb, self.mid, self.head]
+        self.emb, feat = _mlp(self.params, "actor/embedder", obs_dim, embedder, activation, batchnorm=batchnorm)
+        self.mid, feat = _mlp(self.params, "actor/middleware", feat, middleware, activation, batchnorm=batchnorm)
+        self.head = G.Dense(self.params, "actor/ddpg_actor_head/fc_mean", feat, action_dim,
+                            None if batchnorm else "tanh")
+        self.head_bn = G.BatchNorm(self.params, "actor/ddpg_actor_head/batchnorm0", action_dim, "tanh") \
+            if batchnorm else None
+        self.modules = [self.emb, self.mid, self.head] + ([self.head_bn] if batchnorm else [])
+        self.bn_layers = _bn_layers(self.emb, self.mid) + ([self.head_bn] if batchnorm else [])
         self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
         self.scale = torch.as_tensor(np.broadcast_to(np.asarray(output_scale, dtype=np.float32),
                                                      (action_dim,)).copy(), device=device)
@@ -59,7 +75,7 @@ class ActorNet(_ACBase):
 
     def _torso(self, ctx, x, tag, w, pair):
         """embedder then middleware; one dense layer each (the presets' shape): the two go out as one launch."""
-        if len(self.emb.layers) == 1 and len(self.mid.layers) == 1:
+        if len(self.emb.layers) == 1 and len(self.mid.layers) == 1 and not self.bn_layers:
             y1, y2 = G.dense_chain2_forward(ctx, self.emb.layers[0], self.mid.layers[0], x, tag=tag, weights=w,
                                             pair=pair)
             return [x, y1], [y1, y2]
@@ -72,6 +88,10 @@ class ActorNet(_ACBase):
         ctx = self.ctx
         acts, acts2 = self._torso(ctx, self._obs(obs, B), tag, w, False)
         y = self.head.forward(ctx, acts2[-1], tag=tag, weights=w)
+        if self.head_bn is not None:
+            z = y
+            y = self.head_bn.forward(ctx, z, tag=tag, weights=w)
+            y.pre_bn = z
         if out is None and self._uniform_scale == 1.0:
             return y.data.view(B, self.A), (acts, acts2, y)        # tanh output IS the action: no scaling launch
         out = out if out is not None else ctx.buffer("actions", (B, self.A), tag=tag)
@@ -82,6 +102,8 @@ class ActorNet(_ACBase):
         """actor.parallel_prediction([(target, next_states), (online, states)]) (ddpg_agent.py:146-149,
         td3_agent.py:157-160) as ONE pass: obs2 [2, B, D] = (states, next_states); returns actions
         [2, B, A] (row 0: online mu(s), row 1: target mu(s')) and the online activations for backward."""
+        if self.bn_layers:
+            raise NotImplementedError("paired online / target pass with batch normalisation")
         ctx = self.ctx
         x = G.Tensor(obs2.view(2, B, self.obs_dim), B, self.obs_dim, 2)
         acts, acts2 = self._torso(ctx, x, tag, None, True)
@@ -105,6 +127,9 @@ class ActorNet(_ACBase):
         if action_grad is not None:          # None: the caller wrote d loss / d tanh-output into head_grad(saved)
             self.lib.copy_2d(action_grad, self.A, dy, self.A, B, self.A, self._uniform_scale * grad_scale,
                              ctx.stream)
+        if self.head_bn is not None:
+            self.head_bn.backward(ctx, y.pre_bn, y)
+            y = y.pre_bn
         self.head.backward(ctx, acts2[-1], y)
         self.mid.backward(ctx, acts2, need_input_grad=len(self.emb.layers) > 0)
         self.emb.backward(ctx, acts)
@@ -120,20 +145,24 @@ class CriticNet(_ACBase):
 
     def __init__(self, device, obs_dim, action_dim, obs_embedder=(400,), middleware=(300,), streams=1,
                  activation="relu", head_init="normalized_columns", learning_rate=1e-3, adam_beta1=0.9,
-                 adam_beta2=0.999, optimizer_epsilon=1e-8, seed=0):
+                 adam_beta2=0.999, optimizer_epsilon=1e-8, seed=0, batchnorm=False):
+        """batchnorm: DDPGCriticNetworkParameters(use_batchnorm=True) (ddpg_agent.py:36-45): batch normalisation after
+        the observation embedder's and the middleware's dense layers (the Empty action embedder and the V head have
+        none)."""
         self.obs_dim, self.A, self.T = obs_dim, action_dim, streams
         self.params = G.FlatParams()
-        self.emb, efeat = _mlp(self.params, "critic/embedder", obs_dim, obs_embedder, activation)
+        self.emb, efeat = _mlp(self.params, "critic/embedder", obs_dim, obs_embedder, activation, batchnorm=batchnorm)
         if streams > 1 and len(obs_embedder) > 0:
             raise NotImplementedError("a trainable observation embedder below several middleware "
                                       "streams needs summed input gradients")
         self.efeat = efeat
         self.merged = action_dim + efeat                    # sorted inputs: 'action' < 'observation'
         self.mid, feat = _mlp(self.params, "critic/middleware", self.merged, middleware, activation,
-                              towers=streams)
+                              towers=streams, batchnorm=batchnorm)
         init = G.normalized_columns(1.0) if head_init == "normalized_columns" else None
         self.head = G.Dense(self.params, "critic/v_head/output", feat, 1, None, streams, init=init)
         self.modules = [self.emb, self.mid, self.head]
+        self.bn_layers = _bn_layers(self.emb, self.mid)
         self._finish(device, seed, learning_rate, adam_beta1, adam_beta2, optimizer_epsilon)
         self.loss = torch.zeros(4, dtype=torch.float32, device=device)
 

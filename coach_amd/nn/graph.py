@@ -177,6 +177,7 @@ class Tensor:
         self.grad_is_dz = False             # grad already carries act'(data) (applied by the consumer)
         self.grad = None
         self.grad_key = grad_key            # (ctx, name, tag): gradient lives in a cached buffer
+        self.bn_saved = None                # BatchNorm output: (batch mean, batch variance) of the pass, or (None, None)
 
     def tower_stride(self):
         return 0 if self.towers == 0 else self.rows * self.cols
@@ -195,6 +196,7 @@ class Tensor:
         g = self.ensure_grad()
         v = Tensor(self.data[t:t + 1], self.rows, self.cols, 1, u8=self.u8, div=self.div, act=self.act)
         v.grad = g[t:t + 1]
+        v.bn_saved = self.bn_saved
         return v
 
     def slice_towers(self, t0, n, with_grad=True):
@@ -202,6 +204,7 @@ class Tensor:
         v = Tensor(self.data[t0:t0 + n], self.rows, self.cols, n, u8=self.u8, div=self.div, act=self.act)
         if with_grad:
             v.grad = self.ensure_grad()[t0:t0 + n]
+        v.bn_saved = self.bn_saved
         return v
 
     def tower_view(self, t):
@@ -367,6 +370,67 @@ class Dense(Layer):
             else:
                 _rlx.gemm_pair_or_single(dxd)
             x.grad_is_dz = lower is not None
+
+
+class BatchNorm(Layer):
+    """tf.layers.batch_normalization(x, training=is_training) + the activation, after a Dense layer built without one
+    (BatchnormActivationDropout, tensorflow_components/layers.py:26-55, 138-152): momentum 0.99, epsilon 1e-3, gamma / beta
+    trainable, moving_mean / moving_variance not.  csrc/batchnorm.hip.
+
+    The four vectors live in the network's flat parameter buffer: gamma and beta get gradients like any weight; the
+    gradient slots of the moving statistics stay zero, so TF1-Adam leaves them alone (m = v = 0 -> a zero step) and only
+    commit() — the UPDATE_OPS tied to apply_gradients (architecture.py:273-277) — moves them.  Context.bn_training is the
+    network's is_training variable (architecture.py:627-633): batch statistics inside Agent.train, moving ones when acting.
+    """
+    MOMENTUM, EPSILON = 0.99, 1e-3
+    TRACKED_TAG = "train"         # the pass whose batch feeds the moving averages at apply time (ddpg_agent.py:178-193)
+
+    def __init__(self, params, name, channels, activation=None):
+        self.name, self.C, self.act, self.T, self.params = name, channels, activation, 1, params
+        self.gname, self.bname = name + "/gamma", name + "/beta"
+        self.mname, self.vname = name + "/moving_mean", name + "/moving_variance"
+        params.add_group([(self.gname, (channels,)), (self.bname, (channels,)), (self.mname, (channels,)),
+                          (self.vname, (channels,))], 1)
+
+    def initialize(self, rng):
+        self.params.w(self.gname).fill_(1.0)
+        self.params.w(self.vname).fill_(1.0)
+
+    def _saved(self, ctx, tag):
+        return (ctx.buffer(self.name + "/batch_mean", (self.C,), tag=tag),
+                ctx.buffer(self.name + "/batch_variance", (self.C,), tag=tag))
+
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
+        assert not pair and x.towers == 1 and x.cols == self.C and x.act is None, (self.name, x.towers, x.cols, x.act)
+        p, M = self.params, x.rows
+        training = bool(getattr(ctx, "bn_training", False))
+        y = ctx.buffer(self.name, (1, M, self.C), tag=tag)
+        mean, var = self._saved(ctx, tag) if training else (None, None)
+        ctx.lib.bn_forward(x.data, p.w(self.gname, 0, weights), p.w(self.bname, 0, weights),
+                           p.w(self.mname, 0, weights), p.w(self.vname, 0, weights), M, self.C, self.EPSILON,
+                           int(training), _rlx.ACT[self.act], y, mean, var, ctx.stream)
+        out = Tensor(y, M, self.C, 1, grad_key=(ctx, self.name, tag), act=self.act)
+        out.bn_saved = (mean, var)
+        return out
+
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
+        """y.grad = dL/dy (or dL/du when the layer above already applied act'); writes x.grad = dL/d(dense output) and
+        the gamma / beta gradients.  Batch-statistics form only (the reference differentiates inside Agent.train)."""
+        mean, var = y.bn_saved
+        if mean is None:
+            raise ValueError("%s: backward through a batch-norm pass that ran on the moving statistics" % self.name)
+        p, M = self.params, x.rows
+        own = self.act if (self.act is not None and not y.grad_is_dz) else None
+        ctx.lib.bn_backward(y.grad, y.data if own else None, x.data, p.w(self.gname, 0, weights), mean, var, M, self.C,
+                            self.EPSILON, _rlx.ACT[own], x.ensure_grad(), p.g(self.gname) if need_dw else None,
+                            p.g(self.bname) if need_dw else None, ctx.stream)
+        x.grad_is_dz = False
+
+    def commit(self, ctx):
+        """moving statistics <- the batch statistics of the tracked pass (run with the pre-update weights)."""
+        p = self.params
+        mean, var = self._saved(ctx, self.TRACKED_TAG)
+        ctx.lib.bn_update_moving(p.w(self.mname), p.w(self.vname), mean, var, self.C, self.MOMENTUM, ctx.stream)
 
 
 class Conv2d(Layer):

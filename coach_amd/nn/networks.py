@@ -89,6 +89,12 @@ class _NetBase:
             self.adam.step(grad_scale, **kw)
         if mix_rate is not None and self.target is not None and not kw:
             self.update_target(mix_rate)
+        for bn in getattr(self, "bn_layers", ()):          # UPDATE_OPS of apply_gradients (architecture.py:273-277)
+            bn.commit(self.ctx)
+
+    def set_is_training(self, state):
+        """NetworkWrapper.set_is_training (network_wrapper.py:215-224): batch-norm layers use batch statistics."""
+        self.ctx.bn_training = bool(state)
 
     clip_gradients = None
 

@@ -336,6 +336,24 @@ int rlx_conv_tables(int *rowbase, int *koff, int batch, int H, int W, int C, int
 int rlx_col2im(const float *dcol, float *dx, const float *x_out, int deriv_kind, int batch, int H,
                int W, int C, int KH, int KW, int stride, void *stream); /* conv input gradient */
 
+/* Batch normalisation after a dense layer — the `use_batchnorm=True` DDPG networks (agents/ddpg_agent.py:37-60;
+ * architectures/tensorflow_components/layers.py:26-55 -> tf.layers.batch_normalization: momentum 0.99, epsilon 1e-3).
+ * x, y, dy, dx: [batch][channels] fp32, rows contiguous; gamma, beta, statistics: [channels].
+ *   rlx_bn_forward   training != 0: batch mean / population variance (written to save_mean / save_var), else the moving
+ *                    statistics;  y = act(x * inv + (beta - mean * inv)),  inv = rsqrt(var + eps) * gamma
+ *   rlx_bn_backward  dy = d loss / d y: multiplies by act'(y) (activation 0: dy is already d loss / d u), writes dx and,
+ *                    unless NULL, dgamma / dbeta (gradients_wrt_inputs passes need no weight gradients)
+ *   rlx_bn_update_moving  m -= (m - batch) * (1 - momentum): the UPDATE_OPS that run before apply_gradients
+ *                    (architecture.py:273-277) on the batch fed with it (ddpg_agent.py:178-193) */
+int rlx_bn_forward(const float *x, const float *gamma, const float *beta, const float *moving_mean,
+                   const float *moving_var, int batch, int channels, double epsilon, int training, int activation,
+                   float *y, float *save_mean, float *save_var, void *stream);
+int rlx_bn_backward(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
+                    const float *save_var, int batch, int channels, double epsilon, int activation, float *dx,
+                    float *dgamma, float *dbeta, void *stream);
+int rlx_bn_update_moving(float *moving_mean, float *moving_var, const float *batch_mean, const float *batch_var,
+                         int channels, double momentum, void *stream);
+
 /* Fused small-MLP DQN update: DQNAgent.learn_from_batch (agents/dqn_agent.py:81-113) for a vector-observation
  * Q network  obs -> Dense(h1, relu) -> Dense(h2, relu) -> Dense(n_actions)  in ONE launch: online / target (/ Double
  * DQN selector) forward passes, TD targets, |TD errors|, MSE or Huber loss with importance weights

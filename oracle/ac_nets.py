@@ -18,13 +18,32 @@ F32 = np.float32
 EPS32 = np.finfo(np.float32).eps
 
 
+def _batchnorm(arrays, name, activation):
+    return N.BatchNorm(*(arrays["%s/%s" % (name, k)][0].copy() for k in ("gamma", "beta", "moving_mean", "moving_variance")),
+                       activation=activation)
+
+
 def _dense_list(arrays, prefix, tower, activation):
+    """[(name, layer)]; a "<prefix>/batchnorm<i>/gamma" entry marks Dense -> BatchNorm -> activation (the
+    use_batchnorm=True networks of agents/ddpg_agent.py:37-60)."""
     out, i = [], 0
     while "%s/dense%d/kernel" % (prefix, i) in arrays:
-        n = "%s/dense%d" % (prefix, i)
-        out.append((n, N.Dense(arrays[n + "/kernel"][tower].copy(), arrays[n + "/bias"][tower].copy(), activation)))
+        n, bn = "%s/dense%d" % (prefix, i), "%s/batchnorm%d" % (prefix, i)
+        has_bn = bn + "/gamma" in arrays
+        out.append((n, N.Dense(arrays[n + "/kernel"][tower].copy(), arrays[n + "/bias"][tower].copy(),
+                               None if has_bn else activation)))
+        if has_bn:
+            out.append((bn, _batchnorm(arrays, bn, activation)))
         i += 1
     return out
+
+
+def _tensors(l):
+    """(suffix, weight attribute, gradient attribute or None) of a layer's variables."""
+    if isinstance(l, N.BatchNorm):
+        return [("gamma", "gamma", "dgamma"), ("beta", "beta", "dbeta"), ("moving_mean", "moving_mean", None),
+                ("moving_variance", "moving_var", None)]
+    return [("kernel", "W", "dW"), ("bias", "b", "db")]
 
 
 class _Net:
@@ -35,46 +54,64 @@ class _Net:
 
     def apply(self, grad_scale=1.0):
         for name, tower, l in self.layers:
-            self.adam.step((name, tower, "k"), l.W, l.dW, grad_scale)
-            self.adam.step((name, tower, "b"), l.b, l.db, grad_scale)
+            if isinstance(l, N.BatchNorm):
+                l.commit()                      # UPDATE_OPS run before the optimizer step, on the pre-update forward pass
+            for suffix, w, g in _tensors(l):
+                if g is not None:
+                    self.adam.step((name, tower, suffix[0]), getattr(l, w), getattr(l, g), grad_scale)
 
     def weights(self):
         out = {}
         for name, tower, l in self.layers:
-            out.setdefault(name + "/kernel", {})[tower] = l.W
-            out.setdefault(name + "/bias", {})[tower] = l.b
+            for suffix, w, _ in _tensors(l):
+                out.setdefault("%s/%s" % (name, suffix), {})[tower] = getattr(l, w)
         return out
 
     def grads(self):
         out = {}
         for name, tower, l in self.layers:
-            out.setdefault(name + "/kernel", {})[tower] = l.dW
-            out.setdefault(name + "/bias", {})[tower] = l.db
+            for suffix, _, g in _tensors(l):
+                if g is not None:
+                    out.setdefault("%s/%s" % (name, suffix), {})[tower] = getattr(l, g)
         return out
 
     def global_norm(self):
         s = 0.0
         for _, _, l in self.layers:
-            s += float(np.sum(l.dW.astype(np.float64) ** 2) + np.sum(l.db.astype(np.float64) ** 2))
+            for _, _, g in _tensors(l):
+                if g is not None:
+                    s += float(np.sum(getattr(l, g).astype(np.float64) ** 2))
         return np.sqrt(s)
 
     def clone_target(self):
         self.target_layers = copy.deepcopy([l for _, _, l in self.layers])
 
     def mix_target(self, rate):
+        """NetworkWrapper.update_target_network copies the TRAINABLE variables (architecture.py: self.weights =
+        tf.trainable_variables): a target network's moving statistics stay at their initial values."""
         from .optim import mix_weights
         for lt, (_, _, lo) in zip(self.target_layers, self.layers):
-            lt.W[...] = mix_weights(lt.W, lo.W, F32(rate))
-            lt.b[...] = mix_weights(lt.b, lo.b, F32(rate))
+            for _, w, g in _tensors(lo):
+                if g is not None:
+                    getattr(lt, w)[...] = mix_weights(getattr(lt, w), getattr(lo, w), F32(rate))
+
+    def set_is_training(self, state):
+        """is_training of the online AND the target graph (network_wrapper.py:215-224)."""
+        for l in [l for _, _, l in self.layers] + list(getattr(self, "target_layers", [])):
+            if isinstance(l, N.BatchNorm):
+                l.training = bool(state)
 
 
 class ActorOracle(_Net):
     def __init__(self, arrays, scale, activation="relu", lr=1e-4, adam=(0.9, 0.999, 1e-8)):
         emb = _dense_list(arrays, "actor/embedder", 0, activation)
         mid = _dense_list(arrays, "actor/middleware", 0, activation)
-        hn = "actor/ddpg_actor_head/fc_mean"
-        head = N.Dense(arrays[hn + "/kernel"][0].copy(), arrays[hn + "/bias"][0].copy(), "tanh")
+        hn, hbn = "actor/ddpg_actor_head/fc_mean", "actor/ddpg_actor_head/batchnorm0"
+        has_bn = hbn + "/gamma" in arrays
+        head = N.Dense(arrays[hn + "/kernel"][0].copy(), arrays[hn + "/bias"][0].copy(), None if has_bn else "tanh")
         self.layers = [(n, 0, l) for n, l in emb + mid] + [(hn, 0, head)]
+        if has_bn:                               # fc_mean -> batchnorm -> tanh (ddpg_actor_head.py:48-56)
+            self.layers.append((hbn, 0, _batchnorm(arrays, hbn, "tanh")))
         self.scale = F32(scale)
         self._setup(lr, adam)
         self.clone_target()
@@ -153,26 +190,33 @@ class CriticOracle(_Net):
         B = self.merged.shape[0]
         d = np.full((B, 1), 1.0 / B, dtype=F32)
         for l in reversed(streams[0]):
-            d = (d * N.act_grad(l.y, l.act)) @ l.W.T           # no weight gradients
+            if isinstance(l, N.BatchNorm):
+                d = l.backward(d, weights=False)
+            else:
+                d = (d * N.act_grad(l.y, l.act)) @ l.W.T       # no weight gradients
         return d[:, :n_act]
 
 
 def ddpg_update(actor, critic, batch, discount=0.99, clip=None, non_zero_terminal=False):
     """DDPGAgent.learn_from_batch (agents/ddpg_agent.py:137-195)."""
     s, a, r, done, ns = batch
+    actor.set_is_training(True)                # Agent.train brackets the update (agent.py:716,779): batch statistics in
+    critic.set_is_training(True)               # every pass below, target networks included
     next_actions = actor.forward(ns, target=True)
     q_next = critic.forward(ns, next_actions, target=True)[0]
     y = T.ac_td_targets(r, done, q_next[:, None], discount, non_zero_terminal, clip).astype(F32)[:, 0]
     actions_mean = actor.forward(s)
     critic.forward(s, actions_mean)
     g = critic.action_gradient(a.shape[1])
-    critic.forward(s, a)
+    critic.forward(s, a)                       # the batch the critic's moving averages see (:178-180)
     losses = critic.train_backward(y)
     norm = critic.global_norm()
     critic.apply()
-    actor.forward(s)
+    actor.forward(s)                           # ... and the actor's (additional_inputs = the states, :188-193)
     actor.backward(-g)
     actor.apply()
+    actor.set_is_training(False)
+    critic.set_is_training(False)
     return dict(loss=float(sum(losses)), targets=y, norm=norm, action_grad=g)
 
 

@@ -64,6 +64,53 @@ class Dense:
         return dz @ self.W.T
 
 
+class BatchNorm:
+    """tf.layers.batch_normalization(x, training) + activation after a dense layer (tensorflow_components/layers.py:26-55;
+    TF 1.x non-fused path for [B, C]: tf.nn.moments -> population variance, tf.nn.batch_normalization -> x * inv +
+    (beta - mean * inv) with inv = rsqrt(var + eps) * gamma; momentum 0.99, epsilon 1e-3; moving averages move by
+    m -= (m - batch) * (1 - momentum) when the UPDATE_OPS run).  PARITY UNPINNED for TF's rounding, like the rest of
+    this module."""
+    MOMENTUM, EPSILON = 0.99, 1e-3
+
+    def __init__(self, gamma, beta, moving_mean, moving_var, activation=None):
+        self.gamma, self.beta = gamma.astype(F32), beta.astype(F32)
+        self.moving_mean, self.moving_var = moving_mean.astype(F32), moving_var.astype(F32)
+        self.act, self.training, self.pending = activation, False, None
+
+    def forward(self, x):
+        x = np.asarray(x, dtype=F32)
+        self.x = x
+        if self.training:
+            B = F32(x.shape[0])
+            self.mean = (x.sum(0, dtype=F32) / B).astype(F32)
+            d = (x - self.mean).astype(F32)
+            self.var = ((d * d).sum(0, dtype=F32) / B).astype(F32)
+            self.pending = (self.mean, self.var)
+        else:
+            self.mean, self.var = self.moving_mean, self.moving_var
+        self.r = (F32(1) / np.sqrt(self.var + F32(self.EPSILON))).astype(F32)
+        inv = (self.r * self.gamma).astype(F32)
+        self.y = act((x * inv + (self.beta - self.mean * inv)).astype(F32), self.act)
+        return self.y
+
+    def backward(self, dy, weights=True):
+        assert self.training, "the reference differentiates inside Agent.train only"
+        du = (np.asarray(dy, dtype=F32) * act_grad(self.y, self.act)).astype(F32)
+        xh = ((self.x - self.mean) * self.r).astype(F32)
+        B = F32(self.x.shape[0])
+        sb, sg = du.sum(0, dtype=F32), (du * xh).sum(0, dtype=F32)
+        if weights:
+            self.dgamma, self.dbeta = sg.astype(F32), sb.astype(F32)
+        return ((self.gamma * self.r) * (du - sb / B - xh * (sg / B))).astype(F32)
+
+    def commit(self):
+        """the UPDATE_OPS in front of apply_gradients (architecture.py:273-277)."""
+        mean, var = self.pending
+        k = F32(1.0 - self.MOMENTUM)
+        self.moving_mean = (self.moving_mean - (self.moving_mean - mean) * k).astype(F32)
+        self.moving_var = (self.moving_var - (self.moving_var - var) * k).astype(F32)
+
+
 class Conv:
     def __init__(self, W, b, hwc, kernel, stride, activation=None):
         self.W, self.b, self.act = W.astype(F32), b.astype(F32), activation

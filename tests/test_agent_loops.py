@@ -21,6 +21,9 @@ def _mk(dev, name, use_graphs, n_env=8, L=5):
         ep = SyntheticVectorEnvironmentParameters("vector", n_env, (9,), None, action_dim=3, episode_length=L, seed=9)
         if name == "ddpg":
             from coach_amd.agents.ddpg_agent import DDPGAgent as C, DDPGAgentParameters as P
+        elif name == "ddpg_bn":                              # batch-normalised networks (ddpg_agent.py:111-122)
+            from coach_amd.agents.ddpg_agent import DDPGAgent as C, DDPGAgentParameters
+            P = lambda: DDPGAgentParameters(use_batchnorm=True)
         elif name == "td3":
             from coach_amd.agents.td3_agent import TD3Agent as C, TD3AgentParameters as P
         else:
@@ -55,7 +58,7 @@ def _drive(agent, heatup, steps):
     return updates
 
 
-@pytest.mark.parametrize("name", ["dqn", "ddpg", "td3", "sac"])
+@pytest.mark.parametrize("name", ["dqn", "ddpg", "ddpg_bn", "td3", "sac"])
 def test_graph_replay_equals_eager(dev, name):
     import torch
     a = _mk(dev, name, True)
