@@ -29,10 +29,13 @@ class _SchemeView(object):
     def activation_function(self, value):
         self._owner.activation_function = value
 
-    def __getattr__(self, name):                      # batchnorm, dropout_rate, ...: remembered, not used
+    def __getattr__(self, name):                      # dropout_rate, ...: remembered, not used
         extra = object.__getattribute__(self, "_extra")
         if name in extra:
             return extra[name]
+        owner = object.__getattribute__(self, "_owner")
+        if name == "batchnorm" and hasattr(owner, "batchnorm"):
+            return owner.batchnorm
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
@@ -40,6 +43,10 @@ class _SchemeView(object):
             object.__setattr__(self, name, value)
         else:
             self._extra[name] = value
+            if name == "batchnorm" and hasattr(self._owner, "batchnorm"):
+                # the device DDPG networks switch batch normalisation on for the whole network (what
+                # DDPGAgentParameters(use_batchnorm=True) does, ddpg_agent.py:37-60), not per component
+                self._owner.batchnorm = bool(value)
 
 
 class SchemeViews(object):
