@@ -371,9 +371,18 @@ class PPOArchitecture(HipArchitecture):
 
 
 # ================================================================================ DDPG / TD3
+def _no_batchnorm(np_):
+    if getattr(np_, "batchnorm", False):
+        # the moving averages step on the batch fed WITH apply_gradients (additional_inputs, ddpg_agent.py:178-193); this
+        # interface keeps no such pass — coach_amd.agents.ddpg_agent.DDPGAgent runs the batch-normalised networks
+        raise NotImplementedError("batch-normalised DDPG networks are driven by coach_amd.agents.ddpg_agent.DDPGAgent, "
+                                  "not through the Architecture plug-in interface")
+
+
 class ActorArchitecture(HipArchitecture):
     def _build(self, agent_parameters, spaces, np_, seed):
         scale = float(np.maximum(np.abs(spaces.action.low), np.abs(spaces.action.high)).max())
+        _no_batchnorm(np_)
         return ActorNet(self.device, int(spaces.state['observation'].shape[0]), int(spaces.action.shape[0]), scale,
                         np_.observation_embedder_scheme, np_.middleware_scheme, np_.activation_function,
                         *_adam_args(np_), seed)
@@ -411,6 +420,7 @@ class CriticArchitecture(HipArchitecture):
     """DDPG critic (one stream: outputs [Q, mean Q]) / TD3 twin critic ([Q1, Q2, min, mean Q1])."""
 
     def _build(self, agent_parameters, spaces, np_, seed):          # the agents seed the critic with seed + 1
+        _no_batchnorm(np_)
         return CriticNet(self.device, int(spaces.state['observation'].shape[0]), int(spaces.action.shape[0]),
                          np_.observation_embedder_scheme, np_.middleware_scheme, np_.num_streams,
                          np_.activation_function, np_.head_initializer, *_adam_args(np_), seed + 1)
