@@ -30,6 +30,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int kThreads = 256;
@@ -687,6 +688,7 @@ struct GemmPairDev {
     GemmDev g[2];
     int gx[2], gy[2];
     int n0;
+    int t16[2];                 // thin pair: the half runs on 16 x 16 tiles
 };
 template <bool A_TAB0>
 __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmPairDev p) {
@@ -824,6 +826,110 @@ __device__ __forceinline__ void gemm_thin_body(const GemmDev &g, const int bx, c
     }
 }
 
+// ---- the same kernel on 16 x 16 output tiles (v_mfma_f32_16x16x4_f32): 4x the workgroups.  A thin launch is not
+// bound by work but by what ONE CU does in series for its tile (profiles/r02_ab_thin_prefetch_all.txt: operand loads
+// through one L2 port, LDS staging, 50 dependent MFMAs, and nothing overlaps with one wave per SIMD) while most of the
+// chip idles — 100 x 300 is 40 tiles of 32 x 32 on 256 CUs.  Quartering the tile halves the operand bytes and the staging
+// per workgroup and quarters its MFMA passes.  The reduction index keeps its assignment (slabs of 128, wave w owns
+// [32w, 32w + 32), ascending k inside a wave, the four wave partials summed in the same fixed order).
+constexpr int kThin16LD = 17;
+template <bool A_CONTIG_K, bool B_CONTIG_N>
+__device__ __forceinline__ void gemm_thin16_body(const GemmDev &g, const int bx, const int by, const int bz,
+                                                 float *const As, float *const Bs) {
+    constexpr int KS = kThinKS, LD = kThin16LD, NE = 16 * KS / kThreads;    // 8 elements per thread per operand
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int batch = bz;
+    const int m0 = by * 16, n0 = bx * 16;
+    const float *abase = static_cast<const float *>(g.a.base) + batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2);
+    const float *bbase = static_cast<const float *>(g.b.base) + batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2);
+    // epilogue operands first (one output element per thread)
+    const int rl = tid >> 4, cl = tid & 15;
+    const int row = m0 + rl, col = n0 + cl;
+    const bool live = row < g.M && col < g.N;
+    float e_bias = 0.f, e_aux = 0.f;
+    if (live) {
+        if (g.bias) e_bias = g.bias[batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col];
+        if (g.aux) e_aux = g.aux[(size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld + col];
+    }
+    int a_o[NE], a_k[NE], b_o[NE], b_k[NE];
+    long long a_oo[NE], b_oo[NE];
+#pragma unroll
+    for (int p = 0; p < NE; ++p) {
+        const int e = tid + p * kThreads;
+        a_k[p] = A_CONTIG_K ? e % KS : e / 16;
+        a_o[p] = A_CONTIG_K ? e / KS : e % 16;
+        b_k[p] = B_CONTIG_N ? e / 16 : e % KS;
+        b_o[p] = B_CONTIG_N ? e % 16 : e / KS;
+        a_oo[p] = (long long)min(m0 + a_o[p], g.M - 1) * g.a.stride_o;
+        b_oo[p] = (long long)min(n0 + b_o[p], g.N - 1) * g.b.stride_o;
+    }
+    float ra[NE], rb[NE];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < NE; ++p) {
+            const int ka = k0 + a_k[p], kb = k0 + b_k[p];
+            const float va = abase[a_oo[p] + (long long)min(ka, g.K - 1) * g.a.stride_r];
+            const float vb = bbase[b_oo[p] + (long long)min(kb, g.K - 1) * g.b.stride_r];
+            ra[p] = ka < g.K ? va : 0.f;
+            rb[p] = kb < g.K ? vb : 0.f;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int p = 0; p < NE; ++p) {
+            As[a_k[p] * LD + a_o[p]] = ra[p];
+            Bs[b_k[p] * LD + b_o[p]] = rb[p];
+        }
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool do_colsum = g.colsum != nullptr && by == 0 && tid < 16;
+    float csum = 0.f;
+    load(0);
+    store();
+    __syncthreads();
+    for (int k0 = 0; k0 < g.K; k0 += KS) {
+        const bool more = k0 + KS < g.K;
+        if (more) load(k0 + KS);
+        const float *ap = As + (w * 32 + kq) * LD + l15;
+        const float *bp = Bs + (w * 32 + kq) * LD + l15;
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * LD], bp[kk * LD], acc, 0, 0, 0);
+        if (do_colsum) {
+            float sc = 0.f;
+            for (int kk = 0; kk < KS; ++kk) sc += Bs[kk * LD + tid];
+            csum += sc;
+        }
+        __syncthreads();
+        if (more) {
+            store();
+            __syncthreads();
+        }
+    }
+    if (do_colsum && n0 + tid < g.N) g.colsum[(size_t)batch * g.colsum_batch_stride + n0 + tid] = csum;
+    // the four K-quarter partials -> LDS (4 x 16 x 17 floats of As), fixed-order sum.  C/D layout of the 16x16 MFMA:
+    // col = lane & 15, row = 4 * (lane >> 4) + r
+    float *stage = As + w * (16 * LD);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stage[(4 * kq + r) * LD + l15] = acc[r];
+    __syncthreads();
+    if (!live) return;
+    const int o = rl * LD + cl;
+    float v = ((As[o] + As[16 * LD + o]) + As[2 * 16 * LD + o]) + As[3 * 16 * LD + o];
+    v = apply_act(v + e_bias, g.act);
+    if (g.aux) v *= act_deriv(e_aux, g.deriv);
+    float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc + col;
+    *c = g.accumulate ? *c + v : v;
+}
+
+template <bool A_CONTIG_K, bool B_CONTIG_N>
+__global__ void __launch_bounds__(kThreads) gemm_thin16_kernel(const GemmDev g) {
+    __shared__ float As[kThinKS * kThin16LD];
+    __shared__ float Bs[kThinKS * kThin16LD];
+    gemm_thin16_body<A_CONTIG_K, B_CONTIG_N>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
 template <bool A_CONTIG_K, bool B_CONTIG_N>
 __global__ void __launch_bounds__(kThreads) gemm_thin_kernel(const GemmDev g) {
     __shared__ float As[kThinKS * kThinLD];
@@ -841,10 +947,13 @@ __global__ void __launch_bounds__(kThreads) gemm_thin_pair_kernel(const GemmPair
     if (which) flat -= p.n0;
     const int gx = p.gx[which], gy = p.gy[which];
     const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
-    if (!which)
-        gemm_thin_body<false, true>(p.g[0], bx, by, bz, As, Bs);
-    else
-        gemm_thin_body<true, false>(p.g[1], bx, by, bz, As, Bs);
+    if (!which) {
+        if (p.t16[0]) gemm_thin16_body<false, true>(p.g[0], bx, by, bz, As, Bs);
+        else gemm_thin_body<false, true>(p.g[0], bx, by, bz, As, Bs);
+    } else {
+        if (p.t16[1]) gemm_thin16_body<true, false>(p.g[1], bx, by, bz, As, Bs);
+        else gemm_thin_body<true, false>(p.g[1], bx, by, bz, As, Bs);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1354,6 +1463,7 @@ namespace {
 struct GemmPlan {
     bool tiled_fast;            // the fast tiled kernel with 64x64 tiles would run (else: thin / generic / folded paths)
     bool thin, a_ck, b_cn;      // the thin kernel would run, with these operand layouts
+    bool t16;                   // ... on 16 x 16 output tiles (grid sized accordingly)
     GemmDev g;
     dim3 grid;
     bool a_vec_red, u8, b_vec_red, a_tab;
@@ -1377,7 +1487,7 @@ int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, 
 }
 
 int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
-    if (plan) plan->tiled_fast = plan->thin = false;
+    if (plan) plan->tiled_fast = plan->thin = plan->t16 = false;
     RLX_REQUIRE(d_host != nullptr, "rlx_gemm: null descriptor");
     const rlx_gemm_desc &d = *d_host;
     RLX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0,
@@ -1433,15 +1543,26 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
         static const int thin_max_tiles = rlx_env_int("RLX_GEMM_THIN_MAX_TILES", 96);
         if (t64 <= thin_max_tiles && (long long)d.N * d.K <= (1 << 18)) {      // MLP-sized weights only: the scalar loads lose on wide B
             const bool a_ck = d.a_k_stride == 1, b_cn = d.b_n_stride == 1;
-            dim3 tgrid((d.N + 31) / 32, (d.M + 31) / 32, d.batch);
+            // 32 x 32 tiles that leave most CUs idle -> 16 x 16 tiles (4x the workgroups, same reduction order)
+            static const int t16_max_tiles = rlx_env_int("RLX_GEMM_THIN16_MAX_TILES", 128);
+            const long long t32 = (long long)((d.M + 31) / 32) * ((d.N + 31) / 32) * d.batch;
+            const bool t16 = t32 <= t16_max_tiles;
+            const int tile = t16 ? 16 : 32;
+            dim3 tgrid((d.N + tile - 1) / tile, (d.M + tile - 1) / tile, d.batch);
             g.splits = 1; g.kchunk = d.K; g.ws = nullptr; g.vec_epi = 0; g.fold = 0;
             if (plan) {
-                plan->thin = true; plan->a_ck = a_ck; plan->b_cn = b_cn;
+                plan->thin = true; plan->a_ck = a_ck; plan->b_cn = b_cn; plan->t16 = t16;
                 plan->g = g; plan->grid = tgrid; plan->splits = 1;
                 return RLX_OK;
             }
             hipStream_t ts = rlx::as_stream(stream);
-            if (a_ck && b_cn) gemm_thin_kernel<true, true><<<tgrid, kThreads, 0, ts>>>(g);
+            if (t16) {
+                if (a_ck && b_cn) gemm_thin16_kernel<true, true><<<tgrid, kThreads, 0, ts>>>(g);
+                else if (a_ck) gemm_thin16_kernel<true, false><<<tgrid, kThreads, 0, ts>>>(g);
+                else if (b_cn) gemm_thin16_kernel<false, true><<<tgrid, kThreads, 0, ts>>>(g);
+                else gemm_thin16_kernel<false, false><<<tgrid, kThreads, 0, ts>>>(g);
+            }
+            else if (a_ck && b_cn) gemm_thin_kernel<true, true><<<tgrid, kThreads, 0, ts>>>(g);
             else if (a_ck) gemm_thin_kernel<true, false><<<tgrid, kThreads, 0, ts>>>(g);
             else if (b_cn) gemm_thin_kernel<false, true><<<tgrid, kThreads, 0, ts>>>(g);
             else gemm_thin_kernel<false, false><<<tgrid, kThreads, 0, ts>>>(g);
@@ -1583,6 +1704,7 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
         p.g[0] = pw.g; p.g[1] = px.g;
         p.gx[0] = pw.grid.x; p.gy[0] = pw.grid.y; p.gx[1] = px.grid.x; p.gy[1] = px.grid.y;
         p.n0 = (int)(pw.grid.x * pw.grid.y * pw.grid.z);
+        p.t16[0] = pw.t16; p.t16[1] = px.t16;
         const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
         gemm_thin_pair_kernel<<<total, kThreads, 0, rlx::as_stream(stream)>>>(p);
         RLX_LAUNCH_CHECK();
@@ -1599,6 +1721,7 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
     p.g[0] = pw.g; p.g[1] = px.g;
     p.gx[0] = pw.grid.x; p.gy[0] = pw.grid.y; p.gx[1] = px.grid.x; p.gy[1] = px.grid.y;
     p.n0 = (int)(pw.grid.x * pw.grid.y * pw.grid.z);
+    p.t16[0] = p.t16[1] = 0;
     const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
     hipStream_t s = rlx::as_stream(stream);
     if (pw.a_tab)
