@@ -1544,9 +1544,12 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
         if (t64 <= thin_max_tiles && (long long)d.N * d.K <= (1 << 18)) {      // MLP-sized weights only: the scalar loads lose on wide B
             const bool a_ck = d.a_k_stride == 1, b_cn = d.b_n_stride == 1;
             // 32 x 32 tiles that leave most CUs idle -> 16 x 16 tiles (4x the workgroups, same reduction order)
+            // (a launch of its own profits up to 256 tiles — dW 400x300x100, 130 tiles: 5.22 -> 3.81 us; as one half of a
+            // dW + dX pair grid the same problem is better left on 32 x 32 tiles: 5.96 vs 6.6 us for the pair)
             static const int t16_max_tiles = rlx_env_int("RLX_GEMM_THIN16_MAX_TILES", 128);
+            static const int t16_single_max_tiles = rlx_env_int("RLX_GEMM_THIN16_SINGLE_MAX_TILES", 256);
             const long long t32 = (long long)((d.M + 31) / 32) * ((d.N + 31) / 32) * d.batch;
-            const bool t16 = t32 <= t16_max_tiles;
+            const bool t16 = t32 <= (plan ? t16_max_tiles : t16_single_max_tiles);
             const int tile = t16 ? 16 : 32;
             dim3 tgrid((d.N + tile - 1) / tile, (d.M + tile - 1) / tile, d.batch);
             g.splits = 1; g.kchunk = d.K; g.ws = nullptr; g.vec_epi = 0; g.fold = 0;
