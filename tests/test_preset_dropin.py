@@ -210,6 +210,24 @@ def test_mujoco_presets_network_schemes_and_level_selection():
     assert (vp.kind, vp.observation_shape, vp.num_actions) == ("image", (84, 84), 4)
 
 
+@needs_reference
+def test_mujoco_ddpg_preset_with_batchnorm_switch():
+    """The reference's Mujoco_DDPG preset with its one-line variation `DDPGAgentParameters(use_batchnorm=True)`
+    (agents/ddpg_agent.py:111-122): the switch reaches both device networks, the preset's scheme assignments still apply,
+    and the reference's nested access path reads it back."""
+    text = _text("Mujoco_DDPG")
+    assert "DDPGAgentParameters()" in text
+    ap = _exec_preset(text.replace("DDPGAgentParameters()", "DDPGAgentParameters(use_batchnorm=True)"))["agent_params"]
+    for name in ("actor", "critic"):
+        net = ap.network_wrappers[name]
+        assert net.batchnorm is True
+        assert net.input_embedders_parameters['observation'].batchnorm is True
+        assert net.middleware_parameters.batchnorm is True
+        assert net.observation_embedder_scheme == (400,) and net.middleware_scheme == (300,)
+    plain = _exec_preset(text)["agent_params"]
+    assert plain.network_wrappers["actor"].batchnorm is False and plain.network_wrappers["critic"].batchnorm is False
+
+
 def test_reference_idiom_presets_build_on_cpu():
     """the GPU part's presets go through the same import layer; building them needs no device"""
     for name, body in DEVICE_PRESETS.items():
