@@ -41,6 +41,13 @@ __global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBw
     dense_small_bwd_body<NN>(p, blockIdx.x, blockIdx.y, smem);
 }
 
+// 16 features x 16 row groups per workgroup (see dense_small_bwd_body): the RLX_DENSE_SMALL_BWD_WIDE=1 experiment
+template <int NN>
+__global__ void __launch_bounds__(256) dense_small_bwd_wide_kernel(const SmallDenseBwd p) {
+    extern __shared__ float smem[];
+    dense_small_bwd_body<NN, 16, 16>(p, blockIdx.x, blockIdx.y, smem);
+}
+
 template <int NN>
 __global__ void __launch_bounds__(256) dense_small_bwd_multi_kernel(const MultiBwd m) {
     extern __shared__ float smem[];
@@ -92,8 +99,18 @@ int rlx_dense_small_backward(const float *x, long long x_tower_stride, const flo
     SmallDenseBwd p{x, x_tower_stride, w, w_tower_stride, dy, dy_tower_stride, y, y_tower_stride,
                     dw, dw_tower_stride, db, db_tower_stride, dx, dx_tower_stride,
                     M, K, N, activation, lower_activation};
-    dim3 grid((K + kKL - 1) / kKL, towers);
     hipStream_t s = rlx::as_stream(stream);
+    static const bool wide = [] { const char *e = getenv("RLX_DENSE_SMALL_BWD_WIDE"); return e && e[0] == '1'; }();
+    if (wide) {          // opt-in: written after the round's GPU budget was spent; tools/gpu_calls/next_round_ab.sh tests and times it
+        dim3 wgrid((K + 15) / 16, towers);
+        if (NN == 1) dense_small_bwd_wide_kernel<1><<<wgrid, 256, smem, s>>>(p);
+        else if (NN == 4) dense_small_bwd_wide_kernel<4><<<wgrid, 256, smem, s>>>(p);
+        else if (NN == 8) dense_small_bwd_wide_kernel<8><<<wgrid, 256, smem, s>>>(p);
+        else dense_small_bwd_wide_kernel<16><<<wgrid, 256, smem, s>>>(p);
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
+    }
+    dim3 grid((K + kKL - 1) / kKL, towers);
     if (NN == 1) dense_small_bwd_kernel<1><<<grid, 256, smem, s>>>(p);
     else if (NN == 4) dense_small_bwd_kernel<4><<<grid, 256, smem, s>>>(p);
     else if (NN == 8) dense_small_bwd_kernel<8><<<grid, 256, smem, s>>>(p);

@@ -82,12 +82,16 @@ constexpr int kMaxProblems = 4;
 struct MultiFwd { SmallDense p[kMaxProblems]; int towers[kMaxProblems]; int n; };
 struct MultiBwd { SmallDenseBwd p[kMaxProblems]; int towers[kMaxProblems]; int n; };
 
-template <int NN>
+// KL features x RG row groups per workgroup (KL * RG = 256).  The default 32 x 8 is what every caller uses; 16 x 16 is the
+// RLX_DENSE_SMALL_BWD_WIDE=1 experiment of rlx_dense_small_backward: twice the workgroups and, up to M = 128 rows, every x
+// load of a thread in ONE chunk (one exposed round trip instead of two at M = 100) — a different grouping of the dW row
+// sums, to be measured and compared before it becomes a default.
+template <int NN, int KL = kKL, int RG = kRG>
 __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int kblock, int t, float *smem) {
     float *dz = smem;                              // [M][N]
-    float *part = smem + (size_t)p.M * p.N;        // [kRG][kKL][NN] dW partials
-    const int lane = threadIdx.x % kKL, g = threadIdx.x / kKL;
-    const int k = kblock * kKL + lane;
+    float *part = smem + (size_t)p.M * p.N;        // [RG][KL][NN] dW partials
+    const int lane = threadIdx.x % KL, g = threadIdx.x / KL;
+    const int k = kblock * KL + lane;
     const float *dy = p.dy + (size_t)t * p.dy_ts;
     const float *yy = p.y ? p.y + (size_t)t * p.y_ts : nullptr;
     for (int i = threadIdx.x; i < p.M * p.N; i += 256)
@@ -109,18 +113,18 @@ __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int
     auto load_chunk = [&](int m0) {
 #pragma unroll
         for (int u = 0; u < kCH; ++u) {
-            const int mm = m0 + u * kRG;
+            const int mm = m0 + u * RG;
             xv[u] = (live && mm < p.M) ? x[(size_t)mm * p.K + k] : 0.f;
         }
     };
     load_chunk(g);
     __syncthreads();
-    for (int m0 = g; m0 < p.M; m0 += kRG * kCH) {
+    for (int m0 = g; m0 < p.M; m0 += RG * kCH) {
         if (m0 != g) load_chunk(m0);
         if (live) {
 #pragma unroll
             for (int u = 0; u < kCH; ++u) {
-                const int mm = m0 + u * kRG;
+                const int mm = m0 + u * RG;
                 if (mm < p.M) {
                     const float *dzr = dz + (size_t)mm * p.N;
                     float s = 0.f;
@@ -138,7 +142,7 @@ __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int
     }
     if (p.dw) {
 #pragma unroll
-        for (int n = 0; n < NN; ++n) part[((size_t)g * kKL + lane) * NN + n] = acc[n];
+        for (int n = 0; n < NN; ++n) part[((size_t)g * KL + lane) * NN + n] = acc[n];
         __syncthreads();
         if (g == 0 && live) {
             float *dw = p.dw + (size_t)t * p.dw_ts + (size_t)k * p.N;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int
                 if (n < p.N) {
                     float v = part[lane * NN + n];
 #pragma unroll
-                    for (int u = 1; u < kRG; ++u) v += part[(u * kKL + lane) * NN + n];   // fixed order
+                    for (int u = 1; u < RG; ++u) v += part[(u * KL + lane) * NN + n];     // fixed order
                     dw[n] = v;
                 }
         }
