@@ -29,6 +29,18 @@ SMALL_N = 16  # widest layer served by the narrow-dense kernels (csrc/dense_smal
 # towers that read the same input run their first layer as ONE GEMM over the concatenated output
 # columns (rlx_gemm_desc.n_fold); RLX_NO_FOLD=1 restores one batched problem per tower
 FOLD_SHARED_INPUT = os.environ.get("RLX_NO_FOLD", "0") != "1"
+# RLX_FOLD_ONLY_BEYOND_THIN=1 (candidate for the next round, not measured yet): a shared-input layer small enough for the
+# thin GEMM kernel (csrc/gemm.hip: K <= 1024, N * K <= 2^18, <= 96 tiles of 64 x 64) runs as T batched thin launches on
+# 16 x 16 tiles (3-5 us, no split-K reduce) instead of one folded tiled GEMM + reduce (SAC's Q towers: ~9 + 5 us)
+FOLD_ONLY_BEYOND_THIN = os.environ.get("RLX_FOLD_ONLY_BEYOND_THIN", "0") == "1"
+
+
+def _thin_takes(M, N, K, batch):
+    return K <= 1024 and N * K <= (1 << 18) and -(-M // 64) * -(-N // 64) * batch <= 96
+
+
+def _fold(M, N, K, T):
+    return FOLD_SHARED_INPUT and not (FOLD_ONLY_BEYOND_THIN and _thin_takes(M, N, K, T))
 
 
 def _align(n):
@@ -281,7 +293,7 @@ class Dense(Layer):
                     q.y, q.y_tower_stride = y.data_ptr() + c * T * M * self.N * 4, M * self.N
                     q.towers, q.M, q.K, q.N, q.activation = T, M, self.K, self.N, _rlx.ACT[self.act]
                 ctx.lib.dense_small_forward_multi(ctypes.byref(arr), 2, ctx.stream)
-        elif launch and not pair and x.towers == 0 and T > 1 and self.N % 4 == 0 and FOLD_SHARED_INPUT:
+        elif launch and not pair and x.towers == 0 and T > 1 and self.N % 4 == 0 and _fold(M, self.N, self.K, T):
             # the T towers read the SAME input: one GEMM over T*N columns loads (gathers) it once
             _rlx.gemm(M, T * self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
                       b_strides=(self.N, 1), ldc=self.N, bias=p.w(self.bname, t0, weights),
@@ -328,7 +340,7 @@ class Dense(Layer):
         # dW[K,N] = x^T dz : A(k, m) = x[m, k]
         # (db = column sums of dz, accumulated by the same launch from the staged B slabs)
         if need_dw:
-            fold = x.towers == 0 and T > 1 and self.N % 4 == 0 and FOLD_SHARED_INPUT
+            fold = x.towers == 0 and T > 1 and self.N % 4 == 0 and _fold(self.K, self.N, M, T)
 
             def dw(ws, launch=True):
                 if fold:       # shared input: dW of all towers = x^T [dz_0 | dz_1 | ...] in one GEMM
