@@ -349,6 +349,12 @@ class ClippedPPOAgent(object):
             # pre_network_filter over the whole dataset, statistics updated first (:320-322)
             mem.gather_states(rows, n, self.ds_obs_raw[:n])
             self.norm.filter(self.ds_obs_raw[:n], update_internal_state=self.dist is None, out=self.ds_obs[:n])
+            if self.dist is None:
+                # ... and InputFilter.filter then walks the NEXT states of the same Transitions (filters/filter.py:
+                # 314-333): they enter the statistics after the states were normalised (their normalised values are
+                # read by nobody).  Pinned by tests/golden/ppoc_loop.npz: the count grows by 2 n per phase
+                mem.gather_next_states(rows, n, self.ds_obs_raw[:n])
+                self.norm.push(self.ds_obs_raw[:n])
 
         def chunk_obs(c0, m):
             if self.norm is not None:
@@ -383,6 +389,10 @@ class ClippedPPOAgent(object):
             self.memory.gather_states(rows, n, self.ds_obs_raw[:n])
             self.norm.push_shared(self.ds_obs_raw[:n], self.dist)
         self._run(("fill", n), lambda: self._fill_advantages_device(n, rows))
+        if self.norm is not None and self.dist is not None:
+            # the next states of the dataset, after the states were normalised (see _fill_advantages_device)
+            self.memory.gather_next_states(rows, n, self.ds_obs_raw[:n])
+            self.norm.push_shared(self.ds_obs_raw[:n], self.dist)
 
     def _gather_minibatch(self, m, i=0):
         mem, s = self.memory, _rlx.current_stream()

@@ -98,6 +98,12 @@ class ObservationNormalizationFilter(ObservationFilter):
         _rlx.lib().running_stats_merge(delta, D, self.sum, self.sum_squares, self.count, self.mean, self.std,
                                        self.eps, s)
 
+    def push(self, observation):
+        """running_observation_stats.push alone: the batch enters the statistics, nothing is normalised."""
+        _rlx.lib().running_stats_push(observation, int(observation.dtype == torch.float64), observation.shape[0],
+                                      self.dim, self.sum, self.sum_squares, self.count, self.mean, self.std, self.eps,
+                                      _rlx.current_stream())
+
     def filter(self, observation, update_internal_state=True, out=None):
         n = observation.shape[0]
         is64 = observation.dtype == torch.float64

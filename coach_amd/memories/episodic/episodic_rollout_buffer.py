@@ -45,6 +45,9 @@ class DeviceEpisodicRolloutBuffer(object):
         else:
             self.obs_dim = obs_dim
             self.obs = torch.zeros(self.cap, obs_dim, dtype=torch.float32, device=device)
+            # Transition.next_state: a pre-network filter that keeps running statistics sees the next states of the
+            # dataset too (InputFilter.filter walks state AND next_state of every Transition, filters/filter.py:314-333)
+            self.next_obs = torch.zeros(self.cap, obs_dim, dtype=torch.float32, device=device)
             self.cur_state = torch.empty(n_env, obs_dim, dtype=torch.float32, device=device)
         self.action = torch.zeros(self.cap, dtype=torch.int32, device=device) if action_dim is None \
             else torch.zeros(self.cap, action_dim, dtype=torch.float32, device=device)
@@ -122,6 +125,7 @@ class DeviceEpisodicRolloutBuffer(object):
         pairs = [(actions, self.action), (rewards, self.reward), (game_overs, self.game_over)]
         if not self.image:
             pairs.append((self.cur_state, self.obs))
+            pairs.append((next_obs, self.next_obs))          # the env's response (the terminal observation at an episode end)
         self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), None, None, 0, row0, self.n_env,
                               self.cap, self.n_env, self.status, s)
         if self.image:
@@ -168,6 +172,14 @@ class DeviceEpisodicRolloutBuffer(object):
         else:
             self.lib.copy_columns(_rlx.make_columns([(self.obs, out)]), 1, rows, None, 0, 0, self.cap,
                                   n, n, self.status, s)
+        return out
+
+    def gather_next_states(self, rows, n, out):
+        """Transition.next_state of the given storage rows (vector observations) -> out [n, obs_dim]."""
+        if self.image:
+            raise NotImplementedError("next states of image rollouts are not kept (no filter reads them)")
+        self.lib.copy_columns(_rlx.make_columns([(self.next_obs, out)]), 1, rows, None, 0, 0, self.cap, n, n,
+                              self.status, _rlx.current_stream())
         return out
 
     def gather_columns(self, rows, n, pairs):

@@ -211,12 +211,19 @@ class ClippedPPOAgentOracle:
     def __init__(self, arrays, env, n_actions, stack=4, discount=0.99, gae_lambda=0.95, batch_size=64,
                  playing_steps=2048, epochs=10, clip_eps=0.2, beta_entropy=0.01, lr=2.5e-4,
                  reward_clip=(-1.0, 1.0), adam=(0.9, 0.99, 1e-4), ragged=False, continuous=False,
-                 action_low=-1.0, action_high=1.0):
+                 action_low=-1.0, action_high=1.0, normalize=False):
         # continuous: BoxActionSpace — the head outputs [policy_mean, policy_std] (ppo_head.py:118-144), AdditiveNoise
         # samples np.random.normal(mean, std) in TRAIN (exploration_policies/additive_noise.py:99-106); the old policy of
         # train_network is (mean, std) of the frozen copy
         self.continuous = continuous
         self.low, self.high = action_low, action_high
+        # normalize: the Mujoco_ClippedPPO pre-network filter (ObservationNormalizationFilter on numpy running statistics):
+        # acting normalises with the statistics as they are (update_pre_network_filters_state_on_inference = False,
+        # clipped_ppo_agent.py:346-351); train() filters the dataset with update_internal_state = True (:318-322), and
+        # InputFilter.filter (filters/filter.py:314-333) walks the states — push, then normalise — and then the NEXT
+        # states of the same Transitions — pushed too, their normalised values unused.  Pinned to the real reference
+        # agent's loop (tests/golden/ppoc_loop.npz)
+        self.normalize, self.stats = normalize, None
         self.ragged = ragged
         self.episodes = []                                     # (env, first index, end index) in completion order
         self.ep_start = [0] * env.n_env
@@ -253,11 +260,16 @@ class ClippedPPOAgentOracle:
         else:
             self.cur = [f for f in first]
             self._ensure_net((first.shape[1],))
+            if self.normalize and self.stats is None:
+                from .filters import RunningStatsOracle
+                self.stats = RunningStatsOracle((first.shape[1],))
 
     def act(self):
         from . import filters as Fl
         from .explore import categorical_choice
         states = np.stack(self.cur)
+        if self.normalize:
+            states = self.stats.normalize(states).astype(F32)
         if self.continuous:
             mean, std = self.net.policy_mean_std(states)
             probs = (mean, std)
@@ -273,7 +285,7 @@ class ClippedPPOAgentOracle:
             r = float(rew[e])
             if self.reward_clip is not None:
                 r = Fl.reward_clip(r, *self.reward_clip)
-            self.transitions[e].append((self.cur[e], actions[e], r, bool(done[e])))
+            self.transitions[e].append((self.cur[e], actions[e], r, bool(done[e]), nxt[e]))
             if done[e]:
                 self.episodes.append((e, self.ep_start[e], len(self.transitions[e])))
                 self.ep_start[e] = len(self.transitions[e])
@@ -302,6 +314,10 @@ class ClippedPPOAgentOracle:
         else:
             data = [t for e in range(self.n_env) for t in self.transitions[e]]     # episode-major
         states = np.stack([t[0] for t in data])
+        if self.normalize:
+            self.stats.push(states)
+            states = self.stats.normalize(states).astype(F32)
+            self.stats.push(np.stack([t[4] for t in data]))
         actions = np.array([t[1] for t in data])
         rewards = np.array([t[2] for t in data], dtype=np.float64)
         dones = np.array([t[3] for t in data])

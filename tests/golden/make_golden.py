@@ -1407,6 +1407,97 @@ def gen_ppo_loop():
     _save("ppo_loop", **out)
 
 
+def gen_ppoc_loop():
+    """The REAL reference `ClippedPPOAgent` on a BoxActionSpace with the Mujoco_ClippedPPO pre-network filter
+    (ObservationNormalizationFilter, numpy running statistics): acting normalises with the statistics as they are
+    (update_pre_network_filters_state_on_inference = False) and samples np.random.normal(mean, std) through
+    AdditiveNoise; train() pushes the whole dataset into the statistics first, then normalises it with the updated
+    statistics (clipped_ppo_agent.py:318-322) before fill_advantages / train_network.  Three rollouts on the synthetic env;
+    tests/test_update_pins.py replays oracle.agents.ClippedPPOAgentOracle(continuous=True, normalize=True)."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle.agents import ClippedPPOOracle
+    from oracle.synth_env import SynthVecEnv
+    from rl_coach.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
+    from rl_coach.base_parameters import TaskParameters
+    from rl_coach.core_types import EnvResponse, EnvironmentSteps, RunPhase
+    from rl_coach.filters.filter import InputFilter, NoInputFilter, NoOutputFilter
+    from rl_coach.filters.observation.observation_normalization_filter import ObservationNormalizationFilter
+    from rl_coach.spaces import BoxActionSpace, RewardSpace, SpacesDefinition, StateSpace, VectorObservationSpace
+    D, A, L, B, PLAY, EPOCHS, STEPS, SEED = 5, 2, 8, 8, 16, 2, 48, 21
+    out = {"hp": np.array([D, A, L, B, PLAY, EPOCHS, STEPS, SEED])}
+    rng = np.random.RandomState(2)
+    arrays = _rand_arrays(rng, {"main/embedder/dense0": (D, 20, 2), "main/middleware/dense0": (20, 12, 2),
+                                "main/v_head/dense": (12, 1, 1), "main/ppo_head/policy_mean": (12, A, 1)})
+    arrays["main/ppo_head/policy_log_std"] = [rng.uniform(-0.5, 0.1, (A,)).astype(np.float32)]
+    for k, v in arrays.items():
+        for t, arr in enumerate(v):
+            out["init|%s|%d" % (k, t)] = arr
+    ap = ClippedPPOAgentParameters()
+    ap.task_parameters = TaskParameters()
+    ap.name = "agent"
+    ap.visualization.dump_csv = False
+    ap.is_a_highest_level_agent = False
+    ap.input_filter, ap.output_filter = NoInputFilter(), NoOutputFilter()
+    ap.pre_network_filter = InputFilter(is_a_reference_filter=False)
+    ap.pre_network_filter.add_observation_filter('observation', 'normalize_observation',
+                                                 ObservationNormalizationFilter(name='normalize_observation'))
+    ap.network_wrappers['main'].batch_size = B
+    ap.network_wrappers['main'].learning_rate = 1e-3
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(PLAY)
+    ap.algorithm.optimization_epochs = EPOCHS
+    holder = {}
+
+    class Agent(ClippedPPOAgent):
+        def create_networks(self):
+            net = ClippedPPOOracle(copy.deepcopy(arrays), (D,), A, lr=1e-3,
+                                   clip_eps=self.ap.algorithm.clip_likelihood_ratio_using_epsilon,
+                                   beta_entropy=self.ap.algorithm.beta_entropy, continuous=True)
+            holder["net"] = net
+            w = OB.PPOContinuousWrapper(net)
+            w.has_target = True
+            return {'main': w}
+    agent = Agent(ap)
+    agent.set_environment_parameters(SpacesDefinition(
+        state=StateSpace({'observation': VectorObservationSpace(D)}), goal=None,
+        action=BoxActionSpace(A, -1.0, 1.0), reward=RewardSpace(1)))
+    agent.update_log = lambda: None
+    env = SynthVecEnv(1, 1, D, L, 78)
+    random.seed(SEED)
+    np.random.seed(SEED)
+    actions, trained_at, stats = [], [], []
+    resp = EnvResponse(next_state={'observation': env.reset()[0].copy()}, reward=0, game_over=False)
+    agent.reset_internal_state()
+    agent.phase = RunPhase.TRAIN
+    agent.exploration_policy.change_phase(RunPhase.TRAIN)
+    reset_required, first = False, None
+    for step in range(STEPS):
+        if reset_required:
+            agent.reset_internal_state()
+            resp = EnvResponse(next_state={'observation': first.copy()}, reward=0, game_over=False)
+            reset_required = False
+        agent.observe(resp)
+        actions.append(np.array(agent.act().action, dtype=np.float64))
+        nxt, rst, rew, done = env.step()
+        resp = EnvResponse(next_state={'observation': nxt[0].copy()}, reward=float(rew[0]), game_over=bool(done[0]))
+        if resp.game_over:
+            agent.observe(resp)
+            agent.handle_episode_ended()
+            reset_required, first = True, rst[0]
+        before = agent.training_iteration
+        agent.train()
+        if agent.training_iteration != before:
+            trained_at.append(step)
+            rs = agent.pre_network_filter._observation_filters['observation']['normalize_observation'] \
+                .running_observation_stats
+            stats.append(np.concatenate([[rs.n], np.asarray(rs.mean, dtype=np.float64).ravel(),
+                                         np.asarray(rs.std, dtype=np.float64).ravel()]))
+    out["actions"], out["trained_at"], out["stats"] = np.array(actions), np.array(trained_at), np.array(stats)
+    _flat("final", holder["net"].weights(), out)
+    _save("ppoc_loop", **out)
+
+
 def gen_csv_columns():
     """What Agent.update_log (agent.py:509-556) writes: the CSV column list of the REAL reference DQNAgent (own
     __init__, registered signals) after one update_log call, the values of the statistics columns for known
@@ -1478,7 +1569,7 @@ def gen_csv_columns():
 
 
 GROUPS = {"csv_columns": gen_csv_columns, "per": gen_per, "er": gen_er, "episodic": gen_episodic, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop, "sac_loop": gen_sac_loop}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop, "sac_loop": gen_sac_loop, "ppoc_loop": gen_ppoc_loop}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -101,6 +101,9 @@ def _norm_worker(rank, world, port, out_dir):
                 n = agent.memory.num_transitions()
                 raw.append(agent.memory.gather_states(agent.memory.dataset_rows(), n,
                                                       torch.empty_like(agent.ds_obs_raw[:n])).cpu().numpy())
+                # the filter walks the next states of the same transitions too (filters/filter.py:314-333)
+                raw.append(agent.memory.gather_next_states(agent.memory.dataset_rows(), n,
+                                                           torch.empty_like(agent.ds_obs_raw[:n])).cpu().numpy())
             res = agent.train()
     agent.networks["main"].check_status()
     np.savez(os.path.join(out_dir, "norm_%d.npz" % rank), raw=np.concatenate(raw),

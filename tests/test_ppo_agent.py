@@ -60,6 +60,11 @@ def test_ppo_iteration_matches_oracle(rlx, dev):
         for name, per_tower in o.net.weights().items():
             for t, ref in per_tower.items():
                 np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
+        if normalize:                            # states + next states of the phase's transitions, fp64 on both sides
+            assert abs(float(agent.norm.count.item()) - o.stats._count) < 1e-9
+            assert abs(o.stats._count - ((it + 1) * 2 * playing + 1e-2)) < 1e-9
+            np.testing.assert_allclose(agent.norm.mean.cpu().numpy(), o.stats._mean, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(agent.norm.std.cpu().numpy(), o.stats._std, rtol=1e-12, atol=1e-12)
     st = agent.episode_statistics()
     assert st["episodes"] == 2 * n_env and st["mean_length"] == L
 
@@ -138,7 +143,7 @@ def test_ppo_advantages_match_oracle_on_c2_shape(rlx, dev):
 def test_continuous_ppo_with_observation_normalization(dev):
     """Mujoco_ClippedPPO-style agent: continuous head, AdditiveNoise sampling from the policy std,
     ObservationNormalizationFilter as pre-network filter.  hipGraph replay must equal eager execution
-    bit for bit; the running statistics must have seen every transition of every rollout once."""
+    bit for bit; the running statistics must have seen the state and the next state of every transition of every rollout once."""
     import random
     import torch
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
@@ -174,7 +179,8 @@ def test_continuous_ppo_with_observation_normalization(dev):
     np.testing.assert_array_equal(ra, rb)
     assert np.isfinite(ra).all()
     assert torch.equal(a.networks["main"].params.weights, b.networks["main"].params.weights)
-    assert abs(float(a.norm.count.item()) - (3 * 64 + 1e-2)) < 1e-9
+    # states AND next states of every transition enter the statistics (InputFilter.filter, filters/filter.py:314-333)
+    assert abs(float(a.norm.count.item()) - (3 * 2 * 64 + 1e-2)) < 1e-9
     ls = a.networks["main"].params.w("main/ppo_head/policy_log_std").cpu().numpy()
     assert np.abs(ls).max() > 0 and np.isfinite(ls).all()           # the log-std variable is being trained
     assert a.actions.dtype == torch.float32 and bool(torch.isfinite(a.actions).all())
@@ -211,11 +217,15 @@ def test_decaying_clip_schedule_reuses_the_captured_graphs(rlx, dev):
 
 
 @pytest.mark.gpu
-def test_continuous_ppo_iteration_matches_oracle(rlx, dev):
+@pytest.mark.parametrize("normalize", [False, True])
+def test_continuous_ppo_iteration_matches_oracle(rlx, dev, normalize):
     """Mujoco_ClippedPPO-style loop (BoxActionSpace, PPOHead mean / std, actions = clip(N(mean, std))) against the oracle
     agent in continuous mode — whose train() is pinned to the REAL reference agent's train on a BoxActionSpace
     (tests/test_update_pins.py, fixture ppoc).  Same host streams: the sampled actions, the per-epoch results and the
-    weights (policy_log_std included) after two iterations."""
+    weights (policy_log_std included) after two iterations.  normalize: with the ObservationNormalizationFilter as
+    pre-network filter — the oracle's loop in that mode is pinned to the REAL reference agent's loop
+    (tests/golden/ppoc_loop.npz): acting on the statistics as they are, the dataset's states pushed and normalised, then
+    its next states pushed; the running statistics are compared after every phase."""
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
     from coach_amd.core_types import EnvironmentSteps
     from coach_amd.environments.synthetic_vector_environment import (
@@ -230,13 +240,14 @@ def test_continuous_ppo_iteration_matches_oracle(rlx, dev):
     ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(playing)
     ap.algorithm.optimization_epochs = epochs
     ap.algorithm.reward_clipping = None
+    ap.algorithm.normalize_observations = normalize
     net = ap.network_wrappers["main"]
     net.batch_size, net.embedder_scheme, net.middleware_scheme = batch, [32], [32]
     agent = ClippedPPOAgent(ap, env, dev)
     assert agent.continuous
     arrays = agent.networks["main"].params.named_arrays()
     o = ClippedPPOAgentOracle(arrays, SynthVecEnv(1, n_env, D, L, 99), A, batch_size=batch, playing_steps=playing,
-                              epochs=epochs, reward_clip=None, continuous=True)
+                              epochs=epochs, reward_clip=None, continuous=True, normalize=normalize)
     o.reset()
     state = (random.getstate(), np.random.get_state())
     for it in range(2):

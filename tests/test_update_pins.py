@@ -489,6 +489,46 @@ def test_oracle_ppo_agent_loop_equals_real_reference_agent_loop(ragged):
     _check_final(fx, "final", o.net, atol=2e-6)
 
 
+def test_oracle_continuous_normalised_ppo_loop_equals_real_reference_agent_loop():
+    """oracle.agents.ClippedPPOAgentOracle(continuous=True, normalize=True) against the REAL reference ClippedPPOAgent on
+    a BoxActionSpace with the Mujoco_ClippedPPO pre-network filter (ObservationNormalizationFilter on numpy running
+    statistics; tests/golden/ppoc_loop.npz): every sampled action (np.random.normal(mean, std) on observations
+    normalised with the statistics as they were), the steps at which training ran, the running statistics after every
+    training phase — count grows by 2 x the dataset: InputFilter.filter pushes the states and then the next states —
+    and the final weights (policy_log_std included)."""
+    import random
+    from oracle.agents import ClippedPPOAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    fx = np.load(os.path.join(HERE, "golden", "ppoc_loop.npz"))
+    D, A, L, B, PLAY, EPOCHS, STEPS, SEED = (int(x) for x in fx["hp"])
+    arrays = {}
+    for k in fx.files:
+        if k.startswith("init|"):
+            _, name, t = k.split("|")
+            arrays.setdefault(name, {})[int(t)] = fx[k]
+    arrays = {n: [tw[t] for t in sorted(tw)] for n, tw in arrays.items()}
+    random.seed(SEED)
+    np.random.seed(SEED)
+    o = ClippedPPOAgentOracle(arrays, SynthVecEnv(1, 1, D, L, 78), A, batch_size=B, playing_steps=PLAY, epochs=EPOCHS,
+                              lr=1e-3, reward_clip=None, continuous=True, normalize=True)
+    o.reset()
+    actions, trained_at, stats, since = [], [], [], 0
+    for step in range(STEPS):
+        a, _ = o.act()
+        actions.append(np.asarray(a[0], dtype=np.float64))
+        since += 1
+        if since >= PLAY and (step + 1) % L == 0:
+            o.train()
+            trained_at.append(step)
+            stats.append(np.concatenate([[o.stats._count], o.stats._mean, o.stats._std]))
+            since = 0
+    np.testing.assert_array_equal(trained_at, fx["trained_at"])
+    np.testing.assert_allclose(np.array(stats), fx["stats"], rtol=1e-12, atol=1e-12)
+    assert abs(fx["stats"][0][0] - (2 * PLAY + 1e-2)) < 1e-9          # states AND next states were pushed
+    np.testing.assert_allclose(np.array(actions), fx["actions"], rtol=0, atol=1e-6)
+    _check_final(fx, "final", o.net, atol=2e-6)
+
+
 def test_product_training_waits_for_a_complete_episode_with_episodic_memory():
     """DDPG-style scheduling: an episodic memory holds only complete episodes (agent.py:576-584), so the
     reference opens no training phase before the first episode has ended; the device agents' host
