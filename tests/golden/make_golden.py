@@ -1498,6 +1498,95 @@ def gen_ppoc_loop():
     _save("ppoc_loop", **out)
 
 
+def gen_ppo_image_loop():
+    """The headline path at loop level: the REAL reference `ClippedPPOAgent` (DiscreteActionSpace) behind the Atari
+    input filter's stateful part — ObservationStackingFilter(4) on uint8 frames and RewardClippingFilter(-1, 1), as
+    Atari_ClippedPPO-style presets configure them (the rescale / grayscale stages are stateless and pinned on their own) —
+    stepped through three rollouts on the synthetic image env: the stack restarts at every episode start (first frame
+    four times), the transitions hold LazyStack states, rewards are clipped on the way into the memory.
+    tests/test_update_pins.py replays oracle.agents.ClippedPPOAgentOracle in image mode."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle.agents import ClippedPPOOracle
+    from oracle.synth_env import SynthVecEnv
+    from rl_coach.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
+    from rl_coach.base_parameters import TaskParameters
+    from rl_coach.core_types import EnvResponse, EnvironmentSteps, RunPhase
+    from rl_coach.filters.filter import InputFilter, NoInputFilter, NoOutputFilter
+    from rl_coach.filters.observation.observation_stacking_filter import ObservationStackingFilter
+    from rl_coach.filters.reward.reward_clipping_filter import RewardClippingFilter
+    from rl_coach.spaces import DiscreteActionSpace, ObservationSpace, RewardSpace, SpacesDefinition, StateSpace
+    H, A, L, B, PLAY, EPOCHS, STEPS, SEED, STACK = 36, 3, 6, 6, 12, 2, 36, 33, 4
+    out = {"hp": np.array([H, A, L, B, PLAY, EPOCHS, STEPS, SEED, STACK])}
+    rng = np.random.RandomState(6)
+    arrays = _rand_arrays(rng, {"main/embedder/conv0": (8 * 8 * STACK, 32, 2), "main/embedder/conv1": (4 * 4 * 32, 64, 2),
+                                "main/embedder/conv2": (3 * 3 * 64, 64, 2), "main/middleware/dense0": (64, 16, 2),
+                                "main/v_head/dense": (16, 1, 1), "main/ppo_head/policy_fc": (16, A, 1)})
+    for k, v in arrays.items():
+        for t, arr in enumerate(v):
+            out["init|%s|%d" % (k, t)] = arr
+    ap = ClippedPPOAgentParameters()
+    ap.task_parameters = TaskParameters()
+    ap.name = "agent"
+    ap.visualization.dump_csv = False
+    ap.is_a_highest_level_agent = False
+    ap.input_filter = InputFilter(is_a_reference_filter=False)
+    ap.input_filter.add_observation_filter('observation', 'stacking', ObservationStackingFilter(STACK))
+    ap.input_filter.add_reward_filter('clipping', RewardClippingFilter(-1.0, 1.0))
+    ap.output_filter, ap.pre_network_filter = NoOutputFilter(), NoInputFilter()
+    ap.network_wrappers['main'].batch_size = B
+    ap.network_wrappers['main'].learning_rate = 1e-3
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(PLAY)
+    ap.algorithm.optimization_epochs = EPOCHS
+    holder = {}
+
+    class Agent(ClippedPPOAgent):
+        def create_networks(self):
+            net = ClippedPPOOracle(copy.deepcopy(arrays), (H, H, STACK), A, lr=1e-3,
+                                   clip_eps=self.ap.algorithm.clip_likelihood_ratio_using_epsilon,
+                                   beta_entropy=self.ap.algorithm.beta_entropy)
+            holder["net"] = net
+            w = OB.PPOWrapper(net)
+            w.has_target = True
+            return {'main': w}
+    agent = Agent(ap)
+    agent.set_environment_parameters(SpacesDefinition(
+        state=StateSpace({'observation': ObservationSpace(np.array([H, H]), low=0, high=255)}), goal=None,
+        action=DiscreteActionSpace(A), reward=RewardSpace(1)))
+    agent.update_log = lambda: None
+    env = SynthVecEnv(0, 1, H * H, L, 79)
+    frame = lambda flat: np.asarray(flat, dtype=np.uint8).reshape(H, H).copy()
+    random.seed(SEED)
+    np.random.seed(SEED)
+    actions, trained_at, rewards = [], [], []
+    resp = EnvResponse(next_state={'observation': frame(env.reset()[0])}, reward=0, game_over=False)
+    agent.reset_internal_state()
+    agent.phase = RunPhase.TRAIN
+    reset_required, first = False, None
+    for step in range(STEPS):
+        if reset_required:
+            agent.reset_internal_state()
+            resp = EnvResponse(next_state={'observation': frame(first)}, reward=0, game_over=False)
+            reset_required = False
+        agent.observe(resp)
+        actions.append(int(agent.act().action))
+        nxt, rst, rew, done = env.step()
+        rewards.append(float(rew[0]))
+        resp = EnvResponse(next_state={'observation': frame(nxt[0])}, reward=float(rew[0]), game_over=bool(done[0]))
+        if resp.game_over:
+            agent.observe(resp)
+            agent.handle_episode_ended()
+            reset_required, first = True, rst[0]
+        before = agent.training_iteration
+        agent.train()
+        if agent.training_iteration != before:
+            trained_at.append(step)
+    out["actions"], out["trained_at"], out["env_rewards"] = np.array(actions), np.array(trained_at), np.array(rewards)
+    _flat("final", holder["net"].weights(), out)
+    _save("ppo_image_loop", **out)
+
+
 def gen_csv_columns():
     """What Agent.update_log (agent.py:509-556) writes: the CSV column list of the REAL reference DQNAgent (own
     __init__, registered signals) after one update_log call, the values of the statistics columns for known
@@ -1569,7 +1658,7 @@ def gen_csv_columns():
 
 
 GROUPS = {"csv_columns": gen_csv_columns, "per": gen_per, "er": gen_er, "episodic": gen_episodic, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop, "sac_loop": gen_sac_loop, "ppoc_loop": gen_ppoc_loop}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop, "sac_loop": gen_sac_loop, "ppoc_loop": gen_ppoc_loop, "ppo_image_loop": gen_ppo_image_loop}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

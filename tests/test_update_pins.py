@@ -529,6 +529,44 @@ def test_oracle_continuous_normalised_ppo_loop_equals_real_reference_agent_loop(
     _check_final(fx, "final", o.net, atol=2e-6)
 
 
+def test_oracle_image_ppo_loop_with_stacking_and_reward_clipping_equals_real_reference_agent_loop():
+    """The headline path at loop level: oracle.agents.ClippedPPOAgentOracle in image mode (StackingOracle per env, reward
+    clipping) against the REAL reference ClippedPPOAgent behind ObservationStackingFilter(4) + RewardClippingFilter(-1, 1)
+    on uint8 frames (tests/golden/ppo_image_loop.npz): the stack restarts at every episode start, transitions hold the
+    stacked states, rewards are clipped before they are stored — every sampled action, the training steps and the final
+    weights of the conv torso and both heads.  The device agent is compared with this oracle mode on the GPU
+    (tests/test_ppo_agent.py), which chains the C2 path to the reference agent itself."""
+    import random
+    from oracle.agents import ClippedPPOAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    fx = np.load(os.path.join(HERE, "golden", "ppo_image_loop.npz"))
+    H, A, L, B, PLAY, EPOCHS, STEPS, SEED, STACK = (int(x) for x in fx["hp"])
+    arrays = {}
+    for k in fx.files:
+        if k.startswith("init|"):
+            _, name, t = k.split("|")
+            arrays.setdefault(name, {})[int(t)] = fx[k]
+    arrays = {n: [tw[t] for t in sorted(tw)] for n, tw in arrays.items()}
+    random.seed(SEED)
+    np.random.seed(SEED)
+    o = ClippedPPOAgentOracle(arrays, SynthVecEnv(0, 1, H * H, L, 79), A, stack=STACK, batch_size=B, playing_steps=PLAY,
+                              epochs=EPOCHS, lr=1e-3, reward_clip=(-1.0, 1.0))
+    o.reset(frame_hw=(H, H))
+    actions, trained_at, since = [], [], 0
+    for step in range(STEPS):
+        a, _ = o.act()
+        actions.append(int(a[0]))
+        since += 1
+        if since >= PLAY and (step + 1) % L == 0:
+            o.train()
+            trained_at.append(step)
+            since = 0
+    assert np.abs(fx["env_rewards"]).max() >= 1.0 and len(set(fx["env_rewards"].tolist())) > 1
+    np.testing.assert_array_equal(actions, fx["actions"])
+    np.testing.assert_array_equal(trained_at, fx["trained_at"])
+    _check_final(fx, "final", o.net, atol=2e-6)
+
+
 def test_product_training_waits_for_a_complete_episode_with_episodic_memory():
     """DDPG-style scheduling: an episodic memory holds only complete episodes (agent.py:576-584), so the
     reference opens no training phase before the first episode has ended; the device agents' host
