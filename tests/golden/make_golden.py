@@ -1587,6 +1587,107 @@ def gen_ppo_image_loop():
     _save("ppo_image_loop", **out)
 
 
+def gen_dqn_image_loop():
+    """C3 at loop level: the REAL reference `DQNAgent` with PrioritizedExperienceReplay behind ObservationStackingFilter(4)
+    + RewardClippingFilter(-1, 1) on uint8 frames (the stateful part of the Atari input filter), heat-up then training with
+    a wrapping buffer, on the synthetic image env.  Stores every action, the transitions visible at every train(), a key
+    of every sampled transition (sum of its stacked state) and the final weights; tests/test_update_pins.py replays
+    oracle.agents.DQNAgentOracle in image mode (reference_order = True)."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import _oracle_backend as OB
+    from oracle.agents import DQNOracle
+    from oracle.synth_env import SynthVecEnv
+    from rl_coach.agents.dqn_agent import DQNAgent, DQNAgentParameters
+    from rl_coach.base_parameters import TaskParameters
+    from rl_coach.core_types import EnvResponse, EnvironmentSteps, RunPhase
+    from rl_coach.filters.filter import InputFilter, NoInputFilter, NoOutputFilter
+    from rl_coach.filters.observation.observation_stacking_filter import ObservationStackingFilter
+    from rl_coach.filters.reward.reward_clipping_filter import RewardClippingFilter
+    from rl_coach.memories.non_episodic.prioritized_experience_replay import PrioritizedExperienceReplayParameters
+    from rl_coach.schedules import LinearSchedule
+    from rl_coach.spaces import DiscreteActionSpace, ObservationSpace, RewardSpace, SpacesDefinition, StateSpace
+    H, A, L, B, CAP, HEATUP, TRAIN, SEED, STACK = 36, 3, 7, 6, 32, 10, 60, 41, 4
+    out = {"hp": np.array([H, A, L, B, CAP, HEATUP, TRAIN, SEED, STACK])}
+    rng = np.random.RandomState(8)
+    arrays = _rand_arrays(rng, {"main/embedder/conv0": (8 * 8 * STACK, 32, 1), "main/embedder/conv1": (4 * 4 * 32, 64, 1),
+                                "main/embedder/conv2": (3 * 3 * 64, 64, 1), "main/middleware/dense0": (64, 16, 1),
+                                "main/q_head/dense": (16, A, 1)})
+    for k, v in arrays.items():
+        out["init|%s|0" % k] = v[0]
+    frame = lambda flat: np.asarray(flat, dtype=np.uint8).reshape(H, H).copy()
+    for variant in ("uniform", "per"):
+        ap = DQNAgentParameters()
+        ap.task_parameters = TaskParameters()
+        ap.name = "agent"
+        ap.visualization.dump_csv = False
+        ap.is_a_highest_level_agent = False
+        ap.input_filter = InputFilter(is_a_reference_filter=False)
+        ap.input_filter.add_observation_filter('observation', 'stacking', ObservationStackingFilter(STACK))
+        ap.input_filter.add_reward_filter('clipping', RewardClippingFilter(-1.0, 1.0))
+        ap.output_filter, ap.pre_network_filter = NoOutputFilter(), NoInputFilter()
+        if variant == "per":
+            ap.memory = PrioritizedExperienceReplayParameters()           # alpha .6, constant beta .4
+        ap.network_wrappers['main'].batch_size = B
+        ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(1)
+        ap.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(10)
+        ap.memory.max_size = (MemoryGranularity.Transitions, CAP)
+        ap.exploration.epsilon_schedule = LinearSchedule(1.0, 0.1, 40)
+        holder = {}
+
+        class Agent(DQNAgent):
+            def create_networks(self):
+                net = DQNOracle(copy.deepcopy(arrays), (H, H, STACK), A, lr=1e-3, huber=True)
+                holder["net"] = net
+                w = OB.DQNWrapper(net)
+                w.has_target = True
+                w.set_is_training = lambda s: None
+                w.update_target_network = lambda rate=1.0: net.update_target(rate)
+                for n in (w.online_network, w.target_network):
+                    n.reset_internal_memory = lambda: None
+                return {'main': w}
+        agent = Agent(ap)
+        agent.set_environment_parameters(SpacesDefinition(
+            state=StateSpace({'observation': ObservationSpace(np.array([H, H]), low=0, high=255)}), goal=None,
+            action=DiscreteActionSpace(A), reward=RewardSpace(1)))
+        env = SynthVecEnv(0, 1, H * H, L, 80)
+        random.seed(SEED)
+        np.random.seed(SEED)
+        agent.exploration_policy.current_random_value = np.random.rand()      # e_greedy.py:82, after seeding
+        actions, visible, keys = [], [], []
+        sample = agent.memory.sample
+
+        def logged_sample(size):
+            b = sample(size)
+            keys.append([float(np.asarray(t.state['observation'], dtype=np.float64).sum()) for t in b])
+            visible.append(agent.memory.num_transitions())
+            return b
+        agent.memory.sample = logged_sample
+        resp = EnvResponse(next_state={'observation': frame(env.reset()[0])}, reward=0, game_over=False)
+        agent.reset_internal_state()
+        reset_required, first = False, None
+        for step in range(HEATUP + TRAIN):
+            agent.phase = RunPhase.HEATUP if step < HEATUP else RunPhase.TRAIN
+            if reset_required:
+                agent.reset_internal_state()
+                resp = EnvResponse(next_state={'observation': frame(first)}, reward=0, game_over=False)
+                reset_required = False
+            agent.observe(resp)
+            actions.append(int(agent.act().action))
+            nxt, rst, rew, done = env.step()
+            resp = EnvResponse(next_state={'observation': frame(nxt[0])}, reward=float(rew[0]), game_over=bool(done[0]))
+            if resp.game_over:
+                agent.observe(resp)
+                agent.handle_episode_ended()
+                reset_required, first = True, rst[0]
+            if step >= HEATUP:
+                agent.train()
+        out[variant + "|actions"], out[variant + "|visible"] = np.array(actions), np.array(visible)
+        out[variant + "|keys"] = np.array(keys)
+        _flat(variant + "|final", holder["net"].weights(), out)
+    _save("dqn_image_loop", **out)
+
+
 def gen_csv_columns():
     """What Agent.update_log (agent.py:509-556) writes: the CSV column list of the REAL reference DQNAgent (own
     __init__, registered signals) after one update_log call, the values of the statistics columns for known
@@ -1658,7 +1759,7 @@ def gen_csv_columns():
 
 
 GROUPS = {"csv_columns": gen_csv_columns, "per": gen_per, "er": gen_er, "episodic": gen_episodic, "stack": gen_stack, "filters": gen_filters, "gae": gen_gae,
-          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop, "sac_loop": gen_sac_loop, "ppoc_loop": gen_ppoc_loop, "ppo_image_loop": gen_ppo_image_loop}
+          "targets": gen_targets, "explore": gen_explore, "updates": gen_updates, "ppo_update": gen_ppo_update, "cadence": gen_cadence, "defaults": gen_defaults, "presets": gen_presets, "loop": gen_loop, "ppo_loop": gen_ppo_loop, "td3_loop": gen_td3_loop, "ddpg_loop": gen_ddpg_loop, "sac_loop": gen_sac_loop, "ppoc_loop": gen_ppoc_loop, "ppo_image_loop": gen_ppo_image_loop, "dqn_image_loop": gen_dqn_image_loop}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

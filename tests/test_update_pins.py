@@ -450,6 +450,48 @@ def test_oracle_agent_loop_equals_real_reference_agent_loop(variant):
     assert max(visible) == CAP                                   # the buffer did wrap
 
 
+@pytest.mark.parametrize("variant", ["uniform", "per"])
+def test_oracle_image_dqn_loop_with_stacking_equals_real_reference_agent_loop(variant):
+    """C3 at loop level: oracle.agents.DQNAgentOracle in image mode (StackingOracle, reward clipping, Huber loss, the
+    reference's store order) against the REAL reference DQNAgent behind ObservationStackingFilter(4) +
+    RewardClippingFilter(-1, 1) on uint8 frames, uniform and prioritized replay with a wrapping 32-transition buffer
+    (tests/golden/dqn_image_loop.npz): every action, the transitions visible at every train(), every sampled transition
+    (keyed by the sum of its stacked state) and the final conv / dense weights."""
+    import random
+    from coach_amd.schedules import LinearSchedule
+    from oracle.agents import DQNAgentOracle
+    from oracle.synth_env import SynthVecEnv
+    fx = np.load(os.path.join(HERE, "golden", "dqn_image_loop.npz"))
+    H, A, L, B, CAP, HEATUP, TRAIN, SEED, STACK = (int(x) for x in fx["hp"])
+    arrays = {k.split("|")[1]: [fx[k]] for k in fx.files if k.startswith("init|")}
+    random.seed(SEED)
+    np.random.seed(SEED)
+    o = DQNAgentOracle(arrays, SynthVecEnv(0, 1, H * H, L, 80), A, (H, H, STACK), stack=STACK, capacity=CAP,
+                       per={} if variant == "per" else None, batch_size=B, playing_steps=1, target_every=10, huber=True,
+                       lr=1e-3, epsilon_schedule=LinearSchedule(1.0, 0.1, 40), reward_clip=(-1.0, 1.0))
+    o.reference_order = True
+    o.reset(frame_hw=(H, H))
+    actions, visible, keys = [], [], []
+    collate = o._collate
+
+    def logged(d, B_):
+        out = collate(d, B_)
+        keys.append([float(np.asarray(s_, dtype=np.float64).sum()) for s_ in out[0][0]])
+        visible.append(o._num_transitions())
+        return out
+    o._collate = logged
+    for step in range(HEATUP + TRAIN):
+        a = o.heatup_step() if step < HEATUP else o.act()
+        actions.append(int(a[0]))
+        if step >= HEATUP:
+            o.train()
+    np.testing.assert_array_equal(visible, fx[variant + "|visible"])
+    assert max(visible) == CAP                                   # the buffer did wrap
+    np.testing.assert_array_equal(actions, fx[variant + "|actions"])
+    np.testing.assert_array_equal(np.array(keys), fx[variant + "|keys"])
+    _check_final(fx, variant + "|final", o.net, atol=2e-6)
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_oracle_ppo_agent_loop_equals_real_reference_agent_loop(ragged):
     """oracle.agents.ClippedPPOAgentOracle (act + train, n_env = 1) against the REAL reference
