@@ -488,6 +488,24 @@ def gen_explore():
         acts.append(pol.get_action(q[i])[0])
     out["eg_q"], out["eg_actions"], out["eg_eps"] = q, np.array(acts), np.array(eps)
     out["eg_explore_u"], out["eg_rand_act"], out["eg_tie"] = np.array(explore_u), np.array(rand_act), np.array(tie)
+    # ... then an evaluation: phase TEST uses evaluation_epsilon, the schedule stands still, the draws go on
+    pol.change_phase(RunPhase.TEST)
+    q2 = np.random.RandomState(88).randn(80, A).astype(np.float32)     # (own stream: the fixtures below keep their values)
+    acts, eps, explore_u, rand_act, tie = [], [], [], [], []
+    for i in range(80):
+        e = pol.get_control_param()
+        eps.append(e); explore_u.append(pol.current_random_value)
+        st = np.random.get_state()
+        if pol.current_random_value < e:
+            rand_act.append(np.random.choice(A)); tie.append(np.zeros(A))
+        else:
+            rand_act.append(-1); tie.append(np.random.random(A))
+        np.random.set_state(st)
+        acts.append(pol.get_action(q2[i])[0])
+    out["egt_q"], out["egt_actions"], out["egt_eps"] = q2, np.array(acts), np.array(eps)
+    out["egt_explore_u"], out["egt_rand_act"], out["egt_tie"] = np.array(explore_u), np.array(rand_act), np.array(tie)
+    pol.change_phase(RunPhase.TRAIN)
+    out["egt_schedule_after"] = np.float64(pol.epsilon_schedule.current_value)
     # --- additive gaussian noise (continuous)
     D = 6
     space = BoxActionSpace(D, -1.0, 1.0)

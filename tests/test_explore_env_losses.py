@@ -48,6 +48,23 @@ def test_product_egreedy_host_draws_match_reference(golden):
             assert np.array_equal(tie[0], g["eg_tie"][i]), i
         acts.append(E.egreedy_choice(g["eg_q"][i], u[0], ra[0], tie[0], eps))
     assert acts == g["eg_actions"].tolist()
+    # an evaluation right after: phase TEST acts with evaluation_epsilon, the schedule stands still (step_epsilon,
+    # e_greedy.py:112-117), the explore / tie-break draws go on from the same stream
+    pol.phase = RunPhase.TEST
+    acts = []
+    for i in range(len(g["egt_q"])):
+        eps, u, ra, tie = pol.draw()
+        eps = float(eps[0])
+        assert eps == 0.05 == g["egt_eps"][i] and u[0] == g["egt_explore_u"][i], i
+        if u[0] < eps:
+            assert ra[0] == g["egt_rand_act"][i], i
+        else:
+            assert np.array_equal(tie[0], g["egt_tie"][i]), i
+        acts.append(E.egreedy_choice(g["egt_q"][i], u[0], ra[0], tie[0], eps))
+    assert acts == g["egt_actions"].tolist()
+    assert (g["egt_explore_u"] < 0.05).sum() > 0                      # the evaluation did explore a few times
+    pol.phase = RunPhase.TRAIN
+    assert pol.epsilon_schedule.current_value == float(g["egt_schedule_after"])      # untouched by the evaluation
 
 
 def test_product_ou_process_host_noise_matches_reference(golden):
