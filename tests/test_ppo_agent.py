@@ -60,11 +60,6 @@ def test_ppo_iteration_matches_oracle(rlx, dev):
         for name, per_tower in o.net.weights().items():
             for t, ref in per_tower.items():
                 np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
-        if normalize:                            # states + next states of the phase's transitions, fp64 on both sides
-            assert abs(float(agent.norm.count.item()) - o.stats._count) < 1e-9
-            assert abs(o.stats._count - ((it + 1) * 2 * playing + 1e-2)) < 1e-9
-            np.testing.assert_allclose(agent.norm.mean.cpu().numpy(), o.stats._mean, rtol=1e-12, atol=1e-12)
-            np.testing.assert_allclose(agent.norm.std.cpu().numpy(), o.stats._std, rtol=1e-12, atol=1e-12)
     st = agent.episode_statistics()
     assert st["episodes"] == 2 * n_env and st["mean_length"] == L
 
@@ -274,3 +269,8 @@ def test_continuous_ppo_iteration_matches_oracle(rlx, dev, normalize):
         for name, per_tower in o.net.weights().items():
             for t, ref in per_tower.items():
                 np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
+        if normalize:                            # states + next states of the phase's transitions, fp64 on both sides
+            assert abs(float(agent.norm.count.item()) - o.stats._count) < 1e-9
+            assert abs(o.stats._count - ((it + 1) * 2 * playing + 1e-2)) < 1e-9
+            np.testing.assert_allclose(agent.norm.mean.cpu().numpy(), o.stats._mean, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(agent.norm.std.cpu().numpy(), o.stats._std, rtol=1e-12, atol=1e-12)

@@ -3,8 +3,6 @@ ObservationStackingFilter(4) + RewardClippingFilter(-1, 1) on uint8 frames (test
 tests/golden/make_golden.py::gen_ppo_image_loop / gen_dqn_image_loop) — no oracle in between, like
 tests/test_reference_loop.py does for the vector-observation DQN / TD3 / DDPG / SAC loops.
 
-Written after round 2's GPU budget was spent: NOT yet run on a device, therefore parked here instead of tests/.
-`pytest tools/gpu_calls/next_round_tests -m gpu` (tools/gpu_calls/next_round_ab.sh does it); move into tests/ once green.
 """
 import os
 import random
@@ -13,18 +11,9 @@ import sys
 import numpy as np
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(scope="module")
-def dev():
-    import torch
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    return torch.device("cuda:0")
 
 
 def _load_init(fx, params, dev):
