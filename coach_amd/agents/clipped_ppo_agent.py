@@ -146,7 +146,9 @@ class ClippedPPOAgent(object):
             (lens is None or getattr(environment, "lengths", None) is not None)     # per-env limits were declared
         if self.ragged:
             longest = int(max(lens)) if lens is not None else int(self.L)
-            self.steps_per_phase = per_env + longest
+            # + the episode that overshoots the phase; envs whose episode length is DATA (no declared lengths) may also
+            # lose open episodes to forced resets between two training phases (evaluation periods): room for three
+            self.steps_per_phase = per_env + longest * (1 if lens is not None else 4)
         self.memory = DeviceEpisodicRolloutBuffer(
             self.device, self.n_env, self.steps_per_phase,
             frame_shape=ep.observation_shape if self.image else None, stack=self.stack,
@@ -178,6 +180,8 @@ class ClippedPPOAgent(object):
         self.signals = {}
         self._graphs = {}
         self._warm = set()
+        self._episode_steps = np.zeros(self.n_env, dtype=np.int64)
+        self._episode_just_ended = False
         self._alloc_training_buffers()
         self.memory.reset(self.env.reset_internal_state())
 
@@ -270,7 +274,7 @@ class ClippedPPOAgent(object):
                 self.lib.categorical_sample(probs, self.A, self.uniforms_all[0 if self.ragged else step], self.n_env, self.A,
                                             self.actions, s)                # categorical.py:45-48
             else:
-                self.actions.copy_(probs.argmax(dim=1).to(torch.int32))     # :50-56
+                self.lib.argmax_rows(probs, self.A, self.n_env, self.A, self.actions, s)     # :50-56
         if self._device_env:
             # device-resident env: the launch is part of the (captured) step, its host clock ticks in act()
             self.env.launch_step()
@@ -310,10 +314,87 @@ class ClippedPPOAgent(object):
             self._act_device(step)            # CPU emulators behind the env: not a pure device step, never captured
         self.memory.steps += 1
         if self.ragged:
-            self.memory.note_episode_ends(self.env.dones_host)
+            dones = self.env.dones_host
+            self.memory.note_episode_ends(dones)
+            self._episode_steps += 1
+            ended = np.nonzero(dones)[0]
+            self._episode_just_ended = ended.size > 0
+            if ended.size:
+                self.ended_episode_lengths = self._episode_steps[ended].copy()
+                self._episode_steps[ended] = 0
+        else:
+            self._episode_just_ended = self.memory.steps % self.L == 0
+            self.ended_episode_lengths = np.full(self.n_env, self.L, dtype=np.int64)
         self.env.total_steps += self.n_env
         self.total_steps_counter += self.n_env
         return self.n_env
+
+    # ----------------------------------------------------------------------- resets / evaluation
+    def reset_internal_state(self):
+        """GraphManager.reset_internal_state(force_environment_reset=True) + Agent.reset_internal_state
+        (graph_manager.py:411-424, agent.py:603-629): every env starts a new episode now; the running episodes were
+        held in current_episode_buffer and never reach the memory."""
+        if self.image and self.memory.steps > 0:
+            raise NotImplementedError("a forced reset in the middle of an image rollout would restart the frame ring")
+        self.memory.drop_open_episodes()
+        self._episode_steps[:] = 0
+        self._episode_just_ended = False
+        self.lib.episode_stats_init(self.ep_return, self.ep_len, self.n_env, None, _rlx.current_stream())
+        first = self.env.reset_internal_state()
+        self.memory.reset(first)
+        return first
+
+    def evaluate_episodes(self, episodes_per_env=1):
+        """GraphManager.evaluate (graph_manager.py:491-523) for the env vector: every env is reset, whole episodes are
+        played in TEST phase — the most probable action (categorical.py:50-56) / the policy mean
+        (additive_noise.py:99-106), observations through the pre-network filter WITHOUT updating its statistics
+        (clipped_ppo_agent.py:346-350) — nothing is stored, no counter of the training schedule moves; training
+        resumes from a fresh reset.  Returns the mean undiscounted episode reward over envs."""
+        if self.image:
+            raise NotImplementedError("evaluation episodes need a scratch frame stack: vector observations only")
+        prev, prev_env = self.phase, getattr(self.env, "phase", None)
+        self.phase = self.env.phase = RunPhase.TEST
+        s = _rlx.current_stream()
+        n, dev = self.n_env, self.device
+        self.memory.drop_open_episodes()
+        state = self.env.reset_internal_state().clone()
+        total = torch.zeros(n, dtype=torch.float64, device=dev)
+        finished = np.zeros(n, dtype=np.int64)
+        lockstep_t = 0
+        try:
+            while (finished < episodes_per_env).any():
+                states = state
+                if self.norm is not None:
+                    states = self.norm.filter(state, update_internal_state=False, out=self.act_obs)
+                if self.continuous:
+                    mean, _ = self.networks["main"].policy_mean_std(states, n)
+                    self.actions.copy_(mean)
+                else:
+                    probs = self.networks["main"].policy_probs(states, n)
+                    self.lib.argmax_rows(probs, self.A, n, self.A, self.actions, s)
+                next_obs, reset_obs, reward, game_over = self.env.step(self.actions)
+                self.env.total_steps += n
+                active = finished < episodes_per_env
+                total += reward.double() if active.all() else \
+                    reward.double() * torch.from_numpy(active.astype(np.float64)).to(dev)
+                dh = getattr(self.env, "dones_host", None)
+                if dh is None:                                   # lockstep synthetic envs: all end after L steps
+                    lockstep_t += 1
+                    dh = np.full(n, lockstep_t % self.L == 0)
+                finished += dh.astype(np.int64)
+                state.copy_(next_obs)
+                ended = np.nonzero(dh)[0]
+                if ended.size:
+                    idx = torch.from_numpy(ended).to(dev)
+                    state.index_copy_(0, idx, reset_obs.index_select(0, idx))
+        finally:
+            self.phase = prev
+            self.env.phase = prev_env if prev_env is not None else prev
+            self._episode_steps[:] = 0
+            self._episode_just_ended = False
+            self.lib.episode_stats_init(self.ep_return, self.ep_len, n, None, s)
+            self.memory.reset(self.env.reset_internal_state())
+        return float(total.mean().item()) / episodes_per_env
 
     # ------------------------------------------------------------------------------- training
     def _should_train(self):

@@ -445,7 +445,8 @@ class VectorOffPolicyAgent(GraphRunner):
         evaluation episode ended, so reset_required is set).  The memory is not touched: evaluation
         frames go to a scratch stack (memory.begin_evaluation).  Returns the mean undiscounted episode
         reward over envs."""
-        prev = self.phase
+        prev, prev_env = self.phase, getattr(self.env, "phase", None)
+        self.env.phase = RunPhase.TEST           # GraphManager.phase setter: the environment follows (graph_manager.py:333-344)
         first = self.reset_internal_state()
         self.memory.begin_evaluation(first)
         self.phase = RunPhase.TEST
@@ -463,6 +464,7 @@ class VectorOffPolicyAgent(GraphRunner):
                 finished += (dh if dh is not None else np.full(self.n_env, self._episode_just_ended)).astype(np.int64)
         finally:
             self.phase = prev
+            self.env.phase = prev_env if prev_env is not None else prev
             self.current_episode_steps_counter = 0
             self._episode_steps[:] = 0
             self._unconsumed_episode_lengths = []

@@ -98,8 +98,10 @@ def resolve_reference_style(agent_params, env_params):
                 alg.reward_clipping = (float(f.clipping_low), float(f.clipping_high))
             else:
                 raise ValueError("reward filter {!r} has no device implementation".format(f))
-    elif getattr(env_params, "is_atari", False):
-        alg.reward_clipping = (-1.0, 1.0)
+    elif hasattr(env_params, "is_atari") and hasattr(alg, "reward_clipping"):
+        # the level's default input filter: the Atari chain clips, GymVectorEnvironment has none
+        # (gym_environment.py:76-81,106-113)
+        alg.reward_clipping = (-1.0, 1.0) if env_params.is_atari else None
     pre = getattr(agent_params, "pre_network_filter", None)
     if pre is not None and hasattr(pre, "_observation_filters"):
         for d in pre._observation_filters.values():

@@ -88,9 +88,32 @@ __global__ void gaussian_action_kernel(const float *__restrict__ mean, const flo
     out[t] = (float)v;
 }
 
+// np.argmax per row: the FIRST maximal entry (Categorical.get_action outside TRAIN, categorical.py:50-52)
+__global__ void argmax_rows_kernel(const float *__restrict__ v, long long ld, int n_rows, int n_cols, int *out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rows) return;
+    const float *r = v + (size_t)e * ld;
+    int best = 0;
+    float bv = r[0];
+    for (int a = 1; a < n_cols; ++a)
+        if (r[a] > bv) {
+            bv = r[a];
+            best = a;
+        }
+    out[e] = best;
+}
+
 }  // namespace
 
 extern "C" {
+
+int rlx_argmax_rows(const float *values, long long ld, int n_rows, int n_cols, int *out, void *stream) {
+    RLX_REQUIRE(values && out, "rlx_argmax_rows: null pointer");
+    RLX_REQUIRE(n_rows > 0 && n_cols > 0 && ld >= n_cols, "rlx_argmax_rows: bad shape");
+    argmax_rows_kernel<<<(n_rows + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(values, ld, n_rows, n_cols, out);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
 
 int rlx_categorical_sample(const float *probs, long long ld, const double *uniforms, int n_env,
                            int n_actions, int *actions, void *stream) {

@@ -5,7 +5,8 @@ atari_deterministic_v4, atari_schedule :84-145).
 gym, ALE and MuJoCo cannot be installed in this image (no network), so `create(...)` resolves a level to its
 SPACES — observation shape, action space, episode time limit, as gym registers them — and builds the
 device-resident synthetic environment with those spaces (coach_amd/environments/synthetic_vector_environment.py;
-SURVEY.md §8(d) "synthetic fixed-length episodes").  The agent, memory, filter and schedule side of a preset is
+SURVEY.md §8(d) "synthetic fixed-length episodes") — except CartPole-v0 / -v1, whose simulator is restated on the device
+(coach_amd/environments/cartpole_vector_environment.py, gym 0.12.5's physics bit for bit).  The agent, memory, filter and schedule side of a preset is
 exactly what would run against the real simulator; swapping the simulator in is the (f)3 front end
 (coach_amd/environments/emulator_frontend.py) once gym exists.  An unknown level raises instead of guessing.
 """
@@ -118,6 +119,14 @@ def vector_parameters(env_params):
 
 
 def create(env_params, device, rank=0):
-    """The `path` target of the parameter classes above: build the environment of a preset on `device`."""
+    """The `path` target of the parameter classes above: build the environment of a preset on `device`.  CartPole is
+    the one level whose simulator exists on the device (csrc/cartpole.hip); every other level gets the synthetic
+    environment with the level's spaces."""
     from .synthetic_vector_environment import SyntheticVectorEnvironment
+    name = env_params.level_name()
+    if name in ('CartPole-v0', 'CartPole-v1') and not getattr(env_params, "synthetic", False):
+        from .cartpole_vector_environment import CartPoleVectorEnvironment, CartPoleVectorEnvironmentParameters
+        return CartPoleVectorEnvironment(
+            CartPoleVectorEnvironmentParameters(env_params.num_envs, name, env_params.seed, env_params.episode_length),
+            device, rank=rank)
     return SyntheticVectorEnvironment(vector_parameters(env_params), device, rank=rank)

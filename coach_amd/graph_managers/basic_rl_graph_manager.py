@@ -81,6 +81,7 @@ class BasicRLGraphManager(object):
         self.training_steps = 0
         self.phase = RunPhase.UNDEFINED
         self._episodes_logged = 0
+        self._mid_episode = False        # some env is inside an episode that the next period must abandon
 
     # ------------------------------------------------------------------ graph creation (:62-78)
     def create_graph(self):
@@ -100,8 +101,10 @@ class BasicRLGraphManager(object):
             self.create_graph()
 
     def _set_phase(self, phase):
+        """GraphManager.phase setter (graph_manager.py:333-344): the level managers AND the environments follow."""
         self.phase = phase
         self.agent.phase = phase
+        self.environment.phase = phase
 
     # --------------------------------------------------------------------------------- stepping
     def _act(self):
@@ -156,6 +159,24 @@ class BasicRLGraphManager(object):
             self.logger.write(**row)
         agent._target_updated_since_log = False
 
+    def _episodes_ended_on_last_step(self):
+        """how many envs finished an episode on the vector step just taken (each is one EnvironmentEpisodes unit)."""
+        agent = self.agent
+        if not getattr(agent, "_episode_just_ended", False):
+            return 0
+        ended = getattr(agent, "ended_episode_lengths", None)
+        return len(ended) if ended is not None else agent.n_env
+
+    def _fresh_episodes(self):
+        """reset_internal_state(force_environment_reset=True) at the start of a period (graph_manager.py:411-424,
+        477) unless every env stands at the first step of an episode already (the reset that closes an evaluation,
+        or nothing played yet): the running episodes are abandoned, their last response is never observed."""
+        if self._mid_episode and hasattr(self.agent, "reset_internal_state"):
+            first = self.agent.reset_internal_state()
+            if hasattr(self.agent.memory, "reset"):
+                self.agent.memory.reset(first)
+        self._mid_episode = False
+
     def heatup(self, steps):                                                   # :400-424
         self.verify_graph_was_created()
         if steps.num_steps > 0:
@@ -163,16 +184,36 @@ class BasicRLGraphManager(object):
             done = 0
             while done < steps.num_steps:
                 done += self._act()
+            self._mid_episode = self._episodes_ended_on_last_step() != self.agent.n_env
 
     def train_and_act(self, steps):                                            # :463-489
+        """act + train until `steps` have passed, in the unit `steps` is given in (current_step_counter[type(steps)],
+        graph_manager.py:436,479): environment steps, finished episodes (each env's episode counts) or training
+        iterations.  Off-policy agents that offer it take the one-record / one-graph step (DQN step_and_train) — the
+        same call order, host draws and kernels as act() followed by train()."""
         self.verify_graph_was_created()
+        if steps.num_steps <= 0:
+            return
         self._set_phase(RunPhase.TRAIN)
+        self._fresh_episodes()
+        agent = self.agent
+        fused = getattr(agent, "step_and_train", None)
         done = 0
         while done < steps.num_steps:
-            done += self._act()
-            before = self.agent.training_iteration
-            self.agent.train()
-            self.training_steps += self.agent.training_iteration - before
+            before = agent.training_iteration
+            if fused is not None and agent._step_graph_ok():
+                fused()
+                n = agent.n_env
+                self.total_steps_counters[self.phase] += n
+                self._log_finished_episodes()
+            else:
+                n = self._act()
+                agent.train()
+            trained = agent.training_iteration - before
+            self.training_steps += trained
+            done += n if isinstance(steps, EnvironmentSteps) else \
+                self._episodes_ended_on_last_step() if isinstance(steps, EnvironmentEpisodes) else trained
+        self._mid_episode = self._episodes_ended_on_last_step() != agent.n_env
 
     def evaluate(self, steps):                                                 # :491-523
         """Act greedily for `steps` episodes per env without storing or training; returns the mean
@@ -182,14 +223,60 @@ class BasicRLGraphManager(object):
             return None
         self._set_phase(RunPhase.TEST)
         before = self.environment.total_steps
-        reward = self.agent.evaluate_episodes(steps.num_steps)
+        episodes = steps.num_steps if isinstance(steps, EnvironmentEpisodes) else \
+            max(1, -(-steps.num_steps // (self.agent.n_env * self.agent.L)))   # "at least `steps`", whole episodes
+        reward = self.agent.evaluate_episodes(episodes)
+        self._mid_episode = False                        # evaluate_episodes leaves every env freshly reset
         self.total_steps_counters[RunPhase.TEST] += self.environment.total_steps - before
         self.logger.write(**{"Episode #": self._episodes_logged, "Training Iter": self.agent.training_iteration,
                              "Epoch": 0, "In Heatup": 0, "Total steps": self.agent.total_steps_counter,
                              "Evaluation Reward": reward, "Shaped Evaluation Reward": reward})
+        self._set_phase(RunPhase.TRAIN)
         return reward
 
-    def improve(self):                                                         # :525-556
+    # ---------------------------------------------------------------- golden-threshold harness
+    def validation_status(self, win_size=10):
+        """What rl_coach/tests/test_golden.py:103-170 computes from the experiment CSV while a preset runs: the
+        'Evaluation Reward' column without its empty cells, averaged over a window of `win_size` evaluations
+        (np.convolve with ones(min(len, win)) / win, mode 'valid' — the reference divides by win_size even while
+        fewer evaluations exist), compared with `preset_validation_params.min_reward_threshold`; the run has failed
+        once 'Episode #' reaches `max_episodes_to_achieve_reward` without that."""
+        import numpy as np
+        pv = self.preset_validation_params
+        rewards = np.array([float(r["Evaluation Reward"]) for r in self.logger.rows
+                            if r.get("Evaluation Reward", "") != ""], dtype=np.float64)
+        rewards = rewards[~np.isnan(rewards)]
+        averaged = np.convolve(rewards, np.ones(min(len(rewards), win_size)) / win_size, mode='valid') \
+            if len(rewards) >= 1 else np.array([0.0])
+        episode = max([int(r["Episode #"]) for r in self.logger.rows if r.get("Episode #", "") != ""] or [0])
+        passed = bool(np.any(averaged >= pv.min_reward_threshold))
+        return {"passed": passed, "episode": episode, "averaged_rewards": averaged,
+                "exhausted": episode >= pv.max_episodes_to_achieve_reward,
+                "min_reward_threshold": pv.min_reward_threshold,
+                "max_episodes_to_achieve_reward": pv.max_episodes_to_achieve_reward}
+
+    def run_preset_validation(self, time_limit=60 * 60, win_size=10):
+        """The golden test of a preset (test_golden.py:103-170) in-process: improve() until the averaged evaluation
+        reward reaches the preset's threshold (pass) or the episode budget / time limit is spent (fail).  Returns the
+        final validation_status() plus 'reason'."""
+        if not self.preset_validation_params.test:
+            raise ValueError("this preset declares no golden test (preset_validation_params.test is False)")
+        t0 = time.time()
+
+        def stop():
+            st = self.validation_status(win_size)
+            return st["passed"] or st["exhausted"] or time.time() - t0 > time_limit
+        self.improve(should_stop=stop)
+        st = self.validation_status(win_size)
+        st["reason"] = "passed" if st["passed"] else \
+            ("insufficient reward" if st["exhausted"] else "time limit" if time.time() - t0 > time_limit
+             else "improve_steps exhausted")
+        st["wall_s"] = time.time() - t0
+        return st
+
+    def improve(self, should_stop=None):                                       # :525-556
+        """should_stop: optional callable checked after every evaluation period (the reference's evaluate() returns
+        should_stop(), :519-523; the golden harness passes its own)."""
         self.verify_graph_was_created()
         self.heatup(self.schedule.heatup_steps)
         imp = self.schedule.improve_steps
@@ -199,5 +286,7 @@ class BasicRLGraphManager(object):
         while counter() < count_end:
             self.train_and_act(self.schedule.steps_between_evaluation_periods)
             self.evaluate(self.schedule.evaluation_steps)
+            if should_stop is not None and should_stop():
+                break
         self.agent.check_status() if hasattr(self.agent, "check_status") else None
         return self.logger.rows

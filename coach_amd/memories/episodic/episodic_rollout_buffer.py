@@ -93,6 +93,11 @@ class DeviceEpisodicRolloutBuffer(object):
             self._episodes.append((int(e), int(self._ep_start[e]), int(self.steps)))
             self._ep_start[e] = self.steps
 
+    def drop_open_episodes(self):
+        """Agent.reset_internal_state in the middle of an episode replaces current_episode_buffer (agent.py:619): the
+        transitions of every running episode never reach the memory.  Their rows stay allocated until clean()."""
+        self._ep_start[:] = self.steps
+
     # ---- rollout side -------------------------------------------------------------------------
     def reset(self, first_obs):
         """First observation of every env: the stacking filter replicates it (:90-91)."""

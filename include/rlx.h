@@ -554,6 +554,8 @@ int rlx_sac_policy_head_backward(const float *mu_logsig, long long ld, const dou
 /* -------------------------------------------------------- exploration policies -- */
 int rlx_categorical_sample(const float *probs, long long ld, const double *uniforms, int n_env,
                            int n_actions, int *actions, void *stream); /* exploration_policies/categorical.py:45-48 */
+int rlx_argmax_rows(const float *values, long long ld, int n_rows, int n_cols, int *out,
+                    void *stream);            /* np.argmax per row: exploration_policies/categorical.py:50-52 */
 int rlx_egreedy(const float *q_values, long long ld, const double *explore_uniforms,
                 const int *random_actions, const double *tie_break_uniforms, double epsilon,
                 int n_env, int n_actions, int *actions, void *stream); /* exploration_policies/e_greedy.py:84-101 */
@@ -579,6 +581,24 @@ int rlx_synth_env_step_lengths(int kind, void *next_obs, void *reset_obs, float 
                                unsigned char *game_over, int *episode, int *step, int n_env, int obs_elems,
                                const int *episode_len_per_env, unsigned int seed, unsigned int env_id0,
                                void *stream);
+
+/* ------------------------------------------------------------ CartPole-v0 / -v1 -- */
+/* N CartPole environments per GPU: gym 0.12.5's physics (gym/envs/classic_control/cartpole.py `step`, fp64, Euler)
+ * behind gym's TimeLimit (max_episode_steps), i.e. what `GymVectorEnvironment(level='CartPole-v0')` steps through
+ * rl_coach/environments/gym_environment.py:418-474 (presets/CartPole_DQN.py:46, CartPole_ClippedPPO.py:59).
+ * state: fp64[n_env][4] (x, x_dot, theta, theta_dot) — after a step it holds the state the NEXT step starts from
+ * (the new episode's first state where game_over is set).  next_obs / reset_obs: fp32[n_env][4] views of the stepped
+ * state / the new episode's first state (reset_obs is written only where game_over is set); next_state64 (optional):
+ * the stepped state in fp64.  reward = 1.0 per step.  Reset states are Philox draws keyed by (seed, env_id0 + e)
+ * and counted by the episode number.  status: bit 0 = a pole angle outside rlx::libm_sin's table domain, bit 1 = an
+ * action outside {0, 1}.  next_episode != 0: forced reset mid-episode (every env starts its next episode now). */
+int rlx_cartpole_reset(double *state, float *obs, int *episode, int *steps, int n_env, unsigned int seed,
+                       unsigned int env_id0, int next_episode, void *stream);
+int rlx_cartpole_step(const int *action, double *state, int *episode, int *steps, float *next_obs, float *reset_obs,
+                      double *next_state64, float *reward, unsigned char *game_over, int n_env,
+                      int max_episode_steps, unsigned int seed, unsigned int env_id0, int *status, void *stream);
+/* sin / cos rounded like the host libm's (csrc/libm_sincos.hpp) — exposed for tests/test_cartpole.py */
+int rlx_libm_sincos(const double *x, double *sin_out, double *cos_out, int n, int *status, void *stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ def test_cartpole_dqn_preset_improve(dev, tmp_path):
     import importlib
     from coach_amd.core_types import EnvironmentSteps, RunPhase
     preset = importlib.reload(importlib.import_module("coach_amd.presets.CartPole_DQN"))
-    gm = preset.graph_manager
+    gm = preset.make(synthetic=True)
     gm.device = dev
     gm.logger.__init__(str(tmp_path / "exp.csv"))
     gm.schedule.heatup_steps = EnvironmentSteps(400)
