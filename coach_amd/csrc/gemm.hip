@@ -324,12 +324,20 @@ struct FastTile {
     static constexpr int kSmemFloats = 2 * A_BUF + 2 * B_BUF;
 };
 
-template <int BM, int BN, int TM, int TN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
+// KW > 1: the 4 waves also split every K slab — wave group wk multiplies rows [wk*BK/KW, (wk+1)*BK/KW) of the staged
+// slab for the same output tile, and the KW partial tiles are summed through LDS in the fixed order wk = 0, 1, ...
+// before the epilogue.  A 32 x 64 (KW = 2) or 32 x 32 (KW = 4) tile gives a mid-sized problem 2-4x the workgroups of
+// the 64 x 64 tiling WITHOUT partial sums in memory and a second (reduce) launch: what splitting K over workgroups
+// costs on this chip is the launch boundary behind several MB of freshly written partials, not the additions.
+template <int BM, int BN, int TM, int TN, int KW, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
 __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, const int by, const int bz,
                                                const int gdx, const int gdy, float *const smem, float *const lut,
                                                int *const tab_s) {
     constexpr int WN = BN / (32 * TN);
-    static_assert((BM / (32 * TM)) * WN == 4, "a workgroup is 4 waves");
+    constexpr int WMN = (BM / (32 * TM)) * WN;
+    static_assert(WMN * KW == 4, "a workgroup is 4 waves");
+    static_assert(KW == 1 || (TM == 1 && TN == 1), "the in-workgroup K split keeps one accumulator tile per wave");
+    static_assert(BK % (2 * KW) == 0, "every wave group owns whole MFMA k-steps of a slab");
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
     constexpr int NA = BM * BK / 4 / kThreads;
     constexpr int NB = BN * BK / 4 / kThreads;
@@ -339,7 +347,8 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
     static_assert(4 * 32 * 33 <= 2 * A_BUF + 2 * B_BUF, "epilogue staging fits in the operand buffers");
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WN, wn = wid % WN;
+    const int wk = wid / WMN, wmn = wid - wk * WMN;
+    const int wm = wmn / WN, wn = wmn % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int batch = bz / g.splits, split = bz - batch * g.splits;
     const int m0 = by * BM, n0 = bx * BN;
@@ -499,10 +508,11 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
         if (stamp) stamp[1] = wall_clock64();
         // step s: LDS[s&1] = slab s; set N holds slab s+1 (in flight); set F is free and receives slab s+2
         auto mfma_slab = [&](int cur) {
-            const float *ap = As + cur * A_BUF + hi * LDA_S + wm * (32 * TM) + l31;
-            const float *bp = Bs + cur * B_BUF + hi * LDB_S + wn * (32 * TN) + l31;
+            constexpr int KSPAN = BK / KW;                       // this wave group's rows of the slab
+            const float *ap = As + cur * A_BUF + (wk * KSPAN + hi) * LDA_S + wm * (32 * TM) + l31;
+            const float *bp = Bs + cur * B_BUF + (wk * KSPAN + hi) * LDB_S + wn * (32 * TN) + l31;
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
+            for (int kk = 0; kk < KSPAN; kk += 2) {
                 float a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = ap[kk * LDA_S + 32 * i];
@@ -562,6 +572,26 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
     }
 
     if (stamp) stamp[2] = wall_clock64();
+    const bool epi = wk == 0;                 // the waves that hold the complete tile
+    if (KW > 1) {
+        // partial tiles of wave groups 1 .. KW-1 -> LDS (a wave-private 32 x 33 patch each, C/D layout of the MFMA
+        // undone), added by the wave group 0 that owns the same tile, in ascending wk
+        __syncthreads();                      // every wave is done reading the operand buffers
+        float *patch = smem + wid * (32 * 33);
+        if (wk > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int q = 1; q < KW; ++q) {
+                const float *src = smem + (q * WMN + wmn) * (32 * 33);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += src[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
+            }
+        }
+    }
     if (do_colsum && n0 + tid < g.N) {
         const int n = n0 + tid;
         if (g.splits > 1)
@@ -591,7 +621,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
                 // staging covers, instead of one per `it` exposed between an LDS read and a store the compiler may not
                 // move a load across
                 const int ecol = n0 + wn * (32 * TN) + 32 * j + (lane & 7) * 4;
-                const bool ecol_ok = ecol < g.N;
+                const bool ecol_ok = epi && ecol < g.N;
                 const int etw = (!ws && g.fold) ? ecol / g.fold : 0, ecl = (!ws && g.fold) ? ecol % g.fold : ecol;
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 av4[4];
@@ -607,9 +637,11 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
                         av4[it] = *reinterpret_cast<const float4 *>(aux + (size_t)erow * g.aux_ld + ecol);
                 }
                 __syncthreads();
+                if (epi) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r)
+                        stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[i][j][r];
+                }
                 __syncthreads();
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
@@ -617,7 +649,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
                     const int rl = idx >> 3, c4 = (idx & 7) * 4;
                     const int row = m0 + wm * (32 * TM) + 32 * i + rl;
                     const int col = n0 + wn * (32 * TN) + 32 * j + c4;
-                    if (row >= g.M || col >= g.N) continue;
+                    if (!epi || row >= g.M || col >= g.N) continue;
                     const float *sp = stage + rl * 33 + c4;
                     float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
                     float *dst = dst_base + (size_t)row * ld + col;
@@ -649,7 +681,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (32 * TN) + 32 * j + l31;
-        if (col >= g.N) continue;
+        if (!epi || col >= g.N) continue;
         const float bias = (!ws && g.bias) ? g.bias[batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -671,13 +703,13 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
     if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
 }
 
-template <int BM, int BN, int TM, int TN, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
+template <int BM, int BN, int TM, int TN, int KW, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
 __global__ void __launch_bounds__(kThreads, (TM * TN == 1 ? 3 : 1)) gemm_fast_kernel(const GemmDev g) {
     __shared__ __attribute__((aligned(16))) float smem[FastTile<BM, BN, TM, TN>::kSmemFloats];
     __shared__ float lut[A_U8 ? 256 : 1];
     __shared__ int tab_s[A_TAB ? kTabChunk : 1];     // reduction-index offsets of this workgroup's K chunk
-    gemm_fast_body<BM, BN, TM, TN, A_VEC_RED, A_U8, B_VEC_RED, A_TAB>(g, blockIdx.x, blockIdx.y, blockIdx.z,
-                                                                       gridDim.x, gridDim.y, smem, lut, tab_s);
+    gemm_fast_body<BM, BN, TM, TN, KW, A_VEC_RED, A_U8, B_VEC_RED, A_TAB>(g, blockIdx.x, blockIdx.y, blockIdx.z,
+                                                                           gridDim.x, gridDim.y, smem, lut, tab_s);
 }
 
 // Two INDEPENDENT problems in one launch — a layer's weight gradient (dW = X^T dY) and its input gradient
@@ -690,7 +722,9 @@ struct GemmPairDev {
     int n0;
     int t16[2];                 // thin pair: the half runs on 16 x 16 tiles
 };
-template <bool A_TAB0>
+// DX_KW = 2 / 4: the input-gradient half runs on 32 x 64 / 32 x 32 tiles with the K slab split over the wave groups (a
+// mid-sized dX such as the FC layer's 64 x 3136 x 512: no partial sums in memory, no reduce launch)
+template <bool A_TAB0, int DX_KW>
 __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmPairDev p) {
     __shared__ __attribute__((aligned(16))) float smem[FastTile<64, 64, 1, 1>::kSmemFloats];
     __shared__ float lut[1];
@@ -701,9 +735,13 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
     const int gx = p.gx[which], gy = p.gy[which];
     const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
     if (!which)      // weight gradient: A = X^T (vector along the outer index; im2col tables for a convolution)
-        gemm_fast_body<64, 64, 1, 1, false, false, false, A_TAB0>(p.g[0], bx, by, bz, gx, gy, smem, lut, tab_s);
-    else             // input gradient: A = dY (vector along k), B = W^T
-        gemm_fast_body<64, 64, 1, 1, true, false, true, false>(p.g[1], bx, by, bz, gx, gy, smem, lut, tab_s);
+        gemm_fast_body<64, 64, 1, 1, 1, false, false, false, A_TAB0>(p.g[0], bx, by, bz, gx, gy, smem, lut, tab_s);
+    else if (DX_KW == 2) // input gradient: A = dY (vector along k), B = W^T
+        gemm_fast_body<32, 64, 1, 1, 2, true, false, true, false>(p.g[1], bx, by, bz, gx, gy, smem, lut, tab_s);
+    else if (DX_KW == 4)
+        gemm_fast_body<32, 32, 1, 1, 4, true, false, true, false>(p.g[1], bx, by, bz, gx, gy, smem, lut, tab_s);
+    else
+        gemm_fast_body<64, 64, 1, 1, 1, true, false, true, false>(p.g[1], bx, by, bz, gx, gy, smem, lut, tab_s);
 }
 
 
@@ -1340,13 +1378,13 @@ int launch_variant(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, 
     return -1;
 }
 
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, int KW = 1>
 int launch_fast(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, bool a_tab, dim3 grid,
                 hipStream_t s) {
-#define RLX_FAST_CASE(AV, AU, BV, AT)                                                    \
-    if (a_vec_red == AV && a_u8 == AU && b_vec_red == BV && a_tab == AT) {               \
-        gemm_fast_kernel<BM, BN, TM, TN, AV, AU, BV, AT><<<grid, kThreads, 0, s>>>(g);   \
-        return 0;                                                                        \
+#define RLX_FAST_CASE(AV, AU, BV, AT)                                                        \
+    if (a_vec_red == AV && a_u8 == AU && b_vec_red == BV && a_tab == AT) {                   \
+        gemm_fast_kernel<BM, BN, TM, TN, KW, AV, AU, BV, AT><<<grid, kThreads, 0, s>>>(g);   \
+        return 0;                                                                            \
     }
     RLX_FAST_CASE(true, false, false, false)
     RLX_FAST_CASE(true, false, true, false)
@@ -1464,6 +1502,7 @@ struct GemmPlan {
     bool tiled_fast;            // the fast tiled kernel with 64x64 tiles would run (else: thin / generic / folded paths)
     bool thin, a_ck, b_cn;      // the thin kernel would run, with these operand layouts
     bool t16;                   // ... on 16 x 16 output tiles (grid sized accordingly)
+    int kw;                     // 2 / 4: the fast kernel on 32 x 64 / 32 x 32 tiles with the slab split over the wave groups would run
     GemmDev g;
     dim3 grid;
     bool a_vec_red, u8, b_vec_red, a_tab;
@@ -1487,7 +1526,7 @@ int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, 
 }
 
 int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
-    if (plan) plan->tiled_fast = plan->thin = plan->t16 = false;
+    if (plan) { plan->tiled_fast = plan->thin = plan->t16 = false; plan->kw = 1; }
     RLX_REQUIRE(d_host != nullptr, "rlx_gemm: null descriptor");
     const rlx_gemm_desc &d = *d_host;
     RLX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0,
@@ -1591,13 +1630,24 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
         if (tiles_of(128, 128) >= rlx::kCUs) { BM = 128; BN = 128; }
         else if (tiles_of(128, 64) >= rlx::kCUs) { BM = 128; BN = 64; }
     }
+    // Mid-sized problems (too few 64 x 64 tiles for the chip, enough 32 x 64 or 32 x 32 ones): smaller tiles with the K
+    // slab split over the waves of the workgroup instead of K split over workgroups — no partials, no reduce launch.
+    int KW = 1;
+    constexpr int kMinTilesForChip = 192;            // 3/4 of the CUs
+    const bool u8_in = d.a_is_u8 != 0;
+    // (operand combinations launch_fast instantiates; anything else falls back to the bounds-checked 64 x 64 kernel)
+    const bool fast_combo = (!u8_in && !a_tab) || (a_tab && !b_vec_red);
+    if (fast && fast_combo && !narrow && BM == 64 && BN == 64 && tiles_of(64, 64) < kMinTilesForChip) {
+        if (tiles_of(32, 64) >= kMinTilesForChip) { BM = 32; BN = 64; KW = 2; }
+        else if (tiles_of(32, 32) >= kMinTilesForChip) { BM = 32; BN = 32; KW = 4; }
+    }
     const int tiles = (int)tiles_of(BM, BN);
     // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split; a launch that
     // already covers every CU is left alone (its reduce pass would cost more than the imbalance)
     // (RLX_GEMM_SPLIT_MIN_K raises the shortest K that may be split; measured on C2 / C3, splitting
     // every under-filled launch is fastest: 118 vs 129 ms and 325 vs 383 ms per bench step.)
     int splits = 1;
-    if (d.workspace && tiles <= rlx_split_max_tiles() && d.K >= rlx_split_min_k()) {
+    if (KW == 1 && d.workspace && tiles <= rlx_split_max_tiles() && d.K >= rlx_split_min_k()) {
         const int want = (rlx_split_wgs_per_cu() * rlx::kCUs + tiles - 1) / tiles;
         const int max_by_k = d.K / (2 * BK);
         splits = want < max_by_k ? want : max_by_k;
@@ -1613,6 +1663,7 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
         fast = false;
         BM = narrow ? 128 : 64;
         BN = narrow ? 32 : 64;
+        KW = 1;
     }
     g.splits = splits;
     g.kchunk = kchunk;
@@ -1648,8 +1699,9 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
         }
     }
     if (plan) {
-        if (fast && BM == 64 && BN == 64 && !g.fold) {
-            plan->tiled_fast = true;
+        if (fast && ((BM == 64 && BN == 64) || KW > 1) && !g.fold) {
+            plan->tiled_fast = KW == 1;
+            plan->kw = KW;
             plan->g = g;
             plan->grid = grid;
             plan->a_vec_red = a_vec_red; plan->u8 = d.a_is_u8 != 0; plan->b_vec_red = b_vec_red; plan->a_tab = a_tab;
@@ -1672,6 +1724,8 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
         if (BM == 128 && BN == 128) rc = launch_fast<128, 128, 2, 2>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
         else if (BM == 128 && BN == 64) rc = launch_fast<128, 64, 2, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
         else if (narrow) rc = launch_fast<128, 32, 1, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
+        else if (KW == 2) rc = launch_fast<32, 64, 1, 1, 2>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
+        else if (KW == 4) rc = launch_fast<32, 32, 1, 1, 4>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
         else rc = launch_fast<64, 64, 1, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
     }
     if (rc != 0) {
@@ -1698,7 +1752,7 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
     rc = gemm_impl(input_grad, stream, &px);
     if (rc != RLX_OK) return rc;
     static const bool off = [] { const char *e = getenv("RLX_NO_GEMM_PAIR"); return e && e[0] == '1'; }();
-    const bool pairable = !off && pw.tiled_fast && px.tiled_fast &&
+    const bool pairable = !off && pw.tiled_fast && (px.tiled_fast || px.kw > 1) &&
                           !pw.a_vec_red && !pw.u8 && !pw.b_vec_red &&                 // X^T dY
                           px.a_vec_red && !px.u8 && px.b_vec_red && !px.a_tab &&       // dY W^T
                           true;
@@ -1727,10 +1781,11 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
     p.t16[0] = p.t16[1] = 0;
     const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
     hipStream_t s = rlx::as_stream(stream);
-    if (pw.a_tab)
-        gemm_fast_pair_kernel<true><<<total, kThreads, 0, s>>>(p);
-    else
-        gemm_fast_pair_kernel<false><<<total, kThreads, 0, s>>>(p);
+#define RLX_PAIR_CASE(AT, KWX)                                                                   \
+    if (pw.a_tab == AT && px.kw == KWX) gemm_fast_pair_kernel<AT, KWX><<<total, kThreads, 0, s>>>(p);
+    RLX_PAIR_CASE(true, 1) RLX_PAIR_CASE(true, 2) RLX_PAIR_CASE(true, 4)
+    RLX_PAIR_CASE(false, 1) RLX_PAIR_CASE(false, 2) RLX_PAIR_CASE(false, 4)
+#undef RLX_PAIR_CASE
     RLX_LAUNCH_CHECK();
     if (pw.splits > 1) {
         rc = launch_splitk_reduce(pw.g, pw.M, pw.N, pw.batch, pw.splits, s);

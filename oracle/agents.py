@@ -280,7 +280,8 @@ class ClippedPPOAgentOracle:
         else:
             probs = self.net.policy_probs(states)
             actions = [categorical_choice(probs[e], np.random.random_sample()) for e in range(self.n_env)]
-        nxt, rst, rew, done = self.env.step()
+        # (the synthetic envs ignore the actions; a simulator — oracle/cartpole.py — executes them)
+        nxt, rst, rew, done = self.env.step(actions) if getattr(self.env, "takes_actions", False) else self.env.step()
         for e in range(self.n_env):
             r = float(rew[e])
             if self.reward_clip is not None:
@@ -298,6 +299,14 @@ class ClippedPPOAgentOracle:
             else:
                 self.cur[e] = rst[e] if done[e] else nxt[e]
         return actions, probs
+
+    def forced_reset(self):
+        """GraphManager.reset_internal_state(force_environment_reset=True) + Agent.reset_internal_state
+        (graph_manager.py:411-424, agent.py:603-629): the running episodes lived in current_episode_buffer and never
+        reach the memory; every env starts a new episode.  Vector observations only."""
+        for e in range(self.n_env):
+            del self.transitions[e][self.ep_start[e]:]
+        self.cur = [f for f in self.env.reset()]
 
     def complete_transitions(self):
         return sum(b - a for _, a, b in self.episodes)

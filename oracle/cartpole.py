@@ -94,11 +94,17 @@ class CartPoleVecEnv:
     """N independent CartPoles stepped together, auto-reset like the device vector env: step() returns the stepped
     states, the new episodes' first states where an episode ended (else None), rewards, dones."""
 
-    def __init__(self, n_env, seed, env_id0=0, max_episode_steps=200):
+    kind, takes_actions = 1, True                       # what the oracle agent loops (oracle/agents.py) ask an env
+
+    def __init__(self, n_env, seed, env_id0=0, max_episode_steps=200, f32_obs=False):
+        """f32_obs: hand out the observations as the device environment does — the fp64 state rounded to fp32 (the
+        width the networks read; the reference's filters see gym's fp64 array, a 1e-8 relative difference)."""
+        self.n_env = n_env
+        self.dt = np.float32 if f32_obs else np.float64
         self.envs = [CartPole(seed, env_id0 + e, max_episode_steps) for e in range(n_env)]
 
     def reset(self):
-        return np.array([e.reset() for e in self.envs], dtype=np.float64)
+        return np.array([e.reset() for e in self.envs], dtype=np.float64).astype(self.dt)
 
     def step(self, actions):
         nxt, rst, rew, done = [], [], [], []
@@ -107,5 +113,6 @@ class CartPoleVecEnv:
             nxt.append(s)
             rew.append(r)
             done.append(d)
-            rst.append(env.reset() if d else None)
-        return np.array(nxt, dtype=np.float64), rst, np.array(rew, dtype=np.float64), np.array(done, dtype=bool)
+            rst.append(np.array(env.reset(), dtype=np.float64).astype(self.dt) if d else None)
+        return np.array(nxt, dtype=np.float64).astype(self.dt), rst, np.array(rew, dtype=np.float64), \
+            np.array(done, dtype=bool)

@@ -15,6 +15,8 @@ SHAPES = [  # (M, N, K) — the BASELINE layer shapes plus ragged edges
     (64, 512, 3136), (64, 6, 512), (64, 1, 512), (100, 400, 23), (100, 300, 400), (256, 256, 376),
     (256, 34, 256), (32, 2, 512), (1, 1, 1), (33, 65, 31), (129, 33, 130), (25600, 32, 256),
     (5184, 64, 512), (7, 700, 9),
+    # mid-sized: too few 64 x 64 tiles for the chip -> 32 x 64 / 32 x 32 tiles with the K slab split over the waves
+    (3136, 128, 576), (3001, 68, 132), (6272, 64, 576),
 ]
 
 
@@ -37,7 +39,8 @@ def test_gemm_nn_bias_act(rlx, dev, M, N, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(64, 512, 3136), (100, 400, 23), (25600, 32, 256), (33, 65, 31), (5184, 64, 512)])
+@pytest.mark.parametrize("M,N,K", [(64, 512, 3136), (100, 400, 23), (25600, 32, 256), (33, 65, 31), (5184, 64, 512),
+                                   (128, 512, 3136), (60, 132, 3004)])
 def test_gemm_weight_and_input_grads(rlx, dev, M, N, K):
     """dW = X^T dY (TN, reduction over the batch M, split-K) and dX = (dY W^T) * act'(X) (NT)."""
     import torch
