@@ -220,6 +220,30 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class SplitkJob(ctypes.Structure):
+    """rlx_splitk_job (include/rlx.h) — field order must match the header."""
+    _fields_ = [("partials", ctypes.c_void_p), ("colsum_partials", ctypes.c_void_p), ("C", ctypes.c_void_p),
+                ("colsum_out", ctypes.c_void_p), ("ldc", ctypes.c_longlong), ("c_batch_stride", ctypes.c_longlong),
+                ("colsum_batch_stride", ctypes.c_longlong), ("M", ctypes.c_int), ("N", ctypes.c_int),
+                ("batch", ctypes.c_int), ("splits", ctypes.c_int), ("n_fold", ctypes.c_int)]
+
+    def workspace_floats(self):
+        """floats of the workspace the outstanding reduction still reads (0 when nothing is outstanding)."""
+        return (self.M * self.N + self.N) * self.batch * self.splits if self.splits > 1 else 0
+
+
+MAX_SPLITK_JOBS = 8
+
+
+def splitk_reduce_jobs(jobs, stream=None):
+    """sum the partials of the deferred products `jobs` (SplitkJob list) in one launch."""
+    live = [j for j in jobs if j.splits > 1]
+    for i in range(0, len(live), MAX_SPLITK_JOBS):
+        chunk = live[i:i + MAX_SPLITK_JOBS]
+        arr = (SplitkJob * len(chunk))(*chunk)
+        lib().splitk_reduce_jobs(ctypes.byref(arr), len(chunk), current_stream() if stream is None else stream)
+
+
 class SmallDenseProblem(ctypes.Structure):
     """rlx_small_dense_problem (include/rlx.h) — field order must match the header."""
     _fields_ = [
@@ -273,9 +297,12 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
          deriv_aux=None, aux_ld=None, deriv_kind=None, accumulate=False, batch=1,
          a_batch_stride=0, b_batch_stride=0, c_batch_stride=0, bias_batch_stride=0,
          aux_batch_stride=0, workspace=None, colsum_out=None, colsum_batch_stride=0, stream=None,
-         batch_inner=0, a_batch_stride2=0, b_batch_stride2=0, bias_batch_stride2=0, n_fold=0, launch=True):
+         batch_inner=0, a_batch_stride2=0, b_batch_stride2=0, bias_batch_stride2=0, n_fold=0, launch=True,
+         defer=None):
     """Thin wrapper building an rlx_gemm_desc.  a_strides=(row, k), b_strides=(k, n) in elements.
-    launch=False: return the descriptor (for gemm_pair) instead of running it."""
+    launch=False: return the descriptor (for gemm_pair) instead of running it.
+    defer: a SplitkJob — if K gets split over workgroups the reduction of the partials is left to
+    splitk_reduce_jobs (rlx_gemm_defer); `workspace` must then stay untouched until that ran."""
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = int(M), int(N), int(K), int(batch)
     d.A, d.B, d.C = _ptr(A), _ptr(B), _ptr(C)
@@ -308,7 +335,10 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
         return d
     if GEMM_HOOK is not None:
         GEMM_HOOK(GemmDesc.from_buffer_copy(d))
-    lib().gemm(ctypes.byref(d), current_stream() if stream is None else stream)
+    if defer is not None:
+        lib().gemm_defer(ctypes.byref(d), ctypes.byref(defer), current_stream() if stream is None else stream)
+    else:
+        lib().gemm(ctypes.byref(d), current_stream() if stream is None else stream)
 
 
 def gemm_pair_or_single(desc, stream=None):
@@ -326,9 +356,13 @@ def gemm_chain2(first, second, stream=None):
     lib().gemm_chain2(ctypes.byref(first), ctypes.byref(second), current_stream() if stream is None else stream)
 
 
-def gemm_pair(weight_grad, input_grad, stream=None):
-    """two descriptors built with gemm(..., launch=False): a layer's dW and dX products as one launch."""
+def gemm_pair(weight_grad, input_grad, stream=None, defer=None):
+    """two descriptors built with gemm(..., launch=False): a layer's dW and dX products as one launch.
+    defer: a SplitkJob for the weight gradient's split-K reduction (see gemm)."""
     if GEMM_HOOK is not None:       # one entry: the two products go out as one launch
         GEMM_HOOK((GemmDesc.from_buffer_copy(weight_grad), GemmDesc.from_buffer_copy(input_grad)))
-    lib().gemm_pair(ctypes.byref(weight_grad), ctypes.byref(input_grad),
-                    current_stream() if stream is None else stream)
+    s = current_stream() if stream is None else stream
+    if defer is not None:
+        lib().gemm_pair_defer(ctypes.byref(weight_grad), ctypes.byref(input_grad), ctypes.byref(defer), s)
+    else:
+        lib().gemm_pair(ctypes.byref(weight_grad), ctypes.byref(input_grad), s)

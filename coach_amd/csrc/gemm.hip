@@ -1270,6 +1270,85 @@ __global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g
     }
 }
 
+// The outstanding reductions of several deferred products in ONE launch (rlx_splitk_reduce_jobs): blockIdx.z = job,
+// blockIdx.y = batch entry of the job, blockIdx.x = 64 float4 output groups; the scheme of splitk_reduce4_kernel<16>
+// (16 split groups per output group, partials of group q summed in increasing split order, groups combined in the
+// fixed order ((s0 + s1) + s2) + ...).  Plain store: a weight gradient has no epilogue.
+struct ReduceJobs {
+    rlx_splitk_job job[RLX_MAX_SPLITK_JOBS];
+};
+__global__ void __launch_bounds__(1024) splitk_reduce_jobs_kernel(const ReduceJobs jobs) {
+    constexpr int SG = 16;
+    __shared__ float4 part[SG][64];
+    const rlx_splitk_job &g = jobs.job[blockIdx.z];
+    const int batch = blockIdx.y;
+    if (batch >= g.batch) return;
+    const int mn4 = (g.M * g.N) >> 2;
+    if ((int)blockIdx.x * 64 >= mn4 && !(blockIdx.x == 0 && g.colsum_out)) return;
+    const int ox = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int gid = blockIdx.x * 64 + ox;
+    const size_t mn = (size_t)g.M * g.N;
+    const float4 *ws = reinterpret_cast<const float4 *>(g.partials + (size_t)batch * g.splits * mn);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gid < mn4) {
+        int k = q;
+        for (; k + 3 * SG < g.splits; k += 4 * SG) {    // 4 independent loads in flight per thread
+            const float4 a = ws[(size_t)k * mn4 + gid];
+            const float4 b = ws[(size_t)(k + SG) * mn4 + gid];
+            const float4 c = ws[(size_t)(k + 2 * SG) * mn4 + gid];
+            const float4 d = ws[(size_t)(k + 3 * SG) * mn4 + gid];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+            s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+        }
+        for (; k < g.splits; k += SG) {
+            const float4 a = ws[(size_t)k * mn4 + gid];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
+    part[q][ox] = s;
+    __syncthreads();
+    if (q == 0 && gid < mn4) {
+        float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int t = 1; t < SG; ++t) {
+            const float4 p = part[t][ox];
+            v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+        }
+        const int i = gid << 2;
+        const int row = i / g.N, col = i - row * g.N;
+        const int tw = g.n_fold ? col / g.n_fold : batch, cl = g.n_fold ? col % g.n_fold : col;
+        float *c = g.C + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
+        if ((g.ldc & 3) == 0 && (((uintptr_t)c) & 15) == 0) {
+            *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
+        }
+    }
+    if (g.colsum_out && blockIdx.x == 0) {
+        float *cpart = reinterpret_cast<float *>(&part[0][0]);      // [SG][64] floats
+        for (int n0 = 0; n0 < g.N; n0 += 64) {
+            __syncthreads();
+            const int n = n0 + ox;
+            float t = 0.f;
+            if (n < g.N)
+                for (int k = q; k < g.splits; k += SG)
+                    t += g.colsum_partials[((size_t)batch * g.splits + k) * g.N + n];
+            cpart[q * 64 + ox] = t;
+            __syncthreads();
+            if (q == 0 && n < g.N) {
+#pragma unroll
+                for (int u = 1; u < SG; ++u) t += cpart[u * 64 + ox];
+                if (g.n_fold)
+                    g.colsum_out[(size_t)(n / g.n_fold) * g.colsum_batch_stride + n % g.n_fold] = t;
+                else
+                    g.colsum_out[(size_t)batch * g.colsum_batch_stride + n] = t;
+            }
+        }
+    }
+}
+
 // Column sums for bias gradients: out[n] = sum_m x[m][n]  (deterministic two-stage reduction).
 __global__ void colsum_partial_kernel(const float *__restrict__ x, int M, int N, long long ld,
                                       int rows_per_block, float *__restrict__ part) {
@@ -1525,8 +1604,22 @@ int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, 
     return RLX_OK;
 }
 
-int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
+// what a deferred reduction needs (rlx_gemm_defer): only a product with the plain-store epilogue and partials the
+// float4 reduce scheme can read qualifies; anything else is reduced at once (job->splits = 0)
+bool deferrable(const GemmDev &g, int M, int N) {
+    return !g.bias && !g.aux && !g.accumulate && g.act == RLX_ACT_NONE && N % 4 == 0 &&
+           (long long)M * N < (1LL << 31) && aligned16(g.ws);
+}
+void fill_job(rlx_splitk_job *job, const GemmDev &g, int M, int N, int batch, int splits) {
+    job->partials = g.ws; job->colsum_partials = g.colsum ? g.ws_colsum : nullptr;
+    job->C = g.c; job->colsum_out = g.colsum;
+    job->ldc = g.ldc; job->c_batch_stride = g.c_batch_stride; job->colsum_batch_stride = g.colsum_batch_stride;
+    job->M = M; job->N = N; job->batch = batch; job->splits = splits; job->n_fold = g.fold;
+}
+
+int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_splitk_job *defer = nullptr) {
     if (plan) { plan->tiled_fast = plan->thin = plan->t16 = false; plan->kw = 1; }
+    if (defer) defer->splits = 0;
     RLX_REQUIRE(d_host != nullptr, "rlx_gemm: null descriptor");
     const rlx_gemm_desc &d = *d_host;
     RLX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0,
@@ -1695,7 +1788,7 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
             t.n_fold = 0;
             t.a_batch_stride = 0;
             if (plan) return RLX_OK;
-            return gemm_impl(&t, stream, nullptr);
+            return gemm_impl(&t, stream, nullptr, defer);
         }
     }
     if (plan) {
@@ -1735,7 +1828,13 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan) {
     }
     RLX_REQUIRE(rc == 0, "rlx_gemm: unsupported operand combination (uint8 A with transposed B)");
     RLX_LAUNCH_CHECK();
-    if (splits > 1) return launch_splitk_reduce(g, d.M, d.N, d.batch, splits, s);
+    if (splits > 1) {
+        if (defer && deferrable(g, d.M, d.N)) {
+            fill_job(defer, g, d.M, d.N, d.batch, splits);
+            return RLX_OK;
+        }
+        return launch_splitk_reduce(g, d.M, d.N, d.batch, splits, s);
+    }
     return RLX_OK;
 }
 
@@ -1745,7 +1844,49 @@ extern "C" {
 
 int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) { return gemm_impl(d_host, stream, nullptr); }
 
+static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream,
+                          rlx_splitk_job *defer);
+
 int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream) {
+    return gemm_pair_impl(weight_grad, input_grad, stream, nullptr);
+}
+
+int rlx_gemm_defer(const rlx_gemm_desc *desc_host, rlx_splitk_job *job_host, void *stream) {
+    RLX_REQUIRE(job_host != nullptr, "rlx_gemm_defer: null job");
+    return gemm_impl(desc_host, stream, nullptr, job_host);
+}
+
+int rlx_gemm_pair_defer(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad,
+                        rlx_splitk_job *weight_grad_job_host, void *stream) {
+    RLX_REQUIRE(weight_grad_job_host != nullptr, "rlx_gemm_pair_defer: null job");
+    return gemm_pair_impl(weight_grad, input_grad, stream, weight_grad_job_host);
+}
+
+int rlx_splitk_reduce_jobs(const rlx_splitk_job *jobs_host, int n_jobs, void *stream) {
+    RLX_REQUIRE(jobs_host && n_jobs >= 0 && n_jobs <= RLX_MAX_SPLITK_JOBS,
+                "rlx_splitk_reduce_jobs: 0..%d jobs (got %d)", RLX_MAX_SPLITK_JOBS, n_jobs);
+    ReduceJobs jobs;
+    int n = 0, gx = 1, gy = 1;
+    for (int i = 0; i < n_jobs; ++i) {
+        const rlx_splitk_job &j = jobs_host[i];
+        if (j.splits <= 1) continue;
+        RLX_REQUIRE(j.partials && j.C && j.M > 0 && j.N > 0 && j.N % 4 == 0 && j.batch > 0 &&
+                    (long long)j.M * j.N < (1LL << 31) && aligned16(j.partials),
+                    "rlx_splitk_reduce_jobs: job %d is not a float4-reducible product", i);
+        jobs.job[n++] = j;
+        const int bx = (int)(((long long)j.M * j.N / 4 + 63) / 64);
+        gx = bx > gx ? bx : gx;
+        gy = j.batch > gy ? j.batch : gy;
+    }
+    if (n == 0) return RLX_OK;
+    splitk_reduce_jobs_kernel<<<dim3(gx, gy, n), 1024, 0, rlx::as_stream(stream)>>>(jobs);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream,
+                          rlx_splitk_job *defer) {
+    if (defer) defer->splits = 0;
     GemmPlan pw, px;
     int rc = gemm_impl(weight_grad, stream, &pw);
     if (rc != RLX_OK) return rc;
@@ -1770,7 +1911,7 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
     // both problems may split K: their partials must not share workspace memory
     const bool ws_clash = pw.splits > 1 && px.splits > 1 && pw.g.ws == px.g.ws;
     if (!pairable || ws_clash) {
-        rc = gemm_impl(weight_grad, stream, nullptr);
+        rc = gemm_impl(weight_grad, stream, nullptr, defer);
         if (rc != RLX_OK) return rc;
         return gemm_impl(input_grad, stream, nullptr);
     }
@@ -1788,8 +1929,12 @@ int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_g
 #undef RLX_PAIR_CASE
     RLX_LAUNCH_CHECK();
     if (pw.splits > 1) {
-        rc = launch_splitk_reduce(pw.g, pw.M, pw.N, pw.batch, pw.splits, s);
-        if (rc != RLX_OK) return rc;
+        if (defer && deferrable(pw.g, pw.M, pw.N)) {
+            fill_job(defer, pw.g, pw.M, pw.N, pw.batch, pw.splits);
+        } else {
+            rc = launch_splitk_reduce(pw.g, pw.M, pw.N, pw.batch, pw.splits, s);
+            if (rc != RLX_OK) return rc;
+        }
     }
     if (px.splits > 1) return launch_splitk_reduce(px.g, px.M, px.N, px.batch, px.splits, s);
     return RLX_OK;

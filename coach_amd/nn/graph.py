@@ -148,6 +148,7 @@ class Context:
         self.overlap = os.environ.get("RLX_OVERLAP", "0") == "1" and torch.cuda.is_available()
         self.side = torch.cuda.Stream(device=device) if self.overlap else None
         self._forked = False
+        self.deferred, self.arena, self._arena_off = None, None, 0
 
     @property
     def stream(self):
@@ -168,6 +169,37 @@ class Context:
         if self._forked:
             torch.cuda.current_stream().wait_stream(self.side)
             self._forked = False
+
+    # ---- deferred split-K reductions of the weight gradients (rlx_gemm_defer): every dW product of a backward pass
+    # leaves its partial sums in its own slice of an arena; ONE launch sums them all when the pass ends.
+    ARENA_FLOATS = 1 << 25
+
+    def begin_deferring(self):
+        """-> True if this call opened the deferral (its caller must flush)."""
+        if self.deferred is not None:
+            return False
+        if self.arena is None:
+            self.arena = torch.empty(self.ARENA_FLOATS, dtype=torch.float32, device=self.device)
+        self.deferred, self._arena_off = [], 0
+        return True
+
+    def deferred_workspace(self, M, N, batch):
+        """(job, workspace slice) for one deferred product with an M x N output per batch entry."""
+        bound = (M * N + N) * batch * 64                    # rlx_gemm_workspace_floats: at most 64 splits
+        room = self.ARENA_FLOATS - self._arena_off
+        if self.deferred is None or len(self.deferred) >= _rlx.MAX_SPLITK_JOBS or room < (M * N + N) * batch * 2:
+            return None, self.ws.splitk
+        return _rlx.SplitkJob(), self.arena[self._arena_off:self._arena_off + min(bound, room)]
+
+    def commit_deferred(self, job):
+        if job is not None and job.splits > 1:
+            self.deferred.append(job)
+            self._arena_off += (job.workspace_floats() + 3) // 4 * 4
+
+    def flush_deferred(self):
+        jobs, self.deferred = self.deferred, None
+        if jobs:
+            _rlx.splitk_reduce_jobs(jobs, self.stream)
 
     def buffer(self, name, shape, dtype=torch.float32, tag=""):
         key = (name, tuple(shape), dtype, tag)
@@ -341,19 +373,23 @@ class Dense(Layer):
         # (db = column sums of dz, accumulated by the same launch from the staged B slabs)
         if need_dw:
             fold = x.towers == 0 and T > 1 and self.N % 4 == 0 and _fold(self.K, self.N, M, T)
+            job, dws = ctx.deferred_workspace(self.K, T * self.N if fold else self.N, 1 if fold else T) \
+                if not overlap else (None, None)
 
             def dw(ws, launch=True):
+                ws = dws if job is not None else ws
+                dj = job if launch else None          # a pair launch passes the job itself
                 if fold:       # shared input: dW of all towers = x^T [dz_0 | dz_1 | ...] in one GEMM
                     return _rlx.gemm(self.K, T * self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K),
                                      b_strides=(self.N, 1), ldc=self.N, batch=1, b_batch_stride=M * self.N,
                                      c_batch_stride=p.stride(self.kname), workspace=ws,
                                      colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
-                                     n_fold=self.N, launch=launch)
+                                     n_fold=self.N, launch=launch, defer=dj)
                 return _rlx.gemm(self.K, self.N, M, x.data, dz, p.g(self.kname, t0), a_strides=(1, self.K), batch=T,
                                  a_batch_stride=x.tower_stride(), b_batch_stride=M * self.N,
                                  c_batch_stride=p.stride(self.kname), workspace=ws,
                                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
-                                 launch=launch)
+                                 launch=launch, defer=dj)
             pair_dw = need_dx and not shared_dx and not overlap and PAIR_GRADIENT_GEMMS   # dW rides with the dX launch
             if overlap and need_dx:
                 ctx.on_side(dw)
@@ -378,10 +414,12 @@ class Dense(Layer):
                             aux_batch_stride=M * self.K, launch=False)
             if need_dw and not overlap and PAIR_GRADIENT_GEMMS:
                 # dW and dX are independent products of the same dz: one launch (own split-K workspaces)
-                _rlx.gemm_pair(dw(ctx.ws.splitk_side, launch=False), dxd)
+                _rlx.gemm_pair(dw(ctx.ws.splitk_side, launch=False), dxd, defer=job)
             else:
                 _rlx.gemm_pair_or_single(dxd)
             x.grad_is_dz = lower is not None
+        if need_dw:
+            ctx.commit_deferred(job)
 
 
 class BatchNorm(Layer):
@@ -522,21 +560,25 @@ class Conv2d(Layer):
         # dW[K,Co] = cols^T dz : A(k, m) gathered with outer table = koff, reduction table = rowbase
         if need_dw:
             fold = x.towers == 0 and T > 1 and self.Co % 4 == 0 and self.C % 4 == 0 and FOLD_SHARED_INPUT
+            job, dws = ctx.deferred_workspace(self.K, T * self.Co if fold else self.Co, 1 if fold else T) \
+                if not overlap else (None, None)
 
             def dw(ws, launch=True):
+                ws = dws if job is not None else ws
+                dj = job if launch else None          # a pair launch passes the job itself
                 if fold:
                     return _rlx.gemm(self.K, T * self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb),
                                      a_u8=x.u8, a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=1, b_strides=(self.Co, 1),
                                      ldc=self.Co, batch=1, b_batch_stride=M * self.Co,
                                      c_batch_stride=p.stride(self.kname), workspace=ws,
                                      colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
-                                     n_fold=self.Co, launch=launch)
+                                     n_fold=self.Co, launch=launch, defer=dj)
                 return _rlx.gemm(self.K, self.Co, M, x.data, dz, p.g(self.kname, t0), a_tabs=(ko, rb), a_u8=x.u8,
                                  a_div=x.div, a_vec_along_k=0, a_tab_vec_ok=int(self.C % 4 == 0), batch=T,
                                  a_batch_stride=x.tower_stride(), b_batch_stride=M * self.Co,
                                  c_batch_stride=p.stride(self.kname), workspace=ws,
                                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
-                                 launch=launch)
+                                 launch=launch, defer=dj)
             if overlap:
                 ctx.on_side(dw)          # also when this is the first layer: it overlaps the layers above
             elif not pairing:
@@ -549,7 +591,7 @@ class Conv2d(Layer):
                             c_batch_stride=M * self.K, workspace=ctx.ws.splitk, launch=False)
             if pairing:
                 # dW and dcol are independent products of the same dz: one launch (own split-K workspaces)
-                _rlx.gemm_pair(dw(ctx.ws.splitk_side, launch=False), dxd)
+                _rlx.gemm_pair(dw(ctx.ws.splitk_side, launch=False), dxd, defer=job)
             else:
                 _rlx.gemm_pair_or_single(dxd)
             dx = x.ensure_grad()
@@ -558,6 +600,8 @@ class Conv2d(Layer):
             ctx.lib.col2im(dcol, dx, x.data if lower else None, _rlx.ACT[lower], T * B, self.H, self.W,
                            self.C, self.KH, self.KW, self.S, ctx.stream)
             x.grad_is_dz = lower is not None
+        if need_dw:
+            ctx.commit_deferred(job)
 
 
 def dense_chain2_forward(ctx, l1, l2, x, tag="", weights=None, t0=0, nt=None, pair=False):
@@ -687,11 +731,16 @@ class Sequential:
         """layers=(lo, hi): only layers lo <= i < hi (the data-parallel path runs the last layers
         first, starts their gradient all-reduce, then the rest)."""
         lo, hi = layers if layers is not None else (0, len(self.layers))
-        for i in reversed(range(lo, hi)):
-            kw = {"overlap": True} if need_dw else {"need_dw": False}
-            self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),
-                                    weights=weights, t0=t0, nt=nt, **kw)
-        ctx.join()                       # weight gradients issued on the side stream are complete
+        mine = need_dw and ctx.begin_deferring()      # the layers' split-K reductions: one launch at the end
+        try:
+            for i in reversed(range(lo, hi)):
+                kw = {"overlap": True} if need_dw else {"need_dw": False}
+                self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),
+                                        weights=weights, t0=t0, nt=nt, **kw)
+            ctx.join()                   # weight gradients issued on the side stream are complete
+        finally:
+            if mine:
+                ctx.flush_deferred()
 
 
 class AdamState:

@@ -317,6 +317,29 @@ int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_
  * dY — as ONE launch when both take the 64x64 tiled kernel (two launches otherwise; RLX_NO_GEMM_PAIR=1 forces that).
  * Each descriptor is exactly what rlx_gemm would get; when both split K they need disjoint workspaces. */
 int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream);
+
+/* Deferred split-K reduction.  A weight gradient dW = X^T dY has a tiny output and a long reduction (the batch), so
+ * its K is split over workgroups into partial sums [batch][split][M][N] in the workspace, and summing them is a second
+ * launch.  Nobody reads a weight gradient before the optimiser does, so the backward pass of a network can leave
+ * the partials of ALL its layers where they are and sum them in ONE launch at its end: rlx_gemm_defer /
+ * rlx_gemm_pair_defer run the product(s) and, if K was split, describe the outstanding reduction in *job (job->splits
+ * > 1) instead of launching it; rlx_splitk_reduce_jobs sums up to RLX_MAX_SPLITK_JOBS of them (fixed summation order:
+ * reproducible).  The workspace of a deferred product must stay untouched until its job has run.  Only plain
+ * products qualify (no bias / activation / derivative / accumulate epilogue — a weight gradient has none). */
+#define RLX_MAX_SPLITK_JOBS 8
+typedef struct rlx_splitk_job {
+    const float *partials;        /* [batch][splits][M][N] */
+    const float *colsum_partials; /* [batch][splits][N] or NULL */
+    float *C;
+    float *colsum_out;
+    long long ldc, c_batch_stride, colsum_batch_stride;
+    int M, N, batch, splits;      /* splits <= 1: nothing outstanding */
+    int n_fold;
+} rlx_splitk_job;
+int rlx_gemm_defer(const rlx_gemm_desc *desc_host, rlx_splitk_job *job_host, void *stream);
+int rlx_gemm_pair_defer(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad,
+                        rlx_splitk_job *weight_grad_job_host, void *stream);
+int rlx_splitk_reduce_jobs(const rlx_splitk_job *jobs_host, int n_jobs, void *stream);
 /* Two consecutive dense layers (second->A == first->C) as ONE launch when the first has a short reduction (K <= 64,
  * N <= 512: the observation layer of the DDPG / TD3 / DQN MLPs) and both would take the thin kernel: every workgroup
  * recomputes the rows of the hidden layer it needs in LDS.  Bit-identical to the two launches (which are what runs

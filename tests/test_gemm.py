@@ -337,3 +337,44 @@ def test_two_dense_layers_as_one_launch_equal_two(rlx, dev, M, K1, H1, N2, T, mo
                       + params.w("l1/bias").cpu().numpy(), 0)
     np.testing.assert_allclose(outs[True][0][0].cpu().numpy(), ref1, rtol=2e-5, atol=2e-5)
     assert float(outs[True][1].abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_deferred_weight_gradient_reductions_equal_immediate_ones(rlx, dev):
+    """Sequential.backward leaves the split-K partials of every layer's weight gradient in an arena and sums them with
+    ONE rlx_splitk_reduce_jobs launch at its end; the gradients must equal those of the per-layer reductions (same
+    partials; the grouping of the additions differs only for <= 16 splits: tolerance 1e-6 relative)."""
+    import torch
+    from coach_amd.nn import graph as G
+    rng = np.random.RandomState(11)
+    B, T = 64, 2
+    out, launches = {}, {}
+    for deferred in (True, False):
+        params = G.FlatParams()
+        layers = [G.Conv2d(params, "c2", (20, 20, 32), 64, 4, 2, "tanh", T), G.Conv2d(params, "c3", (9, 9, 64), 64, 3, 1, "tanh", T),
+                  G.Dense(params, "fc", 7 * 7 * 64, 512, "tanh", T)]
+        params.finalize(dev)
+        seq = G.Sequential(layers)
+        seq.initialize(np.random.RandomState(5))
+        ctx = G.Context(dev)
+        if not deferred:
+            ctx.begin_deferring = lambda: False
+        if deferred:
+            x_np = np.tanh(rng.randn(T, B, 20 * 20 * 32)).astype(np.float32)
+        x = G.Tensor(dev_tensor(x_np, dev), B, x_np.shape[2], T, act="tanh")
+        acts = seq.forward(ctx, x, tag="t")
+        if deferred:
+            dy_np = rng.randn(*acts[-1].data.shape).astype(np.float32)
+        acts[-1].ensure_grad().copy_(dev_tensor(dy_np, dev))
+        from coach_amd import _rlx
+        before = _rlx.CALL_COUNT
+        seq.backward(ctx, acts, need_input_grad=True)
+        launches[deferred] = _rlx.CALL_COUNT - before
+        torch.cuda.synchronize()
+        assert ctx.deferred is None
+        out[deferred] = (params.grads.clone().cpu().numpy(), x.grad.clone().cpu().numpy())
+    scale = np.abs(out[False][0]).max()
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-6 * scale)
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    assert np.abs(out[True][0]).sum() > 0
+    assert launches[True] == launches[False] + 1             # host calls: + the one reduce call (device launches: fewer)
