@@ -14,8 +14,11 @@ from coach_amd.schedules import LinearSchedule
 ROLLOUT = 2048
 
 
-def make(num_envs=1, seed=1234):
+def make(num_envs=1, seed=1234, agent_seed=0):
+    """seed: the environments' reset-state streams; agent_seed: the agent's host generators and initial weights
+    (the reference's `--seed`, rl_coach/tests/test_golden.py:122 runs its golden tests with 0)."""
     agent = ClippedPPOAgentParameters()
+    agent.seed = agent_seed
     net, alg = agent.network_wrappers['main'], agent.algorithm
     for key, value in dict(learning_rate=3e-4, activation_function='tanh', embedder_scheme=[64],
                            middleware_scheme=[64], batch_size=64, optimizer_epsilon=1e-5,

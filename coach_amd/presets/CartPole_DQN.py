@@ -23,9 +23,12 @@ HYPER = dict(discount=0.99, target_copy_every=100, env_steps_per_update=1, learn
              improve_steps=10000, episodes_between_evaluations=10)
 
 
-def make(num_envs=1, seed=1234, synthetic=False, **overrides):
+def make(num_envs=1, seed=1234, synthetic=False, agent_seed=0, **overrides):
+    """seed: the environments' reset-state streams; agent_seed: the agent's host generators and initial weights
+    (the reference's `--seed`, rl_coach/tests/test_golden.py:122 runs its golden tests with 0)."""
     h = dict(HYPER, **overrides)
     agent = DQNAgentParameters()
+    agent.seed = agent_seed
     alg, net = agent.algorithm, agent.network_wrappers['main']
     alg.discount = h["discount"]
     alg.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(h["target_copy_every"])
