@@ -330,7 +330,6 @@ def gemm_roofline(agent, reps=20):
     from coach_amd import _rlx
     lib = _rlx.lib()
     recorded = []
-    orig = lib.raw("rlx_gemm")
     saved_graphs = agent.use_graphs
     agent.use_graphs = False
     _rlx.GEMM_HOOK = recorded.append
@@ -350,13 +349,12 @@ def gemm_roofline(agent, reps=20):
     lib.event_create(ctypes.byref(ev0))
     lib.event_create(ctypes.byref(ev1))
     total_ms, total_flops, per_shape = 0.0, 0.0, []
-    pair = lib.raw("rlx_gemm_pair")
     n_products = 0
-    for d in recorded:
-        # a recorded tuple is a layer's dW + dX pair: ONE launch (rlx_gemm_pair), timed as such
-        descs = d if isinstance(d, tuple) else (d,)
-        run = (lambda: pair(ctypes.byref(descs[0]), ctypes.byref(descs[1]), stream)) if len(descs) == 2 else \
-            (lambda: orig(ctypes.byref(descs[0]), stream))
+    for rec in recorded:
+        # one record = ONE library call of the GEMM family exactly as the update issued it (a layer's dW + dX pair, a
+        # direct convolution input gradient, the deferred split-K reductions of a backward pass ...): the products it
+        # stands for and a thunk that issues it again
+        descs, run = rec["descs"], rec["run"]
         for _ in range(3):
             run()
         lib.event_record(ev0, stream)
@@ -365,7 +363,7 @@ def gemm_roofline(agent, reps=20):
         lib.event_record(ev1, stream)
         ms = ctypes.c_float()
         lib.event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
-        flops = sum(2.0 * x.M * x.N * x.K * x.batch for x in descs)
+        flops = rec["flops"] if rec["flops"] is not None else sum(2.0 * x.M * x.N * x.K * x.batch for x in descs)
         total_ms += ms.value / reps
         total_flops += flops
         n_products += len(descs)
@@ -380,7 +378,7 @@ def gemm_roofline(agent, reps=20):
     # the same launches (tools/ppo_update_once.py + tools/pmc_summary.py -> profiles/r02_pmc_gemm_traffic.json)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_gemm_traffic.json")) as f:
             pm = json.load(f)
         if pm.get("gemm_launches") == n and pm.get("gemm_products") == n_products:
             traffic = round(pm["traffic_bytes_per_update"] / n)
@@ -391,8 +389,8 @@ def gemm_roofline(agent, reps=20):
             "traffic_unit": "bytes per GEMM launch incl. its split-K reduces (2 x FETCH_SIZE + WRITE_SIZE, PMC passes of "
                             "tools/ppo_update_once.py; algorithmic operand bytes are %.1fe6 per launch)"
                             % (11.9 * n_products / n),
-            "kernel": "gemm_fast_kernel / gemm_fast_pair_kernel + splitk_reduce4 (fp32 MFMA 32x32x2): %d products in "
-                      "%d launches per minibatch update" % (n_products, n),
+            "kernel": "gemm_fast_kernel / gemm_fast_pair_kernel / gemm_win_kernel + split-K reduces (fp32 MFMA 32x32x2): "
+                      "%d products in %d library calls per minibatch update" % (n_products, n),
             "flops_per_launch": total_flops / n, "avg_launch_us": round(1e3 * total_ms / n, 2),
             "gemm_us_per_update": round(1e3 * total_ms, 1)}, per_shape
 

@@ -238,10 +238,27 @@ MAX_SPLITK_JOBS = 8
 def splitk_reduce_jobs(jobs, stream=None):
     """sum the partials of the deferred products `jobs` (SplitkJob list) in one launch."""
     live = [j for j in jobs if j.splits > 1]
+    s = current_stream() if stream is None else stream
     for i in range(0, len(live), MAX_SPLITK_JOBS):
         chunk = live[i:i + MAX_SPLITK_JOBS]
         arr = (SplitkJob * len(chunk))(*chunk)
-        lib().splitk_reduce_jobs(ctypes.byref(arr), len(chunk), current_stream() if stream is None else stream)
+        run = lambda a=arr, n=len(chunk): lib().splitk_reduce_jobs(ctypes.byref(a), n, s)
+        _record((), run, flops=0.0)                # part of the GEMM family's time, no products of its own
+        run()
+
+
+def conv_input_grad(dz, weights, dx, x_out, deriv, tables, B, H, W, C, KH, KW, S, Co, towers, dy_stride, w_stride,
+                    dx_stride, stream=None):
+    """rlx_conv_input_grad; recorded with the flops of the product it replaces (dcol = dz W^T: 2*M*K*Co per tower)."""
+    s = current_stream() if stream is None else stream
+    OH, OW = (H - KH) // S + 1, (W - KW) // S + 1
+    run = lambda: lib().conv_input_grad(dz, weights, dx, x_out, ACT[deriv], tables, B, H, W, C, KH, KW, S, Co, towers,
+                                        dy_stride, w_stride, dx_stride, s)
+    if GEMM_HOOK is not None:
+        d = GemmDesc()
+        d.M, d.N, d.K, d.batch = B * OH * OW, KH * KW * C, Co, towers
+        _record((d,), run)
+    run()
 
 
 class SmallDenseProblem(ctypes.Structure):
@@ -333,36 +350,45 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
     d.n_fold = int(n_fold)
     if not launch:
         return d
-    if GEMM_HOOK is not None:
-        GEMM_HOOK(GemmDesc.from_buffer_copy(d))
+    s = current_stream() if stream is None else stream
     if defer is not None:
-        lib().gemm_defer(ctypes.byref(d), ctypes.byref(defer), current_stream() if stream is None else stream)
+        run = lambda: lib().gemm_defer(ctypes.byref(d), ctypes.byref(defer), s)
     else:
-        lib().gemm(ctypes.byref(d), current_stream() if stream is None else stream)
+        run = lambda: lib().gemm(ctypes.byref(d), s)
+    _record((d,), run)
+    run()
+
+
+def _record(descs, run, flops=None):
+    """bench.py's recorder: the products a launch stands for (their 2*M*N*K*batch are its algorithmic flops unless
+    `flops` says otherwise) and a thunk that issues the same launch again."""
+    if GEMM_HOOK is not None:
+        GEMM_HOOK({"descs": tuple(GemmDesc.from_buffer_copy(x) for x in descs), "run": run, "flops": flops})
 
 
 def gemm_pair_or_single(desc, stream=None):
     """run one descriptor built with gemm(..., launch=False)."""
-    if GEMM_HOOK is not None:
-        GEMM_HOOK(GemmDesc.from_buffer_copy(desc))
-    lib().gemm(ctypes.byref(desc), current_stream() if stream is None else stream)
+    s = current_stream() if stream is None else stream
+    run = lambda: lib().gemm(ctypes.byref(desc), s)
+    _record((desc,), run)
+    run()
 
 
 def gemm_chain2(first, second, stream=None):
     """two descriptors built with gemm(..., launch=False), second.A == first.C: two dense layers as one launch."""
-    if GEMM_HOOK is not None:
-        GEMM_HOOK(GemmDesc.from_buffer_copy(first))
-        GEMM_HOOK(GemmDesc.from_buffer_copy(second))
-    lib().gemm_chain2(ctypes.byref(first), ctypes.byref(second), current_stream() if stream is None else stream)
+    s = current_stream() if stream is None else stream
+    run = lambda: lib().gemm_chain2(ctypes.byref(first), ctypes.byref(second), s)
+    _record((first, second), run)
+    run()
 
 
 def gemm_pair(weight_grad, input_grad, stream=None, defer=None):
     """two descriptors built with gemm(..., launch=False): a layer's dW and dX products as one launch.
     defer: a SplitkJob for the weight gradient's split-K reduction (see gemm)."""
-    if GEMM_HOOK is not None:       # one entry: the two products go out as one launch
-        GEMM_HOOK((GemmDesc.from_buffer_copy(weight_grad), GemmDesc.from_buffer_copy(input_grad)))
     s = current_stream() if stream is None else stream
     if defer is not None:
-        lib().gemm_pair_defer(ctypes.byref(weight_grad), ctypes.byref(input_grad), ctypes.byref(defer), s)
+        run = lambda: lib().gemm_pair_defer(ctypes.byref(weight_grad), ctypes.byref(input_grad), ctypes.byref(defer), s)
     else:
-        lib().gemm_pair(ctypes.byref(weight_grad), ctypes.byref(input_grad), s)
+        run = lambda: lib().gemm_pair(ctypes.byref(weight_grad), ctypes.byref(input_grad), s)
+    _record((weight_grad, input_grad), run)        # one entry: the two products go out as one launch
+    run()

@@ -35,6 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int kThreads = 256;
 constexpr int kTabChunk = 2048;     // longest K chunk of a table-addressed (implicit im2col) launch of the fast kernel
+constexpr int kWinChunk = 1024;     // longest reduction of a windowed-gather launch (three LDS tables of this length)
 
 struct OperandDev {
     const void *base;
@@ -65,6 +66,14 @@ struct GemmDev {
                                 // tower * batch_stride + n % fold): towers that share A run as ONE GEMM
     float a_div;
     unsigned long long *stamps; // diagnostics (rlx_gemm_debug_stamps): [workgroup][4] wall-clock ticks, or null
+    // windowed gather (A_WIN kernels: the input gradient of a convolution computed directly, rlx_conv_input_grad):
+    // A(m, k) = a.base[a.tab_o[m] + a.tab_r[k]] where the window test passes, else 0
+    const int *win_row_yx;      // [M]  (Y << 16) | X of row m; rows that do not exist carry Y = 0x7fff
+    const int *win_k_jyx;       // [K]  (jy << 16) | jx of reduction index k
+    const int *win_b_koff;      // [phases][K] offset of B's reduction index k (the weights' tap layout)
+    const int *win_c_row;       // [M]  element offset of C's (and the derivative operand's) row m, or -1: no such row
+    int win_oh, win_ow;         // the window: valid iff 0 <= Y - jy < win_oh and 0 <= X - jx < win_ow
+    int win_rows_per_phase;     // rows [ph * rpp, (ph + 1) * rpp) use B table ph (rpp is a multiple of the tile height)
 };
 
 // two-level batch offset (paired online/target passes over multi-stream layers): b = bo * inner + bi
@@ -329,10 +338,15 @@ struct FastTile {
 // before the epilogue.  A 32 x 64 (KW = 2) or 32 x 32 (KW = 4) tile gives a mid-sized problem 2-4x the workgroups of
 // the 64 x 64 tiling WITHOUT partial sums in memory and a second (reduce) launch: what splitting K over workgroups
 // costs on this chip is the launch boundary behind several MB of freshly written partials, not the additions.
-template <int BM, int BN, int TM, int TN, int KW, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
+// A_WIN: windowed gather — see GemmDev::win_*; needs A_TAB, both operands vectorised along the reduction index and
+// one accumulator tile per wave.  tab_s then holds three tables of kWinChunk entries: A offsets, (jy, jx), B offsets.
+template <int BM, int BN, int TM, int TN, int KW, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB,
+          bool A_WIN = false>
 __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, const int by, const int bz,
                                                const int gdx, const int gdy, float *const smem, float *const lut,
                                                int *const tab_s) {
+    static_assert(!A_WIN || (A_TAB && A_VEC_RED && B_VEC_RED && !A_U8 && TM == 1 && TN == 1),
+                  "the windowed gather is a table-addressed NT product with one accumulator tile per wave");
     constexpr int WN = BN / (32 * TN);
     constexpr int WMN = (BM / (32 * TM)) * WN;
     static_assert(WMN * KW == 4, "a workgroup is 4 waves");
@@ -372,12 +386,16 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
     // the outer index: thread owns outer group mq of reduction rows (kr_p).
     long long a_off_o[A_VEC_RED ? NA : 1];
     int a_kq = 0, a_kr[NA];
+    int a_yx[A_WIN ? NA : 1];
+    int *const tab2_s = A_WIN ? tab_s + kWinChunk : tab_s, *const tabb_s = A_WIN ? tab_s + 2 * kWinChunk : tab_s;
+    const int *const btab = A_WIN ? g.win_b_koff + (size_t)(m0 / g.win_rows_per_phase) * g.K : nullptr;
     if (A_VEC_RED) {
         a_kq = (tid % (BK / 4)) * 4;
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             const int row = min(m0 + (tid + p * kThreads) / (BK / 4), g.M - 1);
             a_off_o[p] = A_TAB ? (long long)g.a.tab_o[row] : (long long)row * g.a.stride_o;
+            if (A_WIN) a_yx[p] = g.win_row_yx[row];
         }
     } else {
         const int mq = min(m0 + (tid % (BM / 4)) * 4, g.M - 4);
@@ -406,8 +424,26 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
     // one drains the whole in-order load queue (s_waitcnt vmcnt) — the operand loads in flight included — so the
     // main loop reads the chunk's offsets from LDS (staged once per workgroup; LDS has its own counter); only the
     // two slabs the prologue loads look their offsets up in global memory, all at once.
-    constexpr int NR = A_VEC_RED ? 1 : NA;
+    // (windowed gather: whether an element exists depends on the row AND the reduction index, so a register set
+    // carries one absolute offset and one mask per row it loads)
+    constexpr int NR = A_WIN ? NA : (A_VEC_RED ? 1 : NA);
     auto a_red_offsets = [&](int k0, long long (&off)[NR], float (&msk)[NR], bool from_lds) {
+        if (A_WIN) {
+            const int r = k0 + a_kq;
+            const int rc = min(r, kend - 4);
+            const int ko = from_lds ? tab_s[rc - kbeg] : g.a.tab_r[rc];
+            const int jyx = from_lds ? tab2_s[rc - kbeg] : g.win_k_jyx[rc];
+            const int jy = jyx >> 16, jx = jyx & 0xffff;
+#pragma unroll
+            for (int p = 0; p < NA; ++p) {
+                const int Y = a_yx[p] >> 16, X = a_yx[p] & 0xffff;
+                const bool ok = r < kend && (unsigned)(Y - jy) < (unsigned)g.win_oh &&
+                                (unsigned)(X - jx) < (unsigned)g.win_ow;
+                msk[p] = ok ? 1.f : 0.f;
+                off[p] = ok ? a_off_o[p] + (long long)ko : 0;
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NR; ++p) {
             const int r = k0 + (A_VEC_RED ? a_kq : a_kr[p]);
@@ -420,17 +456,19 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
     auto load_a = [&](const long long (&off)[NR], a_raw_t (&ra)[NA]) {
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
-            const long long o = (A_VEC_RED ? a_off_o[p] : a_off_o[0]) + off[A_VEC_RED ? 0 : p];
+            const long long o = A_WIN ? off[p] : (A_VEC_RED ? a_off_o[p] : a_off_o[0]) + off[A_VEC_RED ? 0 : p];
             load_raw(ra[p], abase, o);
         }
     };
-    auto load_b = [&](int k0, float4 (&rb)[NB], float (&msk)[NB]) {
+    auto load_b = [&](int k0, float4 (&rb)[NB], float (&msk)[NB], bool from_lds) {
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
             const int r = k0 + (B_VEC_RED ? b_kq : b_kr[p]);
             const int rc = min(r, kend - (B_VEC_RED ? 4 : 1));
             msk[p] = r < kend ? 1.f : 0.f;
-            const long long o = (B_VEC_RED ? b_off_o[p] : b_off_o[0]) + (long long)rc * g.b.stride_r;
+            const long long ro = A_WIN ? (long long)(from_lds ? tabb_s[rc - kbeg] : btab[rc])
+                                       : (long long)rc * g.b.stride_r;
+            const long long o = (B_VEC_RED ? b_off_o[p] : b_off_o[0]) + ro;
             rb[p] = *reinterpret_cast<const float4 *>(bbase + o);
         }
     };
@@ -440,7 +478,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             float4 v;
-            const float mk = ma[A_VEC_RED ? 0 : p];
+            const float mk = ma[(A_VEC_RED && !A_WIN) ? 0 : p];
             v = raw_to_float4(ra[p], lut);
             v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
             if (A_VEC_RED) {
@@ -499,10 +537,16 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
         if (A_TAB) {
             for (int i = tid; i < kend - kbeg; i += kThreads) tab_s[i] = g.a.tab_r[kbeg + i];
         }
+        if (A_WIN) {
+            for (int i = tid; i < kend - kbeg; i += kThreads) {
+                tab2_s[i] = g.win_k_jyx[kbeg + i];
+                tabb_s[i] = btab[kbeg + i];
+            }
+        }
         load_a(ao0, ra0);
-        load_b(kbeg, rb0, mb0);
+        load_b(kbeg, rb0, mb0, false);
         load_a(ao1, ra1);
-        load_b(kbeg + BK, rb1, mb1);
+        load_b(kbeg + BK, rb1, mb1, false);
         store(0, ra0, ma0, rb0, mb0);
         __syncthreads();
         if (stamp) stamp[1] = wall_clock64();
@@ -538,7 +582,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
                         float (&mb_f)[NB]) {
             a_red_offsets(kbeg + (s + 2) * BK, ao_f, ma_f, true);
             load_a(ao_f, ra_f);
-            load_b(kbeg + (s + 2) * BK, rb_f, mb_f);
+            load_b(kbeg + (s + 2) * BK, rb_f, mb_f, true);
             __builtin_amdgcn_sched_barrier(0);        // keep the requests AHEAD of this slab's MFMAs
             mfma_slab(s & 1);
             store((s & 1) ^ 1, ra_n, ma_n, rb_n, mb_n);
@@ -612,6 +656,14 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
         float *stage = smem + wid * (32 * 33);
         float *dst_base = ws ? ws : c;
         const long long ld = ws ? (long long)g.N : g.ldc;
+        int crow[4] = {0, 0, 0, 0};      // A_WIN: where the lane's four rows of the tile live in C (and in aux), or -1
+        if (A_WIN) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int erow = m0 + wm * 32 + ((it * 64 + lane) >> 3);
+                crow[it] = epi && erow < g.M ? g.win_c_row[erow] : -1;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -633,7 +685,10 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
                 for (int it = 0; it < 4; ++it) {
                     const int erow = m0 + wm * (32 * TM) + 32 * i + ((it * 64 + lane) >> 3);
                     av4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!ws && aux && ecol_ok && erow < g.M)
+                    if (A_WIN) {
+                        if (aux && ecol_ok && crow[it] >= 0)
+                            av4[it] = *reinterpret_cast<const float4 *>(aux + crow[it] + ecol);
+                    } else if (!ws && aux && ecol_ok && erow < g.M)
                         av4[it] = *reinterpret_cast<const float4 *>(aux + (size_t)erow * g.aux_ld + ecol);
                 }
                 __syncthreads();
@@ -650,9 +705,10 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
                     const int row = m0 + wm * (32 * TM) + 32 * i + rl;
                     const int col = n0 + wn * (32 * TN) + 32 * j + c4;
                     if (!epi || row >= g.M || col >= g.N) continue;
+                    if (A_WIN && crow[it] < 0) continue;
                     const float *sp = stage + rl * 33 + c4;
                     float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
-                    float *dst = dst_base + (size_t)row * ld + col;
+                    float *dst = A_WIN ? c + crow[it] + col : dst_base + (size_t)row * ld + col;
                     const int tw = etw, cl = ecl;
                     if (!ws && g.fold) dst = g.c + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
                     if (!ws) {
@@ -710,6 +766,17 @@ __global__ void __launch_bounds__(kThreads, (TM * TN == 1 ? 3 : 1)) gemm_fast_ke
     __shared__ int tab_s[A_TAB ? kTabChunk : 1];     // reduction-index offsets of this workgroup's K chunk
     gemm_fast_body<BM, BN, TM, TN, KW, A_VEC_RED, A_U8, B_VEC_RED, A_TAB>(g, blockIdx.x, blockIdx.y, blockIdx.z,
                                                                            gridDim.x, gridDim.y, smem, lut, tab_s);
+}
+
+// The input gradient of a convolution as ONE product (rlx_conv_input_grad): a windowed gather of dY against the
+// weights' taps — see GemmDev::win_*.
+template <int BM, int BN, int KW>
+__global__ void __launch_bounds__(kThreads, 3) gemm_win_kernel(const GemmDev g) {
+    __shared__ __attribute__((aligned(16))) float smem[FastTile<BM, BN, 1, 1>::kSmemFloats];
+    __shared__ float lut[1];
+    __shared__ int tab_s[3 * kWinChunk];
+    gemm_fast_body<BM, BN, 1, 1, KW, true, false, true, true, true>(g, blockIdx.x, blockIdx.y, blockIdx.z,
+                                                                      gridDim.x, gridDim.y, smem, lut, tab_s);
 }
 
 // Two INDEPENDENT problems in one launch — a layer's weight gradient (dW = X^T dY) and its input gradient
@@ -1391,6 +1458,41 @@ __global__ void conv_tables_kernel(int *__restrict__ rowbase, int *__restrict__ 
     }
 }
 
+// Tables of the direct input gradient of a convolution (rlx_conv_input_grad).  With stride s the input positions
+// split into s*s phases (py, px) = (iy % s, ix % s); inside a phase, row (b, Y, X) = input position (s*Y + py, s*X + px)
+// receives  sum over taps (jy, jx), ky = py + s*jy, kx = px + s*jx, and channels co of
+//     dY[b, Y - jy, X - jx, co] * W[ky, kx, c, co]        where 0 <= Y - jy < OH and 0 <= X - jx < OW,
+// a stride-1 correlation of dY with the phase's sub-kernel: ONE product with M = phases * Mp rows (Mp = rows of a
+// phase, padded to a multiple of 128 so that no tile straddles two phases), N = C, K = (KH/s)*(KW/s)*Co.
+//   rowbase[m] = ((b*OH + Y)*OW + X)*Co, yx[m] = Y<<16 | X (0x7fff: the row does not exist), crow[m] = offset of the
+//   input position in dX / x, or -1;   koff_a[k] = -(jy*OW + jx)*Co + co, jyx[k] = jy<<16 | jx,
+//   koff_b[phase][k] = (ky*KW + kx)*C*Co + co   (the weights are stored [KH][KW][C][Co]).
+__global__ void conv_dx_tables_kernel(int *__restrict__ rowbase, int *__restrict__ yx, int *__restrict__ crow,
+                                      int *__restrict__ koff_a, int *__restrict__ jyx, int *__restrict__ koff_b,
+                                      int batch, int H, int W, int C, int KH, int KW, int s, int Co, int OH, int OW,
+                                      int Mp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = s * s, Hq = (H + s - 1) / s, Wq = (W + s - 1) / s, Jx = KW / s, K = (KH / s) * Jx * Co;
+    if (t < P * Mp) {
+        const int ph = t / Mp, r = t - ph * Mp, py = ph / s, px = ph - py * s;
+        const int X = r % Wq, Y = (r / Wq) % Hq, b = r / (Wq * Hq);
+        const int iy = s * Y + py, ix = s * X + px;
+        const bool real = r < batch * Hq * Wq && iy < H && ix < W;
+        rowbase[t] = real ? ((b * OH + Y) * OW + X) * Co : 0;
+        yx[t] = real ? (Y << 16) | X : (0x7fff << 16);
+        crow[t] = real ? ((b * H + iy) * W + ix) * C : -1;
+    }
+    if (t < K) {
+        const int tap = t / Co, co = t - tap * Co, jy = tap / Jx, jx = tap - jy * Jx;
+        koff_a[t] = -(jy * OW + jx) * Co + co;
+        jyx[t] = (jy << 16) | jx;
+        for (int ph = 0; ph < P; ++ph) {
+            const int py = ph / s, px = ph - py * s;
+            koff_b[ph * K + t] = ((py + s * jy) * KW + (px + s * jx)) * C * Co + co;
+        }
+    }
+}
+
 // col2im as a gather: dX[b,iy,ix,c] = sum over the (ky,kx) whose output position exists of
 // dcol[(b,oy,ox)][(ky,kx,c)], multiplied by act'(x) of the layer that produced x.
 // VEC = 4: one thread per 4 channels (C % 4 == 0), 16-byte loads; 32-bit index arithmetic.
@@ -2019,6 +2121,89 @@ int rlx_conv_tables(int *rowbase, int *koff, int batch, int H, int W, int C, int
     const int n = M > K ? M : K;
     conv_tables_kernel<<<(n + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
         rowbase, koff, batch, H, W, C, KH, KW, stride, OH, OW);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+static int conv_dx_geometry(int batch, int H, int W, int C, int KH, int KW, int stride, int Co, int *OH, int *OW,
+                            int *Mp, int *K, long long *ints) {
+    RLX_REQUIRE(batch > 0 && H >= KH && W >= KW && C > 0 && Co > 0 && KH > 0 && KW > 0 && stride > 0,
+                "rlx_conv_input_grad: bad convolution geometry");
+    RLX_REQUIRE(KH % stride == 0 && KW % stride == 0,
+                "rlx_conv_input_grad: the kernel (%d x %d) must be a multiple of the stride (%d)", KH, KW, stride);
+    RLX_REQUIRE(C % 4 == 0 && Co % 4 == 0, "rlx_conv_input_grad: channel counts must be multiples of 4 (C %d, Co %d)", C, Co);
+    *OH = (H - KH) / stride + 1;
+    *OW = (W - KW) / stride + 1;
+    const int Hq = (H + stride - 1) / stride, Wq = (W + stride - 1) / stride;
+    const long long rows = (long long)batch * Hq * Wq;
+    *Mp = (int)((rows + 127) / 128 * 128);
+    *K = (KH / stride) * (KW / stride) * Co;
+    RLX_REQUIRE(*K <= kWinChunk, "rlx_conv_input_grad: reduction of %d exceeds %d", *K, kWinChunk);
+    const long long P = (long long)stride * stride;
+    RLX_REQUIRE(P * *Mp < (1LL << 30) && (long long)batch * H * W * C < (1LL << 31) && H < 0x7fff && W < 0x7fff,
+                "rlx_conv_input_grad: tensor too large for 32-bit tables");
+    *ints = 3 * P * *Mp + 2LL * *K + P * *K;
+    return RLX_OK;
+}
+
+int rlx_conv_input_grad_tables_ints(int batch, int H, int W, int C, int KH, int KW, int stride, int Co,
+                                    long long *ints_host) {
+    RLX_REQUIRE(ints_host, "rlx_conv_input_grad_tables_ints: null pointer");
+    int OH, OW, Mp, K;
+    return conv_dx_geometry(batch, H, W, C, KH, KW, stride, Co, &OH, &OW, &Mp, &K, ints_host);
+}
+
+int rlx_conv_input_grad_tables(int *tables, int batch, int H, int W, int C, int KH, int KW, int stride, int Co,
+                               void *stream) {
+    RLX_REQUIRE(tables, "rlx_conv_input_grad_tables: null pointer");
+    int OH, OW, Mp, K;
+    long long ints;
+    const int rc = conv_dx_geometry(batch, H, W, C, KH, KW, stride, Co, &OH, &OW, &Mp, &K, &ints);
+    if (rc != RLX_OK) return rc;
+    const int P = stride * stride, M = P * Mp;
+    int *rowbase = tables, *yx = tables + M, *crow = tables + 2 * M, *koff_a = tables + 3 * M, *jyx = koff_a + K,
+        *koff_b = jyx + K;
+    const int n = M > K ? M : K;
+    conv_dx_tables_kernel<<<(n + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
+        rowbase, yx, crow, koff_a, jyx, koff_b, batch, H, W, C, KH, KW, stride, Co, OH, OW, Mp);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_conv_input_grad(const float *dy, const float *weights, float *dx, const float *x_out, int deriv_kind,
+                        const int *tables, int batch, int H, int W, int C, int KH, int KW, int stride, int Co,
+                        int towers, long long dy_tower_stride, long long w_tower_stride, long long dx_tower_stride,
+                        void *stream) {
+    RLX_REQUIRE(dy && weights && dx && tables, "rlx_conv_input_grad: null pointer");
+    RLX_REQUIRE(towers > 0 && deriv_kind >= 0 && deriv_kind <= 2, "rlx_conv_input_grad: bad arguments");
+    int OH, OW, Mp, K;
+    long long ints;
+    const int rc = conv_dx_geometry(batch, H, W, C, KH, KW, stride, Co, &OH, &OW, &Mp, &K, &ints);
+    if (rc != RLX_OK) return rc;
+    RLX_REQUIRE(aligned16(dy) && aligned16(weights) && aligned16(dx) && (!x_out || aligned16(x_out)) &&
+                dy_tower_stride % 4 == 0 && w_tower_stride % 4 == 0 && dx_tower_stride % 4 == 0,
+                "rlx_conv_input_grad: operands must be 16-byte aligned");
+    const int P = stride * stride, M = P * Mp;
+    GemmDev g = {};
+    g.M = M; g.N = C; g.K = K;
+    g.a.base = dy; g.a.tab_o = tables; g.a.tab_r = tables + 3 * M; g.a.batch_stride = dy_tower_stride; g.a.vec_ok = 1;
+    g.b.base = weights; g.b.stride_o = Co; g.b.stride_r = 1; g.b.batch_stride = w_tower_stride; g.b.vec_ok = 1;
+    g.win_row_yx = tables + M; g.win_c_row = tables + 2 * M;
+    g.win_k_jyx = tables + 3 * M + K; g.win_b_koff = tables + 3 * M + 2 * K;
+    g.win_oh = OH; g.win_ow = OW; g.win_rows_per_phase = Mp;
+    g.c = dx; g.ldc = C; g.c_batch_stride = dx_tower_stride;
+    g.aux = deriv_kind != RLX_ACT_NONE ? x_out : nullptr; g.aux_ld = C; g.aux_batch_stride = dx_tower_stride;
+    RLX_REQUIRE(deriv_kind == RLX_ACT_NONE || x_out, "rlx_conv_input_grad: the activation derivative needs x_out");
+    g.deriv = deriv_kind; g.act = RLX_ACT_NONE;
+    g.inner = 1 << 30; g.splits = 1; g.kchunk = K; g.vec_epi = 1; g.a_div = 1.f;
+    hipStream_t s = rlx::as_stream(stream);
+    if (C <= 32) {
+        gemm_win_kernel<128, 32, 1><<<dim3((C + 31) / 32, M / 128, towers), kThreads, 0, s>>>(g);
+    } else if ((long long)(M / 64) * ((C + 63) / 64) * towers >= 192) {
+        gemm_win_kernel<64, 64, 1><<<dim3((C + 63) / 64, M / 64, towers), kThreads, 0, s>>>(g);
+    } else {
+        gemm_win_kernel<32, 64, 2><<<dim3((C + 63) / 64, M / 32, towers), kThreads, 0, s>>>(g);
+    }
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

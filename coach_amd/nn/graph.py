@@ -124,6 +124,7 @@ PAIR_GRADIENT_GEMMS = True
 # thin-kernel launches, and measured SLOWER twice (C4 -34 % with predicated loads, -17 % branch-free:
 # profiles/r02_ab_gemm_pair.txt — every column tile recomputes the hidden rows) — opt-in, RLX_GEMM_CHAIN=1
 CHAIN_DENSE_LAYERS = os.environ.get("RLX_GEMM_CHAIN", "0") == "1"
+DIRECT_CONV_INPUT_GRAD = True     # tests flip it to compare with the column-matrix path
 
 
 class Workspace:
@@ -546,11 +547,30 @@ class Conv2d(Layer):
         # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
         return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag), act=self.act)
 
+    def _dx_tables(self, ctx, B):
+        key = ("convdxtab", self.name, B)
+        if key not in ctx.cache:
+            import ctypes
+            n = ctypes.c_longlong()
+            ctx.lib.conv_input_grad_tables_ints(B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co,
+                                                ctypes.byref(n))
+            tab = torch.empty(n.value, dtype=torch.int32, device=ctx.device)
+            ctx.lib.conv_input_grad_tables(tab, B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, ctx.stream)
+            ctx.cache[key] = tab
+        return ctx.cache[key]
+
+    def direct_input_grad(self):
+        """the input gradient as ONE product gathering dY (rlx_conv_input_grad) instead of the column matrix
+        dcol = dz W^T + col2im: needs the kernel to be a multiple of the stride and 4-aligned channel counts."""
+        return DIRECT_CONV_INPUT_GRAD and self.KH % self.S == 0 and self.KW % self.S == 0 and self.C % 4 == 0 and \
+            self.Co % 4 == 0 and (self.KH // self.S) * (self.KW // self.S) * self.Co <= 1024
+
     def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
         t0, T = self._range(t0, nt)
         B, p = x.rows, self.params
         overlap = overlap and ctx.overlap
-        pairing = need_dx and need_dw and not overlap and PAIR_GRADIENT_GEMMS
+        direct = need_dx and self.direct_input_grad()
+        pairing = need_dx and need_dw and not overlap and PAIR_GRADIENT_GEMMS and not direct
         M = B * self.OH * self.OW
         rb, ko = self._tables(ctx, B)
         dz = y.grad
@@ -583,7 +603,14 @@ class Conv2d(Layer):
                 ctx.on_side(dw)          # also when this is the first layer: it overlaps the layers above
             elif not pairing:
                 dw(ctx.ws.splitk)
-        if need_dx:
+        if direct:
+            assert x.towers == T
+            dx, lower = x.ensure_grad(), x.act
+            _rlx.conv_input_grad(dz, p.w(self.kname, t0, weights), dx, x.data if lower else None, lower,
+                                 self._dx_tables(ctx, B), B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T,
+                                 M * self.Co, p.stride(self.kname), B * self.H * self.W * self.C, ctx.stream)
+            x.grad_is_dz = lower is not None
+        elif need_dx:
             assert x.towers == T
             dcol = ctx.buffer(self.name + "/dcol", (T, M, self.K))
             dxd = _rlx.gemm(M, self.K, self.Co, dz, p.w(self.kname, t0, weights), dcol, b_strides=(1, self.Co),

@@ -313,6 +313,26 @@ typedef struct rlx_gemm_desc {
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
 int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host);
+
+/* Input gradient of a VALID-padding NHWC convolution (tf.gradients of tf.layers.conv2d,
+ * architectures/tensorflow_components/layers.py:108-121, architecture.py:187-220) as ONE product that gathers dY
+ * directly — no column matrix in memory, no col2im pass:
+ *   dx[t][b, iy, ix, c] = act'(x_out[t][b, iy, ix, c]) * sum_{ky, kx, co : iy = s*oy + ky, ix = s*ox + kx}
+ *                         dy[t][b, oy, ox, co] * weights[t][ky, kx, c, co]
+ * for `towers` independent networks (tower strides in elements).  The s*s phases (iy % s, ix % s) of the input are the
+ * row blocks of one GEMM with M = s*s*rows, N = C, K = (KH/s)*(KW/s)*Co whose A operand is a windowed gather of dy
+ * (fp32 MFMA, exact products).  Needs KH % s == 0, KW % s == 0, C % 4 == 0, Co % 4 == 0 and K <= 1024.
+ * `tables`: int32 device buffer of rlx_conv_input_grad_tables_ints(...) entries filled once per geometry by
+ * rlx_conv_input_grad_tables.  deriv_kind != 0 multiplies by the activation derivative of the producing layer's OUTPUT
+ * x_out (same layout as dx). */
+int rlx_conv_input_grad_tables_ints(int batch, int H, int W, int C, int KH, int KW, int stride, int Co,
+                                    long long *ints_host);
+int rlx_conv_input_grad_tables(int *tables, int batch, int H, int W, int C, int KH, int KW, int stride, int Co,
+                               void *stream);
+int rlx_conv_input_grad(const float *dy, const float *weights, float *dx, const float *x_out, int deriv_kind,
+                        const int *tables, int batch, int H, int W, int C, int KH, int KW, int stride, int Co,
+                        int towers, long long dy_tower_stride, long long w_tower_stride, long long dx_tower_stride,
+                        void *stream);
 /* A layer's weight gradient (dW = X^T dY) and input gradient (dX = dY W^T) — two independent products of the same
  * dY — as ONE launch when both take the 64x64 tiled kernel (two launches otherwise; RLX_NO_GEMM_PAIR=1 forces that).
  * Each descriptor is exactly what rlx_gemm would get; when both split K they need disjoint workspaces. */

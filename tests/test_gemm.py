@@ -378,3 +378,79 @@ def test_deferred_weight_gradient_reductions_equal_immediate_ones(rlx, dev):
     np.testing.assert_array_equal(out[True][1], out[False][1])
     assert np.abs(out[True][0]).sum() > 0
     assert launches[True] == launches[False] + 1             # host calls: + the one reduce call (device launches: fewer)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C,KH,KW,s,Co,T", [
+    (64, 9, 9, 64, 3, 3, 1, 64, 2),      # Atari conv3 (C2 minibatch, two towers): 32 x 64 tiles, slab split over the waves
+    (64, 20, 20, 32, 4, 4, 2, 64, 2),    # conv2: four phases, N = 32 -> 128 x 32 tiles
+    (8, 9, 9, 64, 3, 3, 1, 64, 1),
+    (5, 21, 19, 8, 4, 2, 2, 12, 1),      # odd sizes: phases of different extent, rows that do not exist, padding rows
+    (3, 12, 12, 4, 6, 6, 3, 20, 2),      # stride 3
+    (256, 9, 9, 64, 3, 3, 1, 64, 1),     # a value-pass sized batch: 64 x 64 tiles
+])
+def test_conv_input_gradient_direct(rlx, dev, B, H, W, C, KH, KW, s, Co, T):
+    """rlx_conv_input_grad (the windowed gather of dY against the kernel taps, one product) against the fp64 definition
+    dX = col2im(dY W^T) * tanh'(x), per tower."""
+    import ctypes
+    import torch
+    rng = np.random.RandomState(H * W + C + B)
+    OH, OW = (H - KH) // s + 1, (W - KW) // s + 1
+    K = KH * KW * C
+    x = np.tanh(rng.randn(T, B, H, W, C)).astype(np.float32)
+    Wt = (rng.randn(T, K, Co) / np.sqrt(K)).astype(np.float32)
+    dY = rng.randn(T, B * OH * OW, Co).astype(np.float32)
+    n = ctypes.c_longlong()
+    rlx.conv_input_grad_tables_ints(B, H, W, C, KH, KW, s, Co, ctypes.byref(n))
+    tab = torch.empty(n.value, dtype=torch.int32, device=dev)
+    rlx.conv_input_grad_tables(tab, B, H, W, C, KH, KW, s, Co, 0)
+    xd, Wd, dYd = dev_tensor(x, dev), dev_tensor(Wt, dev), dev_tensor(dY, dev)
+    dx = torch.full((T, B, H, W, C), 9.0, dtype=torch.float32, device=dev)
+    rlx.conv_input_grad(dYd, Wd, dx, xd, 2, tab, B, H, W, C, KH, KW, s, Co, T, B * OH * OW * Co, K * Co,
+                        B * H * W * C, 0)
+    for t in range(T):
+        dcol = (dY[t].astype(np.float64) @ Wt[t].astype(np.float64).T).reshape(B, OH, OW, KH, KW, C)
+        ref = np.zeros((B, H, W, C))
+        for ky in range(KH):
+            for kx in range(KW):
+                ref[:, ky:ky + s * OH:s, kx:kx + s * OW:s, :] += dcol[:, :, :, ky, kx, :]
+        ref *= 1 - x[t].astype(np.float64) ** 2
+        np.testing.assert_allclose(dx[t].cpu().numpy(), ref, **_tol(Co * 16))
+    # without the derivative operand
+    rlx.conv_input_grad(dYd, Wd, dx, None, 0, tab, B, H, W, C, KH, KW, s, Co, T, B * OH * OW * Co, K * Co,
+                        B * H * W * C, 0)
+    np.testing.assert_allclose(dx[T - 1].cpu().numpy(), ref / (1 - x[T - 1].astype(np.float64) ** 2), **_tol(Co * 16))
+
+
+@pytest.mark.gpu
+def test_conv_layer_backward_direct_equals_column_matrix_path(rlx, dev):
+    """Conv2d.backward with the direct input gradient against the dcol + col2im path (weight gradients bit for bit: the
+    same launch; input gradients to summation-order tolerance)."""
+    import torch
+    from coach_amd.nn import graph as G
+    rng = np.random.RandomState(2)
+    B, T = 64, 2
+    out = {}
+    for direct in (True, False):
+        params = G.FlatParams()
+        layer = G.Conv2d(params, "c2", (20, 20, 32), 64, 4, 2, "tanh", T)
+        params.finalize(dev)
+        layer.initialize(np.random.RandomState(5))
+        ctx = G.Context(dev)
+        if direct:
+            x_np = np.tanh(rng.randn(T, B, 20 * 20 * 32)).astype(np.float32)
+        x = G.Tensor(dev_tensor(x_np, dev), B, x_np.shape[2], T, act="tanh")
+        y = layer.forward(ctx, x, tag="t")
+        if direct:
+            dy_np = rng.randn(*y.data.shape).astype(np.float32)
+        y.ensure_grad().copy_(dev_tensor(dy_np, dev))
+        G.DIRECT_CONV_INPUT_GRAD = direct
+        try:
+            layer.backward(ctx, x, y, need_dx=True)
+        finally:
+            G.DIRECT_CONV_INPUT_GRAD = True
+        torch.cuda.synchronize()
+        out[direct] = (params.grads.clone().cpu().numpy(), x.grad.clone().cpu().numpy())
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-6 * np.abs(out[False][0]).max())
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=2e-5, atol=2e-5)
+    assert np.abs(out[True][1]).sum() > 0
