@@ -75,7 +75,7 @@ class PrioritizedExperienceReplay(ExperienceReplay):
         self.next_leaf_idx_to_write = 0
         self._list_len = 0
         self._per = {}
-        self._outstanding = 0        # batches drawn but not collated yet (their slot numbers)
+        self._live_slots = set()     # draws made but not collated yet: each owns its idx / rows / weight buffers
         self.lib.per_init(self.sum_tree, self.min_tree, self.max_tree, self.power_of_2_size,
                           self.max_priority, _rlx.current_stream())
 
@@ -89,7 +89,7 @@ class PrioritizedExperienceReplay(ExperienceReplay):
     def clean(self):                                       # :285-299
         super().clean()
         self._list_len = 0
-        self._outstanding = 0
+        self._live_slots = set()
         self.next_leaf_idx_to_write = 0
         self.lib.per_init(self.sum_tree, self.min_tree, self.max_tree, self.power_of_2_size,
                           self.max_priority, _rlx.current_stream())
@@ -129,8 +129,10 @@ class PrioritizedExperienceReplay(ExperienceReplay):
                              "transitions yet. There are currently {} transitions"
                              .format(self.num_transitions()))
         u = np.array([random.random() for _ in range(size)])
-        slot = self._outstanding
-        self._outstanding += 1
+        slot = 0
+        while slot in self._live_slots:      # the lowest slot no outstanding draw owns (any draw / collate interleaving)
+            slot += 1
+        self._live_slots.add(slot)
         p = self._per_buffers(size, slot)
         p["u_stage"].push(u)
         self.lib.per_sample(self.sum_tree, self.min_tree, self.power_of_2_size, p["u"], size,
@@ -143,7 +145,12 @@ class PrioritizedExperienceReplay(ExperienceReplay):
     def collate(self, drawn, size):
         """The payload gather of a drawn batch (Batch collation, core_types.py:488-649).  Slot 0's
         buffers are the ones a captured update graph reads; a later slot is copied into them."""
-        self._outstanding = max(0, self._outstanding - 1)
+        if drawn not in self._live_slots:
+            raise ValueError("collate() of a draw that is not outstanding (slot %r)" % (drawn,))
+        if drawn != 0 and 0 in self._live_slots:
+            raise ValueError("slot 0's buffers are what the captured update reads: the draw that owns them must be "
+                             "collated before a later one")
+        self._live_slots.discard(drawn)
         p = self._per_buffers(size, 0)
         if drawn != 0:
             q = self._per_buffers(size, drawn)

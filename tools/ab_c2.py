@@ -1,0 +1,65 @@
+"""Same-box A/B of the C2 minibatch update (bench.py's agent): us per update with the round-3 changes switched off one
+at a time — direct convolution input gradients, deferred split-K reductions.  Variants are measured alternately in ONE
+process so that box-to-box differences (25 % between boxes of the pool) cancel.  python tools/ab_c2.py [rounds]"""
+import json
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+class _Dist(object):
+    rank, world_size, enabled = 0, 1, False
+
+    def barrier(self):
+        pass
+
+
+def build(direct, defer):
+    import bench
+    from coach_amd.nn import graph as G
+    G.DIRECT_CONV_INPUT_GRAD = direct
+    agent = bench.build_agent(torch.device("cuda:0"), _Dist())
+    if not defer:
+        agent.networks["main"].ctx.begin_deferring = lambda: False
+    agent._ab = (direct, defer)
+    return agent
+
+
+def train_ms(agent):
+    from coach_amd.nn import graph as G
+    G.DIRECT_CONV_INPUT_GRAD = agent._ab[0]
+    for _ in range(agent.steps_per_phase):
+        agent.act()
+    agent.networks["main"].update_target(1.0)
+    agent.fill_advantages()
+    order = list(range(agent.memory.num_transitions()))
+    random.shuffle(order)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    agent.train_network(order, agent.ap.algorithm.optimization_epochs)
+    e1.record()
+    agent.post_training_commands()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def main(rounds=4):
+    variants = {"all on": (True, True), "column-matrix dX": (False, True), "per-layer reduces": (True, False),
+                "both off (call 3 state)": (False, False)}
+    agents = {k: build(*v) for k, v in variants.items()}
+    for a in agents.values():
+        for _ in range(3):
+            train_ms(a)
+    res = {k: [] for k in agents}
+    for _ in range(rounds):
+        for k, a in agents.items():
+            res[k].append(train_ms(a))
+    out = {k: {"us_per_update": round(1e3 * min(v) / 320, 1), "all": [round(1e3 * x / 320, 1) for x in v]} for k, v in res.items()}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 4)
