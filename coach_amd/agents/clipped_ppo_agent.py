@@ -494,7 +494,47 @@ class ClippedPPOAgent(object):
             return self.mb_obs[:m]
         return mem.gather_states(rows, m, self.mb_obs[:m])
 
-    def _minibatch_fb(self, m, clip_rescaler, stop_after_dense=False, i=0):
+    def _gather_epoch(self, n):
+        """The whole epoch's training set in minibatch order with TWO launches (the epoch's permutation is in perm_dev
+        before its first minibatch runs): minibatch i then reads rows [i*B, i*B + m) of these buffers in place — 2
+        launches per epoch instead of 2 per minibatch (a launch costs ~4.6 us here, as much as the gather itself)."""
+        mem, s = self.memory, _rlx.current_stream()
+        e = self._epoch_buffers()
+        cols = [(mem.dataset_rows(), e["rows"]), (self.ds_action, e["action"]), (self.ds_adv, e["adv"]),
+                (self.ds_vtarget, e["vtarget"]), (self.ds_old_probs, e["old"])]
+        if self.continuous:
+            cols.append((self.ds_old_std, e["old_std"]))
+        if self.norm is not None:
+            cols.append((self.ds_obs, e["obs"]))
+        self.lib.copy_columns(_rlx.make_columns(cols), len(cols), self.perm_dev[:n], None, 0, 0, self.ds_adv.numel(), n, n,
+                              mem.status, s)
+        if self.norm is None:
+            mem.gather_states(e["rows"][:n], n, e["obs"][:n])
+        return e
+
+    def _epoch_buffers(self):
+        e = getattr(self, "_epoch_bufs", None)
+        if e is None:
+            cap, dev, f32 = self.memory.cap, self.device, torch.float32
+            e = self._epoch_bufs = dict(
+                rows=torch.empty(cap, dtype=torch.int32, device=dev),
+                action=torch.empty((cap, self.A) if self.continuous else (cap,), dtype=self.actions.dtype, device=dev),
+                adv=torch.empty(cap, dtype=f32, device=dev), vtarget=torch.empty(cap, dtype=f32, device=dev),
+                old=torch.empty(cap, self.A, dtype=f32, device=dev),
+                old_std=torch.empty(cap, self.A, dtype=f32, device=dev) if self.continuous else None,
+                obs=torch.empty((cap,) + tuple(self.mb_obs.shape[1:]), dtype=self.mb_obs.dtype, device=dev))
+        return e
+
+    def _minibatch_fb(self, m, clip_rescaler, stop_after_dense=False, i=0, epoch=None):
+        """epoch: the buffers of _gather_epoch — minibatch i's rows are already in training order."""
+        if epoch is not None:
+            B = self.ap.network_wrappers["main"].batch_size
+            sl = slice(i * B, i * B + m)
+            old = (epoch["old"][sl], epoch["old_std"][sl]) if self.continuous else epoch["old"][sl]
+            self.networks["main"].forward_backward(epoch["obs"][sl], m, epoch["action"][sl], epoch["adv"][sl],
+                                                   epoch["vtarget"][sl], old, clip_rescaler, self.mb_ratio,
+                                                   self.mb_clipped, stop_after_dense=stop_after_dense)
+            return
         obs = self._gather_minibatch(m, i)
         old = (self.mb_old, self.mb_old_std) if self.continuous else self.mb_old
         self.networks["main"].forward_backward(obs, m, self.mb_action, self.mb_adv, self.mb_vtarget,
@@ -535,8 +575,9 @@ class ClippedPPOAgent(object):
                 # whole epoch is one captured graph (one launch from the host instead of nmb, one graph instead of one
                 # per minibatch index)
                 def epoch():
+                    e = self._gather_epoch(n)
                     for i in range(nmb):
-                        self._minibatch_fb(min(B, n - i * B), clip, i=i)
+                        self._minibatch_fb(min(B, n - i * B), clip, i=i, epoch=e)
                         self._minibatch_finish(scale)
                 self._run(("epoch", n, clip, scale), epoch)
                 results.append(self.scalar_acc / nmb)

@@ -44,6 +44,31 @@ class RunPhase(Enum):                                    # core_types.py:186-190
     UNDEFINED = "Undefined"
 
 
+class Transition(object):
+    """core_types.py:236-340 — the object agents written against the reference store and receive
+    (coach_amd/memories/reference_api.py); the device agents move columns instead and never build one."""
+
+    def __init__(self, state=None, action=None, reward=None, next_state=None, game_over=None, info=None, goal=None):
+        self.state = state if state is not None else {}
+        self.action = action
+        self.reward = reward
+        self.n_step_discounted_rewards = None
+        self.next_state = next_state if next_state is not None else {}
+        self.game_over = game_over
+        self.goal = goal
+        self.info = info if info is not None else {}
+
+    def add_info(self, new_info):
+        if not new_info.keys().isdisjoint(self.info.keys()):
+            raise ValueError("The new info dictionary can not be appended to the existing info dictionary since there "
+                             "are overlapping keys between the two. old keys: {}, new keys: {}"
+                             .format(self.info.keys(), new_info.keys()))
+        self.info.update(new_info)
+
+    def update_info(self, new_info):
+        self.info.update(new_info)
+
+
 class DeviceBatch(object):
     """Batch (core_types.py:405-649) whose columns are device tensors gathered by one launch.
     Accessors keep the reference's names; each returns the device tensor, `.numpy(name)` copies a

@@ -562,8 +562,15 @@ class Conv2d(Layer):
     def direct_input_grad(self):
         """the input gradient as ONE product gathering dY (rlx_conv_input_grad) instead of the column matrix
         dcol = dz W^T + col2im: needs the kernel to be a multiple of the stride and 4-aligned channel counts."""
-        return DIRECT_CONV_INPUT_GRAD and self.KH % self.S == 0 and self.KW % self.S == 0 and self.C % 4 == 0 and \
-            self.Co % 4 == 0 and (self.KH // self.S) * (self.KW // self.S) * self.Co <= 1024
+        if not (DIRECT_CONV_INPUT_GRAD and self.KH % self.S == 0 and self.KW % self.S == 0 and self.C % 4 == 0 and
+                self.Co % 4 == 0 and (self.KH // self.S) * (self.KW // self.S) * self.Co <= 1024):
+            return False
+        # The gather multiplies every input position by every tap of its phase, the border ones by zeros: worth it while
+        # that is < 1.3x the products of the column-matrix form (Atari conv2, 4x4 stride 2 on 20x20: 1.23x, -5 us per
+        # update; conv3, 3x3 stride 1 on 9x9 -> 7x7: 1.65x, +3 us — profiles/r03_ab_gemm_changes.txt)
+        s = self.S
+        executed = s * s * (-(-self.H // s)) * (-(-self.W // s)) * (self.KH // s) * (self.KW // s)
+        return DIRECT_CONV_INPUT_GRAD == "always" or executed <= 1.3 * self.OH * self.OW * self.KH * self.KW
 
     def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
         t0, T = self._range(t0, nt)

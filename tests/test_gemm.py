@@ -444,7 +444,7 @@ def test_conv_layer_backward_direct_equals_column_matrix_path(rlx, dev):
         if direct:
             dy_np = rng.randn(*y.data.shape).astype(np.float32)
         y.ensure_grad().copy_(dev_tensor(dy_np, dev))
-        G.DIRECT_CONV_INPUT_GRAD = direct
+        G.DIRECT_CONV_INPUT_GRAD = "always" if direct else False
         try:
             layer.backward(ctx, x, y, need_dx=True)
         finally:

@@ -268,3 +268,91 @@ def test_hip_image_replay_vs_oracle_atari_shape(rlx, dev):
     for k, r in enumerate(rows):
         assert np.array_equal(hs[k], table[r][0])
         assert np.array_equal(hn[k], table[r][1])
+
+
+# ---------------------------------------------------------------- the reference's memory API over the device replays
+def _ref_transition(i, game_over=False):
+    from coach_amd.core_types import Transition
+    return Transition(state={'observation': np.array([i])}, action=0, reward=float(i),
+                      next_state={'observation': np.array([i + 1])}, game_over=game_over)
+
+
+@pytest.mark.gpu
+def test_reference_api_experience_replay_replays_the_reference_trace(rlx, dev, golden):
+    """tests/golden/make_golden.py::gen_er drives the REFERENCE ExperienceReplay with store(Transition) / sample(size);
+    the same calls on coach_amd.memories.reference_api.ExperienceReplay (the device replay behind the reference's
+    signatures) must hand back the same transitions."""
+    from coach_amd.memories.memory import MemoryGranularity
+    from coach_amd.memories.reference_api import ExperienceReplay
+    fx = golden("er")
+    m = ExperienceReplay((MemoryGranularity.Transitions, 1000), device=dev, observation_shape=(1,))
+    for i in range(50):
+        m.store(_ref_transition(i))
+    np.random.seed(7)
+    batch = m.sample(8)
+    assert [t.reward for t in batch] == fx["appB_rewards"].tolist()
+    assert all(t.state['observation'][0] == t.reward and t.next_state['observation'][0] == t.reward + 1 for t in batch)
+    cap, n, B, every, seed = fx["fifo_meta"].tolist()
+    np.random.seed(seed)
+    m = ExperienceReplay((MemoryGranularity.Transitions, cap), device=dev, observation_shape=(1,))
+    sampled, counts = [], []
+    for i in range(n):
+        m.store(_ref_transition(i))
+        if i % every == every - 1:
+            counts.append(m.num_transitions())
+            sampled.append([t.reward for t in m.sample(B)])
+    assert counts == fx["fifo_counts"].tolist()
+    np.testing.assert_array_equal(np.array(sampled), fx["fifo_rewards"])
+    # the info dict of a stored transition is ONE object across visits (the reference hands out the stored objects)
+    t = m.get_transition(3)
+    t.info['mark'] = 7
+    assert m.get_transition(3).info['mark'] == 7 and m.get_transition(4).info == {}
+    assert m.get_last_transition().reward == float(n - 1) and m.get_transition(cap) is None
+    import random
+    random.seed(1)
+    batches = list(m.get_shuffled_training_data_generator(10))
+    assert len(batches) == cap // 10 and sorted(t.reward for b in batches for t in b) == sorted(
+        set(t.reward for b in batches for t in b))                     # whole batches, no transition twice
+    m.check_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c8", "c50", "c1024"])
+def test_reference_api_prioritized_replay_replays_the_reference_trace(rlx, dev, golden, case):
+    """gen_per's call sequence — store(Transition), update_priorities(list, list), sample(size) reading
+    transition.info['idx'] / ['weight'] — on the reference-API adapter: the same leaves, weights, tree roots,
+    maximal priority and (doubled) num_transitions as the reference memory recorded."""
+    import random
+    from coach_amd.memories.memory import MemoryGranularity
+    from coach_amd.memories.reference_api import PrioritizedExperienceReplay
+    from coach_amd.schedules import ConstantSchedule
+    fx = golden("per")
+    max_size, cap, batch, n0, rounds, spr, seed = fx[case + "_meta"].tolist()
+    alpha, beta, eps = fx[case + "_ab"].tolist()
+    random.seed(seed)
+    np.random.seed(seed)
+    m = PrioritizedExperienceReplay((MemoryGranularity.Transitions, max_size), alpha=alpha, beta=ConstantSchedule(beta),
+                                    device=dev, observation_shape=(1,))
+    assert m.power_of_2_size == cap
+    for i in range(n0):
+        m.store(_ref_transition(i))
+    init_err = np.abs(np.random.randn(min(n0, cap)))
+    np.testing.assert_array_equal(init_err, fx[case + "_init_err"])
+    m.update_priorities(list(range(len(init_err))), list(init_err))
+    for r in range(rounds):
+        for s_ in range(spr):
+            m.store(_ref_transition(n0 + r * spr + s_))
+        assert m.num_transitions() == fx[case + "_ntrans"][r]
+        b = m.sample(batch)
+        idx = [t.info['idx'] for t in b]
+        w = [t.info['weight'] for t in b]
+        assert idx == fx[case + "_idx"][r].tolist()
+        np.testing.assert_allclose(w, fx[case + "_w"][r], rtol=1e-14)
+        err = np.abs(np.random.randn(batch)) * (10.0 if r % 3 == 0 else 1.0)
+        if r == 1:
+            err[0] = 0.0
+        m.update_priorities(idx, list(err))
+        assert m.sum_tree_total() == fx[case + "_sum_root"][r] and m.min_tree_total() == fx[case + "_min_root"][r]
+        assert m.maximal_priority == fx[case + "_maxp"][r]
+    with pytest.raises(ValueError, match="don't match"):
+        m.update_priorities([0, 1], [0.5])

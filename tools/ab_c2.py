@@ -47,8 +47,8 @@ def train_ms(agent):
 
 
 def main(rounds=4):
-    variants = {"all on": (True, True), "column-matrix dX": (False, True), "per-layer reduces": (True, False),
-                "both off (call 3 state)": (False, False)}
+    variants = {"default (direct dX where < 1.3x the products)": (True, True), "direct dX always": ("always", True),
+                "column-matrix dX": (False, True), "per-layer reduces": (True, False)}
     agents = {k: build(*v) for k, v in variants.items()}
     for a in agents.values():
         for _ in range(3):
