@@ -124,7 +124,12 @@ PAIR_GRADIENT_GEMMS = True
 # thin-kernel launches, and measured SLOWER twice (C4 -34 % with predicated loads, -17 % branch-free:
 # profiles/r02_ab_gemm_pair.txt — every column tile recomputes the hidden rows) — opt-in, RLX_GEMM_CHAIN=1
 CHAIN_DENSE_LAYERS = os.environ.get("RLX_GEMM_CHAIN", "0") == "1"
-DIRECT_CONV_INPUT_GRAD = True     # tests flip it to compare with the column-matrix path
+# Input gradient of a convolution as one windowed-gather product (rlx_conv_input_grad) instead of dcol = dz W^T + col2im:
+# True = where its extra products stay < 1.3x, "always", or False.  Off by default: same-box A/Bs of the C2 update
+# (profiles/r03_ab_gemm_changes.txt) show -0 .. +5 us per update on the pool's fast boxes and +25 us on its slow ones
+# (the gather's dependent loads pay the slower memory system twice); it halves the HBM bytes of the convolutions'
+# backward pass, so it stays available for configurations where that is the limit.
+DIRECT_CONV_INPUT_GRAD = False
 
 
 class Workspace:

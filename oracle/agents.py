@@ -47,6 +47,21 @@ class _Base:
             out.setdefault(name + "/bias", {})[tower] = l.b
         return out
 
+    def snapshot_grads(self):
+        return [(l.dW.copy(), l.db.copy()) for _, _, l in self._all_layers()]
+
+    def apply_summed_gradients(self, shards, num_workers, scale_down_by_workers):
+        """apply_gradients of a synchronous data-parallel step (architecture.py:469-521): the workers' gradients are
+        summed (fp32, in rank order) and, when scale_down_gradients_by_number_of_workers_for_sync_training is set,
+        divided by the number of workers (:485-488) before the optimizer step."""
+        layers = [l for _, _, l in self._all_layers()]
+        for i, l in enumerate(layers):
+            dW, db = shards[0][i]
+            for sh in shards[1:]:
+                dW, db = (dW + sh[i][0]).astype(F32), (db + sh[i][1]).astype(F32)
+            l.dW, l.db = dW, db
+        self.adam_step(1.0 / num_workers if scale_down_by_workers else 1.0)
+
     def global_norm(self):
         s = 0.0
         for _, _, l in self._all_layers():
@@ -114,7 +129,9 @@ class ClippedPPOOracle(_Base):
         return copy.deepcopy((self.p_tower, self.p_head, self.log_std))
 
     def train_minibatch(self, obs, actions, advantages, value_targets, old_probs, clip_rescaler=1.0,
-                        grad_scale=1.0):
+                        grad_scale=1.0, apply=True):
+        """apply=False: accumulate_gradients only (architecture.py:312-385) — the gradients stay in the layers for
+        apply_summed_gradients (a synchronous data-parallel step applies the SUM over the workers' shards)."""
         x = N.prep_obs(obs, self.image)
         v = self.v_head.forward(self.v_tower.forward(x))
         logits = self.p_head.forward(self.p_tower.forward(x))
@@ -132,9 +149,10 @@ class ClippedPPOOracle(_Base):
         norm = self.global_norm()
         if self.continuous:
             norm = np.sqrt(norm ** 2 + float(np.sum(self.d_log_std.astype(np.float64) ** 2)))
-        self.adam_step(grad_scale)
-        if self.continuous:
-            self.adam.step(("log_std", 0, "k"), self.log_std, self.d_log_std, grad_scale)
+        if apply:
+            self.adam_step(grad_scale)
+            if self.continuous:
+                self.adam.step(("log_std", 0, "k"), self.log_std, self.d_log_std, grad_scale)
         return dict(value_loss=vloss, norm=norm, **pl)
 
 
@@ -175,7 +193,7 @@ class DQNOracle(_Base):
             lt.b[...] = mix_weights(lt.b, lo.b, F32(rate))
 
     def learn_from_batch(self, obs, next_obs, actions, rewards, game_overs, discount, weights=None,
-                         double_dqn=False, grad_scale=1.0):
+                         double_dqn=False, grad_scale=1.0, apply=True):
         q_next = self.q(next_obs, target=True)
         q_next_o = self.q(next_obs) if double_dqn else None
         q = self.q(obs)
@@ -190,7 +208,8 @@ class DQNOracle(_Base):
             for _, _, l in self._all_layers():
                 l.dW = (l.dW * scale).astype(F32)
                 l.db = (l.db * scale).astype(F32)
-        self.adam_step(grad_scale)
+        if apply:
+            self.adam_step(grad_scale)
         return dict(loss=loss, td_errors=td_errors, td_targets=td_targets, norm=norm)
 
 

@@ -237,3 +237,99 @@ def test_split_backward_equals_full(dev):
             assert torch.equal(late, net.params.grads[off:])   # the late bucket was already final
         grads.append(net.params.grads.clone())
     assert torch.equal(grads[0], grads[1])
+
+
+# ------------------------------------------------- a data-parallel update against the ORACLE on the union of the shards
+def _shard(kind, rank, shape, A, B):
+    rng = np.random.RandomState(500 + rank)
+    obs = rng.randint(0, 256, size=(B,) + shape).astype(np.uint8)
+    if kind == "ppo":
+        return dict(obs=obs, actions=rng.randint(0, A, size=B).astype(np.int32), adv=rng.randn(B).astype(np.float32),
+                    vt=rng.randn(B).astype(np.float32))
+    return dict(obs=obs, next_obs=rng.randint(0, 256, size=(B,) + shape).astype(np.uint8),
+                actions=rng.randint(0, A, size=B).astype(np.int32), rewards=rng.randn(B).astype(np.float32),
+                game_overs=(rng.rand(B) < 0.2).astype(np.uint8))
+
+
+def _oracle_worker(rank, world, port, out_dir, kind, scale_down):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), RLX_DIST_BACKEND="gloo")
+    import torch
+    from coach_amd.distributed import GradientSync
+    from coach_amd.nn.networks import ClippedPPONet, DQNNet
+    dev = torch.device("cuda:0")
+    dist = GradientSync()
+    shape, A, B = (44, 44, 4), 4, 16
+    d = {k: torch.from_numpy(v).to(dev) for k, v in _shard(kind, rank, shape, A, B).items()}
+    scale = dist.grad_scale(scale_down)
+    assert scale == (0.5 if scale_down else 1.0)
+    if kind == "ppo":
+        net = ClippedPPONet(dev, shape, A, seed=3)
+        net.update_target(1.0)
+        old = net.policy_probs(d["obs"], B, use_target=True, tag="old")
+        for _ in range(2):                                   # two synchronous steps: the second starts from shared weights
+            net.forward_backward(d["obs"], B, d["actions"], d["adv"], d["vt"], old)
+            dist.all_reduce_sum(net.params.grads)
+            net.finish_update(scale)
+    else:
+        net = DQNNet(dev, shape, A, seed=3)
+        for _ in range(2):
+            net.learn_from_batch(d["obs"], d["next_obs"], B, d["actions"], d["rewards"], d["game_overs"], 0.99,
+                                 grad_scale=scale, sync=dist)
+    net.check_status()
+    np.save(os.path.join(out_dir, "wo_%d.npy" % rank), net.params.weights.cpu().numpy())
+    np.save(os.path.join(out_dir, "mo_%d.npy" % rank), net.adam.m.cpu().numpy())     # first moments: LINEAR in the scale
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind,scale_down", [("ppo", True), ("dqn", True), ("dqn", False)])
+def test_two_rank_update_equals_oracle_on_the_union_of_the_shards(tmp_path, dev, kind, scale_down):
+    """Two ranks, each with ITS OWN minibatch: gradients all-reduced (sum), scaled by 1 / num_workers where
+    scale_down_gradients_by_number_of_workers_for_sync_training says so (architecture.py:485-488: on for DQN / Clipped
+    PPO, off for DDPG / TD3), identical Adam step on every rank — against the oracle network that accumulates the
+    gradient of both shards from the same weights, sums them and applies ONE step."""
+    import torch
+    import torch.multiprocessing as mp
+    from coach_amd.nn.networks import ClippedPPONet, DQNNet
+    from oracle.agents import ClippedPPOOracle, DQNOracle
+    mp.spawn(_oracle_worker, args=(2, _free_port(), str(tmp_path), kind, scale_down), nprocs=2, join=True)
+    w = [np.load(tmp_path / ("wo_%d.npy" % r)) for r in (0, 1)]
+    np.testing.assert_array_equal(w[0], w[1])
+    shape, A, B = (44, 44, 4), 4, 16
+    shards = [_shard(kind, r, shape, A, B) for r in (0, 1)]
+    if kind == "ppo":
+        net = ClippedPPONet(dev, shape, A, seed=3)            # same seed -> the workers' initial weights
+        o = ClippedPPOOracle(net.params.named_arrays(), shape, A)
+        frozen = o.clone_policy()
+        old = [o.policy_probs(s["obs"], frozen) for s in shards]
+        for _ in range(2):
+            grads = []
+            for s, op in zip(shards, old):
+                o.train_minibatch(s["obs"], s["actions"], s["adv"], s["vt"], op, apply=False)
+                grads.append(o.snapshot_grads())
+            o.apply_summed_gradients(grads, 2, scale_down)
+    else:
+        net = DQNNet(dev, shape, A, seed=3)
+        o = DQNOracle(net.params.named_arrays(), shape, A)
+        for _ in range(2):
+            grads = []
+            for s in shards:
+                o.learn_from_batch(s["obs"], s["next_obs"], s["actions"], s["rewards"], s["game_overs"].astype(bool),
+                                   0.99, apply=False)
+                grads.append(o.snapshot_grads())
+            o.apply_summed_gradients(grads, 2, scale_down)
+    net.params.weights.copy_(torch.from_numpy(w[0]).to(dev))
+    hw = net.params.named_arrays()
+    for name, per_tower in o.weights().items():
+        for t, ref in per_tower.items():
+            np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
+    # Adam's step is nearly invariant to a gradient scale; its first moment is linear in it: the 1 / num_workers rule
+    # (or its absence) shows there
+    m = net.params.named_arrays(torch.from_numpy(np.load(tmp_path / "mo_0.npy")).to(dev))
+    head = "main/ppo_head/policy_fc" if kind == "ppo" else "main/q_head/dense"
+    key = [k for k in o.adam.slots if k[0] == head and k[2] == "k"][0]
+    om = o.adam.slots[key].m.reshape(m[head + "/kernel"][0].shape)
+    np.testing.assert_allclose(m[head + "/kernel"][0], om, rtol=2e-3, atol=1e-7)
+    assert np.abs(om).max() > 1e-6

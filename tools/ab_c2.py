@@ -47,8 +47,9 @@ def train_ms(agent):
 
 
 def main(rounds=4):
-    variants = {"default (direct dX where < 1.3x the products)": (True, True), "direct dX always": ("always", True),
-                "column-matrix dX": (False, True), "per-layer reduces": (True, False)}
+    variants = {"default (column-matrix dX, deferred reductions)": (False, True),
+                "direct dX where < 1.3x the products": (True, True), "direct dX always": ("always", True),
+                "per-layer reductions": (False, False)}
     agents = {k: build(*v) for k, v in variants.items()}
     for a in agents.values():
         for _ in range(3):

@@ -17,7 +17,34 @@ def last_update(path):
     return rows[ends[-2] + 1:ends[-1] + 1]
 
 
+def mfma_table(busy_csv, active_csv, out):
+    """rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES and --pmc GRBM_GUI_ACTIVE passes of the same run -> per kernel of the
+    last update: MFMA busy cycles (summed over the chip's 1024 SIMDs) / (GPU-active cycles x 1024) = the fraction of
+    the matrix pipes' cycles spent issuing MFMAs while the kernel ran (the gfx94x MfmaUtil formula; gfx950 has no
+    derived-counter section in ROCm 7.2, MI355X_MICROARCH.md)."""
+    b, a = last_update(busy_csv), last_update(active_csv)
+    assert [r["Kernel_Name"] for r in b] == [r["Kernel_Name"] for r in a]
+    rows, tb, ta = [], 0.0, 0.0
+    for x, y in zip(b, a):
+        busy, act = float(x["Counter_Value"]), float(y["Counter_Value"])
+        rows.append({"name": x["Kernel_Name"][:110], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": act,
+                     "mfma_util": round(busy / (act * 1024.0), 4) if act else None})
+        if "gemm_" in x["Kernel_Name"] or "splitk_reduce" in x["Kernel_Name"]:
+            tb += busy
+            ta += act
+    res = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (separate passes) on "
+                     "tools/ppo_update_once.py, last eager minibatch update",
+           "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)",
+           "gemm_family_mfma_util": round(tb / (ta * 1024.0), 4) if ta else None, "kernels": rows}
+    json.dump(res, open(out, "w"), indent=1)
+    print({k: v for k, v in res.items() if k != "kernels"})
+    for r in rows:
+        print("%-100s %s" % (r["name"][-100:], r["mfma_util"]))
+
+
 def main():
+    if sys.argv[1] == "--mfma":
+        return mfma_table(*sys.argv[2:5])
     fetch, write, out = sys.argv[1:4]
     f, w = last_update(fetch), last_update(write)
     assert [r["Kernel_Name"] for r in f] == [r["Kernel_Name"] for r in w]
