@@ -374,14 +374,6 @@ def gemm_pair_or_single(desc, stream=None):
     run()
 
 
-def gemm_chain2(first, second, stream=None):
-    """two descriptors built with gemm(..., launch=False), second.A == first.C: two dense layers as one launch."""
-    s = current_stream() if stream is None else stream
-    run = lambda: lib().gemm_chain2(ctypes.byref(first), ctypes.byref(second), s)
-    _record((first, second), run)
-    run()
-
-
 def gemm_pair(weight_grad, input_grad, stream=None, defer=None):
     """two descriptors built with gemm(..., launch=False): a layer's dW and dX products as one launch.
     defer: a SplitkJob for the weight gradient's split-K reduction (see gemm)."""

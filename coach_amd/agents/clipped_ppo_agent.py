@@ -95,7 +95,7 @@ def _capture(fn):
 
 
 class ClippedPPOAgent(object):
-    epoch_graph = os.environ.get("RLX_PPO_MINIBATCH_GRAPHS", "0") != "1"   # one hipGraph per epoch, not per minibatch
+    epoch_graph = True      # one hipGraph per epoch, not per minibatch
     ragged = False          # envs end their episodes on different steps (set per instance from the env)
     _device_env = True
 

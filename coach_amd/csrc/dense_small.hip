@@ -35,13 +35,7 @@ __global__ void __launch_bounds__(256) dense_small_fwd_multi_kernel(const MultiF
     dense_small_fwd_row<NN>(p, blockIdx.x, blockIdx.y, part);
 }
 
-template <int NN>
-__global__ void __launch_bounds__(256) dense_small_bwd_kernel(const SmallDenseBwd p) {
-    extern __shared__ float smem[];
-    dense_small_bwd_body<NN>(p, blockIdx.x, blockIdx.y, smem);
-}
-
-// 16 features x 16 row groups per workgroup (see dense_small_bwd_body): the RLX_DENSE_SMALL_BWD_WIDE=1 experiment
+// 16 features x 16 row groups per workgroup (see dense_small_bwd_body)
 template <int NN>
 __global__ void __launch_bounds__(256) dense_small_bwd_wide_kernel(const SmallDenseBwd p) {
     extern __shared__ float smem[];
@@ -100,21 +94,14 @@ int rlx_dense_small_backward(const float *x, long long x_tower_stride, const flo
                     dw, dw_tower_stride, db, db_tower_stride, dx, dx_tower_stride,
                     M, K, N, activation, lower_activation};
     hipStream_t s = rlx::as_stream(stream);
-    static const bool wide = [] { const char *e = getenv("RLX_DENSE_SMALL_BWD_WIDE"); return e && e[0] == '1'; }();
-    if (wide) {          // opt-in: written after the round's GPU budget was spent; tools/gpu_calls/next_round_ab.sh tests and times it
-        dim3 wgrid((K + 15) / 16, towers);
-        if (NN == 1) dense_small_bwd_wide_kernel<1><<<wgrid, 256, smem, s>>>(p);
-        else if (NN == 4) dense_small_bwd_wide_kernel<4><<<wgrid, 256, smem, s>>>(p);
-        else if (NN == 8) dense_small_bwd_wide_kernel<8><<<wgrid, 256, smem, s>>>(p);
-        else dense_small_bwd_wide_kernel<16><<<wgrid, 256, smem, s>>>(p);
-        RLX_LAUNCH_CHECK();
-        return RLX_OK;
-    }
-    dim3 grid((K + kKL - 1) / kKL, towers);
-    if (NN == 1) dense_small_bwd_kernel<1><<<grid, 256, smem, s>>>(p);
-    else if (NN == 4) dense_small_bwd_kernel<4><<<grid, 256, smem, s>>>(p);
-    else if (NN == 8) dense_small_bwd_kernel<8><<<grid, 256, smem, s>>>(p);
-    else dense_small_bwd_kernel<16><<<grid, 256, smem, s>>>(p);
+    // 16 features x 16 row groups per workgroup: twice the workgroups of the 32 x 8 split the multi-problem kernel uses
+    // and, up to 128 rows, every x load of a thread in one chunk (same-box A/B, profiles/r03_ab_candidates.txt: C4 +6 %,
+    // C5 +4 %, C1 unchanged)
+    dim3 wgrid((K + 15) / 16, towers);
+    if (NN == 1) dense_small_bwd_wide_kernel<1><<<wgrid, 256, smem, s>>>(p);
+    else if (NN == 4) dense_small_bwd_wide_kernel<4><<<wgrid, 256, smem, s>>>(p);
+    else if (NN == 8) dense_small_bwd_wide_kernel<8><<<wgrid, 256, smem, s>>>(p);
+    else dense_small_bwd_wide_kernel<16><<<wgrid, 256, smem, s>>>(p);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

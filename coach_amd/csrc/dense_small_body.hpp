@@ -82,10 +82,10 @@ constexpr int kMaxProblems = 4;
 struct MultiFwd { SmallDense p[kMaxProblems]; int towers[kMaxProblems]; int n; };
 struct MultiBwd { SmallDenseBwd p[kMaxProblems]; int towers[kMaxProblems]; int n; };
 
-// KL features x RG row groups per workgroup (KL * RG = 256).  The default 32 x 8 is what every caller uses; 16 x 16 is the
-// RLX_DENSE_SMALL_BWD_WIDE=1 experiment of rlx_dense_small_backward: twice the workgroups and, up to M = 128 rows, every x
+// KL features x RG row groups per workgroup (KL * RG = 256).  32 x 8 is what the multi-problem launch uses; the
+// single-problem launch (rlx_dense_small_backward) takes 16 x 16: twice the workgroups and, up to M = 128 rows, every x
 // load of a thread in ONE chunk (one exposed round trip instead of two at M = 100) — a different grouping of the dW row
-// sums, to be measured and compared before it becomes a default.
+// sums (profiles/r03_ab_candidates.txt).
 template <int NN, int KL = kKL, int RG = kRG>
 __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int kblock, int t, float *smem) {
     float *dz = smem;                              // [M][N]

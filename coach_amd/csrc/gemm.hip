@@ -320,10 +320,8 @@ __device__ __forceinline__ float4 raw_to_float4(const Raw1 &r, const float *lut)
 template <bool U8> struct ARaw { typedef Raw4 type; };
 template <> struct ARaw<true> { typedef Raw1 type; };
 
-// TM x TN accumulator tiles of 32x32 per wave (wave tile 32*TM x 32*TN): with 2x2 the LDS operand
-// reads per MFMA halve and a workgroup carries 4x the MFMA work per prologue/epilogue — what the
-// short-K (K = 64) input-gradient GEMMs need.
-// (one accumulator tile per wave: at most 168 registers, so that three workgroups share a CU)
+// TM x TN accumulator tiles of 32x32 per wave (wave tile 32*TM x 32*TN).  Every instantiation uses ONE tile per wave
+// (at most 168 registers, so that three workgroups share a CU).
 // The body of one workgroup; (bx, by, bz) of a grid (gdx, gdy, .) are passed in so that ONE launch can carry the
 // workgroups of two independent problems (gemm_fast_pair_kernel).  smem / lut / tab_s: the caller's LDS.
 template <int BM, int BN, int TM, int TN>
@@ -1061,157 +1059,6 @@ __global__ void __launch_bounds__(kThreads) gemm_thin_pair_kernel(const GemmPair
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Two consecutive dense layers in ONE launch (the forward pass of the small MLPs of DDPG / TD3 / DQN: obs -> H1 -> H2
-// with a handful of inputs):  y1 = act1(x W1 + b1),  y2 = act2(y1 W2 + b2).
-// A workgroup owns one 32 x 32 tile of y2.  It first computes the 32 rows of y1 it needs — ALL H1 columns, which is
-// cheap because K1 <= 64 — straight into LDS in the k-major layout the second product reads its A operand from
-// (the column-0 workgroups also write y1 to memory: the backward pass needs it), then the thin kernel's second
-// product: the reduction index split over the 4 waves in chunks of 32, partial tiles summed through LDS in the same
-// fixed order.  Same k-order as two gemm_thin_kernel launches: bit-identical outputs.
-struct Chain2Dev {
-    GemmDev g1, g2;           // operands / epilogues of the two layers as rlx_gemm would see them
-    int h1_pad;               // H1 rounded up to a multiple of 32
-};
-constexpr int kChainMaxK1 = 32, kChainMaxH1 = 512;
-
-// (no lane-dependent branches: every operand load is issued from a clamped, always-valid address and masked by a
-// select — predicated loads compile to an exec-mask branch each, which made the first version of this kernel
-// 10 600 instructions and three times slower than the two launches it replaces)
-__global__ void __launch_bounds__(kThreads) gemm_chain2_kernel(const Chain2Dev p) {
-    extern __shared__ float csm[];
-    constexpr int LD = 33;
-    float *xs = csm;                                   // [32][33]       x tile, k-major, zero beyond K1
-    float *h1s = xs + kChainMaxK1 * LD;                // [h1_pad][33]   y1 tile, k-major
-    float *stage = h1s + (size_t)p.h1_pad * LD;        // [4][32][33]    the four waves' partial tiles
-    const GemmDev &g1 = p.g1, &g2 = p.g2;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int batch = blockIdx.z;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    const int K1 = g1.K, H1 = g1.N, N2 = g2.N, M = g1.M;
-    const float *x = static_cast<const float *>(g1.a.base) + batch_off(batch, g1.inner, g1.a.batch_stride, g1.a.batch_stride2);
-    const float *w1 = static_cast<const float *>(g1.b.base) + batch_off(batch, g1.inner, g1.b.batch_stride, g1.b.batch_stride2);
-    const float *b1 = g1.bias ? g1.bias + batch_off(batch, g1.inner, g1.bias_batch_stride, g1.bias_batch_stride2) : nullptr;
-    const float *w2 = static_cast<const float *>(g2.b.base) + batch_off(batch, g2.inner, g2.b.batch_stride, g2.b.batch_stride2);
-    const float *b2 = g2.bias ? g2.bias + batch_off(batch, g2.inner, g2.bias_batch_stride, g2.bias_batch_stride2) : nullptr;
-    float *y1 = g1.c + (size_t)batch * g1.c_batch_stride;
-    float *y2 = g2.c + (size_t)batch * g2.c_batch_stride;
-#pragma unroll
-    for (int i = 0; i < 32 * 32 / kThreads; ++i) {                   // x tile [32 rows][32 k]
-        const int e = tid + i * kThreads;
-        const int k = e & 31, r = e >> 5;
-        const float v = x[(size_t)min(m0 + r, M - 1) * K1 + min(k, K1 - 1)];
-        xs[k * LD + r] = k < K1 ? v : 0.f;
-    }
-    __syncthreads();
-    const int chunks = p.h1_pad >> 5;
-    // ---- layer 1: wave w computes the 32-column chunks w, w + 4, ... of y1's 32 rows; the 16 weight operands of a
-    // chunk are requested together, one chunk ahead of their use
-    auto load_w1 = [&](int c, float (&bv)[16]) {
-        const int col = c * 32 + l31;
-        const float *wp = w1 + min(col, H1 - 1);
-        const bool live = col < H1;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k = 2 * q + hi;
-            const float v = wp[(size_t)min(k, K1 - 1) * H1];
-            bv[q] = (live && k < K1) ? v : 0.f;
-        }
-    };
-    auto chunk1 = [&](int c, const float (&bv)[16]) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[(2 * q + hi) * LD + l31], bv[q], acc, 0, 0, 0);
-        const int col = c * 32 + l31;
-        const bool live = col < H1;
-        const float bias = b1 ? b1[min(col, H1 - 1)] : 0.f;
-        const bool write_y1 = blockIdx.x == 0 && live;
-        float v[16];
-        if (g1.act == RLX_ACT_RELU) {                    // (uniform branches: one activation per launch)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float t = acc[r] + bias; v[r] = t > 0.f ? t : 0.f; }
-        } else if (g1.act == RLX_ACT_TANH) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = tanhf(acc[r] + bias);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float o = live ? v[r] : 0.f;
-            h1s[(size_t)col * LD + rl] = o;
-            if (write_y1 && m0 + rl < M) y1[(size_t)(m0 + rl) * g1.ldc + col] = o;
-        }
-    };
-    {
-        float bva[16], bvb[16];
-        load_w1(w, bva);
-        for (int c = w; c < chunks; c += 8) {
-            load_w1(c + 4, bvb);
-            chunk1(c, bva);
-            if (c + 4 < chunks) {
-                load_w1(c + 8, bva);
-                chunk1(c + 4, bvb);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- layer 2: K = H1 over the 4 waves in chunks of 32 (chunk c -> wave c % 4: gemm_thin_kernel's assignment)
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int col2 = n0 + l31;
-    auto load_w2 = [&](int c, float (&bv)[16]) {
-        const float *bp = w2 + min(col2, N2 - 1);
-        const bool live = col2 < N2;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k = c * 32 + 2 * q + hi;
-            const float v = bp[(size_t)min(k, H1 - 1) * N2];
-            bv[q] = (live && k < H1) ? v : 0.f;
-        }
-    };
-    auto chunk2 = [&](int c, const float (&bv)[16]) {
-        const float *ap = h1s + (size_t)(c * 32 + hi) * LD + l31;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * q * LD], bv[q], acc, 0, 0, 0);
-    };
-    {
-        float bva[16], bvb[16];
-        load_w2(w, bva);
-        for (int c = w; c < chunks; c += 8) {
-            load_w2(c + 4, bvb);
-            chunk2(c, bva);
-            if (c + 4 < chunks) {
-                load_w2(c + 8, bva);
-                chunk2(c + 4, bvb);
-            }
-        }
-    }
-    float *st = stage + w * (32 * LD);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * LD + l31] = acc[r];
-    __syncthreads();
-    const int rl = tid >> 3, c4 = (tid & 7) * 4;
-    const int row = m0 + rl;
-    if (row >= M) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + c4 + j;
-        if (col >= N2) continue;
-        const int o = rl * LD + c4 + j;
-        float v = ((stage[o] + stage[32 * LD + o]) + stage[2 * 32 * LD + o]) + stage[3 * 32 * LD + o];
-        v = apply_act(v + (b2 ? b2[col] : 0.f), g2.act);
-        y2[(size_t)row * g2.ldc + col] = v;
-    }
-}
-
 __global__ void splitk_reduce_kernel(const GemmDev g) {
     const long long mn = (long long)g.M * g.N;
     const int batch = blockIdx.y;
@@ -1581,55 +1428,13 @@ int launch_fast(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, boo
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-// RLX_GEMM_BIG_TILES=1 lets large-M*N launches use 128x128 / 128x64 workgroup tiles (2x2 / 2x1
-// accumulators per wave).  Off by default: at the C2 shapes the short-K GEMMs that qualify are
-// epilogue-bound and measured 15-40 % slower with them (profiles/r01 history in DESIGN.md).
-inline bool rlx_big_tiles() {
-    static const bool v = [] {
-        const char *e = getenv("RLX_GEMM_BIG_TILES");
-        return e && e[0] == '1';
-    }();
-    return v;
-}
-
-inline int rlx_split_min_k() {
-    static const int v = [] {
-        const char *e = getenv("RLX_GEMM_SPLIT_MIN_K");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
-
-// RLX_GEMM_SPLIT_WGS_PER_CU / RLX_GEMM_SPLIT_MAX_TILES: experiment knobs of the split-K heuristic (defaults 2 / 256)
-inline int rlx_env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e && *e ? atoi(e) : dflt;
-}
-inline int rlx_split_wgs_per_cu() {
-    static const int v = rlx_env_int("RLX_GEMM_SPLIT_WGS_PER_CU", 2);
-    return v;
-}
-inline int rlx_split_max_tiles() {
-    static const int v = rlx_env_int("RLX_GEMM_SPLIT_MAX_TILES", rlx::kCUs);
-    return v;
-}
-
-inline bool rlx_no_thin_gemm() {
-    static const bool v = [] {
-        const char *e = getenv("RLX_NO_THIN_GEMM");
-        return e && e[0] == '1';
-    }();
-    return v;
-}
-
-// RLX_GEMM_GENERIC=1 forces the bounds-checked kernel (used by the tests to cross-check the paths)
-inline bool rlx_force_generic_gemm() {
-    static const bool v = [] {
-        const char *e = getenv("RLX_GEMM_GENERIC");
-        return e && e[0] == '1';
-    }();
-    return v;
-}
+// Tuning constants of the path selection (each was measured on the BASELINE shapes; the A/B records are under
+// profiles/: r02_ab_gemm_split_heuristic.txt, r02_ab_thin_16x16_tiles.txt, r01_thin_gemm_ab.txt).
+constexpr int kSplitWgsPerCu = 2;          // split K until ~2 workgroups per CU exist ...
+constexpr int kSplitMaxTiles = rlx::kCUs;  // ... unless the launch already covers every CU
+constexpr int kThinMaxTiles = 96;          // thin kernel: at most this many 64 x 64 tiles
+constexpr int kThin16MaxTiles = 128;       // 16 x 16 tiles inside a dW + dX pair grid up to this many 32 x 32 tiles ...
+constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a launch of its own
 
 // diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
 struct StampCall { int M, N, K, batch, splits, gx, gy, gz; long long offset; };
@@ -1772,18 +1577,15 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
     }
 
     // thin path: few output tiles and a short reduction -> one launch with K split over the waves
-    if (!rlx_no_thin_gemm() && !d.a_row_tab && !d.a_k_tab && !d.a_is_u8 && d.n_fold <= 0 && d.K <= 1024) {
+    if (!d.a_row_tab && !d.a_k_tab && !d.a_is_u8 && d.n_fold <= 0 && d.K <= 1024) {
         const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
-        static const int thin_max_tiles = rlx_env_int("RLX_GEMM_THIN_MAX_TILES", 96);
-        if (t64 <= thin_max_tiles && (long long)d.N * d.K <= (1 << 18)) {      // MLP-sized weights only: the scalar loads lose on wide B
+        if (t64 <= kThinMaxTiles && (long long)d.N * d.K <= (1 << 18)) {      // MLP-sized weights only: the scalar loads lose on wide B
             const bool a_ck = d.a_k_stride == 1, b_cn = d.b_n_stride == 1;
             // 32 x 32 tiles that leave most CUs idle -> 16 x 16 tiles (4x the workgroups, same reduction order)
             // (a launch of its own profits up to 256 tiles — dW 400x300x100, 130 tiles: 5.22 -> 3.81 us; as one half of a
             // dW + dX pair grid the same problem is better left on 32 x 32 tiles: 5.96 vs 6.6 us for the pair)
-            static const int t16_max_tiles = rlx_env_int("RLX_GEMM_THIN16_MAX_TILES", 128);
-            static const int t16_single_max_tiles = rlx_env_int("RLX_GEMM_THIN16_SINGLE_MAX_TILES", 256);
             const long long t32 = (long long)((d.M + 31) / 32) * ((d.N + 31) / 32) * d.batch;
-            const bool t16 = t32 <= (plan ? t16_max_tiles : t16_single_max_tiles);
+            const bool t16 = t32 <= (plan ? kThin16MaxTiles : kThin16SingleMaxTiles);
             const int tile = t16 ? 16 : 32;
             dim3 tgrid((d.N + tile - 1) / tile, (d.M + tile - 1) / tile, d.batch);
             g.splits = 1; g.kchunk = d.K; g.ws = nullptr; g.vec_epi = 0; g.fold = 0;
@@ -1810,21 +1612,17 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
 
     // fast path: every 4-element vector group of both operands is full, in range and aligned
     const bool a_tab = d.a_row_tab && d.a_k_tab;
-    bool fast = !rlx_force_generic_gemm() && g.a.vec_ok && g.b.vec_ok &&
+    bool fast = g.a.vec_ok && g.b.vec_ok &&
                       (a_tab || (!d.a_row_tab && !d.a_k_tab)) &&
                       (a_vec_red ? d.K % 4 == 0 : (d.M % 4 == 0 && d.M >= 4)) &&
                       (b_vec_red ? d.K % 4 == 0 : (d.N % 4 == 0 && d.N >= 4)) && d.K >= 4;
-    // tile shape: narrow-N problems use 128x32 workgroup tiles; when the grid still covers the chip
-    // with them, the fast path takes 2x2 / 2x1 accumulator tiles per wave (128x128 / 128x64)
+    // tile shape: narrow-N problems use 128x32 workgroup tiles, everything else 64x64 (2x2 / 2x1 accumulator tiles
+    // per wave measured 15-40 % slower at the C2 shapes: epilogue-bound, profiles/r01_gemm_microbench.txt)
     const bool narrow = d.N <= 32;
     int BM = narrow ? 128 : 64, BN = narrow ? 32 : 64;
     auto tiles_of = [&](int bm, int bn) {
         return (long long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch;
     };
-    if (fast && !narrow && !d.a_is_u8 && rlx_big_tiles()) {
-        if (tiles_of(128, 128) >= rlx::kCUs) { BM = 128; BN = 128; }
-        else if (tiles_of(128, 64) >= rlx::kCUs) { BM = 128; BN = 64; }
-    }
     // Mid-sized problems (too few 64 x 64 tiles for the chip, enough 32 x 64 or 32 x 32 ones): smaller tiles with the K
     // slab split over the waves of the workgroup instead of K split over workgroups — no partials, no reduce launch.
     int KW = 1;
@@ -1839,11 +1637,11 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
     const int tiles = (int)tiles_of(BM, BN);
     // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split; a launch that
     // already covers every CU is left alone (its reduce pass would cost more than the imbalance)
-    // (RLX_GEMM_SPLIT_MIN_K raises the shortest K that may be split; measured on C2 / C3, splitting
-    // every under-filled launch is fastest: 118 vs 129 ms and 325 vs 383 ms per bench step.)
+    // (measured on C2 / C3, splitting every under-filled launch is fastest: 118 vs 129 ms and 325 vs 383 ms per
+    // bench step against a minimum K of 1024.)
     int splits = 1;
-    if (KW == 1 && d.workspace && tiles <= rlx_split_max_tiles() && d.K >= rlx_split_min_k()) {
-        const int want = (rlx_split_wgs_per_cu() * rlx::kCUs + tiles - 1) / tiles;
+    if (KW == 1 && d.workspace && tiles <= kSplitMaxTiles) {
+        const int want = (kSplitWgsPerCu * rlx::kCUs + tiles - 1) / tiles;
         const int max_by_k = d.K / (2 * BK);
         splits = want < max_by_k ? want : max_by_k;
         if (splits > 64) splits = 64;
@@ -1916,9 +1714,7 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
     int rc = -1;
     if (fast) {
         const bool u8 = d.a_is_u8 != 0;
-        if (BM == 128 && BN == 128) rc = launch_fast<128, 128, 2, 2>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
-        else if (BM == 128 && BN == 64) rc = launch_fast<128, 64, 2, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
-        else if (narrow) rc = launch_fast<128, 32, 1, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
+        if (narrow) rc = launch_fast<128, 32, 1, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
         else if (KW == 2) rc = launch_fast<32, 64, 1, 1, 2>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
         else if (KW == 4) rc = launch_fast<32, 32, 1, 1, 4>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
         else rc = launch_fast<64, 64, 1, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
@@ -1994,12 +1790,11 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
     if (rc != RLX_OK) return rc;
     rc = gemm_impl(input_grad, stream, &px);
     if (rc != RLX_OK) return rc;
-    static const bool off = [] { const char *e = getenv("RLX_NO_GEMM_PAIR"); return e && e[0] == '1'; }();
-    const bool pairable = !off && pw.tiled_fast && (px.tiled_fast || px.kw > 1) &&
+    const bool pairable = pw.tiled_fast && (px.tiled_fast || px.kw > 1) &&
                           !pw.a_vec_red && !pw.u8 && !pw.b_vec_red &&                 // X^T dY
                           px.a_vec_red && !px.u8 && px.b_vec_red && !px.a_tab &&       // dY W^T
                           true;
-    if (!off && pw.thin && px.thin && !pw.a_ck && pw.b_cn && px.a_ck && !px.b_cn) {
+    if (pw.thin && px.thin && !pw.a_ck && pw.b_cn && px.a_ck && !px.b_cn) {
         GemmPairDev p;
         p.g[0] = pw.g; p.g[1] = px.g;
         p.gx[0] = pw.grid.x; p.gy[0] = pw.grid.y; p.gx[1] = px.grid.x; p.gy[1] = px.grid.y;
@@ -2039,46 +1834,6 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
         }
     }
     if (px.splits > 1) return launch_splitk_reduce(px.g, px.M, px.N, px.batch, px.splits, s);
-    return RLX_OK;
-}
-
-int rlx_gemm_chain2(const rlx_gemm_desc *first, const rlx_gemm_desc *second, void *stream) {
-    GemmPlan p1, p2;
-    int rc = gemm_impl(first, stream, &p1);
-    if (rc != RLX_OK) return rc;
-    rc = gemm_impl(second, stream, &p2);
-    if (rc != RLX_OK) return rc;
-    static const bool off = [] { const char *e = getenv("RLX_NO_GEMM_CHAIN"); return e && e[0] == '1'; }();
-    const rlx_gemm_desc &a = *first, &b = *second;
-    bool ok = !off && p1.thin && p2.thin && p1.a_ck && p1.b_cn && p2.a_ck && p2.b_cn &&
-              a.K <= kChainMaxK1 && a.N <= kChainMaxH1 && b.K == a.N && b.M == a.M && b.batch == a.batch &&
-              a.a_row_stride == a.K && a.b_k_stride == a.N && b.b_k_stride == b.N && a.ldc == a.N &&
-              b.a_row_stride == a.ldc && static_cast<const void *>(b.A) == static_cast<const void *>(a.C) &&
-              !a.deriv_aux && !b.deriv_aux && !a.accumulate && !b.accumulate && !a.colsum_out && !b.colsum_out;
-    for (int i = 0; ok && i < a.batch; ++i) {          // the second layer reads batch entry i of the first's output
-        const int inner = b.batch_inner > 0 ? b.batch_inner : (1 << 30);
-        const int bo = i / inner;
-        const long long off2 = (long long)bo * b.a_batch_stride2 + (long long)(i - bo * inner) * b.a_batch_stride;
-        ok = off2 == (long long)i * a.c_batch_stride;
-    }
-    if (!ok) {
-        rc = gemm_impl(first, stream, nullptr);
-        if (rc != RLX_OK) return rc;
-        return gemm_impl(second, stream, nullptr);
-    }
-    Chain2Dev p;
-    p.g1 = p1.g; p.g2 = p2.g;
-    p.h1_pad = (a.N + 31) / 32 * 32;
-    const size_t lds = sizeof(float) * 33 * (size_t)(kChainMaxK1 + p.h1_pad + 4 * 32);
-    static size_t configured = 0;
-    if (lds > configured) {
-        RLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_chain2_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
-    dim3 grid((b.N + 31) / 32, (b.M + 31) / 32, b.batch);
-    gemm_chain2_kernel<<<grid, kThreads, lds, rlx::as_stream(stream)>>>(p);
-    RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
 

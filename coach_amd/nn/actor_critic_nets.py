@@ -74,11 +74,7 @@ class ActorNet(_ACBase):
             raise NotImplementedError("per-dimension output scale is not implemented")
 
     def _torso(self, ctx, x, tag, w, pair):
-        """embedder then middleware; one dense layer each (the presets' shape): the two go out as one launch."""
-        if len(self.emb.layers) == 1 and len(self.mid.layers) == 1 and not self.bn_layers:
-            y1, y2 = G.dense_chain2_forward(ctx, self.emb.layers[0], self.mid.layers[0], x, tag=tag, weights=w,
-                                            pair=pair)
-            return [x, y1], [y1, y2]
+        """embedder then middleware."""
         kw = {"pair": True} if pair else {"weights": w}
         acts = self.emb.forward(ctx, x, tag=tag, **kw)
         return acts, self.mid.forward(ctx, acts[-1], tag=tag, **kw)

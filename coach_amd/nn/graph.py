@@ -27,12 +27,8 @@ from .. import _rlx
 ALIGN = 4  # floats (16 bytes)
 SMALL_N = 16  # widest layer served by the narrow-dense kernels (csrc/dense_small.hip)
 # towers that read the same input run their first layer as ONE GEMM over the concatenated output
-# columns (rlx_gemm_desc.n_fold); RLX_NO_FOLD=1 restores one batched problem per tower
-FOLD_SHARED_INPUT = os.environ.get("RLX_NO_FOLD", "0") != "1"
-# RLX_FOLD_ONLY_BEYOND_THIN=1 (candidate for the next round, not measured yet): a shared-input layer small enough for the
-# thin GEMM kernel (csrc/gemm.hip: K <= 1024, N * K <= 2^18, <= 96 tiles of 64 x 64) runs as T batched thin launches on
-# 16 x 16 tiles (3-5 us, no split-K reduce) instead of one folded tiled GEMM + reduce (SAC's Q towers: ~9 + 5 us)
-FOLD_ONLY_BEYOND_THIN = os.environ.get("RLX_FOLD_ONLY_BEYOND_THIN", "0") == "1"
+# columns (rlx_gemm_desc.n_fold)
+FOLD_SHARED_INPUT = True
 
 
 def _thin_takes(M, N, K, batch):
@@ -40,7 +36,11 @@ def _thin_takes(M, N, K, batch):
 
 
 def _fold(M, N, K, T):
-    return FOLD_SHARED_INPUT and not (FOLD_ONLY_BEYOND_THIN and _thin_takes(M, N, K, T))
+    """... unless the per-tower problem fits the thin GEMM kernel (csrc/gemm.hip: K <= 1024, N * K <= 2^18, <= 96 tiles
+    of 64 x 64) AND the folded product would have to split K over workgroups (K >= 64): T batched thin launches on
+    16 x 16 tiles then beat one folded tiled GEMM + its reduce launch (SAC's Q towers, C5 +14 %; TD3's critic with
+    K = 23 stays folded, C4 -3 % otherwise — profiles/r03_ab_candidates.txt)."""
+    return FOLD_SHARED_INPUT and not (_thin_takes(M, N, K, T) and K >= 64)
 
 
 def _align(n):
@@ -120,10 +120,6 @@ def normalized_columns(std):
 # a layer's dW and dX products (independent, same dz) go out as ONE launch (rlx_gemm_pair); the tests switch it off to
 # compare with the two-launch sequence
 PAIR_GRADIENT_GEMMS = True
-# two consecutive dense layers with a short first reduction as ONE launch (rlx_gemm_chain2): bit-identical to the two
-# thin-kernel launches, and measured SLOWER twice (C4 -34 % with predicated loads, -17 % branch-free:
-# profiles/r02_ab_gemm_pair.txt — every column tile recomputes the hidden rows) — opt-in, RLX_GEMM_CHAIN=1
-CHAIN_DENSE_LAYERS = os.environ.get("RLX_GEMM_CHAIN", "0") == "1"
 # Input gradient of a convolution as one windowed-gather product (rlx_conv_input_grad) instead of dcol = dz W^T + col2im:
 # True = where its extra products stay < 1.3x, "always", or False.  Off by default: same-box A/Bs of the C2 update
 # (profiles/r03_ab_gemm_changes.txt) show -0 .. +5 us per update on the pool's fast boxes and +25 us on its slow ones
@@ -148,33 +144,18 @@ class Context:
         self.ws = ws or Workspace(device)
         self.cache = {}
         self.buffers = {}
-        # opt-in (RLX_OVERLAP=1): measured slower inside hipGraph replays on MI355X / ROCm 7.2
-        # (C2 126 vs 116 ms, C3 376 vs 318 ms per bench step) — the cross-stream edges cost more
-        # than the concurrency returns at these launch sizes
-        self.overlap = os.environ.get("RLX_OVERLAP", "0") == "1" and torch.cuda.is_available()
-        self.side = torch.cuda.Stream(device=device) if self.overlap else None
-        self._forked = False
+        # (weight-gradient GEMMs on a second HIP stream, concurrent with the input-gradient chain, measured slower inside
+        # hipGraph replays on MI355X / ROCm 7.2 — C2 126 vs 116 ms, C3 376 vs 318 ms per bench step: the cross-stream edges
+        # cost more than the concurrency returns at these launch sizes; removed)
+        self.overlap = False
         self.deferred, self.arena, self._arena_off = None, None, 0
 
     @property
     def stream(self):
         return torch.cuda.current_stream().cuda_stream
 
-    # Weight-gradient GEMMs are off the backward critical path (only the optimizer needs them): with
-    # RLX_OVERLAP=1 they run on a second HIP stream, concurrently with the input-gradient chain of
-    # the layers below.  Fork/join are plain event waits and are captured by hipGraphs.
-    def on_side(self, fn):
-        if not self.overlap:
-            return fn(self.ws.splitk)
-        self.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            fn(self.ws.splitk_side)
-        self._forked = True
-
     def join(self):
-        if self._forked:
-            torch.cuda.current_stream().wait_stream(self.side)
-            self._forked = False
+        pass
 
     # ---- deferred split-K reductions of the weight gradients (rlx_gemm_defer): every dW product of a backward pass
     # leaves its partial sums in its own slice of an arena; ONE launch sums them all when the pass ends.
@@ -292,8 +273,8 @@ class Dense(Layer):
         """pair=True: the online and the target copy of the layer in one launch — towers [0, T) use
         the online weights, [T, 2T) the target weights (FlatParams.both); x carries either one tower
         per copy (shared by the T streams of a copy) or one per (copy, stream).
-        launch=False: -> (output Tensor, GEMM descriptor not yet run) for dense_chain2_forward; the descriptor is None
-        when the layer took a path that is not a plain batched GEMM (it has then been run)."""
+        launch=False: -> (output Tensor, GEMM descriptor not yet run); the descriptor is None when the layer took a
+        path that is not a plain batched GEMM (it has then been run)."""
         t0, T = self._range(t0, nt)
         p = self.params
         M = x.rows
@@ -397,9 +378,7 @@ class Dense(Layer):
                                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
                                  launch=launch, defer=dj)
             pair_dw = need_dx and not shared_dx and not overlap and PAIR_GRADIENT_GEMMS   # dW rides with the dX launch
-            if overlap and need_dx:
-                ctx.on_side(dw)
-            elif not pair_dw:
+            if not pair_dw:
                 dw(ctx.ws.splitk)
         if shared_dx:
             # dx = sum_t dz_t W_t^T, each term already multiplied by the lower layer's act'(x)
@@ -611,9 +590,7 @@ class Conv2d(Layer):
                                  c_batch_stride=p.stride(self.kname), workspace=ws,
                                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
                                  launch=launch, defer=dj)
-            if overlap:
-                ctx.on_side(dw)          # also when this is the first layer: it overlaps the layers above
-            elif not pairing:
+            if not pairing:
                 dw(ctx.ws.splitk)
         if direct:
             assert x.towers == T
@@ -643,22 +620,6 @@ class Conv2d(Layer):
             ctx.commit_deferred(job)
 
 
-def dense_chain2_forward(ctx, l1, l2, x, tag="", weights=None, t0=0, nt=None, pair=False):
-    """y1 = l1(x), y2 = l2(y1) — as ONE launch when the library's rlx_gemm_chain2 takes the pair (short first
-    reduction: the observation layer of the DDPG / TD3 / DQN MLPs), otherwise as the two launches.  -> (y1, y2)."""
-    kw = dict(tag=tag, weights=weights, t0=t0, nt=nt)
-    if pair:
-        kw["pair"] = True
-    if not (isinstance(l1, Dense) and isinstance(l2, Dense)) or x.u8 or l1.K > 64 or l1.N > 512 or \
-            l1.N <= SMALL_N or l2.N <= SMALL_N or not CHAIN_DENSE_LAYERS:
-        y1 = l1.forward(ctx, x, **kw)
-        return y1, l2.forward(ctx, y1, **kw)
-    y1, d1 = l1.forward(ctx, x, launch=False, **kw)
-    y2, d2 = l2.forward(ctx, y1, launch=False, **kw)
-    _rlx.gemm_chain2(d1, d2)
-    return y1, y2
-
-
 def small_dense_forward_multi(ctx, items, tag="", weights=None):
     """[(Dense layer, input Tensor)] -> [output Tensor], all layers in ONE launch (each N <= SMALL_N).
     weights: parameter buffer to read instead of the online weights (the target copy)."""
@@ -677,45 +638,6 @@ def small_dense_forward_multi(ctx, items, tag="", weights=None):
         q.towers, q.M, q.K, q.N, q.activation = l.T, M, l.K, l.N, _rlx.ACT[l.act]
         outs.append(Tensor(y, M, l.N, l.T, grad_key=(ctx, l.name, tag), act=l.act))
     ctx.lib.dense_small_forward_multi(ctypes.byref(arr), len(items), ctx.stream)
-    return outs
-
-
-def ppo_discrete_heads_fused(ctx, v_item, pi_item, actions, advantages, old_probs, value_targets, clip_eps, beta,
-                             scalars, value_scalar, status, ratio_out=None, clipped_out=None, tag="", clip_scale=None):
-    """Value head + policy head forward, both losses, both backward passes in ONE launch
-    (rlx_ppo_discrete_heads_fused).  items = (Dense layer, input Tensor).  -> (v Tensor, logits Tensor) with .grad
-    holding the loss gradients, like small_dense_forward_multi + the loss launch + small_dense_backward_multi."""
-    import ctypes
-    arr = (_rlx.SmallDenseProblem * 2)()
-    outs = []
-    for i, (l, x) in enumerate((v_item, pi_item)):
-        assert l.N <= SMALL_N and not x.u8 and x.cols == l.K and x.towers == l.T == 1 and l.act is None
-        M, p = x.rows, l.params
-        y = ctx.buffer(l.name, (l.T, M, l.N), tag=tag)
-        t = Tensor(y, M, l.N, l.T, grad_key=(ctx, l.name, tag), act=l.act)
-        dy, dx = t.ensure_grad(), x.ensure_grad()
-        q = arr[i]
-        q.x, q.x_tower_stride = x.data.data_ptr(), x.tower_stride()
-        q.w, q.w_tower_stride = p.w(l.kname).data_ptr(), p.stride(l.kname)
-        q.bias, q.bias_tower_stride = p.w(l.bname).data_ptr(), p.stride(l.bname)
-        q.y, q.y_tower_stride = y.data_ptr(), M * l.N
-        q.dy, q.dy_tower_stride = dy.data_ptr(), M * l.N
-        q.dw, q.dw_tower_stride = p.g(l.kname).data_ptr(), p.stride(l.kname)
-        q.db, q.db_tower_stride = p.g(l.bname).data_ptr(), p.stride(l.bname)
-        q.dx, q.dx_tower_stride = dx.data_ptr(), M * l.K
-        q.towers, q.M, q.K, q.N = 1, M, l.K, l.N
-        q.activation, q.lower_activation = 0, _rlx.ACT[x.act]
-        x.grad_is_dz = x.act is not None
-        outs.append(t)
-    M = v_item[1].rows
-    scratch = ctx.buffer("ppo_heads_fused/terms", (M, 4), tag=tag)
-    key = ("ppo_heads_fused/sync", (2,), torch.int32, tag)
-    sync = ctx.buffers.get(key)
-    if sync is None:                                     # the kernel leaves the two words zero
-        sync = ctx.buffers[key] = torch.zeros(2, dtype=torch.int32, device=ctx.device)
-    ctx.lib.ppo_discrete_heads_fused(ctypes.byref(arr), actions, advantages, old_probs, old_probs.shape[-1],
-                                     value_targets, float(clip_eps), float(beta), 1.0, scalars, value_scalar,
-                                     ratio_out, clipped_out, scratch, sync, status, clip_scale, ctx.stream)
     return outs
 
 
@@ -757,10 +679,6 @@ class Sequential:
     def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
         acts = [x]
         kw = {"pair": True} if pair else {}
-        if len(self.layers) == 2 and all(isinstance(l, Dense) for l in self.layers):
-            y1, y2 = dense_chain2_forward(ctx, self.layers[0], self.layers[1], x, tag=tag, weights=weights, t0=t0,
-                                          nt=nt, pair=pair)
-            return [x, y1, y2]
         for l in self.layers:
             acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, **kw))
         return acts
@@ -792,7 +710,7 @@ class AdamState:
         self.v = torch.empty_like(params.weights)
         self.state = torch.empty(2, dtype=torch.float32, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # rlx_adam_tf1_step's last-arriver word
-        self.one_launch = os.environ.get("RLX_ADAM_TWO_LAUNCHES", "0") != "1"
+        self.one_launch = True
         _rlx.lib().adam_init(self.m, self.v, params.size, self.state, beta1, beta2, _rlx.current_stream())
 
     def step(self, grad_scale=1.0, lr=None, norm_out=None, workspace=None, acc=None, grads=None, mix_target=None,

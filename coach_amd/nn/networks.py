@@ -130,17 +130,8 @@ class ClippedPPONet(_NetBase):
         self.clip_eps, self.beta = clip_likelihood_ratio_using_epsilon, beta_entropy
         self._clip_scale_dev, self._clip_scale_value = None, None
         self.continuous = continuous
-        import os
-        # RLX_FUSED_HEADS=1: heads forward / losses / heads backward as ONE launch with an in-kernel barrier
-        # (csrc/ppo_heads_fused.hip).  Bit-identical, but measured SLOWER on MI355X (C2: 93.9 vs 89.4 ms per
-        # iteration, profiles/r02_ab_fused_heads.txt): each of the three kernels is ~1-3 us of work behind a ~4 us
-        # launch, and the barrier plus the serialised per-row phase cost more than the two boundaries saved.  Opt-in.
-        # A second form without any grid-wide dependency (ppo_heads_wg_kernel: one workgroup per head, the head's
-        # [B][K] input resident in LDS, selected by the library when it fits) is correct to fp32 noise and slower still
-        # (C2 114.0 vs 103.6 ms per iteration on one box, gpurun_out/r02_call30): two workgroups cannot make up in
-        # parallelism what the three small grids have.  RLX_FUSED_HEADS=1 selects it (RLX_PPO_HEADS_GRID=1: the
-        # barrier form).
-        self._heads_one_launch = os.environ.get("RLX_FUSED_HEADS", "0") == "1"
+        # (heads forward / losses / heads backward as ONE launch was tried twice and lost to these three small grids:
+        # profiles/r02_ab_fused_heads.txt)
         self.params = G.FlatParams()
         self.torso, feat = build_torso(self.params, "main", obs_shape, activation, 2, embedder, middleware)
         self.v_head = G.Dense(self.params, "main/v_head/dense", feat, 1, None, 1,
@@ -230,22 +221,14 @@ class ClippedPPONet(_NetBase):
         mid.ensure_grad()
         xv, xp = mid.tower(0), mid.tower(1)
         fused_heads = self.pi_head.N <= G.SMALL_N and B * self.pi_head.N <= 1024
-        one_launch = fused_heads and not self.continuous and B <= 256 and self._heads_one_launch
-        if one_launch:         # forward, both head losses and backward of both heads: ONE launch
-            v, logits = G.ppo_discrete_heads_fused(ctx, (self.v_head, xv), (self.pi_head, xp), actions, advantages,
-                                                   old_probs, value_targets, self.clip_eps * clip_rescaler, self.beta,
-                                                   self.scalars[0:4], self.scalars[4:5], self.status, ratio_out,
-                                                   clipped_out, tag="train", clip_scale=clip_dev)
-        elif fused_heads:      # value + policy head in one launch (forward here, backward below)
+        if fused_heads:        # value + policy head in one launch (forward here, backward below)
             v, logits = G.small_dense_forward_multi(ctx, [(self.v_head, xv), (self.pi_head, xp)], tag="train")
         else:
             v = self.v_head.forward(ctx, xv, tag="train")
             logits = self.pi_head.forward(ctx, xp, tag="train")
         dv, dlogits = v.ensure_grad(), logits.ensure_grad()
         # head 0: VHead, MSE(target, V), loss weight 1 (head.py:172-181)
-        if one_launch:
-            pass
-        elif not self.continuous:
+        if not self.continuous:
             # ... and head 1, the discrete PPOHead clipped surrogate (+ entropy bonus), in one launch
             self.lib.ppo_discrete_value_losses(logits.data, self.A, actions, advantages, old_probs, self.A, B,
                                                self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
@@ -263,9 +246,7 @@ class ClippedPPONet(_NetBase):
                                          self.params.g("main/ppo_head/policy_log_std"), self.scalars[0:4],
                                          ratio_out, clipped_out, clip_dev, ctx.stream)
 
-        if one_launch:
-            pass
-        elif fused_heads:
+        if fused_heads:
             G.small_dense_backward_multi(ctx, [(self.v_head, xv, v), (self.pi_head, xp, logits)])
         else:
             self.v_head.backward(ctx, xv, v)
@@ -301,6 +282,8 @@ class ClippedPPONet(_NetBase):
 class DQNNet(_NetBase):
     """DQNNetworkParameters (agents/dqn_agent.py:43-56): embedder -> FC middleware -> QHead;
     MSE or Huber loss, importance weights from prioritized replay."""
+    FUSED_MLP = True        # small MLPs: the whole update / the acting step as one launch (tests flip these to cross-check)
+    FUSED_ACT = True
 
     def __init__(self, device, obs_shape, n_actions, activation="relu", embedder="Medium",
                  middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
@@ -333,9 +316,8 @@ class DQNNet(_NetBase):
     def _fused_mlp_setup(self):
         """obs -> Dense(relu) -> Dense(relu) -> Dense(A) Q networks (CartPole_DQN's shape) qualify for
         rlx_mlp_dqn_update: the whole learn_from_batch in ONE launch (csrc/mlp_fused.hip).
-        RLX_NO_FUSED_MLP=1 keeps the layer-by-layer path (the tests cross-check the two)."""
-        import os
-        if os.environ.get("RLX_NO_FUSED_MLP", "0") == "1" or self.image or self.dueling:
+        DQNNet.FUSED_MLP = False keeps the layer-by-layer path (the tests cross-check the two)."""
+        if not self.FUSED_MLP or self.image or self.dueling:
             return None
         ls = self.torso.layers
         if len(ls) != 2 or any(not isinstance(l, G.Dense) or l.act != "relu" or l.T != 1 for l in ls):
@@ -356,9 +338,8 @@ class DQNNet(_NetBase):
 
     def _act_setup(self):
         """the same network shape qualifies for rlx_mlp_q_act: Q(s) of a few envs + the epsilon-greedy choice as one
-        launch (RLX_NO_FUSED_ACT=1 keeps the layer launches + rlx_egreedy)."""
-        import os
-        if os.environ.get("RLX_NO_FUSED_ACT", "0") == "1" or self.image or self.dueling:
+        launch (DQNNet.FUSED_ACT = False keeps the layer launches + rlx_egreedy)."""
+        if not self.FUSED_ACT or self.image or self.dueling:
             return None
         ls = self.torso.layers
         if len(ls) != 2 or any(not isinstance(l, G.Dense) or l.act != "relu" or l.T != 1 for l in ls):

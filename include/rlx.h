@@ -334,7 +334,7 @@ int rlx_conv_input_grad(const float *dy, const float *weights, float *dx, const 
                         int towers, long long dy_tower_stride, long long w_tower_stride, long long dx_tower_stride,
                         void *stream);
 /* A layer's weight gradient (dW = X^T dY) and input gradient (dX = dY W^T) — two independent products of the same
- * dY — as ONE launch when both take the 64x64 tiled kernel (two launches otherwise; RLX_NO_GEMM_PAIR=1 forces that).
+ * dY — as ONE launch when both take the tiled kernel or both the thin kernel (two launches otherwise).
  * Each descriptor is exactly what rlx_gemm would get; when both split K they need disjoint workspaces. */
 int rlx_gemm_pair(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream);
 
@@ -360,11 +360,6 @@ int rlx_gemm_defer(const rlx_gemm_desc *desc_host, rlx_splitk_job *job_host, voi
 int rlx_gemm_pair_defer(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad,
                         rlx_splitk_job *weight_grad_job_host, void *stream);
 int rlx_splitk_reduce_jobs(const rlx_splitk_job *jobs_host, int n_jobs, void *stream);
-/* Two consecutive dense layers (second->A == first->C) as ONE launch when the first has a short reduction (K <= 64,
- * N <= 512: the observation layer of the DDPG / TD3 / DQN MLPs) and both would take the thin kernel: every workgroup
- * recomputes the rows of the hidden layer it needs in LDS.  Bit-identical to the two launches (which are what runs
- * otherwise, or with RLX_NO_GEMM_CHAIN=1); the first layer's output is written as well (the backward pass reads it). */
-int rlx_gemm_chain2(const rlx_gemm_desc *first, const rlx_gemm_desc *second, void *stream);
 /* Diagnostics (tools/gemm_timeline.py): while a device buffer of `capacity_u64` 64-bit words is registered, every
  * tiled-kernel launch of rlx_gemm records, per workgroup, four wall-clock ticks (10 ns: entry, first slab staged,
  * main loop done, exit) in its own region of the buffer; rlx_gemm_debug_calls lists the regions as rows of
@@ -467,19 +462,6 @@ typedef struct rlx_small_dense_problem {
     int towers, M, K, N, activation, lower_activation;
 } rlx_small_dense_problem;
 int rlx_dense_small_forward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
-/* Both heads of discrete Clipped PPO in ONE launch (clipped_ppo_agent.py:209-308 per minibatch): heads_host[0] = the
- * value head (N = 1), heads_host[1] = the policy head; forward (y), head losses (v_head.py:43-52, ppo_head.py:52-116,
- * head.py:143-186) with their gradients written to dy, and the heads' backward pass (dw, db, dx with lower_activation').
- * scalars[0:4] = surrogate, entropy, KL, policy-head total; value_loss_scalar[0] = value loss.  row_terms: [M][4]
- * scratch; sync_words: 2 zero-initialised uint32 (left zero).  Bit-identical to rlx_dense_small_forward_multi +
- * rlx_ppo_discrete_value_losses + rlx_dense_small_backward_multi.  status bits: 1 = action out of range, 8 = barrier
- * timeout. */
-int rlx_ppo_discrete_heads_fused(const rlx_small_dense_problem *heads_host, const int *actions,
-                                 const float *advantages, const float *old_probs, long long ld_old,
-                                 const float *value_targets, float clip_epsilon, float beta_entropy, float grad_scale,
-                                 float *scalars, float *value_loss_scalar, float *likelihood_ratio,
-                                 float *clipped_likelihood_ratio, float *row_terms, unsigned int *sync_words,
-                                 int *status, const float *clip_scale, void *stream);
 int rlx_dense_small_backward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
 
 /* -------------------------------------------------------- head losses (K9) -- */

@@ -264,6 +264,7 @@ def _oracle_worker(rank, world, port, out_dir, kind, scale_down):
     d = {k: torch.from_numpy(v).to(dev) for k, v in _shard(kind, rank, shape, A, B).items()}
     scale = dist.grad_scale(scale_down)
     assert scale == (0.5 if scale_down else 1.0)
+    np.random.seed(3)          # the VHead initializer draws from the GLOBAL numpy stream (heads/head.py:27-33)
     if kind == "ppo":
         net = ClippedPPONet(dev, shape, A, seed=3)
         net.update_target(1.0)
@@ -299,8 +300,9 @@ def test_two_rank_update_equals_oracle_on_the_union_of_the_shards(tmp_path, dev,
     np.testing.assert_array_equal(w[0], w[1])
     shape, A, B = (44, 44, 4), 4, 16
     shards = [_shard(kind, r, shape, A, B) for r in (0, 1)]
+    np.random.seed(3)
     if kind == "ppo":
-        net = ClippedPPONet(dev, shape, A, seed=3)            # same seed -> the workers' initial weights
+        net = ClippedPPONet(dev, shape, A, seed=3)            # same seeds -> the workers' initial weights
         o = ClippedPPOOracle(net.params.named_arrays(), shape, A)
         frozen = o.clone_policy()
         old = [o.policy_probs(s["obs"], frozen) for s in shards]

@@ -294,52 +294,6 @@ def test_weight_and_input_gradient_as_one_launch_equals_two(rlx, dev, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K1,H1,N2,T,mode", [(100, 23, 400, 300, 2, "shared"), (100, 17, 400, 300, 1, "pair"),
-                                                (100, 23, 400, 300, 2, "pair_shared"), (37, 5, 70, 45, 1, "plain"),
-                                                (32, 4, 256, 512, 1, "plain"), (256, 64, 512, 96, 3, "towers")])
-def test_two_dense_layers_as_one_launch_equal_two(rlx, dev, M, K1, H1, N2, T, mode):
-    """rlx_gemm_chain2 (obs -> H1 -> H2 of the small MLPs in one launch, the hidden rows recomputed per workgroup in
-    LDS) against the two thin-kernel launches: both layers' outputs bit for bit, for a shared input, per-tower inputs
-    and the online + target pair form."""
-    import torch
-    from coach_amd.nn import graph as G
-    rng = np.random.RandomState(M + K1)
-    params = G.FlatParams()
-    l1 = G.Dense(params, "l1", K1, H1, "relu", T)
-    l2 = G.Dense(params, "l2", H1, N2, "tanh" if mode == "plain" else "relu", T)
-    params.finalize(dev)
-    for l in (l1, l2):
-        l.initialize(np.random.RandomState(7))
-    params.w("l1/bias").copy_(dev_tensor(rng.randn(H1).astype(np.float32), dev))
-    params.target_weights.copy_(params.weights * 0.5 + 0.01)
-    ctx = G.Context(dev)
-    pair = mode.startswith("pair")
-    if mode == "shared":
-        x = G.Tensor(dev_tensor(rng.randn(1, M, K1).astype(np.float32), dev), M, K1, 0)
-    elif mode == "pair":
-        x = G.Tensor(dev_tensor(rng.randn(2, M, K1).astype(np.float32), dev), M, K1, 2)
-    elif mode == "pair_shared":                       # one input per copy, shared by the T streams of the copy
-        x = G.Tensor(dev_tensor(rng.randn(2, M, K1).astype(np.float32), dev), M, K1, 2)
-    else:
-        x = G.Tensor(dev_tensor(rng.randn(T, M, K1).astype(np.float32), dev), M, K1, T)
-    outs = {}
-    for chained in (True, False):
-        saved, G.CHAIN_DENSE_LAYERS = G.CHAIN_DENSE_LAYERS, chained
-        try:
-            y1, y2 = G.dense_chain2_forward(ctx, l1, l2, x, tag="c%d" % chained, pair=pair)
-        finally:
-            G.CHAIN_DENSE_LAYERS = saved
-        torch.cuda.synchronize()
-        outs[chained] = (y1.data.clone(), y2.data.clone())
-    assert torch.equal(outs[True][0], outs[False][0])
-    assert torch.equal(outs[True][1], outs[False][1])
-    ref1 = np.maximum(x.data[0].cpu().numpy().astype(np.float64) @ params.w("l1/kernel").cpu().numpy().astype(np.float64)
-                      + params.w("l1/bias").cpu().numpy(), 0)
-    np.testing.assert_allclose(outs[True][0][0].cpu().numpy(), ref1, rtol=2e-5, atol=2e-5)
-    assert float(outs[True][1].abs().sum()) > 0
-
-
-@pytest.mark.gpu
 def test_deferred_weight_gradient_reductions_equal_immediate_ones(rlx, dev):
     """Sequential.backward leaves the split-K partials of every layer's weight gradient in an arena and sums them with
     ONE rlx_splitk_reduce_jobs launch at its end; the gradients must equal those of the per-layer reductions (same

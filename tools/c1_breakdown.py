@@ -1,5 +1,5 @@
 """Where does a C1 env-step go?  Host-side wall time of act() / train() with and without a device
-sync after each, for the fused and the layer-by-layer update (RLX_NO_FUSED_MLP=1).  Run on the GPU box."""
+sync after each, for the fused and the layer-by-layer update (DQNNet.FUSED_MLP = False).  Run on the GPU box."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
