@@ -46,18 +46,29 @@ class NetworkWrapper(object):
         self.update_target_network()
 
     # ---- training --------------------------------------------------------------------------
-    def apply_gradients_to_online_network(self, gradients=None):
+    def apply_gradients_to_online_network(self, gradients=None, additional_inputs=None):
+        """network_wrapper.py:143-154 (additional_inputs: batch-norm update ops need none here — the statistics of the
+        tracked pass are committed with the step, nn/graph.py BatchNorm)."""
         net = self.online_network
         net.apply_gradients(net.accumulated_gradients if gradients is None else gradients)
 
-    apply_gradients_to_global_network = apply_gradients_to_online_network
+    def apply_gradients_to_global_network(self, gradients=None, additional_inputs=None):
+        """network_wrapper.py:127-141: with a shared optimizer the GLOBAL network takes the step; without a global
+        network (always, here: workers exchange gradients, not parameters) the online network does."""
+        self.apply_gradients_to_online_network(gradients, additional_inputs)
 
-    def apply_gradients_and_sync_networks(self, reset_gradients=True):
+    def collect_savers(self, parent_path_suffix):
+        """network_wrapper.py:250-270: savers of the copy that holds the most recent parameters — the online network
+        (a global network would take precedence; the target network never does)."""
+        return self.online_network.collect_savers(parent_path_suffix)
+
+    def apply_gradients_and_sync_networks(self, reset_gradients=True, additional_inputs=None):
         net = self.online_network
         step = net.apply_and_reset_gradients if reset_gradients else net.apply_gradients
         step(net.accumulated_gradients)
 
-    def train_and_sync_networks(self, inputs, targets, additional_fetches=[], importance_weights=None):
+    def train_and_sync_networks(self, inputs, targets, additional_fetches=[], importance_weights=None,
+                                use_inputs_for_apply_gradients=False):
         """accumulate (overwriting) + apply; returns accumulate_gradients' tuple
         (total_loss, losses, norm_unclipped_grads, fetched)."""
         out = self.online_network.accumulate_gradients(

@@ -120,6 +120,15 @@ class EpisodicExperienceReplay(ExperienceReplay):
         if record:
             if self._evaluating:
                 raise RuntimeError("the replay memory is not written during evaluation")
+            # BEFORE the write: the ring slot of this step may still hold the oldest listed episode when steps were
+            # written and never listed (open episodes dropped by a forced reset / an evaluation): evict it, like the
+            # reference keeps evicting its oldest episodes (:300-317).  A RUNNING episode that old is a sizing error.
+            while self._episode_first_step and self._gstep - self._episode_first_step[0] >= self._ring_steps:
+                self._evict_first()
+            if self._gstep - int(self._ep_start.min()) >= self._ring_steps:
+                raise RuntimeError("episodic replay ring overrun: a running episode is %d vector steps old, the ring "
+                                   "holds %d (episodes longer than max_episode_length=%d?)"
+                                   % (self._gstep - int(self._ep_start.min()), self._ring_steps, self.Tmax))
             row0 = (self._gstep % self._ring_steps) * self.n_env
             pairs = [(actions, self.action), (rewards, self.reward), (stored_go, self.game_over),
                      (self.cur_state, self.obs), (next_obs, self.next_obs)]
@@ -128,11 +137,6 @@ class EpisodicExperienceReplay(ExperienceReplay):
         self.lib.select_rows(game_overs, reset_obs, next_obs, self.cur_state, self.n_env, self.obs_dim * 4, s)
         if not record:
             return
-        if self._episode_first_step and self._gstep - min(self._episode_first_step[0], int(self._ep_start.min())) \
-                >= self._ring_steps:
-            raise RuntimeError("episodic replay ring overrun: a listed episode is %d vector steps old, the ring holds "
-                               "%d (episodes longer than max_episode_length=%d?)"
-                               % (self._gstep - self._episode_first_step[0], self._ring_steps, self.Tmax))
         self._gstep += 1
         if dones_host is None:
             ended = range(self.n_env) if episode_end else ()

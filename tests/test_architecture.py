@@ -44,10 +44,17 @@ def test_interface_surface_cpu():
             assert list(inspect.signature(getattr(cls, name)).parameters)[1:] == args, (cls.__name__, name)
         assert list(inspect.signature(cls.parallel_predict).parameters) == ["sess", "network_input_tuples"]
         assert list(inspect.signature(cls.construct).parameters)[:2] == ["variable_scope", "devices"]
-    for m in ("sync", "update_target_network", "update_online_network", "apply_gradients_to_online_network",
-              "train_and_sync_networks", "apply_gradients_and_sync_networks", "parallel_prediction",
-              "set_is_training", "set_session"):
-        assert callable(getattr(NetworkWrapper, m))
+    # NetworkWrapper (network_wrapper.py:100-270): every public method with the reference's argument names
+    wrapper = {"sync": [], "update_target_network": ["rate"], "update_online_network": ["rate"],
+               "apply_gradients_to_global_network": ["gradients", "additional_inputs"],
+               "apply_gradients_to_online_network": ["gradients", "additional_inputs"],
+               "train_and_sync_networks": ["inputs", "targets", "additional_fetches", "importance_weights",
+                                           "use_inputs_for_apply_gradients"],
+               "apply_gradients_and_sync_networks": ["reset_gradients", "additional_inputs"],
+               "parallel_prediction": ["network_input_tuples"], "set_is_training": ["state"], "set_session": ["sess"],
+               "collect_savers": ["parent_path_suffix"]}
+    for name, args in wrapper.items():
+        assert list(inspect.signature(getattr(NetworkWrapper, name)).parameters)[1:] == args, name
     with pytest.raises(NotImplementedError):
         NetworkWrapper(_params(), has_target=True, has_global=True, name="main", spaces=_spaces((4,), 2))
 

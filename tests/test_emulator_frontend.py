@@ -160,3 +160,43 @@ def test_clipped_ppo_trains_on_the_emulator_front_end(dev):
                 break
     assert trained == 3
     assert torch.isfinite(agent.networks["main"].params.weights).all()
+
+
+@pytest.mark.gpu
+def test_evaluation_switches_the_environment_to_test_semantics(dev):
+    """GraphManager.phase is also the environments' phase (graph_manager.py:333-344): during evaluate_episodes the front
+    end must apply its TEST rules (a lost life does NOT end the episode, gym_environment.py:418-424) without anyone
+    setting env.phase by hand, and go back to the training rules afterwards."""
+    from coach_amd.agents.dqn_agent import DQNAgent, DQNAgentParameters
+    from coach_amd.core_types import EnvironmentSteps, RunPhase
+    from coach_amd.environments.emulator_frontend import EmulatorEnvironmentParameters, EmulatorVectorEnvironment
+    from coach_amd.graph_managers.basic_rl_graph_manager import BasicRLGraphManager, ScheduleParameters
+    from coach_amd.memories.memory import MemoryGranularity
+    p = EmulatorEnvironmentParameters([_emu(s + 3, life_every=9, lives=3, game_len=60) for s in range(2)], 4,
+                                      random_initialization_steps=0, max_episode_steps=80)
+    env = EmulatorVectorEnvironment(p, dev)
+    seen = []
+    step = env.step
+    env.step = lambda a: (seen.append(env.phase), step(a))[1]
+    ap = DQNAgentParameters()
+    ap.network_wrappers["main"].batch_size = 8
+    ap.algorithm.num_consecutive_playing_steps = EnvironmentSteps(4)
+    ap.memory.max_size = (MemoryGranularity.Transitions, 256)
+    agent = DQNAgent(ap, env, dev)
+    gm = BasicRLGraphManager(ap, p, ScheduleParameters(), device=dev)
+    gm.agent, gm.environment = agent, env
+    random.seed(0); np.random.seed(0)
+    gm.heatup(EnvironmentSteps(16))
+    assert set(seen) == {RunPhase.HEATUP}
+    gm.train_and_act(EnvironmentSteps(16))
+    train_lengths = list(agent.ended_episode_lengths) if agent._episode_just_ended else []
+    del seen[:]
+    reward = agent.evaluate_episodes(1)
+    assert set(seen) == {RunPhase.TEST} and env.phase == RunPhase.TRAIN and agent.phase == RunPhase.TRAIN
+    # TEST semantics: an evaluation episode runs through its life losses (3 lives x 9 steps) instead of ending at the first
+    assert len(seen) >= 2 * 9 and np.isfinite(reward)
+    del seen[:]
+    gm.evaluate(EnvironmentSteps(1))
+    assert set(seen) == {RunPhase.TEST} and gm.phase == RunPhase.TRAIN and env.phase == RunPhase.TRAIN
+    agent.check_status()
+    assert train_lengths is not None

@@ -113,3 +113,33 @@ def test_envs_finishing_on_different_steps(dev):
             assert np.array_equal(b["n_step_discounted_rewards"].cpu().numpy(), np.array(o.nsr))
     m.check_status()
     assert m.episode_lengths() == o.episodes
+
+
+@pytest.mark.gpu
+def test_dropped_open_episodes_never_overrun_the_ring(dev):
+    """Every drop_open_episode() (a forced reset in the middle of an episode: evaluations, period starts) leaves written
+    but never-listed steps in the ring.  However many of those accumulate, the memory keeps working: the slot a new step
+    needs is freed by evicting the oldest listed episode BEFORE the write, the listed episodes are always intact."""
+    import torch
+    m = _memory(dev, 24, False, -1, 1, 6)
+    m.reset(torch.zeros(1, 1, device=dev))
+    t = lambda v, dt: torch.tensor([v], dtype=dt, device=dev)
+    k, listed = 0, []
+    for rnd in range(60):
+        for j in range(4):                                   # four steps of an episode that is then abandoned
+            m.store(t(0, torch.int32).view(1), t(-1.0, torch.float32).view(1), t(0, torch.uint8).view(1),
+                    t(0.0, torch.float32).view(1, 1), t(0.0, torch.float32).view(1, 1), dones_host=np.array([False]))
+        m.drop_open_episode()
+        ep = []
+        for j in range(3):                                   # ... and a complete one
+            k += 1
+            ep.append(float(k))
+            m.store(t(0, torch.int32).view(1), t(float(k), torch.float32).view(1), t(int(j == 2), torch.uint8).view(1),
+                    t(0.0, torch.float32).view(1, 1), t(0.0, torch.float32).view(1, 1), dones_host=np.array([j == 2]))
+        listed.append(ep)
+        n = m.num_transitions()
+        assert 3 <= n <= 24 and n % 3 == 0
+        held = m.gather(m.physical_rows(np.arange(n)), n)["reward"].cpu().numpy()
+        want = np.array([r for e in listed[-(n // 3):] for r in e], dtype=np.float32)
+        assert np.array_equal(held, want), rnd                # the newest n / 3 complete episodes, untouched
+    m.check_status()

@@ -80,17 +80,22 @@ def test_graph_manager_writes_one_reference_style_row_per_episode(dev, tmp_path)
         table = list(csv.DictReader(f))
     assert list(table[0].keys()) == ["Episode #"] + GOLD["dqn_columns"]
     assert len(table) == len(rows)
-    # the CPU twin of the env gives every episode's rewards
+    # the CPU twin of the env gives every episode's rewards.  Heat-up and the two training periods are 14 vector steps
+    # each; env 1 (episodes of 5) is in the middle of an episode when a period ends, so the next period starts from a
+    # forced reset of every env (GraphManager.train_and_act -> reset_internal_state(force_environment_reset=True),
+    # graph_manager.py:477) and the open episode is never logged
     o = SynthVecEnv(1, n_env, 4, L, 21, episode_lengths=[7, 5])
-    o.reset()
-    acc, expect = [[], []], []
-    for _ in range(6 * 7):
-        _, _, rew, done = o.step()
-        for e in range(n_env):
-            acc[e].append(float(rew[e]))
-            if done[e]:
-                expect.append((e, acc[e]))
-                acc[e] = []
+    expect = []
+    for period in range(3):
+        o.reset()
+        acc = [[], []]
+        for _ in range(2 * 7):
+            _, _, rew, done = o.step()
+            for e in range(n_env):
+                acc[e].append(float(rew[e]))
+                if done[e]:
+                    expect.append((e, acc[e]))
+                    acc[e] = []
     assert len(table) == len(expect)
     for row, (e, rewards) in zip(table, expect):
         assert int(row["Episode Length"]) == len(rewards)
