@@ -1435,6 +1435,9 @@ constexpr int kSplitMaxTiles = rlx::kCUs;  // ... unless the launch already cove
 constexpr int kThinMaxTiles = 96;          // thin kernel: at most this many 64 x 64 tiles
 constexpr int kThin16MaxTiles = 128;       // 16 x 16 tiles inside a dW + dX pair grid up to this many 32 x 32 tiles ...
 constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a launch of its own
+// in-workgroup K split: taken when the 64 x 64 tiling has fewer than g_kw_below_tiles tiles and the smaller tiling at
+// least g_kw_min_tiles (rlx_gemm_tuning: an explicit knob for same-process A/Bs, tools/ab_c2.py)
+int g_kw_below_tiles = 192, g_kw_min_tiles = 192;
 
 // diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
 struct StampCall { int M, N, K, batch, splits, gx, gy, gz; long long offset; };
@@ -1468,6 +1471,13 @@ int rlx_gemm_debug_calls(long long *out_host, int max_calls, int *n_calls_host) 
         o[5] = c.gx; o[6] = c.gy; o[7] = c.gz; o[8] = c.offset;
     }
     *n_calls_host = n;
+    return RLX_OK;
+}
+
+int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles) {
+    RLX_REQUIRE(kw_below_tiles >= 0 && kw_min_tiles >= 1, "rlx_gemm_tuning: bad thresholds");
+    g_kw_below_tiles = kw_below_tiles;
+    g_kw_min_tiles = kw_min_tiles;
     return RLX_OK;
 }
 
@@ -1626,13 +1636,12 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
     // Mid-sized problems (too few 64 x 64 tiles for the chip, enough 32 x 64 or 32 x 32 ones): smaller tiles with the K
     // slab split over the waves of the workgroup instead of K split over workgroups — no partials, no reduce launch.
     int KW = 1;
-    constexpr int kMinTilesForChip = 192;            // 3/4 of the CUs
     const bool u8_in = d.a_is_u8 != 0;
     // (operand combinations launch_fast instantiates; anything else falls back to the bounds-checked 64 x 64 kernel)
     const bool fast_combo = (!u8_in && !a_tab) || (a_tab && !b_vec_red);
-    if (fast && fast_combo && !narrow && BM == 64 && BN == 64 && tiles_of(64, 64) < kMinTilesForChip) {
-        if (tiles_of(32, 64) >= kMinTilesForChip) { BM = 32; BN = 64; KW = 2; }
-        else if (tiles_of(32, 32) >= kMinTilesForChip) { BM = 32; BN = 32; KW = 4; }
+    if (fast && fast_combo && !narrow && BM == 64 && BN == 64 && tiles_of(64, 64) < g_kw_below_tiles) {   // default: 3/4 of the CUs
+        if (tiles_of(32, 64) >= g_kw_min_tiles) { BM = 32; BN = 64; KW = 2; }
+        else if (tiles_of(32, 32) >= g_kw_min_tiles) { BM = 32; BN = 32; KW = 4; }
     }
     const int tiles = (int)tiles_of(BM, BN);
     // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split; a launch that

@@ -313,6 +313,10 @@ typedef struct rlx_gemm_desc {
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
 int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host);
+/* Path-selection thresholds of rlx_gemm (process-wide; defaults 192 / 192): a problem whose 64 x 64 tiling has fewer than
+ * kw_below_tiles tiles runs on 32 x 64 / 32 x 32 tiles with the K slab split over the waves of a workgroup, if that
+ * tiling has at least kw_min_tiles tiles.  An explicit knob for same-process A/B measurements (tools/ab_c2.py). */
+int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles);
 
 /* Input gradient of a VALID-padding NHWC convolution (tf.gradients of tf.layers.conv2d,
  * architectures/tensorflow_components/layers.py:108-121, architecture.py:187-220) as ONE product that gathers dY

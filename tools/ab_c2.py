@@ -17,20 +17,22 @@ class _Dist(object):
         pass
 
 
-def build(direct, defer):
+def build(direct, defer, tuning=(192, 192)):
     import bench
     from coach_amd.nn import graph as G
     G.DIRECT_CONV_INPUT_GRAD = direct
     agent = bench.build_agent(torch.device("cuda:0"), _Dist())
     if not defer:
         agent.networks["main"].ctx.begin_deferring = lambda: False
-    agent._ab = (direct, defer)
+    agent._ab = (direct, defer, tuning)
     return agent
 
 
 def train_ms(agent):
+    from coach_amd import _rlx
     from coach_amd.nn import graph as G
     G.DIRECT_CONV_INPUT_GRAD = agent._ab[0]
+    _rlx.lib().gemm_tuning(*agent._ab[2])            # read when the update's graphs are captured
     for _ in range(agent.steps_per_phase):
         agent.act()
     agent.networks["main"].update_target(1.0)
@@ -47,18 +49,21 @@ def train_ms(agent):
 
 
 def main(rounds=4):
-    variants = {"default (column-matrix dX, deferred reductions)": (False, True),
-                "direct dX where < 1.3x the products": (True, True), "direct dX always": ("always", True),
-                "per-layer reductions": (False, False)}
+    variants = {"default (column-matrix dX, deferred reductions, K-in-workgroup below 192 tiles)": (False, True),
+                "K-in-workgroup tiles below 512 tiles (conv1 forward on 32 x 64)": (False, True, (512, 192)),
+                "K-in-workgroup tiles accepted from 64 tiles (FC forward on 32 x 32, no split-K)": (False, True, (192, 64)),
+                "both": (False, True, (512, 64))}
     agents = {k: build(*v) for k, v in variants.items()}
     for a in agents.values():
         for _ in range(3):
             train_ms(a)
+    from coach_amd import _rlx
     res = {k: [] for k in agents}
     for _ in range(rounds):
         for k, a in agents.items():
             res[k].append(train_ms(a))
     out = {k: {"us_per_update": round(1e3 * min(v) / 320, 1), "all": [round(1e3 * x / 320, 1) for x in v]} for k, v in res.items()}
+    _rlx.lib().gemm_tuning(192, 192)
     print(json.dumps(out))
 
 
