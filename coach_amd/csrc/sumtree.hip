@@ -125,6 +125,156 @@ per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__r
     if (tid == 0 && !ring) *max_priority = mx[0];          // (:201)
 }
 
+// The same update for n <= 1024 leaves with ONE memory round trip per FIVE tree levels instead of one per level (the
+// level-synchronous kernel above is a chain of `levels` dependent load -> store -> barrier steps: 17 us for 64 leaves of
+// a 2^20-leaf tree, 23 % of the C3 GPU time in profiles/r03_call8_c3_kernel_stats.csv).
+// Thread i carries the node of leaf i that sits on the current level, with its three values, in registers.  The other
+// child of the node's parent either lies on another updated leaf's path — then some thread holds its NEW value, found
+// through a per-level hash table in LDS (tag = node id, linear probing; threads that reached the same node computed
+// the same values, the first inserts) — or it is untouched by this launch and its value was prefetched, five levels
+// at a time, before the walk reached it.  Parents are recomputed from (left, right) exactly like _propagate (:63-74):
+// bit-identical trees.  Every thread stores the nodes it computes (duplicates store identical values).
+constexpr int kPathSlots = 2048, kPathChunk = 5;
+__global__ void __launch_bounds__(1024)
+per_update_paths_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__restrict__ mx,
+                        int cap, int levels, const int *__restrict__ idx,
+                        const double *__restrict__ err, const double *__restrict__ leaf_pa,
+                        const double *__restrict__ leaf_p, int n, int start_leaf, double alpha,
+                        double eps, double *__restrict__ max_priority, int mode,
+                        int *__restrict__ status) {
+    __shared__ int tag[kPathSlots];
+    __shared__ double vs[kPathSlots], vm[kPathSlots], vx[kPathSlots];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const double stored_priority = (mode == 1) ? *max_priority : alpha;
+    const bool ring = (mode == 1 || mode == 3);
+    // ---- the leaf of this thread (n <= blockDim.x)
+    int node = -1;                      // -1: no valid leaf
+    bool live = false;                  // this thread's occurrence of the leaf is the one that counts
+    double s = 0.0, m = 0.0, x = 0.0;
+    if (tid < n) {
+        int leaf;
+        live = true;
+        if (ring) {
+            leaf = (start_leaf + tid) & (cap - 1);
+            x = stored_priority;
+            int odd = 0;
+            s = (mode == 1) ? rlx::libm_pow(x, alpha, &odd) : eps;     // maximal_priority ** alpha (:274)
+            if (odd) atomicOr(status, 4);
+        } else {
+            leaf = idx[tid];
+            if (leaf < 0 || leaf >= cap) {          // reference raises ValueError (:123-126)
+                atomicOr(status, 1);
+                live = false;
+            }
+            if (mode == 0) {
+                const double e = err[tid];
+                if (e < 0.0) {                      // "priorities must be non-negative" (:195)
+                    atomicOr(status, 2);
+                    live = false;
+                }
+                x = e + eps;
+                int odd = 0;
+                s = rlx::libm_pow(x, alpha, &odd);                    // priority ** self.alpha (:197)
+                if (odd) atomicOr(status, 4);
+            } else {
+                s = leaf_pa[tid];
+                x = leaf_p[tid];
+            }
+        }
+        m = s;
+        if (leaf >= 0 && leaf < cap) {
+            node = leaf + cap - 1;
+            // last occurrence of a duplicated index wins (:214-215); an earlier one adopts the winner's values below
+            if (!ring)
+                for (int j = tid + 1; live && j < n; ++j)
+                    if (idx[j] == leaf) live = false;
+        }
+        if (live) {
+            sum[node] = s;
+            mn[node] = m;
+            mx[node] = x;
+        }
+    }
+    auto clear = [&]() {
+        for (int i = tid; i < kPathSlots; i += nthr) tag[i] = -1;
+    };
+    auto insert = [&](int key, double a, double b, double c) {
+        int slot = key & (kPathSlots - 1);
+        while (true) {
+            const int prev = atomicCAS(&tag[slot], -1, key);
+            if (prev == -1) {
+                vs[slot] = a; vm[slot] = b; vx[slot] = c;
+                return;
+            }
+            if (prev == key) return;
+            slot = (slot + 1) & (kPathSlots - 1);
+        }
+    };
+    auto find = [&](int key) {
+        int slot = key & (kPathSlots - 1);
+        while (tag[slot] != -1) {
+            if (tag[slot] == key) return slot;
+            slot = (slot + 1) & (kPathSlots - 1);
+        }
+        return -1;
+    };
+    // level 0: publish the winning occurrences, the others read their leaf's final values back
+    clear();
+    __syncthreads();
+    if (live) insert(node, s, m, x);
+    __syncthreads();
+    if (node >= 0 && !live) {
+        const int slot = find(node);
+        if (slot >= 0) { s = vs[slot]; m = vm[slot]; x = vx[slot]; }
+        else node = -1;                                   // every occurrence of this leaf was rejected
+    }
+    for (int lvl0 = 0; lvl0 < levels; lvl0 += kPathChunk) {
+        // siblings of this thread's ancestors on the next five levels: one round trip
+        double ps[kPathChunk], pm[kPathChunk], px[kPathChunk];
+        {
+            int a = node;
+#pragma unroll
+            for (int j = 0; j < kPathChunk; ++j) {
+                ps[j] = pm[j] = px[j] = 0.0;
+                if (a > 0 && lvl0 + j < levels) {
+                    const int sib = (a & 1) ? a + 1 : a - 1;
+                    ps[j] = sum[sib]; pm[j] = mn[sib]; px[j] = mx[sib];
+                    a = (a - 1) >> 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPathChunk; ++j) {
+            if (lvl0 + j >= levels) break;
+            __syncthreads();                              // the previous level's lookups are done
+            clear();
+            __syncthreads();
+            if (node > 0) insert(node, s, m, x);
+            __syncthreads();
+            if (node > 0) {
+                const int sib = (node & 1) ? node + 1 : node - 1;
+                double bs = ps[j], bm = pm[j], bx = px[j];
+                const int slot = find(sib);
+                if (slot >= 0) { bs = vs[slot]; bm = vm[slot]; bx = vx[slot]; }
+                const bool left = (node & 1) != 0;        // odd heap index = left child (2p + 1)
+                const double sl = left ? s : bs, sr = left ? bs : s;
+                const double ml = left ? m : bm, mr = left ? bm : m;
+                const double xl = left ? x : bx, xr = left ? bx : x;
+                const int parent = (node - 1) >> 1;
+                s = sl + sr;                              // operator.add (:57)
+                m = (mr < ml) ? mr : ml;                  // python min(a,b): b if b<a else a
+                x = (xr > xl) ? xr : xl;                  // python max(a,b): b if b>a else a
+                sum[parent] = s;
+                mn[parent] = m;
+                mx[parent] = x;
+                node = parent;
+            }
+        }
+    }
+    // every valid path ends at the root with the root's values in registers: maximal_priority = max_tree root (:201)
+    if (!ring && node == 0) *max_priority = x;
+}
+
 // One draw per thread.  u[i] is CPython's random.random() drawn on the host, so that
 // val == random.uniform(seg*i, seg*(i+1)) bit for bit (:240-244).
 __global__ void per_sample_kernel(const double *__restrict__ sum, const double *__restrict__ mn,
@@ -220,6 +370,13 @@ static int launch_update(double *sum_tree, double *min_tree, double *max_tree, i
     if (n == 0) return RLX_OK;
     int threads = ((n + 63) / 64) * 64;
     if (threads > 1024) threads = 1024;
+    if (n <= 1024) {          // one leaf per thread: the path walk with batched round trips
+        per_update_paths_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
+            sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
+            start_leaf, alpha, eps, max_priority, mode, status);
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
+    }
     per_update_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
         sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
         start_leaf, alpha, eps, max_priority, mode, status);

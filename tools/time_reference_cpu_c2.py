@@ -36,7 +36,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def one_worker(play, seed, q=None):
+def one_worker(play, seed, q=None, reps=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import _refstub
@@ -101,7 +101,8 @@ def one_worker(play, seed, q=None):
     reset_required, first = False, None
     t_act = t_train = 0.0
     steps = updates = 0
-    while updates == 0:
+    done_reps = []
+    while len(done_reps) < reps:
         t0 = time.perf_counter()
         if reset_required:
             agent.reset_internal_state()
@@ -124,39 +125,48 @@ def one_worker(play, seed, q=None):
         if agent.training_iteration != before:
             updates = agent.training_iteration - before
             t_train = t2 - t1
-    res = dict(steps=steps, updates=updates, t_act=t_act, t_train=t_train)
+            done_reps.append(dict(steps=steps, updates=updates, t_act=t_act, t_train=t_train))
+            t_act, steps = 0.0, 0
     if q is not None:
-        q.put(res)
-    return res
+        q.put(done_reps)
+    return done_reps
 
 
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--play", type=int, default=128, help="env-steps of the timed sample (a multiple of 64 and of 32)")
     p.add_argument("--procs", type=int, default=1)
+    p.add_argument("--reps", type=int, default=1, help="timed samples per process; the MEDIAN is reported "
+                                                        "(BASELINE.md section 3: median of 5)")
     a = p.parse_args()
     t0 = time.perf_counter()
     if a.procs == 1:
-        results = [one_worker(a.play, 0)]
+        results = [one_worker(a.play, 0, None, a.reps)]
     else:
         q = mp.Queue()
-        ps = [mp.Process(target=one_worker, args=(a.play, i, q)) for i in range(a.procs)]
+        ps = [mp.Process(target=one_worker, args=(a.play, i, q, a.reps)) for i in range(a.procs)]
         for x in ps:
             x.start()
         results = [q.get() for _ in ps]
         for x in ps:
             x.join()
     wall = time.perf_counter() - t0
-    per_proc = []
-    for r in results:
-        t_step = r["t_act"] / r["steps"]
-        # one training phase over `steps` transitions = steps/64 value chunks + steps/64 minibatch updates
-        # (1 epoch); scaled: value pass ~ 1/4 of a minibatch update's cost (1 forward of 4 passes) is NOT
-        # separated — the whole phase is attributed per update, which slightly favours the CPU
-        t_update = r["t_train"] / r["updates"]
-        t_iter = 2048 * t_step + 320 * t_update
-        per_proc.append(dict(env_steps_per_s=2048 / t_iter, updates_per_s=320 / t_iter, s_per_env_step=t_step,
+    per_proc, all_reps = [], []
+    for reps in results:
+        cand = []
+        for r in reps:
+            t_step = r["t_act"] / r["steps"]
+            # one training phase over `steps` transitions = steps/64 value chunks + steps/64 minibatch updates
+            # (1 epoch); scaled: value pass ~ 1/4 of a minibatch update's cost (1 forward of 4 passes) is NOT
+            # separated — the whole phase is attributed per update, which slightly favours the CPU
+            t_update = r["t_train"] / r["updates"]
+            t_iter = 2048 * t_step + 320 * t_update
+            cand.append(dict(env_steps_per_s=2048 / t_iter, updates_per_s=320 / t_iter, s_per_env_step=t_step,
                              s_per_update=t_update))
+        cand.sort(key=lambda c: c["env_steps_per_s"])
+        per_proc.append(cand[len(cand) // 2])                  # the median repetition of this process
+        all_reps.append([round(c["env_steps_per_s"], 3) for c in cand])
+    results = [r[0] for r in results]
     agg = sum(x["env_steps_per_s"] for x in per_proc)
     print(json.dumps({
         "metric": "env-steps/sec (+ grad-updates/sec), C2, reference code on CPU",
@@ -168,9 +178,13 @@ def main():
                   "clipping filters, one policy forward per step) and one training phase over them (fill_advantages + "
                   "train_network, 1 epoch = %d minibatch updates of 64 incl. the per-minibatch old-policy pass), "
                   "scaled to a full C2 iteration = 2048 env-steps + 320 updates; numpy oracle (1 thread) as the "
-                  "network backend; wall %.0f s" % (results[0]["steps"], results[0]["updates"], wall),
+                  "network backend; %d repetitions, median reported; wall %.0f s"
+                  % (results[0]["steps"], results[0]["updates"], a.reps, wall),
+        "repetitions_per_process": a.reps, "env_steps_per_s_of_every_repetition": all_reps,
+        "protocol": "BASELINE.md section 3: >= 10^3 env-steps per repetition for image configs, median of the "
+                    "repetitions, time.perf_counter, heat-up excluded (PPO has none)",
         "host": platform.processor() or platform.machine(), "host_cores": os.cpu_count(),
-        "where": "build container (no GPU)"}))
+        "where": "build container (NOT the GPU box: /root/reference does not exist there)"}))
 
 
 if __name__ == "__main__":
