@@ -125,154 +125,252 @@ per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__r
     if (tid == 0 && !ring) *max_priority = mx[0];          // (:201)
 }
 
-// The same update for n <= 1024 leaves with ONE memory round trip per FIVE tree levels instead of one per level (the
-// level-synchronous kernel above is a chain of `levels` dependent load -> store -> barrier steps: 17 us for 64 leaves of
-// a 2^20-leaf tree, 23 % of the C3 GPU time in profiles/r03_call8_c3_kernel_stats.csv).
-// Thread i carries the node of leaf i that sits on the current level, with its three values, in registers.  The other
-// child of the node's parent either lies on another updated leaf's path — then some thread holds its NEW value, found
-// through a per-level hash table in LDS (tag = node id, linear probing; threads that reached the same node computed
-// the same values, the first inserts) — or it is untouched by this launch and its value was prefetched, five levels
-// at a time, before the walk reached it.  Parents are recomputed from (left, right) exactly like _propagate (:63-74):
-// bit-identical trees.  Every thread stores the nodes it computes (duplicates store identical values).
-constexpr int kPathSlots = 2048, kPathChunk = 5;
-__global__ void __launch_bounds__(1024)
+// The same update for n <= 256 leaves without a memory round trip per level.  The level-synchronous kernel above is
+// a chain of `levels` dependent load -> store -> barrier steps, and a __syncthreads() behind global stores waits for
+// their write acknowledgements: 17 us for 64 leaves of a 2^20-leaf tree, 23 % of the C3 GPU time
+// (profiles/r03_call8_c3_kernel_stats.csv).  Here the updated leaves are first ordered by leaf index (a counting rank
+// in LDS) and thread t takes the t-th of them: it carries the node of that leaf's path that sits on the current level,
+// with its three values, in registers.  In that order the threads below one node form a run [lo, hi] of neighbours,
+// all holding the same values, and the sibling of a left child can only be carried by the run that starts at hi + 1
+// (of a right child: the run that ends at lo - 1).  So one level costs one look at ONE other thread's registers:
+//   * n <= 64 (one wavefront, WAVE): eight ds_bpermute in flight together — one LDS-crossbar round trip, no barrier;
+//   * n <= 256: a 48-byte record per thread in LDS, double-buffered, one barrier per level that waits for LDS traffic
+//     alone.
+// A sibling that no updated leaf lies below is untouched by this launch and was prefetched — the siblings of twenty
+// levels in ONE round trip, issued before the pow.  The first thread of a run writes the node to the tree; those
+// stores are never waited for.  Parents are recomputed from (left, right) exactly like _propagate (:63-74):
+// bit-identical trees.  (A first version that found siblings through an LDS hash table was no faster than the kernel
+// above — four to five dependent LDS round trips per level; profiles/r03_ab_per_update.txt.)
+constexpr int kPathChunk = 20, kPathMaxLeaves = 256;
+#ifdef RLX_PER_PROFILE                  // tools/per_update_profile.hip: phase timestamps of thread 0 (100 MHz counter)
+__device__ long long g_per_prof[8];
+#define PER_PROF(k) do { if (threadIdx.x == 0) g_per_prof[k] = wall_clock64(); } while (0)
+#else
+#define PER_PROF(k) do {} while (0)
+#endif
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ double shfl_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl((int)(b & 0xffffffffll), lane), hi = __shfl((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+struct __attribute__((aligned(16))) PathRec {     // what a run shows its neighbours (n > 64)
+    int node, lo, hi, pad;
+    double s, m, x, pad2;
+};
+
+template <bool WAVE>
+__global__ void __launch_bounds__(WAVE ? 64 : kPathMaxLeaves)
 per_update_paths_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__restrict__ mx,
                         int cap, int levels, const int *__restrict__ idx,
                         const double *__restrict__ err, const double *__restrict__ leaf_pa,
                         const double *__restrict__ leaf_p, int n, int start_leaf, double alpha,
                         double eps, double *__restrict__ max_priority, int mode,
                         int *__restrict__ status) {
-    __shared__ int tag[kPathSlots];
-    __shared__ double vs[kPathSlots], vm[kPathSlots], vx[kPathSlots];
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    constexpr int kThreads = WAVE ? 64 : kPathMaxLeaves;
+    constexpr int kNoLeaf = 0x7fffffff;
+    PER_PROF(0);
+    __shared__ __attribute__((aligned(16))) int key[kThreads];
+    __shared__ int sorted_leaf[kThreads], sorted_lo[kThreads], sorted_hi[kThreads];
+    __shared__ double sorted_a[kThreads], sorted_b[kThreads];
+    __shared__ PathRec rec[WAVE ? 1 : 2][WAVE ? 1 : kPathMaxLeaves];
+    const int tid = threadIdx.x;
     const double stored_priority = (mode == 1) ? *max_priority : alpha;
     const bool ring = (mode == 1 || mode == 3);
-    // ---- the leaf of this thread (n <= blockDim.x)
-    int node = -1;                      // -1: no valid leaf
-    bool live = false;                  // this thread's occurrence of the leaf is the one that counts
-    double s = 0.0, m = 0.0, x = 0.0;
+    // ---- inputs in launch order; an out-of-range index sorts behind everything and carries no node
+    int leaf = kNoLeaf;
+    double in_a = 0.0, in_b = 0.0;
     if (tid < n) {
-        int leaf;
-        live = true;
         if (ring) {
             leaf = (start_leaf + tid) & (cap - 1);
+        } else {
+            leaf = idx[tid];
+            if (mode == 0) in_a = err[tid];
+            else { in_a = leaf_pa[tid]; in_b = leaf_p[tid]; }
+            if (leaf < 0 || leaf >= cap) {          // reference raises ValueError (:123-126)
+                atomicOr(status, 1);
+                leaf = kNoLeaf;
+            }
+        }
+    }
+    key[tid] = leaf;
+    lds_barrier();
+    // ---- order by leaf: position = number of occurrences that sort before this one (ties by launch order).  The
+    // occurrences of one leaf end up as one run whose LAST position is the last occurrence — the one that wins
+    // (:214-215).
+    {
+        int lo = 0, same = 0, before = 0;
+        const int n4 = (n + 3) & ~3;                      // keys behind n are kNoLeaf
+        for (int j = 0; j < n4; j += 4) {
+            const int4 k = *reinterpret_cast<const int4 *>(&key[j]);          // broadcast read
+            const int kk[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lo += (kk[q] < leaf);
+                same += (kk[q] == leaf);
+                before += (kk[q] == leaf && j + q < tid);
+            }
+        }
+        if (tid < n) {
+            const int pos = lo + before;
+            sorted_leaf[pos] = leaf;
+            sorted_lo[pos] = lo;
+            sorted_hi[pos] = lo + same - 1;
+            sorted_a[pos] = in_a;
+            sorted_b[pos] = in_b;
+        }
+    }
+    lds_barrier();
+    // ---- from here on thread t IS position t
+    int node = -1;                      // heap index of the node this thread carries; -1: none
+    int lo = 0, hi = 0;
+    bool valid = false;                 // this occurrence may write its leaf
+    if (tid < n) {
+        leaf = sorted_leaf[tid];
+        lo = sorted_lo[tid];
+        hi = sorted_hi[tid];
+        in_a = sorted_a[tid];
+        in_b = sorted_b[tid];
+        valid = leaf != kNoLeaf;
+        if (valid) node = leaf + cap - 1;
+    }
+    // the loads of every sibling the path will need on the next kPathChunk levels depend on the index alone: they
+    // are issued now and the pow and the leaf level run while they are in flight
+    double ps[kPathChunk], pm[kPathChunk], px[kPathChunk];
+    auto prefetch = [&](int lvl0) {
+        int a = node;
+#pragma unroll
+        for (int j = 0; j < kPathChunk; ++j) {
+            ps[j] = pm[j] = px[j] = 0.0;
+            if (a > 0 && lvl0 + j < levels) {
+                const int sib = (a & 1) ? a + 1 : a - 1;
+                ps[j] = sum[sib]; pm[j] = mn[sib]; px[j] = mx[sib];
+                a = (a - 1) >> 1;
+            }
+        }
+    };
+    PER_PROF(1);
+    prefetch(0);
+    PER_PROF(2);
+    double s = 0.0, m = 0.0, x = 0.0;
+    if (tid < n) {
+        if (ring) {
             x = stored_priority;
             int odd = 0;
             s = (mode == 1) ? rlx::libm_pow(x, alpha, &odd) : eps;     // maximal_priority ** alpha (:274)
             if (odd) atomicOr(status, 4);
+        } else if (mode == 0) {
+            if (in_a < 0.0) {                       // "priorities must be non-negative" (:195)
+                atomicOr(status, 2);
+                valid = false;
+            }
+            x = in_a + eps;
+            int odd = 0;
+            s = rlx::libm_pow(x, alpha, &odd);                        // priority ** self.alpha (:197)
+            if (odd) atomicOr(status, 4);
         } else {
-            leaf = idx[tid];
-            if (leaf < 0 || leaf >= cap) {          // reference raises ValueError (:123-126)
-                atomicOr(status, 1);
-                live = false;
-            }
-            if (mode == 0) {
-                const double e = err[tid];
-                if (e < 0.0) {                      // "priorities must be non-negative" (:195)
-                    atomicOr(status, 2);
-                    live = false;
-                }
-                x = e + eps;
-                int odd = 0;
-                s = rlx::libm_pow(x, alpha, &odd);                    // priority ** self.alpha (:197)
-                if (odd) atomicOr(status, 4);
-            } else {
-                s = leaf_pa[tid];
-                x = leaf_p[tid];
-            }
+            s = in_a;
+            x = in_b;
         }
         m = s;
-        if (leaf >= 0 && leaf < cap) {
-            node = leaf + cap - 1;
-            // last occurrence of a duplicated index wins (:214-215); an earlier one adopts the winner's values below
-            if (!ring)
-                for (int j = tid + 1; live && j < n; ++j)
-                    if (idx[j] == leaf) live = false;
-        }
-        if (live) {
-            sum[node] = s;
-            mn[node] = m;
-            mx[node] = x;
-        }
     }
-    auto clear = [&]() {
-        for (int i = tid; i < kPathSlots; i += nthr) tag[i] = -1;
-    };
-    auto insert = [&](int key, double a, double b, double c) {
-        int slot = key & (kPathSlots - 1);
-        while (true) {
-            const int prev = atomicCAS(&tag[slot], -1, key);
-            if (prev == -1) {
-                vs[slot] = a; vm[slot] = b; vx[slot] = c;
-                return;
+    asm volatile("" : "+v"(s), "+v"(x));
+    PER_PROF(3);
+    // ---- leaf level: the winner shows its values, the other occurrences adopt them.  A rejected winner (negative
+    // error) leaves the leaf as it is; its run walks up with the leaf's present values, which recomputes its
+    // ancestors to what they already are — as the kernel above does.
+    {
+        const bool winner = (tid == hi);
+        int w_ok;
+        double ws, wm, wx;
+        if (WAVE) {
+            w_ok = __shfl((int)valid, hi);
+            ws = shfl_f64(s, hi); wm = shfl_f64(m, hi); wx = shfl_f64(x, hi);
+        } else {
+            if (tid < n) {
+                PathRec r;
+                r.node = valid ? 1 : 0; r.lo = lo; r.hi = hi; r.pad = 0;
+                r.s = s; r.m = m; r.x = x; r.pad2 = 0.0;
+                rec[1][tid] = r;
             }
-            if (prev == key) return;
-            slot = (slot + 1) & (kPathSlots - 1);
+            lds_barrier();
+            const PathRec w = rec[1][tid < n ? hi : 0];
+            w_ok = w.node; ws = w.s; wm = w.m; wx = w.x;
         }
-    };
-    auto find = [&](int key) {
-        int slot = key & (kPathSlots - 1);
-        while (tag[slot] != -1) {
-            if (tag[slot] == key) return slot;
-            slot = (slot + 1) & (kPathSlots - 1);
+        if (node >= 0) {
+            if (winner && valid) {
+                sum[node] = s;
+                mn[node] = m;
+                mx[node] = x;
+            } else if (w_ok) {
+                s = ws; m = wm; x = wx;
+            } else {
+                s = sum[node]; m = mn[node]; x = mx[node];
+            }
         }
-        return -1;
-    };
-    // level 0: publish the winning occurrences, the others read their leaf's final values back
-    clear();
-    __syncthreads();
-    if (live) insert(node, s, m, x);
-    __syncthreads();
-    if (node >= 0 && !live) {
-        const int slot = find(node);
-        if (slot >= 0) { s = vs[slot]; m = vm[slot]; x = vx[slot]; }
-        else node = -1;                                   // every occurrence of this leaf was rejected
     }
+    PER_PROF(4);
     for (int lvl0 = 0; lvl0 < levels; lvl0 += kPathChunk) {
-        // siblings of this thread's ancestors on the next five levels: one round trip
-        double ps[kPathChunk], pm[kPathChunk], px[kPathChunk];
-        {
-            int a = node;
+        if (lvl0 > 0) prefetch(lvl0);                     // trees deeper than kPathChunk levels: one more round trip
+        // All prefetched values arrive HERE.  vmcnt counts loads and stores in issue order: a wait placed inside the
+        // levels below would also wait for the stores of the level before it — the round trip per level this kernel
+        // exists to avoid.
 #pragma unroll
-            for (int j = 0; j < kPathChunk; ++j) {
-                ps[j] = pm[j] = px[j] = 0.0;
-                if (a > 0 && lvl0 + j < levels) {
-                    const int sib = (a & 1) ? a + 1 : a - 1;
-                    ps[j] = sum[sib]; pm[j] = mn[sib]; px[j] = mx[sib];
-                    a = (a - 1) >> 1;
+        for (int j = 0; j < kPathChunk; ++j) asm volatile("" : "+v"(ps[j]), "+v"(pm[j]), "+v"(px[j]));
+        PER_PROF(5);
+#pragma unroll
+        for (int j = 0; j < kPathChunk; ++j) {
+            if (lvl0 + j < levels) {                      // uniform
+                const bool left = (node & 1) != 0;        // odd heap index = left child (2p + 1)
+                const int sib = left ? node + 1 : node - 1;
+                const int cand = left ? hi + 1 : lo - 1;  // where the sibling's run must be, if it exists
+                const bool in_range = node > 0 && cand >= 0 && cand < n;
+                const int src = in_range ? cand : tid;
+                int r_node, r_lo, r_hi;
+                double r_s, r_m, r_x;
+                if (WAVE) {
+                    r_node = __shfl(node, src);
+                    const int ext = __shfl(lo | (hi << 8), src);
+                    r_lo = ext & 0xff; r_hi = ext >> 8;
+                    r_s = shfl_f64(s, src); r_m = shfl_f64(m, src); r_x = shfl_f64(x, src);
+                } else {
+                    const int buf = j & 1;                // (the leaf level used buffer 1; kPathChunk is even)
+                    if (tid < n) {
+                        PathRec r;
+                        r.node = node; r.lo = lo; r.hi = hi; r.pad = 0;
+                        r.s = s; r.m = m; r.x = x; r.pad2 = 0.0;
+                        rec[buf][tid] = r;
+                    }
+                    lds_barrier();                        // one barrier per level: the buffers alternate
+                    const PathRec r = rec[buf][src];
+                    r_node = r.node; r_lo = r.lo; r_hi = r.hi; r_s = r.s; r_m = r.m; r_x = r.x;
+                }
+                if (node > 0) {
+                    double bs = ps[j], bm = pm[j], bx = px[j];
+                    if (in_range && r_node == sib) {
+                        bs = r_s; bm = r_m; bx = r_x;
+                        if (left) hi = r_hi; else lo = r_lo;
+                    }
+                    // (left, right) order does not matter to the result: IEEE addition commutes, and python's
+                    // min(a, b) = b if b < a else a / max(a, b) = b if b > a else a pick between two values that are
+                    // bit-identical whenever neither is smaller (priorities are positive; a NaN sets status bit 4).
+                    node = (node - 1) >> 1;
+                    s = s + bs;                           // operator.add (:57)
+                    m = (bm < m) ? bm : m;
+                    x = (bx > x) ? bx : x;
+                    if (tid == lo) {                      // one thread per distinct node writes it to the tree
+                        sum[node] = s;
+                        mn[node] = m;
+                        mx[node] = x;
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < kPathChunk; ++j) {
-            if (lvl0 + j >= levels) break;
-            __syncthreads();                              // the previous level's lookups are done
-            clear();
-            __syncthreads();
-            if (node > 0) insert(node, s, m, x);
-            __syncthreads();
-            if (node > 0) {
-                const int sib = (node & 1) ? node + 1 : node - 1;
-                double bs = ps[j], bm = pm[j], bx = px[j];
-                const int slot = find(sib);
-                if (slot >= 0) { bs = vs[slot]; bm = vm[slot]; bx = vx[slot]; }
-                const bool left = (node & 1) != 0;        // odd heap index = left child (2p + 1)
-                const double sl = left ? s : bs, sr = left ? bs : s;
-                const double ml = left ? m : bm, mr = left ? bm : m;
-                const double xl = left ? x : bx, xr = left ? bx : x;
-                const int parent = (node - 1) >> 1;
-                s = sl + sr;                              // operator.add (:57)
-                m = (mr < ml) ? mr : ml;                  // python min(a,b): b if b<a else a
-                x = (xr > xl) ? xr : xl;                  // python max(a,b): b if b>a else a
-                sum[parent] = s;
-                mn[parent] = m;
-                mx[parent] = x;
-                node = parent;
-            }
-        }
     }
-    // every valid path ends at the root with the root's values in registers: maximal_priority = max_tree root (:201)
-    if (!ring && node == 0) *max_priority = x;
+    PER_PROF(6);
+    // every path ends at the root with the root's values in registers: maximal_priority = max_tree root (:201)
+    if (!ring && node == 0 && tid == lo) *max_priority = x;
 }
 
 // One draw per thread.  u[i] is CPython's random.random() drawn on the host, so that
@@ -359,6 +457,8 @@ int rlx_per_init(double *sum_tree, double *min_tree, double *max_tree, int capac
     return RLX_OK;
 }
 
+static int g_path_max_leaves = kPathMaxLeaves;
+
 static int launch_update(double *sum_tree, double *min_tree, double *max_tree, int capacity,
                          const int *idx, const double *err, const double *leaf_pa,
                          const double *leaf_p, int n, int start_leaf, double alpha, double eps,
@@ -370,10 +470,15 @@ static int launch_update(double *sum_tree, double *min_tree, double *max_tree, i
     if (n == 0) return RLX_OK;
     int threads = ((n + 63) / 64) * 64;
     if (threads > 1024) threads = 1024;
-    if (n <= 1024) {          // one leaf per thread: the path walk with batched round trips
-        per_update_paths_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
-            sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
-            start_leaf, alpha, eps, max_priority, mode, status);
+    if (n <= g_path_max_leaves) {       // one leaf per thread: the path walk that meets only in LDS
+        if (n <= 64)
+            per_update_paths_kernel<true><<<1, 64, 0, rlx::as_stream(stream)>>>(
+                sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
+                start_leaf, alpha, eps, max_priority, mode, status);
+        else
+            per_update_paths_kernel<false><<<1, kPathMaxLeaves, 0, rlx::as_stream(stream)>>>(
+                sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
+                start_leaf, alpha, eps, max_priority, mode, status);
         RLX_LAUNCH_CHECK();
         return RLX_OK;
     }
@@ -381,6 +486,13 @@ static int launch_update(double *sum_tree, double *min_tree, double *max_tree, i
         sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
         start_leaf, alpha, eps, max_priority, mode, status);
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_per_tuning(int path_max_leaves) {
+    RLX_REQUIRE(path_max_leaves >= 0 && path_max_leaves <= kPathMaxLeaves,
+                "rlx_per_tuning: path_max_leaves %d outside [0, %d]", path_max_leaves, kPathMaxLeaves);
+    g_path_max_leaves = path_max_leaves;
     return RLX_OK;
 }
 

@@ -68,6 +68,10 @@ int rlx_per_store_value(double *sum_tree, double *min_tree, double *max_tree, in
 int rlx_per_update(double *sum_tree, double *min_tree, double *max_tree, int capacity,
                    const int *idx, const double *errors, int n, double alpha, double epsilon,
                    double *max_priority, int *status, void *stream); /* .update_priorities :203-217 */
+/* Updates of at most path_max_leaves leaves (default and maximum 256; 0 = never) run on the kernel whose threads meet
+ * only in LDS instead of the level-synchronous one.  Both write bit-identical trees; the knob exists for same-process
+ * A/B timing (tools/ab_per_update.py). */
+int rlx_per_tuning(int path_max_leaves);
 int rlx_per_update_leaves(double *sum_tree, double *min_tree, double *max_tree, int capacity,
                           const int *idx, const double *leaf_pa, const double *leaf_p, int n,
                           double *max_priority, int *status, void *stream); /* same, host-computed p**alpha */

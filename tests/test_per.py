@@ -273,3 +273,36 @@ def test_hip_per_error_reporting(rlx, dev):
     idx = torch.tensor([1, 2], dtype=torch.int32, device=dev)
     rlx.per_update(h.sum, h.min, h.max, h.cap, idx, err, 2, 0.6, 1e-6, h.maxp, h.status, 0)
     assert int(h.status.item()) & 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap,n,dups", [(1 << 20, 64, 0), (1 << 20, 256, 9), (1 << 12, 200, 40), (64, 64, 30),
+                                        (2, 2, 1), (1 << 16, 1, 0), (1 << 16, 7, 6)])
+def test_both_priority_update_kernels_write_the_same_trees(rlx, dev, cap, n, dups):
+    """rlx_per_tuning: the level-synchronous kernel and the one whose threads meet only in LDS are two schedules of
+    the same arithmetic (_propagate, segment_tree.py:63-74) — trees and maximal priority bit-identical, duplicates
+    (the last occurrence wins, :214-215) and neighbouring leaves included."""
+    import torch
+    trees = []
+    for path_max in (0, 256):
+        rlx.per_tuning(path_max)
+        try:
+            h = _HipBackend(rlx, dev, cap, 0.6, 0.4, 1e-6, exact=False)
+            h.store(min(cap, 4096))
+            r = np.random.RandomState(7)
+            for _ in range(6):
+                idx = r.randint(0, cap, n).astype(np.int32)
+                if n > 3:
+                    idx[1] = idx[0] ^ 1                       # siblings
+                    idx[2] = (idx[0] + 2) % cap               # cousins
+                for d in range(dups):
+                    idx[r.randint(0, n)] = idx[r.randint(0, n)]
+                err = r.rand(n) * 5.0
+                rlx.per_update(h.sum, h.min, h.max, h.cap, torch.from_numpy(idx).to(dev),
+                               torch.from_numpy(err).to(dev), n, 0.6, 1e-6, h.maxp, h.status, 0)
+            assert int(h.status.item()) == 0
+            trees.append([t.cpu().numpy().copy() for t in (h.sum, h.min, h.max, h.maxp)])
+        finally:
+            rlx.per_tuning(256)
+    for a, b in zip(*trees):
+        assert np.array_equal(a, b)
