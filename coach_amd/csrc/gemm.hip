@@ -46,6 +46,7 @@ struct OperandDev {
 };
 
 struct GemmDev {
+    int xcd_mode;               // workgroup id -> tile through xcd_tile_position (process-wide, rlx_gemm_tuning)
     OperandDev a, b;
     float *c;
     long long ldc, c_batch_stride;
@@ -757,13 +758,48 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
     if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
 }
 
+// Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, Workgroup dispatch) and every XCD has its own L2:
+// with the plain id -> tile order, neighbouring tiles — which share an operand panel, the overlapping rows of an im2col
+// gather, or the A slice of one split-K chunk — sit on eight different L2s and each fetches the shared bytes again
+// (FC forward: A was fetched 8 x, profiles/r03_pmc_calibration.json).  The remap hands the tile order out in GROUPS:
+// mode G > 0 gives XCD x the groups x, x + 8, x + 16, ... of G consecutive tiles (neighbours share an L2, and the eight
+// XCDs still sweep the same neighbourhood of the operands at the same time, so what one fetched from HBM the next finds
+// in the Infinity Cache); mode -1 gives each XCD one contiguous share of the whole order.  Bijective for any count (the
+// last, incomplete round of groups keeps the plain order).  Placement is a speed matter only — every tile is computed
+// by exactly one workgroup either way.  `local` counts from the first workgroup of the problem: in a pair launch the
+// halves are remapped separately (all ids with equal local % 8 still share an XCD).
+__device__ __forceinline__ int xcd_tile_position(int mode, int local, int count) {
+    if (mode > 0) {                                    // G = mode, a power of two
+        const int round = 8 * mode;
+        if (local >= count / round * round) return local;
+        const int x = local & 7, slot = local >> 3;
+        return ((slot / mode) * 8 + x) * mode + (slot & (mode - 1));
+    }
+    if (mode < 0) {
+        const int x = local & 7, q = count >> 3, r = count & 7;
+        return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (local >> 3);
+    }
+    return local;
+}
+// (bx, by, bz) of a 3-D grid after the remap; bx runs fastest, as in the hardware's own linear order
+__device__ __forceinline__ void xcd_tile_block(int mode, int &bx, int &by, int &bz) {
+    if (mode == 0) return;
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int v = xcd_tile_position(mode, bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+    bx = v % gx;
+    by = (v / gx) % gy;
+    bz = v / (gx * gy);
+}
+
 template <int BM, int BN, int TM, int TN, int KW, bool A_VEC_RED, bool A_U8, bool B_VEC_RED, bool A_TAB>
 __global__ void __launch_bounds__(kThreads, (TM * TN == 1 ? 3 : 1)) gemm_fast_kernel(const GemmDev g) {
     __shared__ __attribute__((aligned(16))) float smem[FastTile<BM, BN, TM, TN>::kSmemFloats];
     __shared__ float lut[A_U8 ? 256 : 1];
     __shared__ int tab_s[A_TAB ? kTabChunk : 1];     // reduction-index offsets of this workgroup's K chunk
-    gemm_fast_body<BM, BN, TM, TN, KW, A_VEC_RED, A_U8, B_VEC_RED, A_TAB>(g, blockIdx.x, blockIdx.y, blockIdx.z,
-                                                                           gridDim.x, gridDim.y, smem, lut, tab_s);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    xcd_tile_block(g.xcd_mode, bx, by, bz);
+    gemm_fast_body<BM, BN, TM, TN, KW, A_VEC_RED, A_U8, B_VEC_RED, A_TAB>(g, bx, by, bz, gridDim.x, gridDim.y, smem, lut,
+                                                                           tab_s);
 }
 
 // The input gradient of a convolution as ONE product (rlx_conv_input_grad): a windowed gather of dY against the
@@ -773,8 +809,9 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_win_kernel(const GemmDev g) 
     __shared__ __attribute__((aligned(16))) float smem[FastTile<BM, BN, 1, 1>::kSmemFloats];
     __shared__ float lut[1];
     __shared__ int tab_s[3 * kWinChunk];
-    gemm_fast_body<BM, BN, 1, 1, KW, true, false, true, true, true>(g, blockIdx.x, blockIdx.y, blockIdx.z,
-                                                                      gridDim.x, gridDim.y, smem, lut, tab_s);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    xcd_tile_block(g.xcd_mode, bx, by, bz);
+    gemm_fast_body<BM, BN, 1, 1, KW, true, false, true, true, true>(g, bx, by, bz, gridDim.x, gridDim.y, smem, lut, tab_s);
 }
 
 // Two INDEPENDENT problems in one launch — a layer's weight gradient (dW = X^T dY) and its input gradient
@@ -796,7 +833,9 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
     __shared__ int tab_s[A_TAB0 ? kTabChunk : 1];
     int flat = blockIdx.x;
     const int which = flat >= p.n0;
+    // each half keeps its own share of every XCD (the halves differ in cost per tile: the chip stays balanced)
     if (which) flat -= p.n0;
+    flat = xcd_tile_position(p.g[0].xcd_mode, flat, which ? (int)gridDim.x - p.n0 : p.n0);
     const int gx = p.gx[which], gy = p.gy[which];
     const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
     if (!which)      // weight gradient: A = X^T (vector along the outer index; im2col tables for a convolution)
@@ -1437,7 +1476,7 @@ constexpr int kThin16MaxTiles = 128;       // 16 x 16 tiles inside a dW + dX pai
 constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a launch of its own
 // in-workgroup K split: taken when the 64 x 64 tiling has fewer than g_kw_below_tiles tiles and the smaller tiling at
 // least g_kw_min_tiles (rlx_gemm_tuning: an explicit knob for same-process A/Bs, tools/ab_c2.py)
-int g_kw_below_tiles = 192, g_kw_min_tiles = 192;
+int g_kw_below_tiles = 192, g_kw_min_tiles = 192, g_xcd_mode = -1;
 
 // diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
 struct StampCall { int M, N, K, batch, splits, gx, gy, gz; long long offset; };
@@ -1474,10 +1513,13 @@ int rlx_gemm_debug_calls(long long *out_host, int max_calls, int *n_calls_host) 
     return RLX_OK;
 }
 
-int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles) {
+int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode) {
     RLX_REQUIRE(kw_below_tiles >= 0 && kw_min_tiles >= 1, "rlx_gemm_tuning: bad thresholds");
+    RLX_REQUIRE(xcd_mode == -1 || (xcd_mode >= 0 && xcd_mode <= 1024 && (xcd_mode & (xcd_mode - 1)) == 0),
+                "rlx_gemm_tuning: xcd_mode %d is neither -1, 0 nor a power of two", xcd_mode);
     g_kw_below_tiles = kw_below_tiles;
     g_kw_min_tiles = kw_min_tiles;
+    g_xcd_mode = xcd_mode;
     return RLX_OK;
 }
 
@@ -1550,6 +1592,7 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
                 "rlx_gemm: unknown activation");
 
     GemmDev g;
+    g.xcd_mode = g_xcd_mode;
     g.M = d.M; g.N = d.N; g.K = d.K;
     g.a.base = d.A; g.a.tab_o = d.a_row_tab; g.a.tab_r = d.a_k_tab;
     g.a.stride_o = d.a_row_stride; g.a.stride_r = d.a_k_stride; g.a.batch_stride = d.a_batch_stride;
@@ -1949,6 +1992,7 @@ int rlx_conv_input_grad(const float *dy, const float *weights, float *dx, const 
                 "rlx_conv_input_grad: operands must be 16-byte aligned");
     const int P = stride * stride, M = P * Mp;
     GemmDev g = {};
+    g.xcd_mode = g_xcd_mode;
     g.M = M; g.N = C; g.K = K;
     g.a.base = dy; g.a.tab_o = tables; g.a.tab_r = tables + 3 * M; g.a.batch_stride = dy_tower_stride; g.a.vec_ok = 1;
     g.b.base = weights; g.b.stride_o = Co; g.b.stride_r = 1; g.b.batch_stride = w_tower_stride; g.b.vec_ok = 1;

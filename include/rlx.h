@@ -317,10 +317,13 @@ typedef struct rlx_gemm_desc {
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
 int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host);
-/* Path-selection thresholds of rlx_gemm (process-wide; defaults 192 / 192): a problem whose 64 x 64 tiling has fewer than
+/* Path selection of rlx_gemm (process-wide; defaults 192 / 192 / -1): a problem whose 64 x 64 tiling has fewer than
  * kw_below_tiles tiles runs on 32 x 64 / 32 x 32 tiles with the K slab split over the waves of a workgroup, if that
- * tiling has at least kw_min_tiles tiles.  An explicit knob for same-process A/B measurements (tools/ab_c2.py). */
-int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles);
+ * tiling has at least kw_min_tiles tiles.  xcd_mode: how the tiled kernels hand the tile order to the 8 XCDs (one L2
+ * each): 0 = every 8th tile (the hardware's order), G = 2^k > 0: groups of G consecutive tiles round-robin, -1 = one
+ * contiguous share per XCD — so that tiles sharing operand rows share an L2.
+ * An explicit knob for same-process A/B measurements (tools/ab_c2.py); results are identical either way. */
+int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode);
 
 /* Input gradient of a VALID-padding NHWC convolution (tf.gradients of tf.layers.conv2d,
  * architectures/tensorflow_components/layers.py:108-121, architecture.py:187-220) as ONE product that gathers dY

@@ -408,3 +408,35 @@ def test_conv_layer_backward_direct_equals_column_matrix_path(rlx, dev):
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-6 * np.abs(out[False][0]).max())
     np.testing.assert_allclose(out[True][1], out[False][1], rtol=2e-5, atol=2e-5)
     assert np.abs(out[True][1]).sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(3136, 128, 576), (5184, 64, 512), (64, 512, 3136), (3001, 68, 132), (25600, 32, 256)])
+def test_tile_order_does_not_change_a_bit(rlx, dev, M, N, K):
+    """rlx_gemm_tuning's xcd_mode decides which workgroup computes which tile, nothing else: every mode must give the
+    plain order's output bit for bit (a remap that is not a bijection would leave tiles unwritten or written twice) —
+    products, the two-problem pair launch and the windowed convolution input gradient, tile counts that are not
+    multiples of 8 x the group size included."""
+    import torch
+    from coach_amd._rlx import gemm, gemm_pair
+    rng = np.random.RandomState(M + K)
+    A = dev_tensor(rng.randn(M, K).astype(np.float32), dev)
+    B = dev_tensor((rng.randn(K, N) / np.sqrt(K)).astype(np.float32), dev)
+    dY = dev_tensor(rng.randn(M, N).astype(np.float32), dev)
+    ws, ws2 = (torch.empty(1 << 23, dtype=torch.float32, device=dev) for _ in range(2))
+    outs = {}
+    try:
+        for mode in (0, 2, 8, 32, -1):
+            rlx.gemm_tuning(192, 192, mode)
+            C = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+            gemm(M, N, K, A, B, C, workspace=ws)
+            dW = torch.full((K, N), 7.0, dtype=torch.float32, device=dev)
+            dX = torch.full((M, K), 7.0, dtype=torch.float32, device=dev)
+            gemm_pair(gemm(K, N, M, A, dY, dW, a_strides=(1, K), workspace=ws, launch=False),
+                      gemm(M, K, N, dY, B, dX, b_strides=(1, N), workspace=ws2, launch=False))
+            outs[mode] = [t.cpu().numpy() for t in (C, dW, dX)]
+    finally:
+        rlx.gemm_tuning(192, 192, -1)
+    for mode, got in outs.items():
+        for a, b in zip(outs[0], got):
+            assert np.array_equal(a, b), mode

@@ -1,5 +1,5 @@
 """Same-box A/B of the C2 minibatch update (bench.py's agent): us per update with the round-3 changes switched off one
-at a time — direct convolution input gradients, deferred split-K reductions.  Variants are measured alternately in ONE
+at a time — XCD-chunked tile order, direct convolution input gradients, tile-size thresholds.  Variants are measured alternately in ONE
 process so that box-to-box differences (25 % between boxes of the pool) cancel.  python tools/ab_c2.py [rounds]"""
 import json
 import os
@@ -17,7 +17,7 @@ class _Dist(object):
         pass
 
 
-def build(direct, defer, tuning=(192, 192)):
+def build(direct, defer, tuning=(192, 192, -1)):
     import bench
     from coach_amd.nn import graph as G
     G.DIRECT_CONV_INPUT_GRAD = direct
@@ -49,10 +49,12 @@ def train_ms(agent):
 
 
 def main(rounds=4):
-    variants = {"default (column-matrix dX, deferred reductions, K-in-workgroup below 192 tiles)": (False, True),
-                "K-in-workgroup tiles below 512 tiles (conv1 forward on 32 x 64)": (False, True, (512, 192)),
-                "K-in-workgroup tiles accepted from 64 tiles (FC forward on 32 x 32, no split-K)": (False, True, (192, 64)),
-                "both": (False, True, (512, 64))}
+    variants = {"tile order: groups of 8 tiles per XCD": (False, True, (192, 192, 8)),
+                "tile order: plain (every 8th tile per XCD)": (False, True, (192, 192, 0)),
+                "tile order: groups of 2": (False, True, (192, 192, 2)),
+                "tile order: groups of 32": (False, True, (192, 192, 32)),
+                "tile order: one contiguous share per XCD (default)": (False, True, (192, 192, -1)),
+                "direct convolution input gradients, contiguous shares": (True, True, (192, 192, -1))}
     agents = {k: build(*v) for k, v in variants.items()}
     for a in agents.values():
         for _ in range(3):
@@ -63,7 +65,7 @@ def main(rounds=4):
         for k, a in agents.items():
             res[k].append(train_ms(a))
     out = {k: {"us_per_update": round(1e3 * min(v) / 320, 1), "all": [round(1e3 * x / 320, 1) for x in v]} for k, v in res.items()}
-    _rlx.lib().gemm_tuning(192, 192)
+    _rlx.lib().gemm_tuning(192, 192, -1)
     print(json.dumps(out))
 
 

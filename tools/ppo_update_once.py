@@ -2,6 +2,7 @@
 target for `rocprofv3 --pmc` passes (FETCH_SIZE / WRITE_SIZE per GEMM launch); the full bench replays
 hipGraphs with tens of thousands of dispatches, far too many for serialized counter collection.
 Usage: rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -- python tools/ppo_update_once.py
+       [--xcd-mode M]   (rlx_gemm_tuning's third argument; default: the library's default)
 """
 import os
 import sys
@@ -12,6 +13,9 @@ import torch
 
 from coach_amd.nn.networks import ClippedPPONet
 
+if "--xcd-mode" in sys.argv:
+    from coach_amd import _rlx
+    _rlx.lib().gemm_tuning(192, 192, int(sys.argv[sys.argv.index("--xcd-mode") + 1]))
 dev = torch.device("cuda:0")
 B, A, shape = 64, 6, (84, 84, 4)
 np.random.seed(0)
