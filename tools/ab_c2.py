@@ -49,12 +49,10 @@ def train_ms(agent):
 
 
 def main(rounds=4):
-    variants = {"tile order: groups of 8 tiles per XCD": (False, True, (192, 192, 8)),
-                "tile order: plain (every 8th tile per XCD)": (False, True, (192, 192, 0)),
-                "tile order: groups of 2": (False, True, (192, 192, 2)),
-                "tile order: groups of 32": (False, True, (192, 192, 32)),
-                "tile order: one contiguous share per XCD (default)": (False, True, (192, 192, -1)),
-                "direct convolution input gradients, contiguous shares": (True, True, (192, 192, -1))}
+    variants = {"default (contiguous XCD shares, K-in-workgroup tiles: 32 x 64 from 192 tiles)": (False, True, (192, 192, -1)),
+                "32 x 32 tiles preferred (32 x 64 only from 380 tiles)": (False, True, (192, 380, -1)),
+                "K-in-workgroup tiles also below 400 tiles of 64 x 64 (conv1 forward on 32 x 64)": (False, True, (401, 192, -1)),
+                "both": (False, True, (401, 380, -1))}
     agents = {k: build(*v) for k, v in variants.items()}
     for a in agents.values():
         for _ in range(3):

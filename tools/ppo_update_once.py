@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
+if "--lib" in sys.argv:                      # another build of the library (tools/ab_lib.sh)
+    import coach_amd._rlx as _rlx_mod
+    _rlx_mod.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from coach_amd.nn.networks import ClippedPPONet
 
 if "--xcd-mode" in sys.argv:
