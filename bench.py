@@ -490,6 +490,8 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the collective path (RCCL) even with one rank: its structural cost at world size 1")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -521,7 +523,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = GradientSync()
+    dist = GradientSync(force=args.force_dist)
     if dist.world_size != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, dist.world_size))
     if args.workload != "c2":

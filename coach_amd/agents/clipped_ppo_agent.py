@@ -15,7 +15,7 @@ numpy + TF sessions.  What changes, and why it is still the same algorithm:
     the same generators in the same order as the reference and shipped to the device.
   * the per-step and per-minibatch launch sequences are launch-bound (tens of ~10 us kernels), so
     each is captured once into a hipGraph (torch.cuda.CUDAGraph on the current stream) and
-    replayed; RLX_NO_GRAPHS=1 runs the same calls eagerly.
+    replayed; use_graphs=False runs the same calls eagerly.
 """
 import os
 import random
@@ -105,9 +105,8 @@ class ClippedPPOAgent(object):
         self.device = device or environment.device
         self.dist = dist if (dist is not None and dist.enabled) else None
         self.lib = _rlx.lib()
-        if use_graphs is None:
-            use_graphs = os.environ.get("RLX_NO_GRAPHS", "0") != "1"
-        self.use_graphs = use_graphs
+        self.use_graphs = True if use_graphs is None else bool(use_graphs)
+        self.overlap_allreduce = False       # data parallel: reduce the FC + head gradients underneath the conv backward
         alg, net = self.ap.algorithm, self.ap.network_wrappers["main"]
         ep = environment.p
         self.continuous = ep.action_dim is not None      # BoxActionSpace -> continuous PPO head
@@ -587,7 +586,7 @@ class ClippedPPOAgent(object):
                 if self.dist is None:
                     self._run(("mb", m, clip, scale, i), lambda: (self._minibatch_fb(m, clip, i=i),
                                                                   self._minibatch_finish(scale)))
-                elif os.environ.get("RLX_SYNC_ALLREDUCE", "1") == "1":
+                elif not self.overlap_allreduce:
                     # default: one blocking all-reduce per minibatch between two graph segments; the Adam
                     # step of minibatch i-1 rides in the same graph as forward/backward of minibatch i
                     if i == 0:
@@ -599,7 +598,7 @@ class ClippedPPOAgent(object):
                     if i == nmb - 1:
                         self._run(("mb_fin", scale), lambda: self._minibatch_finish(scale))
                 else:
-                    # RLX_SYNC_ALLREDUCE=0 — overlap: the FC + head gradients (95 % of the 13.5 MB) are final
+                    # overlap_allreduce = True — overlap: the FC + head gradients (95 % of the 13.5 MB) are final
                     # before the conv backward starts; their all-reduce runs on RCCL's stream underneath
                     # it.  Costs a third graph segment and a second collective per minibatch (+50 us
                     # measured at world size 1), which eats what it hides at 13.5 MB — opt-in.

@@ -55,7 +55,7 @@ class _SegmentedCapture(object):
 
 class GraphRunner(object):
     """Run a pure-device call sequence eagerly once (allocations), capture it into a hipGraph the
-    second time, replay afterwards.  RLX_NO_GRAPHS=1 keeps everything eager.  With data parallelism
+    second time, replay afterwards.  use_graphs=False (constructor argument, or BasicRLGraphManager.use_graphs) keeps everything eager.  With data parallelism
     (`self.dist`) the sequence is cut at every `_allreduce` call into graph segments."""
 
     _segcap = None
@@ -95,9 +95,7 @@ class GraphRunner(object):
                 self.dist.all_reduce_sum(obj)
 
     def _init_graphs(self, use_graphs=None):
-        if use_graphs is None:
-            use_graphs = os.environ.get("RLX_NO_GRAPHS", "0") != "1"
-        self.use_graphs = use_graphs
+        self.use_graphs = True if use_graphs is None else bool(use_graphs)
         self._graphs, self._warm = {}, set()
 
     def _run(self, key, fn):

@@ -18,16 +18,17 @@ import torch.distributed as dist
 
 
 class GradientSync(object):
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force=False):
+        """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* come from the launcher (torch.distributed.run).
+        backend: "nccl" (= RCCL, the default on a GPU) or "gloo"; force: take the collective path even at world size 1
+        (exercises RCCL on a 1-GPU box: bench.py --force-dist)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        # RLX_FORCE_DIST=1: take the collective path even at world size 1 (exercises RCCL on a 1-GPU box)
-        self.enabled = self.world_size > 1 or os.environ.get("RLX_FORCE_DIST", "0") == "1"
+        self.enabled = self.world_size > 1 or bool(force)
         if self.enabled and not dist.is_initialized():
             if backend is None:
-                backend = os.environ.get("RLX_DIST_BACKEND") or \
-                    ("nccl" if torch.cuda.is_available() else "gloo")
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)

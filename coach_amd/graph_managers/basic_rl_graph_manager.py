@@ -75,6 +75,7 @@ class BasicRLGraphManager(object):
         self.name = name
         self.device = device or torch.device("cuda", 0)
         self.dist = dist
+        self.use_graphs = True           # False: the agent issues every launch eagerly (same calls, same results)
         self.environment = self.agent = None
         self.logger = CsvLogger(csv_path)
         self.total_steps_counters = {RunPhase.HEATUP: 0, RunPhase.TRAIN: 0, RunPhase.TEST: 0}
@@ -90,7 +91,7 @@ class BasicRLGraphManager(object):
         resolve_reference_style(self.agent_params, self.env_params)
         self.environment = dynamic_import(self.env_params.path)(self.env_params, self.device, rank=rank)
         self.agent = dynamic_import(self.agent_params.path)(self.agent_params, self.environment, self.device,
-                                                            dist=self.dist)
+                                                            dist=self.dist, use_graphs=self.use_graphs)
         if self.visualization_parameters.dump_csv and hasattr(self.agent, "enable_signal_statistics"):
             self.agent.enable_signal_statistics()
             self.logger.set_signals(self.agent.SIGNAL_NAMES)

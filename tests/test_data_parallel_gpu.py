@@ -24,8 +24,7 @@ def _free_port():
 def _worker(rank, world, port, out_dir, sync_mode, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), RLX_DIST_BACKEND=backend, RLX_SYNC_ALLREDUCE=sync_mode,
-                      RLX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
     from coach_amd.core_types import EnvironmentSteps
@@ -33,7 +32,7 @@ def _worker(rank, world, port, out_dir, sync_mode, backend="gloo"):
     from coach_amd.environments.synthetic_vector_environment import (
         SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
     dev = torch.device("cuda:0")
-    dist = GradientSync()
+    dist = GradientSync(backend=backend, force=True)
     assert dist.enabled and dist.world_size == world
     ep = SyntheticVectorEnvironmentParameters("image", 8, (44, 44), 4, episode_length=8, seed=21)
     env = SyntheticVectorEnvironment(ep, dev, rank=dist.rank)
@@ -43,6 +42,7 @@ def _worker(rank, world, port, out_dir, sync_mode, backend="gloo"):
     ap.algorithm.optimization_epochs = 2
     ap.network_wrappers["main"].batch_size = 16
     agent = ClippedPPOAgent(ap, env, dev, dist=dist)
+    agent.overlap_allreduce = sync_mode == "0"          # "1": one blocking all-reduce per minibatch
     for _ in range(2):
         res = None
         while res is None:
@@ -72,7 +72,7 @@ def test_two_rank_ppo_iteration(tmp_path):
 def _norm_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), RLX_DIST_BACKEND="gloo")
+                      MASTER_PORT=str(port))
     import torch
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
     from coach_amd.core_types import EnvironmentSteps
@@ -80,7 +80,7 @@ def _norm_worker(rank, world, port, out_dir):
     from coach_amd.environments.synthetic_vector_environment import (
         SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
     dev = torch.device("cuda:0")
-    dist = GradientSync()
+    dist = GradientSync(backend="gloo")
     ep = SyntheticVectorEnvironmentParameters("vector", 8, (11,), None, action_dim=3, episode_length=8, seed=3)
     env = SyntheticVectorEnvironment(ep, dev, rank=dist.rank)
     ap = ClippedPPOAgentParameters()
@@ -137,7 +137,7 @@ def test_two_rank_shared_observation_statistics(tmp_path):
 def _off_policy_worker(rank, world, port, out_dir, name, graphs):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), RLX_DIST_BACKEND="gloo")
+                      MASTER_PORT=str(port))
     import random
     import torch
     from coach_amd.core_types import EnvironmentSteps
@@ -146,7 +146,7 @@ def _off_policy_worker(rank, world, port, out_dir, name, graphs):
         SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters as EP)
     from coach_amd.memories.memory import MemoryGranularity
     dev = torch.device("cuda:0")
-    dist = GradientSync()
+    dist = GradientSync(backend="gloo")
     if name == "dqn":
         from coach_amd.agents.dqn_agent import DQNAgent, DQNAgentParameters
         ap = DQNAgentParameters()
@@ -254,12 +254,12 @@ def _shard(kind, rank, shape, A, B):
 def _oracle_worker(rank, world, port, out_dir, kind, scale_down):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), RLX_DIST_BACKEND="gloo")
+                      MASTER_PORT=str(port))
     import torch
     from coach_amd.distributed import GradientSync
     from coach_amd.nn.networks import ClippedPPONet, DQNNet
     dev = torch.device("cuda:0")
-    dist = GradientSync()
+    dist = GradientSync(backend="gloo")
     shape, A, B = (44, 44, 4), 4, 16
     d = {k: torch.from_numpy(v).to(dev) for k, v in _shard(kind, rank, shape, A, B).items()}
     scale = dist.grad_scale(scale_down)

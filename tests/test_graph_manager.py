@@ -59,17 +59,13 @@ def test_atari_dueling_ddqn_preset_improve(dev, tmp_path):
     from coach_amd.presets import Atari_Dueling_DDQN as preset
     weights = []
     for graphs in ("0", "1"):
-        import os
-        os.environ["RLX_NO_GRAPHS"] = "1" if graphs == "0" else "0"
-        try:
-            random.seed(2); np.random.seed(2)
-            gm = preset.make(num_envs=8, replay_transitions=2048, heatup_steps=256, improve_steps=256,
-                             episode_length=16)
-            gm.device = dev
-            gm.logger.__init__(str(tmp_path / ("exp%s.csv" % graphs)))
-            gm.improve()
-        finally:
-            os.environ.pop("RLX_NO_GRAPHS", None)
+        random.seed(2); np.random.seed(2)
+        gm = preset.make(num_envs=8, replay_transitions=2048, heatup_steps=256, improve_steps=256,
+                         episode_length=16)
+        gm.device = dev
+        gm.use_graphs = graphs == "1"
+        gm.logger.__init__(str(tmp_path / ("exp%s.csv" % graphs)))
+        gm.improve()
         net = gm.agent.networks["main"]
         assert net.dueling and net.clip_gradients == 10 and abs(net.head_gradient_rescale - 2 ** -0.5) < 1e-12
         assert gm.total_steps_counters[RunPhase.TRAIN] == 256
