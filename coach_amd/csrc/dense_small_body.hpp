@@ -86,16 +86,20 @@ struct MultiBwd { SmallDenseBwd p[kMaxProblems]; int towers[kMaxProblems]; int n
 // single-problem launch (rlx_dense_small_backward) takes 16 x 16: twice the workgroups and, up to M = 128 rows, every x
 // load of a thread in ONE chunk (one exposed round trip instead of two at M = 100) — a different grouping of the dW row
 // sums (profiles/r03_ab_candidates.txt).
-template <int NN, int KL = kKL, int RG = kRG>
+// PRESTAGED: the caller has already written dz (the gradient w.r.t. the pre-activation output) into smem[0 .. M*N) —
+// the Clipped-PPO heads launch computes it there from the head losses (ppo_heads_bwd.hip); p.dy / p.y are not read.
+template <int NN, int KL = kKL, int RG = kRG, bool PRESTAGED = false>
 __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int kblock, int t, float *smem) {
     float *dz = smem;                              // [M][N]
     float *part = smem + (size_t)p.M * p.N;        // [RG][KL][NN] dW partials
     const int lane = threadIdx.x % KL, g = threadIdx.x / KL;
     const int k = kblock * KL + lane;
-    const float *dy = p.dy + (size_t)t * p.dy_ts;
-    const float *yy = p.y ? p.y + (size_t)t * p.y_ts : nullptr;
-    for (int i = threadIdx.x; i < p.M * p.N; i += 256)
-        dz[i] = dy[i] * (yy ? act_deriv_out(yy[i], p.act) : 1.f);
+    if (!PRESTAGED) {
+        const float *dy = p.dy + (size_t)t * p.dy_ts;
+        const float *yy = p.y ? p.y + (size_t)t * p.y_ts : nullptr;
+        for (int i = threadIdx.x; i < p.M * p.N; i += 256)
+            dz[i] = dy[i] * (yy ? act_deriv_out(yy[i], p.act) : 1.f);
+    }
     const bool live = k < p.K;
     const float *__restrict__ x = p.x + (size_t)t * p.x_ts;
     float wk[NN], acc[NN];

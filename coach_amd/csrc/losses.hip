@@ -36,16 +36,9 @@ regression_loss_body(const float *__restrict__ out, const float *__restrict__ ta
         for (int j = 0; j < dim; ++j) {
             const float e = out[(size_t)b * ld_out + j] - target[(size_t)b * ld_target + j];
             float l, g;
-            if (kind == 0) {
-                l = e * e;
-                g = 2.f * e;
-            } else {
-                const float a = fabsf(e);
-                l = a <= 1.f ? 0.5f * e * e : a - 0.5f;
-                g = fminf(fmaxf(e, -1.f), 1.f);
-            }
+            regression_terms(e, kind, l, g);
             row += l;
-            if (grad) grad[(size_t)b * ld_grad + j] = grad_scale * w * g / (float)batch;
+            if (grad) grad[(size_t)b * ld_grad + j] = regression_grad(grad_scale, w, g, batch);
         }
         local += w * row;
     }
@@ -92,13 +85,7 @@ ppo_discrete_loss_body(const float *__restrict__ logits, long long ld, const int
     const float sur = block_sum(l_sur, red);
     const float ent = block_sum(l_ent, red);
     const float kl = block_sum(l_kl, red);
-    if (threadIdx.x == 0 && scalars) {
-        const float inv = 1.f / (float)batch;
-        scalars[0] = -sur * inv;                                      // surrogate_loss (:91)
-        scalars[1] = ent * inv;                                       // entropy (:62)
-        scalars[2] = kl * inv;                                        // kl_divergence (:66)
-        scalars[3] = -sur * inv - beta * ent * inv;                   // + entropy_regularization (:95-96)
-    }
+    if (threadIdx.x == 0 && scalars) ppo_discrete_scalars(sur, ent, kl, beta, batch, scalars);
 }
 
 __global__ void __launch_bounds__(kMaxBlock)

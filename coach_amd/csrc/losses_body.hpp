@@ -20,6 +20,34 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return r;
 }
 
+// scalars[0..3] of the discrete Clipped-PPO head from the batch sums (ppo_head.py:62-96)
+__device__ __forceinline__ void ppo_discrete_scalars(float sur, float ent, float kl, float beta, int batch,
+                                                     float *__restrict__ scalars) {
+#pragma clang fp contract(off)
+    const float inv = 1.f / (float)batch;
+    scalars[0] = -sur * inv;                                      // surrogate_loss (:91)
+    scalars[1] = ent * inv;                                       // entropy (:62)
+    scalars[2] = kl * inv;                                        // kl_divergence (:66)
+    scalars[3] = -sur * inv - beta * ent * inv;                   // + entropy_regularization (:95-96)
+}
+
+// One row of a regression head (MSE / Huber, head.py:143-186): loss term and gradient factor of one output
+__device__ __forceinline__ void regression_terms(float e, int kind, float &l, float &g) {
+#pragma clang fp contract(off)
+    if (kind == 0) {
+        l = e * e;
+        g = 2.f * e;
+    } else {
+        const float a = fabsf(e);
+        l = a <= 1.f ? 0.5f * e * e : a - 0.5f;
+        g = fminf(fmaxf(e, -1.f), 1.f);
+    }
+}
+__device__ __forceinline__ float regression_grad(float grad_scale, float w, float g, int batch) {
+#pragma clang fp contract(off)
+    return grad_scale * w * g / (float)batch;
+}
+
 // One sample of the discrete Clipped-PPO head (ppo_head.py:52-116): its surrogate / entropy / KL terms and the
 // gradient of the head loss w.r.t. its logits.  Returns false for an out-of-range action.
 struct PpoRowTerms { float sur, ent, kl; };
@@ -27,6 +55,9 @@ __device__ __forceinline__ bool
 ppo_discrete_row(const float *__restrict__ z, const float *__restrict__ po, int a, int n, float adv, float clip_eps,
                  float beta, float grad_scale, int batch, float *__restrict__ dlogits_row,
                  float *__restrict__ ratio_dst, float *__restrict__ clipped_dst, PpoRowTerms &out) {
+    // compiled into two kernels that must agree bit for bit (losses.hip, ppo_heads_bwd.hip): with contraction left to
+    // the optimiser the two contexts fused different products of this function
+#pragma clang fp contract(off)
     float mx = z[0];
     for (int j = 1; j < n; ++j) mx = fmaxf(mx, z[j]);
     float se = 0.f, so = 0.f;

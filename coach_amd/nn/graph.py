@@ -641,29 +641,48 @@ def small_dense_forward_multi(ctx, items, tag="", weights=None):
     return outs
 
 
+def _small_backward_problem(q, l, x, y):
+    """rlx_small_dense_problem of one narrow layer's backward pass (y.grad = gradient w.r.t. its output)."""
+    M, p = x.rows, l.params
+    assert l.N <= SMALL_N and M * l.N <= 1024 and x.towers == l.T
+    own = l.act if (l.act is not None and not y.grad_is_dz) else None
+    lower = x.act
+    dx = x.ensure_grad()
+    q.x, q.x_tower_stride = x.data.data_ptr(), x.tower_stride()
+    q.w, q.w_tower_stride = p.w(l.kname).data_ptr(), p.stride(l.kname)
+    q.dy, q.dy_tower_stride = y.grad.data_ptr(), M * l.N
+    q.y, q.y_tower_stride = (y.data.data_ptr() if own else None), M * l.N
+    q.dw, q.dw_tower_stride = p.g(l.kname).data_ptr(), p.stride(l.kname)
+    q.db, q.db_tower_stride = p.g(l.bname).data_ptr(), p.stride(l.bname)
+    q.dx, q.dx_tower_stride = dx.data_ptr(), M * l.K
+    q.towers, q.M, q.K, q.N = l.T, M, l.K, l.N
+    q.activation, q.lower_activation = _rlx.ACT[own], _rlx.ACT[lower]
+    x.grad_is_dz = lower is not None
+
+
 def small_dense_backward_multi(ctx, items):
     """[(Dense layer, input Tensor x, output Tensor y with y.grad set)]: dW, db and dx (with the lower
     layer's activation derivative) of every layer in ONE launch."""
     import ctypes
     arr = (_rlx.SmallDenseProblem * len(items))()
     for i, (l, x, y) in enumerate(items):
-        M, p = x.rows, l.params
-        assert l.N <= SMALL_N and M * l.N <= 1024 and x.towers == l.T
-        own = l.act if (l.act is not None and not y.grad_is_dz) else None
-        lower = x.act
-        dx = x.ensure_grad()
-        q = arr[i]
-        q.x, q.x_tower_stride = x.data.data_ptr(), x.tower_stride()
-        q.w, q.w_tower_stride = p.w(l.kname).data_ptr(), p.stride(l.kname)
-        q.dy, q.dy_tower_stride = y.grad.data_ptr(), M * l.N
-        q.y, q.y_tower_stride = (y.data.data_ptr() if own else None), M * l.N
-        q.dw, q.dw_tower_stride = p.g(l.kname).data_ptr(), p.stride(l.kname)
-        q.db, q.db_tower_stride = p.g(l.bname).data_ptr(), p.stride(l.bname)
-        q.dx, q.dx_tower_stride = dx.data_ptr(), M * l.K
-        q.towers, q.M, q.K, q.N = l.T, M, l.K, l.N
-        q.activation, q.lower_activation = _rlx.ACT[own], _rlx.ACT[lower]
-        x.grad_is_dz = lower is not None
+        _small_backward_problem(arr[i], l, x, y)
     ctx.lib.dense_small_backward_multi(ctypes.byref(arr), len(items), ctx.stream)
+
+
+def ppo_heads_loss_backward(ctx, value, policy, value_targets, actions, advantages, old_probs, ld_old, clip_epsilon,
+                            clip_scale, beta, scalars, ratio_out, clipped_out, status):
+    """value / policy = (Dense head, input Tensor x, output Tensor y): both head losses of discrete Clipped PPO and the
+    heads' backward pass in ONE launch (rlx_ppo_heads_loss_backward); y.grad receives dV / dlogits."""
+    import ctypes
+    arr = (_rlx.SmallDenseProblem * 2)()
+    for q, (l, x, y) in zip(arr, (value, policy)):
+        y.ensure_grad()
+        _small_backward_problem(q, l, x, y)
+    B = value[1].rows
+    ctx.lib.ppo_heads_loss_backward(ctypes.byref(arr[0]), ctypes.byref(arr[1]), value[2].data, value_targets,
+                                    policy[2].data, actions, advantages, old_probs, ld_old, B, clip_epsilon, clip_scale,
+                                    beta, 1.0, scalars, ratio_out, clipped_out, status, ctx.stream)
 
 
 class Sequential:

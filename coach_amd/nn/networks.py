@@ -119,6 +119,7 @@ class ClippedPPONet(_NetBase):
     """ClippedPPONetworkParameters (agents/clipped_ppo_agent.py:41-58): two full copies of
     embedder + middleware (use_separate_networks_per_head), head 0 = VHead, head 1 = PPOHead
     (discrete).  tower 0 = value, tower 1 = policy."""
+    HEADS_LOSS_BACKWARD_ONE_LAUNCH = True     # discrete heads: losses + heads' backward as one launch (tests flip it)
 
     def __init__(self, device, obs_shape, n_actions, activation="tanh", embedder="Medium",
                  middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
@@ -226,9 +227,16 @@ class ClippedPPONet(_NetBase):
         else:
             v = self.v_head.forward(ctx, xv, tag="train")
             logits = self.pi_head.forward(ctx, xp, tag="train")
+        one_launch = fused_heads and not self.continuous and B <= 256 and self.HEADS_LOSS_BACKWARD_ONE_LAUNCH
+        if one_launch:         # both head losses + the heads' backward pass: rlx_ppo_heads_loss_backward
+            G.ppo_heads_loss_backward(ctx, (self.v_head, xv, v), (self.pi_head, xp, logits), value_targets, actions,
+                                      advantages, old_probs, self.A, self.clip_eps * clip_rescaler, clip_dev, self.beta,
+                                      self.scalars, ratio_out, clipped_out, self.status)
         dv, dlogits = v.ensure_grad(), logits.ensure_grad()
         # head 0: VHead, MSE(target, V), loss weight 1 (head.py:172-181)
-        if not self.continuous:
+        if one_launch:
+            pass                                                   # (done above)
+        elif not self.continuous:
             # ... and head 1, the discrete PPOHead clipped surrogate (+ entropy bonus), in one launch
             self.lib.ppo_discrete_value_losses(logits.data, self.A, actions, advantages, old_probs, self.A, B,
                                                self.A, self.clip_eps * clip_rescaler, self.beta, 1.0, dlogits,
@@ -246,7 +254,9 @@ class ClippedPPONet(_NetBase):
                                          self.params.g("main/ppo_head/policy_log_std"), self.scalars[0:4],
                                          ratio_out, clipped_out, clip_dev, ctx.stream)
 
-        if fused_heads:
+        if one_launch:
+            pass
+        elif fused_heads:
             G.small_dense_backward_multi(ctx, [(self.v_head, xv, v), (self.pi_head, xp, logits)])
         else:
             self.v_head.backward(ctx, xv, v)

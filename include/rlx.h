@@ -474,6 +474,19 @@ typedef struct rlx_small_dense_problem {
 } rlx_small_dense_problem;
 int rlx_dense_small_forward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
 int rlx_dense_small_backward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
+/* Discrete Clipped-PPO: the losses of both heads (heads/ppo_head.py:52-116, v_head.py:43-52, head.py:143-186) AND the
+ * heads' backward pass (their share of accumulate_gradients, architecture.py:312-385) in ONE launch — what
+ * rlx_ppo_discrete_value_losses followed by rlx_dense_small_backward_multi({value_head, policy_head}) computes, bit for bit
+ * (every workgroup of the backward recomputes the batch's loss-gradient rows instead of reading them behind a launch
+ * boundary).  Heads: one linear tower each over the `batch` <= 256 rows, value N = 1, policy N = n_actions <= 16; their .dy
+ * (optional) receives dV / dlogits, .dw / .db / .dx as in the backward call.  scalars[5] = {surrogate loss, mean entropy,
+ * mean KL(old||new), policy head total, value loss}; clip_scale: device scalar or NULL (see rlx_ppo_discrete_loss). */
+int rlx_ppo_heads_loss_backward(const rlx_small_dense_problem *value_head, const rlx_small_dense_problem *policy_head,
+                                const float *values, const float *value_targets, const float *logits,
+                                const int *actions, const float *advantages, const float *old_probs, long long ld_old,
+                                int batch, float clip_epsilon, const float *clip_scale, float beta_entropy,
+                                float grad_scale, float *scalars, float *likelihood_ratio,
+                                float *clipped_likelihood_ratio, int *status, void *stream);
 
 /* -------------------------------------------------------- head losses (K9) -- */
 /* loss = mean_b(loss_weight * w_b * sum_j l(target, out)); kind 0 = MSE, 1 = Huber(delta 1).

@@ -346,3 +346,44 @@ def test_hip_clipped_ppo_continuous_net_vs_oracle(rlx, dev):
         for name, towers in wo.items():
             for t, arr in towers.items():
                 np.testing.assert_allclose(w[name][t], arr, rtol=1e-3, atol=2e-5, err_msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obs_shape,B,A", [((84, 84, 4), 64, 6), ((17,), 200, 3), ((11,), 7, 16)])
+def test_ppo_heads_losses_and_backward_as_one_launch_equal_the_two_launches(rlx, dev, obs_shape, B, A):
+    """rlx_ppo_heads_loss_backward recomputes the loss-gradient rows in every workgroup of the heads' backward instead of
+    reading them behind a launch boundary: gradients of the whole network, the five loss scalars and the likelihood ratios
+    must equal rlx_ppo_discrete_value_losses + rlx_dense_small_backward_multi bit for bit."""
+    import torch
+    from coach_amd.nn.networks import ClippedPPONet
+    from tests.util import dev_tensor
+    rng = np.random.RandomState(B + A)
+    image = len(obs_shape) == 3
+    obs = rng.randint(0, 256, size=(B,) + obs_shape).astype(np.uint8) if image else \
+        rng.randn(B, *obs_shape).astype(np.float32)
+    obs_d = dev_tensor(obs, dev)
+    actions = dev_tensor(rng.randint(0, A, size=B), dev, np.int32)
+    adv, vt = dev_tensor(rng.randn(B).astype(np.float32), dev), dev_tensor(rng.randn(B).astype(np.float32), dev)
+    got = []
+    saved = ClippedPPONet.HEADS_LOSS_BACKWARD_ONE_LAUNCH
+    try:
+        for one in (False, True):
+            ClippedPPONet.HEADS_LOSS_BACKWARD_ONE_LAUNCH = one
+            np.random.seed(5)
+            net = ClippedPPONet(dev, obs_shape, A, seed=3)
+            net.update_target(1.0)
+            # an old policy that differs from the new one: perturb the online policy head
+            w = net.params.w(net.pi_head.kname)
+            w.add_(dev_tensor((np.random.RandomState(9).randn(*w.shape) * 0.05).astype(np.float32), dev))
+            old = net.policy_probs(obs_d, B, use_target=True, tag="old")
+            ratio = torch.zeros(B, dtype=torch.float32, device=dev)
+            clipped = torch.zeros(B, dtype=torch.float32, device=dev)
+            net.forward_backward(obs_d, B, actions, adv, vt, old, ratio_out=ratio, clipped_out=clipped)
+            net.check_status()
+            got.append([net.params.grads.cpu().numpy().copy(), net.scalars[:5].cpu().numpy().copy(),
+                        ratio.cpu().numpy(), clipped.cpu().numpy()])
+    finally:
+        ClippedPPONet.HEADS_LOSS_BACKWARD_ONE_LAUNCH = saved
+    assert np.abs(got[0][0]).max() > 0 and not np.allclose(got[0][2], 1.0)
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)

@@ -17,21 +17,25 @@ class _Dist(object):
         pass
 
 
-def build(direct, defer, tuning=(192, 192, -1)):
+def build(direct, defer, tuning=(192, 192, -1), heads_one_launch=True):
     import bench
     from coach_amd.nn import graph as G
+    from coach_amd.nn.networks import ClippedPPONet
     G.DIRECT_CONV_INPUT_GRAD = direct
+    ClippedPPONet.HEADS_LOSS_BACKWARD_ONE_LAUNCH = heads_one_launch
     agent = bench.build_agent(torch.device("cuda:0"), _Dist())
     if not defer:
         agent.networks["main"].ctx.begin_deferring = lambda: False
-    agent._ab = (direct, defer, tuning)
+    agent._ab = (direct, defer, tuning, heads_one_launch)
     return agent
 
 
 def train_ms(agent):
     from coach_amd import _rlx
     from coach_amd.nn import graph as G
+    from coach_amd.nn.networks import ClippedPPONet
     G.DIRECT_CONV_INPUT_GRAD = agent._ab[0]
+    ClippedPPONet.HEADS_LOSS_BACKWARD_ONE_LAUNCH = agent._ab[3]
     _rlx.lib().gemm_tuning(*agent._ab[2])            # read when the update's graphs are captured
     for _ in range(agent.steps_per_phase):
         agent.act()
@@ -49,10 +53,8 @@ def train_ms(agent):
 
 
 def main(rounds=4):
-    variants = {"default (contiguous XCD shares, K-in-workgroup tiles: 32 x 64 from 192 tiles)": (False, True, (192, 192, -1)),
-                "32 x 32 tiles preferred (32 x 64 only from 380 tiles)": (False, True, (192, 380, -1)),
-                "K-in-workgroup tiles also below 400 tiles of 64 x 64 (conv1 forward on 32 x 64)": (False, True, (401, 192, -1)),
-                "both": (False, True, (401, 380, -1))}
+    variants = {"default (head losses + heads' backward as one launch)": (False, True, (192, 192, -1), True),
+                "head losses and heads' backward as two launches": (False, True, (192, 192, -1), False)}
     agents = {k: build(*v) for k, v in variants.items()}
     for a in agents.values():
         for _ in range(3):
