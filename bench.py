@@ -576,7 +576,9 @@ def main():
         # exists only in the build container — so its committed timing rides along with its provenance
         # (tools/time_reference_cpu_c2.py: real rl_coach agent / memory / filters, numpy network stand-in)
         ref = {}
-        for key, fn in (("one_core", "r02_cpu_reference_c2_1core.json"), ("all_cores", "r02_cpu_reference_c2.json")):
+        # (round 3 files: BASELINE.md section 3 protocol — 1024 env-steps per repetition, median of 5 — and the minibatch
+        # updates of the timed phase counted correctly; the round-2 files divided a whole phase by ONE update)
+        for key, fn in (("one_core", "r03_cpu_reference_c2_1core.json"), ("all_cores", "r03_cpu_reference_c2.json")):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     r = json.load(f)

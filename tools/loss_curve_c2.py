@@ -116,8 +116,9 @@ def compare(args):
     before = {nm: (float(np.max(np.abs(hip[:kk, j] - orc[:kk, j]) / np.maximum(np.abs(orc[:kk, j]), 1e-12))) if kk else None)
               for j, nm in enumerate(NAMES)}
     out = {"workload": "C2: Clipped PPO, %d vectorized envs, 84x84x4 uint8 observations (synthetic, episodes of %d), %d "
-                       "actions, GAE(0.99, 0.95), rollout %d, minibatch %d, fp32 conv torso x2 — reduced in one respect: "
-                       "%d optimisation epochs per rollout instead of 10" % (N_ENV, L, A, PLAYING, B, st["epochs"]),
+                       "actions, GAE(0.99, 0.95), rollout %d, minibatch %d, fp32 conv torso x2, %d optimisation epochs per "
+                       "rollout%s" % (N_ENV, L, A, PLAYING, B, st["epochs"],
+                                      "" if st["epochs"] == 10 else " (the C2 configuration has 10)"),
            "iterations": n, "env_steps": n * PLAYING, "updates": n * st["epochs"] * (PLAYING // B),
            "window_iterations": W,
            "first_vector_step_with_a_different_sampled_action": first,

@@ -102,6 +102,17 @@ def one_worker(play, seed, q=None, reps=1):
     t_act = t_train = 0.0
     steps = updates = 0
     done_reps = []
+    # fill_advantages (one value pass over the whole rollout, once per training phase) is timed apart from the minibatch
+    # loop: a full C2 iteration has ONE of them per 320 minibatch updates, the sample one per play/64
+    fill = {"t": 0.0}
+    inner_fill = agent.fill_advantages
+
+    def timed_fill(batch):
+        f0 = time.perf_counter()
+        out = inner_fill(batch)
+        fill["t"] += time.perf_counter() - f0
+        return out
+    agent.fill_advantages = timed_fill
     while len(done_reps) < reps:
         t0 = time.perf_counter()
         if reset_required:
@@ -123,10 +134,11 @@ def one_worker(play, seed, q=None, reps=1):
         steps += 1
         t_act += t1 - t0
         if agent.training_iteration != before:
-            updates = agent.training_iteration - before
+            # Agent.training_iteration counts training PHASES; a phase is 1 epoch of steps/64 minibatch updates here
+            updates = steps // B
             t_train = t2 - t1
-            done_reps.append(dict(steps=steps, updates=updates, t_act=t_act, t_train=t_train))
-            t_act, steps = 0.0, 0
+            done_reps.append(dict(steps=steps, updates=updates, t_act=t_act, t_train=t_train, t_fill=fill["t"]))
+            t_act, steps, fill["t"] = 0.0, 0, 0.0
     if q is not None:
         q.put(done_reps)
     return done_reps
@@ -156,13 +168,13 @@ def main():
         cand = []
         for r in reps:
             t_step = r["t_act"] / r["steps"]
-            # one training phase over `steps` transitions = steps/64 value chunks + steps/64 minibatch updates
-            # (1 epoch); scaled: value pass ~ 1/4 of a minibatch update's cost (1 forward of 4 passes) is NOT
-            # separated — the whole phase is attributed per update, which slightly favours the CPU
-            t_update = r["t_train"] / r["updates"]
-            t_iter = 2048 * t_step + 320 * t_update
+            # one training phase over `steps` transitions = fill_advantages over them + steps/64 minibatch updates
+            # (1 epoch); a full iteration = 2048 steps + fill_advantages over 2048 transitions + 320 minibatch updates
+            t_update = (r["t_train"] - r["t_fill"]) / r["updates"]
+            t_fill = r["t_fill"] * 2048.0 / r["steps"]
+            t_iter = 2048 * t_step + t_fill + 320 * t_update
             cand.append(dict(env_steps_per_s=2048 / t_iter, updates_per_s=320 / t_iter, s_per_env_step=t_step,
-                             s_per_update=t_update))
+                             s_per_update=t_update, s_fill_advantages_2048=t_fill))
         cand.sort(key=lambda c: c["env_steps_per_s"])
         per_proc.append(cand[len(cand) // 2])                  # the median repetition of this process
         all_reps.append([round(c["env_steps_per_s"], 3) for c in cand])
@@ -175,9 +187,10 @@ def main():
         "kind": "reference", "cores": a.procs,
         "per_process": {k: round(float(np.mean([x[k] for x in per_proc])), 5) for k in per_proc[0]},
         "sample": "per process: %d env-steps of rollout (Agent.observe / act with the reference's stacking + reward "
-                  "clipping filters, one policy forward per step) and one training phase over them (fill_advantages + "
-                  "train_network, 1 epoch = %d minibatch updates of 64 incl. the per-minibatch old-policy pass), "
-                  "scaled to a full C2 iteration = 2048 env-steps + 320 updates; numpy oracle (1 thread) as the "
+                  "clipping filters, one policy forward per step) and one training phase over them (fill_advantages, timed "
+                  "apart, + train_network, 1 epoch = %d minibatch updates of 64 incl. the per-minibatch old-policy pass), "
+                  "scaled to a full C2 iteration = 2048 env-steps + one fill_advantages over 2048 transitions + 320 "
+                  "updates; numpy oracle (1 thread) as the "
                   "network backend; %d repetitions, median reported; wall %.0f s"
                   % (results[0]["steps"], results[0]["updates"], a.reps, wall),
         "repetitions_per_process": a.reps, "env_steps_per_s_of_every_repetition": all_reps,
