@@ -7,6 +7,9 @@ this network is ~2 s of numpy on the build container and ~0.4 s on the GPU box's
     python tools/loss_curve_c2.py --side oracle --dir gpurun_out/lc_c2                                # CPU, hours
     python tools/loss_curve_c2.py --compare     --dir gpurun_out/lc_c2 --out profiles/r03_loss_curve_c2.json
 
+    python tools/loss_curve_c2.py --side oracle --perturb-ulp --dir gpurun_out/lc_c2                  # the noise floor:
+    python tools/loss_curve_c2.py --compare --first oracle_ulp.npz --dir gpurun_out/lc_c2 --out profiles/...noise_floor.json
+
 The hip side writes the initial weights, the host RNG state after construction and its results; the oracle side
 starts from exactly those.  The synthetic env ignores the actions, so both sides see the same observations for the
 whole run even after the first differently sampled action (reported).  Reduced against the preset in ONE respect,
@@ -76,13 +79,19 @@ def oracle_side(args):
         name, t = k.rsplit("|", 1)
         arrays.setdefault(name, {})[int(t)] = fx[k]
     arrays = {k: [v[t] for t in sorted(v)] for k, v in arrays.items()}
+    if args.perturb_ulp:
+        # the noise floor: the SAME oracle from weights that differ in the last bit of one convolution weight per tower
+        k = sorted(n for n in arrays if n.endswith("kernel"))[0]
+        for a in arrays[k]:
+            a.flat[0] = np.nextafter(a.flat[0], np.float32(np.inf), dtype=np.float32)
+        print("perturbed by one ulp: %s[0] of every tower" % k, flush=True)
     o = ClippedPPOAgentOracle(arrays, SynthVecEnv(0, N_ENV, FRAME[0] * FRAME[1], L, 1234), A, batch_size=B,
                               playing_steps=PLAYING, epochs=st["epochs"])
     o.reset(FRAME)
     random.setstate(st["random"])
     np.random.set_state(st["numpy"])
     res, acts = [], []
-    out = os.path.join(args.dir, "oracle.npz")
+    out = os.path.join(args.dir, "oracle_ulp.npz" if args.perturb_ulp else "oracle.npz")
     t0 = time.perf_counter()
     for it in range(st["iterations"]):
         for _ in range(PLAYING // N_ENV):
@@ -95,7 +104,7 @@ def oracle_side(args):
 
 
 def compare(args):
-    h, o = np.load(os.path.join(args.dir, "hip.npz")), np.load(os.path.join(args.dir, "oracle.npz"))
+    h, o = np.load(os.path.join(args.dir, args.first)), np.load(os.path.join(args.dir, "oracle.npz"))
     with open(os.path.join(args.dir, "rng_state.pkl"), "rb") as f:
         st = pickle.load(f)
     n = min(len(h["results"]), len(o["results"]))
@@ -128,7 +137,7 @@ def compare(args):
                "hip": ha[first][ha[first] != oa[first]].tolist(), "oracle": oa[first][ha[first] != oa[first]].tolist()},
            "identical_sampled_actions": "%d / %d" % (int((ha == oa).sum()), ha.size),
            "max_per_iteration_rel_diff_while_actions_identical": before,
-           "signals": wins, "seconds_hip": float(h["seconds"]), "seconds_oracle_cpu": float(o["seconds"]),
+           "compared": "%s vs oracle.npz" % args.first, "signals": wins, "seconds_hip": float(h["seconds"]), "seconds_oracle_cpu": float(o["seconds"]),
            "oracle_host": "build container, numpy"}
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
@@ -146,6 +155,10 @@ def main():
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--window", type=int, default=7)
     ap.add_argument("--out", default="profiles/r03_loss_curve_c2.json")
+    ap.add_argument("--perturb-ulp", action="store_true",
+                    help="oracle side: start from weights one ulp away in one element per tower (-> oracle_ulp.npz)")
+    ap.add_argument("--first", default="hip.npz",
+                    help="compare: the run set against oracle.npz (oracle_ulp.npz = the oracle against itself)")
     args = ap.parse_args()
     if args.compare:
         compare(args)
