@@ -160,7 +160,8 @@ struct __attribute__((aligned(16))) PathRec {     // what a run shows its neighb
     double s, m, x, pad2;
 };
 
-template <bool WAVE>
+// CONTIG: a store of n consecutive leaves that does not wrap around the ring — already in leaf order, one run per leaf
+template <bool WAVE, bool CONTIG>
 __global__ void __launch_bounds__(WAVE ? 64 : kPathMaxLeaves)
 per_update_paths_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__restrict__ mx,
                         int cap, int levels, const int *__restrict__ idx,
@@ -194,12 +195,13 @@ per_update_paths_kernel(double *__restrict__ sum, double *__restrict__ mn, doubl
             }
         }
     }
+    constexpr bool contiguous = CONTIG;
     key[tid] = leaf;
     lds_barrier();
     // ---- order by leaf: position = number of occurrences that sort before this one (ties by launch order).  The
     // occurrences of one leaf end up as one run whose LAST position is the last occurrence — the one that wins
     // (:214-215).
-    {
+    if (!contiguous) {
         int lo = 0, same = 0, before = 0;
         const int n4 = (n + 3) & ~3;                      // keys behind n are kNoLeaf
         for (int j = 0; j < n4; j += 4) {
@@ -227,11 +229,15 @@ per_update_paths_kernel(double *__restrict__ sum, double *__restrict__ mn, doubl
     int lo = 0, hi = 0;
     bool valid = false;                 // this occurrence may write its leaf
     if (tid < n) {
-        leaf = sorted_leaf[tid];
-        lo = sorted_lo[tid];
-        hi = sorted_hi[tid];
-        in_a = sorted_a[tid];
-        in_b = sorted_b[tid];
+        if (contiguous) {
+            lo = hi = tid;
+        } else {
+            leaf = sorted_leaf[tid];
+            lo = sorted_lo[tid];
+            hi = sorted_hi[tid];
+            in_a = sorted_a[tid];
+            in_b = sorted_b[tid];
+        }
         valid = leaf != kNoLeaf;
         if (valid) node = leaf + cap - 1;
     }
@@ -245,7 +251,16 @@ per_update_paths_kernel(double *__restrict__ sum, double *__restrict__ mn, doubl
             ps[j] = pm[j] = px[j] = 0.0;
             if (a > 0 && lvl0 + j < levels) {
                 const int sib = (a & 1) ? a + 1 : a - 1;
-                ps[j] = sum[sib]; pm[j] = mn[sib]; px[j] = mx[sib];
+                // contiguous store: a sibling with a stored leaf below it is carried by a neighbouring run — its old
+                // value is never used, and near the leaves that is almost every sibling (the loads that remain are the
+                // two edges of the range and, higher up, one address shared by all threads)
+                bool covered = false;
+                if (CONTIG) {                                             // (cap <= 2^30: everything fits an int)
+                    const int h = lvl0 + j;                               // height of `a` and `sib` above the leaves
+                    const int p = sib + 1 - (cap >> h);                   // position within its level
+                    covered = (p << h) < start_leaf + n && ((p + 1) << h) > start_leaf;
+                }
+                if (!covered) { ps[j] = sum[sib]; pm[j] = mn[sib]; px[j] = mx[sib]; }
                 a = (a - 1) >> 1;
             }
         }
@@ -471,14 +486,13 @@ static int launch_update(double *sum_tree, double *min_tree, double *max_tree, i
     int threads = ((n + 63) / 64) * 64;
     if (threads > 1024) threads = 1024;
     if (n <= g_path_max_leaves) {       // one leaf per thread: the path walk that meets only in LDS
-        if (n <= 64)
-            per_update_paths_kernel<true><<<1, 64, 0, rlx::as_stream(stream)>>>(
-                sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
-                start_leaf, alpha, eps, max_priority, mode, status);
-        else
-            per_update_paths_kernel<false><<<1, kPathMaxLeaves, 0, rlx::as_stream(stream)>>>(
-                sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
-                start_leaf, alpha, eps, max_priority, mode, status);
+        const bool contig = (mode == 1 || mode == 3) && n <= capacity && start_leaf >= 0 &&
+                            (long long)start_leaf + n <= capacity && capacity <= (1 << 30);
+        auto kernel = n <= 64 ? (contig ? per_update_paths_kernel<true, true> : per_update_paths_kernel<true, false>)
+                              : (contig ? per_update_paths_kernel<false, true> : per_update_paths_kernel<false, false>);
+        kernel<<<1, n <= 64 ? 64 : kPathMaxLeaves, 0, rlx::as_stream(stream)>>>(
+            sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n, start_leaf, alpha, eps,
+            max_priority, mode, status);
         RLX_LAUNCH_CHECK();
         return RLX_OK;
     }

@@ -300,6 +300,10 @@ def test_both_priority_update_kernels_write_the_same_trees(rlx, dev, cap, n, dup
                 err = r.rand(n) * 5.0
                 rlx.per_update(h.sum, h.min, h.max, h.cap, torch.from_numpy(idx).to(dev),
                                torch.from_numpy(err).to(dev), n, 0.6, 1e-6, h.maxp, h.status, 0)
+                # a store of consecutive leaves (the contiguous fast path), one that wraps around the ring, one leaf
+                for start, m in ((int(r.randint(0, cap)), min(n, cap)), (cap - 1, min(3, cap)), (int(r.randint(0, cap)), 1)):
+                    rlx.per_store(h.sum, h.min, h.max, h.cap, start if start + m <= cap or m > 1 else 0, m, 0.6, h.maxp,
+                                  h.status, 0)
             assert int(h.status.item()) == 0
             trees.append([t.cpu().numpy().copy() for t in (h.sum, h.min, h.max, h.maxp)])
         finally:

@@ -12,6 +12,7 @@
 
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 32, cap = 1 << 20;
+    const bool store = argc > 2;          // any second argument: time rlx_per_store of n consecutive leaves instead
     double *t[3], *maxp, *err;
     int *status, *idx;
     for (auto &p : t) CK(hipMalloc(&p, sizeof(double) * (2 * cap - 1)));
@@ -32,14 +33,16 @@ int main(int argc, char **argv) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0, nullptr));
-        if (rlx_per_update(t[0], t[1], t[2], cap, idx, err, n, 0.6, 1e-6, maxp, status, nullptr)) { printf("update failed\n"); return 1; }
+        if (store) {
+            if (rlx_per_store(t[0], t[1], t[2], cap, (int)(((unsigned)rand() * 2654435761u) % (cap - n)), n, 0.6, maxp, status, nullptr)) { printf("store failed\n"); return 1; }
+        } else if (rlx_per_update(t[0], t[1], t[2], cap, idx, err, n, 0.6, 1e-6, maxp, status, nullptr)) { printf("update failed\n"); return 1; }
         CK(hipEventRecord(e1, nullptr));
         CK(hipDeviceSynchronize());
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         long long p[8];
         CK(hipMemcpyFromSymbol(p, HIP_SYMBOL(g_per_prof), sizeof(p)));
-        printf("rep %d  n %d  events %.1f us |", rep, n, ms * 1e3);
+        printf("%s rep %d  n %d  events %.1f us |", store ? "store " : "update", rep, n, ms * 1e3);
         for (int k = 0; k < 6; ++k) printf("  %s %.2f", names[k], (p[k + 1] - p[k]) * 0.01);
         printf("  | in-kernel total %.2f us\n", (p[6] - p[0]) * 0.01);
     }
