@@ -98,6 +98,7 @@ class ClippedPPOAgent(object):
     epoch_graph = True      # one hipGraph per epoch, not per minibatch
     ragged = False          # envs end their episodes on different steps (set per instance from the env)
     _device_env = True
+    restarts_memory_on_reset = True     # reset_internal_state() also restarts the rollout buffer's frame stack
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         self.ap = agent_parameters
@@ -181,6 +182,8 @@ class ClippedPPOAgent(object):
         self._warm = set()
         self._episode_steps = np.zeros(self.n_env, dtype=np.int64)
         self._episode_just_ended = False
+        self._draw_pool, self._draw_pos, self._draw_table_from = None, 0, None
+        self._eval_mem = None
         self._alloc_training_buffers()
         self.memory.reset(self.env.reset_internal_state())
 
@@ -249,6 +252,25 @@ class ClippedPPOAgent(object):
         self._graphs[key] = _capture(fn)
         return self._graphs[key].replay()
 
+    def _refill_draws(self, from_step):
+        """Lockstep envs: the host draws of the rest of the phase — one uniform (A normals) per (step, env), in the
+        order n_env sequential np.random.choice / np.random.normal calls per step make them (nothing else consumes
+        np.random while acting) — shipped as ONE table indexed by the step.  Draws that were made for steps which
+        never ran (a phase that trained early, the steps a forced reset abandoned) are the next ones of the stream:
+        they are used before anything new is drawn, so the stream is consumed exactly as step-by-step draws would."""
+        shape = (self.n_env, self.A) if self.continuous else (self.n_env,)
+        need = self.steps_per_phase - from_step
+        left = self._draw_pool[self._draw_pos:] if self._draw_pool is not None else np.zeros((0,) + shape)
+        if left.shape[0] < need:
+            m = need - left.shape[0]
+            fresh = np.random.standard_normal((m,) + shape) if self.continuous else np.random.random_sample((m,) + shape)
+            left = np.concatenate([left, fresh], 0)
+        self._draw_pool, self._draw_pos = left, 0
+        table = np.zeros((self.steps_per_phase,) + shape, dtype=np.float64)
+        table[from_step:] = left[:need]
+        self._uniforms.push(table)
+        self._draw_table_from = from_step
+
     # --------------------------------------------------------------------------------- acting
     def _act_device(self, step):
         """Device work of one vector step: stacked states -> online policy tower -> categorical
@@ -297,14 +319,10 @@ class ClippedPPOAgent(object):
         if self.ragged and self.phase == RunPhase.TRAIN:
             self._uniforms.push(np.random.standard_normal((1, self.n_env, self.A)) if self.continuous
                                 else np.random.random_sample((1, self.n_env)))
-        elif step == 0 and self.phase == RunPhase.TRAIN:
-            # draws of the whole phase, in the order n_env sequential np.random.choice calls per step
-            # would make them (nothing else consumes np.random while acting)
-            if self.continuous:
-                u = np.random.standard_normal((self.steps_per_phase, self.n_env, self.A))
-            else:
-                u = np.random.random_sample((self.steps_per_phase, self.n_env))
-            self._uniforms.push(u)
+        elif self.phase == RunPhase.TRAIN:
+            if step == 0 or self._draw_table_from is None:
+                self._refill_draws(step)
+            self._draw_pos += 1
         self.ap.algorithm.clipping_decay_schedule.step()                    # choose_action (:352-354)
         if self._device_env:
             self._run(("act", step, self.phase), lambda: self._act_device(step))
@@ -332,10 +350,11 @@ class ClippedPPOAgent(object):
     def reset_internal_state(self):
         """GraphManager.reset_internal_state(force_environment_reset=True) + Agent.reset_internal_state
         (graph_manager.py:411-424, agent.py:603-629): every env starts a new episode now; the running episodes were
-        held in current_episode_buffer and never reach the memory."""
-        if self.image and self.memory.steps > 0:
-            raise NotImplementedError("a forced reset in the middle of an image rollout would restart the frame ring")
-        self.memory.drop_open_episodes()
+        held in current_episode_buffer and never reach the memory (lockstep envs: their rows and ring frames are
+        rewound, the next episode overwrites them; the host draws made for the abandoned steps' successors are the
+        next ones of the np.random stream and are used first)."""
+        self.memory.drop_open_episodes(None if self.ragged else self.L)
+        self._draw_table_from = None                     # the step -> draw table no longer matches the stream position
         self._episode_steps[:] = 0
         self._episode_just_ended = False
         self.lib.episode_stats_init(self.ep_return, self.ep_len, self.n_env, None, _rlx.current_stream())
@@ -343,49 +362,86 @@ class ClippedPPOAgent(object):
         self.memory.reset(first)
         return first
 
+    def _evaluation_memory(self):
+        """Scratch frame stack of the evaluation episodes (image observations): a one-step rollout buffer whose ring
+        holds stack + 6 frames per env — the training rollout's ring, rows and cursors are never written in TEST
+        phase (Agent.observe_transition stores only in TRAIN / HEATUP, agent.py:956-962)."""
+        if self._eval_mem is None:
+            self._eval_mem = DeviceEpisodicRolloutBuffer(self.device, self.n_env, 1, frame_shape=self.env.p.observation_shape,
+                                                         stack=self.stack)
+        return self._eval_mem
+
+    def _evaluate_device(self, scratch):
+        """Device work of one evaluation step (hipGraph-capturable): state -> most probable action / policy mean ->
+        env step -> scratch frame stack.  Nothing of the training rollout is read or written."""
+        s, n = _rlx.current_stream(), self.n_env
+        states = scratch.current_states() if scratch is not None else self._eval_state
+        if self.norm is not None:
+            states = self.norm.filter(states, update_internal_state=False, out=self.act_obs)
+        if self.continuous:
+            mean, _ = self.networks["main"].policy_mean_std(states, n)
+            self.actions.copy_(mean)
+        else:
+            probs = self.networks["main"].policy_probs(states, n)
+            self.lib.argmax_rows(probs, self.A, n, self.A, self.actions, s)
+        if self._device_env:
+            self.env.launch_step()
+            env = self.env
+            next_obs, reset_obs, reward, game_over = env.next_obs, env.reset_obs, env.reward, env.game_over
+        else:
+            next_obs, reset_obs, reward, game_over = self.env.step(self.actions)
+        self._eval_total.add_(reward.double() * self._eval_active)
+        if scratch is not None:
+            scratch.store_step_at(0, self.actions, reward, game_over, next_obs, reset_obs)
+        else:
+            self._eval_state.copy_(torch.where(game_over.view(-1, 1).bool(), reset_obs, next_obs))
+
     def evaluate_episodes(self, episodes_per_env=1):
-        """GraphManager.evaluate (graph_manager.py:491-523) for the env vector: every env is reset, whole episodes are
-        played in TEST phase — the most probable action (categorical.py:50-56) / the policy mean
-        (additive_noise.py:99-106), observations through the pre-network filter WITHOUT updating its statistics
-        (clipped_ppo_agent.py:346-350) — nothing is stored, no counter of the training schedule moves; training
-        resumes from a fresh reset.  Returns the mean undiscounted episode reward over envs."""
-        if self.image:
-            raise NotImplementedError("evaluation episodes need a scratch frame stack: vector observations only")
+        """GraphManager.evaluate (graph_manager.py:491-523) for the env vector: every env is reset (the open episodes
+        of the rollout are abandoned like at any forced reset), whole episodes are played in TEST phase — the most
+        probable action (categorical.py:50-56) / the policy mean (additive_noise.py:99-106), observations through the
+        pre-network filter WITHOUT updating its statistics (clipped_ppo_agent.py:346-350) — nothing is stored, no
+        counter of the training schedule moves; training resumes from a fresh reset.  Image observations are stacked
+        in a scratch ring (_evaluation_memory).  Returns the mean undiscounted episode reward over envs."""
         prev, prev_env = self.phase, getattr(self.env, "phase", None)
         self.phase = self.env.phase = RunPhase.TEST
         s = _rlx.current_stream()
         n, dev = self.n_env, self.device
-        self.memory.drop_open_episodes()
-        state = self.env.reset_internal_state().clone()
-        total = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.memory.drop_open_episodes(None if self.ragged else self.L)
+        self._draw_table_from = None
+        first = self.env.reset_internal_state()
+        scratch = None
+        if self.image:
+            scratch = self._evaluation_memory()
+            scratch.reset(first)
+        else:
+            if getattr(self, "_eval_state", None) is None:
+                self._eval_state = torch.empty_like(self.memory.cur_state)
+            self._eval_state.copy_(first)
+        if getattr(self, "_eval_total", None) is None:
+            self._eval_total = torch.zeros(n, dtype=torch.float64, device=dev)
+            self._eval_active = torch.ones(n, dtype=torch.float64, device=dev)
+        self._eval_total.zero_()
+        self._eval_active.fill_(1.0)
         finished = np.zeros(n, dtype=np.int64)
         lockstep_t = 0
         try:
             while (finished < episodes_per_env).any():
-                states = state
-                if self.norm is not None:
-                    states = self.norm.filter(state, update_internal_state=False, out=self.act_obs)
-                if self.continuous:
-                    mean, _ = self.networks["main"].policy_mean_std(states, n)
-                    self.actions.copy_(mean)
+                if self._device_env:
+                    self._run(("evaluate",), lambda: self._evaluate_device(scratch))
+                    self.env.host_tick()
                 else:
-                    probs = self.networks["main"].policy_probs(states, n)
-                    self.lib.argmax_rows(probs, self.A, n, self.A, self.actions, s)
-                next_obs, reset_obs, reward, game_over = self.env.step(self.actions)
+                    self._evaluate_device(scratch)
                 self.env.total_steps += n
-                active = finished < episodes_per_env
-                total += reward.double() if active.all() else \
-                    reward.double() * torch.from_numpy(active.astype(np.float64)).to(dev)
                 dh = getattr(self.env, "dones_host", None)
-                if dh is None:                                   # lockstep synthetic envs: all end after L steps
+                if dh is None:                                   # envs without a host clock: all end after L steps
                     lockstep_t += 1
                     dh = np.full(n, lockstep_t % self.L == 0)
+                was_active = finished < episodes_per_env
                 finished += dh.astype(np.int64)
-                state.copy_(next_obs)
-                ended = np.nonzero(dh)[0]
-                if ended.size:
-                    idx = torch.from_numpy(ended).to(dev)
-                    state.index_copy_(0, idx, reset_obs.index_select(0, idx))
+                active = finished < episodes_per_env
+                if (active != was_active).any():                 # an env used up its quota: its further rewards do not count
+                    self._eval_active.copy_(torch.from_numpy(active.astype(np.float64)))
         finally:
             self.phase = prev
             self.env.phase = prev_env if prev_env is not None else prev
@@ -393,7 +449,7 @@ class ClippedPPOAgent(object):
             self._episode_just_ended = False
             self.lib.episode_stats_init(self.ep_return, self.ep_len, n, None, s)
             self.memory.reset(self.env.reset_internal_state())
-        return float(total.mean().item()) / episodes_per_env
+        return float(self._eval_total.mean().item()) / episodes_per_env
 
     # ------------------------------------------------------------------------------- training
     def _should_train(self):
@@ -640,6 +696,15 @@ class ClippedPPOAgent(object):
         return results
 
     # ------------------------------------------------------------------------------ reporting
+    def check_status(self):
+        """device-side error bits (a gather outside the rollout, invalid kernel input) become exceptions here."""
+        bits = int(self.memory.status.item())
+        if bits:
+            self.memory.status.zero_()
+            raise ValueError("rollout buffer kernel reported an out-of-range row (status bits %d)" % bits)
+        for net in self.networks.values():
+            net.check_status()
+
     def episode_statistics(self):
         a = self.ep_acc.cpu().numpy()
         n = max(a[0], 1.0)

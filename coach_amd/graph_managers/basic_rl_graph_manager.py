@@ -174,8 +174,8 @@ class BasicRLGraphManager(object):
         or nothing played yet): the running episodes are abandoned, their last response is never observed."""
         if self._mid_episode and hasattr(self.agent, "reset_internal_state"):
             first = self.agent.reset_internal_state()
-            if hasattr(self.agent.memory, "reset"):
-                self.agent.memory.reset(first)
+            if not getattr(self.agent, "restarts_memory_on_reset", False) and hasattr(self.agent.memory, "reset"):
+                self.agent.memory.reset(first)           # (the on-policy agent restarts its rollout's frame stack itself)
         self._mid_episode = False
 
     def heatup(self, steps):                                                   # :400-424
@@ -289,5 +289,12 @@ class BasicRLGraphManager(object):
             self.evaluate(self.schedule.evaluation_steps)
             if should_stop is not None and should_stop():
                 break
-        self.agent.check_status() if hasattr(self.agent, "check_status") else None
+        self.check_status()
         return self.logger.rows
+
+    def check_status(self):
+        """Device-side error bits of the agent (memory, networks) AND of the environment (an action outside the action
+        space, dynamics outside a table's domain): raised here, once per improve(), not silently dropped."""
+        for obj in (self.agent, self.environment):
+            if hasattr(obj, "check_status"):
+                obj.check_status()

@@ -93,10 +93,27 @@ class DeviceEpisodicRolloutBuffer(object):
             self._episodes.append((int(e), int(self._ep_start[e]), int(self.steps)))
             self._ep_start[e] = self.steps
 
-    def drop_open_episodes(self):
+    def drop_open_episodes(self, episode_length=None):
         """Agent.reset_internal_state in the middle of an episode replaces current_episode_buffer (agent.py:619): the
-        transitions of every running episode never reach the memory.  Their rows stay allocated until clean()."""
-        self._ep_start[:] = self.steps
+        transitions of every running episode never reach the memory.
+
+        Ragged bookkeeping: the open episodes simply are never listed; their rows stay allocated until clean().
+        Lockstep envs (`episode_length` = L, every env ends its episode on steps L-1, 2L-1, ...): the rows of the
+        open episodes are the steps since the last multiple of L — `steps` is rewound to it, so the dataset
+        (`steps * n_env` rows) holds complete episodes only and the next episode's rows overwrite the abandoned ones.
+        The frame ring is rewound with it: the last kept step of every env ended an episode, so its append left the
+        env at (t_fpos + 2, epoff 0) — the post-reset frame that the coming reset replaces in place."""
+        if self.ragged or episode_length is None:
+            self._ep_start[:] = self.steps
+            return 0
+        keep = self.steps - self.steps % int(episode_length)
+        dropped = self.steps - keep
+        if dropped and self.image and keep > 0:
+            last = self.t_fpos[(keep - 1) * self.n_env:keep * self.n_env]
+            self.fpos.copy_(torch.remainder(last + 2, self.F))
+            self.epoff.zero_()
+        self.steps = keep
+        return dropped
 
     # ---- rollout side -------------------------------------------------------------------------
     def reset(self, first_obs):

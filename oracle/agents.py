@@ -322,10 +322,51 @@ class ClippedPPOAgentOracle:
     def forced_reset(self):
         """GraphManager.reset_internal_state(force_environment_reset=True) + Agent.reset_internal_state
         (graph_manager.py:411-424, agent.py:603-629): the running episodes lived in current_episode_buffer and never
-        reach the memory; every env starts a new episode.  Vector observations only."""
+        reach the memory; every env starts a new episode; the stacking filter restarts with it
+        (observation_stacking_filter.py:89-101: reset() empties the deque, the first frame is replicated)."""
         for e in range(self.n_env):
             del self.transitions[e][self.ep_start[e]:]
-        self.cur = [f for f in self.env.reset()]
+        first = self.env.reset()
+        if self.image:
+            first = first.reshape((self.n_env,) + self.frame_hw)
+            for s in self.stackers:
+                s.reset()
+            self.cur = [s.filter(f) for s, f in zip(self.stackers, first)]
+        else:
+            self.cur = [f for f in first]
+
+    def evaluate(self, episodes_per_env=1):
+        """GraphManager.evaluate (graph_manager.py:491-523): forced reset, whole episodes in TEST phase — the most
+        probable action (categorical.py:50-56) / the policy mean (additive_noise.py:99-106), observations through the
+        pre-network filter without updating it (clipped_ppo_agent.py:346-350), nothing stored
+        (agent.py:956-962) — and a fresh reset before training resumes.  Returns the mean total reward per episode
+        over the envs (each env plays `episodes_per_env` episodes; the UNfiltered env reward, agent.py:543-546)."""
+        self.forced_reset()
+        total = np.zeros(self.n_env, dtype=np.float64)
+        finished = np.zeros(self.n_env, dtype=np.int64)
+        while (finished < episodes_per_env).any():
+            states = np.stack(self.cur)
+            if self.normalize:
+                states = self.stats.normalize(states).astype(F32)
+            if self.continuous:
+                actions = [m for m in self.net.policy_mean_std(states)[0]]
+            else:
+                actions = [int(np.argmax(p)) for p in self.net.policy_probs(states)]
+            nxt, rst, rew, done = self.env.step(actions) if getattr(self.env, "takes_actions", False) else self.env.step()
+            active = finished < episodes_per_env
+            total += np.where(active, np.asarray(rew, dtype=np.float64), 0.0)
+            finished += np.asarray(done).astype(np.int64)
+            for e in range(self.n_env):
+                if self.image:
+                    ns = self.stackers[e].filter(nxt[e].reshape(self.frame_hw))
+                    if done[e]:
+                        self.stackers[e].reset()
+                        ns = self.stackers[e].filter(rst[e].reshape(self.frame_hw))
+                    self.cur[e] = ns
+                else:
+                    self.cur[e] = rst[e] if done[e] else nxt[e]
+        self.forced_reset()
+        return float(total.mean()) / episodes_per_env
 
     def complete_transitions(self):
         return sum(b - a for _, a, b in self.episodes)
@@ -334,7 +375,9 @@ class ClippedPPOAgentOracle:
         """ragged mode: the complete episodes hold >= num_consecutive_playing_steps transitions."""
         return self.complete_transitions() >= self.playing_steps
 
-    def train(self):
+    def train(self, max_minibatches=None):
+        """max_minibatches: stop after that many minibatch updates of the FIRST epoch (full-size parity tests: the host
+        shuffles of that epoch are made as usual, the rollout is kept) — None = the whole training phase."""
         import random
         from . import returns as R
         if self.ragged:
@@ -369,6 +412,8 @@ class ClippedPPOAgentOracle:
                 r = self.net.train_minibatch(states[idx], actions[idx], adv[idx].astype(F32),
                                              vt[idx].astype(F32), old)
                 ep.append([r["surrogate"], r["entropy"], r["kl"], r["total"], r["value_loss"]])
+                if max_minibatches is not None and len(ep) >= max_minibatches:
+                    return ep
             out.append(np.mean(np.array(ep, dtype=np.float64), 0))
         self.transitions = [[] for _ in range(self.n_env)]
         self.episodes, self.ep_start = [], [0] * self.n_env
