@@ -322,6 +322,118 @@ def run_off_policy(args, device, dist):
 
 
 # ------------------------------------------------------------------------------------- roofline
+GEMM_FAMILY = ("gemm_", "splitk_reduce")          # kernels that issue (or finish) fp32 MFMA products
+
+
+def _family(name):
+    if name.startswith(GEMM_FAMILY):
+        return "gemm"
+    for key, fam in (("col2im", "col2im"), ("conv_", "col2im"), ("ppo_", "heads"), ("dense_small", "heads"),
+                     ("adam", "adam"), ("img_gather", "gather"), ("copy_columns", "gather")):
+        if name.startswith(key):
+            return fam
+    return "other"
+
+
+def in_update_kernel_trace(agent, n_updates=16, warm=4):
+    """IN-UPDATE kernel durations: `n_updates` consecutive eager minibatch updates on the epoch buffers of the last
+    training phase, every kernel timed by its own dispatch timestamps (librlx's in-process timer, rlx_profile_* —
+    what `rocprofv3 --kernel-trace` reports per dispatch).  Operands are as the previous kernel of the update left
+    them; this is the figure `roofline.frac` is built on.  Returns (per-update microseconds by kernel name, by
+    family, launches per update)."""
+    from coach_amd import _rlx
+    saved_graphs, saved_steps = agent.use_graphs, agent.memory.steps
+    agent.use_graphs = False
+    agent.memory.steps = agent.steps_per_phase      # the (cleaned) rollout's rows are still in HBM
+    try:
+        epoch = agent._gather_epoch(PLAYING_STEPS)
+        for i in range(warm):
+            agent._minibatch_fb(BATCH, None, i=i, epoch=epoch)
+            agent._minibatch_finish(1.0)
+        torch.cuda.synchronize()
+        with _rlx.KernelTimer(256 * n_updates) as timer:
+            for i in range(n_updates):
+                agent._minibatch_fb(BATCH, None, i=(warm + i) % (PLAYING_STEPS // BATCH), epoch=epoch)
+                agent._minibatch_finish(1.0)
+            torch.cuda.synchronize()
+    finally:
+        agent.use_graphs, agent.memory.steps = saved_graphs, saved_steps
+    by_name, by_family, calls = {}, {}, {}
+    for name, us in timer.records:
+        by_name[name] = by_name.get(name, 0.0) + us / n_updates
+        calls[name] = calls.get(name, 0) + 1
+        fam = _family(name)
+        by_family[fam] = by_family.get(fam, 0.0) + us / n_updates
+    table = [{"kernel": k, "launches_per_update": calls[k] / n_updates, "us_per_update": round(v, 2),
+              "avg_us": round(v * n_updates / calls[k], 2)} for k, v in sorted(by_name.items(), key=lambda kv: -kv[1])]
+    return table, {k: round(v, 2) for k, v in by_family.items()}, len(timer.records) / n_updates
+
+
+def epoch_graph_update_us(agent, reps=5):
+    """one minibatch update inside the captured epoch graph (what the timed region replays): device events around
+    `reps` replays of the epoch graph / minibatches per epoch (the epoch's gather launches included)."""
+    graphs = [g for k, g in agent._graphs.items() if k and k[0] == "epoch"]
+    if not graphs:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    graphs[0].replay()
+    e0.record()
+    for _ in range(reps):
+        graphs[0].replay()
+    e1.record()
+    e1.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps / (PLAYING_STEPS // BATCH)
+
+
+def box_calibration(device):
+    """A two-second fixed calibration of THIS box, so that bench lines from different boxes of the pool can be compared
+    (the pool's boxes differ by up to 30 % on identical code): device-to-device copy rate, a compute-bound 4096^3 fp32
+    MFMA product, and the cost of one dependent trivial launch inside a hipGraph."""
+    from coach_amd import _rlx
+    out = {}
+    try:
+        out["device"] = torch.cuda.get_device_name(device)
+        out["compute_units"] = torch.cuda.get_device_properties(device).multi_processor_count
+    except Exception:
+        pass
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 64 << 20
+    a, b = torch.empty(n, dtype=torch.uint8, device=device), torch.zeros(n, dtype=torch.uint8, device=device)
+    for _ in range(3):
+        a.copy_(b)
+    e0.record()
+    for _ in range(20):
+        a.copy_(b)
+    e1.record(); e1.synchronize()
+    out["copy_64MiB_GBps"] = round(2 * n * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)     # read + write
+    M = 4096
+    A = torch.randn(M, M, device=device)
+    B = torch.randn(M, M, device=device)
+    C = torch.empty(M, M, device=device)
+    for _ in range(2):
+        _rlx.gemm(M, M, M, A, B, C)
+    e0.record()
+    for _ in range(5):
+        _rlx.gemm(M, M, M, A, B, C)
+    e1.record(); e1.synchronize()
+    out["gemm_4096_fp32_TFLOPs"] = round(2.0 * M ** 3 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    x = torch.zeros(4, dtype=torch.float32, device=device)
+    x.add_(0.0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(500):
+            x.add_(0.0)
+    g.replay()
+    e0.record()
+    for _ in range(4):
+        g.replay()
+    e1.record(); e1.synchronize()
+    out["graph_dependent_launch_us"] = round(1e3 * e0.elapsed_time(e1) / (4 * 500), 2)
+    del a, b, A, B, C
+    return out
+
+
 def gemm_roofline(agent, reps=20):
     """Per-launch timing of the dominant kernel family (gemm_kernel<...>, fp32 MFMA) with HIP events
     on the launch stream: every GEMM descriptor issued by one minibatch update is recorded, then
@@ -372,46 +484,60 @@ def gemm_roofline(agent, reps=20):
     lib.event_destroy(ev0)
     lib.event_destroy(ev1)
     n = len(recorded)
-    achieved = total_flops / (total_ms * 1e-3) / 1e12
+    warm_tflops = total_flops / (total_ms * 1e-3) / 1e12
+    # algorithmic bytes of the products as GEMMs (A as addressed — the im2col-expanded volume for the convolutions —
+    # + B + C), from the recorded descriptors
+    operand_bytes = sum((x.M * x.K * (1 if x.a_is_u8 else 4) + x.K * x.N * 4 + x.M * x.N * 4) * x.batch
+                        for rec in recorded for x in rec["descs"])
+    # ---- the headline: the same family timed IN the update (see in_update_kernel_trace)
+    table, fam, launches = in_update_kernel_trace(agent)
+    gemm_us = fam.get("gemm", 0.0)
+    achieved = total_flops / (gemm_us * 1e-6) / 1e12
+    update_us = epoch_graph_update_us(agent)
     # HBM-side bytes of the GEMM family per launch: PMC passes cannot run inside this process, so the figure is the
     # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of the same update (tools/ppo_update_once.py +
-    # tools/pmc_summary.py -> profiles/r03_pmc_gemm_traffic.json; the x 2 on FETCH_SIZE is calibrated on this library's
-    # own loads, profiles/r03_pmc_calibration.json), divided by the launches counted HERE; used only if that file
-    # describes the same products.
+    # tools/pmc_summary.py -> profiles/r0N_pmc_gemm_traffic.json; the x 2 on FETCH_SIZE is calibrated on this library's
+    # own loads, profiles/r03_pmc_calibration.json); used only if that file describes the same products AND launches.
+    gemm_launches = sum(r["launches_per_update"] for r in table if r["kernel"].startswith(GEMM_FAMILY))
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_gemm_traffic.json")) as f:
-            pm = json.load(f)
-        if pm.get("gemm_products") == n_products:
-            traffic = round(pm["traffic_bytes_per_update"] / n)
-    except (OSError, ValueError, KeyError):
-        pass
+    for fn in ("r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                pm = json.load(f)
+            if pm.get("gemm_products") == n_products and \
+                    pm.get("gemm_launches", 0) + pm.get("reduce_launches", 0) == round(gemm_launches):
+                traffic = round(pm["traffic_bytes_per_update"] / n)
+                break
+        except (OSError, ValueError, KeyError):
+            pass
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "timing": "IN-UPDATE: per-dispatch begin/end timestamps (librlx rlx_profile_*, = rocprofv3 --kernel-trace "
+                      "durations) of every GEMM-family kernel over 16 consecutive eager minibatch updates, summed per update",
+            "gemm_us_per_update": round(gemm_us, 1), "gemm_launches_per_update": round(gemm_launches, 2),
+            "frac_warm": round(warm_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+            "gemm_us_per_update_warm": round(1e3 * total_ms, 1),
+            "warm_timing": "each library call of the family replayed %d x back to back between one event pair" % reps,
             "traffic_unit": "bytes per library call of the GEMM family, split-K reduces included (2 x FETCH_SIZE + WRITE_SIZE, "
-                            "PMC passes of tools/ppo_update_once.py); operands and results of the %d products are %.1fe6 "
-                            "bytes per call" % (n_products, 131.2 / n),
+                            "PMC passes of tools/ppo_update_once.py); operands (A as addressed) and results of the %d "
+                            "products are %.1fe6 bytes per call" % (n_products, operand_bytes / 1e6 / n),
             "kernel": "gemm_fast_kernel / gemm_fast_pair_kernel / gemm_win_kernel + split-K reduces (fp32 MFMA 32x32x2): "
                       "%d products in %d library calls per minibatch update" % (n_products, n),
-            "flops_per_launch": total_flops / n, "avg_launch_us": round(1e3 * total_ms / n, 2),
-            "gemm_us_per_update": round(1e3 * total_ms, 1)}, per_shape
+            "flops_per_update": total_flops, "flops_per_launch": total_flops / n,
+            "avg_launch_us": round(gemm_us / max(gemm_launches, 1), 2),
+            "update_us_by_family": fam, "kernel_launches_per_update": round(launches, 1),
+            "update_us_sum_of_kernels": round(sum(fam.values()), 1),
+            "update_us_in_epoch_graph": None if update_us is None else round(update_us, 1),
+            "update_kernels": table}, per_shape
 
 
 # ---------------------------------------------------------------------------------- cpu baseline
-def cpu_baseline(budget_s=20.0):
-    """The oracle (numpy restatement of the reference's CPU path) on a bounded sample of the same
-    workload: a few vector env-steps, value chunks and minibatch updates are timed and scaled to one
-    full iteration (32 steps, 32 value chunks of 64, 320 updates incl. the per-minibatch old-policy
-    pass the reference performs)."""
+def _cpu_baseline_once(budget_s):
+    """One timing of the oracle's C2 iteration under the CURRENT BLAS thread setting (see cpu_baseline)."""
     import random
     from oracle.agents import ClippedPPOAgentOracle
     from oracle.synth_env import SynthVecEnv
     from coach_amd.nn import graph as G, networks as NW
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
     # same topology / init as the HIP net, built on the host without touching the GPU library
     params = G.FlatParams()
     torso, feat = NW.build_torso(params, "main", FRAME + (4,), "tanh", 2)
@@ -451,13 +577,40 @@ def cpu_baseline(budget_s=20.0):
     t_mb = (time.perf_counter() - t0) / n_mb
     n_updates = EPOCHS * (PLAYING_STEPS // BATCH)
     t_iter = EP_LEN * t_act + (PLAYING_STEPS // BATCH) * t_val + n_updates * t_mb
-    return {"value": round(PLAYING_STEPS / t_iter, 2), "unit": "env-steps/s", "cores": int(cores),
-            "kind": "port",
-            "sample": "oracle/ (numpy fp32 restatement of rl_coach's CPU path): %d vector env-steps "
-                      "(64 envs), 1 value chunk and %d minibatch updates timed, scaled to one full "
-                      "iteration (32 steps + 32 value chunks + 320 updates); %.3f s/step, %.3f s/chunk, "
-                      "%.3f s/update" % (n_act, n_mb, t_act, t_val, t_mb),
-            "grad_updates_per_s": round(n_updates / t_iter, 3)}
+    return {"value": round(PLAYING_STEPS / t_iter, 2), "unit": "env-steps/s",
+            "grad_updates_per_s": round(n_updates / t_iter, 3),
+            "sample": "%d vector env-steps (64 envs), 1 value chunk and %d minibatch updates timed, scaled to one full "
+                      "iteration (32 steps + 32 value chunks + 320 updates); %.3f s/step, %.3f s/chunk, %.3f s/update"
+                      % (n_act, n_mb, t_act, t_val, t_mb)}
+
+
+def cpu_baseline(budget_s=24.0):
+    """The oracle (numpy fp32 restatement of the reference's CPU path) on a bounded sample of the same workload: a few
+    vector env-steps, value chunks and minibatch updates are timed and scaled to one full iteration (32 steps, 32
+    value chunks of 64, 320 updates incl. the per-minibatch old-policy pass the reference performs).  Timed under
+    three BLAS thread settings: ONE thread — the reference's own setting (coach.py:666 OMP_NUM_THREADS=1, TF
+    intra/inter-op 1, graph_manager.py:219-220) and the figure reported as `value` — 8 threads, and every host core."""
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        all_cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threadpool_limits, all_cores = None, os.cpu_count() or 1
+    settings = [1] if threadpool_limits is None else sorted({1, min(8, all_cores), all_cores})
+    runs = {}
+    for th in settings:
+        if threadpool_limits is None:
+            runs[th] = _cpu_baseline_once(budget_s)
+        else:
+            with threadpool_limits(limits=th):
+                runs[th] = _cpu_baseline_once(budget_s / len(settings))
+    one = runs[settings[0]]
+    out = {"value": one["value"], "unit": "env-steps/s", "cores": settings[0], "kind": "port",
+           "sample": "oracle/ (numpy fp32 restatement of rl_coach's CPU path), %d BLAS thread(s) — the reference runs "
+                     "single-threaded: %s" % (settings[0], one["sample"]),
+           "grad_updates_per_s": one["grad_updates_per_s"], "host_cores": os.cpu_count(),
+           "by_threads": {str(th): {"value": r["value"], "grad_updates_per_s": r["grad_updates_per_s"], "cores": th}
+                          for th, r in runs.items()}}
+    return out
 
 
 def dry_run(args):
@@ -567,6 +720,7 @@ def main():
     if dist.rank == 0 and not args.no_roofline:
         roof, shapes = gemm_roofline(agent)
         out["roofline"] = roof
+        out["box"] = box_calibration(device)
         if args.shapes:
             for s in shapes:
                 print(json.dumps(s), file=sys.stderr)

@@ -179,6 +179,29 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer(object):
+    """`with KernelTimer(max_records) as t: <eager librlx calls>` -> t.records = [(kernel name, microseconds), ...] in
+    launch order: every kernel the library launched inside the block, timed by its own dispatch timestamps
+    (rlx_profile_*, include/rlx.h).  Not usable inside a stream capture."""
+
+    def __init__(self, max_records=4096):
+        self.max_records, self.records = int(max_records), []
+
+    def __enter__(self):
+        lib().profile_begin(self.max_records)
+        return self
+
+    def __exit__(self, *exc):
+        n = ctypes.c_int()
+        lib().profile_end(ctypes.byref(n))
+        if exc[0] is None:
+            name, ms = ctypes.c_char_p(), ctypes.c_float()
+            for i in range(n.value):
+                lib().profile_read(i, ctypes.byref(name), ctypes.byref(ms))
+                self.records.append((name.value.decode().strip("()"), 1e3 * ms.value))
+        return False
+
+
 # --------------------------------------------------------------------------- ABI structures
 class Column(ctypes.Structure):
     """rlx_column (include/rlx.h)."""

@@ -168,8 +168,7 @@ int rlx_copy_2d(const float *src, long long src_ld, float *dst, long long dst_ld
                 float scale, void *stream) {
     RLX_REQUIRE(src && dst, "rlx_copy_2d: null pointer");
     RLX_REQUIRE(rows > 0 && cols > 0 && src_ld >= cols && dst_ld >= cols, "rlx_copy_2d: bad shape");
-    copy_2d_kernel<<<rlx::grid_for((long long)rows * cols, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
-        src, src_ld, dst, dst_ld, rows, cols, scale);
+    RLX_LAUNCH((copy_2d_kernel), rlx::grid_for((long long)rows * cols, kBlock), kBlock, 0, rlx::as_stream(stream), src, src_ld, dst, dst_ld, rows, cols, scale);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -177,14 +176,14 @@ int rlx_copy_2d(const float *src, long long src_ld, float *dst, long long dst_ld
 int rlx_exp_rows(const float *log_std, float *out, int batch, int action_dim, void *stream) {
     RLX_REQUIRE(log_std && out && batch > 0 && action_dim > 0, "rlx_exp_rows: bad arguments");
     const int n = batch * action_dim;
-    exp_rows_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(log_std, out, batch, action_dim);
+    RLX_LAUNCH((exp_rows_kernel), (n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), log_std, out, batch, action_dim);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
 
 int rlx_axpby(float *out, float a, const float *x, float b, const float *y, long long n, void *stream) {
     RLX_REQUIRE(out && x && n > 0, "rlx_axpby: bad arguments");
-    axpby_kernel<<<rlx::grid_for(n, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(out, a, x, b, y, n);
+    RLX_LAUNCH((axpby_kernel), rlx::grid_for(n, kBlock), kBlock, 0, rlx::as_stream(stream), out, a, x, b, y, n);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -192,8 +191,7 @@ int rlx_axpby(float *out, float a, const float *x, float b, const float *y, long
 int rlx_min_pair(const float *q1, const float *q2, float *out_min, float *grad1, float *grad2,
                  float grad_scale, int n, void *stream) {
     RLX_REQUIRE(q1 && q2 && n > 0, "rlx_min_pair: bad arguments");
-    min_pair_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        q1, q2, out_min, grad1, grad2, grad_scale, n);
+    RLX_LAUNCH((min_pair_kernel), (n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), q1, q2, out_min, grad1, grad2, grad_scale, n);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -202,8 +200,7 @@ int rlx_sac_min_targets(const float *q1, const float *q2, const float *sampled_l
                         float *out_min, float *value_targets, float *grad1, float *grad2, void *stream) {
     RLX_REQUIRE(q1 && q2 && sampled_logprob && out_min && value_targets && grad1 && grad2 && n > 0,
                 "rlx_sac_min_targets: bad arguments");
-    sac_min_targets_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        q1, q2, sampled_logprob, grad_scale, n, out_min, value_targets, grad1, grad2);
+    RLX_LAUNCH((sac_min_targets_kernel), (n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), q1, q2, sampled_logprob, grad_scale, n, out_min, value_targets, grad1, grad2);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -212,9 +209,8 @@ int rlx_select_rows(const unsigned char *mask, const void *if_set, const void *i
                     int n, long long row_bytes, void *stream) {
     RLX_REQUIRE(mask && if_set && if_clear && out && n > 0 && row_bytes > 0,
                 "rlx_select_rows: bad arguments");
-    select_rows_kernel<<<rlx::grid_for((long long)n * row_bytes, kBlock), kBlock, 0,
-                         rlx::as_stream(stream)>>>(
-        mask, static_cast<const unsigned char *>(if_set), static_cast<const unsigned char *>(if_clear),
+    RLX_LAUNCH((select_rows_kernel), rlx::grid_for((long long)n * row_bytes, kBlock), kBlock, 0,
+                         rlx::as_stream(stream), mask, static_cast<const unsigned char *>(if_set), static_cast<const unsigned char *>(if_clear),
         static_cast<unsigned char *>(out), n, row_bytes);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -225,8 +221,7 @@ int rlx_sac_policy_head(const float *mu_logsig, long long ld, const double *stan
                         float *out_actions, float *out_logprob, void *stream) {
     RLX_REQUIRE(mu_logsig && standard_normals, "rlx_sac_policy_head: null pointer");
     RLX_REQUIRE(batch > 0 && action_dim > 0 && ld >= 2 * action_dim, "rlx_sac_policy_head: bad shape");
-    sac_policy_head_kernel<<<(batch + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(
-        mu_logsig, ld, standard_normals, batch, action_dim, out_mean, out_log_std, out_raw_actions,
+    RLX_LAUNCH((sac_policy_head_kernel), (batch + 63) / 64, 64, 0, rlx::as_stream(stream), mu_logsig, ld, standard_normals, batch, action_dim, out_mean, out_log_std, out_raw_actions,
         out_actions, out_logprob);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -240,8 +235,7 @@ int rlx_sac_policy_head_backward(const float *mu_logsig, long long ld, const dou
     RLX_REQUIRE(batch > 0 && action_dim > 0 && ld >= 2 * action_dim && ld_grad >= 2 * action_dim,
                 "rlx_sac_policy_head_backward: bad shape");
     const int n = batch * action_dim;
-    sac_policy_head_backward_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        mu_logsig, ld, standard_normals, batch, action_dim, logprob_mean_weight, action_weights,
+    RLX_LAUNCH((sac_policy_head_backward_kernel), (n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), mu_logsig, ld, standard_normals, batch, action_dim, logprob_mean_weight, action_weights,
         action_weight_scale, d_mu_logsig, ld_grad, accumulate);
     RLX_LAUNCH_CHECK();
     return RLX_OK;

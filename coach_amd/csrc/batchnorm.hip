@@ -107,8 +107,7 @@ int rlx_bn_forward(const float *x, const float *gamma, const float *beta, const 
     RLX_REQUIRE(training ? (save_mean && save_var) : (moving_mean && moving_var),
                 "rlx_bn_forward: training needs save_mean / save_var, inference the moving statistics");
     RLX_REQUIRE(epsilon > 0, "rlx_bn_forward: epsilon must be positive");
-    bn_forward_kernel<<<(channels + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        x, gamma, beta, moving_mean, moving_var, batch, channels, (float)epsilon, training, activation, y, save_mean,
+    RLX_LAUNCH((bn_forward_kernel), (channels + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), x, gamma, beta, moving_mean, moving_var, batch, channels, (float)epsilon, training, activation, y, save_mean,
         save_var);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -122,8 +121,7 @@ int rlx_bn_backward(const float *dy, const float *y, const float *x, const float
     RLX_REQUIRE(activation >= 0 && activation <= 2, "rlx_bn_backward: unknown activation %d", activation);
     RLX_REQUIRE(activation == 0 || y, "rlx_bn_backward: the activation derivative needs the layer output");
     RLX_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "rlx_bn_backward: dgamma and dbeta go together");
-    bn_backward_kernel<<<(channels + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        dy, y, x, gamma, save_mean, save_var, batch, channels, (float)epsilon, activation, dx, dgamma, dbeta);
+    RLX_LAUNCH((bn_backward_kernel), (channels + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), dy, y, x, gamma, save_mean, save_var, batch, channels, (float)epsilon, activation, dx, dgamma, dbeta);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -133,8 +131,7 @@ int rlx_bn_update_moving(float *moving_mean, float *moving_var, const float *bat
     RLX_REQUIRE(moving_mean && moving_var && batch_mean && batch_var && channels > 0,
                 "rlx_bn_update_moving: bad arguments");
     RLX_REQUIRE(momentum >= 0 && momentum <= 1, "rlx_bn_update_moving: momentum outside [0, 1]");
-    bn_update_moving_kernel<<<(channels + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        moving_mean, moving_var, batch_mean, batch_var, channels, (float)(1.0 - momentum));
+    RLX_LAUNCH((bn_update_moving_kernel), (channels + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), moving_mean, moving_var, batch_mean, batch_var, channels, (float)(1.0 - momentum));
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -144,7 +144,7 @@ int rlx_cartpole_reset(double *state, float *obs, int *episode, int *steps, int 
                        unsigned int env_id0, int next_episode, void *stream) {
     RLX_REQUIRE(state && obs && episode && steps, "rlx_cartpole_reset: null pointer");
     RLX_REQUIRE(n_env > 0, "rlx_cartpole_reset: n_env must be positive (got %d)", n_env);
-    cartpole_reset_kernel<<<(n_env + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(state, obs, episode, steps, n_env,
+    RLX_LAUNCH((cartpole_reset_kernel), (n_env + 63) / 64, 64, 0, rlx::as_stream(stream), state, obs, episode, steps, n_env,
                                                                                 seed, env_id0, next_episode);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -157,8 +157,7 @@ int rlx_cartpole_step(const int *action, double *state, int *episode, int *steps
                 "rlx_cartpole_step: null pointer");
     RLX_REQUIRE(n_env > 0 && max_episode_steps > 0, "rlx_cartpole_step: bad sizes (n_env %d, max_episode_steps %d)",
                 n_env, max_episode_steps);
-    cartpole_step_kernel<<<(n_env + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(
-        action, state, episode, steps, next_obs, reset_obs, next_state64, reward, game_over, n_env,
+    RLX_LAUNCH((cartpole_step_kernel), (n_env + 63) / 64, 64, 0, rlx::as_stream(stream), action, state, episode, steps, next_obs, reset_obs, next_state64, reward, game_over, n_env,
         max_episode_steps, seed, env_id0, status);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -166,7 +165,7 @@ int rlx_cartpole_step(const int *action, double *state, int *episode, int *steps
 
 int rlx_libm_sincos(const double *x, double *sin_out, double *cos_out, int n, int *status, void *stream) {
     RLX_REQUIRE(x && sin_out && cos_out && status && n > 0, "rlx_libm_sincos: bad arguments");
-    libm_sincos_kernel<<<(n + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(x, sin_out, cos_out, n, status);
+    RLX_LAUNCH((libm_sincos_kernel), (n + 255) / 256, 256, 0, rlx::as_stream(stream), x, sin_out, cos_out, n, status);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -66,10 +66,10 @@ int rlx_dense_small_forward(const float *x, long long x_tower_stride, const floa
                  M, K, N, activation};
     dim3 grid(M, towers);
     hipStream_t s = rlx::as_stream(stream);
-    if (N <= 1) dense_small_fwd_kernel<1><<<grid, 256, 0, s>>>(p);
-    else if (N <= 4) dense_small_fwd_kernel<4><<<grid, 256, 0, s>>>(p);
-    else if (N <= 8) dense_small_fwd_kernel<8><<<grid, 256, 0, s>>>(p);
-    else dense_small_fwd_kernel<16><<<grid, 256, 0, s>>>(p);
+    if (N <= 1) RLX_LAUNCH((dense_small_fwd_kernel<1>), grid, 256, 0, s, p);
+    else if (N <= 4) RLX_LAUNCH((dense_small_fwd_kernel<4>), grid, 256, 0, s, p);
+    else if (N <= 8) RLX_LAUNCH((dense_small_fwd_kernel<8>), grid, 256, 0, s, p);
+    else RLX_LAUNCH((dense_small_fwd_kernel<16>), grid, 256, 0, s, p);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -98,10 +98,10 @@ int rlx_dense_small_backward(const float *x, long long x_tower_stride, const flo
     // and, up to 128 rows, every x load of a thread in one chunk (same-box A/B, profiles/r03_ab_candidates.txt: C4 +6 %,
     // C5 +4 %, C1 unchanged)
     dim3 wgrid((K + 15) / 16, towers);
-    if (NN == 1) dense_small_bwd_wide_kernel<1><<<wgrid, 256, smem, s>>>(p);
-    else if (NN == 4) dense_small_bwd_wide_kernel<4><<<wgrid, 256, smem, s>>>(p);
-    else if (NN == 8) dense_small_bwd_wide_kernel<8><<<wgrid, 256, smem, s>>>(p);
-    else dense_small_bwd_wide_kernel<16><<<wgrid, 256, smem, s>>>(p);
+    if (NN == 1) RLX_LAUNCH((dense_small_bwd_wide_kernel<1>), wgrid, 256, smem, s, p);
+    else if (NN == 4) RLX_LAUNCH((dense_small_bwd_wide_kernel<4>), wgrid, 256, smem, s, p);
+    else if (NN == 8) RLX_LAUNCH((dense_small_bwd_wide_kernel<8>), wgrid, 256, smem, s, p);
+    else RLX_LAUNCH((dense_small_bwd_wide_kernel<16>), wgrid, 256, smem, s, p);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -129,10 +129,10 @@ int rlx_dense_small_forward_multi(const rlx_small_dense_problem *problems_host, 
     }
     dim3 grid(max_m, max_t, n_problems);
     hipStream_t s = rlx::as_stream(stream);
-    if (nn == 1) dense_small_fwd_multi_kernel<1><<<grid, 256, 0, s>>>(m);
-    else if (nn == 4) dense_small_fwd_multi_kernel<4><<<grid, 256, 0, s>>>(m);
-    else if (nn == 8) dense_small_fwd_multi_kernel<8><<<grid, 256, 0, s>>>(m);
-    else dense_small_fwd_multi_kernel<16><<<grid, 256, 0, s>>>(m);
+    if (nn == 1) RLX_LAUNCH((dense_small_fwd_multi_kernel<1>), grid, 256, 0, s, m);
+    else if (nn == 4) RLX_LAUNCH((dense_small_fwd_multi_kernel<4>), grid, 256, 0, s, m);
+    else if (nn == 8) RLX_LAUNCH((dense_small_fwd_multi_kernel<8>), grid, 256, 0, s, m);
+    else RLX_LAUNCH((dense_small_fwd_multi_kernel<16>), grid, 256, 0, s, m);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -170,10 +170,10 @@ int rlx_dense_small_backward_multi(const rlx_small_dense_problem *problems_host,
     RLX_REQUIRE(smem <= 64 * 1024, "rlx_dense_small_backward_multi: batch x outputs exceeds the LDS budget");
     dim3 grid(max_kb, max_t, n_problems);
     hipStream_t s = rlx::as_stream(stream);
-    if (nn == 1) dense_small_bwd_multi_kernel<1><<<grid, 256, smem, s>>>(m);
-    else if (nn == 4) dense_small_bwd_multi_kernel<4><<<grid, 256, smem, s>>>(m);
-    else if (nn == 8) dense_small_bwd_multi_kernel<8><<<grid, 256, smem, s>>>(m);
-    else dense_small_bwd_multi_kernel<16><<<grid, 256, smem, s>>>(m);
+    if (nn == 1) RLX_LAUNCH((dense_small_bwd_multi_kernel<1>), grid, 256, smem, s, m);
+    else if (nn == 4) RLX_LAUNCH((dense_small_bwd_multi_kernel<4>), grid, 256, smem, s, m);
+    else if (nn == 8) RLX_LAUNCH((dense_small_bwd_multi_kernel<8>), grid, 256, smem, s, m);
+    else RLX_LAUNCH((dense_small_bwd_multi_kernel<16>), grid, 256, smem, s, m);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

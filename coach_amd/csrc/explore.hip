@@ -110,7 +110,7 @@ extern "C" {
 int rlx_argmax_rows(const float *values, long long ld, int n_rows, int n_cols, int *out, void *stream) {
     RLX_REQUIRE(values && out, "rlx_argmax_rows: null pointer");
     RLX_REQUIRE(n_rows > 0 && n_cols > 0 && ld >= n_cols, "rlx_argmax_rows: bad shape");
-    argmax_rows_kernel<<<(n_rows + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(values, ld, n_rows, n_cols, out);
+    RLX_LAUNCH((argmax_rows_kernel), (n_rows + 63) / 64, 64, 0, rlx::as_stream(stream), values, ld, n_rows, n_cols, out);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -119,8 +119,7 @@ int rlx_categorical_sample(const float *probs, long long ld, const double *unifo
                            int n_actions, int *actions, void *stream) {
     RLX_REQUIRE(probs && uniforms && actions, "rlx_categorical_sample: null pointer");
     RLX_REQUIRE(n_env > 0 && n_actions > 0 && ld >= n_actions, "rlx_categorical_sample: bad shape");
-    categorical_sample_kernel<<<(n_env + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(
-        probs, ld, uniforms, n_env, n_actions, actions);
+    RLX_LAUNCH((categorical_sample_kernel), (n_env + 63) / 64, 64, 0, rlx::as_stream(stream), probs, ld, uniforms, n_env, n_actions, actions);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -131,8 +130,7 @@ int rlx_egreedy(const float *q_values, long long ld, const double *explore_unifo
     RLX_REQUIRE(q_values && explore_uniforms && random_actions && tie_break_uniforms && actions,
                 "rlx_egreedy: null pointer");
     RLX_REQUIRE(n_env > 0 && n_actions > 0 && ld >= n_actions, "rlx_egreedy: bad shape");
-    egreedy_kernel<<<(n_env + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(
-        q_values, ld, explore_uniforms, random_actions, tie_break_uniforms, epsilon, n_env,
+    RLX_LAUNCH((egreedy_kernel), (n_env + 63) / 64, 64, 0, rlx::as_stream(stream), q_values, ld, explore_uniforms, random_actions, tie_break_uniforms, epsilon, n_env,
         n_actions, actions);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -148,8 +146,7 @@ int rlx_gaussian_action(const float *mean, const float *std_per_dim, const float
                 "rlx_gaussian_action: give both bounds or neither");
     RLX_REQUIRE(n_env > 0 && action_dim > 0, "rlx_gaussian_action: bad shape");
     int n = n_env * action_dim;
-    gaussian_action_kernel<<<(n + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
-        mean, std_per_dim, std_per_sample, standard_normals, action_low, action_high, n_env,
+    RLX_LAUNCH((gaussian_action_kernel), (n + 255) / 256, 256, 0, rlx::as_stream(stream), mean, std_per_dim, std_per_sample, standard_normals, action_low, action_high, n_env,
         action_dim, actions);
     RLX_LAUNCH_CHECK();
     return RLX_OK;

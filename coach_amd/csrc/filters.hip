@@ -217,8 +217,8 @@ int rlx_rgb_to_y_u8(const unsigned char *rgb, unsigned char *out, long long n_pi
                 "observation space low values");   // reference message (to_uint8 :40-41)
     RLX_REQUIRE(((uintptr_t)rgb & 3) == 0 && ((uintptr_t)out & 3) == 0,
                 "rlx_rgb_to_y_u8: buffers must be 4-byte aligned");
-    rgb_to_y_u8_kernel<<<rlx::grid_for(n_pixels / 4 + 1, kBlock), kBlock, 0,
-                         rlx::as_stream(stream)>>>(rgb, out, n_pixels, input_low, input_high);
+    RLX_LAUNCH((rgb_to_y_u8_kernel), rlx::grid_for(n_pixels / 4 + 1, kBlock), kBlock, 0,
+                         rlx::as_stream(stream), rgb, out, n_pixels, input_low, input_high);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -232,13 +232,11 @@ int rlx_running_stats_push(const void *samples, int samples_are_f64, long long n
     hipStream_t s = rlx::as_stream(stream);
     int grid = (dim + 63) / 64;
     if (samples_are_f64)
-        running_stats_push_kernel<double><<<grid, 64, 0, s>>>(
-            static_cast<const double *>(samples), n, dim, sum, sum_squares, count, mean, std, epsilon);
+        RLX_LAUNCH((running_stats_push_kernel<double>), grid, 64, 0, s, static_cast<const double *>(samples), n, dim, sum, sum_squares, count, mean, std, epsilon);
     else
-        running_stats_push_kernel<float><<<grid, 64, 0, s>>>(
-            static_cast<const float *>(samples), n, dim, sum, sum_squares, count, mean, std, epsilon);
+        RLX_LAUNCH((running_stats_push_kernel<float>), grid, 64, 0, s, static_cast<const float *>(samples), n, dim, sum, sum_squares, count, mean, std, epsilon);
     RLX_LAUNCH_CHECK();
-    running_stats_count_kernel<<<1, 1, 0, s>>>(count, (double)n);
+    RLX_LAUNCH((running_stats_count_kernel), 1, 1, 0, s, count, (double)n);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -247,7 +245,7 @@ int rlx_running_stats_merge(const double *delta, int dim, double *sum, double *s
                             double *count, double *mean, double *std, double epsilon, void *stream) {
     RLX_REQUIRE(delta && sum && sum_squares && count && mean && std, "rlx_running_stats_merge: null pointer");
     RLX_REQUIRE(dim > 0, "rlx_running_stats_merge: dim=%d", dim);
-    running_stats_merge_kernel<<<1, 256, 0, rlx::as_stream(stream)>>>(delta, dim, sum, sum_squares, count,
+    RLX_LAUNCH((running_stats_merge_kernel), 1, 256, 0, rlx::as_stream(stream), delta, dim, sum, sum_squares, count,
                                                                       mean, std, epsilon);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -261,11 +259,9 @@ int rlx_running_stats_normalize(const void *x, int x_is_f64, long long n, int di
     const long long total = n * dim;
     hipStream_t s = rlx::as_stream(stream);
     if (x_is_f64)
-        running_stats_normalize_kernel<double><<<rlx::grid_for(total, kBlock), kBlock, 0, s>>>(
-            static_cast<const double *>(x), total, dim, mean, std, clip_low, clip_high, out32, out64);
+        RLX_LAUNCH((running_stats_normalize_kernel<double>), rlx::grid_for(total, kBlock), kBlock, 0, s, static_cast<const double *>(x), total, dim, mean, std, clip_low, clip_high, out32, out64);
     else
-        running_stats_normalize_kernel<float><<<rlx::grid_for(total, kBlock), kBlock, 0, s>>>(
-            static_cast<const float *>(x), total, dim, mean, std, clip_low, clip_high, out32, out64);
+        RLX_LAUNCH((running_stats_normalize_kernel<float>), rlx::grid_for(total, kBlock), kBlock, 0, s, static_cast<const float *>(x), total, dim, mean, std, clip_low, clip_high, out32, out64);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -277,7 +273,7 @@ int rlx_max_over_frames_u8(const unsigned char *frames, unsigned char *out, int 
                     (((uintptr_t)frames | (uintptr_t)out) & 15) == 0,
                 "rlx_max_over_frames_u8: frames must be 16-byte aligned multiples of 16 bytes (got %lld)", frame_bytes);
     dim3 grid(rlx::grid_for(frame_bytes / 16, 256, 64), n_env);
-    max_over_frames_kernel<<<grid, 256, 0, rlx::as_stream(stream)>>>(frames, out, n_frames, frame_bytes);
+    RLX_LAUNCH((max_over_frames_kernel), grid, 256, 0, rlx::as_stream(stream), frames, out, n_frames, frame_bytes);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -292,8 +288,7 @@ int rlx_reward_filter(const float *rewards, float *out, long long n, double resc
     // `if self.clipping_high:` / `if self.clipping_low:` — a bound equal to 0 is not applied.
     const int use_hi = has_clip && clipping_high != 0.0;
     const int use_lo = has_clip && clipping_low != 0.0;
-    reward_filter_kernel<<<rlx::grid_for(n, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
-        rewards, out, n, rescale_factor, use_hi, clipping_high, use_lo, clipping_low);
+    RLX_LAUNCH((reward_filter_kernel), rlx::grid_for(n, kBlock), kBlock, 0, rlx::as_stream(stream), rewards, out, n, rescale_factor, use_hi, clipping_high, use_lo, clipping_low);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -303,8 +298,7 @@ int rlx_resize_bilinear_u8(const unsigned char *in, unsigned char *out, int n, i
     RLX_REQUIRE(in && out, "rlx_resize_bilinear_u8: null pointer");
     RLX_REQUIRE(n > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "rlx_resize_bilinear_u8: bad shape");
     const long long total = (long long)n * OH * OW * C;
-    resize_bilinear_u8_kernel<<<rlx::grid_for(total, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
-        in, out, n, H, W, C, OH, OW);
+    RLX_LAUNCH((resize_bilinear_u8_kernel), rlx::grid_for(total, kBlock), kBlock, 0, rlx::as_stream(stream), in, out, n, H, W, C, OH, OW);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

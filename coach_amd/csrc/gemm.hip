@@ -1432,7 +1432,7 @@ int launch_variant(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, 
                    hipStream_t s) {
 #define RLX_GEMM_CASE(AV, AU, BV)                                                        \
     if (a_vec_red == AV && a_u8 == AU && b_vec_red == BV) {                              \
-        gemm_kernel<BM, BN, AV, AU, BV><<<grid, kThreads, 0, s>>>(g);                    \
+        RLX_LAUNCH((gemm_kernel<BM, BN, AV, AU, BV>), grid, kThreads, 0, s, g);                    \
         return 0;                                                                        \
     }
     RLX_GEMM_CASE(true, false, false)
@@ -1450,7 +1450,7 @@ int launch_fast(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, boo
                 hipStream_t s) {
 #define RLX_FAST_CASE(AV, AU, BV, AT)                                                        \
     if (a_vec_red == AV && a_u8 == AU && b_vec_red == BV && a_tab == AT) {                   \
-        gemm_fast_kernel<BM, BN, TM, TN, KW, AV, AU, BV, AT><<<grid, kThreads, 0, s>>>(g);   \
+        RLX_LAUNCH((gemm_fast_kernel<BM, BN, TM, TN, KW, AV, AU, BV, AT>), grid, kThreads, 0, s, g);   \
         return 0;                                                                            \
     }
     RLX_FAST_CASE(true, false, false, false)
@@ -1552,12 +1552,12 @@ int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, 
     if (N % 4 == 0 && mn < (1LL << 31) && aligned16(g.ws)) {
         dim3 rgrid((unsigned)((mn / 4 + 63) / 64), batch);
         if (splits > 16)
-            splitk_reduce4_kernel<16><<<rgrid, 1024, 0, s>>>(g);
+            RLX_LAUNCH((splitk_reduce4_kernel<16>), rgrid, 1024, 0, s, g);
         else
-            splitk_reduce4_kernel<4><<<rgrid, 256, 0, s>>>(g);
+            RLX_LAUNCH((splitk_reduce4_kernel<4>), rgrid, 256, 0, s, g);
     } else {
         dim3 rgrid(rlx::grid_for(mn, 256, 1024), batch);
-        splitk_reduce_kernel<<<rgrid, 256, 0, s>>>(g);
+        RLX_LAUNCH((splitk_reduce_kernel), rgrid, 256, 0, s, g);
     }
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -1649,15 +1649,15 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
             }
             hipStream_t ts = rlx::as_stream(stream);
             if (t16) {
-                if (a_ck && b_cn) gemm_thin16_kernel<true, true><<<tgrid, kThreads, 0, ts>>>(g);
-                else if (a_ck) gemm_thin16_kernel<true, false><<<tgrid, kThreads, 0, ts>>>(g);
-                else if (b_cn) gemm_thin16_kernel<false, true><<<tgrid, kThreads, 0, ts>>>(g);
-                else gemm_thin16_kernel<false, false><<<tgrid, kThreads, 0, ts>>>(g);
+                if (a_ck && b_cn) RLX_LAUNCH((gemm_thin16_kernel<true, true>), tgrid, kThreads, 0, ts, g);
+                else if (a_ck) RLX_LAUNCH((gemm_thin16_kernel<true, false>), tgrid, kThreads, 0, ts, g);
+                else if (b_cn) RLX_LAUNCH((gemm_thin16_kernel<false, true>), tgrid, kThreads, 0, ts, g);
+                else RLX_LAUNCH((gemm_thin16_kernel<false, false>), tgrid, kThreads, 0, ts, g);
             }
-            else if (a_ck && b_cn) gemm_thin_kernel<true, true><<<tgrid, kThreads, 0, ts>>>(g);
-            else if (a_ck) gemm_thin_kernel<true, false><<<tgrid, kThreads, 0, ts>>>(g);
-            else if (b_cn) gemm_thin_kernel<false, true><<<tgrid, kThreads, 0, ts>>>(g);
-            else gemm_thin_kernel<false, false><<<tgrid, kThreads, 0, ts>>>(g);
+            else if (a_ck && b_cn) RLX_LAUNCH((gemm_thin_kernel<true, true>), tgrid, kThreads, 0, ts, g);
+            else if (a_ck) RLX_LAUNCH((gemm_thin_kernel<true, false>), tgrid, kThreads, 0, ts, g);
+            else if (b_cn) RLX_LAUNCH((gemm_thin_kernel<false, true>), tgrid, kThreads, 0, ts, g);
+            else RLX_LAUNCH((gemm_thin_kernel<false, false>), tgrid, kThreads, 0, ts, g);
             RLX_LAUNCH_CHECK();
             return RLX_OK;
         }
@@ -1829,7 +1829,7 @@ int rlx_splitk_reduce_jobs(const rlx_splitk_job *jobs_host, int n_jobs, void *st
         gy = j.batch > gy ? j.batch : gy;
     }
     if (n == 0) return RLX_OK;
-    splitk_reduce_jobs_kernel<<<dim3(gx, gy, n), 1024, 0, rlx::as_stream(stream)>>>(jobs);
+    RLX_LAUNCH((splitk_reduce_jobs_kernel), dim3(gx, gy, n), 1024, 0, rlx::as_stream(stream), jobs);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -1853,7 +1853,7 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
         p.n0 = (int)(pw.grid.x * pw.grid.y * pw.grid.z);
         p.t16[0] = pw.t16; p.t16[1] = px.t16;
         const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
-        gemm_thin_pair_kernel<<<total, kThreads, 0, rlx::as_stream(stream)>>>(p);
+        RLX_LAUNCH((gemm_thin_pair_kernel), total, kThreads, 0, rlx::as_stream(stream), p);
         RLX_LAUNCH_CHECK();
         return RLX_OK;
     }
@@ -1872,7 +1872,7 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
     const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
     hipStream_t s = rlx::as_stream(stream);
 #define RLX_PAIR_CASE(AT, KWX)                                                                   \
-    if (pw.a_tab == AT && px.kw == KWX) gemm_fast_pair_kernel<AT, KWX><<<total, kThreads, 0, s>>>(p);
+    if (pw.a_tab == AT && px.kw == KWX) RLX_LAUNCH((gemm_fast_pair_kernel<AT, KWX>), total, kThreads, 0, s, p);
     RLX_PAIR_CASE(true, 1) RLX_PAIR_CASE(true, 2) RLX_PAIR_CASE(true, 4)
     RLX_PAIR_CASE(false, 1) RLX_PAIR_CASE(false, 2) RLX_PAIR_CASE(false, 4)
 #undef RLX_PAIR_CASE
@@ -1901,9 +1901,9 @@ int rlx_colsum(const float *x, int M, int N, long long ld, float *out, int accum
     parts = (M + rows_per_block - 1) / rows_per_block;
     hipStream_t s = rlx::as_stream(stream);
     dim3 grid((N + 63) / 64, parts);
-    colsum_partial_kernel<<<grid, 64, 0, s>>>(x, M, N, ld, rows_per_block, workspace);
+    RLX_LAUNCH((colsum_partial_kernel), grid, 64, 0, s, x, M, N, ld, rows_per_block, workspace);
     RLX_LAUNCH_CHECK();
-    colsum_final_kernel<<<(N + 63) / 64, 64, 0, s>>>(workspace, parts, N, out, accumulate);
+    RLX_LAUNCH((colsum_final_kernel), (N + 63) / 64, 64, 0, s, workspace, parts, N, out, accumulate);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -1912,7 +1912,7 @@ int rlx_act_backward(float *dy, const float *y, long long n, int kind, void *str
     RLX_REQUIRE(dy && y && n > 0, "rlx_act_backward: bad arguments");
     RLX_REQUIRE(kind >= 0 && kind <= 2, "rlx_act_backward: unknown activation %d", kind);
     if (kind == RLX_ACT_NONE) return RLX_OK;
-    act_backward_kernel<<<rlx::grid_for(n, 256), 256, 0, rlx::as_stream(stream)>>>(dy, y, n, kind);
+    RLX_LAUNCH((act_backward_kernel), rlx::grid_for(n, 256), 256, 0, rlx::as_stream(stream), dy, y, n, kind);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -1926,8 +1926,7 @@ int rlx_conv_tables(int *rowbase, int *koff, int batch, int H, int W, int C, int
     const int M = batch * OH * OW, K = KH * KW * C;
     RLX_REQUIRE((long long)batch * H * W * C < (1LL << 31), "rlx_conv_tables: input too large for int32 offsets");
     const int n = M > K ? M : K;
-    conv_tables_kernel<<<(n + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
-        rowbase, koff, batch, H, W, C, KH, KW, stride, OH, OW);
+    RLX_LAUNCH((conv_tables_kernel), (n + 255) / 256, 256, 0, rlx::as_stream(stream), rowbase, koff, batch, H, W, C, KH, KW, stride, OH, OW);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -1971,8 +1970,7 @@ int rlx_conv_input_grad_tables(int *tables, int batch, int H, int W, int C, int 
     int *rowbase = tables, *yx = tables + M, *crow = tables + 2 * M, *koff_a = tables + 3 * M, *jyx = koff_a + K,
         *koff_b = jyx + K;
     const int n = M > K ? M : K;
-    conv_dx_tables_kernel<<<(n + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
-        rowbase, yx, crow, koff_a, jyx, koff_b, batch, H, W, C, KH, KW, stride, Co, OH, OW, Mp);
+    RLX_LAUNCH((conv_dx_tables_kernel), (n + 255) / 256, 256, 0, rlx::as_stream(stream), rowbase, yx, crow, koff_a, jyx, koff_b, batch, H, W, C, KH, KW, stride, Co, OH, OW, Mp);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -2006,11 +2004,11 @@ int rlx_conv_input_grad(const float *dy, const float *weights, float *dx, const 
     g.inner = 1 << 30; g.splits = 1; g.kchunk = K; g.vec_epi = 1; g.a_div = 1.f;
     hipStream_t s = rlx::as_stream(stream);
     if (C <= 32) {
-        gemm_win_kernel<128, 32, 1><<<dim3((C + 31) / 32, M / 128, towers), kThreads, 0, s>>>(g);
+        RLX_LAUNCH((gemm_win_kernel<128, 32, 1>), dim3((C + 31) / 32, M / 128, towers), kThreads, 0, s, g);
     } else if ((long long)(M / 64) * ((C + 63) / 64) * towers >= 192) {
-        gemm_win_kernel<64, 64, 1><<<dim3((C + 63) / 64, M / 64, towers), kThreads, 0, s>>>(g);
+        RLX_LAUNCH((gemm_win_kernel<64, 64, 1>), dim3((C + 63) / 64, M / 64, towers), kThreads, 0, s, g);
     } else {
-        gemm_win_kernel<32, 64, 2><<<dim3((C + 63) / 64, M / 32, towers), kThreads, 0, s>>>(g);
+        RLX_LAUNCH((gemm_win_kernel<32, 64, 2>), dim3((C + 63) / 64, M / 32, towers), kThreads, 0, s, g);
     }
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -2026,11 +2024,9 @@ int rlx_col2im(const float *dcol, float *dx, const float *x_out, int deriv_kind,
                 "rlx_col2im: tensor too large for 32-bit indexing");
     const bool vec = C % 4 == 0 && (((uintptr_t)dcol | (uintptr_t)dx | (uintptr_t)x_out) & 15) == 0;
     if (vec)
-        col2im_kernel<4><<<rlx::grid_for(total / 4, 256, 8192), 256, 0, rlx::as_stream(stream)>>>(
-            dcol, dx, x_out, deriv_kind, batch, H, W, C, KH, KW, stride, OH, OW);
+        RLX_LAUNCH((col2im_kernel<4>), rlx::grid_for(total / 4, 256, 8192), 256, 0, rlx::as_stream(stream), dcol, dx, x_out, deriv_kind, batch, H, W, C, KH, KW, stride, OH, OW);
     else
-        col2im_kernel<1><<<rlx::grid_for(total, 256, 8192), 256, 0, rlx::as_stream(stream)>>>(
-            dcol, dx, x_out, deriv_kind, batch, H, W, C, KH, KW, stride, OH, OW);
+        RLX_LAUNCH((col2im_kernel<1>), rlx::grid_for(total, 256, 8192), 256, 0, rlx::as_stream(stream), dcol, dx, x_out, deriv_kind, batch, H, W, C, KH, KW, stride, OH, OW);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -274,8 +274,7 @@ int rlx_regression_loss(const float *out, long long ld_out, const float *target,
                 "rlx_regression_loss: bad shape (batch=%d dim=%d)", batch, dim);
     RLX_REQUIRE(kind == 0 || kind == 1, "rlx_regression_loss: kind must be 0 (mse) or 1 (huber)");
     RLX_REQUIRE(!grad || ld_grad >= dim, "rlx_regression_loss: bad gradient pitch");
-    regression_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
-        out, target, importance_weights, batch, dim, ld_out, ld_target, kind, loss_weight, grad_scale,
+    RLX_LAUNCH((regression_loss_kernel), 1, block_for(batch), 0, rlx::as_stream(stream), out, target, importance_weights, batch, dim, ld_out, ld_target, kind, loss_weight, grad_scale,
         grad, ld_grad, loss_scalar);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -296,7 +295,7 @@ int rlx_ac_critic_losses(const float *q_next1, const float *q_next2, const float
     a.nonzero_terminal_discount = use_non_zero_discount_for_terminal_states; a.has_clip = has_clip;
     a.q = q; a.n_streams = n_streams; a.batch = batch; a.loss_weight = loss_weight;
     a.q_min_out = q_min_out; a.td_targets = td_targets; a.dq = dq; a.loss = loss;
-    ac_critic_losses_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(a);
+    RLX_LAUNCH((ac_critic_losses_kernel), 1, block_for(batch), 0, rlx::as_stream(stream), a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -305,7 +304,7 @@ int rlx_softmax(const float *logits, long long ld, int batch, int n, float *prob
                 long long ld_out, void *stream) {
     RLX_REQUIRE(logits && probs, "rlx_softmax: null pointer");
     RLX_REQUIRE(batch > 0 && n > 0 && ld >= n && ld_out >= n, "rlx_softmax: bad shape");
-    softmax_kernel<<<(batch + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(logits, batch, n, ld, probs,
+    RLX_LAUNCH((softmax_kernel), (batch + 63) / 64, 64, 0, rlx::as_stream(stream), logits, batch, n, ld, probs,
                                                                        ld_out);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -322,8 +321,7 @@ int rlx_ppo_discrete_loss(const float *logits, long long ld, const int *actions,
     RLX_REQUIRE(batch > 0 && n_actions > 0 && ld >= n_actions && ld_old >= n_actions,
                 "rlx_ppo_discrete_loss: bad shape");
     RLX_REQUIRE(!dlogits || ld_grad >= n_actions, "rlx_ppo_discrete_loss: bad gradient pitch");
-    ppo_discrete_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
-        logits, ld, actions, advantages, old_probs, ld_old, batch, n_actions, clip_epsilon,
+    RLX_LAUNCH((ppo_discrete_loss_kernel), 1, block_for(batch), 0, rlx::as_stream(stream), logits, ld, actions, advantages, old_probs, ld_old, batch, n_actions, clip_epsilon,
         beta_entropy, grad_scale, dlogits, ld_grad, scalars, likelihood_ratio,
         clipped_likelihood_ratio, status, clip_scale);
     RLX_LAUNCH_CHECK();
@@ -342,8 +340,7 @@ int rlx_ppo_continuous_loss(const float *mean, long long ld, const float *log_st
                 "rlx_ppo_continuous_loss: bad shape (minibatch must be <= %d rows)", kMaxBlock);
     RLX_REQUIRE((dmean == nullptr) == (dlog_std == nullptr) && (!dmean || ld_grad >= action_dim),
                 "rlx_ppo_continuous_loss: give both gradient outputs or neither");
-    ppo_continuous_loss_kernel<<<1, block_for(batch), 0, rlx::as_stream(stream)>>>(
-        mean, ld, log_std, actions, advantages, old_mean, old_std, ld_old, batch, action_dim, clip_epsilon,
+    RLX_LAUNCH((ppo_continuous_loss_kernel), 1, block_for(batch), 0, rlx::as_stream(stream), mean, ld, log_std, actions, advantages, old_mean, old_std, ld_old, batch, action_dim, clip_epsilon,
         beta_entropy, grad_scale, dmean, ld_grad, dlog_std, scalars, likelihood_ratio,
         clipped_likelihood_ratio, clip_scale);
     RLX_LAUNCH_CHECK();
@@ -366,7 +363,7 @@ int rlx_ppo_discrete_value_losses(const float *logits, long long ld, const int *
                        beta_entropy, grad_scale, dlogits, ld_grad, scalars, likelihood_ratio,
                        clipped_likelihood_ratio, status, values, value_targets, dvalues, value_loss_scalar,
                        clip_scale};
-    ppo_value_losses_kernel<<<2, block_for(batch), 0, rlx::as_stream(stream)>>>(a);
+    RLX_LAUNCH((ppo_value_losses_kernel), 2, block_for(batch), 0, rlx::as_stream(stream), a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

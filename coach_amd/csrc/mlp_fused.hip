@@ -634,14 +634,14 @@ int rlx_mlp_q_act(const float *weights, long long off_w1, long long off_b1, long
     const size_t lds = sizeof(float) * act_lds_floats(n_env, h1, h2);
     hipStream_t st = rlx::as_stream(stream);
     switch (n_env) {
-        case 1: mlp_q_act_kernel<1><<<1, kActThreads, lds, st>>>(p); break;
-        case 2: mlp_q_act_kernel<2><<<1, kActThreads, lds, st>>>(p); break;
-        case 3: mlp_q_act_kernel<3><<<1, kActThreads, lds, st>>>(p); break;
-        case 4: mlp_q_act_kernel<4><<<1, kActThreads, lds, st>>>(p); break;
-        case 5: mlp_q_act_kernel<5><<<1, kActThreads, lds, st>>>(p); break;
-        case 6: mlp_q_act_kernel<6><<<1, kActThreads, lds, st>>>(p); break;
-        case 7: mlp_q_act_kernel<7><<<1, kActThreads, lds, st>>>(p); break;
-        default: mlp_q_act_kernel<8><<<1, kActThreads, lds, st>>>(p); break;
+        case 1: RLX_LAUNCH((mlp_q_act_kernel<1>), 1, kActThreads, lds, st, p); break;
+        case 2: RLX_LAUNCH((mlp_q_act_kernel<2>), 1, kActThreads, lds, st, p); break;
+        case 3: RLX_LAUNCH((mlp_q_act_kernel<3>), 1, kActThreads, lds, st, p); break;
+        case 4: RLX_LAUNCH((mlp_q_act_kernel<4>), 1, kActThreads, lds, st, p); break;
+        case 5: RLX_LAUNCH((mlp_q_act_kernel<5>), 1, kActThreads, lds, st, p); break;
+        case 6: RLX_LAUNCH((mlp_q_act_kernel<6>), 1, kActThreads, lds, st, p); break;
+        case 7: RLX_LAUNCH((mlp_q_act_kernel<7>), 1, kActThreads, lds, st, p); break;
+        default: RLX_LAUNCH((mlp_q_act_kernel<8>), 1, kActThreads, lds, st, p); break;
     }
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -698,7 +698,7 @@ int rlx_mlp_dqn_update(const rlx_mlp_dqn_desc *d_host, void *stream) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    mlp_dqn_update_kernel<<<G, kThreads, lds, rlx::as_stream(stream)>>>(p);
+    RLX_LAUNCH((mlp_dqn_update_kernel), G, kThreads, lds, rlx::as_stream(stream), p);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

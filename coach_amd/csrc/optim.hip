@@ -250,10 +250,9 @@ int rlx_adam_tf1(float *weights, const float *grads, float *m, float *v, long lo
     RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                 "rlx_adam_tf1: buffers must be 16-byte aligned");
     hipStream_t s = rlx::as_stream(stream);
-    adam_tf1_kernel<false><<<rlx::grid_for(n / 4 + 1, kBlock), kBlock, 0, s>>>(
-        weights, grads, m, v, n, learning_rate, beta1, beta2, epsilon, state, grad_scale, nullptr);
+    RLX_LAUNCH((adam_tf1_kernel<false>), rlx::grid_for(n / 4 + 1, kBlock), kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1, beta2, epsilon, state, grad_scale, nullptr);
     RLX_LAUNCH_CHECK();
-    adam_advance_kernel<<<1, 1, 0, s>>>(state, beta1, beta2);
+    RLX_LAUNCH((adam_advance_kernel), 1, 1, 0, s, state, beta1, beta2);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -273,10 +272,10 @@ int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, lo
     if (blocks > workspace_floats) blocks = (int)workspace_floats;
     RLX_REQUIRE(blocks >= 1, "rlx_adam_tf1_norm: workspace too small");
     hipStream_t s = rlx::as_stream(stream);
-    adam_tf1_kernel<true><<<blocks, kBlock, 0, s>>>(weights, grads, m, v, n, learning_rate, beta1, beta2,
+    RLX_LAUNCH((adam_tf1_kernel<true>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1, beta2,
                                                     epsilon, state, grad_scale, workspace);
     RLX_LAUNCH_CHECK();
-    adam_finish_norm_kernel<<<1, kBlock, 0, s>>>(state, beta1, beta2, workspace, blocks, norm_out, acc_src,
+    RLX_LAUNCH((adam_finish_norm_kernel), 1, kBlock, 0, s, state, beta1, beta2, workspace, blocks, norm_out, acc_src,
                                                  acc_dst, n_acc);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -299,7 +298,7 @@ int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, lo
     hipStream_t s = rlx::as_stream(stream);
     const float rate = (float)mix_rate, omr = (float)(1.0 - mix_rate);
 #define RLX_ADAM_STEP(NORM, MIX, TICKET)                                                                      \
-    adam_step_kernel<NORM, MIX, TICKET><<<blocks, kBlock, 0, s>>>(weights, grads, m, v, n, learning_rate, beta1,  \
+    RLX_LAUNCH((adam_step_kernel<NORM, MIX, TICKET>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1,  \
                                                                   beta2, epsilon, state, grad_scale, workspace, \
                                                                   target, rate, omr, ticket)
     if (norm_out && target) RLX_ADAM_STEP(true, true, false);
@@ -309,7 +308,7 @@ int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, lo
 #undef RLX_ADAM_STEP
     RLX_LAUNCH_CHECK();
     if (norm_out) {
-        adam_finish_norm_kernel<<<1, kBlock, 0, s>>>(state, beta1, beta2, workspace, blocks, norm_out, acc_src,
+        RLX_LAUNCH((adam_finish_norm_kernel), 1, kBlock, 0, s, state, beta1, beta2, workspace, blocks, norm_out, acc_src,
                                                      acc_dst, n_acc);
         RLX_LAUNCH_CHECK();
     } else if (n_acc > 0) {
@@ -324,8 +323,7 @@ int rlx_mix_weights(float *target, const float *online, long long n, double rate
                 "rlx_mix_weights: buffers must be 16-byte aligned");
     // new_rate * new_weight + (1 - new_rate) * old_weights: python floats meet fp32 arrays, so
     // both coefficients are rounded to fp32 first (architecture.py:604-605).
-    mix_kernel<<<rlx::grid_for(n / 4 + 1, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
-        target, online, n, (float)rate, (float)(1.0 - rate));
+    RLX_LAUNCH((mix_kernel), rlx::grid_for(n / 4 + 1, kBlock), kBlock, 0, rlx::as_stream(stream), target, online, n, (float)rate, (float)(1.0 - rate));
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -337,9 +335,9 @@ int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspa
     if (parts > workspace_floats) parts = (int)workspace_floats;
     RLX_REQUIRE(parts >= 1, "rlx_global_norm: workspace too small");
     hipStream_t s = rlx::as_stream(stream);
-    sumsq_partial_kernel<<<parts, kBlock, 0, s>>>(x, n, workspace);
+    RLX_LAUNCH((sumsq_partial_kernel), parts, kBlock, 0, s, x, n, workspace);
     RLX_LAUNCH_CHECK();
-    sumsq_final_kernel<<<1, kBlock, 0, s>>>(workspace, parts, norm_out);
+    RLX_LAUNCH((sumsq_final_kernel), 1, kBlock, 0, s, workspace, parts, norm_out);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -348,8 +346,7 @@ int rlx_clip_by_global_norm(float *grads, long long n, const float *global_norm,
                             void *stream) {
     RLX_REQUIRE(grads && global_norm && n > 0, "rlx_clip_by_global_norm: bad arguments");
     RLX_REQUIRE(clip_norm > 0.f, "rlx_clip_by_global_norm: clip_norm must be positive (got %g)", (double)clip_norm);
-    clip_by_global_norm_kernel<<<rlx::grid_for(n, kBlock, 1024), kBlock, 0, rlx::as_stream(stream)>>>(
-        grads, n, global_norm, clip_norm);
+    RLX_LAUNCH((clip_by_global_norm_kernel), rlx::grid_for(n, kBlock, 1024), kBlock, 0, rlx::as_stream(stream), grads, n, global_norm, clip_norm);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -138,9 +138,9 @@ int rlx_ppo_heads_loss_backward(const rlx_small_dense_problem *value_head, const
                       red_threads, clip_epsilon, beta_entropy, grad_scale};
     dim3 grid(kb, 1, 2);
     hipStream_t s = rlx::as_stream(stream);
-    if (nn == 4) ppo_heads_loss_bwd_kernel<4><<<grid, 256, smem, s>>>(a);
-    else if (nn == 8) ppo_heads_loss_bwd_kernel<8><<<grid, 256, smem, s>>>(a);
-    else ppo_heads_loss_bwd_kernel<16><<<grid, 256, smem, s>>>(a);
+    if (nn == 4) RLX_LAUNCH((ppo_heads_loss_bwd_kernel<4>), grid, 256, smem, s, a);
+    else if (nn == 8) RLX_LAUNCH((ppo_heads_loss_bwd_kernel<8>), grid, 256, smem, s, a);
+    else RLX_LAUNCH((ppo_heads_loss_bwd_kernel<16>), grid, 256, smem, s, a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -299,15 +299,14 @@ int rlx_copy_columns(const rlx_column *columns_host, int ncols, const int *src_i
     dim3 grid(rlx::grid_for(max_row / width * n, kBlock, rlx::kMaxStreamBlocks / ncols + 1), ncols);
     hipStream_t s = rlx::as_stream(stream);
     if (width == 16)
-        copy_columns_kernel<uint4><<<grid, kBlock, 0, s>>>(cs, src_idx, dst_idx, src_start,
+        RLX_LAUNCH((copy_columns_kernel<uint4>), grid, kBlock, 0, s, cs, src_idx, dst_idx, src_start,
                                                            dst_start, src_rows, dst_rows, n, status);
     else if (width == 4)
-        copy_columns_kernel<uint32_t><<<grid, kBlock, 0, s>>>(cs, src_idx, dst_idx, src_start,
+        RLX_LAUNCH((copy_columns_kernel<uint32_t>), grid, kBlock, 0, s, cs, src_idx, dst_idx, src_start,
                                                               dst_start, src_rows, dst_rows, n,
                                                               status);
     else
-        copy_columns_kernel<unsigned char><<<grid, kBlock, 0, s>>>(
-            cs, src_idx, dst_idx, src_start, dst_start, src_rows, dst_rows, n, status);
+        RLX_LAUNCH((copy_columns_kernel<unsigned char>), grid, kBlock, 0, s, cs, src_idx, dst_idx, src_start, dst_start, src_rows, dst_rows, n, status);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -321,10 +320,10 @@ int rlx_imgreplay_reset(unsigned char *ring, int *env_fpos, int *env_epoff,
                 frame_bytes);
     dim3 grid(rlx::grid_for(frame_bytes / 4, kBlock, 8), n_env);
     hipStream_t s = rlx::as_stream(stream);
-    img_reset_kernel<<<grid, kBlock, 0, s>>>(ring, env_fpos, env_epoff, first_frame, ring_frames,
+    RLX_LAUNCH((img_reset_kernel), grid, kBlock, 0, s, ring, env_fpos, env_epoff, first_frame, ring_frames,
                                              frame_bytes);
     RLX_LAUNCH_CHECK();
-    img_reset_advance_kernel<<<(n_env + 63) / 64, 64, 0, s>>>(env_fpos, env_epoff, n_env,
+    RLX_LAUNCH((img_reset_advance_kernel), (n_env + 63) / 64, 64, 0, s, env_fpos, env_epoff, n_env,
                                                               ring_frames);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -347,11 +346,11 @@ int rlx_imgreplay_append(unsigned char *ring, int *env_fpos, int *env_epoff, int
                 frame_bytes);
     hipStream_t s = rlx::as_stream(stream);
     dim3 grid(rlx::grid_for(frame_bytes / 4, kBlock, 8), n_env);
-    img_append_kernel<<<grid, kBlock, 0, s>>>(ring, env_fpos, env_epoff, t_fpos, t_epoff,
+    RLX_LAUNCH((img_append_kernel), grid, kBlock, 0, s, ring, env_fpos, env_epoff, t_fpos, t_epoff,
                                               next_frame, reset_frame, done, n_env, ring_frames,
                                               frame_bytes, stack, cursor, capacity, record);
     RLX_LAUNCH_CHECK();
-    img_advance_kernel<<<(n_env + 63) / 64, 64, 0, s>>>(env_fpos, env_epoff, done, n_env,
+    RLX_LAUNCH((img_advance_kernel), (n_env + 63) / 64, 64, 0, s, env_fpos, env_epoff, done, n_env,
                                                         ring_frames, stack, reset_frame != nullptr);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -380,12 +379,12 @@ int rlx_imgreplay_gather(const unsigned char *ring, const int *t_fpos,
     hipStream_t s = rlx::as_stream(stream);
     if (stack == 4) {
         dim3 grid(rlx::grid_for(frame_bytes / 4, kBlock, 8), batch);
-        img_gather4_kernel<<<grid, kBlock, 0, s>>>(ring, t_fpos, t_epoff, env_fpos, env_epoff, idx,
+        RLX_LAUNCH((img_gather4_kernel), grid, kBlock, 0, s, ring, t_fpos, t_epoff, env_fpos, env_epoff, idx,
                                                    n_env, ring_frames, frame_bytes, capacity,
                                                    out_state, out_next, which, status);
     } else {
         dim3 grid(rlx::grid_for((long long)frame_bytes * stack, kBlock, 16), batch);
-        img_gather_generic_kernel<<<grid, kBlock, 0, s>>>(ring, t_fpos, t_epoff, env_fpos,
+        RLX_LAUNCH((img_gather_generic_kernel), grid, kBlock, 0, s, ring, t_fpos, t_epoff, env_fpos,
                                                           env_epoff, idx, n_env, ring_frames,
                                                           frame_bytes, stack, capacity, out_state,
                                                           out_next, which, status);

@@ -398,8 +398,7 @@ int rlx_gae(const float *rewards, const float *values, const unsigned char *game
     RLX_REQUIRE(rewards && values && game_overs && advantages, "rlx_gae: null pointer");
     RLX_REQUIRE(n_seq > 0 && seq_len > 0, "rlx_gae: empty input (n_seq=%d seq_len=%lld)", n_seq,
                 seq_len);
-    reverse_scan_kernel<<<n_seq, kScanBlock, 0, rlx::as_stream(stream)>>>(
-        rewards, values, game_overs, bootstrap_values, seq_len, discount, discount * gae_lambda, 0,
+    RLX_LAUNCH((reverse_scan_kernel), n_seq, kScanBlock, 0, rlx::as_stream(stream), rewards, values, game_overs, bootstrap_values, seq_len, discount, discount * gae_lambda, 0,
         advantages, value_targets);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -410,8 +409,7 @@ int rlx_discounted_returns(const float *rewards, const unsigned char *game_overs
                            float *returns32, void *stream) {
     RLX_REQUIRE(rewards && game_overs && returns64, "rlx_discounted_returns: null pointer");
     RLX_REQUIRE(n_seq > 0 && seq_len > 0, "rlx_discounted_returns: empty input");
-    reverse_scan_kernel<<<n_seq, kScanBlock, 0, rlx::as_stream(stream)>>>(
-        rewards, nullptr, game_overs, nullptr, seq_len, discount, discount, 1, returns64,
+    RLX_LAUNCH((reverse_scan_kernel), n_seq, kScanBlock, 0, rlx::as_stream(stream), rewards, nullptr, game_overs, nullptr, seq_len, discount, discount, 1, returns64,
         returns32);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -419,7 +417,7 @@ int rlx_discounted_returns(const float *rewards, const unsigned char *game_overs
 
 int rlx_signals_reset(double *table, int n_signals, void *stream) {
     RLX_REQUIRE(table && n_signals > 0, "rlx_signals_reset: bad arguments");
-    signals_reset_kernel<<<(n_signals + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(table, n_signals);
+    RLX_LAUNCH((signals_reset_kernel), (n_signals + 63) / 64, 64, 0, rlx::as_stream(stream), table, n_signals);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -439,7 +437,7 @@ int rlx_signals_accumulate(const rlx_signal_source *sources_host, int n_sources,
         src.is_f64[i] = sources_host[i].is_f64;
         src.row[i] = sources_host[i].signal;
     }
-    signals_accumulate_kernel<<<1, 256, 0, rlx::as_stream(stream)>>>(src, table);
+    RLX_LAUNCH((signals_accumulate_kernel), 1, 256, 0, rlx::as_stream(stream), src, table);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -452,8 +450,7 @@ int rlx_episode_nstep_returns(const float *rewards, double *out, double *compact
                 "rlx_episode_nstep_returns: bad episode geometry (length=%d ring_steps=%lld)", length, ring_steps);
     RLX_REQUIRE(n_step == -1 || n_step >= 1,
                 "n-step should be an integer with value >= 1, or set to -1 for always setting to episode length.");
-    episode_nstep_returns_kernel<<<(length + 255) / 256, 256, 0, rlx::as_stream(stream)>>>(
-        rewards, out, compact_out, first_step, length, env, n_env, ring_steps, discount, n_step);
+    RLX_LAUNCH((episode_nstep_returns_kernel), (length + 255) / 256, 256, 0, rlx::as_stream(stream), rewards, out, compact_out, first_step, length, env, n_env, ring_steps, discount, n_step);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -462,7 +459,7 @@ int rlx_standardize(const double *x, long long n, float *out32, double *out64, d
                     void *stream) {
     RLX_REQUIRE(x && (out32 || out64), "rlx_standardize: null pointer");
     RLX_REQUIRE(n > 0, "rlx_standardize: empty input");
-    standardize_kernel<<<1, 1024, 0, rlx::as_stream(stream)>>>(x, n, out32, out64, mean_std);
+    RLX_LAUNCH((standardize_kernel), 1, 1024, 0, rlx::as_stream(stream), x, n, out32, out64, mean_std);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -487,8 +484,7 @@ int rlx_episode_stats_step(const float *reward, const unsigned char *game_over, 
     RLX_REQUIRE(n_env > 0, "rlx_episode_stats_step: n_env must be positive");
     int threads = n_env >= 1024 ? 1024 : 64;
     while (threads < n_env && threads < 1024) threads <<= 1;
-    episode_stats_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
-        reward, game_over, ep_return, ep_len, n_env, acc, last_return, last_len);
+    RLX_LAUNCH((episode_stats_kernel), 1, threads, 0, rlx::as_stream(stream), reward, game_over, ep_return, ep_len, n_env, acc, last_return, last_len);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -529,7 +525,7 @@ int rlx_observe_step(const rlx_observe_desc *d, void *stream) {
     int threads = 64;
     const long long work = (long long)d->n_env * (d->obs_row_bytes / 4 + 1);
     while (threads < work && threads < 1024) threads <<= 1;
-    observe_step_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(a);
+    RLX_LAUNCH((observe_step_kernel), 1, threads, 0, rlx::as_stream(stream), a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -1,6 +1,7 @@
 // Shared host-side plumbing for librlx.so (gfx950 only — no dual backend).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
@@ -24,6 +25,31 @@ inline int grid_for(long long work_items, int block, int cap = kMaxStreamBlocks)
     return (int)g;
 }
 
+
+// In-process kernel timer (rlx_profile_*): while it is armed every launch of this library goes out through
+// hipExtLaunchKernel with a private (start, stop) event pair, which the runtime fills from the dispatch packet's own
+// begin / end timestamps — the duration a kernel trace (rocprofv3 --kernel-trace) reports for that dispatch, taken
+// in situ: same stream, same neighbours, operands as the previous kernel left them.  Eager launches only (an armed
+// timer inside a stream capture is refused by rlx_profile_begin's caller contract: the events are not graph nodes).
+struct Profiler {
+    bool active = false;
+    int n = 0, cap = 0;
+    hipEvent_t *start = nullptr, *stop = nullptr;
+    const char **name = nullptr;
+};
+extern Profiler g_prof;
+
+template <typename F, typename... Args>
+inline void launch(const char *name, F kernel, dim3 grid, dim3 block, unsigned shmem, hipStream_t s,
+                   Args... args) {
+    if (g_prof.active && g_prof.n < g_prof.cap) {
+        const int i = g_prof.n++;
+        g_prof.name[i] = name;
+        hipExtLaunchKernelGGL(kernel, grid, block, shmem, s, g_prof.start[i], g_prof.stop[i], 0, args...);
+    } else {
+        kernel<<<grid, block, shmem, s>>>(args...);
+    }
+}
 }  // namespace rlx
 
 #define RLX_REQUIRE(cond, ...)                      \
@@ -54,3 +80,8 @@ inline int grid_for(long long work_items, int block, int cap = kMaxStreamBlocks)
             return RLX_ERR_HIP;                                                         \
         }                                                                               \
     } while (0)
+
+// Every kernel of the library is launched through this (see rlx::launch): `kernel` in parentheses, so that template
+// argument lists with commas stay one macro argument.
+#define RLX_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    rlx::launch(#kernel, kernel, grid, block, shmem, stream, ##__VA_ARGS__)

@@ -10,6 +10,7 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+Profiler g_prof;
 }  // namespace rlx
 
 extern "C" {
@@ -59,6 +60,52 @@ int rlx_event_elapsed_ms(void *start, void *stop, float *ms_host) {
     RLX_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
     RLX_HIP(hipEventElapsedTime(ms_host, reinterpret_cast<hipEvent_t>(start),
                                 reinterpret_cast<hipEvent_t>(stop)));
+    return RLX_OK;
+}
+
+// ---- in-process kernel timer (rlx_common.hpp: rlx::launch) ------------------------------------------------------
+int rlx_profile_begin(int max_records) {
+    RLX_REQUIRE(max_records > 0 && max_records <= (1 << 20), "rlx_profile_begin: max_records out of range");
+    rlx::Profiler &p = rlx::g_prof;
+    RLX_REQUIRE(!p.active, "rlx_profile_begin: already armed");
+    if (max_records > p.cap) {
+        hipEvent_t *st = new hipEvent_t[max_records], *sp = new hipEvent_t[max_records];
+        const char **nm = new const char *[max_records];
+        for (int i = 0; i < p.cap; ++i) {
+            st[i] = p.start[i];
+            sp[i] = p.stop[i];
+        }
+        for (int i = p.cap; i < max_records; ++i) {
+            RLX_HIP(hipEventCreate(&st[i]));
+            RLX_HIP(hipEventCreate(&sp[i]));
+        }
+        delete[] p.start;
+        delete[] p.stop;
+        delete[] p.name;
+        p.start = st;
+        p.stop = sp;
+        p.name = nm;
+        p.cap = max_records;
+    }
+    p.n = 0;
+    p.active = true;
+    return RLX_OK;
+}
+
+int rlx_profile_end(int *n_records_host) {
+    rlx::Profiler &p = rlx::g_prof;
+    p.active = false;
+    if (n_records_host) *n_records_host = p.n;
+    return RLX_OK;
+}
+
+int rlx_profile_read(int index, const char **name_host, float *ms_host) {
+    rlx::Profiler &p = rlx::g_prof;
+    RLX_REQUIRE(!p.active && index >= 0 && index < p.n && name_host && ms_host,
+                "rlx_profile_read: record %d of %d (timer %s)", index, p.n, p.active ? "still armed" : "stopped");
+    RLX_HIP(hipEventSynchronize(p.stop[index]));
+    RLX_HIP(hipEventElapsedTime(ms_host, p.start[index], p.stop[index]));
+    *name_host = p.name[index];
     return RLX_OK;
 }
 

@@ -464,7 +464,7 @@ int rlx_per_init(double *sum_tree, double *min_tree, double *max_tree, int capac
                 "A segment tree size must be a positive power of 2. The given size is %d", capacity);
     long long n_nodes = 2LL * capacity - 1;
     hipStream_t s = rlx::as_stream(stream);
-    per_init_kernel<<<rlx::grid_for(n_nodes, kBlock), kBlock, 0, s>>>(sum_tree, min_tree,
+    RLX_LAUNCH((per_init_kernel), rlx::grid_for(n_nodes, kBlock), kBlock, 0, s, sum_tree, min_tree,
                                                                       max_tree, n_nodes);
     RLX_LAUNCH_CHECK();
     const double one = 1.0;   // self.maximal_priority = 1.0 (:186)
@@ -490,14 +490,12 @@ static int launch_update(double *sum_tree, double *min_tree, double *max_tree, i
                             (long long)start_leaf + n <= capacity && capacity <= (1 << 30);
         auto kernel = n <= 64 ? (contig ? per_update_paths_kernel<true, true> : per_update_paths_kernel<true, false>)
                               : (contig ? per_update_paths_kernel<false, true> : per_update_paths_kernel<false, false>);
-        kernel<<<1, n <= 64 ? 64 : kPathMaxLeaves, 0, rlx::as_stream(stream)>>>(
-            sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n, start_leaf, alpha, eps,
+        RLX_LAUNCH((kernel), 1, n <= 64 ? 64 : kPathMaxLeaves, 0, rlx::as_stream(stream), sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n, start_leaf, alpha, eps,
             max_priority, mode, status);
         RLX_LAUNCH_CHECK();
         return RLX_OK;
     }
-    per_update_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
-        sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
+    RLX_LAUNCH((per_update_kernel), 1, threads, 0, rlx::as_stream(stream), sum_tree, min_tree, max_tree, capacity, ilog2(capacity), idx, err, leaf_pa, leaf_p, n,
         start_leaf, alpha, eps, max_priority, mode, status);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -552,7 +550,7 @@ int rlx_libm_pow(const double *x, const double *y, double *out, int n, int *stat
                  void *stream) {
     RLX_REQUIRE(x && y && out && status && n >= 0, "rlx_libm_pow: null pointer");
     if (n == 0) return RLX_OK;
-    libm_pow_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(x, y, out, n,
+    RLX_LAUNCH((libm_pow_kernel), (n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), x, y, out, n,
                                                                                      status);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -570,8 +568,7 @@ int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,
                 "rlx_per_sample: the payload ring (%lld rows) is smaller than the tree (%d leaves)",
                 payload_rows, capacity);
     int threads = 64;
-    per_sample_kernel<<<(batch + threads - 1) / threads, threads, 0, rlx::as_stream(stream)>>>(
-        sum_tree, min_tree, capacity, uniforms, batch, num_transitions, beta, out_idx, out_weight,
+    RLX_LAUNCH((per_sample_kernel), (batch + threads - 1) / threads, threads, 0, rlx::as_stream(stream), sum_tree, min_tree, capacity, uniforms, batch, num_transitions, beta, out_idx, out_weight,
         out_priority, stored_total, payload_rows, out_rows);
     RLX_LAUNCH_CHECK();
     return RLX_OK;

@@ -141,7 +141,7 @@ int rlx_synth_env_reset(int kind, void *obs, int *episode, int *step, int n_env,
                 obs_elems);
     const int work = kind == 0 ? obs_elems / 16 : obs_elems;
     dim3 grid(rlx::grid_for(work, 64, 16), n_env);
-    env_reset_kernel<<<grid, 64, 0, rlx::as_stream(stream)>>>(kind, obs, episode, step, n_env,
+    RLX_LAUNCH((env_reset_kernel), grid, 64, 0, rlx::as_stream(stream), kind, obs, episode, step, n_env,
                                                              obs_elems, seed, env_id0);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -179,11 +179,11 @@ static int synth_step(int kind, void *next_obs, void *reset_obs, float *reward, 
     const int work = kind == 0 ? obs_elems / 16 : obs_elems;
     dim3 grid(rlx::grid_for(work, 64, 16), n_env);
     const int fused = grid.x == 1;
-    env_step_kernel<<<grid, 64, 0, s>>>(kind, next_obs, reset_obs, reward, game_over, episode, step,
+    RLX_LAUNCH((env_step_kernel), grid, 64, 0, s, kind, next_obs, reset_obs, reward, game_over, episode, step,
                                         n_env, obs_elems, episode_len, len_per_env, seed, env_id0, fused);
     RLX_LAUNCH_CHECK();
     if (!fused) {
-        env_advance_kernel<<<(n_env + 63) / 64, 64, 0, s>>>(episode, step, game_over, n_env);
+        RLX_LAUNCH((env_advance_kernel), (n_env + 63) / 64, 64, 0, s, episode, step, game_over, n_env);
         RLX_LAUNCH_CHECK();
     }
     return RLX_OK;

@@ -222,8 +222,7 @@ int rlx_dqn_targets(const float *q_next_target, const float *q_next_selector, fl
     RLX_REQUIRE(batch > 0 && n_actions > 0, "rlx_dqn_targets: bad sizes (batch=%d actions=%d)",
                 batch, n_actions);
     if (!q_next_selector) q_next_selector = q_next_target;
-    dqn_targets_kernel<<<(batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        q_next_target, q_next_selector, td_targets, actions, rewards, game_overs, discount, batch,
+    RLX_LAUNCH((dqn_targets_kernel), (batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), q_next_target, q_next_selector, td_targets, actions, rewards, game_overs, discount, batch,
         n_actions, td_errors, status);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -244,8 +243,7 @@ int rlx_dqn_head_loss(const float *q_online, long long ld_q, const float *q_next
     if (!q_next_selector) q_next_selector = q_next_target;
     int threads = 64;
     while (threads < batch) threads <<= 1;
-    dqn_head_loss_kernel<<<1, threads, 0, rlx::as_stream(stream)>>>(
-        q_online, ld_q, q_next_target, q_next_selector, ld_next, actions, rewards, game_overs,
+    RLX_LAUNCH((dqn_head_loss_kernel), 1, threads, 0, rlx::as_stream(stream), q_online, ld_q, q_next_target, q_next_selector, ld_next, actions, rewards, game_overs,
         importance_weights, discount, batch, n_actions, huber, grad_scale, dq, ld_dq, td_errors,
         td_targets, ld_targets, loss_scalar, status);
     RLX_LAUNCH_CHECK();
@@ -256,7 +254,7 @@ int rlx_dueling_combine(const float *state_value, const float *action_advantage,
                         int n_actions, float *q, void *stream) {
     RLX_REQUIRE(state_value && action_advantage && q, "rlx_dueling_combine: null pointer");
     RLX_REQUIRE(batch > 0 && n_actions > 0, "rlx_dueling_combine: bad sizes (batch=%d actions=%d)", batch, n_actions);
-    dueling_combine_kernel<<<(batch + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(state_value, action_advantage,
+    RLX_LAUNCH((dueling_combine_kernel), (batch + 63) / 64, 64, 0, rlx::as_stream(stream), state_value, action_advantage,
                                                                                   batch, n_actions, q);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -267,7 +265,7 @@ int rlx_dueling_combine_backward(const float *dq, int batch, int n_actions, floa
     RLX_REQUIRE(dq && dstate_value && daction_advantage, "rlx_dueling_combine_backward: null pointer");
     RLX_REQUIRE(batch > 0 && n_actions > 0, "rlx_dueling_combine_backward: bad sizes (batch=%d actions=%d)", batch,
                 n_actions);
-    dueling_combine_bwd_kernel<<<(batch + 63) / 64, 64, 0, rlx::as_stream(stream)>>>(dq, batch, n_actions,
+    RLX_LAUNCH((dueling_combine_bwd_kernel), (batch + 63) / 64, 64, 0, rlx::as_stream(stream), dq, batch, n_actions,
                                                                                       dstate_value, daction_advantage);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -279,8 +277,7 @@ int rlx_ac_td_targets(const float *rewards, const unsigned char *game_overs, con
                       float *td_targets, void *stream) {
     RLX_REQUIRE(rewards && game_overs && q_next && td_targets, "rlx_ac_td_targets: null pointer");
     RLX_REQUIRE(batch > 0 && q_stride > 0, "rlx_ac_td_targets: bad sizes");
-    ac_targets_kernel<<<(batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        rewards, game_overs, q_next, q_stride, discount, use_non_zero_discount_for_terminal_states,
+    RLX_LAUNCH((ac_targets_kernel), (batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), rewards, game_overs, q_next, q_stride, discount, use_non_zero_discount_for_terminal_states,
         has_clip, clip_low, clip_high, batch, td_targets);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -293,8 +290,7 @@ int rlx_td3_smooth_actions(const float *next_actions, const double *noise, doubl
                 "rlx_td3_smooth_actions: null pointer");
     RLX_REQUIRE(batch > 0 && action_dim > 0, "rlx_td3_smooth_actions: bad sizes");
     int n = batch * action_dim;
-    td3_smooth_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        next_actions, noise, noise_clipping, action_low, action_high, batch, action_dim, out);
+    RLX_LAUNCH((td3_smooth_kernel), (n + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), next_actions, noise, noise_clipping, action_low, action_high, batch, action_dim, out);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -307,8 +303,7 @@ int rlx_ac_merge_inputs(const float *actions, const float *obs, const float *nex
     RLX_REQUIRE(!noise || (action_low && action_high), "rlx_ac_merge_inputs: smoothing needs the action bounds");
     RLX_REQUIRE(batch > 0 && action_dim > 0 && obs_dim > 0, "rlx_ac_merge_inputs: bad sizes");
     const long long total = 3LL * batch * (action_dim + obs_dim);
-    ac_merge_inputs_kernel<<<rlx::grid_for(total, kBlock), kBlock, 0, rlx::as_stream(stream)>>>(
-        actions, obs, next_actions, noise, noise_clipping, action_low, action_high, next_obs, batch, action_dim,
+    RLX_LAUNCH((ac_merge_inputs_kernel), rlx::grid_for(total, kBlock), kBlock, 0, rlx::as_stream(stream), actions, obs, next_actions, noise, noise_clipping, action_low, action_high, next_obs, batch, action_dim,
         obs_dim, merged2, merged_obs_only);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -318,8 +313,7 @@ int rlx_sac_value_targets(const float *q_min, const float *sampled_logprob, int 
                           float *value_targets, void *stream) {
     RLX_REQUIRE(q_min && sampled_logprob && value_targets, "rlx_sac_value_targets: null pointer");
     RLX_REQUIRE(batch > 0, "rlx_sac_value_targets: bad batch");
-    sac_value_targets_kernel<<<(batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream)>>>(
-        q_min, sampled_logprob, batch, value_targets);
+    RLX_LAUNCH((sac_value_targets_kernel), (batch + kBlock - 1) / kBlock, kBlock, 0, rlx::as_stream(stream), q_min, sampled_logprob, batch, value_targets);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

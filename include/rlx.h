@@ -45,6 +45,16 @@ int rlx_event_destroy(void *event);
 int rlx_event_record(void *event, void *stream);
 int rlx_event_elapsed_ms(void *start, void *stop, float *ms_host); /* syncs on stop */
 
+/* In-process kernel timer: between rlx_profile_begin and rlx_profile_end every kernel this library launches (EAGER
+ * launches on any stream; do not arm it inside a stream capture) carries its own start / stop event pair filled from
+ * the dispatch's begin / end timestamps — the per-dispatch duration a kernel trace reports (the reference has no
+ * counterpart: its TF timeline is the closest thing, architectures/tensorflow_components/architecture.py has none on
+ * this path).  rlx_profile_read(i) returns the kernel's name (a static string: the template instance as written at
+ * the launch site) and its duration in ms, in launch order; it waits for that kernel.  max_records bounds the trace. */
+int rlx_profile_begin(int max_records);
+int rlx_profile_end(int *n_records_host);
+int rlx_profile_read(int index, const char **name_host, float *ms_host);
+
 /* --------------------------------------------- prioritized replay (K5 / K6) -- */
 /* Trees are fp64 array-heaps of 2*capacity-1 nodes exactly as the reference's
  * SegmentTree (memories/non_episodic/prioritized_experience_replay.py:43-156);
