@@ -19,6 +19,15 @@ LOSS_RTOL, LOSS_ATOL = 1e-3, 2e-5
 W_RTOL, W_ATOL = 1e-3, 2e-5
 
 
+def _err(name, a, b):
+    """worst absolute / relative deviation, printed (pytest -s) so that the stated tolerances can be audited."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    d = np.abs(a - b)
+    rel = d / np.maximum(np.abs(b), 1e-12)
+    print("  %-34s max abs %.3e   max rel (|ref| > 1e-3) %.3e" % (name, d.max(), rel[np.abs(b) > 1e-3].max()
+                                                                 if (np.abs(b) > 1e-3).any() else 0.0))
+
+
 def test_c2_rollout_advantages_and_first_updates_match_the_oracle(rlx, dev):
     import torch
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
@@ -91,6 +100,15 @@ def test_c2_rollout_advantages_and_first_updates_match_the_oracle(rlx, dev):
     ep = o.train(max_minibatches=MINIBATCHES)
     assert random.getstate() == dev_random                        # the same two shuffles
 
+    _err("V(s), 2048 states", agent.ds_value[:n].cpu().numpy(), o.dbg["values"])
+    _err("standardised advantages", agent.ds_adv[:n].cpu().numpy(), o.dbg["adv"])
+    _err("value targets", agent.ds_vtarget[:n].cpu().numpy(), o.dbg["vt"])
+    for i in range(MINIBATCHES):
+        _err("losses, minibatch %d" % i, dev_losses[i], np.array(ep[i]))
+        _err("gradient norm, minibatch %d" % i, dev_norms[i], norms[i])
+        worst = max((float(np.max(np.abs(dev_weights[i][name][tw] - ref))), name) for name, pt in snaps[i].items()
+                    for tw, ref in pt.items())
+        print("  weights after minibatch %d: worst abs deviation %.3e (%s)" % (i, worst[0], worst[1]))
     # fill_advantages over the whole rollout (dataset order: env-major)
     np.testing.assert_allclose(agent.ds_value[:n].cpu().numpy(), o.dbg["values"], rtol=OUT_RTOL, atol=OUT_ATOL)
     np.testing.assert_array_equal(agent.ds_reward[:n].cpu().numpy().astype(np.float64), o.dbg["rewards"])
