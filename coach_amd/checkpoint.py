@@ -28,7 +28,8 @@ _MEMORY_SCALARS = ["cursor", "count", "pending", "committed_total", "steps", "_o
                    "_steps_written", "_gstep", "_ep_start", "_episodes", "_episode_first_step", "_order", "_order_head", "_order_len"]
 _AGENT_SCALARS = ["total_steps_counter", "training_iteration", "last_training_phase_step",
                   "last_target_network_update_step", "current_episode_steps_counter", "last_episode_steps",
-                  "_episode_just_ended", "_episode_steps", "_unconsumed_episode_lengths"]
+                  "_episode_just_ended", "_episode_steps", "_unconsumed_episode_lengths",
+                  "_draw_pool", "_draw_pos", "_draw_table_from"]      # PPO: host draws made for steps that have not run yet
 
 
 def agent_state(agent):

@@ -5,6 +5,8 @@ import random
 import numpy as np
 import pytest
 
+from tolerances import LOSS, WEIGHTS
+
 
 def _make(dev, n_env, L, playing, batch, epochs, seed=0, lengths=None, kind="image"):
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
@@ -55,11 +57,11 @@ def test_ppo_iteration_matches_oracle(rlx, dev):
         assert random.getstate() == hip_state[0]               # identical host RNG consumption
         state = hip_state
         hres = np.array([r.cpu().numpy()[:5] for r in res], dtype=np.float64)
-        np.testing.assert_allclose(hres, np.array(ores), rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(hres, np.array(ores), **LOSS)
         hw = agent.networks["main"].params.named_arrays()
         for name, per_tower in o.net.weights().items():
             for t, ref in per_tower.items():
-                np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
+                np.testing.assert_allclose(hw[name][t], ref, err_msg=name, **WEIGHTS)
     st = agent.episode_statistics()
     assert st["episodes"] == 2 * n_env and st["mean_length"] == L
 
@@ -105,11 +107,11 @@ def test_ppo_with_envs_ending_on_different_steps_matches_oracle(rlx, dev, kind, 
         assert np.array_equal(np.random.get_state()[1], hip_state[1][1])     # per-step draws: same np.random stream
         state = hip_state
         hres = np.array([r.cpu().numpy()[:5] for r in res], dtype=np.float64)
-        np.testing.assert_allclose(hres, np.array(ores), rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(hres, np.array(ores), **LOSS)
         hw = agent.networks["main"].params.named_arrays()
         for name, per_tower in o.net.weights().items():
             for t, ref in per_tower.items():
-                np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
+                np.testing.assert_allclose(hw[name][t], ref, err_msg=name, **WEIGHTS)
 
 
 @pytest.mark.gpu
@@ -264,11 +266,11 @@ def test_continuous_ppo_iteration_matches_oracle(rlx, dev, normalize):
         assert random.getstate() == hip_state[0]
         state = hip_state
         hres = np.array([r.cpu().numpy()[:5] for r in res], dtype=np.float64)
-        np.testing.assert_allclose(hres, np.array(ores), rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(hres, np.array(ores), **LOSS)
         hw = agent.networks["main"].params.named_arrays()
         for name, per_tower in o.net.weights().items():
             for t, ref in per_tower.items():
-                np.testing.assert_allclose(hw[name][t], ref, rtol=2e-3, atol=5e-5, err_msg=name)
+                np.testing.assert_allclose(hw[name][t], ref, err_msg=name, **WEIGHTS)
         if normalize:                            # states + next states of the phase's transitions, fp64 on both sides
             assert abs(float(agent.norm.count.item()) - o.stats._count) < 1e-9
             assert abs(o.stats._count - ((it + 1) * 2 * playing + 1e-2)) < 1e-9

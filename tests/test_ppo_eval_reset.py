@@ -14,10 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-# stated tolerances of the device update against the numpy oracle: per-epoch mean losses and the
-# weights after a few Adam steps; the full-size run (tools/loss_curve_c2.py) measures 3e-4 on the losses
-LOSS_RTOL, LOSS_ATOL = 1e-3, 2e-5
-W_RTOL, W_ATOL = 1e-3, 2e-5
+from tolerances import LOSS, WEIGHTS
 
 
 def _make(dev, kind, n_env, L, playing, batch, epochs, seed=0):
@@ -114,10 +111,10 @@ def test_periods_that_end_mid_episode_and_evaluations_match_the_oracle(rlx, dev,
                 last_train = total
                 ores = np.array(o.train())
                 o_train_at.append(t)
-                np.testing.assert_allclose(dev_losses[k], ores, rtol=LOSS_RTOL, atol=LOSS_ATOL)
+                np.testing.assert_allclose(dev_losses[k], ores, **LOSS)
                 for name, per_tower in o.net.weights().items():
                     for tw, ref in per_tower.items():
-                        np.testing.assert_allclose(dev_weights[k][name][tw], ref, rtol=W_RTOL, atol=W_ATOL, err_msg=name)
+                        np.testing.assert_allclose(dev_weights[k][name][tw], ref, err_msg=name, **WEIGHTS)
                 k += 1
             t += 1
         ev = o.evaluate(1)

@@ -12,11 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 N_ENV, L, PLAYING, BATCH, N_ACTIONS, MINIBATCHES = 64, 32, 2048, 64, 6, 3
-# fp32 network outputs rtol 2e-5 (accumulation order), minibatch losses rtol 1e-3 / atol 2e-5,
-# weights after Adam steps rtol 1e-3 / atol 2e-5
-OUT_RTOL, OUT_ATOL = 2e-5, 2e-6
-LOSS_RTOL, LOSS_ATOL = 1e-3, 2e-5
-W_RTOL, W_ATOL = 1e-3, 2e-5
+from tolerances import ADVANTAGE, LOSS, OUT, WEIGHTS
 
 
 def _err(name, a, b):
@@ -110,18 +106,15 @@ def test_c2_rollout_advantages_and_first_updates_match_the_oracle(rlx, dev):
                     for tw, ref in pt.items())
         print("  weights after minibatch %d: worst abs deviation %.3e (%s)" % (i, worst[0], worst[1]))
     # fill_advantages over the whole rollout (dataset order: env-major)
-    np.testing.assert_allclose(agent.ds_value[:n].cpu().numpy(), o.dbg["values"], rtol=OUT_RTOL, atol=OUT_ATOL)
+    np.testing.assert_allclose(agent.ds_value[:n].cpu().numpy(), o.dbg["values"], **OUT)
     np.testing.assert_array_equal(agent.ds_reward[:n].cpu().numpy().astype(np.float64), o.dbg["rewards"])
     np.testing.assert_array_equal(agent.ds_done[:n].cpu().numpy().astype(bool), o.dbg["dones"])
     np.testing.assert_array_equal(agent.ds_action[:n].cpu().numpy(), o.dbg["actions"])
-    # the standardised advantages divide by a std of O(0.1): the fp32 value error is amplified accordingly
-    np.testing.assert_allclose(agent.ds_adv[:n].cpu().numpy(), o.dbg["adv"], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(agent.ds_vtarget[:n].cpu().numpy(), o.dbg["vt"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(agent.ds_adv[:n].cpu().numpy(), o.dbg["adv"], **ADVANTAGE)
+    np.testing.assert_allclose(agent.ds_vtarget[:n].cpu().numpy(), o.dbg["vt"], **OUT)
     for i in range(MINIBATCHES):
-        np.testing.assert_allclose(dev_losses[i], np.array(ep[i]), rtol=LOSS_RTOL, atol=LOSS_ATOL,
-                                   err_msg="losses of minibatch %d" % i)
-        np.testing.assert_allclose(dev_norms[i], norms[i], rtol=LOSS_RTOL, err_msg="gradient norm of minibatch %d" % i)
+        np.testing.assert_allclose(dev_losses[i], np.array(ep[i]), err_msg="losses of minibatch %d" % i, **LOSS)
+        np.testing.assert_allclose(dev_norms[i], norms[i], rtol=LOSS["rtol"], err_msg="gradient norm of minibatch %d" % i)
         for name, per_tower in snaps[i].items():
             for tw, ref in per_tower.items():
-                np.testing.assert_allclose(dev_weights[i][name][tw], ref, rtol=W_RTOL, atol=W_ATOL,
-                                           err_msg="%s after minibatch %d" % (name, i))
+                np.testing.assert_allclose(dev_weights[i][name][tw], ref, err_msg="%s after minibatch %d" % (name, i), **WEIGHTS)

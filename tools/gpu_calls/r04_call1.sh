@@ -6,6 +6,9 @@ O=gpurun_out/r04_call1
 mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
+# canary: some boxes of the pool fault on every kernel of known-good code (torch's own included) — stop at once on those
+timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); print('canary', float((x * 2).sum().item()))" > $O/canary.txt 2>&1
+grep -q "canary 2097152.0" $O/canary.txt || { echo "BAD BOX: torch itself faults"; tail -3 $O/canary.txt; exit 7; }
 timeout 900 python -m pytest tests/test_ppo_eval_reset.py tests/test_ppo_full_size.py -m gpu -q -s --tb=short 2>&1 | tail -60 > $O/new_tests.txt
 tail -30 $O/new_tests.txt
 timeout 1500 python -m pytest tests -m gpu -q --tb=short --durations=5 -x 2>&1 | tail -25 > $O/pytest.txt
