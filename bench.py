@@ -653,6 +653,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json config (default c2 = the headline metric's configuration)")
     ap.add_argument("--no-prefill", action="store_true", help="c3: skip the 2^20-transition pre-fill")
+    ap.add_argument("--gemm-pipeline", type=int, default=None, choices=[0, 1],
+                    help="A/B: main loop of the fast tiled GEMM kernels (rlx_gemm_pipeline): 1 = LDS-DMA ring (the "
+                         "library's default), 0 = register-staged")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only (no GPU, gloo): what the CPU "
                          "test of the N-rank entry point runs")
@@ -677,6 +680,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = GradientSync(force=args.force_dist)
+    if args.gemm_pipeline is not None:
+        from coach_amd import _rlx
+        _rlx.lib().gemm_pipeline(args.gemm_pipeline)
     if dist.world_size != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, dist.world_size))
     if args.workload != "c2":

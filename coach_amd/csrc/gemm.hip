@@ -332,6 +332,165 @@ struct FastTile {
     static constexpr int kSmemFloats = 2 * A_BUF + 2 * B_BUF;
 };
 
+// Everything after the main loop of a fast-kernel workgroup: the in-workgroup K-split sum (KW > 1), the bias-gradient
+// column sums, and the bias / activation / derivative / accumulate (or split-K partial) stores of the accumulator tiles.
+// Shared by the register-staged main loop (gemm_fast_body) and the LDS-DMA ring main loop (gemm_dma_body): the C/D layout
+// of the accumulators does not depend on how the operands reached the MFMAs.  `smem` must no longer be read by anyone
+// (KW == 1 callers pass through the __syncthreads() of the staging patches below).
+template <int BM, int BN, int TM, int TN, int KW, bool A_WIN>
+__device__ __forceinline__ void fast_epilogue(const GemmDev &g, f32x16 (&acc)[TM][TN], float *const smem, const int m0,
+                                              const int n0, const int batch, const int split, const bool do_colsum,
+                                              const float csum, unsigned long long *const stamp) {
+    constexpr int WN = BN / (32 * TN);
+    constexpr int WMN = (BM / (32 * TM)) * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wk = wid / WMN, wmn = wid - wk * WMN;
+    const int wm = wmn / WN, wn = wmn % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    if (stamp) stamp[2] = wall_clock64();
+    const bool epi = wk == 0;                 // the waves that hold the complete tile
+    if (KW > 1) {
+        // partial tiles of wave groups 1 .. KW-1 -> LDS (a wave-private 32 x 33 patch each, C/D layout of the MFMA
+        // undone), added by the wave group 0 that owns the same tile, in ascending wk
+        __syncthreads();                      // every wave is done reading the operand buffers
+        float *patch = smem + wid * (32 * 33);
+        if (wk > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int q = 1; q < KW; ++q) {
+                const float *src = smem + (q * WMN + wmn) * (32 * 33);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += src[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
+            }
+        }
+    }
+    if (do_colsum && n0 + tid < g.N) {
+        const int n = n0 + tid;
+        if (g.splits > 1)
+            g.ws_colsum[((size_t)batch * g.splits + split) * g.N + n] = csum;
+        else if (g.fold)
+            g.colsum[(size_t)(n / g.fold) * g.colsum_batch_stride + n % g.fold] = csum;
+        else
+            g.colsum[(size_t)batch * g.colsum_batch_stride + n] = csum;
+    }
+
+    float *c = g.c + (size_t)batch * g.c_batch_stride;
+    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
+    float *ws = g.splits > 1 ? g.ws + ((size_t)batch * g.splits + split) * (size_t)g.M * g.N : nullptr;
+    if (g.vec_epi) {
+        // 16-byte epilogue: every accumulator tile goes through a wave-private 32x33 LDS patch so
+        // that a lane owns 4 consecutive columns of a row (float4 loads of the derivative operand,
+        // float4 stores; a wave instruction covers 8 rows x 128 B) instead of 16 scalar accesses.
+        float *stage = smem + wid * (32 * 33);
+        float *dst_base = ws ? ws : c;
+        const long long ld = ws ? (long long)g.N : g.ldc;
+        int crow[4] = {0, 0, 0, 0};      // A_WIN: where the lane's four rows of the tile live in C (and in aux), or -1
+        if (A_WIN) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int erow = m0 + wm * 32 + ((it * 64 + lane) >> 3);
+                crow[it] = epi && erow < g.M ? g.win_c_row[erow] : -1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // the tile's bias (one float4 per lane: the column group does not depend on `it`) and its four
+                // activation-derivative float4s are requested BEFORE the staging barriers: one round trip that the
+                // staging covers, instead of one per `it` exposed between an LDS read and a store the compiler may not
+                // move a load across
+                const int ecol = n0 + wn * (32 * TN) + 32 * j + (lane & 7) * 4;
+                const bool ecol_ok = epi && ecol < g.N;
+                const int etw = (!ws && g.fold) ? ecol / g.fold : 0, ecl = (!ws && g.fold) ? ecol % g.fold : ecol;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 av4[4];
+                if (!ws && g.bias && ecol_ok)
+                    bv = *reinterpret_cast<const float4 *>(
+                        g.fold ? g.bias + (size_t)etw * g.bias_batch_stride + ecl :
+                        g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + ecol);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int erow = m0 + wm * (32 * TM) + 32 * i + ((it * 64 + lane) >> 3);
+                    av4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (A_WIN) {
+                        if (aux && ecol_ok && crow[it] >= 0)
+                            av4[it] = *reinterpret_cast<const float4 *>(aux + crow[it] + ecol);
+                    } else if (!ws && aux && ecol_ok && erow < g.M)
+                        av4[it] = *reinterpret_cast<const float4 *>(aux + (size_t)erow * g.aux_ld + ecol);
+                }
+                __syncthreads();
+                if (epi) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[i][j][r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int rl = idx >> 3, c4 = (idx & 7) * 4;
+                    const int row = m0 + wm * (32 * TM) + 32 * i + rl;
+                    const int col = n0 + wn * (32 * TN) + 32 * j + c4;
+                    if (!epi || row >= g.M || col >= g.N) continue;
+                    if (A_WIN && crow[it] < 0) continue;
+                    const float *sp = stage + rl * 33 + c4;
+                    float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                    float *dst = A_WIN ? c + crow[it] + col : dst_base + (size_t)row * ld + col;
+                    const int tw = etw, cl = ecl;
+                    if (!ws && g.fold) dst = g.c + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
+                    if (!ws) {
+                        if (g.bias) {
+                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        }
+                        v.x = apply_act(v.x, g.act); v.y = apply_act(v.y, g.act);
+                        v.z = apply_act(v.z, g.act); v.w = apply_act(v.w, g.act);
+                        if (aux) {
+                            const float4 av = av4[it];
+                            v.x *= act_deriv(av.x, g.deriv); v.y *= act_deriv(av.y, g.deriv);
+                            v.z *= act_deriv(av.z, g.deriv); v.w *= act_deriv(av.w, g.deriv);
+                        }
+                        if (g.accumulate) {
+                            const float4 ov = *reinterpret_cast<const float4 *>(dst);
+                            v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+                        }
+                    }
+                    *reinterpret_cast<float4 *>(dst) = v;
+                }
+            }
+        }
+        if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (32 * TN) + 32 * j + l31;
+        if (!epi || col >= g.N) continue;
+        const float bias = (!ws && g.bias) ? g.bias[batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= g.M) continue;
+                if (ws) {
+                    ws[(size_t)row * g.N + col] = acc[i][j][r];
+                } else {
+                    float v = apply_act(acc[i][j][r] + bias, g.act);
+                    if (aux) v *= act_deriv(aux[(size_t)row * g.aux_ld + col], g.deriv);
+                    float *dst = &c[(size_t)row * g.ldc + col];
+                    *dst = g.accumulate ? *dst + v : v;
+                }
+            }
+        }
+    }
+    if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
+}
+
 // KW > 1: the 4 waves also split every K slab — wave group wk multiplies rows [wk*BK/KW, (wk+1)*BK/KW) of the staged
 // slab for the same output tile, and the KW partial tiles are summed through LDS in the fixed order wk = 0, 1, ...
 // before the epilogue.  A 32 x 64 (KW = 2) or 32 x 32 (KW = 4) tile gives a mid-sized problem 2-4x the workgroups of
@@ -614,148 +773,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDev &g, const int bx, c
         }
     }
 
-    if (stamp) stamp[2] = wall_clock64();
-    const bool epi = wk == 0;                 // the waves that hold the complete tile
-    if (KW > 1) {
-        // partial tiles of wave groups 1 .. KW-1 -> LDS (a wave-private 32 x 33 patch each, C/D layout of the MFMA
-        // undone), added by the wave group 0 that owns the same tile, in ascending wk
-        __syncthreads();                      // every wave is done reading the operand buffers
-        float *patch = smem + wid * (32 * 33);
-        if (wk > 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[0][0][r];
-        }
-        __syncthreads();
-        if (wk == 0) {
-#pragma unroll
-            for (int q = 1; q < KW; ++q) {
-                const float *src = smem + (q * WMN + wmn) * (32 * 33);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][0][r] += src[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
-            }
-        }
-    }
-    if (do_colsum && n0 + tid < g.N) {
-        const int n = n0 + tid;
-        if (g.splits > 1)
-            g.ws_colsum[((size_t)batch * g.splits + split) * g.N + n] = csum;
-        else if (g.fold)
-            g.colsum[(size_t)(n / g.fold) * g.colsum_batch_stride + n % g.fold] = csum;
-        else
-            g.colsum[(size_t)batch * g.colsum_batch_stride + n] = csum;
-    }
-
-    float *c = g.c + (size_t)batch * g.c_batch_stride;
-    const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride : nullptr;
-    float *ws = g.splits > 1 ? g.ws + ((size_t)batch * g.splits + split) * (size_t)g.M * g.N : nullptr;
-    if (g.vec_epi) {
-        // 16-byte epilogue: every accumulator tile goes through a wave-private 32x33 LDS patch so
-        // that a lane owns 4 consecutive columns of a row (float4 loads of the derivative operand,
-        // float4 stores; a wave instruction covers 8 rows x 128 B) instead of 16 scalar accesses.
-        float *stage = smem + wid * (32 * 33);
-        float *dst_base = ws ? ws : c;
-        const long long ld = ws ? (long long)g.N : g.ldc;
-        int crow[4] = {0, 0, 0, 0};      // A_WIN: where the lane's four rows of the tile live in C (and in aux), or -1
-        if (A_WIN) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int erow = m0 + wm * 32 + ((it * 64 + lane) >> 3);
-                crow[it] = epi && erow < g.M ? g.win_c_row[erow] : -1;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                // the tile's bias (one float4 per lane: the column group does not depend on `it`) and its four
-                // activation-derivative float4s are requested BEFORE the staging barriers: one round trip that the
-                // staging covers, instead of one per `it` exposed between an LDS read and a store the compiler may not
-                // move a load across
-                const int ecol = n0 + wn * (32 * TN) + 32 * j + (lane & 7) * 4;
-                const bool ecol_ok = epi && ecol < g.N;
-                const int etw = (!ws && g.fold) ? ecol / g.fold : 0, ecl = (!ws && g.fold) ? ecol % g.fold : ecol;
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 av4[4];
-                if (!ws && g.bias && ecol_ok)
-                    bv = *reinterpret_cast<const float4 *>(
-                        g.fold ? g.bias + (size_t)etw * g.bias_batch_stride + ecl :
-                        g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + ecol);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int erow = m0 + wm * (32 * TM) + 32 * i + ((it * 64 + lane) >> 3);
-                    av4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (A_WIN) {
-                        if (aux && ecol_ok && crow[it] >= 0)
-                            av4[it] = *reinterpret_cast<const float4 *>(aux + crow[it] + ecol);
-                    } else if (!ws && aux && ecol_ok && erow < g.M)
-                        av4[it] = *reinterpret_cast<const float4 *>(aux + (size_t)erow * g.aux_ld + ecol);
-                }
-                __syncthreads();
-                if (epi) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        stage[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[i][j][r];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int idx = it * 64 + lane;
-                    const int rl = idx >> 3, c4 = (idx & 7) * 4;
-                    const int row = m0 + wm * (32 * TM) + 32 * i + rl;
-                    const int col = n0 + wn * (32 * TN) + 32 * j + c4;
-                    if (!epi || row >= g.M || col >= g.N) continue;
-                    if (A_WIN && crow[it] < 0) continue;
-                    const float *sp = stage + rl * 33 + c4;
-                    float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
-                    float *dst = A_WIN ? c + crow[it] + col : dst_base + (size_t)row * ld + col;
-                    const int tw = etw, cl = ecl;
-                    if (!ws && g.fold) dst = g.c + (size_t)tw * g.c_batch_stride + (size_t)row * g.ldc + cl;
-                    if (!ws) {
-                        if (g.bias) {
-                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        }
-                        v.x = apply_act(v.x, g.act); v.y = apply_act(v.y, g.act);
-                        v.z = apply_act(v.z, g.act); v.w = apply_act(v.w, g.act);
-                        if (aux) {
-                            const float4 av = av4[it];
-                            v.x *= act_deriv(av.x, g.deriv); v.y *= act_deriv(av.y, g.deriv);
-                            v.z *= act_deriv(av.z, g.deriv); v.w *= act_deriv(av.w, g.deriv);
-                        }
-                        if (g.accumulate) {
-                            const float4 ov = *reinterpret_cast<const float4 *>(dst);
-                            v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
-                        }
-                    }
-                    *reinterpret_cast<float4 *>(dst) = v;
-                }
-            }
-        }
-        if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (32 * TN) + 32 * j + l31;
-        if (!epi || col >= g.N) continue;
-        const float bias = (!ws && g.bias) ? g.bias[batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row >= g.M) continue;
-                if (ws) {
-                    ws[(size_t)row * g.N + col] = acc[i][j][r];
-                } else {
-                    float v = apply_act(acc[i][j][r] + bias, g.act);
-                    if (aux) v *= act_deriv(aux[(size_t)row * g.aux_ld + col], g.deriv);
-                    float *dst = &c[(size_t)row * g.ldc + col];
-                    *dst = g.accumulate ? *dst + v : v;
-                }
-            }
-        }
-    }
-    if (stamp) { __syncthreads(); stamp[3] = wall_clock64(); }
+    fast_epilogue<BM, BN, TM, TN, KW, A_WIN>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp);
 }
 
 // Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, Workgroup dispatch) and every XCD has its own L2:
@@ -846,6 +864,267 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
         gemm_fast_body<32, 32, 1, 1, 4, true, false, true, false>(p.g[1], bx, by, bz, gx, gy, smem, lut, tab_s);
     else
         gemm_fast_body<64, 64, 1, 1, 1, true, false, true, false>(p.g[1], bx, by, bz, gx, gy, smem, lut, tab_s);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA ring main loop (round 4).  What the in-update kernel timer showed for the register-staged loop above: on the C2
+// shapes a workgroup spends 1.2-1.5 us per 32-deep K slab against 0.2-0.4 us of MFMA issue — one or two workgroups per
+// CU, each wave alone on its SIMD, operands cold (written by the previous kernel, possibly on another XCD), and only two
+// slabs of loads in flight because every slab in flight costs a register set.  Here the operand slabs go from global
+// memory STRAIGHT into a ring of kDmaDepth LDS buffers (global_load_lds_dwordx4: no staging registers, no ds_write
+// pass), kDmaDepth - 1 slabs are in flight at any time, and a slab step is  wait(counted vmcnt) -> ONE barrier ->
+// request slab s + D - 1 -> LDS operand reads + MFMAs of slab s.
+//
+// LDS-DMA writes lane-linearly (LDS byte = wave-uniform base + lane * 16), so the LDS image of an operand slab IS the
+// order in which the lanes address global memory (cdna_hip_programming.md §5.4 rule 21):
+//   * operand contiguous along its OUTER index (W[K][N] in a forward pass, X^T and dY of a weight gradient):
+//     image [k = 32][outer], a lane moves 4 consecutive outer elements of one k; MFMA operands are 32 consecutive
+//     words per half-wave (ds_read_b32, conflict-free) — as in the register-staged kernel, without its transposing
+//     stores;
+//   * operand contiguous along the REDUCTION index (activations of a forward pass, dY and W^T of an input gradient):
+//     image [outer][8 groups of 4 k], the lane that fills (row r, slot j) fetches k-group j ^ ((r >> 1) & 7) — the
+//     swizzle sits on the SOURCE address — and a lane reads its MFMA operands as one ds_read_b128 per four k-steps
+//     (conflict-free for the 16-lane groups of ds_read_b128, MI355X_MICROARCH.md LDS table).
+// Both reads agree on ONE order of the reduction inside a slab: MFMA step t of half-wave h multiplies
+// k = 8 * (t / 4) + 4 * h + t % 4 (the plain kernel: 2 t + h).  fp32 sums are taken in that order — deterministic, the
+// same for every launch of a shape, not bit-identical to the register-staged kernel.
+// Out-of-range reduction indices read a 16-byte zero block (their slab rows hold zeros); out-of-range outer indices are
+// clamped as in the register-staged kernel (their products land in rows / columns the epilogue never stores).
+// The DMA is issued from inline asm, so hipcc neither counts it nor drains it (no vmcnt(0) in front of the operand
+// reads, cdna_hip_programming.md §5.7): completion is counted by hand — every slab is L requests per lane, requests of
+// non-existent slabs are still issued (zero block) so that "all but the newest (D - 2) * L" is the same immediate
+// in every step.  Ordinary loads may not appear inside the loop: table lookups come from LDS.
+#ifndef RLX_DMA_DEPTH
+#define RLX_DMA_DEPTH 4
+#endif
+constexpr int kDmaDepth = RLX_DMA_DEPTH;
+static_assert((kDmaDepth & (kDmaDepth - 1)) == 0 && kDmaDepth >= 2, "the ring index is taken with a mask");
+__device__ __attribute__((aligned(16))) float g_dma_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int BM, int BN>
+struct DmaTile {
+    static constexpr int kSlabFloats = (BM + BN) * BK;
+    static constexpr int kSmemFloats = kDmaDepth * kSlabFloats;
+};
+
+// one 16-byte global -> LDS request per lane; lds_dst: wave-uniform LDS byte address of lane 0's 16 bytes
+__device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB>
+__device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, const int by, const int bz,
+                                              const int gdx, const int gdy, float *const smem, int *const tab_s) {
+    constexpr int D = kDmaDepth;
+    constexpr int WN = BN / 32;
+    constexpr int WMN = (BM / 32) * WN;
+    static_assert(WMN * KW == 4, "a workgroup is 4 waves");
+    static_assert(BK == 32, "slab images are 32 k deep");
+    constexpr int A_SLAB = BM * BK, SLAB = DmaTile<BM, BN>::kSlabFloats;
+    constexpr int NA_I = BM / 32, NB_I = BN / 32;          // 16-byte requests per lane per slab (4 KB per workgroup request)
+    constexpr int L = NA_I + NB_I;
+    static_assert(L * (D - 1) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(4 * 32 * 33 <= DmaTile<BM, BN>::kSmemFloats, "epilogue staging fits in the ring");
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wk = wid / WMN, wmn = wid - wk * WMN;
+    const int wm = wmn / WN, wn = wmn % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int batch = bz / g.splits, split = bz - batch * g.splits;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    unsigned long long *const stamp = g.stamps && tid == 0
+        ? g.stamps + 4 * ((size_t)(bz * gdy + by) * gdx + bx) : nullptr;
+    if (stamp) stamp[0] = wall_clock64();
+
+    const float *const abase = static_cast<const float *>(g.a.base) +
+                               batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2);
+    const float *const bbase = static_cast<const float *>(g.b.base) +
+                               batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2);
+    const float *const zero = g_dma_zero;
+    // branch-free "valid ? p : zero block" (a C++ ?: here became an exec-masked branch around the table lookup)
+    auto pick = [&](const float *p, bool valid) {
+        const uintptr_t m = (uintptr_t)0 - (uintptr_t)valid;
+        return reinterpret_cast<const float *>((reinterpret_cast<uintptr_t>(p) & m) |
+                                               (reinterpret_cast<uintptr_t>(zero) & ~m));
+    };
+
+    // ---- per-lane invariants of the request addresses
+    //   k-vector operand:     lane = (row tid / 8 [+ 32 p], slot tid % 8)          -> k-group slot ^ ((row >> 1) & 7)
+    //   outer-vector operand: lane = (k-row tid / LPR [+ 1024 / extent * p], outer group tid % LPR), LPR = extent / 4
+    long long a_off_o[A_VEC_RED ? NA_I : 1];
+    int a_k = 0;                                            // k-vector: first k of the lane's group within a slab
+    if (A_VEC_RED) {
+        a_k = ((tid & 7) ^ ((tid >> 4) & 7)) * 4;           // row = tid >> 3 (+ 32 p): (row >> 1) & 7 = (tid >> 4) & 7
+#pragma unroll
+        for (int p = 0; p < NA_I; ++p) {
+            const int row = min(m0 + (tid >> 3) + 32 * p, g.M - 1);
+            a_off_o[p] = A_TAB ? (long long)g.a.tab_o[row] : (long long)row * g.a.stride_o;
+        }
+    } else {
+        const int mq = min(m0 + (tid % (BM / 4)) * 4, g.M - 4);
+        a_off_o[0] = A_TAB ? (long long)g.a.tab_o[mq] : (long long)mq * g.a.stride_o;
+    }
+    long long b_off_o[B_VEC_RED ? NB_I : 1];
+    int b_k = 0;
+    if (B_VEC_RED) {
+        b_k = ((tid & 7) ^ ((tid >> 4) & 7)) * 4;
+#pragma unroll
+        for (int p = 0; p < NB_I; ++p) {
+            const int col = min(n0 + (tid >> 3) + 32 * p, g.N - 1);
+            b_off_o[p] = (long long)col * g.b.stride_o;
+        }
+    } else {
+        const int nq = min(n0 + (tid % (BN / 4)) * 4, g.N - 4);
+        b_off_o[0] = g.fold ? (long long)(nq / g.fold) * g.b.batch_stride + (long long)(nq % g.fold) * g.b.stride_o
+                            : (long long)nq * g.b.stride_o;
+    }
+    if (A_TAB) {
+        // the chunk's reduction-index offsets, requested together with the row offsets above (one round trip)
+        for (int i = tid; i < kend - kbeg; i += kThreads) tab_s[i] = g.a.tab_r[kbeg + i];
+        __syncthreads();
+    }
+
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem)) + (unsigned)wid * 1024u;
+    auto issue = [&](int s_idx) {
+        const int k0 = kbeg + s_idx * BK;
+        const unsigned dst = lds0 + (unsigned)((s_idx & (D - 1)) * SLAB) * 4u;
+#pragma unroll
+        for (int p = 0; p < NA_I; ++p) {
+            const float *src;
+            if (A_VEC_RED) {
+                const int k = k0 + a_k;
+                const long long ro = A_TAB ? (long long)tab_s[min(k, kend - 4) - kbeg] : (long long)k * g.a.stride_r;
+                src = pick(abase + a_off_o[p] + ro, k < kend);
+            } else {
+                const int k = k0 + tid / (BM / 4) + (1024 / BM) * p;
+                const long long ro = A_TAB ? (long long)tab_s[min(k, kend - 1) - kbeg] : (long long)k * g.a.stride_r;
+                src = pick(abase + a_off_o[0] + ro, k < kend);
+            }
+            dma16(src, __builtin_amdgcn_readfirstlane(dst + 4096u * p));
+        }
+#pragma unroll
+        for (int p = 0; p < NB_I; ++p) {
+            const float *src;
+            if (B_VEC_RED) {
+                const int k = k0 + b_k;
+                src = pick(bbase + b_off_o[p] + (long long)k * g.b.stride_r, k < kend);
+            } else {
+                const int k = k0 + tid / (BN / 4) + (1024 / BN) * p;
+                src = pick(bbase + b_off_o[0] + (long long)k * g.b.stride_r, k < kend);
+            }
+            dma16(src, __builtin_amdgcn_readfirstlane(dst + (unsigned)A_SLAB * 4u + 4096u * p));
+        }
+    };
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    const bool do_colsum = g.colsum != nullptr && by == 0 && tid < BN;
+    float csum = 0.f;
+
+    // this wave group's MFMA steps of a slab: k-quads q = wk * QS .. + QS - 1, each 8 k (4 per half-wave)
+    constexpr int QS = 4 / KW;
+    const int a_row = wm * 32 + l31, b_col = wn * 32 + l31;
+    auto mfma_slab = [&](int buf) {
+        const float *as = smem + buf * SLAB, *bs = as + A_SLAB;
+        // every operand of the slab is requested from LDS first (32 registers at KW = 1), then the MFMA chain runs behind
+        // counted lgkmcnt waits: one LDS latency per slab instead of one per four MFMAs
+        float av[QS][4], bv[QS][4];
+#pragma unroll
+        for (int qq = 0; qq < QS; ++qq) {
+            const int q = wk * QS + qq;
+            if (A_VEC_RED) {
+                const float4 v = *reinterpret_cast<const float4 *>(as + a_row * 32 + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2));
+                av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[qq][i] = as[(8 * q + 4 * hi + i) * BM + a_row];
+            }
+            if (B_VEC_RED) {
+                const float4 v = *reinterpret_cast<const float4 *>(bs + b_col * 32 + (((2 * q + hi) ^ ((b_col >> 1) & 7)) << 2));
+                bv[qq][0] = v.x; bv[qq][1] = v.y; bv[qq][2] = v.z; bv[qq][3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[qq][i] = bs[(8 * q + 4 * hi + i) * BN + b_col];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 0; qq < QS; ++qq)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[qq][i], bv[qq][i], acc[0][0], 0, 0, 0);
+        if (do_colsum) {
+            float sc = 0.f;
+            if (B_VEC_RED) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 v = *reinterpret_cast<const float4 *>(bs + tid * 32 + (((j + (tid >> 1)) & 7) << 2));
+                    sc += (v.x + v.y) + (v.z + v.w);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) sc += bs[kk * BN + tid];
+            }
+            csum += sc;
+        }
+    };
+
+    if (kbeg < kend) {
+        const int nslab = (kend - kbeg + BK - 1) / BK;
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(d);
+        if (stamp) stamp[1] = wall_clock64();
+        for (int s = 0; s < nslab; ++s) {
+            // slab s has landed once all but the (D - 2) * L newest requests of this lane are complete ...
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (D - 2)) : "memory");
+            // ... for every wave of the workgroup; and everyone is done reading slab s - 1, whose buffer is refilled next
+            asm volatile("s_barrier" ::: "memory");
+            issue(s + D - 1);
+            mfma_slab(s & (D - 1));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // requests of non-existent slabs still target the ring
+    }
+    __syncthreads();                                          // the ring becomes the epilogue's staging area
+    if (stamp) stamp[2] = wall_clock64();
+    fast_epilogue<BM, BN, 1, 1, KW, false>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp);
+}
+
+template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB>
+__global__ void __launch_bounds__(kThreads, 2) gemm_dma_kernel(const GemmDev g) {
+    __shared__ __attribute__((aligned(1024))) float smem[DmaTile<BM, BN>::kSmemFloats];
+    __shared__ int tab_s[A_TAB ? kTabChunk : 1];
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    xcd_tile_block(g.xcd_mode, bx, by, bz);
+    gemm_dma_body<BM, BN, KW, A_VEC_RED, B_VEC_RED, A_TAB>(g, bx, by, bz, gridDim.x, gridDim.y, smem, tab_s);
+}
+
+// a layer's weight gradient and input gradient as one launch (see gemm_fast_pair_kernel), both on the LDS-DMA ring
+template <bool A_TAB0, int DX_KW>
+__global__ void __launch_bounds__(kThreads, 2) gemm_dma_pair_kernel(const GemmPairDev p) {
+    __shared__ __attribute__((aligned(1024))) float smem[DmaTile<64, 64>::kSmemFloats];
+    __shared__ int tab_s[A_TAB0 ? kTabChunk : 1];
+    int flat = blockIdx.x;
+    const int which = flat >= p.n0;
+    if (which) flat -= p.n0;
+    flat = xcd_tile_position(p.g[0].xcd_mode, flat, which ? (int)gridDim.x - p.n0 : p.n0);
+    const int gx = p.gx[which], gy = p.gy[which];
+    const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
+    if (!which)
+        gemm_dma_body<64, 64, 1, false, false, A_TAB0>(p.g[0], bx, by, bz, gx, gy, smem, tab_s);
+    else if (DX_KW == 2)
+        gemm_dma_body<32, 64, 2, true, true, false>(p.g[1], bx, by, bz, gx, gy, smem, tab_s);
+    else if (DX_KW == 4)
+        gemm_dma_body<32, 32, 4, true, true, false>(p.g[1], bx, by, bz, gx, gy, smem, tab_s);
+    else
+        gemm_dma_body<64, 64, 1, true, true, false>(p.g[1], bx, by, bz, gx, gy, smem, tab_s);
 }
 
 
@@ -1465,6 +1744,23 @@ int launch_fast(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, boo
     return -1;
 }
 
+template <int BM, int BN, int KW>
+int launch_dma(const GemmDev &g, bool a_vec_red, bool b_vec_red, bool a_tab, dim3 grid, hipStream_t s) {
+#define RLX_DMA_CASE(AV, BV, AT)                                                                      \
+    if (a_vec_red == AV && b_vec_red == BV && a_tab == AT) {                                          \
+        RLX_LAUNCH((gemm_dma_kernel<BM, BN, KW, AV, BV, AT>), grid, kThreads, 0, s, g);               \
+        return 0;                                                                                     \
+    }
+    RLX_DMA_CASE(true, false, false)
+    RLX_DMA_CASE(true, true, false)
+    RLX_DMA_CASE(false, false, false)
+    RLX_DMA_CASE(false, true, false)
+    RLX_DMA_CASE(true, false, true)
+    RLX_DMA_CASE(false, false, true)
+#undef RLX_DMA_CASE
+    return -1;
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 // Tuning constants of the path selection (each was measured on the BASELINE shapes; the A/B records are under
@@ -1477,6 +1773,9 @@ constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a laun
 // in-workgroup K split: taken when the 64 x 64 tiling has fewer than g_kw_below_tiles tiles and the smaller tiling at
 // least g_kw_min_tiles (rlx_gemm_tuning: an explicit knob for same-process A/Bs, tools/ab_c2.py)
 int g_kw_below_tiles = 192, g_kw_min_tiles = 192, g_xcd_mode = -1;
+// main loop of the fast tiled kernels: 1 = operands through the LDS-DMA ring (gemm_dma_body), 0 = register-staged
+// (gemm_fast_body); rlx_gemm_pipeline, for same-process A/Bs.  uint8 operands and 128 x 32 tiles always take the latter.
+int g_dma = 1;
 
 // diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
 struct StampCall { int M, N, K, batch, splits, gx, gy, gz; long long offset; };
@@ -1520,6 +1819,12 @@ int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode) {
     g_kw_below_tiles = kw_below_tiles;
     g_kw_min_tiles = kw_min_tiles;
     g_xcd_mode = xcd_mode;
+    return RLX_OK;
+}
+
+int rlx_gemm_pipeline(int lds_dma_ring) {
+    RLX_REQUIRE(lds_dma_ring == 0 || lds_dma_ring == 1, "rlx_gemm_pipeline: 0 (register-staged) or 1 (LDS-DMA ring)");
+    g_dma = lds_dma_ring;
     return RLX_OK;
 }
 
@@ -1764,7 +2069,12 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
         }
     }
     int rc = -1;
-    if (fast) {
+    if (fast && g_dma && !d.a_is_u8 && !narrow) {
+        if (KW == 2) rc = launch_dma<32, 64, 2>(g, a_vec_red, b_vec_red, a_tab, grid, s);
+        else if (KW == 4) rc = launch_dma<32, 32, 4>(g, a_vec_red, b_vec_red, a_tab, grid, s);
+        else rc = launch_dma<64, 64, 1>(g, a_vec_red, b_vec_red, a_tab, grid, s);
+    }
+    if (fast && rc != 0) {
         const bool u8 = d.a_is_u8 != 0;
         if (narrow) rc = launch_fast<128, 32, 1, 1>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
         else if (KW == 2) rc = launch_fast<32, 64, 1, 1, 2>(g, a_vec_red, u8, b_vec_red, a_tab, grid, s);
@@ -1872,7 +2182,10 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
     const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
     hipStream_t s = rlx::as_stream(stream);
 #define RLX_PAIR_CASE(AT, KWX)                                                                   \
-    if (pw.a_tab == AT && px.kw == KWX) RLX_LAUNCH((gemm_fast_pair_kernel<AT, KWX>), total, kThreads, 0, s, p);
+    if (pw.a_tab == AT && px.kw == KWX) {                                                        \
+        if (g_dma) RLX_LAUNCH((gemm_dma_pair_kernel<AT, KWX>), total, kThreads, 0, s, p);        \
+        else RLX_LAUNCH((gemm_fast_pair_kernel<AT, KWX>), total, kThreads, 0, s, p);             \
+    }
     RLX_PAIR_CASE(true, 1) RLX_PAIR_CASE(true, 2) RLX_PAIR_CASE(true, 4)
     RLX_PAIR_CASE(false, 1) RLX_PAIR_CASE(false, 2) RLX_PAIR_CASE(false, 4)
 #undef RLX_PAIR_CASE
