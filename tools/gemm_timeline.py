@@ -15,6 +15,8 @@ import torch
 from coach_amd import _rlx
 from coach_amd.nn.networks import ClippedPPONet
 
+if "--pipeline" in sys.argv:          # rlx_gemm_pipeline: 1 = LDS-DMA ring (default), 0 = register-staged
+    _rlx.lib().gemm_pipeline(int(sys.argv[sys.argv.index("--pipeline") + 1]))
 dev = torch.device("cuda:0")
 B, A, shape = 64, 6, (84, 84, 4)
 np.random.seed(0)
