@@ -86,12 +86,8 @@ class ClippedPPOAgentParameters(object):                 # clipped_ppo_agent.py:
 
 
 def _capture(fn):
-    g = torch.cuda.CUDAGraph()
-    # thread_local: with data parallelism RCCL's watchdog thread polls events while we capture; only
-    # calls made by THIS thread may invalidate the capture
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-        fn()
-    return g
+    from .vector_agent import capture
+    return capture(fn)
 
 
 class ClippedPPOAgent(object):

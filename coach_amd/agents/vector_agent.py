@@ -22,11 +22,29 @@ from .. import _rlx
 from ..core_types import EnvironmentSteps, RunPhase, TrainingSteps
 
 
+class no_gc_while_capturing(object):
+    """Python's cyclic garbage collector must not run inside a stream capture: a dead cycle that owns device memory or
+    another hipGraph (an agent of an earlier run, with its closures) would be freed in the middle of the capture — a
+    device free / graph destroy there aborts the process.  Reference-counted frees of the capture's own temporaries are
+    unaffected; whatever garbage accumulates is collected after the capture."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def capture(fn):
     g = torch.cuda.CUDAGraph()
     # thread_local: with data parallelism RCCL's watchdog thread polls events while we capture; only
     # calls made by THIS thread may invalidate the capture
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    with no_gc_while_capturing(), torch.cuda.graph(g, capture_error_mode="thread_local"):
         fn()
     return g
 
@@ -40,11 +58,16 @@ class _SegmentedCapture(object):
 
     def begin(self):
         self._g = torch.cuda.CUDAGraph()
+        self._nogc = no_gc_while_capturing()
+        self._nogc.__enter__()
         self._ctx = torch.cuda.graph(self._g, capture_error_mode="thread_local")
         self._ctx.__enter__()
 
     def end(self, *exc):
-        self._ctx.__exit__(*(exc or (None, None, None)))
+        try:
+            self._ctx.__exit__(*(exc or (None, None, None)))
+        finally:
+            self._nogc.__exit__(None, None, None)
         self.items.append(("graph", self._g))
 
     def split(self, flat):

@@ -1774,8 +1774,9 @@ constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a laun
 // least g_kw_min_tiles (rlx_gemm_tuning: an explicit knob for same-process A/Bs, tools/ab_c2.py)
 int g_kw_below_tiles = 192, g_kw_min_tiles = 192, g_xcd_mode = -1;
 // main loop of the fast tiled kernels: 1 = operands through the LDS-DMA ring (gemm_dma_body), 0 = register-staged
-// (gemm_fast_body); rlx_gemm_pipeline, for same-process A/Bs.  uint8 operands and 128 x 32 tiles always take the latter.
-int g_dma = 1;
+// (gemm_fast_body, the default: measured equal or faster on the C2 shapes, profiles/r04_ab_gemm_pipeline.txt);
+// rlx_gemm_pipeline, for same-process A/Bs.  uint8 operands and 128 x 32 tiles always take the latter.
+int g_dma = 0;
 
 // diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
 struct StampCall { int M, N, K, batch, splits, gx, gy, gz; long long offset; };
