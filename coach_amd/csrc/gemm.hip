@@ -898,6 +898,9 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
 #ifndef RLX_DMA_DEPTH
 #define RLX_DMA_DEPTH 4
 #endif
+#ifndef RLX_DMA_WGS
+#define RLX_DMA_WGS 2          // workgroups per CU the DMA kernels are compiled for (LDS: depth x 16 KB + 8 KB of tables)
+#endif
 constexpr int kDmaDepth = RLX_DMA_DEPTH;
 static_assert((kDmaDepth & (kDmaDepth - 1)) == 0 && kDmaDepth >= 2, "the ring index is taken with a mask");
 __device__ __attribute__((aligned(16))) float g_dma_zero[4] = {0.f, 0.f, 0.f, 0.f};
@@ -905,7 +908,8 @@ __device__ __attribute__((aligned(16))) float g_dma_zero[4] = {0.f, 0.f, 0.f, 0.
 template <int BM, int BN>
 struct DmaTile {
     static constexpr int kSlabFloats = (BM + BN) * BK;
-    static constexpr int kSmemFloats = kDmaDepth * kSlabFloats;
+    static constexpr int kRingFloats = kDmaDepth * kSlabFloats;
+    static constexpr int kSmemFloats = kRingFloats > 4 * 32 * 33 ? kRingFloats : 4 * 32 * 33;   // >= the epilogue's staging
 };
 
 // one 16-byte global -> LDS request per lane; lds_dst: wave-uniform LDS byte address of lane 0's 16 bytes
@@ -1098,7 +1102,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
 }
 
 template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB>
-__global__ void __launch_bounds__(kThreads, 2) gemm_dma_kernel(const GemmDev g) {
+__global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_kernel(const GemmDev g) {
     __shared__ __attribute__((aligned(1024))) float smem[DmaTile<BM, BN>::kSmemFloats];
     __shared__ int tab_s[A_TAB ? kTabChunk : 1];
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -1108,7 +1112,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_dma_kernel(const GemmDev g) 
 
 // a layer's weight gradient and input gradient as one launch (see gemm_fast_pair_kernel), both on the LDS-DMA ring
 template <bool A_TAB0, int DX_KW>
-__global__ void __launch_bounds__(kThreads, 2) gemm_dma_pair_kernel(const GemmPairDev p) {
+__global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_pair_kernel(const GemmPairDev p) {
     __shared__ __attribute__((aligned(1024))) float smem[DmaTile<64, 64>::kSmemFloats];
     __shared__ int tab_s[A_TAB0 ? kTabChunk : 1];
     int flat = blockIdx.x;

@@ -1,0 +1,50 @@
+"""Same-box A/B of (build of the library, rlx_gemm_pipeline mode) pairs on the C2 minibatch update: every configuration
+runs bench.py's agent in its own process, alternately, `rounds` times; us per update = hipGraph replay of 10 epochs x
+32 minibatches / 320, the minimum over the rounds.
+    python tools/ab_c2_pipeline.py rounds lib:mode [lib:mode ...]      e.g.  2 coach_amd/librlx.so:0 coach_amd/ab/librlx_d2.so:1 coach_amd/librlx.so:0:192,200,-1
+(the optional third field is rlx_gemm_tuning's kw_below_tiles,kw_min_tiles,xcd_mode)
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import json, os, random, sys
+sys.path.insert(0, %r)
+import coach_amd._rlx as _rlx
+_rlx.LIB_PATH = sys.argv[1]
+_rlx.lib().gemm_pipeline(int(sys.argv[2]))
+import torch
+sys.path.insert(0, os.path.join(%r, "tools"))
+import ab_c2
+tuning = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (192, 192, -1)
+agent = ab_c2.build(False, True, tuning=tuning)
+ts = [ab_c2.train_ms(agent) for _ in range(6)]
+print(json.dumps({"us_per_update": [round(1e3 * t / 320, 1) for t in ts[2:]]}))
+''' % (ROOT, ROOT)
+
+
+def main():
+    rounds = int(sys.argv[1])
+    cfgs = []
+    for a in sys.argv[2:]:                 # lib:mode[:kw_below,kw_min,xcd_mode]
+        parts = a.split(":")
+        cfgs.append((os.path.abspath(parts[0]), parts[1]) + ((parts[2],) if len(parts) > 2 else ()))
+    res = {c: [] for c in cfgs}
+    for _ in range(rounds):
+        for c in cfgs:
+            out = subprocess.run([sys.executable, "-c", CHILD] + list(c), capture_output=True, text=True, cwd=ROOT)
+            line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+            if not line:
+                print(out.stdout[-2000:], out.stderr[-2000:])
+                raise SystemExit(1)
+            res[c] += json.loads(line[-1])["us_per_update"]
+    for c, v in res.items():
+        print("%-34s pipeline %s tuning %-12s: %.1f us per update (all: %s)" % (
+            os.path.relpath(c[0], ROOT), c[1], c[2] if len(c) > 2 else "default", min(v), v))
+
+
+if __name__ == "__main__":
+    main()
