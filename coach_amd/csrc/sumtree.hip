@@ -436,29 +436,6 @@ __global__ void per_sample_kernel(const double *__restrict__ sum, const double *
     }
 }
 
-// Requests every tree node an update of the given leaves will read — the siblings along their root paths, in all
-// three trees — and throws the values away (a sink word keeps the loads alive): issued where it costs nothing (a side
-// stream, or behind the sample that chose these leaves) it moves the cold round trips of the update out of the
-// update.  No tree is written.
-__global__ void per_touch_kernel(const double *__restrict__ sum, const double *__restrict__ mn,
-                                 const double *__restrict__ mx, int cap, int levels, const int *__restrict__ idx,
-                                 int n, double *__restrict__ sink) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int leaf = idx[t];
-    if (leaf < 0 || leaf >= cap) return;
-    int a = leaf + cap - 1;
-    double acc = sum[a] + mn[a] + mx[a];
-    for (int l = 0; l < levels && a > 0; ++l) {
-        const int sib = (a & 1) ? a + 1 : a - 1;
-        acc += sum[sib];
-        acc += mn[sib];
-        acc += mx[sib];
-        a = (a - 1) >> 1;
-    }
-    if (sink) sink[t] = acc;
-}
-
 __global__ void libm_pow_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                 double *__restrict__ out, int n, int *__restrict__ status) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -567,17 +544,6 @@ int rlx_per_store_value(double *sum_tree, double *min_tree, double *max_tree, in
     return launch_update(sum_tree, min_tree, max_tree, capacity, nullptr, nullptr, nullptr, nullptr,
                          n, start_leaf, /*alpha=p*/ leaf_p, /*eps=p^alpha*/ leaf_pa, max_priority, 3,
                          status, stream, "rlx_per_store_value");
-}
-
-int rlx_per_touch(const double *sum_tree, const double *min_tree, const double *max_tree, int capacity,
-                  const int *idx, int n, double *sink, void *stream) {
-    RLX_REQUIRE(sum_tree && min_tree && max_tree && idx && sink, "rlx_per_touch: null pointer");
-    RLX_REQUIRE(is_pow2(capacity), "rlx_per_touch: capacity %d is not a power of two", capacity);
-    if (n <= 0) return RLX_OK;
-    RLX_LAUNCH((per_touch_kernel), (n + 63) / 64, 64, 0, rlx::as_stream(stream), sum_tree, min_tree, max_tree, capacity,
-               ilog2(capacity), idx, n, sink);
-    RLX_LAUNCH_CHECK();
-    return RLX_OK;
 }
 
 int rlx_libm_pow(const double *x, const double *y, double *out, int n, int *status,

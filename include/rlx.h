@@ -85,12 +85,6 @@ int rlx_per_tuning(int path_max_leaves);
 int rlx_per_update_leaves(double *sum_tree, double *min_tree, double *max_tree, int capacity,
                           const int *idx, const double *leaf_pa, const double *leaf_p, int n,
                           double *max_priority, int *status, void *stream); /* same, host-computed p**alpha */
-/* Loads (and discards: `sink` receives one meaningless double per leaf) every node a priority update of the leaves
- * idx[0..n) is going to read — the siblings along their root paths in the three trees.  The reference has no
- * counterpart (its trees live in host memory); here it lets the caller take the update's cold HBM round trips at a
- * moment of its choosing (prioritized_experience_replay.py:188-217 is what then runs warm).  Writes no tree. */
-int rlx_per_touch(const double *sum_tree, const double *min_tree, const double *max_tree, int capacity,
-                  const int *idx, int n, double *sink, void *stream);
 int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,
                    const double *uniforms, int batch, double num_transitions, double beta,
                    int *out_idx, double *out_weight, double *out_priority, long long stored_total,
