@@ -723,6 +723,19 @@ def main():
                    "hip_graphs": bool(agent.use_graphs)},
         "final_losses": {k: float(v) for k, v in agent.signals.items()},
     }
+    if dist.enabled:
+        # what the collective path looked like in this run, so that a SCALE line explains itself: ranks as the
+        # process group reports them, whether the all-reduce is a node of the update's graph, one gradient all-reduce
+        # of the update's size timed on its own (device time, back to back)
+        import torch.distributed as tdist
+        net = agent.networks["main"]
+        us = dist.all_reduce_us(net.params.grads.numel())
+        out["rccl"] = {"backend": dist.backend(), "world_size": tdist.get_world_size(), "graph_resident": dist.capturable(),
+                       "overlap_two_buckets": bool(agent.overlap_allreduce),
+                       "gradient_bytes": 4 * net.params.grads.numel(),
+                       "late_bucket_bytes": 4 * (net.params.grads.numel() - net.late_gradient_offset()),
+                       "allreduce_us": None if us is None else round(us, 1),
+                       "allreduces_per_step": n_updates * (2 if agent.overlap_allreduce else 1)}
     if dist.rank == 0 and not args.no_roofline:
         roof, shapes = gemm_roofline(agent)
         out["roofline"] = roof

@@ -103,7 +103,9 @@ class ClippedPPOAgent(object):
         self.dist = dist if (dist is not None and dist.enabled) else None
         self.lib = _rlx.lib()
         self.use_graphs = True if use_graphs is None else bool(use_graphs)
-        self.overlap_allreduce = False       # data parallel: reduce the FC + head gradients underneath the conv backward
+        # data parallel: reduce the FC + head gradients (95 % of the bytes, final before the convolution backward starts)
+        # underneath the convolution backward — on as soon as there is a wire to hide (world size > 1)
+        self.overlap_allreduce = self.dist is not None and self.dist.world_size > 1
         alg, net = self.ap.algorithm, self.ap.network_wrappers["main"]
         ep = environment.p
         self.continuous = ep.action_dim is not None      # BoxActionSpace -> continuous PPO head
@@ -621,16 +623,38 @@ class ClippedPPOAgent(object):
             self._perm.push(full)
             self.scalar_acc.zero_()
             nmb = -(-n // B)                                              # math.ceil (:232)
-            if self.dist is None and self.epoch_graph and not self.ragged:      # (ragged: n differs from phase to phase)
+            in_graph = self.dist is not None and self.use_graphs and self.dist.capturable()
+            net = self.networks["main"]
+
+            def reduced_fb(m, i, e=None):
+                """forward / backward of minibatch i with the gradient all-reduce as part of the same call sequence
+                (RCCL collectives are graph nodes): one bucket, or — overlap_allreduce — the FC + head gradients
+                reduced on RCCL's stream underneath the convolution backward, the convolution gradients behind it."""
+                if self.overlap_allreduce and net.late_gradient_offset() > 0:
+                    grads, off = net.params.grads, net.late_gradient_offset()
+                    self._minibatch_fb(m, clip, True, i=i, epoch=e)
+                    w1 = self.dist.all_reduce_sum_async(grads[off:])
+                    net.backward_rest()
+                    w2 = self.dist.all_reduce_sum_async(grads[:off])
+                    w1.wait()
+                    w2.wait()
+                else:
+                    self._minibatch_fb(m, clip, i=i, epoch=e)
+                    self.dist.all_reduce_sum(net.params.grads)
+
+            if (self.dist is None or in_graph) and self.epoch_graph and not self.ragged:   # (ragged: n differs from phase to phase)
                 # every minibatch of the epoch reads its slice of the ONE static permutation buffer pushed above: the
                 # whole epoch is one captured graph (one launch from the host instead of nmb, one graph instead of one
-                # per minibatch index)
+                # per minibatch index) — with data parallelism over RCCL the all-reduces are nodes of that graph
                 def epoch():
                     e = self._gather_epoch(n)
                     for i in range(nmb):
-                        self._minibatch_fb(min(B, n - i * B), clip, i=i, epoch=e)
+                        if self.dist is None:
+                            self._minibatch_fb(min(B, n - i * B), clip, i=i, epoch=e)
+                        else:
+                            reduced_fb(min(B, n - i * B), i, e)
                         self._minibatch_finish(scale)
-                self._run(("epoch", n, clip, scale), epoch)
+                self._run(("epoch", n, clip, scale, self.dist is not None and self.overlap_allreduce), epoch)
                 results.append(self.scalar_acc / nmb)
                 continue
             for i in range(nmb):
@@ -638,9 +662,13 @@ class ClippedPPOAgent(object):
                 if self.dist is None:
                     self._run(("mb", m, clip, scale, i), lambda: (self._minibatch_fb(m, clip, i=i),
                                                                   self._minibatch_finish(scale)))
+                elif in_graph:
+                    self._run(("mb_dp", m, clip, scale, i, self.overlap_allreduce),
+                              lambda: (reduced_fb(m, i), self._minibatch_finish(scale)))
                 elif not self.overlap_allreduce:
-                    # default: one blocking all-reduce per minibatch between two graph segments; the Adam
-                    # step of minibatch i-1 rides in the same graph as forward/backward of minibatch i
+                    # a backend whose collectives cannot be captured (gloo): one blocking all-reduce per minibatch
+                    # between two graph segments; the Adam step of minibatch i-1 rides in the same graph as
+                    # forward/backward of minibatch i
                     if i == 0:
                         self._run(("mb_fb", m, clip, i), lambda: self._minibatch_fb(m, clip, i=i))
                     else:
@@ -650,11 +678,7 @@ class ClippedPPOAgent(object):
                     if i == nmb - 1:
                         self._run(("mb_fin", scale), lambda: self._minibatch_finish(scale))
                 else:
-                    # overlap_allreduce = True — overlap: the FC + head gradients (95 % of the 13.5 MB) are final
-                    # before the conv backward starts; their all-reduce runs on RCCL's stream underneath
-                    # it.  Costs a third graph segment and a second collective per minibatch (+50 us
-                    # measured at world size 1), which eats what it hides at 13.5 MB — opt-in.
-                    net = self.networks["main"]
+                    # the same overlap with eager collectives between three graph segments per minibatch
                     grads, off = net.params.grads, net.late_gradient_offset()
                     self._run(("mb_p1", m, clip, i), lambda: self._minibatch_fb(m, clip, True, i=i))
                     w1 = self.dist.all_reduce_sum_async(grads[off:])

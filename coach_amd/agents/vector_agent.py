@@ -83,8 +83,14 @@ class GraphRunner(object):
 
     _segcap = None
 
+    def _collectives_in_graph(self):
+        """data parallel over RCCL: the all-reduce is a node of the captured update (GradientSync.capturable)."""
+        d = getattr(self, "dist", None)
+        return d is not None and d.capturable()
+
     def _allreduce(self, flat):
-        """Sum `flat` over the ranks: an eager collective, or a segment boundary while capturing."""
+        """Sum `flat` over the ranks: an eager (or captured — RCCL) collective, or a segment boundary while capturing
+        with a backend that cannot be captured."""
         if self._segcap is not None:
             self._segcap.split(flat)
         elif getattr(self, "dist", None) is not None:
@@ -124,7 +130,7 @@ class GraphRunner(object):
     def _run(self, key, fn):
         if not self.use_graphs:
             return fn()
-        if getattr(self, "dist", None) is not None:
+        if getattr(self, "dist", None) is not None and not self._collectives_in_graph():
             return self._run_segmented(key, fn)
         g = self._graphs.get(key)
         if g is not None:

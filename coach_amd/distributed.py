@@ -32,6 +32,64 @@ class GradientSync(object):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+        self._capturable = None
+
+    def backend(self):
+        return dist.get_backend() if self.enabled else None
+
+    def capturable(self):
+        """True when a collective of this process group can be recorded into a hipGraph and replayed (RCCL can; gloo
+        cannot): the update then stays ONE graph with its all-reduce as a node — no segment boundary, no eager launch
+        between two replays.  Probed once with a real capture + replay of a small all-reduce; every rank takes the
+        answer all ranks agree on (a MIN over the ranks), so no rank is left waiting in a collective the others
+        skipped.  GradientSync.graph_collectives = False switches the probe (and the feature) off."""
+        if self._capturable is None:
+            ok = 0
+            if self.enabled and self.graph_collectives and dist.get_backend() == "nccl" and torch.cuda.is_available():
+                try:
+                    x = torch.ones(1024, dtype=torch.float32, device="cuda")
+                    dist.all_reduce(x)                      # communicator set-up stays outside the capture
+                    torch.cuda.synchronize()
+                    x.fill_(1.0)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        dist.all_reduce(x)
+                    g.replay()
+                    torch.cuda.synchronize()
+                    ok = int(float(x[0].item()) == float(self.world_size) ** 2 and float(x[-1].item()) == float(x[0].item()))
+                except Exception:                           # capture refused: the segmented path stays in use
+                    ok = 0
+            if self.enabled:
+                ok = int(self.min_over_ranks(ok))
+            self._capturable = bool(ok)
+        return self._capturable
+
+    graph_collectives = True
+
+    def min_over_ranks(self, value):
+        if not self.enabled:
+            return value
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def all_reduce_us(self, n_floats, reps=20):
+        """Device time of one in-place all-reduce (sum) of n_floats fp32 over the ranks, back to back on the current
+        stream: what bench.py reports as `rccl.allreduce_us` (at world size 1: the collective's fixed cost)."""
+        if not self.enabled or dist.get_backend() != "nccl":
+            return None
+        x = torch.zeros(int(n_floats), dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            dist.all_reduce(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(x)
+        e1.record()
+        e1.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / reps
 
     def all_reduce_sum(self, flat):
         """In-place sum of a flat gradient buffer over all ranks."""

@@ -34,6 +34,11 @@ def _worker(rank, world, port, out_dir, sync_mode, backend="gloo"):
     dev = torch.device("cuda:0")
     dist = GradientSync(backend=backend, force=True)
     assert dist.enabled and dist.world_size == world
+    if sync_mode == "s":                                # collectives between graph segments even on RCCL
+        dist.graph_collectives = False
+    if backend == "nccl":
+        # RCCL collectives are recorded into the update's hipGraph unless switched off
+        assert dist.capturable() == (sync_mode != "s")
     ep = SyntheticVectorEnvironmentParameters("image", 8, (44, 44), 4, episode_length=8, seed=21)
     env = SyntheticVectorEnvironment(ep, dev, rank=dist.rank)
     ap = ClippedPPOAgentParameters()
@@ -42,7 +47,7 @@ def _worker(rank, world, port, out_dir, sync_mode, backend="gloo"):
     ap.algorithm.optimization_epochs = 2
     ap.network_wrappers["main"].batch_size = 16
     agent = ClippedPPOAgent(ap, env, dev, dist=dist)
-    agent.overlap_allreduce = sync_mode == "0"          # "1": one blocking all-reduce per minibatch
+    agent.overlap_allreduce = sync_mode == "0"          # "1" / "s": one blocking all-reduce per minibatch
     for _ in range(2):
         res = None
         while res is None:
@@ -202,15 +207,17 @@ def test_two_rank_off_policy_graph_segments(tmp_path, name):
 
 @pytest.mark.timeout(600)
 def test_rccl_path_world_size_one(tmp_path):
-    """The real RCCL (backend "nccl") collectives at world size 1, where the sum is the identity: the
-    overlapped two-bucket async all-reduce between hipGraph replays must give exactly the weights of
-    the blocking all-reduce (stream ordering between torch's stream, the graphs and RCCL's stream)."""
+    """The real RCCL (backend "nccl") collectives at world size 1, where the sum is the identity: the all-reduce as a
+    NODE of the captured epoch graph — one blocking bucket, or two overlapped buckets on RCCL's stream — must give
+    exactly the weights of eager collectives between graph segments (stream ordering between torch's stream, the
+    graphs and RCCL's stream)."""
     import torch.multiprocessing as mp
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "s"):
         mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), mode, "nccl"), nprocs=1, join=True)
-    w1, w0 = (np.load(tmp_path / ("w_%s_0.npy" % m)) for m in "10")
+    w1, w0, ws = (np.load(tmp_path / ("w_%s_0.npy" % m)) for m in "10s")
     assert np.isfinite(w0).all()
-    np.testing.assert_array_equal(w0, w1)
+    np.testing.assert_array_equal(w0, w1)               # two overlapped buckets == one blocking all-reduce (both IN the graph)
+    np.testing.assert_array_equal(ws, w1)               # collectives as graph nodes == eager collectives between segments
 
 
 def test_split_backward_equals_full(dev):

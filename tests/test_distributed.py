@@ -53,6 +53,10 @@ def _worker(rank, world, port, out_dir):
     sync.barrier()
     t = sync.max_over_ranks(float(rank + 1))
     total = sync.sum_over_ranks(1.0)
+    assert sync.min_over_ranks(float(rank + 1)) == 1.0
+    # gloo collectives cannot be recorded into a device graph: every rank gets the same "no" (the updates then run as
+    # graph segments with eager collectives in between); no all-reduce timing without RCCL
+    assert sync.capturable() is False and sync.backend() == "gloo" and sync.all_reduce_us(16) is None
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), w=w, local=local.numpy(), summed=params.grads.numpy(),
              obs=obs, t=t, total=total)
     torch.distributed.destroy_process_group()
