@@ -317,8 +317,7 @@ def run_off_policy(args, device, dist):
             out["cpu_baseline"]["reference"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "where", "sample")}
         except (OSError, ValueError, KeyError):
             pass
-    if dist.rank == 0:
-        print(json.dumps(out))
+    finish(dist, out)
 
 
 # ------------------------------------------------------------------------------------- roofline
@@ -687,7 +686,6 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, dist.world_size))
     if args.workload != "c2":
         run_off_policy(args, device, dist)
-        dist.barrier()
         return
     agent = build_agent(device, dist)
     for _ in range(args.warmup):
@@ -760,9 +758,25 @@ def main():
                 pass
         if ref:
             out["cpu_baseline"]["reference"] = ref
-    dist.barrier()
+    finish(dist, out)
+
+
+def finish(dist, out):
+    """rank 0's ONE JSON line, as the LAST thing on stdout: the process group is torn down first and the C library's
+    stdout buffer flushed (RCCL prints its version banner through it — left alone it would land behind the JSON)."""
+    if dist.enabled:
+        import torch.distributed as tdist
+        if tdist.is_initialized():
+            dist.barrier()
+            tdist.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if dist.rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

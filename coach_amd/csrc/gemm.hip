@@ -872,9 +872,9 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
 // shapes a workgroup spends 1.2-1.5 us per 32-deep K slab against 0.2-0.4 us of MFMA issue — one or two workgroups per
 // CU, each wave alone on its SIMD, operands cold (written by the previous kernel, possibly on another XCD), and only two
 // slabs of loads in flight because every slab in flight costs a register set.  Here the operand slabs go from global
-// memory STRAIGHT into a ring of kDmaDepth LDS buffers (global_load_lds_dwordx4: no staging registers, no ds_write
-// pass), kDmaDepth - 1 slabs are in flight at any time, and a slab step is  wait(counted vmcnt) -> ONE barrier ->
-// request slab s + D - 1 -> LDS operand reads + MFMAs of slab s.
+// memory STRAIGHT into a ring of kDmaDepth LDS buffers (global_load_lds_dwordx4: no staging registers — 70 VGPRs instead
+// of 140-168 — and no ds_write pass), kDmaDepth - 1 slabs are in flight at any time, and a slab step is
+// wait(counted vmcnt) -> ONE barrier -> request slab s + D - 1 -> LDS operand reads + MFMAs of slab s.
 //
 // LDS-DMA writes lane-linearly (LDS byte = wave-uniform base + lane * 16), so the LDS image of an operand slab IS the
 // order in which the lanes address global memory (cdna_hip_programming.md §5.4 rule 21):
@@ -895,11 +895,17 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
 // reads, cdna_hip_programming.md §5.7): completion is counted by hand — every slab is L requests per lane, requests of
 // non-existent slabs are still issued (zero block) so that "all but the newest (D - 2) * L" is the same immediate
 // in every step.  Ordinary loads may not appear inside the loop: table lookups come from LDS.
+// Ring depth and occupancy, measured on the C2 update (same-box A/Bs of builds, profiles/r04_ab_gemm_pipeline.txt): what
+// pays is NOT a deeper ring — three slabs in flight (depth 4: 64 KB of LDS, two workgroups per CU) were 6 % SLOWER than the
+// register-staged kernel, whose 42 KB let three workgroups share a CU — but the ring's small footprint: depth 2 (one slab
+// in flight behind the one being multiplied; 32 KB + 8 KB of tables) at three workgroups per CU is 3.7 % faster than the
+// register-staged kernel (266 vs 276 us per update), four per CU 2.5 %.  The waves of the neighbouring workgroups hide
+// what a deeper ring would.
 #ifndef RLX_DMA_DEPTH
-#define RLX_DMA_DEPTH 4
+#define RLX_DMA_DEPTH 2
 #endif
 #ifndef RLX_DMA_WGS
-#define RLX_DMA_WGS 2          // workgroups per CU the DMA kernels are compiled for (LDS: depth x 16 KB + 8 KB of tables)
+#define RLX_DMA_WGS 3          // workgroups per CU the DMA kernels are compiled for (LDS: depth x 16 KB + 8 KB of tables)
 #endif
 constexpr int kDmaDepth = RLX_DMA_DEPTH;
 static_assert((kDmaDepth & (kDmaDepth - 1)) == 0 && kDmaDepth >= 2, "the ring index is taken with a mask");
@@ -1778,9 +1784,8 @@ constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a laun
 // least g_kw_min_tiles (rlx_gemm_tuning: an explicit knob for same-process A/Bs, tools/ab_c2.py)
 int g_kw_below_tiles = 192, g_kw_min_tiles = 192, g_xcd_mode = -1;
 // main loop of the fast tiled kernels: 1 = operands through the LDS-DMA ring (gemm_dma_body), 0 = register-staged
-// (gemm_fast_body, the default: measured equal or faster on the C2 shapes, profiles/r04_ab_gemm_pipeline.txt);
-// rlx_gemm_pipeline, for same-process A/Bs.  uint8 operands and 128 x 32 tiles always take the latter.
-int g_dma = 0;
+// (gemm_fast_body); rlx_gemm_pipeline, for same-process A/Bs (profiles/r04_ab_gemm_pipeline.txt).  uint8 operands and 128 x 32 tiles always take the latter.
+int g_dma = 1;
 
 // diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
 struct StampCall { int M, N, K, batch, splits, gx, gy, gz; long long offset; };

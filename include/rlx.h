@@ -334,9 +334,9 @@ int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_
  * contiguous share per XCD — so that tiles sharing operand rows share an L2.
  * An explicit knob for same-process A/B measurements (tools/ab_c2.py); results are identical either way. */
 int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode);
-/* Main loop of the fast tiled kernels: 1 = operand slabs go global -> LDS by DMA into a ring of buffers, three slabs in
- * flight, one barrier per slab (csrc/gemm.hip gemm_dma_body); 0 (default) = the register-staged two-set pipeline of
- * rounds 1-3.  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two
+/* Main loop of the fast tiled kernels: 1 (default) = operand slabs go global -> LDS by DMA into a ring of two buffers,
+ * one barrier per slab, three workgroups per CU (csrc/gemm.hip gemm_dma_body); 0 = the register-staged two-set pipeline
+ * of rounds 1-3 (uint8 operands and 128 x 32 tiles always use it).  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two
  * (both deterministic).  Process-wide, read at launch (or capture) time: exists for same-process A/B measurements. */
 int rlx_gemm_pipeline(int lds_dma_ring);
 

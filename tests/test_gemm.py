@@ -10,12 +10,12 @@ from tests.util import dev_tensor
 @pytest.fixture(autouse=True, params=[1, 0], ids=["lds-dma-ring", "register-staged"])
 def _gemm_pipeline(request):
     """every test of this file runs with both main loops of the fast tiled kernels (rlx_gemm_pipeline): the LDS-DMA ring
-    and the register-staged two-set pipeline (the default)."""
+    (the default) and the register-staged two-set pipeline."""
     from coach_amd import _rlx
     lib = _rlx.lib()
     lib.gemm_pipeline(request.param)
     yield
-    lib.gemm_pipeline(0)
+    lib.gemm_pipeline(1)
 
 
 def _tol(K):
