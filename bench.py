@@ -652,6 +652,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json config (default c2 = the headline metric's configuration)")
     ap.add_argument("--no-prefill", action="store_true", help="c3: skip the 2^20-transition pre-fill")
+    ap.add_argument("--sac-branches", type=int, default=None, choices=[0, 1],
+                    help="A/B (c5): the SAC update's policy / V / Q passes as parallel branches of the captured graph (1, "
+                         "the default) or in sequence (0)")
     ap.add_argument("--gemm-pipeline", type=int, default=None, choices=[0, 1],
                     help="A/B: main loop of the fast tiled GEMM kernels (rlx_gemm_pipeline): 1 = LDS-DMA ring (the "
                          "library's default), 0 = register-staged")
@@ -679,6 +682,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = GradientSync(force=args.force_dist)
+    if args.sac_branches is not None:
+        from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgent
+        SoftActorCriticAgent.parallel_branches = bool(args.sac_branches)
     if args.gemm_pipeline is not None:
         from coach_amd import _rlx
         _rlx.lib().gemm_pipeline(args.gemm_pipeline)

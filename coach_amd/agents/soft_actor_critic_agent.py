@@ -165,22 +165,37 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
         return self.dist.grad_scale(netp.scale_down_gradients_by_number_of_workers_for_sync_training) \
             if self.dist else 1.0
 
+    # The three networks' passes as parallel branches of the captured update (fork / join of side streams): the policy
+    # chain, V's training pass and Q's training pass touch different networks until their losses meet.  Same calls,
+    # same arithmetic, same results as the sequential order (tests/test_ac_nets.py, test_agent_loops.py).
+    parallel_branches = True
+
     def _learn_device(self, b, mix=None):
         pol, q, v = self.networks["policy"], self.networks["q"], self.networks["v"]
-        alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream()
+        alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream
         s, ns = b._states["observation"], b._next_states["observation"]
         resample = alg.resample_noise_per_pass
-        # (1) policy outputs on the first noise draw (:186-190)
+        obs2 = b._info.get("states_pair") if hasattr(b, "_info") else None
+        br = None
+        if self.parallel_branches and self.dist is None and obs2 is not None and torch.cuda.is_available():
+            from .vector_agent import Branches
+            br = getattr(self, "_branches", None)
+            if br is None:
+                br = self._branches = Branches(2)
+            br.fork()
+        # ---- branch A (the stream of the caller): policy.  (1) policy outputs on the first noise draw (:186-190)
         o, p_saved = pol.forward(s, B, self.normals[0], tag="train0")
         # (2) Q(s, sampled actions): log_target = min(Q1, Q2) (:198-200)
-        qv, q_saved = q.forward(s, o["actions"], B, tag="pi")
+        qv, q_saved_pi = q.forward(s, o["actions"], B, tag="pi")
         # min(Q1, Q2), the V targets of (4) = log_target - logp of this first pass (:244) and d mean(min) / d Q_i
         # for (3): one launch
-        dqv = q_saved[4].ensure_grad().view(2, B)
+        dqv = q_saved_pi[4].ensure_grad().view(2, B)
         self.lib.sac_min_targets(qv[0], qv[1], o["logprob"], 1.0 / B, B, self.log_target, self.value_targets,
-                                 dqv[0], dqv[1], s_)
+                                 dqv[0], dqv[1], s_())
+        targets_ready = br.mark() if br else None
         # (3) d mean(Q_min) / d a at the sampled actions (:216-217)
-        q.action_gradient(q_saved, B, self.dq_da, dq_done=True)
+        q.action_gradient(q_saved_pi, B, self.dq_da, dq_done=True)
+        q_weights_free = br.mark() if br else None           # nothing of branch A reads Q's weights after this
         if resample:
             # The three sess.run passes of the reference re-evaluate the SAME deterministic torso
             # (same weights, same states) and only re-sample the head's noise, so their gradients
@@ -196,36 +211,57 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
                          action_weight_scale=-1.0)
         self._sync(pol)
         pol.apply_gradients(self._scale("policy"))                               # :229
-        # (4) V: train_on_batch on the targets computed above (:250)
-        obs2 = b._info.get("states_pair") if hasattr(b, "_info") else None
-        if obs2 is not None:
-            # V_online(s) of this training pass and V_target(s') of the Q targets share their launches
-            v2, v_saved = v.forward_pair(obs2, B)
-            v_next = v2[1]
-        else:
-            _, v_saved = v.forward(s, B, tag="train")
-        v.train_backward(v_saved, self.value_targets, B)
-        self._sync(v)
-        # a soft update of V's target due after this update rides in V's Adam pass — only when V_target(s') was
-        # already evaluated above (paired pass); otherwise it is still needed unmixed below
-        v.apply_gradients(self._scale("v"), mix_rate=mix if obs2 is not None else None)
-        # (5) Q: y = r + (1 - done) gamma V_target(s') (:259-266), train_on_batch (:268)
-        if obs2 is None:
-            v_next, _ = v.forward(ns, B, use_target=True, tag="next")
-        qt, q_saved = q.forward(s, b.actions(), B, tag="train")
-        # TD targets and both Q losses (0.5 * mse each, sac_q_head.py:91-95) + their sum: one launch
-        self.lib.ac_critic_losses(v_next, None, b.rewards(), b.game_overs(), float(alg.discount), 0, 0, 0.0, 0.0,
-                                  qt, 2, B, 0.5, None, self.td_targets, q_saved[4].ensure_grad(), q.loss, s_)
-        q.train_backward(q_saved, None, B)
-        self._sync(q)
-        q.apply_gradients(self._scale("q"), with_norm=True)
+
+        # ---- branch B: (4) V, train_on_batch on the targets computed in (2) (:250)
+        import contextlib
+        with (br.on(0) if br else contextlib.nullcontext()):
+            if obs2 is not None:
+                # V_online(s) of this training pass and V_target(s') of the Q targets share their launches
+                v2, v_saved = v.forward_pair(obs2, B)
+                v_next = v2[1]
+            else:
+                _, v_saved = v.forward(s, B, tag="train")
+            v_next_ready = br.mark() if br else None
+            if br:
+                br.after(targets_ready)
+            v.train_backward(v_saved, self.value_targets, B)
+            self._sync(v)
+            # a soft update of V's target due after this update rides in V's Adam pass — only when V_target(s') was
+            # already evaluated above (paired pass); otherwise it is still needed unmixed below
+            v.apply_gradients(self._scale("v"), mix_rate=mix if obs2 is not None else None)
+
+        # ---- branch C: (5) Q, y = r + (1 - done) gamma V_target(s') (:259-266), train_on_batch (:268)
+        with (br.on(1) if br else contextlib.nullcontext()):
+            if obs2 is None:
+                v_next, _ = v.forward(ns, B, use_target=True, tag="next")
+            qt, q_saved = q.forward(s, b.actions(), B, tag="train")
+            if br:
+                br.after(v_next_ready)
+            # TD targets and both Q losses (0.5 * mse each, sac_q_head.py:91-95) + their sum: one launch
+            self.lib.ac_critic_losses(v_next, None, b.rewards(), b.game_overs(), float(alg.discount), 0, 0, 0.0, 0.0,
+                                      qt, 2, B, 0.5, None, self.td_targets, q_saved[4].ensure_grad(), q.loss, s_())
+            q.train_backward(q_saved, None, B)
+            self._sync(q)
+            if br:
+                br.after(q_weights_free)
+            q.apply_gradients(self._scale("q"), with_norm=True)
+        if br:
+            br.join()
+
+    def _update_record_fields(self):
+        return [("z", (3, self.batch_size, self.A), torch.float64)]
+
+    def _draw_update_host(self):
+        return {"z": np.random.standard_normal((3, self.batch_size, self.A))}
 
     def learn_from_batch(self, batch):
         B = self.batch_size
-        z = np.random.standard_normal((3, B, self.A))
-        self.normals = self._to_device("sac_z", z, torch.float64)     # the staging buffer is the operand
+        if self._staged is not None:
+            self.normals = self._staged["z"]             # shipped with the sampled rows (one record per update)
+        else:
+            self.normals = self._to_device("sac_z", self._draw_update_host()["z"], torch.float64)     # the staging buffer is the operand
         mix = self._mix_rate
-        self._run(("learn", mix), lambda: self._learn_device(batch, mix))
+        self._run(("learn", mix, self._staged is not None), lambda: self._learn_device(batch, mix))
         paired = hasattr(batch, "_info") and batch._info.get("states_pair") is not None
         if mix is not None and paired:                  # (decided here, not in the captured body: replays skip that)
             self._mixed = self._mixed | {"v"}

@@ -172,16 +172,26 @@ class TD3Agent(DDPGAgent):
         self._sync(actor)
         actor.apply_gradients(self._scale("actor"), mix_rate=mix)
 
+    def _update_record_fields(self):
+        return [("z", (self.batch_size, self.A), torch.float64)]
+
+    def _draw_update_host(self):
+        alg = self.ap.algorithm
+        return {"z": np.random.normal(0, alg.policy_noise, (self.batch_size, self.A))}    # :162 (host stream)
+
     def learn_from_batch(self, batch):
         alg, B = self.ap.algorithm, self.batch_size
-        z = np.random.normal(0, alg.policy_noise, (B, self.A))                  # :162 (host stream)
-        # the staging buffer IS the noise operand (a static device tensor): no device-to-device copy behind the upload
-        self.noise = self._to_device("td3_noise", z, torch.float64)
+        if self._staged is not None:
+            self.noise = self._staged["z"]               # shipped with the sampled rows (one record per update)
+        else:
+            # the staging buffer IS the noise operand (a static device tensor): no device-to-device copy behind the upload
+            self.noise = self._to_device("td3_noise", self._draw_update_host()["z"], torch.float64)
         run = self._run
         mix = self._mix_rate
-        run(("critic", mix), lambda: self._critic_device(batch, mix))
+        staged = self._staged is not None          # (the captured graphs read the noise at ITS address)
+        run(("critic", mix, staged), lambda: self._critic_device(batch, mix))
         if self.training_iteration % alg.update_policy_every_x_episode_steps == 0:   # :186
-            run(("actor", mix), lambda: self._actor_device(batch, mix))
+            run(("actor", mix, staged), lambda: self._actor_device(batch, mix))
             if mix is not None:
                 self._mixed = self._mixed | {"actor"}
         if mix is not None:

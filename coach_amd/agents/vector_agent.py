@@ -49,6 +49,42 @@ def capture(fn):
     return g
 
 
+class Branches(object):
+    """Fork / join of side streams for INDEPENDENT parts of one update (SAC: the policy, V and Q passes touch
+    different networks until their losses meet).  Works the same eagerly and inside a stream capture, where the event
+    edges become the dependencies of a hipGraph with parallel branches.  Python still issues the calls one after
+    the other; only the device may overlap them."""
+
+    def __init__(self, n):
+        self.streams = [torch.cuda.Stream() for _ in range(n)]
+
+    def fork(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        for s in self.streams:
+            s.wait_event(ev)
+
+    def on(self, i):
+        return torch.cuda.stream(self.streams[i])
+
+    @staticmethod
+    def mark():
+        """an event behind everything issued so far on the CURRENT stream"""
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    @staticmethod
+    def after(ev):
+        torch.cuda.current_stream().wait_event(ev)
+
+    def join(self):
+        for s in self.streams:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            torch.cuda.current_stream().wait_event(ev)
+
+
 class _SegmentedCapture(object):
     """A call sequence with collectives in it: every stretch between two all-reduces becomes its own
     hipGraph; the collectives stay eager calls between the replays (RCCL is not captured)."""
@@ -389,6 +425,31 @@ class VectorOffPolicyAgent(GraphRunner):
         self.last_training_phase_step = self.total_steps_counter
         return due
 
+    _staged = None            # device views of the current update's record (see _update_record), or None
+
+    def _update_record_fields(self):
+        """[(name, shape, dtype)] of the host draws one update consumes (TD3: the smoothing noise, SAC: the three
+        normal draws), or None: the agent stages nothing but the sampled rows."""
+        return None
+
+    def _draw_update_host(self):
+        """{name: array} — the host draws of ONE update, made exactly as learn_from_batch makes them."""
+        return {}
+
+    def _update_record(self):
+        """A RecordStager [rows | the update's host draws] when the agent has per-update draws and the memory takes
+        device rows (uniform / episodic replay; prioritized replay samples on the device), else None."""
+        rec = getattr(self, "_update_rec", False)
+        if rec is False:
+            rec = None
+            fields = self._update_record_fields()
+            import inspect
+            if fields and "rows_dev" in inspect.signature(self.memory.collate).parameters:
+                from ..staging import RecordStager
+                rec = RecordStager([("rows", (self.batch_size,), torch.int32)] + list(fields), self.device)
+            self._update_rec = rec
+        return rec
+
     _mix_rate = None          # set around learn_from_batch when a soft target update follows the update
     _mixed = frozenset()
 
@@ -412,9 +473,16 @@ class VectorOffPolicyAgent(GraphRunner):
             # every batch of the phase is drawn first (agent.py:726), then learned from in turn; a
             # collated DeviceBatch aliases the memory's static buffers, so collation is per batch
             draws = [self.memory.draw(B) for _ in range(self._training_steps_this_phase())]
+            rec = self._update_record()
             for d in draws:
                 self.training_iteration += 1
-                batch = self.memory.collate(d, B)
+                if rec is not None:
+                    # everything this update needs from the host — the sampled rows AND its random draws (made here, where
+                    # learn_from_batch would make them: same order on the host streams) — is ONE record, one copy
+                    self._staged = rec.push(rows=self.memory.physical_rows(d), **self._draw_update_host())
+                    batch = self.memory.collate(d, B, rows_dev=self._staged["rows"])
+                else:
+                    batch = self.memory.collate(d, B)
                 if self.debug_draws is not None:      # sampled logical indices / PER leaves
                     self.debug_draws.append(batch.info("idx").cpu().numpy().copy()
                                             if "idx" in batch._info else np.asarray(d).copy())
@@ -436,6 +504,7 @@ class VectorOffPolicyAgent(GraphRunner):
                             net.update_target(self._mix_rate)
                     self._target_updated_since_log = True      # 'Update Target Network' column (agent.py:760)
                 self._mix_rate = None
+        self._staged = None
         # the loss of the last update of the phase(s) (a device scalar; no per-update host sync or add)
         return losses[-1] if losses else None
 

@@ -212,8 +212,8 @@ class EpisodicExperienceReplay(ExperienceReplay):
     def _extra_gather_columns(self):
         return [(self.n_step_discounted_rewards, "n_step_discounted_rewards")]
 
-    def collate(self, drawn, size):
-        b = self.gather(self.physical_rows(drawn), size)
+    def collate(self, drawn, size, rows_dev=None):
+        b = self._gather_rows(drawn, size, rows_dev)
         return DeviceBatch(size, {"observation": b["state"]}, {"observation": b["next_state"]},
                            b["action"], b["reward"], b["game_over"],
                            info={"logical_idx": drawn, "states_pair": b["states_pair"],

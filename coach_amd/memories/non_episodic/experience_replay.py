@@ -372,9 +372,18 @@ class ExperienceReplay(Memory):
         reference's order ([sample(B) for _ in range(num_consecutive_training_steps)], agent.py:726)."""
         return self.sample_indices(size)
 
-    def collate(self, drawn, size):
+    def _gather_rows(self, drawn, size, rows_dev):
+        """the batch buffers filled from the physical rows of a draw: shipped here (one small copy), or already on the
+        device in `rows_dev` — the agent staged them together with the update's other host draws (RecordStager)."""
+        if rows_dev is None:
+            return self.gather(self.physical_rows(drawn), size)
+        b = self._batch_buffers(size)
+        self.gather_device(rows_dev, size, b)
+        return b
+
+    def collate(self, drawn, size, rows_dev=None):
         """The device half of sample(): gather the Batch of a draw."""
-        b = self.gather(self.physical_rows(drawn), size)
+        b = self._gather_rows(drawn, size, rows_dev)
         return DeviceBatch(size, {"observation": b["state"]}, {"observation": b["next_state"]},
                            b["action"], b["reward"], b["game_over"],
                            info={"logical_idx": drawn, "states_pair": b["states_pair"]})

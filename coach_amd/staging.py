@@ -40,6 +40,32 @@ class Stager(object):
         return self.dst
 
 
+class RecordStager(object):
+    """Several named host arrays shipped with ONE asynchronous copy: the fields live back to back (16-byte aligned) in
+    one pinned record and one static device record; `views[name]` is the typed device view a captured graph reads.
+    What a training update needs from the host — the sampled rows, the update's random draws — is one record, one blit."""
+
+    def __init__(self, fields, device, depth=16):
+        """fields: [(name, shape, torch dtype), ...]"""
+        self.layout, off = {}, 0
+        for name, shape, dt in fields:
+            off = (off + 15) // 16 * 16
+            nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
+            self.layout[name] = (off, nbytes, tuple(shape), dt)
+            off += nbytes
+        total = (off + 15) // 16 * 16
+        self.stager = Stager((total,), torch.uint8, device, depth=depth)
+        self.host = np.zeros(total, dtype=np.uint8)
+        self.views = {n: self.stager.dst[o:o + b].view(dt).view(*shape) for n, (o, b, shape, dt) in self.layout.items()}
+        self.host_views = {n: self.host[o:o + b].view(_NP[dt]).reshape(shape) for n, (o, b, shape, dt) in self.layout.items()}
+
+    def push(self, **arrays):
+        for name, a in arrays.items():
+            self.host_views[name][...] = a
+        self.stager.push(self.host)
+        return self.views
+
+
 class StagerCache(object):
     """{key: Stager} created on first use from the pushed array's shape."""
 
