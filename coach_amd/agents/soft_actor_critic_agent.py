@@ -167,8 +167,11 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
 
     # The three networks' passes as parallel branches of the captured update (fork / join of side streams): the policy
     # chain, V's training pass and Q's training pass touch different networks until their losses meet.  Same calls,
-    # same arithmetic, same results as the sequential order (tests/test_ac_nets.py, test_agent_loops.py).
-    parallel_branches = True
+    # same arithmetic, same results as the sequential order.  OFF: measured on C5 (profiles/r04_ab_sac_branches.txt) the
+    # update's device time does not move (239-256 us with, 240-243 us without: the cross-stream edges of a hipGraph cost
+    # what the overlap returns at these launch sizes, as round 2 found for the weight-gradient side stream) and the
+    # multi-stream graph launch costs the host 11 % of the C5 rate.
+    parallel_branches = False
 
     def _learn_device(self, b, mix=None):
         pol, q, v = self.networks["policy"], self.networks["q"], self.networks["v"]
