@@ -594,13 +594,9 @@ class ClippedPPOAgent(object):
                                                old, clip_rescaler, self.mb_ratio, self.mb_clipped,
                                                stop_after_dense=stop_after_dense)
 
-    # single GPU, inside the captured epoch: the dense layers' Adam step (95 % of the parameter bytes, HBM-bound) runs on a
-    # side stream underneath the NEXT minibatch's convolutions (ClippedPPONet.finish_update(overlap_dense=True))
-    overlap_adam = True
-
-    def _minibatch_finish(self, scale, overlap=False):
+    def _minibatch_finish(self, scale):
         net = self.networks["main"]
-        net.finish_update(scale, signal_acc=self.scalar_acc, overlap_dense=overlap and self.overlap_adam)
+        net.finish_update(scale, signal_acc=self.scalar_acc)
 
     def train_network(self, order, epochs):
         """clipped_ppo_agent.py:209-308.  `order`: dataset indices after the reference's
@@ -657,8 +653,7 @@ class ClippedPPOAgent(object):
                             self._minibatch_fb(min(B, n - i * B), clip, i=i, epoch=e)
                         else:
                             reduced_fb(min(B, n - i * B), i, e)
-                        self._minibatch_finish(scale, overlap=self.dist is None)
-                    net.join_adam()                      # the epoch ends with every parameter stepped
+                        self._minibatch_finish(scale)
                 self._run(("epoch", n, clip, scale, self.dist is not None and self.overlap_allreduce), epoch)
                 results.append(self.scalar_acc / nmb)
                 continue

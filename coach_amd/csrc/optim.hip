@@ -317,40 +317,6 @@ int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, lo
     return RLX_OK;
 }
 
-// The same step cut in two for callers that overlap its halves with other work (coach_amd/nn/networks.py: the dense
-// layers' 95 % of a Clipped-PPO network's parameters are stepped on a side stream underneath the next minibatch's
-// convolutions): rlx_adam_tf1_part steps one contiguous range and leaves the partial sums of squares of ITS gradients in
-// `workspace` (*parts_host of them, one per workgroup); rlx_adam_finish_norm sums the partials of all parts in their
-// order in memory, takes the root, advances the beta powers once and adds the signal sums.
-int rlx_adam_tf1_part(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
-                      float beta1, float beta2, float epsilon, const float *state, float grad_scale,
-                      float *workspace, long long workspace_floats, int *parts_host, void *stream) {
-    RLX_REQUIRE(weights && grads && m && v && state && workspace && parts_host, "rlx_adam_tf1_part: null pointer");
-    RLX_REQUIRE(n > 0, "rlx_adam_tf1_part: empty parameter range");
-    RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
-                "rlx_adam_tf1_part: buffers must be 16-byte aligned");
-    int blocks = rlx::grid_for(n / 4 + 1, kBlock, 1024);
-    if (blocks > workspace_floats) blocks = (int)workspace_floats;
-    RLX_REQUIRE(blocks >= 1, "rlx_adam_tf1_part: workspace too small");
-    RLX_LAUNCH((adam_step_kernel<true, false, false>), blocks, kBlock, 0, rlx::as_stream(stream), weights, grads, m, v, n,
-               learning_rate, beta1, beta2, epsilon, const_cast<float *>(state), grad_scale, workspace,
-               static_cast<float *>(nullptr), 0.f, 0.f, static_cast<unsigned int *>(nullptr));
-    RLX_LAUNCH_CHECK();
-    *parts_host = blocks;
-    return RLX_OK;
-}
-
-int rlx_adam_finish_norm(float *state, float beta1, float beta2, const float *workspace, int n_parts, float *norm_out,
-                         const float *acc_src, float *acc_dst, int n_acc, void *stream) {
-    RLX_REQUIRE(state && workspace && norm_out && n_parts >= 1, "rlx_adam_finish_norm: bad arguments");
-    RLX_REQUIRE(n_acc == 0 || (acc_src && acc_dst && n_acc > 0 && n_acc <= 64),
-                "rlx_adam_finish_norm: bad signal accumulation arguments");
-    RLX_LAUNCH((adam_finish_norm_kernel), 1, kBlock, 0, rlx::as_stream(stream), state, beta1, beta2, workspace, n_parts,
-               norm_out, acc_src, acc_dst, n_acc);
-    RLX_LAUNCH_CHECK();
-    return RLX_OK;
-}
-
 int rlx_mix_weights(float *target, const float *online, long long n, double rate, void *stream) {
     RLX_REQUIRE(target && online && n > 0, "rlx_mix_weights: bad arguments");
     RLX_REQUIRE((((uintptr_t)target | (uintptr_t)online) & 15) == 0,

@@ -695,14 +695,10 @@ class Sequential:
         for l in self.layers:
             l.initialize(rng)
 
-    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False, before_layer=None):
-        """before_layer = (i, fn): fn() is called right before layer i is issued (a stream join in front of the first
-        layer whose weights an overlapped optimiser step may still be writing)."""
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
         acts = [x]
         kw = {"pair": True} if pair else {}
-        for i, l in enumerate(self.layers):
-            if before_layer is not None and before_layer[0] == i:
-                before_layer[1]()
+        for l in self.layers:
             acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, **kw))
         return acts
 

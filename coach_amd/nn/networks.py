@@ -217,12 +217,7 @@ class ClippedPPONet(_NetBase):
         if clip_rescaler is None:
             assert clip_dev is not None, "set_clip_rescaler first"
             clip_rescaler = 1.0
-        # an optimiser step of the dense layers that is still running on the side stream (finish_update(overlap_dense))
-        # is joined right before the first dense layer reads its weights: the convolutions run underneath it
-        k = self._split_layer()
-        acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train",
-                                  before_layer=(k, self.join_adam) if self._adam_done is not None and k > 0 else None)
-        self.join_adam()
+        acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
         mid = acts[-1]
         mid.ensure_grad()
         xv, xp = mid.tower(0), mid.tower(1)
@@ -279,49 +274,11 @@ class ClippedPPONet(_NetBase):
         if k > 0:
             self.torso.backward(self.ctx, acts, layers=(0, k))
 
-    _adam_done = None         # event behind an optimiser step of the dense layers still running on the side stream
-
-    def join_adam(self):
-        """the current stream waits for an overlapped optimiser step (see finish_update); nothing pending: nothing."""
-        ev, self._adam_done = self._adam_done, None
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-
-    def finish_update(self, grad_scale=1.0, signal_acc=None, overlap_dense=False):
+    def finish_update(self, grad_scale=1.0, signal_acc=None):
         """apply_gradients (architecture.py:469-521): global norm fetch + Adam (+ the running sums of
-        [surrogate, entropy, kl, policy total, value loss, grad norm] into signal_acc).
-
-        overlap_dense: the step is cut at late_gradient_offset() — the convolutions' parameters (5 % of the bytes) are
-        stepped on the current stream, the dense layers' and heads' (95 %: an HBM-bound 16 us) on a side stream together
-        with the norm / beta-power finish; the caller's NEXT forward pass joins it in front of its first dense layer
-        (forward_backward does), so that the next minibatch's convolutions — latency-bound, hardly any HBM traffic — run
-        underneath.  Every other reader of the weights must call join_adam() first.  Same arithmetic per parameter;
-        the gradient norm sums its per-workgroup partials in a different grouping (fp32: last bits)."""
-        acc = (self.scalars, signal_acc, 6) if signal_acc is not None else None
-        off = self.late_gradient_offset() if overlap_dense else 0
-        if not overlap_dense or off <= 0 or not torch.cuda.is_available():
-            self.join_adam()
-            return self.apply_gradients(grad_scale, with_norm=True, acc=acc)
-        import ctypes
-        self.join_adam()
-        p, a, lib, ws = self.params, self.adam, self.lib, self.ctx.ws.small
-        if getattr(self, "_adam_side", None) is None:
-            self._adam_side = torch.cuda.Stream()
-        n_a, n_b = ctypes.c_int(), ctypes.c_int()
-        args = (a.lr, a.beta1, a.beta2, a.eps, a.state, grad_scale)
-        lib.adam_tf1_part(p.weights[:off], p.grads[:off], a.m[:off], a.v[:off], off, *args, ws, ws.numel(),
-                          ctypes.byref(n_a), _rlx.current_stream())
-        fork = torch.cuda.Event()
-        fork.record()
-        self._adam_side.wait_event(fork)
-        with torch.cuda.stream(self._adam_side):
-            lib.adam_tf1_part(p.weights[off:], p.grads[off:], a.m[off:], a.v[off:], p.size - off, *args, ws[n_a.value:],
-                              ws.numel() - n_a.value, ctypes.byref(n_b), _rlx.current_stream())
-            lib.adam_finish_norm(a.state, a.beta1, a.beta2, ws, n_a.value + n_b.value, self.norm,
-                                 acc[0] if acc else None, acc[1] if acc else None, int(acc[2]) if acc else 0,
-                                 _rlx.current_stream())
-            self._adam_done = torch.cuda.Event()
-            self._adam_done.record()
+        [surrogate, entropy, kl, policy total, value loss, grad norm] into signal_acc)."""
+        self.apply_gradients(grad_scale, with_norm=True,
+                             acc=(self.scalars, signal_acc, 6) if signal_acc is not None else None)
 
     def train_minibatch(self, obs, B, actions, advantages, value_targets, old_probs,
                         clip_rescaler=1.0, grad_scale=1.0, ratio_out=None, clipped_out=None):

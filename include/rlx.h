@@ -571,16 +571,6 @@ int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, lo
                       float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
                       float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
                       float *target, double mix_rate, unsigned int *ticket, void *stream);
-/* rlx_adam_tf1_step cut in two, for callers that overlap the halves with other work: _part steps one contiguous range
- * of the flat buffers (the same arithmetic, general_network.py:390-394 / TF 1.14 ApplyAdam) and leaves *parts_host
- * partial sums of squares of its gradients in `workspace`; _finish_norm sums the partials of all parts (laid out back to
- * back), writes tf.global_norm (architecture.py:194), advances the beta powers ONCE and adds acc_src[0..n_acc) onto
- * acc_dst.  Every part of a step must be launched before the finish and read the same `state`. */
-int rlx_adam_tf1_part(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
-                      float beta1, float beta2, float epsilon, const float *state, float grad_scale,
-                      float *workspace, long long workspace_floats, int *parts_host, void *stream);
-int rlx_adam_finish_norm(float *state, float beta1, float beta2, const float *workspace, int n_parts, float *norm_out,
-                         const float *acc_src, float *acc_dst, int n_acc, void *stream);
 int rlx_mix_weights(float *target, const float *online, long long n, double rate,
                     void *stream);   /* architectures/tensorflow_components/architecture.py:598-607 */
 int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,
