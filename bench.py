@@ -306,6 +306,7 @@ def run_off_policy(args, device, dist):
            "episode_stats": {k: (v if np.isfinite(v) else None) for k, v in agent.episode_statistics().items()}}
     if dist.rank == 0 and not args.no_roofline and dist.world_size == 1:
         out["roofline"] = update_roofline(agent, args.workload)
+        out["box"] = box_calibration(device)
     if dist.rank == 0 and dist.world_size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_off_policy(args.workload)
         # the reference's own per-step / per-update code, timed in the build container (tools/time_reference_cpu*.py)
@@ -416,6 +417,34 @@ def box_calibration(device):
         _rlx.gemm(M, M, M, A, B, C)
     e1.record(); e1.synchronize()
     out["gemm_4096_fp32_TFLOPs"] = round(2.0 * M ** 3 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    # beyond the 256 MiB Infinity Cache: 1 GiB device-to-device (HBM rate), and the latency of a dependent load — a
+    # pointer chase over 512 MiB (HBM) and over 16 MiB (what the Infinity Cache / L2 answer) in 256-byte strides.  These
+    # are what separates the pool's box classes (the 64 MiB copy and the MFMA rate above do not).
+    try:
+        big = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+        big2 = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+        big2.copy_(big)
+        e0.record()
+        for _ in range(4):
+            big2.copy_(big)
+        e1.record(); e1.synchronize()
+        out["copy_1GiB_GBps"] = round(2 * (1 << 30) * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del big2
+        lib = _rlx.lib()
+        res = torch.zeros(1, dtype=torch.int32, device=device)
+        for name, nodes in (("chase_512MiB_ns", 1 << 21), ("chase_16MiB_ns", 1 << 16)):
+            perm = torch.randperm(nodes, device=device, generator=torch.Generator(device=device).manual_seed(1)).int()
+            chain = big[:nodes * 256].view(torch.int32)                       # one used word per 256 bytes
+            chain[perm.long() * 64] = torch.roll(perm, -1) * 64
+            steps = 4096
+            lib.probe_chase(chain, int(perm[0].item()) * 64, 256, res, _rlx.current_stream())
+            e0.record()
+            lib.probe_chase(chain, int(perm[0].item()) * 64, steps, res, _rlx.current_stream())
+            e1.record(); e1.synchronize()
+            out[name] = round(1e6 * e0.elapsed_time(e1) / steps, 1)
+        del big
+    except Exception as e:                                                  # (a box short of memory: skip, say so)
+        out["memory_probe_error"] = str(e)[:120]
     x = torch.zeros(4, dtype=torch.float32, device=device)
     x.add_(0.0)
     torch.cuda.synchronize()

@@ -13,6 +13,16 @@ void set_error(const char *fmt, ...) {
 Profiler g_prof;
 }  // namespace rlx
 
+namespace {
+// one lane follows `steps` dependent loads through a chain of indices: the duration / steps is the latency of whatever
+// level of the memory hierarchy the chain's footprint reaches (bench.py's `box` block)
+__global__ void probe_chase_kernel(const int *__restrict__ chain, int start, int steps, int *__restrict__ out) {
+    int i = start;
+    for (int s = 0; s < steps; ++s) i = chain[i];
+    *out = i;
+}
+}  // namespace
+
 extern "C" {
 
 int rlx_abi_version(void) { return 4; }   // 2: adam_tf1_norm / sac head accumulate; 3: gemm desc batch_inner, n_fold; 4: per_sample payload rows, libm pow
@@ -60,6 +70,15 @@ int rlx_event_elapsed_ms(void *start, void *stop, float *ms_host) {
     RLX_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
     RLX_HIP(hipEventElapsedTime(ms_host, reinterpret_cast<hipEvent_t>(start),
                                 reinterpret_cast<hipEvent_t>(stop)));
+    return RLX_OK;
+}
+
+// Dependent-load latency probe (measurement utility, no reference counterpart): follows chain[i] -> i for `steps`
+// loads from `start` in ONE lane and writes the final index (so that the loads cannot be dropped).
+int rlx_probe_chase(const int *chain, int start, int steps, int *out, void *stream) {
+    RLX_REQUIRE(chain && out && start >= 0 && steps > 0, "rlx_probe_chase: bad arguments");
+    RLX_LAUNCH((probe_chase_kernel), 1, 1, 0, rlx::as_stream(stream), chain, start, steps, out);
+    RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
 

@@ -45,6 +45,10 @@ int rlx_event_destroy(void *event);
 int rlx_event_record(void *event, void *stream);
 int rlx_event_elapsed_ms(void *start, void *stop, float *ms_host); /* syncs on stop */
 
+/* Latency probe for bench.py's `box` block (no reference counterpart): one lane follows `steps` dependent 4-byte loads
+ * i = chain[i] from `start` and stores the last index in *out; time it with events. */
+int rlx_probe_chase(const int *chain, int start, int steps, int *out, void *stream);
+
 /* In-process kernel timer: between rlx_profile_begin and rlx_profile_end every kernel this library launches (EAGER
  * launches on any stream; do not arm it inside a stream capture) carries its own start / stop event pair filled from
  * the dispatch's begin / end timestamps — the per-dispatch duration a kernel trace reports (the reference has no
