@@ -137,13 +137,20 @@ __global__ void reward_filter_kernel(const float *__restrict__ in, float *__rest
 
 // K2 (a4) — ObservationRescaleToSizeFilter: skimage.transform.resize(obs, out_shape, order=1,
 // mode='reflect', anti_aliasing=False, preserve_range=True).astype('uint8')
-// (filters/observation/observation_rescale_to_size_filter.py:62-79).  scikit-image is an
-// un-vendored dependency (requirements.txt:9, >= 0.13): restated from its published warp path
-// (transform/_warps.py resize -> warp with scale = in/out, output pixel o samples the input at
-// (o + 0.5) * scale - 0.5; _shared/interpolation.pxd bilinear_interpolation: floor/ceil neighbours,
-// top/bottom blends in fp64).  For down-scaling every sample coordinate lies inside the image, so
-// the 'reflect' boundary mode never engages; coordinates are clamped for safety.  Parity unpinned
-// beyond the reference's all-ones test (tests/filters/observation/test_observation_rescale_to_size_filter.py:16-47).
+// (filters/observation/observation_rescale_to_size_filter.py:62-79).  scikit-image is an un-vendored dependency
+// (requirements.txt:9, >= 0.13); since 0.19 it executes this call as scipy.ndimage.zoom(order=1, mode='mirror',
+// grid_mode=True), whose arithmetic (ndimage/src/ni_interpolation.c NI_ZoomShift) is followed here operation by
+// operation in fp64 — no contraction (this file is compiled with -ffp-contract=off):
+//   cc = (o + 0.5) * (in / out) - 0.5;  support floor(cc), floor(cc) + 1 mirrored about 0 and in - 1;
+//   weights (1 - y, y), y = cc - floor(cc);  t = (v00 wr0) wc0 + (v01 wr0) wc1 + (v10 wr1) wc0 + (v11 wr1) wc1, in that order.
+// oracle/filters.py restates the same and is pinned to scipy bit for bit on every pixel; the kernel equals the oracle
+// bit for bit (tests/test_filter_classes.py).  scikit-image itself cannot be installed here.
+__device__ __forceinline__ int mirror_index(int i, int n) {
+    if (n == 1) return 0;
+    if (i < 0) i = -i;
+    if (i > n - 1) i = 2 * (n - 1) - i;
+    return i;
+}
 __global__ void resize_bilinear_u8_kernel(const unsigned char *__restrict__ in,
                                           unsigned char *__restrict__ out, int n, int H, int W, int C,
                                           int OH, int OW) {
@@ -155,19 +162,20 @@ __global__ void resize_bilinear_u8_kernel(const unsigned char *__restrict__ in,
         const int ox = (int)((t / C) % OW);
         const int oy = (int)((t / ((long long)C * OW)) % OH);
         const int b = (int)(t / ((long long)C * OW * OH));
-        double r = ((double)oy + 0.5) * sr - 0.5;
-        double q = ((double)ox + 0.5) * sc - 0.5;
-        r = fmin(fmax(r, 0.0), (double)(H - 1));
-        q = fmin(fmax(q, 0.0), (double)(W - 1));
-        const int r0 = (int)floor(r), r1 = (int)ceil(r);
-        const int c0 = (int)floor(q), c1 = (int)ceil(q);
-        const double dr = r - (double)r0, dc = q - (double)c0;
+        const double r = ((double)oy + 0.5) * sr - 0.5;
+        const double q = ((double)ox + 0.5) * sc - 0.5;
+        const double fr = floor(r), fq = floor(q);
+        const double yr = r - fr, yq = q - fq;
+        const double wr0 = 1.0 - yr, wr1 = yr, wc0 = 1.0 - yq, wc1 = yq;
+        const int r0 = mirror_index((int)fr, H), r1 = mirror_index((int)fr + 1, H);
+        const int c0 = mirror_index((int)fq, W), c1 = mirror_index((int)fq + 1, W);
         const unsigned char *img = in + (size_t)b * H * W * C;
         const double p00 = img[((size_t)r0 * W + c0) * C + c], p01 = img[((size_t)r0 * W + c1) * C + c];
         const double p10 = img[((size_t)r1 * W + c0) * C + c], p11 = img[((size_t)r1 * W + c1) * C + c];
-        const double top = (1 - dc) * p00 + dc * p01;
-        const double bottom = (1 - dc) * p10 + dc * p11;
-        const double v = (1 - dr) * top + dr * bottom;
+        double v = (p00 * wr0) * wc0;
+        v = v + (p01 * wr0) * wc1;
+        v = v + (p10 * wr1) * wc0;
+        v = v + (p11 * wr1) * wc1;
         out[t] = (unsigned char)(int)v;                                    // astype('uint8')
     }
 }

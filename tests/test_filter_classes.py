@@ -3,8 +3,9 @@
 Mirrors rl_coach/tests/filters/test_filters_stacking.py:19-66 (the Atari chain on all-ones frames:
 rescale -> RGB-to-Y -> uint8 -> stack; shapes and values) and
 tests/filters/observation/test_observation_rescale_to_size_filter.py:16-47 (shape / range of the
-rescaled observation), plus resize vs the oracle restatement on random images (parity unpinned:
-scikit-image is absent).
+rescaled observation), plus the resize kernel vs the oracle restatement on random images, bit for bit (the oracle is
+pinned bit for bit to scipy.ndimage.zoom, the routine scikit-image >= 0.19 executes this call with —
+tests/test_filters.py; scikit-image itself is absent).
 """
 import numpy as np
 import pytest

@@ -23,24 +23,24 @@ def test_oracle_rgb_to_y_uint8_matches_reference(golden):
     assert np.array_equal(F.to_uint8(obs, -100, 100), ((obs + 100) / 200 * 255).astype('uint8'))
 
 
-@pytest.mark.parametrize("H,W,C", [(210, 160, None), (210, 160, 3), (96, 96, None), (50, 70, None), (84, 84, None)])
-def test_oracle_resize_matches_scipy_zoom(H, W, C):
+@pytest.mark.parametrize("H,W,C,out", [(210, 160, None, (84, 84)), (210, 160, 3, (84, 84)), (96, 96, None, (84, 84)),
+                                       (50, 70, None, (84, 84)), (84, 84, None, (84, 84)), (480, 640, 3, (84, 84)),
+                                       (33, 47, None, (61, 29)), (250, 160, 1, (84, 84)), (1, 9, None, (3, 4))])
+def test_oracle_resize_equals_scipy_zoom_bit_for_bit(H, W, C, out):
     """ObservationRescaleToSizeFilter's skimage.transform.resize(obs, shape, anti_aliasing=False, preserve_range=True)
-    (observation_rescale_to_size_filter.py:62-79; order 1, mode 'reflect') against an independent implementation of the
-    same sampling rule: scipy.ndimage.zoom(order=1, mode='reflect', grid_mode=True) — pixel centres mapped by
-    (o + 0.5) * in / out - 0.5, the routine scikit-image >= 0.19's resize itself delegates to for this call.  scikit-image
-    is not installed, so this is what pins oracle.filters.resize_bilinear_u8 beyond the reference's all-ones test: equal
-    after the uint8 truncation except where the interpolated value sits on an integer and the two float paths round to
-    either side of it (1 LSB, < 0.1 % of the pixels)."""
+    (observation_rescale_to_size_filter.py:62-79; order 1, mode 'reflect').  scikit-image (>= 0.19) executes exactly
+    this call as scipy.ndimage.zoom(image.astype(float), out / in, order=1, mode='mirror', grid_mode=True) — numpy.pad's
+    'reflect' is ndimage's 'mirror' — and scipy is installed: oracle.filters.resize_bilinear_u8 restates that routine's
+    arithmetic and must equal it on EVERY pixel after the uint8 truncation, down-scaling, up-scaling (where the mirror
+    boundary engages) and with channels.  scikit-image itself is not installable here (parity with it: unpinned)."""
     import scipy.ndimage as ndi
     rng = np.random.RandomState(H * 7 + W)
     img = rng.randint(0, 256, size=(H, W) if C is None else (H, W, C)).astype(np.uint8)
-    mine = F.resize_bilinear_u8(img, (84, 84))
-    zf = (84 / H, 84 / W) + (() if C is None else (1,))
-    ref = ndi.zoom(img.astype(np.float64), zf, order=1, mode='reflect', grid_mode=True).astype(np.uint8)
+    mine = F.resize_bilinear_u8(img, out)
+    zf = (out[0] / H, out[1] / W) + (() if C is None else (1,))
+    ref = ndi.zoom(img.astype(np.float64), zf, order=1, mode='mirror', grid_mode=True).astype(np.uint8)
     assert mine.shape == ref.shape and mine.dtype == np.uint8
-    d = np.abs(mine.astype(int) - ref.astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())
+    np.testing.assert_array_equal(mine, ref)
 
 
 def test_oracle_reward_filters_match_reference(golden):
