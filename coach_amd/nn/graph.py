@@ -159,14 +159,22 @@ class Context:
 
     # ---- deferred split-K reductions of the weight gradients (rlx_gemm_defer): every dW product of a backward pass
     # leaves its partial sums in its own slice of an arena; ONE launch sums them all when the pass ends.
+    # ONE arena per device, shared by every network's context: a backward pass flushes its reductions before it returns
+    # and the passes of one process queue on one stream, so two contexts never have partial sums outstanding together
+    # (128 MB once, instead of once per network).  Deferral does not change a weight gradient by a bit: the reduce
+    # launch sums every job's partials in the order the immediate reduction would (csrc/gemm.hip splitk_reduce_jobs_kernel).
     ARENA_FLOATS = 1 << 25
+    _arenas = {}
 
     def begin_deferring(self):
         """-> True if this call opened the deferral (its caller must flush)."""
         if self.deferred is not None:
             return False
         if self.arena is None:
-            self.arena = torch.empty(self.ARENA_FLOATS, dtype=torch.float32, device=self.device)
+            key = str(self.device)
+            if key not in Context._arenas:
+                Context._arenas[key] = torch.empty(self.ARENA_FLOATS, dtype=torch.float32, device=self.device)
+            self.arena = Context._arenas[key]
         self.deferred, self._arena_off = [], 0
         return True
 
