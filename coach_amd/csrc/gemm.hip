@@ -1513,19 +1513,16 @@ __global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g
 }
 
 // The outstanding reductions of several deferred products in ONE launch (rlx_splitk_reduce_jobs): blockIdx.z = job,
-// blockIdx.y = batch entry of the job, blockIdx.x = 64 float4 output groups; per job the scheme launch_splitk_reduce
-// would have picked for it — 16 split groups per output group for more than 16 splits, else 4 (the other wave groups
-// of the workgroup idle) — partials of group q summed in increasing split order, groups combined in the fixed order
-// ((s0 + s1) + s2) + ...: a deferred reduction gives bit for bit the weight gradient of the immediate one.
-// Plain store: a weight gradient has no epilogue.
+// blockIdx.y = batch entry of the job, blockIdx.x = 64 float4 output groups; the scheme of splitk_reduce4_kernel<16>
+// (16 split groups per output group, partials of group q summed in increasing split order, groups combined in the
+// fixed order ((s0 + s1) + s2) + ...).  Plain store: a weight gradient has no epilogue.
 struct ReduceJobs {
     rlx_splitk_job job[RLX_MAX_SPLITK_JOBS];
 };
 __global__ void __launch_bounds__(1024) splitk_reduce_jobs_kernel(const ReduceJobs jobs) {
-    constexpr int SGMAX = 16;
-    __shared__ float4 part[SGMAX][64];
+    constexpr int SG = 16;
+    __shared__ float4 part[SG][64];
     const rlx_splitk_job &g = jobs.job[blockIdx.z];
-    const int SG = g.splits > 16 ? 16 : 4;            // launch_splitk_reduce's choice for this product
     const int batch = blockIdx.y;
     if (batch >= g.batch) return;
     const int mn4 = (g.M * g.N) >> 2;
@@ -1535,7 +1532,7 @@ __global__ void __launch_bounds__(1024) splitk_reduce_jobs_kernel(const ReduceJo
     const size_t mn = (size_t)g.M * g.N;
     const float4 *ws = reinterpret_cast<const float4 *>(g.partials + (size_t)batch * g.splits * mn);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gid < mn4 && q < SG) {
+    if (gid < mn4) {
         int k = q;
         for (; k + 3 * SG < g.splits; k += 4 * SG) {    // 4 independent loads in flight per thread
             const float4 a = ws[(size_t)k * mn4 + gid];
@@ -1556,6 +1553,7 @@ __global__ void __launch_bounds__(1024) splitk_reduce_jobs_kernel(const ReduceJo
     __syncthreads();
     if (q == 0 && gid < mn4) {
         float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
         for (int t = 1; t < SG; ++t) {
             const float4 p = part[t][ox];
             v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
@@ -1576,7 +1574,7 @@ __global__ void __launch_bounds__(1024) splitk_reduce_jobs_kernel(const ReduceJo
             __syncthreads();
             const int n = n0 + ox;
             float t = 0.f;
-            if (n < g.N && q < SG)
+            if (n < g.N)
                 for (int k = q; k < g.splits; k += SG)
                     t += g.colsum_partials[((size_t)batch * g.splits + k) * g.N + n];
             cpart[q * 64 + ox] = t;

@@ -161,8 +161,11 @@ class Context:
     # leaves its partial sums in its own slice of an arena; ONE launch sums them all when the pass ends.
     # ONE arena per device, shared by every network's context: a backward pass flushes its reductions before it returns
     # and the passes of one process queue on one stream, so two contexts never have partial sums outstanding together
-    # (128 MB once, instead of once per network).  Deferral does not change a weight gradient by a bit: the reduce
-    # launch sums every job's partials in the order the immediate reduction would (csrc/gemm.hip splitk_reduce_jobs_kernel).
+    # (128 MB once, instead of once per network).  Deferral changes the GROUPING of a reduction's additions for products
+    # with <= 16 splits (the one launch always sums 16 split groups, the immediate reduction 4 for those): same partials,
+    # last-bit differences in such a weight gradient (tests/test_gemm.py states the tolerance).  Making the two groupings
+    # equal was tried and undone: it moves every network's trajectory by those last bits, and the device-vs-recorded-
+    # reference loop tests (tests/test_reference_image_loops.py) pin action sequences that contain fp32 near-ties.
     ARENA_FLOATS = 1 << 25
     _arenas = {}
 
