@@ -18,24 +18,30 @@ def last_update(path):
 
 
 def mfma_table(busy_csv, active_csv, out):
-    """rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES and --pmc GRBM_GUI_ACTIVE passes of the same run -> per kernel of the
-    last update: MFMA busy cycles (summed over the chip's 1024 SIMDs) / (GPU-active cycles x 1024) = the fraction of
-    the matrix pipes' cycles spent issuing MFMAs while the kernel ran (the gfx94x MfmaUtil formula; gfx950 has no
-    derived-counter section in ROCm 7.2, MI355X_MICROARCH.md)."""
+    """rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES pass (the dispatch records carry start / end timestamps)
+    -> per kernel of the last update: MFMA busy cycles (summed over the chip's 1024 SIMDs; = MFMA instructions x their
+    64 / 16 ... cycles) / (dispatch duration x 2.4 GHz x 1024 SIMDs) = the fraction of the matrix pipes' cycles spent
+    on MFMAs while the kernel ran.  2.4 GHz is the top of the clock range, so the figure is a lower bound where the clock
+    sat lower.  (GRBM_GUI_ACTIVE, the denominator of the gfx94x MfmaUtil formula, is collected too and kept in the rows:
+    on gfx950 / ROCm 7.2 it does not scale with the dispatch duration — 260 k 'cycles' for a 7 us fill kernel — so it is
+    not used.)  Durations are those of THIS pass: a counter-collection run serialises dispatches, kernels run cold."""
     b, a = last_update(busy_csv), last_update(active_csv)
     assert [r["Kernel_Name"] for r in b] == [r["Kernel_Name"] for r in a]
-    rows, tb, ta = [], 0.0, 0.0
+    rows, tb, tt = [], 0.0, 0.0
     for x, y in zip(b, a):
         busy, act = float(x["Counter_Value"]), float(y["Counter_Value"])
+        dur_ns = float(x["End_Timestamp"]) - float(x["Start_Timestamp"])
         rows.append({"name": x["Kernel_Name"][:110], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": act,
-                     "mfma_util": round(busy / (act * 1024.0), 4) if act else None})
+                     "duration_us": round(dur_ns / 1e3, 2),
+                     "mfma_util": round(busy / (dur_ns * 2.4 * 1024.0), 4) if dur_ns > 0 else None})
         if "gemm_" in x["Kernel_Name"] or "splitk_reduce" in x["Kernel_Name"]:
             tb += busy
-            ta += act
-    res = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (separate passes) on "
+            tt += dur_ns
+    res = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES (dispatch timestamps of the same pass) on "
                      "tools/ppo_update_once.py, last eager minibatch update",
-           "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)",
-           "gemm_family_mfma_util": round(tb / (ta * 1024.0), 4) if ta else None, "kernels": rows}
+           "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration [ns] * 2.4 cycles/ns * 256 CUs * 4 SIMDs)",
+           "gemm_family_mfma_util": round(tb / (tt * 2.4 * 1024.0), 4) if tt else None,
+           "gemm_family_us_in_this_pass": round(tt / 1e3, 1), "kernels": rows}
     json.dump(res, open(out, "w"), indent=1)
     print({k: v for k, v in res.items() if k != "kernels"})
     for r in rows:
