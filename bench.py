@@ -549,8 +549,8 @@ def gemm_roofline(agent, reps=20):
             "traffic_unit": "bytes per library call of the GEMM family, split-K reduces included (2 x FETCH_SIZE + WRITE_SIZE, "
                             "PMC passes of tools/ppo_update_once.py); operands (A as addressed) and results of the %d "
                             "products are %.1fe6 bytes per call" % (n_products, operand_bytes / 1e6 / n),
-            "kernel": "gemm_fast_kernel / gemm_fast_pair_kernel / gemm_win_kernel + split-K reduces (fp32 MFMA 32x32x2): "
-                      "%d products in %d library calls per minibatch update" % (n_products, n),
+            "kernel": "gemm_dma_kernel / gemm_dma_pair_kernel (LDS-DMA ring) and gemm_fast_kernel (uint8 frames) + split-K "
+                      "reduces (fp32 MFMA 32x32x2): %d products in %d library calls per minibatch update" % (n_products, n),
             "flops_per_update": total_flops, "flops_per_launch": total_flops / n,
             "avg_launch_us": round(gemm_us / max(gemm_launches, 1), 2),
             "update_us_by_family": fam, "kernel_launches_per_update": round(launches, 1),

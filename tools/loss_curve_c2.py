@@ -37,20 +37,21 @@ def hip_side(args):
         SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
     dev = torch.device("cuda:0")
     env = SyntheticVectorEnvironment(SyntheticVectorEnvironmentParameters("image", N_ENV, FRAME, A, episode_length=L,
-                                                                         seed=1234), dev)
+                                                                         seed=1234 + args.seed), dev)
     p = ClippedPPOAgentParameters()
-    p.seed = 0
+    p.seed = args.seed
     p.algorithm.num_consecutive_playing_steps = EnvironmentSteps(PLAYING)
     p.algorithm.optimization_epochs = args.epochs
     p.network_wrappers["main"].batch_size = B
     agent = ClippedPPOAgent(p, env, dev)
     os.makedirs(args.dir, exist_ok=True)
-    arrays = agent.networks["main"].params.named_arrays()
-    np.savez_compressed(os.path.join(args.dir, "init.npz"), **{"%s|%d" % (k, t): a for k, v in arrays.items()
-                                                                for t, a in enumerate(v)})
+    if not args.no_init:           # (13.5 MB per seed; the oracle side can rebuild the same arrays on the CPU: rebuild_init)
+        arrays = agent.networks["main"].params.named_arrays()
+        np.savez_compressed(os.path.join(args.dir, "init.npz"), **{"%s|%d" % (k, t): a for k, v in arrays.items()
+                                                                    for t, a in enumerate(v)})
     with open(os.path.join(args.dir, "rng_state.pkl"), "wb") as f:
         pickle.dump({"random": random.getstate(), "numpy": np.random.get_state(), "epochs": args.epochs,
-                     "iterations": args.iterations}, f)
+                     "iterations": args.iterations, "seed": args.seed}, f)
     res, acts = [], []
     t0 = time.perf_counter()
     for it in range(args.iterations):
@@ -68,24 +69,55 @@ def hip_side(args):
                                                              time.perf_counter() - t0))
 
 
+def rebuild_init(seed):
+    """The initial weights ClippedPPOAgent(seed) builds, rebuilt on the CPU without the GPU library: the agent seeds the
+    host generators (agents/agent.py:49-55), ClippedPPONet lays out torso x2 / value head / policy head and initialises
+    them from RandomState(seed) — the value head's normalized-columns initialiser from the GLOBAL np.random stream
+    (heads/head.py:27-33).  Checked bit for bit against the device side's own init.npz (--check-init)."""
+    from coach_amd.nn import graph as G, networks as NW
+    random.seed(seed)
+    np.random.seed(seed)
+    params = G.FlatParams()
+    torso, feat = NW.build_torso(params, "main", FRAME + (4,), "tanh", 2, "Medium", "Medium")
+    vh = G.Dense(params, "main/v_head/dense", feat, 1, None, 1, init=G.normalized_columns(1.0))
+    ph = G.Dense(params, "main/ppo_head/policy_fc", feat, A, None, 1)
+    params.finalize("cpu")
+    rng = np.random.RandomState(seed)
+    for m in (torso, vh, ph):
+        m.initialize(rng)
+    return params.named_arrays()
+
+
 def oracle_side(args):
     from oracle.agents import ClippedPPOAgentOracle
     from oracle.synth_env import SynthVecEnv
     with open(os.path.join(args.dir, "rng_state.pkl"), "rb") as f:
         st = pickle.load(f)
-    fx = np.load(os.path.join(args.dir, "init.npz"))
-    arrays = {}
-    for k in fx.files:
-        name, t = k.rsplit("|", 1)
-        arrays.setdefault(name, {})[int(t)] = fx[k]
-    arrays = {k: [v[t] for t in sorted(v)] for k, v in arrays.items()}
+    init = os.path.join(args.dir, "init.npz")
+    if os.path.exists(init):
+        fx = np.load(init)
+        arrays = {}
+        for k in fx.files:
+            name, t = k.rsplit("|", 1)
+            arrays.setdefault(name, {})[int(t)] = fx[k]
+        arrays = {k: [v[t] for t in sorted(v)] for k, v in arrays.items()}
+        if args.check_init:
+            mine = rebuild_init(st.get("seed", 0))
+            assert sorted(mine) == sorted(arrays)
+            for k in arrays:
+                for a, b in zip(arrays[k], mine[k]):
+                    assert a.dtype == b.dtype and np.array_equal(a, b), k
+            print("rebuild_init(%d) == init.npz of the device side, every tensor bit for bit" % st.get("seed", 0))
+            return
+    else:
+        arrays = rebuild_init(st.get("seed", 0))
     if args.perturb_ulp:
         # the noise floor: the SAME oracle from weights that differ in the last bit of one convolution weight per tower
         k = sorted(n for n in arrays if n.endswith("kernel"))[0]
         for a in arrays[k]:
             a.flat[0] = np.nextafter(a.flat[0], np.float32(np.inf), dtype=np.float32)
         print("perturbed by one ulp: %s[0] of every tower" % k, flush=True)
-    o = ClippedPPOAgentOracle(arrays, SynthVecEnv(0, N_ENV, FRAME[0] * FRAME[1], L, 1234), A, batch_size=B,
+    o = ClippedPPOAgentOracle(arrays, SynthVecEnv(0, N_ENV, FRAME[0] * FRAME[1], L, 1234 + st.get("seed", 0)), A, batch_size=B,
                               playing_steps=PLAYING, epochs=st["epochs"])
     o.reset(FRAME)
     random.setstate(st["random"])
@@ -146,8 +178,66 @@ def compare(args):
         print(nm, wins[nm]["max_window_rel_diff"])
 
 
+def ensemble(args):
+    """K independent experiments (agent seed s: initial weights and host streams; env seed 1234 + s), each run on both
+    sides from identical starting points (<dir>/seed<s>/{hip,oracle}.npz).  Per window of `--window` iterations and per
+    signal: mean and standard error over the seeds on either side, the relative difference of the two ENSEMBLE MEANS
+    and that difference in units of its own standard error (paired over the seeds: the two sides of a seed share
+    everything up to the first differently sampled action)."""
+    seeds = [int(x) for x in args.seeds.split(",")]
+    W = args.window
+    per_side = {"hip": [], "oracle": []}
+    first_div = {}
+    n = None
+    for sd in seeds:
+        d = os.path.join(args.dir, "seed%d" % sd)
+        h, o = np.load(os.path.join(d, "hip.npz")), np.load(os.path.join(d, "oracle.npz"))
+        k = min(len(h["results"]), len(o["results"]))
+        n = k if n is None else min(n, k)
+        per_side["hip"].append(h["results"].mean(1))
+        per_side["oracle"].append(o["results"].mean(1))
+        steps = k * (PLAYING // N_ENV)
+        diff = np.nonzero((h["actions"][:steps] != o["actions"][:steps]).any(1))[0]
+        first_div[sd] = int(diff[0]) if diff.size else None
+    k = n // W * W
+    hip = np.stack([x[:k] for x in per_side["hip"]])            # [seed, iteration, signal]
+    orc = np.stack([x[:k] for x in per_side["oracle"]])
+    K = len(seeds)
+    out = {"workload": "C2: Clipped PPO, %d vectorized envs, 84x84x4 uint8 observations, rollout %d, minibatch %d; "
+                       "%d seeds x %d iterations (%d env-steps each)" % (N_ENV, PLAYING, B, K, k, k * PLAYING),
+           "seeds": seeds, "window_iterations": W,
+           "first_vector_step_with_a_different_sampled_action": first_div, "signals": {}}
+    for j, nm in enumerate(NAMES):
+        hw = hip[:, :, j].reshape(K, -1, W).mean(2)             # [seed, window]
+        ow = orc[:, :, j].reshape(K, -1, W).mean(2)
+        hm, om = hw.mean(0), ow.mean(0)
+        hse, ose = hw.std(0, ddof=1) / np.sqrt(K), ow.std(0, ddof=1) / np.sqrt(K)
+        d = hw - ow                                             # paired differences
+        dse = d.std(0, ddof=1) / np.sqrt(K)
+        rel = np.abs(hm - om) / np.maximum(np.abs(om), 1e-12)
+        out["signals"][nm] = {
+            "hip_mean": [float(x) for x in hm], "hip_se": [float(x) for x in hse],
+            "oracle_mean": [float(x) for x in om], "oracle_se": [float(x) for x in ose],
+            "rel_diff_of_ensemble_means": [round(float(x), 6) for x in rel],
+            "oracle_relative_se": [round(float(x), 6) for x in ose / np.maximum(np.abs(om), 1e-12)],
+            "paired_diff_in_standard_errors": [round(float(x), 3) for x in d.mean(0) / np.maximum(dse, 1e-300)],
+            "max_rel_diff_of_ensemble_means": float(rel.max()),
+            "within_1_percent_in_every_window": bool((rel <= 0.01).all()),
+            "within_two_standard_errors_in_every_window": bool((np.abs(d.mean(0)) <= 2 * np.maximum(dse, 1e-300)).all())}
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+    for nm in NAMES:
+        s_ = out["signals"][nm]
+        print("%-14s max rel diff of ensemble means %.4f   (oracle's own relative s.e. up to %.4f)   within 1 %%: %s   "
+              "within 2 s.e.: %s" % (nm, s_["max_rel_diff_of_ensemble_means"], max(s_["oracle_relative_se"]),
+                                    s_["within_1_percent_in_every_window"], s_["within_two_standard_errors_in_every_window"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0, help="agent seed (weights, host streams); the env seed is 1234 + seed")
+    ap.add_argument("--ensemble", action="store_true", help="compare <dir>/seed<s>/ for s in --seeds")
+    ap.add_argument("--seeds", default="0,1,2,3,4,5,6,7")
     ap.add_argument("--side", choices=["hip", "oracle"])
     ap.add_argument("--compare", action="store_true")
     ap.add_argument("--dir", default="gpurun_out/lc_c2")
@@ -155,13 +245,24 @@ def main():
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--window", type=int, default=7)
     ap.add_argument("--out", default="profiles/r03_loss_curve_c2.json")
+    ap.add_argument("--hip-seeds", default="", help="hip side: run these seeds in turn into <dir>/seed<s>/")
+    ap.add_argument("--no-init", action="store_true", help="hip side: do not write init.npz (the oracle side rebuilds it)")
+    ap.add_argument("--check-init", action="store_true",
+                    help="oracle side: only check that rebuild_init equals the device side's init.npz")
     ap.add_argument("--perturb-ulp", action="store_true",
                     help="oracle side: start from weights one ulp away in one element per tower (-> oracle_ulp.npz)")
     ap.add_argument("--first", default="hip.npz",
                     help="compare: the run set against oracle.npz (oracle_ulp.npz = the oracle against itself)")
     args = ap.parse_args()
-    if args.compare:
+    if args.ensemble:
+        ensemble(args)
+    elif args.compare:
         compare(args)
+    elif args.side == "hip" and args.hip_seeds:
+        base = args.dir
+        for sd in (int(x) for x in args.hip_seeds.split(",")):       # several experiments in one process (one import)
+            args.seed, args.dir = sd, os.path.join(base, "seed%d" % sd)
+            hip_side(args)
     elif args.side == "hip":
         hip_side(args)
     else:
