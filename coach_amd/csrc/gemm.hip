@@ -337,10 +337,19 @@ struct FastTile {
 // Shared by the register-staged main loop (gemm_fast_body) and the LDS-DMA ring main loop (gemm_dma_body): the C/D layout
 // of the accumulators does not depend on how the operands reached the MFMAs.  `smem` must no longer be read by anyone
 // (KW == 1 callers pass through the __syncthreads() of the staging patches below).
-template <int BM, int BN, int TM, int TN, int KW, bool A_WIN>
+// The epilogue's own operands — the tile's bias and the four activation-derivative float4s of a lane — when the caller
+// requested them BEFORE its main loop (gemm_dma_body): inside the update they are cold lines, and fetched here their
+// round trip sits exposed between the last MFMA and the first store (conv1 / conv2 forward on a slow-class box:
+// 8.4-8.9 us of epilogue against 2.0-3.7 us warm, profiles/r04_ab_gemm_pipeline.txt).
+struct EpiPre {
+    float4 bv, av[4];
+};
+template <int BM, int BN, int TM, int TN, int KW, bool A_WIN, bool PRE = false>
 __device__ __forceinline__ void fast_epilogue(const GemmDev &g, f32x16 (&acc)[TM][TN], float *const smem, const int m0,
                                               const int n0, const int batch, const int split, const bool do_colsum,
-                                              const float csum, unsigned long long *const stamp) {
+                                              const float csum, unsigned long long *const stamp,
+                                              const EpiPre *const pre = nullptr) {
+    static_assert(!PRE || (TM == 1 && TN == 1 && !A_WIN), "prefetched epilogue operands: one tile per wave");
     constexpr int WN = BN / (32 * TN);
     constexpr int WMN = (BM / (32 * TM)) * WN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -409,7 +418,9 @@ __device__ __forceinline__ void fast_epilogue(const GemmDev &g, f32x16 (&acc)[TM
                 const int etw = (!ws && g.fold) ? ecol / g.fold : 0, ecl = (!ws && g.fold) ? ecol % g.fold : ecol;
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 av4[4];
-                if (!ws && g.bias && ecol_ok)
+                if (PRE)
+                    bv = pre->bv;
+                else if (!ws && g.bias && ecol_ok)
                     bv = *reinterpret_cast<const float4 *>(
                         g.fold ? g.bias + (size_t)etw * g.bias_batch_stride + ecl :
                         g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + ecol);
@@ -417,7 +428,9 @@ __device__ __forceinline__ void fast_epilogue(const GemmDev &g, f32x16 (&acc)[TM
                 for (int it = 0; it < 4; ++it) {
                     const int erow = m0 + wm * (32 * TM) + 32 * i + ((it * 64 + lane) >> 3);
                     av4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (A_WIN) {
+                    if (PRE) {
+                        av4[it] = pre->av[it];
+                    } else if (A_WIN) {
                         if (aux && ecol_ok && crow[it] >= 0)
                             av4[it] = *reinterpret_cast<const float4 *>(aux + crow[it] + ecol);
                     } else if (!ws && aux && ecol_ok && erow < g.M)
@@ -995,6 +1008,28 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
         b_off_o[0] = g.fold ? (long long)(nq / g.fold) * g.b.batch_stride + (long long)(nq % g.fold) * g.b.stride_o
                             : (long long)nq * g.b.stride_o;
     }
+    // the epilogue's operands, requested now (see EpiPre): same addresses and conditions as fast_epilogue's own loads
+    EpiPre pre;
+    pre.bv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) pre.av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool pre_ok = g.vec_epi && g.splits == 1;        // (split-K partials have no epilogue operands)
+    if (pre_ok) {
+        const int ecol = n0 + wn * 32 + (lane & 7) * 4;
+        const bool ecol_ok = wk == 0 && ecol < g.N;
+        if (g.bias && ecol_ok)
+            pre.bv = *reinterpret_cast<const float4 *>(
+                g.fold ? g.bias + (size_t)(ecol / g.fold) * g.bias_batch_stride + ecol % g.fold
+                       : g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + ecol);
+        if (g.aux && ecol_ok) {
+            const float *aux = g.aux + (size_t)batch * g.aux_batch_stride;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int erow = m0 + wm * 32 + ((it * 64 + lane) >> 3);
+                if (erow < g.M) pre.av[it] = *reinterpret_cast<const float4 *>(aux + (size_t)erow * g.aux_ld + ecol);
+            }
+        }
+    }
     if (A_TAB) {
         // the chunk's reduction-index offsets, requested together with the row offsets above (one round trip)
         for (int i = tid; i < kend - kbeg; i += kThreads) tab_s[i] = g.a.tab_r[kbeg + i];
@@ -1104,7 +1139,10 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     }
     __syncthreads();                                          // the ring becomes the epilogue's staging area
     if (stamp) stamp[2] = wall_clock64();
-    fast_epilogue<BM, BN, 1, 1, KW, false>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp);
+    if (pre_ok)
+        fast_epilogue<BM, BN, 1, 1, KW, false, true>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp, &pre);
+    else
+        fast_epilogue<BM, BN, 1, 1, KW, false>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp);
 }
 
 template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB>
