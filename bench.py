@@ -773,6 +773,12 @@ def main():
         roof, shapes = gemm_roofline(agent)
         out["roofline"] = roof
         out["box"] = box_calibration(device)
+        # the one number that separates the pool's box classes on identical code: the first convolution's forward
+        # product (uint8 frames, cold operands) as it runs INSIDE the update — 19 us on fast-class boxes, 31 us on slow
+        conv1 = [k for k in roof["update_kernels"] if k["kernel"].startswith("gemm_fast_kernel") and
+                 k["kernel"].endswith("true, true, false, true>")]
+        if conv1:
+            out["box"]["conv1_forward_in_update_us"] = conv1[0]["avg_us"]
         if args.shapes:
             for s in shapes:
                 print(json.dumps(s), file=sys.stderr)
