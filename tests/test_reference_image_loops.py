@@ -73,6 +73,7 @@ def test_device_dqn_image_loop_equals_real_reference_agent_loop(dev, variant):
     from coach_amd.memories.memory import MemoryGranularity
     from coach_amd.memories.non_episodic.prioritized_experience_replay import PrioritizedExperienceReplayParameters
     from coach_amd.schedules import LinearSchedule
+    import torch
     fx = np.load(os.path.join(GOLDEN, "dqn_image_loop.npz"))
     H, A, L, B, CAP, HEATUP, TRAIN, SEED, STACK = (int(x) for x in fx["hp"])
     env = SyntheticVectorEnvironment(
@@ -94,7 +95,7 @@ def test_device_dqn_image_loop_equals_real_reference_agent_loop(dev, variant):
     random.seed(SEED)
     np.random.seed(SEED)
     agent.exploration_policy.current_random_value[:] = np.random.rand()
-    actions, visible, keys = [], [], []
+    actions, visible, keys, q_gap = [], [], [], []
     collate = agent.memory.collate
 
     def logged(d, B_):
@@ -107,6 +108,12 @@ def test_device_dqn_image_loop_equals_real_reference_agent_loop(dev, variant):
         agent.phase = RunPhase.HEATUP if step < HEATUP else RunPhase.TRAIN
         agent.act()
         actions.append(int(agent.actions.cpu()[0]))
+        q = getattr(agent, "_q_act", None)                   # the Q values the greedy choice of this step was made from
+        if q is not None and step >= HEATUP:
+            top = torch.sort(q[0].double(), descending=True).values
+            q_gap.append(float((top[0] - top[1]) / max(float(top.abs().max()), 1e-30)))
+        else:
+            q_gap.append(1.0)
         if step >= HEATUP:
             agent.train()
     agent.check_status()
@@ -119,4 +126,12 @@ def test_device_dqn_image_loop_equals_real_reference_agent_loop(dev, variant):
     # uniform replay: every batch; prioritized: fp32 TD errors may move a stratified draw across a leaf boundary late in
     # the run (see tests/test_reference_loop.py)
     assert same == len(keys) if variant == "uniform" else same >= 20, same
-    np.testing.assert_array_equal(actions[:HEATUP + same], fx[variant + "|actions"][:HEATUP + same])
+    # The greedy action is an argmax over fp32 Q values: where the recorded reference loop and the device pick different
+    # actions, the device's two best Q values must be an fp32 NEAR-TIE (relative gap < 1e-5: a different summation order
+    # inside a GEMM is enough to swap them) — a first difference anywhere else is a failure.  Up to that step the action
+    # sequences must be identical, and it may not come early.
+    ref_actions = fx[variant + "|actions"][:HEATUP + same]
+    diff = np.nonzero(np.asarray(actions[:HEATUP + same]) != ref_actions)[0]
+    if diff.size:
+        t = int(diff[0])
+        assert t >= HEATUP + 10 and q_gap[t] < 1e-5, (t, q_gap[t], actions[t], int(ref_actions[t]))
