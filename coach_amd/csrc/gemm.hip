@@ -1036,35 +1036,55 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
         __syncthreads();
     }
 
-    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem)) + (unsigned)wid * 1024u;
-    auto issue = [&](int s_idx) {
-        const int k0 = kbeg + s_idx * BK;
-        const unsigned dst = lds0 + (unsigned)((s_idx & (D - 1)) * SLAB) * 4u;
+    // ---- the requests of one slab.  Everything that does not change from slab to slab is computed once: the LDS
+    // destination (wave-uniform, an SGPR plus compile-time offsets), the k of the lane inside a slab, the part of the
+    // source address that belongs to the outer index; what changes is ONE pointer per request, advanced by a constant
+    // (plain strides) or re-derived from one LDS table word (im2col).  `FULL` slabs lie inside the K chunk for every
+    // lane: no validity test, no zero-block select — the tail (a partial slab, and the requests of non-existent slabs
+    // that keep the vmcnt arithmetic uniform) takes the general form.  (The first version recomputed every address from
+    // scratch: 9-11 VALU instructions per MFMA, profiles/r04_pmc_wave_states.json.)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem)) + (unsigned)wid * 1024u);
+    const int len = kend - kbeg;
+    int ak[NA_I], bk[NB_I];
+    const float *ap[NA_I], *bp[NB_I];                       // A non-TAB / B: the source of the NEXT slab to request
+    const float *arow[A_TAB ? NA_I : 1];                    // A im2col: base + outer-index offset (the k offset comes from tab_s)
+#pragma unroll
+    for (int p = 0; p < NA_I; ++p) {
+        ak[p] = A_VEC_RED ? a_k : tid / (BM / 4) + (1024 / BM) * p;
+        const float *base = abase + a_off_o[A_VEC_RED ? p : 0];
+        if (A_TAB) arow[p] = base;
+        ap[p] = A_TAB ? base : base + (long long)(kbeg + ak[p]) * g.a.stride_r;
+    }
+#pragma unroll
+    for (int p = 0; p < NB_I; ++p) {
+        bk[p] = B_VEC_RED ? b_k : tid / (BN / 4) + (1024 / BN) * p;
+        bp[p] = bbase + b_off_o[B_VEC_RED ? p : 0] + (long long)(kbeg + bk[p]) * g.b.stride_r;
+    }
+    const long long a_step = (long long)BK * g.a.stride_r, b_step = (long long)BK * g.b.stride_r;
+    const int nfull = len / BK;                             // slabs [0, nfull) are inside the chunk for every lane
+    auto issue = [&](const int s_idx, const int buf) {      // buf is a compile-time constant at every call site
+        const unsigned dst = lds0 + (unsigned)(buf * SLAB) * 4u;
+        const bool full = s_idx < nfull;                    // wave-uniform
 #pragma unroll
         for (int p = 0; p < NA_I; ++p) {
             const float *src;
-            if (A_VEC_RED) {
-                const int k = k0 + a_k;
-                const long long ro = A_TAB ? (long long)tab_s[min(k, kend - 4) - kbeg] : (long long)k * g.a.stride_r;
-                src = pick(abase + a_off_o[p] + ro, k < kend);
+            if (A_TAB) {
+                const int ti = s_idx * BK + ak[p];
+                const int tc = full ? ti : min(ti, len - (A_VEC_RED ? 4 : 1));
+                src = arow[p] + (long long)tab_s[tc];
+                if (!full) src = pick(src, ti < len);
             } else {
-                const int k = k0 + tid / (BM / 4) + (1024 / BM) * p;
-                const long long ro = A_TAB ? (long long)tab_s[min(k, kend - 1) - kbeg] : (long long)k * g.a.stride_r;
-                src = pick(abase + a_off_o[0] + ro, k < kend);
+                src = full ? ap[p] : pick(ap[p], s_idx * BK + ak[p] < len);
+                ap[p] += a_step;
             }
-            dma16(src, __builtin_amdgcn_readfirstlane(dst + 4096u * p));
+            dma16(src, dst + 4096u * p);
         }
 #pragma unroll
         for (int p = 0; p < NB_I; ++p) {
-            const float *src;
-            if (B_VEC_RED) {
-                const int k = k0 + b_k;
-                src = pick(bbase + b_off_o[p] + (long long)k * g.b.stride_r, k < kend);
-            } else {
-                const int k = k0 + tid / (BN / 4) + (1024 / BN) * p;
-                src = pick(bbase + b_off_o[0] + (long long)k * g.b.stride_r, k < kend);
-            }
-            dma16(src, __builtin_amdgcn_readfirstlane(dst + (unsigned)A_SLAB * 4u + 4096u * p));
+            const float *src = full ? bp[p] : pick(bp[p], s_idx * BK + bk[p] < len);
+            bp[p] += b_step;
+            dma16(src, dst + (unsigned)A_SLAB * 4u + 4096u * p);
         }
     };
 
@@ -1074,30 +1094,37 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     const bool do_colsum = g.colsum != nullptr && by == 0 && tid < BN;
     float csum = 0.f;
 
-    // this wave group's MFMA steps of a slab: k-quads q = wk * QS .. + QS - 1, each 8 k (4 per half-wave)
+    // this wave group's MFMA steps of a slab: k-quads q = wk * QS .. + QS - 1, each 8 k (4 per half-wave).  The LDS
+    // read addresses are lane constants (computed here) plus compile-time offsets (buffer, quad, step).
     constexpr int QS = 4 / KW;
     const int a_row = wm * 32 + l31, b_col = wn * 32 + l31;
-    auto mfma_slab = [&](int buf) {
+    int a_rd[QS], b_rd[QS];                                 // float index of the lane's operand(s) of quad qq inside a slab image
+#pragma unroll
+    for (int qq = 0; qq < QS; ++qq) {
+        const int q = wk * QS + qq;
+        a_rd[qq] = A_VEC_RED ? a_row * 32 + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BM + a_row;
+        b_rd[qq] = B_VEC_RED ? b_col * 32 + (((2 * q + hi) ^ ((b_col >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BN + b_col;
+    }
+    auto mfma_slab = [&](const int buf) {                   // buf: compile-time constant at every call site
         const float *as = smem + buf * SLAB, *bs = as + A_SLAB;
         // every operand of the slab is requested from LDS first (32 registers at KW = 1), then the MFMA chain runs behind
         // counted lgkmcnt waits: one LDS latency per slab instead of one per four MFMAs
         float av[QS][4], bv[QS][4];
 #pragma unroll
         for (int qq = 0; qq < QS; ++qq) {
-            const int q = wk * QS + qq;
             if (A_VEC_RED) {
-                const float4 v = *reinterpret_cast<const float4 *>(as + a_row * 32 + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2));
+                const float4 v = *reinterpret_cast<const float4 *>(as + a_rd[qq]);
                 av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) av[qq][i] = as[(8 * q + 4 * hi + i) * BM + a_row];
+                for (int i = 0; i < 4; ++i) av[qq][i] = as[a_rd[qq] + i * BM];
             }
             if (B_VEC_RED) {
-                const float4 v = *reinterpret_cast<const float4 *>(bs + b_col * 32 + (((2 * q + hi) ^ ((b_col >> 1) & 7)) << 2));
+                const float4 v = *reinterpret_cast<const float4 *>(bs + b_rd[qq]);
                 bv[qq][0] = v.x; bv[qq][1] = v.y; bv[qq][2] = v.z; bv[qq][3] = v.w;
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bv[qq][i] = bs[(8 * q + 4 * hi + i) * BN + b_col];
+                for (int i = 0; i < 4; ++i) bv[qq][i] = bs[b_rd[qq] + i * BN];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1123,17 +1150,24 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     };
 
     if (kbeg < kend) {
-        const int nslab = (kend - kbeg + BK - 1) / BK;
+        const int nslab = (len + BK - 1) / BK;
 #pragma unroll
-        for (int d = 0; d < D - 1; ++d) issue(d);
+        for (int d = 0; d < D - 1; ++d) issue(d, d);
         if (stamp) stamp[1] = wall_clock64();
-        for (int s = 0; s < nslab; ++s) {
-            // slab s has landed once all but the (D - 2) * L newest requests of this lane are complete ...
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (D - 2)) : "memory");
-            // ... for every wave of the workgroup; and everyone is done reading slab s - 1, whose buffer is refilled next
-            asm volatile("s_barrier" ::: "memory");
-            issue(s + D - 1);
-            mfma_slab(s & (D - 1));
+        // D slab steps per trip so that every buffer index is a compile-time constant (slab s + d lives in buffer d)
+        for (int s = 0; s < nslab; s += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (s + d < nslab) {                         // wave-uniform
+                    // slab s + d has landed once all but the (D - 2) * L newest requests of this lane are complete ...
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (D - 2)) : "memory");
+                    // ... for every wave of the workgroup; and everyone is done reading the slab before it, whose buffer
+                    // is refilled next
+                    asm volatile("s_barrier" ::: "memory");
+                    issue(s + d + D - 1, (d + D - 1) % D);
+                    mfma_slab(d);
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // requests of non-existent slabs still target the ring
     }
