@@ -920,8 +920,12 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
 #ifndef RLX_DMA_WGS
 #define RLX_DMA_WGS 3          // workgroups per CU the DMA kernels are compiled for (LDS: depth x 16 KB + 8 KB of tables)
 #endif
+#ifndef RLX_DMA_TAB
+#define RLX_DMA_TAB 2048       // im2col offsets of one K chunk staged in LDS by the DMA kernels (ints); longer chunks take the register-staged kernel
+#endif
 constexpr int kDmaDepth = RLX_DMA_DEPTH;
-static_assert((kDmaDepth & (kDmaDepth - 1)) == 0 && kDmaDepth >= 2, "the ring index is taken with a mask");
+constexpr int kDmaTabChunk = RLX_DMA_TAB;
+static_assert(kDmaDepth >= 2 && kDmaTabChunk <= kTabChunk, "ring depth / table size");
 __device__ __attribute__((aligned(16))) float g_dma_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
 template <int BM, int BN>
@@ -1182,7 +1186,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
 template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB>
 __global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_kernel(const GemmDev g) {
     __shared__ __attribute__((aligned(1024))) float smem[DmaTile<BM, BN>::kSmemFloats];
-    __shared__ int tab_s[A_TAB ? kTabChunk : 1];
+    __shared__ int tab_s[A_TAB ? kDmaTabChunk : 1];
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     xcd_tile_block(g.xcd_mode, bx, by, bz);
     gemm_dma_body<BM, BN, KW, A_VEC_RED, B_VEC_RED, A_TAB>(g, bx, by, bz, gridDim.x, gridDim.y, smem, tab_s);
@@ -1192,7 +1196,7 @@ __global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_kernel(const G
 template <bool A_TAB0, int DX_KW>
 __global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_pair_kernel(const GemmPairDev p) {
     __shared__ __attribute__((aligned(1024))) float smem[DmaTile<64, 64>::kSmemFloats];
-    __shared__ int tab_s[A_TAB0 ? kTabChunk : 1];
+    __shared__ int tab_s[A_TAB0 ? kDmaTabChunk : 1];
     int flat = blockIdx.x;
     const int which = flat >= p.n0;
     if (which) flat -= p.n0;
@@ -2151,7 +2155,7 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
         }
     }
     int rc = -1;
-    if (fast && g_dma && !d.a_is_u8 && !narrow) {
+    if (fast && g_dma && !d.a_is_u8 && !narrow && (!a_tab || kchunk <= kDmaTabChunk)) {
         if (KW == 2) rc = launch_dma<32, 64, 2>(g, a_vec_red, b_vec_red, a_tab, grid, s);
         else if (KW == 4) rc = launch_dma<32, 32, 4>(g, a_vec_red, b_vec_red, a_tab, grid, s);
         else rc = launch_dma<64, 64, 1>(g, a_vec_red, b_vec_red, a_tab, grid, s);
@@ -2265,7 +2269,8 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
     hipStream_t s = rlx::as_stream(stream);
 #define RLX_PAIR_CASE(AT, KWX)                                                                   \
     if (pw.a_tab == AT && px.kw == KWX) {                                                        \
-        if (g_dma) RLX_LAUNCH((gemm_dma_pair_kernel<AT, KWX>), total, kThreads, 0, s, p);        \
+        if (g_dma && (!AT || pw.g.kchunk <= kDmaTabChunk))                                       \
+            RLX_LAUNCH((gemm_dma_pair_kernel<AT, KWX>), total, kThreads, 0, s, p);               \
         else RLX_LAUNCH((gemm_fast_pair_kernel<AT, KWX>), total, kThreads, 0, s, p);             \
     }
     RLX_PAIR_CASE(true, 1) RLX_PAIR_CASE(true, 2) RLX_PAIR_CASE(true, 4)
