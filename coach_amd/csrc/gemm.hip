@@ -928,9 +928,10 @@ constexpr int kDmaTabChunk = RLX_DMA_TAB;
 static_assert(kDmaDepth >= 2 && kDmaTabChunk <= kTabChunk, "ring depth / table size");
 __device__ __attribute__((aligned(16))) float g_dma_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <int BM, int BN>
+template <int BM, int BN, bool A_U8 = false>
 struct DmaTile {
-    static constexpr int kSlabFloats = (BM + BN) * BK;
+    static constexpr int kASlabFloats = A_U8 ? BM * BK / 4 : BM * BK;       // uint8 A: the slab image holds raw bytes
+    static constexpr int kSlabFloats = kASlabFloats + BN * BK;
     static constexpr int kRingFloats = kDmaDepth * kSlabFloats;
     static constexpr int kSmemFloats = kRingFloats > 4 * 32 * 33 ? kRingFloats : 4 * 32 * 33;   // >= the epilogue's staging
 };
@@ -944,19 +945,36 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
-template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB>
+// the 4-byte request (uint8 operands: four consecutive bytes per lane; LDS byte = base + lane * 4)
+__device__ __forceinline__ void dma4(const unsigned char *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// A_U8 (the first convolution: uint8 frames through im2col tables): the A slab image holds RAW BYTES — k-vector: [row][32
+// bytes], a lane requests the 4 bytes of k-group slot ^ ((row >> 2) & 7) (32 banks of 4 bytes: 4 rows per bank row, the
+// 8 rows of a bank class get 8 different slots: conflict-free ds_read_b32); outer-vector: [k][BM bytes], a lane requests 4
+// consecutive outer elements of one k — and the conversion byte / a_div (exact quotients from a 256-entry LDS table, as in
+// the register-staged kernel) happens when the MFMA operands are read.
+template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB, bool A_U8 = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, const int by, const int bz,
-                                              const int gdx, const int gdy, float *const smem, int *const tab_s) {
+                                              const int gdx, const int gdy, float *const smem, int *const tab_s,
+                                              const float *const lut = nullptr) {
+    static_assert(!A_U8 || A_TAB, "uint8 operands come through im2col tables");
     constexpr int D = kDmaDepth;
     constexpr int WN = BN / 32;
     constexpr int WMN = (BM / 32) * WN;
     static_assert(WMN * KW == 4, "a workgroup is 4 waves");
     static_assert(BK == 32, "slab images are 32 k deep");
-    constexpr int A_SLAB = BM * BK, SLAB = DmaTile<BM, BN>::kSlabFloats;
-    constexpr int NA_I = BM / 32, NB_I = BN / 32;          // 16-byte requests per lane per slab (4 KB per workgroup request)
+    constexpr int A_SLAB = DmaTile<BM, BN, A_U8>::kASlabFloats, SLAB = DmaTile<BM, BN, A_U8>::kSlabFloats;
+    constexpr int NA_I = BM / 32, NB_I = BN / 32;          // requests per lane per slab (16 bytes each; uint8 A: 4 bytes)
     constexpr int L = NA_I + NB_I;
+    constexpr unsigned A_REQ = A_U8 ? 1024u : 4096u;       // bytes one workgroup-wide A request fills
     static_assert(L * (D - 1) <= 63, "vmcnt is a 6-bit counter");
-    static_assert(4 * 32 * 33 <= DmaTile<BM, BN>::kSmemFloats, "epilogue staging fits in the ring");
+    static_assert(4 * 32 * 33 <= DmaTile<BM, BN, A_U8>::kSmemFloats, "epilogue staging fits in the ring");
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wk = wid / WMN, wmn = wid - wk * WMN;
@@ -970,11 +988,17 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
         ? g.stamps + 4 * ((size_t)(bz * gdy + by) * gdx + bx) : nullptr;
     if (stamp) stamp[0] = wall_clock64();
 
-    const float *const abase = static_cast<const float *>(g.a.base) +
-                               batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2);
+    // (uint8 A: `abase`, the offset tables and every A pointer below count BYTES; typed float * only to share the code)
+    const float *const abase = A_U8
+        ? reinterpret_cast<const float *>(static_cast<const unsigned char *>(g.a.base) +
+                                          batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2))
+        : static_cast<const float *>(g.a.base) + batch_off(batch, g.inner, g.a.batch_stride, g.a.batch_stride2);
     const float *const bbase = static_cast<const float *>(g.b.base) +
                                batch_off(batch, g.inner, g.b.batch_stride, g.b.batch_stride2);
     const float *const zero = g_dma_zero;
+    auto a_at = [&](const float *base, long long elems) {   // base advanced by `elems` A elements
+        return A_U8 ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(base) + elems) : base + elems;
+    };
     // branch-free "valid ? p : zero block" (a C++ ?: here became an exec-masked branch around the table lookup)
     auto pick = [&](const float *p, bool valid) {
         const uintptr_t m = (uintptr_t)0 - (uintptr_t)valid;
@@ -988,7 +1012,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     long long a_off_o[A_VEC_RED ? NA_I : 1];
     int a_k = 0;                                            // k-vector: first k of the lane's group within a slab
     if (A_VEC_RED) {
-        a_k = ((tid & 7) ^ ((tid >> 4) & 7)) * 4;           // row = tid >> 3 (+ 32 p): (row >> 1) & 7 = (tid >> 4) & 7
+        a_k = A_U8 ? ((tid & 7) ^ ((tid >> 5) & 7)) * 4     // uint8: slot ^ ((row >> 2) & 7), row = tid >> 3 (+ 32 p)
+                   : ((tid & 7) ^ ((tid >> 4) & 7)) * 4;    // row = tid >> 3 (+ 32 p): (row >> 1) & 7 = (tid >> 4) & 7
 #pragma unroll
         for (int p = 0; p < NA_I; ++p) {
             const int row = min(m0 + (tid >> 3) + 32 * p, g.M - 1);
@@ -1034,6 +1059,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
             }
         }
     }
+    if (A_U8) const_cast<float *>(lut)[tid] = (float)tid / g.a_div;       // kThreads == 256; the barrier below publishes it
     if (A_TAB) {
         // the chunk's reduction-index offsets, requested together with the row offsets above (one round trip)
         for (int i = tid; i < kend - kbeg; i += kThreads) tab_s[i] = g.a.tab_r[kbeg + i];
@@ -1049,6 +1075,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     // scratch: 9-11 VALU instructions per MFMA, profiles/r04_pmc_wave_states.json.)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(
         static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem)) + (unsigned)wid * 1024u);
+    const unsigned lds0a = A_U8 ? __builtin_amdgcn_readfirstlane(           // a wave's 4-byte requests fill 256 bytes
+        static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem)) + (unsigned)wid * 256u) : lds0;
     const int len = kend - kbeg;
     int ak[NA_I], bk[NB_I];
     const float *ap[NA_I], *bp[NB_I];                       // A non-TAB / B: the source of the NEXT slab to request
@@ -1056,7 +1084,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
 #pragma unroll
     for (int p = 0; p < NA_I; ++p) {
         ak[p] = A_VEC_RED ? a_k : tid / (BM / 4) + (1024 / BM) * p;
-        const float *base = abase + a_off_o[A_VEC_RED ? p : 0];
+        const float *base = a_at(abase, a_off_o[A_VEC_RED ? p : 0]);
         if (A_TAB) arow[p] = base;
         ap[p] = A_TAB ? base : base + (long long)(kbeg + ak[p]) * g.a.stride_r;
     }
@@ -1076,13 +1104,14 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
             if (A_TAB) {
                 const int ti = s_idx * BK + ak[p];
                 const int tc = full ? ti : min(ti, len - (A_VEC_RED ? 4 : 1));
-                src = arow[p] + (long long)tab_s[tc];
+                src = a_at(arow[p], (long long)tab_s[tc]);
                 if (!full) src = pick(src, ti < len);
             } else {
                 src = full ? ap[p] : pick(ap[p], s_idx * BK + ak[p] < len);
                 ap[p] += a_step;
             }
-            dma16(src, dst + 4096u * p);
+            if (A_U8) dma4(reinterpret_cast<const unsigned char *>(src), lds0a + (unsigned)(buf * SLAB) * 4u + A_REQ * p);
+            else dma16(src, dst + A_REQ * p);
         }
 #pragma unroll
         for (int p = 0; p < NB_I; ++p) {
@@ -1106,7 +1135,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
 #pragma unroll
     for (int qq = 0; qq < QS; ++qq) {
         const int q = wk * QS + qq;
-        a_rd[qq] = A_VEC_RED ? a_row * 32 + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BM + a_row;
+        a_rd[qq] = A_U8 ? (A_VEC_RED ? a_row * 8 + ((2 * q + hi) ^ ((a_row >> 2) & 7))      // dword of the lane's 4 bytes
+                                     : (8 * q + 4 * hi) * BM + a_row)                         // byte of its first k
+                        : A_VEC_RED ? a_row * 32 + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BM + a_row;
         b_rd[qq] = B_VEC_RED ? b_col * 32 + (((2 * q + hi) ^ ((b_col >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BN + b_col;
     }
     auto mfma_slab = [&](const int buf) {                   // buf: compile-time constant at every call site
@@ -1116,7 +1147,14 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
         float av[QS][4], bv[QS][4];
 #pragma unroll
         for (int qq = 0; qq < QS; ++qq) {
-            if (A_VEC_RED) {
+            if (A_U8 && A_VEC_RED) {
+                const uint32_t w = reinterpret_cast<const uint32_t *>(as)[a_rd[qq]];
+                av[qq][0] = lut[w & 0xffu]; av[qq][1] = lut[(w >> 8) & 0xffu];
+                av[qq][2] = lut[(w >> 16) & 0xffu]; av[qq][3] = lut[w >> 24];
+            } else if (A_U8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[qq][i] = lut[reinterpret_cast<const unsigned char *>(as)[a_rd[qq] + i * BM]];
+            } else if (A_VEC_RED) {
                 const float4 v = *reinterpret_cast<const float4 *>(as + a_rd[qq]);
                 av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
             } else {
@@ -1183,13 +1221,14 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
         fast_epilogue<BM, BN, 1, 1, KW, false>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp);
 }
 
-template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB>
+template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB, bool A_U8 = false>
 __global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_kernel(const GemmDev g) {
-    __shared__ __attribute__((aligned(1024))) float smem[DmaTile<BM, BN>::kSmemFloats];
+    __shared__ __attribute__((aligned(1024))) float smem[DmaTile<BM, BN, A_U8>::kSmemFloats];
     __shared__ int tab_s[A_TAB ? kDmaTabChunk : 1];
+    __shared__ float lut[A_U8 ? 256 : 1];
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     xcd_tile_block(g.xcd_mode, bx, by, bz);
-    gemm_dma_body<BM, BN, KW, A_VEC_RED, B_VEC_RED, A_TAB>(g, bx, by, bz, gridDim.x, gridDim.y, smem, tab_s);
+    gemm_dma_body<BM, BN, KW, A_VEC_RED, B_VEC_RED, A_TAB, A_U8>(g, bx, by, bz, gridDim.x, gridDim.y, smem, tab_s, lut);
 }
 
 // a layer's weight gradient and input gradient as one launch (see gemm_fast_pair_kernel), both on the LDS-DMA ring
@@ -1831,7 +1870,13 @@ int launch_fast(const GemmDev &g, bool a_vec_red, bool a_u8, bool b_vec_red, boo
 }
 
 template <int BM, int BN, int KW>
-int launch_dma(const GemmDev &g, bool a_vec_red, bool b_vec_red, bool a_tab, dim3 grid, hipStream_t s) {
+int launch_dma(const GemmDev &g, bool a_vec_red, bool b_vec_red, bool a_tab, bool a_u8, dim3 grid, hipStream_t s) {
+    if (a_u8) {                  // uint8 frames: through im2col tables, B along N (what fast_combo admits)
+        if (!a_tab || b_vec_red) return -1;
+        if (a_vec_red) RLX_LAUNCH((gemm_dma_kernel<BM, BN, KW, true, false, true, true>), grid, kThreads, 0, s, g);
+        else RLX_LAUNCH((gemm_dma_kernel<BM, BN, KW, false, false, true, true>), grid, kThreads, 0, s, g);
+        return 0;
+    }
 #define RLX_DMA_CASE(AV, BV, AT)                                                                      \
     if (a_vec_red == AV && b_vec_red == BV && a_tab == AT) {                                          \
         RLX_LAUNCH((gemm_dma_kernel<BM, BN, KW, AV, BV, AT>), grid, kThreads, 0, s, g);               \
@@ -1860,7 +1905,8 @@ constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a laun
 // least g_kw_min_tiles (rlx_gemm_tuning: an explicit knob for same-process A/Bs, tools/ab_c2.py)
 int g_kw_below_tiles = 192, g_kw_min_tiles = 192, g_xcd_mode = -1;
 // main loop of the fast tiled kernels: 1 = operands through the LDS-DMA ring (gemm_dma_body), 0 = register-staged
-// (gemm_fast_body); rlx_gemm_pipeline, for same-process A/Bs (profiles/r04_ab_gemm_pipeline.txt).  uint8 operands and 128 x 32 tiles always take the latter.
+// (gemm_fast_body); rlx_gemm_pipeline, for same-process A/Bs (profiles/r04_ab_gemm_pipeline.txt).  128 x 32 tiles always take the latter;
+// uint8 operands take the ring only in mode 2 (4-byte requests: measured equal to the register path, profiles/r04_ab_u8_dma.txt).
 int g_dma = 1;
 
 // diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
@@ -2155,10 +2201,11 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
         }
     }
     int rc = -1;
-    if (fast && g_dma && !d.a_is_u8 && !narrow && (!a_tab || kchunk <= kDmaTabChunk)) {
-        if (KW == 2) rc = launch_dma<32, 64, 2>(g, a_vec_red, b_vec_red, a_tab, grid, s);
-        else if (KW == 4) rc = launch_dma<32, 32, 4>(g, a_vec_red, b_vec_red, a_tab, grid, s);
-        else rc = launch_dma<64, 64, 1>(g, a_vec_red, b_vec_red, a_tab, grid, s);
+    if (fast && g_dma && (g_dma >= 2 || !d.a_is_u8) && !narrow && (!a_tab || kchunk <= kDmaTabChunk)) {
+        const bool u8 = d.a_is_u8 != 0;
+        if (KW == 2) rc = launch_dma<32, 64, 2>(g, a_vec_red, b_vec_red, a_tab, u8, grid, s);
+        else if (KW == 4) rc = launch_dma<32, 32, 4>(g, a_vec_red, b_vec_red, a_tab, u8, grid, s);
+        else rc = launch_dma<64, 64, 1>(g, a_vec_red, b_vec_red, a_tab, u8, grid, s);
     }
     if (fast && rc != 0) {
         const bool u8 = d.a_is_u8 != 0;

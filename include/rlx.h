@@ -340,7 +340,7 @@ int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_
 int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode);
 /* Main loop of the fast tiled kernels: 1 (default) = operand slabs go global -> LDS by DMA into a ring of two buffers,
  * one barrier per slab, three workgroups per CU (csrc/gemm.hip gemm_dma_body); 0 = the register-staged two-set pipeline
- * of rounds 1-3 (uint8 operands and 128 x 32 tiles always use it).  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two
+ * of rounds 1-3 (128 x 32 tiles always use it); 2 = the ring for uint8 operands too (4-byte requests; measured equal to 1).  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two
  * (both deterministic).  Process-wide, read at launch (or capture) time: exists for same-process A/B measurements. */
 int rlx_gemm_pipeline(int lds_dma_ring);
 

@@ -7,10 +7,11 @@ import pytest
 from tests.util import dev_tensor
 
 
-@pytest.fixture(autouse=True, params=[1, 0], ids=["lds-dma-ring", "register-staged"])
+@pytest.fixture(autouse=True, params=[2, 0], ids=["lds-dma-ring", "register-staged"])
 def _gemm_pipeline(request):
     """every test of this file runs with both main loops of the fast tiled kernels (rlx_gemm_pipeline): the LDS-DMA ring
-    (the default) and the register-staged two-set pipeline."""
+    (mode 2: uint8 operands included; the default, mode 1, sends those to the other loop) and the register-staged two-set
+    pipeline."""
     from coach_amd import _rlx
     lib = _rlx.lib()
     lib.gemm_pipeline(request.param)
