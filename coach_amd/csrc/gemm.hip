@@ -924,6 +924,10 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
 #define RLX_DMA_TAB 2048       // im2col offsets of one K chunk staged in LDS by the DMA kernels (ints); longer chunks take the register-staged kernel
 #endif
 constexpr int kDmaDepth = RLX_DMA_DEPTH;
+#ifndef RLX_DMA_DEPTH_U8
+#define RLX_DMA_DEPTH_U8 4       // a uint8 A slab is 2 KB (fp32: 8 KB): four slabs deep still leaves three workgroups per CU
+#endif
+constexpr int kDmaDepthU8 = RLX_DMA_DEPTH_U8;
 constexpr int kDmaTabChunk = RLX_DMA_TAB;
 static_assert(kDmaDepth >= 2 && kDmaTabChunk <= kTabChunk, "ring depth / table size");
 __device__ __attribute__((aligned(16))) float g_dma_zero[4] = {0.f, 0.f, 0.f, 0.f};
@@ -932,7 +936,8 @@ template <int BM, int BN, bool A_U8 = false>
 struct DmaTile {
     static constexpr int kASlabFloats = A_U8 ? BM * BK / 4 : BM * BK;       // uint8 A: the slab image holds raw bytes
     static constexpr int kSlabFloats = kASlabFloats + BN * BK;
-    static constexpr int kRingFloats = kDmaDepth * kSlabFloats;
+    static constexpr int kDepth = A_U8 ? kDmaDepthU8 : kDmaDepth;
+    static constexpr int kRingFloats = kDepth * kSlabFloats;
     static constexpr int kSmemFloats = kRingFloats > 4 * 32 * 33 ? kRingFloats : 4 * 32 * 33;   // >= the epilogue's staging
 };
 
@@ -964,7 +969,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
                                               const int gdx, const int gdy, float *const smem, int *const tab_s,
                                               const float *const lut = nullptr) {
     static_assert(!A_U8 || A_TAB, "uint8 operands come through im2col tables");
-    constexpr int D = kDmaDepth;
+    constexpr int D = DmaTile<BM, BN, A_U8>::kDepth;
     constexpr int WN = BN / 32;
     constexpr int WMN = (BM / 32) * WN;
     static_assert(WMN * KW == 4, "a workgroup is 4 waves");
@@ -1955,7 +1960,8 @@ int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode) {
 }
 
 int rlx_gemm_pipeline(int lds_dma_ring) {
-    RLX_REQUIRE(lds_dma_ring == 0 || lds_dma_ring == 1, "rlx_gemm_pipeline: 0 (register-staged) or 1 (LDS-DMA ring)");
+    RLX_REQUIRE(lds_dma_ring >= 0 && lds_dma_ring <= 2,
+                "rlx_gemm_pipeline: 0 (register-staged), 1 (LDS-DMA ring) or 2 (ring for uint8 operands too)");
     g_dma = lds_dma_ring;
     return RLX_OK;
 }
