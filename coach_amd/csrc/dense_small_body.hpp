@@ -86,10 +86,14 @@ struct MultiBwd { SmallDenseBwd p[kMaxProblems]; int towers[kMaxProblems]; int n
 // single-problem launch (rlx_dense_small_backward) takes 16 x 16: twice the workgroups and, up to M = 128 rows, every x
 // load of a thread in ONE chunk (one exposed round trip instead of two at M = 100) — a different grouping of the dW row
 // sums (profiles/r03_ab_candidates.txt).
-// PRESTAGED: the caller has already written dz (the gradient w.r.t. the pre-activation output) into smem[0 .. M*N) —
+// PRESTAGED: the caller writes dz (the gradient w.r.t. the pre-activation output) into smem[0 .. M*N) itself (STAGE) —
 // the Clipped-PPO heads launch computes it there from the head losses (ppo_heads_bwd.hip); p.dy / p.y are not read.
-template <int NN, int KL = kKL, int RG = kRG, bool PRESTAGED = false>
-__device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int kblock, int t, float *smem) {
+struct NoStage { __device__ __forceinline__ void operator()() const {} };
+// STAGE (PRESTAGED only): called AFTER this thread's w and x loads have been issued and before the barrier that
+// publishes dz — the caller computes dz there, under the loads' latency instead of in front of it.
+template <int NN, int KL = kKL, int RG = kRG, bool PRESTAGED = false, typename STAGE = NoStage>
+__device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int kblock, int t, float *smem,
+                                                     STAGE stage = STAGE()) {
     float *dz = smem;                              // [M][N]
     float *part = smem + (size_t)p.M * p.N;        // [RG][KL][NN] dW partials
     const int lane = threadIdx.x % KL, g = threadIdx.x / KL;
@@ -122,6 +126,7 @@ __device__ __forceinline__ void dense_small_bwd_body(const SmallDenseBwd &p, int
         }
     };
     load_chunk(g);
+    if (PRESTAGED) stage();
     __syncthreads();
     for (int m0 = g; m0 < p.M; m0 += RG * kCH) {
         if (m0 != g) load_chunk(m0);

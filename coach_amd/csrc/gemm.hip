@@ -1909,6 +1909,7 @@ constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a laun
 // in-workgroup K split: taken when the 64 x 64 tiling has fewer than g_kw_below_tiles tiles and the smaller tiling at
 // least g_kw_min_tiles (rlx_gemm_tuning: an explicit knob for same-process A/Bs, tools/ab_c2.py)
 int g_kw_below_tiles = 192, g_kw_min_tiles = 192, g_xcd_mode = -1;
+int g_split_cap = 64;      // most K splits one product is cut into (rlx_gemm_split_cap)
 // main loop of the fast tiled kernels: 1 = operands through the LDS-DMA ring (gemm_dma_body), 0 = register-staged
 // (gemm_fast_body); rlx_gemm_pipeline, for same-process A/Bs (profiles/r04_ab_gemm_pipeline.txt).  128 x 32 tiles always take the latter;
 // uint8 operands take the ring only in mode 2 (4-byte requests: measured equal to the register path, profiles/r04_ab_u8_dma.txt).
@@ -1959,6 +1960,12 @@ int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode) {
     return RLX_OK;
 }
 
+int rlx_gemm_split_cap(int max_splits) {
+    RLX_REQUIRE(max_splits >= 1 && max_splits <= 256, "rlx_gemm_split_cap: 1 <= max_splits <= 256");
+    g_split_cap = max_splits;
+    return RLX_OK;
+}
+
 int rlx_gemm_pipeline(int lds_dma_ring) {
     RLX_REQUIRE(lds_dma_ring >= 0 && lds_dma_ring <= 2,
                 "rlx_gemm_pipeline: 0 (register-staged), 1 (LDS-DMA ring) or 2 (ring for uint8 operands too)");
@@ -1969,8 +1976,8 @@ int rlx_gemm_pipeline(int lds_dma_ring) {
 int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_host) {
     RLX_REQUIRE(floats_host && M > 0 && N > 0 && K > 0 && batch > 0,
                 "rlx_gemm_workspace_floats: bad arguments");
-    // upper bound used by rlx_gemm's split heuristic (at most 64 splits)
-    *floats_host = ((long long)M * N + N) * batch * 64;   /* + column-sum partials */
+    // upper bound used by rlx_gemm's split heuristic (at most rlx_gemm_split_cap splits, 64 by default)
+    *floats_host = ((long long)M * N + N) * batch * g_split_cap;   /* + column-sum partials */
     return RLX_OK;
 }
 
@@ -2139,7 +2146,7 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
         const int want = (kSplitWgsPerCu * rlx::kCUs + tiles - 1) / tiles;
         const int max_by_k = d.K / (2 * BK);
         splits = want < max_by_k ? want : max_by_k;
-        if (splits > 64) splits = 64;
+        if (splits > g_split_cap) splits = g_split_cap;
         if (splits < 1) splits = 1;
         while (splits > 1 && ((long long)d.M * d.N + d.N) * d.batch * splits > d.workspace_floats) --splits;
     }

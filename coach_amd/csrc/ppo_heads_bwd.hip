@@ -47,58 +47,76 @@ __device__ __forceinline__ float block_sum_first(float v, float *red, int nt) {
     return r;
 }
 
+// three such sums through ONE tree (each component goes through exactly the additions of block_sum_first)
+__device__ __forceinline__ void block_sum3_first(float &x, float &y, float &z, float (*red)[256], int nt) {
+    const int tid = threadIdx.x;
+    if (tid < nt) { red[0][tid] = x; red[1][tid] = y; red[2][tid] = z; }
+    __syncthreads();
+    for (int d = nt >> 1; d > 0; d >>= 1) {
+        if (tid < d) {
+            red[0][tid] += red[0][tid + d];
+            red[1][tid] += red[1][tid + d];
+            red[2][tid] += red[2][tid + d];
+        }
+        __syncthreads();
+    }
+    x = red[0][0]; y = red[1][0]; z = red[2][0];
+    __syncthreads();
+}
+
 template <int NN>
 __global__ void __launch_bounds__(256) ppo_heads_loss_bwd_kernel(const PpoHeadsBwdArgs a) {
     extern __shared__ float smem[];
-    __shared__ float red[256];
+    __shared__ float red[3][256];
     const bool is_policy = blockIdx.z == 1;
     const SmallDenseBwd &p = is_policy ? a.policy : a.value;
     if ((int)blockIdx.x * kKL >= p.K) return;
     const bool writer = blockIdx.x == 0;
     const int b = threadIdx.x, B = a.batch;
     float *dz = smem;                                         // [B][N] of this head
-    if (is_policy) {
-        const float clip = a.clip_scale ? a.clip_eps * *a.clip_scale : a.clip_eps;
-        float l_sur = 0.f, l_ent = 0.f, l_kl = 0.f;
-        if (b < B) {
-            PpoRowTerms t;
-            if (!ppo_discrete_row(a.logits + (size_t)b * a.ld, a.old_probs + (size_t)b * a.ld_old, a.actions[b],
-                                  a.n_actions, a.advantages[b], clip, a.beta, a.grad_scale, B,
-                                  dz + (size_t)b * a.n_actions, (writer && a.ratio_out) ? a.ratio_out + b : nullptr,
-                                  (writer && a.clipped_out) ? a.clipped_out + b : nullptr, t)) {
-                if (writer) atomicOr(a.status, 1);
-                for (int j = 0; j < a.n_actions; ++j) dz[(size_t)b * a.n_actions + j] = 0.f;
-            } else {
-                l_sur = t.sur; l_ent = t.ent; l_kl = t.kl;
+    // the head losses and dz: runs inside dense_small_bwd_body, behind the issue of that body's weight and input loads
+    auto stage = [&]() {
+        if (is_policy) {
+            const float clip = a.clip_scale ? a.clip_eps * *a.clip_scale : a.clip_eps;
+            float l_sur = 0.f, l_ent = 0.f, l_kl = 0.f;
+            if (b < B) {
+                PpoRowTerms t;
+                if (!ppo_discrete_row(a.logits + (size_t)b * a.ld, a.old_probs + (size_t)b * a.ld_old, a.actions[b],
+                                      a.n_actions, a.advantages[b], clip, a.beta, a.grad_scale, B,
+                                      dz + (size_t)b * a.n_actions, (writer && a.ratio_out) ? a.ratio_out + b : nullptr,
+                                      (writer && a.clipped_out) ? a.clipped_out + b : nullptr, t)) {
+                    if (writer) atomicOr(a.status, 1);
+                    for (int j = 0; j < a.n_actions; ++j) dz[(size_t)b * a.n_actions + j] = 0.f;
+                } else {
+                    l_sur = t.sur; l_ent = t.ent; l_kl = t.kl;
+                }
+            }
+            if (writer) {
+                block_sum3_first(l_sur, l_ent, l_kl, red, a.red_threads);
+                if (threadIdx.x == 0) ppo_discrete_scalars(l_sur, l_ent, l_kl, a.beta, B, a.scalars);
+            }
+        } else {
+            float local = 0.f;
+            if (b < B) {                                       // VHead: MSE(target, V), loss weight 1 (head.py:172-181)
+                const float w = 1.f;
+                const float e = a.v[b] - a.v_target[b];
+                float l, g;
+                regression_terms(e, 0, l, g);
+                dz[b] = regression_grad(a.grad_scale, w, g, B);
+                local = w * l;
+            }
+            if (writer) {
+                const float s = block_sum_first(local, red[0], a.red_threads);
+                if (threadIdx.x == 0) a.scalars[4] = s / (float)B;
             }
         }
-        if (writer) {
-            const float sur = block_sum_first(l_sur, red, a.red_threads);
-            const float ent = block_sum_first(l_ent, red, a.red_threads);
-            const float kl = block_sum_first(l_kl, red, a.red_threads);
-            if (threadIdx.x == 0) ppo_discrete_scalars(sur, ent, kl, a.beta, B, a.scalars);
+        __syncthreads();
+        if (writer && p.dy) {                                  // the head-output gradients, for whoever reads y.grad
+            float *dy = const_cast<float *>(p.dy);
+            for (int i = threadIdx.x; i < B * p.N; i += 256) dy[i] = dz[i];
         }
-    } else {
-        float local = 0.f;
-        if (b < B) {                                       // VHead: MSE(target, V), loss weight 1 (head.py:172-181)
-            const float w = 1.f;
-            const float e = a.v[b] - a.v_target[b];
-            float l, g;
-            regression_terms(e, 0, l, g);
-            dz[b] = regression_grad(a.grad_scale, w, g, B);
-            local = w * l;
-        }
-        if (writer) {
-            const float s = block_sum_first(local, red, a.red_threads);
-            if (threadIdx.x == 0) a.scalars[4] = s / (float)B;
-        }
-    }
-    __syncthreads();
-    if (writer && p.dy) {                                  // the head-output gradients, for whoever reads y.grad
-        float *dy = const_cast<float *>(p.dy);
-        for (int i = threadIdx.x; i < B * p.N; i += 256) dy[i] = dz[i];
-    }
-    dense_small_bwd_body<NN, kKL, kRG, true>(p, blockIdx.x, 0, smem);
+    };
+    dense_small_bwd_body<NN, kKL, kRG, true>(p, blockIdx.x, 0, smem, stage);
 }
 
 }  // namespace

@@ -126,6 +126,8 @@ PAIR_GRADIENT_GEMMS = True
 # (the gather's dependent loads pay the slower memory system twice); it halves the HBM bytes of the convolutions'
 # backward pass, so it stays available for configurations where that is the limit.
 DIRECT_CONV_INPUT_GRAD = False
+# most K splits a deferred product may get room for (rlx_gemm_split_cap's largest useful setting; its default is 64)
+SPLIT_CAP_BOUND = 128
 
 
 class Workspace:
@@ -183,7 +185,7 @@ class Context:
 
     def deferred_workspace(self, M, N, batch):
         """(job, workspace slice) for one deferred product with an M x N output per batch entry."""
-        bound = (M * N + N) * batch * 64                    # rlx_gemm_workspace_floats: at most 64 splits
+        bound = (M * N + N) * batch * SPLIT_CAP_BOUND
         room = self.ARENA_FLOATS - self._arena_off
         if self.deferred is None or len(self.deferred) >= _rlx.MAX_SPLITK_JOBS or room < (M * N + N) * batch * 2:
             return None, self.ws.splitk

@@ -343,6 +343,9 @@ int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode);
  * of rounds 1-3 (128 x 32 tiles always use it); 2 = the ring for uint8 operands too (4-byte requests; measured equal to 1).  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two
  * (both deterministic).  Process-wide, read at launch (or capture) time: exists for same-process A/B measurements. */
 int rlx_gemm_pipeline(int lds_dma_ring);
+/* The most K splits rlx_gemm cuts one product into (default 64; the workspace given with the descriptor bounds it as
+ * well).  Process-wide, read at launch / capture time: a knob for same-process A/B measurements. */
+int rlx_gemm_split_cap(int max_splits);
 
 /* Input gradient of a VALID-padding NHWC convolution (tf.gradients of tf.layers.conv2d,
  * architectures/tensorflow_components/layers.py:108-121, architecture.py:187-220) as ONE product that gathers dY

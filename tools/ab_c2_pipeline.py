@@ -2,7 +2,7 @@
 runs bench.py's agent in its own process, alternately, `rounds` times; us per update = hipGraph replay of 10 epochs x
 32 minibatches / 320, the minimum over the rounds.
     python tools/ab_c2_pipeline.py rounds lib:mode [lib:mode ...]      e.g.  2 coach_amd/librlx.so:0 coach_amd/ab/librlx_d2.so:1 coach_amd/librlx.so:0:192,200,-1
-(the optional third field is rlx_gemm_tuning's kw_below_tiles,kw_min_tiles,xcd_mode)
+(the optional third field is rlx_gemm_tuning's kw_below_tiles,kw_min_tiles,xcd_mode[,rlx_gemm_split_cap])
 """
 import json
 import os
@@ -20,6 +20,9 @@ import torch
 sys.path.insert(0, os.path.join(%r, "tools"))
 import ab_c2
 tuning = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (192, 192, -1)
+if len(tuning) > 3:                       # 4th value: rlx_gemm_split_cap
+    _rlx.lib().gemm_split_cap(tuning[3])
+    tuning = tuning[:3]
 agent = ab_c2.build(False, True, tuning=tuning)
 ts = [ab_c2.train_ms(agent) for _ in range(6)]
 print(json.dumps({"us_per_update": [round(1e3 * t / 320, 1) for t in ts[2:]]}))
