@@ -255,6 +255,7 @@ class SplitkJob(ctypes.Structure):
         return (self.M * self.N + self.N) * self.batch * self.splits if self.splits > 1 else 0
 
 
+ADAM_TICKET_WORDS = 1056        # rlx.h RLX_ADAM_TICKET_WORDS
 MAX_SPLITK_JOBS = 8
 
 

@@ -26,6 +26,26 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// "Am I the last workgroup of this launch?" without 1024 read-modify-writes on ONE word: an agent-scope atomic on one
+// address is performed at the memory side, one after the other (measured ~10 ns each: 1024 of them were +10 us on the C2
+// Adam launch, profiles/r04_ab_adam_norm_in_kernel.txt).  Two levels: workgroup b draws from group b % 32's word (32
+// words on separate 128-byte lines, in parallel), the last of a group draws from the top word — 32 + 32 serialised
+// operations instead of 1024.  Whatever a workgroup made visible at agent scope before its draw is visible to the
+// workgroup this returns true for (the draws are chained through their return values).  Re-arms itself.
+// ticket: RLX_ADAM_TICKET_WORDS zero-initialised 32-bit words.
+constexpr unsigned kTicketGroups = 32, kTicketStride = 32;
+static_assert(kTicketStride * (1 + kTicketGroups) == RLX_ADAM_TICKET_WORDS, "rlx.h: RLX_ADAM_TICKET_WORDS");
+__device__ __forceinline__ bool draw_last_ticket(unsigned int *ticket) {
+    const unsigned G = gridDim.x < kTicketGroups ? gridDim.x : kTicketGroups;
+    const unsigned grp = blockIdx.x % G, gsize = (gridDim.x - grp + G - 1) / G;
+    unsigned int *gw = ticket + kTicketStride * (1 + grp);
+    if (__hip_atomic_fetch_add(gw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gsize - 1) return false;
+    __hip_atomic_store(gw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != G - 1) return false;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // state[0] = beta1_power, state[1] = beta2_power (fp32, device).
 template <bool NORM>
 __global__ void adam_tf1_kernel(float *__restrict__ w, const float *__restrict__ g,
@@ -80,16 +100,19 @@ __global__ void adam_tf1_kernel(float *__restrict__ w, const float *__restrict__
 // Adam (+ per-block partial sums of squares for tf.global_norm) (+ the soft target update in the same elementwise pass).
 // Without the norm the beta-power advance needs no second launch: the block that finishes LAST (a relaxed agent-scope
 // ticket — nothing is published, so no fence) writes the advanced powers; every block read them at its start and has
-// finished.  With the norm the partial sums would have to be PUBLISHED to that block, and a release fence behind
-// 28 B/parameter of stores costs far more than the finish launch it saves (measured: C2 +29 us per update, C3 +68 us,
-// gpurun_out/r02_call24) — there adam_finish_norm_kernel stays a second launch (TICKET = false).
+// finished.  With the norm the partial sums have to be PUBLISHED to that block.  A release fence behind 28 B/parameter
+// of stores costs far more than the finish launch it saves (measured: C2 +29 us per update, C3 +68 us,
+// gpurun_out/r02_call24); round 4 publishes them without one: each partial is ONE agent-scope store (write-through),
+// waited for (vmcnt) before the ticket is drawn, and the last block reads the partials with agent-scope loads.
+// TICKET = false keeps the two-launch form (adam_finish_norm_kernel), which rlx_adam_norm_in_kernel(0) selects.
 template <bool NORM, bool MIX, bool TICKET>
 __global__ void __launch_bounds__(kBlock)
 adam_step_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                  long long n, float lr, float beta1, float beta2, float eps, float *state, float grad_scale,
-                 float *__restrict__ sumsq_part, float *__restrict__ target, float rate, float one_minus_rate,
-                 unsigned int *ticket) {
+                 float *sumsq_part, float *__restrict__ target, float rate, float one_minus_rate,
+                 unsigned int *ticket, float *norm_out, const float *acc_src, float *acc_dst, int n_acc) {
     __shared__ float red[kBlock];
+    __shared__ int last_s;
     float ss = 0.f;
     const float b1p = state[0], b2p = state[1];
     const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
@@ -132,17 +155,149 @@ adam_step_kernel(float *__restrict__ w, const float *__restrict__ g, float *__re
             if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
             __syncthreads();
         }
-        if (threadIdx.x == 0) sumsq_part[blockIdx.x] = red[0];
+        if (threadIdx.x == 0) {
+            // with the ticket: an agent-scope store (written through to the memory side, past this XCD's L2) ...
+            if (TICKET) __hip_atomic_store(&sumsq_part[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else sumsq_part[blockIdx.x] = red[0];
+        }
     }
     if (!TICKET) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == gridDim.x - 1) {
+        // ... that has completed before the ticket is drawn: the partial sums are published without a release fence
+        // (a fence here would first write back every dirty line of the 28 B/parameter this launch stores)
+        if (NORM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool last = draw_last_ticket(ticket);
+        if (last && !NORM) {
             state[0] = b1p * beta1;       // AdamOptimizer._finish: beta1_power *= beta1
             state[1] = b2p * beta2;
-            *ticket = 0u;                 // re-armed for the next launch on the stream
         }
+        last_s = last;
+    }
+    if (!NORM) return;
+    __syncthreads();
+    if (!last_s) return;
+    // adam_finish_norm_kernel's arithmetic, in its order, by the workgroup that drew the last ticket (agent-scope loads:
+    // the partials come from the memory side, not from a stale line of this XCD's L2)
+    float s = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
+        s += __hip_atomic_load(&sumsq_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = kBlock >> 1; d > 0; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        norm_out[0] = sqrtf(red[0]);
+        state[0] = b1p * beta1;
+        state[1] = b2p * beta2;
+        for (int i = 0; i < n_acc; ++i) acc_dst[i] += acc_src[i];
+    }
+}
+
+// Adam + tf.global_norm + the finish in ONE launch, for buffers a grid can hold in registers (<= kNormIt float4 per array
+// and thread).  Why not adam_step_kernel<true, *, true>: there a block's sum of squares is complete only behind its
+// stores, and waiting for the published partial (vmcnt is one in-order counter) means waiting for those stores to drain
+// before the block gives up its slot — that form only breaks even with the finish launch it saves (212.3 vs 212.5 us per
+// C2 update, profiles/r04_ab_adam_norm_in_kernel.txt).  Here every load is issued first, the sum of squares is complete
+// BEFORE the first store, and it is published by an agent-scope atomic exchange issued in front of the stores; at the
+// end of the block the exchange has long returned (the ticket draw is made to depend on its return value), and the
+// block that draws the last ticket does adam_finish_norm_kernel's arithmetic in its order: 210.2 us per update.
+constexpr int kNormIt = 4;
+template <bool MIX>
+__global__ void __launch_bounds__(kBlock)
+adam_step_norm_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                      long long n, float lr, float beta1, float beta2, float eps, float *state, float grad_scale,
+                      float *sumsq_part, float *__restrict__ target, float rate, float one_minus_rate,
+                      unsigned int *ticket, float *norm_out, const float *acc_src, float *acc_dst, int n_acc) {
+    __shared__ float red[kBlock];
+    __shared__ int last_s;
+    const float b1p = state[0], b2p = state[1];
+    const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n >> 2;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 gw[kNormIt], mw[kNormIt], vw[kNormIt], ww[kNormIt], tw[kNormIt];
+#pragma unroll
+    for (int it = 0; it < kNormIt; ++it) {
+        const long long i = i0 + it * stride;
+        if (i < n4) {
+            gw[it] = reinterpret_cast<const float4 *>(g)[i];
+            mw[it] = reinterpret_cast<float4 *>(m)[i];
+            vw[it] = reinterpret_cast<float4 *>(v)[i];
+            ww[it] = reinterpret_cast<float4 *>(w)[i];
+            if (MIX) tw[it] = reinterpret_cast<float4 *>(target)[i];
+        }
+    }
+    const long long it0 = (n4 << 2) + i0;            // the (at most 3) elements behind the last float4: one thread each
+    const bool has_tail = it0 < n;
+    const float gt = has_tail ? g[it0] : 0.f;
+    float ss = 0.f;                                   // the additions of adam_step_kernel<true>, in its order
+#pragma unroll
+    for (int it = 0; it < kNormIt; ++it)
+        if (i0 + it * stride < n4) {
+            const float *gp = &gw[it].x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ss += gp[k] * gp[k];
+        }
+    if (has_tail) ss += gt * gt;
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int d = kBlock >> 1; d > 0; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    float old = 0.f;
+    if (threadIdx.x == 0)
+        old = __hip_atomic_exchange(&sumsq_part[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int it = 0; it < kNormIt; ++it) {
+        const long long i = i0 + it * stride;
+        if (i < n4) {
+            float *gp = &gw[it].x, *mp = &mw[it].x, *vp = &vw[it].x, *wp = &ww[it].x, *tp = &tw[it].x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gr = gp[k] * grad_scale;
+                mp[k] += (gr - mp[k]) * omb1;
+                vp[k] += (gr * gr - vp[k]) * omb2;
+                wp[k] -= (mp[k] * alpha) / (sqrtf(vp[k]) + eps);
+                if (MIX) tp[k] = rate * wp[k] + one_minus_rate * tp[k];
+            }
+            reinterpret_cast<float4 *>(m)[i] = mw[it];
+            reinterpret_cast<float4 *>(v)[i] = vw[it];
+            reinterpret_cast<float4 *>(w)[i] = ww[it];
+            if (MIX) reinterpret_cast<float4 *>(target)[i] = tw[it];
+        }
+    }
+    if (has_tail) {
+        const float gr = gt * grad_scale;
+        m[it0] += (gr - m[it0]) * omb1;
+        v[it0] += (gr * gr - v[it0]) * omb2;
+        w[it0] -= (m[it0] * alpha) / (sqrtf(v[it0]) + eps);
+        if (MIX) target[it0] = rate * w[it0] + one_minus_rate * target[it0];
+    }
+    if (threadIdx.x == 0) {
+        asm volatile("" ::"v"(old) : "memory");        // the draw is not issued before the exchange has returned
+        last_s = draw_last_ticket(ticket);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
+        s += __hip_atomic_load(&sumsq_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = kBlock >> 1; d > 0; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        norm_out[0] = sqrtf(red[0]);
+        state[0] = b1p * beta1;
+        state[1] = b2p * beta2;
+        for (int i = 0; i < n_acc; ++i) acc_dst[i] += acc_src[i];
     }
 }
 
@@ -227,6 +382,7 @@ __global__ void clip_by_global_norm_kernel(float *__restrict__ g, long long n, c
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= scale;
 }
 
+int g_norm_in_kernel = 2;       // rlx_adam_norm_in_kernel
 }  // namespace
 
 extern "C" {
@@ -281,6 +437,11 @@ int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, lo
     return RLX_OK;
 }
 
+int rlx_adam_norm_in_kernel(int on) {
+    g_norm_in_kernel = on;
+    return RLX_OK;
+}
+
 int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
                       float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
                       float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
@@ -300,7 +461,28 @@ int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, lo
 #define RLX_ADAM_STEP(NORM, MIX, TICKET)                                                                      \
     RLX_LAUNCH((adam_step_kernel<NORM, MIX, TICKET>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1,  \
                                                                   beta2, epsilon, state, grad_scale, workspace, \
-                                                                  target, rate, omr, ticket)
+                                                                  target, rate, omr, ticket, nullptr, nullptr, nullptr, 0)
+    // one launch with the norm as well (the finish by the last workgroup, see adam_step_kernel)
+    if (norm_out && g_norm_in_kernel == 2 && (n >> 2) <= (long long)blocks * kBlock * kNormIt) {
+        if (target)
+            RLX_LAUNCH((adam_step_norm_kernel<true>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1, beta2,
+                       epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc);
+        else
+            RLX_LAUNCH((adam_step_norm_kernel<false>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1, beta2,
+                       epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc);
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
+    }
+    if (norm_out && g_norm_in_kernel == 1) {
+        if (target)
+            RLX_LAUNCH((adam_step_kernel<true, true, true>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1,
+                       beta2, epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc);
+        else
+            RLX_LAUNCH((adam_step_kernel<true, false, true>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1,
+                       beta2, epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc);
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
+    }
     if (norm_out && target) RLX_ADAM_STEP(true, true, false);
     else if (norm_out) RLX_ADAM_STEP(true, false, false);
     else if (target) RLX_ADAM_STEP(false, true, true);

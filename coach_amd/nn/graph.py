@@ -741,7 +741,7 @@ class AdamState:
         self.m = torch.empty_like(params.weights)
         self.v = torch.empty_like(params.weights)
         self.state = torch.empty(2, dtype=torch.float32, device=dev)
-        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # rlx_adam_tf1_step's last-arriver word
+        self.ticket = torch.zeros(_rlx.ADAM_TICKET_WORDS, dtype=torch.int32, device=dev)   # rlx_adam_tf1_step's last-arriver count
         self.one_launch = True
         _rlx.lib().adam_init(self.m, self.v, params.size, self.state, beta1, beta2, _rlx.current_stream())
 

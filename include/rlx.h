@@ -570,14 +570,22 @@ int rlx_adam_tf1_norm(float *weights, const float *grads, float *m, float *v, lo
                       const float *acc_src, float *acc_dst, int n_acc, void *stream);
 /* rlx_adam_tf1 / rlx_adam_tf1_norm with (target != NULL) the soft target update
  * target = rate * w_new + (1 - rate) * target (rlx_mix_weights' arithmetic) in the same elementwise pass.  Without
- * norm_out it is ONE launch: the last workgroup to finish (device ticket, no fence) advances the beta powers; with
- * norm_out the norm / beta-power / signal-sum finish stays a second small launch (publishing the partial sums from
- * every workgroup costs more than that launch).  ticket: one zero-initialised 32-bit device word owned by this
- * optimiser; the kernel re-arms it. */
+ * norm_out it is ONE launch: the last workgroup to finish (device ticket, no fence) advances the beta powers.  With
+ * norm_out it is one launch as well when a workgroup's share fits its registers (up to 4.2 M parameters; larger buffers
+ * take the two-launch form): the sums of squares are complete before the first store and are published without a
+ * release fence (agent-scope atomics), and the workgroup that draws the last ticket does the finish — same arithmetic,
+ * same order, bit-identical to the two-launch form.
+ * ticket: RLX_ADAM_TICKET_WORDS zero-initialised 32-bit device words owned by this optimiser (a two-level last-arriver
+ * count: 32 group words + 1, each on its own 128-byte line); the kernel re-arms them. */
+#define RLX_ADAM_TICKET_WORDS 1056
 int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
                       float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
                       float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
                       float *target, double mix_rate, unsigned int *ticket, void *stream);
+/* How rlx_adam_tf1_step finishes the gradient norm: 2 (default) inside the Adam launch, the workgroup's share held in
+ * registers (falls back to 0 beyond 4.2 M parameters); 1: inside the grid-stride Adam launch (any size; measured equal to
+ * 0); 0: the separate finish launch.  Process-wide, read at launch / capture time: for same-process A/Bs and tests. */
+int rlx_adam_norm_in_kernel(int on);
 int rlx_mix_weights(float *target, const float *online, long long n, double rate,
                     void *stream);   /* architectures/tensorflow_components/architecture.py:598-607 */
 int rlx_global_norm(const float *x, long long n, float *norm_out, float *workspace,

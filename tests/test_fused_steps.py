@@ -190,15 +190,19 @@ def test_sac_min_targets_equals_min_pair_and_value_targets(dev):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,with_norm,with_mix", [(3_400_000, True, False), (130_001, True, True), (70_000, False, True),
-                                                   (257, False, False)])
-def test_adam_step_one_launch_equals_adam_finish_and_mix(dev, n, with_norm, with_mix):
+@pytest.mark.parametrize("n,with_norm,with_mix,norm_in_kernel", [
+    (3_400_000, True, False, 2), (130_001, True, True, 2), (70_000, False, True, 2), (257, False, False, 2),
+    (5_000_003, True, True, 2),        # beyond a workgroup's registers: the separate finish launch
+    (3_400_000, True, False, 1), (5_000_003, True, True, 1), (130_001, True, True, 1),   # grid-stride one-launch form
+    (130_001, True, True, 0), (3_400_000, True, False, 0)])                              # always two launches
+def test_adam_step_one_launch_equals_adam_finish_and_mix(dev, n, with_norm, with_mix, norm_in_kernel):
     """rlx_adam_tf1_step (Adam + norm + beta-power advance by the last workgroup to finish, + the soft target update in
     the same pass) against rlx_adam_tf1(_norm) followed by rlx_mix_weights: weights, slots, beta powers, norm, signal
     sums and target bit for bit, over several steps (the ticket re-arms itself)."""
     import torch
     from coach_amd import _rlx
     lib, s_ = _rlx.lib(), _rlx.current_stream()
+    lib.adam_norm_in_kernel(norm_in_kernel)
     rng = np.random.RandomState(n % 1000)
     w0 = rng.randn(n).astype(np.float32)
     t0 = rng.randn(n).astype(np.float32)
@@ -212,7 +216,7 @@ def test_adam_step_one_launch_equals_adam_finish_and_mix(dev, n, with_norm, with
     a, b = fresh(), fresh()
     ws_a = torch.empty(1 << 12, dtype=torch.float32, device=dev)
     ws_b = torch.empty(1 << 12, dtype=torch.float32, device=dev)
-    ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+    ticket = torch.zeros(_rlx.ADAM_TICKET_WORDS, dtype=torch.int32, device=dev)
     for step in range(4):
         g = _t((rng.randn(n) * 0.1).astype(np.float32), dev)
         src = _t(rng.randn(3).astype(np.float32), dev)
@@ -229,4 +233,5 @@ def test_adam_step_one_launch_equals_adam_finish_and_mix(dev, n, with_norm, with
                           b["t"] if with_mix else None, 0.005, ticket, s_)
         for k in a:
             assert torch.equal(a[k], b[k]), (step, k)
-        assert int(ticket.item()) == 0
+        assert int(ticket.abs().sum().item()) == 0
+    lib.adam_norm_in_kernel(2)

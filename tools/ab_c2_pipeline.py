@@ -2,7 +2,8 @@
 runs bench.py's agent in its own process, alternately, `rounds` times; us per update = hipGraph replay of 10 epochs x
 32 minibatches / 320, the minimum over the rounds.
     python tools/ab_c2_pipeline.py rounds lib:mode [lib:mode ...]      e.g.  2 coach_amd/librlx.so:0 coach_amd/ab/librlx_d2.so:1 coach_amd/librlx.so:0:192,200,-1
-(the optional third field is rlx_gemm_tuning's kw_below_tiles,kw_min_tiles,xcd_mode[,rlx_gemm_split_cap])
+(the optional third field is rlx_gemm_tuning's kw_below_tiles,kw_min_tiles,xcd_mode[,rlx_gemm_split_cap]; an optional fourth
+field is a list of knob=value calls, e.g. lib:1:192,192,-1:adam_norm_in_kernel=0)
 """
 import json
 import os
@@ -23,6 +24,9 @@ tuning = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else
 if len(tuning) > 3:                       # 4th value: rlx_gemm_split_cap
     _rlx.lib().gemm_split_cap(tuning[3])
     tuning = tuning[:3]
+for kv in (sys.argv[4].split(",") if len(sys.argv) > 4 else []):      # knob=value: lib.<knob>(int(value))
+    k, v = kv.split("=")
+    getattr(_rlx.lib(), k)(int(v))
 agent = ab_c2.build(False, True, tuning=tuning)
 ts = [ab_c2.train_ms(agent) for _ in range(6)]
 print(json.dumps({"us_per_update": [round(1e3 * t / 320, 1) for t in ts[2:]]}))
@@ -34,7 +38,7 @@ def main():
     cfgs = []
     for a in sys.argv[2:]:                 # lib:mode[:kw_below,kw_min,xcd_mode]
         parts = a.split(":")
-        cfgs.append((os.path.abspath(parts[0]), parts[1]) + ((parts[2],) if len(parts) > 2 else ()))
+        cfgs.append((os.path.abspath(parts[0]), parts[1]) + tuple(parts[2:4]))
     res = {c: [] for c in cfgs}
     for _ in range(rounds):
         for c in cfgs:
@@ -45,8 +49,8 @@ def main():
                 raise SystemExit(1)
             res[c] += json.loads(line[-1])["us_per_update"]
     for c, v in res.items():
-        print("%-34s pipeline %s tuning %-12s: %.1f us per update (all: %s)" % (
-            os.path.relpath(c[0], ROOT), c[1], c[2] if len(c) > 2 else "default", min(v), v))
+        print("%-34s pipeline %s tuning %-12s %-24s: %.1f us per update (all: %s)" % (
+            os.path.relpath(c[0], ROOT), c[1], c[2] if len(c) > 2 else "default", c[3] if len(c) > 3 else "", min(v), v))
 
 
 if __name__ == "__main__":
