@@ -15,6 +15,8 @@ import torch
 from coach_amd import _rlx
 from coach_amd.nn.networks import ClippedPPONet
 
+if "--lib" in sys.argv:               # another build of the library (tools/ab_lib.sh)
+    _rlx.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 if "--pipeline" in sys.argv:          # rlx_gemm_pipeline: 1 = LDS-DMA ring (default), 0 = register-staged
     _rlx.lib().gemm_pipeline(int(sys.argv[sys.argv.index("--pipeline") + 1]))
 dev = torch.device("cuda:0")
