@@ -1101,6 +1101,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     const long long a_step = (long long)BK * g.a.stride_r, b_step = (long long)BK * g.b.stride_r;
     const int nfull = len / BK;                             // slabs [0, nfull) are inside the chunk for every lane
     auto issue = [&](const int s_idx, const int buf) {      // buf is a compile-time constant at every call site
+#ifdef RLX_DBG_NO_DMA       // timing experiment only (wrong results): what the loop costs without the operand traffic
+        return;
+#endif
         const unsigned dst = lds0 + (unsigned)(buf * SLAB) * 4u;
         const bool full = s_idx < nfull;                    // wave-uniform
 #pragma unroll
@@ -1145,11 +1148,14 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
                         : A_VEC_RED ? a_row * 32 + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BM + a_row;
         b_rd[qq] = B_VEC_RED ? b_col * 32 + (((2 * q + hi) ^ ((b_col >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BN + b_col;
     }
-    auto mfma_slab = [&](const int buf) {                   // buf: compile-time constant at every call site
+    // The slab step is software-pipelined through REGISTERS: while the MFMA chain of slab s runs, the operands of slab
+    // s + 1 are already being read from LDS into the other register set, behind the wait / barrier / DMA issue that made
+    // them available — those sit in the MIDDLE of the chain (an MFMA is issued and executes on its own; the wave goes on
+    // to the independent instructions behind it).  With one wave per SIMD (the forward products: 196-400 workgroups on
+    // 256 CUs) nothing else can fill the matrix pipe while a wave waits, reads and synchronises: the step took ~1 275
+    // cycles for 512 cycles of MFMAs at KW = 2, whatever the ring depth (profiles/r04_timeline_ring_depth.txt).
+    auto load_ops = [&](const int buf, float (&av)[QS][4], float (&bv)[QS][4]) {   // buf: compile-time constant at every call site
         const float *as = smem + buf * SLAB, *bs = as + A_SLAB;
-        // every operand of the slab is requested from LDS first (32 registers at KW = 1), then the MFMA chain runs behind
-        // counted lgkmcnt waits: one LDS latency per slab instead of one per four MFMAs
-        float av[QS][4], bv[QS][4];
 #pragma unroll
         for (int qq = 0; qq < QS; ++qq) {
             if (A_U8 && A_VEC_RED) {
@@ -1174,12 +1180,6 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
                 for (int i = 0; i < 4; ++i) bv[qq][i] = bs[b_rd[qq] + i * BN];
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int qq = 0; qq < QS; ++qq)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[qq][i], bv[qq][i], acc[0][0], 0, 0, 0);
         if (do_colsum) {
             float sc = 0.f;
             if (B_VEC_RED) {
@@ -1195,24 +1195,50 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
             csum += sc;
         }
     };
+    // MFMA steps [t0, t1) of a slab's 4 * QS (the order of the sum inside a slab is unchanged: quad by quad, i = 0..3)
+    auto mfma_steps = [&](const float (&av)[QS][4], const float (&bv)[QS][4], const int t0, const int t1) {
+#ifdef RLX_DBG_NO_MFMA      // timing experiment only (wrong results): what the loop costs without the matrix work
+#pragma unroll
+        for (int t = t0; t < t1; ++t) acc[0][0][t & 15] += av[t >> 2][t & 3] * bv[t >> 2][t & 3];
+#else
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t >> 2][t & 3], bv[t >> 2][t & 3], acc[0][0], 0, 0, 0);
+#endif
+    };
 
     if (kbeg < kend) {
         const int nslab = (len + BK - 1) / BK;
+        float ra[2][QS][4], rb[2][QS][4];                    // operand registers of the slab in the chain / the next one
 #pragma unroll
         for (int d = 0; d < D - 1; ++d) issue(d, d);
+        // slab 0: landed once all but the (D - 2) * L newest requests of this lane are complete, for every wave
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (D - 2)) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        issue(D - 1, D - 1);
+        load_ops(0, ra[0], rb[0]);
         if (stamp) stamp[1] = wall_clock64();
-        // D slab steps per trip so that every buffer index is a compile-time constant (slab s + d lives in buffer d)
-        for (int s = 0; s < nslab; s += D) {
+        // U slab steps per trip so that buffer index (s % D) and register set (s % 2) are compile-time constants
+        constexpr int U = D % 2 == 0 ? D : 2 * D;
+        constexpr int T = 4 * QS, TH = T / 2;
+        for (int s = 0; s < nslab; s += U) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
+            for (int d = 0; d < U; ++d) {
                 if (s + d < nslab) {                         // wave-uniform
-                    // slab s + d has landed once all but the (D - 2) * L newest requests of this lane are complete ...
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (D - 2)) : "memory");
-                    // ... for every wave of the workgroup; and everyone is done reading the slab before it, whose buffer
-                    // is refilled next
-                    asm volatile("s_barrier" ::: "memory");
-                    issue(s + d + D - 1, (d + D - 1) % D);
-                    mfma_slab(d);
+                    mfma_steps(ra[d & 1], rb[d & 1], 0, TH);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + d + 1 < nslab) {
+                        // slab s + d + 1 has landed (this lane's requests) ...
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (D - 2)) : "memory");
+                        // ... this wave's LDS reads of slab s + d are complete (they fed the MFMAs above) ...
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        // ... for every wave: slab s + d + 1 may be read, the buffer of slab s + d refilled
+                        asm volatile("s_barrier" ::: "memory");
+                        issue(s + d + D, d % D);
+                        load_ops((d + 1) % D, ra[(d + 1) & 1], rb[(d + 1) & 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_steps(ra[d & 1], rb[d & 1], TH, T);
                 }
             }
         }

@@ -21,6 +21,70 @@ __global__ void probe_chase_kernel(const int *__restrict__ chain, int start, int
     for (int s = 0; s < steps; ++s) i = chain[i];
     *out = i;
 }
+// every wave runs `iters` dependent v_mfma_f32_32x32x2_f32 (one accumulator: the chain of a GEMM slab) between two
+// readings of the shader-clock counter and of the constant 100 MHz counter; lane 0 of every workgroup's wave 0 records
+// both differences: cycles per MFMA, and the clock the shader actually ran at under that load
+__global__ void __launch_bounds__(256) probe_mfma_kernel(int iters, long long *__restrict__ out, float *__restrict__ sink) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float a = 1.f + threadIdx.x * 1e-6f, b = 1.f - threadIdx.x * 1e-6f;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    float keep = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) keep += acc[r];
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (keep == 12345.678f) *sink = keep;                    // never true: the chain stays live
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = w1 - w0;
+    }
+}
+// How long do K back-to-back 16-byte-per-lane loads of one wave take — as global -> LDS requests (global_load_lds_dwordx4)
+// and as ordinary loads into registers?  Every wave of the workgroup issues K requests for lines of an L2-resident
+// buffer and waits for all of them; lane 0 of wave 0 records the shader cycles.
+template <int K, bool LDS_DMA>
+__global__ void __launch_bounds__(256) probe_requests_kernel(const float *__restrict__ src, long long *__restrict__ out,
+                                                             float *__restrict__ sink, int round) {
+    __shared__ __attribute__((aligned(1024))) float ring[K * 1024 + 4];        // K x 4 KB (256 lanes x 16 bytes)
+    const int tid = threadIdx.x, wid = tid >> 6;
+    const float *p = src + ((size_t)blockIdx.x * 256 + tid) * 4 + (size_t)(round & 0xffff) * 64;
+    if (wid >= (round >> 16) && (round >> 16) > 0) {          // round >> 16 = number of waves that issue (0: all four)
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        static_cast<unsigned>(reinterpret_cast<uintptr_t>(ring)) + (unsigned)wid * 1024u);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v[K];
+    __syncthreads();
+    const long long c0 = clock64();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float *q = p + (size_t)k * 256 * 1024;           // another 1 MB page of the buffer per request
+        if (LDS_DMA) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(q), "s"(lds0 + 4096u * k) : "memory");
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[k]) : "v"(q) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long c1 = clock64();
+    float keepv = 0.f;
+    if (!LDS_DMA) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) keepv += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    __syncthreads();
+    if (LDS_DMA) keepv = ring[tid];
+    if (keepv == 12345.678f) *sink = keepv;
+    if (tid == 0) out[blockIdx.x] = c1 - c0;
+}
 }  // namespace
 
 extern "C" {
@@ -79,6 +143,37 @@ int rlx_probe_chase(const int *chain, int start, int steps, int *out, void *stre
     RLX_REQUIRE(chain && out && start >= 0 && steps > 0, "rlx_probe_chase: bad arguments");
     RLX_LAUNCH((probe_chase_kernel), 1, 1, 0, rlx::as_stream(stream), chain, start, steps, out);
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+// Matrix-pipe clock probe (measurement utility, no reference counterpart): `workgroups` x 4 waves each run `iters`
+// dependent fp32 32x32x2 MFMAs; out[2 w] = shader-clock cycles, out[2 w + 1] = ticks of the constant 100 MHz counter of
+// workgroup w.  cycles / iters = cycles per MFMA of a dependent chain; cycles / ticks * 100 = the shader clock in MHz
+// under that load (bench.py's `box` block).
+int rlx_probe_mfma(int workgroups, int iters, long long *out, float *sink, void *stream) {
+    RLX_REQUIRE(workgroups > 0 && iters > 0 && out && sink, "rlx_probe_mfma: bad arguments");
+    RLX_LAUNCH((probe_mfma_kernel), workgroups, 256, 0, rlx::as_stream(stream), iters, out, sink);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+// Request-pipelining probe (measurement utility): every wave of `workgroups` workgroups issues `requests` (1, 2, 4, 8)
+// back-to-back 16-byte-per-lane loads — global -> LDS (lds_dma != 0) or into registers — from `src` (>= 9 MB + the
+// workgroups' share) and waits for all of them; out[w] = shader cycles of workgroup w.
+int rlx_probe_requests(int workgroups, int requests, int lds_dma, int round, const float *src, long long *out, float *sink,
+                       void *stream) {
+    RLX_REQUIRE(workgroups > 0 && src && out && sink, "rlx_probe_requests: bad arguments");
+    hipStream_t s = rlx::as_stream(stream);
+#define RLX_PROBE_REQ(K)                                                                                   \
+    if (requests == K) {                                                                                   \
+        if (lds_dma) RLX_LAUNCH((probe_requests_kernel<K, true>), workgroups, 256, 0, s, src, out, sink, round);  \
+        else RLX_LAUNCH((probe_requests_kernel<K, false>), workgroups, 256, 0, s, src, out, sink, round);         \
+        RLX_LAUNCH_CHECK();                                                                                \
+        return RLX_OK;                                                                                     \
+    }
+    RLX_PROBE_REQ(1) RLX_PROBE_REQ(2) RLX_PROBE_REQ(4) RLX_PROBE_REQ(8)
+#undef RLX_PROBE_REQ
+    RLX_REQUIRE(false, "rlx_probe_requests: requests must be 1, 2, 4 or 8");
     return RLX_OK;
 }
 

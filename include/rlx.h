@@ -48,6 +48,16 @@ int rlx_event_elapsed_ms(void *start, void *stop, float *ms_host); /* syncs on s
 /* Latency probe for bench.py's `box` block (no reference counterpart): one lane follows `steps` dependent 4-byte loads
  * i = chain[i] from `start` and stores the last index in *out; time it with events. */
 int rlx_probe_chase(const int *chain, int start, int steps, int *out, void *stream);
+/* Matrix-pipe clock probe (measurement utility): `workgroups` x 4 waves each run `iters` dependent
+ * v_mfma_f32_32x32x2_f32; out[2 w] = shader-clock cycles and out[2 w + 1] = ticks of the constant 100 MHz counter that
+ * workgroup w's chain took: cycles per MFMA, and the clock the shader really ran at under that load. */
+int rlx_probe_mfma(int workgroups, int iters, long long *out, float *sink, void *stream);
+/* Request-pipelining probe (measurement utility): every wave of `workgroups` workgroups issues `requests` (1, 2, 4 or 8)
+ * back-to-back 16-byte-per-lane loads from src — global -> LDS requests (lds_dma != 0: what the GEMM ring issues) or
+ * ordinary loads into registers — and waits for all of them; out[w] = shader-clock cycles of workgroup w.  src: at least
+ * 8 MB + 4 KB * workgroups + 256 * round bytes. */
+int rlx_probe_requests(int workgroups, int requests, int lds_dma, int round, const float *src, long long *out, float *sink,
+                       void *stream);
 
 /* In-process kernel timer: between rlx_profile_begin and rlx_profile_end every kernel this library launches (EAGER
  * launches on any stream; do not arm it inside a stream capture) carries its own start / stop event pair filled from
