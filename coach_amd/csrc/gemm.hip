@@ -25,6 +25,7 @@
 // deterministically by splitk_reduce_kernel, which also applies bias / activation.
 // blockIdx.z also carries a batch index (the two separate Clipped-PPO towers run as one launch).
 #include "rlx_common.hpp"
+#include "dense_small_body.hpp"
 #include <cstdlib>
 
 namespace {
@@ -1659,6 +1660,142 @@ __global__ void __launch_bounds__(64 * SG) splitk_reduce4_kernel(const GemmDev g
 }
 
 // The outstanding reductions of several deferred products in ONE launch (rlx_splitk_reduce_jobs): blockIdx.z = job,
+// splitk_reduce4_kernel<16> for ONE ROW per workgroup (blockIdx.x = row, blockIdx.y = batch entry; 64 float4 groups per
+// pass, N / 256 passes: every output goes through exactly that kernel's additions) + the narrow layers that read the row
+// (rlx_gemm_desc.row_heads): the finished row — bias and activation applied — is kept in LDS, and the first four waves
+// then run dense_small_fwd_row's arithmetic on it (a quarter of K per wave, lanes stride over k, wave butterfly, the four
+// partials combined in order): the head outputs are bit-identical to rlx_dense_small_forward_multi's, one launch earlier.
+constexpr int kRowHeadsMaxN = 2048;
+// P = passes of 64 float4 groups that cover a row (N <= 256 P).  Everything the workgroup reads is requested before
+// the first barrier — the partials of ALL passes, the epilogue operands, the head's weight rows — so that the row costs
+// one exposed memory round trip, like the reduction alone did.
+template <int NN, int P>
+__global__ void __launch_bounds__(1024) splitk_reduce_rows_kernel(const GemmDev g, const rlx_small::MultiFwd heads) {
+    constexpr int SG = 16;
+    __shared__ float4 part[SG][64];
+    __shared__ float hrow[256 * P];
+    __shared__ float hpart[4][NN];
+    const int row = blockIdx.x, batch = blockIdx.y;
+    const int n4 = g.N >> 2, mn4 = (g.M * g.N) >> 2;
+    const int ox = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int lane = ox, wave = q;
+    const size_t mn = (size_t)g.M * g.N;
+    const float4 *ws = reinterpret_cast<const float4 *>(g.ws + (size_t)batch * g.splits * mn);
+    const rlx_small::SmallDense &hp = heads.p[batch];
+    const bool has_head = hp.w != nullptr;                    // workgroup-uniform
+    // the head's weight rows of this lane (waves 0-3: a quarter of K each, lanes stride over k): P rows of N floats
+    const int kq = has_head ? (hp.K + 3) / 4 : 0;
+    const int k1 = has_head && wave < 4 ? min(hp.K, (wave + 1) * kq) : 0;
+    float wreg[P][NN];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int k = wave * kq + lane + 64 * j;
+#pragma unroll
+        for (int n = 0; n < NN; ++n) wreg[j][n] = (has_head && wave < 4 && k < k1 && n < hp.N) ? hp.w[(size_t)k * hp.N + n] : 0.f;
+    }
+    float4 sp[P];
+    float eb[P][4], ea[P][4], ec[P][4];
+#pragma unroll
+    for (int ps = 0; ps < P; ++ps) {
+        const bool live = ps * 64 + ox < n4;
+        const int gid = row * n4 + ps * 64 + ox, col = (ps * 64 + ox) << 2;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) eb[ps][jj] = ea[ps][jj] = ec[ps][jj] = 0.f;
+        if (q == 0 && live) {
+            const float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc + col;
+            const float *bias = !g.bias ? nullptr
+                                        : g.bias + batch_off(batch, g.inner, g.bias_batch_stride, g.bias_batch_stride2) + col;
+            const float *aux = g.aux ? g.aux + (size_t)batch * g.aux_batch_stride + (size_t)row * g.aux_ld + col : nullptr;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (bias) eb[ps][jj] = bias[jj];
+                if (aux) ea[ps][jj] = aux[jj];
+                if (g.accumulate) ec[ps][jj] = c[jj];
+            }
+        }
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {                                           // splitk_reduce4_kernel<16>'s additions, in its order
+            int k = q;
+            for (; k + 3 * SG < g.splits; k += 4 * SG) {
+                const float4 a = ws[(size_t)k * mn4 + gid];
+                const float4 b = ws[(size_t)(k + SG) * mn4 + gid];
+                const float4 cc = ws[(size_t)(k + 2 * SG) * mn4 + gid];
+                const float4 d = ws[(size_t)(k + 3 * SG) * mn4 + gid];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+                s.x += cc.x; s.y += cc.y; s.z += cc.z; s.w += cc.w;
+                s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+            }
+            for (; k < g.splits; k += SG) {
+                const float4 a = ws[(size_t)k * mn4 + gid];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+        }
+        sp[ps] = s;
+    }
+#pragma unroll
+    for (int ps = 0; ps < P; ++ps) {
+        const bool live = ps * 64 + ox < n4;
+        const int col = (ps * 64 + ox) << 2;
+        if (ps > 0) __syncthreads();                          // part is reused
+        part[q][ox] = sp[ps];
+        __syncthreads();
+        if (q == 0 && live) {
+            float *c = g.c + (size_t)batch * g.c_batch_stride + (size_t)row * g.ldc + col;
+            float v[4] = {sp[ps].x, sp[ps].y, sp[ps].z, sp[ps].w};
+#pragma unroll
+            for (int t = 1; t < SG; ++t) {
+                const float4 pp = part[t][ox];
+                v[0] += pp.x; v[1] += pp.y; v[2] += pp.z; v[3] += pp.w;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                float t = apply_act(v[jj] + eb[ps][jj], g.act);
+                if (g.aux) t *= act_deriv(ea[ps][jj], g.deriv);
+                v[jj] = g.accumulate ? ec[ps][jj] + t : t;
+                hrow[col + jj] = v[jj];
+            }
+            if ((g.ldc & 3) == 0 && (((uintptr_t)c) & 15) == 0) {
+                *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
+            }
+        }
+    }
+    if (!has_head) return;
+    __syncthreads();                                          // the row is complete in LDS
+    // ---- dense_small_fwd_row on it: lane's k = wave * kq + lane + 64 j, ascending, fmaf per output
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[n] = 0.f;
+    if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int k = wave * kq + lane + 64 * j;
+            if (k < k1) {
+                const float xv = hrow[k];
+#pragma unroll
+                for (int n = 0; n < NN; ++n)
+                    if (n < hp.N) acc[n] = fmaf(xv, wreg[j][n], acc[n]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            float v = acc[n];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) hpart[wave][n] = v;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < hp.N) {
+        const int n = threadIdx.x;
+        float v = ((hpart[0][n] + hpart[1][n]) + hpart[2][n]) + hpart[3][n];
+        v += hp.b ? hp.b[n] : 0.f;
+        hp.y[(size_t)row * hp.N + n] = rlx_small::act_apply(v, hp.act);
+    }
+}
+
 // blockIdx.y = batch entry of the job, blockIdx.x = 64 float4 output groups; the scheme of splitk_reduce4_kernel<16>
 // (16 split groups per output group, partials of group q summed in increasing split order, groups combined in the
 // fixed order ((s0 + s1) + s2) + ...).  Plain store: a weight gradient has no epilogue.
@@ -2039,6 +2176,53 @@ int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, 
     return RLX_OK;
 }
 
+// rlx_gemm_desc.row_heads: the reduction pass of a product split over K finishes whole rows and runs the narrow layers that
+// read them (splitk_reduce_rows_kernel).  Returns false when the combination is not the one that kernel reproduces bit
+// for bit (the caller then reduces as usual and rlx_gemm launches the heads behind it).
+thread_local bool tl_row_heads_done = false;
+bool launch_reduce_with_row_heads(const GemmDev &g, const rlx_gemm_desc &d, int splits, hipStream_t s) {
+    const long long mn = (long long)d.M * d.N;
+    if (splits <= 16 || d.N % 4 != 0 || mn >= (1LL << 31) || !aligned16(g.ws) || g.fold || g.colsum ||
+        d.N > kRowHeadsMaxN || d.batch > rlx_small::kMaxProblems || d.n_row_heads > d.batch)
+        return false;
+    rlx_small::MultiFwd m;
+    m.n = d.batch;
+    for (int t = 0; t < rlx_small::kMaxProblems; ++t) {
+        m.p[t] = rlx_small::SmallDense{nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0};
+        m.towers[t] = 0;
+    }
+    int nn = 1;
+    for (int i = 0; i < d.n_row_heads; ++i) {
+        const rlx_small_dense_problem &q = d.row_heads[i];
+        if (!q.x || !q.w || !q.y || q.towers != 1 || q.M != d.M || q.K != d.N || q.N < 1 || q.N > rlx_small::kMaxN ||
+            q.activation < 0 || q.activation > 2)
+            return false;
+        int t = -1;
+        for (int b = 0; b < d.batch; ++b)
+            if (q.x == d.C + (size_t)b * d.c_batch_stride) t = b;
+        if (t < 0 || m.p[t].w || d.ldc != d.N) return false;
+        m.p[t] = rlx_small::SmallDense{q.x, 0, q.w, 0, q.bias, 0, q.y, 0, q.M, q.K, q.N, q.activation};
+        m.towers[t] = 1;
+        const int c = q.N == 1 ? 1 : (q.N <= 4 ? 4 : (q.N <= 8 ? 8 : 16));
+        if (c > nn) nn = c;
+    }
+    dim3 rgrid(d.M, d.batch);
+    const int passes = (d.N / 4 + 63) / 64;                 // 1 .. 8
+#define RLX_ROWS(NNV, PV) RLX_LAUNCH((splitk_reduce_rows_kernel<NNV, PV>), rgrid, 1024, 0, s, g, m)
+#define RLX_ROWS_P(NNV)                                    \
+    if (passes <= 1) RLX_ROWS(NNV, 1);                     \
+    else if (passes <= 2) RLX_ROWS(NNV, 2);                \
+    else if (passes <= 4) RLX_ROWS(NNV, 4);                \
+    else RLX_ROWS(NNV, 8)
+    if (nn == 1) { RLX_ROWS_P(1); }
+    else if (nn == 4) { RLX_ROWS_P(4); }
+    else if (nn == 8) { RLX_ROWS_P(8); }
+    else { RLX_ROWS_P(16); }
+#undef RLX_ROWS_P
+#undef RLX_ROWS
+    return true;
+}
+
 // what a deferred reduction needs (rlx_gemm_defer): only a product with the plain-store epilogue and partials the
 // float4 reduce scheme can read qualifies; anything else is reduced at once (job->splits = 0)
 bool deferrable(const GemmDev &g, int M, int N) {
@@ -2265,6 +2449,11 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
             fill_job(defer, g, d.M, d.N, d.batch, splits);
             return RLX_OK;
         }
+        if (d.row_heads && d.n_row_heads > 0 && launch_reduce_with_row_heads(g, d, splits, s)) {
+            tl_row_heads_done = true;
+            RLX_LAUNCH_CHECK();
+            return RLX_OK;
+        }
         return launch_splitk_reduce(g, d.M, d.N, d.batch, splits, s);
     }
     return RLX_OK;
@@ -2274,7 +2463,12 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
 
 extern "C" {
 
-int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) { return gemm_impl(d_host, stream, nullptr); }
+int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
+    tl_row_heads_done = false;
+    const int rc = gemm_impl(d_host, stream, nullptr);
+    if (rc != RLX_OK || !d_host->row_heads || d_host->n_row_heads <= 0 || tl_row_heads_done) return rc;
+    return rlx_dense_small_forward_multi(d_host->row_heads, d_host->n_row_heads, stream);   // not fused: behind the product
+}
 
 static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad, void *stream,
                           rlx_splitk_job *defer);

@@ -282,7 +282,7 @@ class Dense(Layer):
                 xavier_uniform(rng, self.K, self.N, (self.K, self.N))
             self.params.w(self.kname, t).copy_(torch.from_numpy(np.ascontiguousarray(w)))
 
-    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False, launch=True):
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False, launch=True, row_heads=None):
         """pair=True: the online and the target copy of the layer in one launch — towers [0, T) use
         the online weights, [T, 2T) the target weights (FlatParams.both); x carries either one tower
         per copy (shared by the T streams of a copy) or one per (copy, stream).
@@ -307,7 +307,7 @@ class Dense(Layer):
             assert x.towers in (0, T), (self.name, x.towers, T)
             a_stride, TT = x.tower_stride(), T
         y = ctx.buffer(self.name, (TT, M, self.N), tag=tag)
-        desc = None
+        desc, head_outs = None, None
         if self.N <= SMALL_N and not x.u8:
             # heads: coalesced FMA kernel, no MFMA tile / split-K round trip (csrc/dense_small.hip)
             if not pair:
@@ -332,6 +332,9 @@ class Dense(Layer):
                       activation=self.act, batch=1, b_batch_stride=wstride, c_batch_stride=M * self.N,
                       bias_batch_stride=bstride, workspace=ctx.ws.splitk, n_fold=self.N)
         else:
+            if row_heads:
+                heads_arr, head_outs = row_head_problems(ctx, row_heads, y, M, self.N, tag, weights)
+                kw = dict(kw, row_heads=heads_arr)
             desc = _rlx.gemm(M, self.N, self.K, x.data, p.w(self.kname, t0, weights), y,
                              bias=p.w(self.bname, t0, weights), activation=self.act, batch=TT,
                              a_batch_stride=a_stride, b_batch_stride=wstride,
@@ -339,6 +342,9 @@ class Dense(Layer):
                              workspace=ctx.ws.splitk, launch=launch, **kw)
         T = TT
         out = Tensor(y, M, self.N, T, grad_key=(ctx, self.name, tag), act=self.act)
+        if row_heads:
+            assert head_outs is not None and launch, "row_heads: only on the tiled-GEMM path of a wide layer"
+            return out, head_outs
         return out if launch else (out, desc)
 
     def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
@@ -633,6 +639,25 @@ class Conv2d(Layer):
             ctx.commit_deferred(job)
 
 
+def row_head_problems(ctx, row_heads, y, M, N, tag, weights=None):
+    """rlx_gemm_desc.row_heads for [(narrow Dense layer, tower index of the wide layer's output it reads)]: the ctypes
+    array and the heads' output Tensors (what small_dense_forward_multi would have returned)."""
+    arr = (_rlx.SmallDenseProblem * len(row_heads))()
+    outs = []
+    for i, (l, t) in enumerate(row_heads):
+        assert l.N <= SMALL_N and l.K == N and l.T == 1
+        p = l.params
+        hy = ctx.buffer(l.name, (l.T, M, l.N), tag=tag)
+        q = arr[i]
+        q.x, q.x_tower_stride = y.data_ptr() + t * M * N * 4, 0
+        q.w, q.w_tower_stride = p.w(l.kname, 0, weights).data_ptr(), p.stride(l.kname)
+        q.bias, q.bias_tower_stride = p.w(l.bname, 0, weights).data_ptr(), p.stride(l.bname)
+        q.y, q.y_tower_stride = hy.data_ptr(), M * l.N
+        q.towers, q.M, q.K, q.N, q.activation = l.T, M, l.K, l.N, _rlx.ACT[l.act]
+        outs.append(Tensor(hy, M, l.N, l.T, grad_key=(ctx, l.name, tag), act=l.act))
+    return arr, outs
+
+
 def small_dense_forward_multi(ctx, items, tag="", weights=None):
     """[(Dense layer, input Tensor)] -> [output Tensor], all layers in ONE launch (each N <= SMALL_N).
     weights: parameter buffer to read instead of the online weights (the target copy)."""
@@ -708,10 +733,16 @@ class Sequential:
         for l in self.layers:
             l.initialize(rng)
 
-    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False, row_heads=None):
+        """row_heads: [(narrow Dense layer, tower index)] reading the LAST layer's output — computed by that layer's
+        launch where it can (rlx_gemm_desc.row_heads); returns (acts, head outputs) then."""
         acts = [x]
         kw = {"pair": True} if pair else {}
-        for l in self.layers:
+        for i, l in enumerate(self.layers):
+            if row_heads and i == len(self.layers) - 1:
+                y, heads = l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, row_heads=row_heads, **kw)
+                acts.append(y)
+                return acts, heads
             acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, **kw))
         return acts
 

@@ -120,6 +120,7 @@ class ClippedPPONet(_NetBase):
     embedder + middleware (use_separate_networks_per_head), head 0 = VHead, head 1 = PPOHead
     (discrete).  tower 0 = value, tower 1 = policy."""
     HEADS_LOSS_BACKWARD_ONE_LAUNCH = True     # discrete heads: losses + heads' backward as one launch (tests flip it)
+    HEADS_FORWARD_WITH_TORSO = True           # the heads' forward inside the last dense layer's split-K reduction (tests flip it)
 
     def __init__(self, device, obs_shape, n_actions, activation="tanh", embedder="Medium",
                  middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
@@ -217,12 +218,19 @@ class ClippedPPONet(_NetBase):
         if clip_rescaler is None:
             assert clip_dev is not None, "set_clip_rescaler first"
             clip_rescaler = 1.0
-        acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
+        fused_heads = self.pi_head.N <= G.SMALL_N and B * self.pi_head.N <= 1024
+        heads_with_torso = fused_heads and self.HEADS_FORWARD_WITH_TORSO and self.torso.layers[-1].N > G.SMALL_N
+        if heads_with_torso:   # the heads' forward rides on the last dense layer's launch (rlx_gemm_desc.row_heads)
+            acts, (v, logits) = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train",
+                                                   row_heads=[(self.v_head, 0), (self.pi_head, 1)])
+        else:
+            acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train")
         mid = acts[-1]
         mid.ensure_grad()
         xv, xp = mid.tower(0), mid.tower(1)
-        fused_heads = self.pi_head.N <= G.SMALL_N and B * self.pi_head.N <= 1024
-        if fused_heads:        # value + policy head in one launch (forward here, backward below)
+        if heads_with_torso:
+            pass
+        elif fused_heads:      # value + policy head in one launch (forward here, backward below)
             v, logits = G.small_dense_forward_multi(ctx, [(self.v_head, xv), (self.pi_head, xp)], tag="train")
         else:
             v = self.v_head.forward(ctx, xv, tag="train")

@@ -305,6 +305,7 @@ enum { RLX_ACT_NONE = 0, RLX_ACT_RELU = 1, RLX_ACT_TANH = 2 };
  * terms of the activation OUTPUT); C = accumulate ? C + v : v.
  * Replaces tf.layers.dense / tf.layers.conv2d and their gradients
  * (architectures/tensorflow_components/layers.py:108-121,168-185). */
+struct rlx_small_dense_problem;   /* below: the narrow layers (heads) */
 typedef struct rlx_gemm_desc {
     const void *A;            /* float (or uint8 when a_is_u8) */
     const int *a_row_tab;     /* offset per m (elements) or NULL -> m * a_row_stride */
@@ -337,6 +338,14 @@ typedef struct rlx_gemm_desc {
      * tower * *_batch_stride + (n % n_fold).  The separate value / policy networks of Clipped PPO
      * (clipped_ppo_agent.py:50) read the same observation: their first layer gathers it once. */
     int n_fold;
+    /* Narrow layers that read ROWS of this product's output (the value / policy heads on the last dense layer of their
+     * tower, heads/v_head.py:43-48, ppo_head.py:100-116): row_heads[i].x must be C + t * c_batch_stride for a batch entry
+     * t (one head per entry at most), K = N of this product, M = M, towers = 1, N <= 16.  When the product is split over
+     * K, the reduction pass that finishes a row (bias, activation) computes its head outputs right there — the row is in
+     * LDS — instead of a separate launch; otherwise rlx_gemm runs rlx_dense_small_forward_multi(row_heads) behind the
+     * product.  Either way y of every head is complete in stream order, with identical values.  NULL / 0: none. */
+    const struct rlx_small_dense_problem *row_heads;
+    int n_row_heads;
 } rlx_gemm_desc;
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);

@@ -349,6 +349,46 @@ def test_hip_clipped_ppo_continuous_net_vs_oracle(rlx, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("obs_shape,B,A", [((84, 84, 4), 64, 6), ((84, 84, 4), 16, 3), ((17,), 200, 3)])
+def test_ppo_heads_forward_inside_the_dense_reduction_equals_the_separate_launch(rlx, dev, obs_shape, B, A):
+    """rlx_gemm_desc.row_heads: the split-K reduction of the last dense layer finishes whole rows and computes the value /
+    policy head outputs on them (or, where the product is not split that way, rlx_gemm launches the heads behind it):
+    head outputs, dense activations, the losses and every gradient equal the separate heads launch bit for bit."""
+    import torch
+    from coach_amd.nn.networks import ClippedPPONet
+    from tests.util import dev_tensor
+    rng = np.random.RandomState(B + A)
+    image = len(obs_shape) == 3
+    obs = rng.randint(0, 256, size=(B,) + obs_shape).astype(np.uint8) if image else \
+        rng.randn(B, *obs_shape).astype(np.float32)
+    obs_d = dev_tensor(obs, dev)
+    actions = dev_tensor(rng.randint(0, A, size=B), dev, np.int32)
+    adv, vt = dev_tensor(rng.randn(B).astype(np.float32), dev), dev_tensor(rng.randn(B).astype(np.float32), dev)
+    got = []
+    saved = ClippedPPONet.HEADS_FORWARD_WITH_TORSO
+    try:
+        for fused in (False, True):
+            ClippedPPONet.HEADS_FORWARD_WITH_TORSO = fused
+            np.random.seed(5)
+            net = ClippedPPONet(dev, obs_shape, A, seed=3)
+            net.update_target(1.0)
+            w = net.params.w(net.pi_head.kname)
+            w.add_(dev_tensor((np.random.RandomState(9).randn(*w.shape) * 0.05).astype(np.float32), dev))
+            old = net.policy_probs(obs_d, B, use_target=True, tag="old")
+            net.forward_backward(obs_d, B, actions, adv, vt, old)
+            net.check_status()
+            ctx = net.ctx
+            got.append([net.params.grads.cpu().numpy().copy(), net.scalars[:5].cpu().numpy().copy(),
+                        ctx.buffer(net.v_head.name, (1, B, 1), tag="train").cpu().numpy().copy(),
+                        ctx.buffer(net.pi_head.name, (1, B, A), tag="train").cpu().numpy().copy()])
+    finally:
+        ClippedPPONet.HEADS_FORWARD_WITH_TORSO = saved
+    assert np.abs(got[0][0]).max() > 0 and np.abs(got[0][3]).max() > 0
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("obs_shape,B,A", [((84, 84, 4), 64, 6), ((17,), 200, 3), ((11,), 7, 16)])
 def test_ppo_heads_losses_and_backward_as_one_launch_equal_the_two_launches(rlx, dev, obs_shape, B, A):
     """rlx_ppo_heads_loss_backward recomputes the loss-gradient rows in every workgroup of the heads' backward instead of

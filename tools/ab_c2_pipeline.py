@@ -26,7 +26,11 @@ if len(tuning) > 3:                       # 4th value: rlx_gemm_split_cap
     tuning = tuning[:3]
 for kv in (sys.argv[4].split(",") if len(sys.argv) > 4 else []):      # knob=value: lib.<knob>(int(value))
     k, v = kv.split("=")
-    getattr(_rlx.lib(), k)(int(v))
+    if k.startswith("net."):                 # a class switch of the network, e.g. net.HEADS_FORWARD_WITH_TORSO=0
+        from coach_amd.nn.networks import ClippedPPONet
+        setattr(ClippedPPONet, k[4:], bool(int(v)))
+    else:
+        getattr(_rlx.lib(), k)(int(v))
 agent = ab_c2.build(False, True, tuning=tuning)
 ts = [ab_c2.train_ms(agent) for _ in range(6)]
 print(json.dumps({"us_per_update": [round(1e3 * t / 320, 1) for t in ts[2:]]}))
