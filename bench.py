@@ -445,6 +445,19 @@ def box_calibration(device):
         del big
     except Exception as e:                                                  # (a box short of memory: skip, say so)
         out["memory_probe_error"] = str(e)[:120]
+    # the matrix pipe itself: cycles per dependent fp32 32x32x2 MFMA and the clock the shader holds with every CU busy on
+    # them (rlx_probe_mfma) — the denominator of roofline.frac assumes 64 cycles at 2.4 GHz
+    try:
+        wgs, iters = 1024, 8192
+        probe = torch.zeros(2 * wgs, dtype=torch.int64, device=device)
+        sink = torch.zeros(1, dtype=torch.float32, device=device)
+        for _ in range(2):
+            _rlx.lib().probe_mfma(wgs, iters, probe, sink, _rlx.current_stream())
+        torch.cuda.synchronize()
+        pr = probe.cpu().numpy().reshape(wgs, 2).astype(np.float64)
+        out["shader_MHz_under_mfma"] = int(round(float(np.median(pr[:, 0] / pr[:, 1])) * 100.0))
+    except Exception as e:
+        out["mfma_probe_error"] = str(e)[:120]
     x = torch.zeros(4, dtype=torch.float32, device=device)
     x.add_(0.0)
     torch.cuda.synchronize()

@@ -26,7 +26,10 @@ if len(tuning) > 3:                       # 4th value: rlx_gemm_split_cap
     tuning = tuning[:3]
 for kv in (sys.argv[4].split(",") if len(sys.argv) > 4 else []):      # knob=value: lib.<knob>(int(value))
     k, v = kv.split("=")
-    if k.startswith("net."):                 # a class switch of the network, e.g. net.HEADS_FORWARD_WITH_TORSO=0
+    if k.startswith("graph."):               # a module switch of coach_amd.nn.graph, e.g. graph.DIRECT_CONV_INPUT_GRAD=1
+        import coach_amd.nn.graph as _G
+        setattr(_G, k[6:], {"0": False, "1": True}.get(v, v))
+    elif k.startswith("net."):                 # a class switch of the network, e.g. net.HEADS_FORWARD_WITH_TORSO=0
         from coach_amd.nn.networks import ClippedPPONet
         setattr(ClippedPPONet, k[4:], bool(int(v)))
     else:
