@@ -1,7 +1,7 @@
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of tools/ppo_update_once.py (two separate passes) -> the
 per-update HBM traffic of the GEMM family (profiles/r0N_pmc_gemm_traffic.json, read by bench.py `roofline.traffic`).
 The LAST eager minibatch update of the run is summarised: every dispatch after the previous update's
-adam_finish_norm_kernel.  FETCH_SIZE is doubled (gfx950 counts 128-byte requests in 64-byte units,
+Adam launch.  FETCH_SIZE is doubled (gfx950 counts 128-byte requests in 64-byte units,
 MI355X_MICROARCH.md); both counters are in KB.
 
     python tools/pmc_summary.py gpurun_out/r02_final/pmc_FETCH_SIZE.csv gpurun_out/r02_final/pmc_WRITE_SIZE.csv out.json
@@ -13,7 +13,10 @@ import sys
 
 def last_update(path):
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"]))
-    ends = [i for i, r in enumerate(rows) if "adam_finish_norm_kernel" in r["Kernel_Name"]]
+    # an update ends with its Adam launch: adam_finish_norm_kernel (two-launch form) or, since the norm is finished inside
+    # the Adam launch, the adam_step*_kernel itself
+    last_of = lambda key: [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
+    ends = last_of("adam_finish_norm_kernel") or last_of("adam_step")
     return rows[ends[-2] + 1:ends[-1] + 1]
 
 
