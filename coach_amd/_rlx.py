@@ -124,6 +124,10 @@ class _Lib:
             self._fns[name] = fn
         if missing:
             raise RlxUnavailable("librlx.so does not export: " + ", ".join(missing))
+        built = self._fns["rlx_abi_version"]()
+        if built != ABI_VERSION:             # struct layouts / buffer contracts of this package and of the binary differ
+            raise RlxUnavailable("%s is ABI version %d, this package drives version %d: rebuild it "
+                                 "(python -c 'import __graft_entry__ as g; g.build()')" % (LIB_PATH, built, ABI_VERSION))
 
     def raw(self, name):
         return self._fns[name]
@@ -257,6 +261,7 @@ class SplitkJob(ctypes.Structure):
 
 
 ADAM_TICKET_WORDS = 1056        # rlx.h RLX_ADAM_TICKET_WORDS
+ABI_VERSION = 5                 # rlx_abi_version() of the library this module's structures and buffer sizes match
 MAX_SPLITK_JOBS = 8
 
 

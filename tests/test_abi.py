@@ -11,7 +11,7 @@ from coach_amd import _rlx
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _rlx.lib()                      # raises RlxUnavailable if a declared symbol is missing
     assert len(lib.protos) >= 10
-    assert lib.raw("rlx_abi_version")() >= 1
+    assert lib.raw("rlx_abi_version")() == _rlx.ABI_VERSION      # (the loader refuses a library of another version)
     assert lib.build_arch() == "gfx950"
 
 
