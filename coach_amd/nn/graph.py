@@ -642,6 +642,22 @@ class Conv2d(Layer):
 def row_head_problems(ctx, row_heads, y, M, N, tag, weights=None):
     """rlx_gemm_desc.row_heads for [(narrow Dense layer, tower index of the wide layer's output it reads)]: the ctypes
     array and the heads' output Tensors (what small_dense_forward_multi would have returned)."""
+    if row_heads and row_heads[0][1] == "pair":
+        # [(layer, "pair")]: the wide layer ran the online and the target copy as batch entries 0 and 1 (Dense.forward
+        # pair=True); the head does the same — ONE output Tensor with two towers, as its own pair launch returns
+        (l, _), = row_heads
+        assert l.N <= SMALL_N and l.K == N and l.T == 1
+        p = l.params
+        hy = ctx.buffer(l.name, (2, M, l.N), tag=tag)
+        arr = (_rlx.SmallDenseProblem * 2)()
+        for c in range(2):
+            q = arr[c]
+            q.x, q.x_tower_stride = y.data_ptr() + c * M * N * 4, 0
+            q.w, q.w_tower_stride = p.w(l.kname).data_ptr() + c * p.size * 4, p.stride(l.kname)
+            q.bias, q.bias_tower_stride = p.w(l.bname).data_ptr() + c * p.size * 4, p.stride(l.bname)
+            q.y, q.y_tower_stride = hy.data_ptr() + c * M * l.N * 4, M * l.N
+            q.towers, q.M, q.K, q.N, q.activation = 1, M, l.K, l.N, _rlx.ACT[l.act]
+        return arr, [Tensor(hy, M, l.N, 2, grad_key=(ctx, l.name, tag), act=l.act)]
     arr = (_rlx.SmallDenseProblem * len(row_heads))()
     outs = []
     for i, (l, t) in enumerate(row_heads):

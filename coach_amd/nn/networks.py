@@ -300,6 +300,7 @@ class ClippedPPONet(_NetBase):
 class DQNNet(_NetBase):
     """DQNNetworkParameters (agents/dqn_agent.py:43-56): embedder -> FC middleware -> QHead;
     MSE or Huber loss, importance weights from prioritized replay."""
+    HEAD_FORWARD_WITH_TORSO = True     # image networks: the Q head's forward rides on the last dense layer's launch
     FUSED_MLP = True        # small MLPs: the whole update / the acting step as one launch (tests flip these to cross-check)
     FUSED_ACT = True
 
@@ -488,8 +489,13 @@ class DQNNet(_NetBase):
             cols = int(np.prod(self.obs_shape))
             both = states_pair.view(2, B, cols)
             x = G.Tensor(both, B, cols, 2, u8=self.image, div=255.0 if self.image else 1.0)
-            acts2 = self.torso.forward(ctx, x, tag="pair", pair=True)
-            q2 = self.q_head.forward(ctx, acts2[-1], tag="pair", pair=True)
+            if self.HEAD_FORWARD_WITH_TORSO and self.A <= G.SMALL_N and self.q_head.T == 1 and \
+                    self.torso.layers[-1].N > G.SMALL_N:
+                # the Q head of both copies inside the last dense layer's split-K reduction (rlx_gemm_desc.row_heads)
+                acts2, (q2,) = self.torso.forward(ctx, x, tag="pair", pair=True, row_heads=[(self.q_head, "pair")])
+            else:
+                acts2 = self.torso.forward(ctx, x, tag="pair", pair=True)
+                q2 = self.q_head.forward(ctx, acts2[-1], tag="pair", pair=True)
             q_next = q2.data[1].view(B, self.A)
             acts = [x.tower_view(0)] + [a.tower(0) for a in acts2[1:]]
             q = q2.tower(0)

@@ -389,6 +389,43 @@ def test_ppo_heads_forward_inside_the_dense_reduction_equals_the_separate_launch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,A", [(32, 6), (32, 4)])
+def test_dqn_head_forward_inside_the_dense_reduction_equals_the_separate_launch(rlx, dev, B, A):
+    """The image DQN update with online(s) and target(s') as two towers of the same launches: the Q head of both copies
+    computed by the last dense layer's split-K reduction (rlx_gemm_desc.row_heads, batch_inner addressing) — loss, TD
+    errors, every gradient and every weight after the Adam step equal the separate head launch bit for bit."""
+    import torch
+    from coach_amd.nn.networks import DQNNet
+    from tests.util import dev_tensor
+    rng = np.random.RandomState(B + A)
+    shape = (84, 84, 4)
+    both = dev_tensor(rng.randint(0, 256, size=(2, B) + shape).astype(np.uint8), dev)
+    actions = dev_tensor(rng.randint(0, A, size=B), dev, np.int32)
+    rewards = dev_tensor(rng.randn(B).astype(np.float32), dev)
+    overs = dev_tensor((rng.rand(B) < 0.1).astype(np.uint8), dev, np.uint8)
+    got = []
+    saved = DQNNet.HEAD_FORWARD_WITH_TORSO
+    try:
+        for fused in (False, True):
+            DQNNet.HEAD_FORWARD_WITH_TORSO = fused
+            np.random.seed(5)
+            net = DQNNet(dev, shape, A, seed=3)
+            net.update_target(1.0)
+            w = net.params.w(net.q_head.kname)
+            w.add_(dev_tensor((np.random.RandomState(9).randn(*w.shape) * 0.05).astype(np.float32), dev))
+            td = torch.zeros(B, dtype=torch.float64, device=dev)
+            net.learn_from_batch(both[0], both[1], B, actions, rewards, overs, 0.99, td_errors=td, states_pair=both)
+            net.check_status()
+            got.append([net.params.grads.cpu().numpy().copy(), net.params.weights.cpu().numpy().copy(),
+                        net.loss.cpu().numpy().copy(), td.cpu().numpy().copy()])
+    finally:
+        DQNNet.HEAD_FORWARD_WITH_TORSO = saved
+    assert np.abs(got[0][0]).max() > 0 and np.abs(got[0][3]).max() > 0
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("obs_shape,B,A", [((84, 84, 4), 64, 6), ((17,), 200, 3), ((11,), 7, 16)])
 def test_ppo_heads_losses_and_backward_as_one_launch_equal_the_two_launches(rlx, dev, obs_shape, B, A):
     """rlx_ppo_heads_loss_backward recomputes the loss-gradient rows in every workgroup of the heads' backward instead of
