@@ -700,6 +700,8 @@ def main():
     ap.add_argument("--gemm-pipeline", type=int, default=None, choices=[0, 1],
                     help="A/B: main loop of the fast tiled GEMM kernels (rlx_gemm_pipeline): 1 = LDS-DMA ring (the "
                          "library's default), 0 = register-staged")
+    ap.add_argument("--ppo-chunk", type=int, default=None,
+                    help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only (no GPU, gloo): what the CPU "
                          "test of the N-rank entry point runs")
@@ -727,6 +729,9 @@ def main():
     if args.sac_branches is not None:
         from coach_amd.agents.soft_actor_critic_agent import SoftActorCriticAgent
         SoftActorCriticAgent.parallel_branches = bool(args.sac_branches)
+    if args.ppo_chunk is not None:
+        from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
+        ClippedPPOAgent.DATASET_CHUNK = args.ppo_chunk
     if args.gemm_pipeline is not None:
         from coach_amd import _rlx
         _rlx.lib().gemm_pipeline(args.gemm_pipeline)

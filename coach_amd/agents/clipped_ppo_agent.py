@@ -95,6 +95,7 @@ class ClippedPPOAgent(object):
     ragged = False          # envs end their episodes on different steps (set per instance from the env)
     _device_env = True
     restarts_memory_on_reset = True     # reset_internal_state() also restarts the rollout buffer's frame stack
+    DATASET_CHUNK = 2048    # rows per forward pass of the whole-dataset passes (V(s) for GAE, the old policy): 256 -> 2048 is -1.0 ms per C2 iteration (profiles/r04_ab_ppo_chunk.txt)
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         self.ap = agent_parameters
@@ -208,7 +209,7 @@ class ClippedPPOAgent(object):
         self.adv_stats = torch.empty(2, dtype=f64, device=dev)
         obs_tail = tuple(self.memory.cur_state.shape[1:])
         odt = self.memory.cur_state.dtype
-        self.chunk = 256
+        self.chunk = min(int(self.DATASET_CHUNK), cap)
         self.chunk_obs = torch.empty((self.chunk,) + obs_tail, dtype=odt, device=dev)
         self.mb_obs = torch.empty((B,) + obs_tail, dtype=odt, device=dev)
         self.mb_rows = torch.empty(B, dtype=torch.int32, device=dev)
