@@ -154,8 +154,12 @@ class ClippedPPONet(_NetBase):
     def policy_probs(self, obs, B, use_target=False, tag="act", out=None):
         """softmax(policy_fc(policy tower(obs)))  — target weights = the frozen 'old policy'."""
         w = self.target if use_target else None
-        acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w, t0=1, nt=1)
-        logits = self.pi_head.forward(self.ctx, acts[-1], tag=tag, weights=w)
+        if self.HEADS_FORWARD_WITH_TORSO and self.pi_head.N <= G.SMALL_N and self.torso.layers[-1].N > G.SMALL_N:
+            acts, (logits,) = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w, t0=1, nt=1,
+                                                 row_heads=[(self.pi_head, 0)])
+        else:
+            acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w, t0=1, nt=1)
+            logits = self.pi_head.forward(self.ctx, acts[-1], tag=tag, weights=w)
         probs = out if out is not None else self.ctx.buffer("probs", (B, self.A), tag=tag)
         self.lib.softmax(logits.data, self.A, B, self.A, probs, self.A, self.ctx.stream)
         return probs
@@ -176,8 +180,12 @@ class ClippedPPONet(_NetBase):
 
     def values(self, obs, B, tag="val", out=None):
         """V(s) from the value tower of the online network (fill_advantages :161-170)."""
-        acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, t0=0, nt=1)
-        v = self.v_head.forward(self.ctx, acts[-1], tag=tag)
+        if self.HEADS_FORWARD_WITH_TORSO and self.torso.layers[-1].N > G.SMALL_N:
+            acts, (v,) = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, t0=0, nt=1,
+                                            row_heads=[(self.v_head, 0)])
+        else:
+            acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, t0=0, nt=1)
+            v = self.v_head.forward(self.ctx, acts[-1], tag=tag)
         if out is not None:
             out.copy_(v.data.view(-1))
             return out
