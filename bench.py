@@ -564,6 +564,9 @@ def gemm_roofline(agent, reps=20):
                             "products are %.1fe6 bytes per call" % (n_products, operand_bytes / 1e6 / n),
             "kernel": "gemm_dma_kernel / gemm_dma_pair_kernel (LDS-DMA ring) and gemm_fast_kernel (uint8 frames) + split-K "
                       "reduces (fp32 MFMA 32x32x2): %d products in %d library calls per minibatch update" % (n_products, n),
+            "limiter": "measured (profiles/r04_slab_step_ablation.txt): the slab loops of these launches are bound by operand "
+                       "delivery, ~30 GB/s of line fills per CU from beyond the XCD's L2 (every kernel of the update starts "
+                       "cold), with the MFMA chain hidden under it; the MFMA peak stays the denominator of frac",
             "flops_per_update": total_flops, "flops_per_launch": total_flops / n,
             "avg_launch_us": round(gemm_us / max(gemm_launches, 1), 2),
             "update_us_by_family": fam, "kernel_launches_per_update": round(launches, 1),
