@@ -452,3 +452,61 @@ def test_tile_order_does_not_change_a_bit(rlx, dev, M, N, K):
     for mode, got in outs.items():
         for a, b in zip(outs[0], got):
             assert np.array_equal(a, b), mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,batch,head_n,act,head_act", [
+    (64, 512, 3136, 2, (1, 6), "relu", (None, None)),        # the Clipped-PPO middleware: value and policy head
+    (7, 260, 4096, 1, (3,), "tanh", ("tanh",)),              # a partial second pass (65 float4 groups), a partial row count
+    (100, 320, 4000, 3, (16, 1), "none", ("relu", None)),    # two row tiles; the third batch entry has no head
+    (60, 1024, 4000, 1, (16,), "none", ("relu",)),           # four passes
+    (1, 256, 2048, 2, (8, 8), "relu", (None, "tanh")),       # one row, one pass
+    (33, 1984, 2100, 1, (5,), "relu", (None,)),              # eight passes (a row of 31 tiles: 17 splits)
+    (64, 512, 320, 2, (1, 6), "relu", (None, None))])        # few splits (<= 16): not fused — rlx_gemm launches the heads behind the product
+def test_row_heads_in_the_split_k_reduction_equal_the_separate_launches(rlx, dev, M, N, K, batch, head_n, act, head_act):
+    """rlx_gemm_desc.row_heads against rlx_gemm followed by rlx_dense_small_forward_multi: the product's output AND the
+    head outputs bit for bit, whatever the path rlx_gemm takes (fused reduction, or the heads launched behind it)."""
+    import ctypes
+    import torch
+    from coach_amd import _rlx
+    from coach_amd._rlx import gemm
+    rng = np.random.RandomState(M + N + K + batch)
+    A = dev_tensor(rng.randn(batch, M, K).astype(np.float32), dev)
+    B = dev_tensor((rng.randn(batch, K, N) / np.sqrt(K)).astype(np.float32), dev)
+    bias = dev_tensor(rng.randn(batch, N).astype(np.float32), dev)
+    hw = [dev_tensor((rng.randn(N, n) / np.sqrt(N)).astype(np.float32), dev) for n in head_n]
+    hb = [dev_tensor(rng.randn(n).astype(np.float32), dev) for n in head_n]
+    ws = torch.empty(1 << 23, dtype=torch.float32, device=dev)
+    lib, s_ = _rlx.lib(), _rlx.current_stream()
+
+    def problems(C, ys):
+        arr = (_rlx.SmallDenseProblem * len(head_n))()
+        for i, n in enumerate(head_n):
+            q = arr[i]
+            q.x, q.x_tower_stride = C.data_ptr() + i * M * N * 4, 0
+            q.w, q.w_tower_stride = hw[i].data_ptr(), 0
+            q.bias, q.bias_tower_stride = hb[i].data_ptr(), 0
+            q.y, q.y_tower_stride = ys[i].data_ptr(), M * n
+            q.towers, q.M, q.K, q.N, q.activation = 1, M, N, n, _rlx.ACT[head_act[i]]
+        return arr
+    kw = dict(bias=bias, activation=act, batch=batch, a_batch_stride=M * K, b_batch_stride=K * N, c_batch_stride=M * N,
+              bias_batch_stride=N, workspace=ws)
+    C0 = torch.full((batch, M, N), 7.0, dtype=torch.float32, device=dev)
+    y0 = [torch.full((M, n), 5.0, dtype=torch.float32, device=dev) for n in head_n]
+    gemm(M, N, K, A, B, C0, **kw)
+    arr0 = problems(C0, y0)
+    lib.dense_small_forward_multi(ctypes.byref(arr0), len(head_n), s_)
+    C1 = torch.full((batch, M, N), 7.0, dtype=torch.float32, device=dev)
+    y1 = [torch.full((M, n), 5.0, dtype=torch.float32, device=dev) for n in head_n]
+    with _rlx.KernelTimer(64) as timer:
+        gemm(M, N, K, A, B, C1, row_heads=problems(C1, y1), **kw)
+    names = [n for n, _ in timer.records]
+    fused = any("splitk_reduce_rows_kernel" in n for n in names)
+    assert fused == (K >= 2000), names                       # the cases built to be split > 16 ways take the fused reduction
+    assert fused != any("dense_small_fwd" in n for n in names), names
+    assert torch.equal(C0, C1)
+    for a, b in zip(y0, y1):
+        assert torch.equal(a, b)
+    ref = np.maximum(C0[0].cpu().numpy().astype(np.float64), -np.inf) @ hw[0].cpu().numpy().astype(np.float64) + hb[0].cpu().numpy()
+    if head_act[0] is None:
+        np.testing.assert_allclose(y0[0].cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
