@@ -13,7 +13,8 @@ def last_update(path):
     rows = sorted(csv.DictReader(open(path)), key=lambda r: (int(r["Dispatch_Id"]), r["Counter_Name"]))
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})
     name = {int(r["Dispatch_Id"]): r["Kernel_Name"] for r in rows}
-    ends = [i for i in ids if "adam_finish_norm_kernel" in name[i]]
+    # an update ends with its Adam launch (adam_finish_norm_kernel in the two-launch form, else the adam_step*_kernel)
+    ends = [i for i in ids if "adam_finish_norm_kernel" in name[i]] or [i for i in ids if "adam_step" in name[i]]
     keep = [i for i in ids if ends[-2] < i <= ends[-1]]
     out = {i: {"name": name[i]} for i in keep}
     for r in rows:
