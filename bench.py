@@ -786,6 +786,8 @@ def main():
         us = dist.all_reduce_us(net.params.grads.numel())
         out["rccl"] = {"backend": dist.backend(), "world_size": tdist.get_world_size(), "graph_resident": dist.capturable(),
                        "overlap_two_buckets": bool(agent.overlap_allreduce),
+                       "overlap_decision": agent.overlap_decision,      # measured at the first training phase; None = forced
+                       "probe_note": dist.probe_note,
                        "gradient_bytes": 4 * net.params.grads.numel(),
                        "late_bucket_bytes": 4 * (net.params.grads.numel() - net.late_gradient_offset()),
                        "allreduce_us": None if us is None else round(us, 1),

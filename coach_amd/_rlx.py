@@ -197,7 +197,11 @@ class KernelTimer(object):
 
     def __exit__(self, *exc):
         n = ctypes.c_int()
-        lib().profile_end(ctypes.byref(n))
+        try:
+            lib().profile_end(ctypes.byref(n))       # raises when launches overflowed max_records (an undercounting trace)
+        except Exception:
+            if exc[0] is None:
+                raise
         if exc[0] is None:
             name, ms = ctypes.c_char_p(), ctypes.c_float()
             for i in range(n.value):

@@ -105,8 +105,10 @@ class ClippedPPOAgent(object):
         self.lib = _rlx.lib()
         self.use_graphs = True if use_graphs is None else bool(use_graphs)
         # data parallel: reduce the FC + head gradients (95 % of the bytes, final before the convolution backward starts)
-        # underneath the convolution backward — on as soon as there is a wire to hide (world size > 1)
-        self.overlap_allreduce = self.dist is not None and self.dist.world_size > 1
+        # underneath the convolution backward?  None = decided from measurements at the first training phase
+        # (_decide_overlap); True / False = forced (tests, A/B)
+        self.overlap_allreduce = None if self.dist is not None else False
+        self.overlap_decision = None
         alg, net = self.ap.algorithm, self.ap.network_wrappers["main"]
         ep = environment.p
         self.continuous = ep.action_dim is not None      # BoxActionSpace -> continuous PPO head
@@ -599,6 +601,46 @@ class ClippedPPOAgent(object):
         net = self.networks["main"]
         net.finish_update(scale, signal_acc=self.scalar_acc)
 
+    OVERLAP_EDGE_PAIR_US = 50.0     # what a fork / join pair of cross-stream edges per minibatch costs (measured
+                                    # +50 us at world size 1 in round 1; every round-4 branch experiment lost for the same reason)
+
+    def _decide_overlap(self, n, clip):
+        """Two-bucket overlap or one blocking all-reduce per minibatch — chosen once, from this job's own numbers:
+        the overlap can hide at most min(all-reduce of the late bucket, convolution backward) per minibatch and costs a
+        cross-stream edge pair.  Both are MEASURED here (the collective alone, RCCL only; the convolution backward
+        between two events on a dry forward / backward of the first minibatch — it writes activations and gradients
+        that the real pass overwrites, no weight, Adam slot or signal sum changes).  Every rank takes the decision of
+        the slowest rank.  Without graph-resident collectives (gloo, or a failed RCCL probe) the answer is the single
+        blocking all-reduce: three graph segments and two eager collectives per minibatch measured as a net loss."""
+        net, d = self.networks["main"], self.dist
+        off = net.late_gradient_offset()
+        rec = {"graph_resident": bool(self.use_graphs and d.capturable()), "edge_pair_us": self.OVERLAP_EDGE_PAIR_US,
+               "late_bucket_allreduce_us": None, "conv_backward_us": None}
+        if not rec["graph_resident"] or off <= 0:
+            rec.update(overlap=False, why="collectives are not graph nodes on this backend" if off > 0
+                       else "no early-finished bucket (no convolution layers)")
+        else:
+            B = self.ap.network_wrappers["main"].batch_size
+            m = min(B, n)
+            e = self._gather_epoch(n)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            us = []
+            for _ in range(3):
+                self._minibatch_fb(m, clip, True, i=0, epoch=e)
+                ev[0].record()
+                net.backward_rest()
+                ev[1].record()
+                ev[1].synchronize()
+                us.append(1e3 * ev[0].elapsed_time(ev[1]))
+            bw = d.max_over_ranks(min(us))
+            ar = d.max_over_ranks(d.all_reduce_us(net.params.grads.numel() - off) or 0.0)
+            hidden = min(ar, bw)
+            rec.update(late_bucket_allreduce_us=round(ar, 1), conv_backward_us=round(bw, 1), overlap=bool(hidden > self.OVERLAP_EDGE_PAIR_US),
+                       why="min(all-reduce, convolution backward) = %.1f us %s the %.0f us edge pair"
+                           % (hidden, ">" if hidden > self.OVERLAP_EDGE_PAIR_US else "<=", self.OVERLAP_EDGE_PAIR_US))
+        self.overlap_decision = rec
+        self.overlap_allreduce = rec["overlap"]
+
     def train_network(self, order, epochs):
         """clipped_ppo_agent.py:209-308.  `order`: dataset indices after the reference's
         `dataset[:num_steps]; shuffle(dataset)`; every epoch re-shuffles (Batch.shuffle,
@@ -624,6 +666,8 @@ class ClippedPPOAgent(object):
             self._perm.push(full)
             self.scalar_acc.zero_()
             nmb = -(-n // B)                                              # math.ceil (:232)
+            if self.overlap_allreduce is None:
+                self._decide_overlap(n, clip)
             in_graph = self.dist is not None and self.use_graphs and self.dist.capturable()
             net = self.networks["main"]
 

@@ -185,6 +185,9 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
             br = getattr(self, "_branches", None)
             if br is None:
                 br = self._branches = Branches(2)
+                # V's and Q's backward passes run on side streams next to each other: their deferred split-K partial
+                # sums must not share the per-device arena (both would start at offset 0)
+                v.ctx.private_arena = q.ctx.private_arena = True
             br.fork()
         # ---- branch A (the stream of the caller): policy.  (1) policy outputs on the first noise draw (:186-190)
         o, p_saved = pol.forward(s, B, self.normals[0], tag="train0")

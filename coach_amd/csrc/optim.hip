@@ -26,6 +26,13 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// The fence-free publication below (partial sums stored at agent scope, completed by s_waitcnt / by the return of an
+// exchange before the ticket is drawn) leans on how gfx942 / gfx950 perform agent-scope stores and atomics at the memory
+// side; no other target may compile it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "optim.hip: the last-arriver ticket protocol is written for gfx950 (gfx942-compatible) only"
+#endif
+
 // "Am I the last workgroup of this launch?" without 1024 read-modify-writes on ONE word: an agent-scope atomic on one
 // address is performed at the memory side, one after the other (measured ~10 ns each: 1024 of them were +10 us on the C2
 // Adam launch, profiles/r04_ab_adam_norm_in_kernel.txt).  Two levels: workgroup b draws from group b % 32's word (32
@@ -177,6 +184,9 @@ adam_step_kernel(float *__restrict__ w, const float *__restrict__ g, float *__re
     if (!NORM) return;
     __syncthreads();
     if (!last_s) return;
+    // the one workgroup that reads the other workgroups' partial sums pairs their publication with an agent-scope acquire
+    // (one invalidate on one workgroup; the expensive release side stays elided, see above)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // adam_finish_norm_kernel's arithmetic, in its order, by the workgroup that drew the last ticket (agent-scope loads:
     // the partials come from the memory side, not from a stale line of this XCD's L2)
     float s = 0.f;
@@ -284,6 +294,7 @@ adam_step_norm_kernel(float *__restrict__ w, const float *__restrict__ g, float 
     }
     __syncthreads();
     if (!last_s) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // pairs the publication of the partial sums (one workgroup only)
     float s = 0.f;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
         s += __hip_atomic_load(&sumsq_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -33,7 +33,8 @@ inline int grid_for(long long work_items, int block, int cap = kMaxStreamBlocks)
 // timer inside a stream capture is refused by rlx_profile_begin's caller contract: the events are not graph nodes).
 struct Profiler {
     bool active = false;
-    int n = 0, cap = 0;
+    int n = 0, cap = 0;         // records taken / allocated event pairs
+    int limit = 0, dropped = 0; // max_records of the armed trace / launches that found it full (rlx_profile_end fails)
     hipEvent_t *start = nullptr, *stop = nullptr;
     const char **name = nullptr;
 };
@@ -42,11 +43,12 @@ extern Profiler g_prof;
 template <typename F, typename... Args>
 inline void launch(const char *name, F kernel, dim3 grid, dim3 block, unsigned shmem, hipStream_t s,
                    Args... args) {
-    if (g_prof.active && g_prof.n < g_prof.cap) {
+    if (g_prof.active && g_prof.n < g_prof.limit) {
         const int i = g_prof.n++;
         g_prof.name[i] = name;
         hipExtLaunchKernelGGL(kernel, grid, block, shmem, s, g_prof.start[i], g_prof.stop[i], 0, args...);
     } else {
+        if (g_prof.active) ++g_prof.dropped;
         kernel<<<grid, block, shmem, s>>>(args...);
     }
 }

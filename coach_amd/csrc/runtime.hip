@@ -185,13 +185,30 @@ int rlx_profile_begin(int max_records) {
     if (max_records > p.cap) {
         hipEvent_t *st = new hipEvent_t[max_records], *sp = new hipEvent_t[max_records];
         const char **nm = new const char *[max_records];
+        int made = p.cap;                   // events [p.cap, made) of both arrays are new and ours to destroy on failure
+        hipError_t err = hipSuccess;
+        for (; made < max_records && err == hipSuccess; ++made) {
+            err = hipEventCreate(&st[made]);
+            if (err == hipSuccess) {
+                err = hipEventCreate(&sp[made]);
+                if (err != hipSuccess) (void)hipEventDestroy(st[made]);
+            }
+            if (err != hipSuccess) break;
+        }
+        if (err != hipSuccess) {
+            for (int i = p.cap; i < made; ++i) {
+                (void)hipEventDestroy(st[i]);
+                (void)hipEventDestroy(sp[i]);
+            }
+            delete[] st;
+            delete[] sp;
+            delete[] nm;
+            rlx::set_error("rlx_profile_begin: hipEventCreate failed: %s", hipGetErrorString(err));
+            return RLX_ERR_HIP;
+        }
         for (int i = 0; i < p.cap; ++i) {
             st[i] = p.start[i];
             sp[i] = p.stop[i];
-        }
-        for (int i = p.cap; i < max_records; ++i) {
-            RLX_HIP(hipEventCreate(&st[i]));
-            RLX_HIP(hipEventCreate(&sp[i]));
         }
         delete[] p.start;
         delete[] p.stop;
@@ -202,6 +219,8 @@ int rlx_profile_begin(int max_records) {
         p.cap = max_records;
     }
     p.n = 0;
+    p.limit = max_records;                  // the bound the caller asked for, also when the arrays are larger
+    p.dropped = 0;
     p.active = true;
     return RLX_OK;
 }
@@ -210,6 +229,8 @@ int rlx_profile_end(int *n_records_host) {
     rlx::Profiler &p = rlx::g_prof;
     p.active = false;
     if (n_records_host) *n_records_host = p.n;
+    // a trace that ran out of records is an error, not a shorter trace: sums over it would undercount
+    RLX_REQUIRE(p.dropped == 0, "rlx_profile_end: %d launches beyond max_records = %d went out untimed", p.dropped, p.limit);
     return RLX_OK;
 }
 

@@ -12,6 +12,7 @@ Payloads are 1.5-13.5 MB: a single flat buffer keeps this t
 update; RCCL picks its direct/ring algorithm per message size on the xGMI mesh.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -45,7 +46,8 @@ class GradientSync(object):
         skipped.  GradientSync.graph_collectives = False switches the probe (and the feature) off."""
         if self._capturable is None:
             ok = 0
-            if self.enabled and self.graph_collectives and dist.get_backend() == "nccl" and torch.cuda.is_available():
+            on_rccl = self.enabled and self.graph_collectives and dist.get_backend() == "nccl" and torch.cuda.is_available()
+            if on_rccl:
                 try:
                     x = torch.ones(1024, dtype=torch.float32, device="cuda")
                     dist.all_reduce(x)                      # communicator set-up stays outside the capture
@@ -53,16 +55,36 @@ class GradientSync(object):
                     x.fill_(1.0)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        dist.all_reduce(x)
-                    g.replay()
+                        dist.all_reduce(x)                  # recorded, not executed: x is still all ones
+                    for _ in range(self.PROBE_REPLAYS):
+                        g.replay()
                     torch.cuda.synchronize()
-                    ok = int(float(x[0].item()) == float(self.world_size) ** 2 and float(x[-1].item()) == float(x[0].item()))
-                except Exception:                           # capture refused: the segmented path stays in use
+                    want = self.probe_expected(self.world_size, self.PROBE_REPLAYS)
+                    ok = int(float(x[0].item()) == want and float(x[-1].item()) == want)
+                    if not ok:
+                        self.probe_note = "replayed all-reduce gave %r, expected %r" % (float(x[0].item()), want)
+                except Exception as e:                      # capture refused: the segmented path stays in use
                     ok = 0
+                    self.probe_note = "capture refused: %s" % (str(e).splitlines() or [type(e).__name__])[0]
             if self.enabled:
                 ok = int(self.min_over_ranks(ok))
+            if on_rccl and not ok:
+                # not silent: an RCCL job that falls back to graph segments with eager collectives says so once
+                sys.stderr.write("coach_amd.distributed: rank %d: all-reduce is not graph-resident (%s); "
+                                 "updates run as graph segments around eager collectives\n"
+                                 % (self.rank, self.probe_note or "another rank's probe failed"))
             self._capturable = bool(ok)
         return self._capturable
+
+    PROBE_REPLAYS = 2
+    probe_note = None
+
+    @staticmethod
+    def probe_expected(world_size, replays):
+        """What an in-place sum all-reduce of ones holds after `replays` replays of its captured graph on `world_size`
+        ranks: every replay multiplies by the world size (the capture itself executes nothing).  Two replays tell a
+        graph that really re-executes (W ** 2) from one whose node ran once (W) whenever W >= 2."""
+        return float(world_size) ** int(replays)
 
     graph_collectives = True
 

@@ -168,15 +168,18 @@ class Context:
     # last-bit differences in such a weight gradient (tests/test_gemm.py states the tolerance).  Making the two groupings
     # equal was tried and undone: it moves every network's trajectory by those last bits, and the device-vs-recorded-
     # reference loop tests (tests/test_reference_image_loops.py) pin action sequences that contain fp32 near-ties.
+    # The sharing rests on "one stream": a context whose passes run on a SIDE stream next to another context's
+    # (SoftActorCriticAgent.parallel_branches) sets private_arena = True and gets an arena of its own.
     ARENA_FLOATS = 1 << 25
     _arenas = {}
+    private_arena = False
 
     def begin_deferring(self):
         """-> True if this call opened the deferral (its caller must flush)."""
         if self.deferred is not None:
             return False
-        if self.arena is None:
-            key = str(self.device)
+        if self.arena is None or (self.private_arena and self.arena is Context._arenas.get(str(self.device))):
+            key = (str(self.device), id(self)) if self.private_arena else str(self.device)
             if key not in Context._arenas:
                 Context._arenas[key] = torch.empty(self.ARENA_FLOATS, dtype=torch.float32, device=self.device)
             self.arena = Context._arenas[key]

@@ -64,7 +64,8 @@ int rlx_probe_requests(int workgroups, int requests, int lds_dma, int round, con
  * the dispatch's begin / end timestamps — the per-dispatch duration a kernel trace reports (the reference has no
  * counterpart: its TF timeline is the closest thing, architectures/tensorflow_components/architecture.py has none on
  * this path).  rlx_profile_read(i) returns the kernel's name (a static string: the template instance as written at
- * the launch site) and its duration in ms, in launch order; it waits for that kernel.  max_records bounds the trace. */
+ * the launch site) and its duration in ms, in launch order; it waits for that kernel.  max_records bounds the trace:
+ * launches beyond it go out untimed and rlx_profile_end then FAILS (the records taken stay readable). */
 int rlx_profile_begin(int max_records);
 int rlx_profile_end(int *n_records_host);
 int rlx_profile_read(int index, const char **name_host, float *ms_host);

@@ -47,13 +47,22 @@ def _worker(rank, world, port, out_dir, sync_mode, backend="gloo"):
     ap.algorithm.optimization_epochs = 2
     ap.network_wrappers["main"].batch_size = 16
     agent = ClippedPPOAgent(ap, env, dev, dist=dist)
-    agent.overlap_allreduce = sync_mode == "0"          # "1" / "s": one blocking all-reduce per minibatch
+    if sync_mode != "a":                                # "a": the agent decides from its own measurements
+        agent.overlap_allreduce = sync_mode == "0"      # "1" / "s": one blocking all-reduce per minibatch
     for _ in range(2):
         res = None
         while res is None:
             agent.act()
             res = agent.train()
     agent.networks["main"].check_status()
+    if sync_mode == "a":
+        rec = agent.overlap_decision
+        assert rec is not None and agent.overlap_allreduce is rec["overlap"]
+        if backend == "gloo":                           # not graph-resident: the single blocking all-reduce
+            assert rec["overlap"] is False and rec["graph_resident"] is False
+        else:                                           # RCCL: both terms were measured on this box
+            assert rec["graph_resident"] and rec["conv_backward_us"] > 0 and rec["late_bucket_allreduce_us"] > 0
+            assert rec["overlap"] == (min(rec["conv_backward_us"], rec["late_bucket_allreduce_us"]) > rec["edge_pair_us"])
     w = agent.networks["main"].params.weights.cpu().numpy()
     np.save(os.path.join(out_dir, "w_%s_%d.npy" % (sync_mode, rank)), w)
     np.save(os.path.join(out_dir, "obs_%s_%d.npy" % (sync_mode, rank)), env.obs.cpu().numpy())
@@ -63,9 +72,11 @@ def _worker(rank, world, port, out_dir, sync_mode, backend="gloo"):
 @pytest.mark.timeout(600)
 def test_two_rank_ppo_iteration(tmp_path):
     import torch.multiprocessing as mp
-    for mode in ("1", "0"):                                  # blocking all-reduce, then overlapped
+    for mode in ("1", "0", "a"):                             # blocking all-reduce, overlapped, the agent's own choice
         mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
-    w = {(m, r): np.load(tmp_path / ("w_%s_%d.npy" % (m, r))) for m in "10" for r in (0, 1)}
+    w = {(m, r): np.load(tmp_path / ("w_%s_%d.npy" % (m, r))) for m in "10a" for r in (0, 1)}
+    np.testing.assert_array_equal(w[("a", 0)], w[("1", 0)])  # the default (decided at the first phase) == blocking
+    np.testing.assert_array_equal(w[("a", 0)], w[("a", 1)])
     assert np.isfinite(w[("0", 0)]).all()
     np.testing.assert_array_equal(w[("1", 0)], w[("1", 1)])  # ranks agree bit for bit
     np.testing.assert_array_equal(w[("0", 0)], w[("0", 1)])
@@ -212,9 +223,10 @@ def test_rccl_path_world_size_one(tmp_path):
     exactly the weights of eager collectives between graph segments (stream ordering between torch's stream, the
     graphs and RCCL's stream)."""
     import torch.multiprocessing as mp
-    for mode in ("1", "0", "s"):
+    for mode in ("1", "0", "s", "a"):                   # "a": the agent measures and chooses (checked in the worker)
         mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), mode, "nccl"), nprocs=1, join=True)
-    w1, w0, ws = (np.load(tmp_path / ("w_%s_0.npy" % m)) for m in "10s")
+    w1, w0, ws, wa = (np.load(tmp_path / ("w_%s_0.npy" % m)) for m in "10sa")
+    np.testing.assert_array_equal(wa, w1)               # the decision's dry forward / backward changes no weight
     assert np.isfinite(w0).all()
     np.testing.assert_array_equal(w0, w1)               # two overlapped buckets == one blocking all-reduce (both IN the graph)
     np.testing.assert_array_equal(ws, w1)               # collectives as graph nodes == eager collectives between segments

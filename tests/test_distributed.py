@@ -57,6 +57,13 @@ def _worker(rank, world, port, out_dir):
     # gloo collectives cannot be recorded into a device graph: every rank gets the same "no" (the updates then run as
     # graph segments with eager collectives in between); no all-reduce timing without RCCL
     assert sync.capturable() is False and sync.backend() == "gloo" and sync.all_reduce_us(16) is None
+    # the probe's arithmetic against REAL collectives: what PROBE_REPLAYS replays of an in-place sum of ones must leave
+    # (round 4 expected W ** 2 after ONE replay and therefore answered "no" on every RCCL job with W >= 2)
+    x = torch.ones(8)
+    for _ in range(GradientSync.PROBE_REPLAYS):
+        sync.all_reduce_sum(x)
+    assert GradientSync.PROBE_REPLAYS == 2 and float(x[0]) == GradientSync.probe_expected(world, 2) == float(world) ** 2
+    assert GradientSync.probe_expected(world, 1) == float(world) and GradientSync.probe_expected(1, 2) == 1.0
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), w=w, local=local.numpy(), summed=params.grads.numpy(),
              obs=obs, t=t, total=total)
     torch.distributed.destroy_process_group()

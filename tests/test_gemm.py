@@ -510,3 +510,29 @@ def test_row_heads_in_the_split_k_reduction_equal_the_separate_launches(rlx, dev
     ref = np.maximum(C0[0].cpu().numpy().astype(np.float64), -np.inf) @ hw[0].cpu().numpy().astype(np.float64) + hb[0].cpu().numpy()
     if head_act[0] is None:
         np.testing.assert_allclose(y0[0].cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_kernel_timer_overflow_is_an_error(dev):
+    """rlx_profile_*: a trace bounded at max_records must not silently drop launches (bench.py sums the records into the
+    headline roofline) — the launches beyond the bound still run, and closing the trace fails."""
+    import torch
+    from coach_amd import _rlx
+    lib = _rlx.lib()
+    s_ = _rlx.current_stream()
+    x = torch.zeros(1024, dtype=torch.float32, device=dev)
+    y = torch.ones(1024, dtype=torch.float32, device=dev)
+    with _rlx.KernelTimer(2) as timer:
+        lib.mix_weights(x, y, 1024, 0.5, s_)
+        lib.mix_weights(x, y, 1024, 0.5, s_)
+    assert len(timer.records) == 2 and all(us > 0 for _, us in timer.records)
+    with pytest.raises(Exception, match="beyond max_records = 1"):
+        with _rlx.KernelTimer(1):                    # smaller than the event arrays allocated above: the bound is the request
+            lib.mix_weights(x, y, 1024, 0.5, s_)
+            lib.mix_weights(x, y, 1024, 0.5, s_)
+            lib.mix_weights(x, y, 1024, 0.5, s_)
+    torch.cuda.synchronize()
+    assert float(x[0]) == 1.0 - 0.5 ** 5              # all five launches ran, timed or not
+    with _rlx.KernelTimer(4) as timer:               # and the timer is usable again
+        lib.mix_weights(x, y, 1024, 0.5, s_)
+    assert len(timer.records) == 1
