@@ -31,12 +31,12 @@ FRAME = (84, 84)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 
 
-def build_agent(device, dist, seed=0):
+def build_agent(device, dist, seed=0, ep_len=None):
     from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent, ClippedPPOAgentParameters
     from coach_amd.core_types import EnvironmentSteps
     from coach_amd.environments.synthetic_vector_environment import (
         SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
-    ep = SyntheticVectorEnvironmentParameters("image", N_ENV, FRAME, N_ACTIONS, episode_length=EP_LEN,
+    ep = SyntheticVectorEnvironmentParameters("image", N_ENV, FRAME, N_ACTIONS, episode_length=ep_len or EP_LEN,
                                               seed=1234)
     env = SyntheticVectorEnvironment(ep, device, rank=dist.rank)
     ap = ClippedPPOAgentParameters()
@@ -111,10 +111,11 @@ def build_off_policy(name, device, dist):
     return SoftActorCriticAgent(ap, env, device, dist=dist)
 
 
-def cpu_baseline_off_policy(name, budget_s=8.0):
-    """The oracle's update step (numpy restatement of the reference agent's learn_from_batch) timed
-    on a bounded number of repetitions; env-steps/s follows from the workload's updates-per-env-step
-    ratio (acting cost is not included: an upper bound on the CPU path)."""
+def _cpu_off_policy_once(name, budget_s=8.0):
+    """One timing under the CURRENT BLAS thread setting (see cpu_baseline_off_policy): the oracle's update step (numpy
+    restatement of the reference agent's learn_from_batch) and its acting step — ONE forward pass of the acting network
+    on ONE state per env-step, which is how the reference acts (one env per process, agent.py:790-830) — each on a
+    bounded number of repetitions; env-steps/s = 1 / (acting + updates-per-env-step x update)."""
     import numpy as np
     from coach_amd.nn import graph as G, networks as NW, actor_critic_nets as AC
     rng = np.random.RandomState(0)
@@ -145,6 +146,7 @@ def cpu_baseline_off_policy(name, budget_s=8.0):
         obs = rng.randint(0, 256, size=(B,) + shape).astype(np.uint8) if name == "c3" else rng.randn(B, 4).astype(np.float32)
         a, r, d = rng.randint(0, A, B), rng.randn(B).astype(np.float32), rng.rand(B) < 0.1
         t, n = timed(lambda: o.learn_from_batch(obs, obs, a, r, d, 0.99))
+        ta, na = timed(lambda: o.q(obs[:1]))
         per_step = 1.0 if name == "c1" else 0.25
     elif name == "c4":
         from oracle import ac_nets as O
@@ -166,6 +168,7 @@ def cpu_baseline_off_policy(name, budget_s=8.0):
             it[0] += 1
             O.td3_update(oa, oc, batch, rng.normal(0, 0.2, (B, A)), it[0], -np.ones(A, np.float32), np.ones(A, np.float32))
         t, n = timed(f)
+        ta, na = timed(lambda: oa.forward(batch[0][:1]))
         per_step = 1.0
     else:
         from oracle import ac_nets as O
@@ -186,15 +189,43 @@ def cpu_baseline_off_policy(name, budget_s=8.0):
         batch = (rng.randn(B, D).astype(np.float32), rng.uniform(-1, 1, (B, A)).astype(np.float32),
                  rng.randn(B).astype(np.float32), np.zeros(B, bool), rng.randn(B, D).astype(np.float32))
         t, n = timed(lambda: O.sac_update(op, oq, ov, batch, rng.standard_normal((3, B, A))))
+        ta, na = timed(lambda: op.forward(batch[0][:1], rng.standard_normal((1, A))))
         per_step = 1.0
+    step_s = ta + t * per_step
+    return {"value": round(1.0 / step_s, 2), "unit": "env-steps/s", "grad_updates_per_s": round(per_step / step_s, 2),
+            "update_s": t, "act_s": ta,
+            "sample": "%d update steps at %.4f s + %d acting forward passes (one state each) at %.5f s; %.2f updates per "
+                      "env-step" % (n, t, na, ta, per_step)}
+
+
+def cpu_baseline_off_policy(name, budget_s=12.0):
+    """`cpu_baseline` of the off-policy workloads, like C2's (cpu_baseline below): the oracle timed under three BLAS
+    thread settings on this box — ONE thread, the reference's own setting (coach.py:666 OMP_NUM_THREADS=1;
+    graph_manager.py:219-220 intra / inter-op 1) and the figure reported as `value`; 8 threads; every host core —
+    acting cost included."""
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p_.get("num_threads", 1) for p_ in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_info, threadpool_limits
+        all_cores = max([p_.get("num_threads", 1) for p_ in threadpool_info()] + [1])
     except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": round(1.0 / (t * per_step), 2), "unit": "env-steps/s", "cores": int(cores), "kind": "port",
-            "grad_updates_per_s": round(1.0 / t, 2),
-            "sample": "oracle/ update step (numpy): %d repetitions, %.4f s per update; acting cost not included" % (n, t)}
+        threadpool_limits, all_cores = None, os.cpu_count() or 1
+    settings = [1] if threadpool_limits is None else sorted({1, min(8, all_cores), all_cores})
+    runs = {}
+    for th in settings:
+        if threadpool_limits is None:
+            runs[th] = _cpu_off_policy_once(name, budget_s)
+        else:
+            with threadpool_limits(limits=th):
+                runs[th] = _cpu_off_policy_once(name, budget_s / len(settings))
+    one = runs[settings[0]]
+    return {"value": one["value"], "unit": "env-steps/s", "cores": settings[0], "kind": "port",
+            "grad_updates_per_s": one["grad_updates_per_s"], "host_cores": os.cpu_count(),
+            "sample": "oracle/ (numpy fp32 restatement of rl_coach's CPU path), %d BLAS thread(s) — the reference runs "
+                      "single-threaded: %s" % (settings[0], one["sample"]),
+            "by_threads": {str(th): {"value": r["value"], "grad_updates_per_s": r["grad_updates_per_s"], "cores": th,
+                                     "update_s": round(r["update_s"], 5), "act_s": round(r["act_s"], 6)}
+                           for th, r in runs.items()}}
+
+
 
 
 def prefill_c3(agent):
@@ -705,6 +736,10 @@ def main():
                          "library's default), 0 = register-staged")
     ap.add_argument("--ppo-chunk", type=int, default=None,
                     help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
+    ap.add_argument("--episode-length", type=int, default=EP_LEN,
+                    help="c2: length of the synthetic episodes.  32 (default): every episode closes on the 2048-step "
+                         "rollout boundary.  1024 (SURVEY.md 8(d)'s Atari-like length): act_for_full_episodes makes a "
+                         "step 65 536 env-steps, V(s) / GAE run over all of them, the 320 updates train on dataset[:2048]")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only (no GPU, gloo): what the CPU "
                          "test of the N-rank entry point runs")
@@ -743,7 +778,7 @@ def main():
     if args.workload != "c2":
         run_off_policy(args, device, dist)
         return
-    agent = build_agent(device, dist)
+    agent = build_agent(device, dist, ep_len=args.episode_length)
     for _ in range(args.warmup):
         one_step(agent)
     torch.cuda.synchronize()
@@ -759,7 +794,8 @@ def main():
     agent.networks["main"].check_status()
 
     n_updates = EPOCHS * (PLAYING_STEPS // BATCH)
-    env_steps = dist.world_size * PLAYING_STEPS * args.steps
+    steps_per_iter = N_ENV * agent.steps_per_phase      # = PLAYING_STEPS when the episodes close on the rollout boundary
+    env_steps = dist.world_size * steps_per_iter * args.steps
     out = {
         "metric": "env-steps/sec (+ grad-updates/sec) on Atari-like Clipped-PPO, 64 vectorized envs/GPU",
         "value": round(env_steps / elapsed, 1), "unit": "env-steps/s", "n_gpus": dist.world_size,
@@ -768,10 +804,14 @@ def main():
         "data": "synthetic",
         "grad_updates_per_s": round(n_updates * args.steps / elapsed, 1),
         "config": {"workload": "C2: Atari-Pong-like Clipped-PPO, %d vectorized envs/GPU, 84x84x4 uint8 obs, "
-                               "GAE(0.99,0.95), rollout %d env-steps (episodes of %d), %d epochs x %d "
+                               "GAE(0.99,0.95), rollout %d env-steps (episodes of %d%s), %d epochs x %d "
                                "minibatches of %d, fp32 conv torso x2 (value/policy), TF1-Adam"
-                               % (N_ENV, PLAYING_STEPS, EP_LEN, EPOCHS, PLAYING_STEPS // BATCH, BATCH),
-                   "global_env_steps_per_step": dist.world_size * PLAYING_STEPS,
+                               % (N_ENV, steps_per_iter, args.episode_length,
+                                  "" if steps_per_iter == PLAYING_STEPS else
+                                  ": act_for_full_episodes plays until every episode is complete, V(s) and GAE over the "
+                                  "whole dataset, training on dataset[:%d]" % PLAYING_STEPS,
+                                  EPOCHS, PLAYING_STEPS // BATCH, BATCH),
+                   "global_env_steps_per_step": dist.world_size * steps_per_iter,
                    "parallelism": "dp%d (env vectors sharded per GPU, flat fp32 gradient all-reduce)"
                                   % dist.world_size,
                    "hip_graphs": bool(agent.use_graphs)},

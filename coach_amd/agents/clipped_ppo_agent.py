@@ -477,8 +477,13 @@ class ClippedPPOAgent(object):
             return True
         return False
 
-    def _fill_advantages_device(self, n, rows):
+    def _fill_advantages_device(self, n, rows, n_train=None):
+        """n_train: the transitions the phase trains on (dataset[:num_steps], :330-331) — the only ones whose old-policy
+        outputs are read.  With episodes longer than the playing phase (L = 1024, 64 envs: a dataset of 65 536
+        transitions, 2 048 trained on) the old-policy pass over the whole dataset would be 32 x the work the
+        reference's per-minibatch pass does."""
         mem, net, alg = self.memory, self.networks["main"], self.ap.algorithm
+        n_train = n if n_train is None else min(n, n_train)
         s = _rlx.current_stream()
         mem.gather_columns(rows, n, [(mem.reward, self.ds_reward), (mem.game_over, self.ds_done),
                                      (mem.action, self.ds_action)])
@@ -507,8 +512,8 @@ class ClippedPPOAgent(object):
                      alg.discount, alg.gae_lambda, self.ds_adv64, self.ds_vtarget, s)
         self.lib.standardize(self.ds_adv64, n, self.ds_adv, None, self.adv_stats, s)
         # old policy = target network, frozen for the whole phase (:238-241, hoisted out of the loop)
-        for c0 in range(0, n, self.chunk):
-            m = min(self.chunk, n - c0)
+        for c0 in range(0, n_train, self.chunk):
+            m = min(self.chunk, n_train - c0)
             if self.continuous:
                 net.policy_mean_std(chunk_obs(c0, m), m, use_target=True, tag="old",
                                     out_mean=self.ds_old_probs[c0:c0 + m], out_std=self.ds_old_std[c0:c0 + m])
@@ -525,7 +530,8 @@ class ClippedPPOAgent(object):
             # shared running statistics: the collective stays outside the captured graph
             self.memory.gather_states(rows, n, self.ds_obs_raw[:n])
             self.norm.push_shared(self.ds_obs_raw[:n], self.dist)
-        self._run(("fill", n), lambda: self._fill_advantages_device(n, rows))
+        n_train = min(n, self.ap.algorithm.num_consecutive_playing_steps.num_steps)
+        self._run(("fill", n, n_train), lambda: self._fill_advantages_device(n, rows, n_train))
         if self.norm is not None and self.dist is not None:
             # the next states of the dataset, after the states were normalised (see _fill_advantages_device)
             self.memory.gather_next_states(rows, n, self.ds_obs_raw[:n])

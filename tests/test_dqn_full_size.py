@@ -1,0 +1,211 @@
+"""DQN + prioritized replay at the FULL size of BASELINE config C3 — 64 envs, 84x84x4 uint8 observations, minibatches of
+32, the Atari_DQN_with_PER network — device against the numpy oracle agent (rl_coach/agents/dqn_agent.py:81-113,
+memories/non_episodic/prioritized_experience_replay.py:203-262): a ring of 2^14 transitions that has WRAPPED, every
+leaf carrying its own priority (|N(0,1)| written through update_priorities on both sides, as bench.py's pre-fill does),
+then one training vector step = 16 updates with importance weights and priority write-back.
+
+tests/test_dqn_agent.py runs the same loop at B = 8 / 2 envs / capacity 128, which selects other GEMM tiles
+(gemm_dma<32,32,4>, gemm_fast<128,32> and the paired dW + dX kernel only appear at B = 32) — this is the driver-run
+parity test at the size the bench line is quoted on.
+
+Bit-exact: heat-up and exploration actions, the state of the three trees after the fill, the sampled leaves of (at
+least) the first three updates, the importance weights of identical leaves.  Tolerance (stated where asserted): TD
+errors, losses, weights — fp32 accumulation order.  The oracle's layer arithmetic is unpinned against TF's own rounding
+(DESIGN.md §6)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_ENV, FRAME, A, B, CAP, EP_LEN = 64, (84, 84), 4, 32, 1 << 14, 100
+HEATUP_STEPS = CAP // N_ENV + 5           # 261 vector steps = 16 704 transitions: the ring wraps by 320 rows
+LR = 2.5e-4
+
+
+def _err(name, a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    d = np.abs(a - b)
+    big = np.abs(b) > 1e-3
+    print("  %-40s max abs %.3e   max rel (|ref| > 1e-3) %.3e" % (name, d.max(), (d[big] / np.abs(b[big])).max()
+                                                                 if big.any() else 0.0))
+
+
+def test_c3_wrapped_per_ring_and_first_updates_match_the_oracle(rlx, dev):
+    import torch
+    from coach_amd.agents.dqn_agent import DQNAgent, DQNAgentParameters
+    from coach_amd.core_types import RunPhase
+    from coach_amd.environments.synthetic_vector_environment import (
+        SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
+    from coach_amd.memories.memory import MemoryGranularity
+    from coach_amd.memories.non_episodic.prioritized_experience_replay import PrioritizedExperienceReplayParameters
+    from coach_amd.schedules import LinearSchedule
+    from oracle.agents import DQNAgentOracle
+    from oracle.synth_env import SynthVecEnv
+
+    env = SyntheticVectorEnvironment(SyntheticVectorEnvironmentParameters("image", N_ENV, FRAME, A, episode_length=EP_LEN,
+                                                                          seed=1234), dev)
+    ap = DQNAgentParameters()                         # playing steps 4, target copy every 10 000 env-steps, Huber, Adam
+    ap.seed = 0
+    ap.memory = PrioritizedExperienceReplayParameters()
+    ap.memory.max_size = (MemoryGranularity.Transitions, CAP)
+    ap.memory.beta = LinearSchedule(0.4, 1.0, 12500000)                 # presets/Atari_DQN_with_PER.py
+    ap.algorithm.reward_clipping = (-1.0, 1.0)
+    ap.exploration.epsilon_schedule = LinearSchedule(0.5, 0.1, 1000000)  # half of the 64 actions of the step are greedy
+    ap.network_wrappers["main"].batch_size = B
+    agent = DQNAgent(ap, env, dev)
+    agent.debug_draws, agent.debug_losses = [], []
+    net = agent.networks["main"]
+    assert agent.batch_size == B and agent.memory.power_of_2_size == CAP
+
+    random.seed(0)
+    np.random.seed(0)
+    o = DQNAgentOracle(net.params.named_arrays(), SynthVecEnv(0, N_ENV, FRAME[0] * FRAME[1], EP_LEN, 1234), A,
+                       FRAME + (4,), capacity=CAP, per={}, batch_size=B, playing_steps=4, target_every=10000,
+                       epsilon_schedule=LinearSchedule(0.5, 0.1, 1000000), reward_clip=(-1.0, 1.0))
+    # the oracle's replay takes beta as a number: the schedule (stepped once per sampled batch, :256) is driven here
+    beta = LinearSchedule(0.4, 1.0, 12500000)
+    sample = o.per.sample
+
+    def sample_with_schedule(size, uniforms):
+        o.per.beta = beta.current_value
+        out = sample(size, uniforms)
+        beta.step()
+        return out
+    o.per.sample = sample_with_schedule
+    o.reference_order = True
+    o.reset(FRAME)
+    np.testing.assert_array_equal(agent.exploration_policy.current_random_value, o.cur_rand)
+    assert agent.exploration_policy.epsilon_schedule.current_value == o.eps_sched.current_value == 0.5
+    start = (random.getstate(), np.random.get_state())
+
+    # the oracle's updates, recorded: importance weights in, TD errors out
+    o_rec = []
+    inner = o.net.learn_from_batch
+
+    def recording(s, ns, a, r, done, discount, w, double):
+        res = inner(s, ns, a, r, done, discount, w, double)
+        o_rec.append((None if w is None else np.array(w, dtype=np.float64), np.array(res["td_errors"], dtype=np.float64)))
+        return res
+    o.net.learn_from_batch = recording
+
+    err = np.abs(np.random.RandomState(7).standard_normal(CAP))       # a priority of its own for every leaf
+
+    # ---- oracle: heat-up past the wrap, priorities, one training vector step
+    random.setstate(start[0]); np.random.set_state(start[1])
+    o_acts = [np.array(o.heatup_step()) for _ in range(HEATUP_STEPS)]
+    assert o.count == CAP and o.cursor == (HEATUP_STEPS - 1) * N_ENV % CAP        # (the last step's rows are still held)
+    o.per.update_priorities(list(range(CAP)), [float(x) for x in err])
+    o_acts.append(np.array(o.act()))
+    o.train()
+    o_trees = [t.tree.copy() for t in (o.per.sum_tree, o.per.min_tree, o.per.max_tree)]
+    n_upd = len(o.losses)
+    assert n_upd == N_ENV // 4 == 16 and len(o.sampled) == n_upd
+
+    # ---- device: the same, from the same host streams
+    random.setstate(start[0]); np.random.set_state(start[1])
+    d_acts = []
+    agent.phase = RunPhase.HEATUP
+    for _ in range(HEATUP_STEPS):
+        agent.act()
+        d_acts.append(agent.actions.cpu().numpy().copy())
+    mem = agent.memory
+    idx_all = torch.arange(CAP, dtype=torch.int32, device=dev)
+    err_dev = torch.from_numpy(err).to(dev)
+    for i in range(0, CAP, 1024):
+        mem.update_priorities(idx_all[i:i + 1024], err_dev[i:i + 1024])
+    mem.check_status()
+    d_rec = []
+    learn = agent.learn_from_batch
+
+    def recording_dev(batch):
+        w = batch.info("weight").cpu().numpy().astype(np.float64).copy()
+        loss = learn(batch)
+        d_rec.append((w, agent.td_errors.cpu().numpy().astype(np.float64).copy()))
+        return loss
+    agent.learn_from_batch = recording_dev
+    agent.phase = RunPhase.TRAIN
+    agent.act()
+    d_acts.append(agent.actions.cpu().numpy().copy())
+    agent.train()
+    agent.check_status()
+    assert len(agent.debug_draws) == n_upd and len(d_rec) == n_upd
+
+    # ---- 1. actions (heat-up draws, then epsilon-greedy at epsilon ~ 0.5 on the Q values of 64 states: bit-exact)
+    np.testing.assert_array_equal(np.array(d_acts), np.array(o_acts))
+
+    # ---- 2. sampled leaves: the first three updates bit for bit (the requirement); how far the identity holds is printed
+    same = 0
+    for d, s_ in zip(agent.debug_draws, o.sampled):
+        if not np.array_equal(d, s_):
+            break
+        same += 1
+    print("\n  sampled leaves identical for the first %d of %d updates (ring of %d, wrapped by %d rows)"
+          % (same, n_upd, CAP, HEATUP_STEPS * N_ENV - N_ENV - CAP))
+    assert same >= 3, "PER leaves diverged after %d updates" % same
+    leaves = np.concatenate(o.sampled[:same])
+    assert leaves.min() >= 0 and leaves.max() < CAP and len(np.unique(leaves)) > same * B // 2
+
+    # ---- 3. per update while the batches are identical: importance weights (fp64, same tree -> same bits for the first
+    #         update; later ones see priorities written back from fp32 TD errors), TD errors, loss
+    np.testing.assert_array_equal(d_rec[0][0], o_rec[0][0])
+    assert len(np.unique(o_rec[0][0])) > B // 2                 # real importance weights, not a constant
+    for k in range(same):
+        np.testing.assert_allclose(d_rec[k][0], o_rec[k][0], rtol=1e-5, err_msg="importance weights of update %d" % k)
+        # TD error = target - Q(s, a): two fp32 network outputs of O(0.1 .. 1) each good to tests/tolerances.py OUT;
+        # from the second update on the weights behind them differ by what Adam makes of fp32 noise (see 4.)
+        tol = dict(rtol=1e-4, atol=4e-6) if k == 0 else dict(rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(d_rec[k][1], o_rec[k][1], err_msg="TD errors of update %d" % k, **tol)
+    _err("importance weights, update 0..%d" % (same - 1), np.array([r[0] for r in d_rec[:same]]),
+         np.array([r[0] for r in o_rec[:same]]))
+    _err("TD errors, update 0", d_rec[0][1], o_rec[0][1])
+    _err("TD errors, updates 0..%d" % (same - 1), np.array([r[1] for r in d_rec[:same]]), np.array([r[1] for r in o_rec[:same]]))
+    _err("loss, updates 0..%d" % (same - 1), agent.debug_losses[:same], o.losses[:same])
+    np.testing.assert_allclose(agent.debug_losses[0], o.losses[0], rtol=2e-4, atol=2e-6)       # tolerances.LOSS
+    np.testing.assert_allclose(agent.debug_losses[:3], o.losses[:3], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], rtol=5e-2, atol=6e-3)
+
+    # ---- 4. priority write-back: every leaf the first update touched holds (|TD error| + 1e-6) ** 0.6 of the DEVICE's TD
+    #         errors, bit for bit, unless a later update sampled the leaf again; untouched leaves are the fill's
+    trees = [t.cpu().numpy() for t in (mem.sum_tree, mem.min_tree, mem.max_tree)]
+    touched = np.zeros(CAP, dtype=bool)
+    for d in agent.debug_draws:
+        touched[d] = True
+    untouched = np.nonzero(~touched)[0] + CAP - 1
+    for t, ot in zip(trees, o_trees):
+        np.testing.assert_array_equal(t[untouched], ot[untouched])
+    last = {}
+    for k, d in enumerate(agent.debug_draws):
+        for j, leaf in enumerate(d):
+            last[int(leaf)] = (k, j)
+    for leaf, (k, j) in list(last.items())[:256]:
+        p = abs(float(d_rec[k][1][j])) + 1e-6
+        assert trees[0][leaf + CAP - 1] == p ** 0.6 and trees[2][leaf + CAP - 1] == p, (leaf, k, j)
+    # the sum tree is consistent with its leaves (parents = left + right, the reference's propagation)
+    inner_nodes = np.arange(CAP - 1)
+    np.testing.assert_array_equal(trees[0][inner_nodes], trees[0][2 * inner_nodes + 1] + trees[0][2 * inner_nodes + 2])
+    if same == n_upd:
+        np.testing.assert_allclose(trees[0][0], o_trees[0][0], rtol=1e-6)
+
+    # ---- 5. every weight after the phase's updates.  Adam's first steps move a weight by ~lr * sign(gradient): an
+    #         element whose gradient is fp32 noise around zero can land one or two learning rates apart on the two sides
+    #         while everything that drives the loss agrees — the bound of tests/test_dqn_agent.py, and the share of
+    #         elements inside tests/tolerances.py WEIGHTS is printed and bounded
+    from tolerances import WEIGHTS
+    w_hip, w_or = net.params.named_arrays(), o.net.weights()
+    worst, inside, total = 0.0, 0, 0
+    for name, towers in w_or.items():
+        a, b = w_hip[name][0].astype(np.float64), towers[0].astype(np.float64)
+        d = np.abs(a - b)
+        worst = max(worst, d.max())
+        inside += int((d <= WEIGHTS["atol"] + WEIGHTS["rtol"] * np.abs(b)).sum())
+        total += d.size
+        assert d.max() <= 4 * LR * max(1, n_upd // 4), (name, d.max())
+        assert (d <= 3e-5).mean() >= 0.9, (name, (d <= 3e-5).mean())
+    print("  weights after %d updates: max abs diff %.3e (lr = %.1e), %.4f %% of %d elements inside rtol %.0e / atol %.0e"
+          % (n_upd, worst, LR, 100.0 * inside / total, total, WEIGHTS["rtol"], WEIGHTS["atol"]))
+    assert inside / total >= 0.9
+    # the target network was copied after the first update of the phase (16 704 env-steps >= 10 000): it holds the
+    # online weights as they were THEN, not the final ones
+    assert o.last_target > 0
