@@ -149,10 +149,12 @@ def test_c3_wrapped_per_ring_and_first_updates_match_the_oracle(rlx, dev):
 
     # ---- 3. per update while the batches are identical: importance weights (fp64, same tree -> same bits for the first
     #         update; later ones see priorities written back from fp32 TD errors), TD errors, loss
-    np.testing.assert_array_equal(d_rec[0][0], o_rec[0][0])
+    # (the oracle hands its network the weights as fp32, dqn_agent.py:104-106 through the fp32 feed: compared at that width)
+    np.testing.assert_array_equal(d_rec[0][0].astype(np.float32), o_rec[0][0].astype(np.float32))
     assert len(np.unique(o_rec[0][0])) > B // 2                 # real importance weights, not a constant
     for k in range(same):
-        np.testing.assert_allclose(d_rec[k][0], o_rec[k][0], rtol=1e-5, err_msg="importance weights of update %d" % k)
+        np.testing.assert_allclose(d_rec[k][0], o_rec[k][0], rtol=1e-5 if k else 1e-7,
+                                   err_msg="importance weights of update %d" % k)
         # TD error = target - Q(s, a): two fp32 network outputs of O(0.1 .. 1) each good to tests/tolerances.py OUT;
         # from the second update on the weights behind them differ by what Adam makes of fp32 noise (see 4.)
         tol = dict(rtol=1e-4, atol=4e-6) if k == 0 else dict(rtol=2e-3, atol=2e-4)
