@@ -734,6 +734,12 @@ def main():
     ap.add_argument("--gemm-pipeline", type=int, default=None, choices=[0, 1],
                     help="A/B: main loop of the fast tiled GEMM kernels (rlx_gemm_pipeline): 1 = LDS-DMA ring (the "
                          "library's default), 0 = register-staged")
+    ap.add_argument("--adam-rider", type=int, default=None, choices=[0, 1],
+                    help="A/B (c2): the dense layers' Adam step as extra workgroups of the convolution backward's pair "
+                         "launches (1, the default at world size 1) or inside the closing Adam launch (0)")
+    ap.add_argument("--rider-blocks", type=int, default=None, help="A/B: workgroups of the Adam rider (AdamState.RIDER_BLOCKS)")
+    ap.add_argument("--rider-launches", type=int, default=None,
+                    help="A/B: pair launches the rider's range is divided over (AdamState.RIDER_LAUNCHES)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
                     help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
     ap.add_argument("--episode-length", type=int, default=EP_LEN,
@@ -770,6 +776,15 @@ def main():
     if args.ppo_chunk is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
         ClippedPPOAgent.DATASET_CHUNK = args.ppo_chunk
+    if args.adam_rider is not None:
+        from coach_amd.nn.networks import ClippedPPONet
+        ClippedPPONet.ADAM_RIDER = bool(args.adam_rider)
+    if args.rider_blocks is not None or args.rider_launches is not None:
+        from coach_amd.nn.graph import AdamState
+        if args.rider_blocks is not None:
+            AdamState.RIDER_BLOCKS = args.rider_blocks
+        if args.rider_launches is not None:
+            AdamState.RIDER_LAUNCHES = args.rider_launches
     if args.gemm_pipeline is not None:
         from coach_amd import _rlx
         _rlx.lib().gemm_pipeline(args.gemm_pipeline)

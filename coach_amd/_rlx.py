@@ -265,7 +265,7 @@ class SplitkJob(ctypes.Structure):
 
 
 ADAM_TICKET_WORDS = 1056        # rlx.h RLX_ADAM_TICKET_WORDS
-ABI_VERSION = 5                 # rlx_abi_version() of the library this module's structures and buffer sizes match
+ABI_VERSION = 6                 # rlx_abi_version() of the library this module's structures and buffer sizes match
 MAX_SPLITK_JOBS = 8
 
 

@@ -215,12 +215,19 @@ class ClippedPPONet(_NetBase):
             self._clip_scale_dev.fill_(float(value))
             self._clip_scale_value = float(value)
 
+    ADAM_RIDER = True        # forward_backward(adam_rider=...): honoured only while this is on (tests / A-B flip it)
+
     def forward_backward(self, obs, B, actions, advantages, value_targets, old_probs,
-                         clip_rescaler=1.0, ratio_out=None, clipped_out=None, stop_after_dense=False):
+                         clip_rescaler=1.0, ratio_out=None, clipped_out=None, stop_after_dense=False, adam_rider=None):
         """accumulate_gradients (tensorflow_components/architecture.py:312-385): forward both towers,
         head losses, backward; leaves d total_loss / d theta in params.grads.
         stop_after_dense: stop once the dense layers' gradients are final (backward_rest() resumes).
-        clip_rescaler None: the device scalar of set_clip_rescaler."""
+        clip_rescaler None: the device scalar of set_clip_rescaler.
+        adam_rider (a gradient scale, normally 1.0): the caller will follow this pass with finish_update(that scale)
+        and nothing else — the Adam step of the dense layers' and heads' parameters (final before the convolution
+        backward starts, 95 % of the bytes) then travels as extra workgroups of the convolution layers' dW + dX pair
+        launches (AdamState.arm_rider) and finish_update steps only the rest.  Same weights, bit for bit; the gradient
+        norm sums its squares in another order."""
         ctx = self.ctx
         clip_dev = self._clip_scale_dev if clip_rescaler is None else None
         if clip_rescaler is None:
@@ -282,6 +289,19 @@ class ClippedPPONet(_NetBase):
             k = self._split_layer()
             self.torso.backward(ctx, acts, layers=(k, len(self.torso.layers)))
             self._resume = (acts, k)
+        elif adam_rider is not None and self.ADAM_RIDER and self._split_layer() > 0 and ctx.deferred is None:
+            # the backward pass in two halves inside ONE deferral (the same jobs, the same single reduction launch as
+            # torso.backward(ctx, acts)); between them the dense layers' and the heads' gradients are final unless one
+            # of them is still a deferred split-K sum
+            k = self._split_layer()
+            ctx.begin_deferring()
+            try:
+                self.torso.backward(ctx, acts, layers=(k, len(self.torso.layers)))
+                if not ctx.deferred:
+                    self.adam.arm_rider(self.late_gradient_offset(), float(adam_rider))
+                self.torso.backward(ctx, acts, layers=(0, k))
+            finally:
+                ctx.flush_deferred()
         else:
             self.torso.backward(ctx, acts)
 
