@@ -215,7 +215,10 @@ class ClippedPPONet(_NetBase):
             self._clip_scale_dev.fill_(float(value))
             self._clip_scale_value = float(value)
 
-    ADAM_RIDER = True        # forward_backward(adam_rider=...): honoured only while this is on (tests / A-B flip it)
+    # forward_backward(adam_rider=...) is honoured only while this is on.  OFF by default: measured -0.3 .. -1.3 % per C2
+    # update (profiles/r05_ab_adam_rider.txt) — the pair launch that carries the rider grows by what the closing Adam launch
+    # saves, because the convolution products wait on memory LATENCY and the rider's streaming traffic raises it
+    ADAM_RIDER = False
 
     def forward_backward(self, obs, B, actions, advantages, value_targets, old_probs,
                          clip_rescaler=1.0, ratio_out=None, clipped_out=None, stop_after_dense=False, adam_rider=None):
