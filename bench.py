@@ -740,6 +740,8 @@ def main():
     ap.add_argument("--rider-blocks", type=int, default=None, help="A/B: workgroups of the Adam rider (AdamState.RIDER_BLOCKS)")
     ap.add_argument("--rider-launches", type=int, default=None,
                     help="A/B: pair launches the rider's range is divided over (AdamState.RIDER_LAUNCHES)")
+    ap.add_argument("--fuse-conv", type=int, default=None, choices=[0, 1],
+                    help="A/B: conv2 -> conv3 forward as one launch (nn.graph.FUSE_CONV_PAIR; 1 = the default)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
                     help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
     ap.add_argument("--episode-length", type=int, default=EP_LEN,
@@ -776,6 +778,9 @@ def main():
     if args.ppo_chunk is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
         ClippedPPOAgent.DATASET_CHUNK = args.ppo_chunk
+    if args.fuse_conv is not None:
+        from coach_amd.nn import graph as _G
+        _G.FUSE_CONV_PAIR = bool(args.fuse_conv)
     if args.adam_rider is not None:
         from coach_amd.nn.networks import ClippedPPONet
         ClippedPPONet.ADAM_RIDER = bool(args.adam_rider)

@@ -39,7 +39,7 @@ _CTYPE = {
     "size_t": ctypes.c_size_t,
 }
 
-_VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported"}  # return a value, not an rlx_status
+_VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
 

@@ -1,0 +1,290 @@
+// conv2 -> conv3 of the Atari torso as ONE launch: the second convolution's output stays in LDS and feeds the third.
+//
+// Replaces, for the image embedder of rl_coach (architectures/embedder_parameters.py "Medium": conv 32 x 8 x 8 / 4,
+// 64 x 4 x 4 / 2, 64 x 3 x 3 / 1; tensorflow_components/layers.py:108-121 tf.layers.conv2d VALID NHWC), the forward
+// products of its second and third layer — two launches of the tiled implicit-im2col GEMM (gemm.hip), 15.7 us each in the
+// Clipped-PPO minibatch update against 2.2 / 1.5 us of matrix work at the chip's fp32 MFMA rate.  What those launches
+// wait for is operand delivery from beyond the XCD's L2: every workgroup pulls the whole
+// weight matrix AND its slice of an activation tensor the previous launch has just written on other XCDs.  Here one
+// workgroup owns HALF AN IMAGE of one tower end to end:
+//
+//   conv1 activations of its rows (contiguous in NHWC: 12 or 14 rows x 20 x 32 fp32, 31-36 KB)  -> LDS, once
+//   conv2 on those rows: 45 / 54 output positions x 64 channels, K = 512           (A from LDS, W2 streamed through a ring)
+//   its output -> LDS (and the rows this half OWNS -> global memory: the backward pass reads them)
+//   conv3 on that: 21 / 28 positions x 64 channels, K = 576                         (A from LDS, W3 streamed through the ring)
+//
+// Halves: conv3 rows [0, 3) need conv2 rows [0, 5) need conv1 rows [0, 12); conv3 rows [3, 7) need conv2 rows [3, 9) need
+// conv1 rows [6, 20): conv2 rows 3 and 4 are computed by both halves (11 % redundant conv2 work), each half stores the
+// rows it owns ([0, 4) / [4, 9)).  2 x images x towers workgroups of 8 waves: 256 for the PPO minibatch (64 images, two
+// towers) — one per CU — instead of 324 + 196 on two launches.  The conv2 activations never travel through memory on
+// their way to conv3, one launch boundary (and one cold start of every operand) is gone.
+//
+// ARITHMETIC: bit-identical to the two tiled launches it replaces when those run on 32 x 64 tiles with the K slab split
+// over two wave groups (gemm_dma_kernel<32, 64, 2, ...>, what rlx_gemm picks for these products at 64 images x 2 towers):
+// per output element the same v_mfma_f32_32x32x2_f32 chain — slabs of 32 k in ascending order, inside a slab the k-quads
+// {0, 1} by wave group 0 and {2, 3} by wave group 1, MFMA step t of a quad multiplying k = 8 q + t (half-wave 0) and
+// 8 q + 4 + t (half-wave 1) — the two partial tiles added as group 0 + group 1, then bias, then the activation.  The
+// host side (coach_amd/nn/graph.py) takes this kernel only where the tiled path would have run that configuration, so a
+// network's trajectory does not move by a bit (tests/test_conv_fused.py compares the two paths with torch.equal).
+//
+// LDS (105 KB, one workgroup per CU): conv1 rows [position][32 + 4 pad] (the pad spreads the 16-byte operand reads of
+// lanes that are 2 input columns apart over the banks), conv2 output [position][64 + 4], a ring of two 8 KB weight slabs
+// filled by global_load_lds_dwordx4 (one 16-byte request per lane per slab, 512 lanes = 32 k x 64 n), 8 wave patches of
+// 32 x 33 for the partial-tile exchange and the 16-byte epilogue.
+// Bound: MFMA issue of a CU (conv2: 8 wave-jobs of 128 MFMAs on 4 SIMDs = 6.8 us; conv3: 4 wave-jobs of 144 MFMAs =
+// 3.8 us) with the weight stream (275 KB per workgroup) underneath.
+#include "rlx_common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 512;
+constexpr int H1 = 20, W1 = 20, C1 = 32;             // conv1 output = conv2 input
+constexpr int K2 = 4, S2 = 2, C2 = 64, O2 = 9;       // conv2: 4 x 4 stride 2 -> 9 x 9 x 64
+constexpr int K3 = 3, C3 = 64, O3 = 7;               // conv3: 3 x 3 stride 1 -> 7 x 7 x 64
+constexpr int P1 = C1 + 4, P2 = C2 + 4;              // LDS position strides (floats)
+constexpr int kIn1Rows = 14, kOut2Rows = 6;
+constexpr int kIn1Floats = kIn1Rows * W1 * P1;       // 10 080
+constexpr int kOut2Floats = kOut2Rows * O2 * P2;     // 3 672
+constexpr int kSlabFloats = 32 * 64;                 // one weight slab: 32 k x 64 output channels
+constexpr int kPatchFloats = 32 * 33;
+constexpr int kSmemFloats = kIn1Floats + kOut2Floats + 2 * kSlabFloats + 8 * kPatchFloats;
+constexpr int kSlabs2 = K2 * K2 * C1 / 32;           // 16
+constexpr int kSlabs3 = K3 * K3 * C2 / 32;           // 18
+static_assert(S2 * (O2 - 1) + K2 == H1 && O2 - K3 + 1 == O3, "geometry");
+static_assert(kSmemFloats * 4 <= 160 * 1024, "LDS");
+
+struct ConvPairArgs {
+    const float *x1; long long x1_ts;                // [T][B * 400][32]  conv1 activations
+    const float *w2; long long w2_ts;                // [T][512][64]
+    const float *b2; long long b2_ts;                // [T][64]
+    const float *w3; long long w3_ts;                // [T][576][64]
+    const float *b3; long long b3_ts;
+    float *y2; long long y2_ts;                      // [T][B * 81][64]
+    float *y3; long long y3_ts;                      // [T][B * 49][64]
+    int B, T, act;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == RLX_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == RLX_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// one 16-byte global -> LDS request per lane; lds_dst: wave-uniform LDS byte address of lane 0's 16 bytes (gemm.hip dma16)
+__device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+__global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvPairArgs a) {
+    __shared__ __attribute__((aligned(1024))) float smem[kSmemFloats];     // 105 KB static (gfx950: up to 160 KB)
+    float *const ring = smem;                                  // (first: the DMA destinations stay 1 KB aligned)
+    float *const patches = ring + 2 * kSlabFloats;
+    float *const in1 = patches + 8 * kPatchFloats;
+    float *const out2 = in1 + kIn1Floats;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int half = blockIdx.x & 1;
+    const int img = (blockIdx.x >> 1) % a.B, t = (blockIdx.x >> 1) / a.B;
+    // rows of this half: conv3 [r3, r3 + n3), conv2 [r2, r2 + n2) (owned: [own_lo, own_hi)), conv1 [r1, r1 + n1)
+    const int r3 = half ? 3 : 0, n3 = half ? 4 : 3;
+    const int r2 = half ? 3 : 0, n2 = half ? 6 : 5;
+    const int r1 = half ? 6 : 0, n1 = half ? 14 : 12;
+    const int own_lo = half ? 4 : 0, own_hi = half ? 9 : 4;
+    const int np2 = n2 * O2, np3 = n3 * O3;                   // output positions of this half (45 / 54, 21 / 28)
+
+    const float *const w2 = a.w2 + (size_t)t * a.w2_ts, *const w3 = a.w3 + (size_t)t * a.w3_ts;
+    // weight slab g (0 .. 33: conv2's 16, then conv3's 18) -> ring buffer g & 1: lane tid moves 4 consecutive output
+    // channels of k-row tid / 16
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
+        static_cast<unsigned>(reinterpret_cast<uintptr_t>(ring)) + (unsigned)w * 1024u);
+    const int wrow = tid >> 4, wcol = (tid & 15) * 4;
+    auto issue = [&](const int g) {
+        const float *src = g < kSlabs2 ? w2 + (size_t)(g * 32 + wrow) * C2 + wcol
+                                       : w3 + (size_t)((g - kSlabs2) * 32 + wrow) * C3 + wcol;
+        dma16(src, ring_lds + (unsigned)(g & 1) * (kSlabFloats * 4u));
+    };
+    issue(0);
+
+    // ---- conv1 activations of rows [r1, r1 + n1) -> in1[position][P1]
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.x1 + (size_t)t * a.x1_ts +
+                                                             ((size_t)img * (H1 * W1) + (size_t)r1 * W1) * C1);
+        const int n4 = n1 * W1 * (C1 / 4);
+        for (int f = tid; f < n4; f += kThreads) {
+            const float4 v = src[f];
+            *reinterpret_cast<float4 *>(in1 + (f >> 3) * P1 + (f & 7) * 4) = v;
+        }
+    }
+
+    // ---- conv2: 2 row tiles x 2 column tiles x 2 wave groups = 8 wave-jobs
+    {
+        const int wk = w >> 2, wm = (w >> 1) & 1, wn = w & 1;
+        const int p = min(wm * 32 + l31, np2 - 1);            // rows past the last position repeat it (never stored)
+        const int oy = p / O2, ox = p - oy * O2;
+        const float *const arow = in1 + ((2 * oy) * W1 + 2 * ox) * P1 + 4 * hi;
+        const int b_col = wn * 32 + l31;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int g = 0; g < kSlabs2; ++g) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's request of slab g (and its in1 loads) landed
+            __syncthreads();                                       // ... every lane's; slab g - 1 has been read by every wave
+            issue(g + 1);                                          // (g + 1 = 16: conv3's first slab)
+            const int ky = g >> 2, kx = g & 3;
+            const float *as = arow + (ky * W1 + kx) * P1;
+            const float *bs = ring + (g & 1) * kSlabFloats;
+            float av[2][4], bv[2][4];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = wk * 2 + qq;
+                const float4 v = *reinterpret_cast<const float4 *>(as + 8 * q);
+                av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[qq][i] = bs[(8 * q + 4 * hi + i) * C2 + b_col];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s >> 2][s & 3], bv[s >> 2][s & 3], acc, 0, 0, 0);
+        }
+        // partial tile of wave group 1 -> its patch; wave group 0 adds it (group 0 + group 1, gemm.hip fast_epilogue)
+        float *const patch = patches + w * kPatchFloats;
+        if (wk == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+            const float *src = patches + (w + 4) * kPatchFloats;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += src[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
+            // C / D layout undone through the wave's own patch: a lane then owns 4 consecutive channels of a position
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+            const float4 bias = *reinterpret_cast<const float4 *>(a.b2 + (size_t)t * a.b2_ts + wn * 32 + (lane & 7) * 4);
+            float *const y2 = a.y2 + (size_t)t * a.y2_ts + (size_t)img * (O2 * O2) * C2;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane;
+                const int rl = idx >> 3, c4 = (idx & 7) * 4;
+                const int pos = wm * 32 + rl;
+                if (pos >= np2) continue;
+                const float *sp = patch + rl * 33 + c4;
+                float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                v.x = apply_act(v.x, a.act); v.y = apply_act(v.y, a.act);
+                v.z = apply_act(v.z, a.act); v.w = apply_act(v.w, a.act);
+                *reinterpret_cast<float4 *>(out2 + pos * P2 + wn * 32 + c4) = v;
+                const int row = r2 + pos / O2;                    // conv2 output row of this position
+                if (row >= own_lo && row < own_hi)
+                    *reinterpret_cast<float4 *>(y2 + (size_t)(r2 * O2 + pos) * C2 + wn * 32 + c4) = v;
+            }
+        }
+    }
+
+    // ---- conv3: 1 row tile x 2 column tiles x 2 wave groups = 4 wave-jobs (waves 0 .. 3); waves 4 .. 7 keep the weight
+    //      stream and the barriers going
+    {
+        const bool active = w < 4;
+        const int wk = (w >> 1) & 1, wn = w & 1;
+        const int p = min(l31, np3 - 1);
+        const int oy = p / O3, ox = p - oy * O3;
+        const float *const arow = out2 + (oy * O2 + ox) * P2 + 4 * hi;
+        const int b_col = wn * 32 + l31;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int g = kSlabs2; g < kSlabs2 + kSlabs3; ++g) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                       // (g = 16: also publishes out2)
+            if (g + 1 < kSlabs2 + kSlabs3) issue(g + 1);
+            if (active) {
+                const int s3 = g - kSlabs2, tap = s3 >> 1;
+                const int ky = tap / K3, kx = tap - ky * K3;
+                const float *as = arow + (ky * O2 + kx) * P2 + (s3 & 1) * 32;
+                const float *bs = ring + (g & 1) * kSlabFloats;
+                float av[2][4], bv[2][4];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = wk * 2 + qq;
+                    const float4 v = *reinterpret_cast<const float4 *>(as + 8 * q);
+                    av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bv[qq][i] = bs[(8 * q + 4 * hi + i) * C3 + b_col];
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s >> 2][s & 3], bv[s >> 2][s & 3], acc, 0, 0, 0);
+            }
+        }
+        float *const patch = patches + w * kPatchFloats;
+        __syncthreads();                                           // conv2's patches are no longer read
+        if (active && wk == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
+        }
+        __syncthreads();
+        if (active && wk == 0) {
+            const float *src = patches + (w + 2) * kPatchFloats;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += src[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
+        }
+        __syncthreads();
+        if (active && wk == 0) {
+            const float4 bias = *reinterpret_cast<const float4 *>(a.b3 + (size_t)t * a.b3_ts + wn * 32 + (lane & 7) * 4);
+            float *const y3 = a.y3 + (size_t)t * a.y3_ts + ((size_t)img * (O3 * O3) + (size_t)r3 * O3) * C3;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane;
+                const int rl = idx >> 3, c4 = (idx & 7) * 4;
+                if (rl >= np3) continue;
+                const float *sp = patch + rl * 33 + c4;
+                float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                v.x = apply_act(v.x, a.act); v.y = apply_act(v.y, a.act);
+                v.z = apply_act(v.z, a.act); v.w = apply_act(v.w, a.act);
+                *reinterpret_cast<float4 *>(y3 + (size_t)rl * C3 + wn * 32 + c4) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlx_conv23_forward_supported(int H, int W, int C, int k2, int s2, int c2, int k3, int s3, int c3) {
+    return H == H1 && W == W1 && C == C1 && k2 == K2 && s2 == S2 && c2 == C2 && k3 == K3 && s3 == 1 && c3 == C3;
+}
+
+int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *w2, long long w2_tower_stride,
+                       const float *b2, long long b2_tower_stride, const float *w3, long long w3_tower_stride,
+                       const float *b3, long long b3_tower_stride, float *y2, long long y2_tower_stride, float *y3,
+                       long long y3_tower_stride, int batch, int towers, int activation, void *stream) {
+    RLX_REQUIRE(x1 && w2 && b2 && w3 && b3 && y2 && y3, "rlx_conv23_forward: null pointer");
+    RLX_REQUIRE(batch >= 1 && towers >= 1 && (long long)batch * towers <= (1 << 20), "rlx_conv23_forward: bad batch / towers");
+    RLX_REQUIRE(activation >= 0 && activation <= 2, "rlx_conv23_forward: unknown activation");
+    RLX_REQUIRE((((uintptr_t)x1 | (uintptr_t)w2 | (uintptr_t)b2 | (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)y2 |
+                  (uintptr_t)y3) & 15) == 0 &&
+                    ((x1_tower_stride | w2_tower_stride | b2_tower_stride | w3_tower_stride | b3_tower_stride |
+                      y2_tower_stride | y3_tower_stride) & 3) == 0,
+                "rlx_conv23_forward: operands must be 16-byte aligned");
+    ConvPairArgs a{x1, x1_tower_stride, w2, w2_tower_stride, b2, b2_tower_stride, w3, w3_tower_stride, b3, b3_tower_stride,
+                   y2, y2_tower_stride, y3, y3_tower_stride, batch, towers, activation};
+    RLX_LAUNCH((conv23_forward_kernel), 2 * batch * towers, kThreads, 0, rlx::as_stream(stream), a);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+}  // extern "C"

@@ -127,6 +127,24 @@ PAIR_GRADIENT_GEMMS = True
 # (the gather's dependent loads pay the slower memory system twice); it halves the HBM bytes of the convolutions'
 # backward pass, so it stays available for configurations where that is the limit.
 DIRECT_CONV_INPUT_GRAD = False
+# The Atari torso's second and third convolution as ONE launch with the second layer's output in LDS
+# (rlx_conv23_forward, csrc/conv_fused.hip) — taken only where the two tiled launches it replaces would run on 32 x 64
+# tiles with two wave groups per K slab (_kw2_tiling below: rlx_gemm's own rule), because exactly there the fused
+# kernel's sums are bit-identical to theirs.  The tests flip it to compare the two paths.
+FUSE_CONV_PAIR = True
+KW_BELOW_TILES = KW_MIN_TILES = 192        # rlx_gemm_tuning's defaults (csrc/gemm.hip g_kw_below_tiles / g_kw_min_tiles)
+
+
+def _kw2_tiling(M, N, batch):
+    """rlx_gemm runs an M x N x K product of `batch` towers on 32 x 64 tiles with the K slab split over two wave groups
+    (csrc/gemm.hip gemm_impl: fewer than KW_BELOW_TILES 64 x 64 tiles, at least KW_MIN_TILES 32 x 64 tiles)."""
+    if N <= 32:
+        return False
+    t64 = -(-M // 64) * -(-N // 64) * batch
+    t32 = -(-M // 32) * -(-N // 64) * batch
+    return t64 < KW_BELOW_TILES and t32 >= KW_MIN_TILES
+
+
 # most K splits a deferred product may get room for (rlx_gemm_split_cap's largest useful setting; its default is 64)
 SPLIT_CAP_BOUND = 128
 
@@ -758,13 +776,47 @@ class Sequential:
         launch where it can (rlx_gemm_desc.row_heads); returns (acts, head outputs) then."""
         acts = [x]
         kw = {"pair": True} if pair else {}
+        skip = -1
         for i, l in enumerate(self.layers):
+            if i == skip:
+                continue
+            fused = self._fused_conv_pair(ctx, i, acts[-1], tag, weights, t0, nt, pair)
+            if fused is not None:
+                acts.extend(fused)
+                skip = i + 1
+                continue
             if row_heads and i == len(self.layers) - 1:
                 y, heads = l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, row_heads=row_heads, **kw)
                 acts.append(y)
                 return acts, heads
             acts.append(l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, **kw))
         return acts
+
+    def _fused_conv_pair(self, ctx, i, x, tag, weights, t0, nt, pair):
+        """layers i and i + 1 as one launch (rlx_conv23_forward) -> [y_i, y_{i+1}], or None: both convolutions, the
+        geometry the kernel is compiled for, fp32 per-tower input, and batch / towers for which the two tiled launches
+        would have summed in the fused kernel's order (FUSE_CONV_PAIR)."""
+        if not FUSE_CONV_PAIR or pair or i + 1 >= len(self.layers):
+            return None
+        a, b = self.layers[i], self.layers[i + 1]
+        if not (isinstance(a, Conv2d) and isinstance(b, Conv2d)) or x.u8 or a.act != b.act or a.T != b.T:
+            return None
+        t0_, T = a._range(t0, nt)
+        if x.towers != T or not ctx.lib.conv23_forward_supported(a.H, a.W, a.C, a.KH, a.S, a.Co, b.KH, b.S, b.Co):
+            return None
+        B = x.rows
+        M2, M3 = B * a.OH * a.OW, B * b.OH * b.OW
+        if not (_kw2_tiling(M2, a.Co, T) and _kw2_tiling(M3, b.Co, T)):
+            return None
+        p = a.params
+        y2 = ctx.buffer(a.name, (T, M2, a.Co), tag=tag)
+        y3 = ctx.buffer(b.name, (T, M3, b.Co), tag=tag)
+        ctx.lib.conv23_forward(x.data, x.tower_stride(), p.w(a.kname, t0_, weights), p.stride(a.kname),
+                               p.w(a.bname, t0_, weights), p.stride(a.bname), p.w(b.kname, t0_, weights), p.stride(b.kname),
+                               p.w(b.bname, t0_, weights), p.stride(b.bname), y2, M2 * a.Co, y3, M3 * b.Co, B, T,
+                               _rlx.ACT[a.act], ctx.stream)
+        return [Tensor(y2, B, a.OH * a.OW * a.Co, T, grad_key=(ctx, a.name, tag), act=a.act),
+                Tensor(y3, B, b.OH * b.OW * b.Co, T, grad_key=(ctx, b.name, tag), act=b.act)]
 
     def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None, need_dw=True,
                  layers=None):

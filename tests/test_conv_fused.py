@@ -1,0 +1,101 @@
+"""conv2 -> conv3 of the Atari torso as one launch (rlx_conv23_forward, coach_amd/csrc/conv_fused.hip) against the two
+tiled implicit-im2col launches it replaces (tf.layers.conv2d twice, tensorflow_components/layers.py:108-121).
+
+The fused kernel is taken only where rlx_gemm would run both products on 32 x 64 tiles with two wave groups per K slab,
+and there its fp32 sums are the same MFMA chains in the same order: every activation must be BIT-IDENTICAL, and so must a
+whole Clipped-PPO update built on it.  (Against the numpy oracle the convolution layers are covered by tests/test_nn.py and
+tests/test_ppo_full_size.py, which now run through this kernel at the C2 size.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torso(dev, act, seed):
+    import torch
+    from coach_amd.nn import graph as G, networks as NW
+    params = G.FlatParams()
+    torso, feat = NW.build_torso(params, "main", (84, 84, 4), act, 2, "Medium", "Medium")
+    params.finalize(dev)
+    rng = np.random.RandomState(seed)
+    torso.initialize(rng)
+    for l in torso.layers:                                   # non-zero biases: the epilogue's bias add is exercised
+        for t in range(2):
+            params.w(l.bname, t).copy_(torch.from_numpy(rng.randn(*params.w(l.bname, t).shape).astype(np.float32) * 0.1))
+    return params, torso
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+@pytest.mark.parametrize("B", [64, 72])
+def test_fused_pair_equals_the_two_tiled_launches_bit_for_bit(rlx, dev, act, B):
+    import torch
+    from coach_amd import _rlx
+    from coach_amd.nn import graph as G
+    assert G._kw2_tiling(B * 81, 64, 2) and G._kw2_tiling(B * 49, 64, 2)
+    params, torso = _torso(dev, act, 1)
+    obs = torch.from_numpy(np.random.RandomState(2).randint(0, 256, size=(B, 84, 84, 4)).astype(np.uint8)).to(dev)
+    x = G.input_tensor(obs, B, 84 * 84 * 4, u8=True, div=255.0)
+    outs, names = {}, {}
+    for fused in (False, True):
+        G.FUSE_CONV_PAIR = fused
+        try:
+            ctx = G.Context(dev)
+            with _rlx.KernelTimer(64) as timer:
+                acts = torso.forward(ctx, x, tag="t")
+            outs[fused] = [a.data.clone() for a in acts[1:]]
+            names[fused] = [n for n, _ in timer.records]
+        finally:
+            G.FUSE_CONV_PAIR = True
+    assert not any("conv23" in n for n in names[False])
+    assert sum("conv23_forward_kernel" in n for n in names[True]) == 1
+    assert len(names[True]) == len(names[False]) - 1            # one launch instead of two
+    assert len(outs[True]) == len(outs[False]) == 4
+    for i, (a, b) in enumerate(zip(outs[True], outs[False])):
+        assert a.shape == b.shape
+        assert torch.equal(a, b), "layer %d: %d of %d elements differ, max %g" % (
+            i, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
+    assert float(outs[True][2].abs().max()) > 0.05              # (not a comparison of zeros)
+
+
+def test_other_batches_keep_the_tiled_launches(rlx, dev):
+    """where rlx_gemm would pick another tiling (8 images: thin / 32 x 32 tiles) the sums would differ in their last
+    bits — the fused kernel is not taken, and the pinned small-batch trajectories of the other tests do not move."""
+    import torch
+    from coach_amd import _rlx
+    from coach_amd.nn import graph as G
+    params, torso = _torso(dev, "tanh", 3)
+    for B in (8, 32, 256):
+        obs = torch.from_numpy(np.random.RandomState(4).randint(0, 256, size=(B, 84, 84, 4)).astype(np.uint8)).to(dev)
+        ctx = G.Context(dev)
+        with _rlx.KernelTimer(64) as timer:
+            torso.forward(ctx, G.input_tensor(obs, B, 84 * 84 * 4, u8=True, div=255.0), tag="t")
+        assert not any("conv23" in n for n, _ in timer.records), B
+
+
+def test_clipped_ppo_update_through_the_fused_pair_is_bit_identical(rlx, dev):
+    import torch
+    from coach_amd.nn import graph as G
+    from coach_amd.nn.networks import ClippedPPONet
+    B, A, shape = 64, 6, (84, 84, 4)
+    rng = np.random.RandomState(0)
+    obs = torch.from_numpy(rng.randint(0, 256, size=(B,) + shape).astype(np.uint8)).to(dev)
+    acts = torch.from_numpy(rng.randint(0, A, size=B).astype(np.int32)).to(dev)
+    adv = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
+    vt = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
+    res = {}
+    for fused in (False, True):
+        G.FUSE_CONV_PAIR = fused
+        try:
+            np.random.seed(1)
+            net = ClippedPPONet(dev, shape, A, seed=2)
+            net.update_target(1.0)
+            old = net.policy_probs(obs, B, use_target=True, tag="old")
+            for _ in range(2):
+                net.forward_backward(obs, B, acts, adv, vt, old)
+                net.finish_update(1.0)
+            net.check_status()
+            res[fused] = (net.params.weights.clone(), net.scalars.clone())
+        finally:
+            G.FUSE_CONV_PAIR = True
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
