@@ -740,6 +740,7 @@ def main():
     ap.add_argument("--rider-blocks", type=int, default=None, help="A/B: workgroups of the Adam rider (AdamState.RIDER_BLOCKS)")
     ap.add_argument("--rider-launches", type=int, default=None,
                     help="A/B: pair launches the rider's range is divided over (AdamState.RIDER_LAUNCHES)")
+    ap.add_argument("--conv23-depth", type=int, default=None, help="A/B: weight slabs in rlx_conv23_forward's ring")
     ap.add_argument("--fuse-conv", type=int, default=None, choices=[0, 1],
                     help="A/B: conv2 -> conv3 forward as one launch (nn.graph.FUSE_CONV_PAIR; 1 = the default)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
@@ -778,6 +779,9 @@ def main():
     if args.ppo_chunk is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
         ClippedPPOAgent.DATASET_CHUNK = args.ppo_chunk
+    if args.conv23_depth is not None:
+        from coach_amd import _rlx
+        _rlx.lib().conv23_depth(args.conv23_depth)
     if args.fuse_conv is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_PAIR = bool(args.fuse_conv)

@@ -49,11 +49,12 @@ constexpr int kIn1Floats = kIn1Rows * W1 * P1;       // 10 080
 constexpr int kOut2Floats = kOut2Rows * O2 * P2;     // 3 672
 constexpr int kSlabFloats = 32 * 64;                 // one weight slab: 32 k x 64 output channels
 constexpr int kPatchFloats = 32 * 33;
-constexpr int kSmemFloats = kIn1Floats + kOut2Floats + 2 * kSlabFloats + 8 * kPatchFloats;
+// weight slabs in the ring (kDepth - 1 requests in flight per lane): a template parameter, rlx_conv23_depth() selects
+constexpr int smem_floats(int depth) { return kIn1Floats + kOut2Floats + depth * kSlabFloats + 8 * kPatchFloats; }
 constexpr int kSlabs2 = K2 * K2 * C1 / 32;           // 16
 constexpr int kSlabs3 = K3 * K3 * C2 / 32;           // 18
 static_assert(S2 * (O2 - 1) + K2 == H1 && O2 - K3 + 1 == O3, "geometry");
-static_assert(kSmemFloats * 4 <= 160 * 1024, "LDS");
+static_assert(smem_floats(8) * 4 <= 160 * 1024, "LDS");
 
 struct ConvPairArgs {
     const float *x1; long long x1_ts;                // [T][B * 400][32]  conv1 activations
@@ -81,10 +82,11 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+template <int kDepth>
 __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvPairArgs a) {
-    __shared__ __attribute__((aligned(1024))) float smem[kSmemFloats];     // 105 KB static (gfx950: up to 160 KB)
+    __shared__ __attribute__((aligned(1024))) float smem[smem_floats(kDepth)];     // 105-154 KB static (gfx950: up to 160 KB)
     float *const ring = smem;                                  // (first: the DMA destinations stay 1 KB aligned)
-    float *const patches = ring + 2 * kSlabFloats;
+    float *const patches = ring + kDepth * kSlabFloats;
     float *const in1 = patches + 8 * kPatchFloats;
     float *const out2 = in1 + kIn1Floats;
 
@@ -105,12 +107,26 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
         static_cast<unsigned>(reinterpret_cast<uintptr_t>(ring)) + (unsigned)w * 1024u);
     const int wrow = tid >> 4, wcol = (tid & 15) * 4;
+    // Every lane issues exactly ONE request per slab, in slab order, kDepth - 1 slabs ahead; slab g has landed for a lane
+    // once all but its newest kDepth - 2 vector-memory operations are complete (they retire in order; other loads /
+    // stores of the lane only make the wait longer).  Requests of non-existent slabs (g >= 34) are still issued — they
+    // re-read the last slab into a buffer nobody reads again — so that the count is the same in every step.
+    constexpr int kSlabsAll = kSlabs2 + kSlabs3;
     auto issue = [&](const int g) {
-        const float *src = g < kSlabs2 ? w2 + (size_t)(g * 32 + wrow) * C2 + wcol
-                                       : w3 + (size_t)((g - kSlabs2) * 32 + wrow) * C3 + wcol;
-        dma16(src, ring_lds + (unsigned)(g & 1) * (kSlabFloats * 4u));
+        const int gg = g < kSlabsAll ? g : kSlabsAll - 1;
+        const float *src = gg < kSlabs2 ? w2 + (size_t)(gg * 32 + wrow) * C2 + wcol
+                                        : w3 + (size_t)((gg - kSlabs2) * 32 + wrow) * C3 + wcol;
+        dma16(src, ring_lds + (unsigned)(g % kDepth) * (kSlabFloats * 4u));
     };
-    issue(0);
+    // landed(g) for this lane -> its LDS reads of slab g - 1 are complete -> every wave: slab g may be read, the buffer
+    // of slab g - 1 refilled
+    auto step_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDepth - 2) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+    };
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d) issue(d);
 
     // ---- conv1 activations of rows [r1, r1 + n1) -> in1[position][P1]
     {
@@ -134,12 +150,11 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         for (int g = 0; g < kSlabs2; ++g) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's request of slab g (and its in1 loads) landed
-            __syncthreads();                                       // ... every lane's; slab g - 1 has been read by every wave
-            issue(g + 1);                                          // (g + 1 = 16: conv3's first slab)
+            step_sync();                                           // (g = 0: also publishes in1)
+            issue(g + kDepth - 1);                                 // (from g = 17 - kDepth on: conv3's first slabs)
             const int ky = g >> 2, kx = g & 3;
             const float *as = arow + (ky * W1 + kx) * P1;
-            const float *bs = ring + (g & 1) * kSlabFloats;
+            const float *bs = ring + (g % kDepth) * kSlabFloats;
             float av[2][4], bv[2][4];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
@@ -204,14 +219,13 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         for (int g = kSlabs2; g < kSlabs2 + kSlabs3; ++g) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                       // (g = 16: also publishes out2)
-            if (g + 1 < kSlabs2 + kSlabs3) issue(g + 1);
+            step_sync();                                           // (g = 16: also publishes out2)
+            issue(g + kDepth - 1);
             if (active) {
                 const int s3 = g - kSlabs2, tap = s3 >> 1;
                 const int ky = tap / K3, kx = tap - ky * K3;
                 const float *as = arow + (ky * O2 + kx) * P2 + (s3 & 1) * 32;
-                const float *bs = ring + (g & 1) * kSlabFloats;
+                const float *bs = ring + (g % kDepth) * kSlabFloats;
                 float av[2][4], bv[2][4];
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
@@ -227,6 +241,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
             }
         }
         float *const patch = patches + w * kPatchFloats;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the requests of non-existent slabs still target the ring
         __syncthreads();                                           // conv2's patches are no longer read
         if (active && wk == 1) {
 #pragma unroll
@@ -260,6 +275,8 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
     }
 }
 
+int g_depth = 4;
+
 }  // namespace
 
 extern "C" {
@@ -282,8 +299,20 @@ int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *
                 "rlx_conv23_forward: operands must be 16-byte aligned");
     ConvPairArgs a{x1, x1_tower_stride, w2, w2_tower_stride, b2, b2_tower_stride, w3, w3_tower_stride, b3, b3_tower_stride,
                    y2, y2_tower_stride, y3, y3_tower_stride, batch, towers, activation};
-    RLX_LAUNCH((conv23_forward_kernel), 2 * batch * towers, kThreads, 0, rlx::as_stream(stream), a);
+    const unsigned grid = 2u * batch * towers;
+    hipStream_t s = rlx::as_stream(stream);
+    if (g_depth == 2) RLX_LAUNCH((conv23_forward_kernel<2>), grid, kThreads, 0, s, a);
+    else if (g_depth == 3) RLX_LAUNCH((conv23_forward_kernel<3>), grid, kThreads, 0, s, a);
+    else if (g_depth == 6) RLX_LAUNCH((conv23_forward_kernel<6>), grid, kThreads, 0, s, a);
+    else if (g_depth == 8) RLX_LAUNCH((conv23_forward_kernel<8>), grid, kThreads, 0, s, a);
+    else RLX_LAUNCH((conv23_forward_kernel<4>), grid, kThreads, 0, s, a);
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_conv23_depth(int depth) {
+    RLX_REQUIRE(depth == 2 || depth == 3 || depth == 4 || depth == 6 || depth == 8, "rlx_conv23_depth: 2, 3, 4, 6 or 8");
+    g_depth = depth;
     return RLX_OK;
 }
 

@@ -77,6 +77,8 @@ int rlx_profile_read(int index, const char **name_host, float *ms_host);
  * on 32 x 64 tiles with two wave groups per K slab (coach_amd/csrc/conv_fused.hip).  rlx_conv23_forward_supported: 1 for
  * the geometry the kernel is compiled for. */
 int rlx_conv23_forward_supported(int H, int W, int C, int k2, int s2, int c2, int k3, int s3, int c3);
+/* weight slabs in rlx_conv23_forward's LDS ring (2, 3, 4 = default, 6, 8): process-wide, for same-process A/Bs */
+int rlx_conv23_depth(int depth);
 int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *w2, long long w2_tower_stride,
                        const float *b2, long long b2_tower_stride, const float *w3, long long w3_tower_stride,
                        const float *b3, long long b3_tower_stride, float *y2, long long y2_tower_stride, float *y3,
