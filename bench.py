@@ -353,7 +353,7 @@ def run_off_policy(args, device, dist):
 
 
 # ------------------------------------------------------------------------------------- roofline
-GEMM_FAMILY = ("gemm_", "splitk_reduce")          # kernels that issue (or finish) fp32 MFMA products
+GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_")          # kernels that issue (or finish) fp32 MFMA products
 
 
 def _family(name):
@@ -593,8 +593,9 @@ def gemm_roofline(agent, reps=20):
             "traffic_unit": "bytes per library call of the GEMM family, split-K reduces included (2 x FETCH_SIZE + WRITE_SIZE, "
                             "PMC passes of tools/ppo_update_once.py); operands (A as addressed) and results of the %d "
                             "products are %.1fe6 bytes per call" % (n_products, operand_bytes / 1e6 / n),
-            "kernel": "gemm_dma_kernel / gemm_dma_pair_kernel (LDS-DMA ring) and gemm_fast_kernel (uint8 frames) + split-K "
-                      "reduces (fp32 MFMA 32x32x2): %d products in %d library calls per minibatch update" % (n_products, n),
+            "kernel": "gemm_dma_kernel / gemm_dma_pair_kernel (LDS-DMA ring), gemm_fast_kernel (uint8 frames), "
+                      "conv23_forward_kernel (conv2 -> conv3 per half image, conv2's output in LDS) + split-K reduces "
+                      "(fp32 MFMA 32x32x2): %d products in %d library calls per minibatch update" % (n_products, n),
             "limiter": "measured (profiles/r04_slab_step_ablation.txt): the slab loops of these launches are bound by operand "
                        "delivery, ~30 GB/s of line fills per CU from beyond the XCD's L2 (every kernel of the update starts "
                        "cold), with the MFMA chain hidden under it; the MFMA peak stays the denominator of frac",
@@ -741,6 +742,7 @@ def main():
     ap.add_argument("--rider-launches", type=int, default=None,
                     help="A/B: pair launches the rider's range is divided over (AdamState.RIDER_LAUNCHES)")
     ap.add_argument("--conv23-depth", type=int, default=None, help="A/B: weight slabs in rlx_conv23_forward's ring")
+    ap.add_argument("--conv23-step", type=int, default=2, help="A/B: slabs per synchronisation step of rlx_conv23_forward")
     ap.add_argument("--fuse-conv", type=int, default=None, choices=[0, 1],
                     help="A/B: conv2 -> conv3 forward as one launch (nn.graph.FUSE_CONV_PAIR; 1 = the default)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
@@ -781,7 +783,7 @@ def main():
         ClippedPPOAgent.DATASET_CHUNK = args.ppo_chunk
     if args.conv23_depth is not None:
         from coach_amd import _rlx
-        _rlx.lib().conv23_depth(args.conv23_depth)
+        _rlx.lib().conv23_depth(args.conv23_depth, args.conv23_step)
     if args.fuse_conv is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_PAIR = bool(args.fuse_conv)

@@ -34,6 +34,7 @@
 // Bound: MFMA issue of a CU (conv2: 8 wave-jobs of 128 MFMAs on 4 SIMDs = 6.8 us; conv3: 4 wave-jobs of 144 MFMAs =
 // 3.8 us) with the weight stream (275 KB per workgroup) underneath.
 #include "rlx_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -65,6 +66,7 @@ struct ConvPairArgs {
     float *y2; long long y2_ts;                      // [T][B * 81][64]
     float *y3; long long y3_ts;                      // [T][B * 49][64]
     int B, T, act;
+    unsigned long long *stamps;                      // diagnostics (rlx_conv23_debug_stamps): [workgroup][8] 10 ns ticks, or null
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -82,8 +84,10 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
-template <int kDepth>
+// kDepth: weight slabs in the ring; S: slabs per sync point (one wait + barrier + S requests per S slabs; kDepth >= 2 S)
+template <int kDepth, int S>
 __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvPairArgs a) {
+    static_assert(kDepth >= 2 * S && kSlabs2 % S == 0 && kSlabs3 % S == 0, "ring depth / step");
     __shared__ __attribute__((aligned(1024))) float smem[smem_floats(kDepth)];     // 105-154 KB static (gfx950: up to 160 KB)
     float *const ring = smem;                                  // (first: the DMA destinations stay 1 KB aligned)
     float *const patches = ring + kDepth * kSlabFloats;
@@ -101,6 +105,8 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
     const int own_lo = half ? 4 : 0, own_hi = half ? 9 : 4;
     const int np2 = n2 * O2, np3 = n3 * O3;                   // output positions of this half (45 / 54, 21 / 28)
 
+    unsigned long long *const stamp = a.stamps && tid == 0 ? a.stamps + 8 * (size_t)blockIdx.x : nullptr;
+    if (stamp) stamp[0] = wall_clock64();
     const float *const w2 = a.w2 + (size_t)t * a.w2_ts, *const w3 = a.w3 + (size_t)t * a.w3_ts;
     // weight slab g (0 .. 33: conv2's 16, then conv3's 18) -> ring buffer g & 1: lane tid moves 4 consecutive output
     // channels of k-row tid / 16
@@ -120,13 +126,33 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
     };
     // landed(g) for this lane -> its LDS reads of slab g - 1 are complete -> every wave: slab g may be read, the buffer
     // of slab g - 1 refilled
-    auto step_sync = [&]() {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDepth - 2) : "memory");
+    // sync point of slab k (one per slab, in slab order): wait for it, let every wave finish its LDS reads of slab k - 1,
+    // refill that buffer with slab k + kDepth - 1.  Between two sync points exactly kDepth - 1 requests are outstanding.
+    // (S slabs per sync point: before it kDepth - S requests are outstanding, S of them must have landed, S are issued)
+    int next_issue = kDepth - S;
+    auto sync_point = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDepth - 2 * S) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < S; ++j) issue(next_issue++);
+    };
+    // a workgroup barrier that publishes LDS writes WITHOUT draining the weight requests in flight (__syncthreads() waits
+    // for vmcnt(0) too)
+    auto lds_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
     };
 #pragma unroll
-    for (int d = 0; d < kDepth - 1; ++d) issue(d);
+    for (int d = 0; d < kDepth - S; ++d) issue(d);
+
+    // both epilogues' biases, requested now (a cold load in front of a tanh chain otherwise): conv2's epilogue is shared
+    // by the wave pair (w & 3, (w & 3) + 4) that owns a tile — columns of tile w & 1; conv3's by all 8 waves — tile tid >> 8
+    const float4 bias2 = *reinterpret_cast<const float4 *>(a.b2 + (size_t)t * a.b2_ts + (w & 1) * 32 + (lane & 7) * 4);
+    const float4 bias3 = *reinterpret_cast<const float4 *>(a.b3 + (size_t)t * a.b3_ts + (tid >> 8) * 32 + (tid & 7) * 4);
+    float4 y2v[2];                                             // this lane's share of the conv2 activations it owns
+    long long y2off[2] = {-1, -1};                             // (stored at the very end: a store in front of the next
+                                                               // slab wait would make that wait wait for its acknowledgement)
 
     // ---- conv1 activations of rows [r1, r1 + n1) -> in1[position][P1]
     {
@@ -149,13 +175,14 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int g = 0; g < kSlabs2; ++g) {
-            step_sync();                                           // (g = 0: also publishes in1)
-            issue(g + kDepth - 1);                                 // (from g = 17 - kDepth on: conv3's first slabs)
+        // The slab step is software-pipelined through registers (as gemm.hip's ring loop): while the MFMA chain of slab g
+        // runs, the sync point of slab g + 1 and the LDS reads of its operands happen in the MIDDLE of the chain — with the
+        // barrier in front of the reads and the MFMAs behind them, the two waves of a SIMD did everything in lockstep
+        // (23 us per launch against 11.7 us of MFMA issue).  The order of the sum is unchanged.
+        auto load_ops = [&](const int g, float (&av)[2][4], float (&bv)[2][4]) {
             const int ky = g >> 2, kx = g & 3;
             const float *as = arow + (ky * W1 + kx) * P1;
             const float *bs = ring + (g % kDepth) * kSlabFloats;
-            float av[2][4], bv[2][4];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int q = wk * 2 + qq;
@@ -164,17 +191,46 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bv[qq][i] = bs[(8 * q + 4 * hi + i) * C2 + b_col];
             }
+        };
+        // one STEP = S slabs: its 8 S MFMAs in slab order, the sync point + operand reads of the next step in their middle
+        float ra[2][S][2][4], rb[2][S][2][4];
+        auto load_step = [&](const int p, float (&av)[S][2][4], float (&bv)[S][2][4]) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s >> 2][s & 3], bv[s >> 2][s & 3], acc, 0, 0, 0);
+            for (int j = 0; j < S; ++j) load_ops(p * S + j, av[j], bv[j]);
+        };
+        auto mfma_half = [&](const float (&av)[S][2][4], const float (&bv)[S][2][4], const int half_) {
+#pragma unroll
+            for (int m = half_ * 4 * S; m < (half_ + 1) * 4 * S; ++m)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m >> 3][(m >> 2) & 1][m & 3], bv[m >> 3][(m >> 2) & 1][m & 3],
+                                                           acc, 0, 0, 0);
+        };
+        auto do_step = [&](auto cur, const int p, const bool has_next) {
+            constexpr int c = decltype(cur)::value;
+            mfma_half(ra[c], rb[c], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                sync_point();
+                load_step(p + 1, ra[1 - c], rb[1 - c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(ra[c], rb[c], 1);
+        };
+        constexpr int kSteps2 = kSlabs2 / S;
+        sync_point();                                              // step 0 (also publishes in1)
+        if (stamp) stamp[1] = wall_clock64();
+        load_step(0, ra[0], rb[0]);
+        for (int p = 0; p < kSteps2; p += 2) {
+            do_step(std::integral_constant<int, 0>(), p, p + 1 < kSteps2);
+            if (p + 1 < kSteps2) do_step(std::integral_constant<int, 1>(), p + 1, p + 2 < kSteps2);
         }
+        if (stamp) stamp[2] = wall_clock64();
         // partial tile of wave group 1 -> its patch; wave group 0 adds it (group 0 + group 1, gemm.hip fast_epilogue)
         float *const patch = patches + w * kPatchFloats;
         if (wk == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
         }
-        __syncthreads();
+        lds_barrier();
         if (wk == 0) {
             const float *src = patches + (w + 4) * kPatchFloats;
 #pragma unroll
@@ -183,25 +239,28 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
         }
-        __syncthreads();
-        if (wk == 0) {
-            const float4 bias = *reinterpret_cast<const float4 *>(a.b2 + (size_t)t * a.b2_ts + wn * 32 + (lane & 7) * 4);
-            float *const y2 = a.y2 + (size_t)t * a.y2_ts + (size_t)img * (O2 * O2) * C2;
+        lds_barrier();
+        {
+            // bias + activation by BOTH waves of the pair that computed the tile (rows it = 0, 1 by wave group 0, it = 2, 3
+            // by wave group 1): half the tanh chain per wave
+            const float *const tile = patches + (w & 3) * kPatchFloats;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = it * 64 + lane;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int idx = (2 * wk + h2) * 64 + lane;
                 const int rl = idx >> 3, c4 = (idx & 7) * 4;
                 const int pos = wm * 32 + rl;
                 if (pos >= np2) continue;
-                const float *sp = patch + rl * 33 + c4;
+                const float *sp = tile + rl * 33 + c4;
                 float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
-                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                v.x += bias2.x; v.y += bias2.y; v.z += bias2.z; v.w += bias2.w;
                 v.x = apply_act(v.x, a.act); v.y = apply_act(v.y, a.act);
                 v.z = apply_act(v.z, a.act); v.w = apply_act(v.w, a.act);
                 *reinterpret_cast<float4 *>(out2 + pos * P2 + wn * 32 + c4) = v;
                 const int row = r2 + pos / O2;                    // conv2 output row of this position
-                if (row >= own_lo && row < own_hi)
-                    *reinterpret_cast<float4 *>(y2 + (size_t)(r2 * O2 + pos) * C2 + wn * 32 + c4) = v;
+                if (row >= own_lo && row < own_hi) {
+                    y2v[h2] = v;
+                    y2off[h2] = (long long)(r2 * O2 + pos) * C2 + wn * 32 + c4;
+                }
             }
         }
     }
@@ -218,36 +277,60 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int g = kSlabs2; g < kSlabs2 + kSlabs3; ++g) {
-            step_sync();                                           // (g = 16: also publishes out2)
-            issue(g + kDepth - 1);
-            if (active) {
-                const int s3 = g - kSlabs2, tap = s3 >> 1;
-                const int ky = tap / K3, kx = tap - ky * K3;
-                const float *as = arow + (ky * O2 + kx) * P2 + (s3 & 1) * 32;
-                const float *bs = ring + (g % kDepth) * kSlabFloats;
-                float av[2][4], bv[2][4];
+        auto load_ops = [&](const int g, float (&av)[2][4], float (&bv)[2][4]) {
+            if (!active) return;
+            const int s3 = g - kSlabs2, tap = s3 >> 1;
+            const int ky = tap / K3, kx = tap - ky * K3;
+            const float *as = arow + (ky * O2 + kx) * P2 + (s3 & 1) * 32;
+            const float *bs = ring + (g % kDepth) * kSlabFloats;
 #pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const int q = wk * 2 + qq;
-                    const float4 v = *reinterpret_cast<const float4 *>(as + 8 * q);
-                    av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = wk * 2 + qq;
+                const float4 v = *reinterpret_cast<const float4 *>(as + 8 * q);
+                av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) bv[qq][i] = bs[(8 * q + 4 * hi + i) * C3 + b_col];
-                }
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s >> 2][s & 3], bv[s >> 2][s & 3], acc, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) bv[qq][i] = bs[(8 * q + 4 * hi + i) * C3 + b_col];
             }
+        };
+        float ra[2][S][2][4], rb[2][S][2][4];
+        auto load_step = [&](const int p, float (&av)[S][2][4], float (&bv)[S][2][4]) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) load_ops(kSlabs2 + p * S + j, av[j], bv[j]);
+        };
+        auto mfma_half = [&](const float (&av)[S][2][4], const float (&bv)[S][2][4], const int half_) {
+            if (!active) return;
+#pragma unroll
+            for (int m = half_ * 4 * S; m < (half_ + 1) * 4 * S; ++m)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m >> 3][(m >> 2) & 1][m & 3], bv[m >> 3][(m >> 2) & 1][m & 3],
+                                                           acc, 0, 0, 0);
+        };
+        auto do_step = [&](auto cur, const int p, const bool has_next) {
+            constexpr int c = decltype(cur)::value;
+            mfma_half(ra[c], rb[c], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                sync_point();
+                load_step(p + 1, ra[1 - c], rb[1 - c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(ra[c], rb[c], 1);
+        };
+        constexpr int kSteps3 = kSlabs3 / S;
+        sync_point();                                              // conv3's step 0 (its barrier also publishes out2)
+        if (stamp) stamp[3] = wall_clock64();
+        load_step(0, ra[0], rb[0]);
+        for (int p = 0; p < kSteps3; p += 2) {
+            do_step(std::integral_constant<int, 0>(), p, p + 1 < kSteps3);
+            if (p + 1 < kSteps3) do_step(std::integral_constant<int, 1>(), p + 1, p + 2 < kSteps3);
         }
+        if (stamp) stamp[4] = wall_clock64();
         float *const patch = patches + w * kPatchFloats;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the requests of non-existent slabs still target the ring
-        __syncthreads();                                           // conv2's patches are no longer read
+        lds_barrier();                                             // conv2's patches are no longer read
         if (active && wk == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
         }
-        __syncthreads();
+        lds_barrier();
         if (active && wk == 0) {
             const float *src = patches + (w + 2) * kPatchFloats;
 #pragma unroll
@@ -255,27 +338,34 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
         }
-        __syncthreads();
-        if (active && wk == 0) {
-            const float4 bias = *reinterpret_cast<const float4 *>(a.b3 + (size_t)t * a.b3_ts + wn * 32 + (lane & 7) * 4);
-            float *const y3 = a.y3 + (size_t)t * a.y3_ts + ((size_t)img * (O3 * O3) + (size_t)r3 * O3) * C3;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = it * 64 + lane;
-                const int rl = idx >> 3, c4 = (idx & 7) * 4;
-                if (rl >= np3) continue;
-                const float *sp = patch + rl * 33 + c4;
+        lds_barrier();
+        {
+            // the two 32 x 32 tiles (patches 0 and 1) are 512 float4: one per lane of the workgroup
+            const int tile = tid >> 8, idx = tid & 255;
+            const int rl = idx >> 3, c4 = (idx & 7) * 4;
+            if (rl < np3) {
+                const float *sp = patches + tile * kPatchFloats + rl * 33 + c4;
                 float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
-                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                v.x += bias3.x; v.y += bias3.y; v.z += bias3.z; v.w += bias3.w;
                 v.x = apply_act(v.x, a.act); v.y = apply_act(v.y, a.act);
                 v.z = apply_act(v.z, a.act); v.w = apply_act(v.w, a.act);
-                *reinterpret_cast<float4 *>(y3 + (size_t)rl * C3 + wn * 32 + c4) = v;
+                float *const y3 = a.y3 + (size_t)t * a.y3_ts + ((size_t)img * (O3 * O3) + (size_t)r3 * O3) * C3;
+                *reinterpret_cast<float4 *>(y3 + (size_t)rl * C3 + tile * 32 + c4) = v;
             }
         }
     }
+    {
+        float *const y2 = a.y2 + (size_t)t * a.y2_ts + (size_t)img * (O2 * O2) * C2;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+            if (y2off[h2] >= 0) *reinterpret_cast<float4 *>(y2 + y2off[h2]) = y2v[h2];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the requests of non-existent slabs still target the ring)
+    if (stamp) { __syncthreads(); stamp[5] = wall_clock64(); }
 }
 
-int g_depth = 4;
+int g_depth = 4, g_step = 2;       // measured on the C2 update: profiles/r05_ab_conv23.txt
+unsigned long long *g_stamps = nullptr;
 
 }  // namespace
 
@@ -298,21 +388,34 @@ int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *
                       y2_tower_stride | y3_tower_stride) & 3) == 0,
                 "rlx_conv23_forward: operands must be 16-byte aligned");
     ConvPairArgs a{x1, x1_tower_stride, w2, w2_tower_stride, b2, b2_tower_stride, w3, w3_tower_stride, b3, b3_tower_stride,
-                   y2, y2_tower_stride, y3, y3_tower_stride, batch, towers, activation};
+                   y2, y2_tower_stride, y3, y3_tower_stride, batch, towers, activation, g_stamps};
     const unsigned grid = 2u * batch * towers;
     hipStream_t s = rlx::as_stream(stream);
-    if (g_depth == 2) RLX_LAUNCH((conv23_forward_kernel<2>), grid, kThreads, 0, s, a);
-    else if (g_depth == 3) RLX_LAUNCH((conv23_forward_kernel<3>), grid, kThreads, 0, s, a);
-    else if (g_depth == 6) RLX_LAUNCH((conv23_forward_kernel<6>), grid, kThreads, 0, s, a);
-    else if (g_depth == 8) RLX_LAUNCH((conv23_forward_kernel<8>), grid, kThreads, 0, s, a);
-    else RLX_LAUNCH((conv23_forward_kernel<4>), grid, kThreads, 0, s, a);
+#define RLX_C23(D, SS) RLX_LAUNCH((conv23_forward_kernel<D, SS>), grid, kThreads, 0, s, a)
+    if (g_step == 2) {
+        if (g_depth <= 4) RLX_C23(4, 2);
+        else if (g_depth == 6) RLX_C23(6, 2);
+        else RLX_C23(8, 2);
+    } else if (g_depth == 2) RLX_C23(2, 1);
+    else if (g_depth == 3) RLX_C23(3, 1);
+    else if (g_depth == 6) RLX_C23(6, 1);
+    else if (g_depth == 8) RLX_C23(8, 1);
+    else RLX_C23(4, 1);
+#undef RLX_C23
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
 
-int rlx_conv23_depth(int depth) {
+int rlx_conv23_debug_stamps(void *buffer) {
+    g_stamps = static_cast<unsigned long long *>(buffer);
+    return RLX_OK;
+}
+
+int rlx_conv23_depth(int depth, int slabs_per_step) {
     RLX_REQUIRE(depth == 2 || depth == 3 || depth == 4 || depth == 6 || depth == 8, "rlx_conv23_depth: 2, 3, 4, 6 or 8");
+    RLX_REQUIRE(slabs_per_step == 1 || (slabs_per_step == 2 && depth >= 4), "rlx_conv23_depth: 1 slab per step, or 2 with depth >= 4");
     g_depth = depth;
+    g_step = slabs_per_step;
     return RLX_OK;
 }
 

@@ -77,8 +77,13 @@ int rlx_profile_read(int index, const char **name_host, float *ms_host);
  * on 32 x 64 tiles with two wave groups per K slab (coach_amd/csrc/conv_fused.hip).  rlx_conv23_forward_supported: 1 for
  * the geometry the kernel is compiled for. */
 int rlx_conv23_forward_supported(int H, int W, int C, int k2, int s2, int c2, int k3, int s3, int c3);
-/* weight slabs in rlx_conv23_forward's LDS ring (2, 3, 4 = default, 6, 8): process-wide, for same-process A/Bs */
-int rlx_conv23_depth(int depth);
+/* weight slabs in rlx_conv23_forward's LDS ring (2, 3, 4, 6, 8) and slabs per synchronisation step (1, or 2 with depth
+ * >= 4): process-wide, for same-process A/Bs */
+int rlx_conv23_depth(int depth, int slabs_per_step);
+/* diagnostics: while buffer != NULL every workgroup of rlx_conv23_forward records 10 ns ticks at [8 w + 0 .. 5]: entry,
+ * conv2's first slab and the conv1 rows staged, conv2's slab loop done, conv3's first slab staged (conv2's epilogue done),
+ * conv3's slab loop done, exit.  buffer: 16 * batch * towers 64-bit words. */
+int rlx_conv23_debug_stamps(void *buffer);
 int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *w2, long long w2_tower_stride,
                        const float *b2, long long b2_tower_stride, const float *w3, long long w3_tower_stride,
                        const float *b3, long long b3_tower_stride, float *y2, long long y2_tower_stride, float *y3,

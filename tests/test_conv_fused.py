@@ -10,6 +10,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+DEFAULT_RING = (4, 2)        # rlx_conv23_depth's defaults (csrc/conv_fused.hip g_depth, g_step)
+
 
 def _torso(dev, act, seed):
     import torch
@@ -26,13 +28,14 @@ def _torso(dev, act, seed):
 
 
 @pytest.mark.parametrize("act", ["tanh", "relu"])
-@pytest.mark.parametrize("B,depth", [(64, 4), (72, 4), (64, 2), (64, 3), (64, 6), (64, 8)])
+@pytest.mark.parametrize("B,depth", [(64, (4, 1)), (72, (4, 1)), (64, (2, 1)), (64, (3, 1)), (64, (6, 1)), (64, (8, 1)),
+                                     (64, (4, 2)), (72, (6, 2)), (64, (8, 2))])
 def test_fused_pair_equals_the_two_tiled_launches_bit_for_bit(rlx, dev, act, B, depth, request):
     import torch
     from coach_amd import _rlx
     from coach_amd.nn import graph as G
-    rlx.conv23_depth(depth)
-    request.addfinalizer(lambda: rlx.conv23_depth(4))
+    rlx.conv23_depth(*depth)
+    request.addfinalizer(lambda: rlx.conv23_depth(*DEFAULT_RING))
     assert G._kw2_tiling(B * 81, 64, 2) and G._kw2_tiling(B * 49, 64, 2)
     params, torso = _torso(dev, act, 1)
     obs = torch.from_numpy(np.random.RandomState(2).randint(0, 256, size=(B, 84, 84, 4)).astype(np.uint8)).to(dev)
