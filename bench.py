@@ -741,6 +741,8 @@ def main():
     ap.add_argument("--rider-blocks", type=int, default=None, help="A/B: workgroups of the Adam rider (AdamState.RIDER_BLOCKS)")
     ap.add_argument("--rider-launches", type=int, default=None,
                     help="A/B: pair launches the rider's range is divided over (AdamState.RIDER_LAUNCHES)")
+    ap.add_argument("--multi-dw", type=int, default=None, choices=[0, 1],
+                    help="A/B: the convolution layers' weight gradients as one launch behind the dX chain (nn.graph.MULTI_DW)")
     ap.add_argument("--conv23-depth", type=int, default=None, help="A/B: weight slabs in rlx_conv23_forward's ring")
     ap.add_argument("--conv23-step", type=int, default=2, help="A/B: slabs per synchronisation step of rlx_conv23_forward")
     ap.add_argument("--fuse-conv", type=int, default=None, choices=[0, 1],
@@ -781,6 +783,9 @@ def main():
     if args.ppo_chunk is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
         ClippedPPOAgent.DATASET_CHUNK = args.ppo_chunk
+    if args.multi_dw is not None:
+        from coach_amd.nn import graph as _G2
+        _G2.MULTI_DW = bool(args.multi_dw)
     if args.conv23_depth is not None:
         from coach_amd import _rlx
         _rlx.lib().conv23_depth(args.conv23_depth, args.conv23_step)

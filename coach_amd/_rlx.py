@@ -411,6 +411,22 @@ def gemm_pair_or_single(desc, stream=None):
     run()
 
 
+def gemm_multi(descs, jobs, stream=None):
+    """descriptors built with gemm(..., launch=False) of up to three weight-gradient products -> ONE launch
+    (rlx_gemm_multi_defer); jobs: their SplitkJob objects (filled where a split-K reduction stays outstanding)."""
+    s = current_stream() if stream is None else stream
+    n = len(descs)
+    darr = (GemmDesc * n)(*descs)
+    jarr = (SplitkJob * n)()
+
+    def run():
+        lib().gemm_multi_defer(darr, n, jarr, s)
+        for i, j in enumerate(jobs):
+            ctypes.memmove(ctypes.addressof(j), ctypes.addressof(jarr[i]), ctypes.sizeof(SplitkJob))
+    _record(tuple(descs), run)                     # one entry: the products go out as one launch
+    run()
+
+
 def gemm_pair(weight_grad, input_grad, stream=None, defer=None):
     """two descriptors built with gemm(..., launch=False): a layer's dW and dX products as one launch.
     defer: a SplitkJob for the weight gradient's split-K reduction (see gemm)."""

@@ -1296,6 +1296,36 @@ __global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_pair_kernel(co
 }
 
 
+// Up to three WEIGHT-GRADIENT products of a backward pass as one launch (rlx_gemm_multi_defer): the convolution layers'
+// dW = cols^T dz are independent of each other once the input-gradient chain has produced every layer's dz, each is a
+// split-K product of a few hundred workgroups that starts cold, and issued back to back (inside their layers' dW + dX
+// pairs) they ran one after the other.  Workgroups [start[i], start[i + 1]) belong to product i; kind 0: fp32 activations
+// through im2col tables on the LDS-DMA ring, kind 1: uint8 frames through the register-staged loop.  Each product keeps
+// the tiling and the K split rlx_gemm would give it alone: the sums are bit-identical to the per-layer launches.
+struct GemmMultiDev {
+    GemmDev g[3];
+    int gx[3], gy[3];
+    int start[4];
+    int kind[3];
+    int n;
+};
+__global__ void __launch_bounds__(kThreads, 3) gemm_multi_dw_kernel(const GemmMultiDev p) {
+    constexpr int kFloats = DmaTile<64, 64>::kSmemFloats > FastTile<64, 64, 1, 1>::kSmemFloats
+                                ? DmaTile<64, 64>::kSmemFloats : FastTile<64, 64, 1, 1>::kSmemFloats;
+    __shared__ __attribute__((aligned(1024))) float smem[kFloats];
+    __shared__ int tab_s[kTabChunk];
+    __shared__ float lut[256];
+    int flat = blockIdx.x;
+    const int which = (p.n > 2 && flat >= p.start[2]) ? 2 : (flat >= p.start[1] ? 1 : 0);
+    flat = xcd_tile_position(p.g[0].xcd_mode, flat - p.start[which], p.start[which + 1] - p.start[which]);
+    const int gx = p.gx[which], gy = p.gy[which];
+    const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
+    if (p.kind[which] == 1)
+        gemm_fast_body<64, 64, 1, 1, 1, false, true, false, true>(p.g[which], bx, by, bz, gx, gy, smem, lut, tab_s);
+    else
+        gemm_dma_body<64, 64, 1, false, false, true>(p.g[which], bx, by, bz, gx, gy, smem, tab_s);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Thin GEMM: small M*N with a short reduction (the MLP layers of DQN / TD3 / SAC at B = 32..256, the
 // FC input gradient of the conv nets).  The tiled kernels above cover such a problem with a handful of
@@ -2169,6 +2199,7 @@ struct GemmPlan {
     dim3 grid;
     bool a_vec_red, u8, b_vec_red, a_tab;
     int splits, M, N, batch;
+    bool allow_fold = false;    // in: towers folded into N may count as tiled_fast (the caller's kernel runs the fold epilogue)
 };
 
 int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, hipStream_t s) {
@@ -2415,7 +2446,7 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
         }
     }
     if (plan) {
-        if (fast && ((BM == 64 && BN == 64) || KW > 1) && !g.fold) {
+        if (fast && ((BM == 64 && BN == 64) || KW > 1) && (!g.fold || plan->allow_fold)) {
             plan->tiled_fast = KW == 1;
             plan->kw = KW;
             plan->g = g;
@@ -2583,6 +2614,55 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
         }
     }
     if (px.splits > 1) return launch_splitk_reduce(px.g, px.M, px.N, px.batch, px.splits, s);
+    return RLX_OK;
+}
+
+int rlx_gemm_multi_defer(const rlx_gemm_desc *descs_host, int n, rlx_splitk_job *jobs_host, void *stream) {
+    RLX_REQUIRE(descs_host && jobs_host && n >= 1 && n <= 3, "rlx_gemm_multi_defer: 1 .. 3 descriptors and their jobs");
+    GemmPlan pl[3];
+    bool multi = n >= 2 && g_dma != 0;
+    for (int i = 0; i < n; ++i) {
+        jobs_host[i].splits = 0;
+        pl[i].allow_fold = true;
+        const int rc = gemm_impl(&descs_host[i], stream, &pl[i]);
+        if (rc != RLX_OK) return rc;
+        // what the one-launch form takes: 64 x 64 tiles, A^T gathered through im2col tables (vector along the outer
+        // index), B along N; fp32 on the ring (its table chunk bound) or uint8 on the register-staged loop
+        multi = multi && pl[i].tiled_fast && !pl[i].a_vec_red && !pl[i].b_vec_red && pl[i].a_tab &&
+                (pl[i].u8 ? pl[i].g.kchunk <= kTabChunk : pl[i].g.kchunk <= kDmaTabChunk);
+    }
+    for (int i = 0; multi && i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (pl[i].splits > 1 && pl[j].splits > 1 && pl[i].g.ws == pl[j].g.ws) multi = false;   // partials would collide
+    if (!multi) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = gemm_impl(&descs_host[i], stream, nullptr, &jobs_host[i]);
+            if (rc != RLX_OK) return rc;
+        }
+        return RLX_OK;
+    }
+    GemmMultiDev p;
+    p.n = n;
+    p.start[0] = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int k = i < n ? i : n - 1;
+        p.g[i] = pl[k].g;
+        p.gx[i] = pl[k].grid.x; p.gy[i] = pl[k].grid.y;
+        p.kind[i] = pl[k].u8 ? 1 : 0;
+        p.start[i + 1] = p.start[i] + (i < n ? (int)(pl[k].grid.x * pl[k].grid.y * pl[k].grid.z) : 0);
+    }
+    hipStream_t s = rlx::as_stream(stream);
+    RLX_LAUNCH((gemm_multi_dw_kernel), (unsigned)p.start[n], kThreads, 0, s, p);
+    RLX_LAUNCH_CHECK();
+    for (int i = 0; i < n; ++i) {
+        if (pl[i].splits <= 1) continue;
+        if (deferrable(pl[i].g, pl[i].M, pl[i].N)) {
+            fill_job(&jobs_host[i], pl[i].g, pl[i].M, pl[i].N, pl[i].batch, pl[i].splits);
+        } else {
+            const int rc = launch_splitk_reduce(pl[i].g, pl[i].M, pl[i].N, pl[i].batch, pl[i].splits, s);
+            if (rc != RLX_OK) return rc;
+        }
+    }
     return RLX_OK;
 }
 

@@ -145,6 +145,11 @@ def _kw2_tiling(M, N, batch):
     return t64 < KW_BELOW_TILES and t32 >= KW_MIN_TILES
 
 
+# The convolution layers' weight-gradient products of a backward pass as ONE launch behind the input-gradient chain
+# (rlx_gemm_multi_defer) instead of one per layer inside its dW + dX pair.  Same tilings and K splits: bit-identical sums.
+# OFF: measured +8 us per C2 update (profiles/r05_ab_multi_dw.txt) — the one launch takes as long as the three products one
+# after the other; co-resident independent products do not overlap on this chip at these sizes.
+MULTI_DW = False
 # most K splits a deferred product may get room for (rlx_gemm_split_cap's largest useful setting; its default is 64)
 SPLIT_CAP_BOUND = 128
 
@@ -213,10 +218,20 @@ class Context:
             return None, self.ws.splitk
         return _rlx.SplitkJob(), self.arena[self._arena_off:self._arena_off + min(bound, room)]
 
-    def commit_deferred(self, job):
+    def commit_deferred(self, job, reserved=False):
+        """reserved: the job's slice was set aside by reserve_deferred_workspace (the arena offset already moved)."""
         if job is not None and job.splits > 1:
             self.deferred.append(job)
-            self._arena_off += (job.workspace_floats() + 3) // 4 * 4
+            if not reserved:
+                self._arena_off += (job.workspace_floats() + 3) // 4 * 4
+
+    def reserve_deferred_workspace(self, M, N, batch):
+        """deferred_workspace for a product that is launched LATER, together with others (rlx_gemm_multi_defer): its
+        slice — the most its split-K partials can take — is set aside now, so that the next product's slice lies behind it."""
+        job, ws = self.deferred_workspace(M, N, batch)
+        if job is not None:
+            self._arena_off += (ws.numel() + 3) // 4 * 4
+        return job, ws
 
     def flush_deferred(self):
         jobs, self.deferred = self.deferred, None
@@ -597,12 +612,14 @@ class Conv2d(Layer):
         executed = s * s * (-(-self.H // s)) * (-(-self.W // s)) * (self.KH // s) * (self.KW // s)
         return DIRECT_CONV_INPUT_GRAD == "always" or executed <= 1.3 * self.OH * self.OW * self.KH * self.KW
 
-    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False):
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False, dw_later=None):
+        """dw_later (a list): the weight-gradient product is not launched — its (descriptor, split-K job) is appended for
+        Sequential.backward to issue together with the other convolution layers' (rlx_gemm_multi_defer)."""
         t0, T = self._range(t0, nt)
         B, p = x.rows, self.params
         overlap = overlap and ctx.overlap
         direct = need_dx and self.direct_input_grad()
-        pairing = need_dx and need_dw and not overlap and PAIR_GRADIENT_GEMMS and not direct
+        pairing = need_dx and need_dw and not overlap and PAIR_GRADIENT_GEMMS and not direct and dw_later is None
         M = B * self.OH * self.OW
         rb, ko = self._tables(ctx, B)
         dz = y.grad
@@ -612,8 +629,8 @@ class Conv2d(Layer):
         # dW[K,Co] = cols^T dz : A(k, m) gathered with outer table = koff, reduction table = rowbase
         if need_dw:
             fold = x.towers == 0 and T > 1 and self.Co % 4 == 0 and self.C % 4 == 0 and FOLD_SHARED_INPUT
-            job, dws = ctx.deferred_workspace(self.K, T * self.Co if fold else self.Co, 1 if fold else T) \
-                if not overlap else (None, None)
+            take = ctx.reserve_deferred_workspace if dw_later is not None else ctx.deferred_workspace
+            job, dws = take(self.K, T * self.Co if fold else self.Co, 1 if fold else T) if not overlap else (None, None)
 
             def dw(ws, launch=True):
                 ws = dws if job is not None else ws
@@ -631,7 +648,9 @@ class Conv2d(Layer):
                                  c_batch_stride=p.stride(self.kname), workspace=ws,
                                  colsum_out=p.g(self.bname, t0), colsum_batch_stride=p.stride(self.bname),
                                  launch=launch, defer=dj)
-            if not pairing:
+            if dw_later is not None and job is not None:
+                dw_later.append((dw(None, launch=False), job))
+            elif not pairing:
                 dw(ctx.ws.splitk)
         if direct:
             assert x.towers == T
@@ -657,7 +676,7 @@ class Conv2d(Layer):
             ctx.lib.col2im(dcol, dx, x.data if lower else None, _rlx.ACT[lower], T * B, self.H, self.W,
                            self.C, self.KH, self.KW, self.S, ctx.stream)
             x.grad_is_dz = lower is not None
-        if need_dw:
+        if need_dw and not (dw_later is not None and job is not None):
             ctx.commit_deferred(job)
 
 
@@ -832,10 +851,21 @@ class Sequential:
         lo, hi = layers if layers is not None else (0, len(self.layers))
         mine = need_dw and ctx.begin_deferring()      # the layers' split-K reductions: one launch at the end
         try:
+            # MULTI_DW: the convolution layers' weight gradients wait until the input-gradient chain has passed all of
+            # them, then go out as ONE launch (up to three products) instead of one per layer inside its dW + dX pair
+            later = [] if (MULTI_DW and need_dw and ctx.deferred is not None and not ctx.overlap and
+                           sum(isinstance(self.layers[i], Conv2d) for i in range(lo, hi)) >= 2) else None
             for i in reversed(range(lo, hi)):
                 kw = {"overlap": True} if need_dw else {"need_dw": False}
+                if later is not None and isinstance(self.layers[i], Conv2d):
+                    kw["dw_later"] = later
                 self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),
                                         weights=weights, t0=t0, nt=nt, **kw)
+            while later:
+                group, later = later[:3], later[3:]
+                _rlx.gemm_multi([d for d, _ in group], [j for _, j in group])
+                for _, j in group:
+                    ctx.commit_deferred(j, reserved=True)
             ctx.join()                   # weight gradients issued on the side stream are complete
         finally:
             if mine:

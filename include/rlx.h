@@ -432,6 +432,12 @@ int rlx_gemm_defer(const rlx_gemm_desc *desc_host, rlx_splitk_job *job_host, voi
 int rlx_gemm_pair_defer(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc *input_grad,
                         rlx_splitk_job *weight_grad_job_host, void *stream);
 int rlx_splitk_reduce_jobs(const rlx_splitk_job *jobs_host, int n_jobs, void *stream);
+/* Up to three weight-gradient products (the convolution layers' dW = cols^T dz of one backward pass,
+ * architectures/tensorflow_components/architecture.py:187-220 tf.gradients) as ONE launch, each with the tiling and K split
+ * rlx_gemm would give it alone (bit-identical sums) and its split-K reduction deferred into jobs[i] as rlx_gemm_defer
+ * does (jobs[i].splits = 0: nothing to reduce).  Descriptors that do not qualify for the one-launch form (anything but
+ * 64 x 64 tiles of an im2col-gathered A^T) are launched one by one. */
+int rlx_gemm_multi_defer(const rlx_gemm_desc *descs, int n, rlx_splitk_job *jobs, void *stream);
 /* Diagnostics (tools/gemm_timeline.py): while a device buffer of `capacity_u64` 64-bit words is registered, every
  * tiled-kernel launch of rlx_gemm records, per workgroup, four wall-clock ticks (10 ns: entry, first slab staged,
  * main loop done, exit) in its own region of the buffer; rlx_gemm_debug_calls lists the regions as rows of
