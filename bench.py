@@ -741,6 +741,8 @@ def main():
     ap.add_argument("--rider-blocks", type=int, default=None, help="A/B: workgroups of the Adam rider (AdamState.RIDER_BLOCKS)")
     ap.add_argument("--rider-launches", type=int, default=None,
                     help="A/B: pair launches the rider's range is divided over (AdamState.RIDER_LAUNCHES)")
+    ap.add_argument("--big-tiles", type=int, default=None, choices=[0, 1],
+                    help="A/B: several accumulator tiles per wave for large products (rlx_gemm_big_tiles; 1 = default)")
     ap.add_argument("--multi-dw", type=int, default=None, choices=[0, 1],
                     help="A/B: the convolution layers' weight gradients as one launch behind the dX chain (nn.graph.MULTI_DW)")
     ap.add_argument("--conv23-depth", type=int, default=None, help="A/B: weight slabs in rlx_conv23_forward's ring")
@@ -783,6 +785,9 @@ def main():
     if args.ppo_chunk is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
         ClippedPPOAgent.DATASET_CHUNK = args.ppo_chunk
+    if args.big_tiles is not None:
+        from coach_amd import _rlx as _r
+        _r.lib().gemm_big_tiles(args.big_tiles)
     if args.multi_dw is not None:
         from coach_amd.nn import graph as _G2
         _G2.MULTI_DW = bool(args.multi_dw)

@@ -972,14 +972,18 @@ __device__ __forceinline__ void dma4(const unsigned char *gsrc, unsigned lds_dst
 // 8 rows of a bank class get 8 different slots: conflict-free ds_read_b32); outer-vector: [k][BM bytes], a lane requests 4
 // consecutive outer elements of one k — and the conversion byte / a_div (exact quotients from a 256-entry LDS table, as in
 // the register-staged kernel) happens when the MFMA operands are read.
-template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB, bool A_U8 = false>
+// TM x TN: 32 x 32 accumulator tiles per wave (1 x 1 everywhere in the update's shapes; 2 x 2 = a 64 x 64 wave tile for the
+// large products — half the LDS operand reads and half the slab bytes per MFMA; the order of every element's sum does not
+// depend on it).
+template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB, bool A_U8 = false, int TM = 1, int TN = 1>
 __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, const int by, const int bz,
                                               const int gdx, const int gdy, float *const smem, int *const tab_s,
                                               const float *const lut = nullptr) {
     static_assert(!A_U8 || A_TAB, "uint8 operands come through im2col tables");
+    static_assert(TM * TN == 1 || (KW == 1 && !A_U8), "multi-tile waves: fp32 operands, no in-workgroup K split");
     constexpr int D = DmaTile<BM, BN, A_U8>::kDepth;
-    constexpr int WN = BN / 32;
-    constexpr int WMN = (BM / 32) * WN;
+    constexpr int WN = BN / (32 * TN);
+    constexpr int WMN = (BM / (32 * TM)) * WN;
     static_assert(WMN * KW == 4, "a workgroup is 4 waves");
     static_assert(BK == 32, "slab images are 32 k deep");
     constexpr int A_SLAB = DmaTile<BM, BN, A_U8>::kASlabFloats, SLAB = DmaTile<BM, BN, A_U8>::kSlabFloats;
@@ -1055,9 +1059,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     pre.bv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int it = 0; it < 4; ++it) pre.av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool pre_ok = g.vec_epi && g.splits == 1;        // (split-K partials have no epilogue operands)
+    const bool pre_ok = TM * TN == 1 && g.vec_epi && g.splits == 1;        // (split-K partials have no epilogue operands)
     if (pre_ok) {
-        const int ecol = n0 + wn * 32 + (lane & 7) * 4;
+        const int ecol = n0 + wn * (32 * TN) + (lane & 7) * 4;
         const bool ecol_ok = wk == 0 && ecol < g.N;
         if (g.bias && ecol_ok)
             pre.bv = *reinterpret_cast<const float4 *>(
@@ -1067,7 +1071,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
             const float *aux = g.aux + (size_t)batch * g.aux_batch_stride;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int erow = m0 + wm * 32 + ((it * 64 + lane) >> 3);
+                const int erow = m0 + wm * (32 * TM) + ((it * 64 + lane) >> 3);
                 if (erow < g.M) pre.av[it] = *reinterpret_cast<const float4 *>(aux + (size_t)erow * g.aux_ld + ecol);
             }
         }
@@ -1137,24 +1141,35 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
         }
     };
 
-    f32x16 acc[1][1];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const bool do_colsum = g.colsum != nullptr && by == 0 && tid < BN;
     float csum = 0.f;
 
     // this wave group's MFMA steps of a slab: k-quads q = wk * QS .. + QS - 1, each 8 k (4 per half-wave).  The LDS
     // read addresses are lane constants (computed here) plus compile-time offsets (buffer, quad, step).
     constexpr int QS = 4 / KW;
-    const int a_row = wm * 32 + l31, b_col = wn * 32 + l31;
-    int a_rd[QS], b_rd[QS];                                 // float index of the lane's operand(s) of quad qq inside a slab image
+    int a_rd[TM][QS], b_rd[TN][QS];                         // float index of the lane's operand(s) of quad qq inside a slab image
 #pragma unroll
     for (int qq = 0; qq < QS; ++qq) {
         const int q = wk * QS + qq;
-        a_rd[qq] = A_U8 ? (A_VEC_RED ? a_row * 8 + ((2 * q + hi) ^ ((a_row >> 2) & 7))      // dword of the lane's 4 bytes
-                                     : (8 * q + 4 * hi) * BM + a_row)                         // byte of its first k
-                        : A_VEC_RED ? a_row * 32 + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BM + a_row;
-        b_rd[qq] = B_VEC_RED ? b_col * 32 + (((2 * q + hi) ^ ((b_col >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BN + b_col;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int a_row = (wm * TM + i) * 32 + l31;
+            a_rd[i][qq] = A_U8 ? (A_VEC_RED ? a_row * 8 + ((2 * q + hi) ^ ((a_row >> 2) & 7))      // dword of the lane's 4 bytes
+                                            : (8 * q + 4 * hi) * BM + a_row)                         // byte of its first k
+                               : A_VEC_RED ? a_row * 32 + (((2 * q + hi) ^ ((a_row >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BM + a_row;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int b_col = (wn * TN + j) * 32 + l31;
+            b_rd[j][qq] = B_VEC_RED ? b_col * 32 + (((2 * q + hi) ^ ((b_col >> 1) & 7)) << 2) : (8 * q + 4 * hi) * BN + b_col;
+        }
     }
     // The slab step is software-pipelined through REGISTERS: while the MFMA chain of slab s runs, the operands of slab
     // s + 1 are already being read from LDS into the other register set, behind the wait / barrier / DMA issue that made
@@ -1162,30 +1177,37 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     // to the independent instructions behind it).  With one wave per SIMD (the forward products: 196-400 workgroups on
     // 256 CUs) nothing else can fill the matrix pipe while a wave waits, reads and synchronises: the step took ~1 275
     // cycles for 512 cycles of MFMAs at KW = 2, whatever the ring depth (profiles/r04_timeline_ring_depth.txt).
-    auto load_ops = [&](const int buf, float (&av)[QS][4], float (&bv)[QS][4]) {   // buf: compile-time constant at every call site
+    auto load_ops = [&](const int buf, float (&av)[TM][QS][4], float (&bv)[TN][QS][4]) {   // buf: compile-time constant at every call site
         const float *as = smem + buf * SLAB, *bs = as + A_SLAB;
 #pragma unroll
         for (int qq = 0; qq < QS; ++qq) {
-            if (A_U8 && A_VEC_RED) {
-                const uint32_t w = reinterpret_cast<const uint32_t *>(as)[a_rd[qq]];
-                av[qq][0] = lut[w & 0xffu]; av[qq][1] = lut[(w >> 8) & 0xffu];
-                av[qq][2] = lut[(w >> 16) & 0xffu]; av[qq][3] = lut[w >> 24];
-            } else if (A_U8) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) av[qq][i] = lut[reinterpret_cast<const unsigned char *>(as)[a_rd[qq] + i * BM]];
-            } else if (A_VEC_RED) {
-                const float4 v = *reinterpret_cast<const float4 *>(as + a_rd[qq]);
-                av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
-            } else {
+            for (int ti = 0; ti < TM; ++ti) {
+                if (A_U8 && A_VEC_RED) {
+                    const uint32_t w = reinterpret_cast<const uint32_t *>(as)[a_rd[ti][qq]];
+                    av[ti][qq][0] = lut[w & 0xffu]; av[ti][qq][1] = lut[(w >> 8) & 0xffu];
+                    av[ti][qq][2] = lut[(w >> 16) & 0xffu]; av[ti][qq][3] = lut[w >> 24];
+                } else if (A_U8) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) av[qq][i] = as[a_rd[qq] + i * BM];
+                    for (int i = 0; i < 4; ++i)
+                        av[ti][qq][i] = lut[reinterpret_cast<const unsigned char *>(as)[a_rd[ti][qq] + i * BM]];
+                } else if (A_VEC_RED) {
+                    const float4 v = *reinterpret_cast<const float4 *>(as + a_rd[ti][qq]);
+                    av[ti][qq][0] = v.x; av[ti][qq][1] = v.y; av[ti][qq][2] = v.z; av[ti][qq][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[ti][qq][i] = as[a_rd[ti][qq] + i * BM];
+                }
             }
-            if (B_VEC_RED) {
-                const float4 v = *reinterpret_cast<const float4 *>(bs + b_rd[qq]);
-                bv[qq][0] = v.x; bv[qq][1] = v.y; bv[qq][2] = v.z; bv[qq][3] = v.w;
-            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bv[qq][i] = bs[b_rd[qq] + i * BN];
+            for (int tj = 0; tj < TN; ++tj) {
+                if (B_VEC_RED) {
+                    const float4 v = *reinterpret_cast<const float4 *>(bs + b_rd[tj][qq]);
+                    bv[tj][qq][0] = v.x; bv[tj][qq][1] = v.y; bv[tj][qq][2] = v.z; bv[tj][qq][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bv[tj][qq][i] = bs[b_rd[tj][qq] + i * BN];
+                }
             }
         }
         if (do_colsum) {
@@ -1204,20 +1226,24 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
         }
     };
     // MFMA steps [t0, t1) of a slab's 4 * QS (the order of the sum inside a slab is unchanged: quad by quad, i = 0..3)
-    auto mfma_steps = [&](const float (&av)[QS][4], const float (&bv)[QS][4], const int t0, const int t1) {
+    auto mfma_steps = [&](const float (&av)[TM][QS][4], const float (&bv)[TN][QS][4], const int t0, const int t1) {
 #ifdef RLX_DBG_NO_MFMA      // timing experiment only (wrong results): what the loop costs without the matrix work
 #pragma unroll
-        for (int t = t0; t < t1; ++t) acc[0][0][t & 15] += av[t >> 2][t & 3] * bv[t >> 2][t & 3];
+        for (int t = t0; t < t1; ++t) acc[0][0][t & 15] += av[0][t >> 2][t & 3] * bv[0][t >> 2][t & 3];
 #else
 #pragma unroll
         for (int t = t0; t < t1; ++t)
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t >> 2][t & 3], bv[t >> 2][t & 3], acc[0][0], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t >> 2][t & 3], bv[j][t >> 2][t & 3], acc[i][j], 0, 0, 0);
 #endif
     };
 
     if (kbeg < kend) {
         const int nslab = (len + BK - 1) / BK;
-        float ra[2][QS][4], rb[2][QS][4];                    // operand registers of the slab in the chain / the next one
+        float ra[2][TM][QS][4], rb[2][TN][QS][4];            // operand registers of the slab in the chain / the next one
 #pragma unroll
         for (int d = 0; d < D - 1; ++d) issue(d, d);
         // slab 0: landed once all but the (D - 2) * L newest requests of this lane are complete, for every wave
@@ -1254,10 +1280,14 @@ __device__ __forceinline__ void gemm_dma_body(const GemmDev &g, const int bx, co
     }
     __syncthreads();                                          // the ring becomes the epilogue's staging area
     if (stamp) stamp[2] = wall_clock64();
-    if (pre_ok)
-        fast_epilogue<BM, BN, 1, 1, KW, false, true>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp, &pre);
-    else
-        fast_epilogue<BM, BN, 1, 1, KW, false>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp);
+    if constexpr (TM * TN == 1) {
+        if (pre_ok)
+            fast_epilogue<BM, BN, 1, 1, KW, false, true>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp, &pre);
+        else
+            fast_epilogue<BM, BN, 1, 1, KW, false>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp);
+    } else {
+        fast_epilogue<BM, BN, TM, TN, KW, false>(g, acc, smem, m0, n0, batch, split, do_colsum, csum, stamp);
+    }
 }
 
 template <int BM, int BN, int KW, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB, bool A_U8 = false>
@@ -1268,6 +1298,20 @@ __global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_kernel(const G
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     xcd_tile_block(g.xcd_mode, bx, by, bz);
     gemm_dma_body<BM, BN, KW, A_VEC_RED, B_VEC_RED, A_TAB, A_U8>(g, bx, by, bz, gridDim.x, gridDim.y, smem, tab_s, lut);
+}
+
+// Large products (thousands of tiles: the whole-dataset passes of Clipped PPO, acting on big vectors, the box calibration):
+// several accumulator tiles per wave on the same ring — 128 x 128 per workgroup with 64 x 64 per wave (half the slab bytes and
+// half the LDS operand reads per MFMA of the 64 x 64 workgroup tile; 64 KB of ring: two workgroups per CU), or, when N is 64,
+// 128 x 64 with 64 x 32 per wave (three quarters; 48 KB: three per CU).
+// Every output element is still ONE chain over the slabs in k order: bit-identical to the 64 x 64 tiling.
+template <int BM, int BN, int TM, int TN, bool A_VEC_RED, bool B_VEC_RED, bool A_TAB>
+__global__ void __launch_bounds__(kThreads, 2) gemm_dma_big_kernel(const GemmDev g) {
+    __shared__ __attribute__((aligned(1024))) float smem[DmaTile<BM, BN>::kSmemFloats];
+    __shared__ int tab_s[A_TAB ? kDmaTabChunk : 1];
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    xcd_tile_block(g.xcd_mode, bx, by, bz);
+    gemm_dma_body<BM, BN, 1, A_VEC_RED, B_VEC_RED, A_TAB, false, TM, TN>(g, bx, by, bz, gridDim.x, gridDim.y, smem, tab_s);
 }
 
 // a layer's weight gradient and input gradient as one launch (see gemm_fast_pair_kernel), both on the LDS-DMA ring
@@ -2101,12 +2145,27 @@ int launch_dma(const GemmDev &g, bool a_vec_red, bool b_vec_red, bool a_tab, boo
     return -1;
 }
 
+template <int BM, int BN, int TM, int TN>
+int launch_dma_big(const GemmDev &g, bool a_vec_red, bool b_vec_red, bool a_tab, dim3 grid, hipStream_t s) {
+#define RLX_BIG_CASE(AV, BV, AT)                                                                      \
+    if (a_vec_red == AV && b_vec_red == BV && a_tab == AT) {                                          \
+        RLX_LAUNCH((gemm_dma_big_kernel<BM, BN, TM, TN, AV, BV, AT>), grid, kThreads, 0, s, g);               \
+        return 0;                                                                                     \
+    }
+    RLX_BIG_CASE(true, false, false)
+    RLX_BIG_CASE(true, false, true)
+    RLX_BIG_CASE(true, true, false)
+#undef RLX_BIG_CASE
+    return -1;
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 // Tuning constants of the path selection (each was measured on the BASELINE shapes; the A/B records are under
 // profiles/: r02_ab_gemm_split_heuristic.txt, r02_ab_thin_16x16_tiles.txt, r01_thin_gemm_ab.txt).
 constexpr int kSplitWgsPerCu = 2;          // split K until ~2 workgroups per CU exist ...
 constexpr int kSplitMaxTiles = rlx::kCUs;  // ... unless the launch already covers every CU
+constexpr int kBigMinTiles = rlx::kCUs;    // 128 x 128 workgroup tiles: at least one per CU (128 x 64: two)
 constexpr int kThinMaxTiles = 96;          // thin kernel: at most this many 64 x 64 tiles
 constexpr int kThin16MaxTiles = 128;       // 16 x 16 tiles inside a dW + dX pair grid up to this many 32 x 32 tiles ...
 constexpr int kThin16SingleMaxTiles = 256; // ... and up to this many for a launch of its own
@@ -2118,6 +2177,7 @@ int g_split_cap = 64;      // most K splits one product is cut into (rlx_gemm_sp
 // (gemm_fast_body); rlx_gemm_pipeline, for same-process A/Bs (profiles/r04_ab_gemm_pipeline.txt).  128 x 32 tiles always take the latter;
 // uint8 operands take the ring only in mode 2 (4-byte requests: measured equal to the register path, profiles/r04_ab_u8_dma.txt).
 int g_dma = 1;
+int g_big_tiles = 1;      // 64 x 64 per wave for products of >= kBigMinTiles such tiles (rlx_gemm_big_tiles)
 
 // diagnostics: per-workgroup phase stamps of the fast kernel, one region per rlx_gemm call
 struct StampCall { int M, N, K, batch, splits, gx, gy, gz; long long offset; };
@@ -2167,6 +2227,11 @@ int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode) {
 int rlx_gemm_split_cap(int max_splits) {
     RLX_REQUIRE(max_splits >= 1 && max_splits <= 256, "rlx_gemm_split_cap: 1 <= max_splits <= 256");
     g_split_cap = max_splits;
+    return RLX_OK;
+}
+
+int rlx_gemm_big_tiles(int on) {
+    g_big_tiles = on < 0 ? 0 : (on > 2 ? 2 : on);      // 2: also the 128 x 64 variant for N <= 64
     return RLX_OK;
 }
 
@@ -2412,6 +2477,15 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
         BN = narrow ? 32 : 64;
         KW = 1;
     }
+    // large products: 2 x 2 accumulator tiles per wave (gemm_dma_big_kernel) — fp32 operands on the ring, no K split
+    int big = 0;            // 1: 128 x 128 (64 x 64 per wave), 2: 128 x 64 (64 x 32 per wave)
+    if (fast && g_dma && g_big_tiles && !plan && !u8_in && !narrow && KW == 1 && splits == 1 && !g.fold &&
+        BM == 64 && BN == 64 && (!a_tab || kchunk <= kDmaTabChunk) && !(!a_vec_red) && !(a_tab && b_vec_red)) {
+        if (d.N >= 128 && tiles_of(128, 128) >= kBigMinTiles) { big = 1; BM = 128; BN = 128; }
+        // (128 x 64 with 64 x 32 per wave for the N = 64 convolutions of the whole-dataset passes: neutral to slightly worse,
+        // profiles/r05_ab_big_wave_tiles.txt — g_big_tiles == 2 keeps it reachable for A/Bs)
+        else if (g_big_tiles == 2 && d.N <= 64 && tiles_of(128, 64) >= 2 * kBigMinTiles) { big = 2; BM = 128; BN = 64; }
+    }
     g.splits = splits;
     g.kchunk = kchunk;
     g.ws = d.workspace;
@@ -2466,7 +2540,13 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
         }
     }
     int rc = -1;
-    if (fast && g_dma && (g_dma >= 2 || !d.a_is_u8) && !narrow && (!a_tab || kchunk <= kDmaTabChunk)) {
+    if (big == 1) rc = launch_dma_big<128, 128, 2, 2>(g, a_vec_red, b_vec_red, a_tab, grid, s);
+    else if (big == 2) rc = launch_dma_big<128, 64, 2, 1>(g, a_vec_red, b_vec_red, a_tab, grid, s);
+    if (rc != 0 && big) {                       // (no instance for this operand combination: back to 64 x 64)
+        big = 0; BM = BN = 64;
+        grid = dim3((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * splits);
+    }
+    if (rc != 0 && fast && g_dma && (g_dma >= 2 || !d.a_is_u8) && !narrow && (!a_tab || kchunk <= kDmaTabChunk)) {
         const bool u8 = d.a_is_u8 != 0;
         if (KW == 2) rc = launch_dma<32, 64, 2>(g, a_vec_red, b_vec_red, a_tab, u8, grid, s);
         else if (KW == 4) rc = launch_dma<32, 32, 4>(g, a_vec_red, b_vec_red, a_tab, u8, grid, s);

@@ -382,6 +382,11 @@ int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode);
  * of rounds 1-3 (128 x 32 tiles always use it); 2 = the ring for uint8 operands too (4-byte requests; measured equal to 1).  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two
  * (both deterministic).  Process-wide, read at launch (or capture) time: exists for same-process A/B measurements. */
 int rlx_gemm_pipeline(int lds_dma_ring);
+/* 64 x 64 per wave (2 x 2 accumulator tiles; 128 x 128 or 256 x 64 per workgroup) for products of at least 256 such tiles
+ * without a K split: 1 (default: 128 x 128 for N >= 128) / 0 / 2 (also 128 x 64 for N <= 64, measured neutral on the
+ * convolution layers of the whole-dataset passes).  Bit-identical results either way
+ * (every element stays one chain over K); process-wide, for same-process A/Bs and tests. */
+int rlx_gemm_big_tiles(int on);
 /* The most K splits rlx_gemm cuts one product into (default 64; the workspace given with the descriptor bounds it as
  * well).  Process-wide, read at launch / capture time: a knob for same-process A/B measurements. */
 int rlx_gemm_split_cap(int max_splits);

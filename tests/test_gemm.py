@@ -536,3 +536,72 @@ def test_kernel_timer_overflow_is_an_error(dev):
     with _rlx.KernelTimer(4) as timer:               # and the timer is usable again
         lib.mix_weights(x, y, 1024, 0.5, s_)
     assert len(timer.records) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,bt", [(4096, 4096, 512, False), (16384, 256, 384, False), (4100, 200, 1000, False),
+                                      (131072, 64, 512, False), (70000, 36, 96, False), (8192, 640, 256, True)])
+def test_big_wave_tiles_equal_the_64x64_tiling_bit_for_bit(rlx, dev, M, N, K, bt, request):
+    """rlx_gemm_big_tiles: products of hundreds of 128-row tiles run with several accumulator tiles per wave (128 x 128 or
+    128 x 64 per workgroup).  Every output element is the same chain over K as on 64 x 64 tiles: torch.equal, bias and
+    activation included; bt: B given transposed (the input-gradient form dY W^T)."""
+    import torch
+    from coach_amd import _rlx
+    from coach_amd._rlx import gemm
+    rng = np.random.RandomState(M % 1000 + N + K)
+    A = dev_tensor(rng.randn(M, K).astype(np.float32), dev)
+    B = dev_tensor((rng.randn(N, K) if bt else rng.randn(K, N)).astype(np.float32) / np.float32(np.sqrt(K)), dev)
+    bias = dev_tensor(rng.randn(N).astype(np.float32), dev)
+    ws = torch.empty(1 << 22, dtype=torch.float32, device=dev)
+    out, names = {}, {}
+    ring = request.node.callspec.params["_gemm_pipeline"] != 0        # (the register-staged loop has no such tiling)
+    for big in (0, 2):
+        rlx.gemm_big_tiles(big)
+        try:
+            C = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+            with _rlx.KernelTimer(16) as timer:
+                gemm(M, N, K, A, B, C, bias=bias, activation="tanh", workspace=ws,
+                     **({"b_strides": (1, K)} if bt else {}))
+            out[big], names[big] = C, [n for n, _ in timer.records]
+        finally:
+            rlx.gemm_big_tiles(1)
+    out[1], names[1] = out[2], names[2]
+    assert torch.equal(out[0], out[1])
+    assert not any("big_kernel" in n for n in names[0])
+    t128 = -(-M // 128)
+    expect_big = (N >= 128 and t128 * -(-N // 128) >= 256) or (N <= 64 and t128 >= 512)       # csrc/gemm.hip kBigMinTiles
+    assert any("gemm_dma_big_kernel" in n for n in names[1]) == (expect_big and ring), names[1]
+    if M <= 16384:
+        ref = np.tanh(A.cpu().numpy().astype(np.float64) @ (B.cpu().numpy().astype(np.float64).T if bt else
+                                                           B.cpu().numpy().astype(np.float64)) + bias.cpu().numpy())
+        np.testing.assert_allclose(out[1].cpu().numpy(), ref, **_tol(K))
+
+
+@pytest.mark.gpu
+def test_big_wave_tiles_on_a_convolution_of_the_whole_dataset(rlx, dev, request):
+    """conv2 of the Atari torso over 2048 images (the V(s) / old-policy passes of Clipped PPO: 165 888 rows through im2col
+    tables) on 128 x 64 workgroup tiles against the 64 x 64 tiling: bit-identical."""
+    import torch
+    from coach_amd import _rlx
+    from coach_amd.nn import graph as G
+    params = G.FlatParams()
+    conv = G.Conv2d(params, "c2", (20, 20, 32), 64, 4, 2, "tanh", 1)
+    params.finalize(dev)
+    conv.initialize(np.random.RandomState(0))
+    B = 2048
+    x = torch.from_numpy(np.random.RandomState(1).randn(1, B, 20 * 20 * 32).astype(np.float32)).to(dev)
+    out, names = {}, {}
+    ring = request.node.callspec.params["_gemm_pipeline"] != 0
+    for big in (0, 2):
+        rlx.gemm_big_tiles(big)
+        try:
+            ctx = G.Context(dev)
+            conv.forward(ctx, G.Tensor(x, B, 20 * 20 * 32, 1), tag="w")       # (tables)
+            with _rlx.KernelTimer(16) as timer:
+                y = conv.forward(ctx, G.Tensor(x, B, 20 * 20 * 32, 1), tag="t")
+            out[big], names[big] = y.data.clone(), [n for n, _ in timer.records]
+        finally:
+            rlx.gemm_big_tiles(1)
+    assert torch.equal(out[0], out[2])
+    assert any("gemm_dma_big_kernel" in n for n in names[2]) == ring, names[2]
+    assert not any("big_kernel" in n for n in names[0])
