@@ -572,7 +572,7 @@ def gemm_roofline(agent, reps=20):
     # own loads, profiles/r03_pmc_calibration.json); used only if that file describes the same products AND launches.
     gemm_launches = sum(r["launches_per_update"] for r in table if r["kernel"].startswith(GEMM_FAMILY))
     traffic = None
-    for fn in ("r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json"):
+    for fn in ("r05_pmc_gemm_traffic.json", "r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 pm = json.load(f)
@@ -741,6 +741,8 @@ def main():
     ap.add_argument("--rider-blocks", type=int, default=None, help="A/B: workgroups of the Adam rider (AdamState.RIDER_BLOCKS)")
     ap.add_argument("--rider-launches", type=int, default=None,
                     help="A/B: pair launches the rider's range is divided over (AdamState.RIDER_LAUNCHES)")
+    ap.add_argument("--direct-conv-dx", default=None, choices=["0", "1", "always"],
+                    help="A/B: convolution input gradients as one windowed-gather product (nn.graph.DIRECT_CONV_INPUT_GRAD)")
     ap.add_argument("--big-tiles", type=int, default=None, choices=[0, 1],
                     help="A/B: several accumulator tiles per wave for large products (rlx_gemm_big_tiles; 1 = default)")
     ap.add_argument("--multi-dw", type=int, default=None, choices=[0, 1],
@@ -785,6 +787,9 @@ def main():
     if args.ppo_chunk is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
         ClippedPPOAgent.DATASET_CHUNK = args.ppo_chunk
+    if args.direct_conv_dx is not None:
+        from coach_amd.nn import graph as _G3
+        _G3.DIRECT_CONV_INPUT_GRAD = {"0": False, "1": True, "always": "always"}[args.direct_conv_dx]
     if args.big_tiles is not None:
         from coach_amd import _rlx as _r
         _r.lib().gemm_big_tiles(args.big_tiles)
