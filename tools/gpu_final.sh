@@ -15,7 +15,10 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 400 python bench.py --shapes > $O/bench_c2.json 2> $O/bench_c2.err
 for w in c1 c3 c4 c5; do timeout 300 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; done
 timeout 300 python bench.py --force-dist --no-cpu-baseline --no-roofline > $O/bench_c2_force_dist.json 2> $O/bench_c2_force_dist.err
-for w in c2 c1 c3 c4 c5 c2_force_dist; do python - <<PY
+timeout 400 python bench.py --episode-length 1024 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_c2_L1024.json 2> $O/bench_c2_L1024.err
+timeout 300 python bench.py --fuse-conv 0 --no-cpu-baseline > $O/bench_c2_unfused.json 2> $O/bench_c2_unfused.err
+python tools/conv23_timeline.py 2>&1 | grep -v amdgpu.ids > $O/conv23_timeline.txt
+for w in c2 c1 c3 c4 c5 c2_force_dist c2_L1024 c2_unfused; do python - <<PY
 import json
 try:
     d=json.loads(open('$O/bench_$w.json').read().strip().splitlines()[-1])
@@ -43,5 +46,14 @@ python tools/pmc_summary.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/pmc_g
 python tools/pmc_summary.py --mfma $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv $O/pmc_GRBM_GUI_ACTIVE.csv $O/pmc_mfma_util.json 2>&1 | head -3 | cut -c1-300
 (cd /tmp && REPS=50 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_eager -- python $R/tools/ppo_update_once.py > $R/$O/kt_eager.log 2>&1)
 f=$(find /tmp/kt_eager -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/eager_update_kernel_stats.csv
+A="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"
+B="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
+i=1
+for set in "$A" "$B"; do
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/sq_$i -- python $R/tools/ppo_update_once.py > $R/$O/sq_$i.log 2>&1)
+f=$(find /tmp/sq_$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f $O/sq_$i.csv
+i=$((i+1))
+done
+python tools/pmc_wave_states.py $O/sq_1.csv $O/sq_2.csv $O/pmc_wave_states.json 2>&1 | tail -16
 head -16 $O/c2_kernel_stats.csv | cut -c1-170
 du -sh $O
