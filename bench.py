@@ -735,12 +735,6 @@ def main():
     ap.add_argument("--gemm-pipeline", type=int, default=None, choices=[0, 1],
                     help="A/B: main loop of the fast tiled GEMM kernels (rlx_gemm_pipeline): 1 = LDS-DMA ring (the "
                          "library's default), 0 = register-staged")
-    ap.add_argument("--adam-rider", type=int, default=None, choices=[0, 1],
-                    help="A/B (c2): the dense layers' Adam step as extra workgroups of the convolution backward's pair "
-                         "launches (1, the default at world size 1) or inside the closing Adam launch (0)")
-    ap.add_argument("--rider-blocks", type=int, default=None, help="A/B: workgroups of the Adam rider (AdamState.RIDER_BLOCKS)")
-    ap.add_argument("--rider-launches", type=int, default=None,
-                    help="A/B: pair launches the rider's range is divided over (AdamState.RIDER_LAUNCHES)")
     ap.add_argument("--direct-conv-dx", default=None, choices=["0", "1", "always"],
                     help="A/B: convolution input gradients as one windowed-gather product (nn.graph.DIRECT_CONV_INPUT_GRAD)")
     ap.add_argument("--big-tiles", type=int, default=None, choices=[0, 1],
@@ -802,15 +796,6 @@ def main():
     if args.fuse_conv is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_PAIR = bool(args.fuse_conv)
-    if args.adam_rider is not None:
-        from coach_amd.nn.networks import ClippedPPONet
-        ClippedPPONet.ADAM_RIDER = bool(args.adam_rider)
-    if args.rider_blocks is not None or args.rider_launches is not None:
-        from coach_amd.nn.graph import AdamState
-        if args.rider_blocks is not None:
-            AdamState.RIDER_BLOCKS = args.rider_blocks
-        if args.rider_launches is not None:
-            AdamState.RIDER_LAUNCHES = args.rider_launches
     if args.gemm_pipeline is not None:
         from coach_amd import _rlx
         _rlx.lib().gemm_pipeline(args.gemm_pipeline)

@@ -589,22 +589,19 @@ class ClippedPPOAgent(object):
 
     def _minibatch_fb(self, m, clip_rescaler, stop_after_dense=False, i=0, epoch=None):
         """epoch: the buffers of _gather_epoch — minibatch i's rows are already in training order."""
-        # one process, no gradient exchange: _minibatch_finish(1.0) follows directly, so the dense layers' Adam step
-        # may ride on the convolution backward (ClippedPPONet.forward_backward adam_rider)
-        rider = 1.0 if (self.dist is None and not stop_after_dense) else None
         if epoch is not None:
             B = self.ap.network_wrappers["main"].batch_size
             sl = slice(i * B, i * B + m)
             old = (epoch["old"][sl], epoch["old_std"][sl]) if self.continuous else epoch["old"][sl]
             self.networks["main"].forward_backward(epoch["obs"][sl], m, epoch["action"][sl], epoch["adv"][sl],
                                                    epoch["vtarget"][sl], old, clip_rescaler, self.mb_ratio,
-                                                   self.mb_clipped, stop_after_dense=stop_after_dense, adam_rider=rider)
+                                                   self.mb_clipped, stop_after_dense=stop_after_dense)
             return
         obs = self._gather_minibatch(m, i)
         old = (self.mb_old, self.mb_old_std) if self.continuous else self.mb_old
         self.networks["main"].forward_backward(obs, m, self.mb_action, self.mb_adv, self.mb_vtarget,
                                                old, clip_rescaler, self.mb_ratio, self.mb_clipped,
-                                               stop_after_dense=stop_after_dense, adam_rider=rider)
+                                               stop_after_dense=stop_after_dense)
 
     def _minibatch_finish(self, scale):
         net = self.networks["main"]

@@ -26,7 +26,6 @@
 // blockIdx.z also carries a batch index (the two separate Clipped-PPO towers run as one launch).
 #include "rlx_common.hpp"
 #include "dense_small_body.hpp"
-#include "adam_rider.hpp"
 #include <cstdlib>
 
 namespace {
@@ -856,8 +855,6 @@ struct GemmPairDev {
     int gx[2], gy[2];
     int n0;
     int t16[2];                 // thin pair: the half runs on 16 x 16 tiles
-    int n_gemm;                 // workgroups of the two products; the ones behind them carry `rider` (adam_rider.hpp)
-    rlx::AdamRider rider;
 };
 // DX_KW = 2 / 4: the input-gradient half runs on 32 x 64 / 32 x 32 tiles with the K slab split over the wave groups (a
 // mid-sized dX such as the FC layer's 64 x 3136 x 512: no partial sums in memory, no reduce launch)
@@ -867,14 +864,10 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_fast_pair_kernel(const GemmP
     __shared__ float lut[1];
     __shared__ int tab_s[A_TAB0 ? kTabChunk : 1];
     int flat = blockIdx.x;
-    if (flat >= p.n_gemm) {      // a rider workgroup: an Adam step of a parameter range nobody in this launch touches
-        rlx::adam_rider_block(p.rider, flat - p.n_gemm, smem);
-        return;
-    }
     const int which = flat >= p.n0;
     // each half keeps its own share of every XCD (the halves differ in cost per tile: the chip stays balanced)
     if (which) flat -= p.n0;
-    flat = xcd_tile_position(p.g[0].xcd_mode, flat, which ? p.n_gemm - p.n0 : p.n0);
+    flat = xcd_tile_position(p.g[0].xcd_mode, flat, which ? (int)gridDim.x - p.n0 : p.n0);
     const int gx = p.gx[which], gy = p.gy[which];
     const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
     if (!which)      // weight gradient: A = X^T (vector along the outer index; im2col tables for a convolution)
@@ -1320,13 +1313,9 @@ __global__ void __launch_bounds__(kThreads, RLX_DMA_WGS) gemm_dma_pair_kernel(co
     __shared__ __attribute__((aligned(1024))) float smem[DmaTile<64, 64>::kSmemFloats];
     __shared__ int tab_s[A_TAB0 ? kDmaTabChunk : 1];
     int flat = blockIdx.x;
-    if (flat >= p.n_gemm) {      // a rider workgroup (see gemm_fast_pair_kernel)
-        rlx::adam_rider_block(p.rider, flat - p.n_gemm, smem);
-        return;
-    }
     const int which = flat >= p.n0;
     if (which) flat -= p.n0;
-    flat = xcd_tile_position(p.g[0].xcd_mode, flat, which ? p.n_gemm - p.n0 : p.n0);
+    flat = xcd_tile_position(p.g[0].xcd_mode, flat, which ? (int)gridDim.x - p.n0 : p.n0);
     const int gx = p.gx[which], gy = p.gy[which];
     const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
     if (!which)
@@ -2651,8 +2640,6 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
         p.n0 = (int)(pw.grid.x * pw.grid.y * pw.grid.z);
         p.t16[0] = pw.t16; p.t16[1] = px.t16;
         const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
-        p.n_gemm = (int)total;
-        p.rider = rlx::AdamRider{};
         RLX_LAUNCH((gemm_thin_pair_kernel), total, kThreads, 0, rlx::as_stream(stream), p);
         RLX_LAUNCH_CHECK();
         return RLX_OK;
@@ -2669,11 +2656,7 @@ static int gemm_pair_impl(const rlx_gemm_desc *weight_grad, const rlx_gemm_desc 
     p.gx[0] = pw.grid.x; p.gy[0] = pw.grid.y; p.gx[1] = px.grid.x; p.gy[1] = px.grid.y;
     p.n0 = (int)(pw.grid.x * pw.grid.y * pw.grid.z);
     p.t16[0] = p.t16[1] = 0;
-    const unsigned n_gemm = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
-    p.n_gemm = (int)n_gemm;
-    // a pending Adam rider (rlx_adam_rider_arm) travels as extra workgroups behind the two products'
-    p.rider = rlx::AdamRider{};
-    const unsigned total = n_gemm + (rlx::take_rider_share(&p.rider) ? (unsigned)p.rider.blocks : 0u);
+    const unsigned total = (unsigned)p.n0 + px.grid.x * px.grid.y * px.grid.z;
     hipStream_t s = rlx::as_stream(stream);
 #define RLX_PAIR_CASE(AT, KWX)                                                                   \
     if (pw.a_tab == AT && px.kw == KWX) {                                                        \

@@ -21,7 +21,6 @@
 // float4 accesses, grid-stride, <= 2048 workgroups.  Compiled with -ffp-contract=off so that the
 // mixing rounds like numpy's two products + add.
 #include "rlx_common.hpp"
-#include "adam_rider.hpp"
 
 namespace {
 
@@ -118,7 +117,7 @@ __global__ void __launch_bounds__(kBlock)
 adam_step_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                  long long n, float lr, float beta1, float beta2, float eps, float *state, float grad_scale,
                  float *sumsq_part, float *__restrict__ target, float rate, float one_minus_rate,
-                 unsigned int *ticket, float *norm_out, const float *acc_src, float *acc_dst, int n_acc, int n_extra) {
+                 unsigned int *ticket, float *norm_out, const float *acc_src, float *acc_dst, int n_acc) {
     __shared__ float red[kBlock];
     __shared__ int last_s;
     float ss = 0.f;
@@ -191,7 +190,7 @@ adam_step_kernel(float *__restrict__ w, const float *__restrict__ g, float *__re
     // adam_finish_norm_kernel's arithmetic, in its order, by the workgroup that drew the last ticket (agent-scope loads:
     // the partials come from the memory side, not from a stale line of this XCD's L2)
     float s = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x + n_extra; i += kBlock)   // + the partial sums a rider left behind ours
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
         s += __hip_atomic_load(&sumsq_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     red[threadIdx.x] = s;
     __syncthreads();
@@ -221,7 +220,7 @@ __global__ void __launch_bounds__(kBlock)
 adam_step_norm_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                       long long n, float lr, float beta1, float beta2, float eps, float *state, float grad_scale,
                       float *sumsq_part, float *__restrict__ target, float rate, float one_minus_rate,
-                      unsigned int *ticket, float *norm_out, const float *acc_src, float *acc_dst, int n_acc, int n_extra) {
+                      unsigned int *ticket, float *norm_out, const float *acc_src, float *acc_dst, int n_acc) {
     __shared__ float red[kBlock];
     __shared__ int last_s;
     const float b1p = state[0], b2p = state[1];
@@ -297,7 +296,7 @@ adam_step_norm_kernel(float *__restrict__ w, const float *__restrict__ g, float 
     if (!last_s) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // pairs the publication of the partial sums (one workgroup only)
     float s = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x + n_extra; i += kBlock)   // + the partial sums a rider left behind ours
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
         s += __hip_atomic_load(&sumsq_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     red[threadIdx.x] = s;
     __syncthreads();
@@ -395,44 +394,7 @@ __global__ void clip_by_global_norm_kernel(float *__restrict__ g, long long n, c
 }
 
 int g_norm_in_kernel = 2;       // rlx_adam_norm_in_kernel
-
-// the rider as a launch of its own: what rlx_adam_rider_flush issues when no pair launch took the armed range
-__global__ void __launch_bounds__(kBlock) adam_rider_kernel(const rlx::AdamRider r) {
-    __shared__ float red[kBlock];
-    rlx::adam_rider_block(r, blockIdx.x, red);
-}
-
 }  // namespace
-
-
-namespace rlx {
-PendingRider &pending_rider() {
-    static thread_local PendingRider p;
-    return p;
-}
-bool take_rider_share(AdamRider *out) {
-    PendingRider &p = pending_rider();
-    if (!p.armed) return false;
-    const int L = p.launches_left > 1 ? p.launches_left : 1;
-    AdamRider share = p.r;
-    if (L > 1) {
-        share.n4 = (p.r.n4 + L - 1) / L;
-        share.blocks = p.r.blocks / L > 0 ? p.r.blocks / L : 1;
-    }
-    *out = share;
-    // what stays pending
-    p.r.w += share.n4 * 4; p.r.g += share.n4 * 4; p.r.m += share.n4 * 4; p.r.v += share.n4 * 4;
-    p.r.n4 -= share.n4;
-    p.r.blocks -= share.blocks;
-    if (p.r.sumsq_part) p.r.sumsq_part += share.blocks;
-    p.launches_left = L - 1;
-    if (p.r.n4 <= 0 || p.r.blocks <= 0) {
-        // (blocks ran out before the range did: cannot happen — the last share takes everything that is left)
-        p.armed = false;
-    }
-    return true;
-}
-}  // namespace rlx
 
 extern "C" {
 
@@ -491,32 +453,10 @@ int rlx_adam_norm_in_kernel(int on) {
     return RLX_OK;
 }
 
-static int adam_step_blocks(long long n, bool with_norm, long long workspace_floats, int n_extra) {
-    int blocks = rlx::grid_for(n / 4 + 1, kBlock, 1024);
-    if (with_norm && blocks + n_extra > workspace_floats) blocks = (int)workspace_floats - n_extra;
-    return blocks;
-}
-
-int rlx_adam_step_blocks(long long n, long long workspace_floats, int n_extra, int *blocks_host) {
-    RLX_REQUIRE(n > 0 && blocks_host && n_extra >= 0, "rlx_adam_step_blocks: bad arguments");
-    *blocks_host = adam_step_blocks(n, true, workspace_floats, n_extra);
-    RLX_REQUIRE(*blocks_host >= 1, "rlx_adam_step_blocks: workspace too small");
-    return RLX_OK;
-}
-
 int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
                       float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
                       float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
                       float *target, double mix_rate, unsigned int *ticket, void *stream) {
-    return rlx_adam_tf1_step_parts(weights, grads, m, v, n, learning_rate, beta1, beta2, epsilon, state, grad_scale, norm_out,
-                                   workspace, workspace_floats, acc_src, acc_dst, n_acc, target, mix_rate, ticket, 0, stream);
-}
-
-int rlx_adam_tf1_step_parts(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
-                            float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
-                            float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
-                            float *target, double mix_rate, unsigned int *ticket, int n_extra, void *stream) {
-    RLX_REQUIRE(n_extra >= 0 && (n_extra == 0 || norm_out), "rlx_adam_tf1_step_parts: extra partial sums belong to a norm");
     RLX_REQUIRE(weights && grads && m && v && state && ticket, "rlx_adam_tf1_step: null pointer");
     RLX_REQUIRE(n > 0, "rlx_adam_tf1_step: empty parameter buffer");
     RLX_REQUIRE(!norm_out || workspace, "rlx_adam_tf1_step: the gradient norm needs a workspace");
@@ -524,32 +464,33 @@ int rlx_adam_tf1_step_parts(float *weights, const float *grads, float *m, float 
                 "rlx_adam_tf1_step: bad signal accumulation arguments");
     RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)target) & 15) == 0,
                 "rlx_adam_tf1_step: buffers must be 16-byte aligned");
-    const int blocks = adam_step_blocks(n, norm_out != nullptr, workspace_floats, n_extra);
+    int blocks = rlx::grid_for(n / 4 + 1, kBlock, 1024);
+    if (norm_out && blocks > workspace_floats) blocks = (int)workspace_floats;
     RLX_REQUIRE(blocks >= 1, "rlx_adam_tf1_step: workspace too small");
     hipStream_t s = rlx::as_stream(stream);
     const float rate = (float)mix_rate, omr = (float)(1.0 - mix_rate);
 #define RLX_ADAM_STEP(NORM, MIX, TICKET)                                                                      \
     RLX_LAUNCH((adam_step_kernel<NORM, MIX, TICKET>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1,  \
                                                                   beta2, epsilon, state, grad_scale, workspace, \
-                                                                  target, rate, omr, ticket, nullptr, nullptr, nullptr, 0, 0)
+                                                                  target, rate, omr, ticket, nullptr, nullptr, nullptr, 0)
     // one launch with the norm as well (the finish by the last workgroup, see adam_step_kernel)
     if (norm_out && g_norm_in_kernel == 2 && (n >> 2) <= (long long)blocks * kBlock * kNormIt) {
         if (target)
             RLX_LAUNCH((adam_step_norm_kernel<true>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1, beta2,
-                       epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc, n_extra);
+                       epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc);
         else
             RLX_LAUNCH((adam_step_norm_kernel<false>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1, beta2,
-                       epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc, n_extra);
+                       epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc);
         RLX_LAUNCH_CHECK();
         return RLX_OK;
     }
     if (norm_out && g_norm_in_kernel == 1) {
         if (target)
             RLX_LAUNCH((adam_step_kernel<true, true, true>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1,
-                       beta2, epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc, n_extra);
+                       beta2, epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc);
         else
             RLX_LAUNCH((adam_step_kernel<true, false, true>), blocks, kBlock, 0, s, weights, grads, m, v, n, learning_rate, beta1,
-                       beta2, epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc, n_extra);
+                       beta2, epsilon, state, grad_scale, workspace, target, rate, omr, ticket, norm_out, acc_src, acc_dst, n_acc);
         RLX_LAUNCH_CHECK();
         return RLX_OK;
     }
@@ -560,7 +501,7 @@ int rlx_adam_tf1_step_parts(float *weights, const float *grads, float *m, float 
 #undef RLX_ADAM_STEP
     RLX_LAUNCH_CHECK();
     if (norm_out) {
-        RLX_LAUNCH((adam_finish_norm_kernel), 1, kBlock, 0, s, state, beta1, beta2, workspace, blocks + n_extra, norm_out, acc_src,
+        RLX_LAUNCH((adam_finish_norm_kernel), 1, kBlock, 0, s, state, beta1, beta2, workspace, blocks, norm_out, acc_src,
                                                      acc_dst, n_acc);
         RLX_LAUNCH_CHECK();
     } else if (n_acc > 0) {
@@ -568,36 +509,6 @@ int rlx_adam_tf1_step_parts(float *weights, const float *grads, float *m, float 
     }
     return RLX_OK;
 }
-
-int rlx_adam_rider_arm(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
-                       float beta1, float beta2, float epsilon, const float *state, float grad_scale,
-                       float *sumsq_part, int blocks, int launches) {
-    RLX_REQUIRE(weights && grads && m && v && state, "rlx_adam_rider_arm: null pointer");
-    RLX_REQUIRE(n > 0 && n % 4 == 0, "rlx_adam_rider_arm: the range must be a multiple of 4 parameters");
-    RLX_REQUIRE((((uintptr_t)weights | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
-                "rlx_adam_rider_arm: the range must start 16-byte aligned");
-    RLX_REQUIRE(launches >= 1 && blocks >= launches && blocks <= 4096, "rlx_adam_rider_arm: 1 <= launches <= blocks <= 4096");
-    rlx::PendingRider &p = rlx::pending_rider();
-    RLX_REQUIRE(!p.armed, "rlx_adam_rider_arm: a rider is already pending (rlx_adam_rider_flush first)");
-    p.r = rlx::AdamRider{weights, grads, m, v, n / 4, state, sumsq_part, learning_rate, beta1, beta2, epsilon, grad_scale, blocks};
-    p.launches_left = launches;
-    p.armed = true;
-    return RLX_OK;
-}
-
-int rlx_adam_rider_flush(void *stream, int *was_pending_host) {
-    rlx::PendingRider &p = rlx::pending_rider();
-    if (was_pending_host) *was_pending_host = p.armed ? 1 : 0;
-    if (!p.armed) return RLX_OK;
-    p.launches_left = 1;                      // everything that is left, as one launch of its own
-    rlx::AdamRider r;
-    rlx::take_rider_share(&r);
-    p.armed = false;
-    RLX_LAUNCH((adam_rider_kernel), r.blocks, kBlock, 0, rlx::as_stream(stream), r);
-    RLX_LAUNCH_CHECK();
-    return RLX_OK;
-}
-
 
 int rlx_mix_weights(float *target, const float *online, long long n, double rate, void *stream) {
     RLX_REQUIRE(target && online && n > 0, "rlx_mix_weights: bad arguments");

@@ -885,32 +885,6 @@ class AdamState:
         self.one_launch = True
         _rlx.lib().adam_init(self.m, self.v, params.size, self.state, beta1, beta2, _rlx.current_stream())
 
-    # ---- Adam rider (rlx_adam_rider_*): the step of the parameters [offset, size) travels as extra workgroups of the
-    # next tiled dW + dX pair launch(es); step(..., n=offset) then closes the update over [0, offset)
-    RIDER_BLOCKS = 512
-    RIDER_LAUNCHES = 1
-
-    def arm_rider(self, offset, grad_scale=1.0, with_norm=True):
-        """-> True when the range [offset, size) qualifies (16-byte aligned, a multiple of 4 parameters) and was armed."""
-        p = self.params
-        n = p.size - offset
-        if offset <= 0 or n <= 0 or offset % 4 or n % 4 or not self.one_launch:
-            return False
-        lib = _rlx.lib()
-        if self.rider_ws is None:
-            self.rider_ws = torch.empty(8192, dtype=torch.float32, device=p.weights.device)
-        blocks = min(self.RIDER_BLOCKS, max(self.RIDER_LAUNCHES, n // 4 // 256))
-        own = ctypes.c_int()
-        lib.adam_step_blocks(offset, self.rider_ws.numel(), blocks, ctypes.byref(own))
-        self._rider = (offset, blocks, own.value)
-        lib.adam_rider_arm(p.weights[offset:], p.grads[offset:], self.m[offset:], self.v[offset:], n, self.lr, self.beta1,
-                           self.beta2, self.eps, self.state, grad_scale,
-                           self.rider_ws[own.value:] if with_norm else None, blocks, self.RIDER_LAUNCHES)
-        return True
-
-    rider_ws = None
-    _rider = None
-
     def step(self, grad_scale=1.0, lr=None, norm_out=None, workspace=None, acc=None, grads=None, mix_target=None,
              mix_rate=0.0):
         """norm_out given: the same pass also returns tf.global_norm of the gradients; acc =
@@ -920,21 +894,6 @@ class AdamState:
         p = self.params
         lr = self.lr if lr is None else lr
         g = p.grads if grads is None else grads
-        if self._rider is not None:
-            # the rest of an update whose upper range a rider stepped (arm_rider): whatever no pair launch carried goes out
-            # now, then Adam over [0, offset) with the rider's partial sums of squares behind its own
-            offset, blocks, own = self._rider
-            self._rider = None
-            if grads is not None or mix_target is not None or lr != self.lr:
-                raise ValueError("an armed Adam rider closes with the plain step of the same optimiser")
-            _rlx.lib().adam_rider_flush(_rlx.current_stream(), None)
-            _rlx.lib().adam_tf1_step_parts(p.weights, g, self.m, self.v, offset, lr, self.beta1, self.beta2, self.eps,
-                                           self.state, grad_scale, norm_out, self.rider_ws if norm_out is not None else None,
-                                           self.rider_ws.numel() if norm_out is not None else 0,
-                                           acc[0] if acc else None, acc[1] if acc else None, int(acc[2]) if acc else 0,
-                                           None, 0.0, self.ticket, blocks if norm_out is not None else 0,
-                                           _rlx.current_stream())
-            return
         if self.one_launch:
             _rlx.lib().adam_tf1_step(p.weights, g, self.m, self.v, p.size, lr, self.beta1, self.beta2, self.eps,
                                      self.state, grad_scale, norm_out, workspace if norm_out is not None else None,

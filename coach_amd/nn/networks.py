@@ -215,22 +215,12 @@ class ClippedPPONet(_NetBase):
             self._clip_scale_dev.fill_(float(value))
             self._clip_scale_value = float(value)
 
-    # forward_backward(adam_rider=...) is honoured only while this is on.  OFF by default: measured -0.3 .. -1.3 % per C2
-    # update (profiles/r05_ab_adam_rider.txt) — the pair launch that carries the rider grows by what the closing Adam launch
-    # saves, because the convolution products wait on memory LATENCY and the rider's streaming traffic raises it
-    ADAM_RIDER = False
-
     def forward_backward(self, obs, B, actions, advantages, value_targets, old_probs,
-                         clip_rescaler=1.0, ratio_out=None, clipped_out=None, stop_after_dense=False, adam_rider=None):
+                         clip_rescaler=1.0, ratio_out=None, clipped_out=None, stop_after_dense=False):
         """accumulate_gradients (tensorflow_components/architecture.py:312-385): forward both towers,
         head losses, backward; leaves d total_loss / d theta in params.grads.
         stop_after_dense: stop once the dense layers' gradients are final (backward_rest() resumes).
-        clip_rescaler None: the device scalar of set_clip_rescaler.
-        adam_rider (a gradient scale, normally 1.0): the caller will follow this pass with finish_update(that scale)
-        and nothing else — the Adam step of the dense layers' and heads' parameters (final before the convolution
-        backward starts, 95 % of the bytes) then travels as extra workgroups of the convolution layers' dW + dX pair
-        launches (AdamState.arm_rider) and finish_update steps only the rest.  Same weights, bit for bit; the gradient
-        norm sums its squares in another order."""
+        clip_rescaler None: the device scalar of set_clip_rescaler."""
         ctx = self.ctx
         clip_dev = self._clip_scale_dev if clip_rescaler is None else None
         if clip_rescaler is None:
@@ -292,19 +282,6 @@ class ClippedPPONet(_NetBase):
             k = self._split_layer()
             self.torso.backward(ctx, acts, layers=(k, len(self.torso.layers)))
             self._resume = (acts, k)
-        elif adam_rider is not None and self.ADAM_RIDER and self._split_layer() > 0 and ctx.deferred is None:
-            # the backward pass in two halves inside ONE deferral (the same jobs, the same single reduction launch as
-            # torso.backward(ctx, acts)); between them the dense layers' and the heads' gradients are final unless one
-            # of them is still a deferred split-K sum
-            k = self._split_layer()
-            ctx.begin_deferring()
-            try:
-                self.torso.backward(ctx, acts, layers=(k, len(self.torso.layers)))
-                if not ctx.deferred:
-                    self.adam.arm_rider(self.late_gradient_offset(), float(adam_rider))
-                self.torso.backward(ctx, acts, layers=(0, k))
-            finally:
-                ctx.flush_deferred()
         else:
             self.torso.backward(ctx, acts)
 

@@ -632,30 +632,6 @@ int rlx_adam_tf1_step(float *weights, const float *grads, float *m, float *v, lo
                       float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
                       float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
                       float *target, double mix_rate, unsigned int *ticket, void *stream);
-/* rlx_adam_tf1_step over PART of a parameter buffer when another launch has already stepped the rest (an Adam rider,
- * below): workspace[blocks .. blocks + n_extra) hold that launch's partial sums of squares (blocks =
- * rlx_adam_step_blocks(n, workspace_floats, n_extra)); the norm written to norm_out covers both.  n_extra = 0 is
- * rlx_adam_tf1_step. */
-int rlx_adam_tf1_step_parts(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
-                            float beta1, float beta2, float epsilon, float *state, float grad_scale, float *norm_out,
-                            float *workspace, long long workspace_floats, const float *acc_src, float *acc_dst, int n_acc,
-                            float *target, double mix_rate, unsigned int *ticket, int n_extra, void *stream);
-int rlx_adam_step_blocks(long long n, long long workspace_floats, int n_extra, int *blocks_host);
-/* Adam rider.  The reference applies ALL gradients in one session.run after the whole backward pass
- * (architectures/tensorflow_components/architecture.py:469-521); the arithmetic per parameter is elementwise, so a
- * parameter whose gradient is already final may be stepped earlier, as long as nothing reads the weight in between.
- * rlx_adam_rider_arm records an Adam step (rlx_adam_tf1's arithmetic, bit for bit) of n parameters — n % 4 == 0, 16-byte
- * aligned — of THIS host thread; the next `launches` calls of rlx_gemm_pair / rlx_gemm_pair_defer that launch a tiled
- * pair grid carry an equal share of it each as extra workgroups (`blocks` workgroups of 256 threads in total): the
- * memory-bound Adam traffic runs underneath latency-bound matrix products in ONE dispatch.  state = {beta1_power,
- * beta2_power} is read, not advanced: the Adam launch over the rest of the buffer (rlx_adam_tf1_step_parts) advances it
- * and finishes the norm from sumsq_part[0 .. blocks) (may be NULL: no norm).  rlx_adam_rider_flush launches whatever
- * no pair launch took as a kernel of its own (*was_pending_host = 1 if there was any); call it before the closing Adam
- * launch.  Arm / flush are host-side state only: capturable. */
-int rlx_adam_rider_arm(float *weights, const float *grads, float *m, float *v, long long n, float learning_rate,
-                       float beta1, float beta2, float epsilon, const float *state, float grad_scale,
-                       float *sumsq_part, int blocks, int launches);
-int rlx_adam_rider_flush(void *stream, int *was_pending_host);
 /* How rlx_adam_tf1_step finishes the gradient norm: 2 (default) inside the Adam launch, the workgroup's share held in
  * registers (falls back to 0 beyond 4.2 M parameters); 1: inside the grid-stride Adam launch (any size; measured equal to
  * 0); 0: the separate finish launch.  Process-wide, read at launch / capture time: for same-process A/Bs and tests. */
