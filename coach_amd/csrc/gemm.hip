@@ -2213,6 +2213,13 @@ int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode) {
     return RLX_OK;
 }
 
+int rlx_gemm_tuning_get(int *kw_below_tiles_host, int *kw_min_tiles_host, int *xcd_mode_host) {
+    if (kw_below_tiles_host) *kw_below_tiles_host = g_kw_below_tiles;
+    if (kw_min_tiles_host) *kw_min_tiles_host = g_kw_min_tiles;
+    if (xcd_mode_host) *xcd_mode_host = g_xcd_mode;
+    return RLX_OK;
+}
+
 int rlx_gemm_split_cap(int max_splits) {
     RLX_REQUIRE(max_splits >= 1 && max_splits <= 256, "rlx_gemm_split_cap: 1 <= max_splits <= 256");
     g_split_cap = max_splits;

@@ -132,17 +132,19 @@ DIRECT_CONV_INPUT_GRAD = False
 # tiles with two wave groups per K slab (_kw2_tiling below: rlx_gemm's own rule), because exactly there the fused
 # kernel's sums are bit-identical to theirs.  The tests flip it to compare the two paths.
 FUSE_CONV_PAIR = True
-KW_BELOW_TILES = KW_MIN_TILES = 192        # rlx_gemm_tuning's defaults (csrc/gemm.hip g_kw_below_tiles / g_kw_min_tiles)
 
 
 def _kw2_tiling(M, N, batch):
     """rlx_gemm runs an M x N x K product of `batch` towers on 32 x 64 tiles with the K slab split over two wave groups
-    (csrc/gemm.hip gemm_impl: fewer than KW_BELOW_TILES 64 x 64 tiles, at least KW_MIN_TILES 32 x 64 tiles)."""
+    (csrc/gemm.hip gemm_impl: fewer than kw_below_tiles 64 x 64 tiles, at least kw_min_tiles 32 x 64 tiles — the LIVE
+    values of rlx_gemm_tuning, 192 / 192 unless an A/B tool changed them)."""
     if N <= 32:
         return False
+    below, least = ctypes.c_int(), ctypes.c_int()
+    _rlx.lib().gemm_tuning_get(ctypes.byref(below), ctypes.byref(least), None)
     t64 = -(-M // 64) * -(-N // 64) * batch
     t32 = -(-M // 32) * -(-N // 64) * batch
-    return t64 < KW_BELOW_TILES and t32 >= KW_MIN_TILES
+    return t64 < below.value and t32 >= least.value
 
 
 # The convolution layers' weight-gradient products of a backward pass as ONE launch behind the input-gradient chain

@@ -377,6 +377,9 @@ int rlx_gemm_workspace_floats(int M, int N, int K, int batch, long long *floats_
  * contiguous share per XCD — so that tiles sharing operand rows share an L2.
  * An explicit knob for same-process A/B measurements (tools/ab_c2.py); results are identical either way. */
 int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode);
+/* the current values (NULL: not wanted) — what a caller that mirrors rlx_gemm's tile rule (coach_amd/nn/graph.py
+ * _kw2_tiling: where rlx_conv23_forward is bit-identical to the tiled launches) must read instead of assuming the defaults */
+int rlx_gemm_tuning_get(int *kw_below_tiles, int *kw_min_tiles, int *xcd_mode);
 /* Main loop of the fast tiled kernels: 1 (default) = operand slabs go global -> LDS by DMA into a ring of two buffers,
  * one barrier per slab, three workgroups per CU (csrc/gemm.hip gemm_dma_body); 0 = the register-staged two-set pipeline
  * of rounds 1-3 (128 x 32 tiles always use it); 2 = the ring for uint8 operands too (4-byte requests; measured equal to 1).  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two

@@ -105,3 +105,16 @@ def test_clipped_ppo_update_through_the_fused_pair_is_bit_identical(rlx, dev):
             G.FUSE_CONV_PAIR = True
     assert torch.equal(res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])
+
+
+def test_the_tile_rule_follows_rlx_gemm_tuning(rlx, dev):
+    """_kw2_tiling reads the library's LIVE thresholds: after rlx_gemm_tuning moved them the fused kernel is not taken where
+    the tiled launches no longer run the configuration it reproduces."""
+    from coach_amd.nn import graph as G
+    assert G._kw2_tiling(64 * 81, 64, 2) and G._kw2_tiling(64 * 49, 64, 2)
+    rlx.gemm_tuning(0, 192, -1)                 # (no in-workgroup K split at all)
+    try:
+        assert not G._kw2_tiling(64 * 81, 64, 2)
+    finally:
+        rlx.gemm_tuning(192, 192, -1)
+    assert G._kw2_tiling(64 * 81, 64, 2)
