@@ -540,7 +540,8 @@ def test_kernel_timer_overflow_is_an_error(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,bt", [(4096, 4096, 512, False), (16384, 256, 384, False), (4100, 200, 1000, False),
-                                      (131072, 64, 512, False), (70000, 36, 96, False), (8192, 640, 256, True)])
+                                      (131072, 64, 512, False), (70000, 36, 96, False), (8192, 640, 256, True),
+                                      (33000, 132, 260, False), (16500, 260, 36, True)])
 def test_big_wave_tiles_equal_the_64x64_tiling_bit_for_bit(rlx, dev, M, N, K, bt, request):
     """rlx_gemm_big_tiles: products of hundreds of 128-row tiles run with several accumulator tiles per wave (128 x 128 or
     128 x 64 per workgroup).  Every output element is the same chain over K as on 64 x 64 tiles: torch.equal, bias and
