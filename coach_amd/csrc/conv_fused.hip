@@ -51,11 +51,11 @@ constexpr int kOut2Floats = kOut2Rows * O2 * P2;     // 3 672
 constexpr int kSlabFloats = 32 * 64;                 // one weight slab: 32 k x 64 output channels
 constexpr int kPatchFloats = 32 * 33;
 // weight slabs in the ring (kDepth - 1 requests in flight per lane): a template parameter, rlx_conv23_depth() selects
-constexpr int smem_floats(int depth) { return kIn1Floats + kOut2Floats + depth * kSlabFloats + 8 * kPatchFloats; }
+constexpr int smem_floats(int depth, int patches = 8) { return kIn1Floats + kOut2Floats + depth * kSlabFloats + patches * kPatchFloats; }
 constexpr int kSlabs2 = K2 * K2 * C1 / 32;           // 16
 constexpr int kSlabs3 = K3 * K3 * C2 / 32;           // 18
 static_assert(S2 * (O2 - 1) + K2 == H1 && O2 - K3 + 1 == O3, "geometry");
-static_assert(smem_floats(8) * 4 <= 160 * 1024, "LDS");
+static_assert(smem_floats(8, 8) * 4 <= 160 * 1024 && smem_floats(4, 12) * 4 <= 160 * 1024, "LDS");
 
 struct ConvPairArgs {
     const float *x1; long long x1_ts;                // [T][B * 400][32]  conv1 activations
@@ -85,13 +85,19 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst) {
 }
 
 // kDepth: weight slabs in the ring; S: slabs per sync point (one wait + barrier + S requests per S slabs; kDepth >= 2 S)
-template <int kDepth, int S>
+// KWG: wave groups per K slab of the TILED launches this one reproduces bit for bit — 2: 32 x 64 tiles, k-quads {0, 1} and
+// {2, 3} each in one accumulator, partials added 0 + 1; 4: 32 x 32 tiles, one accumulator per k-quad, added ((0 + 1) + 2) + 3
+// (what rlx_gemm picks for one tower of 64 images, or 32 images x 2 networks: acting, the DQN update).  The 8 waves then carry
+// 2 quad-accumulators each in conv2 and one each in conv3 (all eight busy).
+template <int kDepth, int S, int KWG = 2>
 __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvPairArgs a) {
     static_assert(kDepth >= 2 * S && kSlabs2 % S == 0 && kSlabs3 % S == 0, "ring depth / step");
-    __shared__ __attribute__((aligned(1024))) float smem[smem_floats(kDepth)];     // 105-154 KB static (gfx950: up to 160 KB)
+    static_assert(KWG == 2 || KWG == 4, "two or four wave groups per K slab");
+    constexpr int kPatches = KWG == 2 ? 8 : 12;
+    __shared__ __attribute__((aligned(1024))) float smem[smem_floats(kDepth, kPatches)];     // 105-154 KB static (gfx950: up to 160 KB)
     float *const ring = smem;                                  // (first: the DMA destinations stay 1 KB aligned)
     float *const patches = ring + kDepth * kSlabFloats;
-    float *const in1 = patches + 8 * kPatchFloats;
+    float *const in1 = patches + kPatches * kPatchFloats;
     float *const out2 = in1 + kIn1Floats;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -172,9 +178,10 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         const int oy = p / O2, ox = p - oy * O2;
         const float *const arow = in1 + ((2 * oy) * W1 + 2 * ox) * P1 + 4 * hi;
         const int b_col = wn * 32 + l31;
-        f32x16 acc;
+        constexpr int NACC = KWG == 2 ? 1 : 2;                  // KWG 4: the wave's two k-quads sum separately
+        f32x16 acc, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
         // The slab step is software-pipelined through registers (as gemm.hip's ring loop): while the MFMA chain of slab g
         // runs, the sync point of slab g + 1 and the LDS reads of its operands happen in the MIDDLE of the chain — with the
         // barrier in front of the reads and the MFMAs behind them, the two waves of a SIMD did everything in lockstep
@@ -185,7 +192,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
             const float *bs = ring + (g % kDepth) * kSlabFloats;
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
-                const int q = wk * 2 + qq;
+                const int q = KWG == 2 ? wk * 2 + qq : wk + 2 * qq;      // (KWG 4: quads wk and wk + 2)
                 const float4 v = *reinterpret_cast<const float4 *>(as + 8 * q);
                 av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
 #pragma unroll
@@ -200,9 +207,11 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         };
         auto mfma_half = [&](const float (&av)[S][2][4], const float (&bv)[S][2][4], const int half_) {
 #pragma unroll
-            for (int m = half_ * 4 * S; m < (half_ + 1) * 4 * S; ++m)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m >> 3][(m >> 2) & 1][m & 3], bv[m >> 3][(m >> 2) & 1][m & 3],
-                                                           acc, 0, 0, 0);
+            for (int m = half_ * 4 * S; m < (half_ + 1) * 4 * S; ++m) {
+                const float x = av[m >> 3][(m >> 2) & 1][m & 3], y = bv[m >> 3][(m >> 2) & 1][m & 3];
+                if (NACC == 1 || ((m >> 2) & 1) == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc1, 0, 0, 0);
+            }
         };
         auto do_step = [&](auto cur, const int p, const bool has_next) {
             constexpr int c = decltype(cur)::value;
@@ -229,12 +238,24 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         if (wk == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
+            if (NACC == 2) {                                  // (quad 3's partial: patches 8 .. 11)
+                float *const patch3 = patches + (w + 4) * kPatchFloats;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch3[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc1[r];
+            }
         }
         lds_barrier();
         if (wk == 0) {
             const float *src = patches + (w + 4) * kPatchFloats;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += src[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
+            if (NACC == 2) {                                  // ((q0 + q1) + q2) + q3: q2 is this wave's second accumulator
+                const float *src3 = patches + (w + 8) * kPatchFloats;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += src3[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
+            }
             // C / D layout undone through the wave's own patch: a lane then owns 4 consecutive channels of a position
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
@@ -268,8 +289,9 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
     // ---- conv3: 1 row tile x 2 column tiles x 2 wave groups = 4 wave-jobs (waves 0 .. 3); waves 4 .. 7 keep the weight
     //      stream and the barriers going
     {
-        const bool active = w < 4;
-        const int wk = (w >> 1) & 1, wn = w & 1;
+        const bool active = KWG == 4 || w < 4;                // (KWG 4: eight wave-jobs of one k-quad each)
+        const int wk = KWG == 2 ? (w >> 1) & 1 : w >> 1, wn = w & 1;
+        constexpr int NQ3 = KWG == 2 ? 2 : 1;                   // k-quads per wave and slab
         const int p = min(l31, np3 - 1);
         const int oy = p / O3, ox = p - oy * O3;
         const float *const arow = out2 + (oy * O2 + ox) * P2 + 4 * hi;
@@ -284,8 +306,8 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
             const float *as = arow + (ky * O2 + kx) * P2 + (s3 & 1) * 32;
             const float *bs = ring + (g % kDepth) * kSlabFloats;
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int q = wk * 2 + qq;
+            for (int qq = 0; qq < NQ3; ++qq) {
+                const int q = KWG == 2 ? wk * 2 + qq : wk;
                 const float4 v = *reinterpret_cast<const float4 *>(as + 8 * q);
                 av[qq][0] = v.x; av[qq][1] = v.y; av[qq][2] = v.z; av[qq][3] = v.w;
 #pragma unroll
@@ -297,12 +319,14 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
 #pragma unroll
             for (int j = 0; j < S; ++j) load_ops(kSlabs2 + p * S + j, av[j], bv[j]);
         };
+        // (a step's 4 NQ3 S MFMAs in slab order, quad by quad; first half / second half around the sync point)
         auto mfma_half = [&](const float (&av)[S][2][4], const float (&bv)[S][2][4], const int half_) {
             if (!active) return;
 #pragma unroll
-            for (int m = half_ * 4 * S; m < (half_ + 1) * 4 * S; ++m)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m >> 3][(m >> 2) & 1][m & 3], bv[m >> 3][(m >> 2) & 1][m & 3],
-                                                           acc, 0, 0, 0);
+            for (int m = half_ * 2 * NQ3 * S; m < (half_ + 1) * 2 * NQ3 * S; ++m) {
+                const int j = m / (4 * NQ3), qq = (m / 4) % NQ3, i = m & 3;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][qq][i], bv[j][qq][i], acc, 0, 0, 0);
+            }
         };
         auto do_step = [&](auto cur, const int p, const bool has_next) {
             constexpr int c = decltype(cur)::value;
@@ -326,15 +350,18 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         if (stamp) stamp[4] = wall_clock64();
         float *const patch = patches + w * kPatchFloats;
         lds_barrier();                                             // conv2's patches are no longer read
-        if (active && wk == 1) {
+        if (active && wk >= 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
         }
         lds_barrier();
         if (active && wk == 0) {
-            const float *src = patches + (w + 2) * kPatchFloats;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += src[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
+            for (int q = 1; q < KWG; ++q) {                   // + group 1 (+ group 2 + group 3), in that order
+                const float *src = patches + (w + 2 * q) * kPatchFloats;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += src[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = acc[r];
         }
@@ -378,10 +405,11 @@ int rlx_conv23_forward_supported(int H, int W, int C, int k2, int s2, int c2, in
 int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *w2, long long w2_tower_stride,
                        const float *b2, long long b2_tower_stride, const float *w3, long long w3_tower_stride,
                        const float *b3, long long b3_tower_stride, float *y2, long long y2_tower_stride, float *y3,
-                       long long y3_tower_stride, int batch, int towers, int activation, void *stream) {
+                       long long y3_tower_stride, int batch, int towers, int activation, int wave_groups, void *stream) {
     RLX_REQUIRE(x1 && w2 && b2 && w3 && b3 && y2 && y3, "rlx_conv23_forward: null pointer");
     RLX_REQUIRE(batch >= 1 && towers >= 1 && (long long)batch * towers <= (1 << 20), "rlx_conv23_forward: bad batch / towers");
     RLX_REQUIRE(activation >= 0 && activation <= 2, "rlx_conv23_forward: unknown activation");
+    RLX_REQUIRE(wave_groups == 2 || wave_groups == 4, "rlx_conv23_forward: wave_groups is 2 or 4");
     RLX_REQUIRE((((uintptr_t)x1 | (uintptr_t)w2 | (uintptr_t)b2 | (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)y2 |
                   (uintptr_t)y3) & 15) == 0 &&
                     ((x1_tower_stride | w2_tower_stride | b2_tower_stride | w3_tower_stride | b3_tower_stride |
@@ -392,7 +420,8 @@ int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *
     const unsigned grid = 2u * batch * towers;
     hipStream_t s = rlx::as_stream(stream);
 #define RLX_C23(D, SS) RLX_LAUNCH((conv23_forward_kernel<D, SS>), grid, kThreads, 0, s, a)
-    if (g_step == 2) {
+    if (wave_groups == 4) RLX_LAUNCH((conv23_forward_kernel<4, 2, 4>), grid, kThreads, 0, s, a);
+    else if (g_step == 2) {
         if (g_depth <= 4) RLX_C23(4, 2);
         else if (g_depth == 6) RLX_C23(6, 2);
         else RLX_C23(8, 2);

@@ -134,17 +134,26 @@ DIRECT_CONV_INPUT_GRAD = False
 FUSE_CONV_PAIR = True
 
 
-def _kw2_tiling(M, N, batch):
-    """rlx_gemm runs an M x N x K product of `batch` towers on 32 x 64 tiles with the K slab split over two wave groups
-    (csrc/gemm.hip gemm_impl: fewer than kw_below_tiles 64 x 64 tiles, at least kw_min_tiles 32 x 64 tiles — the LIVE
-    values of rlx_gemm_tuning, 192 / 192 unless an A/B tool changed them)."""
+def _tiled_wave_groups(M, N, batch):
+    """How rlx_gemm would tile an M x N x K product of `batch` towers (csrc/gemm.hip gemm_impl, with the LIVE thresholds of
+    rlx_gemm_tuning: 192 / 192 unless an A/B tool changed them): 2 = 32 x 64 tiles with the K slab split over two wave
+    groups, 4 = 32 x 32 tiles with four, 1 = anything else (64 x 64 tiles, narrow tiles, K split over workgroups)."""
     if N <= 32:
-        return False
+        return 1
     below, least = ctypes.c_int(), ctypes.c_int()
     _rlx.lib().gemm_tuning_get(ctypes.byref(below), ctypes.byref(least), None)
     t64 = -(-M // 64) * -(-N // 64) * batch
-    t32 = -(-M // 32) * -(-N // 64) * batch
-    return t64 < below.value and t32 >= least.value
+    if t64 >= below.value:
+        return 1
+    if -(-M // 32) * -(-N // 64) * batch >= least.value:
+        return 2
+    if -(-M // 32) * -(-N // 32) * batch >= least.value:
+        return 4
+    return 1
+
+
+def _kw2_tiling(M, N, batch):
+    return _tiled_wave_groups(M, N, batch) == 2
 
 
 # The convolution layers' weight-gradient products of a backward pass as ONE launch behind the input-gradient chain
@@ -816,26 +825,34 @@ class Sequential:
     def _fused_conv_pair(self, ctx, i, x, tag, weights, t0, nt, pair):
         """layers i and i + 1 as one launch (rlx_conv23_forward) -> [y_i, y_{i+1}], or None: both convolutions, the
         geometry the kernel is compiled for, fp32 per-tower input, and batch / towers for which the two tiled launches
-        would have summed in the fused kernel's order (FUSE_CONV_PAIR)."""
-        if not FUSE_CONV_PAIR or pair or i + 1 >= len(self.layers):
+        would BOTH have run with two (or both with four) wave groups per K slab — the fused kernel then sums in exactly
+        their order (FUSE_CONV_PAIR).  Two towers of 63 .. 75 images: two groups (the Clipped-PPO minibatch); one tower of
+        64 images or 32 images x (online, target): four (acting; the DQN update)."""
+        if not FUSE_CONV_PAIR or i + 1 >= len(self.layers):
             return None
         a, b = self.layers[i], self.layers[i + 1]
         if not (isinstance(a, Conv2d) and isinstance(b, Conv2d)) or x.u8 or a.act != b.act or a.T != b.T:
             return None
         t0_, T = a._range(t0, nt)
+        p = a.params
+        ws2, bs2, ws3, bs3 = p.stride(a.kname), p.stride(a.bname), p.stride(b.kname), p.stride(b.bname)
+        if pair:          # online and target copy of a one-tower network as two towers (Conv2d.forward pair=True)
+            if a.T != 1 or weights is not None:
+                return None
+            T, ws2, bs2, ws3, bs3 = 2, p.size, p.size, p.size, p.size
         if x.towers != T or not ctx.lib.conv23_forward_supported(a.H, a.W, a.C, a.KH, a.S, a.Co, b.KH, b.S, b.Co):
             return None
         B = x.rows
         M2, M3 = B * a.OH * a.OW, B * b.OH * b.OW
-        if not (_kw2_tiling(M2, a.Co, T) and _kw2_tiling(M3, b.Co, T)):
+        groups = _tiled_wave_groups(M2, a.Co, T)
+        if groups not in (2, 4) or _tiled_wave_groups(M3, b.Co, T) != groups:
             return None
-        p = a.params
         y2 = ctx.buffer(a.name, (T, M2, a.Co), tag=tag)
         y3 = ctx.buffer(b.name, (T, M3, b.Co), tag=tag)
         stream = ctx.stream
-        args = (x.data, x.tower_stride(), p.w(a.kname, t0_, weights), p.stride(a.kname),
-                p.w(a.bname, t0_, weights), p.stride(a.bname), p.w(b.kname, t0_, weights), p.stride(b.kname),
-                p.w(b.bname, t0_, weights), p.stride(b.bname), y2, M2 * a.Co, y3, M3 * b.Co, B, T, _rlx.ACT[a.act], stream)
+        args = (x.data, x.tower_stride(), p.w(a.kname, t0_, weights), ws2, p.w(a.bname, t0_, weights), bs2,
+                p.w(b.kname, t0_, weights), ws3, p.w(b.bname, t0_, weights), bs3, y2, M2 * a.Co, y3, M3 * b.Co, B, T,
+                _rlx.ACT[a.act], groups, stream)
         run = lambda: ctx.lib.conv23_forward(*args)
         if _rlx.GEMM_HOOK is not None:       # bench.py's recorder: the two products this launch stands for
             d2, d3 = _rlx.GemmDesc(), _rlx.GemmDesc()

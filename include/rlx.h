@@ -73,8 +73,8 @@ int rlx_profile_read(int index, const char **name_host, float *ms_host);
 /* The second and third convolution of the Atari torso (embedder "Medium": 64 x 4 x 4 / 2 on 20 x 20 x 32, then 64 x 3 x 3 / 1)
  * as ONE launch: half an image of one tower per workgroup, the second layer's output stays in LDS and feeds the third
  * (tf.layers.conv2d twice, architectures/tensorflow_components/layers.py:108-121).  y2 / y3 receive both layers'
- * activations (the backward pass reads them).  Bit-identical to the two rlx_gemm launches it replaces where those run
- * on 32 x 64 tiles with two wave groups per K slab (coach_amd/csrc/conv_fused.hip).  rlx_conv23_forward_supported: 1 for
+ * activations (the backward pass reads them).  wave_groups = 2 / 4: bit-identical to the two rlx_gemm launches it replaces
+ * where those run on 32 x 64 tiles with two wave groups per K slab / on 32 x 32 tiles with four (coach_amd/csrc/conv_fused.hip).  rlx_conv23_forward_supported: 1 for
  * the geometry the kernel is compiled for. */
 int rlx_conv23_forward_supported(int H, int W, int C, int k2, int s2, int c2, int k3, int s3, int c3);
 /* weight slabs in rlx_conv23_forward's LDS ring (2, 3, 4, 6, 8) and slabs per synchronisation step (1, or 2 with depth
@@ -87,7 +87,7 @@ int rlx_conv23_debug_stamps(void *buffer);
 int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *w2, long long w2_tower_stride,
                        const float *b2, long long b2_tower_stride, const float *w3, long long w3_tower_stride,
                        const float *b3, long long b3_tower_stride, float *y2, long long y2_tower_stride, float *y3,
-                       long long y3_tower_stride, int batch, int towers, int activation, void *stream);
+                       long long y3_tower_stride, int batch, int towers, int activation, int wave_groups, void *stream);
 
 /* --------------------------------------------- prioritized replay (K5 / K6) -- */
 /* Trees are fp64 array-heaps of 2*capacity-1 nodes exactly as the reference's

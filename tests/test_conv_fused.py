@@ -63,14 +63,74 @@ def test_fused_pair_equals_the_two_tiled_launches_bit_for_bit(rlx, dev, act, B, 
     assert float(outs[True][2].abs().max()) > 0.05              # (not a comparison of zeros)
 
 
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+@pytest.mark.parametrize("B,towers", [(64, 1), (32, 2), (36, 2), (70, 1)])
+def test_fused_pair_with_four_wave_groups_equals_the_32x32_tiling_bit_for_bit(rlx, dev, act, B, towers):
+    """One tower of 64 images (acting) or two of 32 (the DQN update's online + target pass): rlx_gemm runs conv2 / conv3 on
+    32 x 32 tiles with FOUR wave groups per K slab, one accumulator per k-quad, summed ((0 + 1) + 2) + 3 — the fused
+    kernel's wave_groups = 4 form reproduces exactly that."""
+    import torch
+    from coach_amd import _rlx
+    from coach_amd.nn import graph as G
+    assert G._tiled_wave_groups(B * 81, 64, towers) == 4 and G._tiled_wave_groups(B * 49, 64, towers) == 4
+    params, torso = _torso(dev, act, 5)
+    obs = torch.from_numpy(np.random.RandomState(6).randint(0, 256, size=(B, 84, 84, 4)).astype(np.uint8)).to(dev)
+    x = G.input_tensor(obs, B, 84 * 84 * 4, u8=True, div=255.0)
+    kw = dict(t0=1, nt=1) if towers == 1 else {}
+    outs, names = {}, {}
+    for fused in (False, True):
+        G.FUSE_CONV_PAIR = fused
+        try:
+            ctx = G.Context(dev)
+            with _rlx.KernelTimer(64) as timer:
+                acts = torso.forward(ctx, x, tag="t", **kw)
+            outs[fused] = [a.data.clone() for a in acts[1:]]
+            names[fused] = [n for n, _ in timer.records]
+        finally:
+            G.FUSE_CONV_PAIR = True
+    assert sum("conv23_forward_kernel<4, 2, 4>" in n for n in names[True]) == 1, names[True]
+    assert any("gemm_dma_kernel" in n for n in names[False]) and not any("conv23" in n for n in names[False])
+    for i, (a, b) in enumerate(zip(outs[True], outs[False])):
+        assert torch.equal(a, b), "layer %d: %d of %d elements differ, max %g" % (
+            i, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
+    assert float(outs[True][2].abs().max()) > 0.05
+
+
+def test_dqn_update_through_the_fused_pair_is_bit_identical(rlx, dev):
+    """DQNNet.learn_from_batch at the C3 shape (B = 32, online + target as the two towers of one pass, relu)."""
+    import torch
+    from coach_amd.nn import graph as G
+    from coach_amd.nn.networks import DQNNet
+    B, A, shape = 32, 4, (84, 84, 4)
+    rng = np.random.RandomState(0)
+    s = torch.from_numpy(rng.randint(0, 256, size=(B,) + shape).astype(np.uint8)).to(dev)
+    s2 = torch.from_numpy(rng.randint(0, 256, size=(B,) + shape).astype(np.uint8)).to(dev)
+    acts = torch.from_numpy(rng.randint(0, A, size=B).astype(np.int32)).to(dev)
+    rew = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
+    done = torch.from_numpy((rng.rand(B) < 0.2).astype(np.uint8)).to(dev)
+    res = {}
+    for fused in (False, True):
+        G.FUSE_CONV_PAIR = fused
+        try:
+            net = DQNNet(dev, shape, A, seed=2)
+            for _ in range(2):
+                net.learn_from_batch(s, s2, B, acts, rew, done, 0.99)
+            net.check_status()
+            res[fused] = (net.params.weights.clone(), net.loss.clone())
+        finally:
+            G.FUSE_CONV_PAIR = True
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+
+
 def test_other_batches_keep_the_tiled_launches(rlx, dev):
-    """where rlx_gemm would pick another tiling (8 images: thin / 32 x 32 tiles) the sums would differ in their last
-    bits — the fused kernel is not taken, and the pinned small-batch trajectories of the other tests do not move."""
+    """where rlx_gemm would pick another tiling (8 images: thin / split K; 256: 64 x 64 tiles) the sums would differ in their
+    last bits — the fused kernel is not taken, and the pinned small-batch trajectories of the other tests do not move."""
     import torch
     from coach_amd import _rlx
     from coach_amd.nn import graph as G
     params, torso = _torso(dev, "tanh", 3)
-    for B in (8, 32, 256):
+    for B in (8, 16, 256):
         obs = torch.from_numpy(np.random.RandomState(4).randint(0, 256, size=(B, 84, 84, 4)).astype(np.uint8)).to(dev)
         ctx = G.Context(dev)
         with _rlx.KernelTimer(64) as timer:

@@ -13,7 +13,10 @@ def test_kw2_tiling_matches_the_documented_batch_window():
     assert (below.value, least.value, xcd.value) == (192, 192, -1)          # rlx_gemm_tuning's defaults
     ok = [B for B in range(1, 200) if G._kw2_tiling(B * 81, 64, 2) and G._kw2_tiling(B * 49, 64, 2)]
     assert ok == list(range(63, 76))            # two towers: 63 .. 75 images (the C2 minibatch of 64 is inside)
-    assert not G._kw2_tiling(64 * 81, 64, 1)    # one tower (acting): rlx_gemm takes 32 x 32 tiles there — not fused
+    assert not G._kw2_tiling(64 * 81, 64, 1)    # one tower (acting): rlx_gemm takes 32 x 32 tiles there ...
+    assert G._tiled_wave_groups(64 * 81, 64, 1) == 4 and G._tiled_wave_groups(64 * 49, 64, 1) == 4    # ... with four wave groups
+    assert G._tiled_wave_groups(32 * 81, 64, 2) == 4 and G._tiled_wave_groups(32 * 49, 64, 2) == 4    # (the DQN update: 32 x 2)
+    assert G._tiled_wave_groups(16 * 49, 64, 2) == 1 and G._tiled_wave_groups(256 * 81, 64, 2) == 1
     assert not G._kw2_tiling(64 * 400, 32, 2)   # N <= 32: the narrow 128 x 32 tiling
     assert lib.conv23_forward_supported(20, 20, 32, 4, 2, 64, 3, 1, 64) == 1
     assert lib.conv23_forward_supported(20, 20, 32, 4, 2, 64, 3, 1, 32) == 0
