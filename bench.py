@@ -745,8 +745,9 @@ def main():
                     help="A/B: the convolution layers' weight gradients as one launch behind the dX chain (nn.graph.MULTI_DW)")
     ap.add_argument("--conv23-depth", type=int, default=None, help="A/B: weight slabs in rlx_conv23_forward's ring")
     ap.add_argument("--conv23-step", type=int, default=2, help="A/B: slabs per synchronisation step of rlx_conv23_forward")
-    ap.add_argument("--fuse-conv", type=int, default=None, choices=[0, 1],
-                    help="A/B: conv2 -> conv3 forward as one launch (nn.graph.FUSE_CONV_PAIR; 1 = the default)")
+    ap.add_argument("--fuse-conv", type=int, default=None, choices=[0, 1, 2],
+                    help="A/B: the torso's forward convolutions as one launch — 0: three tiled launches, 1: conv2 -> conv3 fused "
+                         "(nn.graph.FUSE_CONV_PAIR), 2 = the default: conv1 in front of them too (FUSE_CONV_FIRST)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
                     help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
     ap.add_argument("--episode-length", type=int, default=EP_LEN,
@@ -797,7 +798,7 @@ def main():
         _rlx.lib().conv23_depth(args.conv23_depth, args.conv23_step)
     if args.fuse_conv is not None:
         from coach_amd.nn import graph as _G
-        _G.FUSE_CONV_PAIR = bool(args.fuse_conv)
+        _G.FUSE_CONV_PAIR, _G.FUSE_CONV_FIRST = args.fuse_conv >= 1, args.fuse_conv >= 2
     if args.gemm_pipeline is not None:
         from coach_amd import _rlx
         _rlx.lib().gemm_pipeline(args.gemm_pipeline)
@@ -870,6 +871,10 @@ def main():
                  k["kernel"].endswith("true, true, false, true>")]
         if conv1:
             out["box"]["conv1_forward_in_update_us"] = conv1[0]["avg_us"]
+        # (with conv1 inside the fused forward launch that kernel is gone from the update: the fused launch is the probe)
+        fused = [k for k in roof["update_kernels"] if k["kernel"].startswith("conv23_forward_kernel")]
+        if fused:
+            out["box"]["fused_conv_forward_in_update_us"] = fused[0]["avg_us"]
         if args.shapes:
             for s in shapes:
                 print(json.dumps(s), file=sys.stderr)

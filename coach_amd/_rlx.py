@@ -39,7 +39,8 @@ _CTYPE = {
     "size_t": ctypes.c_size_t,
 }
 
-_VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported"}  # return a value, not an rlx_status
+_VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
+                    "rlx_conv123_forward_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
 
@@ -265,7 +266,7 @@ class SplitkJob(ctypes.Structure):
 
 
 ADAM_TICKET_WORDS = 1056        # rlx.h RLX_ADAM_TICKET_WORDS
-ABI_VERSION = 6                 # rlx_abi_version() of the library this module's structures and buffer sizes match
+ABI_VERSION = 7                 # rlx_abi_version() of the library this module's structures and buffer sizes match
 MAX_SPLITK_JOBS = 8
 
 

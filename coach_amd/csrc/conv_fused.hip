@@ -51,11 +51,19 @@ constexpr int kOut2Floats = kOut2Rows * O2 * P2;     // 3 672
 constexpr int kSlabFloats = 32 * 64;                 // one weight slab: 32 k x 64 output channels
 constexpr int kPatchFloats = 32 * 33;
 // weight slabs in the ring (kDepth - 1 requests in flight per lane): a template parameter, rlx_conv23_depth() selects
-constexpr int smem_floats(int depth, int patches = 8) { return kIn1Floats + kOut2Floats + depth * kSlabFloats + patches * kPatchFloats; }
+// conv1 inside the launch (SPLIT1 > 0): the uint8 frame rows of this half (up to 60 rows x 84 x 4 bytes) + the byte -> float table
+constexpr int H0 = 84, W0 = 84, C0 = 4, K1 = 8, S1 = 4;  // conv1: 8 x 8 stride 4 on 84 x 84 x 4 -> 20 x 20 x 32
+constexpr int kRow0Bytes = W0 * C0;                      // 336
+constexpr int kIn0Floats = (S1 * kIn1Rows + K1 - S1) * kRow0Bytes / 4;      // 60 rows: 5 040
+constexpr int kSlabs1 = K1 * K1 * C0 * C1 / kSlabFloats; // conv1's weights as 4 ring slabs of 64 k x 32 channels
+constexpr int smem_floats(int depth, int patches = 8, bool with1 = false) {
+    return kIn1Floats + kOut2Floats + depth * kSlabFloats + patches * kPatchFloats + (with1 ? kIn0Floats + 256 : 0);
+}
 constexpr int kSlabs2 = K2 * K2 * C1 / 32;           // 16
 constexpr int kSlabs3 = K3 * K3 * C2 / 32;           // 18
 static_assert(S2 * (O2 - 1) + K2 == H1 && O2 - K3 + 1 == O3, "geometry");
-static_assert(smem_floats(8, 8) * 4 <= 160 * 1024 && smem_floats(4, 12) * 4 <= 160 * 1024, "LDS");
+static_assert(S1 * (H1 - 1) + K1 == H0 && kRow0Bytes % 16 == 0 && (H0 * kRow0Bytes) % 16 == 0 && kSlabs1 == 4, "conv1 geometry");
+static_assert(smem_floats(8, 8) * 4 <= 160 * 1024 && smem_floats(4, 12, true) * 4 <= 160 * 1024, "LDS");
 
 struct ConvPairArgs {
     const float *x1; long long x1_ts;                // [T][B * 400][32]  conv1 activations
@@ -67,6 +75,11 @@ struct ConvPairArgs {
     float *y3; long long y3_ts;                      // [T][B * 49][64]
     int B, T, act;
     unsigned long long *stamps;                      // diagnostics (rlx_conv23_debug_stamps): [workgroup][8] 10 ns ticks, or null
+    // conv1 in the same launch (rlx_conv123_forward; x1 is then its OUTPUT)
+    const unsigned char *x0; long long x0_ts;        // [T or 1][B][84][84][4] uint8 frames (x0_ts = 0: the towers share them)
+    const float *w1; long long w1_ts;                // [T][256][32]
+    const float *b1; long long b1_ts;
+    float a_div;                                     // frame byte / a_div = network input (observation rescaling, 255)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -89,12 +102,19 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_dst) {
 // {2, 3} each in one accumulator, partials added 0 + 1; 4: 32 x 32 tiles, one accumulator per k-quad, added ((0 + 1) + 2) + 3
 // (what rlx_gemm picks for one tower of 64 images, or 32 images x 2 networks: acting, the DQN update).  The 8 waves then carry
 // 2 quad-accumulators each in conv2 and one each in conv3 (all eight busy).
-template <int kDepth, int S, int KWG = 2>
+// SPLIT1 > 0: conv1 runs in front, in the same workgroup, from the uint8 frame rows of this half (rlx_conv123_forward) —
+// its 256-long sums in the order of the register-staged tiled kernel that otherwise computes them (gemm_fast_body: slabs of
+// 32 k ascending, MFMA step kk multiplying k = kk and kk + 1): SPLIT1 = 1 one chain per element (the folded two-tower
+// product of the PPO update, 64 x 64 tiles, no K split); SPLIT1 = 3 three chains over k [0, 96), [96, 192), [192, 256)
+// combined as splitk_reduce4_kernel<4> does (what rlx_gemm does on 128 x 32 tiles for 200 of them: acting, the DQN update).
+template <int kDepth, int S, int KWG = 2, int SPLIT1 = 0>
 __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvPairArgs a) {
     static_assert(kDepth >= 2 * S && kSlabs2 % S == 0 && kSlabs3 % S == 0, "ring depth / step");
     static_assert(KWG == 2 || KWG == 4, "two or four wave groups per K slab");
+    static_assert(SPLIT1 == 0 || ((SPLIT1 == 1 || SPLIT1 == 3) && kDepth == 4 && S == 2), "conv1 in front: one or three K chunks, ring 4 / 2");
     constexpr int kPatches = KWG == 2 ? 8 : 12;
-    __shared__ __attribute__((aligned(1024))) float smem[smem_floats(kDepth, kPatches)];     // 105-154 KB static (gfx950: up to 160 KB)
+    constexpr int kPre = SPLIT1 ? kSlabs1 : 0;                 // ring slabs in front of conv2's
+    __shared__ __attribute__((aligned(1024))) float smem[smem_floats(kDepth, kPatches, SPLIT1 > 0)];     // 105-156 KB static (gfx950: up to 160 KB)
     float *const ring = smem;                                  // (first: the DMA destinations stay 1 KB aligned)
     float *const patches = ring + kDepth * kSlabFloats;
     float *const in1 = patches + kPatches * kPatchFloats;
@@ -123,11 +143,17 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
     // once all but its newest kDepth - 2 vector-memory operations are complete (they retire in order; other loads /
     // stores of the lane only make the wait longer).  Requests of non-existent slabs (g >= 34) are still issued — they
     // re-read the last slab into a buffer nobody reads again — so that the count is the same in every step.
-    constexpr int kSlabsAll = kSlabs2 + kSlabs3;
+    // (with conv1 in front: 4 more slabs ahead of them, 64 k x 32 channels each — the same 8 KB, lane tid's 16 bytes at
+    // float 4 tid of the slab in all three weight matrices)
+    constexpr int kSlabsAll = kPre + kSlabs2 + kSlabs3;
+    const float *const w1 = SPLIT1 ? a.w1 + (size_t)t * a.w1_ts : nullptr;
     auto issue = [&](const int g) {
         const int gg = g < kSlabsAll ? g : kSlabsAll - 1;
-        const float *src = gg < kSlabs2 ? w2 + (size_t)(gg * 32 + wrow) * C2 + wcol
-                                        : w3 + (size_t)((gg - kSlabs2) * 32 + wrow) * C3 + wcol;
+        const float *src = gg < kPre + kSlabs2 ? w2 + (size_t)((gg - kPre) * 32 + wrow) * C2 + wcol
+                                               : w3 + (size_t)((gg - kPre - kSlabs2) * 32 + wrow) * C3 + wcol;
+        if constexpr (SPLIT1 > 0) {
+            if (gg < kPre) src = w1 + (size_t)gg * kSlabFloats + tid * 4;
+        }
         dma16(src, ring_lds + (unsigned)(g % kDepth) * (kSlabFloats * 4u));
     };
     // landed(g) for this lane -> its LDS reads of slab g - 1 are complete -> every wave: slab g may be read, the buffer
@@ -161,13 +187,135 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
                                                                // slab wait would make that wait wait for its acknowledgement)
 
     // ---- conv1 activations of rows [r1, r1 + n1) -> in1[position][P1]
-    {
+    float4 y1v[2][4];                                          // (SPLIT1: the conv1 activations this lane stores at the end)
+    unsigned y1mask = 0;
+    if constexpr (SPLIT1 == 0) {
         const float4 *src = reinterpret_cast<const float4 *>(a.x1 + (size_t)t * a.x1_ts +
                                                              ((size_t)img * (H1 * W1) + (size_t)r1 * W1) * C1);
         const int n4 = n1 * W1 * (C1 / 4);
         for (int f = tid; f < n4; f += kThreads) {
             const float4 v = src[f];
             *reinterpret_cast<float4 *>(in1 + (f >> 3) * P1 + (f & 7) * 4) = v;
+        }
+    } else {
+        // ---- conv1 from the frame: rows [4 r1, 4 r1 + 4 n1 + 4) of the image as raw bytes in LDS; an output position's
+        //      patch row ky is 32 CONTIGUOUS bytes there (8 pixels x 4 stacked frames = k 32 ky .. 32 ky + 31).
+        //      9 (8) tiles of 32 positions x 32 channels on the 8 waves: wave w computes tile w.
+        unsigned char *const in0 = reinterpret_cast<unsigned char *>(out2 + kOut2Floats);
+        float *const lut = reinterpret_cast<float *>(in0) + kIn0Floats;
+        const int np1 = n1 * W1;                               // 240 / 280 positions
+        const float4 bias1 = *reinterpret_cast<const float4 *>(a.b1 + (size_t)t * a.b1_ts + (lane & 7) * 4);
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.x0 + (size_t)t * a.x0_ts + (size_t)img * (H0 * kRow0Bytes) +
+                                                               (size_t)(S1 * r1) * kRow0Bytes);
+            const int n16 = (S1 * n1 + K1 - S1) * (kRow0Bytes / 16);
+            for (int f = tid; f < n16; f += kThreads) reinterpret_cast<uint4 *>(in0)[f] = src[f];
+            if (tid < 256) lut[tid] = (float)tid / a.a_div;    // gemm.hip's table: the same division, once per byte value
+        }
+        // tile 8 (the lower half's positions 256 .. 279): one chain -> wave 0 computes it too; three K chunks -> chunk c by
+        // wave 1 + c (the busiest SIMD then issues 128 + 48 MFMAs more than its two tiles instead of 128 more)
+        const bool nine = np1 > 256;
+        int pb[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int p = min((tl ? 8 : w) * 32 + l31, np1 - 1);
+            const int oy = p / W1, ox = p - oy * W1;
+            pb[tl] = (S1 * oy) * kRow0Bytes + (S1 * ox) * C0;
+        }
+        f32x16 ca[SPLIT1], cb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cb[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < SPLIT1; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ca[c][r] = 0.f;
+        // unit u = kernel row ky = k [32 u, 32 u + 32): 16 MFMA steps per tile, step s multiplying k = 32 u + 2 s + hi
+        auto unit = [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            constexpr int chunk = SPLIT1 == 1 ? 0 : u / 3;     // K chunks of 96 = 3 kernel rows
+            const float *bp = ring + ((u >> 1) % kDepth) * kSlabFloats + ((u & 1) * 32 + hi) * C1 + l31;
+            float b[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) b[s] = bp[2 * s * C1];
+            auto tile = [&](const int off, f32x16 &acc) {
+                const uint4 lo = *reinterpret_cast<const uint4 *>(in0 + off + u * kRow0Bytes);
+                const uint4 up = *reinterpret_cast<const uint4 *>(in0 + off + u * kRow0Bytes + 16);
+                const unsigned wd[8] = {lo.x, lo.y, lo.z, lo.w, up.x, up.y, up.z, up.w};
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const unsigned sh = wd[s >> 1] >> (8 * hi);                       // bytes 2 s' + hi of the word
+                    const float x = lut[(s & 1) ? (sh >> 16) & 0xffu : sh & 0xffu];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, b[s], acc, 0, 0, 0);
+                }
+            };
+            tile(pb[0], ca[chunk]);
+            if (nine && w == (SPLIT1 == 1 ? 0 : 1 + chunk)) tile(pb[1], cb);          // (wave-uniform)
+        };
+        sync_point();                                          // (publishes in0 and the table)
+        if (stamp) stamp[6] = wall_clock64();
+        unit(std::integral_constant<int, 0>()); unit(std::integral_constant<int, 1>());
+        unit(std::integral_constant<int, 2>()); unit(std::integral_constant<int, 3>());
+        sync_point();
+        unit(std::integral_constant<int, 4>()); unit(std::integral_constant<int, 5>());
+        unit(std::integral_constant<int, 6>()); unit(std::integral_constant<int, 7>());
+        if (stamp) stamp[7] = wall_clock64();
+        // epilogue, wave by wave through its own patch: (chunk sums as the reduce launch adds them) + bias, activation ->
+        // in1 for conv2, and the rows this half owns ([0, 10) / [10, 20)) kept for the store at the end
+        float *const patch = patches + w * kPatchFloats;
+        const int own1_lo = half ? 10 : 0, own1_hi = half ? 20 : 10;
+        auto finish = [&](const int tile_index, const f32x16 &v, float4 (&keep)[4], const int mask_shift) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = v[r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane;
+                const int rl = idx >> 3, c4 = (idx & 7) * 4;
+                const int pos = tile_index * 32 + rl;
+                if (pos >= np1) continue;
+                const float *sp = patch + rl * 33 + c4;
+                float4 o = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                o.x += bias1.x; o.y += bias1.y; o.z += bias1.z; o.w += bias1.w;
+                o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act);
+                o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
+                *reinterpret_cast<float4 *>(in1 + pos * P1 + c4) = o;
+                const int row = r1 + pos / W1;
+                if (row >= own1_lo && row < own1_hi) {
+                    keep[it] = o;
+                    y1mask |= 1u << (mask_shift + it);
+                }
+            }
+        };
+        // splitk_reduce4_kernel<4> on three partials: thread group q sums 0 + partial q (q = 3: nothing), then
+        // ((s0 + s1) + s2) + s3
+        {
+            f32x16 v = ca[0];
+            if constexpr (SPLIT1 == 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = (((0.f + ca[0][r]) + (0.f + ca[1][r])) + (0.f + ca[2][r])) + 0.f;
+            }
+            finish(w, v, y1v[0], 0);
+        }
+        if constexpr (SPLIT1 == 1) {
+            if (nine && w == 0) finish(8, cb, y1v[1], 4);
+        } else if (nine) {                                     // (workgroup-uniform)
+            __builtin_amdgcn_wave_barrier();
+            if (w >= 1 && w <= 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = cb[r];
+            }
+            lds_barrier();
+            if (w == 0) {
+                f32x16 v;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = ((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31;
+                    v[r] = (((0.f + patches[1 * kPatchFloats + e]) + (0.f + patches[2 * kPatchFloats + e])) +
+                            (0.f + patches[3 * kPatchFloats + e])) + 0.f;
+                }
+                finish(8, v, y1v[1], 4);
+            }
         }
     }
 
@@ -189,7 +337,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         auto load_ops = [&](const int g, float (&av)[2][4], float (&bv)[2][4]) {
             const int ky = g >> 2, kx = g & 3;
             const float *as = arow + (ky * W1 + kx) * P1;
-            const float *bs = ring + (g % kDepth) * kSlabFloats;
+            const float *bs = ring + ((g + kPre) % kDepth) * kSlabFloats;
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int q = KWG == 2 ? wk * 2 + qq : wk + 2 * qq;      // (KWG 4: quads wk and wk + 2)
@@ -304,7 +452,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
             const int s3 = g - kSlabs2, tap = s3 >> 1;
             const int ky = tap / K3, kx = tap - ky * K3;
             const float *as = arow + (ky * O2 + kx) * P2 + (s3 & 1) * 32;
-            const float *bs = ring + (g % kDepth) * kSlabFloats;
+            const float *bs = ring + ((g + kPre) % kDepth) * kSlabFloats;
 #pragma unroll
             for (int qq = 0; qq < NQ3; ++qq) {
                 const int q = KWG == 2 ? wk * 2 + qq : wk;
@@ -381,6 +529,18 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
             }
         }
     }
+    if constexpr (SPLIT1 > 0) {
+        // (x1 is conv1's output here: [T][B * 400][32])
+        float *const y1 = const_cast<float *>(a.x1) + (size_t)t * a.x1_ts + ((size_t)img * (H1 * W1) + (size_t)r1 * W1) * C1;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (y1mask & (1u << (tl * 4 + it))) {
+                    const int idx = it * 64 + lane;
+                    *reinterpret_cast<float4 *>(y1 + (size_t)((tl ? 8 : w) * 32 + (idx >> 3)) * C1 + (idx & 7) * 4) = y1v[tl][it];
+                }
+    }
     {
         float *const y2 = a.y2 + (size_t)t * a.y2_ts + (size_t)img * (O2 * O2) * C2;
 #pragma unroll
@@ -416,7 +576,8 @@ int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *
                       y2_tower_stride | y3_tower_stride) & 3) == 0,
                 "rlx_conv23_forward: operands must be 16-byte aligned");
     ConvPairArgs a{x1, x1_tower_stride, w2, w2_tower_stride, b2, b2_tower_stride, w3, w3_tower_stride, b3, b3_tower_stride,
-                   y2, y2_tower_stride, y3, y3_tower_stride, batch, towers, activation, g_stamps};
+                   y2, y2_tower_stride, y3, y3_tower_stride, batch, towers, activation, g_stamps,
+                   nullptr, 0, nullptr, 0, nullptr, 0, 1.f};
     const unsigned grid = 2u * batch * towers;
     hipStream_t s = rlx::as_stream(stream);
 #define RLX_C23(D, SS) RLX_LAUNCH((conv23_forward_kernel<D, SS>), grid, kThreads, 0, s, a)
@@ -431,6 +592,42 @@ int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *
     else if (g_depth == 8) RLX_C23(8, 1);
     else RLX_C23(4, 1);
 #undef RLX_C23
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_conv123_forward_supported(int H, int W, int C, int k1, int s1, int c1) {
+    return H == H0 && W == W0 && C == C0 && k1 == K1 && s1 == S1 && c1 == C1;
+}
+
+int rlx_conv123_forward(const unsigned char *x0, long long x0_tower_stride, float a_div, const float *w1,
+                        long long w1_tower_stride, const float *b1, long long b1_tower_stride, float *y1,
+                        long long y1_tower_stride, const float *w2, long long w2_tower_stride, const float *b2,
+                        long long b2_tower_stride, const float *w3, long long w3_tower_stride, const float *b3,
+                        long long b3_tower_stride, float *y2, long long y2_tower_stride, float *y3,
+                        long long y3_tower_stride, int batch, int towers, int activation, int wave_groups,
+                        int conv1_chunks, void *stream) {
+    RLX_REQUIRE(x0 && w1 && b1 && y1 && w2 && b2 && w3 && b3 && y2 && y3, "rlx_conv123_forward: null pointer");
+    RLX_REQUIRE(batch >= 1 && towers >= 1 && (long long)batch * towers <= (1 << 20), "rlx_conv123_forward: bad batch / towers");
+    RLX_REQUIRE(activation >= 0 && activation <= 2, "rlx_conv123_forward: unknown activation");
+    RLX_REQUIRE(wave_groups == 2 || wave_groups == 4, "rlx_conv123_forward: wave_groups is 2 or 4");
+    RLX_REQUIRE(conv1_chunks == 1 || conv1_chunks == 3, "rlx_conv123_forward: conv1_chunks is 1 or 3");
+    RLX_REQUIRE(a_div != 0.f, "rlx_conv123_forward: a_div must be non-zero");
+    RLX_REQUIRE((((uintptr_t)x0 | (uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)y1 | (uintptr_t)w2 | (uintptr_t)b2 |
+                  (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)y2 | (uintptr_t)y3) & 15) == 0 &&
+                    (x0_tower_stride & 15) == 0 &&
+                    ((w1_tower_stride | b1_tower_stride | y1_tower_stride | w2_tower_stride | b2_tower_stride |
+                      w3_tower_stride | b3_tower_stride | y2_tower_stride | y3_tower_stride) & 3) == 0,
+                "rlx_conv123_forward: operands must be 16-byte aligned");
+    ConvPairArgs a{y1, y1_tower_stride, w2, w2_tower_stride, b2, b2_tower_stride, w3, w3_tower_stride, b3, b3_tower_stride,
+                   y2, y2_tower_stride, y3, y3_tower_stride, batch, towers, activation, g_stamps,
+                   x0, x0_tower_stride, w1, w1_tower_stride, b1, b1_tower_stride, a_div};
+    const unsigned grid = 2u * batch * towers;
+    hipStream_t s = rlx::as_stream(stream);
+    if (wave_groups == 2 && conv1_chunks == 1) RLX_LAUNCH((conv23_forward_kernel<4, 2, 2, 1>), grid, kThreads, 0, s, a);
+    else if (wave_groups == 2) RLX_LAUNCH((conv23_forward_kernel<4, 2, 2, 3>), grid, kThreads, 0, s, a);
+    else if (conv1_chunks == 1) RLX_LAUNCH((conv23_forward_kernel<4, 2, 4, 1>), grid, kThreads, 0, s, a);
+    else RLX_LAUNCH((conv23_forward_kernel<4, 2, 4, 3>), grid, kThreads, 0, s, a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

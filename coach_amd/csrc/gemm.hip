@@ -2261,6 +2261,10 @@ struct GemmPlan {
     bool a_vec_red, u8, b_vec_red, a_tab;
     int splits, M, N, batch;
     bool allow_fold = false;    // in: towers folded into N may count as tiled_fast (the caller's kernel runs the fold epilogue)
+    // what a launch of this descriptor would be (rlx_gemm_describe): the vector-load tiled kernel or not, its tile, wave
+    // groups per K slab, K chunks over workgroups, chunk length, operands through the LDS-DMA ring or staged by registers
+    bool q_fast = false, q_ring = false;
+    int q_bm = 0, q_bn = 0, q_kw = 0, q_splits = 0, q_kchunk = 0;
 };
 
 int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, hipStream_t s) {
@@ -2516,6 +2520,8 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
         }
     }
     if (plan) {
+        plan->q_fast = fast; plan->q_bm = BM; plan->q_bn = BN; plan->q_kw = KW; plan->q_splits = splits; plan->q_kchunk = kchunk;
+        plan->q_ring = fast && g_dma && (g_dma >= 2 || !d.a_is_u8) && !narrow && (!a_tab || kchunk <= kDmaTabChunk);
         if (fast && ((BM == 64 && BN == 64) || KW > 1) && (!g.fold || plan->allow_fold)) {
             plan->tiled_fast = KW == 1;
             plan->kw = KW;
@@ -2580,6 +2586,16 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
 }  // namespace
 
 extern "C" {
+
+int rlx_gemm_describe(const rlx_gemm_desc *desc, int *out8_host) {
+    RLX_REQUIRE(desc && out8_host, "rlx_gemm_describe: null pointer");
+    GemmPlan plan{};
+    const int rc = gemm_impl(desc, nullptr, &plan, nullptr);
+    if (rc != RLX_OK) return rc;
+    out8_host[0] = plan.q_fast; out8_host[1] = plan.q_bm; out8_host[2] = plan.q_bn; out8_host[3] = plan.q_kw;
+    out8_host[4] = plan.q_splits; out8_host[5] = plan.q_kchunk; out8_host[6] = plan.q_ring; out8_host[7] = plan.thin;
+    return RLX_OK;
+}
 
 int rlx_gemm(const rlx_gemm_desc *d_host, void *stream) {
     tl_row_heads_done = false;

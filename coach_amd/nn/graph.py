@@ -132,6 +132,9 @@ DIRECT_CONV_INPUT_GRAD = False
 # tiles with two wave groups per K slab (_kw2_tiling below: rlx_gemm's own rule), because exactly there the fused
 # kernel's sums are bit-identical to theirs.  The tests flip it to compare the two paths.
 FUSE_CONV_PAIR = True
+# ... and the first convolution in front of them in the same launch (rlx_conv123_forward), where rlx_gemm_describe says its
+# own launch would sum in one of the two orders that kernel reproduces (Sequential._fused_conv_triple)
+FUSE_CONV_FIRST = True
 
 
 def _tiled_wave_groups(M, N, batch):
@@ -569,6 +572,13 @@ class Conv2d(Layer):
         return ctx.cache[key]
 
     def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
+        y, T, args, kw = self.forward_product(ctx, x, tag, weights, t0, nt, pair)
+        _rlx.gemm(*args, **kw)
+        # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
+        return Tensor(y, x.rows, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag), act=self.act)
+
+    def forward_product(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False):
+        """-> (output buffer, towers, _rlx.gemm's positional and keyword arguments) of the layer's forward product."""
         t0, T = self._range(t0, nt)
         B, p = x.rows, self.params
         wstride, bstride = p.stride(self.kname), p.stride(self.bname)
@@ -583,20 +593,17 @@ class Conv2d(Layer):
         if not pair and x.towers == 0 and T > 1 and self.Co % 4 == 0 and self.C % 4 == 0 and FOLD_SHARED_INPUT:
             # the towers convolve the SAME frames: one implicit-im2col GEMM over T*Co output channels
             # gathers (and converts) every patch once instead of T times
-            _rlx.gemm(M, T * self.Co, self.K, x.data, p.w(self.kname, t0, weights), y, a_tabs=(rb, ko),
-                      a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=1, b_strides=(self.Co, 1),
-                      ldc=self.Co, bias=p.w(self.bname, t0, weights), activation=self.act, batch=1,
-                      b_batch_stride=wstride, c_batch_stride=M * self.Co, bias_batch_stride=bstride,
-                      workspace=ctx.ws.splitk, n_fold=self.Co)
-        else:
-            _rlx.gemm(M, self.Co, self.K, x.data, p.w(self.kname, t0, weights), y, a_tabs=(rb, ko),
-                      a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=int(self.C % 4 == 0),
-                      bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
-                      a_batch_stride=x.tower_stride(), b_batch_stride=wstride,
-                      c_batch_stride=M * self.Co, bias_batch_stride=bstride,
-                      workspace=ctx.ws.splitk)
-        # same memory read as [T, B, OH*OW*Co]: flattening (embedder.py:120-121) is free
-        return Tensor(y, B, self.OH * self.OW * self.Co, T, grad_key=(ctx, self.name, tag), act=self.act)
+            return y, T, (M, T * self.Co, self.K, x.data, p.w(self.kname, t0, weights), y), dict(
+                a_tabs=(rb, ko), a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=1, b_strides=(self.Co, 1),
+                ldc=self.Co, bias=p.w(self.bname, t0, weights), activation=self.act, batch=1,
+                b_batch_stride=wstride, c_batch_stride=M * self.Co, bias_batch_stride=bstride,
+                workspace=ctx.ws.splitk, n_fold=self.Co)
+        return y, T, (M, self.Co, self.K, x.data, p.w(self.kname, t0, weights), y), dict(
+            a_tabs=(rb, ko), a_u8=x.u8, a_div=x.div, a_vec_along_k=1, a_tab_vec_ok=int(self.C % 4 == 0),
+            bias=p.w(self.bname, t0, weights), activation=self.act, batch=T,
+            a_batch_stride=x.tower_stride(), b_batch_stride=wstride,
+            c_batch_stride=M * self.Co, bias_batch_stride=bstride,
+            workspace=ctx.ws.splitk)
 
     def _dx_tables(self, ctx, B):
         key = ("convdxtab", self.name, B)
@@ -806,14 +813,15 @@ class Sequential:
         launch where it can (rlx_gemm_desc.row_heads); returns (acts, head outputs) then."""
         acts = [x]
         kw = {"pair": True} if pair else {}
-        skip = -1
+        done = 0                     # layers [0, done) are computed
         for i, l in enumerate(self.layers):
-            if i == skip:
+            if i < done:
                 continue
-            fused = self._fused_conv_pair(ctx, i, acts[-1], tag, weights, t0, nt, pair)
+            fused = (self._fused_conv_triple(ctx, i, acts[-1], tag, weights, t0, nt, pair) or
+                     self._fused_conv_pair(ctx, i, acts[-1], tag, weights, t0, nt, pair))
             if fused is not None:
                 acts.extend(fused)
-                skip = i + 1
+                done = i + len(fused)
                 continue
             if row_heads and i == len(self.layers) - 1:
                 y, heads = l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, row_heads=row_heads, **kw)
@@ -862,6 +870,68 @@ class Sequential:
         run()
         return [Tensor(y2, B, a.OH * a.OW * a.Co, T, grad_key=(ctx, a.name, tag), act=a.act),
                 Tensor(y3, B, b.OH * b.OW * b.Co, T, grad_key=(ctx, b.name, tag), act=b.act)]
+
+    def _fused_conv_triple(self, ctx, i, x, tag, weights, t0, nt, pair):
+        """layers i, i + 1, i + 2 as one launch (rlx_conv123_forward: the first convolution from the uint8 frames in front of
+        the fused pair) -> [y_i, y_{i+1}, y_{i+2}], or None.  On top of _fused_conv_pair's conditions for the last two:
+        rlx_gemm_describe must say that the first layer's own launch would be the register-staged tiled kernel summing
+        K = 256 in one chain (64 x 64 tiles: the two towers of the PPO update folded into N) or in three 96-long chunks
+        on 128 x 32 tiles (one tower of 64 frames, 32 frames x (online, target)) — the two orders the kernel reproduces."""
+        if not (FUSE_CONV_PAIR and FUSE_CONV_FIRST) or i + 2 >= len(self.layers):
+            return None
+        f, a, b = self.layers[i], self.layers[i + 1], self.layers[i + 2]
+        if not all(isinstance(l, Conv2d) for l in (f, a, b)) or not x.u8 or not (f.act == a.act == b.act) or \
+                not (f.T == a.T == b.T):
+            return None
+        t0_, T = f._range(t0, nt)
+        p = f.params
+        if pair:
+            if f.T != 1 or weights is not None:
+                return None
+            T = 2
+        stride = (lambda name: p.size) if pair else p.stride
+        lib = ctx.lib
+        if x.towers not in (0, T) or f.out_hwc != (a.H, a.W, a.C) or a.out_hwc != (b.H, b.W, b.C) or \
+                not lib.conv123_forward_supported(f.H, f.W, f.C, f.KH, f.S, f.Co) or \
+                not lib.conv23_forward_supported(a.H, a.W, a.C, a.KH, a.S, a.Co, b.KH, b.S, b.Co):
+            return None
+        B = x.rows
+        M1, M2, M3 = B * f.OH * f.OW, B * a.OH * a.OW, B * b.OH * b.OW
+        groups = _tiled_wave_groups(M2, a.Co, T)
+        if groups not in (2, 4) or _tiled_wave_groups(M3, b.Co, T) != groups:
+            return None
+        y1, T1, gargs, gkw = f.forward_product(ctx, x, tag, weights, t0, nt, pair)
+        assert T1 == T
+        d1 = _rlx.gemm(*gargs, launch=False, **gkw)
+        q = (ctypes.c_int * 8)()
+        lib.gemm_describe(ctypes.byref(d1), q)
+        fast, bm, bn, kw, splits, kchunk, ring, thin = list(q)
+        if not fast or ring or thin or kw != 1:
+            return None
+        if (bm, bn) not in ((64, 64), (128, 32)):
+            return None
+        if splits == 1:
+            chunks = 1
+        elif splits == 3 and kchunk == 96:       # (<= 16 chunks of a 4-aligned N: splitk_reduce4_kernel<4> adds them)
+            chunks = 3
+        else:
+            return None
+        y2 = ctx.buffer(a.name, (T, M2, a.Co), tag=tag)
+        y3 = ctx.buffer(b.name, (T, M3, b.Co), tag=tag)
+        w = lambda l: p.w(l.kname, t0_, weights)
+        bi = lambda l: p.w(l.bname, t0_, weights)
+        args = (x.data, x.tower_stride(), float(x.div), w(f), stride(f.kname), bi(f), stride(f.bname), y1, M1 * f.Co,
+                w(a), stride(a.kname), bi(a), stride(a.bname), w(b), stride(b.kname), bi(b), stride(b.bname),
+                y2, M2 * a.Co, y3, M3 * b.Co, B, T, _rlx.ACT[f.act], groups, chunks, ctx.stream)
+        run = lambda: lib.conv123_forward(*args)
+        if _rlx.GEMM_HOOK is not None:       # bench.py's recorder: the three products this launch stands for
+            d2, d3 = _rlx.GemmDesc(), _rlx.GemmDesc()
+            d2.M, d2.N, d2.K, d2.batch = M2, a.Co, a.K, T
+            d3.M, d3.N, d3.K, d3.batch = M3, b.Co, b.K, T
+            _rlx._record((d1, d2, d3), run)
+        run()
+        return [Tensor(y, B, l.OH * l.OW * l.Co, T, grad_key=(ctx, l.name, tag), act=l.act)
+                for y, l in ((y1, f), (y2, a), (y3, b))]
 
     def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None, need_dw=True,
                  layers=None):

@@ -88,6 +88,21 @@ int rlx_conv23_forward(const float *x1, long long x1_tower_stride, const float *
                        const float *b2, long long b2_tower_stride, const float *w3, long long w3_tower_stride,
                        const float *b3, long long b3_tower_stride, float *y2, long long y2_tower_stride, float *y3,
                        long long y3_tower_stride, int batch, int towers, int activation, int wave_groups, void *stream);
+/* ... and the FIRST convolution (32 x 8 x 8 / 4 on 84 x 84 x 4 uint8 frames, rescaled by 1 / a_div:
+ * architectures/embedder_parameters.py + observation rescaling filter) in front of them in the same launch: the frame rows
+ * of a half image go to LDS as bytes, conv1's output feeds conv2 from LDS and is also written to y1 (the backward pass reads
+ * it).  x0: [towers or 1][batch][84][84][4] (x0_tower_stride in BYTES, 0 = every tower reads the same frames).
+ * conv1_chunks = 1 / 3: bit-identical to rlx_gemm's conv1 launch where that sums K = 256 in one chain (64 x 64 tiles) / in
+ * three chains over 96-long K chunks combined by its split-K reduce launch (128 x 32 tiles, 200 of them) — with operands
+ * staged by registers (rlx_gemm_describe reports all of that; coach_amd/nn/graph.py asks it before taking this launch). */
+int rlx_conv123_forward_supported(int H, int W, int C, int k1, int s1, int c1);
+int rlx_conv123_forward(const unsigned char *x0, long long x0_tower_stride, float a_div, const float *w1,
+                        long long w1_tower_stride, const float *b1, long long b1_tower_stride, float *y1,
+                        long long y1_tower_stride, const float *w2, long long w2_tower_stride, const float *b2,
+                        long long b2_tower_stride, const float *w3, long long w3_tower_stride, const float *b3,
+                        long long b3_tower_stride, float *y2, long long y2_tower_stride, float *y3,
+                        long long y3_tower_stride, int batch, int towers, int activation, int wave_groups,
+                        int conv1_chunks, void *stream);
 
 /* --------------------------------------------- prioritized replay (K5 / K6) -- */
 /* Trees are fp64 array-heaps of 2*capacity-1 nodes exactly as the reference's
@@ -380,6 +395,12 @@ int rlx_gemm_tuning(int kw_below_tiles, int kw_min_tiles, int xcd_mode);
 /* the current values (NULL: not wanted) — what a caller that mirrors rlx_gemm's tile rule (coach_amd/nn/graph.py
  * _kw2_tiling: where rlx_conv23_forward is bit-identical to the tiled launches) must read instead of assuming the defaults */
 int rlx_gemm_tuning_get(int *kw_below_tiles, int *kw_min_tiles, int *xcd_mode);
+/* What rlx_gemm WOULD launch for this descriptor, without launching: out8 = {vector-load tiled kernel (else: thin / generic
+ * paths, the other fields are then meaningless), tile rows, tile columns, wave groups per K slab, K chunks over workgroups
+ * (> 1: partials + a reduce launch), chunk length, operands through the LDS-DMA ring (0: staged by registers — the order
+ * of the fp32 sum inside a slab differs, see rlx_gemm_pipeline), thin kernel}.  For callers that replace a launch by a
+ * fused one ONLY where the sums stay bit-identical (rlx_conv123_forward). */
+int rlx_gemm_describe(const rlx_gemm_desc *desc, int *out8);
 /* Main loop of the fast tiled kernels: 1 (default) = operand slabs go global -> LDS by DMA into a ring of two buffers,
  * one barrier per slab, three workgroups per CU (csrc/gemm.hip gemm_dma_body); 0 = the register-staged two-set pipeline
  * of rounds 1-3 (128 x 32 tiles always use it); 2 = the ring for uint8 operands too (4-byte requests; measured equal to 1).  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two

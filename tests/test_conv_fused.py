@@ -36,6 +36,8 @@ def test_fused_pair_equals_the_two_tiled_launches_bit_for_bit(rlx, dev, act, B, 
     from coach_amd.nn import graph as G
     rlx.conv23_depth(*depth)
     request.addfinalizer(lambda: rlx.conv23_depth(*DEFAULT_RING))
+    G.FUSE_CONV_FIRST = False                    # (this test: the PAIR kernel in all its ring shapes)
+    request.addfinalizer(lambda: setattr(G, "FUSE_CONV_FIRST", True))
     assert G._kw2_tiling(B * 81, 64, 2) and G._kw2_tiling(B * 49, 64, 2)
     params, torso = _torso(dev, act, 1)
     obs = torch.from_numpy(np.random.RandomState(2).randint(0, 256, size=(B, 84, 84, 4)).astype(np.uint8)).to(dev)
@@ -65,7 +67,7 @@ def test_fused_pair_equals_the_two_tiled_launches_bit_for_bit(rlx, dev, act, B, 
 
 @pytest.mark.parametrize("act", ["tanh", "relu"])
 @pytest.mark.parametrize("B,towers", [(64, 1), (32, 2), (36, 2), (70, 1)])
-def test_fused_pair_with_four_wave_groups_equals_the_32x32_tiling_bit_for_bit(rlx, dev, act, B, towers):
+def test_fused_pair_with_four_wave_groups_equals_the_32x32_tiling_bit_for_bit(rlx, dev, act, B, towers, request):
     """One tower of 64 images (acting) or two of 32 (the DQN update's online + target pass): rlx_gemm runs conv2 / conv3 on
     32 x 32 tiles with FOUR wave groups per K slab, one accumulator per k-quad, summed ((0 + 1) + 2) + 3 — the fused
     kernel's wave_groups = 4 form reproduces exactly that."""
@@ -73,6 +75,8 @@ def test_fused_pair_with_four_wave_groups_equals_the_32x32_tiling_bit_for_bit(rl
     from coach_amd import _rlx
     from coach_amd.nn import graph as G
     assert G._tiled_wave_groups(B * 81, 64, towers) == 4 and G._tiled_wave_groups(B * 49, 64, towers) == 4
+    G.FUSE_CONV_FIRST = False
+    request.addfinalizer(lambda: setattr(G, "FUSE_CONV_FIRST", True))
     params, torso = _torso(dev, act, 5)
     obs = torch.from_numpy(np.random.RandomState(6).randint(0, 256, size=(B, 84, 84, 4)).astype(np.uint8)).to(dev)
     x = G.input_tensor(obs, B, 84 * 84 * 4, u8=True, div=255.0)
@@ -96,8 +100,68 @@ def test_fused_pair_with_four_wave_groups_equals_the_32x32_tiling_bit_for_bit(rl
     assert float(outs[True][2].abs().max()) > 0.05
 
 
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+@pytest.mark.parametrize("B,towers,groups,chunks", [(64, 2, 2, 1), (72, 2, 2, 1), (63, 2, 2, 1), (64, 1, 4, 3), (70, 1, 4, 3),
+                                                    (32, 2, 4, 3), (36, 2, 4, 3)])
+def test_fused_triple_equals_the_tiled_launches_bit_for_bit(rlx, dev, act, B, towers, groups, chunks):
+    """rlx_conv123_forward: conv1 from the uint8 frames in front of the fused pair.  Two towers of 63 .. 75 frames: conv1's own
+    launch sums K = 256 in ONE chain (the towers folded into N, 64 x 64 tiles, no K split); one tower of 64 or two of 32: in
+    THREE chains over 96-long chunks that a reduce launch combines — the kernel reproduces either, every activation of the
+    three layers is bit-identical to the tiled launches' and to the pair kernel's behind a tiled conv1."""
+    import torch
+    from coach_amd import _rlx
+    from coach_amd.nn import graph as G
+    params, torso = _torso(dev, act, 7)
+    obs = torch.from_numpy(np.random.RandomState(8).randint(0, 256, size=(B, 84, 84, 4)).astype(np.uint8)).to(dev)
+    x = G.input_tensor(obs, B, 84 * 84 * 4, u8=True, div=255.0)
+    kw = dict(t0=1, nt=1) if towers == 1 else {}
+    outs, names = {}, {}
+    for mode, (pair, first) in {"tiled": (False, False), "pair": (True, False), "triple": (True, True)}.items():
+        G.FUSE_CONV_PAIR, G.FUSE_CONV_FIRST = pair, first
+        try:
+            ctx = G.Context(dev)
+            with _rlx.KernelTimer(64) as timer:
+                acts = torso.forward(ctx, x, tag="t", **kw)
+            outs[mode] = [a.data.clone() for a in acts[1:]]
+            names[mode] = [n for n, _ in timer.records if not n.startswith("conv_tables")]
+        finally:
+            G.FUSE_CONV_PAIR = G.FUSE_CONV_FIRST = True
+    want = "conv23_forward_kernel<4, 2, %d, %d>" % (groups, chunks)
+    assert sum(want in n for n in names["triple"]) == 1, names["triple"]
+    assert want in names["triple"][0], names["triple"]               # (the FIRST launch of the pass)
+    assert any("splitk_reduce4_kernel" in n for n in names["tiled"][:2]) == (chunks == 3), names["tiled"]
+    assert len(names["triple"]) == len(names["tiled"]) - (3 if chunks == 3 else 2)
+    for mode in ("tiled", "pair"):
+        for i, (a, b) in enumerate(zip(outs["triple"], outs[mode])):
+            assert a.shape == b.shape
+            assert torch.equal(a, b), "%s, layer %d: %d of %d elements differ, max %g" % (
+                mode, i, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
+    assert len(outs["triple"]) == 4 and float(outs["triple"][0].abs().max()) > 0.05
+
+
+def test_the_triple_is_not_taken_where_conv1_sums_in_another_order(rlx, dev):
+    """uint8 operands through the LDS-DMA ring (rlx_gemm_pipeline(2)) pair the k of an MFMA step differently: rlx_gemm_describe
+    reports it and the forward pass keeps conv1's own launch (the pair kernel still follows it)."""
+    import torch
+    from coach_amd import _rlx
+    from coach_amd.nn import graph as G
+    params, torso = _torso(dev, "tanh", 9)
+    obs = torch.from_numpy(np.random.RandomState(10).randint(0, 256, size=(64, 84, 84, 4)).astype(np.uint8)).to(dev)
+    x = G.input_tensor(obs, 64, 84 * 84 * 4, u8=True, div=255.0)
+    rlx.gemm_pipeline(2)
+    try:
+        ctx = G.Context(dev)
+        with _rlx.KernelTimer(64) as timer:
+            torso.forward(ctx, x, tag="t")
+        names = [n for n, _ in timer.records]
+    finally:
+        rlx.gemm_pipeline(1)
+    assert any("gemm_dma_kernel" in n for n in names) and any("conv23_forward_kernel<4, 2>" in n for n in names), names
+
+
 def test_dqn_update_through_the_fused_pair_is_bit_identical(rlx, dev):
-    """DQNNet.learn_from_batch at the C3 shape (B = 32, online + target as the two towers of one pass, relu)."""
+    """DQNNet.learn_from_batch at the C3 shape (B = 32, online(s) + target(s') as the two towers of one pass over the replay
+    buffer's collated [2, B, ...] states — parallel_prediction, dqn_agent.py:86-89 —, relu)."""
     import torch
     from coach_amd.nn import graph as G
     from coach_amd.nn.networks import DQNNet
@@ -105,6 +169,8 @@ def test_dqn_update_through_the_fused_pair_is_bit_identical(rlx, dev):
     rng = np.random.RandomState(0)
     s = torch.from_numpy(rng.randint(0, 256, size=(B,) + shape).astype(np.uint8)).to(dev)
     s2 = torch.from_numpy(rng.randint(0, 256, size=(B,) + shape).astype(np.uint8)).to(dev)
+    both = torch.stack([s, s2]).contiguous()
+    s, s2 = both[0], both[1]
     acts = torch.from_numpy(rng.randint(0, A, size=B).astype(np.int32)).to(dev)
     rew = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
     done = torch.from_numpy((rng.rand(B) < 0.2).astype(np.uint8)).to(dev)
@@ -114,9 +180,14 @@ def test_dqn_update_through_the_fused_pair_is_bit_identical(rlx, dev):
         try:
             net = DQNNet(dev, shape, A, seed=2)
             for _ in range(2):
-                net.learn_from_batch(s, s2, B, acts, rew, done, 0.99)
+                net.learn_from_batch(s, s2, B, acts, rew, done, 0.99, states_pair=both)
             net.check_status()
             res[fused] = (net.params.weights.clone(), net.loss.clone())
+            if fused:                 # (conv1 included: 32 frames x (online, target) = 200 tiles of 128 x 32, three K chunks)
+                from coach_amd import _rlx
+                with _rlx.KernelTimer(256) as timer:
+                    net.learn_from_batch(s, s2, B, acts, rew, done, 0.99, states_pair=both)
+                assert any("conv23_forward_kernel<4, 2, 4, 3>" in n for n, _ in timer.records), [n for n, _ in timer.records]
         finally:
             G.FUSE_CONV_PAIR = True
     assert torch.equal(res[True][0], res[False][0])
