@@ -39,6 +39,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 512;
 constexpr int H1 = 20, W1 = 20, C1 = 32;             // conv1 output = conv2 input
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
                                                                // slab wait would make that wait wait for its acknowledgement)
 
     // ---- conv1 activations of rows [r1, r1 + n1) -> in1[position][P1]
-    float4 y1v[2][4];                                          // (SPLIT1: the conv1 activations this lane stores at the end)
+    float4 y1v[2][4];                                          // (SPLIT1: the conv1 activations this lane stores at the end; [1][0]: tile 8's)
     unsigned y1mask = 0;
     if constexpr (SPLIT1 == 0) {
         const float4 *src = reinterpret_cast<const float4 *>(a.x1 + (size_t)t * a.x1_ts +
@@ -212,44 +213,58 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
             for (int f = tid; f < n16; f += kThreads) reinterpret_cast<uint4 *>(in0)[f] = src[f];
             if (tid < 256) lut[tid] = (float)tid / a.a_div;    // gemm.hip's table: the same division, once per byte value
         }
-        // tile 8 (the lower half's positions 256 .. 279): one chain -> wave 0 computes it too; three K chunks -> chunk c by
-        // wave 1 + c (the busiest SIMD then issues 128 + 48 MFMAs more than its two tiles instead of 128 more)
+        // tile 8 (the lower half's positions 256 .. 279) as four 16 x 16 blocks on waves 0 .. 3 — one per SIMD — with
+        // v_mfma_f32_16x16x4_f32 (lane group g = lane / 16 supplies k = 4 j + g of step j; the same ascending-k chain per
+        // element): the busiest SIMD issues 2 x 8192 + 2048 cycles of MFMA instead of 3 x 8192
         const bool nine = np1 > 256;
+        const int l15 = lane & 15, g4 = lane >> 4;
         int pb[2];
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
-            const int p = min((tl ? 8 : w) * 32 + l31, np1 - 1);
+            const int p = min(tl ? 256 + 16 * ((w >> 1) & 1) + l15 : w * 32 + l31, np1 - 1);
             const int oy = p / W1, ox = p - oy * W1;
             pb[tl] = (S1 * oy) * kRow0Bytes + (S1 * ox) * C0;
         }
-        f32x16 ca[SPLIT1], cb;
+        f32x16 ca[SPLIT1];
+        f32x4 cs[SPLIT1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cb[r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < SPLIT1; ++c)
+        for (int c = 0; c < SPLIT1; ++c) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ca[c][r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[c][r] = 0.f;
+        }
         // unit u = kernel row ky = k [32 u, 32 u + 32): 16 MFMA steps per tile, step s multiplying k = 32 u + 2 s + hi
         auto unit = [&](auto U) {
             constexpr int u = decltype(U)::value;
             constexpr int chunk = SPLIT1 == 1 ? 0 : u / 3;     // K chunks of 96 = 3 kernel rows
-            const float *bp = ring + ((u >> 1) % kDepth) * kSlabFloats + ((u & 1) * 32 + hi) * C1 + l31;
-            float b[16];
+            const float *bs = ring + ((u >> 1) % kDepth) * kSlabFloats + (u & 1) * 32 * C1;
+            {
+                const float *bp = bs + hi * C1 + l31;
+                float b[16];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) b[s] = bp[2 * s * C1];
-            auto tile = [&](const int off, f32x16 &acc) {
-                const uint4 lo = *reinterpret_cast<const uint4 *>(in0 + off + u * kRow0Bytes);
-                const uint4 up = *reinterpret_cast<const uint4 *>(in0 + off + u * kRow0Bytes + 16);
+                for (int s = 0; s < 16; ++s) b[s] = bp[2 * s * C1];
+                const uint4 lo = *reinterpret_cast<const uint4 *>(in0 + pb[0] + u * kRow0Bytes);
+                const uint4 up = *reinterpret_cast<const uint4 *>(in0 + pb[0] + u * kRow0Bytes + 16);
                 const unsigned wd[8] = {lo.x, lo.y, lo.z, lo.w, up.x, up.y, up.z, up.w};
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const unsigned sh = wd[s >> 1] >> (8 * hi);                       // bytes 2 s' + hi of the word
                     const float x = lut[(s & 1) ? (sh >> 16) & 0xffu : sh & 0xffu];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, b[s], acc, 0, 0, 0);
+                    ca[chunk] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, b[s], ca[chunk], 0, 0, 0);
                 }
-            };
-            tile(pb[0], ca[chunk]);
-            if (nine && w == (SPLIT1 == 1 ? 0 : 1 + chunk)) tile(pb[1], cb);          // (wave-uniform)
+            }
+            if (nine && w < 4) {                               // (wave-uniform)
+                const float *bp = bs + g4 * C1 + 16 * (w & 1) + l15;
+                const uint4 lo = *reinterpret_cast<const uint4 *>(in0 + pb[1] + u * kRow0Bytes);
+                const uint4 up = *reinterpret_cast<const uint4 *>(in0 + pb[1] + u * kRow0Bytes + 16);
+                const unsigned wd[8] = {lo.x, lo.y, lo.z, lo.w, up.x, up.y, up.z, up.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = lut[(wd[j] >> (8 * g4)) & 0xffu];                 // byte g of word j: k = 4 j + g
+                    cs[chunk] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, bp[4 * j * C1], cs[chunk], 0, 0, 0);
+                }
+            }
         };
         sync_point();                                          // (publishes in0 and the table)
         if (stamp) stamp[6] = wall_clock64();
@@ -263,11 +278,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         // in1 for conv2, and the rows this half owns ([0, 10) / [10, 20)) kept for the store at the end
         float *const patch = patches + w * kPatchFloats;
         const int own1_lo = half ? 10 : 0, own1_hi = half ? 20 : 10;
-        auto finish = [&](const int tile_index, const f32x16 &v, float4 (&keep)[4], const int mask_shift) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = v[r];
-            __builtin_amdgcn_wave_barrier();
+        auto rows = [&](const int tile_index, float4 (&keep)[4], const int mask_shift) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = it * 64 + lane;
@@ -295,26 +306,41 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = (((0.f + ca[0][r]) + (0.f + ca[1][r])) + (0.f + ca[2][r])) + 0.f;
             }
-            finish(w, v, y1v[0], 0);
-        }
-        if constexpr (SPLIT1 == 1) {
-            if (nine && w == 0) finish(8, cb, y1v[1], 4);
-        } else if (nine) {                                     // (workgroup-uniform)
             __builtin_amdgcn_wave_barrier();
-            if (w >= 1 && w <= 3) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = cb[r];
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31] = v[r];
+            __builtin_amdgcn_wave_barrier();
+            rows(w, y1v[0], 0);
+        }
+        if (nine) {                                            // (workgroup-uniform) tile 8: assembled in patch 0
+            lds_barrier();
+            if (w < 4) {
+                f32x4 v = cs[0];
+                if constexpr (SPLIT1 == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (((0.f + cs[0][r]) + (0.f + cs[1][r])) + (0.f + cs[2][r])) + 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)                      // D: row 4 g + r, column lane % 16 of the block
+                    patches[(16 * ((w >> 1) & 1) + 4 * g4 + r) * 33 + 16 * (w & 1) + l15] = v[r];
             }
             lds_barrier();
-            if (w == 0) {
-                f32x16 v;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int e = ((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + l31;
-                    v[r] = (((0.f + patches[1 * kPatchFloats + e]) + (0.f + patches[2 * kPatchFloats + e])) +
-                            (0.f + patches[3 * kPatchFloats + e])) + 0.f;
+            if (w < 4) {                                       // its 32 x 8 float4: one per lane of waves 0 .. 3
+                const int rl = tid >> 3, c4 = (tid & 7) * 4;
+                const int pos = 256 + rl;
+                if (pos < np1) {
+                    const float *sp = patches + rl * 33 + c4;
+                    float4 o = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                    o.x += bias1.x; o.y += bias1.y; o.z += bias1.z; o.w += bias1.w;
+                    o.x = apply_act(o.x, a.act); o.y = apply_act(o.y, a.act);
+                    o.z = apply_act(o.z, a.act); o.w = apply_act(o.w, a.act);
+                    *reinterpret_cast<float4 *>(in1 + pos * P1 + c4) = o;
+                    const int row = r1 + pos / W1;
+                    if (row >= own1_lo && row < own1_hi) {
+                        y1v[1][0] = o;
+                        y1mask |= 1u << 4;
+                    }
                 }
-                finish(8, v, y1v[1], 4);
             }
         }
     }
@@ -533,13 +559,13 @@ __global__ void __launch_bounds__(kThreads, 2) conv23_forward_kernel(const ConvP
         // (x1 is conv1's output here: [T][B * 400][32])
         float *const y1 = const_cast<float *>(a.x1) + (size_t)t * a.x1_ts + ((size_t)img * (H1 * W1) + (size_t)r1 * W1) * C1;
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-                if (y1mask & (1u << (tl * 4 + it))) {
-                    const int idx = it * 64 + lane;
-                    *reinterpret_cast<float4 *>(y1 + (size_t)((tl ? 8 : w) * 32 + (idx >> 3)) * C1 + (idx & 7) * 4) = y1v[tl][it];
-                }
+        for (int it = 0; it < 4; ++it)
+            if (y1mask & (1u << it)) {
+                const int idx = it * 64 + lane;
+                *reinterpret_cast<float4 *>(y1 + (size_t)(w * 32 + (idx >> 3)) * C1 + (idx & 7) * 4) = y1v[0][it];
+            }
+        if (y1mask & (1u << 4))                                // (tile 8: position 256 + tid / 8)
+            *reinterpret_cast<float4 *>(y1 + (size_t)(256 + (tid >> 3)) * C1 + (tid & 7) * 4) = y1v[1][0];
     }
     {
         float *const y2 = a.y2 + (size_t)t * a.y2_ts + (size_t)img * (O2 * O2) * C2;
