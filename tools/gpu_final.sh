@@ -17,8 +17,10 @@ for w in c1 c3 c4 c5; do timeout 300 python bench.py --workload $w > $O/bench_$w
 timeout 300 python bench.py --force-dist --no-cpu-baseline --no-roofline > $O/bench_c2_force_dist.json 2> $O/bench_c2_force_dist.err
 timeout 400 python bench.py --episode-length 1024 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_c2_L1024.json 2> $O/bench_c2_L1024.err
 timeout 300 python bench.py --fuse-conv 0 --no-cpu-baseline > $O/bench_c2_unfused.json 2> $O/bench_c2_unfused.err
+timeout 300 python bench.py --fuse-conv 1 --no-cpu-baseline > $O/bench_c2_pair_only.json 2> $O/bench_c2_pair_only.err
 python tools/conv23_timeline.py 2>&1 | grep -v amdgpu.ids > $O/conv23_timeline.txt
-for w in c2 c1 c3 c4 c5 c2_force_dist c2_L1024 c2_unfused; do python - <<PY
+python tools/conv23_timeline.py --pair 2>&1 | grep -v amdgpu.ids >> $O/conv23_timeline.txt
+for w in c2 c1 c3 c4 c5 c2_force_dist c2_L1024 c2_unfused c2_pair_only; do python - <<PY
 import json
 try:
     d=json.loads(open('$O/bench_$w.json').read().strip().splitlines()[-1])
