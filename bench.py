@@ -594,13 +594,13 @@ def gemm_roofline(agent, reps=20):
                             "PMC passes of tools/ppo_update_once.py); operands (A as addressed) and results of the %d "
                             "products are %.1fe6 bytes per call" % (n_products, operand_bytes / 1e6 / n),
             "kernel": "gemm_dma_kernel / gemm_dma_pair_kernel (LDS-DMA ring), gemm_fast_kernel (uint8 frames), "
-                      "conv23_forward_kernel (conv2 -> conv3 per half image, conv2's output in LDS) + split-K reduces "
+                      "conv23_forward_kernel (conv1 -> conv2 -> conv3 forward per half image, activations in LDS) + split-K reduces "
                       "(fp32 MFMA 32x32x2): %d products in %d library calls per minibatch update" % (n_products, n),
             "limiter": "measured (profiles/r04_slab_step_ablation.txt, profiles/r05_ab_*.txt): the tiled launches are bound by "
                        "operand delivery — fills in flight from beyond the XCD's L2, every kernel of the update starts cold — "
                        "with the MFMA chain hidden under it; co-resident independent work does not overlap (it lengthens the "
-                       "fills), only fewer bytes through the CUs help: conv23_forward_kernel keeps conv2's output in LDS and "
-                       "runs at 0.46 MFMA-busy; the MFMA peak stays the denominator of frac",
+                       "fills), only fewer bytes through the CUs help: conv23_forward_kernel keeps conv1's and conv2's output in LDS "
+                       "and runs at 0.45 MFMA-busy; the MFMA peak stays the denominator of frac",
             "flops_per_update": total_flops, "flops_per_launch": total_flops / n,
             "avg_launch_us": round(gemm_us / max(gemm_launches, 1), 2),
             "update_us_by_family": fam, "kernel_launches_per_update": round(launches, 1),
