@@ -353,7 +353,7 @@ def run_off_policy(args, device, dist):
 
 
 # ------------------------------------------------------------------------------------- roofline
-GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_")          # kernels that issue (or finish) fp32 MFMA products
+GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_", "conv32_")          # kernels that issue (or finish) fp32 MFMA products
 
 
 def _family(name):
@@ -748,6 +748,8 @@ def main():
     ap.add_argument("--fuse-conv", type=int, default=None, choices=[0, 1, 2],
                     help="A/B: the torso's forward convolutions as one launch — 0: three tiled launches, 1: conv2 -> conv3 fused "
                          "(nn.graph.FUSE_CONV_PAIR), 2 = the default: conv1 in front of them too (FUSE_CONV_FIRST)")
+    ap.add_argument("--fuse-conv-bwd", type=int, default=None, choices=[0, 1],
+                    help="A/B: the input gradients of conv3 / conv2 as one launch (nn.graph.FUSE_CONV_INPUT_GRADS; 1 = default)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
                     help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
     ap.add_argument("--episode-length", type=int, default=EP_LEN,
@@ -799,6 +801,9 @@ def main():
     if args.fuse_conv is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_PAIR, _G.FUSE_CONV_FIRST = args.fuse_conv >= 1, args.fuse_conv >= 2
+    if args.fuse_conv_bwd is not None:
+        from coach_amd.nn import graph as _G
+        _G.FUSE_CONV_INPUT_GRADS = bool(args.fuse_conv_bwd)
     if args.gemm_pipeline is not None:
         from coach_amd import _rlx
         _rlx.lib().gemm_pipeline(args.gemm_pipeline)

@@ -40,7 +40,7 @@ _CTYPE = {
 }
 
 _VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
-                    "rlx_conv123_forward_supported"}  # return a value, not an rlx_status
+                    "rlx_conv123_forward_supported", "rlx_conv32_input_grad_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
 

@@ -135,6 +135,12 @@ FUSE_CONV_PAIR = True
 # ... and the first convolution in front of them in the same launch (rlx_conv123_forward), where rlx_gemm_describe says its
 # own launch would sum in one of the two orders that kernel reproduces (Sequential._fused_conv_triple)
 FUSE_CONV_FIRST = True
+# The input gradients of the third and second convolution in the backward pass as ONE launch with both column matrices in
+# LDS (rlx_conv32_input_grad, csrc/conv_bwd_fused.hip) instead of a dW + dcol pair launch and a col2im launch per layer; the
+# two weight-gradient products then run on their own.  Taken where rlx_gemm_describe says the dcol products would sum in
+# the order that kernel reproduces, and only when there are enough half images (workgroups) to fill the chip.
+FUSE_CONV_INPUT_GRADS = True
+FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = 192
 
 
 def _tiled_wave_groups(M, N, batch):
@@ -933,6 +939,53 @@ class Sequential:
         return [Tensor(y, B, l.OH * l.OW * l.Co, T, grad_key=(ctx, l.name, tag), act=l.act)
                 for y, l in ((y1, f), (y2, a), (y3, b))]
 
+    def _fused_conv_input_grads(self, ctx, acts, i, weights, t0, nt, kw, need_dx_below):
+        """The input gradients of convolution layers i and i - 1 as one launch (rlx_conv32_input_grad: both column matrices
+        stay in LDS), then the two weight-gradient products as launches of their own -> True; or False (nothing done):
+        the geometry the kernel is compiled for, per-tower fp32 activations, enough half images to fill the chip, and
+        rlx_gemm_describe saying that the two dcol products would run on the LDS-DMA ring without a K split — the order of
+        sums the kernel reproduces (FUSE_CONV_INPUT_GRADS)."""
+        b, a = self.layers[i], self.layers[i - 1]
+        if not FUSE_CONV_INPUT_GRADS or not (isinstance(a, Conv2d) and isinstance(b, Conv2d)) or ctx.overlap or \
+                not need_dx_below or a.T != b.T or a.direct_input_grad() or b.direct_input_grad():
+            return False
+        y3, x2, x1 = acts[i + 1], acts[i], acts[i - 1]
+        t0_, T = b._range(t0, nt)
+        B, p, lib = x2.rows, b.params, ctx.lib
+        if x2.towers != T or x1.towers != T or x1.u8 or x2.act != x1.act or a.out_hwc != (b.H, b.W, b.C) or \
+                2 * B * T < FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS or \
+                not lib.conv32_input_grad_supported(a.H, a.W, a.C, a.KH, a.S, a.Co, b.KH, b.S, b.Co):
+            return False
+        M3, M2, M1 = B * b.OH * b.OW, B * a.OH * a.OW, B * a.H * a.W
+        dz3 = y3.grad
+        dz2, dz1 = x2.ensure_grad(), x1.ensure_grad()
+        descs = []
+        for l, M, dz in ((b, M3, dz3), (a, M2, dz2)):        # the dcol products Conv2d.backward would launch
+            dcol = ctx.buffer(l.name + "/dcol", (T, M, l.K))
+            d = _rlx.gemm(M, l.K, l.Co, dz, p.w(l.kname, t0_, weights), dcol, b_strides=(1, l.Co), batch=T,
+                          a_batch_stride=M * l.Co, b_batch_stride=p.stride(l.kname), c_batch_stride=M * l.K,
+                          workspace=ctx.ws.splitk, launch=False)
+            q = (ctypes.c_int * 8)()
+            lib.gemm_describe(ctypes.byref(d), q)
+            fast, bm, bn, kwg, splits, kchunk, ring, thin = list(q)
+            if not (fast and ring and not thin and kwg == 1 and splits == 1):
+                return False
+            descs.append(d)
+        if b.act is not None and not y3.grad_is_dz:
+            lib.act_backward(dz3, y3.data, dz3.numel(), _rlx.ACT[b.act], ctx.stream)
+            y3.grad_is_dz = True
+        args = (dz3, M3 * b.Co, p.w(b.kname, t0_, weights), p.stride(b.kname), x2.data, M2 * a.Co, dz2, M2 * a.Co,
+                p.w(a.kname, t0_, weights), p.stride(a.kname), x1.data, M1 * a.C, dz1, M1 * a.C, B, T,
+                _rlx.ACT[x2.act], ctx.stream)
+        run = lambda: lib.conv32_input_grad(*args)
+        _rlx._record(tuple(descs), run)
+        run()
+        x2.grad_is_dz, x1.grad_is_dz = x2.act is not None, x1.act is not None
+        if kw.get("need_dw", True):
+            for l, x, y in ((b, x2, y3), (a, x1, x2)):
+                l.backward(ctx, x, y, need_dx=False, weights=weights, t0=t0, nt=nt, **kw)
+        return True
+
     def backward(self, ctx, acts, need_input_grad=False, weights=None, t0=0, nt=None, need_dw=True,
                  layers=None):
         """layers=(lo, hi): only layers lo <= i < hi (the data-parallel path runs the last layers
@@ -944,8 +997,14 @@ class Sequential:
             # them, then go out as ONE launch (up to three products) instead of one per layer inside its dW + dX pair
             later = [] if (MULTI_DW and need_dw and ctx.deferred is not None and not ctx.overlap and
                            sum(isinstance(self.layers[i], Conv2d) for i in range(lo, hi)) >= 2) else None
-            for i in reversed(range(lo, hi)):
+            i = hi
+            while i > lo:
+                i -= 1
                 kw = {"overlap": True} if need_dw else {"need_dw": False}
+                if i - 1 >= lo and later is None and \
+                        self._fused_conv_input_grads(ctx, acts, i, weights, t0, nt, kw, i - 1 > 0 or need_input_grad):
+                    i -= 1               # layers i and i - 1 are done
+                    continue
                 if later is not None and isinstance(self.layers[i], Conv2d):
                     kw["dw_later"] = later
                 self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),

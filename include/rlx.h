@@ -104,6 +104,22 @@ int rlx_conv123_forward(const unsigned char *x0, long long x0_tower_stride, floa
                         long long y3_tower_stride, int batch, int towers, int activation, int wave_groups,
                         int conv1_chunks, void *stream);
 
+/* The INPUT-GRADIENT chain of the same two layers in the backward pass as one launch (tf.gradients through the two
+ * tf.layers.conv2d, layers.py:108-121; architecture.py:312-385 accumulate_gradients): per half image of a tower
+ * dcol3 = dz3 W3^T -> dz2 = col2im(dcol3) * act'(y2) -> dcol2 = dz2 W2^T -> dz1 = col2im(dcol2) * act'(y1), both column
+ * matrices in LDS (coach_amd/csrc/conv_bwd_fused.hip).  dz3: gradient at conv3's pre-activation [towers][batch * 49][64];
+ * y2 / y1: the stored activations of conv2 / conv1; dz2 / dz1 (out): gradients at their pre-activations (what the layers'
+ * weight-gradient products read).  Bit-identical to rlx_gemm (dcol) + rlx_col2im per layer where rlx_gemm_describe
+ * reports the LDS-DMA ring without a K split for the dcol products. */
+int rlx_conv32_input_grad_supported(int H, int W, int C, int k2, int s2, int c2, int k3, int s3, int c3);
+int rlx_conv32_input_grad(const float *dz3, long long dz3_tower_stride, const float *w3, long long w3_tower_stride,
+                          const float *y2, long long y2_tower_stride, float *dz2, long long dz2_tower_stride,
+                          const float *w2, long long w2_tower_stride, const float *y1, long long y1_tower_stride,
+                          float *dz1, long long dz1_tower_stride, int batch, int towers, int activation, void *stream);
+/* diagnostics as rlx_conv23_debug_stamps: [8 w + 0 .. 5] = entry, first product's operands staged, its K loop done,
+ * second product's operands staged (= first gather done), its K loop done, exit */
+int rlx_conv32_debug_stamps(void *buffer);
+
 /* --------------------------------------------- prioritized replay (K5 / K6) -- */
 /* Trees are fp64 array-heaps of 2*capacity-1 nodes exactly as the reference's
  * SegmentTree (memories/non_episodic/prioritized_experience_replay.py:43-156);

@@ -1,0 +1,96 @@
+"""The input-gradient chain of the Atari torso's third and second convolution as ONE launch (rlx_conv32_input_grad,
+coach_amd/csrc/conv_bwd_fused.hip: both column matrices stay in LDS) against what it replaces per layer — the dcol product
+inside the dW + dcol pair launch and rlx_col2im (tf.gradients through tf.layers.conv2d,
+architectures/tensorflow_components/layers.py:108-121, architecture.py:312-385).
+
+Every dcol element is the same fp32 MFMA chain over K = 64 and the gathers add the taps in col2im's order, so every
+gradient of a Clipped-PPO minibatch update — and every weight after the Adam step — must be BIT-IDENTICAL."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _update(dev, B, A, act, fused, steps=2):
+    import torch
+    from coach_amd import _rlx
+    from coach_amd.nn import graph as G
+    from coach_amd.nn.networks import ClippedPPONet
+    shape = (84, 84, 4)
+    rng = np.random.RandomState(0)
+    obs = torch.from_numpy(rng.randint(0, 256, size=(B,) + shape).astype(np.uint8)).to(dev)
+    acts = torch.from_numpy(rng.randint(0, A, size=B).astype(np.int32)).to(dev)
+    adv = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
+    vt = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
+    G.FUSE_CONV_INPUT_GRADS = fused
+    try:
+        np.random.seed(1)
+        net = ClippedPPONet(dev, shape, A, seed=2, activation=act)
+        net.update_target(1.0)
+        old = net.policy_probs(obs, B, use_target=True, tag="old")
+        for _ in range(steps - 1):
+            net.forward_backward(obs, B, acts, adv, vt, old)
+            net.finish_update(1.0)
+        with _rlx.KernelTimer(128) as timer:
+            net.forward_backward(obs, B, acts, adv, vt, old)
+        grads = net.params.grads.clone()
+        net.finish_update(1.0)
+        net.check_status()
+        return grads, net.params.weights.clone(), net.scalars.clone(), [n for n, _ in timer.records]
+    finally:
+        G.FUSE_CONV_INPUT_GRADS = True
+
+
+@pytest.mark.parametrize("B", [64, 72, 63])
+def test_fused_input_gradient_chain_is_bit_identical_in_a_ppo_update(rlx, dev, B):
+    import torch
+    ref = _update(dev, B, 6, "tanh", False)
+    new = _update(dev, B, 6, "tanh", True)
+    assert sum("conv32_input_grad_kernel" in n for n in new[3]) == 1, new[3]
+    assert not any("conv32" in n for n in ref[3]) and sum("col2im" in n for n in ref[3]) == 2, ref[3]
+    assert not any("col2im" in n for n in new[3]), new[3]
+    g0, g1 = ref[0], new[0]
+    assert torch.equal(g0, g1), "%d of %d gradient elements differ, max %g" % (
+        int((g0 != g1).sum()), g0.numel(), float((g0 - g1).abs().max()))
+    assert torch.equal(ref[1], new[1]) and torch.equal(ref[2], new[2])
+    assert float(g0.abs().max()) > 0
+
+
+def test_small_batches_keep_the_per_layer_launches(rlx, dev):
+    """fewer half images than workgroups the chip wants (FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS): the pair launches stay"""
+    new = _update(dev, 32, 4, "tanh", True)
+    assert not any("conv32" in n for n in new[3]) and sum("col2im" in n for n in new[3]) == 2, new[3]
+
+
+def test_the_kernel_alone_against_gemm_and_col2im(rlx, dev):
+    """rlx_conv32_input_grad on random operands (relu derivative: exact zeros and ones) against rlx_gemm + rlx_col2im."""
+    import torch
+    from coach_amd import _rlx
+    B, T = 20, 2
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dz3, w3, w2 = rnd(T, B * 49, 64), rnd(T, 576, 64) * 0.1, rnd(T, 512, 64) * 0.1
+    y2, y1 = torch.relu(rnd(T, B * 81, 64)), torch.relu(rnd(T, B * 400, 32))
+    lib, s = rlx, _rlx.current_stream()
+    ws = torch.empty(1 << 22, device=dev)
+    outs = {}
+    for act, code in (("relu", _rlx.ACT["relu"]), ("tanh", _rlx.ACT["tanh"])):
+        yy2, yy1 = (y2, y1) if act == "relu" else (torch.tanh(y2 - 0.5), torch.tanh(y1 - 0.5))
+        dcol3 = torch.empty(T, B * 49, 576, device=dev)
+        _rlx.gemm(B * 49, 576, 64, dz3, w3, dcol3, b_strides=(1, 64), batch=T, a_batch_stride=B * 49 * 64,
+                  b_batch_stride=576 * 64, c_batch_stride=B * 49 * 576, workspace=ws)
+        dz2 = torch.empty(T, B * 81, 64, device=dev)
+        lib.col2im(dcol3, dz2, yy2, code, T * B, 9, 9, 64, 3, 3, 1, s)
+        dcol2 = torch.empty(T, B * 81, 512, device=dev)
+        _rlx.gemm(B * 81, 512, 64, dz2, w2, dcol2, b_strides=(1, 64), batch=T, a_batch_stride=B * 81 * 64,
+                  b_batch_stride=512 * 64, c_batch_stride=B * 81 * 512, workspace=ws)
+        dz1 = torch.empty(T, B * 400, 32, device=dev)
+        lib.col2im(dcol2, dz1, yy1, code, T * B, 20, 20, 32, 4, 4, 2, s)
+        f2, f1 = torch.full_like(dz2, float("nan")), torch.full_like(dz1, float("nan"))
+        lib.conv32_input_grad(dz3, B * 49 * 64, w3, 576 * 64, yy2, B * 81 * 64, f2, B * 81 * 64, w2, 512 * 64,
+                              yy1, B * 400 * 32, f1, B * 400 * 32, B, T, code, s)
+        torch.cuda.synchronize()
+        for name, a, b in (("dz2", dz2, f2), ("dz1", dz1, f1)):
+            assert torch.equal(a, b), "%s %s: %d of %d elements differ, max %g" % (
+                act, name, int((a != b).sum()), a.numel(), float((a - b).abs().nan_to_num(1e9).max()))
+        assert float(dz1.abs().max()) > 0
