@@ -749,7 +749,7 @@ def main():
                     help="A/B: the torso's forward convolutions as one launch — 0: three tiled launches, 1: conv2 -> conv3 fused "
                          "(nn.graph.FUSE_CONV_PAIR), 2 = the default: conv1 in front of them too (FUSE_CONV_FIRST)")
     ap.add_argument("--fuse-conv-bwd", type=int, default=None, choices=[0, 1],
-                    help="A/B: the input gradients of conv3 / conv2 as one launch (nn.graph.FUSE_CONV_INPUT_GRADS; 1 = default)")
+                    help="A/B: the input gradients of conv3 / conv2 as one launch (nn.graph.FUSE_CONV_INPUT_GRADS; 0 = default)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
                     help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
     ap.add_argument("--episode-length", type=int, default=EP_LEN,

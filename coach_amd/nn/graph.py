@@ -139,7 +139,10 @@ FUSE_CONV_FIRST = True
 # LDS (rlx_conv32_input_grad, csrc/conv_bwd_fused.hip) instead of a dW + dcol pair launch and a col2im launch per layer; the
 # two weight-gradient products then run on their own.  Taken where rlx_gemm_describe says the dcol products would sum in
 # the order that kernel reproduces, and only when there are enough half images (workgroups) to fill the chip.
-FUSE_CONV_INPUT_GRADS = True
+# OFF: bit-identical, but only -2 us per C2 update (profiles/r05_ab_conv32.txt): the launch takes 32.5 us against
+# 2 x (9.7 us of dcol inside the pair launch + 7.6 us of col2im), because the weight-gradient products it leaves behind
+# cost 14 us each on their own.  Entry point, tests and A/B flag (bench.py --fuse-conv-bwd 1) stay.
+FUSE_CONV_INPUT_GRADS = False
 FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = 192
 
 

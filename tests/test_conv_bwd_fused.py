@@ -38,7 +38,7 @@ def _update(dev, B, A, act, fused, steps=2):
         net.check_status()
         return grads, net.params.weights.clone(), net.scalars.clone(), [n for n, _ in timer.records]
     finally:
-        G.FUSE_CONV_INPUT_GRADS = True
+        G.FUSE_CONV_INPUT_GRADS = False                      # (the default: profiles/r05_ab_conv32.txt)
 
 
 @pytest.mark.parametrize("B", [64, 72, 63])

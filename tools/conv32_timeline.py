@@ -13,6 +13,9 @@ import torch
 from coach_amd import _rlx
 from coach_amd.nn.networks import ClippedPPONet
 
+from coach_amd.nn import graph as _G
+
+_G.FUSE_CONV_INPUT_GRADS = True          # (off by default: profiles/r05_ab_conv32.txt)
 lib = _rlx.lib()
 dev = torch.device("cuda:0")
 B, A, shape = 64, 6, (84, 84, 4)

@@ -19,5 +19,5 @@ except Exception as e:
     print('$1', 'ERR', e); print(open('$O/bench_$1.err').read()[-1500:])
 PY
 }
-run c2_bwd_fused "--steps 10 --warmup 3"
+run c2_bwd_fused "--steps 10 --warmup 3 --fuse-conv-bwd 1"
 run c2_bwd_pairs "--steps 10 --warmup 3 --fuse-conv-bwd 0"
