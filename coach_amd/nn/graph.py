@@ -901,6 +901,7 @@ class Sequential:
         stride = (lambda name: p.size) if pair else p.stride
         lib = ctx.lib
         if x.towers not in (0, T) or f.out_hwc != (a.H, a.W, a.C) or a.out_hwc != (b.H, b.W, b.C) or \
+                x.data.data_ptr() % 16 or x.tower_stride() % 16 or \
                 not lib.conv123_forward_supported(f.H, f.W, f.C, f.KH, f.S, f.Co) or \
                 not lib.conv23_forward_supported(a.H, a.W, a.C, a.KH, a.S, a.Co, b.KH, b.S, b.Co):
             return None
