@@ -27,7 +27,15 @@
 // host side (coach_amd/nn/graph.py) takes this kernel only where the tiled path would have run that configuration, so a
 // network's trajectory does not move by a bit (tests/test_conv_fused.py compares the two paths with torch.equal).
 //
-// LDS (105 KB, one workgroup per CU): conv1 rows [position][32 + 4 pad] (the pad spreads the 16-byte operand reads of
+// WITH conv1 IN FRONT (rlx_conv123_forward, template parameter SPLIT1 > 0): the same workgroup first computes the conv1
+// rows it needs from the uint8 frame rows of its half image (52 / 60 rows x 336 bytes in LDS, bytes -> float through
+// gemm.hip's 256-entry table, W1 through the same ring), writes them to the LDS image conv2 reads and the rows it owns to
+// memory — in the order of sums of the register-staged tiled kernel that otherwise computes them (one chain over K = 256,
+// or three 96-long chunks combined as the split-K reduce launch combines them).  8 / 9 position tiles on 8 waves; the ninth
+// as four 16 x 16 blocks on four SIMDs (v_mfma_f32_16x16x4_f32: the same ascending-k chain, at half the issue rate).
+// 35.8 us against 21.3 + 19.3 us in the PPO update.
+//
+// LDS (105 KB, one workgroup per CU; 139 - 156 KB with conv1 in front): conv1 rows [position][32 + 4 pad] (the pad spreads the 16-byte operand reads of
 // lanes that are 2 input columns apart over the banks), conv2 output [position][64 + 4], a ring of two 8 KB weight slabs
 // filled by global_load_lds_dwordx4 (one 16-byte request per lane per slab, 512 lanes = 32 k x 64 n), 8 wave patches of
 // 32 x 33 for the partial-tile exchange and the 16-byte epilogue.
