@@ -95,6 +95,10 @@ class ClippedPPOAgent(object):
     ragged = False          # envs end their episodes on different steps (set per instance from the env)
     _device_env = True
     restarts_memory_on_reset = True     # reset_internal_state() also restarts the rollout buffer's frame stack
+    # an acting step's small launches merged: softmax + categorical draw (rlx_softmax_categorical_sample); reward filter +
+    # episode totals + the action / reward / game_over columns (rlx_rollout_observe_step).  12 -> 9 launches per vector step
+    # of the image agent; the flag is for same-process A/Bs and the tests that compare both forms
+    FUSE_ACTING_LAUNCHES = True
     DATASET_CHUNK = 2048    # rows per forward pass of the whole-dataset passes (V(s) for GAE, the old policy): 256 -> 2048 is -1.0 ms per C2 iteration (profiles/r04_ab_ppo_chunk.txt)
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
@@ -291,12 +295,17 @@ class ClippedPPOAgent(object):
             else:
                 self.actions.copy_(mean)
         else:
-            probs = self.networks["main"].policy_probs(states, self.n_env)
-            if self.phase == RunPhase.TRAIN:
-                self.lib.categorical_sample(probs, self.A, self.uniforms_all[0 if self.ragged else step], self.n_env, self.A,
-                                            self.actions, s)                # categorical.py:45-48
+            if self.phase == RunPhase.TRAIN and self.FUSE_ACTING_LAUNCHES:
+                # softmax + categorical draw (categorical.py:45-48) as one launch
+                self.networks["main"].policy_probs(states, self.n_env,
+                                                   sample=(self.uniforms_all[0 if self.ragged else step], self.actions))
             else:
-                self.lib.argmax_rows(probs, self.A, self.n_env, self.A, self.actions, s)     # :50-56
+                probs = self.networks["main"].policy_probs(states, self.n_env)
+                if self.phase == RunPhase.TRAIN:
+                    self.lib.categorical_sample(probs, self.A, self.uniforms_all[0 if self.ragged else step], self.n_env,
+                                                self.A, self.actions, s)        # categorical.py:45-48
+                else:
+                    self.lib.argmax_rows(probs, self.A, self.n_env, self.A, self.actions, s)     # :50-56
         if self._device_env:
             # device-resident env: the launch is part of the (captured) step, its host clock ticks in act()
             self.env.launch_step()
@@ -306,6 +315,16 @@ class ClippedPPOAgent(object):
             next_obs, reset_obs, reward, game_over = self.env.step(self.actions)
         has_clip = alg.reward_clipping is not None
         lo, hi = alg.reward_clipping if has_clip else (0.0, 0.0)
+        if self.FUSE_ACTING_LAUNCHES and self.n_env <= 1024:
+            # reward filter -> episode totals -> the step's action / reward / game_over columns: one launch
+            m = self.memory
+            row0 = step * self.n_env
+            self.lib.rollout_observe_step(reward, self.filtered_reward, float(alg.reward_rescale), int(has_clip), float(lo),
+                                          float(hi), game_over, self.ep_return, self.ep_len, self.ep_acc, None, None,
+                                          self.actions, self.actions.element_size() * (self.actions.numel() // self.n_env),
+                                          m.action, m.reward, m.game_over, row0, m.cap, self.n_env, m.status, s)
+            m.store_step_at(step, self.actions, self.filtered_reward, game_over, next_obs, reset_obs, columns=False)
+            return
         self.lib.reward_filter(reward, self.filtered_reward, self.n_env, alg.reward_rescale,
                                int(has_clip), lo, hi, s)
         self.lib.episode_stats_step(self.filtered_reward, game_over, self.ep_return, self.ep_len,

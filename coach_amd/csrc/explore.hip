@@ -39,6 +39,39 @@ __global__ void categorical_sample_kernel(const float *__restrict__ probs, long 
     actions[e] = idx < n_actions ? idx : n_actions - 1;
 }
 
+// softmax of the policy head's logits (tf.nn.softmax, ppo_head.py:108: losses.hip softmax_kernel's arithmetic, one row per
+// thread) and the categorical draw above on the probabilities it just produced, in ONE launch: what an acting step of
+// Clipped PPO does with the head's output.  probs_out may be null (acting needs only the action).
+__global__ void softmax_categorical_sample_kernel(const float *__restrict__ logits, long long ld,
+                                                  const double *__restrict__ u, int n_env, int n_actions,
+                                                  float *__restrict__ probs_out, long long ld_out,
+                                                  int *__restrict__ actions) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_env) return;
+    const float *z = logits + (size_t)e * ld;
+    float mx = z[0];
+    for (int j = 1; j < n_actions; ++j) mx = fmaxf(mx, z[j]);
+    float s = 0.f;
+    for (int j = 0; j < n_actions; ++j) s += expf(z[j] - mx);
+    double total = 0.0;
+    for (int j = 0; j < n_actions; ++j) {
+        const float pj = expf(z[j] - mx) / s;
+        if (probs_out) probs_out[(size_t)e * ld_out + j] = pj;
+        total += (double)pj;                              // cumsum()[-1]
+    }
+    const double uu = u[e];
+    double c = 0.0;
+    int idx = n_actions;                                  // searchsorted(..., side='right')
+    for (int j = 0; j < n_actions; ++j) {
+        c += (double)(expf(z[j] - mx) / s);
+        if (uu < c / total) {                             // first j with cdf[j] > u
+            idx = j;
+            break;
+        }
+    }
+    actions[e] = idx < n_actions ? idx : n_actions - 1;
+}
+
 // explore_u[e]   = the policy's current_random_value (np.random.rand())
 // random_act[e]  = action_space.sample() drawn by the host for exploring envs (ignored otherwise)
 // tie_rand[e][a] = np.random.random(action_values.shape) for greedy envs
@@ -120,6 +153,17 @@ int rlx_categorical_sample(const float *probs, long long ld, const double *unifo
     RLX_REQUIRE(probs && uniforms && actions, "rlx_categorical_sample: null pointer");
     RLX_REQUIRE(n_env > 0 && n_actions > 0 && ld >= n_actions, "rlx_categorical_sample: bad shape");
     RLX_LAUNCH((categorical_sample_kernel), (n_env + 63) / 64, 64, 0, rlx::as_stream(stream), probs, ld, uniforms, n_env, n_actions, actions);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_softmax_categorical_sample(const float *logits, long long ld, const double *uniforms, int n_env,
+                                   int n_actions, float *probs_out, long long ld_out, int *actions, void *stream) {
+    RLX_REQUIRE(logits && uniforms && actions, "rlx_softmax_categorical_sample: null pointer");
+    RLX_REQUIRE(n_env > 0 && n_actions > 0 && ld >= n_actions && (!probs_out || ld_out >= n_actions),
+                "rlx_softmax_categorical_sample: bad shape");
+    RLX_LAUNCH((softmax_categorical_sample_kernel), (n_env + 63) / 64, 64, 0, rlx::as_stream(stream), logits, ld, uniforms,
+               n_env, n_actions, probs_out, ld_out, actions);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -273,6 +273,24 @@ __device__ __forceinline__ void observe_copy_rows(const unsigned char *__restric
     }
 }
 
+// The same for a lockstep ROLLOUT buffer (Clipped PPO's acting step): reward filter -> episode totals -> the step's action /
+// filtered reward / game_over columns at rows [row0, row0 + n_env) (the frames go through rlx_imgreplay_append, vector
+// observations through their own copy).  Uses ObserveArgs with dst_rows = null and the column pointers already at row0.
+__global__ void __launch_bounds__(1024) rollout_observe_kernel(const ObserveArgs a) {
+    for (int e = threadIdx.x; e < a.n_env; e += blockDim.x) {
+        double r = (double)a.reward_in[e] * a.rescale;
+        if (a.use_hi) r = fmin(r, a.hi);
+        if (a.use_lo) r = fmax(r, a.lo);
+        a.reward_out[e] = (float)r;
+    }
+    __syncthreads();
+    episode_stats_body(a.reward_out, a.done, a.ep_return, a.ep_len, a.n_env, a.acc, a.last_return, a.last_len);
+    observe_copy_rows(a.actions, a.mem_action, a.action_row_bytes, a.n_env, nullptr, a.mem_rows, a.status);
+    observe_copy_rows(reinterpret_cast<const unsigned char *>(a.reward_out), a.mem_reward, 4, a.n_env, nullptr, a.mem_rows,
+                      a.status);
+    observe_copy_rows(a.stored_done, a.mem_done, 1, a.n_env, nullptr, a.mem_rows, a.status);
+}
+
 __global__ void __launch_bounds__(1024) observe_step_kernel(const ObserveArgs a) {
     for (int e = threadIdx.x; e < a.n_env; e += blockDim.x) {
         double r = (double)a.reward_in[e] * a.rescale;
@@ -485,6 +503,37 @@ int rlx_episode_stats_step(const float *reward, const unsigned char *game_over, 
     int threads = n_env >= 1024 ? 1024 : 64;
     while (threads < n_env && threads < 1024) threads <<= 1;
     RLX_LAUNCH((episode_stats_kernel), 1, threads, 0, rlx::as_stream(stream), reward, game_over, ep_return, ep_len, n_env, acc, last_return, last_len);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_rollout_observe_step(const float *reward, float *filtered_reward, double reward_rescale, int has_clip,
+                             double clip_low, double clip_high, const unsigned char *game_over, double *ep_return,
+                             int *ep_len, double *acc, double *last_return, int *last_len, const void *actions,
+                             long long action_row_bytes, void *mem_action, float *mem_reward,
+                             unsigned char *mem_game_over, long long row0, long long mem_rows, int n_env, int *status,
+                             void *stream) {
+    RLX_REQUIRE(reward && filtered_reward && game_over && ep_return && ep_len && acc,
+                "rlx_rollout_observe_step: null reward / episode-statistics pointer");
+    RLX_REQUIRE(actions && action_row_bytes > 0 && mem_action && mem_reward && mem_game_over && status,
+                "rlx_rollout_observe_step: null column pointer");
+    RLX_REQUIRE(n_env > 0 && n_env <= 1024, "rlx_rollout_observe_step: 1 <= n_env <= 1024 (got %d)", n_env);
+    RLX_REQUIRE(row0 >= 0 && mem_rows > 0, "rlx_rollout_observe_step: bad rows");
+    ObserveArgs a{};
+    a.reward_in = reward; a.reward_out = filtered_reward; a.rescale = reward_rescale;
+    a.use_hi = has_clip && clip_high != 0.0; a.hi = clip_high;        // (a bound equal to 0 is not applied: rlx_reward_filter)
+    a.use_lo = has_clip && clip_low != 0.0; a.lo = clip_low;
+    a.done = game_over; a.stored_done = game_over;
+    a.ep_return = ep_return; a.ep_len = ep_len; a.acc = acc; a.last_return = last_return; a.last_len = last_len;
+    a.actions = static_cast<const unsigned char *>(actions); a.action_row_bytes = action_row_bytes;
+    a.mem_action = static_cast<unsigned char *>(mem_action) + row0 * action_row_bytes;
+    a.mem_reward = reinterpret_cast<unsigned char *>(mem_reward + row0);
+    a.mem_done = mem_game_over + row0;
+    a.dst_rows = nullptr; a.mem_rows = mem_rows - row0;               // rows left from row0: beyond -> status bit 1
+    a.status = status; a.n_env = n_env;
+    int threads = n_env >= 1024 ? 1024 : 64;                          // (rlx_episode_stats_step's: the same reduction tree)
+    while (threads < n_env && threads < 1024) threads <<= 1;
+    RLX_LAUNCH((rollout_observe_kernel), 1, threads, 0, rlx::as_stream(stream), a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -140,16 +140,19 @@ class DeviceEpisodicRolloutBuffer(object):
         self.store_step_at(self.steps, actions, rewards, game_overs, next_obs, reset_obs)
         self.steps += 1
 
-    def store_step_at(self, step, actions, rewards, game_overs, next_obs, reset_obs):
-        """Device work of store_step for an explicit step index (hipGraph-capturable: no host state)."""
+    def store_step_at(self, step, actions, rewards, game_overs, next_obs, reset_obs, columns=True):
+        """Device work of store_step for an explicit step index (hipGraph-capturable: no host state).
+        columns=False: the action / reward / game_over columns of this step are already written
+        (rlx_rollout_observe_step); only the observations are stored here."""
         s = _rlx.current_stream()
         row0 = step * self.n_env
-        pairs = [(actions, self.action), (rewards, self.reward), (game_overs, self.game_over)]
+        pairs = [(actions, self.action), (rewards, self.reward), (game_overs, self.game_over)] if columns else []
         if not self.image:
             pairs.append((self.cur_state, self.obs))
             pairs.append((next_obs, self.next_obs))          # the env's response (the terminal observation at an episode end)
-        self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), None, None, 0, row0, self.n_env,
-                              self.cap, self.n_env, self.status, s)
+        if pairs:
+            self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), None, None, 0, row0, self.n_env,
+                                  self.cap, self.n_env, self.status, s)
         if self.image:
             self.lib.imgreplay_append(self.ring, self.fpos, self.epoff, self.t_fpos, self.t_epoff,
                                       next_obs, reset_obs, game_overs, self.n_env, self.F, self.fb,

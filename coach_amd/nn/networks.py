@@ -151,8 +151,9 @@ class ClippedPPONet(_NetBase):
         self.norm = self.scalars[5:6]
 
     # ---- inference -------------------------------------------------------------------------
-    def policy_probs(self, obs, B, use_target=False, tag="act", out=None):
-        """softmax(policy_fc(policy tower(obs)))  — target weights = the frozen 'old policy'."""
+    def policy_probs(self, obs, B, use_target=False, tag="act", out=None, sample=None):
+        """softmax(policy_fc(policy tower(obs)))  — target weights = the frozen 'old policy'.
+        sample=(uniforms [B] fp64, actions [B] int32 out): draw the actions in the same launch and return None."""
         w = self.target if use_target else None
         if self.HEADS_FORWARD_WITH_TORSO and self.pi_head.N <= G.SMALL_N and self.torso.layers[-1].N > G.SMALL_N:
             acts, (logits,) = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w, t0=1, nt=1,
@@ -160,6 +161,12 @@ class ClippedPPONet(_NetBase):
         else:
             acts = self.torso.forward(self.ctx, self.obs_tensor(obs, B), tag=tag, weights=w, t0=1, nt=1)
             logits = self.pi_head.forward(self.ctx, acts[-1], tag=tag, weights=w)
+        if sample is not None:
+            # acting: the categorical draw in the softmax launch (rlx_softmax_categorical_sample); the probabilities
+            # themselves are not needed by anyone
+            uniforms, actions = sample
+            self.lib.softmax_categorical_sample(logits.data, self.A, uniforms, B, self.A, None, 0, actions, self.ctx.stream)
+            return None
         probs = out if out is not None else self.ctx.buffer("probs", (B, self.A), tag=tag)
         self.lib.softmax(logits.data, self.A, B, self.A, probs, self.A, self.ctx.stream)
         return probs

@@ -261,6 +261,15 @@ typedef struct rlx_observe_desc {
     int n_env;
 } rlx_observe_desc;
 int rlx_observe_step(const rlx_observe_desc *desc_host, void *stream);
+/* The same for a lockstep rollout buffer (ClippedPPOAgent's acting step, agents/agent.py:905-973 + the episodic memory's
+ * store): rlx_reward_filter -> rlx_episode_stats_step -> the step's action / filtered reward / game_over columns at rows
+ * [row0, row0 + n_env) as ONE launch (frames go through rlx_imgreplay_append).  status bit 1: a row beyond mem_rows. */
+int rlx_rollout_observe_step(const float *reward, float *filtered_reward, double reward_rescale, int has_clip,
+                             double clip_low, double clip_high, const unsigned char *game_over, double *ep_return,
+                             int *ep_len, double *acc, double *last_return, int *last_len, const void *actions,
+                             long long action_row_bytes, void *mem_action, float *mem_reward,
+                             unsigned char *mem_game_over, long long row0, long long mem_rows, int n_env, int *status,
+                             void *stream);
 
 /* --------------------------------------------------- agent targets (K7 / K10) -- */
 /* td_targets holds Q_online(s,.) on entry (fp32 [batch, n_actions]); column actions[i] of row i is
@@ -723,6 +732,10 @@ int rlx_sac_policy_head_backward(const float *mu_logsig, long long ld, const dou
 /* -------------------------------------------------------- exploration policies -- */
 int rlx_categorical_sample(const float *probs, long long ld, const double *uniforms, int n_env,
                            int n_actions, int *actions, void *stream); /* exploration_policies/categorical.py:45-48 */
+/* rlx_softmax (tf.nn.softmax of the policy head's logits, heads/ppo_head.py:108) + rlx_categorical_sample on the
+ * probabilities it produces, as ONE launch — the acting step of discrete Clipped PPO.  probs_out may be NULL. */
+int rlx_softmax_categorical_sample(const float *logits, long long ld, const double *uniforms, int n_env,
+                                   int n_actions, float *probs_out, long long ld_out, int *actions, void *stream);
 int rlx_argmax_rows(const float *values, long long ld, int n_rows, int n_cols, int *out,
                     void *stream);            /* np.argmax per row: exploration_policies/categorical.py:50-52 */
 int rlx_egreedy(const float *q_values, long long ld, const double *explore_uniforms,
