@@ -291,19 +291,9 @@ class DQNAgent(VectorOffPolicyAgent):
         return loss if k else None
 
 
-class DDQNAgentParameters(DQNAgentParameters):           # ddqn_agent.py:24-34
-    def __init__(self):
-        super().__init__()
-        # Double DQN's own defaults: slower target copies, lower final / evaluation epsilon
-        self.algorithm.num_steps_between_copying_online_weights_to_target = EnvironmentSteps(30000)
-        self.exploration.epsilon_schedule = LinearSchedule(1, 0.01, 1000000)
-        self.exploration.evaluation_epsilon = 0.001
-
-    @property
-    def path(self):
-        return 'coach_amd.agents.dqn_agent:DDQNAgent'
-
-
-class DDQNAgent(DQNAgent):
-    """select_actions = argmax of the ONLINE network at s' (ddqn_agent.py:43)."""
-    double_dqn = True
+def __getattr__(name):
+    # Double DQN lives in ddqn_agent.py, as in the reference; older imports of it from this module keep working
+    if name in ("DDQNAgent", "DDQNAgentParameters"):
+        from . import ddqn_agent
+        return getattr(ddqn_agent, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

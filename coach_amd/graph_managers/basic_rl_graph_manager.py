@@ -11,14 +11,7 @@ import importlib
 import time
 
 from ..core_types import EnvironmentEpisodes, EnvironmentSteps, RunPhase, TrainingSteps
-
-
-class ScheduleParameters(object):                        # base_parameters.py:589-601
-    def __init__(self):
-        self.heatup_steps = EnvironmentSteps(0)
-        self.evaluation_steps = EnvironmentEpisodes(0)
-        self.steps_between_evaluation_periods = EnvironmentSteps(10000)
-        self.improve_steps = TrainingSteps(10000000000)
+from .graph_manager import ScheduleParameters  # noqa: F401  (presets import it from either module)
 
 
 def dynamic_import(path):

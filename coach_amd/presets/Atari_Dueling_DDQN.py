@@ -9,7 +9,7 @@ shortened from the reference's 50 M-step `atari_schedule` to a smoke-sized run.
 """
 import math
 
-from coach_amd.agents.dqn_agent import DDQNAgentParameters
+from coach_amd.agents.ddqn_agent import DDQNAgentParameters
 from coach_amd.architectures.head_parameters import DuelingQHeadParameters
 from coach_amd.core_types import EnvironmentEpisodes, EnvironmentSteps
 from coach_amd.environments.synthetic_vector_environment import SyntheticVectorEnvironmentParameters

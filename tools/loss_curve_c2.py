@@ -124,13 +124,31 @@ def oracle_side(args):
     np.random.set_state(st["numpy"])
     res, acts = [], []
     out = os.path.join(args.dir, "oracle_ulp.npz" if args.perturb_ulp else "oracle.npz")
+    forced = None
+    if args.follow_hip_actions:
+        # SAME INPUTS for all 100 k steps: the oracle draws its own uniform numbers (the host stream stays aligned) and
+        # samples its own action, but RECORDS the action the device took at that vector step — the synthetic env ignores
+        # actions, so the recorded transition is the only place an action enters.  Both engines then train on identical
+        # histories to the end, and what is compared is f_device(history) against f_oracle(history), not two samples of
+        # a stochastic process.  The oracle's own samples are kept (`own_actions`): where they differ from the device's
+        # is where a free run would have forked.
+        forced = np.load(os.path.join(args.dir, "hip.npz"))["actions"]
+        out = os.path.join(args.dir, "oracle_forced_ulp.npz" if args.perturb_ulp else "oracle_forced.npz")
+    own = []
     t0 = time.perf_counter()
     for it in range(st["iterations"]):
         for _ in range(PLAYING // N_ENV):
             a, _ = o.act()
+            if forced is not None:
+                own.append(np.array(a, dtype=np.int8))
+                a = [int(x) for x in forced[len(acts)]]
+                for e in range(N_ENV):
+                    t = o.transitions[e][-1]
+                    o.transitions[e][-1] = (t[0], a[e]) + tuple(t[2:])
             acts.append(np.array(a, dtype=np.int8))
         res.append(np.array(o.train(), dtype=np.float64))
-        np.savez_compressed(out, results=np.array(res), actions=np.array(acts), seconds=time.perf_counter() - t0)
+        np.savez_compressed(out, results=np.array(res), actions=np.array(acts), own_actions=np.array(own),
+                            seconds=time.perf_counter() - t0)
         print("oracle iteration %d / %d  (%.0f s)  %s" % (it + 1, st["iterations"], time.perf_counter() - t0,
                                                           np.round(res[-1].mean(0), 5)), flush=True)
 
@@ -233,6 +251,65 @@ def ensemble(args):
                                     s_["within_1_percent_in_every_window"], s_["within_two_standard_errors_in_every_window"]))
 
 
+def forced_report(args):
+    """hip.npz against oracle_forced.npz (--follow-hip-actions) for each seed in --seeds: both engines trained on the
+    SAME action history for the whole run.  Per signal: the largest relative difference of a per-epoch mean loss, of a
+    per-iteration mean and of a window mean (the statistic the free-running ensembles use), and how it develops
+    (first / middle / last seventh of the run); plus how many of the oracle's own samples differed from the device's."""
+    seeds = [int(x) for x in args.seeds.split(",")]
+    W = args.window
+    out = {"workload": "C2: Clipped PPO, %d vectorized envs, 84x84x4 uint8 observations, rollout %d, minibatch %d; the oracle "
+                       "records the device's action at every vector step (identical histories on both sides)"
+                       % (N_ENV, PLAYING, B), "window_iterations": W, "seeds": {}}
+    worst = {nm: 0.0 for nm in NAMES}
+    for sd in seeds:
+        d = os.path.join(args.dir, "seed%d" % sd)
+        f = os.path.join(d, "oracle_forced.npz")
+        if not os.path.exists(f):
+            continue
+        h, o = np.load(os.path.join(d, "hip.npz")), np.load(f)
+        with open(os.path.join(d, "rng_state.pkl"), "rb") as fh:
+            st = pickle.load(fh)
+        n = min(len(h["results"]), len(o["results"]))
+        if n == 0:
+            continue
+        hr, orr = h["results"][:n], o["results"][:n]                # [iteration, epoch, signal]
+        steps = n * (PLAYING // N_ENV)
+        assert np.array_equal(h["actions"][:steps], o["actions"][:steps])
+        own = o["own_actions"][:steps]
+        flips = np.nonzero((own != h["actions"][:steps]).any(1))[0]
+        rec = {"iterations": n, "env_steps": n * PLAYING, "epochs_per_rollout": st["epochs"],
+               "updates": n * st["epochs"] * (PLAYING // B),
+               "oracle_own_samples_that_differ": int((own != h["actions"][:steps]).sum()),
+               "of": int(own.size), "first_vector_step_where_they_differ": int(flips[0]) if flips.size else None,
+               "seconds_oracle_cpu": float(o["seconds"]), "signals": {}}
+        for j, nm in enumerate(NAMES):
+            den = np.maximum(np.abs(orr[:, :, j]), 1e-12)
+            rel_e = np.abs(hr[:, :, j] - orr[:, :, j]) / den                        # per epoch
+            hi, oi = hr[:, :, j].mean(1), orr[:, :, j].mean(1)
+            rel_i = np.abs(hi - oi) / np.maximum(np.abs(oi), 1e-12)                 # per iteration
+            k = n // W * W
+            sig = {"max_rel_diff_per_epoch": float(rel_e.max()), "max_rel_diff_per_iteration": float(rel_i.max()),
+                   "rel_diff_per_iteration": [float("%.3g" % x) for x in rel_i]}
+            if k:
+                hw, ow = hi[:k].reshape(-1, W).mean(1), oi[:k].reshape(-1, W).mean(1)
+                rel_w = np.abs(hw - ow) / np.maximum(np.abs(ow), 1e-12)
+                sig["rel_diff_per_window"] = [float("%.3g" % x) for x in rel_w]
+                sig["max_rel_diff_per_window"] = float(rel_w.max())
+            worst[nm] = max(worst[nm], sig["max_rel_diff_per_iteration"])
+            rec["signals"][nm] = sig
+        out["seeds"][str(sd)] = rec
+    out["max_rel_diff_per_iteration_over_all_seeds"] = worst
+    out["within_1_percent_at_every_iteration_of_every_seed"] = bool(all(v <= 0.01 for v in worst.values()))
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+    for sd, rec in out["seeds"].items():
+        print("seed %s: %d iterations; oracle's own samples differing: %d / %d; max rel diff per iteration: %s"
+              % (sd, rec["iterations"], rec["oracle_own_samples_that_differ"], rec["of"],
+                 {nm: "%.2e" % rec["signals"][nm]["max_rel_diff_per_iteration"] for nm in NAMES}))
+    print("within 1 % at every iteration of every seed:", out["within_1_percent_at_every_iteration_of_every_seed"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0, help="agent seed (weights, host streams); the env seed is 1234 + seed")
@@ -251,10 +328,16 @@ def main():
                     help="oracle side: only check that rebuild_init equals the device side's init.npz")
     ap.add_argument("--perturb-ulp", action="store_true",
                     help="oracle side: start from weights one ulp away in one element per tower (-> oracle_ulp.npz)")
+    ap.add_argument("--follow-hip-actions", action="store_true",
+                    help="oracle side: record the device's actions (hip.npz) instead of the oracle's own samples "
+                         "(-> oracle_forced.npz): identical histories on both sides for the whole run")
+    ap.add_argument("--forced", action="store_true", help="compare / ensemble: hip.npz against oracle_forced.npz")
     ap.add_argument("--first", default="hip.npz",
                     help="compare: the run set against oracle.npz (oracle_ulp.npz = the oracle against itself)")
     args = ap.parse_args()
-    if args.ensemble:
+    if args.forced:
+        forced_report(args)
+    elif args.ensemble:
         ensemble(args)
     elif args.compare:
         compare(args)
