@@ -750,6 +750,9 @@ def main():
                          "(nn.graph.FUSE_CONV_PAIR), 2 = the default: conv1 in front of them too (FUSE_CONV_FIRST)")
     ap.add_argument("--fuse-acting", type=int, default=None, choices=[0, 1],
                     help="A/B (c2): an acting step's small launches merged (ClippedPPOAgent.FUSE_ACTING_LAUNCHES; 1 = default)")
+    ap.add_argument("--record-acting", type=int, default=None, choices=[0, 1],
+                    help="A/B (c2): the acting steps leave V(s) and the action probabilities in the rollout — no whole-dataset "
+                         "value / old-policy pass (ClippedPPOAgent.RECORD_WHILE_ACTING; 1 = default)")
     ap.add_argument("--fuse-conv-bwd", type=int, default=None, choices=[0, 1],
                     help="A/B: the input gradients of conv3 / conv2 as one launch (nn.graph.FUSE_CONV_INPUT_GRADS; 0 = default)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
@@ -803,6 +806,9 @@ def main():
     if args.fuse_conv is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_PAIR, _G.FUSE_CONV_FIRST = args.fuse_conv >= 1, args.fuse_conv >= 2
+    if args.record_acting is not None:
+        from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent as _A2
+        _A2.RECORD_WHILE_ACTING = bool(args.record_acting)
     if args.fuse_acting is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent as _A
         _A.FUSE_ACTING_LAUNCHES = bool(args.fuse_acting)

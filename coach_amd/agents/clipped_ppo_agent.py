@@ -99,6 +99,13 @@ class ClippedPPOAgent(object):
     # episode totals + the action / reward / game_over columns (rlx_rollout_observe_step).  12 -> 9 launches per vector step
     # of the image agent; the flag is for same-process A/Bs and the tests that compare both forms
     FUSE_ACTING_LAUNCHES = True
+    # discrete image agent: an acting step runs BOTH towers and leaves V(s) and the action probabilities in two rollout
+    # columns (ClippedPPONet.act_and_record) — the weights do not change between a rollout and its training phase and the
+    # old policy of that phase is the acting policy, so the V(s) pass over the whole dataset and the old-policy pass of
+    # fill_advantages recompute exactly those numbers; with the columns recorded they are two gathers.  The value
+    # tower rides in the same launches as the policy tower (the fused convolution launch has a workgroup per half image
+    # and tower: 128 -> 256 of the chip's 256 CUs).  The flag is for same-process A/Bs and the equivalence test
+    RECORD_WHILE_ACTING = True
     DATASET_CHUNK = 2048    # rows per forward pass of the whole-dataset passes (V(s) for GAE, the old policy): 256 -> 2048 is -1.0 ms per C2 iteration (profiles/r04_ab_ppo_chunk.txt)
 
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
@@ -159,6 +166,7 @@ class ClippedPPOAgent(object):
             frame_shape=ep.observation_shape if self.image else None, stack=self.stack,
             obs_dim=None if self.image else int(ep.observation_shape[0]),
             action_dim=self.A if self.continuous else None)
+        self._rec_missing = False       # a stored step of the current rollout was NOT recorded (another phase / path)
         dev, n = self.device, self.n_env
         self.actions = torch.zeros((n, self.A), dtype=torch.float32, device=dev) if self.continuous else \
             torch.zeros(n, dtype=torch.int32, device=dev)
@@ -169,6 +177,7 @@ class ClippedPPOAgent(object):
             from ..filters.observation import ObservationNormalizationFilter
             self.norm = ObservationNormalizationFilter(int(ep.observation_shape[0]), dev)
             self.act_obs = torch.empty(n, int(ep.observation_shape[0]), dtype=torch.float32, device=dev)
+        self._records_acting()          # allocates the rollout's V(s) / probability columns where they are used
         if self.continuous:
             lo = np.broadcast_to(np.asarray(ep.action_low, dtype=np.float32), (self.A,)).copy()
             hi = np.broadcast_to(np.asarray(ep.action_high, dtype=np.float32), (self.A,)).copy()
@@ -295,7 +304,12 @@ class ClippedPPOAgent(object):
             else:
                 self.actions.copy_(mean)
         else:
-            if self.phase == RunPhase.TRAIN and self.FUSE_ACTING_LAUNCHES:
+            if self.phase == RunPhase.TRAIN and self._records_acting():
+                m, r0 = self.memory, step * self.n_env
+                self.networks["main"].act_and_record(states, self.n_env, self.uniforms_all[0 if self.ragged else step],
+                                                     self.actions, m.act_value[r0:r0 + self.n_env],
+                                                     m.act_probs[r0:r0 + self.n_env])
+            elif self.phase == RunPhase.TRAIN and self.FUSE_ACTING_LAUNCHES:
                 # softmax + categorical draw (categorical.py:45-48) as one launch
                 self.networks["main"].policy_probs(states, self.n_env,
                                                    sample=(self.uniforms_all[0 if self.ragged else step], self.actions))
@@ -331,11 +345,22 @@ class ClippedPPOAgent(object):
                                     self.n_env, self.ep_acc, None, None, s)
         self.memory.store_step_at(step, self.actions, self.filtered_reward, game_over, next_obs, reset_obs)
 
+    def _records_acting(self):
+        """V(s) and the action probabilities are recorded by the acting step (RECORD_WHILE_ACTING): the discrete image
+        agent without an observation-normalisation filter (that filter's statistics move between acting and training,
+        clipped_ppo_agent.py:320-322, so its V(s) pass is NOT a recomputation)."""
+        rec = self.RECORD_WHILE_ACTING and self.image and not self.continuous and self.norm is None
+        if rec and not hasattr(self.memory, "act_value"):
+            self.memory.enable_policy_columns(self.A)
+        return rec
+
     def act(self):
         """One vector step: observe -> act -> env.step (LevelManager.step, level_manager.py:215-269)."""
         step = self.memory.steps
         if step >= self.memory.T:
             raise ValueError("rollout buffer is full; call train()")
+        if not (self.phase == RunPhase.TRAIN and self._records_acting()):
+            self._rec_missing = True            # this step's rows carry no recorded V(s) / probabilities
         if self.ragged and self.phase == RunPhase.TRAIN:
             self._uniforms.push(np.random.standard_normal((1, self.n_env, self.A)) if self.continuous
                                 else np.random.random_sample((1, self.n_env)))
@@ -496,7 +521,7 @@ class ClippedPPOAgent(object):
             return True
         return False
 
-    def _fill_advantages_device(self, n, rows, n_train=None):
+    def _fill_advantages_device(self, n, rows, n_train=None, recorded=False):
         """n_train: the transitions the phase trains on (dataset[:num_steps], :330-331) — the only ones whose old-policy
         outputs are read.  With episodes longer than the playing phase (L = 1024, 64 envs: a dataset of 65 536
         transitions, 2 048 trained on) the old-policy pass over the whole dataset would be 32 x the work the
@@ -504,8 +529,10 @@ class ClippedPPOAgent(object):
         mem, net, alg = self.memory, self.networks["main"], self.ap.algorithm
         n_train = n if n_train is None else min(n, n_train)
         s = _rlx.current_stream()
-        mem.gather_columns(rows, n, [(mem.reward, self.ds_reward), (mem.game_over, self.ds_done),
-                                     (mem.action, self.ds_action)])
+        cols = [(mem.reward, self.ds_reward), (mem.game_over, self.ds_done), (mem.action, self.ds_action)]
+        if recorded:       # V(s) and the old policy's probabilities were left in the rollout by the acting steps
+            cols += [(mem.act_value, self.ds_value), (mem.act_probs, self.ds_old_probs)]
+        mem.gather_columns(rows, n, cols)
         if self.norm is not None:
             # pre_network_filter over the whole dataset, statistics updated first (:320-322)
             mem.gather_states(rows, n, self.ds_obs_raw[:n])
@@ -521,7 +548,7 @@ class ClippedPPOAgent(object):
             if self.norm is not None:
                 return self.ds_obs[c0:c0 + m]
             return mem.gather_states(rows[c0:c0 + m], m, self.chunk_obs[:m])
-        for c0 in range(0, n, self.chunk):
+        for c0 in range(0, 0 if recorded else n, self.chunk):
             m = min(self.chunk, n - c0)
             net.values(chunk_obs(c0, m), m, out=self.ds_value[c0:c0 + m])
         # lockstep: n_env sequences of equal length; ragged: the complete episodes back to back — ONE sequence, the scan
@@ -531,7 +558,7 @@ class ClippedPPOAgent(object):
                      alg.discount, alg.gae_lambda, self.ds_adv64, self.ds_vtarget, s)
         self.lib.standardize(self.ds_adv64, n, self.ds_adv, None, self.adv_stats, s)
         # old policy = target network, frozen for the whole phase (:238-241, hoisted out of the loop)
-        for c0 in range(0, n_train, self.chunk):
+        for c0 in range(0, 0 if recorded else n_train, self.chunk):
             m = min(self.chunk, n_train - c0)
             if self.continuous:
                 net.policy_mean_std(chunk_obs(c0, m), m, use_target=True, tag="old",
@@ -550,7 +577,9 @@ class ClippedPPOAgent(object):
             self.memory.gather_states(rows, n, self.ds_obs_raw[:n])
             self.norm.push_shared(self.ds_obs_raw[:n], self.dist)
         n_train = min(n, self.ap.algorithm.num_consecutive_playing_steps.num_steps)
-        self._run(("fill", n, n_train), lambda: self._fill_advantages_device(n, rows, n_train))
+        # every stored step of this rollout left its V(s) / action probabilities behind (RECORD_WHILE_ACTING)?
+        recorded = self._records_acting() and not self._rec_missing
+        self._run(("fill", n, n_train, recorded), lambda: self._fill_advantages_device(n, rows, n_train, recorded))
         if self.norm is not None and self.dist is not None:
             # the next states of the dataset, after the states were normalised (see _fill_advantages_device)
             self.memory.gather_next_states(rows, n, self.ds_obs_raw[:n])
@@ -763,6 +792,7 @@ class ClippedPPOAgent(object):
 
     def post_training_commands(self):
         self.memory.clean()                                               # :310-312
+        self._rec_missing = False
 
     def train(self):
         """ClippedPPOAgent.train (:314-344)."""

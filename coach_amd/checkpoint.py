@@ -22,14 +22,14 @@ def _tensors_of(obj, names):
 
 _MEMORY_TENSORS = ["ring", "fpos", "epoff", "t_fpos", "t_epoff", "cur_state", "obs", "next_obs", "action",
                    "reward", "game_over", "sum_tree", "min_tree", "max_tree", "max_priority",
-                   "n_step_discounted_rewards"]
+                   "n_step_discounted_rewards", "act_value", "act_probs"]
 _MEMORY_SCALARS = ["cursor", "count", "pending", "committed_total", "steps", "_open", "_list_len",
                    "next_leaf_idx_to_write", "_frames_total", "_episode_steps", "_step_frames",
                    "_steps_written", "_gstep", "_ep_start", "_episodes", "_episode_first_step", "_order", "_order_head", "_order_len"]
 _AGENT_SCALARS = ["total_steps_counter", "training_iteration", "last_training_phase_step",
                   "last_target_network_update_step", "current_episode_steps_counter", "last_episode_steps",
                   "_episode_just_ended", "_episode_steps", "_unconsumed_episode_lengths",
-                  "_draw_pool", "_draw_pos", "_draw_table_from"]      # PPO: host draws made for steps that have not run yet
+                  "_draw_pool", "_draw_pos", "_draw_table_from", "_rec_missing"]      # PPO: host draws made for steps that have not run yet
 
 
 def agent_state(agent):

@@ -63,6 +63,13 @@ class DeviceEpisodicRolloutBuffer(object):
         self._rows_dev = None
         self._rows_valid = -1
 
+    def enable_policy_columns(self, n_actions):
+        """Two more columns per transition, written by the acting step itself (ClippedPPONet.act_and_record): V(s) of
+        the stored state and the action probabilities the action was drawn from — what fill_advantages and the
+        old-policy pass of the training phase would otherwise recompute over the whole dataset."""
+        self.act_value = torch.zeros(self.cap, dtype=torch.float32, device=self.device)
+        self.act_probs = torch.zeros(self.cap, n_actions, dtype=torch.float32, device=self.device)
+
     # ---- Memory interface (memories/memory.py:41-77) ------------------------------------------
     def num_transitions(self):
         if self.ragged:

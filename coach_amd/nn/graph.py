@@ -728,10 +728,18 @@ def row_head_problems(ctx, row_heads, y, M, N, tag, weights=None):
         return arr, [Tensor(hy, M, l.N, 2, grad_key=(ctx, l.name, tag), act=l.act)]
     arr = (_rlx.SmallDenseProblem * len(row_heads))()
     outs = []
-    for i, (l, t) in enumerate(row_heads):
+    for i, item in enumerate(row_heads):
+        # (layer, tower) or (layer, tower, out): `out` — a contiguous fp32 tensor of M * N elements — receives the head's
+        # output instead of the context's buffer (a step's rows of a rollout column: no copy launch behind the head)
+        l, t = item[0], item[1]
         assert l.N <= SMALL_N and l.K == N and l.T == 1
         p = l.params
-        hy = ctx.buffer(l.name, (l.T, M, l.N), tag=tag)
+        hy = item[2] if len(item) > 2 and item[2] is not None else None
+        if hy is not None:
+            assert hy.is_contiguous() and hy.dtype == torch.float32 and hy.numel() == l.T * M * l.N
+            hy = hy.view(l.T, M, l.N)
+        else:
+            hy = ctx.buffer(l.name, (l.T, M, l.N), tag=tag)
         q = arr[i]
         q.x, q.x_tower_stride = y.data_ptr() + t * M * N * 4, 0
         q.w, q.w_tower_stride = p.w(l.kname, 0, weights).data_ptr(), p.stride(l.kname)

@@ -171,6 +171,30 @@ class ClippedPPONet(_NetBase):
         self.lib.softmax(logits.data, self.A, B, self.A, probs, self.A, self.ctx.stream)
         return probs
 
+    def act_and_record(self, obs, B, uniforms, actions, value_out, probs_out, tag="actrec"):
+        """One acting step of the discrete agent that also leaves what the training phase needs from these states:
+        BOTH towers run (the forward of forward_backward, launch for launch), the categorical draw happens in the softmax
+        launch as in policy_probs(sample=...), V(s) goes to value_out [B] and the action probabilities to probs_out
+        [B, A] — rows of the rollout's own columns.  The weights do not change between a rollout's steps and its training
+        phase, and the old policy of that phase IS the acting policy (networks['main'].sync() at its start,
+        clipped_ppo_agent.py:326), so fill_advantages' pass over the whole dataset (:161-170) and the old-policy pass
+        (:238-241) recompute exactly these numbers: with them recorded here both passes disappear."""
+        ctx = self.ctx
+        fused_heads = self.pi_head.N <= G.SMALL_N and B * self.pi_head.N <= 1024
+        if fused_heads and self.HEADS_FORWARD_WITH_TORSO and self.torso.layers[-1].N > G.SMALL_N:
+            acts, (v, logits) = self.torso.forward(ctx, self.obs_tensor(obs, B), tag=tag,
+                                                   row_heads=[(self.v_head, 0, value_out), (self.pi_head, 1)])
+        else:
+            acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag=tag)
+            mid = acts[-1]
+            if fused_heads:
+                v, logits = G.small_dense_forward_multi(ctx, [(self.v_head, mid.tower_view(0)), (self.pi_head, mid.tower_view(1))], tag=tag)
+            else:
+                v = self.v_head.forward(ctx, mid.tower_view(0), tag=tag)
+                logits = self.pi_head.forward(ctx, mid.tower_view(1), tag=tag)
+            value_out.copy_(v.data.view(-1))
+        self.lib.softmax_categorical_sample(logits.data, self.A, uniforms, B, self.A, probs_out, self.A, actions, ctx.stream)
+
     def policy_mean_std(self, obs, B, use_target=False, tag="act", out_mean=None, out_std=None):
         """Continuous head outputs [policy_mean, policy_std] (ppo_head.py:139-144): std = exp(log_std)
         tiled over the batch (the +eps is added where the distribution is built)."""
