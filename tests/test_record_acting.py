@@ -13,14 +13,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _rollout(dev, n_env, L, playing, batch, flag=True):
-    from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent
     from test_ppo_agent import _make
-    ClippedPPOAgent.RECORD_WHILE_ACTING = flag
-    try:
-        random.seed(5); np.random.seed(5)
-        agent = _make(dev, n_env, L, playing, batch, 1, seed=0)
-    finally:
-        ClippedPPOAgent.RECORD_WHILE_ACTING = True
+    random.seed(5); np.random.seed(5)
+    agent = _make(dev, n_env, L, playing, batch, 1, seed=0)
+    agent.RECORD_WHILE_ACTING = flag          # (instance attribute: this agent only, for its whole life)
     return agent
 
 
