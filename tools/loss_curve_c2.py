@@ -45,26 +45,52 @@ def hip_side(args):
     p.network_wrappers["main"].batch_size = B
     agent = ClippedPPOAgent(p, env, dev)
     os.makedirs(args.dir, exist_ok=True)
-    if not args.no_init:           # (13.5 MB per seed; the oracle side can rebuild the same arrays on the CPU: rebuild_init)
+    forced = None
+    if args.follow_hip_actions:
+        # the device trains on the action history of <dir>/hip.npz (an earlier run of this side) instead of its own
+        # samples: the step's action column is overwritten before anything reads it (the synthetic env ignores actions;
+        # the recorded probabilities are whole rows).  With --perturb-ulp: the DEVICE's own noise floor under an
+        # identical history (hip_forced_ulp.npz against hip_forced.npz), to set beside engine against engine
+        # (hip_forced.npz against oracle_forced.npz) and the oracle's (oracle_forced_ulp.npz against oracle_forced.npz).
+        forced = torch.from_numpy(np.load(os.path.join(args.dir, "hip.npz"))["actions"].astype(np.int32)).to(dev)
+    if args.perturb_ulp:
+        params = agent.networks["main"].params
+        k = sorted(n for n in params.entries if n.endswith("kernel"))[0]       # the oracle side's choice (same names)
+        towers = params.entries[k][2]
+        for t in range(towers):
+            flat = params.w(k, t).view(-1)
+            flat[0] = float(np.nextafter(np.float32(flat[0].item()), np.float32(np.inf), dtype=np.float32))
+        t = towers
+        print("perturbed by one ulp: %s[0] of %d tower(s)" % (k, t), flush=True)
+    if not args.no_init and forced is None:           # (13.5 MB per seed; the oracle side can rebuild the same arrays on the CPU: rebuild_init)
         arrays = agent.networks["main"].params.named_arrays()
         np.savez_compressed(os.path.join(args.dir, "init.npz"), **{"%s|%d" % (k, t): a for k, v in arrays.items()
                                                                     for t, a in enumerate(v)})
-    with open(os.path.join(args.dir, "rng_state.pkl"), "wb") as f:
-        pickle.dump({"random": random.getstate(), "numpy": np.random.get_state(), "epochs": args.epochs,
-                     "iterations": args.iterations, "seed": args.seed}, f)
-    res, acts = [], []
+    if forced is None:
+        with open(os.path.join(args.dir, "rng_state.pkl"), "wb") as f:
+            pickle.dump({"random": random.getstate(), "numpy": np.random.get_state(), "epochs": args.epochs,
+                         "iterations": args.iterations, "seed": args.seed}, f)
+    res, acts, own = [], [], []
     t0 = time.perf_counter()
     for it in range(args.iterations):
         while True:
             agent.act()
-            acts.append(agent.actions.cpu().numpy().astype(np.int8))
+            if forced is not None:
+                own.append(agent.actions.cpu().numpy().astype(np.int8))
+                r0 = (agent.memory.steps - 1) * N_ENV
+                agent.memory.action[r0:r0 + N_ENV].copy_(forced[len(acts)])
+                acts.append(forced[len(acts)].cpu().numpy().astype(np.int8))
+            else:
+                acts.append(agent.actions.cpu().numpy().astype(np.int8))
             r = agent.train()
             if r is not None:
                 break
         res.append(np.array([x.cpu().numpy()[:5] for x in r], dtype=np.float64))
     agent.networks["main"].check_status()
-    np.savez_compressed(os.path.join(args.dir, "hip.npz"), results=np.array(res), actions=np.array(acts),
-                        seconds=time.perf_counter() - t0)
+    name = ("hip_ulp.npz" if args.perturb_ulp else "hip.npz") if forced is None else \
+        ("hip_forced_ulp.npz" if args.perturb_ulp else "hip_forced.npz")
+    np.savez_compressed(os.path.join(args.dir, name), results=np.array(res), actions=np.array(acts),
+                        own_actions=np.array(own), seconds=time.perf_counter() - t0)
     print("hip side: %d iterations, %d env-steps, %.1f s" % (args.iterations, args.iterations * PLAYING,
                                                              time.perf_counter() - t0))
 
@@ -209,7 +235,7 @@ def ensemble(args):
     n = None
     for sd in seeds:
         d = os.path.join(args.dir, "seed%d" % sd)
-        h, o = np.load(os.path.join(d, "hip.npz")), np.load(os.path.join(d, "oracle.npz"))
+        h, o = np.load(os.path.join(d, args.first)), np.load(os.path.join(d, args.second))
         k = min(len(h["results"]), len(o["results"]))
         n = k if n is None else min(n, k)
         per_side["hip"].append(h["results"].mean(1))
@@ -224,6 +250,8 @@ def ensemble(args):
     out = {"workload": "C2: Clipped PPO, %d vectorized envs, 84x84x4 uint8 observations, rollout %d, minibatch %d; "
                        "%d seeds x %d iterations (%d env-steps each)" % (N_ENV, PLAYING, B, K, k, k * PLAYING),
            "seeds": seeds, "window_iterations": W,
+           "compared": "%s ('hip_*' keys below) against %s ('oracle_*' keys below), free-running: each run trains on its "
+                       "own sampled actions" % (args.first, args.second),
            "first_vector_step_with_a_different_sampled_action": first_div, "signals": {}}
     for j, nm in enumerate(NAMES):
         hw = hip[:, :, j].reshape(K, -1, W).mean(2)             # [seed, window]
@@ -252,62 +280,76 @@ def ensemble(args):
 
 
 def forced_report(args):
-    """hip.npz against oracle_forced.npz (--follow-hip-actions) for each seed in --seeds: both engines trained on the
-    SAME action history for the whole run.  Per signal: the largest relative difference of a per-epoch mean loss, of a
-    per-iteration mean and of a window mean (the statistic the free-running ensembles use), and how it develops
-    (first / middle / last seventh of the run); plus how many of the oracle's own samples differed from the device's."""
+    """Runs that trained on the SAME action history (the one of <dir>/seed<s>/hip.npz), pair by pair, for each seed in
+    --seeds:
+        engines      hip_forced.npz (or hip.npz itself)  against  oracle_forced.npz      device engine vs CPU oracle
+        device_ulp   hip_forced_ulp.npz                  against  hip_forced.npz         the device against itself, one
+                                                                                         initial weight per tower moved by 1 ulp
+        oracle_ulp   oracle_forced_ulp.npz               against  oracle_forced.npz      the oracle against itself, same move
+    Per pair, seed and signal: the relative difference of the per-iteration mean losses and of the window means (the
+    statistic of the free-running ensembles); per pair and signal over the seeds: median and maximum per window.  If the
+    engines pair is not larger than the two self pairs, the two engines are as close as either is to itself."""
     seeds = [int(x) for x in args.seeds.split(",")]
     W = args.window
-    out = {"workload": "C2: Clipped PPO, %d vectorized envs, 84x84x4 uint8 observations, rollout %d, minibatch %d; the oracle "
-                       "records the device's action at every vector step (identical histories on both sides)"
-                       % (N_ENV, PLAYING, B), "window_iterations": W, "seeds": {}}
-    worst = {nm: 0.0 for nm in NAMES}
-    for sd in seeds:
-        d = os.path.join(args.dir, "seed%d" % sd)
-        f = os.path.join(d, "oracle_forced.npz")
-        if not os.path.exists(f):
-            continue
-        h, o = np.load(os.path.join(d, "hip.npz")), np.load(f)
-        with open(os.path.join(d, "rng_state.pkl"), "rb") as fh:
-            st = pickle.load(fh)
-        n = min(len(h["results"]), len(o["results"]))
-        if n == 0:
-            continue
-        hr, orr = h["results"][:n], o["results"][:n]                # [iteration, epoch, signal]
-        steps = n * (PLAYING // N_ENV)
-        assert np.array_equal(h["actions"][:steps], o["actions"][:steps])
-        own = o["own_actions"][:steps]
-        flips = np.nonzero((own != h["actions"][:steps]).any(1))[0]
-        rec = {"iterations": n, "env_steps": n * PLAYING, "epochs_per_rollout": st["epochs"],
-               "updates": n * st["epochs"] * (PLAYING // B),
-               "oracle_own_samples_that_differ": int((own != h["actions"][:steps]).sum()),
-               "of": int(own.size), "first_vector_step_where_they_differ": int(flips[0]) if flips.size else None,
-               "seconds_oracle_cpu": float(o["seconds"]), "signals": {}}
-        for j, nm in enumerate(NAMES):
-            den = np.maximum(np.abs(orr[:, :, j]), 1e-12)
-            rel_e = np.abs(hr[:, :, j] - orr[:, :, j]) / den                        # per epoch
-            hi, oi = hr[:, :, j].mean(1), orr[:, :, j].mean(1)
-            rel_i = np.abs(hi - oi) / np.maximum(np.abs(oi), 1e-12)                 # per iteration
+    pairs = [("engines_final_tree", "hip_forced.npz", "oracle_forced.npz"),
+             ("engines_tree_of_the_action_history", "hip.npz", "oracle_forced.npz"),
+             ("device_ulp", "hip_forced_ulp.npz", "hip_forced.npz"),
+             ("oracle_ulp", "oracle_forced_ulp.npz", "oracle_forced.npz")]
+    out = {"workload": "C2: Clipped PPO, %d vectorized envs, 84x84x4 uint8 observations, rollout %d, minibatch %d; every run "
+                       "of a seed records the action history of that seed's hip.npz (identical histories)"
+                       % (N_ENV, PLAYING, B), "window_iterations": W, "pairs": {}}
+    for pname, fa, fb in pairs:
+        per_seed, wins = {}, {nm: [] for nm in NAMES}
+        for sd in seeds:
+            d = os.path.join(args.dir, "seed%d" % sd)
+            if not (os.path.exists(os.path.join(d, fa)) and os.path.exists(os.path.join(d, fb))):
+                continue
+            x, y = np.load(os.path.join(d, fa)), np.load(os.path.join(d, fb))
+            n = min(len(x["results"]), len(y["results"]))
+            if n == 0:
+                continue
+            steps = n * (PLAYING // N_ENV)
+            assert np.array_equal(x["actions"][:steps], y["actions"][:steps]), (pname, sd)
+            xr, yr = x["results"][:n], y["results"][:n]                # [iteration, epoch, signal]
+            rec = {"iterations": n, "env_steps": n * PLAYING, "updates": n * xr.shape[1] * (PLAYING // B), "signals": {}}
+            for side, f in (("first", x), ("second", y)):
+                if "own_actions" in f.files and len(f["own_actions"]):
+                    own = f["own_actions"][:steps]
+                    rec["own_samples_of_the_%s_run_differing_from_the_history" % side] = \
+                        "%d / %d" % (int((own != x["actions"][:len(own)]).sum()), own.size)
             k = n // W * W
-            sig = {"max_rel_diff_per_epoch": float(rel_e.max()), "max_rel_diff_per_iteration": float(rel_i.max()),
-                   "rel_diff_per_iteration": [float("%.3g" % x) for x in rel_i]}
-            if k:
-                hw, ow = hi[:k].reshape(-1, W).mean(1), oi[:k].reshape(-1, W).mean(1)
-                rel_w = np.abs(hw - ow) / np.maximum(np.abs(ow), 1e-12)
-                sig["rel_diff_per_window"] = [float("%.3g" % x) for x in rel_w]
-                sig["max_rel_diff_per_window"] = float(rel_w.max())
-            worst[nm] = max(worst[nm], sig["max_rel_diff_per_iteration"])
-            rec["signals"][nm] = sig
-        out["seeds"][str(sd)] = rec
-    out["max_rel_diff_per_iteration_over_all_seeds"] = worst
-    out["within_1_percent_at_every_iteration_of_every_seed"] = bool(all(v <= 0.01 for v in worst.values()))
+            for j, nm in enumerate(NAMES):
+                xi, yi = xr[:, :, j].mean(1), yr[:, :, j].mean(1)
+                rel_i = np.abs(xi - yi) / np.maximum(np.abs(yi), 1e-12)
+                sig = {"rel_diff_per_iteration": [float("%.3g" % v) for v in rel_i],
+                       "max_rel_diff_per_iteration": float(rel_i.max())}
+                if k:
+                    xw, yw = xi[:k].reshape(-1, W).mean(1), yi[:k].reshape(-1, W).mean(1)
+                    rel_w = np.abs(xw - yw) / np.maximum(np.abs(yw), 1e-12)
+                    sig["rel_diff_per_window"] = [float("%.3g" % v) for v in rel_w]
+                    wins[nm].append(rel_w)
+                rec["signals"][nm] = sig
+            per_seed[str(sd)] = rec
+        if not per_seed:
+            continue
+        summ = {}
+        for nm in NAMES:
+            if wins[nm]:
+                m = min(len(w) for w in wins[nm])
+                a_ = np.stack([w[:m] for w in wins[nm]])
+                summ[nm] = {"seeds": len(wins[nm]), "median_over_seeds_per_window": [float("%.3g" % v) for v in np.median(a_, 0)],
+                            "max_over_seeds_per_window": [float("%.3g" % v) for v in a_.max(0)],
+                            "worst_window_of_any_seed": float(a_.max())}
+        out["pairs"][pname] = {"first": fa, "second": fb, "over_seeds": summ, "seeds": per_seed}
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
-    for sd, rec in out["seeds"].items():
-        print("seed %s: %d iterations; oracle's own samples differing: %d / %d; max rel diff per iteration: %s"
-              % (sd, rec["iterations"], rec["oracle_own_samples_that_differ"], rec["of"],
-                 {nm: "%.2e" % rec["signals"][nm]["max_rel_diff_per_iteration"] for nm in NAMES}))
-    print("within 1 % at every iteration of every seed:", out["within_1_percent_at_every_iteration_of_every_seed"])
+    for pname, p_ in out["pairs"].items():
+        print("%s  (%s vs %s), %d seed(s), iterations %s" % (pname, p_["first"], p_["second"], len(p_["seeds"]),
+                                                             sorted(set(r["iterations"] for r in p_["seeds"].values()))))
+        for nm in NAMES:
+            if nm in p_["over_seeds"]:
+                o_ = p_["over_seeds"][nm]
+                print("   %-13s median per window %s   max %s" % (nm, o_["median_over_seeds_per_window"], o_["max_over_seeds_per_window"]))
 
 
 def main():
@@ -332,6 +374,7 @@ def main():
                     help="oracle side: record the device's actions (hip.npz) instead of the oracle's own samples "
                          "(-> oracle_forced.npz): identical histories on both sides for the whole run")
     ap.add_argument("--forced", action="store_true", help="compare / ensemble: hip.npz against oracle_forced.npz")
+    ap.add_argument("--second", default="oracle.npz", help="ensemble: the second run set (default: the oracle's)")
     ap.add_argument("--first", default="hip.npz",
                     help="compare: the run set against oracle.npz (oracle_ulp.npz = the oracle against itself)")
     args = ap.parse_args()
