@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5, call 28: identical histories, the device with products cut into <= 16 K slices (another summation order in every update)
+set -u
+export TMPDIR=/tmp
+timeout 400 python tools/loss_curve_c2.py --side hip --hip-seeds 0,1,2,3,4,5,6,7 --dir profiles/r05_lc_forced --iterations 49 --epochs 10 --no-init --follow-hip-actions --split-cap 16 2>&1 | grep -v amdgpu.ids | tail -4
+mkdir -p gpurun_out/lc_forced_dev3
+for s in 0 1 2 3 4 5 6 7; do mkdir -p gpurun_out/lc_forced_dev3/seed$s; cp profiles/r05_lc_forced/seed$s/hip_forced_cap16.npz gpurun_out/lc_forced_dev3/seed$s/; done

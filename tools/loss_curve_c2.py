@@ -36,6 +36,12 @@ def hip_side(args):
     from coach_amd.environments.synthetic_vector_environment import (
         SyntheticVectorEnvironment, SyntheticVectorEnvironmentParameters)
     dev = torch.device("cuda:0")
+    if args.split_cap:
+        # another valid fp32 engine: products cut into at most this many K slices (default 64) — the weight gradients of
+        # the convolutions are then summed in other groups, every update, everywhere (a CONTINUOUS source of last-bit
+        # differences, like the one between two engines; --perturb-* only move the starting point)
+        from coach_amd import _rlx
+        _rlx.lib().gemm_split_cap(args.split_cap)
     env = SyntheticVectorEnvironment(SyntheticVectorEnvironmentParameters("image", N_ENV, FRAME, A, episode_length=L,
                                                                          seed=1234 + args.seed), dev)
     p = ClippedPPOAgentParameters()
@@ -53,7 +59,16 @@ def hip_side(args):
         # identical history (hip_forced_ulp.npz against hip_forced.npz), to set beside engine against engine
         # (hip_forced.npz against oracle_forced.npz) and the oracle's (oracle_forced_ulp.npz against oracle_forced.npz).
         forced = torch.from_numpy(np.load(os.path.join(args.dir, "hip.npz"))["actions"].astype(np.int32)).to(dev)
-    if args.perturb_ulp:
+    if args.perturb_all:
+        # EVERY weight one ulp up or down (seeded coin per weight): the size of difference two engines have everywhere
+        # (another summation order in every product), where --perturb-ulp moves one weight per tower
+        w = agent.networks["main"].params.weights
+        g = torch.Generator().manual_seed(777 + args.seed)
+        up = (torch.rand(w.numel(), generator=g) < 0.5).to(dev)
+        inf = torch.full_like(w, float("inf"))
+        w.copy_(torch.nextafter(w, torch.where(up, inf, -inf)))
+        print("perturbed by one ulp: every weight (%d), random direction" % w.numel(), flush=True)
+    elif args.perturb_ulp:
         params = agent.networks["main"].params
         k = sorted(n for n in params.entries if n.endswith("kernel"))[0]       # the oracle side's choice (same names)
         towers = params.entries[k][2]
@@ -87,8 +102,10 @@ def hip_side(args):
                 break
         res.append(np.array([x.cpu().numpy()[:5] for x in r], dtype=np.float64))
     agent.networks["main"].check_status()
-    name = ("hip_ulp.npz" if args.perturb_ulp else "hip.npz") if forced is None else \
-        ("hip_forced_ulp.npz" if args.perturb_ulp else "hip_forced.npz")
+    tag = "_ulpall" if args.perturb_all else ("_ulp" if args.perturb_ulp else "")
+    if args.split_cap:
+        tag += "_cap%d" % args.split_cap
+    name = ("hip%s.npz" % tag) if forced is None else ("hip_forced%s.npz" % tag)
     np.savez_compressed(os.path.join(args.dir, name), results=np.array(res), actions=np.array(acts),
                         own_actions=np.array(own), seconds=time.perf_counter() - t0)
     print("hip side: %d iterations, %d env-steps, %.1f s" % (args.iterations, args.iterations * PLAYING,
@@ -285,6 +302,10 @@ def forced_report(args):
         engines      hip_forced.npz (or hip.npz itself)  against  oracle_forced.npz      device engine vs CPU oracle
         device_ulp   hip_forced_ulp.npz                  against  hip_forced.npz         the device against itself, one
                                                                                          initial weight per tower moved by 1 ulp
+        device_every_weight_one_ulp  hip_forced_ulpall.npz against hip_forced.npz       ... EVERY initial weight moved by 1 ulp
+        device_other_k_split  hip_forced_cap16.npz       against  hip_forced.npz         ... with products cut into <= 16 K slices
+                                                                                         instead of <= 64: other summation groups
+                                                                                         in every update (a second fp32 engine)
         oracle_ulp   oracle_forced_ulp.npz               against  oracle_forced.npz      the oracle against itself, same move
     Per pair, seed and signal: the relative difference of the per-iteration mean losses and of the window means (the
     statistic of the free-running ensembles); per pair and signal over the seeds: median and maximum per window.  If the
@@ -292,8 +313,9 @@ def forced_report(args):
     seeds = [int(x) for x in args.seeds.split(",")]
     W = args.window
     pairs = [("engines_final_tree", "hip_forced.npz", "oracle_forced.npz"),
-             ("engines_tree_of_the_action_history", "hip.npz", "oracle_forced.npz"),
              ("device_ulp", "hip_forced_ulp.npz", "hip_forced.npz"),
+             ("device_every_weight_one_ulp", "hip_forced_ulpall.npz", "hip_forced.npz"),
+             ("device_other_k_split", "hip_forced_cap16.npz", "hip_forced.npz"),
              ("oracle_ulp", "oracle_forced_ulp.npz", "oracle_forced.npz")]
     out = {"workload": "C2: Clipped PPO, %d vectorized envs, 84x84x4 uint8 observations, rollout %d, minibatch %d; every run "
                        "of a seed records the action history of that seed's hip.npz (identical histories)"
@@ -370,6 +392,10 @@ def main():
                     help="oracle side: only check that rebuild_init equals the device side's init.npz")
     ap.add_argument("--perturb-ulp", action="store_true",
                     help="oracle side: start from weights one ulp away in one element per tower (-> oracle_ulp.npz)")
+    ap.add_argument("--split-cap", type=int, default=0,
+                    help="hip side: rlx_gemm_split_cap(N) for the whole run (-> hip[_forced]_cap<N>.npz): other summation groups")
+    ap.add_argument("--perturb-all", action="store_true",
+                    help="hip side: start from weights in which EVERY element is one ulp up or down (-> hip[_forced]_ulpall.npz)")
     ap.add_argument("--follow-hip-actions", action="store_true",
                     help="oracle side: record the device's actions (hip.npz) instead of the oracle's own samples "
                          "(-> oracle_forced.npz): identical histories on both sides for the whole run")
