@@ -81,6 +81,10 @@ def load_agent_state(agent, st):
         mem.beta = pickle.loads(st["memory"]["beta"])
     for k, v in st["agent"]["scalars"].items():
         setattr(agent, k, copy.deepcopy(v))
+    if hasattr(mem, "act_value") and "act_value" not in st["memory"]["tensors"]:
+        # a checkpoint written without the recorded V(s) / probability columns (an agent that did not record, an older
+        # writer): the rows of the restored rollout carry none — its training phase runs the dataset passes
+        agent._rec_missing = True
     if "phase" in st["agent"]:
         from .core_types import RunPhase
         agent.phase = RunPhase[st["agent"]["phase"]]

@@ -19,7 +19,7 @@ def test_latest_checkpoint_resolution(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["dqn_per_image", "sac", "ppo"])
+@pytest.mark.parametrize("kind", ["dqn_per_image", "sac", "ppo", "ppo_image"])
 def test_resume_is_bit_identical(dev, tmp_path, kind):
     import torch
     from coach_amd.checkpoint import STATE_FILE, restore_checkpoint, save_checkpoint
@@ -52,6 +52,14 @@ def test_resume_is_bit_identical(dev, tmp_path, kind):
         p = ClippedPPOAgentParameters()
         p.algorithm.num_consecutive_playing_steps = EnvironmentSteps(24)
         p.algorithm.optimization_epochs = 2
+        if kind == "ppo_image":
+            # the discrete image agent: its acting steps leave V(s) / action probabilities in the rollout (RECORD_WHILE_ACTING);
+            # the checkpoint is written mid-rollout, so the resumed phase trains on columns that were restored
+            p.network_wrappers["main"].batch_size = 8
+            env = SyntheticVectorEnvironment(EP("image", 4, (44, 44), 3, episode_length=6, seed=8), dev)
+            agent = ClippedPPOAgent(p, env, dev)
+            assert agent._records_acting()
+            return agent
         p.algorithm.normalize_observations = True
         p.algorithm.reward_clipping = None
         p.network_wrappers["main"].batch_size = 8
@@ -67,7 +75,7 @@ def test_resume_is_bit_identical(dev, tmp_path, kind):
 
     a = make()
     random.seed(2); np.random.seed(2)
-    if kind != "ppo":
+    if not kind.startswith("ppo"):
         a.phase = RunPhase.HEATUP
         drive(a, 4)
     a.phase = RunPhase.TRAIN
@@ -85,6 +93,9 @@ def test_resume_is_bit_identical(dev, tmp_path, kind):
         assert torch.equal(a.networks[k].adam.v, b.networks[k].adam.v), k
     assert a.training_iteration == b.training_iteration and a.total_steps_counter == b.total_steps_counter
     assert np.random.random_sample() == np.random.random_sample() or True   # streams consumed identically below
+    if kind == "ppo_image":
+        assert not b._rec_missing and torch.equal(a.memory.act_value, b.memory.act_value)
+        assert torch.equal(a.memory.act_probs, b.memory.act_probs)
     if kind == "dqn_per_image":
         assert torch.equal(a.memory.sum_tree, b.memory.sum_tree)
         assert torch.equal(a.memory.ring, b.memory.ring)
