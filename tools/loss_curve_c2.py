@@ -49,6 +49,11 @@ def hip_side(args):
     p.algorithm.num_consecutive_playing_steps = EnvironmentSteps(PLAYING)
     p.algorithm.optimization_epochs = args.epochs
     p.network_wrappers["main"].batch_size = B
+    if args.clip_eps:
+        # not C2: another clipping range of the surrogate.  (Tried with 10, where the clip almost never binds, to see whether a
+        # one-ulp perturbation still grows as fast: ten unclipped epochs per rollout collapse the policy to determinism within
+        # the first seven iterations — entropy 0.00 in 4 of 5 seeds — so that run says nothing about C2: call 30.)
+        p.algorithm.clip_likelihood_ratio_using_epsilon = args.clip_eps
     agent = ClippedPPOAgent(p, env, dev)
     os.makedirs(args.dir, exist_ok=True)
     forced = None
@@ -105,6 +110,8 @@ def hip_side(args):
     tag = "_ulpall" if args.perturb_all else ("_ulp" if args.perturb_ulp else "")
     if args.split_cap:
         tag += "_cap%d" % args.split_cap
+    if args.clip_eps:
+        tag += "_eps%g" % args.clip_eps
     name = ("hip%s.npz" % tag) if forced is None else ("hip_forced%s.npz" % tag)
     np.savez_compressed(os.path.join(args.dir, name), results=np.array(res), actions=np.array(acts),
                         own_actions=np.array(own), seconds=time.perf_counter() - t0)
@@ -392,6 +399,8 @@ def main():
                     help="oracle side: only check that rebuild_init equals the device side's init.npz")
     ap.add_argument("--perturb-ulp", action="store_true",
                     help="oracle side: start from weights one ulp away in one element per tower (-> oracle_ulp.npz)")
+    ap.add_argument("--clip-eps", type=float, default=0.0,
+                    help="hip side: clip_likelihood_ratio_using_epsilon of the run (-> ..._eps<X>.npz); 0 = the preset's 0.2")
     ap.add_argument("--split-cap", type=int, default=0,
                     help="hip side: rlx_gemm_split_cap(N) for the whole run (-> hip[_forced]_cap<N>.npz): other summation groups")
     ap.add_argument("--perturb-all", action="store_true",
