@@ -10,6 +10,15 @@ this network is ~2 s of numpy on the build container and ~0.4 s on the GPU box's
     python tools/loss_curve_c2.py --side oracle --perturb-ulp --dir gpurun_out/lc_c2                  # the noise floor:
     python tools/loss_curve_c2.py --compare --first oracle_ulp.npz --dir gpurun_out/lc_c2 --out profiles/...noise_floor.json
 
+Round 5 — what "within 1 %" can mean at the real schedule (10 epochs): the same statistic for the device against ITSELF started one ulp
+away, and runs that train on an IDENTICAL action history:
+
+    python tools/loss_curve_c2.py --side hip --hip-seeds 0,..,15 --epochs 10 --no-init [--perturb-ulp]   # hip.npz / hip_ulp.npz
+    python tools/loss_curve_c2.py --ensemble --seeds 0,..,15 --first hip.npz --second hip_ulp.npz --out ...   # device vs device + 1 ulp
+    python tools/loss_curve_c2.py --side hip    --follow-hip-actions [--perturb-ulp | --perturb-all | --split-cap 16] ...   # followers of
+    python tools/loss_curve_c2.py --side oracle --follow-hip-actions [--perturb-ulp] --dir <dir>/seed<s>                     # hip.npz's actions
+    python tools/loss_curve_c2.py --forced --seeds 0,..,7 --dir <dir> --out ...        # pair by pair: engines; each engine vs itself
+
 The hip side writes the initial weights, the host RNG state after construction and its results; the oracle side
 starts from exactly those.  The synthetic env ignores the actions, so both sides see the same observations for the
 whole run even after the first differently sampled action (reported).  Reduced against the preset in ONE respect,
