@@ -319,6 +319,7 @@ def run_off_policy(args, device, dist):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    sampler = LoadSampler() if dist.rank == 0 and not args.no_roofline else None
     it0, t0 = agent.training_iteration, time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -338,6 +339,7 @@ def run_off_policy(args, device, dist):
     if dist.rank == 0 and not args.no_roofline and dist.world_size == 1:
         out["roofline"] = update_roofline(agent, args.workload)
         out["box"] = box_calibration(device)
+        out["box"]["under_load"] = sampler.result() if sampler else None
     if dist.rank == 0 and dist.world_size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_off_policy(args.workload)
         # the reference's own per-step / per-update code, timed in the build container (tools/time_reference_cpu*.py)
@@ -416,6 +418,39 @@ def epoch_graph_update_us(agent, reps=5):
     return 1e3 * e0.elapsed_time(e1) / reps / (PLAYING_STEPS // BATCH)
 
 
+class LoadSampler(object):
+    """clock / power / busy readings of the card this process computes on, and of the host's OTHER cards (other tenants),
+    taken by a separate process (tools/box_info.py --sample) WHILE the timed region runs: `box.under_load`."""
+
+    def __init__(self, seconds=3.0):
+        import subprocess
+        try:
+            self.p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "box_info.py"), "--sample", str(seconds)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        except Exception:
+            self.p = None
+
+    def result(self):
+        if self.p is None:
+            return None
+        try:
+            out, _ = self.p.communicate(timeout=20)
+            return json.loads(out.strip().splitlines()[-1])
+        except Exception:
+            return None
+
+
+def box_settings():
+    """what kind of box this is (driver / firmware / module parameters / partition modes / which card of the host / what the
+    neighbours are doing): tools/box_info.py summary()."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import box_info
+        return box_info.summary()
+    except Exception as e:
+        return {"error": str(e)[:200]}
+
+
 def box_calibration(device):
     """A two-second fixed calibration of THIS box, so that bench lines from different boxes of the pool can be compared
     (the pool's boxes differ by up to 30 % on identical code): device-to-device copy rate, a compute-bound 4096^3 fp32
@@ -489,6 +524,20 @@ def box_calibration(device):
         out["shader_MHz_under_mfma"] = int(round(float(np.median(pr[:, 0] / pr[:, 1])) * 100.0))
     except Exception as e:
         out["mfma_probe_error"] = str(e)[:120]
+    # issue rate vs dependent latency of the two fp32 MFMA shapes (rlx_probe_mfma_shape; guide: 64 / 64 and 32 / 40 cycles)
+    try:
+        wgs, iters, cyc = 256, 8192, {}
+        probe = torch.zeros(2 * wgs, dtype=torch.int64, device=device)
+        sink = torch.zeros(1, dtype=torch.float32, device=device)
+        for small, chains in ((0, 1), (0, 2), (1, 1), (1, 2)):
+            for _ in range(2):
+                _rlx.lib().probe_mfma_shape(wgs, iters, small, chains, probe, sink, _rlx.current_stream())
+            torch.cuda.synchronize()
+            pr = probe.cpu().numpy().reshape(wgs, 2).astype(np.float64)
+            cyc["%s_%dchain" % ("16x16x4" if small else "32x32x2", chains)] = round(float(np.median(pr[:, 0])) / (iters * chains), 1)
+        out["mfma_cycles_per_instruction"] = cyc
+    except Exception as e:
+        out["mfma_shape_probe_error"] = str(e)[:120]
     x = torch.zeros(4, dtype=torch.float32, device=device)
     x.add_(0.0)
     torch.cuda.synchronize()
@@ -503,6 +552,7 @@ def box_calibration(device):
     e1.record(); e1.synchronize()
     out["graph_dependent_launch_us"] = round(1e3 * e0.elapsed_time(e1) / (4 * 500), 2)
     del a, b, A, B, C
+    out["settings"] = box_settings()
     return out
 
 
@@ -829,6 +879,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    sampler = LoadSampler(min(3.0, 0.06 * args.steps)) if dist.rank == 0 and not args.no_roofline else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = one_step(agent)
@@ -881,6 +932,7 @@ def main():
         roof, shapes = gemm_roofline(agent)
         out["roofline"] = roof
         out["box"] = box_calibration(device)
+        out["box"]["under_load"] = sampler.result() if sampler else None
         # the one number that separates the pool's box classes on identical code: the first convolution's forward
         # product (uint8 frames, cold operands) as it runs INSIDE the update — 19 us on fast-class boxes, 31 us on slow
         conv1 = [k for k in roof["update_kernels"] if k["kernel"].startswith("gemm_fast_kernel") and

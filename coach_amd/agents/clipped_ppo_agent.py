@@ -801,8 +801,13 @@ class ClippedPPOAgent(object):
         alg = self.ap.algorithm
         net = self.networks["main"]
         results = None
-        for _ in range(alg.num_consecutive_training_steps):
+        for pass_index in range(alg.num_consecutive_training_steps):
             net.update_target(1.0)                                        # networks['main'].sync() (:326)
+            if pass_index > 0:
+                # the columns the acting steps recorded are V(s) and the action probabilities under the weights of the
+                # ROLLOUT; from the second pass on the reference's fill_advantages sees the weights the first pass
+                # trained (and the old policy sync() just copied from them): recompute
+                self._rec_missing = True
             self.fill_advantages()
             n = min(self.memory.num_transitions(), alg.num_consecutive_playing_steps.num_steps)
             order = list(range(n))                                        # dataset[:num_steps] (:330-331)

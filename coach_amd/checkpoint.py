@@ -73,6 +73,8 @@ def load_agent_state(agent, st):
         net.adam.m.copy_(s["adam_m"]); net.adam.v.copy_(s["adam_v"]); net.adam.state.copy_(s["adam_state"])
     mem = agent.memory
     for k, t in st["memory"]["tensors"].items():
+        if k in ("act_value", "act_probs") and not hasattr(mem, k):
+            continue                         # written by a recording agent, restored into one that does not record
         getattr(mem, k).copy_(t)
     import copy
     for k, v in st["memory"]["scalars"].items():

@@ -42,6 +42,47 @@ __global__ void __launch_bounds__(256) probe_mfma_kernel(int iters, long long *_
         out[2 * blockIdx.x + 1] = w1 - w0;
     }
 }
+// The same for either fp32 MFMA shape with CHAINS independent accumulators per wave, issued round-robin with nothing
+// between the MFMAs of a chain but the other chains' MFMAs: CHAINS = 1 measures the dependent-accumulator latency, CHAINS >= 2
+// the issue rate of the pipe (the 68 cycles DESIGN quoted for 16x16x4 were one dependent chain with
+// other instructions in it, not the issue rate).
+template <bool SMALL, int CHAINS>
+__global__ void __launch_bounds__(256) probe_mfma_shape_kernel(int iters, long long *__restrict__ out, float *__restrict__ sink) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x16 big[CHAINS];
+    f32x4 small[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) big[c][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) small[c][r] = 0.f;
+    }
+    const float a = 1.f + threadIdx.x * 1e-6f, b = 1.f - threadIdx.x * 1e-6f;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) {
+            if (SMALL) small[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, small[c], 0, 0, 0);
+            else big[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, big[c], 0, 0, 0);
+        }
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep += big[c][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep += small[c][r];
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (keep == 12345.678f) *sink = keep;
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = w1 - w0;
+    }
+}
 // How long do K back-to-back 16-byte-per-lane loads of one wave take — as global -> LDS requests (global_load_lds_dwordx4)
 // and as ordinary loads into registers?  Every wave of the workgroup issues K requests for lines of an L2-resident
 // buffer and waits for all of them; lane 0 of wave 0 records the shader cycles.
@@ -155,6 +196,24 @@ int rlx_probe_mfma(int workgroups, int iters, long long *out, float *sink, void 
     RLX_LAUNCH((probe_mfma_kernel), workgroups, 256, 0, rlx::as_stream(stream), iters, out, sink);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
+}
+
+// rlx_probe_mfma for either fp32 MFMA shape and 1 / 2 / 4 independent accumulator chains per wave (`iters` MFMAs PER CHAIN):
+// cycles / (iters * chains) = cycles per MFMA at that interleave.
+int rlx_probe_mfma_shape(int workgroups, int iters, int small_shape, int chains, long long *out, float *sink, void *stream) {
+    RLX_REQUIRE(workgroups > 0 && iters > 0 && out && sink && (chains == 1 || chains == 2 || chains == 4),
+                "rlx_probe_mfma_shape: bad arguments (chains must be 1, 2 or 4)");
+    hipStream_t s = rlx::as_stream(stream);
+#define RLX_PROBE_SHAPE(S, C)                                                                             \
+    if ((small_shape != 0) == S && chains == C) {                                                         \
+        RLX_LAUNCH((probe_mfma_shape_kernel<S, C>), workgroups, 256, 0, s, iters, out, sink);             \
+        RLX_LAUNCH_CHECK();                                                                               \
+        return RLX_OK;                                                                                    \
+    }
+    RLX_PROBE_SHAPE(false, 1) RLX_PROBE_SHAPE(false, 2) RLX_PROBE_SHAPE(false, 4)
+    RLX_PROBE_SHAPE(true, 1) RLX_PROBE_SHAPE(true, 2) RLX_PROBE_SHAPE(true, 4)
+#undef RLX_PROBE_SHAPE
+    return RLX_ERR_INVALID_ARG;
 }
 
 // Request-pipelining probe (measurement utility): every wave of `workgroups` workgroups issues `requests` (1, 2, 4, 8)

@@ -226,10 +226,15 @@ class Context:
         if self.deferred is not None:
             return False
         if self.arena is None or (self.private_arena and self.arena is Context._arenas.get(str(self.device))):
-            key = (str(self.device), id(self)) if self.private_arena else str(self.device)
-            if key not in Context._arenas:
-                Context._arenas[key] = torch.empty(self.ARENA_FLOATS, dtype=torch.float32, device=self.device)
-            self.arena = Context._arenas[key]
+            if self.private_arena:
+                # owned by this context and freed with it (a class-level entry keyed by id(self) would outlive the
+                # context and could be picked up by a later one with the same id)
+                self.arena = torch.empty(self.ARENA_FLOATS, dtype=torch.float32, device=self.device)
+            else:
+                key = str(self.device)
+                if key not in Context._arenas:
+                    Context._arenas[key] = torch.empty(self.ARENA_FLOATS, dtype=torch.float32, device=self.device)
+                self.arena = Context._arenas[key]
         self.deferred, self._arena_off = [], 0
         return True
 

@@ -52,6 +52,10 @@ int rlx_probe_chase(const int *chain, int start, int steps, int *out, void *stre
  * v_mfma_f32_32x32x2_f32; out[2 w] = shader-clock cycles and out[2 w + 1] = ticks of the constant 100 MHz counter that
  * workgroup w's chain took: cycles per MFMA, and the clock the shader really ran at under that load. */
 int rlx_probe_mfma(int workgroups, int iters, long long *out, float *sink, void *stream);
+/* The same for either fp32 MFMA shape (small_shape != 0: v_mfma_f32_16x16x4_f32) with `chains` (1, 2 or 4) independent
+ * accumulators per wave issued round-robin, `iters` MFMAs per chain: chains = 1 is the dependent-accumulator latency,
+ * chains >= 2 the issue rate of the matrix pipe. */
+int rlx_probe_mfma_shape(int workgroups, int iters, int small_shape, int chains, long long *out, float *sink, void *stream);
 /* Request-pipelining probe (measurement utility): every wave of `workgroups` workgroups issues `requests` (1, 2, 4 or 8)
  * back-to-back 16-byte-per-lane loads from src — global -> LDS requests (lds_dma != 0: what the GEMM ring issues) or
  * ordinary loads into registers — and waits for all of them; out[w] = shader-clock cycles of workgroup w.  src: at least

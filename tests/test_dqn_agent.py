@@ -116,6 +116,9 @@ def test_dqn_agent_matches_oracle(dev, kind, per, double):
         np.testing.assert_array_equal(a_hip[:steps_same], a_or[:steps_same])
         # identical batches and importance weights: the first updates agree to fp32 accumulation noise;
         # later ones drift by what Adam makes of that noise (elements with ~0 gradient move +-lr on its sign)
+        dl, ol = np.asarray(agent.debug_losses[:same], dtype=np.float64), np.asarray(o.losses[:same], dtype=np.float64)
+        print("\n  PER: %d identical batches; losses max rel diff %.3e (first 3: %.3e)"
+              % (same, (np.abs(dl - ol) / np.abs(ol)).max(), (np.abs(dl[:3] - ol[:3]) / np.abs(ol[:3])).max()))
         np.testing.assert_allclose(agent.debug_losses[:3], o.losses[:3], rtol=2e-4)
         # (small losses late in the run: an absolute slack of the size of one lr-step's effect on a ~0.02 loss)
         np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], rtol=5e-2, atol=6e-3)
@@ -129,6 +132,10 @@ def test_dqn_agent_matches_oracle(dev, kind, per, double):
     # of fp32 accumulation noise, so a few per cent of the conv kernel elements may sit up to a couple
     # of learning rates (2.5e-4 each update) apart while everything that drives the loss agrees
     lr = 2.5e-4
+    dl, ol = np.asarray(agent.debug_losses, dtype=np.float64), np.asarray(o.losses, dtype=np.float64)
+    print("\n  uniform: %d updates; losses max rel diff %.3e; weights max abs diff %.3e"
+          % (len(dl), (np.abs(dl - ol) / np.abs(ol)).max(),
+             max(float(np.abs(w_hip[n][0] - t[0]).max()) for n, t in w_or.items())))
     for name, towers in w_or.items():
         d = np.abs(w_hip[name][0] - towers[0])
         assert d.max() <= 4 * lr, (name, d.max())

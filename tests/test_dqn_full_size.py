@@ -143,7 +143,7 @@ def test_c3_wrapped_per_ring_and_first_updates_match_the_oracle(rlx, dev):
         same += 1
     print("\n  sampled leaves identical for the first %d of %d updates (ring of %d, wrapped by %d rows)"
           % (same, n_upd, CAP, HEATUP_STEPS * N_ENV - N_ENV - CAP))
-    assert same >= 3, "PER leaves diverged after %d updates" % same
+    assert same == n_upd, "PER leaves diverged after %d of %d updates (measured round 5: all 16 identical)" % (same, n_upd)
     leaves = np.concatenate(o.sampled[:same])
     assert leaves.min() >= 0 and leaves.max() < CAP and len(np.unique(leaves)) > same * B // 2
 
@@ -153,20 +153,21 @@ def test_c3_wrapped_per_ring_and_first_updates_match_the_oracle(rlx, dev):
     np.testing.assert_array_equal(d_rec[0][0].astype(np.float32), o_rec[0][0].astype(np.float32))
     assert len(np.unique(o_rec[0][0])) > B // 2                 # real importance weights, not a constant
     for k in range(same):
-        np.testing.assert_allclose(d_rec[k][0], o_rec[k][0], rtol=1e-5 if k else 1e-7,
+        # measured (profiles/r05_call2_pytest_new_tests.txt): 1.8e-7 relative over the 16 updates — bound at 10 x
+        np.testing.assert_allclose(d_rec[k][0], o_rec[k][0], rtol=2e-6 if k else 1e-7,
                                    err_msg="importance weights of update %d" % k)
-        # TD error = target - Q(s, a): two fp32 network outputs of O(0.1 .. 1) each good to tests/tolerances.py OUT;
-        # from the second update on the weights behind them differ by what Adam makes of fp32 noise (see 4.)
-        tol = dict(rtol=1e-4, atol=4e-6) if k == 0 else dict(rtol=2e-3, atol=2e-4)
-        np.testing.assert_allclose(d_rec[k][1], o_rec[k][1], err_msg="TD errors of update %d" % k, **tol)
+        # TD error = target - Q(s, a): two fp32 network outputs of O(0.1 .. 1).  Measured: 1.5e-7 absolute in the first
+        # update, 1.9e-7 over all 16 — bound at 10 x that for every update (tests/tolerances.py OUT is the stated bound of
+        # a network output: atol 2e-6)
+        np.testing.assert_allclose(d_rec[k][1], o_rec[k][1], err_msg="TD errors of update %d" % k, rtol=1e-5, atol=2e-6)
     _err("importance weights, update 0..%d" % (same - 1), np.array([r[0] for r in d_rec[:same]]),
          np.array([r[0] for r in o_rec[:same]]))
     _err("TD errors, update 0", d_rec[0][1], o_rec[0][1])
     _err("TD errors, updates 0..%d" % (same - 1), np.array([r[1] for r in d_rec[:same]]), np.array([r[1] for r in o_rec[:same]]))
     _err("loss, updates 0..%d" % (same - 1), agent.debug_losses[:same], o.losses[:same])
-    np.testing.assert_allclose(agent.debug_losses[0], o.losses[0], rtol=2e-4, atol=2e-6)       # tolerances.LOSS
-    np.testing.assert_allclose(agent.debug_losses[:3], o.losses[:3], rtol=2e-3, atol=2e-5)
-    np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], rtol=5e-2, atol=6e-3)
+    # every update of the phase inside tests/tolerances.py LOSS (measured: 2.2e-7 relative)
+    from tolerances import LOSS
+    np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], **LOSS)
 
     # ---- 4. priority write-back: every leaf the first update touched holds (|TD error| + 1e-6) ** 0.6 of the DEVICE's TD
     #         errors, bit for bit, unless a later update sampled the leaf again; untouched leaves are the fill's
@@ -190,10 +191,8 @@ def test_c3_wrapped_per_ring_and_first_updates_match_the_oracle(rlx, dev):
     if same == n_upd:
         np.testing.assert_allclose(trees[0][0], o_trees[0][0], rtol=1e-6)
 
-    # ---- 5. every weight after the phase's updates.  Adam's first steps move a weight by ~lr * sign(gradient): an
-    #         element whose gradient is fp32 noise around zero can land one or two learning rates apart on the two sides
-    #         while everything that drives the loss agrees — the bound of tests/test_dqn_agent.py, and the share of
-    #         elements inside tests/tolerances.py WEIGHTS is printed and bounded
+    # ---- 5. every weight after the phase's updates: ALL elements inside tests/tolerances.py WEIGHTS, and the worst
+    #         absolute deviation within ~10 x of what round 5 measured (7.5e-9 after 16 Adam steps)
     from tolerances import WEIGHTS
     w_hip, w_or = net.params.named_arrays(), o.net.weights()
     worst, inside, total = 0.0, 0, 0
@@ -203,11 +202,10 @@ def test_c3_wrapped_per_ring_and_first_updates_match_the_oracle(rlx, dev):
         worst = max(worst, d.max())
         inside += int((d <= WEIGHTS["atol"] + WEIGHTS["rtol"] * np.abs(b)).sum())
         total += d.size
-        assert d.max() <= 4 * LR * max(1, n_upd // 4), (name, d.max())
-        assert (d <= 3e-5).mean() >= 0.9, (name, (d <= 3e-5).mean())
+        assert d.max() <= 1e-7, (name, d.max())
     print("  weights after %d updates: max abs diff %.3e (lr = %.1e), %.4f %% of %d elements inside rtol %.0e / atol %.0e"
           % (n_upd, worst, LR, 100.0 * inside / total, total, WEIGHTS["rtol"], WEIGHTS["atol"]))
-    assert inside / total >= 0.9
+    assert inside == total, "%d of %d weights outside tolerances.WEIGHTS" % (total - inside, total)
     # the target network was copied after the first update of the phase (16 704 env-steps >= 10 000): it holds the
     # online weights as they were THEN, not the final ones
     assert o.last_target > 0
