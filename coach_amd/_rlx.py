@@ -39,7 +39,7 @@ _CTYPE = {
     "size_t": ctypes.c_size_t,
 }
 
-_VALUE_RETURNING = {"rlx_abi_version", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
+_VALUE_RETURNING = {"rlx_abi_version", "rlx_td3_fused_supported", "rlx_sac_fused_supported", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
                     "rlx_conv123_forward_supported", "rlx_conv32_input_grad_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
@@ -322,6 +322,32 @@ class MlpDqnDesc(ctypes.Structure):
         ("discount", ctypes.c_double)] + [(n, ctypes.c_int) for n in (
             "batch", "obs_dim", "h1", "h2", "n_actions", "huber", "double_dqn")] + [(n, ctypes.c_float) for n in (
                 "learning_rate", "beta1", "beta2", "epsilon", "grad_scale")]
+
+
+class Mlp3(ctypes.Structure):
+    """rlx_mlp3 (include/rlx.h) — field order must match the header."""
+    _fields_ = [(n, ctypes.c_longlong) for n in ("off_w1", "off_b1", "off_w2", "off_b2", "off_w3", "off_b3",
+                                                 "tower_stride1", "tower_stride2", "tower_stride3")] + \
+               [(n, ctypes.c_int) for n in ("d_in", "h1", "h2", "d_out")]
+
+
+class FusedNet(ctypes.Structure):
+    """rlx_fused_net (include/rlx.h) — field order must match the header."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("weights", "target_weights", "adam_m", "adam_v", "adam_state", "grads",
+                                               "norm_out", "ticket")] + \
+               [(n, ctypes.c_float) for n in ("learning_rate", "beta1", "beta2", "epsilon", "grad_scale", "mix_rate")]
+
+
+class Td3FusedDesc(ctypes.Structure):
+    """rlx_td3_fused_desc (include/rlx.h) — field order must match the header."""
+    _fields_ = [("actor", FusedNet), ("critic", FusedNet), ("actor_mlp", Mlp3), ("critic_mlp", Mlp3)] + \
+               [(n, ctypes.c_void_p) for n in ("obs", "next_obs", "actions", "rewards", "game_overs", "noise",
+                                               "action_low", "action_high")] + \
+               [(n, ctypes.c_double) for n in ("noise_clip", "discount", "clip_low", "clip_high")] + \
+               [("use_non_zero_discount_for_terminal_states", ctypes.c_int), ("has_clip", ctypes.c_int),
+                ("actor_scale", ctypes.c_float), ("batch", ctypes.c_int), ("obs_dim", ctypes.c_int),
+                ("act_dim", ctypes.c_int), ("workspace", ctypes.c_void_p), ("workspace_floats", ctypes.c_longlong)] + \
+               [(n, ctypes.c_void_p) for n in ("td_targets", "q_min", "loss", "neg_action_grad")]
 
 
 class ObserveDesc(ctypes.Structure):

@@ -83,6 +83,19 @@ class TD3AgentParameters(object):                                # td3_agent.py:
 
 
 class TD3Agent(DDPGAgent):
+    # The update as five launches (csrc/ac_fused.hip: row-local chains + one weight-gradient / Adam launch per network)
+    # instead of ~36 layer-by-layer ones, wherever the networks have the Mujoco_TD3 topology (nn/fused_updates.py
+    # FusedTD3.layers); the tests flip it to compare the two paths.
+    FUSED_UPDATE = True
+
+    def _fused(self):
+        f = self.__dict__.get("_fused_td3", False)
+        if f is False:
+            from ..nn.fused_updates import FusedTD3
+            f = FusedTD3(self) if FusedTD3.supported(self) else None
+            self._fused_td3 = f
+        return f if self.FUSED_UPDATE else None
+
     def __init__(self, agent_parameters, environment, device=None, dist=None, use_graphs=None):
         super().__init__(agent_parameters, environment, device, dist, use_graphs)
         B, dev = self.batch_size, self.device
@@ -132,6 +145,17 @@ class TD3Agent(DDPGAgent):
     def _critic_device(self, b, mix=None):
         """mix: rate of the soft target update due after this update, applied by the critic's Adam pass itself (nothing
         reads the critic's target between its Adam step and the end of the update)."""
+        fused = self._fused()
+        if fused is not None:
+            critic = self.networks["critic"]
+            wg = self.dist is not None               # data parallel: gradients out, all-reduce, the flat Adam launch
+            fused.critic_update(b, mix, write_grads=wg)
+            if wg:
+                self._sync(critic)
+                critic.apply_gradients(self._scale("critic"), with_norm=True, mix_rate=mix)
+            self._loss_total = critic.loss[critic.T]
+            self._agrad_merged = None
+            return
         obs2 = b._info.get("states_pair") if hasattr(b, "_info") else None
         if obs2 is not None and self.networks["critic"].T == 2:
             return self._critic_device_paired(b, obs2, mix)
@@ -155,6 +179,14 @@ class TD3Agent(DDPGAgent):
 
     def _actor_device(self, b, mix=None):
         actor, critic = self.networks["actor"], self.networks["critic"]
+        fused = self._fused()
+        if fused is not None:
+            wg = self.dist is not None
+            fused.actor_update(b, mix, write_grads=wg)
+            if wg:
+                self._sync(actor)
+                actor.apply_gradients(self._scale("actor"), mix_rate=mix)
+            return
         B = self.batch_size
         s = b._states["observation"]
         if self._agrad_merged is not None:

@@ -786,6 +786,55 @@ int rlx_cartpole_step(const int *action, double *state, int *episode, int *steps
 /* sin / cos rounded like the host libm's (csrc/libm_sincos.hpp) — exposed for tests/test_cartpole.py */
 int rlx_libm_sincos(const double *x, double *sin_out, double *cos_out, int n, int *status, void *stream);
 
+
+/* ------------------------------------------------------------ fused continuous-control updates (ac_fused.hip) -- */
+/* A 2-hidden-layer MLP inside a flat parameter buffer: float offsets of the three layers' kernels ([in][out], TF layout)
+ * and biases for tower 0, and the offset between the towers of each layer's parameter group (twin critics). */
+typedef struct rlx_mlp3 {
+    long long off_w1, off_b1, off_w2, off_b2, off_w3, off_b3;
+    long long tower_stride1, tower_stride2, tower_stride3;
+    int d_in, h1, h2, d_out;
+} rlx_mlp3;
+/* One network's flat buffers and optimiser as the fused updates drive them (TF1 Adam of rlx_adam_tf1; mix_rate >= 0: the
+ * soft target update w_t <- rate w + (1 - rate) w_t rides in the same pass; norm_out: tf.global_norm of the update's raw
+ * gradients or null; ticket: >= 1 zeroed 32-bit word, re-armed by every launch). */
+typedef struct rlx_fused_net {
+    float *weights, *target_weights, *adam_m, *adam_v, *adam_state, *grads, *norm_out;
+    unsigned int *ticket;
+    float learning_rate, beta1, beta2, epsilon, grad_scale, mix_rate;
+} rlx_fused_net;
+/* TD3Agent.learn_from_batch (rl_coach/agents/td3_agent.py:148-209) on MLP actor / twin-critic networks (td3_agent.py:36-68:
+ * actor obs -> h1 -> h2 -> tanh head x actor_scale, critic concat(action, obs) -> h1 -> h2 -> Dense(1) per stream; relu).
+ * obs / next_obs [batch][obs_dim], actions [batch][act_dim], rewards [batch], game_overs [batch] (as stored),
+ * noise [batch][act_dim] fp64: the host's np.random.normal(0, policy_noise) draw BEFORE clipping (:162) or null.
+ * Outputs: td_targets [batch], q_min [batch] (output #2 of the target critic), loss [3] = stream losses and their sum,
+ * neg_action_grad [batch][act_dim] = -actor_scale * d mean(Q_1) / d a (actor step). */
+typedef struct rlx_td3_fused_desc {
+    rlx_fused_net actor, critic;
+    rlx_mlp3 actor_mlp, critic_mlp;
+    const float *obs, *next_obs, *actions, *rewards;
+    const unsigned char *game_overs;
+    const double *noise;
+    const float *action_low, *action_high;
+    double noise_clip, discount, clip_low, clip_high;
+    int use_non_zero_discount_for_terminal_states, has_clip;
+    float actor_scale;
+    int batch, obs_dim, act_dim;
+    float *workspace; long long workspace_floats;
+    float *td_targets, *q_min, *loss, *neg_action_grad;
+} rlx_td3_fused_desc;
+int rlx_td3_fused_supported(const rlx_td3_fused_desc *desc_host);           /* 1 / 0: shapes only (pointers not read) */
+/* Measurement switch (no reference counterpart): workgroup 0 of every chain kernel records s_memtime at its phase
+ * boundaries into the LAST 96 int64 words of the workspace. */
+int rlx_fused_phase_stamps(int enable);
+int rlx_td3_fused_workspace_floats(const rlx_td3_fused_desc *desc_host, long long *floats_host);
+/* The critic half (:157-184) as three launches: target chain + online forward, loss + input-gradient chain, weight
+ * gradients + Adam (+ norm, + soft target update when critic.mix_rate >= 0).  write_grads != 0: the weight gradients go
+ * to critic.grads and no optimiser step is taken (data parallel: the caller all-reduces and steps). */
+int rlx_td3_fused_critic_update(const rlx_td3_fused_desc *desc_host, int write_grads, void *stream);
+/* The actor half (:186-207) as two launches; uses the critic's CURRENT (already updated) online weights. */
+int rlx_td3_fused_actor_update(const rlx_td3_fused_desc *desc_host, int write_grads, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

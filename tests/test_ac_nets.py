@@ -280,12 +280,16 @@ def test_ddpg_update_matches_oracle(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("paired", [False, True])
-def test_td3_update_matches_oracle(dev, paired):
+@pytest.mark.parametrize("paired,fused", [(False, False), (True, False), (True, True)])
+def test_td3_update_matches_oracle(dev, paired, fused, monkeypatch):
+    """fused: the five-launch update of csrc/ac_fused.hip (the default wherever the topology allows it); otherwise the
+    layer-by-layer launch chain."""
     import torch
     from coach_amd.agents.td3_agent import TD3Agent, TD3AgentParameters
+    monkeypatch.setattr(TD3Agent, "FUSED_UPDATE", fused)
     D, A, B = 17, 6, 100
     ag = _agent(dev, TD3Agent, TD3AgentParameters(), D, A, B)
+    assert (ag._fused() is not None) == fused
     actor, critic = ag.networks["actor"], ag.networks["critic"]
     oa = O.ActorOracle(actor.params.named_arrays(), 1.0, lr=1e-3)
     oc = O.CriticOracle(critic.params.named_arrays(), streams=2, lr=1e-3)
