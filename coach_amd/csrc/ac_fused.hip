@@ -79,23 +79,27 @@ struct Td3Dev {
     int nonzero_terminal, has_clip;
     float actor_scale;
     int B, D, A, nrb;
+    // leading dimensions of the buffers the weight-gradient launch reads (mlp_dw_adam_kernel's operand contract: rows padded
+    // to 128, columns to 64, zero outside): batch rows, merged critic input, critic h1 / h2, actor input / h1 / h2
+    int Bp, ldx, ld1c, ld2c, ldxa, ld1a, ld2a;
     // critic step
     float *zT;        // [B][kSplit][A]      partial head sums of mu_target(s')
-    float *xm;        // [B][A + D]          merged online critic input (a, s)
-    float *h1c, *h2c; // [2][B][h1], [2][B][h2]
+    float *xm;        // [Bp][ldx]           merged online critic input (a, s)
+    float *h1c, *h2c; // [2][Bp][ld1c], [2][Bp][ld2c]
     float *qp, *qTp;  // [2][kSplit][B]      partial Q_s(s, a), partial Q_target_s(s', a'')
-    float *dq, *dh2;  // [2][B], [2][B][h2]
-    float *dh1p;      // [2][kSplit][B][h1]  partial dz1 (before relu')
+    float *dq, *dh2;  // [2][Bp][64] (column 0), [2][Bp][ld2c]
+    float *dh1p;      // [2][kSplit][Bp][ld1c]  partial dz1 (before relu')
     float *loss_part; // [2][nrb]
     float *td_targets, *q_min;
     // actor step
-    float *h1a, *h2a; // [B][h1a], [B][h2a]
+    float *xa;        // [Bp][ldxa]          the states again, padded (the actor's first-layer operand)
+    float *h1a, *h2a; // [Bp][ld1a], [Bp][ld2a]
     float *za;        // [B][kSplit][A]      partial head sums of mu(s)
     float *ya;        // [B][A]              tanh output
     float *h1q;       // [B][h1]             h1 of Q_1(s, mu(s))
     float *dh1qp;     // [kSplit][B][h1]     partial dz1 of the critic pass
-    float *dz3, *dh2a;// [B][A], [B][h2a]
-    float *dh1ap;     // [kSplit][B][h1a]
+    float *dz3, *dh2a;// [Bp][64], [Bp][ld2a]
+    float *dh1ap;     // [kSplit][Bp][ld1a]
     float *neg_dq_da;
     long long *stamps;                    // [96] s_memtime of workgroup 0 at the phase boundaries, or null (tools/ac_fused_phases.py)
 };
@@ -147,14 +151,14 @@ __global__ void __launch_bounds__(T) td3_forward1_kernel(const Td3Dev p) {
             if (row0 + r < B && col < M)
                 v = col < A ? p.actions[(size_t)(row0 + r) * A + col] : p.obs[(size_t)(row0 + r) * D + (col - A)];
             L.x[r * kPitch + col] = v;
-            if (s == 0 && c == 0 && row0 + r < B && col < M) p.xm[(size_t)(row0 + r) * M + col] = v;
+            if (s == 0 && c == 0 && row0 + r < B && col < M) p.xm[(size_t)(row0 + r) * p.ldx + col] = v;
         }
         __syncthreads();
         const float *w = p.cw;
         dense_fwd(L.x, kPitch, M, w + cm.o_w1 + s * cm.s1, cm.h1, w + cm.o_b1 + s * cm.s1, cm.h1, RLX_ACT_RELU, L.a, kPitch, L.parts,
-                  c == 0 ? p.h1c + (size_t)s * B * cm.h1 : nullptr, cm.h1, row0, B);
+                  c == 0 ? p.h1c + (size_t)s * p.Bp * p.ld1c : nullptr, p.ld1c, row0, B);
         dense_fwd(L.a, kPitch, cm.h1, w + cm.o_w2 + s * cm.s2 + lo, cm.h2, w + cm.o_b2 + s * cm.s2 + lo, hi - lo, RLX_ACT_RELU, L.b,
-                  kPitch, L.parts, p.h2c + (size_t)s * B * cm.h2 + lo, cm.h2, row0, B);
+                  kPitch, L.parts, p.h2c + (size_t)s * p.Bp * p.ld2c + lo, p.ld2c, row0, B);
         head_partial(L.b, kPitch, w + cm.o_w3 + s * cm.s3, lo, hi, 1, p.qp + ((size_t)s * kSplit + c) * B, 1, row0, B);
     }
 }
@@ -216,7 +220,7 @@ __global__ void __launch_bounds__(T) td3_critic_backward_kernel(const Td3Dev p) 
     const Mlp3 &cm = p.cm;
     const int lo = slice_lo(cm.h2, c), hi = slice_lo(cm.h2, c + 1), wc = hi - lo;
     RLX_STAMP(32);
-    load_rows(L.b, kPitch, p.h2c + (size_t)s * B * cm.h2 + lo, cm.h2, wc, row0, B);
+    load_rows(L.b, kPitch, p.h2c + (size_t)s * p.Bp * p.ld2c + lo, p.ld2c, wc, row0, B);
     if (tid < R) {
         const int i = row0 + tid;
         float dq = 0.f, term = 0.f;
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(T) td3_critic_backward_kernel(const Td3Dev p) 
             const float e = qs - y;                                               // head.py:143-186 (MSE): l = e^2, g = 2 e
             term = e * e;
             dq = 1.f * 1.f * (2.f * e) / (float)B;
-            if (c == 0) p.dq[(size_t)s * B + i] = dq;
+            if (c == 0) p.dq[((size_t)s * p.Bp + i) * 64] = dq;
         }
         L.small[tid] = dq;
         L.small[R + tid] = term;
@@ -267,12 +271,12 @@ __global__ void __launch_bounds__(T) td3_critic_backward_kernel(const Td3Dev p) 
         float v = 0.f;
         if (k < wc && L.b[r * kPitch + k] > 0.f) v = L.small[r] * w3[k];
         L.c[r * kPitch + k] = v;
-        if (k < wc && row0 + r < B) p.dh2[((size_t)s * B + row0 + r) * cm.h2 + lo + k] = v;
+        if (k < wc && row0 + r < B) p.dh2[((size_t)s * p.Bp + row0 + r) * p.ld2c + lo + k] = v;
     }
     __syncthreads();
     RLX_STAMP(34);
     dense_bwdT(L.c, kPitch, wc, p.cw + cm.o_w2 + s * cm.s2 + lo, cm.h2, cm.h1, nullptr, 0, L.d, kPitch, L.wt,
-               p.dh1p + ((size_t)s * kSplit + c) * B * cm.h1, cm.h1, row0, B);
+               p.dh1p + ((size_t)s * kSplit + c) * p.Bp * p.ld1c, p.ld1c, row0, B);
     RLX_STAMP(35);
 }
 
@@ -287,10 +291,15 @@ __global__ void __launch_bounds__(T) td3_actor_forward_kernel(const Td3Dev p) {
     RLX_STAMP(48);
     load_rows(L.x, kPitch, p.obs, D, D, row0, B);
     __syncthreads();
+    if (c == 0)
+        for (int e = threadIdx.x; e < R * D; e += T) {
+            const int r = e / D, col = e - r * D;
+            if (row0 + r < B) p.xa[(size_t)(row0 + r) * p.ldxa + col] = L.x[r * kPitch + col];
+        }
     dense_fwd(L.x, kPitch, D, p.aw + am.o_w1, am.h1, p.aw + am.o_b1, am.h1, RLX_ACT_RELU, L.a, kPitch, L.parts,
-              c == 0 ? p.h1a : nullptr, am.h1, row0, B);
+              c == 0 ? p.h1a : nullptr, p.ld1a, row0, B);
     dense_fwd(L.a, kPitch, am.h1, p.aw + am.o_w2 + lo, am.h2, p.aw + am.o_b2 + lo, hi - lo, RLX_ACT_RELU, L.b, kPitch, L.parts,
-              p.h2a + lo, am.h2, row0, B);
+              p.h2a + lo, p.ld2a, row0, B);
     head_partial(L.b, kPitch, p.aw + am.o_w3, lo, hi, A, p.za + (size_t)c * A, (long long)kSplit * A, row0, B);
     RLX_STAMP(49);
 }
@@ -361,7 +370,7 @@ __global__ void __launch_bounds__(T) td3_actor_backward_kernel(const Td3Dev p) {
         }
         L.a[r * kPitch + k] = v;
     }
-    load_rows(L.b, kPitch, p.h2a + lo, am.h2, wc, row0, B);
+    load_rows(L.b, kPitch, p.h2a + lo, p.ld2a, wc, row0, B);
     if (tid < R * 16) {
         const int r = tid >> 4, col = tid & 15;
         L.small[tid] = (col < A && row0 + r < B) ? p.ya[(size_t)(row0 + r) * A + col] : 0.f;
@@ -379,7 +388,7 @@ __global__ void __launch_bounds__(T) td3_actor_backward_kernel(const Td3Dev p) {
             const float y = L.small[r * 16 + col];
             v = gy[r * 16 + col] * (1.f - y * y);
             if (c == 0 && row0 + r < B) {
-                p.dz3[(size_t)(row0 + r) * A + col] = v;
+                p.dz3[(size_t)(row0 + r) * 64 + col] = v;
                 p.neg_dq_da[(size_t)(row0 + r) * A + col] = gy[r * 16 + col];
             }
         }
@@ -387,9 +396,9 @@ __global__ void __launch_bounds__(T) td3_actor_backward_kernel(const Td3Dev p) {
     }
     __syncthreads();
     // dz2a[r][k] = relu'(h2a[r][k]) * sum_j dz3[r][j] W3[k][j]   for the slice's k
-    dense_bwdT_few_cols(dz3, 16, A, p.aw + am.o_w3 + (size_t)lo * A, wc, L.b, kPitch, L.c, kPitch, p.dh2a + lo, am.h2, row0, B);
+    dense_bwdT_few_cols(dz3, 16, A, p.aw + am.o_w3 + (size_t)lo * A, wc, L.b, kPitch, L.c, kPitch, p.dh2a + lo, p.ld2a, row0, B);
     dense_bwdT(L.c, kPitch, wc, p.aw + am.o_w2 + lo, am.h2, am.h1, nullptr, 0, L.d, kPitch, L.wt,
-               p.dh1ap + (size_t)c * B * am.h1, am.h1, row0, B);
+               p.dh1ap + (size_t)c * p.Bp * p.ld1a, p.ld1a, row0, B);
     RLX_STAMP(65);
 }
 
@@ -420,108 +429,134 @@ struct DwArgs {
     unsigned *ticket;                 // one zeroed word
     // loss finalisation riding with the last arriver (TD3 / SAC critics): loss_out[s] = scale * sum(parts[s][..]) / B
     const float *loss_part; float *loss_out; int loss_streams, loss_parts; float loss_scale;
+    long long *stamps;                // phase stamps of workgroup 0 / wave 0 (tools/ac_fused_phases.py) or null
 };
+#define RLX_DW_STAMP(slot) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[(slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// A workgroup owns a 64 x 64 block of one layer's dW (4 waves, a 32 x 32 MFMA tile each).  Both operands of the block —
+// 64 feature columns of the layer's input and 64 columns of its output gradient, all batch rows — are staged in LDS by
+// 16-byte coalesced loads first: fed straight from memory an MFMA step costs two 4-byte loads per lane, 200 load
+// instructions per wave at B = 100 (x 6 where the gradient operand is a sum of slice partials under relu'), and the launch
+// took 17 us of which 10 were those loads (profiles/r06_td3_dw_phases.txt).
+constexpr int kDwBlock = 64, kDwRows = 128, kDwPitch = kDwBlock + 4;
+
+// Operand contract: every A / G / mask matrix of a job is one of this library's workspace buffers, [roundup(B, 128)] rows
+// of ld = roundup(cols, 64) floats, 16-byte aligned, ZERO outside [B][cols] (allocated zeroed, never written there): the
+// staging is eight unconditional 16-byte loads per operand and thread — no clamps, no masks (the version with clamped
+// addresses and masked stores spent 8 us in ~2700 instructions per thread here, profiles/r06_td3_dw_phases.txt).
+constexpr int kDwPieces = kDwRows * (kDwBlock / 4) / kDwThreads;        // 8
+__device__ __forceinline__ void dw_stage(f32x4 (&dst)[kDwPieces], const float *__restrict__ p, unsigned ld, int b0, int col0) {
+    const unsigned t = threadIdx.x;
+    const float *q = p + (unsigned)(b0 + (t >> 4)) * ld + (unsigned)col0 + 4u * (t & 15u);
+#pragma unroll
+    for (int i = 0; i < kDwPieces; ++i) dst[i] = *reinterpret_cast<const f32x4 *>(q + (unsigned)(16 * i) * ld);
+}
+
 __global__ void __launch_bounds__(kDwThreads) mlp_dw_adam_kernel(const DwArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[kDwRows * kDwPitch];
+    __shared__ __attribute__((aligned(16))) float Gs[kDwRows * kDwPitch];
+    __shared__ float ss_s[kDwThreads / 64];
     __shared__ int last_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * (kDwThreads / 64) + wave);   // wave-uniform: scalar descriptor loads
-    const bool live = tile < a.tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int tile = blockIdx.x;                        // block-uniform: scalar descriptor loads
+    RLX_DW_STAMP(0);
     int j = 0;
     while (j + 1 < a.n_jobs && tile >= a.job[j + 1].tile0) ++j;
     const DwJob &jb = a.job[j];
     const DwNet &nt = a.net[jb.net];
-    const int lt = live ? tile - jb.tile0 : 0, ti = lt / jb.tiles_n, tj = lt - ti * jb.tiles_n;
-    const int i0 = 32 * ti, n0 = 32 * tj, B = a.B;
-    const bool arow = i0 + l31 < jb.K, gcol = n0 + l31 < jb.N;
+    const int lt = tile - jb.tile0, ti = lt / jb.tiles_n, tj = lt - ti * jb.tiles_n;
+    const int i0 = kDwBlock * ti + 32 * wi, n0 = kDwBlock * tj + 32 * wj, B = a.B;
+    const bool gcol = n0 + l31 < jb.N;
     const bool mix = nt.target != nullptr && nt.rate >= 0.f;
-    // every address is clamped into its buffer and every load is unconditional (masked afterwards): the loads of a phase
-    // go out back to back and the sched_barriers keep them there
-    const float *ap = jb.A + min(i0 + l31, jb.K - 1), *gp = jb.G + min(n0 + l31, jb.N - 1);
-    long long idx[16];
+    unsigned idx[16];                                    // element offsets in the network's flat buffers (< 2^31)
     bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = i0 + mfma_row(r, hi);
-        ok[r] = live && gcol && row < jb.K;
-        idx[r] = jb.o_w + (long long)min(row, jb.K - 1) * jb.N + min(n0 + l31, jb.N - 1);
+        ok[r] = gcol && row < jb.K;
+        idx[r] = (unsigned)jb.o_w + (unsigned)min(row, jb.K - 1) * (unsigned)jb.N + (unsigned)min(n0 + l31, jb.N - 1);
     }
-    const long long ib = jb.o_b + min(n0 + l31, jb.N - 1);
-    // ---- phase 1 requests: the optimiser state of the tile's 16 + 1 elements (cold: nothing has touched m / v since the
-    //      last update) and the first 128 batch rows of both operands
-    float mi[17], vi[17], wi[17], tg[17];
-    if (!a.write_grads) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            mi[r] = nt.m[idx[r]];
-            vi[r] = nt.v[idx[r]];
-            wi[r] = nt.w[idx[r]];
-            tg[r] = mix ? nt.target[idx[r]] : 0.f;
-        }
-        mi[16] = nt.m[ib]; vi[16] = nt.v[ib]; wi[16] = nt.w[ib]; tg[16] = mix ? nt.target[ib] : 0.f;
-    }
+    const unsigned ib = (unsigned)jb.o_b + (unsigned)min(n0 + l31, jb.N - 1);
+    float mi[17], vi[17], wgt[17], tg[17];
+    const float *tsrc = mix ? nt.target : nt.w;          // (no soft update: the word is loaded and dropped)
     const float b1p = nt.state[0], b2p = nt.state[1];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float bsum = 0.f;
-    if (jb.g_parts > 1) {
-        // summed partials under relu': 64 batch rows per step (32 x (1 + parts + 1) loads in flight)
-        const float *mp = jb.mask + min(n0 + l31, jb.N - 1);
-        constexpr int kU = 32;
-        for (int b0 = 0; b0 < B; b0 += 2 * kU) {
-            float av[kU], gq[kU][kSplit], mk[kU];
+    for (int b0 = 0; b0 < B; b0 += kDwRows) {
+        if (b0 > 0) __syncthreads();
+        // ---- stage rows b0 .. b0 + 127: thread t takes the 16-byte pieces t, t + 256, ... of each operand (16 per row)
+        constexpr int kPieces = kDwPieces;
+        RLX_DW_STAMP(7);
+        f32x4 ap[kPieces], gp[kPieces];
+        dw_stage(ap, jb.A, (unsigned)jb.lda, b0, kDwBlock * ti);
+        dw_stage(gp, jb.G, (unsigned)jb.ldg, b0, kDwBlock * tj);
+        if (jb.g_parts > 1) {
+            // the gradient operand is the sum of the slices' partials (slice order) under relu' of the layer's output:
+            // all requests of the phase first, then the arithmetic
+            f32x4 part[kSplit - 1][kPieces], mk[kPieces];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int b = b0 + 2 * u + hi;
-                const long long bc = b < B ? b : B - 1;
-                av[u] = ap[bc * jb.lda];
-                mk[u] = mp[bc * jb.ldg];
-#pragma unroll
-                for (int q = 0; q < kSplit; ++q) gq[u][q] = gp[bc * jb.ldg + (q < jb.g_parts ? q : 0) * jb.g_part_stride];
-            }
+            for (int z = 1; z < kSplit; ++z)
+                dw_stage(part[z - 1], jb.G + (z < jb.g_parts ? z : 0) * jb.g_part_stride, (unsigned)jb.ldg, b0, kDwBlock * tj);
+            dw_stage(mk, jb.mask, (unsigned)jb.ldg, b0, kDwBlock * tj);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int b = b0 + 2 * u + hi;
-                if (b0 + 2 * u < B) {
-                    float y = gq[u][0];
+            for (int i = 0; i < kPieces; ++i) {
 #pragma unroll
-                    for (int q = 1; q < kSplit; ++q) y += q < jb.g_parts ? gq[u][q] : 0.f;
-                    y = (gcol && b < B && mk[u] > 0.f) ? y : 0.f;
-                    const float x = (arow && b < B) ? av[u] : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
-                    bsum += y;
+                for (int z = 1; z < kSplit; ++z)
+                    if (z < jb.g_parts) gp[i] += part[z - 1][i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gp[i][e] = mk[i][e] > 0.f ? gp[i][e] : 0.f;
+            }
+        }
+        if (!a.write_grads && b0 == 0) {
+            // ---- behind the first chunk's operand requests (vector-memory loads return in order: in front of them these
+            //      cold lines — nothing has touched m / v since the last update — would hold the staging up): the optimiser
+            //      state of this lane's 16 + 1 elements; unconditional loads from clamped addresses, masked at the store
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                mi[r] = nt.m[idx[r]];
+                vi[r] = nt.v[idx[r]];
+                wgt[r] = nt.w[idx[r]];
+                tg[r] = tsrc[idx[r]];
+            }
+            mi[16] = nt.m[ib]; vi[16] = nt.v[ib]; wgt[16] = nt.w[ib]; tg[16] = tsrc[ib];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int f = tid + i * kDwThreads, row = f >> 4, q = f & 15;
+            *reinterpret_cast<f32x4 *>(As + row * kDwPitch + 4 * q) = ap[i];
+            *reinterpret_cast<f32x4 *>(Gs + row * kDwPitch + 4 * q) = gp[i];
+        }
+        RLX_DW_STAMP(8);
+        __syncthreads();
+        RLX_DW_STAMP(9);
+        const int rows = min(kDwRows, B - b0);
+        const float *ar = As + hi * kDwPitch + 32 * wi + l31, *gr = Gs + hi * kDwPitch + 32 * wj + l31;
+        for (int u = 0; 2 * u < rows; u += 8) {
+            float x[8], y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                  // rows beyond `rows` were staged as zeros
+                x[e] = ar[min(2 * (u + e), kDwRows - 2) * kDwPitch];
+                y[e] = gr[min(2 * (u + e), kDwRows - 2) * kDwPitch];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (2 * (u + e) < kDwRows) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[e], y[e], acc, 0, 0, 0);
+                    bsum += y[e];
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
-    } else
-    for (int b0 = 0; b0 < B; b0 += 128) {
-        float av[64], gv[64];
-#pragma unroll
-        for (int u = 0; u < 64; ++u) {
-            const int b = b0 + 2 * u + hi;
-            const long long bc = b < B ? b : B - 1;
-            av[u] = ap[bc * jb.lda];
-            gv[u] = gp[bc * jb.ldg];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 64; ++u) {
-            const int b = b0 + 2 * u + hi;
-            if (b0 + 2 * u < B) {                                       // wave-uniform
-                const float x = (arow && b < B) ? av[u] : 0.f, y = (gcol && b < B) ? gv[u] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
-                bsum += y;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
+    RLX_DW_STAMP(1);
     bsum += __shfl_xor(bsum, 32, 64);                  // the two lane halves hold the even / odd batch rows
-    const bool bias_lane = live && ti == 0 && gcol && hi == 0;
+    const bool bias_lane = ti == 0 && wi == 0 && gcol && hi == 0;
     if (a.write_grads) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -529,7 +564,7 @@ __global__ void __launch_bounds__(kDwThreads) mlp_dw_adam_kernel(const DwArgs a)
         if (bias_lane) nt.grads[ib] = bsum;
         if (!a.loss_out) return;
     }
-    // ---- tf.global_norm partial of this tile, published BEFORE the Adam stores (an agent-scope store behind 50 stores
+    // ---- tf.global_norm partial of this block, published BEFORE the Adam stores (an agent-scope store behind 50 stores
     //      would wait for all of them: vector-memory operations retire in order), then the ticket
     float ss = 0.f;
 #pragma unroll
@@ -538,11 +573,16 @@ __global__ void __launch_bounds__(kDwThreads) mlp_dw_adam_kernel(const DwArgs a)
     if (bias_lane) ss += bsum * bsum;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) ss += __shfl_xor(ss, d, 64);
-    if (lane == 0 && live) __hip_atomic_store(&a.norm_part[tile], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) ss_s[wave] = ss;
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (tid == 0) {
+        const float tot = ((ss_s[0] + ss_s[1]) + ss_s[2]) + ss_s[3];
+        __hip_atomic_store(&a.norm_part[tile], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RLX_DW_STAMP(2);
         last_s = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        RLX_DW_STAMP(3);
+    }
     // ---- Adam from the accumulators (every workgroup read the beta powers above, before it drew its ticket: the last
     //      arriver may advance them while the others are still storing)
     if (!a.write_grads) {
@@ -551,32 +591,34 @@ __global__ void __launch_bounds__(kDwThreads) mlp_dw_adam_kernel(const DwArgs a)
 #pragma unroll
         for (int r = 0; r < 17; ++r) {
             const float g = r < 16 ? acc[r] : bsum;
-            const float gr = g * nt.gscale;
-            mi[r] += (gr - mi[r]) * omb1;
-            vi[r] += (gr * gr - vi[r]) * omb2;
-            wi[r] -= (mi[r] * alpha) / (sqrtf(vi[r]) + nt.eps);
-            tg[r] = nt.rate * wi[r] + nt.omr * tg[r];
+            const float gr2 = g * nt.gscale;
+            mi[r] += (gr2 - mi[r]) * omb1;
+            vi[r] += (gr2 * gr2 - vi[r]) * omb2;
+            wgt[r] -= (mi[r] * alpha) / (sqrtf(vi[r]) + nt.eps);
+            tg[r] = nt.rate * wgt[r] + nt.omr * tg[r];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (ok[r]) {
                 nt.m[idx[r]] = mi[r];
                 nt.v[idx[r]] = vi[r];
-                nt.w[idx[r]] = wi[r];
+                nt.w[idx[r]] = wgt[r];
                 if (mix) nt.target[idx[r]] = tg[r];
             }
         if (bias_lane) {
             nt.m[ib] = mi[16];
             nt.v[ib] = vi[16];
-            nt.w[ib] = wi[16];
+            nt.w[ib] = wgt[16];
             if (mix) nt.target[ib] = tg[16];
         }
     }
+    RLX_DW_STAMP(4);
     __syncthreads();
+    RLX_DW_STAMP(5);
     if (!last_s) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (wave < a.n_nets && !a.write_grads) {
-        // one wave per network: its tiles' sums of squares in tile order (lanes stride, then a fixed butterfly)
+        // one wave per network: its blocks' sums of squares in block order (lanes stride, then a fixed butterfly)
         const DwNet &nn = a.net[wave];
         float s = 0.f;
         for (int t = nn.tile_lo + lane; t < nn.tile_hi; t += 64)
@@ -615,13 +657,14 @@ inline Mlp3 to_dev(const rlx_mlp3 &m) {
     return d;
 }
 
-inline int tiles_of(int K, int N) { return ((K + 31) / 32) * ((N + 31) / 32); }
+inline int tiles_of(int K, int N) { return ((K + kDwBlock - 1) / kDwBlock) * ((N + kDwBlock - 1) / kDwBlock); }
 
 struct DwBuilder {
     DwArgs a;
     DwBuilder() {
         a.n_jobs = a.n_nets = a.tiles = 0;
         a.loss_part = nullptr; a.loss_out = nullptr; a.loss_streams = a.loss_parts = 0; a.loss_scale = 1.f;
+        a.stamps = nullptr;
     }
     int add_net(const rlx_fused_net &n) {
         DwNet &d = a.net[a.n_nets];
@@ -641,7 +684,7 @@ struct DwBuilder {
     void add_job(int net, const float *A, long long lda, const float *G, long long ldg, long long o_w, long long o_b, int K, int N) {
         DwJob &j = a.job[a.n_jobs++];
         j.A = A; j.lda = lda; j.G = G; j.ldg = ldg; j.o_w = o_w; j.o_b = o_b; j.K = K; j.N = N; j.net = net;
-        j.tile0 = a.tiles; j.tiles_n = (N + 31) / 32; j.g_parts = 1; j.mask = nullptr; j.g_part_stride = 0;
+        j.tile0 = a.tiles; j.tiles_n = (N + kDwBlock - 1) / kDwBlock; j.g_parts = 1; j.mask = nullptr; j.g_part_stride = 0;
         a.tiles += tiles_of(K, N);
         a.net[net].tile_hi = a.tiles;
     }
@@ -655,24 +698,30 @@ inline hipError_t set_lds(K kernel, size_t bytes = kChainLdsBytes) {
 }
 
 struct Td3Ws {
-    long long zT, xm, h1c, h2c, qp, qTp, dq, dh2, dh1p, loss_part, h1a, h2a, za, ya, h1q, dh1qp, dz3, dh2a, dh1ap, norm_part,
+    long long zT, xm, h1c, h2c, qp, qTp, dq, dh2, dh1p, loss_part, xa, h1a, h2a, za, ya, h1q, dh1qp, dz3, dh2a, dh1ap, norm_part,
         stamps, total;
 };
+inline int pad64(int n) { return (n + 63) & ~63; }
+inline int pad128(int n) { return (n + 127) & ~127; }
 inline Td3Ws td3_layout(int B, int D, int A, const rlx_mlp3 &am, const rlx_mlp3 &cm) {
     Td3Ws w;
     long long o = 0;
     auto take = [&](long long n) { const long long at = o; o += (n + 3) & ~3LL; return at; };
     const int nrb = (B + R - 1) / R;
+    const long long Bp = pad128(B), ldx = pad64(A + D), l1c = pad64(cm.h1), l2c = pad64(cm.h2), lxa = pad64(D), l1a = pad64(am.h1),
+                    l2a = pad64(am.h2);
+    // (the buffers the weight-gradient launch reads come first and padded; they rely on the workspace having been ZEROED
+    // when it was allocated — nothing writes their padding)
+    w.xm = take(Bp * ldx);
+    w.h1c = take(2 * Bp * l1c); w.h2c = take(2 * Bp * l2c);
+    w.dq = take(2 * Bp * 64); w.dh2 = take(2 * Bp * l2c); w.dh1p = take(2LL * kSplit * Bp * l1c);
+    w.xa = take(Bp * lxa); w.h1a = take(Bp * l1a); w.h2a = take(Bp * l2a);
+    w.dz3 = take(Bp * 64); w.dh2a = take(Bp * l2a); w.dh1ap = take((long long)kSplit * Bp * l1a);
     w.zT = take((long long)B * kSplit * A);
-    w.xm = take((long long)B * (A + D));
-    w.h1c = take(2LL * B * cm.h1); w.h2c = take(2LL * B * cm.h2);
-    w.qp = take(2LL * kSplit * B); w.qTp = take(2LL * kSplit * B); w.dq = take(2LL * B);
-    w.dh2 = take(2LL * B * cm.h2); w.dh1p = take(2LL * kSplit * B * cm.h1);
+    w.qp = take(2LL * kSplit * B); w.qTp = take(2LL * kSplit * B);
     w.loss_part = take(2LL * nrb);
-    w.h1a = take((long long)B * am.h1); w.h2a = take((long long)B * am.h2);
     w.za = take((long long)B * kSplit * A); w.ya = take((long long)B * A);
     w.h1q = take((long long)B * cm.h1); w.dh1qp = take((long long)kSplit * B * cm.h1);
-    w.dz3 = take((long long)B * A); w.dh2a = take((long long)B * am.h2); w.dh1ap = take((long long)kSplit * B * am.h1);
     const long long tc = 2LL * (tiles_of(A + D, cm.h1) + tiles_of(cm.h1, cm.h2) + tiles_of(cm.h2, 1));
     const long long ta = tiles_of(D, am.h1) + tiles_of(am.h1, am.h2) + tiles_of(am.h2, A);
     w.norm_part = take(tc > ta ? tc : ta);
@@ -705,10 +754,12 @@ inline Td3Dev td3_dev(const rlx_td3_fused_desc &d) {
     p.nonzero_terminal = d.use_non_zero_discount_for_terminal_states; p.has_clip = d.has_clip;
     p.actor_scale = d.actor_scale;
     p.B = d.batch; p.D = d.obs_dim; p.A = d.act_dim; p.nrb = (d.batch + R - 1) / R;
+    p.Bp = pad128(d.batch); p.ldx = pad64(d.obs_dim + d.act_dim); p.ld1c = pad64(d.critic_mlp.h1); p.ld2c = pad64(d.critic_mlp.h2);
+    p.ldxa = pad64(d.obs_dim); p.ld1a = pad64(d.actor_mlp.h1); p.ld2a = pad64(d.actor_mlp.h2);
     float *ws = d.workspace;
     p.zT = ws + w.zT; p.xm = ws + w.xm; p.h1c = ws + w.h1c; p.h2c = ws + w.h2c; p.qp = ws + w.qp; p.qTp = ws + w.qTp;
     p.dq = ws + w.dq; p.dh2 = ws + w.dh2; p.dh1p = ws + w.dh1p; p.loss_part = ws + w.loss_part;
-    p.h1a = ws + w.h1a; p.h2a = ws + w.h2a; p.za = ws + w.za; p.ya = ws + w.ya; p.h1q = ws + w.h1q; p.dh1qp = ws + w.dh1qp;
+    p.xa = ws + w.xa; p.h1a = ws + w.h1a; p.h2a = ws + w.h2a; p.za = ws + w.za; p.ya = ws + w.ya; p.h1q = ws + w.h1q; p.dh1qp = ws + w.dh1qp;
     p.dz3 = ws + w.dz3; p.dh2a = ws + w.dh2a; p.dh1ap = ws + w.dh1ap;
     p.td_targets = d.td_targets; p.q_min = d.q_min; p.neg_dq_da = d.neg_action_grad;
     p.stamps = g_stamps ? reinterpret_cast<long long *>(ws + w.stamps) : nullptr;
@@ -750,8 +801,7 @@ static int td3_common_checks(const rlx_td3_fused_desc &d, const char *who) {
 
 static int launch_dw(DwBuilder &b, int B, int write_grads, float *norm_part, unsigned *ticket, hipStream_t st) {
     b.a.B = B; b.a.write_grads = write_grads; b.a.norm_part = norm_part; b.a.ticket = ticket;
-    const int wgs = (b.a.tiles + kDwThreads / 64 - 1) / (kDwThreads / 64);
-    RLX_LAUNCH((mlp_dw_adam_kernel), wgs, kDwThreads, 0, st, b.a);
+    RLX_LAUNCH((mlp_dw_adam_kernel), b.a.tiles, kDwThreads, 0, st, b.a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -785,16 +835,18 @@ int rlx_td3_fused_critic_update(const rlx_td3_fused_desc *d_host, int write_grad
     const rlx_mlp3 &cm = d.critic_mlp;
     const int B = d.batch, M = d.obs_dim + d.act_dim;
     for (int s = 0; s < 2; ++s) {
-        b.add_partial_job(net, p.xm, M, p.dh1p + (size_t)s * kSplit * B * cm.h1, cm.h1, kSplit, (long long)B * cm.h1,
-                          p.h1c + (size_t)s * B * cm.h1, cm.off_w1 + s * cm.tower_stride1, cm.off_b1 + s * cm.tower_stride1, M,
+        const size_t Bp = p.Bp;
+        b.add_partial_job(net, p.xm, p.ldx, p.dh1p + (size_t)s * kSplit * Bp * p.ld1c, p.ld1c, kSplit, (long long)Bp * p.ld1c,
+                          p.h1c + (size_t)s * Bp * p.ld1c, cm.off_w1 + s * cm.tower_stride1, cm.off_b1 + s * cm.tower_stride1, M,
                           cm.h1);
-        b.add_job(net, p.h1c + (size_t)s * B * cm.h1, cm.h1, p.dh2 + (size_t)s * B * cm.h2, cm.h2,
+        b.add_job(net, p.h1c + (size_t)s * Bp * p.ld1c, p.ld1c, p.dh2 + (size_t)s * Bp * p.ld2c, p.ld2c,
                   cm.off_w2 + s * cm.tower_stride2, cm.off_b2 + s * cm.tower_stride2, cm.h1, cm.h2);
-        b.add_job(net, p.h2c + (size_t)s * B * cm.h2, cm.h2, p.dq + (size_t)s * B, 1, cm.off_w3 + s * cm.tower_stride3,
+        b.add_job(net, p.h2c + (size_t)s * Bp * p.ld2c, p.ld2c, p.dq + (size_t)s * Bp * 64, 64, cm.off_w3 + s * cm.tower_stride3,
                   cm.off_b3 + s * cm.tower_stride3, cm.h2, 1);
     }
     b.a.loss_part = p.loss_part; b.a.loss_out = d.loss; b.a.loss_streams = 2; b.a.loss_parts = p.nrb; b.a.loss_scale = 1.f;
     const Td3Ws w = td3_layout(d.batch, d.obs_dim, d.act_dim, d.actor_mlp, d.critic_mlp);
+    b.a.stamps = p.stamps ? p.stamps + 80 : nullptr;
     return launch_dw(b, B, write_grads, d.workspace + w.norm_part, d.critic.ticket, st);
 }
 
@@ -825,10 +877,10 @@ int rlx_td3_fused_actor_update(const rlx_td3_fused_desc *d_host, int write_grads
     const int net = b.add_net(d.actor);
     const rlx_mlp3 &am = d.actor_mlp;
     const int B = d.batch;
-    b.add_partial_job(net, d.obs, d.obs_dim, p.dh1ap, am.h1, kSplit, (long long)B * am.h1, p.h1a, am.off_w1, am.off_b1, d.obs_dim,
+    b.add_partial_job(net, p.xa, p.ldxa, p.dh1ap, p.ld1a, kSplit, (long long)p.Bp * p.ld1a, p.h1a, am.off_w1, am.off_b1, d.obs_dim,
                       am.h1);
-    b.add_job(net, p.h1a, am.h1, p.dh2a, am.h2, am.off_w2, am.off_b2, am.h1, am.h2);
-    b.add_job(net, p.h2a, am.h2, p.dz3, d.act_dim, am.off_w3, am.off_b3, am.h2, d.act_dim);
+    b.add_job(net, p.h1a, p.ld1a, p.dh2a, p.ld2a, am.off_w2, am.off_b2, am.h1, am.h2);
+    b.add_job(net, p.h2a, p.ld2a, p.dz3, 64, am.off_w3, am.off_b3, am.h2, d.act_dim);
     const Td3Ws w = td3_layout(d.batch, d.obs_dim, d.act_dim, d.actor_mlp, d.critic_mlp);
     return launch_dw(b, B, write_grads, d.workspace + w.norm_part, d.actor.ticket, st);
 }
