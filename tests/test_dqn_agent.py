@@ -120,8 +120,16 @@ def test_dqn_agent_matches_oracle(dev, kind, per, double):
         print("\n  PER: %d identical batches; losses max rel diff %.3e (first 3: %.3e)"
               % (same, (np.abs(dl - ol) / np.abs(ol)).max(), (np.abs(dl[:3] - ol[:3]) / np.abs(ol[:3])).max()))
         np.testing.assert_allclose(agent.debug_losses[:3], o.losses[:3], rtol=2e-4)
-        # (small losses late in the run: an absolute slack of the size of one lr-step's effect on a ~0.02 loss)
-        np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], rtol=5e-2, atol=6e-3)
+        if kind == "vector":
+            # measured (round 6, profiles/r06_call7_pytest.txt): all 60 batches identical, losses within 1.2e-5 — bound at
+            # ~10 x: tests/tolerances.py LOSS for every update
+            from tolerances import LOSS
+            assert same == len(o.sampled), "PER leaves diverged after %d of %d batches" % (same, len(o.sampled))
+            np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], **LOSS)
+        else:
+            # image networks: the batches stay identical for 13 - 34 updates (one borderline leaf ends it); small losses
+            # late in the run: an absolute slack of the size of one lr-step's effect on a ~0.02 loss
+            np.testing.assert_allclose(agent.debug_losses[:same], o.losses[:same], rtol=5e-2, atol=6e-3)
         return
     for d, s_ in zip(agent.debug_draws, o.sampled):
         np.testing.assert_array_equal(d, s_)                 # replay indices bit-exact
@@ -136,6 +144,15 @@ def test_dqn_agent_matches_oracle(dev, kind, per, double):
     print("\n  uniform: %d updates; losses max rel diff %.3e; weights max abs diff %.3e"
           % (len(dl), (np.abs(dl - ol) / np.abs(ol)).max(),
              max(float(np.abs(w_hip[n][0] - t[0]).max()) for n, t in w_or.items())))
+    if kind == "vector":
+        # measured (round 6): losses 2.3e-7 relative over the 60 updates, weights 2.2e-8 absolute — bounds at ~10 x,
+        # every weight inside tests/tolerances.py WEIGHTS
+        from tolerances import WEIGHTS
+        np.testing.assert_allclose(agent.debug_losses, o.losses, rtol=5e-6)
+        for name, towers in w_or.items():
+            np.testing.assert_allclose(w_hip[name][0], towers[0], err_msg=name, **WEIGHTS)
+            assert np.abs(w_hip[name][0] - towers[0]).max() <= 3e-7, name
+        return
     for name, towers in w_or.items():
         d = np.abs(w_hip[name][0] - towers[0])
         assert d.max() <= 4 * lr, (name, d.max())
