@@ -355,7 +355,7 @@ def run_off_policy(args, device, dist):
 
 
 # ------------------------------------------------------------------------------------- roofline
-GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_", "conv32_")          # kernels that issue (or finish) fp32 MFMA products
+GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_", "conv32_", "ppo_fc_heads")   # kernels that issue (or finish) fp32 MFMA products
 
 
 def _family(name):
@@ -803,6 +803,8 @@ def main():
     ap.add_argument("--record-acting", type=int, default=None, choices=[0, 1],
                     help="A/B (c2): the acting steps leave V(s) and the action probabilities in the rollout — no whole-dataset "
                          "value / old-policy pass (ClippedPPOAgent.RECORD_WHILE_ACTING; 1 = default)")
+    ap.add_argument("--fc-heads", type=int, default=None, choices=[0, 1],
+                    help="A/B: the last dense layer + heads + losses + heads' backward as one launch (rlx_ppo_fc_heads)")
     ap.add_argument("--fuse-conv-bwd", type=int, default=None, choices=[0, 1],
                     help="A/B: the input gradients of conv3 / conv2 as one launch (nn.graph.FUSE_CONV_INPUT_GRADS; 0 = default)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
@@ -862,6 +864,9 @@ def main():
     if args.fuse_acting is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent as _A
         _A.FUSE_ACTING_LAUNCHES = bool(args.fuse_acting)
+    if args.fc_heads is not None:
+        from coach_amd.nn.networks import ClippedPPONet as _N
+        _N.FC_HEADS_ONE_LAUNCH = bool(args.fc_heads)
     if args.fuse_conv_bwd is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_INPUT_GRADS = bool(args.fuse_conv_bwd)

@@ -39,7 +39,7 @@ _CTYPE = {
     "size_t": ctypes.c_size_t,
 }
 
-_VALUE_RETURNING = {"rlx_abi_version", "rlx_td3_fused_supported", "rlx_sac_fused_supported", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
+_VALUE_RETURNING = {"rlx_abi_version", "rlx_ppo_fc_heads_supported", "rlx_td3_fused_supported", "rlx_sac_fused_supported", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
                     "rlx_conv123_forward_supported", "rlx_conv32_input_grad_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
@@ -348,6 +348,19 @@ class Td3FusedDesc(ctypes.Structure):
                 ("actor_scale", ctypes.c_float), ("batch", ctypes.c_int), ("obs_dim", ctypes.c_int),
                 ("act_dim", ctypes.c_int), ("workspace", ctypes.c_void_p), ("workspace_floats", ctypes.c_longlong)] + \
                [(n, ctypes.c_void_p) for n in ("td_targets", "q_min", "loss", "neg_action_grad")]
+
+
+class PpoFcHeadsDesc(ctypes.Structure):
+    """rlx_ppo_fc_heads_desc (include/rlx.h) — field order must match the header."""
+    P, LL, F, I = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_int
+    _fields_ = [("x", P), ("x_tower_stride", LL), ("weights", P), ("weight_tower_stride", LL), ("bias", P),
+                ("bias_tower_stride", LL), ("value_w", P), ("value_b", P), ("policy_w", P), ("policy_b", P),
+                ("value_targets", P), ("advantages", P), ("old_probs", P), ("ld_old", LL), ("actions", P), ("clip_scale", P),
+                ("clip_epsilon", F), ("beta_entropy", F), ("grad_scale", F), ("batch", I), ("in_features", I), ("units", I),
+                ("n_actions", I), ("activation", I), ("h", P), ("dz", P), ("values", P), ("logits", P), ("dvalues", P),
+                ("dlogits", P), ("d_value_w", P), ("d_value_b", P), ("d_policy_w", P), ("d_policy_b", P), ("scalars", P),
+                ("likelihood_ratio", P), ("clipped_likelihood_ratio", P), ("status", P), ("workspace", P),
+                ("workspace_floats", LL), ("tickets", P)]
 
 
 class ObserveDesc(ctypes.Structure):

@@ -820,6 +820,62 @@ def ppo_heads_loss_backward(ctx, value, policy, value_targets, actions, advantag
                                     beta, 1.0, scalars, ratio_out, clipped_out, status, ctx.stream)
 
 
+def ppo_fc_heads_supported(ctx, layer, x, v_head, pi_head):
+    """Can rlx_ppo_fc_heads run `layer` (the torso's last Dense, two towers) + both discrete heads + losses + the heads'
+    backward pass as one launch?"""
+    return (isinstance(layer, Dense) and layer.T == 2 and x.towers == 2 and not x.u8 and v_head.T == 1 and pi_head.T == 1 and
+            v_head.N == 1 and v_head.K == layer.N and pi_head.K == layer.N and v_head.act is None and pi_head.act is None and
+            x.data.data_ptr() % 16 == 0 and layer.params.stride(layer.kname) % 4 == 0 and
+            bool(ctx.lib.ppo_fc_heads_supported(x.rows, layer.K, layer.N, pi_head.N)))
+
+
+def ppo_fc_heads(ctx, layer, x, v_head, pi_head, value_targets, actions, advantages, old_probs, ld_old, clip_epsilon,
+                 clip_scale, beta, scalars, ratio_out, clipped_out, status, tag=""):
+    """-> (mid, v, logits): the layer's output Tensor with mid.grad = d loss / d pre-activation (grad_is_dz), the heads'
+    outputs with their gradients; the heads' weight gradients are in params.grads (rlx_ppo_fc_heads: one launch)."""
+    import ctypes
+    p, B, N, K = layer.params, x.rows, layer.N, layer.K
+    y = ctx.buffer(layer.name, (2, B, N), tag=tag)
+    mid = Tensor(y, B, N, 2, grad_key=(ctx, layer.name, tag), act=layer.act)
+    dz = mid.ensure_grad()
+    v = Tensor(ctx.buffer(v_head.name, (1, B, 1), tag=tag), B, 1, 1, grad_key=(ctx, v_head.name, tag), act=None)
+    lg = Tensor(ctx.buffer(pi_head.name, (1, B, pi_head.N), tag=tag), B, pi_head.N, 1, grad_key=(ctx, pi_head.name, tag), act=None)
+    key = ("ppo_fc_heads/ws", N)
+    ws = ctx.cache.get(key)
+    if ws is None:
+        floats, words = ctypes.c_longlong(), ctypes.c_longlong()
+        ctx.lib.ppo_fc_heads_workspace(N, ctypes.byref(floats), ctypes.byref(words))
+        ws = ctx.cache[key] = (torch.zeros(floats.value, dtype=torch.float32, device=ctx.device),
+                               torch.zeros(words.value, dtype=torch.int32, device=ctx.device))
+    d = _rlx.PpoFcHeadsDesc()
+    d.x, d.x_tower_stride = x.data.data_ptr(), B * K
+    d.weights, d.weight_tower_stride = p.w(layer.kname).data_ptr(), p.stride(layer.kname)
+    d.bias, d.bias_tower_stride = p.w(layer.bname).data_ptr(), p.stride(layer.bname)
+    hp = v_head.params
+    d.value_w, d.value_b = hp.w(v_head.kname).data_ptr(), hp.w(v_head.bname).data_ptr()
+    d.policy_w, d.policy_b = hp.w(pi_head.kname).data_ptr(), hp.w(pi_head.bname).data_ptr()
+    d.value_targets, d.advantages, d.old_probs, d.ld_old = value_targets.data_ptr(), advantages.data_ptr(), old_probs.data_ptr(), ld_old
+    d.actions = actions.data_ptr()
+    d.clip_scale = clip_scale.data_ptr() if clip_scale is not None else None
+    d.clip_epsilon, d.beta_entropy, d.grad_scale = float(clip_epsilon), float(beta), 1.0
+    d.batch, d.in_features, d.units, d.n_actions, d.activation = B, K, N, pi_head.N, _rlx.ACT[layer.act]
+    d.h, d.dz = y.data_ptr(), dz.data_ptr()
+    d.values, d.logits = v.data.data_ptr(), lg.data.data_ptr()
+    d.dvalues, d.dlogits = v.ensure_grad().data_ptr(), lg.ensure_grad().data_ptr()
+    d.d_value_w, d.d_value_b = hp.g(v_head.kname).data_ptr(), hp.g(v_head.bname).data_ptr()
+    d.d_policy_w, d.d_policy_b = hp.g(pi_head.kname).data_ptr(), hp.g(pi_head.bname).data_ptr()
+    d.scalars = scalars.data_ptr()
+    d.likelihood_ratio = ratio_out.data_ptr() if ratio_out is not None else None
+    d.clipped_likelihood_ratio = clipped_out.data_ptr() if clipped_out is not None else None
+    d.status = status.data_ptr()
+    d.workspace, d.workspace_floats, d.tickets = ws[0].data_ptr(), ws[0].numel(), ws[1].data_ptr()
+    run = lambda: ctx.lib.ppo_fc_heads(ctypes.byref(d), ctx.stream)
+    _rlx._record((), run, flops=2.0 * 2 * B * N * K)        # bench.py's recorder: the two towers' dense products
+    run()
+    mid.grad_is_dz = True
+    return mid, v, lg
+
+
 class Sequential:
     """A chain of Dense / Conv2d layers replicated over `towers` identical copies."""
 
@@ -830,9 +886,10 @@ class Sequential:
         for l in self.layers:
             l.initialize(rng)
 
-    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False, row_heads=None):
+    def forward(self, ctx, x, tag="", weights=None, t0=0, nt=None, pair=False, row_heads=None, skip_last=False):
         """row_heads: [(narrow Dense layer, tower index)] reading the LAST layer's output — computed by that layer's
-        launch where it can (rlx_gemm_desc.row_heads); returns (acts, head outputs) then."""
+        launch where it can (rlx_gemm_desc.row_heads); returns (acts, head outputs) then.
+        skip_last: stop in front of the last layer (its caller runs it fused with what follows: ppo_fc_heads)."""
         acts = [x]
         kw = {"pair": True} if pair else {}
         done = 0                     # layers [0, done) are computed
@@ -845,6 +902,8 @@ class Sequential:
                 acts.extend(fused)
                 done = i + len(fused)
                 continue
+            if skip_last and i == len(self.layers) - 1:
+                return acts
             if row_heads and i == len(self.layers) - 1:
                 y, heads = l.forward(ctx, acts[-1], tag=tag, weights=weights, t0=t0, nt=nt, row_heads=row_heads, **kw)
                 acts.append(y)

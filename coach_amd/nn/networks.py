@@ -121,6 +121,14 @@ class ClippedPPONet(_NetBase):
     (discrete).  tower 0 = value, tower 1 = policy."""
     HEADS_LOSS_BACKWARD_ONE_LAUNCH = True     # discrete heads: losses + heads' backward as one launch (tests flip it)
     HEADS_FORWARD_WITH_TORSO = True           # the heads' forward inside the last dense layer's split-K reduction (tests flip it)
+    # the last dense layer of both towers + heads forward + both losses + heads backward as ONE launch (rlx_ppo_fc_heads,
+    # csrc/ppo_fc_fused.hip) where the shape allows it (discrete heads, minibatch <= 64 rows).  OFF: measured on C2 it is
+    # 34.8 us against 11.0 + 8.0 + 11.2 us for the three launches it replaces (1 MB of split-K partials instead of 6.5 MB, 10
+    # launches per update instead of 12) and the update comes out 198.1 us against 193.8 us (same box, bench.py --fc-heads
+    # 1 / 0, profiles/r06_ab_fc_heads.txt): its three in-launch hand-offs (8 K splits -> tile, 16 tiles -> tower, dy back to
+    # the tiles) each cost a write-through + read round trip, which is what a launch boundary costs here.  Entry point,
+    # parity test (tests/test_ppo_fc_fused.py) and A/B flag stay.
+    FC_HEADS_ONE_LAUNCH = False
 
     def __init__(self, device, obs_shape, n_actions, activation="tanh", embedder="Medium",
                  middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
@@ -259,7 +267,23 @@ class ClippedPPONet(_NetBase):
             clip_rescaler = 1.0
         fused_heads = self.pi_head.N <= G.SMALL_N and B * self.pi_head.N <= 1024
         heads_with_torso = fused_heads and self.HEADS_FORWARD_WITH_TORSO and self.torso.layers[-1].N > G.SMALL_N
-        if heads_with_torso:   # the heads' forward rides on the last dense layer's launch (rlx_gemm_desc.row_heads)
+        if self.FC_HEADS_ONE_LAUNCH and heads_with_torso and not self.continuous and self.HEADS_LOSS_BACKWARD_ONE_LAUNCH:
+            acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train", skip_last=True)
+            if len(acts) == len(self.torso.layers) and \
+                    G.ppo_fc_heads_supported(ctx, self.torso.layers[-1], acts[-1], self.v_head, self.pi_head):
+                mid, v, logits = G.ppo_fc_heads(ctx, self.torso.layers[-1], acts[-1], self.v_head, self.pi_head, value_targets,
+                                                actions, advantages, old_probs, self.A, self.clip_eps * clip_rescaler, clip_dev,
+                                                self.beta, self.scalars, ratio_out, clipped_out, self.status, tag="train")
+                acts.append(mid)
+                return self._backward_torso(acts, stop_after_dense)
+            # (not this shape: the layer-by-layer path below recomputes nothing — acts holds the layers in front of the last)
+            last = self.torso.layers[-1]
+            if heads_with_torso:
+                y, (v, logits) = last.forward(ctx, acts[-1], tag="train", row_heads=[(self.v_head, 0), (self.pi_head, 1)])
+            else:
+                y = last.forward(ctx, acts[-1], tag="train")
+            acts.append(y)
+        elif heads_with_torso:   # the heads' forward rides on the last dense layer's launch (rlx_gemm_desc.row_heads)
             acts, (v, logits) = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train",
                                                    row_heads=[(self.v_head, 0), (self.pi_head, 1)])
         else:
@@ -309,6 +333,10 @@ class ClippedPPONet(_NetBase):
             self.v_head.backward(ctx, xv, v)
             self.pi_head.backward(ctx, xp, logits)
         mid.grad_is_dz = xv.grad_is_dz and xp.grad_is_dz     # the heads wrote dz of the middleware
+        self._backward_torso(acts, stop_after_dense)
+
+    def _backward_torso(self, acts, stop_after_dense):
+        ctx = self.ctx
         if stop_after_dense:
             k = self._split_layer()
             self.torso.backward(ctx, acts, layers=(k, len(self.torso.layers)))

@@ -835,6 +835,38 @@ int rlx_td3_fused_critic_update(const rlx_td3_fused_desc *desc_host, int write_g
 /* The actor half (:186-207) as two launches; uses the critic's CURRENT (already updated) online weights. */
 int rlx_td3_fused_actor_update(const rlx_td3_fused_desc *desc_host, int write_grads, void *stream);
 
+
+/* ------------------------------------------------- Clipped PPO: last dense layer + heads + losses, one launch -- */
+/* The middleware's Dense(units) of both towers (tower 0 = value, tower 1 = policy; layers.py:168-185), VHead / discrete
+ * PPOHead forward (heads/v_head.py:43-52, heads/ppo_head.py:52-116), both head losses (head.py:143-186) and the heads'
+ * backward pass (architecture.py:312-385) — what rlx_gemm (row_heads) + rlx_ppo_heads_loss_backward did in three launches.
+ * x [2][batch][in_features]; weights [in][units] / bias [units] per tower; value_w [units][1], policy_w [units][n_actions].
+ * Outputs: h (the layer's output) and dz = d loss / d (its pre-activation) [2][batch][units]; values [batch], logits
+ * [batch][n_actions] and their gradients; the heads' weight / bias gradients; scalars [5] = surrogate, entropy, KL, policy
+ * total, value loss.  workspace / tickets: rlx_ppo_fc_heads_workspace (tickets zeroed once; every launch re-arms them). */
+typedef struct rlx_ppo_fc_heads_desc {
+    const float *x; long long x_tower_stride;
+    const float *weights; long long weight_tower_stride;
+    const float *bias; long long bias_tower_stride;
+    const float *value_w, *value_b, *policy_w, *policy_b;
+    const float *value_targets, *advantages, *old_probs; long long ld_old;
+    const int *actions;
+    const float *clip_scale;                 /* device scalar multiplying clip_epsilon, or null */
+    float clip_epsilon, beta_entropy, grad_scale;
+    int batch, in_features, units, n_actions, activation;
+    float *h, *dz, *values, *logits, *dvalues, *dlogits;
+    float *d_value_w, *d_value_b, *d_policy_w, *d_policy_b;
+    float *scalars, *likelihood_ratio, *clipped_likelihood_ratio;
+    int *status;
+    float *workspace; long long workspace_floats;
+    unsigned int *tickets;
+} rlx_ppo_fc_heads_desc;
+int rlx_ppo_fc_heads_supported(int batch, int in_features, int units, int n_actions);      /* 1 / 0 */
+int rlx_ppo_fc_heads_workspace(int units, long long *floats_host, long long *ticket_words_host);
+int rlx_ppo_fc_heads(const rlx_ppo_fc_heads_desc *desc_host, void *stream);
+/* Measurement switch: workgroup 0 and the last arrivers record s_memtime into the workspace's last 16 int64. */
+int rlx_ppo_fc_heads_stamps(int enable);
+
 #ifdef __cplusplus
 }
 #endif
