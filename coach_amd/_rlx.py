@@ -350,6 +350,19 @@ class Td3FusedDesc(ctypes.Structure):
                [(n, ctypes.c_void_p) for n in ("td_targets", "q_min", "loss", "neg_action_grad")]
 
 
+class SacFusedDesc(ctypes.Structure):
+    """rlx_sac_fused_desc (include/rlx.h) — field order must match the header."""
+    _fields_ = [("policy", FusedNet), ("q", FusedNet), ("v", FusedNet), ("policy_mlp", Mlp3), ("v_mlp", Mlp3)] + \
+               [(n, ctypes.c_longlong) for n in ("q_off_obs_w", "q_off_obs_b", "q_off_act_w", "q_off_act_b", "q_off_fc_w",
+                                                 "q_off_fc_b", "q_off_out_w", "q_off_out_b", "q_stride_obs", "q_stride_act",
+                                                 "q_stride_fc", "q_stride_out")] + \
+               [(n, ctypes.c_void_p) for n in ("obs", "next_obs", "actions", "rewards", "game_overs", "normals")] + \
+               [("discount", ctypes.c_double)] + \
+               [(n, ctypes.c_int) for n in ("resample_noise_per_pass", "batch", "obs_dim", "act_dim", "q_hidden", "reserved")] + \
+               [("workspace", ctypes.c_void_p), ("workspace_floats", ctypes.c_longlong)] + \
+               [(n, ctypes.c_void_p) for n in ("value_targets", "log_target", "td_targets", "dq_da", "q_loss", "v_loss")]
+
+
 class PpoFcHeadsDesc(ctypes.Structure):
     """rlx_ppo_fc_heads_desc (include/rlx.h) — field order must match the header."""
     P, LL, F, I = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_int

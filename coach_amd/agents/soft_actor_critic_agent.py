@@ -173,8 +173,36 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
     # multi-stream graph launch costs the host 11 % of the C5 rate.
     parallel_branches = False
 
+    # The update as six launches (csrc/ac_fused.hip: every launch carries one level of ALL networks + one weight-gradient /
+    # Adam launch for the three of them) instead of ~42 layer-by-layer ones, wherever the networks have the Mujoco_SAC
+    # topology (nn/fused_updates.py FusedSAC.layers); the tests flip it to compare the two paths.
+    FUSED_UPDATE = True
+
+    def _fused(self):
+        f = self.__dict__.get("_fused_sac", False)
+        if f is False:
+            from ..nn.fused_updates import FusedSAC
+            f = FusedSAC(self) if FusedSAC.supported(self) else None
+            self._fused_sac = f
+        return f if self.FUSED_UPDATE else None
+
+    def _v_mixes_in_update(self, batch):
+        """Whether a soft target update due after this update rides in V's Adam pass: always in the fused chain (it
+        evaluates V_target(s') first), otherwise only when the paired pass did."""
+        return self._fused() is not None or (hasattr(batch, "_info") and batch._info.get("states_pair") is not None)
+
     def _learn_device(self, b, mix=None):
         pol, q, v = self.networks["policy"], self.networks["q"], self.networks["v"]
+        fused = self._fused()
+        if fused is not None:
+            wg = self.dist is not None               # data parallel: gradients out, all-reduce, the flat Adam launches
+            fused.update(b, mix, write_grads=wg)
+            if wg:
+                for name, net in (("policy", pol), ("q", q), ("v", v)):
+                    self._sync(net)
+                    net.apply_gradients(self._scale(name), **({"with_norm": True} if name == "q" else
+                                                              {"mix_rate": mix} if name == "v" else {}))
+            return
         alg, B, s_ = self.ap.algorithm, self.batch_size, _rlx.current_stream
         s, ns = b._states["observation"], b._next_states["observation"]
         resample = alg.resample_noise_per_pass
@@ -268,8 +296,7 @@ class SoftActorCriticAgent(VectorOffPolicyAgent):
             self.normals = self._to_device("sac_z", self._draw_update_host()["z"], torch.float64)     # the staging buffer is the operand
         mix = self._mix_rate
         self._run(("learn", mix, self._staged is not None), lambda: self._learn_device(batch, mix))
-        paired = hasattr(batch, "_info") and batch._info.get("states_pair") is not None
-        if mix is not None and paired:                  # (decided here, not in the captured body: replays skip that)
+        if mix is not None and self._v_mixes_in_update(batch):     # (decided here, not in the captured body: replays skip that)
             self._mixed = self._mixed | {"v"}
         qn = self.networks["q"]
         self.signals = {"Loss": qn.loss[2], "Grads (unclipped)": qn.norm,

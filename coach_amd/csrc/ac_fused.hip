@@ -106,10 +106,11 @@ struct Td3Dev {
 #define RLX_STAMP(slot) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[(slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 // the 4 rows' partial head sums of one column slice: out[r][j] = sum_{k in slice} h[r][k] W3[k][j]  (j < NO <= 16)
+template <int RR = R>
 __device__ __forceinline__ void head_partial(const float *hs, int hp, const float *__restrict__ W3, int n_lo, int n_hi, int NO,
                                              float *__restrict__ out, long long ld, int row0, int B) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = wave; o < R * NO; o += T / 64) {
+    for (int o = wave; o < RR * NO; o += T / 64) {
         const int r = o / NO, j = o - r * NO;
         float sum = 0.f;
         for (int k = n_lo + lane; k < n_hi; k += 64) sum = fmaf(hs[r * hp + (k - n_lo)], W3[(size_t)k * NO + j], sum);
@@ -429,6 +430,7 @@ struct DwArgs {
     unsigned *ticket;                 // one zeroed word
     // loss finalisation riding with the last arriver (TD3 / SAC critics): loss_out[s] = scale * sum(parts[s][..]) / B
     const float *loss_part; float *loss_out; int loss_streams, loss_parts; float loss_scale;
+    const float *loss2_part; float *loss2_out; int loss2_parts;        // a second, single-stream loss (SAC: the V network's)
     long long *stamps;                // phase stamps of workgroup 0 / wave 0 (tools/ac_fused_phases.py) or null
 };
 #define RLX_DW_STAMP(slot) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[(slot)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -644,6 +646,13 @@ __global__ void __launch_bounds__(kDwThreads) mlp_dw_adam_kernel(const DwArgs a)
             if (lane == 0) a.loss_out[s] = v;
         }
         if (lane == 0) a.loss_out[a.loss_streams] = total;
+        if (a.loss2_out) {
+            float v = 0.f;
+            for (int i = lane; i < a.loss2_parts; i += 64) v += a.loss2_part[i];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0) a.loss2_out[0] = v / (float)a.B;
+        }
     }
     if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -664,7 +673,7 @@ struct DwBuilder {
     DwBuilder() {
         a.n_jobs = a.n_nets = a.tiles = 0;
         a.loss_part = nullptr; a.loss_out = nullptr; a.loss_streams = a.loss_parts = 0; a.loss_scale = 1.f;
-        a.stamps = nullptr;
+        a.stamps = nullptr; a.loss2_part = nullptr; a.loss2_out = nullptr; a.loss2_parts = 0;
     }
     int add_net(const rlx_fused_net &n) {
         DwNet &d = a.net[a.n_nets];
@@ -741,6 +750,377 @@ inline int td3_check(const rlx_td3_fused_desc &d) {
     return 1;
 }
 
+// =================================================================================================================
+// Soft Actor-Critic (rl_coach/agents/soft_actor_critic_agent.py:168-280) on the same building blocks: 8 batch rows per
+// workgroup (B = 256: two 4-row MFMA block sets on the same weight registers), every wide layer in kSplit column slices.
+// Here the FIRST layers are wide too (376 x 256), so a network's forward pass is two launches (a slice of layer 1 needs
+// nothing, a slice of layer 2 needs all of layer 1) — and every launch carries the same level of ALL networks:
+//   sac_layer1_kernel    h1 slices of policy(s), V(s), V_target(s') and relu(obs_fc_t(s)) of both Q towers
+//   sac_layer2_kernel    h2 slices + partial head sums of policy / V / V_target; Q_t(s, a): act_fc, sum, fc1 slice, partial Q_t
+//   sac_q_pi_kernel      policy head (first noise draw, :186-190) -> a ~ pi, log pi; Q_t(s, a ~ pi) up to partial Q_t (:198-200)
+//   sac_q_grad_kernel    min(Q_1, Q_2), V targets (:244), d mean(min) / d Q_t -> partial d / d (fc1 input) (:216-217)
+//   sac_backward_kernel  role P: dQ/da -> the policy head's gradient on the 2nd / 3rd noise draw (:210-227) -> dz2, partial
+//                        dz1; role V: loss and backward of V (:250); role Q_t: y = r + (1 - done) gamma V_target(s')
+//                        (:259-266), loss and backward of Q_t (:268)
+//   mlp_dw_adam_kernel   all fourteen layers' weight gradients + the three Adam steps (+ V's soft target update)
+// Every forward pass sees the weights as they were before this update (the reference applies the policy's step before it
+// forms the V / Q targets, but no target reads the policy's weights: soft_actor_critic_agent.py:229-266).
+constexpr int RS = 8, SP = 388, HP = 64;           // rows per workgroup, activation pitch (widths <= 384), narrow-array pitch
+constexpr size_t kSacFwdLds = sizeof(float) * (3 * RS * SP + kPartFloats + 4 * RS * HP);
+constexpr size_t kSacBwdLds = sizeof(float) * (4 * RS * SP + 4 * RS * HP + 2 * kTileFloats);
+static_assert(2 * kSacFwdLds <= 160 * 1024 && kSacBwdLds <= 160 * 1024, "SAC chain kernels: LDS budget");
+constexpr float kLogSigCapMin = -20.f, kLogSigCapMax = 2.f;       // sac_head.py:26-27
+constexpr float kEpsF32 = 1.1920928955078125e-07f;                 // np.finfo(np.float32).eps (utils.py:38)
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
+struct SacQ {                                       // SACQHead (heads/sac_q_head.py:46-96), tower t at + t * stride
+    long long o_wo, o_bo, o_wa, o_ba, o_w1, o_b1, o_wq, o_bq;
+    long long s_o, s_a, s_1, s_q;
+};
+struct SacDev {
+    const float *pw, *vw, *vwt, *qw;
+    Mlp3 pm, vm;
+    SacQ qm;
+    const float *obs, *next_obs, *actions, *rewards;
+    const unsigned char *dones;
+    const double *normals;                          // [3][B][A]
+    double discount;
+    int resample;
+    int B, D, A, H, nrb, Bp, ldx, ldh;
+    // padded (rows to 128, columns to 64, zero outside): operands of the weight-gradient launch
+    float *xs, *ab, *h1P, *h1V, *ho, *h2P, *h2V, *haB, *hs, *h2Q;
+    float *dyP, *dz2P, *dh1Pp, *dvV, *dz2V, *dh1Vp, *dqQ, *dfc1, *dhqp;
+    // plain
+    float *h1VT, *zP, *vp, *vTp, *qp, *logp0, *haP, *h2Qp, *qpp, *dhpp, *v_loss_part, *q_loss_part;
+    float *value_targets, *log_target, *td_targets, *dq_da;
+    long long *stamps;
+};
+
+// mu_logsig[r][j] = bias[j] + the slices' partial head sums in slice order  (j < 2 A) -> zz [RS][HP]
+__device__ __forceinline__ void sac_head_sums(const SacDev &p, int row0, float *zz) {
+    const int A2 = 2 * p.A;
+    for (int e = threadIdx.x; e < RS * HP; e += T) {
+        const int r = e / HP, j = e - r * HP, i = row0 + r;
+        float v = 0.f;
+        if (i < p.B && j < A2) {
+            const float *zp = p.zP + ((size_t)i * kSplit) * A2 + j;
+            v = zp[0];
+#pragma unroll
+            for (int q = 1; q < kSplit; ++q) v += zp[(size_t)q * A2];
+            v += p.pw[p.pm.o_b3 + j];
+        }
+        zz[e] = v;
+    }
+}
+
+__global__ void __launch_bounds__(T, 4) sac_layer1_kernel(const SacDev p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *x = smem, *y = x + RS * SP, *parts = y + 2 * RS * SP;
+    const int role = blockIdx.x % (5 * kSplit), rb = blockIdx.x / (5 * kSplit), row0 = rb * RS;
+    const int net = role / kSplit, c = role % kSplit;
+    const int B = p.B, D = p.D;
+    load_rows<RS>(x, SP, net == 2 ? p.next_obs : p.obs, D, D, row0, B);
+    __syncthreads();
+    if (net == 0 && c == 0)
+        for (int e = threadIdx.x; e < RS * D; e += T) {
+            const int r = e / D, col = e - r * D;
+            if (row0 + r < B) p.xs[(size_t)(row0 + r) * p.ldx + col] = x[r * SP + col];
+        }
+    const float *W, *bias;
+    float *out;
+    int N;
+    long long gld = p.ldh;
+    if (net == 0) { W = p.pw + p.pm.o_w1; bias = p.pw + p.pm.o_b1; N = p.pm.h1; out = p.h1P; }
+    else if (net == 1) { W = p.vw + p.vm.o_w1; bias = p.vw + p.vm.o_b1; N = p.vm.h1; out = p.h1V; }
+    else if (net == 2) { W = p.vwt + p.vm.o_w1; bias = p.vwt + p.vm.o_b1; N = p.vm.h1; out = p.h1VT; gld = N; }
+    else {
+        const int t = net - 3;
+        W = p.qw + p.qm.o_wo + t * p.qm.s_o; bias = p.qw + p.qm.o_bo + t * p.qm.s_o; N = p.H;
+        out = p.ho + (size_t)t * p.Bp * p.ldh;
+    }
+    const int lo = slice_lo(N, c), hi = slice_lo(N, c + 1);
+    dense_fwd<RS>(x, SP, D, W + lo, N, bias + lo, hi - lo, RLX_ACT_RELU, y, SP, parts, out + lo, gld, row0, B);
+}
+
+__global__ void __launch_bounds__(T, 4) sac_layer2_kernel(const SacDev p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *x = smem, *y = x + RS * SP, *z = y + RS * SP, *parts = z + RS * SP, *small = parts + kPartFloats;
+    const int tid = threadIdx.x, role = blockIdx.x % (5 * kSplit), rb = blockIdx.x / (5 * kSplit), row0 = rb * RS;
+    const int net = role / kSplit, c = role % kSplit;
+    const int B = p.B, A = p.A, H = p.H;
+    if (net < 3) {
+        const Mlp3 &m = net == 0 ? p.pm : p.vm;
+        const float *w = net == 0 ? p.pw : (net == 1 ? p.vw : p.vwt);
+        const float *h1 = net == 0 ? p.h1P : (net == 1 ? p.h1V : p.h1VT);
+        const int lo = slice_lo(m.h2, c), hi = slice_lo(m.h2, c + 1);
+        load_rows<RS>(x, SP, h1, net == 2 ? m.h1 : p.ldh, m.h1, row0, B);
+        __syncthreads();
+        float *save = net == 0 ? p.h2P + lo : (net == 1 ? p.h2V + lo : nullptr);
+        dense_fwd<RS>(x, SP, m.h1, w + m.o_w2 + lo, m.h2, w + m.o_b2 + lo, hi - lo, RLX_ACT_RELU, y, SP, parts, save, p.ldh, row0, B);
+        if (net == 0) head_partial<RS>(y, SP, w + m.o_w3, lo, hi, 2 * A, p.zP + (size_t)c * 2 * A, (long long)kSplit * 2 * A, row0, B);
+        else head_partial<RS>(y, SP, w + m.o_w3, lo, hi, 1, (net == 1 ? p.vp : p.vTp) + (size_t)c * B, 1, row0, B);
+    } else {
+        // Q_t(s, a): relu(obs_fc(s)) from the first launch + relu(act_fc(a)) -> fc1 slice -> the slice's share of Q_t
+        const int t = net - 3;
+        const SacQ &q = p.qm;
+        const int lo = slice_lo(H, c), hi = slice_lo(H, c + 1);
+        load_rows<RS>(x, SP, p.ho + (size_t)t * p.Bp * p.ldh, p.ldh, H, row0, B);
+        load_rows<RS>(small, HP, p.actions, A, A, row0, B);
+        __syncthreads();
+        if (t == 0 && c == 0)
+            for (int e = tid; e < RS * A; e += T) {
+                const int r = e / A, col = e - r * A;
+                if (row0 + r < B) p.ab[(size_t)(row0 + r) * 64 + col] = small[r * HP + col];
+            }
+        dense_fwd<RS>(small, HP, A, p.qw + q.o_wa + t * q.s_a, H, p.qw + q.o_ba + t * q.s_a, H, RLX_ACT_RELU, z, SP, parts,
+                      c == 0 ? p.haB + (size_t)t * p.Bp * p.ldh : nullptr, p.ldh, row0, B);
+        for (int e = tid; e < RS * pad16(H); e += T) {       // qi_obs_emb + qi_act_emb (sac_q_head.py:63-67)
+            const int r = e / pad16(H), k = e - r * pad16(H);
+            const float v = k < H ? x[r * SP + k] + z[r * SP + k] : 0.f;
+            x[r * SP + k] = v;
+            if (c == 0 && k < H && row0 + r < B) p.hs[((size_t)t * p.Bp + row0 + r) * p.ldh + k] = v;
+        }
+        __syncthreads();
+        dense_fwd<RS>(x, SP, H, p.qw + q.o_w1 + t * q.s_1 + lo, H, p.qw + q.o_b1 + t * q.s_1 + lo, hi - lo, RLX_ACT_RELU, y, SP, parts,
+                      p.h2Q + (size_t)t * p.Bp * p.ldh + lo, p.ldh, row0, B);
+        head_partial<RS>(y, SP, p.qw + q.o_wq + t * q.s_q, lo, hi, 1, p.qp + ((size_t)t * kSplit + c) * B, 1, row0, B);
+    }
+}
+
+// SACPolicyHead on the first noise draw (heads/sac_head.py:60-97): a = tanh(mu + sigma n), log pi; then Q_t(s, a)
+__global__ void __launch_bounds__(T, 4) sac_q_pi_kernel(const SacDev p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *x = smem, *y = x + RS * SP, *z = y + RS * SP, *parts = z + RS * SP, *small = parts + kPartFloats;
+    float *zz = small, *act0 = small + RS * HP, *t1 = small + 2 * RS * HP, *t2 = small + 3 * RS * HP;
+    const int tid = threadIdx.x, role = blockIdx.x % (2 * kSplit), rb = blockIdx.x / (2 * kSplit), row0 = rb * RS;
+    const int t = role / kSplit, c = role % kSplit;
+    const int B = p.B, A = p.A, H = p.H;
+    const SacQ &q = p.qm;
+    const int lo = slice_lo(H, c), hi = slice_lo(H, c + 1);
+    sac_head_sums(p, row0, zz);
+    load_rows<RS>(x, SP, p.ho + (size_t)t * p.Bp * p.ldh, p.ldh, H, row0, B);
+    __syncthreads();
+    for (int e = tid; e < RS * HP; e += T) {
+        const int r = e / HP, a = e - r * HP, i = row0 + r;
+        float av = 0.f, lp = 0.f, cr = 0.f;
+        if (i < B && a < A) {
+            const float mu = zz[r * HP + a];
+            const float ls = fminf(fmaxf(zz[r * HP + A + a], kLogSigCapMin), kLogSigCapMax);   // :65-66
+            const float sd = expf(ls);
+            const float nz = (float)p.normals[(size_t)i * A + a];
+            const float raw = mu + sd * nz;                                             // sample() :79
+            av = tanhf(raw);                                                            // :82
+            const float zv = (raw - mu) / sd;
+            lp = -0.5f * zv * zv - ls - kHalfLog2Pi;                                    // log_prob :90
+            cr = logf(1.f - av * av + kEpsF32);                                         // :58
+        }
+        act0[e] = av; t1[e] = lp; t2[e] = cr;
+    }
+    __syncthreads();
+    if (t == 0 && c == 0 && tid < RS && row0 + tid < B) {      // the sums in action order, as the head's row loop
+        float lp = 0.f, cr = 0.f;
+        for (int a = 0; a < A; ++a) { lp += t1[tid * HP + a]; cr += t2[tid * HP + a]; }
+        p.logp0[row0 + tid] = lp - cr;
+    }
+    dense_fwd<RS>(act0, HP, A, p.qw + q.o_wa + t * q.s_a, H, p.qw + q.o_ba + t * q.s_a, H, RLX_ACT_RELU, z, SP, parts,
+                  c == 0 ? p.haP + (size_t)t * B * H : nullptr, H, row0, B);
+    for (int e = tid; e < RS * pad16(H); e += T) {
+        const int r = e / pad16(H), k = e - r * pad16(H);
+        x[r * SP + k] = k < H ? x[r * SP + k] + z[r * SP + k] : 0.f;
+    }
+    __syncthreads();
+    dense_fwd<RS>(x, SP, H, p.qw + q.o_w1 + t * q.s_1 + lo, H, p.qw + q.o_b1 + t * q.s_1 + lo, hi - lo, RLX_ACT_RELU, y, SP, parts,
+                  p.h2Qp + (size_t)t * B * H + lo, H, row0, B);
+    head_partial<RS>(y, SP, p.qw + q.o_wq + t * q.s_q, lo, hi, 1, p.qpp + ((size_t)t * kSplit + c) * B, 1, row0, B);
+}
+
+// min(Q_1, Q_2)(s, a ~ pi), the V targets, d mean(min) / d Q_t and its way down to the input of fc1 (slice partial)
+__global__ void __launch_bounds__(T) sac_q_grad_kernel(const SacDev p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *b = smem, *cb = b + RS * SP, *d = cb + RS * SP, *small = d + 2 * RS * SP, *wt = small + 4 * RS * HP;
+    const int tid = threadIdx.x, role = blockIdx.x % (2 * kSplit), rb = blockIdx.x / (2 * kSplit), row0 = rb * RS;
+    const int t = role / kSplit, c = role % kSplit;
+    const int B = p.B, H = p.H;
+    const SacQ &q = p.qm;
+    const int lo = slice_lo(H, c), hi = slice_lo(H, c + 1), wc = hi - lo;
+    load_rows<RS>(b, SP, p.h2Qp + (size_t)t * B * H + lo, H, wc, row0, B);
+    if (tid < RS) {
+        const int i = row0 + tid;
+        float dq = 0.f;
+        if (i < B) {
+            float qv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float *pp = p.qpp + (size_t)u * kSplit * B + i;
+                float v = pp[0];
+#pragma unroll
+                for (int z = 1; z < kSplit; ++z) v += pp[(size_t)z * B];
+                qv[u] = v + p.qw[q.o_bq + u * q.s_q];
+            }
+            const bool first = qv[0] <= qv[1];               // tf.minimum: x <= y -> x gets the gradient
+            const float m = first ? qv[0] : qv[1];
+            if (t == 0 && c == 0) {
+                p.log_target[i] = m;
+                p.value_targets[i] = m - p.logp0[i];          // :244 (fp32 numpy arrays in the reference)
+            }
+            dq = (first == (t == 0)) ? 1.0f / (float)B : 0.f;
+        }
+        small[tid] = dq;
+    }
+    __syncthreads();
+    const float *wq = p.qw + q.o_wq + t * q.s_q + lo;
+    for (int e = tid; e < RS * pad16(wc); e += T) {
+        const int r = e / pad16(wc), k = e - r * pad16(wc);
+        cb[r * SP + k] = (k < wc && b[r * SP + k] > 0.f) ? small[r] * wq[k] : 0.f;
+    }
+    __syncthreads();
+    dense_bwdT<RS>(cb, SP, wc, p.qw + q.o_w1 + t * q.s_1 + lo, H, H, nullptr, 0, d, SP, wt,
+                   p.dhpp + ((size_t)t * kSplit + c) * B * H, H, row0, B);
+}
+
+__global__ void __launch_bounds__(T) sac_backward_kernel(const SacDev p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *b = smem, *cb = b + RS * SP, *d = cb + RS * SP, *e2 = d + RS * SP, *small = e2 + RS * SP, *wt = small + 4 * RS * HP;
+    const int tid = threadIdx.x, role = blockIdx.x % (4 * kSplit), rb = blockIdx.x / (4 * kSplit), row0 = rb * RS;
+    const int kind = role / kSplit, c = role % kSplit;
+    const int B = p.B, A = p.A, H = p.H;
+    if (kind == 0) {
+        // ---- policy: dQ/da at the sampled actions, the head's gradient, dz2 slice, partial dz1
+        const SacQ &q = p.qm;
+        const Mlp3 &m = p.pm;
+        const int lo = slice_lo(m.h2, c), hi = slice_lo(m.h2, c + 1), wc = hi - lo;
+        float *zz = small, *da0 = small + RS * HP, *da1 = small + 2 * RS * HP, *dyb = small + 3 * RS * HP;
+        sac_head_sums(p, row0, zz);
+        for (int t = 0; t < 2; ++t) {
+            float *dst = t == 0 ? d : e2;
+            for (int e = tid; e < RS * pad16(H); e += T) {
+                const int r = e / pad16(H), k = e - r * pad16(H), i = row0 + r;
+                float v = 0.f;
+                if (i < B && k < H && p.haP[((size_t)t * B + i) * H + k] > 0.f) {
+                    const float *pp = p.dhpp + ((size_t)t * kSplit * B + i) * H + k;
+                    v = pp[0];
+#pragma unroll
+                    for (int z = 1; z < kSplit; ++z) v += pp[(size_t)z * B * H];
+                }
+                dst[r * SP + k] = v;
+            }
+        }
+        load_rows<RS>(b, SP, p.h2P + lo, p.ldh, wc, row0, B);
+        __syncthreads();
+        dense_bwdT_few_rows<RS>(d, SP, H, p.qw + q.o_wa, H, A, 1.f, da0, HP);
+        dense_bwdT_few_rows<RS>(e2, SP, H, p.qw + q.o_wa + q.s_a, H, A, 1.f, da1, HP);
+        for (int e = tid; e < RS * HP; e += T) {
+            const int r = e / HP, a = e - r * HP, i = row0 + r;
+            float dmu = 0.f, dls = 0.f;
+            if (i < B && a < A) {
+                const float g = da0[r * HP + a] + da1[r * HP + a];          // the shared action input sums the towers
+                if (c == 0) p.dq_da[(size_t)i * A + a] = g;
+                const float mu = zz[r * HP + a], ls_raw = zz[r * HP + A + a];
+                const bool inside = ls_raw >= kLogSigCapMin && ls_raw <= kLogSigCapMax;      // clip_by_value's gradient
+                const float ls = fminf(fmaxf(ls_raw, kLogSigCapMin), kLogSigCapMax);
+                const float sd = expf(ls);
+                const float w_lp = 1.0f / (float)B;
+                // weighted_gradients[5] (mean log-prob, weight 1) and - weighted_gradients[3] (actions, weights dQ/da): on
+                // the second and third noise draw (resample), or both on the first
+                const float n1 = (float)p.normals[((size_t)(p.resample ? 1 : 0) * B + i) * A + a];
+                const float n2 = (float)p.normals[((size_t)(p.resample ? 2 : 0) * B + i) * A + a];
+                {
+                    const float raw = mu + sd * n1, tt = tanhf(raw), one_m = 1.f - tt * tt;
+                    const float dcorr = 2.f * tt * one_m / (one_m + kEpsF32);
+                    const float g_raw = w_lp * dcorr;
+                    if (p.resample) {
+                        dmu = g_raw;
+                        dls = inside ? g_raw * sd * n1 + w_lp * (-1.f) : 0.f;
+                        const float raw2 = mu + sd * n2, t2 = tanhf(raw2), om2 = 1.f - t2 * t2;
+                        float g2 = 0.f;
+                        g2 += -1.f * g * om2;
+                        dmu = dmu + g2;
+                        dls = dls + (inside ? g2 * sd * n2 + 0.f * (-1.f) : 0.f);
+                    } else {
+                        float gr = g_raw;
+                        gr += -1.f * g * one_m;
+                        dmu = gr;
+                        dls = inside ? gr * sd * n1 + w_lp * (-1.f) : 0.f;
+                    }
+                }
+            }
+            if (a < A) {
+                dyb[r * HP + a] = dmu;
+                dyb[r * HP + A + a] = dls;
+                if (c == 0 && i < B) {
+                    p.dyP[(size_t)i * 64 + a] = dmu;
+                    p.dyP[(size_t)i * 64 + A + a] = dls;
+                }
+            } else if (a >= 2 * A) {
+                dyb[r * HP + a] = 0.f;
+            }
+        }
+        __syncthreads();
+        dense_bwdT_few_cols<RS>(dyb, HP, 2 * A, p.pw + m.o_w3 + (size_t)lo * 2 * A, wc, b, SP, cb, SP, p.dz2P + lo, p.ldh, row0, B);
+        dense_bwdT<RS>(cb, SP, wc, p.pw + m.o_w2 + lo, m.h2, m.h1, nullptr, 0, d, SP, wt, p.dh1Pp + (size_t)c * p.Bp * p.ldh, p.ldh,
+                       row0, B);
+    } else {
+        // ---- V (kind 1) or Q tower kind - 2: the regression loss of a Dense(1) head and its backward pass
+        const bool isv = kind == 1;
+        const int t = kind - 2;
+        const SacQ &q = p.qm;
+        const Mlp3 &m = p.vm;
+        const int NH = isv ? m.h2 : H;
+        const int lo = slice_lo(NH, c), hi = slice_lo(NH, c + 1), wc = hi - lo;
+        load_rows<RS>(b, SP, (isv ? p.h2V : p.h2Q + (size_t)t * p.Bp * p.ldh) + lo, p.ldh, wc, row0, B);
+        if (tid < RS) {
+            const int i = row0 + tid;
+            float dv = 0.f, term = 0.f;
+            if (i < B) {
+                const float *pp = (isv ? p.vp : p.qp + (size_t)t * kSplit * B) + i;
+                float v = pp[0];
+#pragma unroll
+                for (int z = 1; z < kSplit; ++z) v += pp[(size_t)z * B];
+                v += isv ? p.vw[m.o_b3] : p.qw[q.o_bq + t * q.s_q];
+                float y;
+                if (isv) {
+                    y = p.value_targets[i];
+                } else {
+                    const float *tp = p.vTp + i;
+                    float vt = tp[0];
+#pragma unroll
+                    for (int z = 1; z < kSplit; ++z) vt += tp[(size_t)z * B];
+                    vt += p.vwt[m.o_b3];
+                    const double yy = (double)p.rewards[i] + (1.0 - (p.dones[i] ? 1.0 : 0.0)) * p.discount * (double)vt;   // :259-266
+                    y = (float)yy;
+                    if (t == 0 && c == 0) p.td_targets[i] = y;
+                }
+                const float w = isv ? 1.f : 0.5f;                      // v_head.py MSE; sac_q_head.py:91-95 0.5 * mse each
+                const float e = v - y;
+                term = w * (e * e);
+                dv = 1.f * w * (2.f * e) / (float)B;
+                if (c == 0) (isv ? p.dvV : p.dqQ + (size_t)t * p.Bp * 64)[(size_t)i * 64] = dv;
+            }
+            small[tid] = dv;
+            small[RS + tid] = term;
+        }
+        __syncthreads();
+        if (tid == 0 && c == 0) {
+            float sacc = 0.f;
+            for (int r = 0; r < RS; ++r) sacc += small[RS + r];
+            (isv ? p.v_loss_part : p.q_loss_part + (size_t)t * p.nrb)[rb] = sacc;
+        }
+        const float *w3 = (isv ? p.vw + m.o_w3 : p.qw + q.o_wq + t * q.s_q) + lo;
+        float *save = (isv ? p.dz2V : p.dfc1 + (size_t)t * p.Bp * p.ldh) + lo;
+        for (int e = tid; e < RS * pad16(wc); e += T) {
+            const int r = e / pad16(wc), k = e - r * pad16(wc);
+            float v = 0.f;
+            if (k < wc && b[r * SP + k] > 0.f) v = small[r] * w3[k];
+            cb[r * SP + k] = v;
+            if (k < wc && row0 + r < B) save[(size_t)(row0 + r) * p.ldh + k] = v;
+        }
+        __syncthreads();
+        const float *w2 = isv ? p.vw + m.o_w2 + lo : p.qw + q.o_w1 + t * q.s_1 + lo;
+        float *part = isv ? p.dh1Vp + (size_t)c * p.Bp * p.ldh : p.dhqp + ((size_t)t * kSplit + c) * p.Bp * p.ldh;
+        dense_bwdT<RS>(cb, SP, wc, w2, NH, isv ? m.h1 : H, nullptr, 0, d, SP, wt, part, p.ldh, row0, B);
+    }
+}
+
 static bool g_stamps = false;            // rlx_fused_phase_stamps(1): workgroup 0 of every chain kernel records its phase boundaries
 
 inline Td3Dev td3_dev(const rlx_td3_fused_desc &d) {
@@ -763,6 +1143,72 @@ inline Td3Dev td3_dev(const rlx_td3_fused_desc &d) {
     p.dz3 = ws + w.dz3; p.dh2a = ws + w.dh2a; p.dh1ap = ws + w.dh1ap;
     p.td_targets = d.td_targets; p.q_min = d.q_min; p.neg_dq_da = d.neg_action_grad;
     p.stamps = g_stamps ? reinterpret_cast<long long *>(ws + w.stamps) : nullptr;
+    return p;
+}
+
+
+struct SacWs {
+    long long xs, ab, h1P, h1V, ho, h2P, h2V, haB, hs, h2Q, dyP, dz2P, dh1Pp, dvV, dz2V, dh1Vp, dqQ, dfc1, dhqp;
+    long long h1VT, zP, vp, vTp, qp, logp0, haP, h2Qp, qpp, dhpp, v_loss_part, q_loss_part, norm_part, stamps, total;
+};
+inline int sac_blocks(const rlx_sac_fused_desc &d) {
+    const int D = d.obs_dim, A = d.act_dim, H = d.q_hidden;
+    const rlx_mlp3 &pm = d.policy_mlp, &vm = d.v_mlp;
+    return tiles_of(D, pm.h1) + tiles_of(pm.h1, pm.h2) + tiles_of(pm.h2, 2 * A) + tiles_of(D, vm.h1) + tiles_of(vm.h1, vm.h2) +
+           tiles_of(vm.h2, 1) + 2 * (tiles_of(D, H) + tiles_of(A, H) + tiles_of(H, H) + tiles_of(H, 1));
+}
+inline SacWs sac_layout(const rlx_sac_fused_desc &d) {
+    SacWs w;
+    long long o = 0;
+    auto take = [&](long long n) { const long long at = o; o += (n + 3) & ~3LL; return at; };
+    const long long B = d.batch, Bp = pad128(d.batch), ldx = pad64(d.obs_dim), ldh = pad64(d.q_hidden), H = d.q_hidden, A = d.act_dim;
+    const long long nrb = (B + RS - 1) / RS;
+    // (the operands of the weight-gradient launch first, padded; they rely on the workspace having been ZEROED at allocation)
+    w.xs = take(Bp * ldx); w.ab = take(Bp * 64);
+    w.h1P = take(Bp * ldh); w.h1V = take(Bp * ldh); w.ho = take(2 * Bp * ldh); w.h2P = take(Bp * ldh); w.h2V = take(Bp * ldh);
+    w.haB = take(2 * Bp * ldh); w.hs = take(2 * Bp * ldh); w.h2Q = take(2 * Bp * ldh);
+    w.dyP = take(Bp * 64); w.dz2P = take(Bp * ldh); w.dh1Pp = take(kSplit * Bp * ldh);
+    w.dvV = take(Bp * 64); w.dz2V = take(Bp * ldh); w.dh1Vp = take(kSplit * Bp * ldh);
+    w.dqQ = take(2 * Bp * 64); w.dfc1 = take(2 * Bp * ldh); w.dhqp = take(2LL * kSplit * Bp * ldh);
+    w.h1VT = take(B * H); w.zP = take(B * kSplit * 2 * A); w.vp = take(kSplit * B); w.vTp = take(kSplit * B); w.qp = take(2LL * kSplit * B);
+    w.logp0 = take(B); w.haP = take(2 * B * H); w.h2Qp = take(2 * B * H); w.qpp = take(2LL * kSplit * B); w.dhpp = take(2LL * kSplit * B * H);
+    w.v_loss_part = take(nrb); w.q_loss_part = take(2 * nrb);
+    w.norm_part = take(sac_blocks(d));
+    w.stamps = take(2 * 96);
+    w.total = o;
+    return w;
+}
+inline int sac_check(const rlx_sac_fused_desc &d) {
+    const rlx_mlp3 &pm = d.policy_mlp, &vm = d.v_mlp;
+    const int H = d.q_hidden;
+    if (d.batch < 1 || d.batch > 4096 || d.obs_dim < 1 || d.obs_dim > SP - 4 || d.act_dim < 1 || 2 * d.act_dim > HP - 16) return 0;
+    if (pm.d_in != d.obs_dim || vm.d_in != d.obs_dim || pm.d_out != 2 * d.act_dim || vm.d_out != 1) return 0;
+    const int widths[5] = {pm.h1, pm.h2, vm.h1, vm.h2, H};
+    for (int i = 0; i < 5; ++i)
+        if (widths[i] % 4 || widths[i] < 32 * kSplit || widths[i] > SP - 4) return 0;
+    return 1;
+}
+inline SacDev sac_dev(const rlx_sac_fused_desc &d) {
+    SacDev p;
+    const SacWs w = sac_layout(d);
+    p.pw = d.policy.weights; p.vw = d.v.weights; p.vwt = d.v.target_weights; p.qw = d.q.weights;
+    p.pm = to_dev(d.policy_mlp); p.vm = to_dev(d.v_mlp);
+    p.qm.o_wo = d.q_off_obs_w; p.qm.o_bo = d.q_off_obs_b; p.qm.o_wa = d.q_off_act_w; p.qm.o_ba = d.q_off_act_b;
+    p.qm.o_w1 = d.q_off_fc_w; p.qm.o_b1 = d.q_off_fc_b; p.qm.o_wq = d.q_off_out_w; p.qm.o_bq = d.q_off_out_b;
+    p.qm.s_o = d.q_stride_obs; p.qm.s_a = d.q_stride_act; p.qm.s_1 = d.q_stride_fc; p.qm.s_q = d.q_stride_out;
+    p.obs = d.obs; p.next_obs = d.next_obs; p.actions = d.actions; p.rewards = d.rewards; p.dones = d.game_overs;
+    p.normals = d.normals; p.discount = d.discount; p.resample = d.resample_noise_per_pass;
+    p.B = d.batch; p.D = d.obs_dim; p.A = d.act_dim; p.H = d.q_hidden; p.nrb = (d.batch + RS - 1) / RS;
+    p.Bp = pad128(d.batch); p.ldx = pad64(d.obs_dim); p.ldh = pad64(d.q_hidden);
+    float *ws = d.workspace;
+    p.xs = ws + w.xs; p.ab = ws + w.ab; p.h1P = ws + w.h1P; p.h1V = ws + w.h1V; p.ho = ws + w.ho; p.h2P = ws + w.h2P; p.h2V = ws + w.h2V;
+    p.haB = ws + w.haB; p.hs = ws + w.hs; p.h2Q = ws + w.h2Q; p.dyP = ws + w.dyP; p.dz2P = ws + w.dz2P; p.dh1Pp = ws + w.dh1Pp;
+    p.dvV = ws + w.dvV; p.dz2V = ws + w.dz2V; p.dh1Vp = ws + w.dh1Vp; p.dqQ = ws + w.dqQ; p.dfc1 = ws + w.dfc1; p.dhqp = ws + w.dhqp;
+    p.h1VT = ws + w.h1VT; p.zP = ws + w.zP; p.vp = ws + w.vp; p.vTp = ws + w.vTp; p.qp = ws + w.qp; p.logp0 = ws + w.logp0;
+    p.haP = ws + w.haP; p.h2Qp = ws + w.h2Qp; p.qpp = ws + w.qpp; p.dhpp = ws + w.dhpp; p.v_loss_part = ws + w.v_loss_part;
+    p.q_loss_part = ws + w.q_loss_part;
+    p.value_targets = d.value_targets; p.log_target = d.log_target; p.td_targets = d.td_targets; p.dq_da = d.dq_da;
+    p.stamps = nullptr;
     return p;
 }
 
@@ -883,6 +1329,83 @@ int rlx_td3_fused_actor_update(const rlx_td3_fused_desc *d_host, int write_grads
     b.add_job(net, p.h2a, p.ld2a, p.dz3, 64, am.off_w3, am.off_b3, am.h2, d.act_dim);
     const Td3Ws w = td3_layout(d.batch, d.obs_dim, d.act_dim, d.actor_mlp, d.critic_mlp);
     return launch_dw(b, B, write_grads, d.workspace + w.norm_part, d.actor.ticket, st);
+}
+
+
+int rlx_sac_fused_supported(const rlx_sac_fused_desc *d) { return d ? sac_check(*d) : 0; }
+
+int rlx_sac_fused_workspace_floats(const rlx_sac_fused_desc *d, long long *floats_host) {
+    RLX_REQUIRE(d && floats_host, "rlx_sac_fused_workspace_floats: null pointer");
+    RLX_REQUIRE(sac_check(*d), "rlx_sac_fused_workspace_floats: unsupported shape");
+    *floats_host = sac_layout(*d).total;
+    return RLX_OK;
+}
+
+// SoftActorCriticAgent.learn_from_batch (soft_actor_critic_agent.py:168-280) as six launches.  write_grads != 0: the weight
+// gradients of all three networks go to their grads buffers and no optimiser step is taken.
+int rlx_sac_fused_update(const rlx_sac_fused_desc *d_host, int write_grads, void *stream) {
+    RLX_REQUIRE(d_host != nullptr, "rlx_sac_fused_update: null descriptor");
+    const rlx_sac_fused_desc &d = *d_host;
+    RLX_REQUIRE(sac_check(d), "rlx_sac_fused_update: unsupported shape (batch=%d obs=%d act=%d hidden %d)", d.batch, d.obs_dim,
+                d.act_dim, d.q_hidden);
+    RLX_REQUIRE(d.policy.weights && d.q.weights && d.v.weights && d.v.target_weights && d.obs && d.next_obs && d.actions &&
+                    d.rewards && d.game_overs && d.normals && d.workspace && d.value_targets && d.log_target && d.td_targets &&
+                    d.dq_da && d.q_loss && d.v_loss,
+                "rlx_sac_fused_update: null pointer");
+    const rlx_fused_net *nets[3] = {&d.policy, &d.q, &d.v};
+    for (int i = 0; i < 3; ++i)
+        RLX_REQUIRE(write_grads ? nets[i]->grads != nullptr : (nets[i]->adam_m && nets[i]->adam_v && nets[i]->adam_state),
+                    "rlx_sac_fused_update: null optimiser pointer (network %d)", i);
+    RLX_REQUIRE(d.policy.ticket != nullptr, "rlx_sac_fused_update: null ticket");
+    const SacWs w = sac_layout(d);
+    RLX_REQUIRE(d.workspace_floats >= w.total, "rlx_sac_fused_update: workspace of %lld floats, need %lld", d.workspace_floats, w.total);
+    static bool configured = false;
+    if (!configured) {
+        RLX_HIP(set_lds(sac_layer1_kernel, kSacFwdLds));
+        RLX_HIP(set_lds(sac_layer2_kernel, kSacFwdLds));
+        RLX_HIP(set_lds(sac_q_pi_kernel, kSacFwdLds));
+        RLX_HIP(set_lds(sac_q_grad_kernel, kSacBwdLds));
+        RLX_HIP(set_lds(sac_backward_kernel, kSacBwdLds));
+        configured = true;
+    }
+    const SacDev p = sac_dev(d);
+    hipStream_t st = rlx::as_stream(stream);
+    RLX_LAUNCH((sac_layer1_kernel), 5 * kSplit * p.nrb, T, kSacFwdLds, st, p);
+    RLX_LAUNCH_CHECK();
+    RLX_LAUNCH((sac_layer2_kernel), 5 * kSplit * p.nrb, T, kSacFwdLds, st, p);
+    RLX_LAUNCH_CHECK();
+    RLX_LAUNCH((sac_q_pi_kernel), 2 * kSplit * p.nrb, T, kSacFwdLds, st, p);
+    RLX_LAUNCH_CHECK();
+    RLX_LAUNCH((sac_q_grad_kernel), 2 * kSplit * p.nrb, T, kSacBwdLds, st, p);
+    RLX_LAUNCH_CHECK();
+    RLX_LAUNCH((sac_backward_kernel), 4 * kSplit * p.nrb, T, kSacBwdLds, st, p);
+    RLX_LAUNCH_CHECK();
+    DwBuilder b;
+    const int np = b.add_net(d.policy);
+    const rlx_mlp3 &pm = d.policy_mlp, &vm = d.v_mlp;
+    const long long Bp = p.Bp, ldh = p.ldh;
+    const int D = d.obs_dim, A = d.act_dim, H = d.q_hidden;
+    b.add_partial_job(np, p.xs, p.ldx, p.dh1Pp, ldh, kSplit, Bp * ldh, p.h1P, pm.off_w1, pm.off_b1, D, pm.h1);
+    b.add_job(np, p.h1P, ldh, p.dz2P, ldh, pm.off_w2, pm.off_b2, pm.h1, pm.h2);
+    b.add_job(np, p.h2P, ldh, p.dyP, 64, pm.off_w3, pm.off_b3, pm.h2, 2 * A);
+    const int nq = b.add_net(d.q);
+    for (int t = 0; t < 2; ++t) {
+        b.add_partial_job(nq, p.xs, p.ldx, p.dhqp + (size_t)t * kSplit * Bp * ldh, ldh, kSplit, Bp * ldh, p.ho + (size_t)t * Bp * ldh,
+                          d.q_off_obs_w + t * d.q_stride_obs, d.q_off_obs_b + t * d.q_stride_obs, D, H);
+        b.add_partial_job(nq, p.ab, 64, p.dhqp + (size_t)t * kSplit * Bp * ldh, ldh, kSplit, Bp * ldh, p.haB + (size_t)t * Bp * ldh,
+                          d.q_off_act_w + t * d.q_stride_act, d.q_off_act_b + t * d.q_stride_act, A, H);
+        b.add_job(nq, p.hs + (size_t)t * Bp * ldh, ldh, p.dfc1 + (size_t)t * Bp * ldh, ldh, d.q_off_fc_w + t * d.q_stride_fc,
+                  d.q_off_fc_b + t * d.q_stride_fc, H, H);
+        b.add_job(nq, p.h2Q + (size_t)t * Bp * ldh, ldh, p.dqQ + (size_t)t * Bp * 64, 64, d.q_off_out_w + t * d.q_stride_out,
+                  d.q_off_out_b + t * d.q_stride_out, H, 1);
+    }
+    const int nv = b.add_net(d.v);
+    b.add_partial_job(nv, p.xs, p.ldx, p.dh1Vp, ldh, kSplit, Bp * ldh, p.h1V, vm.off_w1, vm.off_b1, D, vm.h1);
+    b.add_job(nv, p.h1V, ldh, p.dz2V, ldh, vm.off_w2, vm.off_b2, vm.h1, vm.h2);
+    b.add_job(nv, p.h2V, ldh, p.dvV, 64, vm.off_w3, vm.off_b3, vm.h2, 1);
+    b.a.loss_part = p.q_loss_part; b.a.loss_out = d.q_loss; b.a.loss_streams = 2; b.a.loss_parts = p.nrb; b.a.loss_scale = 1.f;
+    b.a.loss2_part = p.v_loss_part; b.a.loss2_out = d.v_loss; b.a.loss2_parts = p.nrb;
+    return launch_dw(b, d.batch, write_grads, d.workspace + w.norm_part, d.policy.ticket, st);
 }
 
 }  // extern "C"

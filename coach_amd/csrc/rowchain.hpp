@@ -27,7 +27,8 @@
 
 namespace rlx_chain {
 
-constexpr int R = 4;                       // batch rows per workgroup (= the rows of a 4 x 4 MFMA block)
+constexpr int R = 4;                       // batch rows per workgroup: one 4 x 4 MFMA block row set (the functions' default RR);
+                                           // RR = 8 gives a workgroup two of them on the same weight registers (SAC: B = 256)
 constexpr int T = 512;                     // threads per workgroup (8 waves)
 constexpr int kPartFloats = 8192;          // K-split partial sums: S * R * N <= kPartFloats
 constexpr int kMaxWidth = 512;             // widest activation row held in LDS
@@ -73,9 +74,10 @@ __device__ __forceinline__ void prefetch_retire(PrefetchToken &t) {
 __device__ __forceinline__ long long layer_floats(int K, int N) { return (((long long)K * N + 3) & ~3LL) + ((N + 3) & ~3); }
 
 // xs[r][c] = src[row0 + r][c] for c < cols, 0 up to `pitch` and for rows >= B
+template <int RR = R>
 __device__ __forceinline__ void load_rows(float *xs, int pitch, const float *__restrict__ src, long long ld, int cols,
                                           int row0, int B) {
-    for (int e = threadIdx.x; e < R * pitch; e += T) {
+    for (int e = threadIdx.x; e < RR * pitch; e += T) {
         const int r = e / pitch, c = e - r * pitch;
         xs[e] = (c < cols && row0 + r < B) ? src[(long long)(row0 + r) * ld + c] : 0.f;
     }
@@ -88,9 +90,11 @@ __device__ __forceinline__ void load_rows(float *xs, int pitch, const float *__r
 //   parts: LDS scratch of kPartFloats.  Ends with a barrier: ys is readable by every thread.
 //   ldw: row stride of W in floats (= N for a whole layer; a column SLICE of a layer passes the layer's width and W / bias /
 //   gout already offset to the slice's first column).
+template <int RR = R>
 __device__ __forceinline__ void dense_fwd(const float *xs, int xp, int K, const float *__restrict__ W, int ldw,
                                           const float *__restrict__ bias, int N, int act, float *ys, int yp, float *parts,
                                           float *__restrict__ gout, long long gld, int row0, int B) {
+    constexpr int RB = RR / 4;                       // 4-row MFMA block sets of the workgroup
     const int tid = threadIdx.x;
     int S;
     if ((N & 3) == 0 && N >= 32) {
@@ -98,24 +102,27 @@ __device__ __forceinline__ void dense_fwd(const float *xs, int xp, int K, const 
         // lanes of an MFMA block share their slice (G4 is a multiple of 4), the blocks of a wave need not
         const int G = N >> 2, G4 = (G + 3) & ~3;
         S = T / G4;
-        while (S > 1 && S * R * N > kPartFloats) --S;
+        while (S > 1 && S * RR * N > kPartFloats) --S;
         if (S > 16) S = 16;
         const int Kc = (((K + S - 1) / S) + 15) & ~15;
         S = (K + Kc - 1) / Kc;
         const int g = tid % G4, s = tid / G4;
         if (s < S) {
-            f32x4 acc[4];                              // acc[c][r] = out[r][4 g + c]
+            f32x4 acc[RB][4];                          // acc[rb][c][r] = out[4 rb + r][4 g + c]
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int K16 = (K + 15) & ~15;
             const int k1 = min(K16, (s + 1) * Kc);
             const unsigned nb = (unsigned)ldw * 4u;                        // bytes per weight row
             const char *wc = reinterpret_cast<const char *>(W + 4 * min(g, G - 1));
-            const float *xrow = xs + (tid & 3) * xp;                       // A operand: this lane's row of the block
+            const float *xrow = xs + (tid & 3) * xp;                       // A operand: this lane's row of the block (+ 4 rb rows)
 #ifndef RLX_CHAIN_STEP
 #define RLX_CHAIN_STEP 32
 #endif
-            constexpr int kStep = RLX_CHAIN_STEP;     // weight rows requested per step (a multiple of 16)
+            // weight rows requested per step (a multiple of 16); 8-row workgroups keep it at 16: 128 registers, two workgroups per CU
+            constexpr int kStep = RR > 4 ? 16 : RLX_CHAIN_STEP;
             for (int k = s * Kc; k < k1; k += kStep) {
                 // all weight rows of the step are requested, THEN consumed (the sched_barriers keep the scheduler from
                 // sinking each load to its first use); rows in [K, K16) re-read row K - 1 against zeros of xs, rows beyond
@@ -128,9 +135,12 @@ __device__ __forceinline__ void dense_fwd(const float *xs, int xp, int K, const 
 #pragma unroll
                 for (int j = 0; j < kStep; ++j) w[j] = f32x4{1.f + tid + j, 2.f, 3.f, 4.f + k};
 #endif
-                f32x4 xa[kStep / 4];
+                f32x4 xa[RB][kStep / 4];
 #pragma unroll
-                for (int q = 0; q < kStep / 4; ++q) xa[q] = *reinterpret_cast<const f32x4 *>(xrow + min(k + 4 * q, K16 - 4));
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int q = 0; q < kStep / 4; ++q)
+                        xa[rb][q] = *reinterpret_cast<const f32x4 *>(xrow + 4 * rb * xp + min(k + 4 * q, K16 - 4));
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef RLX_CHAIN_ABLATE_MATH
 #pragma unroll
@@ -141,25 +151,28 @@ __device__ __forceinline__ void dense_fwd(const float *xs, int xp, int K, const 
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const f32x4 wv = w[4 * q + e];
-                                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[q][e], wv[0], acc[0], 0, 0, 0);
-                                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[q][e], wv[1], acc[1], 0, 0, 0);
-                                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[q][e], wv[2], acc[2], 0, 0, 0);
-                                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[q][e], wv[3], acc[3], 0, 0, 0);
+#pragma unroll
+                                for (int rb = 0; rb < RB; ++rb) {
+                                    acc[rb][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[rb][q][e], wv[0], acc[rb][0], 0, 0, 0);
+                                    acc[rb][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[rb][q][e], wv[1], acc[rb][1], 0, 0, 0);
+                                    acc[rb][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[rb][q][e], wv[2], acc[rb][2], 0, 0, 0);
+                                    acc[rb][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[rb][q][e], wv[3], acc[rb][3], 0, 0, 0);
+                                }
                             }
                         }
                     }
                 }
 #else
 #pragma unroll
-                for (int j = 0; j < kStep; ++j) acc[j & 3][0] += w[j][0] + w[j][1] + w[j][2] + w[j][3] + xa[j & 3][0];
+                for (int j = 0; j < kStep; ++j) acc[0][j & 3][0] += w[j][0] + w[j][1] + w[j][2] + w[j][3] + xa[0][j & 3][0];
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (g < G) {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    *reinterpret_cast<float4 *>(parts + (size_t)(s * R + r) * N + 4 * g) =
-                        make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                for (int r = 0; r < RR; ++r)
+                    *reinterpret_cast<float4 *>(parts + (size_t)(s * RR + r) * N + 4 * g) =
+                        make_float4(acc[r >> 2][0][r & 3], acc[r >> 2][1][r & 3], acc[r >> 2][2][r & 3], acc[r >> 2][3][r & 3]);
             }
         }
     } else {
@@ -172,9 +185,9 @@ __device__ __forceinline__ void dense_fwd(const float *xs, int xp, int K, const 
         S = (K + Kc - 1) / Kc;
         const int n = tid % N, s = tid / N;
         if (s < S) {
-            float acc[R];
+            float acc[RR];
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = 0.f;
+            for (int r = 0; r < RR; ++r) acc[r] = 0.f;
             const int k1 = min(K, (s + 1) * Kc);
             for (int k = s * Kc; k < k1; k += 8) {
                 float w[8];
@@ -188,23 +201,23 @@ __device__ __forceinline__ void dense_fwd(const float *xs, int xp, int K, const 
                 for (int j = 0; j < 8; ++j) {
                     const int kk = min(k + j, k1 - 1);
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r] = fmaf(xs[r * xp + kk], w[j], acc[r]);
+                    for (int r = 0; r < RR; ++r) acc[r] = fmaf(xs[r * xp + kk], w[j], acc[r]);
                 }
             }
 #pragma unroll
-            for (int r = 0; r < R; ++r) parts[(size_t)(s * R + r) * N + n] = acc[r];
+            for (int r = 0; r < RR; ++r) parts[(size_t)(s * RR + r) * N + n] = acc[r];
         }
     }
     __syncthreads();
     const int N16 = pad16(N);                        // the next layer reads its input in steps of 16: zero the tail
-    for (int o = tid; o < R * N16; o += T) {
+    for (int o = tid; o < RR * N16; o += T) {
         const int r = o / N16, n = o - r * N16;
         if (n >= N) {
             ys[r * yp + n] = 0.f;
             continue;
         }
         float v = parts[(size_t)r * N + n];
-        for (int s = 1; s < S; ++s) v += parts[(size_t)(s * R + r) * N + n];
+        for (int s = 1; s < S; ++s) v += parts[(size_t)(s * RR + r) * N + n];
         v = act_apply(bias ? v + bias[n] : v, act);
         ys[r * yp + n] = v;
         if (gout && row0 + r < B) gout[(long long)(row0 + r) * gld + n] = v;
@@ -223,9 +236,11 @@ __device__ __forceinline__ void dense_fwd(const float *xs, int xp, int K, const 
 //   forward pass: relu mask) or null.  wt: LDS, 2 * kTileFloats.  Ends with a barrier.
 //   ldw: row stride of W in floats; a column slice passes W offset to its first column, N = the slice's width and dys =
 //   the slice's entries of dy.
+template <int RR = R>
 __device__ __forceinline__ void dense_bwdT(const float *dys, int dp, int N, const float *__restrict__ W, int ldw, int K,
                                            const float *hs, int hp, float *dxs, int xp, float *wt,
                                            float *__restrict__ gout, long long gld, int row0, int B) {
+    constexpr int RB = RR / 4;
     const int tid = threadIdx.x;
     constexpr int kPre = kMaxWidth * (kTileCols / 4) / T;           // 4 pieces of 16 bytes per thread and tile
     static_assert(kPre == 4, "dense_bwdT: four pieces per thread and tile");
@@ -250,21 +265,26 @@ __device__ __forceinline__ void dense_bwdT(const float *dys, int dp, int N, cons
     _Pragma("unroll") for (int i = 0; i < kPre; ++i) *reinterpret_cast<f32x4 *>((buf) + dst_off[i]) = pre[i];
     const int krow = min((tid >> 6) * 64 + (tid & 63), kMaxWidth - 1);       // this lane's output k
     const float *arow = dys + (tid & 3) * dp;
-    f32x4 acc[4];
+    f32x4 acc[RB][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define RLX_CHAIN_TILE(cur, t)                                                                                \
     {                                                                                                         \
-        float4 bq[4], aq[4];                                                                                  \
+        float4 bq[4], aq[RB][4];                                                                              \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                       \
             bq[q] = *reinterpret_cast<const float4 *>((cur) + krow * kTilePitch + 4 * q);                     \
-            aq[q] = *reinterpret_cast<const float4 *>(arow + (t) * kTileCols + 4 * q);                        \
+            _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                 \
+                aq[rb][q] = *reinterpret_cast<const float4 *>(arow + 4 * rb * dp + (t) * kTileCols + 4 * q);  \
         }                                                                                                     \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                       \
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[q].x, bq[q].x, acc[0], 0, 0, 0);                   \
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[q].y, bq[q].y, acc[1], 0, 0, 0);                   \
-            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[q].z, bq[q].z, acc[2], 0, 0, 0);                   \
-            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[q].w, bq[q].w, acc[3], 0, 0, 0);                   \
+            _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) {                                               \
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[rb][q].x, bq[q].x, acc[rb][0], 0, 0, 0);   \
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[rb][q].y, bq[q].y, acc[rb][1], 0, 0, 0);   \
+                acc[rb][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[rb][q].z, bq[q].z, acc[rb][2], 0, 0, 0);   \
+                acc[rb][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[rb][q].w, bq[q].w, acc[rb][3], 0, 0, 0);   \
+            }                                                                                                 \
         }                                                                                                     \
     }
     float *buf0 = wt, *buf1 = wt + kTileFloats;
@@ -310,15 +330,15 @@ __device__ __forceinline__ void dense_bwdT(const float *dys, int dp, int N, cons
     const int k = (tid >> 6) * 64 + (tid & 63);
     if (k < K) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+        for (int r = 0; r < RR; ++r) {
+            float v = (acc[r >> 2][0][r & 3] + acc[r >> 2][1][r & 3]) + (acc[r >> 2][2][r & 3] + acc[r >> 2][3][r & 3]);
             if (hs && !(hs[r * hp + k] > 0.f)) v = 0.f;
             dxs[r * xp + k] = v;
             if (gout && row0 + r < B) gout[(long long)(row0 + r) * gld + k] = v;
         }
     }
     // the consumers read their input in steps of 16: zero the tail
-    for (int e = tid; e < R * (pad16(K) - K); e += T) {
+    for (int e = tid; e < RR * (pad16(K) - K); e += T) {
         const int r = e / (pad16(K) - K), c = e - r * (pad16(K) - K);
         dxs[r * xp + K + c] = 0.f;
     }
@@ -327,21 +347,22 @@ __device__ __forceinline__ void dense_bwdT(const float *dys, int dp, int N, cons
 
 // Transposed product of a NARROW layer (heads, N <= 64): dxs[r][k] = mask * sum_n dys[r][n] W[k][n]; thread k reads its
 // N contiguous weights (adjacent threads, adjacent rows: the wave covers one contiguous span).
+template <int RR = R>
 __device__ __forceinline__ void dense_bwdT_few_cols(const float *dys, int dp, int N, const float *__restrict__ W, int K,
                                                     const float *hs, int hp, float *dxs, int xp, float *__restrict__ gout,
                                                     long long gld, int row0, int B) {
     for (int k = threadIdx.x; k < pad16(K); k += T) {
-        float acc[R];
+        float acc[RR];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        for (int r = 0; r < RR; ++r) acc[r] = 0.f;
         if (k < K)
             for (int n = 0; n < N; ++n) {
                 const float w = W[(size_t)k * N + n];
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r] = fmaf(dys[r * dp + n], w, acc[r]);
+                for (int r = 0; r < RR; ++r) acc[r] = fmaf(dys[r * dp + n], w, acc[r]);
             }
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < RR; ++r) {
             float v = acc[r];
             if (k >= K || (hs && !(hs[r * hp + k] > 0.f))) v = 0.f;
             dxs[r * xp + k] = v;
@@ -353,10 +374,11 @@ __device__ __forceinline__ void dense_bwdT_few_cols(const float *dys, int dp, in
 
 // Transposed product onto FEW outputs (the action columns of a critic's first layer, K <= 64 rows of W): a wave per
 // (row r, output k), lanes along n (coalesced), butterfly sum.  dxs[r][k] = scale * sum_n dys[r][n] W[k][n].
+template <int RR = R>
 __device__ __forceinline__ void dense_bwdT_few_rows(const float *dys, int dp, int N, const float *__restrict__ W, long long ldw,
                                                     int K, float scale, float *dxs, int xp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = wave; o < R * K; o += T / 64) {
+    for (int o = wave; o < RR * K; o += T / 64) {
         const int r = o / K, k = o - r * K;
         float s = 0.f;
         for (int n = lane; n < N; n += 64) s = fmaf(dys[r * dp + n], W[(size_t)k * ldw + n], s);

@@ -115,3 +115,70 @@ class FusedTD3(object):
     def actor_update(self, b, mix=None, write_grads=False):
         self._fill(b, mix)
         _rlx.lib().td3_fused_actor_update(ctypes.byref(self.desc), int(write_grads), _rlx.current_stream())
+
+
+class FusedSAC(object):
+    """SoftActorCriticAgent's update through rlx_sac_fused_update (six launches).  Taken for the Mujoco_SAC topology: policy
+    and V with one embedder layer + one middleware layer (relu), the twin Q head with two layers of one width."""
+
+    @staticmethod
+    def layers(agent):
+        pol, q, v = (agent.networks[k] for k in ("policy", "q", "v"))
+        pe, pm, ve, vm = (_dense_layers(x) for x in (pol.emb, pol.mid, v.emb, v.mid))
+        if None in (pe, pm, ve, vm) or any(len(x) != 1 for x in (pe, pm, ve, vm)) or len(q.fcs) != 1:
+            return None
+        if any(l.act != "relu" for l in pe + pm + ve + vm + [q.obs_fc, q.act_fc] + q.fcs):
+            return None
+        if pol.head.act is not None or v.head.act is not None or q.out.act is not None or q.fcs[0].N != q.h0:
+            return None
+        return (pe[0], pm[0], pol.head), (ve[0], vm[0], v.head)
+
+    def __init__(self, agent):
+        self.agent = agent
+        ls = self.layers(agent)
+        if ls is None:
+            raise ValueError("FusedSAC: unsupported network topology")
+        pol, q, v = (agent.networks[k] for k in ("policy", "q", "v"))
+        d = self.desc = _rlx.SacFusedDesc()
+        d.policy_mlp = mlp3(pol.params, *ls[0])
+        d.v_mlp = mlp3(v.params, *ls[1])
+        P = q.params
+        for tag, l in (("obs", q.obs_fc), ("act", q.act_fc), ("fc", q.fcs[0]), ("out", q.out)):
+            setattr(d, "q_off_%s_w" % tag, P.entries[l.kname][0])
+            setattr(d, "q_off_%s_b" % tag, P.entries[l.bname][0])
+            if P.stride(l.kname) != P.stride(l.bname):
+                raise ValueError("FusedSAC: kernel and bias tower strides differ")
+            setattr(d, "q_stride_%s" % tag, P.stride(l.kname))
+        d.batch, d.obs_dim, d.act_dim, d.q_hidden = agent.batch_size, agent.obs_dim, agent.A, q.h0
+        if not _rlx.lib().sac_fused_supported(ctypes.byref(d)):
+            raise ValueError("FusedSAC: unsupported shape")
+        need = ctypes.c_longlong()
+        _rlx.lib().sac_fused_workspace_floats(ctypes.byref(d), ctypes.byref(need))
+        self.ws = torch.zeros(need.value, dtype=torch.float32, device=agent.device)
+        d.workspace, d.workspace_floats = self.ws.data_ptr(), need.value
+        alg = agent.ap.algorithm
+        d.discount = float(alg.discount)
+        d.resample_noise_per_pass = int(bool(alg.resample_noise_per_pass))
+        d.value_targets, d.log_target = agent.value_targets.data_ptr(), agent.log_target.data_ptr()
+        d.td_targets, d.dq_da = agent.td_targets.data_ptr(), agent.dq_da.data_ptr()
+        d.q_loss, d.v_loss = q.loss.data_ptr(), v.loss.data_ptr()
+
+    @classmethod
+    def supported(cls, agent):
+        try:
+            cls(agent)
+            return True
+        except (ValueError, AttributeError):
+            return False
+
+    def update(self, b, mix=None, write_grads=False):
+        a, d = self.agent, self.desc
+        pol, q, v = (a.networks[k] for k in ("policy", "q", "v"))
+        d.policy = fused_net(pol, a._scale("policy"))
+        d.q = fused_net(q, a._scale("q"), with_norm=True)
+        d.v = fused_net(v, a._scale("v"), mix)
+        d.obs = b._states["observation"].data_ptr()
+        d.next_obs = b._next_states["observation"].data_ptr()
+        d.actions, d.rewards, d.game_overs = b.actions().data_ptr(), b.rewards().data_ptr(), b.game_overs().data_ptr()
+        d.normals = a.normals.data_ptr()
+        _rlx.lib().sac_fused_update(ctypes.byref(d), int(write_grads), _rlx.current_stream())

@@ -836,6 +836,30 @@ int rlx_td3_fused_critic_update(const rlx_td3_fused_desc *desc_host, int write_g
 int rlx_td3_fused_actor_update(const rlx_td3_fused_desc *desc_host, int write_grads, void *stream);
 
 
+/* SoftActorCriticAgent.learn_from_batch (rl_coach/agents/soft_actor_critic_agent.py:168-280) on the Mujoco_SAC topology:
+ * policy obs -> h1 -> h2 -> [mu | log sigma] (heads/sac_head.py:60-97), V obs -> h1 -> h2 -> 1 with a target copy, twin Q
+ * towers relu(obs_fc s) + relu(act_fc a) -> fc -> 1 (heads/sac_q_head.py:46-96; q_* = float offsets of tower 0's tensors in
+ * q.weights and the towers' strides).  normals [3][batch][act_dim] fp64: the host's standard-normal draws of the three
+ * policy passes (resample_noise_per_pass == 0: only the first is used).  Outputs: value_targets, log_target = min(Q1, Q2),
+ * td_targets [batch], dq_da [batch][act_dim], q_loss [3] = the towers' losses and their sum, v_loss [1].
+ * policy.ticket: >= 1 zeroed word.  Six launches. */
+typedef struct rlx_sac_fused_desc {
+    rlx_fused_net policy, q, v;
+    rlx_mlp3 policy_mlp, v_mlp;
+    long long q_off_obs_w, q_off_obs_b, q_off_act_w, q_off_act_b, q_off_fc_w, q_off_fc_b, q_off_out_w, q_off_out_b;
+    long long q_stride_obs, q_stride_act, q_stride_fc, q_stride_out;
+    const float *obs, *next_obs, *actions, *rewards;
+    const unsigned char *game_overs;
+    const double *normals;
+    double discount;
+    int resample_noise_per_pass, batch, obs_dim, act_dim, q_hidden, reserved;
+    float *workspace; long long workspace_floats;
+    float *value_targets, *log_target, *td_targets, *dq_da, *q_loss, *v_loss;
+} rlx_sac_fused_desc;
+int rlx_sac_fused_supported(const rlx_sac_fused_desc *desc_host);
+int rlx_sac_fused_workspace_floats(const rlx_sac_fused_desc *desc_host, long long *floats_host);
+int rlx_sac_fused_update(const rlx_sac_fused_desc *desc_host, int write_grads, void *stream);
+
 /* ------------------------------------------------- Clipped PPO: last dense layer + heads + losses, one launch -- */
 /* The middleware's Dense(units) of both towers (tower 0 = value, tower 1 = policy; layers.py:168-185), VHead / discrete
  * PPOHead forward (heads/v_head.py:43-52, heads/ppo_head.py:52-116), both head losses (head.py:143-186) and the heads'
