@@ -104,6 +104,7 @@ struct Td3Dev {
     long long *stamps;                    // [96] s_memtime of workgroup 0 at the phase boundaries, or null (tools/ac_fused_phases.py)
 };
 #define RLX_STAMP(slot) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[(slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define RLX_STAMP_WG(wg, slot) do { if (p.stamps && blockIdx.x == (wg) && threadIdx.x == 0) p.stamps[(slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 // the 4 rows' partial head sums of one column slice: out[r][j] = sum_{k in slice} h[r][k] W3[k][j]  (j < NO <= 16)
 template <int RR = R>
@@ -117,6 +118,25 @@ __device__ __forceinline__ void head_partial(const float *hs, int hp, const floa
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
         if (lane == 0 && row0 + r < B) out[(long long)(row0 + r) * ld + j] = sum;
+    }
+}
+
+// the same sums for a WIDER head (SAC policy: 2 A outputs) whose slice rows ws [n_hi - n_lo][NO] already sit in LDS: a thread per
+// (row, output), k ascending — no butterflies, no strided global reads (head_partial on 34 outputs: 34 rounds of a 136-byte
+// stride gather + 6 shuffles per wave, ~24 us of sac_layer2_kernel's 33)
+template <int RR = R>
+__device__ __forceinline__ void head_partial_lds(const float *hs, int hp, const float *ws, int wc, int NO,
+                                                 float *__restrict__ out, long long ld, int row0, int B) {
+    for (int o = threadIdx.x; o < RR * NO; o += T) {
+        const int r = o / NO, j = o - r * NO;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                  // wc % 4 == 0 (slice_lo)
+        for (int k = 0; k < wc; k += 4) {
+            s0 = fmaf(hs[r * hp + k], ws[k * NO + j], s0);
+            s1 = fmaf(hs[r * hp + k + 1], ws[(k + 1) * NO + j], s1);
+            s2 = fmaf(hs[r * hp + k + 2], ws[(k + 2) * NO + j], s2);
+            s3 = fmaf(hs[r * hp + k + 3], ws[(k + 3) * NO + j], s3);
+        }
+        if (row0 + r < B) out[(long long)(row0 + r) * ld + j] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -758,8 +778,9 @@ inline int td3_check(const rlx_td3_fused_desc &d) {
 //   sac_layer1_kernel    h1 slices of policy(s), V(s), V_target(s') and relu(obs_fc_t(s)) of both Q towers
 //   sac_layer2_kernel    h2 slices + partial head sums of policy / V / V_target; Q_t(s, a): act_fc, sum, fc1 slice, partial Q_t
 //   sac_q_pi_kernel      policy head (first noise draw, :186-190) -> a ~ pi, log pi; Q_t(s, a ~ pi) up to partial Q_t (:198-200)
-//   sac_q_grad_kernel    min(Q_1, Q_2), V targets (:244), d mean(min) / d Q_t -> partial d / d (fc1 input) (:216-217)
-//   sac_backward_kernel  role P: dQ/da -> the policy head's gradient on the 2nd / 3rd noise draw (:210-227) -> dz2, partial
+//   sac_q_grad_kernel    min(Q_1, Q_2), V targets (:244), d mean(min) / d Q_t -> this slice's share of d / d (fc1 input) -> its
+//                        share of dQ/da (:216-217; linear in the hidden gradient, which therefore never goes to memory)
+//   sac_backward_kernel  role P: sum of the dQ/da shares -> the policy head's gradient on the 2nd / 3rd noise draw (:210-227) -> dz2, partial
 //                        dz1; role V: loss and backward of V (:250); role Q_t: y = r + (1 - done) gamma V_target(s')
 //                        (:259-266), loss and backward of Q_t (:268)
 //   mlp_dw_adam_kernel   all fourteen layers' weight gradients + the three Adam steps (+ V's soft target update)
@@ -791,7 +812,7 @@ struct SacDev {
     float *xs, *ab, *h1P, *h1V, *ho, *h2P, *h2V, *haB, *hs, *h2Q;
     float *dyP, *dz2P, *dh1Pp, *dvV, *dz2V, *dh1Vp, *dqQ, *dfc1, *dhqp;
     // plain
-    float *h1VT, *zP, *vp, *vTp, *qp, *logp0, *haP, *h2Qp, *qpp, *dhpp, *v_loss_part, *q_loss_part;
+    float *h1VT, *zP, *vp, *vTp, *qp, *logp0, *haP, *h2Qp, *qpp, *dapp, *v_loss_part, *q_loss_part;
     float *value_targets, *log_target, *td_targets, *dq_da;
     long long *stamps;
 };
@@ -819,8 +840,10 @@ __global__ void __launch_bounds__(T, 4) sac_layer1_kernel(const SacDev p) {
     const int role = blockIdx.x % (5 * kSplit), rb = blockIdx.x / (5 * kSplit), row0 = rb * RS;
     const int net = role / kSplit, c = role % kSplit;
     const int B = p.B, D = p.D;
+    RLX_STAMP(0);
     load_rows<RS>(x, SP, net == 2 ? p.next_obs : p.obs, D, D, row0, B);
     __syncthreads();
+    RLX_STAMP(1);
     if (net == 0 && c == 0)
         for (int e = threadIdx.x; e < RS * D; e += T) {
             const int r = e / D, col = e - r * D;
@@ -839,7 +862,9 @@ __global__ void __launch_bounds__(T, 4) sac_layer1_kernel(const SacDev p) {
         out = p.ho + (size_t)t * p.Bp * p.ldh;
     }
     const int lo = slice_lo(N, c), hi = slice_lo(N, c + 1);
+    RLX_STAMP(2);
     dense_fwd<RS>(x, SP, D, W + lo, N, bias + lo, hi - lo, RLX_ACT_RELU, y, SP, parts, out + lo, gld, row0, B);
+    RLX_STAMP(3);
 }
 
 __global__ void __launch_bounds__(T, 4) sac_layer2_kernel(const SacDev p) {
@@ -853,12 +878,27 @@ __global__ void __launch_bounds__(T, 4) sac_layer2_kernel(const SacDev p) {
         const float *w = net == 0 ? p.pw : (net == 1 ? p.vw : p.vwt);
         const float *h1 = net == 0 ? p.h1P : (net == 1 ? p.h1V : p.h1VT);
         const int lo = slice_lo(m.h2, c), hi = slice_lo(m.h2, c + 1);
+        RLX_STAMP(8);
+        // the policy head's rows of this slice ([hi - lo][2 A], contiguous) travel with the input rows: z holds them
+        constexpr int kW3 = (RS * SP + T - 1) / T;
+        float w3v[kW3];
+        const int n3 = net == 0 ? (hi - lo) * 2 * A : 0;
+        const float *w3g = w + m.o_w3 + (size_t)lo * 2 * A;
+#pragma unroll
+        for (int j = 0; j < kW3; ++j)
+            if (j * T < n3) w3v[j] = w3g[min(tid + j * T, n3 - 1)];
         load_rows<RS>(x, SP, h1, net == 2 ? m.h1 : p.ldh, m.h1, row0, B);
+#pragma unroll
+        for (int j = 0; j < kW3; ++j)
+            if (j * T < n3 && tid + j * T < n3) z[tid + j * T] = w3v[j];
         __syncthreads();
+        RLX_STAMP(9);
         float *save = net == 0 ? p.h2P + lo : (net == 1 ? p.h2V + lo : nullptr);
         dense_fwd<RS>(x, SP, m.h1, w + m.o_w2 + lo, m.h2, w + m.o_b2 + lo, hi - lo, RLX_ACT_RELU, y, SP, parts, save, p.ldh, row0, B);
-        if (net == 0) head_partial<RS>(y, SP, w + m.o_w3, lo, hi, 2 * A, p.zP + (size_t)c * 2 * A, (long long)kSplit * 2 * A, row0, B);
+        RLX_STAMP(10);
+        if (net == 0) head_partial_lds<RS>(y, SP, z, hi - lo, 2 * A, p.zP + (size_t)c * 2 * A, (long long)kSplit * 2 * A, row0, B);
         else head_partial<RS>(y, SP, w + m.o_w3, lo, hi, 1, (net == 1 ? p.vp : p.vTp) + (size_t)c * B, 1, row0, B);
+        RLX_STAMP(11);
     } else {
         // Q_t(s, a): relu(obs_fc(s)) from the first launch + relu(act_fc(a)) -> fc1 slice -> the slice's share of Q_t
         const int t = net - 3;
@@ -897,9 +937,11 @@ __global__ void __launch_bounds__(T, 4) sac_q_pi_kernel(const SacDev p) {
     const int B = p.B, A = p.A, H = p.H;
     const SacQ &q = p.qm;
     const int lo = slice_lo(H, c), hi = slice_lo(H, c + 1);
+    RLX_STAMP(16);
     sac_head_sums(p, row0, zz);
     load_rows<RS>(x, SP, p.ho + (size_t)t * p.Bp * p.ldh, p.ldh, H, row0, B);
     __syncthreads();
+    RLX_STAMP(17);
     for (int e = tid; e < RS * HP; e += T) {
         const int r = e / HP, a = e - r * HP, i = row0 + r;
         float av = 0.f, lp = 0.f, cr = 0.f;
@@ -917,6 +959,7 @@ __global__ void __launch_bounds__(T, 4) sac_q_pi_kernel(const SacDev p) {
         act0[e] = av; t1[e] = lp; t2[e] = cr;
     }
     __syncthreads();
+    RLX_STAMP(18);
     if (t == 0 && c == 0 && tid < RS && row0 + tid < B) {      // the sums in action order, as the head's row loop
         float lp = 0.f, cr = 0.f;
         for (int a = 0; a < A; ++a) { lp += t1[tid * HP + a]; cr += t2[tid * HP + a]; }
@@ -924,6 +967,7 @@ __global__ void __launch_bounds__(T, 4) sac_q_pi_kernel(const SacDev p) {
     }
     dense_fwd<RS>(act0, HP, A, p.qw + q.o_wa + t * q.s_a, H, p.qw + q.o_ba + t * q.s_a, H, RLX_ACT_RELU, z, SP, parts,
                   c == 0 ? p.haP + (size_t)t * B * H : nullptr, H, row0, B);
+    RLX_STAMP(19);
     for (int e = tid; e < RS * pad16(H); e += T) {
         const int r = e / pad16(H), k = e - r * pad16(H);
         x[r * SP + k] = k < H ? x[r * SP + k] + z[r * SP + k] : 0.f;
@@ -931,7 +975,9 @@ __global__ void __launch_bounds__(T, 4) sac_q_pi_kernel(const SacDev p) {
     __syncthreads();
     dense_fwd<RS>(x, SP, H, p.qw + q.o_w1 + t * q.s_1 + lo, H, p.qw + q.o_b1 + t * q.s_1 + lo, hi - lo, RLX_ACT_RELU, y, SP, parts,
                   p.h2Qp + (size_t)t * B * H + lo, H, row0, B);
+    RLX_STAMP(20);
     head_partial<RS>(y, SP, p.qw + q.o_wq + t * q.s_q, lo, hi, 1, p.qpp + ((size_t)t * kSplit + c) * B, 1, row0, B);
+    RLX_STAMP(21);
 }
 
 // min(Q_1, Q_2)(s, a ~ pi), the V targets, d mean(min) / d Q_t and its way down to the input of fc1 (slice partial)
@@ -943,7 +989,24 @@ __global__ void __launch_bounds__(T) sac_q_grad_kernel(const SacDev p) {
     const int B = p.B, H = p.H;
     const SacQ &q = p.qm;
     const int lo = slice_lo(H, c), hi = slice_lo(H, c + 1), wc = hi - lo;
+    const int A = p.A, lane = tid & 63, wave = tid >> 6;
+    float *hm = d + RS * SP, *red = small;           // act_fc's output rows (relu mask); the waves' partial dQ/da tiles
+    RLX_STAMP(24);
+    // B operands of the dQ/da product at the end (act_fc^T of tower t, 16 x 16 x 4 MFMAs: lane l supplies
+    // act_fc[a = 16 u + l % 16][n = 4 step + l / 16]; wave w owns steps [w NS, (w + 1) NS)): requested now, used last
+    constexpr int kNS = (SP - 4 + 31) / 32;
+    const int NS = (H + 31) >> 5;
+    float wb[kNS][2];
+#pragma unroll
+    for (int st = 0; st < kNS; ++st)
+        if (st < NS) {
+            const int n = min((wave * NS + st) * 4 + (lane >> 4), H - 1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                wb[st][u] = p.qw[q.o_wa + t * q.s_a + (size_t)min(16 * u + (lane & 15), A - 1) * H + n];
+        }
     load_rows<RS>(b, SP, p.h2Qp + (size_t)t * B * H + lo, H, wc, row0, B);
+    load_rows<RS>(hm, SP, p.haP + (size_t)t * B * H, H, H, row0, B);
     if (tid < RS) {
         const int i = row0 + tid;
         float dq = 0.f;
@@ -968,14 +1031,45 @@ __global__ void __launch_bounds__(T) sac_q_grad_kernel(const SacDev p) {
         small[tid] = dq;
     }
     __syncthreads();
+    RLX_STAMP(25);
     const float *wq = p.qw + q.o_wq + t * q.s_q + lo;
     for (int e = tid; e < RS * pad16(wc); e += T) {
         const int r = e / pad16(wc), k = e - r * pad16(wc);
         cb[r * SP + k] = (k < wc && b[r * SP + k] > 0.f) ? small[r] * wq[k] : 0.f;
     }
     __syncthreads();
-    dense_bwdT<RS>(cb, SP, wc, p.qw + q.o_w1 + t * q.s_1 + lo, H, H, nullptr, 0, d, SP, wt,
-                   p.dhpp + ((size_t)t * kSplit + c) * B * H, H, row0, B);
+    RLX_STAMP(26);
+    dense_bwdT<RS>(cb, SP, wc, p.qw + q.o_w1 + t * q.s_1 + lo, H, H, nullptr, 0, d, SP, wt, nullptr, 0, row0, B);
+    RLX_STAMP(27);
+    // This slice's share of d mean(min Q) / d a (:216-217): (d under act_fc's relu) x act_fc^T.  The product is linear in d,
+    // so the slices' shares are summed by the consumer (sac_backward_kernel) — the hidden gradient never goes to memory.
+    {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const int r = lane & 7;                              // A rows 8 .. 15 repeat rows 0 .. 7 (their results are dropped)
+#pragma unroll
+        for (int st = 0; st < kNS; ++st)
+            if (st < NS) {
+                const int n = (wave * NS + st) * 4 + (lane >> 4), nn = min(n, H - 1);
+                const float av = (n < H && hm[r * SP + nn] > 0.f) ? d[r * SP + nn] : 0.f;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wb[st][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wb[st][1], acc[1], 0, 0, 0);
+            }
+        if (lane < 32) {                                     // D: row = 4 (lane / 16) + v, column = lane % 16
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) red[(wave * RS + 4 * (lane >> 4) + v) * 32 + 16 * u + (lane & 15)] = acc[u][v];
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < RS * A; o += T) {
+        const int r = o / A, a = o - r * A;
+        float v = red[r * 32 + a];
+#pragma unroll
+        for (int w = 1; w < T / 64; ++w) v += red[(w * RS + r) * 32 + a];
+        if (row0 + r < B) p.dapp[(((size_t)t * kSplit + c) * B + row0 + r) * A + a] = v;
+    }
+    RLX_STAMP(28);
 }
 
 __global__ void __launch_bounds__(T) sac_backward_kernel(const SacDev p) {
@@ -989,31 +1083,66 @@ __global__ void __launch_bounds__(T) sac_backward_kernel(const SacDev p) {
         const SacQ &q = p.qm;
         const Mlp3 &m = p.pm;
         const int lo = slice_lo(m.h2, c), hi = slice_lo(m.h2, c + 1), wc = hi - lo;
-        float *zz = small, *da0 = small + RS * HP, *da1 = small + 2 * RS * HP, *dyb = small + 3 * RS * HP;
-        sac_head_sums(p, row0, zz);
-        for (int t = 0; t < 2; ++t) {
-            float *dst = t == 0 ? d : e2;
-            for (int e = tid; e < RS * pad16(H); e += T) {
-                const int r = e / pad16(H), k = e - r * pad16(H), i = row0 + r;
-                float v = 0.f;
-                if (i < B && k < H && p.haP[((size_t)t * B + i) * H + k] > 0.f) {
-                    const float *pp = p.dhpp + ((size_t)t * kSplit * B + i) * H + k;
-                    v = pp[0];
+        float *zz = small, *dyb = small + 3 * RS * HP;
+        float *w3s = wt;                            // the head's rows of this slice [wc][2 A]
+        RLX_STAMP(32);
+        // ---- every operand of the head's gradient is requested before the first one is waited for (a dependent global
+        // load costs ~1 us here; the first version of this branch paid ~40 of them in a row: profiles/r06_sac_backward_phases.txt)
+        static_assert(RS * HP == T, "one element of the head's output per thread");
+        const int A2 = 2 * A;
+        const int zr = tid / HP, zj = tid - zr * HP, zi = row0 + zr;
+        float zpart[kSplit], zbias, dap[2 * kSplit];
+        double nz1, nz2;
+        {
+            const float *zp = p.zP + ((size_t)min(zi, B - 1) * kSplit) * A2 + min(zj, A2 - 1);
 #pragma unroll
-                    for (int z = 1; z < kSplit; ++z) v += pp[(size_t)z * B * H];
-                }
-                dst[r * SP + k] = v;
-            }
+            for (int z = 0; z < kSplit; ++z) zpart[z] = zp[(size_t)z * A2];
+            zbias = p.pw[m.o_b3 + min(zj, A2 - 1)];
+            const size_t ne = (size_t)min(zi, B - 1) * A + min(zj, A - 1);
+            nz1 = p.normals[(size_t)(p.resample ? 1 : 0) * B * A + ne];
+            nz2 = p.normals[(size_t)(p.resample ? 2 : 0) * B * A + ne];
+#pragma unroll
+            for (int z = 0; z < 2 * kSplit; ++z) dap[z] = p.dapp[(size_t)z * B * A + ne];       // sac_q_grad_kernel's shares
         }
-        load_rows<RS>(b, SP, p.h2P + lo, p.ldh, wc, row0, B);
+        float bv[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = min(tid + it * T, RS * wc - 1), r = e / wc, col = e - r * wc;
+            bv[it] = p.h2P[(size_t)min(row0 + r, B - 1) * p.ldh + lo + col];
+        }
+        constexpr int kW3 = 9;                      // (h2 / kSplit + 4) 2 A <= 9 T (sac_check)
+        float w3v[kW3];
+        const int n3 = wc * A2;
+        const float *w3g = p.pw + m.o_w3 + (size_t)lo * A2;
+#pragma unroll
+        for (int j = 0; j < kW3; ++j)
+            if (j * T < n3) w3v[j] = w3g[min(tid + j * T, n3 - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float v = zpart[0];
+#pragma unroll
+            for (int z = 1; z < kSplit; ++z) v += zpart[z];
+            zz[tid] = (zi < B && zj < A2) ? v + zbias : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + it * T, r = e / wc, col = e - r * wc;
+            if (e < RS * wc) b[r * SP + col] = bv[it];
+        }
+#pragma unroll
+        for (int j = 0; j < kW3; ++j)
+            if (j * T < n3 && tid + j * T < n3) w3s[tid + j * T] = w3v[j];
+        // d mean(min Q) / d a: tower 0's slices in order, then tower 1's (the shared action input sums the towers)
+        float g_da = dap[0];
+#pragma unroll
+        for (int z = 1; z < 2 * kSplit; ++z) g_da += dap[z];
         __syncthreads();
-        dense_bwdT_few_rows<RS>(d, SP, H, p.qw + q.o_wa, H, A, 1.f, da0, HP);
-        dense_bwdT_few_rows<RS>(e2, SP, H, p.qw + q.o_wa + q.s_a, H, A, 1.f, da1, HP);
-        for (int e = tid; e < RS * HP; e += T) {
-            const int r = e / HP, a = e - r * HP, i = row0 + r;
+        RLX_STAMP(35);
+        {
+            const int r = zr, a = zj, i = zi;
             float dmu = 0.f, dls = 0.f;
             if (i < B && a < A) {
-                const float g = da0[r * HP + a] + da1[r * HP + a];          // the shared action input sums the towers
+                const float g = g_da;
                 if (c == 0) p.dq_da[(size_t)i * A + a] = g;
                 const float mu = zz[r * HP + a], ls_raw = zz[r * HP + A + a];
                 const bool inside = ls_raw >= kLogSigCapMin && ls_raw <= kLogSigCapMax;      // clip_by_value's gradient
@@ -1022,8 +1151,7 @@ __global__ void __launch_bounds__(T) sac_backward_kernel(const SacDev p) {
                 const float w_lp = 1.0f / (float)B;
                 // weighted_gradients[5] (mean log-prob, weight 1) and - weighted_gradients[3] (actions, weights dQ/da): on
                 // the second and third noise draw (resample), or both on the first
-                const float n1 = (float)p.normals[((size_t)(p.resample ? 1 : 0) * B + i) * A + a];
-                const float n2 = (float)p.normals[((size_t)(p.resample ? 2 : 0) * B + i) * A + a];
+                const float n1 = (float)nz1, n2 = (float)nz2;
                 {
                     const float raw = mu + sd * n1, tt = tanhf(raw), one_m = 1.f - tt * tt;
                     const float dcorr = 2.f * tt * one_m / (one_m + kEpsF32);
@@ -1056,9 +1184,22 @@ __global__ void __launch_bounds__(T) sac_backward_kernel(const SacDev p) {
             }
         }
         __syncthreads();
-        dense_bwdT_few_cols<RS>(dyb, HP, 2 * A, p.pw + m.o_w3 + (size_t)lo * 2 * A, wc, b, SP, cb, SP, p.dz2P + lo, p.ldh, row0, B);
+        RLX_STAMP(36);
+        // dz2[:, slice] = relu'(h2) * (dy W3^T): the slice's rows of the head's weights are in LDS
+        for (int e = tid; e < RS * pad16(wc); e += T) {
+            const int r = e / pad16(wc), k = e - r * pad16(wc);
+            float acc = 0.f;
+            if (k < wc)
+                for (int n = 0; n < A2; ++n) acc = fmaf(dyb[r * HP + n], w3s[k * A2 + n], acc);
+            const float v = (k < wc && b[r * SP + k] > 0.f) ? acc : 0.f;
+            cb[r * SP + k] = v;
+            if (k < wc && row0 + r < B) p.dz2P[(size_t)(row0 + r) * p.ldh + lo + k] = v;
+        }
+        __syncthreads();
+        RLX_STAMP(37);
         dense_bwdT<RS>(cb, SP, wc, p.pw + m.o_w2 + lo, m.h2, m.h1, nullptr, 0, d, SP, wt, p.dh1Pp + (size_t)c * p.Bp * p.ldh, p.ldh,
                        row0, B);
+        RLX_STAMP(38);
     } else {
         // ---- V (kind 1) or Q tower kind - 2: the regression loss of a Dense(1) head and its backward pass
         const bool isv = kind == 1;
@@ -1067,6 +1208,7 @@ __global__ void __launch_bounds__(T) sac_backward_kernel(const SacDev p) {
         const Mlp3 &m = p.vm;
         const int NH = isv ? m.h2 : H;
         const int lo = slice_lo(NH, c), hi = slice_lo(NH, c + 1), wc = hi - lo;
+        RLX_STAMP_WG(2 * kSplit, 48);
         load_rows<RS>(b, SP, (isv ? p.h2V : p.h2Q + (size_t)t * p.Bp * p.ldh) + lo, p.ldh, wc, row0, B);
         if (tid < RS) {
             const int i = row0 + tid;
@@ -1100,6 +1242,7 @@ __global__ void __launch_bounds__(T) sac_backward_kernel(const SacDev p) {
             small[RS + tid] = term;
         }
         __syncthreads();
+        RLX_STAMP_WG(2 * kSplit, 49);
         if (tid == 0 && c == 0) {
             float sacc = 0.f;
             for (int r = 0; r < RS; ++r) sacc += small[RS + r];
@@ -1115,9 +1258,11 @@ __global__ void __launch_bounds__(T) sac_backward_kernel(const SacDev p) {
             if (k < wc && row0 + r < B) save[(size_t)(row0 + r) * p.ldh + k] = v;
         }
         __syncthreads();
+        RLX_STAMP_WG(2 * kSplit, 50);
         const float *w2 = isv ? p.vw + m.o_w2 + lo : p.qw + q.o_w1 + t * q.s_1 + lo;
         float *part = isv ? p.dh1Vp + (size_t)c * p.Bp * p.ldh : p.dhqp + ((size_t)t * kSplit + c) * p.Bp * p.ldh;
         dense_bwdT<RS>(cb, SP, wc, w2, NH, isv ? m.h1 : H, nullptr, 0, d, SP, wt, part, p.ldh, row0, B);
+        RLX_STAMP_WG(2 * kSplit, 51);
     }
 }
 
@@ -1149,7 +1294,7 @@ inline Td3Dev td3_dev(const rlx_td3_fused_desc &d) {
 
 struct SacWs {
     long long xs, ab, h1P, h1V, ho, h2P, h2V, haB, hs, h2Q, dyP, dz2P, dh1Pp, dvV, dz2V, dh1Vp, dqQ, dfc1, dhqp;
-    long long h1VT, zP, vp, vTp, qp, logp0, haP, h2Qp, qpp, dhpp, v_loss_part, q_loss_part, norm_part, stamps, total;
+    long long h1VT, zP, vp, vTp, qp, logp0, haP, h2Qp, qpp, dapp, v_loss_part, q_loss_part, norm_part, stamps, total;
 };
 inline int sac_blocks(const rlx_sac_fused_desc &d) {
     const int D = d.obs_dim, A = d.act_dim, H = d.q_hidden;
@@ -1171,7 +1316,7 @@ inline SacWs sac_layout(const rlx_sac_fused_desc &d) {
     w.dvV = take(Bp * 64); w.dz2V = take(Bp * ldh); w.dh1Vp = take(kSplit * Bp * ldh);
     w.dqQ = take(2 * Bp * 64); w.dfc1 = take(2 * Bp * ldh); w.dhqp = take(2LL * kSplit * Bp * ldh);
     w.h1VT = take(B * H); w.zP = take(B * kSplit * 2 * A); w.vp = take(kSplit * B); w.vTp = take(kSplit * B); w.qp = take(2LL * kSplit * B);
-    w.logp0 = take(B); w.haP = take(2 * B * H); w.h2Qp = take(2 * B * H); w.qpp = take(2LL * kSplit * B); w.dhpp = take(2LL * kSplit * B * H);
+    w.logp0 = take(B); w.haP = take(2 * B * H); w.h2Qp = take(2 * B * H); w.qpp = take(2LL * kSplit * B); w.dapp = take(2LL * kSplit * B * A);
     w.v_loss_part = take(nrb); w.q_loss_part = take(2 * nrb);
     w.norm_part = take(sac_blocks(d));
     w.stamps = take(2 * 96);
@@ -1186,6 +1331,10 @@ inline int sac_check(const rlx_sac_fused_desc &d) {
     const int widths[5] = {pm.h1, pm.h2, vm.h1, vm.h2, H};
     for (int i = 0; i < 5; ++i)
         if (widths[i] % 4 || widths[i] < 32 * kSplit || widths[i] > SP - 4) return 0;
+    // a slice of the policy head's rows is staged in LDS (sac_layer2_kernel: one activation buffer; sac_backward_kernel: <= 9 per thread)
+    if ((pm.h2 / kSplit + 4) * 2 * d.act_dim > 9 * T || RS * (pm.h2 / kSplit + 4) > 2 * T ||
+        (pm.h2 / kSplit + 4) * 2 * d.act_dim > RS * SP) return 0;
+    if ((d.q_off_act_w | d.q_stride_act | d.q_off_obs_w | d.q_stride_obs | d.q_off_fc_w | d.q_stride_fc) & 3) return 0;
     return 1;
 }
 inline SacDev sac_dev(const rlx_sac_fused_desc &d) {
@@ -1205,10 +1354,10 @@ inline SacDev sac_dev(const rlx_sac_fused_desc &d) {
     p.haB = ws + w.haB; p.hs = ws + w.hs; p.h2Q = ws + w.h2Q; p.dyP = ws + w.dyP; p.dz2P = ws + w.dz2P; p.dh1Pp = ws + w.dh1Pp;
     p.dvV = ws + w.dvV; p.dz2V = ws + w.dz2V; p.dh1Vp = ws + w.dh1Vp; p.dqQ = ws + w.dqQ; p.dfc1 = ws + w.dfc1; p.dhqp = ws + w.dhqp;
     p.h1VT = ws + w.h1VT; p.zP = ws + w.zP; p.vp = ws + w.vp; p.vTp = ws + w.vTp; p.qp = ws + w.qp; p.logp0 = ws + w.logp0;
-    p.haP = ws + w.haP; p.h2Qp = ws + w.h2Qp; p.qpp = ws + w.qpp; p.dhpp = ws + w.dhpp; p.v_loss_part = ws + w.v_loss_part;
+    p.haP = ws + w.haP; p.h2Qp = ws + w.h2Qp; p.qpp = ws + w.qpp; p.dapp = ws + w.dapp; p.v_loss_part = ws + w.v_loss_part;
     p.q_loss_part = ws + w.q_loss_part;
     p.value_targets = d.value_targets; p.log_target = d.log_target; p.td_targets = d.td_targets; p.dq_da = d.dq_da;
-    p.stamps = nullptr;
+    p.stamps = g_stamps ? reinterpret_cast<long long *>(ws + w.stamps) : nullptr;
     return p;
 }
 
