@@ -275,14 +275,29 @@ def update_roofline(agent, workload, reps=200):
     agent.learn_from_batch(batch)
     calls = _rlx.CALL_COUNT - c0
     agent.use_graphs = saved
-    for _ in range(3):
-        agent.learn_from_batch(batch)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        agent.learn_from_batch(batch)
-    e1.record()
-    e1.synchronize()
+    # The update's host draws (TD3: the smoothing noise, SAC: three normal draws of B x A — ~100-200 us of np.random per
+    # update, more than the device needs for the update itself) are made ONCE and staged, as the training loop stages them
+    # with the sampled rows: what is timed is the device's duration of the captured update, not the host's RNG.
+    host_draw_us = None
+    fields = getattr(agent, "_update_record_fields", lambda: None)()
+    if fields:
+        import time as _time
+        t0 = _time.perf_counter()
+        for _ in range(20):
+            draw = agent._draw_update_host()
+        host_draw_us = 1e6 * (_time.perf_counter() - t0) / 20
+        agent._staged = {k: torch.as_tensor(v, device=agent.device) for k, v in draw.items()}
+    try:
+        for _ in range(3):
+            agent.learn_from_batch(batch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            agent.learn_from_batch(batch)
+        e1.record()
+        e1.synchronize()
+    finally:
+        agent._staged = None
     us = 1e3 * e0.elapsed_time(e1) / reps
     flops = UPDATE_FLOPS[workload]
     achieved = flops / (us * 1e-6) / 1e12
@@ -290,6 +305,7 @@ def update_roofline(agent, workload, reps=200):
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), "traffic": None,
             "kernel": "one gradient update (learn_from_batch: forward passes, targets, loss, backward, Adam) as captured",
             "update_us": round(us, 2), "update_flops": flops, "library_calls_per_update": calls,
+            "host_draws_us_per_update": None if host_draw_us is None else round(host_draw_us, 1),
             "latency_model": {"launch_floor_us": LAUNCH_FLOOR_US, "floor_us": round(calls * LAUNCH_FLOOR_US, 1),
                               "note": "latency-bound: the floor of `calls` dependent launches, not the MFMA rate, "
                                       "bounds this update (a call may launch 1-2 kernels)"}}
@@ -355,7 +371,7 @@ def run_off_policy(args, device, dist):
 
 
 # ------------------------------------------------------------------------------------- roofline
-GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_", "conv32_", "ppo_fc_heads")   # kernels that issue (or finish) fp32 MFMA products
+GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_", "conv32_", "conv_dw_u8", "ppo_fc_heads")   # kernels that issue (or finish) fp32 MFMA products
 
 
 def _family(name):
@@ -803,6 +819,8 @@ def main():
     ap.add_argument("--record-acting", type=int, default=None, choices=[0, 1],
                     help="A/B (c2): the acting steps leave V(s) and the action probabilities in the rollout — no whole-dataset "
                          "value / old-policy pass (ClippedPPOAgent.RECORD_WHILE_ACTING; 1 = default)")
+    ap.add_argument("--conv-dw-u8", type=int, default=None, choices=[0, 1],
+                    help="A/B: conv1's weight gradient by rlx_conv_dw_u8 (frame rows + the image's dz in LDS) or by rlx_gemm")
     ap.add_argument("--fc-heads", type=int, default=None, choices=[0, 1],
                     help="A/B: the last dense layer + heads + losses + heads' backward as one launch (rlx_ppo_fc_heads)")
     ap.add_argument("--fuse-conv-bwd", type=int, default=None, choices=[0, 1],
@@ -864,6 +882,9 @@ def main():
     if args.fuse_acting is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent as _A
         _A.FUSE_ACTING_LAUNCHES = bool(args.fuse_acting)
+    if args.conv_dw_u8 is not None:
+        from coach_amd.nn import graph as _G2
+        _G2.CONV_DW_U8 = bool(args.conv_dw_u8)
     if args.fc_heads is not None:
         from coach_amd.nn.networks import ClippedPPONet as _N
         _N.FC_HEADS_ONE_LAUNCH = bool(args.fc_heads)

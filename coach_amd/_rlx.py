@@ -40,7 +40,7 @@ _CTYPE = {
 }
 
 _VALUE_RETURNING = {"rlx_abi_version", "rlx_ppo_fc_heads_supported", "rlx_td3_fused_supported", "rlx_sac_fused_supported", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
-                    "rlx_conv123_forward_supported", "rlx_conv32_input_grad_supported"}  # return a value, not an rlx_status
+                    "rlx_conv123_forward_supported", "rlx_conv32_input_grad_supported", "rlx_conv_dw_u8_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
 
@@ -292,6 +292,20 @@ def conv_input_grad(dz, weights, dx, x_out, deriv, tables, B, H, W, C, KH, KW, S
     if GEMM_HOOK is not None:
         d = GemmDesc()
         d.M, d.N, d.K, d.batch = B * OH * OW, KH * KW * C, Co, towers
+        _record((d,), run)
+    run()
+
+
+def conv_dw_u8(frames, a_div, dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw, dw_tower_stride, db, db_tower_stride,
+               workspace, job, stream=None):
+    """rlx_conv_dw_u8: the first convolution's weight gradient from uint8 frames, its reduction deferred into `job`."""
+    s = current_stream() if stream is None else stream
+    run = lambda: lib().conv_dw_u8(frames, float(a_div), dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw,
+                                   dw_tower_stride, db, db_tower_stride, workspace, workspace.numel(), ctypes.byref(job), s)
+    if GEMM_HOOK is not None:
+        OH, OW = (H - KH) // S + 1, (W - KW) // S + 1
+        d = GemmDesc()
+        d.M, d.N, d.K, d.batch, d.a_is_u8 = KH * KW * C, towers * Co, B * OH * OW, 1, 1
         _record((d,), run)
     run()
 

@@ -175,6 +175,9 @@ def _kw2_tiling(M, N, batch):
 MULTI_DW = False
 # most K splits a deferred product may get room for (rlx_gemm_split_cap's largest useful setting; its default is 64)
 SPLIT_CAP_BOUND = 128
+# conv1's weight gradient from the uint8 frames by rlx_conv_dw_u8 (one workgroup per image and pair of kernel rows) instead of
+# the register-staged implicit-im2col product of rlx_gemm; the tests flip it to compare the two
+CONV_DW_U8 = True
 
 
 class Workspace:
@@ -682,6 +685,13 @@ class Conv2d(Layer):
                                  launch=launch, defer=dj)
             if dw_later is not None and job is not None:
                 dw_later.append((dw(None, launch=False), job))
+            elif (not pairing and fold and x.u8 and job is not None and CONV_DW_U8 and
+                  ctx.lib.conv_dw_u8_supported(B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T)):
+                # the first convolution of an image torso: frame rows and the image's dz in LDS, one workgroup per (image,
+                # pair of kernel rows), one deferred split per image (csrc/conv_dw_u8.hip)
+                _rlx.conv_dw_u8(x.data, x.div, dz, M * self.Co, B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T,
+                                p.g(self.kname, t0), p.stride(self.kname), p.g(self.bname, t0), p.stride(self.bname), dws, job,
+                                ctx.stream)
             elif not pairing:
                 dw(ctx.ws.splitk)
         if direct:

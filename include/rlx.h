@@ -860,6 +860,25 @@ int rlx_sac_fused_supported(const rlx_sac_fused_desc *desc_host);
 int rlx_sac_fused_workspace_floats(const rlx_sac_fused_desc *desc_host, long long *floats_host);
 int rlx_sac_fused_update(const rlx_sac_fused_desc *desc_host, int write_grads, void *stream);
 
+/* ------------------------------------------------- first convolution's weight gradient from uint8 frames -- */
+/* dW1 = cols(frames)^T dz1 and db1 = column sums of dz1 for the first convolution of an image torso whose towers read the
+ * SAME uint8 frames (rl_coach/architectures/tensorflow_components/embedders/image_embedder.py:33-40, layers.py:108-121;
+ * the tf.gradients pass of architecture.py:187-220) — what rlx_gemm computed as an implicit-im2col product on its
+ * register-staged uint8 loop.  frames [B][H][W][C] uint8 (network input = byte / a_div), dz [towers][B * OH * OW][filters]
+ * (tower stride dz_tower_stride floats).  One workgroup per (image, pair of kernel rows); the images' partial sums go to
+ * `workspace` and *job_host describes their outstanding reduction (one split per image, summed in image order) for
+ * rlx_splitk_reduce_jobs: dw [KH * KW * C][filters] per tower (tower stride dw_tower_stride), db [filters] per tower or
+ * NULL.  Shapes: KW * C == 32, KH even, towers * filters == 64, 2 <= B <= 128 (rlx_conv_dw_u8_supported). */
+int rlx_conv_dw_u8_supported(int B, int H, int W, int C, int KH, int KW, int S, int filters, int towers);   /* 1 / 0 */
+int rlx_conv_dw_u8_workspace_floats(int B, int H, int W, int C, int KH, int KW, int S, int filters, int towers,
+                                    long long *floats_host);
+int rlx_conv_dw_u8(const unsigned char *frames, float a_div, const float *dz, long long dz_tower_stride, int B, int H, int W,
+                   int C, int KH, int KW, int S, int filters, int towers, float *dw, long long dw_tower_stride, float *db,
+                   long long db_tower_stride, float *workspace, long long workspace_floats, rlx_splitk_job *job_host,
+                   void *stream);
+/* Measurement switch (no reference counterpart): workgroup 0 records s_memtime at its phase boundaries into 5 int64 words. */
+int rlx_conv_dw_u8_stamps(long long *device_words5);
+
 /* ------------------------------------------------- Clipped PPO: last dense layer + heads + losses, one launch -- */
 /* The middleware's Dense(units) of both towers (tower 0 = value, tower 1 = policy; layers.py:168-185), VHead / discrete
  * PPOHead forward (heads/v_head.py:43-52, heads/ppo_head.py:52-116), both head losses (head.py:143-186) and the heads'
