@@ -40,7 +40,7 @@ _CTYPE = {
 }
 
 _VALUE_RETURNING = {"rlx_abi_version", "rlx_ppo_fc_heads_supported", "rlx_td3_fused_supported", "rlx_sac_fused_supported", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
-                    "rlx_conv123_forward_supported", "rlx_conv32_input_grad_supported", "rlx_conv_dw_u8_supported"}  # return a value, not an rlx_status
+                    "rlx_conv123_forward_supported", "rlx_conv32_input_grad_supported", "rlx_conv_dw_u8_supported", "rlx_conv_dw_f32_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
 
@@ -306,6 +306,20 @@ def conv_dw_u8(frames, a_div, dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, to
         OH, OW = (H - KH) // S + 1, (W - KW) // S + 1
         d = GemmDesc()
         d.M, d.N, d.K, d.batch, d.a_is_u8 = KH * KW * C, towers * Co, B * OH * OW, 1, 1
+        _record((d,), run)
+    run()
+
+
+def conv_dw_f32(x, x_tower_stride, dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw, dw_tower_stride, db,
+                db_tower_stride, workspace, job, stream=None):
+    """rlx_conv_dw_f32: an inner convolution's weight gradient from fp32 activations, its reduction deferred into `job`."""
+    s = current_stream() if stream is None else stream
+    run = lambda: lib().conv_dw_f32(x, x_tower_stride, dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw, dw_tower_stride,
+                                    db, db_tower_stride, workspace, workspace.numel(), ctypes.byref(job), s)
+    if GEMM_HOOK is not None:
+        OH, OW = (H - KH) // S + 1, (W - KW) // S + 1
+        d = GemmDesc()
+        d.M, d.N, d.K, d.batch = KH * KW * C, Co, B * OH * OW, towers
         _record((d,), run)
     run()
 

@@ -139,10 +139,10 @@ FUSE_CONV_FIRST = True
 # LDS (rlx_conv32_input_grad, csrc/conv_bwd_fused.hip) instead of a dW + dcol pair launch and a col2im launch per layer; the
 # two weight-gradient products then run on their own.  Taken where rlx_gemm_describe says the dcol products would sum in
 # the order that kernel reproduces, and only when there are enough half images (workgroups) to fill the chip.
-# OFF: bit-identical, but only -2 us per C2 update (profiles/r05_ab_conv32.txt): the launch takes 32.5 us against
-# 2 x (9.7 us of dcol inside the pair launch + 7.6 us of col2im), because the weight-gradient products it leaves behind
-# cost 14 us each on their own.  Entry point, tests and A/B flag (bench.py --fuse-conv-bwd 1) stay.
-FUSE_CONV_INPUT_GRADS = False
+# Round 5 left it OFF (-2 us per C2 update: the weight-gradient products it leaves behind cost 14 us each as tiled launches of
+# their own, profiles/r05_ab_conv32.txt); ON since those products run through rlx_conv_dw_f32 (11.5 / 12.9 us):
+# 182.3 against 188.8 us per update (profiles/r06_ab_conv_dw_f32.txt).  bench.py --fuse-conv-bwd 0 / 1 is the A/B.
+FUSE_CONV_INPUT_GRADS = True
 FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = 192
 
 
@@ -178,6 +178,8 @@ SPLIT_CAP_BOUND = 128
 # conv1's weight gradient from the uint8 frames by rlx_conv_dw_u8 (one workgroup per image and pair of kernel rows) instead of
 # the register-staged implicit-im2col product of rlx_gemm; the tests flip it to compare the two
 CONV_DW_U8 = True
+# the inner convolutions' weight gradients, when they run on their own, by rlx_conv_dw_f32 (csrc/conv_dw_f32.hip)
+CONV_DW_F32 = True
 
 
 class Workspace:
@@ -692,6 +694,13 @@ class Conv2d(Layer):
                 _rlx.conv_dw_u8(x.data, x.div, dz, M * self.Co, B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T,
                                 p.g(self.kname, t0), p.stride(self.kname), p.g(self.bname, t0), p.stride(self.bname), dws, job,
                                 ctx.stream)
+            elif (not pairing and not fold and not x.u8 and job is not None and CONV_DW_F32 and x.towers == T and
+                  ctx.lib.conv_dw_f32_supported(B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T)):
+                # an inner convolution's weight gradient on its own (the input gradients went through
+                # rlx_conv32_input_grad): the pair's input rows and dz in LDS, one deferred split per image pair
+                _rlx.conv_dw_f32(x.data, x.tower_stride(), dz, M * self.Co, B, self.H, self.W, self.C, self.KH, self.KW, self.S,
+                                 self.Co, T, p.g(self.kname, t0), p.stride(self.kname), p.g(self.bname, t0),
+                                 p.stride(self.bname), dws, job, ctx.stream)
             elif not pairing:
                 dw(ctx.ws.splitk)
         if direct:

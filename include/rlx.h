@@ -879,6 +879,18 @@ int rlx_conv_dw_u8(const unsigned char *frames, float a_div, const float *dz, lo
 /* Measurement switch (no reference counterpart): workgroup 0 records s_memtime at its phase boundaries into 5 int64 words. */
 int rlx_conv_dw_u8_stamps(long long *device_words5);
 
+/* The same for an inner convolution layer with fp32 input activations x [towers][B][H][W][C] (tower stride x_tower_stride)
+ * and 64 filters — the Atari torso's conv2 (4 x 4 x 32 stride 2 on 20 x 20) and conv3 (3 x 3 x 64 stride 1 on 9 x 9): one
+ * workgroup per (tower, pair of images, kernel row), one deferred split per image pair.  dw [KH * KW * C][64] per tower. */
+int rlx_conv_dw_f32_supported(int B, int H, int W, int C, int KH, int KW, int S, int filters, int towers);   /* 1 / 0 */
+int rlx_conv_dw_f32_workspace_floats(int B, int H, int W, int C, int KH, int KW, int S, int filters, int towers,
+                                     long long *floats_host);
+int rlx_conv_dw_f32(const float *x, long long x_tower_stride, const float *dz, long long dz_tower_stride, int B, int H, int W,
+                    int C, int KH, int KW, int S, int filters, int towers, float *dw, long long dw_tower_stride, float *db,
+                    long long db_tower_stride, float *workspace, long long workspace_floats, rlx_splitk_job *job_host,
+                    void *stream);
+int rlx_conv_dw_f32_stamps(long long *device_words4);
+
 /* ------------------------------------------------- Clipped PPO: last dense layer + heads + losses, one launch -- */
 /* The middleware's Dense(units) of both towers (tower 0 = value, tower 1 = policy; layers.py:168-185), VHead / discrete
  * PPOHead forward (heads/v_head.py:43-52, heads/ppo_head.py:52-116), both head losses (head.py:143-186) and the heads'

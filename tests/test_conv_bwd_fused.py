@@ -22,8 +22,9 @@ def _update(dev, B, A, act, fused, steps=2):
     acts = torch.from_numpy(rng.randint(0, A, size=B).astype(np.int32)).to(dev)
     adv = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
     vt = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
-    G.FUSE_CONV_INPUT_GRADS = fused
-    try:
+    saved_fuse, G.FUSE_CONV_INPUT_GRADS = G.FUSE_CONV_INPUT_GRADS, fused
+    saved_dw, G.CONV_DW_F32 = G.CONV_DW_F32, False           # (the weight gradients through rlx_gemm on both sides: another
+    try:                                                     # order of their sums is tests/test_conv_dw_f32.py's subject)
         np.random.seed(1)
         net = ClippedPPONet(dev, shape, A, seed=2, activation=act)
         net.update_target(1.0)
@@ -38,7 +39,8 @@ def _update(dev, B, A, act, fused, steps=2):
         net.check_status()
         return grads, net.params.weights.clone(), net.scalars.clone(), [n for n, _ in timer.records]
     finally:
-        G.FUSE_CONV_INPUT_GRADS = False                      # (the default: profiles/r05_ab_conv32.txt)
+        G.FUSE_CONV_INPUT_GRADS = saved_fuse
+        G.CONV_DW_F32 = saved_dw
 
 
 @pytest.mark.parametrize("B", [64, 72, 63])

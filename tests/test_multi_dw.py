@@ -20,8 +20,12 @@ def test_multi_dw_equals_per_layer_launches_bit_for_bit(rlx, dev, shape, B, A):
     adv = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
     vt = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
     res = {}
+    # (the products as rlx_gemm tiles them on both sides: the round-6 kernels that replaced them by default — rlx_conv_dw_u8,
+    # rlx_conv_dw_f32 behind rlx_conv32_input_grad — have tests of their own)
+    saved = G.CONV_DW_U8, G.CONV_DW_F32, G.FUSE_CONV_INPUT_GRADS
     for multi in (False, True):
         G.MULTI_DW = multi
+        G.CONV_DW_U8 = G.CONV_DW_F32 = G.FUSE_CONV_INPUT_GRADS = False
         try:
             np.random.seed(1)
             net = ClippedPPONet(dev, shape, A, seed=2)
@@ -37,6 +41,7 @@ def test_multi_dw_equals_per_layer_launches_bit_for_bit(rlx, dev, shape, B, A):
             res[multi] = (grads, net.params.weights.clone(), [n for n, _ in timer.records])
         finally:
             G.MULTI_DW = False
+            G.CONV_DW_U8, G.CONV_DW_F32, G.FUSE_CONV_INPUT_GRADS = saved
     assert torch.equal(res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])
     assert float(res[True][0].abs().max()) > 0

@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 6, call 17: rlx_conv_dw_f32 (conv2 / conv3 weight gradients with the image pair's rows and dz in LDS): parity, phases,
+# A/B of the C2 line with the fused input-gradient chain
+set -u
+O=gpurun_out/r06_call17
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_conv_dw_f32.py tests/test_conv_bwd_fused.py -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" > $O/pytest.txt; tail -30 $O/pytest.txt
+timeout 200 python tools/conv_dw_f32_phases.py 2>&1 | grep -v amdgpu.ids | tee $O/phases.txt
+run() { # name, flags
+  timeout 500 python bench.py --no-cpu-baseline $2 > $O/bench_$1.json 2> $O/bench_$1.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open('$O/bench_$1.json').read().strip().splitlines()[-1])
+    r=d['roofline']
+    print('%-12s' % '$1', d['value'], d['ms_per_step'], 'frac', r['frac'], 'gemm_us', r['gemm_us_per_update'], 'update_us', r.get('update_us_in_epoch_graph'), 'conv', d['box'].get('fused_conv_forward_in_update_us'), 'launches', r.get('kernel_launches_per_update'))
+    for k in r['update_kernels']: print('      %-70s %5.1f x %4.1f' % (k['kernel'][:70], k['launches_per_update'], k['avg_us']))
+except Exception as e:
+    print('$1', 'ERR', e); print(open('$O/bench_$1.err').read()[-1500:])
+PY
+}
+run fused "--steps 10 --warmup 3 --fuse-conv-bwd 1"
+run pairs "--steps 10 --warmup 3 --fuse-conv-bwd 0"
+run fused2 "--steps 10 --warmup 3 --fuse-conv-bwd 1"
