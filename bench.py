@@ -371,7 +371,7 @@ def run_off_policy(args, device, dist):
 
 
 # ------------------------------------------------------------------------------------- roofline
-GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_", "conv32_", "conv_dw_u8", "ppo_fc_heads")   # kernels that issue (or finish) fp32 MFMA products
+GEMM_FAMILY = ("gemm_", "splitk_reduce", "conv23_", "conv32_", "conv_dw_", "ppo_fc_heads")   # kernels that issue (or finish) fp32 MFMA products
 
 
 def _family(name):
@@ -819,6 +819,8 @@ def main():
     ap.add_argument("--record-acting", type=int, default=None, choices=[0, 1],
                     help="A/B (c2): the acting steps leave V(s) and the action probabilities in the rollout — no whole-dataset "
                          "value / old-policy pass (ClippedPPOAgent.RECORD_WHILE_ACTING; 1 = default)")
+    ap.add_argument("--conv-dw-one-launch", type=int, default=None, choices=[0, 1],
+                    help="A/B: the three convolution weight gradients as one launch (rlx_conv_dw_multi) or three")
     ap.add_argument("--conv-dw-u8", type=int, default=None, choices=[0, 1],
                     help="A/B: conv1's weight gradient by rlx_conv_dw_u8 (frame rows + the image's dz in LDS) or by rlx_gemm")
     ap.add_argument("--fc-heads", type=int, default=None, choices=[0, 1],
@@ -882,6 +884,9 @@ def main():
     if args.fuse_acting is not None:
         from coach_amd.agents.clipped_ppo_agent import ClippedPPOAgent as _A
         _A.FUSE_ACTING_LAUNCHES = bool(args.fuse_acting)
+    if args.conv_dw_one_launch is not None:
+        from coach_amd.nn import graph as _G3
+        _G3.CONV_DW_ONE_LAUNCH = bool(args.conv_dw_one_launch)
     if args.conv_dw_u8 is not None:
         from coach_amd.nn import graph as _G2
         _G2.CONV_DW_U8 = bool(args.conv_dw_u8)

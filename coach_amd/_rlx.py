@@ -296,32 +296,48 @@ def conv_input_grad(dz, weights, dx, x_out, deriv, tables, B, H, W, C, KH, KW, S
     run()
 
 
-def conv_dw_u8(frames, a_div, dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw, dw_tower_stride, db, db_tower_stride,
-               workspace, job, stream=None):
-    """rlx_conv_dw_u8: the first convolution's weight gradient from uint8 frames, its reduction deferred into `job`."""
-    s = current_stream() if stream is None else stream
-    run = lambda: lib().conv_dw_u8(frames, float(a_div), dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw,
-                                   dw_tower_stride, db, db_tower_stride, workspace, workspace.numel(), ctypes.byref(job), s)
-    if GEMM_HOOK is not None:
-        OH, OW = (H - KH) // S + 1, (W - KW) // S + 1
-        d = GemmDesc()
-        d.M, d.N, d.K, d.batch, d.a_is_u8 = KH * KW * C, towers * Co, B * OH * OW, 1, 1
-        _record((d,), run)
-    run()
+class ConvDwItem(ctypes.Structure):
+    """rlx_conv_dw_item (include/rlx.h) — field order must match the header."""
+    _fields_ = [("x", ctypes.c_void_p), ("x_tower_stride", ctypes.c_longlong), ("x_is_u8", ctypes.c_int), ("a_div", ctypes.c_float),
+                ("dz", ctypes.c_void_p), ("dz_tower_stride", ctypes.c_longlong)] + \
+               [(n, ctypes.c_int) for n in ("B", "H", "W", "C", "KH", "KW", "S", "filters", "towers")] + \
+               [("dw", ctypes.c_void_p), ("dw_tower_stride", ctypes.c_longlong), ("db", ctypes.c_void_p),
+                ("db_tower_stride", ctypes.c_longlong), ("workspace", ctypes.c_void_p), ("workspace_floats", ctypes.c_longlong)]
 
 
-def conv_dw_f32(x, x_tower_stride, dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw, dw_tower_stride, db,
-                db_tower_stride, workspace, job, stream=None):
-    """rlx_conv_dw_f32: an inner convolution's weight gradient from fp32 activations, its reduction deferred into `job`."""
+def conv_dw_item(x, x_tower_stride, x_is_u8, a_div, dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw, dw_tower_stride, db,
+                 db_tower_stride, workspace):
+    it = ConvDwItem()
+    it.x, it.x_tower_stride, it.x_is_u8, it.a_div = x.data_ptr(), x_tower_stride, int(bool(x_is_u8)), float(a_div)
+    it.dz, it.dz_tower_stride = dz.data_ptr(), dz_tower_stride
+    it.B, it.H, it.W, it.C, it.KH, it.KW, it.S, it.filters, it.towers = B, H, W, C, KH, KW, S, Co, towers
+    it.dw, it.dw_tower_stride, it.db, it.db_tower_stride = dw.data_ptr(), dw_tower_stride, _ptr(db), db_tower_stride
+    it.workspace, it.workspace_floats = workspace.data_ptr(), workspace.numel()
+    return it
+
+
+def conv_dw_multi(items, jobs, stream=None):
+    """rlx_conv_dw_multi: the convolution layers' weight gradients of one backward pass as ONE launch; jobs[i] receives
+    item i's outstanding reduction (the SAME SplitkJob objects the caller commits)."""
     s = current_stream() if stream is None else stream
-    run = lambda: lib().conv_dw_f32(x, x_tower_stride, dz, dz_tower_stride, B, H, W, C, KH, KW, S, Co, towers, dw, dw_tower_stride,
-                                    db, db_tower_stride, workspace, workspace.numel(), ctypes.byref(job), s)
+    n = len(items)
+    arr = (ConvDwItem * n)(*items)
+    jarr = (SplitkJob * n)()
+
+    def run():
+        lib().conv_dw_multi(arr, jarr, n, s)
     if GEMM_HOOK is not None:
-        OH, OW = (H - KH) // S + 1, (W - KW) // S + 1
-        d = GemmDesc()
-        d.M, d.N, d.K, d.batch = KH * KW * C, Co, B * OH * OW, towers
-        _record((d,), run)
+        descs = []
+        for it in items:
+            OH, OW = (it.H - it.KH) // it.S + 1, (it.W - it.KW) // it.S + 1
+            d = GemmDesc()
+            d.M, d.K = it.KH * it.KW * it.C, it.B * OH * OW
+            d.N, d.batch, d.a_is_u8 = (it.towers * it.filters, 1, 1) if it.x_is_u8 else (it.filters, it.towers, 0)
+            descs.append(d)
+        _record(tuple(descs), run)
     run()
+    for j, out in zip(jarr, jobs):
+        ctypes.memmove(ctypes.byref(out), ctypes.byref(j), ctypes.sizeof(SplitkJob))
 
 
 class SmallDenseProblem(ctypes.Structure):

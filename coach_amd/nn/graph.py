@@ -180,6 +180,8 @@ SPLIT_CAP_BOUND = 128
 CONV_DW_U8 = True
 # the inner convolutions' weight gradients, when they run on their own, by rlx_conv_dw_f32 (csrc/conv_dw_f32.hip)
 CONV_DW_F32 = True
+# ... and all of a backward pass's LDS-resident weight-gradient products as ONE launch (rlx_conv_dw_multi)
+CONV_DW_ONE_LAUNCH = True
 
 
 class Workspace:
@@ -649,9 +651,12 @@ class Conv2d(Layer):
         executed = s * s * (-(-self.H // s)) * (-(-self.W // s)) * (self.KH // s) * (self.KW // s)
         return DIRECT_CONV_INPUT_GRAD == "always" or executed <= 1.3 * self.OH * self.OW * self.KH * self.KW
 
-    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False, dw_later=None):
+    def backward(self, ctx, x, y, need_dx=True, weights=None, t0=0, nt=None, need_dw=True, overlap=False, dw_later=None,
+                 dw_collect=None):
         """dw_later (a list): the weight-gradient product is not launched — its (descriptor, split-K job) is appended for
-        Sequential.backward to issue together with the other convolution layers' (rlx_gemm_multi_defer)."""
+        Sequential.backward to issue together with the other convolution layers' (rlx_gemm_multi_defer).  dw_collect (a
+        list): the same for a product that goes through the LDS-resident kernels — its (rlx_conv_dw_item, job) is appended
+        for ONE rlx_conv_dw_multi launch at the end of the backward pass."""
         t0, T = self._range(t0, nt)
         B, p = x.rows, self.params
         overlap = overlap and ctx.overlap
@@ -666,8 +671,18 @@ class Conv2d(Layer):
         # dW[K,Co] = cols^T dz : A(k, m) gathered with outer table = koff, reduction table = rowbase
         if need_dw:
             fold = x.towers == 0 and T > 1 and self.Co % 4 == 0 and self.C % 4 == 0 and FOLD_SHARED_INPUT
-            take = ctx.reserve_deferred_workspace if dw_later is not None else ctx.deferred_workspace
+            # the LDS-resident weight-gradient kernels (csrc/conv_dw_u8.hip: the first convolution of an image torso, frame
+            # rows + the image's dz in LDS; csrc/conv_dw_f32.hip: an inner convolution on its own — its input gradient went
+            # through rlx_conv32_input_grad): one deferred split per image / image pair
+            geo = (B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T)
+            lds_u8 = bool(not pairing and not overlap and dw_later is None and fold and x.u8 and CONV_DW_U8 and
+                          ctx.lib.conv_dw_u8_supported(*geo))
+            lds_f32 = bool(not pairing and not overlap and dw_later is None and not fold and not x.u8 and CONV_DW_F32 and
+                           x.towers == T and ctx.lib.conv_dw_f32_supported(*geo))
+            collecting = dw_collect is not None and (lds_u8 or lds_f32)
+            take = ctx.reserve_deferred_workspace if dw_later is not None or collecting else ctx.deferred_workspace
             job, dws = take(self.K, T * self.Co if fold else self.Co, 1 if fold else T) if not overlap else (None, None)
+            collecting = collecting and job is not None
 
             def dw(ws, launch=True):
                 ws = dws if job is not None else ws
@@ -687,20 +702,14 @@ class Conv2d(Layer):
                                  launch=launch, defer=dj)
             if dw_later is not None and job is not None:
                 dw_later.append((dw(None, launch=False), job))
-            elif (not pairing and fold and x.u8 and job is not None and CONV_DW_U8 and
-                  ctx.lib.conv_dw_u8_supported(B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T)):
-                # the first convolution of an image torso: frame rows and the image's dz in LDS, one workgroup per (image,
-                # pair of kernel rows), one deferred split per image (csrc/conv_dw_u8.hip)
-                _rlx.conv_dw_u8(x.data, x.div, dz, M * self.Co, B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T,
-                                p.g(self.kname, t0), p.stride(self.kname), p.g(self.bname, t0), p.stride(self.bname), dws, job,
-                                ctx.stream)
-            elif (not pairing and not fold and not x.u8 and job is not None and CONV_DW_F32 and x.towers == T and
-                  ctx.lib.conv_dw_f32_supported(B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T)):
-                # an inner convolution's weight gradient on its own (the input gradients went through
-                # rlx_conv32_input_grad): the pair's input rows and dz in LDS, one deferred split per image pair
-                _rlx.conv_dw_f32(x.data, x.tower_stride(), dz, M * self.Co, B, self.H, self.W, self.C, self.KH, self.KW, self.S,
-                                 self.Co, T, p.g(self.kname, t0), p.stride(self.kname), p.g(self.bname, t0),
-                                 p.stride(self.bname), dws, job, ctx.stream)
+            elif (lds_u8 or lds_f32) and job is not None:
+                item = _rlx.conv_dw_item(x.data, 0 if lds_u8 else x.tower_stride(), lds_u8, x.div if lds_u8 else 1.0, dz,
+                                         M * self.Co, *geo, p.g(self.kname, t0), p.stride(self.kname), p.g(self.bname, t0),
+                                         p.stride(self.bname), dws)
+                if collecting:
+                    dw_collect.append((item, job))
+                else:
+                    _rlx.conv_dw_multi([item], [job], ctx.stream)
             elif not pairing:
                 dw(ctx.ws.splitk)
         if direct:
@@ -727,7 +736,7 @@ class Conv2d(Layer):
             ctx.lib.col2im(dcol, dx, x.data if lower else None, _rlx.ACT[lower], T * B, self.H, self.W,
                            self.C, self.KH, self.KW, self.S, ctx.stream)
             x.grad_is_dz = lower is not None
-        if need_dw and not (dw_later is not None and job is not None):
+        if need_dw and not ((dw_later is not None or collecting) and job is not None):
             ctx.commit_deferred(job)
 
 
@@ -1092,10 +1101,16 @@ class Sequential:
             # them, then go out as ONE launch (up to three products) instead of one per layer inside its dW + dX pair
             later = [] if (MULTI_DW and need_dw and ctx.deferred is not None and not ctx.overlap and
                            sum(isinstance(self.layers[i], Conv2d) for i in range(lo, hi)) >= 2) else None
+            # CONV_DW_ONE_LAUNCH: the LDS-resident weight-gradient products of the convolution layers go out as ONE launch
+            # (rlx_conv_dw_multi) once the input-gradient chain has passed all of them
+            collect = [] if (CONV_DW_ONE_LAUNCH and need_dw and later is None and ctx.deferred is not None and
+                             not ctx.overlap) else None
             i = hi
             while i > lo:
                 i -= 1
                 kw = {"overlap": True} if need_dw else {"need_dw": False}
+                if collect is not None and isinstance(self.layers[i], Conv2d):
+                    kw["dw_collect"] = collect
                 if i - 1 >= lo and later is None and \
                         self._fused_conv_input_grads(ctx, acts, i, weights, t0, nt, kw, i - 1 > 0 or need_input_grad):
                     i -= 1               # layers i and i - 1 are done
@@ -1104,6 +1119,13 @@ class Sequential:
                     kw["dw_later"] = later
                 self.layers[i].backward(ctx, acts[i], acts[i + 1], need_dx=(i > 0 or need_input_grad),
                                         weights=weights, t0=t0, nt=nt, **kw)
+            while collect:
+                # longest workgroups first: the uint8 layer, then the fp32 layers by reduction length
+                group = sorted(collect[:3], key=lambda e: (not e[0].x_is_u8, -e[0].H))
+                collect = collect[3:]
+                _rlx.conv_dw_multi([it for it, _ in group], [j for _, j in group], ctx.stream)
+                for _, j in group:
+                    ctx.commit_deferred(j, reserved=True)
             while later:
                 group, later = later[:3], later[3:]
                 _rlx.gemm_multi([d for d, _ in group], [j for _, j in group])

@@ -891,6 +891,21 @@ int rlx_conv_dw_f32(const float *x, long long x_tower_stride, const float *dz, l
                     void *stream);
 int rlx_conv_dw_f32_stamps(long long *device_words4);
 
+/* The weight gradients of up to three convolution layers of one backward pass — independent once the input-gradient chain
+ * has passed — as ONE launch: items[i] is what rlx_conv_dw_u8 (x_is_u8, x = frames) or rlx_conv_dw_f32 would get, jobs[i]
+ * receives its outstanding reduction.  The one-launch form takes at most one uint8 item of the Atari geometry and two fp32
+ * items; any other combination is issued item by item (same results either way). */
+typedef struct rlx_conv_dw_item {
+    const void *x; long long x_tower_stride;
+    int x_is_u8; float a_div;
+    const float *dz; long long dz_tower_stride;
+    int B, H, W, C, KH, KW, S, filters, towers;
+    float *dw; long long dw_tower_stride;
+    float *db; long long db_tower_stride;
+    float *workspace; long long workspace_floats;
+} rlx_conv_dw_item;
+int rlx_conv_dw_multi(const rlx_conv_dw_item *items_host, rlx_splitk_job *jobs_host, int n_items, void *stream);
+
 /* ------------------------------------------------- Clipped PPO: last dense layer + heads + losses, one launch -- */
 /* The middleware's Dense(units) of both towers (tower 0 = value, tower 1 = policy; layers.py:168-185), VHead / discrete
  * PPOHead forward (heads/v_head.py:43-52, heads/ppo_head.py:52-116), both head losses (head.py:143-186) and the heads'

@@ -57,7 +57,7 @@ def test_unsupported_shapes_are_refused(rlx):
     assert rlx.conv_dw_f32_supported(300, 9, 9, 64, 3, 3, 1, 64, 2) == 0      # more pairs than deferred splits
 
 
-def _update(dev, B, flag):
+def _update(dev, B, flag, one_launch=False):
     import torch
     from coach_amd import _rlx
     from coach_amd.nn import graph as G
@@ -68,8 +68,8 @@ def _update(dev, B, flag):
     acts = torch.from_numpy(rng.randint(0, A, size=B).astype(np.int32)).to(dev)
     adv = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
     vt = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
-    saved = G.CONV_DW_F32, G.FUSE_CONV_INPUT_GRADS
-    G.CONV_DW_F32, G.FUSE_CONV_INPUT_GRADS = flag, True
+    saved = G.CONV_DW_F32, G.FUSE_CONV_INPUT_GRADS, G.CONV_DW_ONE_LAUNCH
+    G.CONV_DW_F32, G.FUSE_CONV_INPUT_GRADS, G.CONV_DW_ONE_LAUNCH = flag, True, one_launch
     try:
         np.random.seed(1)
         net = ClippedPPONet(dev, shape, A, seed=2, activation="tanh")
@@ -82,7 +82,7 @@ def _update(dev, B, flag):
         net.check_status()
         return grads, [n for n, _ in timer.records], net
     finally:
-        G.CONV_DW_F32, G.FUSE_CONV_INPUT_GRADS = saved
+        G.CONV_DW_F32, G.FUSE_CONV_INPUT_GRADS, G.CONV_DW_ONE_LAUNCH = saved
 
 
 @pytest.mark.parametrize("B", [64, 63])
@@ -106,3 +106,16 @@ def test_ppo_update_takes_the_kernel_and_agrees_with_the_tiled_products(rlx, dev
     assert not differ[~inner].any()                           # another summation order of these two gradients, nothing else
     np.testing.assert_allclose(g1[inner], g0[inner], rtol=1e-4, atol=2e-6 * np.abs(g0[inner]).max())
     assert np.abs(g0[inner]).max() > 0
+
+
+@pytest.mark.parametrize("B", [64, 63])
+def test_one_launch_of_the_three_layers_is_bit_identical_to_three_launches(rlx, dev, B):
+    """rlx_conv_dw_multi (csrc/conv_dw_multi.hip): the same device code, the same partial sums, one grid."""
+    import torch
+    three = _update(dev, B, True, one_launch=False)
+    one = _update(dev, B, True, one_launch=True)
+    assert sum("conv_dw_multi_kernel" in n for n in one[1]) == 1 and not any("conv_dw_f32_kernel" in n or "conv_dw_u8_kernel" in n
+                                                                             for n in one[1]), one[1]
+    assert sum("conv_dw_f32_kernel" in n for n in three[1]) == 2 and sum("conv_dw_u8_kernel" in n for n in three[1]) == 1, three[1]
+    assert len(one[1]) == len(three[1]) - 2
+    assert torch.equal(one[0], three[0])

@@ -80,6 +80,7 @@ def _update(dev, B, flag):
     adv = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
     vt = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
     saved, G.CONV_DW_U8 = G.CONV_DW_U8, flag
+    saved_one, G.CONV_DW_ONE_LAUNCH = G.CONV_DW_ONE_LAUNCH, False      # (the kernel as a launch of its own)
     try:
         np.random.seed(1)
         net = ClippedPPONet(dev, shape, A, seed=2, activation="tanh")
@@ -93,6 +94,7 @@ def _update(dev, B, flag):
         return grads, net.params.weights.clone(), [n for n, _ in timer.records], net
     finally:
         G.CONV_DW_U8 = saved
+        G.CONV_DW_ONE_LAUNCH = saved_one
 
 
 @pytest.mark.parametrize("B", [64, 63])
