@@ -638,7 +638,7 @@ def gemm_roofline(agent, reps=20):
     # own loads, profiles/r03_pmc_calibration.json); used only if that file describes the same products AND launches.
     gemm_launches = sum(r["launches_per_update"] for r in table if r["kernel"].startswith(GEMM_FAMILY))
     traffic = None
-    for fn in ("r05_pmc_gemm_traffic.json", "r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json"):
+    for fn in ("r06_pmc_gemm_traffic.json", "r05_pmc_gemm_traffic.json", "r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 pm = json.load(f)

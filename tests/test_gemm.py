@@ -343,7 +343,9 @@ def test_deferred_weight_gradient_reductions_equal_immediate_ones(rlx, dev):
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-6 * scale)
     np.testing.assert_array_equal(out[True][1], out[False][1])
     assert np.abs(out[True][0]).sum() > 0
-    assert launches[True] == launches[False] + 1             # host calls: + the one reduce call (device launches: fewer)
+    # host calls: + the one reduce call, - one where the convolution layers' weight gradients go out as one launch
+    # (CONV_DW_ONE_LAUNCH needs the deferred arena); device launches: fewer either way
+    assert launches[True] <= launches[False] + 1
 
 
 @pytest.mark.gpu

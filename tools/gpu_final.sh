@@ -1,9 +1,9 @@
 #!/bin/bash
 # final evidence of a round: full GPU suite (no -x), smoke, the five bench lines (roofline + box + cpu_baseline), kernel
-# traces of the bench commands, PMC passes on one eager update (traffic, MFMA busy cycles).  Writes gpurun_out/r05_final/;
-# what is kept goes to profiles/r05_final_*.  Every step runs under its own timeout.
+# traces of the bench commands, PMC passes on one eager update (traffic, MFMA busy cycles).  Writes gpurun_out/r06_final/;
+# what is kept goes to profiles/r06_final_*.  Every step runs under its own timeout.
 set -u
-O=gpurun_out/r05_final
+O=gpurun_out/r06_final
 mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD

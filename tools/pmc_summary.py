@@ -37,7 +37,7 @@ def mfma_table(busy_csv, active_csv, out):
         rows.append({"name": x["Kernel_Name"][:110], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": act,
                      "duration_us": round(dur_ns / 1e3, 2),
                      "mfma_util": round(busy / (dur_ns * 2.4 * 1024.0), 4) if dur_ns > 0 else None})
-        if "gemm_" in x["Kernel_Name"] or "splitk_reduce" in x["Kernel_Name"] or "conv23_" in x["Kernel_Name"] or "conv32_" in x["Kernel_Name"]:
+        if any(k in x["Kernel_Name"] for k in ("gemm_", "splitk_reduce", "conv23_", "conv32_", "conv_dw_")):
             tb += busy
             tt += dur_ns
     res = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES (dispatch timestamps of the same pass) on "
@@ -57,7 +57,7 @@ def main():
     fetch, write, out = sys.argv[1:4]
     f, w = last_update(fetch), last_update(write)
     assert [r["Kernel_Name"] for r in f] == [r["Kernel_Name"] for r in w]
-    gemm = lambda n: "gemm_" in n or "conv23_" in n or "conv32_" in n    # (the fused convolution launches: 2-3 products each)
+    gemm = lambda n: any(k in n for k in ("gemm_", "conv23_", "conv32_", "conv_dw_"))    # (the fused launches: 2-3 products each)
     red = lambda n: "splitk_reduce" in n
     kernels, fk, wk = [], 0.0, 0.0
     n_gemm = n_red = 0
@@ -76,6 +76,8 @@ def main():
             import re
             targs = re.search(r"conv23_forward_kernel<([^>]*)>", n).group(1).split(",")
             return 3 if len(targs) >= 4 and int(targs[3]) > 0 else 2
+        if "conv_dw_multi" in n:                             # the three convolution weight gradients
+            return 3
         return 2 if ("pair" in n or "conv32_" in n) else 1
     products = sum(n_products(k["name"]) for k in kernels if gemm(k["name"]))
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/ppo_update_once.py, "
