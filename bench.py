@@ -823,6 +823,9 @@ def main():
                     help="A/B: the three convolution weight gradients as one launch (rlx_conv_dw_multi) or three")
     ap.add_argument("--conv-dw-u8", type=int, default=None, choices=[0, 1],
                     help="A/B: conv1's weight gradient by rlx_conv_dw_u8 (frame rows + the image's dz in LDS) or by rlx_gemm")
+    ap.add_argument("--heads-row-local", type=int, default=None, choices=[0, 1],
+                    help="A/B: the row-local part of the discrete heads inside the last dense layer's reduction, the rest on the "
+                         "deferred-reduction launch (rlx_ppo_fc_rows; default on)")
     ap.add_argument("--fc-heads", type=int, default=None, choices=[0, 1],
                     help="A/B: the last dense layer + heads + losses + heads' backward as one launch (rlx_ppo_fc_heads)")
     ap.add_argument("--fuse-conv-bwd", type=int, default=None, choices=[0, 1],
@@ -890,6 +893,9 @@ def main():
     if args.conv_dw_u8 is not None:
         from coach_amd.nn import graph as _G2
         _G2.CONV_DW_U8 = bool(args.conv_dw_u8)
+    if args.heads_row_local is not None:
+        from coach_amd.nn.networks import ClippedPPONet as _N2
+        _N2.HEADS_ROW_LOCAL = bool(args.heads_row_local)
     if args.fc_heads is not None:
         from coach_amd.nn.networks import ClippedPPONet as _N
         _N.FC_HEADS_ONE_LAUNCH = bool(args.fc_heads)

@@ -39,7 +39,7 @@ _CTYPE = {
     "size_t": ctypes.c_size_t,
 }
 
-_VALUE_RETURNING = {"rlx_abi_version", "rlx_ppo_fc_heads_supported", "rlx_td3_fused_supported", "rlx_sac_fused_supported", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
+_VALUE_RETURNING = {"rlx_abi_version", "rlx_ppo_fc_heads_supported", "rlx_ppo_fc_rows_supported", "rlx_td3_fused_supported", "rlx_sac_fused_supported", "rlx_mlp_dqn_supported", "rlx_mlp_q_act_supported", "rlx_conv23_forward_supported",
                     "rlx_conv123_forward_supported", "rlx_conv32_input_grad_supported", "rlx_conv_dw_u8_supported", "rlx_conv_dw_f32_supported"}  # return a value, not an rlx_status
 
 _DECL = re.compile(r"^\s*(int|const char \*)\s*(rlx_\w+)\s*\(([^;{]*?)\)\s*;", re.M | re.S)
@@ -266,20 +266,27 @@ class SplitkJob(ctypes.Structure):
 
 
 ADAM_TICKET_WORDS = 1056        # rlx.h RLX_ADAM_TICKET_WORDS
-ABI_VERSION = 7                 # rlx_abi_version() of the library this module's structures and buffer sizes match
+ABI_VERSION = 8                 # rlx_abi_version() of the library this module's structures and buffer sizes match
 MAX_SPLITK_JOBS = 8
 
 
-def splitk_reduce_jobs(jobs, stream=None):
-    """sum the partials of the deferred products `jobs` (SplitkJob list) in one launch."""
+def splitk_reduce_jobs(jobs, stream=None, ppo_tail=None):
+    """sum the partials of the deferred products `jobs` (SplitkJob list) in one launch.
+    ppo_tail: a PpoRowsDesc whose all-rows part (rlx_ppo_heads_tail) rides on the (last) launch as extra workgroups."""
     live = [j for j in jobs if j.splits > 1]
     s = current_stream() if stream is None else stream
     for i in range(0, len(live), MAX_SPLITK_JOBS):
         chunk = live[i:i + MAX_SPLITK_JOBS]
         arr = (SplitkJob * len(chunk))(*chunk)
-        run = lambda a=arr, n=len(chunk): lib().splitk_reduce_jobs(ctypes.byref(a), n, s)
+        if ppo_tail is not None and i + MAX_SPLITK_JOBS >= len(live):
+            run = lambda a=arr, n=len(chunk), t=ppo_tail: lib().splitk_reduce_jobs_ppo_tail(ctypes.byref(a), n, ctypes.byref(t), s)
+            ppo_tail = None
+        else:
+            run = lambda a=arr, n=len(chunk): lib().splitk_reduce_jobs(ctypes.byref(a), n, s)
         _record((), run, flops=0.0)                # part of the GEMM family's time, no products of its own
         run()
+    if ppo_tail is not None:                       # nothing to reduce: the tail as a launch of its own
+        lib().ppo_heads_tail(ctypes.byref(ppo_tail), s)
 
 
 def conv_input_grad(dz, weights, dx, x_out, deriv, tables, B, H, W, C, KH, KW, S, Co, towers, dy_stride, w_stride,
@@ -418,6 +425,15 @@ class PpoFcHeadsDesc(ctypes.Structure):
                 ("dlogits", P), ("d_value_w", P), ("d_value_b", P), ("d_policy_w", P), ("d_policy_b", P), ("scalars", P),
                 ("likelihood_ratio", P), ("clipped_likelihood_ratio", P), ("status", P), ("workspace", P),
                 ("workspace_floats", LL), ("tickets", P)]
+
+
+class PpoRowsDesc(ctypes.Structure):
+    """rlx_ppo_rows_desc (include/rlx.h) — field order must match the header."""
+    P, LL, F, I = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_int
+    _fields_ = [("value_head", SmallDenseProblem), ("policy_head", SmallDenseProblem), ("value_targets", P), ("actions", P),
+                ("advantages", P), ("old_probs", P), ("ld_old", LL), ("clip_scale", P), ("clip_epsilon", F),
+                ("beta_entropy", F), ("grad_scale", F), ("batch", I), ("row_terms", P), ("scalars", P),
+                ("likelihood_ratio", P), ("clipped_likelihood_ratio", P), ("status", P)]
 
 
 class ObserveDesc(ctypes.Structure):

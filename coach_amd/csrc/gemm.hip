@@ -26,6 +26,7 @@
 // blockIdx.z also carries a batch index (the two separate Clipped-PPO towers run as one launch).
 #include "rlx_common.hpp"
 #include "dense_small_body.hpp"
+#include "losses_body.hpp"
 #include <cstdlib>
 
 namespace {
@@ -1743,12 +1744,34 @@ constexpr int kRowHeadsMaxN = 2048;
 // P = passes of 64 float4 groups that cover a row (N <= 256 P).  Everything the workgroup reads is requested before
 // the first barrier — the partials of ALL passes, the epilogue operands, the head's weight rows — so that the row costs
 // one exposed memory round trip, like the reduction alone did.
-template <int NN, int P>
-__global__ void __launch_bounds__(1024) splitk_reduce_rows_kernel(const GemmDev g, const rlx_small::MultiFwd heads) {
+// PPO (rlx_ppo_fc_rows): the row also gets everything of the discrete Clipped-PPO update that is LOCAL to it — the head's loss
+// terms, the gradient at the head's outputs (losses_body.hpp: the arithmetic of the stand-alone loss kernels) and
+// dz = act'(h) (dy W_head^T), the gradient at this dense layer's pre-activation output (dense_small_bwd_body's chain: n
+// ascending from 0.f, then the activation derivative) — from the row in LDS and the head's weight rows in registers.  What
+// needs all rows (the heads' weight gradients, the loss scalars) is left to rlx_ppo_heads_tail / rlx_splitk_reduce_jobs_ppo_tail.
+struct PpoRowsDev {
+    int kind[rlx_small::kMaxProblems];        // per batch entry: 0 none, 1 value head (MSE), 2 discrete policy head
+    float *dy[rlx_small::kMaxProblems];       // [M][N] gradient at the head's outputs
+    float *dx[rlx_small::kMaxProblems];       // [M][K] gradient at the dense layer's pre-activation output (this tower)
+    const float *v_target, *adv, *old_probs; long long ld_old;
+    const int *actions;
+    const float *clip_scale;
+    float *row_terms;                         // [M][4]: value loss term, surrogate, entropy, KL
+    float *ratio_out, *clipped_out;
+    int *status;
+    float clip_eps, beta, grad_scale;
+    int lower_act;
+};
+
+template <int NN, int P, bool PPO = false>
+__global__ void __launch_bounds__(1024) splitk_reduce_rows_kernel(const GemmDev g, const rlx_small::MultiFwd heads,
+                                                                  const PpoRowsDev r) {
     constexpr int SG = 16;
     __shared__ float4 part[SG][64];
     __shared__ float hrow[256 * P];
     __shared__ float hpart[4][NN];
+    __shared__ float yrow[NN], dzrow[NN], porow[NN], prow[2];
+    __shared__ int prow_act;
     const int row = blockIdx.x, batch = blockIdx.y;
     const int n4 = g.N >> 2, mn4 = (g.M * g.N) >> 2;
     const int ox = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -1766,6 +1789,21 @@ __global__ void __launch_bounds__(1024) splitk_reduce_rows_kernel(const GemmDev 
         const int k = wave * kq + lane + 64 * j;
 #pragma unroll
         for (int n = 0; n < NN; ++n) wreg[j][n] = (has_head && wave < 4 && k < k1 && n < hp.N) ? hp.w[(size_t)k * hp.N + n] : 0.f;
+    }
+    // PPO: what thread 0 needs of this row's sample, requested with everything else — one value per thread (threads
+    // 0 .. N-1: the old policy's probabilities; 16, 17, 18: advantage, action, clip range; value tower: thread 0 the target)
+    float pre = 0.f;
+    int pre_i = 0;
+    if (PPO) {
+        const int tid = threadIdx.x;
+        if (r.kind[batch] == 2) {
+            if (tid < hp.N) pre = r.old_probs[(size_t)row * r.ld_old + tid];
+            else if (tid == 16) pre = r.adv[row];
+            else if (tid == 17) pre_i = r.actions[row];
+            else if (tid == 18) pre = r.clip_scale ? r.clip_eps * *r.clip_scale : r.clip_eps;
+        } else if (r.kind[batch] == 1 && tid == 0) {
+            pre = r.v_target[row];
+        }
     }
     float4 sp[P];
     float eb[P][4], ea[P][4], ec[P][4];
@@ -1866,8 +1904,111 @@ __global__ void __launch_bounds__(1024) splitk_reduce_rows_kernel(const GemmDev 
         const int n = threadIdx.x;
         float v = ((hpart[0][n] + hpart[1][n]) + hpart[2][n]) + hpart[3][n];
         v += hp.b ? hp.b[n] : 0.f;
-        hp.y[(size_t)row * hp.N + n] = rlx_small::act_apply(v, hp.act);
+        v = rlx_small::act_apply(v, hp.act);
+        hp.y[(size_t)row * hp.N + n] = v;
+        if (PPO) yrow[n] = v;
     }
+    if (!PPO) return;
+    const int kind = r.kind[batch];                           // workgroup-uniform
+    if (kind == 0) return;
+    if (kind == 2) {
+        const int tid = threadIdx.x;
+        if (tid < hp.N) porow[tid] = pre;
+        else if (tid == 16) prow[0] = pre;
+        else if (tid == 17) prow_act = pre_i;
+        else if (tid == 18) prow[1] = pre;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        using namespace rlx_losses;
+        const int B = g.M;
+        if (kind == 1) {                                      // VHead: MSE(target, V), loss weight 1 (head.py:172-181)
+            if (lane == 0) {
+                const float w = 1.f;
+                const float e = yrow[0] - pre;
+                float l, gg;
+                regression_terms(e, 0, l, gg);
+                dzrow[0] = regression_grad(r.grad_scale, w, gg, B);
+                r.row_terms[(size_t)row * 4] = w * l;
+                if (r.dy[batch]) r.dy[batch][row] = dzrow[0];
+            }
+        } else {                                              // discrete PPOHead (ppo_head.py:52-116), one action per lane
+            PpoRowTerms t;
+            float *dyr = r.dy[batch] ? r.dy[batch] + (size_t)row * hp.N : nullptr;
+            if (!ppo_discrete_row_wave(yrow, porow, prow_act, hp.N, prow[0], prow[1], r.beta, r.grad_scale, B, dzrow,
+                                       r.ratio_out ? r.ratio_out + row : nullptr, r.clipped_out ? r.clipped_out + row : nullptr, t)) {
+                if (lane == 0) atomicOr(r.status, 1);
+                if (lane < hp.N) dzrow[lane] = 0.f;
+                t.sur = t.ent = t.kl = 0.f;
+            }
+            if (lane == 0) {
+                r.row_terms[(size_t)row * 4 + 1] = t.sur;
+                r.row_terms[(size_t)row * 4 + 2] = t.ent;
+                r.row_terms[(size_t)row * 4 + 3] = t.kl;
+            }
+            if (dyr && lane < hp.N) dyr[lane] = dzrow[lane];
+        }
+    }
+    __syncthreads();
+    if (wave < 4 && r.dx[batch]) {                            // dense_small_bwd_body's dx of this row
+        float *dx = r.dx[batch] + (size_t)row * hp.K;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int k = wave * kq + lane + 64 * j;
+            if (k < k1) {
+                float s = 0.f;
+#pragma unroll
+                for (int n = 0; n < NN; ++n)
+                    if (n < hp.N) s = fmaf(dzrow[n], wreg[j][n], s);
+                dx[k] = r.lower_act ? s * rlx_small::act_deriv_out(hrow[k], r.lower_act) : s;
+            }
+        }
+    }
+}
+
+// The part of the discrete Clipped-PPO heads' backward pass that needs ALL rows, behind splitk_reduce_rows_kernel<.., true>:
+// dW and db of both heads from the rows' head-output gradients (dense_small_bwd_body: the sums of rlx_ppo_heads_loss_backward,
+// bit for bit) and the loss scalars from the rows' terms (the same reduction trees).  blockIdx-free: kblock = 32-feature
+// block, is_policy = head; 256 threads.
+struct PpoTailDev {
+    rlx_small::SmallDenseBwd value, policy;   // dy = the head-output gradients the rows kernel wrote; dx = nullptr
+    const float *row_terms;
+    float *scalars;
+    int batch, red_threads, nn;
+    float beta;
+};
+template <int NN>
+__device__ __forceinline__ void ppo_heads_tail_body(const PpoTailDev &a, int kblock, bool is_policy, float *smem,
+                                                    float (*red)[256]) {
+    using namespace rlx_losses;
+    const rlx_small::SmallDenseBwd &p = is_policy ? a.policy : a.value;
+    if (kblock * rlx_small::kKL >= p.K) return;
+    if (kblock == 0) {
+        const int b = threadIdx.x, B = a.batch;
+        if (is_policy) {
+            float l_sur = 0.f, l_ent = 0.f, l_kl = 0.f;
+            if (b < B) {
+                l_sur = a.row_terms[(size_t)b * 4 + 1];
+                l_ent = a.row_terms[(size_t)b * 4 + 2];
+                l_kl = a.row_terms[(size_t)b * 4 + 3];
+            }
+            block_sum3_first(l_sur, l_ent, l_kl, red, a.red_threads);
+            if (threadIdx.x == 0) ppo_discrete_scalars(l_sur, l_ent, l_kl, a.beta, B, a.scalars);
+        } else {
+            const float local = b < B ? a.row_terms[(size_t)b * 4] : 0.f;
+            const float s = block_sum_first(local, red[0], a.red_threads);
+            if (threadIdx.x == 0) a.scalars[4] = s / (float)B;
+        }
+    }
+    rlx_small::dense_small_bwd_body<NN, rlx_small::kKL, rlx_small::kRG, false>(p, kblock, 0, smem);
+}
+constexpr int kTailSmemFloats = 256 * rlx_small::kMaxN + rlx_small::kRG * rlx_small::kKL * rlx_small::kMaxN;
+
+template <int NN>
+__global__ void __launch_bounds__(256) ppo_heads_tail_kernel(const PpoTailDev a) {
+    __shared__ float smem[kTailSmemFloats];
+    __shared__ float red[3][256];
+    ppo_heads_tail_body<NN>(a, blockIdx.x, blockIdx.z == 1, smem, red);
 }
 
 // blockIdx.y = batch entry of the job, blockIdx.x = 64 float4 output groups; the scheme of splitk_reduce4_kernel<16>
@@ -1876,10 +2017,8 @@ __global__ void __launch_bounds__(1024) splitk_reduce_rows_kernel(const GemmDev 
 struct ReduceJobs {
     rlx_splitk_job job[RLX_MAX_SPLITK_JOBS];
 };
-__global__ void __launch_bounds__(1024) splitk_reduce_jobs_kernel(const ReduceJobs jobs) {
+__device__ __forceinline__ void splitk_reduce_job_body(const rlx_splitk_job &g, float4 (*part)[64]) {
     constexpr int SG = 16;
-    __shared__ float4 part[SG][64];
-    const rlx_splitk_job &g = jobs.job[blockIdx.z];
     const int batch = blockIdx.y;
     if (batch >= g.batch) return;
     const int mn4 = (g.M * g.N) >> 2;
@@ -1946,6 +2085,28 @@ __global__ void __launch_bounds__(1024) splitk_reduce_jobs_kernel(const ReduceJo
             }
         }
     }
+}
+__global__ void __launch_bounds__(1024) splitk_reduce_jobs_kernel(const ReduceJobs jobs) {
+    __shared__ float4 part[16][64];
+    splitk_reduce_job_body(jobs.job[blockIdx.z], part);
+}
+// ... and, in the same launch, the all-rows part of the discrete Clipped-PPO heads' backward pass (ppo_heads_tail_body) as
+// the workgroups of one more z slice (z = 0): blockIdx.x = 32-feature block, blockIdx.y = head; their first four waves work, the
+// other twelve leave at once (s_barrier counts the surviving waves of a workgroup).  The heads' gradients and the loss
+// scalars are not read before the optimizer step, which is behind this launch anyway: one launch less in the chain.
+template <int NN>
+__global__ void __launch_bounds__(1024) splitk_reduce_jobs_tail_kernel(const ReduceJobs jobs, int n_jobs, const PpoTailDev tail) {
+    __shared__ float4 part[16][64];
+    __shared__ float smem[kTailSmemFloats];
+    __shared__ float red[3][256];
+    // z = 0: the tail (dispatched first — its workgroups are few and each is a chain of dependent round trips; behind the
+    // 800 reduction workgroups they started 3-4 us late and the launch took 11.1 instead of 6.5 us)
+    if (blockIdx.z > 0) {
+        splitk_reduce_job_body(jobs.job[blockIdx.z - 1], part);
+        return;
+    }
+    if (blockIdx.y > 1 || threadIdx.x >= 256) return;
+    ppo_heads_tail_body<NN>(tail, blockIdx.x, blockIdx.y == 1, smem, red);
 }
 
 // Column sums for bias gradients: out[n] = sum_m x[m][n]  (deterministic two-stage reduction).
@@ -2287,6 +2448,7 @@ int launch_splitk_reduce(const GemmDev &g, int M, int N, int batch, int splits, 
 // read them (splitk_reduce_rows_kernel).  Returns false when the combination is not the one that kernel reproduces bit
 // for bit (the caller then reduces as usual and rlx_gemm launches the heads behind it).
 thread_local bool tl_row_heads_done = false;
+thread_local const rlx_ppo_rows_desc *tl_ppo_rows = nullptr;      // rlx_ppo_fc_rows: the rows also get the Clipped-PPO epilogue
 bool launch_reduce_with_row_heads(const GemmDev &g, const rlx_gemm_desc &d, int splits, hipStream_t s) {
     const long long mn = (long long)d.M * d.N;
     if (splits <= 16 || d.N % 4 != 0 || mn >= (1LL << 31) || !aligned16(g.ws) || g.fold || g.colsum ||
@@ -2315,7 +2477,36 @@ bool launch_reduce_with_row_heads(const GemmDev &g, const rlx_gemm_desc &d, int 
     }
     dim3 rgrid(d.M, d.batch);
     const int passes = (d.N / 4 + 63) / 64;                 // 1 .. 8
-#define RLX_ROWS(NNV, PV) RLX_LAUNCH((splitk_reduce_rows_kernel<NNV, PV>), rgrid, 1024, 0, s, g, m)
+    PpoRowsDev r{};
+    if (tl_ppo_rows) {
+        const rlx_ppo_rows_desc &q = *tl_ppo_rows;
+        if (passes > 4 || nn < 4) return false;
+        const rlx_small_dense_problem *hq[2] = {&q.value_head, &q.policy_head};
+        for (int i = 0; i < 2; ++i) {
+            int t = -1;
+            for (int b = 0; b < d.batch; ++b)
+                if (hq[i]->x == d.C + (size_t)b * d.c_batch_stride) t = b;
+            if (t < 0) return false;
+            r.kind[t] = i + 1;
+            r.dy[t] = const_cast<float *>(hq[i]->dy);
+            r.dx[t] = hq[i]->dx;
+        }
+        r.v_target = q.value_targets; r.adv = q.advantages; r.old_probs = q.old_probs; r.ld_old = q.ld_old;
+        r.actions = q.actions; r.clip_scale = q.clip_scale; r.row_terms = q.row_terms;
+        r.ratio_out = q.likelihood_ratio; r.clipped_out = q.clipped_likelihood_ratio; r.status = q.status;
+        r.clip_eps = q.clip_epsilon; r.beta = q.beta_entropy; r.grad_scale = q.grad_scale;
+        r.lower_act = q.value_head.lower_activation;
+#define RLX_ROWS_PPO(NNV)                                                                                  \
+    if (passes <= 1) RLX_LAUNCH((splitk_reduce_rows_kernel<NNV, 1, true>), rgrid, 1024, 0, s, g, m, r);     \
+    else if (passes <= 2) RLX_LAUNCH((splitk_reduce_rows_kernel<NNV, 2, true>), rgrid, 1024, 0, s, g, m, r); \
+    else RLX_LAUNCH((splitk_reduce_rows_kernel<NNV, 4, true>), rgrid, 1024, 0, s, g, m, r)
+        if (nn == 4) { RLX_ROWS_PPO(4); }
+        else if (nn == 8) { RLX_ROWS_PPO(8); }
+        else { RLX_ROWS_PPO(16); }
+#undef RLX_ROWS_PPO
+        return true;
+    }
+#define RLX_ROWS(NNV, PV) RLX_LAUNCH((splitk_reduce_rows_kernel<NNV, PV>), rgrid, 1024, 0, s, g, m, r)
 #define RLX_ROWS_P(NNV)                                    \
     if (passes <= 1) RLX_ROWS(NNV, 1);                     \
     else if (passes <= 2) RLX_ROWS(NNV, 2);                \
@@ -2640,6 +2831,114 @@ int rlx_splitk_reduce_jobs(const rlx_splitk_job *jobs_host, int n_jobs, void *st
     }
     if (n == 0) return RLX_OK;
     RLX_LAUNCH((splitk_reduce_jobs_kernel), dim3(gx, gy, n), 1024, 0, rlx::as_stream(stream), jobs);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+// ---- discrete Clipped PPO: the last dense layer's K-split reduction finishes the rows AND what of the heads' losses /
+// backward pass is local to a row (rlx_ppo_fc_rows); the rest rides on the backward pass's deferred reductions
+namespace {
+int ppo_rows_check(const rlx_ppo_rows_desc *q, const char *who) {
+    RLX_REQUIRE(q && q->value_targets && q->actions && q->advantages && q->old_probs && q->row_terms && q->scalars &&
+                q->status, "%s: null pointer", who);
+    const rlx_small_dense_problem *h[2] = {&q->value_head, &q->policy_head};
+    for (int i = 0; i < 2; ++i) {
+        RLX_REQUIRE(h[i]->x && h[i]->w && h[i]->y && h[i]->dy && h[i]->dw && h[i]->dx, "%s: null pointer in head %d", who, i);
+        RLX_REQUIRE(h[i]->towers == 1 && h[i]->M == q->batch && h[i]->K > 0 && h[i]->activation == 0,
+                    "%s: head %d must be one linear tower over the %d rows of the batch", who, i, q->batch);
+        RLX_REQUIRE(h[i]->lower_activation >= 0 && h[i]->lower_activation <= 2, "%s: unknown activation", who);
+    }
+    RLX_REQUIRE(q->value_head.N == 1 && q->policy_head.N >= 2 && q->policy_head.N <= rlx_small::kMaxN &&
+                q->value_head.K == q->policy_head.K && q->value_head.lower_activation == q->policy_head.lower_activation,
+                "%s: value head N = 1, policy head 2 <= N <= %d, both on the same dense layer", who, rlx_small::kMaxN);
+    RLX_REQUIRE(q->batch >= 1 && q->batch <= 256, "%s: 1 <= batch <= 256 (one row per thread in the scalar sums)", who);
+    return RLX_OK;
+}
+PpoTailDev ppo_tail_dev(const rlx_ppo_rows_desc &q) {
+    PpoTailDev t{};
+    const rlx_small_dense_problem *h[2] = {&q.value_head, &q.policy_head};
+    rlx_small::SmallDenseBwd *d[2] = {&t.value, &t.policy};
+    for (int i = 0; i < 2; ++i)
+        *d[i] = rlx_small::SmallDenseBwd{h[i]->x, 0, h[i]->w, 0, h[i]->dy, 0, nullptr, 0, h[i]->dw, 0, h[i]->db, 0, nullptr, 0,
+                                         h[i]->M, h[i]->K, h[i]->N, 0, 0};
+    t.row_terms = q.row_terms; t.scalars = q.scalars; t.batch = q.batch; t.beta = q.beta_entropy;
+    t.red_threads = 64;
+    while (t.red_threads < q.batch) t.red_threads <<= 1;     // block_for() of the stand-alone loss kernels
+    t.nn = q.policy_head.N <= 4 ? 4 : (q.policy_head.N <= 8 ? 8 : 16);
+    return t;
+}
+}  // namespace
+
+int rlx_ppo_fc_rows_supported(const rlx_gemm_desc *fc, int n_actions) {
+    if (!fc || fc->row_heads || fc->batch != 2 || fc->N % 4 != 0 || fc->N > 1024 || fc->M > 256 || n_actions < 2 ||
+        n_actions > rlx_small::kMaxN || fc->ldc != fc->N || fc->n_fold > 0 || fc->colsum_out)
+        return 0;
+    GemmPlan plan{};
+    if (gemm_impl(fc, nullptr, &plan, nullptr) != RLX_OK) return 0;
+    return plan.q_splits > 16 ? 1 : 0;
+}
+
+int rlx_ppo_fc_rows(const rlx_gemm_desc *fc, const rlx_ppo_rows_desc *rows, void *stream) {
+    const int rc0 = ppo_rows_check(rows, "rlx_ppo_fc_rows");
+    if (rc0 != RLX_OK) return rc0;
+    RLX_REQUIRE(fc && !fc->row_heads && rlx_ppo_fc_rows_supported(fc, rows->policy_head.N) && fc->M == rows->batch &&
+                fc->N == rows->value_head.K,
+                "rlx_ppo_fc_rows: not a product rlx_ppo_fc_rows_supported accepts, or its shape does not match the heads");
+    rlx_small_dense_problem heads[2] = {rows->value_head, rows->policy_head};
+    rlx_gemm_desc d = *fc;
+    d.row_heads = heads;
+    d.n_row_heads = 2;
+    tl_row_heads_done = false;
+    tl_ppo_rows = rows;
+    const int rc = gemm_impl(&d, stream, nullptr);
+    tl_ppo_rows = nullptr;
+    if (rc != RLX_OK) return rc;
+    RLX_REQUIRE(tl_row_heads_done, "rlx_ppo_fc_rows: the product did not take the row-finishing reduction");
+    return RLX_OK;
+}
+
+int rlx_ppo_heads_tail(const rlx_ppo_rows_desc *rows, void *stream) {
+    const int rc0 = ppo_rows_check(rows, "rlx_ppo_heads_tail");
+    if (rc0 != RLX_OK) return rc0;
+    const PpoTailDev t = ppo_tail_dev(*rows);
+    const int kb = (rows->value_head.K + rlx_small::kKL - 1) / rlx_small::kKL;
+    dim3 grid(kb, 1, 2);
+    hipStream_t s = rlx::as_stream(stream);
+    if (t.nn == 4) RLX_LAUNCH((ppo_heads_tail_kernel<4>), grid, 256, 0, s, t);
+    else if (t.nn == 8) RLX_LAUNCH((ppo_heads_tail_kernel<8>), grid, 256, 0, s, t);
+    else RLX_LAUNCH((ppo_heads_tail_kernel<16>), grid, 256, 0, s, t);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_splitk_reduce_jobs_ppo_tail(const rlx_splitk_job *jobs_host, int n_jobs, const rlx_ppo_rows_desc *rows, void *stream) {
+    RLX_REQUIRE(jobs_host && n_jobs >= 0 && n_jobs <= RLX_MAX_SPLITK_JOBS,
+                "rlx_splitk_reduce_jobs_ppo_tail: 0..%d jobs (got %d)", RLX_MAX_SPLITK_JOBS, n_jobs);
+    const int rc0 = ppo_rows_check(rows, "rlx_splitk_reduce_jobs_ppo_tail");
+    if (rc0 != RLX_OK) return rc0;
+    ReduceJobs jobs;
+    int n = 0, gx = 1, gy = 1;
+    for (int i = 0; i < n_jobs; ++i) {
+        const rlx_splitk_job &j = jobs_host[i];
+        if (j.splits <= 1) continue;
+        RLX_REQUIRE(j.partials && j.C && j.M > 0 && j.N > 0 && j.N % 4 == 0 && j.batch > 0 &&
+                    (long long)j.M * j.N < (1LL << 31) && aligned16(j.partials),
+                    "rlx_splitk_reduce_jobs_ppo_tail: job %d is not a float4-reducible product", i);
+        jobs.job[n++] = j;
+        const int bx = (int)(((long long)j.M * j.N / 4 + 63) / 64);
+        gx = bx > gx ? bx : gx;
+        gy = j.batch > gy ? j.batch : gy;
+    }
+    if (n == 0) return rlx_ppo_heads_tail(rows, stream);
+    const PpoTailDev t = ppo_tail_dev(*rows);
+    const int kb = (rows->value_head.K + rlx_small::kKL - 1) / rlx_small::kKL;
+    gx = kb > gx ? kb : gx;
+    gy = gy < 2 ? 2 : gy;
+    dim3 grid(gx, gy, n + 1);
+    hipStream_t s = rlx::as_stream(stream);
+    if (t.nn == 4) RLX_LAUNCH((splitk_reduce_jobs_tail_kernel<4>), grid, 1024, 0, s, jobs, n, t);
+    else if (t.nn == 8) RLX_LAUNCH((splitk_reduce_jobs_tail_kernel<8>), grid, 1024, 0, s, jobs, n, t);
+    else RLX_LAUNCH((splitk_reduce_jobs_tail_kernel<16>), grid, 1024, 0, s, jobs, n, t);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -33,37 +33,6 @@ struct PpoHeadsBwdArgs {
     float clip_eps, beta, grad_scale;
 };
 
-// block_sum of losses_body.hpp over the first nt threads of a LARGER block (the tree of a block of nt threads)
-__device__ __forceinline__ float block_sum_first(float v, float *red, int nt) {
-    const int tid = threadIdx.x;
-    if (tid < nt) red[tid] = v;
-    __syncthreads();
-    for (int d = nt >> 1; d > 0; d >>= 1) {
-        if (tid < d) red[tid] += red[tid + d];
-        __syncthreads();
-    }
-    const float r = red[0];
-    __syncthreads();
-    return r;
-}
-
-// three such sums through ONE tree (each component goes through exactly the additions of block_sum_first)
-__device__ __forceinline__ void block_sum3_first(float &x, float &y, float &z, float (*red)[256], int nt) {
-    const int tid = threadIdx.x;
-    if (tid < nt) { red[0][tid] = x; red[1][tid] = y; red[2][tid] = z; }
-    __syncthreads();
-    for (int d = nt >> 1; d > 0; d >>= 1) {
-        if (tid < d) {
-            red[0][tid] += red[0][tid + d];
-            red[1][tid] += red[1][tid + d];
-            red[2][tid] += red[2][tid + d];
-        }
-        __syncthreads();
-    }
-    x = red[0][0]; y = red[1][0]; z = red[2][0];
-    __syncthreads();
-}
-
 template <int NN>
 __global__ void __launch_bounds__(256) ppo_heads_loss_bwd_kernel(const PpoHeadsBwdArgs a) {
     extern __shared__ float smem[];

@@ -270,8 +270,17 @@ class Context:
 
     def flush_deferred(self):
         jobs, self.deferred = self.deferred, None
-        if jobs:
-            _rlx.splitk_reduce_jobs(jobs, self.stream)
+        tail, self.ppo_tail = self.ppo_tail, None      # (ppo_fc_rows: the heads' all-rows part rides on this launch)
+        if jobs or tail is not None:
+            _rlx.splitk_reduce_jobs(jobs or [], self.stream, ppo_tail=tail)
+
+    ppo_tail = None
+
+    def flush_ppo_tail(self):
+        """the pending all-rows part of ppo_fc_rows as a launch of its own (no deferred-reduction launch took it along)."""
+        tail, self.ppo_tail = self.ppo_tail, None
+        if tail is not None:
+            self.lib.ppo_heads_tail(ctypes.byref(tail), self.stream)
 
     def buffer(self, name, shape, dtype=torch.float32, tag=""):
         key = (name, tuple(shape), dtype, tag)
@@ -846,6 +855,62 @@ def ppo_heads_loss_backward(ctx, value, policy, value_targets, actions, advantag
     ctx.lib.ppo_heads_loss_backward(ctypes.byref(arr[0]), ctypes.byref(arr[1]), value[2].data, value_targets,
                                     policy[2].data, actions, advantages, old_probs, ld_old, B, clip_epsilon, clip_scale,
                                     beta, 1.0, scalars, ratio_out, clipped_out, status, ctx.stream)
+
+
+def ppo_fc_rows(ctx, layer, x, v_head, pi_head, value_targets, actions, advantages, old_probs, ld_old, clip_epsilon,
+                clip_scale, beta, scalars, ratio_out, clipped_out, status, tag="", tail_now=False):
+    """`layer` (the torso's last Dense, two towers: value / policy) on x with everything of the discrete heads that is local
+    to a row inside its K-split reduction (rlx_ppo_fc_rows: heads forward, the rows' loss terms, dV / dlogits, dz of the
+    layer) -> (mid, v, logits) with their gradients set, or None where the layer's product does not take that reduction
+    (nothing launched).  The all-rows part (the heads' dW / db, the loss scalars) is left pending on the context:
+    Context.flush_deferred takes it along with the backward pass's reductions; tail_now: launched here (a caller that
+    reads the heads' gradients before the torso's backward pass has ended)."""
+    p, hp = layer.params, v_head.params
+    if not (layer.T == 2 and x.towers == 2 and not x.u8 and x.cols == layer.K and v_head.T == 1 and pi_head.T == 1 and
+            v_head.N == 1 and 2 <= pi_head.N <= SMALL_N and v_head.K == layer.N and pi_head.K == layer.N and
+            v_head.act is None and pi_head.act is None and x.rows <= 256):
+        return None
+    M, N, K = x.rows, layer.N, layer.K
+    y = ctx.buffer(layer.name, (2, M, N), tag=tag)
+    d = _rlx.gemm(M, N, K, x.data, p.w(layer.kname), y, bias=p.w(layer.bname), activation=layer.act, batch=2,
+                  a_batch_stride=x.tower_stride(), b_batch_stride=p.stride(layer.kname), c_batch_stride=M * N,
+                  bias_batch_stride=p.stride(layer.bname), workspace=ctx.ws.splitk, launch=False)
+    if not ctx.lib.ppo_fc_rows_supported(ctypes.byref(d), pi_head.N):
+        return None
+    mid = Tensor(y, M, N, 2, grad_key=(ctx, layer.name, tag), act=layer.act)
+    dz = mid.ensure_grad()
+    r = _rlx.PpoRowsDesc()
+    outs = []
+    for t, (q, l) in enumerate(((r.value_head, v_head), (r.policy_head, pi_head))):
+        hy = ctx.buffer(l.name, (1, M, l.N), tag=tag)
+        out = Tensor(hy, M, l.N, 1, grad_key=(ctx, l.name, tag), act=None)
+        q.x, q.x_tower_stride = y.data_ptr() + t * M * N * 4, 0
+        q.w, q.w_tower_stride = hp.w(l.kname).data_ptr(), hp.stride(l.kname)
+        q.bias, q.bias_tower_stride = hp.w(l.bname).data_ptr(), hp.stride(l.bname)
+        q.y, q.y_tower_stride = hy.data_ptr(), M * l.N
+        q.dy, q.dy_tower_stride = out.ensure_grad().data_ptr(), M * l.N
+        q.dw, q.dw_tower_stride = hp.g(l.kname).data_ptr(), hp.stride(l.kname)
+        q.db, q.db_tower_stride = hp.g(l.bname).data_ptr(), hp.stride(l.bname)
+        q.dx, q.dx_tower_stride = dz.data_ptr() + t * M * N * 4, M * N
+        q.towers, q.M, q.K, q.N = 1, M, l.K, l.N
+        q.activation, q.lower_activation = 0, _rlx.ACT[layer.act]
+        outs.append(out)
+    r.value_targets, r.actions, r.advantages = _rlx._ptr(value_targets), _rlx._ptr(actions), _rlx._ptr(advantages)
+    r.old_probs, r.ld_old, r.clip_scale = _rlx._ptr(old_probs), int(ld_old), _rlx._ptr(clip_scale)
+    r.clip_epsilon, r.beta_entropy, r.grad_scale, r.batch = float(clip_epsilon), float(beta), 1.0, M
+    r.row_terms = ctx.buffer("ppo_fc_rows/terms", (M, 4), tag=tag).data_ptr()
+    r.scalars, r.status = _rlx._ptr(scalars), _rlx._ptr(status)
+    r.likelihood_ratio, r.clipped_likelihood_ratio = _rlx._ptr(ratio_out), _rlx._ptr(clipped_out)
+    r._keep = (d,)
+    run = lambda: ctx.lib.ppo_fc_rows(ctypes.byref(d), ctypes.byref(r), ctx.stream)
+    _rlx._record((d,), run)
+    run()
+    mid.grad_is_dz = layer.act is not None
+    ctx.flush_ppo_tail()                          # (a tail still pending from a pass whose backward never ran)
+    ctx.ppo_tail = r
+    if tail_now:
+        ctx.flush_ppo_tail()
+    return mid, outs[0], outs[1]
 
 
 def ppo_fc_heads_supported(ctx, layer, x, v_head, pi_head):

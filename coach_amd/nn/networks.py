@@ -129,6 +129,13 @@ class ClippedPPONet(_NetBase):
     # the tiles) each cost a write-through + read round trip, which is what a launch boundary costs here.  Entry point,
     # parity test (tests/test_ppo_fc_fused.py) and A/B flag stay.
     FC_HEADS_ONE_LAUNCH = False
+    # discrete heads, minibatch <= 256 rows: what of the heads' losses and backward pass is LOCAL TO A ROW (heads forward, the
+    # row's loss terms, dV / dlogits, dz of the last dense layer) runs in the workgroup that finishes that row of the dense
+    # layer's K-split reduction (rlx_ppo_fc_rows), and the rest — dW / db of the heads, the loss scalars, which nobody reads
+    # before the Adam step — as extra workgroups of the backward pass's deferred-reduction launch
+    # (rlx_splitk_reduce_jobs_ppo_tail): the heads' launch (11.3 us of the C2 update, tens of workgroups) disappears from
+    # the chain.  Bit-identical to the three-launch path (tests/test_ppo_fc_rows.py); tests and bench.py --heads-row-local flip it.
+    HEADS_ROW_LOCAL = True
 
     def __init__(self, device, obs_shape, n_actions, activation="tanh", embedder="Medium",
                  middleware="Medium", learning_rate=2.5e-4, adam_beta1=0.9, adam_beta2=0.99,
@@ -267,9 +274,18 @@ class ClippedPPONet(_NetBase):
             clip_rescaler = 1.0
         fused_heads = self.pi_head.N <= G.SMALL_N and B * self.pi_head.N <= 1024
         heads_with_torso = fused_heads and self.HEADS_FORWARD_WITH_TORSO and self.torso.layers[-1].N > G.SMALL_N
-        if self.FC_HEADS_ONE_LAUNCH and heads_with_torso and not self.continuous and self.HEADS_LOSS_BACKWARD_ONE_LAUNCH:
+        discrete_fused = heads_with_torso and not self.continuous and self.HEADS_LOSS_BACKWARD_ONE_LAUNCH
+        if (self.FC_HEADS_ONE_LAUNCH or (self.HEADS_ROW_LOCAL and B <= 256)) and discrete_fused:
             acts = self.torso.forward(ctx, self.obs_tensor(obs, B), tag="train", skip_last=True)
-            if len(acts) == len(self.torso.layers) and \
+            if self.HEADS_ROW_LOCAL and B <= 256 and not self.FC_HEADS_ONE_LAUNCH and len(acts) == len(self.torso.layers):
+                res = G.ppo_fc_rows(ctx, self.torso.layers[-1], acts[-1], self.v_head, self.pi_head, value_targets, actions,
+                                    advantages, old_probs, self.A, self.clip_eps * clip_rescaler, clip_dev, self.beta,
+                                    self.scalars, ratio_out, clipped_out, self.status, tag="train",
+                                    tail_now=stop_after_dense)
+                if res is not None:
+                    acts.append(res[0])
+                    return self._backward_torso(acts, stop_after_dense)
+            if self.FC_HEADS_ONE_LAUNCH and len(acts) == len(self.torso.layers) and \
                     G.ppo_fc_heads_supported(ctx, self.torso.layers[-1], acts[-1], self.v_head, self.pi_head):
                 mid, v, logits = G.ppo_fc_heads(ctx, self.torso.layers[-1], acts[-1], self.v_head, self.pi_head, value_targets,
                                                 actions, advantages, old_probs, self.A, self.clip_eps * clip_rescaler, clip_dev,
@@ -343,6 +359,7 @@ class ClippedPPONet(_NetBase):
             self._resume = (acts, k)
         else:
             self.torso.backward(ctx, acts)
+        ctx.flush_ppo_tail()        # (no deferred-reduction launch took the heads' all-rows part along)
 
     def backward_rest(self):
         acts, k = self._resume

@@ -612,6 +612,39 @@ int rlx_ppo_heads_loss_backward(const rlx_small_dense_problem *value_head, const
                                 int batch, float clip_epsilon, const float *clip_scale, float beta_entropy,
                                 float grad_scale, float *scalars, float *likelihood_ratio,
                                 float *clipped_likelihood_ratio, int *status, void *stream);
+/* The same update with the heads' work split by what it depends on (round 6).  Everything of rlx_ppo_heads_loss_backward that
+ * is LOCAL TO A ROW — the head's forward on the finished row, the row's loss terms (heads/ppo_head.py:52-116, v_head.py:43-52,
+ * head.py:143-186), the gradient at the head's outputs and dz = act'(h) (dy W_head^T), the gradient at the last dense layer's
+ * pre-activation output (architecture.py:312-385) — runs in the workgroup that finishes that row of the dense layer
+ * (layers.py:168-185: its K-split reduction, one workgroup per row and tower): rlx_ppo_fc_rows = rlx_gemm(fc) with
+ * row_heads = {value_head, policy_head} + the row-local part.  What needs ALL rows and is read by nobody before the
+ * optimizer step — dW / db of both heads, scalars[5] — is rlx_ppo_heads_tail, a launch of its own, or
+ * rlx_splitk_reduce_jobs_ppo_tail: extra workgroups of the backward pass's deferred-reduction launch (rlx_splitk_reduce_jobs).
+ * Two launches of the update's chain become none.  Values: those of rlx_gemm(row_heads) + rlx_ppo_heads_loss_backward bit for
+ * bit (the same per-row arithmetic, the same chains and reduction trees).
+ * value_head / policy_head as for rlx_ppo_heads_loss_backward, all of x, w, y, dy, dw, dx required: x = the tower's rows of
+ * fc->C, y receives V / the logits, dy dV / dlogits, dx dz of the tower.  row_terms: [batch][4] floats of scratch that carries
+ * {value loss term, surrogate, entropy, KL} of each row from the rows launch to the tail.
+ * rlx_ppo_fc_rows_supported(fc, n_actions) -> 1 where rlx_gemm would split fc (two towers, <= 256 rows, N % 4 == 0,
+ * N <= 1024, no row_heads of its own) into more than 16 K chunks, i.e. where the row-finishing reduction runs. */
+typedef struct rlx_ppo_rows_desc {
+    rlx_small_dense_problem value_head, policy_head;
+    const float *value_targets;
+    const int *actions;
+    const float *advantages;
+    const float *old_probs; long long ld_old;
+    const float *clip_scale;               /* device scalar or NULL (see rlx_ppo_discrete_loss) */
+    float clip_epsilon, beta_entropy, grad_scale;
+    int batch;
+    float *row_terms;
+    float *scalars;                        /* [5] as in rlx_ppo_heads_loss_backward */
+    float *likelihood_ratio, *clipped_likelihood_ratio;   /* [batch] or NULL */
+    int *status;
+} rlx_ppo_rows_desc;
+int rlx_ppo_fc_rows_supported(const rlx_gemm_desc *fc, int n_actions);
+int rlx_ppo_fc_rows(const rlx_gemm_desc *fc, const rlx_ppo_rows_desc *rows, void *stream);
+int rlx_ppo_heads_tail(const rlx_ppo_rows_desc *rows, void *stream);
+int rlx_splitk_reduce_jobs_ppo_tail(const rlx_splitk_job *jobs_host, int n_jobs, const rlx_ppo_rows_desc *rows, void *stream);
 
 /* -------------------------------------------------------- head losses (K9) -- */
 /* loss = mean_b(loss_weight * w_b * sum_j l(target, out)); kind 0 = MSE, 1 = Huber(delta 1).

@@ -19,6 +19,7 @@ def dev():
 
 def _run(net, fused, obs, B, actions, adv, vt, old):
     net.FC_HEADS_ONE_LAUNCH = fused          # (instance attribute: the class default is off)
+    net.HEADS_ROW_LOCAL = False              # the reference here is the three-launch path (tests/test_ppo_fc_rows.py: the row-local one)
     net.params.grads.zero_()
     net.scalars.zero_()
     net.forward_backward(obs, B, actions, adv, vt, old)
