@@ -823,6 +823,9 @@ def main():
                     help="A/B: the three convolution weight gradients as one launch (rlx_conv_dw_multi) or three")
     ap.add_argument("--conv-dw-u8", type=int, default=None, choices=[0, 1],
                     help="A/B: conv1's weight gradient by rlx_conv_dw_u8 (frame rows + the image's dz in LDS) or by rlx_gemm")
+    ap.add_argument("--conv-fwd-groups", type=int, default=None, choices=[0, 4],
+                    help="A/B: wave groups per K slab of the fused forward convolutions (0: the tiled launches' rule, 4: always four)")
+    ap.add_argument("--split-cap", type=int, default=None, help="A/B: rlx_gemm_split_cap (most K chunks per product; default 64)")
     ap.add_argument("--heads-row-local", type=int, default=None, choices=[0, 1],
                     help="A/B: the row-local part of the discrete heads inside the last dense layer's reduction, the rest on the "
                          "deferred-reduction launch (rlx_ppo_fc_rows; default on)")
@@ -893,6 +896,12 @@ def main():
     if args.conv_dw_u8 is not None:
         from coach_amd.nn import graph as _G2
         _G2.CONV_DW_U8 = bool(args.conv_dw_u8)
+    if args.conv_fwd_groups is not None:
+        from coach_amd.nn import graph as _G4
+        _G4.CONV_FORWARD_WAVE_GROUPS = args.conv_fwd_groups or None
+    if args.split_cap is not None:
+        from coach_amd import _rlx as _R
+        _R.lib().gemm_split_cap(int(args.split_cap))
     if args.heads_row_local is not None:
         from coach_amd.nn.networks import ClippedPPONet as _N2
         _N2.HEADS_ROW_LOCAL = bool(args.heads_row_local)

@@ -28,8 +28,11 @@
 // whose A operands (its dz rows, 32 values per lane) live in registers for the whole product; the B operands of a job are
 // 8 float4 per lane read STRAIGHT from the weight matrix (a dcol column is a weight row: 64 contiguous k), requested one job
 // ahead; no LDS staging of the weights, no barrier inside a product.  (A first version on 16 x 16 blocks with
-// v_mfma_f32_16x16x4_f32 was bit-identical too and twice as slow: that instruction issues at HALF the 32 x 32 x 2 rate on
-// gfx950 — 64 cycles for 2048 flops, measured in both this kernel and conv_fused.hip.)
+// v_mfma_f32_16x16x4_f32 was bit-identical too and twice as slow — it ran ONE dependent chain per wave: 44 cycles per
+// instruction instead of the 32 the instruction issues at with two independent chains (box.mfma_cycles_per_instruction,
+// rlx_probe_mfma: the same flop rate as 32 x 32 x 2 then).  Two chains per wave in THIS kernel measured slower again —
+// 35.9 against 32.8 us, profiles/r06_ab_conv32_pairs.txt: a SIMD already interleaves the chains of its two waves, and the B
+// operands come straight from memory, so a second chain only adds registers.)
 // LDS 115 KB: column matrix 93 KB, dz3 9.5 KB, dz2 12 KB.
 // Bound: MFMA issue of one CU — 36 + 32 jobs of 32 MFMAs on 4 SIMDs = 34.8 k cycles = 16 us — plus two gather passes.
 #include "rlx_common.hpp"

@@ -32,7 +32,8 @@
 // gemm.hip's 256-entry table, W1 through the same ring), writes them to the LDS image conv2 reads and the rows it owns to
 // memory — in the order of sums of the register-staged tiled kernel that otherwise computes them (one chain over K = 256,
 // or three 96-long chunks combined as the split-K reduce launch combines them).  8 / 9 position tiles on 8 waves; the ninth
-// as four 16 x 16 blocks on four SIMDs (v_mfma_f32_16x16x4_f32: the same ascending-k chain, at half the issue rate).
+// as four 16 x 16 blocks on four SIMDs (v_mfma_f32_16x16x4_f32: the same ascending-k chain; one dependent chain per wave issues
+// every 44 cycles, two independent ones every 32 — the 32 x 32 x 2 flop rate — rlx_probe_mfma).
 // 35.8 us against 21.3 + 19.3 us in the PPO update.
 //
 // LDS (105 KB, one workgroup per CU; 139 - 156 KB with conv1 in front): conv1 rows [position][32 + 4 pad] (the pad spreads the 16-byte operand reads of

@@ -144,6 +144,13 @@ FUSE_CONV_FIRST = True
 # 182.3 against 188.8 us per update (profiles/r06_ab_conv_dw_f32.txt).  bench.py --fuse-conv-bwd 0 / 1 is the A/B.
 FUSE_CONV_INPUT_GRADS = True
 FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = 192
+# Wave groups per K slab of the fused forward launch (rlx_conv23_forward / rlx_conv123_forward).  None: what the tiled launches
+# would have used at this batch (2 for two towers of 63 .. 75 images — the third convolution then runs on four of the
+# eight waves, as the tiled kernel split its K chain — 4 for acting and the DQN update): the fused launch is then
+# bit-identical to the tiled ones.  4: every fused forward launch runs with four groups (conv3 on all eight waves); the
+# sums of the two-tower minibatch then differ from the tiled launches' in the last bits (another grouping of the k-quads),
+# inside tests/tolerances.py against the oracle.
+CONV_FORWARD_WAVE_GROUPS = None
 
 
 def _tiled_wave_groups(M, N, batch):
@@ -1029,6 +1036,7 @@ class Sequential:
         groups = _tiled_wave_groups(M2, a.Co, T)
         if groups not in (2, 4) or _tiled_wave_groups(M3, b.Co, T) != groups:
             return None
+        groups = CONV_FORWARD_WAVE_GROUPS or groups
         y2 = ctx.buffer(a.name, (T, M2, a.Co), tag=tag)
         y3 = ctx.buffer(b.name, (T, M3, b.Co), tag=tag)
         stream = ctx.stream
@@ -1075,6 +1083,7 @@ class Sequential:
         groups = _tiled_wave_groups(M2, a.Co, T)
         if groups not in (2, 4) or _tiled_wave_groups(M3, b.Co, T) != groups:
             return None
+        groups = CONV_FORWARD_WAVE_GROUPS or groups
         y1, T1, gargs, gkw = f.forward_product(ctx, x, tag, weights, t0, nt, pair)
         assert T1 == T
         d1 = _rlx.gemm(*gargs, launch=False, **gkw)
