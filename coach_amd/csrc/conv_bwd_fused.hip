@@ -41,6 +41,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 512;
 constexpr int H1 = 20, W1 = 20, C1 = 32;             // conv1 activation = conv2 input
@@ -75,6 +76,13 @@ __device__ __forceinline__ float act_deriv(float y, int kind) {      // gemm.hip
     return 1.f;
 }
 
+// TAIL16: the second row tile of both products (positions 32 .. 34 of 35, 32 .. 44 of 45) as a 16-row tile on
+// v_mfma_f32_16x16x4_f32 — a tail job is 16 rows x 32 columns = TWO independent 16 x 16 accumulator chains (the two column
+// halves), which is what lets that instruction issue every 32 cycles: 32 of them = 1024 cycles per job against 2048 for the
+// padded 32 x 32 tile.  Waves 0 .. 3 then take the full row tile, waves 4 .. 7 the tail (one of each per SIMD), column
+// tiles w % 4 + 4 i.  A tail element sums its k in the order 16 g + j (lane group g of step j): rows >= 32 of a column
+// matrix differ from the 32 x 32 x 2 chain in the last bits.
+template <bool TAIL16>
 __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const ConvBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
     float *const dcol = smem;
@@ -98,15 +106,27 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
         asm volatile("s_barrier" ::: "memory");
     };
     // B operands of one job: column n = 32 ct + lane % 32 of dcol = row n of the weight matrix, k = 8 q + 4 hi + i of slab
-    // s -> float4 number 8 s + 2 q + hi of that row
-    const int rt = w & 1;                            // this wave's row tile
-    auto load_b = [&](const float *wmat, const int j, float4 (&bq)[8]) {
-        const float4 *row = reinterpret_cast<const float4 *>(wmat + (size_t)((j >> 1) * 32 + l31) * 64) + hi;
+    // s -> float4 number 8 s + 2 q + hi of that row.  A tail job (TAIL16, rt == 1): columns 32 ct + 16 h + lane % 16 for
+    // the two chains h, k = 16 g + 4 c + 0 .. 3 -> float4 number 4 g + c of the row, kept as bq[4 h + c].
+    const int rt = TAIL16 ? w >> 2 : w & 1;          // this wave's row tile
+    const int c0 = TAIL16 ? w & 3 : w >> 1;          // its column tiles: c0 + 4 i
+    const int l15 = lane & 15, g4 = lane >> 4;
+    auto load_b = [&](const float *wmat, const int ct, float4 (&bq)[8]) {
+        if (TAIL16 && rt) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 *row = reinterpret_cast<const float4 *>(wmat + (size_t)(ct * 32 + 16 * h + l15) * 64) + 4 * g4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bq[4 * h + c] = row[c];
+            }
+            return;
+        }
+        const float4 *row = reinterpret_cast<const float4 *>(wmat + (size_t)(ct * 32 + l31) * 64) + hi;
 #pragma unroll
         for (int c = 0; c < 8; ++c) bq[c] = row[2 * c];
     };
     float4 bq[2][8];
-    load_b(w3, w, bq[0]);                            // (job w: the first of this wave)
+    load_b(w3, c0, bq[0]);                           // (the first job of this wave)
 
     // the activations both gathers multiply by, requested now: this lane's items of gather 3 (2) and of gather 2 (4)
     float4 y2v[2], y1v[4];
@@ -134,12 +154,19 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
 
     // one product: dcol[np x 32 ncols] = dz (LDS, np x 64) wmat^T; bq[0] holds the B operands of this wave's first job;
     // next_w / next_first: where to prefetch from after the last job (the next product's first job), or null
-    auto product = [&](const float *dzs, const int np, const int ld, const float *wmat, const int njobs,
+    auto product = [&](const float *dzs, const int np, const int ld, const float *wmat, const int nct,
                        const float *next_w, const int stamp_i) {
         lds_barrier();                               // dzs is complete (and the previous gather's reads of dcol are done)
         if (stamp) stamp[stamp_i] = wall_clock64();
         float av[32];
-        {
+        if (TAIL16 && rt) {                          // rows 32 + lane % 16, k = 16 g + 0 .. 15
+            const float *ar = dzs + min(32 + l15, np - 1) * PZ + 16 * g4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 v = *reinterpret_cast<const float4 *>(ar + 4 * c);
+                av[4 * c] = v.x; av[4 * c + 1] = v.y; av[4 * c + 2] = v.z; av[4 * c + 3] = v.w;
+            }
+        } else {
             const float *ar = dzs + min(rt * 32 + l31, np - 1) * PZ + 4 * hi;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {            // float4 number 2 c + hi of the row: k = 8 c + 4 hi + 0 .. 3
@@ -147,31 +174,49 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
                 av[4 * c] = v.x; av[4 * c + 1] = v.y; av[4 * c + 2] = v.z; av[4 * c + 3] = v.w;
             }
         }
-        auto do_job = [&](auto cur, const int j) {
+        auto comp = [](const float4 &b4, const int i) { return i == 0 ? b4.x : i == 1 ? b4.y : i == 2 ? b4.z : b4.w; };
+        auto do_job = [&](auto cur, const int ct) {
             constexpr int c = decltype(cur)::value;
-            if (j + 8 < njobs) load_b(wmat, j + 8, bq[1 - c]);
-            else if (next_w) load_b(next_w, w, bq[1 - c]);
+            if (ct + 4 < nct) load_b(wmat, ct + 4, bq[1 - c]);
+            else if (next_w) load_b(next_w, c0, bq[1 - c]);
+            if (TAIL16 && rt) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], comp(bq[c][i >> 2], i & 3), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], comp(bq[c][4 + (i >> 2)], i & 3), acc1, 0, 0, 0);
+                }
+                float *dst = dcol + ct * 32 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 32 + 4 * g4 + r;
+                    if (row < np) {
+                        dst[row * ld] = acc0[r];
+                        dst[row * ld + 16] = acc1[r];
+                    }
+                }
+                return;
+            }
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const float4 b4 = bq[c][i >> 2];
-                const float b = (i & 3) == 0 ? b4.x : (i & 3) == 1 ? b4.y : (i & 3) == 2 ? b4.z : b4.w;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b, acc, 0, 0, 0);
-            }
-            float *dst = dcol + (j >> 1) * 32 + l31;
+            for (int i = 0; i < 32; ++i)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], comp(bq[c][i >> 2], i & 3), acc, 0, 0, 0);
+            float *dst = dcol + ct * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (row < np) dst[row * ld] = acc[r];
             }
         };
-        for (int j = w; j < njobs; j += 16) {
-            do_job(std::integral_constant<int, 0>(), j);
-            if (j + 8 < njobs) do_job(std::integral_constant<int, 1>(), j + 8);
+        int nj = 0;
+        for (int ct = c0; ct < nct; ct += 8) {
+            do_job(std::integral_constant<int, 0>(), ct);
+            ++nj;
+            if (ct + 4 < nct) { do_job(std::integral_constant<int, 1>(), ct + 4); ++nj; }
         }
-        if (next_w && (((njobs - w + 7) >> 3) & 1)) {   // an odd number of jobs: the prefetch for the next product went to set 1
+        if (next_w && (nj & 1)) {                    // an odd number of jobs: the prefetch for the next product went to set 1
 #pragma unroll
             for (int c = 0; c < 8; ++c) bq[0][c] = bq[1][c];
         }
@@ -180,7 +225,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
     };
 
     // ---- dcol3 = dz3 W3^T
-    product(dz3s, NP3, LD3, w3, 2 * (N3 / 32), w2, 1);
+    product(dz3s, NP3, LD3, w3, N3 / 32, w2, 1);
     // ---- dz2 = col2im(dcol3) * act'(y2): item = (position of dz2 rows [x20, x20 + 5), 4 channels)
     {
         float *const dz2 = a.dz2 + (size_t)t * a.dz2_ts + ((size_t)img * (O2 * O2) + (size_t)x20 * O2) * C2;
@@ -208,7 +253,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
         }
     }
     // ---- dcol2 = dz2 W2^T (its first barrier publishes dz2s and closes the gather's reads of dcol)
-    product(dz2s, NP2, LD2, w2, 2 * (N2 / 32), nullptr, 3);
+    product(dz2s, NP2, LD2, w2, N2 / 32, nullptr, 3);
     // ---- dz1 = col2im(dcol2) * act'(y1): item = (position of dz1 rows [x10, x10 + 10), 4 channels)
     {
         float *const dz1 = a.dz1 + (size_t)t * a.dz1_ts + ((size_t)img * (H1 * W1) + (size_t)x10 * W1) * C1;
@@ -238,6 +283,7 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
 }
 
 unsigned long long *g_stamps = nullptr;
+int g_tail16 = 0;           // rlx_conv32_tail_tiles
 
 }  // namespace
 
@@ -261,8 +307,14 @@ int rlx_conv32_input_grad(const float *dz3, long long dz3_tower_stride, const fl
                 "rlx_conv32_input_grad: operands must be 16-byte aligned");
     ConvBwdArgs a{dz3, dz3_tower_stride, w3, w3_tower_stride, y2, y2_tower_stride, dz2, dz2_tower_stride,
                   w2, w2_tower_stride, y1, y1_tower_stride, dz1, dz1_tower_stride, batch, towers, activation, g_stamps};
-    RLX_LAUNCH(conv32_input_grad_kernel, 2u * batch * towers, kThreads, 0, rlx::as_stream(stream), a);
+    if (g_tail16) RLX_LAUNCH(conv32_input_grad_kernel<true>, 2u * batch * towers, kThreads, 0, rlx::as_stream(stream), a);
+    else RLX_LAUNCH(conv32_input_grad_kernel<false>, 2u * batch * towers, kThreads, 0, rlx::as_stream(stream), a);
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_conv32_tail_tiles(int sixteen_rows) {
+    g_tail16 = sixteen_rows ? 1 : 0;
     return RLX_OK;
 }
 

@@ -96,3 +96,37 @@ def test_the_kernel_alone_against_gemm_and_col2im(rlx, dev):
             assert torch.equal(a, b), "%s %s: %d of %d elements differ, max %g" % (
                 act, name, int((a != b).sum()), a.numel(), float((a - b).abs().nan_to_num(1e9).max()))
         assert float(dz1.abs().max()) > 0
+
+
+def test_sixteen_row_tail_tiles_against_the_bit_identical_form(rlx, dev):
+    """rlx_conv32_tail_tiles(1): the second row tile of both products as a 16-row tile on v_mfma_f32_16x16x4_f32 (two
+    accumulator chains per wave).  Rows >= 32 of a column matrix sum their 64 k in another order: every gradient within a
+    few ulp of the result's scale of the default form, and the positions whose taps all come from rows < 32 bit-identical."""
+    import torch
+    from coach_amd import _rlx
+    B, T = 20, 2
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dz3, w3, w2 = rnd(T, B * 49, 64), rnd(T, 576, 64) * 0.1, rnd(T, 512, 64) * 0.1
+    y2, y1 = torch.tanh(rnd(T, B * 81, 64)), torch.tanh(rnd(T, B * 400, 32))
+    s = _rlx.current_stream()
+    code = _rlx.ACT["tanh"]
+    out = {}
+    try:
+        for tail in (0, 1):
+            rlx.conv32_tail_tiles(tail)
+            f2, f1 = torch.full_like(y2, float("nan")), torch.full_like(y1, float("nan"))
+            rlx.conv32_input_grad(dz3, B * 49 * 64, w3, 576 * 64, y2, B * 81 * 64, f2, B * 81 * 64, w2, 512 * 64,
+                                  y1, B * 400 * 32, f1, B * 400 * 32, B, T, code, s)
+            torch.cuda.synchronize()
+            out[tail] = (f2, f1)
+    finally:
+        rlx.conv32_tail_tiles(0)
+    for name, a, b in (("dz2", out[0][0], out[1][0]), ("dz1", out[0][1], out[1][1])):
+        assert not torch.isnan(b).any(), name
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 4e-6 * scale, (name, float((a - b).abs().max()), scale)
+        assert not torch.equal(a, b), name                      # (another order of sums somewhere: the variant did run)
+    # the first rows of the upper half image depend on full-tile rows only
+    a, b = out[0][1].view(T, B, 20, 20, 32), out[1][1].view(T, B, 20, 20, 32)
+    assert torch.equal(a[:, :, :2], b[:, :, :2])
