@@ -827,6 +827,8 @@ def main():
                     help="A/B: wave groups per K slab of the fused forward convolutions (0: the tiled launches' rule, 4: always four)")
     ap.add_argument("--conv32-tail16", type=int, default=None, choices=[0, 1],
                     help="A/B: 16-row tail tiles (v_mfma_f32_16x16x4_f32, two chains per wave) in the fused input-gradient chain")
+    ap.add_argument("--conv32-prefetch", type=int, default=None, choices=[1, 2],
+                    help="A/B: jobs ahead a wave of the fused input-gradient chain requests its weight operands")
     ap.add_argument("--split-cap", type=int, default=None, help="A/B: rlx_gemm_split_cap (most K chunks per product; default 64)")
     ap.add_argument("--heads-row-local", type=int, default=None, choices=[0, 1],
                     help="A/B: the row-local part of the discrete heads inside the last dense layer's reduction, the rest on the "
@@ -904,6 +906,9 @@ def main():
     if args.conv32_tail16 is not None:
         from coach_amd import _rlx as _R2
         _R2.lib().conv32_tail_tiles(int(args.conv32_tail16))
+    if args.conv32_prefetch is not None:
+        from coach_amd import _rlx as _R3
+        _R3.lib().conv32_prefetch(int(args.conv32_prefetch))
     if args.split_cap is not None:
         from coach_amd import _rlx as _R
         _R.lib().gemm_split_cap(int(args.split_cap))

@@ -82,7 +82,9 @@ __device__ __forceinline__ float act_deriv(float y, int kind) {      // gemm.hip
 // padded 32 x 32 tile.  Waves 0 .. 3 then take the full row tile, waves 4 .. 7 the tail (one of each per SIMD), column
 // tiles w % 4 + 4 i.  A tail element sums its k in the order 16 g + j (lane group g of step j): rows >= 32 of a column
 // matrix differ from the 32 x 32 x 2 chain in the last bits.
-template <bool TAIL16>
+// PF: how many jobs ahead a wave requests its B operands (PF + 1 register sets of 8 float4 in a ring): 1 = the original; a
+// tail job is half as long as a full one, so one job ahead no longer covers the load (rlx_conv32_prefetch).
+template <bool TAIL16, int PF>
 __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const ConvBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
     float *const dcol = smem;
@@ -125,8 +127,10 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
 #pragma unroll
         for (int c = 0; c < 8; ++c) bq[c] = row[2 * c];
     };
-    float4 bq[2][8];
-    load_b(w3, c0, bq[0]);                           // (the first job of this wave)
+    constexpr int kSets = PF + 1;
+    float4 bq[kSets][8];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_b(w3, c0 + 4 * p, bq[p]);      // (the first PF jobs of this wave: 18 column tiles >= c0 + 4 PF)
 
     // the activations both gathers multiply by, requested now: this lane's items of gather 3 (2) and of gather 2 (4)
     float4 y2v[2], y1v[4];
@@ -175,10 +179,25 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
             }
         }
         auto comp = [](const float4 &b4, const int i) { return i == 0 ? b4.x : i == 1 ? b4.y : i == 2 ? b4.z : b4.w; };
-        auto do_job = [&](auto cur, const int ct) {
+        const int nj = (nct - c0 + 3) >> 2;          // jobs of this wave in this product
+        auto do_job = [&](auto cur, const int ct, const int idx) {
             constexpr int c = decltype(cur)::value;
-            if (ct + 4 < nct) load_b(wmat, ct + 4, bq[1 - c]);
-            else if (next_w) load_b(next_w, c0, bq[1 - c]);
+            constexpr int cn = (c + PF) % kSets;     // the set job idx + PF goes to
+            if constexpr (TAIL16) {
+                // ALWAYS issued (past the last job of the last product: the current rows once more, never used).  With the
+                // request under a branch the compiler's s_waitcnt insertion has to assume it may not have been issued and
+                // waits for all but the newest two loads by the end of a job (vmcnt(9) .. vmcnt(2) in front of the eight MFMA
+                // groups): the prefetch then hides under a quarter of a job instead of a whole one and a K loop takes MFMA
+                // time PLUS load time — measured by taking either out: 11.4 = 8.3 + 5.2 - 2 us (profiles/r06_conv32_tail16.txt).
+                // Unconditional: vmcnt(16) .. vmcnt(10), the loads have a whole job to land.
+                const bool here = idx + PF < nj;
+                const float *const src = here || !next_w ? wmat : next_w;
+                const int sct = here ? ct + 4 * PF : (next_w ? c0 + 4 * (idx + PF - nj) : ct);
+                load_b(src, sct, bq[cn]);
+            } else {                                 // (the bit-identical form as it was measured in rounds 5 / 6)
+                if (idx + PF < nj) load_b(wmat, ct + 4 * PF, bq[cn]);
+                else if (next_w) load_b(next_w, c0 + 4 * (idx + PF - nj), bq[cn]);
+            }
             if (TAIL16 && rt) {
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -210,15 +229,33 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
                 if (row < np) dst[row * ld] = acc[r];
             }
         };
-        int nj = 0;
-        for (int ct = c0; ct < nct; ct += 8) {
-            do_job(std::integral_constant<int, 0>(), ct);
-            ++nj;
-            if (ct + 4 < nct) { do_job(std::integral_constant<int, 1>(), ct + 4); ++nj; }
+        // the wave's jobs in turn through the register sets 0, 1 (, 2), ...: job idx in set idx % kSets (compile-time indices)
+        for (int idx = 0, ct = c0; ct < nct;) {
+            do_job(std::integral_constant<int, 0>(), ct, idx);
+            ct += 4; ++idx;
+            if (ct >= nct) break;
+            do_job(std::integral_constant<int, 1>(), ct, idx);
+            ct += 4; ++idx;
+            if constexpr (kSets > 2) {
+                if (ct >= nct) break;
+                do_job(std::integral_constant<int, kSets - 1>(), ct, idx);
+                ct += 4; ++idx;
+            }
         }
-        if (next_w && (nj & 1)) {                    // an odd number of jobs: the prefetch for the next product went to set 1
+        if (next_w) {                                // the next product's first PF jobs sit in sets nj % kSets, ...: to 0, 1
+            const int r = nj % kSets;
+            if (kSets == 2 && r == 1) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) bq[0][c] = bq[1][c];
+                for (int c = 0; c < 8; ++c) bq[0][c] = bq[1][c];
+            }
+            if (kSets == 3 && r == 1) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { bq[0][c] = bq[1][c]; bq[1][c] = bq[kSets - 1][c]; }
+            }
+            if (kSets == 3 && r == 2) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { const float4 t = bq[0][c]; bq[0][c] = bq[kSets - 1][c]; bq[1][c] = t; }
+            }
         }
         if (stamp) stamp[stamp_i + 1] = wall_clock64();
         lds_barrier();                               // dcol complete
@@ -283,7 +320,8 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
 }
 
 unsigned long long *g_stamps = nullptr;
-int g_tail16 = 0;           // rlx_conv32_tail_tiles
+int g_tail16 = 1;           // rlx_conv32_tail_tiles
+int g_prefetch = 1;         // rlx_conv32_prefetch
 
 }  // namespace
 
@@ -307,14 +345,24 @@ int rlx_conv32_input_grad(const float *dz3, long long dz3_tower_stride, const fl
                 "rlx_conv32_input_grad: operands must be 16-byte aligned");
     ConvBwdArgs a{dz3, dz3_tower_stride, w3, w3_tower_stride, y2, y2_tower_stride, dz2, dz2_tower_stride,
                   w2, w2_tower_stride, y1, y1_tower_stride, dz1, dz1_tower_stride, batch, towers, activation, g_stamps};
-    if (g_tail16) RLX_LAUNCH(conv32_input_grad_kernel<true>, 2u * batch * towers, kThreads, 0, rlx::as_stream(stream), a);
-    else RLX_LAUNCH(conv32_input_grad_kernel<false>, 2u * batch * towers, kThreads, 0, rlx::as_stream(stream), a);
+    const unsigned grid = 2u * batch * towers;
+    hipStream_t s = rlx::as_stream(stream);
+    if (g_tail16 && g_prefetch == 2) RLX_LAUNCH((conv32_input_grad_kernel<true, 2>), grid, kThreads, 0, s, a);
+    else if (g_tail16) RLX_LAUNCH((conv32_input_grad_kernel<true, 1>), grid, kThreads, 0, s, a);
+    else if (g_prefetch == 2) RLX_LAUNCH((conv32_input_grad_kernel<false, 2>), grid, kThreads, 0, s, a);
+    else RLX_LAUNCH((conv32_input_grad_kernel<false, 1>), grid, kThreads, 0, s, a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
 
 int rlx_conv32_tail_tiles(int sixteen_rows) {
     g_tail16 = sixteen_rows ? 1 : 0;
+    return RLX_OK;
+}
+
+int rlx_conv32_prefetch(int jobs_ahead) {
+    RLX_REQUIRE(jobs_ahead == 1 || jobs_ahead == 2, "rlx_conv32_prefetch: 1 or 2 jobs ahead");
+    g_prefetch = jobs_ahead;
     return RLX_OK;
 }
 

@@ -123,10 +123,14 @@ int rlx_conv32_input_grad(const float *dz3, long long dz3_tower_stride, const fl
 /* diagnostics as rlx_conv23_debug_stamps: [8 w + 0 .. 5] = entry, first product's operands staged, its K loop done,
  * second product's operands staged (= first gather done), its K loop done, exit */
 int rlx_conv32_debug_stamps(void *buffer);
-/* Process-wide (default 0): 1 = the second row tile of both products (3 of 35, 13 of 45 positions) runs as a 16-row tile
+/* Process-wide (default 1): 1 = the second row tile of both products (3 of 35, 13 of 45 positions) runs as a 16-row tile
  * on v_mfma_f32_16x16x4_f32 with two accumulator chains per wave — half the MFMA cycles of the padded 32-row tile; rows
- * >= 32 of a column matrix then sum k in another order (last bits; 0 = bit-identical to rlx_gemm + rlx_col2im). */
+ * >= 32 of a column matrix then sum k in another order (last bits: -3 us per Clipped-PPO update, profiles/r06_conv32_tail16.txt); 0 = 32-row tiles throughout, bit-identical to
+ * rlx_gemm + rlx_col2im. */
 int rlx_conv32_tail_tiles(int sixteen_rows);
+/* how many jobs ahead a wave of that launch requests its weight operands: 1 (default) or 2 (one more register set; results
+ * unchanged) */
+int rlx_conv32_prefetch(int jobs_ahead);
 
 /* --------------------------------------------- prioritized replay (K5 / K6) -- */
 /* Trees are fp64 array-heaps of 2*capacity-1 nodes exactly as the reference's

@@ -3,15 +3,18 @@ coach_amd/csrc/conv_bwd_fused.hip: both column matrices stay in LDS) against wha
 inside the dW + dcol pair launch and rlx_col2im (tf.gradients through tf.layers.conv2d,
 architectures/tensorflow_components/layers.py:108-121, architecture.py:312-385).
 
-Every dcol element is the same fp32 MFMA chain over K = 64 and the gathers add the taps in col2im's order, so every
-gradient of a Clipped-PPO minibatch update — and every weight after the Adam step — must be BIT-IDENTICAL."""
+With 32-row tiles throughout (rlx_conv32_tail_tiles(0)) every dcol element is the same fp32 MFMA chain over K = 64 and the
+gathers add the taps in col2im's order, so every gradient of a Clipped-PPO minibatch update — and every weight after the
+Adam step — must be BIT-IDENTICAL.  The default (16-row tail tiles on v_mfma_f32_16x16x4_f32) sums the k of the tail rows in
+another order: held to a few ulp of each gradient tensor's scale here, and to tests/tolerances.py against the oracle in
+tests/test_ppo_full_size.py."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def _update(dev, B, A, act, fused, steps=2):
+def _update(dev, B, A, act, fused, steps=2, tail16=0):
     import torch
     from coach_amd import _rlx
     from coach_amd.nn import graph as G
@@ -24,6 +27,7 @@ def _update(dev, B, A, act, fused, steps=2):
     vt = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
     saved_fuse, G.FUSE_CONV_INPUT_GRADS = G.FUSE_CONV_INPUT_GRADS, fused
     saved_dw, G.CONV_DW_F32 = G.CONV_DW_F32, False           # (the weight gradients through rlx_gemm on both sides: another
+    _rlx.lib().conv32_tail_tiles(tail16)
     try:                                                     # order of their sums is tests/test_conv_dw_f32.py's subject)
         np.random.seed(1)
         net = ClippedPPONet(dev, shape, A, seed=2, activation=act)
@@ -41,6 +45,7 @@ def _update(dev, B, A, act, fused, steps=2):
     finally:
         G.FUSE_CONV_INPUT_GRADS = saved_fuse
         G.CONV_DW_F32 = saved_dw
+        _rlx.lib().conv32_tail_tiles(1)                      # (the library's default)
 
 
 @pytest.mark.parametrize("B", [64, 72, 63])
@@ -56,6 +61,21 @@ def test_fused_input_gradient_chain_is_bit_identical_in_a_ppo_update(rlx, dev, B
         int((g0 != g1).sum()), g0.numel(), float((g0 - g1).abs().max()))
     assert torch.equal(ref[1], new[1]) and torch.equal(ref[2], new[2])
     assert float(g0.abs().max()) > 0
+
+
+def test_default_tail_tiles_in_a_ppo_update(rlx, dev):
+    """the default form (16-row tail tiles) against the per-layer launches: every gradient tensor within 1e-5 of its scale,
+    the weights after two Adam steps within tests/tolerances.py."""
+    import torch
+    from tolerances import WEIGHTS
+    ref = _update(dev, 64, 6, "tanh", False)
+    new = _update(dev, 64, 6, "tanh", True, tail16=1)
+    assert any("conv32_input_grad_kernel<true" in n for n in new[3]), new[3]
+    g0, g1 = ref[0], new[0]
+    assert not torch.equal(g0, g1)
+    assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max())
+    np.testing.assert_allclose(new[1].cpu().numpy(), ref[1].cpu().numpy(), **WEIGHTS)
+    np.testing.assert_allclose(new[2][:5].cpu().numpy(), ref[2][:5].cpu().numpy(), rtol=1e-6, atol=1e-7)
 
 
 def test_small_batches_keep_the_per_layer_launches(rlx, dev):
@@ -76,7 +96,8 @@ def test_the_kernel_alone_against_gemm_and_col2im(rlx, dev):
     lib, s = rlx, _rlx.current_stream()
     ws = torch.empty(1 << 22, device=dev)
     outs = {}
-    for act, code in (("relu", _rlx.ACT["relu"]), ("tanh", _rlx.ACT["tanh"])):
+    lib.conv32_tail_tiles(0)                 # (32-row tiles throughout: the bit-identical form; the default is restored by
+    for act, code in (("relu", _rlx.ACT["relu"]), ("tanh", _rlx.ACT["tanh"])):   # the test of the tail tiles below)
         yy2, yy1 = (y2, y1) if act == "relu" else (torch.tanh(y2 - 0.5), torch.tanh(y1 - 0.5))
         dcol3 = torch.empty(T, B * 49, 576, device=dev)
         _rlx.gemm(B * 49, 576, 64, dz3, w3, dcol3, b_strides=(1, 64), batch=T, a_batch_stride=B * 49 * 64,
@@ -96,6 +117,7 @@ def test_the_kernel_alone_against_gemm_and_col2im(rlx, dev):
             assert torch.equal(a, b), "%s %s: %d of %d elements differ, max %g" % (
                 act, name, int((a != b).sum()), a.numel(), float((a - b).abs().nan_to_num(1e9).max()))
         assert float(dz1.abs().max()) > 0
+    lib.conv32_tail_tiles(1)
 
 
 def test_sixteen_row_tail_tiles_against_the_bit_identical_form(rlx, dev):
@@ -114,14 +136,20 @@ def test_sixteen_row_tail_tiles_against_the_bit_identical_form(rlx, dev):
     out = {}
     try:
         for tail in (0, 1):
-            rlx.conv32_tail_tiles(tail)
-            f2, f1 = torch.full_like(y2, float("nan")), torch.full_like(y1, float("nan"))
-            rlx.conv32_input_grad(dz3, B * 49 * 64, w3, 576 * 64, y2, B * 81 * 64, f2, B * 81 * 64, w2, 512 * 64,
-                                  y1, B * 400 * 32, f1, B * 400 * 32, B, T, code, s)
-            torch.cuda.synchronize()
-            out[tail] = (f2, f1)
+            for ahead in (1, 2):             # (operands requested one or two jobs ahead: the same sums)
+                rlx.conv32_tail_tiles(tail)
+                rlx.conv32_prefetch(ahead)
+                f2, f1 = torch.full_like(y2, float("nan")), torch.full_like(y1, float("nan"))
+                rlx.conv32_input_grad(dz3, B * 49 * 64, w3, 576 * 64, y2, B * 81 * 64, f2, B * 81 * 64, w2, 512 * 64,
+                                      y1, B * 400 * 32, f1, B * 400 * 32, B, T, code, s)
+                torch.cuda.synchronize()
+                if ahead == 1:
+                    out[tail] = (f2, f1)
+                else:
+                    assert torch.equal(f2, out[tail][0]) and torch.equal(f1, out[tail][1]), (tail, ahead)
     finally:
-        rlx.conv32_tail_tiles(0)
+        rlx.conv32_tail_tiles(1)             # (the library's defaults)
+        rlx.conv32_prefetch(1)
     for name, a, b in (("dz2", out[0][0], out[1][0]), ("dz1", out[0][1], out[1][1])):
         assert not torch.isnan(b).any(), name
         scale = float(a.abs().max())

@@ -2,7 +2,7 @@
 Clipped-PPO minibatch update (C2 shapes): rlx_conv32_debug_stamps makes every workgroup record 10 ns ticks at entry, once the
 first product's operands are staged, after its K loop, once the second product's operands are staged (= the first gather is
 done), after its K loop, and at exit.  Eager updates; the stamps of the last one are read.
-Usage: python tools/conv32_timeline.py"""
+Usage: python tools/conv32_timeline.py [--tail16]      (--tail16: rlx_conv32_tail_tiles(1))"""
 import os
 import sys
 
@@ -17,6 +17,10 @@ from coach_amd.nn import graph as _G
 
 _G.FUSE_CONV_INPUT_GRADS = True          # (off by default: profiles/r05_ab_conv32.txt)
 lib = _rlx.lib()
+if "--tail16" in sys.argv:
+    lib.conv32_tail_tiles(1)
+if "--ahead2" in sys.argv:
+    lib.conv32_prefetch(2)
 dev = torch.device("cuda:0")
 B, A, shape = 64, 6, (84, 84, 4)
 np.random.seed(0)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# round 6, call 26 (prefetch requests unconditional): fused input-gradient chain — 16-row tail tiles x operands requested one / two jobs ahead
+set -u
+O=gpurun_out/r06_call26
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_conv_bwd_fused.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | grep -v "amdgpu.ids" | tail -15 | tee $O/pytest.txt
+run() { # name, flags
+  timeout 500 python bench.py --no-cpu-baseline $2 > $O/bench_$1.json 2> $O/bench_$1.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open('$O/bench_$1.json').read().strip().splitlines()[-1])
+    r=d['roofline']
+    print('%-12s' % '$1', d['value'], d['ms_per_step'], 'frac', r['frac'], 'gemm_us', r['gemm_us_per_update'], 'update_us', r.get('update_us_in_epoch_graph'), 'conv', d['box'].get('fused_conv_forward_in_update_us'), 'launches', r.get('kernel_launches_per_update'))
+    print('     ', '  '.join('%s %.1f' % (k['kernel'][:28], k['avg_us']) for k in r['update_kernels']))
+except Exception as e:
+    print('$1', 'ERR', e); print(open('$O/bench_$1.err').read()[-1500:])
+PY
+}
+run base "--steps 10 --warmup 3"
+run t16a2 "--steps 10 --warmup 3 --conv32-tail16 1 --conv32-prefetch 2"
+run t0a2 "--steps 10 --warmup 3 --conv32-prefetch 2"
+run t16a1 "--steps 10 --warmup 3 --conv32-tail16 1"
+run t16a2b "--steps 10 --warmup 3 --conv32-tail16 1 --conv32-prefetch 2"
+python tools/conv32_timeline.py --tail16 --ahead2 2>&1 | grep -v amdgpu.ids | tail -14 | tee $O/timeline.txt
