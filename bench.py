@@ -829,6 +829,8 @@ def main():
                     help="A/B: 16-row tail tiles (v_mfma_f32_16x16x4_f32, two chains per wave) in the fused input-gradient chain")
     ap.add_argument("--conv32-prefetch", type=int, default=None, choices=[1, 2],
                     help="A/B: jobs ahead a wave of the fused input-gradient chain requests its weight operands")
+    ap.add_argument("--conv-dw-passes", type=int, default=None, choices=[1, 2, 4],
+                    help="A/B: the one-launch convolution weight gradients with operands staged in one / two passes")
     ap.add_argument("--split-cap", type=int, default=None, help="A/B: rlx_gemm_split_cap (most K chunks per product; default 64)")
     ap.add_argument("--heads-row-local", type=int, default=None, choices=[0, 1],
                     help="A/B: the row-local part of the discrete heads inside the last dense layer's reduction, the rest on the "
@@ -909,6 +911,9 @@ def main():
     if args.conv32_prefetch is not None:
         from coach_amd import _rlx as _R3
         _R3.lib().conv32_prefetch(int(args.conv32_prefetch))
+    if args.conv_dw_passes is not None:
+        from coach_amd import _rlx as _R4
+        _R4.lib().conv_dw_passes(int(args.conv_dw_passes))
     if args.split_cap is not None:
         from coach_amd import _rlx as _R
         _R.lib().gemm_split_cap(int(args.split_cap))

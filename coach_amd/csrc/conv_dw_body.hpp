@@ -175,6 +175,135 @@ __device__ __forceinline__ void conv_dw_u8_body(const DwU8 &a, const int bid, fl
     RLX_DWU8_STAMP(4);
 }
 
+
+// The same product in NP PASSES over the image's output rows (Atari geometry only: OH = OW = 20, rowf = 336): LDS holds the
+// frame rows and the dz of 20 / NP output rows at a time — 79 KB (NP = 2) or 40 KB (NP = 4) instead of 157 KB, so that two /
+// three workgroups share a CU and one workgroup's fills (its binding resource: ~30 GB/s per CU, 129 KB per workgroup) run
+// under the others' products.  The frame bytes of all passes are requested at entry (registers); a pass's dz is requested
+// when the previous pass's products are done.  Same sums: a wave's accumulators run through the positions in the same
+// order, and the bias gradient's four chains per column (positions g + 16 k + {0, 4, 8, 12}) take the same positions in the
+// same order, pass by pass.
+template <int NP>
+__device__ __forceinline__ void conv_dw_u8_body_passes(const DwU8 &a, const int bid, float *smem) {
+    constexpr int OWT = 20, SCT = 16, ROWD = 84, kRows = 20 / NP, kPP = kRows * OWT;  // positions per pass
+    constexpr int kRowF = 4 * ROWD;                                                    // 336
+    static_assert(NP == 2 || NP == 4, "conv_dw_u8_body_passes: 2 or 4 passes");
+    float *lut = smem;                                   // [256]; later the column-sum scratch
+    float *xf = lut + 256;                               // [kRows][2][rowf]
+    float *dzl = xf + kRows * 2 * kRowF;                 // [kPP][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = bid & 7, rest = bid >> 3;
+    const int q = rest % a.NQ, b = (rest / a.NQ) * 8 + xcd;
+    if (b >= a.B) return;
+    RLX_DWU8_STAMP(0);
+    lut[tid] = (float)tid / a.a_div;
+    constexpr int kF = 14, kND = 2 * 20 * ROWD, kNDP = kND / NP;                     // 3360 dwords, per pass 1680 / 840
+    const unsigned char *img = a.x + (size_t)b * a.H * kRowF;
+    unsigned fb[kF];
+#pragma unroll
+    for (int j = 0; j < kF; ++j) {
+        const int idx = min(tid + j * kThreads, kND - 1), r = idx / ROWD, d = idx - r * ROWD;
+        const int src_row = a.S * (r >> 1) + 2 * q + (r & 1);
+        fb[j] = *reinterpret_cast<const unsigned *>(img + (size_t)src_row * kRowF + 4 * d);
+    }
+    const unsigned dz_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(dzl));
+    const int pos_l = lane >> 4, n4 = (lane & 15) * 4, tw = n4 / a.Co, ch = n4 - tw * a.Co;
+    const float *src0 = a.dz + (size_t)tw * a.dz_ts + ((size_t)b * a.P + pos_l) * a.Co + ch;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto request_dz = [&](const int pass) {              // kPP / 4 blocks of 1 KB: 4 positions x 64 channels each
+        for (int blk = wave_u; blk < kPP / 4; blk += kThreads / 64)
+            dma16(src0 + (size_t)(pass * (kPP / 4) + blk) * 4 * a.Co, __builtin_amdgcn_readfirstlane(dz_base + (unsigned)blk * 1024u));
+    };
+    auto convert = [&](const int pass) {                 // this pass's frame rows: dwords [pass * kNDP, (pass + 1) * kNDP)
+#pragma unroll
+        for (int j = 0; j < kF; ++j) {
+            const int idx = tid + j * kThreads - pass * kNDP;
+            if (idx >= 0 && idx < kNDP) {
+                const unsigned w = fb[j];
+                const f32x4 v = {lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]};
+                *reinterpret_cast<f32x4 *>(xf + 4 * idx) = v;
+            }
+        }
+    };
+    const int mh = wave & 1, nh = wave >> 1, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc1[i] = 0.f;
+    const float *const ap = xf + mh * kRowF + l31;
+    const float *const bp = dzl + nh * 32 + l31;
+    constexpr int row2 = 2 * kRowF, kS = OWT / 2;
+    float av[2][kS], bv[2][kS];
+    const int cn = tid & 63, cg = tid >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // the bias gradient's chains of column cn, group cg (q == 0)
+    auto rows = [&]() {
+        const float *ar = ap + hi * SCT, *br = bp + hi * kN;
+#define RLX_DWU8_READ(buf)                                                  \
+    _Pragma("unroll") for (int u = 0; u < kS; ++u) {                        \
+        av[buf][u] = ar[2 * SCT * u];                                       \
+        bv[buf][u] = br[2 * kN * u];                                        \
+    }                                                                       \
+    ar += row2; br += OWT * kN;
+#define RLX_DWU8_MATH(buf)                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < kS; u += 2) {                                                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u], bv[buf][u], acc, 0, 0, 0);                        \
+        if (u + 1 < kS) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u + 1], bv[buf][u + 1], acc1, 0, 0, 0); \
+    }
+        RLX_DWU8_READ(0)
+        for (int py = 0; py < kRows; py += 2) {
+            if (py + 1 < kRows) { RLX_DWU8_READ(1) }
+            RLX_DWU8_MATH(0)
+            if (py + 1 < kRows) {
+                if (py + 2 < kRows) { RLX_DWU8_READ(0) }
+                RLX_DWU8_MATH(1)
+            }
+        }
+#undef RLX_DWU8_READ
+#undef RLX_DWU8_MATH
+    };
+    auto column_sums = [&](const int pass) {             // positions [pass * kPP, (pass + 1) * kPP) of this thread's group:
+        const int first = pass * kPP;                    // global position cg + 4 i belongs to chain i % 4
+        for (int pos = cg + ((first - cg + 3) & ~3); pos < first + kPP; pos += 4) {
+            const float v = dzl[(pos - first) * kN + cn];
+            const int chain = ((pos - cg) >> 2) & 3;
+            s0 += chain == 0 ? v : 0.f;
+            s1 += chain == 1 ? v : 0.f;
+            s2 += chain == 2 ? v : 0.f;
+            s3 += chain == 3 ? v : 0.f;
+        }
+    };
+    request_dz(0);
+    __syncthreads();                                     // the table
+    RLX_DWU8_STAMP(1);
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        if (pass > 0) {
+            __syncthreads();                             // the previous pass's operands are no longer read
+            request_dz(pass);
+        }
+        convert(pass);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (pass == 0) { RLX_DWU8_STAMP(2); }
+        rows();
+        if (q == 0) column_sums(pass);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
+    RLX_DWU8_STAMP(3);
+    float *out = a.part + ((size_t)b * a.K + q * 64 + mh * 32) * kN + nh * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * kN] = acc[r];
+    if (q == 0) {
+        __syncthreads();                                 // (the table's words: every wave has converted its last pass)
+        lut[cg * 64 + cn] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (tid < 64) a.cpart[(size_t)b * kN + tid] = ((lut[tid] + lut[64 + tid]) + lut[128 + tid]) + lut[192 + tid];
+    }
+    RLX_DWU8_STAMP(4);
+}
+template <int NP>
+constexpr size_t lds_u8_passes() { return sizeof(float) * (size_t)(256 + (20 / NP) * 2 * 336 + (20 / NP) * 20 * kN); }
+
 struct GeometryU8 {
     int OH, OW, K, P, rowf, NQ;
     size_t lds;
@@ -311,6 +440,118 @@ __device__ __forceinline__ void conv_dw_f32_body(const DwF32 &a, const int bid, 
         if (tid < 64) a.cpart[((size_t)t * a.splits + g) * kN + tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
     }
     RLX_DWF_STAMP(3);
+}
+
+
+// conv_dw_f32_body in TWO PASSES over the output rows ([0, R0) and [R0, OH)): the pair's input rows and dz of one pass at a
+// time in LDS (conv2 of the Atari torso: 50 KB instead of 88 KB), for the same reason as conv_dw_u8_body_two_pass.  The
+// accumulators run through the positions in the same order; the bias gradient's column sums are taken pass by pass
+// (another grouping of that sum than the one-pass body's).
+template <int C, int KW, int S, int W, int OW, int R0>
+__device__ __forceinline__ void conv_dw_f32_body_two_pass(const DwF32 &a, const int bid, float *smem) {
+    constexpr int kRowF = W * C;
+    constexpr int kMT = KW * C;
+    constexpr int kSub = kMT / 32 * 2 / 4;
+    static_assert(kMT % 64 == 0 && (OW - 1) * S + KW <= W, "conv_dw_f32: geometry");
+    const int OH = a.OH, P = OH * OW;
+    constexpr int xf_floats = (2 * R0 * kRowF + 255) & ~255, dz_floats = (2 * R0 * OW * kN + 255) & ~255;
+    float *xf = smem;                                     // [2 images][rows of the pass][kRowF]
+    float *dzl = xf + xf_floats;                          // [2 images][positions of the pass][64]
+    float *red = dzl + dz_floats;                         // [256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = bid & 7, rest = bid >> 3;
+    const int ky = rest % a.KH, pt = (rest / a.KH) * 8 + xcd;
+    if (pt >= a.units) return;
+    const int t = pt / a.splits, g = pt - t * a.splits;
+    const int img0 = 2 * g, n_img = min(2, a.B - img0);
+    RLX_DWF_STAMP(0);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned xf_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(xf));
+    const unsigned dz_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(dzl));
+    const float *xsrc = a.x + (size_t)t * a.x_ts;
+    const float *dsrc = a.dz + (size_t)t * a.dz_ts;
+    auto stage = [&](const int r0, const int nr) {        // output rows [r0, r0 + nr)
+        const int per_img = nr * kRowF, per_dz = nr * OW * kN;
+        for (int blk = wave_u; blk * 256 < 2 * per_img; blk += kThreads / 64) {
+            const int f = min(blk * 256 + lane * 4, 2 * per_img - 4);
+            const int im = f / per_img, q0 = f - im * per_img, py = q0 / kRowF, col = q0 - py * kRowF;
+            const int img = img0 + min(im, n_img - 1);
+            dma16(xsrc + ((size_t)img * a.H + (S * (r0 + py) + ky)) * kRowF + col,
+                  __builtin_amdgcn_readfirstlane(xf_base + (unsigned)blk * 1024u));
+        }
+        for (int blk = wave_u; blk * 256 < 2 * per_dz; blk += kThreads / 64) {
+            const int f = min(blk * 256 + lane * 4, 2 * per_dz - 4);
+            const int im = f / per_dz, off = f - im * per_dz;
+            const int img = img0 + min(im, n_img - 1);
+            dma16(dsrc + ((size_t)img * P + (size_t)r0 * OW) * kN + off,
+                  __builtin_amdgcn_readfirstlane(dz_base + (unsigned)blk * 1024u));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (n_img < 2) {                                  // the second image of the last pair of an odd batch: no contribution
+            for (int e = tid; e < per_dz; e += kThreads) dzl[per_dz + e] = 0.f;
+            __syncthreads();
+        }
+    };
+    const int nh = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[kSub];
+#pragma unroll
+    for (int j = 0; j < kSub; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    float av[2][OW][kSub], bv[2][OW];
+    const int cn = tid & 63, cq = tid >> 6;
+    float csum = 0.f;
+    auto rows = [&](const int nr) {
+        const float *ar = xf + hi * nr * kRowF + 32 * (wave >> 1) + l31;
+        const float *br = dzl + hi * nr * OW * kN + nh * 32 + l31;
+#define RLX_DWF_READ(buf)                                                          \
+    _Pragma("unroll") for (int u = 0; u < OW; ++u) {                               \
+        _Pragma("unroll") for (int j = 0; j < kSub; ++j) av[buf][u][j] = ar[S * C * u + 64 * j]; \
+        bv[buf][u] = br[kN * u];                                                   \
+    }                                                                              \
+    ar += kRowF; br += OW * kN;
+#define RLX_DWF_MATH(buf)                                                          \
+    _Pragma("unroll") for (int u = 0; u < OW; ++u)                                 \
+        _Pragma("unroll") for (int j = 0; j < kSub; ++j)                           \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][j], bv[buf][u], acc[j], 0, 0, 0);
+        RLX_DWF_READ(0)
+        for (int py = 0; py < nr; py += 2) {
+            if (py + 1 < nr) { RLX_DWF_READ(1) }
+            RLX_DWF_MATH(0)
+            if (py + 1 < nr) {
+                if (py + 2 < nr) { RLX_DWF_READ(0) }
+                RLX_DWF_MATH(1)
+            }
+        }
+#undef RLX_DWF_READ
+#undef RLX_DWF_MATH
+        if (ky == 0 && a.cpart)                           // bias gradient: this thread's share of column cn over the pass
+            for (int pos = cq; pos < 2 * nr * OW; pos += 4) csum += dzl[pos * kN + cn];
+    };
+    stage(0, R0);
+    RLX_DWF_STAMP(1);
+    rows(R0);
+    __syncthreads();                                      // pass 0's operands are no longer read
+    stage(R0, OH - R0);
+    rows(OH - R0);
+    RLX_DWF_STAMP(2);
+    const int K = a.KH * kMT;
+    float *out = a.part + (((size_t)t * a.splits + g) * K + (size_t)ky * kMT + 32 * (wave >> 1)) * kN + nh * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < kSub; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(size_t)(64 * j + (r & 3) + 8 * (r >> 2) + 4 * hi) * kN] = acc[j][r];
+    if (ky == 0 && a.cpart) {
+        red[cq * 64 + cn] = csum;
+        __syncthreads();
+        if (tid < 64) a.cpart[((size_t)t * a.splits + g) * kN + tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    }
+    RLX_DWF_STAMP(3);
+}
+template <int C, int W, int OW, int R0>
+constexpr size_t lds_f32_two_pass() {
+    return sizeof(float) * (size_t)(((2 * R0 * W * C + 255) & ~255) + ((2 * R0 * OW * kN + 255) & ~255) + 256);
 }
 
 struct GeometryF32 {

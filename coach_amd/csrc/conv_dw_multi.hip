@@ -19,24 +19,38 @@ struct MultiArgs {
     int nb_u8, nb_f[2], kind[2];
 };
 
+// PASSES > 1: the bodies take their operands in passes over the output rows (conv_dw_u8_body_passes,
+// conv_dw_f32_body_two_pass) so that several workgroups share a CU — one's fills under the others' products (every
+// workgroup of the launch is allocated the largest body's LDS: at 157 KB even the 59 KB conv3 workgroups ran one per CU).
+//   2: conv1 in two passes (79 KB), conv2 in two (50 KB), conv3 in one (59 KB)      -> two workgroups per CU
+//   4: conv1 in four passes (40 KB), conv2 in two (50 KB), conv3 in two (34 KB)     -> three workgroups per CU
+template <int PASSES>
 __global__ void __launch_bounds__(kThreads) conv_dw_multi_kernel(const MultiArgs m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
     if (bid < m.nb_u8) {
-        conv_dw_u8_body<20, 16, 84>(m.u8, bid, smem);
+        if constexpr (PASSES > 1) conv_dw_u8_body_passes<PASSES>(m.u8, bid, smem);
+        else conv_dw_u8_body<20, 16, 84>(m.u8, bid, smem);
         return;
     }
     bid -= m.nb_u8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (bid < m.nb_f[i]) {
-            if (m.kind[i] == 1) conv_dw_f32_body<64, 3, 1, 9, 7>(m.f[i], bid, smem);
-            else conv_dw_f32_body<32, 4, 2, 20, 9>(m.f[i], bid, smem);
+            if (m.kind[i] == 1) {
+                if constexpr (PASSES == 4) conv_dw_f32_body_two_pass<64, 3, 1, 9, 7, 4>(m.f[i], bid, smem);
+                else conv_dw_f32_body<64, 3, 1, 9, 7>(m.f[i], bid, smem);
+            } else {
+                if constexpr (PASSES > 1) conv_dw_f32_body_two_pass<32, 4, 2, 20, 9, 5>(m.f[i], bid, smem);
+                else conv_dw_f32_body<32, 4, 2, 20, 9>(m.f[i], bid, smem);
+            }
             return;
         }
         bid -= m.nb_f[i];
     }
 }
+
+int g_passes = 2;          // rlx_conv_dw_passes
 
 }  // namespace
 
@@ -127,12 +141,36 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items, rlx_splitk_job *jobs, int n
     }
     static bool configured = false;
     if (!configured) {
-        RLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_dw_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
+        RLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_dw_multi_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_dw_multi_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_dw_multi_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    RLX_LAUNCH((conv_dw_multi_kernel), m.nb_u8 + m.nb_f[0] + m.nb_f[1], kThreads, lds, rlx::as_stream(stream), m);
+    const unsigned grid = m.nb_u8 + m.nb_f[0] + m.nb_f[1];
+    if (g_passes > 1) {
+        // per-body LDS of the multi-pass forms
+        size_t lds2 = iu ? (g_passes == 4 ? lds_u8_passes<4>() : lds_u8_passes<2>()) : 0;
+        for (int k = 0; k < 2; ++k) {
+            if (!fi[k]) continue;
+            const size_t l = m.kind[k] == 2 ? lds_f32_two_pass<32, 20, 9, 5>()
+                                            : (g_passes == 4 ? lds_f32_two_pass<64, 9, 7, 4>() : gf[k].lds);
+            lds2 = l > lds2 ? l : lds2;
+        }
+        if (g_passes == 4) RLX_LAUNCH((conv_dw_multi_kernel<4>), grid, kThreads, lds2, rlx::as_stream(stream), m);
+        else RLX_LAUNCH((conv_dw_multi_kernel<2>), grid, kThreads, lds2, rlx::as_stream(stream), m);
+    } else {
+        RLX_LAUNCH((conv_dw_multi_kernel<1>), grid, kThreads, lds, rlx::as_stream(stream), m);
+    }
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_conv_dw_passes(int passes) {
+    RLX_REQUIRE(passes == 1 || passes == 2 || passes == 4, "rlx_conv_dw_passes: 1, 2 or 4");
+    g_passes = passes;
     return RLX_OK;
 }
 

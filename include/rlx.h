@@ -946,6 +946,11 @@ typedef struct rlx_conv_dw_item {
     float *workspace; long long workspace_floats;
 } rlx_conv_dw_item;
 int rlx_conv_dw_multi(const rlx_conv_dw_item *items_host, rlx_splitk_job *jobs_host, int n_items, void *stream);
+/* Process-wide (default 2): 2 = the one-launch form stages conv1's and conv2's operands in TWO passes over the output rows
+ * (79 KB of LDS per workgroup instead of 157 KB: two workgroups per CU, one's fills under the other's products).  Weight
+ * gradients identical; the inner layer's bias gradient sums its positions in another grouping (last bits).  -6 us per Clipped-PPO
+ * update (profiles/r06_ab_conv_dw_passes.txt).  1 = the bodies of rlx_conv_dw_u8 / rlx_conv_dw_f32 as they are. */
+int rlx_conv_dw_passes(int passes);
 
 /* ------------------------------------------------- Clipped PPO: last dense layer + heads + losses, one launch -- */
 /* The middleware's Dense(units) of both towers (tower 0 = value, tower 1 = policy; layers.py:168-185), VHead / discrete

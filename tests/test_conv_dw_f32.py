@@ -113,9 +113,41 @@ def test_one_launch_of_the_three_layers_is_bit_identical_to_three_launches(rlx, 
     """rlx_conv_dw_multi (csrc/conv_dw_multi.hip): the same device code, the same partial sums, one grid."""
     import torch
     three = _update(dev, B, True, one_launch=False)
-    one = _update(dev, B, True, one_launch=True)
+    try:
+        rlx.conv_dw_passes(1)                # (the three launches stage in one pass; two passes: the test below)
+        one = _update(dev, B, True, one_launch=True)
+    finally:
+        rlx.conv_dw_passes(2)                # the library's default
     assert sum("conv_dw_multi_kernel" in n for n in one[1]) == 1 and not any("conv_dw_f32_kernel" in n or "conv_dw_u8_kernel" in n
                                                                              for n in one[1]), one[1]
     assert sum("conv_dw_f32_kernel" in n for n in three[1]) == 2 and sum("conv_dw_u8_kernel" in n for n in three[1]) == 1, three[1]
     assert len(one[1]) == len(three[1]) - 2
     assert torch.equal(one[0], three[0])
+
+
+@pytest.mark.parametrize("B,passes", [(64, 2), (63, 2), (64, 4), (63, 4)])
+def test_two_pass_staging_of_the_one_launch_form(rlx, dev, B, passes):
+    """rlx_conv_dw_passes(2): conv1's and conv2's operands in two passes over the output rows (half the LDS, two workgroups per
+    CU).  Every accumulator runs through its positions in the same order — weight gradients and conv1's bias gradient bit for
+    bit; conv2's bias gradient groups its column sums by pass (last bits)."""
+    import torch
+    try:
+        rlx.conv_dw_passes(1)
+        one = _update(dev, B, True, one_launch=True)
+        rlx.conv_dw_passes(passes)
+        two = _update(dev, B, True, one_launch=True)
+    finally:
+        rlx.conv_dw_passes(2)                # the library's default
+    assert sum("conv_dw_multi_kernel<%d>" % passes in n for n in two[1]) == 1, two[1]
+    g1, g2 = one[0], two[0]
+    net = one[2]
+    kernels = [k for k in net.params.entries if k.endswith("/kernel")]
+    same = torch.ones(g1.numel(), dtype=torch.bool, device=g1.device)
+    for key in (kernels[1:2] if passes == 2 else kernels[1:3]):       # (four: conv3 in two passes as well)
+        off, shape, towers, stride = net.params.entries[key[:-len("kernel")] + "bias"]
+        assert shape == (64,)
+        for t in range(towers):
+            same[off + t * stride: off + t * stride + 64] = False
+    assert torch.equal(g1[same], g2[same]), "%d elements differ outside the inner layers' bias gradients" % int((g1[same] != g2[same]).sum())
+    a, b = g1[~same], g2[~same]
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) and float(a.abs().max()) > 0
