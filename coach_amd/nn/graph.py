@@ -150,7 +150,7 @@ FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = 192
 # bit-identical to the tiled ones.  4: every fused forward launch runs with four groups (conv3 on all eight waves); the
 # sums of the two-tower minibatch then differ from the tiled launches' in the last bits (another grouping of the k-quads),
 # inside tests/tolerances.py against the oracle.
-CONV_FORWARD_WAVE_GROUPS = None
+CONV_FORWARD_WAVE_GROUPS = 4           # (-0.9 us on the C2 update's forward launch, profiles/r06_ab_conv_fwd_groups_split_cap.txt)
 
 
 def _tiled_wave_groups(M, N, batch):

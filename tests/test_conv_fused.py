@@ -13,6 +13,17 @@ pytestmark = pytest.mark.gpu
 DEFAULT_RING = (4, 2)        # rlx_conv23_depth's defaults (csrc/conv_fused.hip g_depth, g_step)
 
 
+@pytest.fixture(autouse=True)
+def _tile_rule_wave_groups():
+    """This file tests the BIT-IDENTICAL form: the fused launch with the wave groups the tiled launches would have used
+    (nn.graph.CONV_FORWARD_WAVE_GROUPS = None).  The default since round 6 is four groups everywhere (conv3 on all eight
+    waves at the two-tower minibatch too): test_four_wave_groups_everywhere_stay_within_the_tolerances below."""
+    from coach_amd.nn import graph as G
+    saved, G.CONV_FORWARD_WAVE_GROUPS = G.CONV_FORWARD_WAVE_GROUPS, None
+    yield
+    G.CONV_FORWARD_WAVE_GROUPS = saved
+
+
 def _torso(dev, act, seed):
     import torch
     from coach_amd.nn import graph as G, networks as NW
@@ -236,6 +247,44 @@ def test_clipped_ppo_update_through_the_fused_pair_is_bit_identical(rlx, dev):
             G.FUSE_CONV_PAIR = True
     assert torch.equal(res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])
+
+
+def test_four_wave_groups_everywhere_stay_within_the_tolerances(rlx, dev):
+    """CONV_FORWARD_WAVE_GROUPS = 4 (the default): at the two-tower minibatch the k-quads of a slab are grouped as the 32 x 32
+    tiling groups them, not as the 32 x 64 tiling the tiled launches would use there — activations within tolerances.OUT of
+    the bit-identical form, weights after two updates within tolerances.WEIGHTS."""
+    import torch
+    from tolerances import OUT, WEIGHTS
+    from coach_amd import _rlx
+    from coach_amd.nn import graph as G
+    from coach_amd.nn.networks import ClippedPPONet
+    B, A, shape = 64, 6, (84, 84, 4)
+    rng = np.random.RandomState(0)
+    obs = torch.from_numpy(rng.randint(0, 256, size=(B,) + shape).astype(np.uint8)).to(dev)
+    acts = torch.from_numpy(rng.randint(0, A, size=B).astype(np.int32)).to(dev)
+    adv = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
+    vt = torch.from_numpy(rng.randn(B).astype(np.float32)).to(dev)
+    res = {}
+    for groups in (None, 4):
+        G.CONV_FORWARD_WAVE_GROUPS = groups
+        np.random.seed(1)
+        net = ClippedPPONet(dev, shape, A, seed=2)
+        net.update_target(1.0)
+        old = net.policy_probs(obs, B, use_target=True, tag="old")
+        with _rlx.KernelTimer(64) as timer:
+            net.forward_backward(obs, B, acts, adv, vt, old)
+        names = [n for n, _ in timer.records]
+        net.finish_update(1.0)
+        net.forward_backward(obs, B, acts, adv, vt, old)
+        net.finish_update(1.0)
+        net.check_status()
+        h = net.ctx.buffer(net.torso.layers[2].name, (2, B * 49, 64), tag="train").clone()
+        res[groups] = (net.params.weights.clone(), h, names)
+    assert any("conv23_forward_kernel<4, 2, 2, 1>" in n for n in res[None][2]), res[None][2]
+    assert any("conv23_forward_kernel<4, 2, 4, 1>" in n for n in res[4][2]), res[4][2]
+    np.testing.assert_allclose(res[4][1].cpu().numpy(), res[None][1].cpu().numpy(), **OUT)
+    np.testing.assert_allclose(res[4][0].cpu().numpy(), res[None][0].cpu().numpy(), **WEIGHTS)
+    assert not torch.equal(res[4][1], res[None][1])
 
 
 def test_the_tile_rule_follows_rlx_gemm_tuning(rlx, dev):
