@@ -41,6 +41,8 @@ class no_gc_while_capturing(object):
 
 
 def capture(fn):
+    from ..distributed import quiesce_before_capture
+    quiesce_before_capture()         # (eager RCCL collectives still held by the process group's watchdog: see there)
     g = torch.cuda.CUDAGraph()
     # thread_local: with data parallelism RCCL's watchdog thread polls events while we capture; only
     # calls made by THIS thread may invalidate the capture
@@ -140,7 +142,8 @@ class GraphRunner(object):
             if key not in self._warm:
                 self._warm.add(key)
                 return fn()
-            torch.cuda.synchronize()
+            from ..distributed import quiesce_before_capture
+            quiesce_before_capture()         # (once per captured sequence: no collective runs between its segments' captures)
             cap = self._segcap = _SegmentedCapture()
             cap.begin()
             try:

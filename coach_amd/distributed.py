@@ -18,6 +18,20 @@ import torch
 import torch.distributed as dist
 
 
+def quiesce_before_capture(pause_s=0.25):
+    """Call before a stream capture in a process that has issued EAGER RCCL collectives.  ProcessGroupNCCL's watchdog thread
+    polls the completion event of every eager collective it still holds (every ~100 ms, hipEventQuery); a captured
+    collective pulls RCCL's internal stream into the capture, and on ROCm 7.2 a query of an event that was recorded on that
+    stream — eagerly, before the capture — then fails with hipErrorCapturedEvent in the watchdog thread, which terminates
+    the process (seen once in four runs of tests/test_data_parallel_gpu.py::test_rccl_path_world_size_one, where eager
+    timing all-reduces run right in front of the epoch's capture).  Waiting for the device and then for one watchdog
+    period lets the watchdog retire those collectives first.  No-op without an initialised RCCL process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and torch.cuda.is_available():
+        import time
+        torch.cuda.synchronize()
+        time.sleep(pause_s)
+
+
 class GradientSync(object):
     def __init__(self, backend=None, force=False):
         """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* come from the launcher (torch.distributed.run).
@@ -51,8 +65,9 @@ class GradientSync(object):
                 try:
                     x = torch.ones(1024, dtype=torch.float32, device="cuda")
                     dist.all_reduce(x)                      # communicator set-up stays outside the capture
-                    torch.cuda.synchronize()
+                    quiesce_before_capture()
                     x.fill_(1.0)
+                    torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         dist.all_reduce(x)                  # recorded, not executed: x is still all ones
