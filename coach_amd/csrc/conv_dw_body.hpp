@@ -3,6 +3,7 @@
 // conv_dw_multi.hip, which runs all three layers of the Atari torso as ONE launch.  See those files for what each replaces.
 #pragma once
 #include "rlx_common.hpp"
+#include <type_traits>
 
 namespace rlx_convdw {
 
@@ -248,13 +249,22 @@ __device__ __forceinline__ void conv_dw_u8_body_passes(const DwU8 &a, const int 
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u], bv[buf][u], acc, 0, 0, 0);                        \
         if (u + 1 < kS) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u + 1], bv[buf][u + 1], acc1, 0, 0, 0); \
     }
+        // (kRows is a compile-time count: the loop unrolls, every read is unconditional; sched_barrier keeps a row's reads in
+        // one block in front of the previous row's products — the scheduler otherwise sinks each read to its use: two reads,
+        // a full lgkmcnt(0) wait, two products)
         RLX_DWU8_READ(0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
         for (int py = 0; py < kRows; py += 2) {
             if (py + 1 < kRows) { RLX_DWU8_READ(1) }
+            __builtin_amdgcn_sched_barrier(0);
             RLX_DWU8_MATH(0)
+            __builtin_amdgcn_sched_barrier(0);
             if (py + 1 < kRows) {
                 if (py + 2 < kRows) { RLX_DWU8_READ(0) }
+                __builtin_amdgcn_sched_barrier(0);
                 RLX_DWU8_MATH(1)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #undef RLX_DWU8_READ
@@ -447,13 +457,13 @@ __device__ __forceinline__ void conv_dw_f32_body(const DwF32 &a, const int bid, 
 // time in LDS (conv2 of the Atari torso: 50 KB instead of 88 KB), for the same reason as conv_dw_u8_body_two_pass.  The
 // accumulators run through the positions in the same order; the bias gradient's column sums are taken pass by pass
 // (another grouping of that sum than the one-pass body's).
-template <int C, int KW, int S, int W, int OW, int R0>
+template <int C, int KW, int S, int W, int OW, int R0, int OHT>
 __device__ __forceinline__ void conv_dw_f32_body_two_pass(const DwF32 &a, const int bid, float *smem) {
     constexpr int kRowF = W * C;
     constexpr int kMT = KW * C;
     constexpr int kSub = kMT / 32 * 2 / 4;
     static_assert(kMT % 64 == 0 && (OW - 1) * S + KW <= W, "conv_dw_f32: geometry");
-    const int OH = a.OH, P = OH * OW;
+    const int P = OHT * OW;
     constexpr int xf_floats = (2 * R0 * kRowF + 255) & ~255, dz_floats = (2 * R0 * OW * kN + 255) & ~255;
     float *xf = smem;                                     // [2 images][rows of the pass][kRowF]
     float *dzl = xf + xf_floats;                          // [2 images][positions of the pass][64]
@@ -502,7 +512,11 @@ __device__ __forceinline__ void conv_dw_f32_body_two_pass(const DwF32 &a, const 
     float av[2][OW][kSub], bv[2][OW];
     const int cn = tid & 63, cq = tid >> 6;
     float csum = 0.f;
-    auto rows = [&](const int nr) {
+    // NR is a compile-time row count: the row loop unrolls completely and every LDS read is unconditional — with the next
+    // row's reads under a run-time "is there a next row" the compiler waits for ALL outstanding LDS reads (lgkmcnt(0)) in
+    // front of a row's products, the double buffer hides nothing (profiles/r06_conv32_tail16.txt, the same mechanism)
+    auto rows = [&](auto nr_c) {
+        constexpr int nr = decltype(nr_c)::value;
         const float *ar = xf + hi * nr * kRowF + 32 * (wave >> 1) + l31;
         const float *br = dzl + hi * nr * OW * kN + nh * 32 + l31;
 #define RLX_DWF_READ(buf)                                                          \
@@ -515,13 +529,20 @@ __device__ __forceinline__ void conv_dw_f32_body_two_pass(const DwF32 &a, const 
     _Pragma("unroll") for (int u = 0; u < OW; ++u)                                 \
         _Pragma("unroll") for (int j = 0; j < kSub; ++j)                           \
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][j], bv[buf][u], acc[j], 0, 0, 0);
+        // (sched_barrier: the scheduler otherwise sinks every read to its use — two reads, a full wait, two products)
         RLX_DWF_READ(0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
         for (int py = 0; py < nr; py += 2) {
             if (py + 1 < nr) { RLX_DWF_READ(1) }
+            __builtin_amdgcn_sched_barrier(0);
             RLX_DWF_MATH(0)
+            __builtin_amdgcn_sched_barrier(0);
             if (py + 1 < nr) {
                 if (py + 2 < nr) { RLX_DWF_READ(0) }
+                __builtin_amdgcn_sched_barrier(0);
                 RLX_DWF_MATH(1)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #undef RLX_DWF_READ
@@ -531,10 +552,10 @@ __device__ __forceinline__ void conv_dw_f32_body_two_pass(const DwF32 &a, const 
     };
     stage(0, R0);
     RLX_DWF_STAMP(1);
-    rows(R0);
+    rows(std::integral_constant<int, R0>());
     __syncthreads();                                      // pass 0's operands are no longer read
-    stage(R0, OH - R0);
-    rows(OH - R0);
+    stage(R0, OHT - R0);
+    rows(std::integral_constant<int, OHT - R0>());
     RLX_DWF_STAMP(2);
     const int K = a.KH * kMT;
     float *out = a.part + (((size_t)t * a.splits + g) * K + (size_t)ky * kMT + 32 * (wave >> 1)) * kN + nh * 32 + l31;

@@ -22,7 +22,7 @@ struct MultiArgs {
 // PASSES > 1: the bodies take their operands in passes over the output rows (conv_dw_u8_body_passes,
 // conv_dw_f32_body_two_pass) so that several workgroups share a CU — one's fills under the others' products (every
 // workgroup of the launch is allocated the largest body's LDS: at 157 KB even the 59 KB conv3 workgroups ran one per CU).
-//   2: conv1 in two passes (79 KB), conv2 in two (50 KB), conv3 in one (59 KB)      -> two workgroups per CU
+//   2: conv1 in two passes (79 KB), conv2 in two (50 KB), conv3 in two (34 KB)      -> two workgroups per CU
 //   4: conv1 in four passes (40 KB), conv2 in two (50 KB), conv3 in two (34 KB)     -> three workgroups per CU
 template <int PASSES>
 __global__ void __launch_bounds__(kThreads) conv_dw_multi_kernel(const MultiArgs m) {
@@ -38,10 +38,10 @@ __global__ void __launch_bounds__(kThreads) conv_dw_multi_kernel(const MultiArgs
     for (int i = 0; i < 2; ++i) {
         if (bid < m.nb_f[i]) {
             if (m.kind[i] == 1) {
-                if constexpr (PASSES == 4) conv_dw_f32_body_two_pass<64, 3, 1, 9, 7, 4>(m.f[i], bid, smem);
+                if constexpr (PASSES > 1) conv_dw_f32_body_two_pass<64, 3, 1, 9, 7, 4, 7>(m.f[i], bid, smem);
                 else conv_dw_f32_body<64, 3, 1, 9, 7>(m.f[i], bid, smem);
             } else {
-                if constexpr (PASSES > 1) conv_dw_f32_body_two_pass<32, 4, 2, 20, 9, 5>(m.f[i], bid, smem);
+                if constexpr (PASSES > 1) conv_dw_f32_body_two_pass<32, 4, 2, 20, 9, 5, 9>(m.f[i], bid, smem);
                 else conv_dw_f32_body<32, 4, 2, 20, 9>(m.f[i], bid, smem);
             }
             return;
@@ -155,8 +155,7 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items, rlx_splitk_job *jobs, int n
         size_t lds2 = iu ? (g_passes == 4 ? lds_u8_passes<4>() : lds_u8_passes<2>()) : 0;
         for (int k = 0; k < 2; ++k) {
             if (!fi[k]) continue;
-            const size_t l = m.kind[k] == 2 ? lds_f32_two_pass<32, 20, 9, 5>()
-                                            : (g_passes == 4 ? lds_f32_two_pass<64, 9, 7, 4>() : gf[k].lds);
+            const size_t l = m.kind[k] == 2 ? lds_f32_two_pass<32, 20, 9, 5>() : lds_f32_two_pass<64, 9, 7, 4>();
             lds2 = l > lds2 ? l : lds2;
         }
         if (g_passes == 4) RLX_LAUNCH((conv_dw_multi_kernel<4>), grid, kThreads, lds2, rlx::as_stream(stream), m);

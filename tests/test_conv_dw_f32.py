@@ -143,7 +143,7 @@ def test_two_pass_staging_of_the_one_launch_form(rlx, dev, B, passes):
     net = one[2]
     kernels = [k for k in net.params.entries if k.endswith("/kernel")]
     same = torch.ones(g1.numel(), dtype=torch.bool, device=g1.device)
-    for key in (kernels[1:2] if passes == 2 else kernels[1:3]):       # (four: conv3 in two passes as well)
+    for key in kernels[1:3]:                 # (conv2 and conv3 in two passes: their column sums group by pass)
         off, shape, towers, stride = net.params.entries[key[:-len("kernel")] + "bias"]
         assert shape == (64,)
         for t in range(towers):
