@@ -129,31 +129,44 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
     };
     constexpr int kSets = PF + 1;
     float4 bq[kSets][8];
-#pragma unroll
-    for (int p = 0; p < PF; ++p) load_b(w3, c0 + 4 * p, bq[p]);      // (the first PF jobs of this wave: 18 column tiles >= c0 + 4 PF)
-
-    // the activations both gathers multiply by, requested now: this lane's items of gather 3 (2) and of gather 2 (4)
     float4 y2v[2], y1v[4];
-    {
-        const float *y2 = a.y2 + (size_t)t * a.y2_ts + ((size_t)img * (O2 * O2) + (size_t)x20 * O2) * C2;
+    const float *const y2 = a.y2 + (size_t)t * a.y2_ts + ((size_t)img * (O2 * O2) + (size_t)x20 * O2) * C2;
+    const float *const y1 = a.y1 + (size_t)t * a.y1_ts + ((size_t)img * (H1 * W1) + (size_t)x10 * W1) * C1;
+    const float4 *const src3 = reinterpret_cast<const float4 *>(a.dz3 + (size_t)t * a.dz3_ts +
+                                                                ((size_t)img * (O3 * O3) + (size_t)z0 * O3) * C3);
+    if constexpr (TAIL16) {
+        // request order = need order, every request unconditional (clamped): dz3's rows first — the first product waits for
+        // nothing else —, then the first job's weight rows, then the activations the gathers multiply by (needed 10 us
+        // later).  Loads return in order: with the activations in front, the staging of dz3 waited for 48 KB of cold
+        // activation lines, and its wait was a vmcnt(0).
+        static_assert(NP3 * 16 > kThreads && NP3 * 16 <= 2 * kThreads, "two dz3 requests per lane");
+        const float4 d0 = src3[tid], d1 = src3[min(tid + kThreads, NP3 * 16 - 1)];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) load_b(w3, c0 + 4 * p, bq[p]);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) y2v[it] = *reinterpret_cast<const float4 *>(y2 + (size_t)min(it * kThreads + tid, NP2 * 16 - 1) * 4);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) y1v[it] = *reinterpret_cast<const float4 *>(y1 + (size_t)min(it * kThreads + tid, NP1 * 8 - 1) * 4);
+        *reinterpret_cast<float4 *>(dz3s + (tid >> 4) * PZ + (tid & 15) * 4) = d0;
+        if (tid + kThreads < NP3 * 16)
+            *reinterpret_cast<float4 *>(dz3s + ((tid + kThreads) >> 4) * PZ + (tid & 15) * 4) = d1;
+    } else {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) load_b(w3, c0 + 4 * p, bq[p]);      // (the first PF jobs of this wave: 18 column tiles >= c0 + 4 PF)
+        // the activations both gathers multiply by, requested now: this lane's items of gather 3 (2) and of gather 2 (4)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int item = it * kThreads + tid;
             y2v[it] = item < NP2 * 16 ? *reinterpret_cast<const float4 *>(y2 + (size_t)item * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const float *y1 = a.y1 + (size_t)t * a.y1_ts + ((size_t)img * (H1 * W1) + (size_t)x10 * W1) * C1;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int item = it * kThreads + tid;
             y1v[it] = item < NP1 * 8 ? *reinterpret_cast<const float4 *>(y1 + (size_t)item * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
-    // dz3 rows [z0, z0 + 5) of this image: 35 x 64 contiguous floats -> dz3s[position][PZ]
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(a.dz3 + (size_t)t * a.dz3_ts +
-                                                             ((size_t)img * (O3 * O3) + (size_t)z0 * O3) * C3);
+        // dz3 rows [z0, z0 + 5) of this image: 35 x 64 contiguous floats -> dz3s[position][PZ]
         for (int f = tid; f < NP3 * 16; f += kThreads)
-            *reinterpret_cast<float4 *>(dz3s + (f >> 4) * PZ + (f & 15) * 4) = src[f];
+            *reinterpret_cast<float4 *>(dz3s + (f >> 4) * PZ + (f & 15) * 4) = src3[f];
     }
 
     // one product: dcol[np x 32 ncols] = dz (LDS, np x 64) wmat^T; bq[0] holds the B operands of this wave's first job;
@@ -272,17 +285,23 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
             if (item >= NP2 * 16) continue;
             const int pl = item >> 4, c4 = (item & 15) * 4;
             const int iy = x20 + pl / O2, ix = pl % O2;
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int ky = 0; ky < K3; ++ky) {
-                const int oy = iy - ky;
-                if (iy < ky || oy >= O3) continue;
+            // all nine taps requested at once (a tap that does not exist: a valid address, its value not added), then added in
+            // col2im's order — a chain of dependent LDS reads under branches before (the gather pass was latency, not work)
+            float4 tv[K3 * K3];
+            bool tok[K3 * K3];
+#pragma unroll
+            for (int ky = 0; ky < K3; ++ky)
+#pragma unroll
                 for (int kx = 0; kx < K3; ++kx) {
-                    const int ox = ix - kx;
-                    if (ix < kx || ox >= O3) continue;
-                    const float4 v = *reinterpret_cast<const float4 *>(dcol + ((oy - z0) * O3 + ox) * LD3 + (ky * K3 + kx) * C2 + c4);
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                    const int oy = iy - ky, ox = ix - kx;
+                    const bool ok = iy >= ky && oy < O3 && ix >= kx && ox < O3;
+                    tok[ky * K3 + kx] = ok;
+                    tv[ky * K3 + kx] = *reinterpret_cast<const float4 *>(dcol + (ok ? (oy - z0) * O3 + ox : 0) * LD3 + (ky * K3 + kx) * C2 + c4);
                 }
-            }
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < K3 * K3; ++q)
+                if (tok[q]) { s.x += tv[q].x; s.y += tv[q].y; s.z += tv[q].z; s.w += tv[q].w; }
             s.x *= act_deriv(y2v[it].x, a.act); s.y *= act_deriv(y2v[it].y, a.act);
             s.z *= act_deriv(y2v[it].z, a.act); s.w *= act_deriv(y2v[it].w, a.act);
             *reinterpret_cast<float4 *>(dz2s + pl * PZ + c4) = s;
@@ -300,17 +319,24 @@ __global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const Co
             if (item >= NP1 * 8) continue;
             const int pl = item >> 3, c4 = (item & 7) * 4;
             const int iy = x10 + pl / W1, ix = pl % W1;
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int ky = iy % S2; ky < K2; ky += S2) {
-                const int oy = (iy - ky) / S2;
-                if (iy < ky || oy >= O2) continue;
-                for (int kx = ix % S2; kx < K2; kx += S2) {
-                    const int ox = (ix - kx) / S2;
-                    if (ix < kx || ox >= O2) continue;
-                    const float4 v = *reinterpret_cast<const float4 *>(dcol + ((oy - x20) * O2 + ox) * LD2 + (ky * K2 + kx) * C1 + c4);
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            // the (K2 / S2)^2 = 4 taps of this position's phase, requested at once, added in col2im's order
+            constexpr int kT = K2 / S2;
+            float4 tv[kT * kT];
+            bool tok[kT * kT];
+#pragma unroll
+            for (int a2 = 0; a2 < kT; ++a2)
+#pragma unroll
+                for (int b2 = 0; b2 < kT; ++b2) {
+                    const int ky = iy % S2 + a2 * S2, kx = ix % S2 + b2 * S2;
+                    const int oy = (iy - ky) / S2, ox = (ix - kx) / S2;
+                    const bool ok = iy >= ky && oy < O2 && ix >= kx && ox < O2;
+                    tok[a2 * kT + b2] = ok;
+                    tv[a2 * kT + b2] = *reinterpret_cast<const float4 *>(dcol + (ok ? (oy - x20) * O2 + ox : 0) * LD2 + (ky * K2 + kx) * C1 + c4);
                 }
-            }
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < kT * kT; ++q)
+                if (tok[q]) { s.x += tv[q].x; s.y += tv[q].y; s.z += tv[q].z; s.w += tv[q].w; }
             s.x *= act_deriv(y1v[it].x, a.act); s.y *= act_deriv(y1v[it].y, a.act);
             s.z *= act_deriv(y1v[it].z, a.act); s.w *= act_deriv(y1v[it].w, a.act);
             *reinterpret_cast<float4 *>(dz1 + (size_t)item * 4) = s;
