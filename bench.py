@@ -839,6 +839,9 @@ def main():
                     help="A/B: the last dense layer + heads + losses + heads' backward as one launch (rlx_ppo_fc_heads)")
     ap.add_argument("--fuse-conv-bwd", type=int, default=None, choices=[0, 1],
                     help="A/B: the input gradients of conv3 / conv2 as one launch (nn.graph.FUSE_CONV_INPUT_GRADS; 0 = default)")
+    ap.add_argument("--fuse-conv-bwd-min-wg", type=int, default=None,
+                    help="A/B: fewest half-image workgroups for which the fused input-gradient chain is taken "
+                         "(nn.graph.FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
                     help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
     ap.add_argument("--episode-length", type=int, default=EP_LEN,
@@ -926,6 +929,9 @@ def main():
     if args.fuse_conv_bwd is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_INPUT_GRADS = bool(args.fuse_conv_bwd)
+    if args.fuse_conv_bwd_min_wg is not None:
+        from coach_amd.nn import graph as _G
+        _G.FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = int(args.fuse_conv_bwd_min_wg)
     if args.gemm_pipeline is not None:
         from coach_amd import _rlx
         _rlx.lib().gemm_pipeline(args.gemm_pipeline)

@@ -314,19 +314,161 @@ __device__ __forceinline__ void conv_dw_u8_body_passes(const DwU8 &a, const int 
 template <int NP>
 constexpr size_t lds_u8_passes() { return sizeof(float) * (size_t)(256 + (20 / NP) * 2 * 336 + (20 / NP) * 20 * kN); }
 
+// ONE tower of 32 filters (T * Co == 32: the DQN update's backward pass through the Atari torso, B = 32) — Atari geometry only.
+// The staging is conv_dw_u8_body_passes<2>'s (frame rows of a pair of kernel rows as fp32 + the dz of 10 output rows at a
+// time, 53 KB: three workgroups per CU); the dz tile is [positions][32], a 1 KB block = 8 positions.  With half the channels
+// there is one 32-channel block per kernel row, so the four waves are (kernel row of the pair) x (HALF of the pass's output
+// rows): a wave issues 100 instead of 200 products, and the workgroup leaves TWO splits per image (rows 0-4 + 10-14 and rows
+// 5-9 + 15-19) of [K][32] in the deferred split-K workspace — 2 B splits in all, summed in split order by the reduction.
+constexpr int kNH = 32;
+__device__ __forceinline__ void conv_dw_u8_body_half(const DwU8 &a, const int bid, float *smem) {
+    constexpr int NP = 2, OWT = 20, SCT = 16, ROWD = 84, kRows = 20 / NP, kPP = kRows * OWT, kRowF = 4 * ROWD;
+    constexpr int kRW = kRows / 2;                       // output rows per wave and pass
+    float *lut = smem;                                   // [256]; later the column-sum scratch
+    float *xf = lut + 256;                               // [kRows][2][rowf]
+    float *dzl = xf + kRows * 2 * kRowF;                 // [kPP][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = bid & 7, rest = bid >> 3;
+    const int q = rest % a.NQ, b = (rest / a.NQ) * 8 + xcd;
+    if (b >= a.B) return;
+    RLX_DWU8_STAMP(0);
+    lut[tid] = (float)tid / a.a_div;
+    constexpr int kF = 14, kND = 2 * 20 * ROWD, kNDP = kND / NP;
+    const unsigned char *img = a.x + (size_t)b * a.H * kRowF;
+    unsigned fb[kF];
+#pragma unroll
+    for (int j = 0; j < kF; ++j) {
+        const int idx = min(tid + j * kThreads, kND - 1), r = idx / ROWD, d = idx - r * ROWD;
+        const int src_row = a.S * (r >> 1) + 2 * q + (r & 1);
+        fb[j] = *reinterpret_cast<const unsigned *>(img + (size_t)src_row * kRowF + 4 * d);
+    }
+    const unsigned dz_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(dzl));
+    const float *src0 = a.dz + (size_t)b * a.P * kNH + lane * 4;          // the image's dz: [P][32] contiguous
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int kBlk = kPP * kNH / 256;                // 25 blocks of 1 KB per pass
+    auto request_dz = [&](const int pass) {
+        for (int blk = wave_u; blk < kBlk; blk += kThreads / 64)
+            dma16(src0 + (size_t)(pass * kBlk + blk) * 256, __builtin_amdgcn_readfirstlane(dz_base + (unsigned)blk * 1024u));
+    };
+    auto convert = [&](const int pass) {
+#pragma unroll
+        for (int j = 0; j < kF; ++j) {
+            const int idx = tid + j * kThreads - pass * kNDP;
+            if (idx >= 0 && idx < kNDP) {
+                const unsigned w = fb[j];
+                const f32x4 v = {lut[w & 255u], lut[(w >> 8) & 255u], lut[(w >> 16) & 255u], lut[w >> 24]};
+                *reinterpret_cast<f32x4 *>(xf + 4 * idx) = v;
+            }
+        }
+    };
+    const int mh = wave & 1, rh = wave >> 1, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc1[i] = 0.f;
+    constexpr int row2 = 2 * kRowF, kS = OWT / 2;
+    const float *const ap = xf + mh * kRowF + l31 + hi * SCT + rh * kRW * row2;
+    const float *const bp = dzl + l31 + hi * kNH + rh * kRW * OWT * kNH;
+    float av[2][kS], bv[2][kS];
+    auto rows = [&]() {
+        const float *ar = ap, *br = bp;
+#define RLX_DWU8_READ(buf)                                                  \
+    _Pragma("unroll") for (int u = 0; u < kS; ++u) {                        \
+        av[buf][u] = ar[2 * SCT * u];                                       \
+        bv[buf][u] = br[2 * kNH * u];                                       \
+    }                                                                       \
+    ar += row2; br += OWT * kNH;
+#define RLX_DWU8_MATH(buf)                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < kS; u += 2) {                                                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u], bv[buf][u], acc, 0, 0, 0);                        \
+        if (u + 1 < kS) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u + 1], bv[buf][u + 1], acc1, 0, 0, 0); \
+    }
+        RLX_DWU8_READ(0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int py = 0; py < kRW; py += 2) {
+            if (py + 1 < kRW) { RLX_DWU8_READ(1) }
+            __builtin_amdgcn_sched_barrier(0);
+            RLX_DWU8_MATH(0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (py + 1 < kRW) {
+                if (py + 2 < kRW) { RLX_DWU8_READ(0) }
+                __builtin_amdgcn_sched_barrier(0);
+                RLX_DWU8_MATH(1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef RLX_DWU8_READ
+#undef RLX_DWU8_MATH
+    };
+    const int cn = tid & 31, cg = tid >> 5;              // bias gradient (q == 0): column cn, positions cg + 8 k
+    float s0 = 0.f, s1 = 0.f;
+    request_dz(0);
+    __syncthreads();                                     // the table
+    RLX_DWU8_STAMP(1);
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        if (pass > 0) {
+            __syncthreads();                             // the previous pass's operands are no longer read
+            request_dz(pass);
+        }
+        convert(pass);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (pass == 0) { RLX_DWU8_STAMP(2); }
+        rows();
+        if (q == 0) {
+            int pos = cg;
+            for (; pos + 8 < kPP; pos += 16) {           // two chains, added at the end
+                s0 += dzl[pos * kNH + cn];
+                s1 += dzl[(pos + 8) * kNH + cn];
+            }
+            if (pos < kPP) s0 += dzl[pos * kNH + cn];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
+    RLX_DWU8_STAMP(3);
+    float *out = a.part + ((size_t)(2 * b + rh) * a.K + q * 64 + mh * 32) * kNH + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * kNH] = acc[r];
+    if (q == 0) {
+        __syncthreads();                                 // (the table's words: every wave has converted its last pass)
+        lut[cg * kNH + cn] = s0 + s1;
+        __syncthreads();
+        if (tid < kNH) {
+            float s = lut[tid];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) s += lut[g * kNH + tid];
+            a.cpart[(size_t)(2 * b) * kNH + tid] = s;
+            a.cpart[(size_t)(2 * b + 1) * kNH + tid] = 0.f;
+        }
+    }
+    RLX_DWU8_STAMP(4);
+}
+constexpr size_t lds_u8_half() { return sizeof(float) * (size_t)(256 + 10 * 2 * 336 + 10 * 20 * kNH); }
+
 struct GeometryU8 {
     int OH, OW, K, P, rowf, NQ;
     size_t lds;
+    int nch, splits;                  // output columns of a split (64, or 32: conv_dw_u8_body_half) and splits (B, or 2 B)
 };
 inline bool geometry_u8(int B, int H, int W, int C, int KH, int KW, int S, int Co, int T, GeometryU8 *g) {
     if (B < 2 || B > 128 || H < KH || W < KW || S < 1 || KH < 2 || (KH & 1)) return false;
-    if (KW * C != 32 || T * Co != kN || (Co & 3) || (kN % Co)) return false;       // a patch row = 32 floats, 64 folded channels
+    const bool half = T == 1 && Co == kNH;                                           // one tower of 32 filters: conv_dw_u8_body_half
+    if (KW * C != 32 || (T * Co != kN && !half) || (Co & 3) || (kN % Co)) return false;   // a patch row = 32 floats, 64 folded channels
     g->OH = (H - KH) / S + 1;
     g->OW = (W - KW) / S + 1;
     g->K = KH * KW * C;
     g->P = g->OH * g->OW;
     g->rowf = W * C;
     g->NQ = KH / 2;
+    g->nch = half ? kNH : kN;
+    g->splits = half ? 2 * B : B;
+    if (half) {                                                                      // the Atari geometry only, 2 B <= 128 splits
+        if (g->OH != 20 || g->OW != 20 || S * C != 16 || g->rowf != 336 || KH != 8 || B > 64) return false;
+        g->lds = lds_u8_half();
+        return true;
+    }
     if ((g->rowf & 3) || (g->P & 15) || g->OW < 2) return false;
     if (2 * g->OH * (g->rowf / 4) > 16 * kThreads) return false;
     g->lds = sizeof(float) * (256 + (size_t)g->OH * 2 * g->rowf + (size_t)g->P * kN);

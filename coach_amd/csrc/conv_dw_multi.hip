@@ -17,6 +17,7 @@ struct MultiArgs {
     DwU8 u8;
     DwF32 f[2];
     int nb_u8, nb_f[2], kind[2];
+    int u8_half;               // the uint8 item is one tower of 32 filters: conv_dw_u8_body_half
 };
 
 // PASSES > 1: the bodies take their operands in passes over the output rows (conv_dw_u8_body_passes,
@@ -29,7 +30,8 @@ __global__ void __launch_bounds__(kThreads) conv_dw_multi_kernel(const MultiArgs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
     if (bid < m.nb_u8) {
-        if constexpr (PASSES > 1) conv_dw_u8_body_passes<PASSES>(m.u8, bid, smem);
+        if (m.u8_half) conv_dw_u8_body_half(m.u8, bid, smem);
+        else if constexpr (PASSES > 1) conv_dw_u8_body_passes<PASSES>(m.u8, bid, smem);
         else conv_dw_u8_body<20, 16, 84>(m.u8, bid, smem);
         return;
     }
@@ -94,6 +96,7 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items, rlx_splitk_job *jobs, int n
     MultiArgs m;
     m.nb_u8 = m.nb_f[0] = m.nb_f[1] = 0;
     m.kind[0] = m.kind[1] = 0;
+    m.u8_half = 0;
     size_t lds = 0;
     if (iu) {
         const rlx_conv_dw_item &it = *iu;
@@ -109,12 +112,13 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items, rlx_splitk_job *jobs, int n
         a.B = it.B; a.H = it.H; a.W = it.W; a.C = it.C; a.KH = it.KH; a.S = it.S; a.OH = gu.OH; a.OW = gu.OW; a.Co = it.filters;
         a.K = gu.K; a.P = gu.P; a.rowf = gu.rowf; a.NQ = gu.NQ; a.stamps = nullptr;
         m.nb_u8 = ((it.B + 7) / 8) * 8 * gu.NQ;
+        m.u8_half = gu.nch == kNH;
         lds = gu.lds;
         rlx_splitk_job &j = jobs[ju];
         j.partials = a.part; j.colsum_partials = it.db ? a.cpart : nullptr;
         j.C = it.dw; j.colsum_out = it.db;
         j.ldc = it.filters; j.c_batch_stride = it.dw_tower_stride; j.colsum_batch_stride = it.db_tower_stride;
-        j.M = gu.K; j.N = kN; j.batch = 1; j.splits = it.B; j.n_fold = it.filters;
+        j.M = gu.K; j.N = gu.nch; j.batch = 1; j.splits = gu.splits; j.n_fold = it.filters;
     }
     for (int k = 0; k < 2; ++k) {
         if (!fi[k]) continue;
@@ -152,7 +156,7 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items, rlx_splitk_job *jobs, int n
     const unsigned grid = m.nb_u8 + m.nb_f[0] + m.nb_f[1];
     if (g_passes > 1) {
         // per-body LDS of the multi-pass forms
-        size_t lds2 = iu ? (g_passes == 4 ? lds_u8_passes<4>() : lds_u8_passes<2>()) : 0;
+        size_t lds2 = iu ? (m.u8_half ? lds_u8_half() : (g_passes == 4 ? lds_u8_passes<4>() : lds_u8_passes<2>())) : 0;
         for (int k = 0; k < 2; ++k) {
             if (!fi[k]) continue;
             const size_t l = m.kind[k] == 2 ? lds_f32_two_pass<32, 20, 9, 5>() : lds_f32_two_pass<64, 9, 7, 4>();

@@ -34,6 +34,11 @@ __global__ void __launch_bounds__(kThreads) conv_dw_u8_kernel(const DwU8 a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     conv_dw_u8_body<OWT, SCT, ROWD>(a, blockIdx.x, smem);
 }
+// one tower of 32 filters (the DQN update, B = 32): waves = kernel row x half of the output rows, two splits per image
+__global__ void __launch_bounds__(kThreads) conv_dw_u8_half_kernel(const DwU8 a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_dw_u8_body_half(a, blockIdx.x, smem);
+}
 
 static long long *g_stamps = nullptr;
 
@@ -90,7 +95,9 @@ int rlx_conv_dw_u8(const unsigned char *frames, float a_div, const float *dz, lo
     a.rowf = g.rowf; a.NQ = g.NQ;
     a.stamps = g_stamps;
     const int grid = ((B + 7) / 8) * 8 * g.NQ;
-    if (g.OW == 20 && g.OH == 20 && S * C == 16 && g.rowf == 336)          // the Atari torso: 84 x 84 x 4 frames, 8 x 8 stride 4
+    if (g.nch == kNH)
+        RLX_LAUNCH((conv_dw_u8_half_kernel), grid, kThreads, g.lds, rlx::as_stream(stream), a);
+    else if (g.OW == 20 && g.OH == 20 && S * C == 16 && g.rowf == 336)     // the Atari torso: 84 x 84 x 4 frames, 8 x 8 stride 4
         RLX_LAUNCH((conv_dw_u8_kernel<20, 16, 84>), grid, kThreads, g.lds, rlx::as_stream(stream), a);
     else
         RLX_LAUNCH((conv_dw_u8_kernel<0, 0, 0>), grid, kThreads, g.lds, rlx::as_stream(stream), a);
@@ -99,7 +106,7 @@ int rlx_conv_dw_u8(const unsigned char *frames, float a_div, const float *dz, lo
     j.partials = a.part; j.colsum_partials = db ? a.cpart : nullptr;
     j.C = dw; j.colsum_out = db;
     j.ldc = Co; j.c_batch_stride = dw_tower_stride; j.colsum_batch_stride = db_tower_stride;
-    j.M = g.K; j.N = kN; j.batch = 1; j.splits = B; j.n_fold = Co;
+    j.M = g.K; j.N = g.nch; j.batch = 1; j.splits = g.splits; j.n_fold = Co;
     return RLX_OK;
 }
 

@@ -691,7 +691,9 @@ class Conv2d(Layer):
             # rows + the image's dz in LDS; csrc/conv_dw_f32.hip: an inner convolution on its own — its input gradient went
             # through rlx_conv32_input_grad): one deferred split per image / image pair
             geo = (B, self.H, self.W, self.C, self.KH, self.KW, self.S, self.Co, T)
-            lds_u8 = bool(not pairing and not overlap and dw_later is None and fold and x.u8 and CONV_DW_U8 and
+            # (one tower of 32 filters — the DQN update — has a body of its own: two splits per image, conv_dw_u8_body_half)
+            half = T == 1 and x.towers in (0, 1) and self.Co == 32
+            lds_u8 = bool(not pairing and not overlap and dw_later is None and (fold or half) and x.u8 and CONV_DW_U8 and
                           ctx.lib.conv_dw_u8_supported(*geo))
             lds_f32 = bool(not pairing and not overlap and dw_later is None and not fold and not x.u8 and CONV_DW_F32 and
                            x.towers == T and ctx.lib.conv_dw_f32_supported(*geo))
