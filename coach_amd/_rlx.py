@@ -266,19 +266,24 @@ class SplitkJob(ctypes.Structure):
 
 
 ADAM_TICKET_WORDS = 1056        # rlx.h RLX_ADAM_TICKET_WORDS
-ABI_VERSION = 8                 # rlx_abi_version() of the library this module's structures and buffer sizes match
+ABI_VERSION = 9                 # rlx_abi_version() of the library this module's structures and buffer sizes match
 MAX_SPLITK_JOBS = 8
 
 
-def splitk_reduce_jobs(jobs, stream=None, ppo_tail=None):
+def splitk_reduce_jobs(jobs, stream=None, ppo_tail=None, per_tail=None):
     """sum the partials of the deferred products `jobs` (SplitkJob list) in one launch.
-    ppo_tail: a PpoRowsDesc whose all-rows part (rlx_ppo_heads_tail) rides on the (last) launch as extra workgroups."""
+    ppo_tail: a PpoRowsDesc whose all-rows part (rlx_ppo_heads_tail) rides on the (last) launch as extra workgroups.
+    per_tail: the argument tuple of rlx_per_update (without the stream) — the prioritized replay's priority update rides on
+    the (last) launch as one workgroup (rlx_splitk_reduce_jobs_per_update)."""
     live = [j for j in jobs if j.splits > 1]
     s = current_stream() if stream is None else stream
     for i in range(0, len(live), MAX_SPLITK_JOBS):
         chunk = live[i:i + MAX_SPLITK_JOBS]
         arr = (SplitkJob * len(chunk))(*chunk)
-        if ppo_tail is not None and i + MAX_SPLITK_JOBS >= len(live):
+        if per_tail is not None and ppo_tail is None and i + MAX_SPLITK_JOBS >= len(live):
+            run = lambda a=arr, n=len(chunk), t=per_tail: lib().splitk_reduce_jobs_per_update(ctypes.byref(a), n, *t, s)
+            per_tail = None
+        elif ppo_tail is not None and i + MAX_SPLITK_JOBS >= len(live):
             run = lambda a=arr, n=len(chunk), t=ppo_tail: lib().splitk_reduce_jobs_ppo_tail(ctypes.byref(a), n, ctypes.byref(t), s)
             ppo_tail = None
         else:
@@ -287,6 +292,8 @@ def splitk_reduce_jobs(jobs, stream=None, ppo_tail=None):
         run()
     if ppo_tail is not None:                       # nothing to reduce: the tail as a launch of its own
         lib().ppo_heads_tail(ctypes.byref(ppo_tail), s)
+    if per_tail is not None:
+        lib().per_update(*per_tail, s)
 
 
 def conv_input_grad(dz, weights, dx, x_out, deriv, tables, B, H, W, C, KH, KW, S, Co, towers, dy_stride, w_stride,
@@ -301,6 +308,24 @@ def conv_input_grad(dz, weights, dx, x_out, deriv, tables, B, H, W, C, KH, KW, S
         d.M, d.N, d.K, d.batch = B * OH * OW, KH * KW * C, Co, towers
         _record((d,), run)
     run()
+
+
+class PerUpdateDesc(ctypes.Structure):
+    """rlx_per_update_desc (include/rlx.h): the arguments of rlx_per_update for a rider launch."""
+    _fields_ = [("sum_tree", ctypes.c_void_p), ("min_tree", ctypes.c_void_p), ("max_tree", ctypes.c_void_p),
+                ("capacity", ctypes.c_int), ("idx", ctypes.c_void_p), ("td_errors", ctypes.c_void_p), ("n", ctypes.c_int),
+                ("alpha", ctypes.c_double), ("epsilon", ctypes.c_double), ("max_priority", ctypes.c_void_p),
+                ("status", ctypes.c_void_p)]
+
+
+def per_update_desc(args):
+    """PrioritizedExperienceReplay.priority_update_args() -> PerUpdateDesc"""
+    sum_t, min_t, max_t, cap, idx, err, n, alpha, eps, maxp, status = args
+    d = PerUpdateDesc()
+    d.sum_tree, d.min_tree, d.max_tree, d.capacity = sum_t.data_ptr(), min_t.data_ptr(), max_t.data_ptr(), int(cap)
+    d.idx, d.td_errors, d.n, d.alpha, d.epsilon = idx.data_ptr(), err.data_ptr(), int(n), float(alpha), float(eps)
+    d.max_priority, d.status = maxp.data_ptr(), status.data_ptr()
+    return d
 
 
 class ConvDwItem(ctypes.Structure):

@@ -123,13 +123,25 @@ class DQNAgent(VectorOffPolicyAgent):
         self._q_act = q.data.view(self.n_env, self.A)
 
     # ------------------------------------------------------------------------------- training
-    def _learn_device(self, b, weights):
+    PER_UPDATE_RIDES = True
+
+    def _per_ride_ok(self):
+        """the image network's backward pass ends in a deferred-reduction launch (the fused small-MLP update and the
+        dueling head's path do not pass through Context.flush_deferred in a way that is guaranteed to run)."""
         net = self.networks["main"]
+        return self.image and net._fused is None
+
+    def _learn_device(self, b, weights, per_ride=None):
+        net = self.networks["main"]
+        net.ctx.per_tail = per_ride
         net.learn_from_batch(b._states["observation"], b._next_states["observation"], self.batch_size,
                              b.actions(), b.rewards(), b.game_overs(), self.ap.algorithm.discount,
                              importance_weights=weights, td_errors=self.td_errors,
                              double_dqn=self.double_dqn, grad_scale=self._grad_scale(),
                              sync=self if self.dist is not None else None, states_pair=b._info.get("states_pair"))
+        if net.ctx.per_tail is not None:          # no deferred-reduction launch took it along
+            net.ctx.per_tail = None
+            _rlx.lib().per_update(*per_ride, _rlx.current_stream())
 
     def _grad_scale(self):
         netp = self.ap.network_wrappers["main"]
@@ -140,8 +152,12 @@ class DQNAgent(VectorOffPolicyAgent):
         """DQNAgent.learn_from_batch (dqn_agent.py:81-113)."""
         per = isinstance(self.memory, PrioritizedExperienceReplay)
         weights = batch.info("weight") if per else None           # fp64, as rlx_per_sample wrote them
-        self._run(("learn", per), lambda: self._learn_device(batch, weights))
-        if per:                                   # update_transition_priorities_and_get_weights
+        # update_transition_priorities_and_get_weights: the priority update rides on the backward pass's deferred-reduction
+        # launch (rlx_splitk_reduce_jobs_per_update) where the network's backward pass has one; else a launch of its own
+        ride = self.memory.priority_update_args(batch.info("idx"), self.td_errors) \
+            if per and self.PER_UPDATE_RIDES and self._per_ride_ok() else None
+        self._run(("learn", per, ride is not None), lambda: self._learn_device(batch, weights, ride))
+        if per and ride is None:
             self.memory.update_priorities(batch.info("idx"), self.td_errors)
         loss = self.networks["main"].loss
         self.signals = {"Loss": loss, "Grads (unclipped)": self.networks["main"].norm}

@@ -37,6 +37,12 @@
 // Bound: MFMA issue of one CU — 36 + 32 jobs of 32 MFMAs on 4 SIMDs = 34.8 k cycles = 16 us — plus two gather passes.
 #include "rlx_common.hpp"
 #include <type_traits>
+// the prioritized replay's priority update as a rider (see conv32_input_grad_kernel's RIDER): glibc's pow with every fusion
+// explicit — no contraction inside these two headers, whatever this file is compiled with
+#pragma clang fp contract(off)
+#include "libm_pow.hpp"
+#include "per_update_body.hpp"
+#pragma clang fp contract(fast)
 
 namespace {
 
@@ -69,6 +75,14 @@ struct ConvBwdArgs {
     int B, T, act;
     unsigned long long *stamps;
 };
+struct PerRider {                                    // rlx_per_update's arguments (n <= 64 leaves)
+    double *sum, *mn, *mx, *max_priority;
+    const int *idx;
+    const double *err;
+    int *status;
+    double alpha, eps;
+    int cap, levels, n;
+};
 
 __device__ __forceinline__ float act_deriv(float y, int kind) {      // gemm.hip's: through the activation's OUTPUT
     if (kind == RLX_ACT_RELU) return y > 0.f ? 1.f : 0.f;
@@ -84,8 +98,20 @@ __device__ __forceinline__ float act_deriv(float y, int kind) {      // gemm.hip
 // matrix differ from the 32 x 32 x 2 chain in the last bits.
 // PF: how many jobs ahead a wave requests its B operands (PF + 1 register sets of 8 float4 in a ring): 1 = the original; a
 // tail job is half as long as a full one, so one job ahead no longer covers the load (rlx_conv32_prefetch).
-template <bool TAIL16, int PF>
-__global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const ConvBwdArgs a) {
+// RIDER (the DQN update: B = 32, one tower -> 64 workgroups on 256 CUs): one MORE workgroup, the last of the grid, runs
+// PrioritizedExperienceReplay.update_priorities (prioritized_experience_replay.py:203-217) of the batch's <= 64 leaves on its
+// first wave — a 10 us chain of dependent round trips that was a launch of its own behind every update.  Its inputs (the TD
+// errors) exist since the head's loss; nothing reads the trees before the next sample(); a CU that this launch leaves idle
+// takes it.  An instantiation of its own: the kernel the Clipped-PPO update runs is compiled without it.
+template <bool TAIL16, int PF, bool RIDER = false>
+__global__ void __launch_bounds__(kThreads, 2) conv32_input_grad_kernel(const ConvBwdArgs a, const PerRider rider) {
+    if (RIDER && (int)blockIdx.x == 2 * a.B * a.T) {
+        if (threadIdx.x < 64)
+            rlx_per::per_update_paths_body<true, false>(rider.sum, rider.mn, rider.mx, rider.cap, rider.levels, rider.idx,
+                                                        rider.err, nullptr, nullptr, rider.n, 0, rider.alpha, rider.eps,
+                                                        rider.max_priority, 0, rider.status);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
     float *const dcol = smem;
     float *const dz3s = dcol + kDcolFloats;
@@ -357,10 +383,11 @@ int rlx_conv32_input_grad_supported(int H, int W, int C, int k2, int s2, int c2,
     return H == H1 && W == W1 && C == C1 && k2 == K2 && s2 == S2 && c2 == C2 && k3 == K3 && s3 == 1 && c3 == C3;
 }
 
-int rlx_conv32_input_grad(const float *dz3, long long dz3_tower_stride, const float *w3, long long w3_tower_stride,
-                          const float *y2, long long y2_tower_stride, float *dz2, long long dz2_tower_stride,
-                          const float *w2, long long w2_tower_stride, const float *y1, long long y1_tower_stride,
-                          float *dz1, long long dz1_tower_stride, int batch, int towers, int activation, void *stream) {
+static int conv32_launch(const float *dz3, long long dz3_tower_stride, const float *w3, long long w3_tower_stride,
+                         const float *y2, long long y2_tower_stride, float *dz2, long long dz2_tower_stride,
+                         const float *w2, long long w2_tower_stride, const float *y1, long long y1_tower_stride,
+                         float *dz1, long long dz1_tower_stride, int batch, int towers, int activation,
+                         const rlx_per_update_desc *per, void *stream) {
     RLX_REQUIRE(dz3 && w3 && y2 && dz2 && w2 && y1 && dz1, "rlx_conv32_input_grad: null pointer");
     RLX_REQUIRE(batch >= 1 && towers >= 1 && (long long)batch * towers <= (1 << 20), "rlx_conv32_input_grad: bad batch / towers");
     RLX_REQUIRE(activation >= 0 && activation <= 2, "rlx_conv32_input_grad: unknown activation");
@@ -373,12 +400,44 @@ int rlx_conv32_input_grad(const float *dz3, long long dz3_tower_stride, const fl
                   w2, w2_tower_stride, y1, y1_tower_stride, dz1, dz1_tower_stride, batch, towers, activation, g_stamps};
     const unsigned grid = 2u * batch * towers;
     hipStream_t s = rlx::as_stream(stream);
-    if (g_tail16 && g_prefetch == 2) RLX_LAUNCH((conv32_input_grad_kernel<true, 2>), grid, kThreads, 0, s, a);
-    else if (g_tail16) RLX_LAUNCH((conv32_input_grad_kernel<true, 1>), grid, kThreads, 0, s, a);
-    else if (g_prefetch == 2) RLX_LAUNCH((conv32_input_grad_kernel<false, 2>), grid, kThreads, 0, s, a);
-    else RLX_LAUNCH((conv32_input_grad_kernel<false, 1>), grid, kThreads, 0, s, a);
+    PerRider r{};
+    if (per) {
+        RLX_REQUIRE(per->sum_tree && per->min_tree && per->max_tree && per->max_priority && per->status && per->idx &&
+                    per->td_errors, "rlx_conv32_input_grad_per_update: null pointer in the priority update");
+        RLX_REQUIRE(per->capacity > 0 && (per->capacity & (per->capacity - 1)) == 0,
+                    "rlx_conv32_input_grad_per_update: capacity %d is not a power of two", per->capacity);
+        RLX_REQUIRE(per->n >= 1 && per->n <= 64, "rlx_conv32_input_grad_per_update: 1 .. 64 leaves ride on the launch (got %d)", per->n);
+        int levels = 0;
+        while ((1 << levels) < per->capacity) ++levels;
+        r = PerRider{per->sum_tree, per->min_tree, per->max_tree, per->max_priority, per->idx, per->td_errors, per->status,
+                     per->alpha, per->epsilon, per->capacity, levels, per->n};
+        if (g_tail16) RLX_LAUNCH((conv32_input_grad_kernel<true, 1, true>), grid + 1, kThreads, 0, s, a, r);
+        else RLX_LAUNCH((conv32_input_grad_kernel<false, 1, true>), grid + 1, kThreads, 0, s, a, r);
+    }
+    else if (g_tail16 && g_prefetch == 2) RLX_LAUNCH((conv32_input_grad_kernel<true, 2>), grid, kThreads, 0, s, a, r);
+    else if (g_tail16) RLX_LAUNCH((conv32_input_grad_kernel<true, 1>), grid, kThreads, 0, s, a, r);
+    else if (g_prefetch == 2) RLX_LAUNCH((conv32_input_grad_kernel<false, 2>), grid, kThreads, 0, s, a, r);
+    else RLX_LAUNCH((conv32_input_grad_kernel<false, 1>), grid, kThreads, 0, s, a, r);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
+}
+
+int rlx_conv32_input_grad(const float *dz3, long long dz3_tower_stride, const float *w3, long long w3_tower_stride,
+                          const float *y2, long long y2_tower_stride, float *dz2, long long dz2_tower_stride,
+                          const float *w2, long long w2_tower_stride, const float *y1, long long y1_tower_stride,
+                          float *dz1, long long dz1_tower_stride, int batch, int towers, int activation, void *stream) {
+    return conv32_launch(dz3, dz3_tower_stride, w3, w3_tower_stride, y2, y2_tower_stride, dz2, dz2_tower_stride, w2,
+                         w2_tower_stride, y1, y1_tower_stride, dz1, dz1_tower_stride, batch, towers, activation, nullptr, stream);
+}
+
+int rlx_conv32_input_grad_per_update(const float *dz3, long long dz3_tower_stride, const float *w3, long long w3_tower_stride,
+                                     const float *y2, long long y2_tower_stride, float *dz2, long long dz2_tower_stride,
+                                     const float *w2, long long w2_tower_stride, const float *y1, long long y1_tower_stride,
+                                     float *dz1, long long dz1_tower_stride, int batch, int towers, int activation,
+                                     const rlx_per_update_desc *per, void *stream) {
+    RLX_REQUIRE(per != nullptr, "rlx_conv32_input_grad_per_update: null priority update");
+    return conv32_launch(dz3, dz3_tower_stride, w3, w3_tower_stride, y2, y2_tower_stride, dz2, dz2_tower_stride, w2,
+                         w2_tower_stride, y1, y1_tower_stride, dz1, dz1_tower_stride, batch, towers, activation, per, stream);
 }
 
 int rlx_conv32_tail_tiles(int sixteen_rows) {

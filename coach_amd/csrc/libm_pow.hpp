@@ -46,7 +46,11 @@ LIBM_POW_FN double from_bits(uint64_t u) {
 }
 }  // namespace libm_detail
 
-LIBM_POW_FN double libm_pow(double x, double y, int *inexact_domain) {
+// log_tab: kLogTab as [128 * 3] doubles, exp_tab: kExpTab [256] — the tables themselves, or a copy the caller keeps closer
+// (rlx_per_sample: in LDS, filled in the round trip that fetches the tree's top levels: each pow is otherwise two more
+// dependent loads on the kernel's critical path)
+LIBM_POW_FN double libm_pow_tabs(double x, double y, int *inexact_domain, const double *log_tab,
+                                 const unsigned long long *exp_tab) {
     using namespace libm_detail;
     const uint64_t ix = bits(x), iy = bits(y);
     const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
@@ -60,7 +64,7 @@ LIBM_POW_FN double libm_pow(double x, double y, int *inexact_domain) {
     const int64_t k = (int64_t)tmp >> 52;
     const double z = from_bits(ix - (tmp & (0xfffull << 52)));
     const double kd = (double)(int32_t)k;
-    const double invc = kLogTab[i][0], logc = kLogTab[i][1], logctail = kLogTab[i][2];
+    const double invc = log_tab[3 * i], logc = log_tab[3 * i + 1], logctail = log_tab[3 * i + 2];
     const double r = fma(z, invc, -1.0);
     const double t1 = fma(kd, kLn2Hi, logc);
     const double t2 = t1 + r;
@@ -98,8 +102,8 @@ LIBM_POW_FN double libm_pow(double x, double y, int *inexact_domain) {
     rr = fma(kk, kNegLn2LoN, rr);
     rr = elo + rr;
     const int idx = 2 * (int)(ki & 127);
-    const double tail = from_bits(kExpTab[idx]);
-    const uint64_t sbits = kExpTab[idx + 1] + (ki << 45);
+    const double tail = from_bits(exp_tab[idx]);
+    const uint64_t sbits = exp_tab[idx + 1] + (ki << 45);
     const double r2 = rr * rr;
     const double p23 = fma(rr, kExpPoly[1], kExpPoly[0]);
     const double s = rr + tail;
@@ -110,5 +114,10 @@ LIBM_POW_FN double libm_pow(double x, double y, int *inexact_domain) {
     const double scale = from_bits(sbits);
     return fma(tm, scale, scale);
 }
+
+LIBM_POW_FN double libm_pow(double x, double y, int *inexact_domain) {
+    return libm_pow_tabs(x, y, inexact_domain, &libm_detail::kLogTab[0][0], libm_detail::kExpTab);
+}
+constexpr int kLibmPowLogDoubles = 128 * 3, kLibmPowExpWords = 256;
 
 }  // namespace rlx

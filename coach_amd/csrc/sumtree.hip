@@ -19,6 +19,8 @@
 // (SURVEY.md §8(d)).
 #include "rlx_common.hpp"
 #include "libm_pow.hpp"
+#include "splitk_reduce_body.hpp"
+#include "per_update_body.hpp"
 #include <cmath>
 
 namespace {
@@ -141,26 +143,10 @@ per_update_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__r
 // stores are never waited for.  Parents are recomputed from (left, right) exactly like _propagate (:63-74):
 // bit-identical trees.  (A first version that found siblings through an LDS hash table was no faster than the kernel
 // above — four to five dependent LDS round trips per level; profiles/r03_ab_per_update.txt.)
-constexpr int kPathChunk = 20, kPathMaxLeaves = 256;
-#ifdef RLX_PER_PROFILE                  // tools/per_update_profile.hip: phase timestamps of thread 0 (100 MHz counter)
-__device__ long long g_per_prof[8];
-#define PER_PROF(k) do { if (threadIdx.x == 0) g_per_prof[k] = wall_clock64(); } while (0)
-#else
-#define PER_PROF(k) do {} while (0)
-#endif
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ double shfl_f64(double v, int lane) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __shfl((int)(b & 0xffffffffll), lane), hi = __shfl((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-struct __attribute__((aligned(16))) PathRec {     // what a run shows its neighbours (n > 64)
-    int node, lo, hi, pad;
-    double s, m, x, pad2;
-};
-
-// CONTIG: a store of n consecutive leaves that does not wrap around the ring — already in leaf order, one run per leaf
+// (the device body: per_update_body.hpp, shared with conv_bwd_fused.hip)
+using rlx_per::kPathChunk;
+using rlx_per::kPathMaxLeaves;
+using rlx_per::per_update_paths_body;
 template <bool WAVE, bool CONTIG>
 __global__ void __launch_bounds__(WAVE ? 64 : kPathMaxLeaves)
 per_update_paths_kernel(double *__restrict__ sum, double *__restrict__ mn, double *__restrict__ mx,
@@ -169,259 +155,136 @@ per_update_paths_kernel(double *__restrict__ sum, double *__restrict__ mn, doubl
                         const double *__restrict__ leaf_p, int n, int start_leaf, double alpha,
                         double eps, double *__restrict__ max_priority, int mode,
                         int *__restrict__ status) {
-    constexpr int kThreads = WAVE ? 64 : kPathMaxLeaves;
-    constexpr int kNoLeaf = 0x7fffffff;
-    PER_PROF(0);
-    __shared__ __attribute__((aligned(16))) int key[kThreads];
-    __shared__ int sorted_leaf[kThreads], sorted_lo[kThreads], sorted_hi[kThreads];
-    __shared__ double sorted_a[kThreads], sorted_b[kThreads];
-    __shared__ PathRec rec[WAVE ? 1 : 2][WAVE ? 1 : kPathMaxLeaves];
-    const int tid = threadIdx.x;
-    const double stored_priority = (mode == 1) ? *max_priority : alpha;
-    const bool ring = (mode == 1 || mode == 3);
-    // ---- inputs in launch order; an out-of-range index sorts behind everything and carries no node
-    int leaf = kNoLeaf;
-    double in_a = 0.0, in_b = 0.0;
-    if (tid < n) {
-        if (ring) {
-            leaf = (start_leaf + tid) & (cap - 1);
-        } else {
-            leaf = idx[tid];
-            if (mode == 0) in_a = err[tid];
-            else { in_a = leaf_pa[tid]; in_b = leaf_p[tid]; }
-            if (leaf < 0 || leaf >= cap) {          // reference raises ValueError (:123-126)
-                atomicOr(status, 1);
-                leaf = kNoLeaf;
-            }
-        }
+    per_update_paths_body<WAVE, CONTIG>(sum, mn, mx, cap, levels, idx, err, leaf_pa, leaf_p, n, start_leaf, alpha, eps,
+                                        max_priority, mode, status);
+}
+
+// update_priorities (:203-217) of <= 64 sampled leaves as the FIRST-dispatched workgroup of the backward pass's deferred
+// split-K reduction launch (rlx_splitk_reduce_jobs_per_update): the TD errors exist since the head's loss kernel, the
+// tree is not read again before the next sample() — the update needs no launch of its own in the chain of an off-policy
+// update (10.3 us of the C3 update: one workgroup, a chain of dependent round trips).  One wave of the workgroup works;
+// the other fifteen leave at once (s_barrier counts the surviving waves).
+struct PerUpdateDev {
+    double *sum, *mn, *mx, *max_priority;
+    const int *idx;
+    const double *err;
+    int *status;
+    double alpha, eps;
+    int cap, levels, n;
+};
+__global__ void __launch_bounds__(1024) splitk_reduce_jobs_per_kernel(const rlx_reduce::ReduceJobs jobs, const PerUpdateDev u) {
+    __shared__ float4 part[16][64];
+    if (blockIdx.z > 0) {
+        rlx_reduce::splitk_reduce_job_body(jobs.job[blockIdx.z - 1], part);
+        return;
     }
-    constexpr bool contiguous = CONTIG;
-    key[tid] = leaf;
-    lds_barrier();
-    // ---- order by leaf: position = number of occurrences that sort before this one (ties by launch order).  The
-    // occurrences of one leaf end up as one run whose LAST position is the last occurrence — the one that wins
-    // (:214-215).
-    if (!contiguous) {
-        int lo = 0, same = 0, before = 0;
-        const int n4 = (n + 3) & ~3;                      // keys behind n are kNoLeaf
-        for (int j = 0; j < n4; j += 4) {
-            const int4 k = *reinterpret_cast<const int4 *>(&key[j]);          // broadcast read
-            const int kk[4] = {k.x, k.y, k.z, k.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                lo += (kk[q] < leaf);
-                same += (kk[q] == leaf);
-                before += (kk[q] == leaf && j + q < tid);
-            }
-        }
-        if (tid < n) {
-            const int pos = lo + before;
-            sorted_leaf[pos] = leaf;
-            sorted_lo[pos] = lo;
-            sorted_hi[pos] = lo + same - 1;
-            sorted_a[pos] = in_a;
-            sorted_b[pos] = in_b;
-        }
-    }
-    lds_barrier();
-    // ---- from here on thread t IS position t
-    int node = -1;                      // heap index of the node this thread carries; -1: none
-    int lo = 0, hi = 0;
-    bool valid = false;                 // this occurrence may write its leaf
-    if (tid < n) {
-        if (contiguous) {
-            lo = hi = tid;
-        } else {
-            leaf = sorted_leaf[tid];
-            lo = sorted_lo[tid];
-            hi = sorted_hi[tid];
-            in_a = sorted_a[tid];
-            in_b = sorted_b[tid];
-        }
-        valid = leaf != kNoLeaf;
-        if (valid) node = leaf + cap - 1;
-    }
-    // the loads of every sibling the path will need on the next kPathChunk levels depend on the index alone: they
-    // are issued now and the pow and the leaf level run while they are in flight
-    double ps[kPathChunk], pm[kPathChunk], px[kPathChunk];
-    auto prefetch = [&](int lvl0) {
-        int a = node;
-#pragma unroll
-        for (int j = 0; j < kPathChunk; ++j) {
-            ps[j] = pm[j] = px[j] = 0.0;
-            if (a > 0 && lvl0 + j < levels) {
-                const int sib = (a & 1) ? a + 1 : a - 1;
-                // contiguous store: a sibling with a stored leaf below it is carried by a neighbouring run — its old
-                // value is never used, and near the leaves that is almost every sibling (the loads that remain are the
-                // two edges of the range and, higher up, one address shared by all threads)
-                bool covered = false;
-                if (CONTIG) {                                             // (cap <= 2^30: everything fits an int)
-                    const int h = lvl0 + j;                               // height of `a` and `sib` above the leaves
-                    const int p = sib + 1 - (cap >> h);                   // position within its level
-                    covered = (p << h) < start_leaf + n && ((p + 1) << h) > start_leaf;
-                }
-                if (!covered) { ps[j] = sum[sib]; pm[j] = mn[sib]; px[j] = mx[sib]; }
-                a = (a - 1) >> 1;
-            }
-        }
-    };
-    PER_PROF(1);
-    prefetch(0);
-    PER_PROF(2);
-    double s = 0.0, m = 0.0, x = 0.0;
-    if (tid < n) {
-        if (ring) {
-            x = stored_priority;
-            int odd = 0;
-            s = (mode == 1) ? rlx::libm_pow(x, alpha, &odd) : eps;     // maximal_priority ** alpha (:274)
-            if (odd) atomicOr(status, 4);
-        } else if (mode == 0) {
-            if (in_a < 0.0) {                       // "priorities must be non-negative" (:195)
-                atomicOr(status, 2);
-                valid = false;
-            }
-            x = in_a + eps;
-            int odd = 0;
-            s = rlx::libm_pow(x, alpha, &odd);                        // priority ** self.alpha (:197)
-            if (odd) atomicOr(status, 4);
-        } else {
-            s = in_a;
-            x = in_b;
-        }
-        m = s;
-    }
-    asm volatile("" : "+v"(s), "+v"(x));
-    PER_PROF(3);
-    // ---- leaf level: the winner shows its values, the other occurrences adopt them.  A rejected winner (negative
-    // error) leaves the leaf as it is; its run walks up with the leaf's present values, which recomputes its
-    // ancestors to what they already are — as the kernel above does.
-    {
-        const bool winner = (tid == hi);
-        int w_ok;
-        double ws, wm, wx;
-        if (WAVE) {
-            w_ok = __shfl((int)valid, hi);
-            ws = shfl_f64(s, hi); wm = shfl_f64(m, hi); wx = shfl_f64(x, hi);
-        } else {
-            if (tid < n) {
-                PathRec r;
-                r.node = valid ? 1 : 0; r.lo = lo; r.hi = hi; r.pad = 0;
-                r.s = s; r.m = m; r.x = x; r.pad2 = 0.0;
-                rec[1][tid] = r;
-            }
-            lds_barrier();
-            const PathRec w = rec[1][tid < n ? hi : 0];
-            w_ok = w.node; ws = w.s; wm = w.m; wx = w.x;
-        }
-        if (node >= 0) {
-            if (winner && valid) {
-                sum[node] = s;
-                mn[node] = m;
-                mx[node] = x;
-            } else if (w_ok) {
-                s = ws; m = wm; x = wx;
-            } else {
-                s = sum[node]; m = mn[node]; x = mx[node];
-            }
-        }
-    }
-    PER_PROF(4);
-    for (int lvl0 = 0; lvl0 < levels; lvl0 += kPathChunk) {
-        if (lvl0 > 0) prefetch(lvl0);                     // trees deeper than kPathChunk levels: one more round trip
-        // All prefetched values arrive HERE.  vmcnt counts loads and stores in issue order: a wait placed inside the
-        // levels below would also wait for the stores of the level before it — the round trip per level this kernel
-        // exists to avoid.
-#pragma unroll
-        for (int j = 0; j < kPathChunk; ++j) asm volatile("" : "+v"(ps[j]), "+v"(pm[j]), "+v"(px[j]));
-        PER_PROF(5);
-#pragma unroll
-        for (int j = 0; j < kPathChunk; ++j) {
-            if (lvl0 + j < levels) {                      // uniform
-                const bool left = (node & 1) != 0;        // odd heap index = left child (2p + 1)
-                const int sib = left ? node + 1 : node - 1;
-                const int cand = left ? hi + 1 : lo - 1;  // where the sibling's run must be, if it exists
-                const bool in_range = node > 0 && cand >= 0 && cand < n;
-                const int src = in_range ? cand : tid;
-                int r_node, r_lo, r_hi;
-                double r_s, r_m, r_x;
-                if (WAVE) {
-                    r_node = __shfl(node, src);
-                    const int ext = __shfl(lo | (hi << 8), src);
-                    r_lo = ext & 0xff; r_hi = ext >> 8;
-                    r_s = shfl_f64(s, src); r_m = shfl_f64(m, src); r_x = shfl_f64(x, src);
-                } else {
-                    const int buf = j & 1;                // (the leaf level used buffer 1; kPathChunk is even)
-                    if (tid < n) {
-                        PathRec r;
-                        r.node = node; r.lo = lo; r.hi = hi; r.pad = 0;
-                        r.s = s; r.m = m; r.x = x; r.pad2 = 0.0;
-                        rec[buf][tid] = r;
-                    }
-                    lds_barrier();                        // one barrier per level: the buffers alternate
-                    const PathRec r = rec[buf][src];
-                    r_node = r.node; r_lo = r.lo; r_hi = r.hi; r_s = r.s; r_m = r.m; r_x = r.x;
-                }
-                if (node > 0) {
-                    double bs = ps[j], bm = pm[j], bx = px[j];
-                    if (in_range && r_node == sib) {
-                        bs = r_s; bm = r_m; bx = r_x;
-                        if (left) hi = r_hi; else lo = r_lo;
-                    }
-                    // (left, right) order does not matter to the result: IEEE addition commutes, and python's
-                    // min(a, b) = b if b < a else a / max(a, b) = b if b > a else a pick between two values that are
-                    // bit-identical whenever neither is smaller (priorities are positive; a NaN sets status bit 4).
-                    node = (node - 1) >> 1;
-                    s = s + bs;                           // operator.add (:57)
-                    m = (bm < m) ? bm : m;
-                    x = (bx > x) ? bx : x;
-                    if (tid == lo) {                      // one thread per distinct node writes it to the tree
-                        sum[node] = s;
-                        mn[node] = m;
-                        mx[node] = x;
-                    }
-                }
-            }
-        }
-    }
-    PER_PROF(6);
-    // every path ends at the root with the root's values in registers: maximal_priority = max_tree root (:201)
-    if (!ring && node == 0 && tid == lo) *max_priority = x;
+    if (blockIdx.x != 0 || blockIdx.y != 0 || threadIdx.x >= 64) return;
+    per_update_paths_body<true, false>(u.sum, u.mn, u.mx, u.cap, u.levels, u.idx, u.err, nullptr, nullptr, u.n, 0, u.alpha,
+                                       u.eps, u.max_priority, 0, u.status);
 }
 
 // One draw per thread.  u[i] is CPython's random.random() drawn on the host, so that
 // val == random.uniform(seg*i, seg*(i+1)) bit for bit (:240-244).
-__global__ void per_sample_kernel(const double *__restrict__ sum, const double *__restrict__ mn,
-                                  int cap, const double *__restrict__ u, int batch,
-                                  double n_transitions, double beta, int *__restrict__ out_idx,
-                                  double *__restrict__ out_weight,
-                                  double *__restrict__ out_priority, long long stored_total,
-                                  long long payload_rows, int *__restrict__ out_rows) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= batch) return;
+//
+// _retrieve (:76-92) is a chain of log2(cap) dependent loads — 20 round trips to L2 / HBM for the 2^20-leaf tree, 8.5 us of
+// the C3 update's critical path as a plain loop.  Here (same comparisons on the same values: bit-identical leaves)
+//   * the top kTopSteps + 1 levels (<= 4095 nodes, 32 KB) are loaded into LDS by the whole block in ONE round trip,
+//     together with u[i] and the roots — every draw's first kTopSteps steps run from LDS;
+//   * below that a draw takes THREE levels per round trip: from node n it requests sum[] of the left child, of both
+//     possible left grandchildren and of all eight possible great-grandchildren (11 loads in flight), then takes the
+//     three steps from registers.  The number of LDS steps is chosen so that the rest is a multiple of three: the last
+//     step of the last group holds both leaves, so the leaf value needs no load of its own.
+// 4 round trips instead of 21 for the 2^20-leaf tree.
+constexpr int kSampleThreads = 256, kTopMaxSteps = 11;
+__global__ void __launch_bounds__(kSampleThreads)
+per_sample_kernel(const double *__restrict__ sum, const double *__restrict__ mn,
+                  int cap, int levels, int top_steps, const double *__restrict__ u, int batch,
+                  double n_transitions, double beta, int *__restrict__ out_idx,
+                  double *__restrict__ out_weight,
+                  double *__restrict__ out_priority, long long stored_total,
+                  long long payload_rows, int *__restrict__ out_rows) {
+    extern __shared__ __attribute__((aligned(16))) double top[];         // nodes [0, 2^(top_steps + 1) - 1)
+    __shared__ double log_tab[rlx::kLibmPowLogDoubles];                  // glibc's pow tables: filled in the same round trip
+    __shared__ unsigned long long exp_tab[rlx::kLibmPowExpWords];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kSampleThreads + tid;
     const int n_nodes = 2 * cap - 1;
-    const double total = sum[0];
+    const int n_top = (2 << top_steps) - 1;                              // <= n_nodes (top_steps <= levels)
+    const double ui = i < batch ? u[i] : 0.0;
+    const double mn0 = mn[0];
+    {
+        const double *lt = &rlx::libm_detail::kLogTab[0][0];
+        static_assert(rlx::kLibmPowLogDoubles <= 2 * kSampleThreads && rlx::kLibmPowExpWords <= kSampleThreads, "pow tables");
+        const double l0 = lt[tid], l1 = lt[min(tid + kSampleThreads, rlx::kLibmPowLogDoubles - 1)];
+        const unsigned long long e0 = rlx::libm_detail::kExpTab[tid];
+        log_tab[tid] = l0;
+        if (tid + kSampleThreads < rlx::kLibmPowLogDoubles) log_tab[tid + kSampleThreads] = l1;
+        exp_tab[tid] = e0;
+    }
+    for (int k0 = tid; k0 < n_top; k0 += 8 * kSampleThreads) {           // eight loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = sum[min(k0 + j * kSampleThreads, n_top - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j * kSampleThreads < n_top) top[k0 + j * kSampleThreads] = v[j];
+    }
+    __syncthreads();
+    if (i >= batch) return;
+    const double total = top[0];
     const double segment_size = total / (double)batch;                   // (:232)
-    const double min_probability = mn[0] / total;                        // (:235)
+    const double min_probability = mn0 / total;                          // (:235)
     int odd = 0;                                  // (an empty tree gives inf/nan here, as in the reference)
-    const double max_weight = rlx::libm_pow(min_probability * n_transitions, -beta, &odd);  // (:236)
+    const double max_weight = rlx::libm_pow_tabs(min_probability * n_transitions, -beta, &odd, log_tab, exp_tab);  // (:236)
     const double a = segment_size * (double)i;                           // (:240)
     const double b = segment_size * (double)(i + 1);                     // (:241)
-    double val = a + (b - a) * u[i];                                     // random.uniform
+    double val = a + (b - a) * ui;                                       // random.uniform
     int node = 0;
-    while (true) {                                                       // _retrieve (:76-92)
-        int left = 2 * node + 1;
-        if (left >= n_nodes) break;
-        double tl = sum[left];
-        if (val <= tl) {
-            node = left;
-        } else {
-            val = val - tl;
-            node = left + 1;
+    double leaf_value = total;                                           // (cap == 1: the root is the leaf)
+    bool have = cap == 1;
+#define RLX_PER_STEP(tl, tr, have_r)                                     \
+    if (val <= (tl)) { node = left; leaf_value = (tl); have = true; }    \
+    else { val = val - (tl); node = left + 1; leaf_value = (tr); have = (have_r); }
+    for (int s = 0; s < top_steps; ++s) {                                // _retrieve (:76-92), levels held in LDS
+        const int left = 2 * node + 1;
+        const double tl = top[left], tr = top[left + 1];
+        RLX_PER_STEP(tl, tr, true)
+    }
+    for (int s = top_steps; s < levels; s += 3) {                        // three levels per round trip
+        const int l1 = 2 * node + 1;                                     // children l1, l1 + 1
+        const int l2 = 2 * l1 + 1;                                       // grandchildren l2 .. l2 + 3
+        const int l3 = 2 * l2 + 1;                                       // great-grandchildren l3 .. l3 + 7
+        const bool two = s + 1 < levels, three = s + 2 < levels;
+        const double c1 = sum[l1];
+        double g[2] = {0.0, 0.0}, h[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (two) { g[0] = sum[l2]; g[1] = sum[l2 + 2]; }
+        if (three) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h[k] = sum[l3 + k];
+        }
+        {
+            const int left = l1;
+            RLX_PER_STEP(c1, 0.0, false)
+        }
+        if (two) {
+            const int left = 2 * node + 1;
+            const double tl = node == l1 ? g[0] : g[1];
+            RLX_PER_STEP(tl, 0.0, false)
+        }
+        if (three) {
+            const int left = 2 * node + 1, k = left - l3;                // 0, 2, 4 or 6
+            double tl = h[0], tr = h[1];
+            if (k == 2) { tl = h[2]; tr = h[3]; }
+            if (k == 4) { tl = h[4]; tr = h[5]; }
+            if (k == 6) { tl = h[6]; tr = h[7]; }
+            RLX_PER_STEP(tl, tr, true)
         }
     }
-    const double leaf_value = sum[node];
+#undef RLX_PER_STEP
+    if (!have) leaf_value = sum[node];
+    (void)n_nodes;
     const double priority = leaf_value / total;                          // (:247)
-    const double weight = rlx::libm_pow(n_transitions * priority, -beta, &odd);   // (:248)
+    const double weight = rlx::libm_pow_tabs(n_transitions * priority, -beta, &odd, log_tab, exp_tab);   // (:248)
     out_idx[i] = node - cap + 1;
     out_weight[i] = weight / max_weight;                                 // (:249)
     if (out_priority) out_priority[i] = leaf_value;
@@ -556,6 +419,46 @@ int rlx_libm_pow(const double *x, const double *y, double *out, int n, int *stat
     return RLX_OK;
 }
 
+int rlx_splitk_reduce_jobs_per_update(const rlx_splitk_job *jobs_host, int n_jobs, double *sum_tree, double *min_tree,
+                                      double *max_tree, int capacity, const int *idx, const double *td_errors, int n,
+                                      double alpha, double epsilon, double *max_priority, int *status, void *stream) {
+    RLX_REQUIRE(jobs_host && n_jobs >= 0 && n_jobs <= RLX_MAX_SPLITK_JOBS,
+                "rlx_splitk_reduce_jobs_per_update: 0..%d jobs (got %d)", RLX_MAX_SPLITK_JOBS, n_jobs);
+    RLX_REQUIRE(sum_tree && min_tree && max_tree && max_priority && status && idx && td_errors,
+                "rlx_splitk_reduce_jobs_per_update: null pointer");
+    RLX_REQUIRE(is_pow2(capacity), "rlx_splitk_reduce_jobs_per_update: capacity %d is not a power of two", capacity);
+    RLX_REQUIRE(n >= 1 && n <= 64, "rlx_splitk_reduce_jobs_per_update: 1 .. 64 leaves ride on the launch (got %d)", n);
+    rlx_reduce::ReduceJobs jobs;
+    int m = 0, gx = 1, gy = 1;
+    for (int i = 0; i < n_jobs; ++i) {
+        const rlx_splitk_job &j = jobs_host[i];
+        if (j.splits <= 1) continue;
+        RLX_REQUIRE(j.partials && j.C && j.M > 0 && j.N > 0 && j.N % 4 == 0 && j.batch > 0 &&
+                    (long long)j.M * j.N < (1LL << 31) && (((uintptr_t)j.partials) & 15) == 0,
+                    "rlx_splitk_reduce_jobs_per_update: job %d is not a float4-reducible product", i);
+        jobs.job[m++] = j;
+        const int bx = (int)(((long long)j.M * j.N / 4 + 63) / 64);
+        gx = bx > gx ? bx : gx;
+        gy = j.batch > gy ? j.batch : gy;
+    }
+    if (m == 0)
+        return rlx_per_update(sum_tree, min_tree, max_tree, capacity, idx, td_errors, n, alpha, epsilon, max_priority, status,
+                              stream);
+    PerUpdateDev u;
+    u.sum = sum_tree; u.mn = min_tree; u.mx = max_tree; u.max_priority = max_priority; u.idx = idx; u.err = td_errors;
+    u.status = status; u.alpha = alpha; u.eps = epsilon; u.cap = capacity; u.levels = ilog2(capacity); u.n = n;
+    RLX_LAUNCH((splitk_reduce_jobs_per_kernel), dim3(gx, gy, m + 1), 1024, 0, rlx::as_stream(stream), jobs, u);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+static int g_sample_top_steps = 8;            // tools/per_sample_bench.py: 8 levels from LDS + 4 groups of three beat 11 + 3 (9.8 against 10.4 us)
+int rlx_per_sample_top_steps(int steps) {           /* A/B: the most tree levels rlx_per_sample descends from LDS (default 8) */
+    RLX_REQUIRE(steps >= 0 && steps <= kTopMaxSteps, "rlx_per_sample_top_steps: 0 .. %d", kTopMaxSteps);
+    g_sample_top_steps = steps;
+    return RLX_OK;
+}
+
 int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,
                    const double *uniforms, int batch, double num_transitions, double beta,
                    int *out_idx, double *out_weight, double *out_priority, long long stored_total,
@@ -567,9 +470,15 @@ int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,
     RLX_REQUIRE(!out_rows || (stored_total >= 0 && payload_rows >= capacity),
                 "rlx_per_sample: the payload ring (%lld rows) is smaller than the tree (%d leaves)",
                 payload_rows, capacity);
-    int threads = 64;
-    RLX_LAUNCH((per_sample_kernel), (batch + threads - 1) / threads, threads, 0, rlx::as_stream(stream), sum_tree, min_tree, capacity, uniforms, batch, num_transitions, beta, out_idx, out_weight,
-        out_priority, stored_total, payload_rows, out_rows);
+    int levels = 0;
+    while ((1 << levels) < capacity) ++levels;
+    // steps taken from LDS: the most (<= kTopMaxSteps) that leave a multiple of three for the three-level groups
+    int top_steps = levels < g_sample_top_steps ? levels : g_sample_top_steps;
+    while (top_steps > 0 && (levels - top_steps) % 3 != 0) --top_steps;
+    const size_t lds = sizeof(double) * (size_t)((2 << top_steps) - 1);
+    RLX_LAUNCH((per_sample_kernel), (batch + kSampleThreads - 1) / kSampleThreads, kSampleThreads, lds, rlx::as_stream(stream),
+               sum_tree, min_tree, capacity, levels, top_steps, uniforms, batch, num_transitions, beta, out_idx, out_weight,
+               out_priority, stored_total, payload_rows, out_rows);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -49,6 +49,8 @@ class ExperienceReplayParameters(MemoryParameters):      # experience_replay.py:
 
 
 class ExperienceReplay(Memory):
+    GATHER_ONE_LAUNCH = True     # image replay: the batch's small columns ride on the frame gather's launch
+
     def __init__(self, max_size, allow_duplicates_in_batch_sampling=True, device=None, n_env=1,
                  observation_shape=None, stack=None, action_dim=None, min_episode_length=1):
         """
@@ -360,6 +362,13 @@ class ExperienceReplay(Memory):
         if not self.image:
             pairs += [(self.obs, b["state"]), (self.next_obs, b["next_state"])]
         pairs += [(src, b[key]) for src, key in self._extra_gather_columns()]
+        if self.image and self.stack == 4 and self.GATHER_ONE_LAUNCH and \
+                all((src[0].numel() if src.dim() > 1 else 1) * src.element_size() * size <= 65536 for src, _ in pairs):
+            # the small columns ride on the frame gather's launch (rlx_imgreplay_gather_columns)
+            self.lib.imgreplay_gather_columns(self.ring, self.t_fpos, self.t_epoff, rows, size, self.n_env, self.F,
+                                              self.fb, self.stack, self.rows, b["state"], b["next_state"],
+                                              _rlx.make_columns(pairs), len(pairs), self.status, s)
+            return
         self.lib.copy_columns(_rlx.make_columns(pairs), len(pairs), rows, None, 0, 0, self.rows, size,
                               size, self.status, s)
         if self.image:

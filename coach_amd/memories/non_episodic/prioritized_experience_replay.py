@@ -52,6 +52,8 @@ class PrioritizedExperienceReplayParameters(ExperienceReplayParameters):     # :
 
 
 class PrioritizedExperienceReplay(ExperienceReplay):
+    ZERO_COPY_DRAWS = True       # the B uniform draws of a sample() are read by the kernel from pinned host memory (no blit)
+
     def __init__(self, max_size, alpha=0.6, beta=None, epsilon=1e-6,
                  allow_duplicates_in_batch_sampling=True, exact_pow="device", **device_kwargs):
         if max_size[0] != MemoryGranularity.Transitions:                                   # :173-175
@@ -134,11 +136,15 @@ class PrioritizedExperienceReplay(ExperienceReplay):
             slot += 1
         self._live_slots.add(slot)
         p = self._per_buffers(size, slot)
-        p["u_stage"].push(u)
-        self.lib.per_sample(self.sum_tree, self.min_tree, self.power_of_2_size, p["u"], size,
+        st = p["u_stage"]
+        mapped = self.ZERO_COPY_DRAWS and st.cuda
+        u_dev = st.push_mapped(u) if mapped else st.push(u)       # mapped: rlx_per_sample reads the pinned slot itself
+        self.lib.per_sample(self.sum_tree, self.min_tree, self.power_of_2_size, u_dev, size,
                             float(self.num_transitions()), float(self.beta.current_value), p["idx"],
                             p["weight"], None, self.committed_total, self.rows, p["rows"],
                             _rlx.current_stream())
+        if mapped:
+            st.mapped_done()
         self.beta.step()
         return slot
 
@@ -189,6 +195,15 @@ class PrioritizedExperienceReplay(ExperienceReplay):
             self.lib.per_update(self.sum_tree, self.min_tree, self.max_tree, self.power_of_2_size,
                                 indices, error_values, n, self.alpha, self.epsilon, self.max_priority,
                                 self.status, s)
+
+    def priority_update_args(self, indices, error_values):
+        """the arguments of rlx_per_update for update_priorities(indices, error_values), or None where the update cannot ride
+        on another launch (host pow, more than 64 leaves): what nn.graph.Context.per_tail takes."""
+        n = int(indices.numel())
+        if self.host_pow or n < 1 or n > 64 or n != int(error_values.numel()):
+            return None
+        return (self.sum_tree, self.min_tree, self.max_tree, self.power_of_2_size, indices, error_values, n,
+                self.alpha, self.epsilon, self.max_priority, self.status)
 
     def check_status(self):
         s = int(self.status.item())

@@ -142,8 +142,15 @@ FUSE_CONV_FIRST = True
 # Round 5 left it OFF (-2 us per C2 update: the weight-gradient products it leaves behind cost 14 us each as tiled launches of
 # their own, profiles/r05_ab_conv32.txt); ON since those products run through rlx_conv_dw_f32 (11.5 / 12.9 us):
 # 182.3 against 188.8 us per update (profiles/r06_ab_conv_dw_f32.txt).  bench.py --fuse-conv-bwd 0 / 1 is the A/B.
+# At 64 half-image workgroups (the DQN update: B = 32, one tower) the chain alone is no faster than the two tiled pairs + col2im
+# it replaces (24.3 against 33.7 us, but it leaves the weight gradients behind); with all three weight gradients in ONE
+# LDS-resident launch behind it (conv1 through conv_dw_u8_body_half) the C3 update is 143.3 against 150.1 us
+# (gpurun_out/r06_call34, profiles/r06_ab_c3_backward.txt).
 FUSE_CONV_INPUT_GRADS = True
-FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = 192
+FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = 64
+# a pending PrioritizedExperienceReplay priority update (Context.per_tail) rides on the fused input-gradient launch while
+# that launch leaves CUs idle (one workgroup per CU: 115 KB of LDS each); behind a full chip it would start last
+PER_RIDER_MAX_WORKGROUPS = 256
 # Wave groups per K slab of the fused forward launch (rlx_conv23_forward / rlx_conv123_forward).  None: what the tiled launches
 # would have used at this batch (2 for two towers of 63 .. 75 images — the third convolution then runs on four of the
 # eight waves, as the tiled kernel split its K chain — 4 for acting and the DQN update): the fused launch is then
@@ -278,10 +285,12 @@ class Context:
     def flush_deferred(self):
         jobs, self.deferred = self.deferred, None
         tail, self.ppo_tail = self.ppo_tail, None      # (ppo_fc_rows: the heads' all-rows part rides on this launch)
-        if jobs or tail is not None:
-            _rlx.splitk_reduce_jobs(jobs or [], self.stream, ppo_tail=tail)
+        per, self.per_tail = self.per_tail, None       # (prioritized replay: update_priorities rides on this launch)
+        if jobs or tail is not None or per is not None:
+            _rlx.splitk_reduce_jobs(jobs or [], self.stream, ppo_tail=tail, per_tail=per)
 
     ppo_tail = None
+    per_tail = None            # set by the agent in front of an update: PrioritizedExperienceReplay.priority_update_args()
 
     def flush_ppo_tail(self):
         """the pending all-rows part of ppo_fc_rows as a launch of its own (no deferred-reduction launch took it along)."""
@@ -1157,7 +1166,14 @@ class Sequential:
         args = (dz3, M3 * b.Co, p.w(b.kname, t0_, weights), p.stride(b.kname), x2.data, M2 * a.Co, dz2, M2 * a.Co,
                 p.w(a.kname, t0_, weights), p.stride(a.kname), x1.data, M1 * a.C, dz1, M1 * a.C, B, T,
                 _rlx.ACT[x2.act], ctx.stream)
-        run = lambda: lib.conv32_input_grad(*args)
+        per, ctx.per_tail = ctx.per_tail, None
+        if per is not None and 2 * B * T + 1 <= PER_RIDER_MAX_WORKGROUPS:
+            # the prioritized replay's priority update as one more workgroup of this launch (a CU it leaves idle takes it)
+            pd = _rlx.per_update_desc(per)
+            run = lambda: lib.conv32_input_grad_per_update(*args[:-1], ctypes.byref(pd), args[-1])
+        else:
+            ctx.per_tail = per
+            run = lambda: lib.conv32_input_grad(*args)
         _rlx._record(tuple(descs), run)
         run()
         x2.grad_is_dz, x1.grad_is_dz = x2.act is not None, x1.act is not None

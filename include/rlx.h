@@ -120,6 +120,27 @@ int rlx_conv32_input_grad(const float *dz3, long long dz3_tower_stride, const fl
                           const float *y2, long long y2_tower_stride, float *dz2, long long dz2_tower_stride,
                           const float *w2, long long w2_tower_stride, const float *y1, long long y1_tower_stride,
                           float *dz1, long long dz1_tower_stride, int batch, int towers, int activation, void *stream);
+/* The same launch with PrioritizedExperienceReplay.update_priorities (prioritized_experience_replay.py:203-217; called right
+ * behind learn_from_batch, agents/dqn_agent.py:106-109) of the batch's n <= 64 sampled leaves as ONE MORE workgroup: the
+ * arguments of rlx_per_update as a structure.  The DQN update (batch 32, one tower) fills 64 of 256 CUs with this launch; the
+ * priority update — a 10 us chain of dependent round trips, so far a launch of its own behind every update — runs beside it.
+ * Its inputs (the TD errors) exist since the head's loss and nothing reads the trees before the next sample(): trees
+ * bit-identical to rlx_per_update's (same device code: coach_amd/csrc/per_update_body.hpp). */
+typedef struct rlx_per_update_desc {
+    double *sum_tree, *min_tree, *max_tree;
+    int capacity;
+    const int *idx;
+    const double *td_errors;
+    int n;
+    double alpha, epsilon;
+    double *max_priority;
+    int *status;
+} rlx_per_update_desc;
+int rlx_conv32_input_grad_per_update(const float *dz3, long long dz3_tower_stride, const float *w3, long long w3_tower_stride,
+                                     const float *y2, long long y2_tower_stride, float *dz2, long long dz2_tower_stride,
+                                     const float *w2, long long w2_tower_stride, const float *y1, long long y1_tower_stride,
+                                     float *dz1, long long dz1_tower_stride, int batch, int towers, int activation,
+                                     const rlx_per_update_desc *per, void *stream);
 /* diagnostics as rlx_conv23_debug_stamps: [8 w + 0 .. 5] = entry, first product's operands staged, its K loop done,
  * second product's operands staged (= first gather done), its K loop done, exit */
 int rlx_conv32_debug_stamps(void *buffer);
@@ -170,6 +191,7 @@ int rlx_per_sample(const double *sum_tree, const double *min_tree, int capacity,
                                                                         out_rows (optional): payload-ring row of every sampled
                                                                         leaf when the ring holds payload_rows >= capacity rows
                                                                         and stored_total transitions were stored so far */
+int rlx_per_sample_top_steps(int steps);   /* A/B knob: the most tree levels rlx_per_sample descends from LDS (0 .. 11, default 8) */
 
 int rlx_libm_pow(const double *x, const double *y, double *out, int n, int *status,
                  void *stream);  /* out[i] = x[i] ** y[i] as the host libm rounds it (test hook of
@@ -213,6 +235,13 @@ int rlx_imgreplay_gather(const unsigned char *ring, const int *t_fpos,
                          int stack, long long capacity, unsigned char *out_state,
                          unsigned char *out_next, int *status,
                          void *stream);                              /* LazyStack.__array__ (:37-41) for a batch */
+/* rlx_imgreplay_gather of sampled rows (stack == 4) + rlx_copy_columns(columns, src_idx = idx, n = batch) of the batch's
+ * small columns (actions, rewards, game_overs: core_types.py:488-649) as ONE launch: the columns are gathered by one
+ * more workgroup of the same grid (row_bytes * batch <= 65536 per column; the columns' tables have `capacity` rows). */
+int rlx_imgreplay_gather_columns(const unsigned char *ring, const int *t_fpos, const unsigned char *t_epoff,
+                                 const int *idx, int batch, int n_env, int ring_frames, int frame_bytes, int stack,
+                                 long long capacity, unsigned char *out_state, unsigned char *out_next,
+                                 const rlx_column *columns_host, int ncols, int *status, void *stream);
 
 /* ------------------------------------- returns / GAE / episode stats (K8 / K12) -- */
 /* n_seq independent trajectories of seq_len steps, contiguous; game_overs cut episodes inside a
@@ -653,6 +682,14 @@ int rlx_ppo_fc_rows_supported(const rlx_gemm_desc *fc, int n_actions);
 int rlx_ppo_fc_rows(const rlx_gemm_desc *fc, const rlx_ppo_rows_desc *rows, void *stream);
 int rlx_ppo_heads_tail(const rlx_ppo_rows_desc *rows, void *stream);
 int rlx_splitk_reduce_jobs_ppo_tail(const rlx_splitk_job *jobs_host, int n_jobs, const rlx_ppo_rows_desc *rows, void *stream);
+/* rlx_splitk_reduce_jobs + rlx_per_update(idx, td_errors, n <= 64) as ONE launch: PrioritizedExperienceReplay.
+ * update_priorities (memories/non_episodic/prioritized_experience_replay.py:203-217; called right behind learn_from_batch,
+ * agents/dqn_agent.py:106-109) is one workgroup, dispatched first, of the backward pass's deferred-reduction launch — the TD
+ * errors exist since the head's loss, and nothing reads the trees before the next sample().  Trees bit-identical to
+ * rlx_per_update's.  No deferred job with splits > 1: rlx_per_update as a launch of its own. */
+int rlx_splitk_reduce_jobs_per_update(const rlx_splitk_job *jobs_host, int n_jobs, double *sum_tree, double *min_tree,
+                                      double *max_tree, int capacity, const int *idx, const double *td_errors, int n,
+                                      double alpha, double epsilon, double *max_priority, int *status, void *stream);
 
 /* -------------------------------------------------------- head losses (K9) -- */
 /* loss = mean_b(loss_weight * w_b * sum_j l(target, out)); kind 0 = MSE, 1 = Huber(delta 1).

@@ -80,8 +80,10 @@ def test_default_tail_tiles_in_a_ppo_update(rlx, dev):
 
 def test_small_batches_keep_the_per_layer_launches(rlx, dev):
     """fewer half images than workgroups the chip wants (FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS): the pair launches stay"""
-    new = _update(dev, 32, 4, "tanh", True)
+    new = _update(dev, 12, 4, "tanh", True)           # two towers x 12 images = 48 half images < 64
     assert not any("conv32" in n for n in new[3]) and sum("col2im" in n for n in new[3]) == 2, new[3]
+    new = _update(dev, 32, 4, "tanh", True)           # 128 half images (round 6: taken from 64 on, the DQN update's count)
+    assert any("conv32" in n for n in new[3]) and not any("col2im" in n for n in new[3]), new[3]
 
 
 def test_the_kernel_alone_against_gemm_and_col2im(rlx, dev):

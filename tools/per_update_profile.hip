@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         long long p[8];
-        CK(hipMemcpyFromSymbol(p, HIP_SYMBOL(g_per_prof), sizeof(p)));
+        CK(hipMemcpyFromSymbol(p, HIP_SYMBOL(rlx_per::g_per_prof), sizeof(p)));
         printf("%s rep %d  n %d  events %.1f us |", store ? "store " : "update", rep, n, ms * 1e3);
         for (int k = 0; k < 6; ++k) printf("  %s %.2f", names[k], (p[k + 1] - p[k]) * 0.01);
         printf("  | in-kernel total %.2f us\n", (p[6] - p[0]) * 0.01);
