@@ -13,6 +13,7 @@
 // Elementwise, HBM-bound, a few hundred bytes per launch at the BASELINE batch sizes: the point
 // of these kernels is that Q values never leave the device between the two network passes.
 #include "rlx_common.hpp"
+#include "dense_small_body.hpp"
 
 namespace {
 
@@ -103,6 +104,81 @@ dqn_head_loss_kernel(const float *__restrict__ q, long long ld_q, const float *_
         __syncthreads();
     }
     if (i == 0 && loss) loss[0] = red[0] / (float)batch;
+}
+
+// The same TD targets / |TD errors| / loss / dQ AND the Q head's backward pass (dW, db, dx with the lower layer's
+// activation derivative: tf.gradients through the head's Dense layer, architecture.py:312-385) in ONE launch
+// (rlx_dqn_head_loss_backward) — as rlx_ppo_heads_loss_backward does for the Clipped-PPO heads: the loss kernel is 1-2 us of
+// work behind a launch boundary, and its output dQ [B, A] is what every workgroup of the head's backward stages into LDS
+// first.  Each workgroup computes the rows itself (one row per thread, the arithmetic above: one rounding), under the
+// latency of its weight and input loads; the workgroup of feature block 0 writes dQ, the TD errors and the loss scalar
+// (the same tree over `red_threads` terms as the stand-alone kernel's blockDim: bit-identical scalar).
+struct DqnHeadBwdArgs {
+    rlx_small::SmallDenseBwd head;               // .dy receives dQ (written by feature block 0)
+    const float *q; long long ld_q;
+    const float *q_next, *q_sel; long long ld_next;
+    const int *actions;
+    const float *rewards;
+    const unsigned char *dones;
+    const double *weights;
+    double discount;
+    double *td_errors;
+    float *loss;
+    int *status;
+    int batch, n_actions, huber, red_threads;
+    float grad_scale;
+};
+
+template <int NN>
+__global__ void __launch_bounds__(256) dqn_head_loss_bwd_kernel(const DqnHeadBwdArgs a) {
+    extern __shared__ float smem[];
+    __shared__ float red[256];
+    const bool writer = blockIdx.x == 0;
+    const int i = threadIdx.x, B = a.batch, A = a.n_actions;
+    float *dz = smem;                                         // [B][A]
+    auto stage = [&]() {
+        float term = 0.f;
+        if (i < B) {
+            const float *qs = a.q_sel + (size_t)i * a.ld_next;
+            int best = 0;
+            float bv = qs[0];
+            for (int k = 1; k < A; ++k)
+                if (qs[k] > bv) { bv = qs[k]; best = k; }              // np.argmax: first maximum
+            const int act = a.actions[i];
+            if (act < 0 || act >= A) {
+                if (writer) atomicOr(a.status, 1);
+                for (int k = 0; k < A; ++k) dz[(size_t)i * A + k] = 0.f;
+            } else {
+                const double qn = (double)a.q_next[(size_t)i * a.ld_next + best];
+                const double y = (double)a.rewards[i] + (1.0 - (a.dones[i] ? 1.0 : 0.0)) * a.discount * qn;   // :100-101
+                const float qa = a.q[(size_t)i * a.ld_q + act];
+                if (writer && a.td_errors) a.td_errors[i] = fabs(y - (double)qa);                              // :102
+                const float y32 = (float)y;                                                                     // :103
+                const float e = qa - y32;
+                const float w = a.weights ? (float)a.weights[i] : 1.f;
+                float l, g;
+                if (!a.huber) { l = e * e; g = 2.f * e; }
+                else { const float ae = fabsf(e); l = ae <= 1.f ? 0.5f * e * e : ae - 0.5f; g = fminf(fmaxf(e, -1.f), 1.f); }
+                term = w * l;
+                for (int k = 0; k < A; ++k) dz[(size_t)i * A + k] = k == act ? a.grad_scale * w * g / (float)B : 0.f;
+            }
+        }
+        if (writer) {                                         // (block-uniform) the stand-alone kernel's tree over its blockDim
+            red[i] = i < a.red_threads ? term : 0.f;
+            __syncthreads();
+            for (int d = a.red_threads >> 1; d > 0; d >>= 1) {
+                if (i < d) red[i] += red[i + d];
+                __syncthreads();
+            }
+            if (i == 0 && a.loss) a.loss[0] = red[0] / (float)B;
+        }
+        __syncthreads();
+        if (writer && a.head.dy) {                            // dQ, for whoever reads q.grad
+            float *dy = const_cast<float *>(a.head.dy);
+            for (int k = threadIdx.x; k < B * A; k += 256) dy[k] = dz[k];
+        }
+    };
+    rlx_small::dense_small_bwd_body<NN, 16, 16, true>(a.head, blockIdx.x, 0, smem, stage);
 }
 
 // TD = r + (1 - done) * discount * q      (or r + discount * q), optionally clipped.
@@ -246,6 +322,43 @@ int rlx_dqn_head_loss(const float *q_online, long long ld_q, const float *q_next
     RLX_LAUNCH((dqn_head_loss_kernel), 1, threads, 0, rlx::as_stream(stream), q_online, ld_q, q_next_target, q_next_selector, ld_next, actions, rewards, game_overs,
         importance_weights, discount, batch, n_actions, huber, grad_scale, dq, ld_dq, td_errors,
         td_targets, ld_targets, loss_scalar, status);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_dqn_head_loss_backward(const rlx_small_dense_problem *q_head, const float *q_online, long long ld_q,
+                               const float *q_next_target, const float *q_next_selector, long long ld_next,
+                               const int *actions, const float *rewards, const unsigned char *game_overs,
+                               const double *importance_weights, double discount, int batch, int n_actions, int huber,
+                               float grad_scale, double *td_errors, float *loss_scalar, int *status, void *stream) {
+    RLX_REQUIRE(q_head && q_online && q_next_target && actions && rewards && game_overs && status,
+                "rlx_dqn_head_loss_backward: null pointer");
+    RLX_REQUIRE(q_head->x && q_head->w && q_head->dy && (q_head->dw || q_head->dx), "rlx_dqn_head_loss_backward: null pointer in the head");
+    RLX_REQUIRE(q_head->towers == 1 && q_head->M == batch && q_head->N == n_actions && q_head->K > 0 && q_head->activation == 0 &&
+                    q_head->lower_activation >= 0 && q_head->lower_activation <= 2,
+                "rlx_dqn_head_loss_backward: the head must be one linear tower [batch] x [K] -> [n_actions]");
+    RLX_REQUIRE(batch >= 1 && batch <= 256 && n_actions >= 1 && n_actions <= rlx_small::kMaxN && ld_q >= n_actions &&
+                    ld_next >= n_actions,
+                "rlx_dqn_head_loss_backward: 1 <= batch <= 256 (one row per thread), 1 <= actions <= %d", rlx_small::kMaxN);
+    if (!q_next_selector) q_next_selector = q_next_target;
+    const int NN = n_actions <= 1 ? 1 : n_actions <= 4 ? 4 : n_actions <= 8 ? 8 : 16;
+    const size_t smem = ((size_t)batch * n_actions + 16 * 16 * NN) * sizeof(float);
+    RLX_REQUIRE(smem <= 64 * 1024, "rlx_dqn_head_loss_backward: batch x actions exceeds the LDS budget");
+    int red_threads = 64;
+    while (red_threads < batch) red_threads <<= 1;       // blockDim of the stand-alone loss kernel
+    DqnHeadBwdArgs a{rlx_small::SmallDenseBwd{q_head->x, q_head->x_tower_stride, q_head->w, q_head->w_tower_stride, q_head->dy,
+                                               q_head->dy_tower_stride, nullptr, 0, q_head->dw, q_head->dw_tower_stride,
+                                               q_head->db, q_head->db_tower_stride, q_head->dx, q_head->dx_tower_stride,
+                                               q_head->M, q_head->K, q_head->N, 0, q_head->lower_activation},
+                     q_online, ld_q, q_next_target, q_next_selector, ld_next, actions, rewards, game_overs,
+                     importance_weights, discount, td_errors, loss_scalar, status, batch, n_actions, huber, red_threads,
+                     grad_scale};
+    const dim3 grid((q_head->K + 15) / 16);
+    hipStream_t s = rlx::as_stream(stream);
+    if (NN == 1) RLX_LAUNCH((dqn_head_loss_bwd_kernel<1>), grid, 256, smem, s, a);
+    else if (NN == 4) RLX_LAUNCH((dqn_head_loss_bwd_kernel<4>), grid, 256, smem, s, a);
+    else if (NN == 8) RLX_LAUNCH((dqn_head_loss_bwd_kernel<8>), grid, 256, smem, s, a);
+    else RLX_LAUNCH((dqn_head_loss_bwd_kernel<16>), grid, 256, smem, s, a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

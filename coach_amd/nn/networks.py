@@ -385,6 +385,7 @@ class DQNNet(_NetBase):
     """DQNNetworkParameters (agents/dqn_agent.py:43-56): embedder -> FC middleware -> QHead;
     MSE or Huber loss, importance weights from prioritized replay."""
     HEAD_FORWARD_WITH_TORSO = True     # image networks: the Q head's forward rides on the last dense layer's launch
+    HEAD_LOSS_BACKWARD_ONE_LAUNCH = True   # the head's loss (TD targets, dQ) and its backward pass as one launch
     FUSED_MLP = True        # small MLPs: the whole update / the acting step as one launch (tests flip these to cross-check)
     FUSED_ACT = True
 
@@ -596,10 +597,24 @@ class DQNNet(_NetBase):
         w = importance_weights
         if w is not None and w.dtype != torch.float64:
             w = w.double()
-        self.lib.dqn_head_loss(q.data, self.A, q_next, sel, self.A, actions, rewards, game_overs, w,
-                               float(discount), B, self.A, int(self.huber), 1.0, dq, self.A, td_errors,
-                               None, self.A, self.loss, self.status, ctx.stream)
-        self._backward_from_q(acts, q, saved if self.dueling else None, B)
+        feat = acts[-1]
+        if self.HEAD_LOSS_BACKWARD_ONE_LAUNCH and not self.dueling and self.head_gradient_rescale == 1.0 and \
+                self.q_head.T == 1 and self.A <= G.SMALL_N and B * self.A <= 1024 and B <= 256 and not feat.u8 and \
+                feat.towers == 1:
+            # TD targets, |TD errors|, loss, dQ AND the Q head's backward pass (dW, db, dz of the last dense layer) in one
+            # launch (rlx_dqn_head_loss_backward): what the two calls of the else branch compute, bit for bit
+            import ctypes
+            prob = _rlx.SmallDenseProblem()
+            G._small_backward_problem(prob, self.q_head, feat, q)
+            self.lib.dqn_head_loss_backward(ctypes.byref(prob), q.data, self.A, q_next, sel, self.A, actions, rewards,
+                                            game_overs, w, float(discount), B, self.A, int(self.huber), 1.0, td_errors,
+                                            self.loss, self.status, ctx.stream)
+            self.torso.backward(ctx, acts)
+        else:
+            self.lib.dqn_head_loss(q.data, self.A, q_next, sel, self.A, actions, rewards, game_overs, w,
+                                   float(discount), B, self.A, int(self.huber), 1.0, dq, self.A, td_errors,
+                                   None, self.A, self.loss, self.status, ctx.stream)
+            self._backward_from_q(acts, q, saved if self.dueling else None, B)
         clipped = self.clip_by_global_norm()          # this worker's gradient, before it is shared
         if sync is not None:                          # data-parallel: ONE all-reduce of the flat buffer
             sync.all_reduce_sum(self.params.grads)

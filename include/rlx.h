@@ -634,6 +634,15 @@ typedef struct rlx_small_dense_problem {
     float *dx; long long dx_tower_stride;
     int towers, M, K, N, activation, lower_activation;
 } rlx_small_dense_problem;
+/* rlx_dqn_head_loss + the Q head's backward pass (rlx_dense_small_backward of q_head: dW, db, dx with the lower layer's
+ * activation derivative; tf.gradients through the head, architecture.py:312-385) as ONE launch.  q_head: x, w, dy (receives
+ * dQ), dw / db / dx as for rlx_dense_small_backward_multi, one linear tower with M = batch <= 256, N = n_actions <= 16.
+ * Values: those of the two launches bit for bit (the same row arithmetic, the same reduction trees). */
+int rlx_dqn_head_loss_backward(const rlx_small_dense_problem *q_head, const float *q_online, long long ld_q,
+                               const float *q_next_target, const float *q_next_selector, long long ld_next,
+                               const int *actions, const float *rewards, const unsigned char *game_overs,
+                               const double *importance_weights, double discount, int batch, int n_actions, int huber,
+                               float grad_scale, double *td_errors, float *loss_scalar, int *status, void *stream);
 int rlx_dense_small_forward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
 int rlx_dense_small_backward_multi(const rlx_small_dense_problem *problems_host, int n_problems, void *stream);
 /* Discrete Clipped-PPO: the losses of both heads (heads/ppo_head.py:52-116, v_head.py:43-52, head.py:143-186) AND the
