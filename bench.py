@@ -842,6 +842,8 @@ def main():
     ap.add_argument("--fuse-conv-bwd-min-wg", type=int, default=None,
                     help="A/B: fewest half-image workgroups for which the fused input-gradient chain is taken "
                          "(nn.graph.FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS)")
+    ap.add_argument("--conv1-chunks", type=int, default=None, choices=[1, 3],
+                    help="A/B: accumulator chains of conv1 in the fused forward launch (nn.graph.CONV1_CHUNKS)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
                     help="A/B (c2): rows per forward pass of Clipped PPO's whole-dataset passes (ClippedPPOAgent.DATASET_CHUNK)")
     ap.add_argument("--episode-length", type=int, default=EP_LEN,
@@ -929,6 +931,9 @@ def main():
     if args.fuse_conv_bwd is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_INPUT_GRADS = bool(args.fuse_conv_bwd)
+    if args.conv1_chunks is not None:
+        from coach_amd.nn import graph as _G5
+        _G5.CONV1_CHUNKS = int(args.conv1_chunks)
     if args.fuse_conv_bwd_min_wg is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS = int(args.fuse_conv_bwd_min_wg)

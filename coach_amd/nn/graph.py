@@ -157,6 +157,7 @@ PER_RIDER_MAX_WORKGROUPS = 256
 # bit-identical to the tiled ones.  4: every fused forward launch runs with four groups (conv3 on all eight waves); the
 # sums of the two-tower minibatch then differ from the tiled launches' in the last bits (another grouping of the k-quads),
 # inside tests/tolerances.py against the oracle.
+CONV1_CHUNKS = None      # A/B (bench.py --conv1-chunks): accumulator chains of conv1's K = 256 in the fused forward launch (None: as the tiled launch would split K)
 CONV_FORWARD_WAVE_GROUPS = 4           # (-0.9 us on the C2 update's forward launch, profiles/r06_ab_conv_fwd_groups_split_cap.txt)
 
 
@@ -1111,6 +1112,7 @@ class Sequential:
             chunks = 3
         else:
             return None
+        chunks = CONV1_CHUNKS or chunks
         y2 = ctx.buffer(a.name, (T, M2, a.Co), tag=tag)
         y3 = ctx.buffer(b.name, (T, M3, b.Co), tag=tag)
         w = lambda l: p.w(l.kname, t0_, weights)
