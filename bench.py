@@ -842,6 +842,10 @@ def main():
     ap.add_argument("--fuse-conv-bwd-min-wg", type=int, default=None,
                     help="A/B: fewest half-image workgroups for which the fused input-gradient chain is taken "
                          "(nn.graph.FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS)")
+    ap.add_argument("--kw-min-tiles", type=int, default=None,
+                    help="A/B: rlx_gemm_desc.kw_min_tiles of the dense layers' input gradients (fewest 32-row tiles for which K is "
+                         "split over the waves of a workgroup instead of over workgroups + a reduce launch; default 96, "
+                         "0 = the library's 192)")
     ap.add_argument("--conv1-chunks", type=int, default=None, choices=[1, 3],
                     help="A/B: accumulator chains of conv1 in the fused forward launch (nn.graph.CONV1_CHUNKS)")
     ap.add_argument("--ppo-chunk", type=int, default=None,
@@ -931,6 +935,9 @@ def main():
     if args.fuse_conv_bwd is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_INPUT_GRADS = bool(args.fuse_conv_bwd)
+    if args.kw_min_tiles is not None:
+        from coach_amd.nn import graph as _G6
+        _G6.DENSE_DX_KW_MIN_TILES = int(args.kw_min_tiles)
     if args.conv1_chunks is not None:
         from coach_amd.nn import graph as _G5
         _G5.CONV1_CHUNKS = int(args.conv1_chunks)

@@ -250,6 +250,7 @@ class GemmDesc(ctypes.Structure):
         ("bias_batch_stride2", ctypes.c_longlong),
         ("n_fold", ctypes.c_int),
         ("row_heads", ctypes.c_void_p), ("n_row_heads", ctypes.c_int),
+        ("kw_min_tiles", ctypes.c_int),
     ]
 
 
@@ -266,7 +267,7 @@ class SplitkJob(ctypes.Structure):
 
 
 ADAM_TICKET_WORDS = 1056        # rlx.h RLX_ADAM_TICKET_WORDS
-ABI_VERSION = 9                 # rlx_abi_version() of the library this module's structures and buffer sizes match
+ABI_VERSION = 10                # rlx_abi_version() of the library this module's structures and buffer sizes match
 MAX_SPLITK_JOBS = 8
 
 
@@ -487,7 +488,7 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
          a_batch_stride=0, b_batch_stride=0, c_batch_stride=0, bias_batch_stride=0,
          aux_batch_stride=0, workspace=None, colsum_out=None, colsum_batch_stride=0, stream=None,
          batch_inner=0, a_batch_stride2=0, b_batch_stride2=0, bias_batch_stride2=0, n_fold=0, launch=True,
-         defer=None, row_heads=None):
+         defer=None, row_heads=None, kw_min_tiles=0):
     """Thin wrapper building an rlx_gemm_desc.  a_strides=(row, k), b_strides=(k, n) in elements.
     launch=False: return the descriptor (for gemm_pair) instead of running it.
     defer: a SplitkJob — if K gets split over workgroups the reduction of the partials is left to
@@ -520,6 +521,7 @@ def gemm(M, N, K, A, B, C, *, a_strides=None, a_tabs=None, a_u8=False, a_div=1.0
     d.a_batch_stride2, d.b_batch_stride2 = int(a_batch_stride2), int(b_batch_stride2)
     d.bias_batch_stride2 = int(bias_batch_stride2)
     d.n_fold = int(n_fold)
+    d.kw_min_tiles = int(kw_min_tiles)
     if row_heads is not None:                 # a ctypes array of SmallDenseProblem (kept alive by the descriptor)
         d._row_heads = row_heads
         d.row_heads, d.n_row_heads = ctypes.addressof(row_heads), len(row_heads)

@@ -2570,8 +2570,9 @@ int gemm_impl(const rlx_gemm_desc *d_host, void *stream, GemmPlan *plan, rlx_spl
     // (operand combinations launch_fast instantiates; anything else falls back to the bounds-checked 64 x 64 kernel)
     const bool fast_combo = (!u8_in && !a_tab) || (a_tab && !b_vec_red);
     if (fast && fast_combo && !narrow && BM == 64 && BN == 64 && tiles_of(64, 64) < g_kw_below_tiles) {   // default: 3/4 of the CUs
-        if (tiles_of(32, 64) >= g_kw_min_tiles) { BM = 32; BN = 64; KW = 2; }
-        else if (tiles_of(32, 32) >= g_kw_min_tiles) { BM = 32; BN = 32; KW = 4; }
+        const int kw_min = d.kw_min_tiles > 0 ? d.kw_min_tiles : g_kw_min_tiles;       // (a per-product hint: rlx.h)
+        if (tiles_of(32, 64) >= kw_min) { BM = 32; BN = 64; KW = 2; }
+        else if (tiles_of(32, 32) >= kw_min) { BM = 32; BN = 32; KW = 4; }
     }
     const int tiles = (int)tiles_of(BM, BN);
     // split K until ~2 workgroups per CU exist, keeping >= 2 slabs of 32 per split; a launch that

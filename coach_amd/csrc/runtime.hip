@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) probe_requests_kernel(const float *__rest
 
 extern "C" {
 
-int rlx_abi_version(void) { return 9; }   // 9: rlx_conv32_input_grad_per_update / rlx_splitk_reduce_jobs_per_update (rlx_per_update_desc), rlx_imgreplay_gather_columns, conv_dw_u8 for one tower of 32 filters (2 B splits); 8: rlx_ppo_fc_rows / rlx_ppo_heads_tail / rlx_splitk_reduce_jobs_ppo_tail, fused TD3 / SAC updates, rlx_conv_dw_*; 7: rlx_conv123_forward, rlx_gemm_describe; 6: rlx_conv23_forward, rlx_gemm_multi_defer, rlx_gemm_big_tiles; 2: adam_tf1_norm / sac head accumulate; 3: gemm desc batch_inner, n_fold; 4: per_sample payload rows, libm pow; 5: rlx_adam_tf1_step ticket = RLX_ADAM_TICKET_WORDS words
+int rlx_abi_version(void) { return 10; }   // 10: rlx_gemm_desc.kw_min_tiles, rlx_dqn_head_loss_backward; 9: rlx_conv32_input_grad_per_update / rlx_splitk_reduce_jobs_per_update (rlx_per_update_desc), rlx_imgreplay_gather_columns, conv_dw_u8 for one tower of 32 filters (2 B splits); 8: rlx_ppo_fc_rows / rlx_ppo_heads_tail / rlx_splitk_reduce_jobs_ppo_tail, fused TD3 / SAC updates, rlx_conv_dw_*; 7: rlx_conv123_forward, rlx_gemm_describe; 6: rlx_conv23_forward, rlx_gemm_multi_defer, rlx_gemm_big_tiles; 2: adam_tf1_norm / sac head accumulate; 3: gemm desc batch_inner, n_fold; 4: per_sample payload rows, libm pow; 5: rlx_adam_tf1_step ticket = RLX_ADAM_TICKET_WORDS words
 const char *rlx_last_error(void) { return rlx::g_err; }
 const char *rlx_build_arch(void) { return "gfx950"; }
 

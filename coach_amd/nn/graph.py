@@ -157,6 +157,7 @@ PER_RIDER_MAX_WORKGROUPS = 256
 # bit-identical to the tiled ones.  4: every fused forward launch runs with four groups (conv3 on all eight waves); the
 # sums of the two-tower minibatch then differ from the tiled launches' in the last bits (another grouping of the k-quads),
 # inside tests/tolerances.py against the oracle.
+DENSE_DX_KW_MIN_TILES = 96       # rlx_gemm_desc.kw_min_tiles of a dense layer's input gradient (0: the library's 192)
 CONV1_CHUNKS = None      # A/B (bench.py --conv1-chunks): accumulator chains of conv1's K = 256 in the fused forward launch (None: as the tiled launch would split K)
 CONV_FORWARD_WAVE_GROUPS = 4           # (-0.9 us on the C2 update's forward launch, profiles/r06_ab_conv_fwd_groups_split_cap.txt)
 
@@ -509,11 +510,13 @@ class Dense(Layer):
             dx = x.ensure_grad()
             # dx[M,K] = dz W^T : B(n, k) = W[k, n]; the epilogue multiplies by the lower layer's
             # activation derivative, so dx IS that layer's dz (no separate act_backward launch)
+            # (kw_min_tiles: at batch 32 the product is 98 tiles of 32 x 32 — K over the waves of a workgroup instead of a
+            # K split over workgroups + a reduce launch in the chain: -3.4 us per DQN update, DENSE_DX_KW_MIN_TILES)
             dxd = _rlx.gemm(M, self.K, self.N, dz, p.w(self.kname, t0, weights), dx, b_strides=(1, self.N),
                             batch=T, a_batch_stride=M * self.N, b_batch_stride=p.stride(self.kname),
                             c_batch_stride=M * self.K, workspace=ctx.ws.splitk,
                             deriv_aux=x.data if lower else None, aux_ld=self.K, deriv_kind=lower,
-                            aux_batch_stride=M * self.K, launch=False)
+                            aux_batch_stride=M * self.K, launch=False, kw_min_tiles=DENSE_DX_KW_MIN_TILES)
             if need_dw and not overlap and PAIR_GRADIENT_GEMMS:
                 # dW and dX are independent products of the same dz: one launch (own split-K workspaces)
                 _rlx.gemm_pair(dw(ctx.ws.splitk_side, launch=False), dxd, defer=job)

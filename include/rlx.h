@@ -447,6 +447,12 @@ typedef struct rlx_gemm_desc {
      * product.  Either way y of every head is complete in stream order, with identical values.  NULL / 0: none. */
     const struct rlx_small_dense_problem *row_heads;
     int n_row_heads;
+    /* 0: the library's rule (rlx_gemm_tuning's kw_min_tiles, default 192).  > 0: for THIS product, the fewest 32 x 64 / 32 x 32
+     * tiles for which K is split over the waves of a workgroup (no partials, no reduce launch) rather than over workgroups.
+     * A dense layer's input gradient at batch 32 (M = 32, N = 3136, K = 512: 98 tiles of 32 x 32) sits in the chain of the
+     * update in front of the convolutions' backward pass: with 96 it is one launch of 13.7 us instead of 12.4 + a 4.7 us reduce
+     * launch (coach_amd/nn/graph.py Dense.backward; profiles/r06_ab_c3_kw_min_tiles.txt). */
+    int kw_min_tiles;
 } rlx_gemm_desc;
 
 int rlx_gemm(const rlx_gemm_desc *desc_host, void *stream);
