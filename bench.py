@@ -842,6 +842,8 @@ def main():
     ap.add_argument("--fuse-conv-bwd-min-wg", type=int, default=None,
                     help="A/B: fewest half-image workgroups for which the fused input-gradient chain is taken "
                          "(nn.graph.FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS)")
+    ap.add_argument("--conv-dw-pairs", type=int, default=None, choices=[0, 1, 2],
+                    help="A/B: image pairs per workgroup of the conv2 / conv3 weight gradients (rlx_conv_dw_pairs_per_workgroup)")
     ap.add_argument("--kw-min-tiles", type=int, default=None,
                     help="A/B: rlx_gemm_desc.kw_min_tiles of the dense layers' input gradients (fewest 32-row tiles for which K is "
                          "split over the waves of a workgroup instead of over workgroups + a reduce launch; default 96, "
@@ -935,6 +937,9 @@ def main():
     if args.fuse_conv_bwd is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_INPUT_GRADS = bool(args.fuse_conv_bwd)
+    if args.conv_dw_pairs is not None:
+        from coach_amd import _rlx as _R7
+        _R7.lib().conv_dw_pairs_per_workgroup(int(args.conv_dw_pairs))
     if args.kw_min_tiles is not None:
         from coach_amd.nn import graph as _G6
         _G6.DENSE_DX_KW_MIN_TILES = int(args.kw_min_tiles)

@@ -483,6 +483,7 @@ struct DwF32 {
     float *part, *cpart;              // [T][splits][K][64], [T][splits][64]
     int B, H, OH, KH, splits, units;  // units = towers * splits
     long long *stamps;
+    int ppw;                          // image pairs per workgroup (two-pass body; 1: a split per pair)
 };
 
 #define RLX_DWF_STAMP(i) do { if (a.stamps && bid == 0 && threadIdx.x == 0) a.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -615,7 +616,10 @@ __device__ __forceinline__ void conv_dw_f32_body_two_pass(const DwF32 &a, const 
     const int ky = rest % a.KH, pt = (rest / a.KH) * 8 + xcd;
     if (pt >= a.units) return;
     const int t = pt / a.splits, g = pt - t * a.splits;
-    const int img0 = 2 * g, n_img = min(2, a.B - img0);
+    // a.ppw image pairs per workgroup, one after the other into the same accumulators (ppw = 2: half the splits — half the
+    // partial sums written here and read by the deferred reduction)
+    const int ppw = a.ppw > 1 ? a.ppw : 1, n_pairs = (a.B + 1) >> 1;
+    int img0 = 2 * g * ppw, n_img = min(2, a.B - img0);
     RLX_DWF_STAMP(0);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned xf_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(xf));
@@ -692,12 +696,19 @@ __device__ __forceinline__ void conv_dw_f32_body_two_pass(const DwF32 &a, const 
         if (ky == 0 && a.cpart)                           // bias gradient: this thread's share of column cn over the pass
             for (int pos = cq; pos < 2 * nr * OW; pos += 4) csum += dzl[pos * kN + cn];
     };
-    stage(0, R0);
-    RLX_DWF_STAMP(1);
-    rows(std::integral_constant<int, R0>());
-    __syncthreads();                                      // pass 0's operands are no longer read
-    stage(R0, OHT - R0);
-    rows(std::integral_constant<int, OHT - R0>());
+    for (int pp = 0; pp < ppw && g * ppw + pp < n_pairs; ++pp) {
+        if (pp > 0) {
+            __syncthreads();                              // the previous pair's operands are no longer read
+            img0 = 2 * (g * ppw + pp);
+            n_img = min(2, a.B - img0);
+        }
+        stage(0, R0);
+        if (pp == 0) { RLX_DWF_STAMP(1); }
+        rows(std::integral_constant<int, R0>());
+        __syncthreads();                                  // pass 0's operands are no longer read
+        stage(R0, OHT - R0);
+        rows(std::integral_constant<int, OHT - R0>());
+    }
     RLX_DWF_STAMP(2);
     const int K = a.KH * kMT;
     float *out = a.part + (((size_t)t * a.splits + g) * K + (size_t)ky * kMT + 32 * (wave >> 1)) * kN + nh * 32 + l31;
@@ -721,7 +732,7 @@ struct GeometryF32 {
     int OH, OW, K, P, splits, kind;   // kind 1: 3 x 3 x 64 stride 1 on 9 x 9; 2: 4 x 4 x 32 stride 2 on 20 x 20
     size_t lds;
 };
-inline bool geometry_f32(int B, int H, int W, int C, int KH, int KW, int S, int Co, int T, GeometryF32 *g) {
+inline bool geometry_f32(int B, int H, int W, int C, int KH, int KW, int S, int Co, int T, GeometryF32 *g, int ppw = 1) {
     if (B < 3 || Co != kN || T < 1) return false;
     g->kind = 0;
     if (H == 9 && W == 9 && C == 64 && KH == 3 && KW == 3 && S == 1) g->kind = 1;
@@ -731,7 +742,7 @@ inline bool geometry_f32(int B, int H, int W, int C, int KH, int KW, int S, int 
     g->OW = (W - KW) / S + 1;
     g->K = KH * KW * C;
     g->P = g->OH * g->OW;
-    g->splits = (B + 1) / 2;
+    g->splits = ((B + 1) / 2 + ppw - 1) / ppw;
     if (g->splits > 128) return false;
     g->lds = sizeof(float) * ((size_t)((2 * g->OH * W * C + 255) & ~255) + (size_t)((2 * g->P * kN + 255) & ~255) + 256);
     return g->lds <= 160 * 1024;

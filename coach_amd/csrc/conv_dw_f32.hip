@@ -84,7 +84,7 @@ int rlx_conv_dw_f32(const float *x, long long x_tower_stride, const float *dz, l
     DwF32 a;
     a.x = x; a.x_ts = x_tower_stride; a.dz = dz; a.dz_ts = dz_tower_stride;
     a.part = workspace; a.cpart = db ? workspace + (size_t)towers * g.splits * g.K * kN : nullptr;
-    a.B = B; a.H = H; a.OH = g.OH; a.KH = KH; a.splits = g.splits;
+    a.B = B; a.H = H; a.OH = g.OH; a.KH = KH; a.splits = g.splits; a.ppw = 1;
     a.stamps = g_stamps;
     a.units = towers * g.splits;                                  // (tower, pair)
     const int grid = ((a.units + 7) / 8) * 8 * KH;

@@ -53,6 +53,15 @@ __global__ void __launch_bounds__(kThreads) conv_dw_multi_kernel(const MultiArgs
 }
 
 int g_passes = 2;          // rlx_conv_dw_passes
+int g_pairs_per_wg = 0;    // rlx_conv_dw_pairs_per_workgroup (0: by the number of workgroups)
+// image pairs per workgroup of an fp32 item: two where (tower, pair) units are plentiful (the Clipped-PPO minibatch: 2 x 32 —
+// same launch time, half the partial sums: 8.9 MB less written and read back per update, profiles/r06_ab_conv_dw_pairs.txt),
+// one where that would leave CUs without work (the DQN update's 16 pairs: 165.8 against 156.7 ms per C3 step)
+inline int pairs_per_wg(int B, int towers) {
+    if (g_passes <= 1) return 1;
+    if (g_pairs_per_wg > 0) return g_pairs_per_wg;
+    return towers * ((B + 1) / 2) >= 64 ? 2 : 1;
+}
 
 }  // namespace
 
@@ -74,7 +83,8 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items, rlx_splitk_job *jobs, int n
                   gu.OH == 20 && it.S * it.C == 16 && gu.rowf == 336;
             iu = &it; ju = i; ++n_u8;
         } else {
-            one = n_f < 2 && geometry_f32(it.B, it.H, it.W, it.C, it.KH, it.KW, it.S, it.filters, it.towers, &gf[n_f < 2 ? n_f : 1]);
+            one = n_f < 2 && geometry_f32(it.B, it.H, it.W, it.C, it.KH, it.KW, it.S, it.filters, it.towers, &gf[n_f < 2 ? n_f : 1],
+                                          pairs_per_wg(it.B, it.towers));
             if (n_f < 2) { fi[n_f] = &it; jf[n_f] = i; }
             ++n_f;
         }
@@ -133,6 +143,7 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items, rlx_splitk_job *jobs, int n
         a.x = static_cast<const float *>(it.x); a.x_ts = it.x_tower_stride; a.dz = it.dz; a.dz_ts = it.dz_tower_stride;
         a.part = it.workspace; a.cpart = it.db ? it.workspace + (size_t)it.towers * g.splits * g.K * kN : nullptr;
         a.B = it.B; a.H = it.H; a.OH = g.OH; a.KH = it.KH; a.splits = g.splits; a.units = it.towers * g.splits;
+        a.ppw = pairs_per_wg(it.B, it.towers);
         a.stamps = nullptr;
         m.nb_f[k] = ((a.units + 7) / 8) * 8 * it.KH;
         m.kind[k] = g.kind;
@@ -168,6 +179,12 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items, rlx_splitk_job *jobs, int n
         RLX_LAUNCH((conv_dw_multi_kernel<1>), grid, kThreads, lds, rlx::as_stream(stream), m);
     }
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rlx_conv_dw_pairs_per_workgroup(int pairs) {
+    RLX_REQUIRE(pairs >= 0 && pairs <= 2, "rlx_conv_dw_pairs_per_workgroup: 0 (by the number of workgroups), 1 or 2");
+    g_pairs_per_wg = pairs;
     return RLX_OK;
 }
 

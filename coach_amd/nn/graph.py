@@ -162,6 +162,23 @@ CONV1_CHUNKS = None      # A/B (bench.py --conv1-chunks): accumulator chains of 
 CONV_FORWARD_WAVE_GROUPS = 4           # (-0.9 us on the C2 update's forward launch, profiles/r06_ab_conv_fwd_groups_split_cap.txt)
 
 
+def _fused_operands_aligned(args):
+    """what RLX_REQUIRE checks inside rlx_conv23_forward / rlx_conv123_forward, asked BEFORE the fused launch is chosen: every
+    tensor operand 16-byte aligned, every tower stride (the integer behind a tensor) a multiple of 4 floats — a misaligned
+    caller-supplied weights view or output buffer takes the tiled launches instead of raising."""
+    prev_tensor = False
+    for a in args:
+        if hasattr(a, "data_ptr"):
+            if a.data_ptr() % 16:
+                return False
+            prev_tensor = True
+        else:
+            if prev_tensor and isinstance(a, int) and a % 4:
+                return False
+            prev_tensor = False
+    return True
+
+
 def _tiled_wave_groups(M, N, batch):
     """How rlx_gemm would tile an M x N x K product of `batch` towers (csrc/gemm.hip gemm_impl, with the LIVE thresholds of
     rlx_gemm_tuning: 192 / 192 unless an A/B tool changed them): 2 = 32 x 64 tiles with the K slab split over two wave
@@ -1058,6 +1075,8 @@ class Sequential:
         args = (x.data, x.tower_stride(), p.w(a.kname, t0_, weights), ws2, p.w(a.bname, t0_, weights), bs2,
                 p.w(b.kname, t0_, weights), ws3, p.w(b.bname, t0_, weights), bs3, y2, M2 * a.Co, y3, M3 * b.Co, B, T,
                 _rlx.ACT[a.act], groups, stream)
+        if not _fused_operands_aligned(args):    # (a caller-supplied `weights` view: the tiled launches take anything)
+            return None
         run = lambda: ctx.lib.conv23_forward(*args)
         if _rlx.GEMM_HOOK is not None:       # bench.py's recorder: the two products this launch stands for
             d2, d3 = _rlx.GemmDesc(), _rlx.GemmDesc()
@@ -1123,6 +1142,8 @@ class Sequential:
         args = (x.data, x.tower_stride(), float(x.div), w(f), stride(f.kname), bi(f), stride(f.bname), y1, M1 * f.Co,
                 w(a), stride(a.kname), bi(a), stride(a.bname), w(b), stride(b.kname), bi(b), stride(b.bname),
                 y2, M2 * a.Co, y3, M3 * b.Co, B, T, _rlx.ACT[f.act], groups, chunks, ctx.stream)
+        if not _fused_operands_aligned(args[3:]):
+            return None
         run = lambda: lib.conv123_forward(*args)
         if _rlx.GEMM_HOOK is not None:       # bench.py's recorder: the three products this launch stands for
             d2, d3 = _rlx.GemmDesc(), _rlx.GemmDesc()

@@ -478,7 +478,7 @@ int rlx_gemm_describe(const rlx_gemm_desc *desc, int *out8);
  * of rounds 1-3 (128 x 32 tiles always use it); 2 = the ring for uint8 operands too (4-byte requests; measured equal to 1).  Same products, same tiles; the order of the fp32 sum inside a 32-deep slab differs between the two
  * (both deterministic).  Process-wide, read at launch (or capture) time: exists for same-process A/B measurements. */
 int rlx_gemm_pipeline(int lds_dma_ring);
-/* 64 x 64 per wave (2 x 2 accumulator tiles; 128 x 128 or 256 x 64 per workgroup) for products of at least 256 such tiles
+/* 64 x 64 (or 64 x 32) per wave (2 x 2 / 2 x 1 accumulator tiles; 128 x 128 or 128 x 64 per workgroup) for products of at least 256 such tiles
  * without a K split: 1 (default: 128 x 128 for N >= 128) / 0 / 2 (also 128 x 64 for N <= 64, measured neutral on the
  * convolution layers of the whole-dataset passes).  Bit-identical results either way
  * (every element stays one chain over K); process-wide, for same-process A/Bs and tests. */
@@ -1003,6 +1003,11 @@ int rlx_conv_dw_multi(const rlx_conv_dw_item *items_host, rlx_splitk_job *jobs_h
  * gradients identical; the inner layer's bias gradient sums its positions in another grouping (last bits).  -6 us per Clipped-PPO
  * update (profiles/r06_ab_conv_dw_passes.txt).  1 = the bodies of rlx_conv_dw_u8 / rlx_conv_dw_f32 as they are. */
 int rlx_conv_dw_passes(int passes);
+/* Process-wide, multi-pass forms only: image pairs an fp32 item's workgroup takes one after the other into the same
+ * accumulators.  2: half the splits of the conv2 / conv3 weight gradients — 8.9 MB less partial sums written and read back per
+ * Clipped-PPO minibatch update at the same launch time — at half the workgroups; 1: a split per pair; 0 (default): 2 where an
+ * item has >= 64 (tower, pair) units, else 1 (profiles/r06_ab_conv_dw_pairs.txt). */
+int rlx_conv_dw_pairs_per_workgroup(int pairs);
 
 /* ------------------------------------------------- Clipped PPO: last dense layer + heads + losses, one launch -- */
 /* The middleware's Dense(units) of both towers (tower 0 = value, tower 1 = policy; layers.py:168-185), VHead / discrete

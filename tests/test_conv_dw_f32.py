@@ -132,12 +132,14 @@ def test_two_pass_staging_of_the_one_launch_form(rlx, dev, B, passes):
     bit; conv2's bias gradient groups its column sums by pass (last bits)."""
     import torch
     try:
+        rlx.conv_dw_pairs_per_workgroup(1)   # (a split per image pair in both forms: the grouping of the batch sum is not under test)
         rlx.conv_dw_passes(1)
         one = _update(dev, B, True, one_launch=True)
         rlx.conv_dw_passes(passes)
         two = _update(dev, B, True, one_launch=True)
     finally:
-        rlx.conv_dw_passes(2)                # the library's default
+        rlx.conv_dw_passes(2)                # the library's defaults
+        rlx.conv_dw_pairs_per_workgroup(0)
     assert sum("conv_dw_multi_kernel<%d>" % passes in n for n in two[1]) == 1, two[1]
     g1, g2 = one[0], two[0]
     net = one[2]
@@ -151,3 +153,21 @@ def test_two_pass_staging_of_the_one_launch_form(rlx, dev, B, passes):
     assert torch.equal(g1[same], g2[same]), "%d elements differ outside the inner layers' bias gradients" % int((g1[same] != g2[same]).sum())
     a, b = g1[~same], g2[~same]
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) and float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize("B", [64, 63, 34])
+def test_two_image_pairs_per_workgroup_halve_the_splits(rlx, dev, B):
+    """rlx_conv_dw_pairs_per_workgroup(2): an fp32 item's workgroup takes two image pairs into the same accumulators — half
+    the splits in the deferred arena; another grouping of the sum over the batch (fp32 tolerance), conv1 untouched."""
+    try:
+        rlx.conv_dw_pairs_per_workgroup(1)
+        ref = _update(dev, B, True, one_launch=True)
+        rlx.conv_dw_pairs_per_workgroup(2)
+        new = _update(dev, B, True, one_launch=True)
+    finally:
+        rlx.conv_dw_pairs_per_workgroup(0)              # the library's default: by the number of workgroups
+    assert sum("conv_dw_multi_kernel" in n for n in new[1]) == 1, new[1]
+    g0, g1 = ref[0].cpu().numpy(), new[0].cpu().numpy()
+    assert np.abs(g0).max() > 0
+    np.testing.assert_allclose(g1, g0, rtol=1e-4, atol=2e-6 * np.abs(g0).max())
+    assert (g0 != g1).any()

@@ -3,7 +3,7 @@
 # traces of the bench commands, PMC passes on one eager update (traffic, MFMA busy cycles).  Writes gpurun_out/r06_final/;
 # what is kept goes to profiles/r06_final_*.  Every step runs under its own timeout.
 set -u
-O=gpurun_out/r06_final3
+O=gpurun_out/r06_final4
 mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
@@ -59,12 +59,3 @@ done
 python tools/pmc_wave_states.py $O/sq_1.csv $O/sq_2.csv $O/pmc_wave_states.json 2>&1 | tail -16
 head -16 $O/c2_kernel_stats.csv | cut -c1-170
 du -sh $O
-# A/B riders of the final call: conv1 as one accumulator chain in the fused forward launch (C3 / acting)
-for v in 1 3; do timeout 300 python bench.py --workload c3 --no-cpu-baseline --conv1-chunks $v > $O/bench_c3_chunks$v.json 2> $O/bench_c3_chunks$v.err; python - <<PY
-import json
-try:
-    d=json.loads(open('$O/bench_c3_chunks$v.json').read().strip().splitlines()[-1]); print('c3 conv1 chunks $v', d['value'], d['ms_per_step'], d['roofline'].get('update_us'))
-except Exception as e:
-    print('c3 chunks $v ERR', e)
-PY
-done
