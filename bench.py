@@ -842,6 +842,11 @@ def main():
     ap.add_argument("--fuse-conv-bwd-min-wg", type=int, default=None,
                     help="A/B: fewest half-image workgroups for which the fused input-gradient chain is taken "
                          "(nn.graph.FUSE_CONV_INPUT_GRADS_MIN_WORKGROUPS)")
+    ap.add_argument("--update-chunk", type=int, default=None,
+                    help="A/B (c4 / c5): consecutive updates of a train() call per captured graph (VectorOffPolicyAgent.UPDATE_CHUNK; "
+                         "default 8, 1 = every update on its own)")
+    ap.add_argument("--host-draws-ahead", type=int, default=None, choices=[0, 1],
+                    help="A/B (c4 / c5): the host-RNG side of Agent.train on a producer thread (VectorOffPolicyAgent.HOST_DRAWS_AHEAD)")
     ap.add_argument("--conv-dw-pairs", type=int, default=None, choices=[0, 1, 2],
                     help="A/B: image pairs per workgroup of the conv2 / conv3 weight gradients (rlx_conv_dw_pairs_per_workgroup)")
     ap.add_argument("--kw-min-tiles", type=int, default=None,
@@ -937,6 +942,12 @@ def main():
     if args.fuse_conv_bwd is not None:
         from coach_amd.nn import graph as _G
         _G.FUSE_CONV_INPUT_GRADS = bool(args.fuse_conv_bwd)
+    if args.update_chunk is not None:
+        from coach_amd.agents.vector_agent import VectorOffPolicyAgent as _V2
+        _V2.UPDATE_CHUNK = int(args.update_chunk)
+    if args.host_draws_ahead is not None:
+        from coach_amd.agents.vector_agent import VectorOffPolicyAgent as _V
+        _V.HOST_DRAWS_AHEAD = bool(args.host_draws_ahead)
     if args.conv_dw_pairs is not None:
         from coach_amd import _rlx as _R7
         _R7.lib().conv_dw_pairs_per_workgroup(int(args.conv_dw_pairs))

@@ -109,6 +109,9 @@ class TD3Agent(DDPGAgent):
         # the synthetic episodes end on their time limit -> game_over False (:215-227)
         return self.zero_go if self.ap.algorithm.clear_game_over_on_time_limit else game_over
 
+    def _schedule_phase(self, iteration):
+        return iteration % self.ap.algorithm.update_policy_every_x_episode_steps      # the delayed actor step (:186)
+
     def _training_steps_this_phase(self):
         # current_episode_steps_counter updates in a row at each episode end (:211-213): the phases of a vector
         # step take the lengths of the episodes that just finished, in env order

@@ -166,8 +166,10 @@ class GraphRunner(object):
         self.use_graphs = True if use_graphs is None else bool(use_graphs)
         self._graphs, self._warm = {}, set()
 
+    _inline_run = False      # set while a captured sequence runs sub-sequences that would otherwise be graphs of their own
+
     def _run(self, key, fn):
-        if not self.use_graphs:
+        if not self.use_graphs or self._inline_run:
             return fn()
         if getattr(self, "dist", None) is not None and not self._collectives_in_graph():
             return self._run_segmented(key, fn)
@@ -193,6 +195,53 @@ class AlgorithmParameters(object):                       # base_parameters.py:17
         self.act_for_full_episodes = False
         self.reward_clipping = None                      # RewardClippingFilter bounds or None
         self.reward_rescale = 1.0                        # RewardRescaleFilter factor
+
+
+class _HostDrawsAhead(object):
+    """The host-RNG side of one Agent.train call — per phase the index draws of every batch (agent.py:726), then per update its
+    own draws (TD3's smoothing noise, SAC's three normal arrays: `_draw_update_host`) — made IN ORDER by a producer thread a
+    bounded number of updates ahead of the loop that ships them.  Nothing else consumes the host streams inside train() and
+    the uniform replay does not change there, so the values and their order are those of the loop drawing them itself
+    (tests/test_host_draws_ahead.py: weights and generator state bit-identical); numpy's legacy generators fill arrays
+    without the GIL, so SAC's 13 056 normals per update (119 us on one core — as long as the device's whole update) come
+    off the launching thread."""
+
+    def __init__(self, items, n, depth=32):
+        """items: an iterator over the n per-update host items, in the order the consuming loop would make them"""
+        import queue
+        import threading
+        self._q, self._stop = queue.Queue(maxsize=depth), False
+        self._t = threading.Thread(target=self._fill, args=(items, n), daemon=True)
+        self._t.start()
+
+    def __next__(self):
+        return self.get()
+
+    def _fill(self, items, n):
+        import queue
+        try:
+            for _ in range(n):
+                item = next(items)
+                while not self._stop:
+                    try:
+                        self._q.put(item, timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
+                if self._stop:
+                    return
+        except BaseException as e:          # surfaces in the consuming thread
+            self._q.put(e)
+
+    def get(self):
+        item = self._q.get()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        self._stop = True
+        self._t.join()
 
 
 class VectorOffPolicyAgent(GraphRunner):
@@ -429,6 +478,15 @@ class VectorOffPolicyAgent(GraphRunner):
         return due
 
     _staged = None            # device views of the current update's record (see _update_record), or None
+    # the host-RNG side of a train() call on a producer thread (_HostDrawsAhead): same values, measured SLOWER — C5 953 - 1087
+    # against 727 ms per step, C4 2521 against 2398 (profiles/r06_ab_host_draws_ahead.txt): every hand-over of the GIL between
+    # the launching thread and the producer is a futex wake-up, and there are several per update.  Off.
+    HOST_DRAWS_AHEAD = False
+    # K consecutive updates of a train() call as ONE captured graph over ONE staged record of K rows / K sets of host draws
+    # (_train_chunk): one blit and one replay per K updates instead of one record, one gather launch and one or two replays
+    # per update — the TD3 / SAC loops are bound by the launching thread, not by the device (C4: 80.9 us of kernels in a
+    # 94.8 us update).  0 / 1: every update on its own.
+    UPDATE_CHUNK = 8
 
     def _update_record_fields(self):
         """[(name, shape, dtype)] of the host draws one update consumes (TD3: the smoothing noise, SAC: the three
@@ -472,17 +530,40 @@ class VectorOffPolicyAgent(GraphRunner):
         alg = self.ap.algorithm
         B = self.batch_size
         losses = []
-        for _ in range(phases):
-            # every batch of the phase is drawn first (agent.py:726), then learned from in turn; a
-            # collated DeviceBatch aliases the memory's static buffers, so collation is per batch
-            draws = [self.memory.draw(B) for _ in range(self._training_steps_this_phase())]
-            rec = self._update_record()
-            for d in draws:
+        rec = self._update_record()
+        steps_list = [self._training_steps_this_phase() for _ in range(phases)]
+
+        def host_items():
+            """(drawn batch, the update's host draws or None) of every update of this call, in the reference's order on the host
+            streams: every batch of a phase is drawn first (agent.py:726), then each update's own draws where
+            learn_from_batch would make them; a collated DeviceBatch aliases the memory's static buffers, so collation is
+            per batch (below)."""
+            for steps in steps_list:
+                draws = [self.memory.draw(B) for _ in range(steps)]
+                for d in draws:
+                    yield d, (self._draw_update_host() if rec is not None else None)
+        total = sum(steps_list)
+        from ..memories.non_episodic.experience_replay import ExperienceReplay
+        # the whole host-RNG side of the call on a producer thread: the uniform / episodic replay's draw() is host-only (the
+        # prioritized one launches its descent: excluded), no store happens
+        # inside train(), and nothing else touches the host streams until the last update has its draws
+        ahead = _HostDrawsAhead(host_items(), total) \
+            if rec is not None and self.HOST_DRAWS_AHEAD and total >= 8 and type(self.memory).draw is ExperienceReplay.draw else None
+        source = ahead if ahead is not None else host_items()
+        K = int(self.UPDATE_CHUNK or 0)
+        chunked = 0
+        try:
+            if K > 1 and rec is not None and self.use_graphs and self.dist is None and self.signal_stats is None and \
+                    self.debug_draws is None and self.debug_losses is None:
+                while total - chunked >= K:
+                    losses.append(self._train_chunk(source, K, B, alg))
+                    chunked += K
+            for _ in range(total - chunked):
+                d, host = next(source)
                 self.training_iteration += 1
                 if rec is not None:
-                    # everything this update needs from the host — the sampled rows AND its random draws (made here, where
-                    # learn_from_batch would make them: same order on the host streams) — is ONE record, one copy
-                    self._staged = rec.push(rows=self.memory.physical_rows(d), **self._draw_update_host())
+                    # everything this update needs from the host — the sampled rows AND its random draws — is ONE record, one copy
+                    self._staged = rec.push(rows=self.memory.physical_rows(d), **host)
                     batch = self.memory.collate(d, B, rows_dev=self._staged["rows"])
                 else:
                     batch = self.memory.collate(d, B)
@@ -507,9 +588,75 @@ class VectorOffPolicyAgent(GraphRunner):
                             net.update_target(self._mix_rate)
                     self._target_updated_since_log = True      # 'Update Target Network' column (agent.py:760)
                 self._mix_rate = None
+        finally:
+            if ahead is not None:
+                ahead.close()
         self._staged = None
         # the loss of the last update of the phase(s) (a device scalar; no per-update host sync or add)
         return losses[-1] if losses else None
+
+    def _schedule_phase(self, iteration):
+        """what of `training_iteration` decides the SHAPE of the next updates (TD3: the delayed actor step) — part of the key
+        of a chunk's graph."""
+        return 0
+
+    def _chunk_record(self, K):
+        recs = self.__dict__.setdefault("_chunk_recs", {})
+        r = recs.get(K)
+        if r is None:
+            from ..staging import RecordStager
+            fields = [("rows", (K, self.batch_size), torch.int32)] + \
+                [(n, (K,) + tuple(shape), dt) for n, shape, dt in self._update_record_fields()]
+            r = recs[K] = RecordStager(fields, self.device)
+        return r
+
+    def _train_chunk(self, source, K, B, alg):
+        """The next K updates of this train() call as one graph replay: their sampled rows and host draws (made in the
+        loop's order) go out as ONE record, the graph runs gather + learn_from_batch (+ the target mixes that are not part of
+        an Adam pass) K times on the record's K slices.  Host bookkeeping — the iteration counter, the target-update rule's
+        counters (agent.py:640-660), which update is a delayed-policy step — is done here, outside the captured body, in the
+        per-update loop's order; the graph is keyed by everything of it that shapes the launches."""
+        crec = self._chunk_record(K)
+        it0 = self.training_iteration
+        has_target = any(n.target is not None for n in self.networks.values())
+        mixes, ds = [], []
+        for k in range(K):
+            d, host = next(source)
+            ds.append(d)
+            crec.host_views["rows"][k] = self.memory.physical_rows(d)
+            for name, a in host.items():
+                crec.host_views[name][k] = a
+            self.training_iteration += 1
+            mixes.append(bool(has_target and self._should_update_online_weights_to_target()))
+        crec.stager.push(crec.host)
+        views = crec.views
+        rate = alg.rate_for_copying_weights_to_target
+        key = ("chunk", K, tuple(mixes), self._schedule_phase(it0))
+        cache = self.__dict__.setdefault("_chunk_loss", {})
+
+        def body():
+            self._inline_run = True
+            try:
+                for k in range(K):
+                    self.training_iteration = it0 + k + 1
+                    self._staged = {n: v[k] for n, v in views.items()}
+                    batch = self.memory.collate(ds[k], B, rows_dev=self._staged["rows"])
+                    self._mix_rate = rate if mixes[k] else None
+                    self._mixed = set()
+                    cache[key] = self.learn_from_batch(batch)
+                    if mixes[k]:
+                        for name, net in self.networks.items():
+                            if net.target is not None and name not in self._mixed:
+                                net.update_target(self._mix_rate)
+                    self._mix_rate = None
+            finally:
+                self._inline_run = False
+        self._run(key, body)
+        self.training_iteration = it0 + K
+        self._staged = None
+        if any(mixes):
+            self._target_updated_since_log = True
+        return cache[key]
 
     def _training_steps_this_phase(self):
         return self.ap.algorithm.num_consecutive_training_steps
