@@ -3,7 +3,7 @@
 # traces of the bench commands, PMC passes on one eager update (traffic, MFMA busy cycles).  Writes gpurun_out/r06_final/;
 # what is kept goes to profiles/r06_final_*.  Every step runs under its own timeout.
 set -u
-O=gpurun_out/r06_final4
+O=gpurun_out/r06_final5
 mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
