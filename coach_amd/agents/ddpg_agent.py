@@ -197,6 +197,9 @@ class DDPGAgent(VectorOffPolicyAgent):
         return self.dist.grad_scale(netp.scale_down_gradients_by_number_of_workers_for_sync_training) \
             if self.dist else 1.0
 
+    def _update_record_fields(self):
+        return []            # no per-update host draws: the record is the sampled rows (staged, eight updates per replay)
+
     def learn_from_batch(self, batch):
         mix = self._mix_rate
         # Agent.train brackets its updates with set_is_training(True / False) on every network, targets included

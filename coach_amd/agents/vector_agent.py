@@ -490,7 +490,8 @@ class VectorOffPolicyAgent(GraphRunner):
 
     def _update_record_fields(self):
         """[(name, shape, dtype)] of the host draws one update consumes (TD3: the smoothing noise, SAC: the three
-        normal draws), or None: the agent stages nothing but the sampled rows."""
+        normal draws; DDPG: [] — the sampled rows alone are the record), or None: the agent stages nothing (its memory
+        ships the rows itself)."""
         return None
 
     def _draw_update_host(self):
@@ -505,7 +506,7 @@ class VectorOffPolicyAgent(GraphRunner):
             rec = None
             fields = self._update_record_fields()
             import inspect
-            if fields and "rows_dev" in inspect.signature(self.memory.collate).parameters:
+            if fields is not None and "rows_dev" in inspect.signature(self.memory.collate).parameters:
                 from ..staging import RecordStager
                 rec = RecordStager([("rows", (self.batch_size,), torch.int32)] + list(fields), self.device)
             self._update_rec = rec

@@ -42,8 +42,7 @@ def test_producer_thread_changes_nothing(dev, name, L):
         VectorOffPolicyAgent.HOST_DRAWS_AHEAD = saved
     off, on = res[False], res[True]
     assert sum(off[0]) > 0 and off[0] == on[0]
-    if name in ("td3", "sac"):                     # (DDPG has no per-update host draws: no record, no producer)
-        assert on[5] and sum(on[5]) == sum(on[0]), (on[5], on[0])
+    assert on[5] and sum(on[5]) == sum(on[0]), (on[5], on[0])
     for k in off[1]:
         assert torch.equal(off[1][k], on[1][k]), k
     for k in off[2]:
@@ -51,7 +50,7 @@ def test_producer_thread_changes_nothing(dev, name, L):
     assert np.array_equal(off[3], on[3]) and off[4] == on[4]
 
 
-@pytest.mark.parametrize("name,L", [("td3", 10), ("td3", 7), ("sac", 5)])
+@pytest.mark.parametrize("name,L", [("td3", 10), ("td3", 7), ("sac", 5), ("ddpg", 5), ("ddpg_bn", 5)])
 def test_chunks_of_updates_in_one_graph_change_nothing(dev, name, L):
     """VectorOffPolicyAgent.UPDATE_CHUNK: K consecutive updates of a train() call as one captured graph over one staged record
     (one blit, one replay) against one record, one gather and one or two replays per update: weights, targets and both host
